@@ -1,0 +1,128 @@
+/*
+ * wtzmo_hip.h — C ABI of libwtzmo_hip.so, the MI355X (gfx950) implementation of SMARTdenovo's
+ * wtzmo hot path.  Plain C, caller-owned host buffers, opaque device context, no callbacks.
+ *
+ * The reference has no plugin/FFI boundary: the path's boundary is the `wtzmo` process itself
+ * (SURVEY.md §8b).  This ABI therefore mirrors the reference's *function* granularity, so that each
+ * entry point can be parity-tested against the reference function it replaces, and is consumed by
+ * our own host driver (smartdenovo_amd/csrc/host/, the drop-in `wtzmo` executable):
+ *
+ *   wtz_upload_reads     <- push_long_read_wtzmo / BaseBank          wtzmo.c:207-215, dna.h:318-410
+ *   wtz_index_build      <- index_wtzmo                               wtzmo.c:349-430
+ *   wtz_zindex_build     <- index_single_read_seeds (all reads once)  hzm_aln.h:70-115
+ *   wtz_candidates       <- query_wtzmo                               wtzmo.c:433-573
+ *   wtz_pairs_seed       <- query_single_read_seeds + process_hzmps + merge_paired_kmers_window +
+ *                           chaining_wtseedv | dot_matrix_align_hzmps hzm_aln.h:173-224, 580-713, 1134-1186
+ *   wtz_pairs_align      <- fast_seeds_align_hzmo + global_align_regs_hzmo (kswx_extend_align_core,
+ *                           kswx_extend_align_shift_core, ksw_global2) hzm_aln.h:1247-1486, kswx.h:101-335, ksw.c:503-586
+ *
+ * Everything returned is integer and bit-exact against `wtzmo -t 1`.  The order-dependent state of
+ * the reference (closed pairs, contained-read masking, per-read coverage: wtzmo.c:806-822, 1065-1100,
+ * 1309-1334) stays with the caller: these functions are pure in (reads, parameters, arguments).
+ *
+ * Threading: one context per GPU, thread-compatible (not thread-safe per context).
+ * Errors: 0 on success, a negative WTZ_E_* otherwise; wtz_last_error() has the message.
+ */
+#ifndef WTZMO_HIP_H
+#define WTZMO_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WTZ_OK        0
+#define WTZ_E_ARG    -1   /* bad argument */
+#define WTZ_E_HIP    -2   /* HIP runtime error (no device, launch failure, ...) */
+#define WTZ_E_POOL   -3   /* device scratch pool exhausted: retry with fewer items or a larger pool */
+#define WTZ_E_STATE  -4   /* call order violated (e.g. align before seed) */
+
+/* Parameters: one field per reference WTZMO field that the path reads (wtzmo.c:98-132, 1663-1689). */
+typedef struct {
+	uint32_t ksize, zsize, hk, hz, ksave, kovl, ncand, nbest;
+	uint32_t kwin, kstep, ztot, zovl, max_kmer_freq, max_zmer_freq, max_kmer_var;
+	float    win_rep_norm, win_rep_cutoff;
+	int32_t  w, ew, W, M, X, O, E, T;
+	int32_t  min_score; float min_id;
+	int32_t  dot_matrix, xvar, yvar, min_block_len, max_overhang;
+	float    deviation_penalty, gap_penalty;
+} wtz_params_c;
+
+typedef struct wtz_ctx wtz_ctx_t;
+
+typedef struct {
+	uint64_t n_occ;          /* sampled k-mer occurrences in the indexed range */
+	uint64_t n_distinct;     /* distinct sampled k-mers (ktyp) */
+	uint64_t ktot;           /* sum of saturating counts (wtzmo.c:380-388) */
+	uint64_t n_kept;         /* k-mers with 2 <= cnt <= K (the hash table content) */
+	uint32_t max_kmer_freq;  /* resolved K */
+	uint32_t avg_rdlen;      /* wtzmo.c:361-368 */
+} wtz_index_stats_t;
+
+typedef struct {
+	uint32_t n_hits;         /* |cache| of the pair */
+	uint32_t gate;           /* n_hits*zsize >= ztot (wtzmo.c:857) */
+	uint32_t ovl[2];         /* zmo: SEED[dir].ovl after chaining_wtseedv (0 when no window) */
+	uint32_t nwin[2];        /* zmo: chain windows kept for strand dir (only when ovl >= ztot) */
+	int32_t  dm_score, dm_qb, dm_qe, dm_tb, dm_te, dm_dir;   /* dmo: kswr_t of dot_matrix_align_hzmps */
+} wtz_pair_summary_t;
+
+typedef struct { int32_t beg[2], end[2]; } wtz_winbox_t;     /* wt_seed_t.beg/end of a chain window */
+
+typedef struct {
+	int32_t  score, tb, te, qb, qe, aln, mat, mis, ins, del;   /* kswx_t of global_align_regs_hzmo */
+	uint32_t n_regs;         /* windows that passed wtzmo.c:1026; 0 means "regs->size == 0" (wtzmo.c:1029) */
+	uint32_t cigar_len;      /* number of (len<<4|op) words, op M0/I1/D2 */
+	uint64_t cigar_off;      /* offset of this item's CIGAR inside the buffer returned by wtz_fetch_cigars */
+} wtz_aln_result_t;
+
+typedef struct {
+	double   ms_index, ms_zindex, ms_candidates, ms_pairs, ms_winalign, ms_stitch;   /* HIP-event kernel time per stage */
+	uint64_t n_candidates_q, n_pairs, n_winalign, n_stitch;                           /* work items launched */
+	uint64_t cells_shift, cells_fixed, cells_global;                                  /* DP cell updates as the reference loops execute them */
+	uint64_t bytes_seed_algo;                                                         /* algorithmic bytes of seed lookup */
+	uint64_t pool_peak;
+} wtz_counters_t;
+
+const char *wtz_last_error(void);
+int  wtz_device_count(void);
+
+int  wtz_ctx_create(int device, const wtz_params_c *params, uint64_t pool_bytes, wtz_ctx_t **out);
+void wtz_ctx_destroy(wtz_ctx_t *ctx);
+
+/* bits: 2-bit packed bases, 32 per word, base i at bits ((~i)&31)*2 of word i>>5 (dna.h:78);
+ * rdoff/rdlen per read in READ-ID order (id = rank by length DESC under the reference's sort, wtzmo.c:1708). */
+int  wtz_upload_reads(wtz_ctx_t *ctx, const uint64_t *bits, uint64_t n_words, const uint64_t *rdoff, const uint32_t *rdlen, uint32_t n_reads);
+
+/* A2 over read ids [id_beg, id_end). *max_kmer_freq: in = -K (0/1 = auto), out = resolved cutoff. */
+int  wtz_index_build(wtz_ctx_t *ctx, uint32_t id_beg, uint32_t id_end, uint32_t *max_kmer_freq, wtz_index_stats_t *stats);
+
+/* A5 for every read + the candidate-side occurrence caps of A6. Call once after wtz_upload_reads. */
+int  wtz_zindex_build(wtz_ctx_t *ctx);
+
+/* A3. cand: nq rows of (ncand+1) u64 `id<<32|ol`; ncand_io[i]: in = entries already in row i
+ * (candidate heaps carried across -G index parts, else 0), out = entries after this index part.
+ * Rows are the reference's heap arrays verbatim (the caller applies wtzmo.c:813-822). */
+int  wtz_candidates(wtz_ctx_t *ctx, const uint32_t *qids, uint32_t nq, uint64_t *cand, uint32_t *ncand_io);
+
+/* Start a batch: releases all per-batch device results of the previous one. */
+int  wtz_batch_begin(wtz_ctx_t *ctx);
+
+/* A5/A6/A7 for n (query, candidate) pairs. Results stay on the device for wtz_pairs_windows / wtz_pairs_align. */
+int  wtz_pairs_seed(wtz_ctx_t *ctx, const uint32_t *qid, const uint32_t *cid, uint32_t n, wtz_pair_summary_t *out);
+
+/* Chain windows of the last wtz_pairs_seed, packed in (pair, strand) order: sum of nwin[] entries. */
+int  wtz_pairs_windows(wtz_ctx_t *ctx, wtz_winbox_t *wins, uint64_t n_wins);
+
+/* A9 + A10 for m (pair index into the last wtz_pairs_seed, strand) items. */
+int  wtz_pairs_align(wtz_ctx_t *ctx, const uint32_t *pair_idx, const uint8_t *dir, uint32_t m, wtz_aln_result_t *out);
+int  wtz_fetch_cigars(wtz_ctx_t *ctx, uint32_t *dst, uint64_t n_ops);
+
+int  wtz_get_counters(wtz_ctx_t *ctx, wtz_counters_t *out);
+int  wtz_reset_counters(wtz_ctx_t *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

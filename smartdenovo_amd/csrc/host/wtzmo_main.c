@@ -1,0 +1,644 @@
+/*
+ * wtzmo — MI355X-native drop-in for SMARTdenovo's `wtzmo` (same argv, same .ovl / .contained files).
+ *
+ * Host side in plain C.  All hot-path computation (k-mer index + seed lookup, z-mer matching,
+ * window detection / chaining or the dot-matrix engine, the three banded DPs) runs on the GPU
+ * through the C ABI of libwtzmo_hip.so (include/wtzmo_hip.h).  What stays here is exactly the part
+ * of the reference that is sequential by definition: the order-dependent commit of `wtzmo -t 1`
+ * (closed pairs, contained-read masking, per-read coverage, record order; wtzmo.c:806-822, 933-986,
+ * 1005-1123, 1170-1249, 1309-1334), replayed over device results that are pure functions of
+ * (query, candidate).
+ *
+ * Execution shape: queries are taken in id order in batches; for a batch the GPU computes, for every
+ * candidate pair not already closed when the batch is planned, the pair result and the alignment of
+ * its best strand (a superset of what the reference would touch, because the closed/masked sets only
+ * grow); the host then commits the batch strictly in query order.  Batch size adapts to the fraction
+ * of speculative work that the commit discards.
+ *
+ * Extra options (not in the reference):  --gpu <id>, --pool-gb <n>, --batch <max queries>,
+ * --stats <file> ("pairs\tpair_bp\toverlap_seconds\tindex_seconds"), --lib-check.
+ */
+#define _GNU_SOURCE
+#include <getopt.h>
+#include <unistd.h>
+#include <time.h>
+#include "wtz_host.h"
+
+static int usage(void){
+	printf(
+	"WTZMO (MI355X): overlapper of long reads using homopolymer compressed k-mer seeding\n"
+	"Drop-in for SMARTdenovo wtzmo 1.0 -- identical options and file formats; hot path on the GPU\n"
+	"Usage: wtzmo [options]\n"
+	" -t <int>    accepted for compatibility (the GPU path is deterministic and equals `wtzmo -t 1`)\n"
+	" -P <int> -p <int>  total parallel jobs / index of this job\n"
+	" -i <string> long reads (+) *   -I <string> query-only reads (+)   -b <string> clip regions (+)\n"
+	" -J <int>    min read length    -o <string> output *  -f overwrite   -9 <string> tested pairs out\n"
+	" -L <string> tested pairs in (+)  -F <string> reads to mask (+)  -C no .contained file  -N seeds only\n"
+	" -H <int> -k <int> -K <int> -S <int> -d <int> -G <int>      k-mer seeding [3,16,0,4,300,1]\n"
+	" -z <int> -Z <int> -l <int> -y <int> -R <int> -r <int> -q <int>  z-mer windows [10,64,2,800,200,300,100]\n"
+	" -U <float>x5 | -U -1   dot-matrix engine    -A <int> -B <int> candidates / best [500,100]\n"
+	" -w -e -W -M -X -O -E -T  alignment [50,800,3200,2,-5,-3,-1,-50]   -s <int> -m <float> [200,0.5]\n"
+	" --gpu <int> --pool-gb <int> --batch <int> --stats <file>\n");
+	return 1;
+}
+
+typedef struct { char **a; int n, cap; } strlist_t;
+static void sl_push(strlist_t *l, char *s){ if(l->n == l->cap){ l->cap = l->cap ? l->cap * 2 : 4; l->a = (char**)hx_realloc(l->a, sizeof(char*) * (size_t)l->cap); } l->a[l->n++] = s; }
+
+typedef struct { uint64_t e; uint32_t pidx; uint32_t pad; } cand_t;
+static int gt_cand(const void *a, const void *b, void *ctx){ (void)ctx; return (uint32_t)((const cand_t*)b)->e > (uint32_t)((const cand_t*)a)->e; }   /* wtzmo.c:821 */
+static int gt_read(const void *a, const void *b, void *ctx){ (void)ctx; return ((const hx_read_t*)b)->len > ((const hx_read_t*)a)->len; }               /* wtzmo.c:1708 */
+
+typedef struct { uint32_t pb2, dir, ovl, closed, pidx; } seed_t;
+static int gt_seed(const void *a, const void *b, void *ctx){ (void)ctx; return ((const seed_t*)b)->ovl > ((const seed_t*)a)->ovl; }                    /* wtzmo.c:986 */
+
+typedef struct { uint32_t pb1, pb2, dir2; int qb, qe, tb, te, score, mat, mis, ins, del, aln; char *cigar; } hit_t;
+
+typedef struct {      /* results of the query processed last, not yet merged into the global state */
+	uint32_t rd_id;
+	hit_t *hits; size_t nhit, caphit;
+	uint32_t *masks; size_t nmask, capmask;
+	uint64_t *closed; size_t nclosed, capclosed;
+	seed_t *seeds; size_t nseed, capseed;
+} pending_t;
+
+typedef struct {
+	wtz_params_c P; int do_align; uint32_t n_idx, n_job, i_job;
+	hx_store_t st; uint8_t *masked; uint32_t *rdcovs; hx_set_t closed;
+	uint32_t *rdlen; uint32_t avg_rdlen;
+	wtz_ctx_t *ctx; FILE *out;
+	uint64_t pair_bp, n_pairs, nrec;
+	/* candidate rows */
+	uint64_t *rows; uint32_t *nrow; uint32_t *row_of; uint32_t stride; uint32_t rows_cap; int rows_all;
+	uint32_t max_batch;
+	/* batch */
+	uint32_t *bq; uint32_t nbq;
+	uint32_t *pq, *pc; uint32_t npair, cappair;
+	uint32_t *rowpair; size_t caprowpair;      /* pair index per (batch query slot, row entry) */
+	wtz_pair_summary_t *sum; uint64_t *box_off; wtz_winbox_t *boxes; uint64_t nbox, capbox;
+	uint32_t *item_of; uint32_t *it_pair; uint8_t *it_dir; uint32_t nitem; wtz_aln_result_t *aln; uint32_t *cig; uint64_t ncig, capcig;
+	pending_t pend;
+	/* stats */
+	uint64_t spec_pairs, used_pairs, spec_items, used_items, spec_queries, used_queries;
+} eng_t;
+
+#define DIE_WTZ(rc, what) do { if((rc) != WTZ_OK){ fprintf(stderr, " -- %s failed: %s --\n", what, wtz_last_error()); exit(1); } } while(0)
+
+static uint32_t nbest_of(const eng_t *E, uint32_t id){
+	uint32_t nb = (uint32_t)(((size_t)E->P.nbest) * E->rdlen[id] / E->avg_rdlen);      /* wtzmo.c:806-807 */
+	return nb < E->P.nbest ? E->P.nbest : nb;
+}
+
+/* ---------------- record writer + state merge (wtzmo.c:1170-1249, 1319-1329) ---------------- */
+static void flush_pending(eng_t *E){
+	pending_t *p = &E->pend;
+	const hx_read_t *reads = E->st.reads;
+	if(p->rd_id != 0xFFFFFFFFu){
+		if(!E->do_align){
+			for(size_t i = 0; i < p->nseed; i++){
+				const seed_t *s = &p->seeds[i];
+				if(s->closed) continue;
+				fprintf(E->out, "# %s\t%c\t%d", reads[p->rd_id].name, '+', reads[p->rd_id].len);
+				fprintf(E->out, "\t%s\t%c\t%d", reads[s->pb2].name, "+-"[s->dir], reads[s->pb2].len);
+				fprintf(E->out, "\t%d\n", s->ovl);
+			}
+		} else {
+			for(size_t j = 0; j < p->nhit; j++){
+				hit_t *h = &p->hits[j];
+				E->nrec++;
+				if(h->aln == 0) h->aln = 1;
+				uint32_t x1 = (uint32_t)(h->tb < h->qb ? h->tb : h->qb);
+				int r1 = (int)reads[h->pb1].len - h->te, r2 = (int)reads[h->pb2].len - h->qe;
+				uint32_t x2 = (uint32_t)(r1 < r2 ? r1 : r2);
+				if(x1 + x2 <= 200u){ E->rdcovs[h->pb1]++; E->rdcovs[h->pb2]++; }          /* max_unalign_in_dovetail, wtzmo.c:175 */
+				fprintf(E->out, "%s\t%c\t%d\t%d\t%d", reads[h->pb1].name, '+', reads[h->pb1].len, h->tb, h->te);
+				fprintf(E->out, "\t%s\t%c\t%d\t%d\t%d", reads[h->pb2].name, "+-"[h->dir2], reads[h->pb2].len, h->qb, h->qe);
+				fprintf(E->out, "\t%d\t%0.3f\t%d\t%d\t%d\t%d", h->score, 1.0 * h->mat / h->aln, h->mat, h->mis, h->ins, h->del);
+				if(h->cigar){ fprintf(E->out, "\t%s\n", h->cigar); free(h->cigar); h->cigar = NULL; }
+				else fprintf(E->out, "\t0M\n");
+			}
+		}
+	}
+	p->nhit = 0; p->nseed = 0;
+	for(size_t i = 0; i < p->nmask; i++) E->masked[p->masks[i]] = 1;
+	p->nmask = 0;
+	for(size_t i = 0; i < p->nclosed; i++){
+		if(hx_set_put(&E->closed, p->closed[i])){
+			uint32_t a = (uint32_t)(p->closed[i] >> 33), b = (uint32_t)((p->closed[i] & 0xFFFFFFFFu) >> 1);
+			E->pair_bp += (uint64_t)E->rdlen[a] + E->rdlen[b]; E->n_pairs++;
+		}
+	}
+	p->nclosed = 0;
+}
+
+static void pend_mask(pending_t *p, uint32_t id){
+	for(size_t i = 0; i < p->nmask; i++) if(p->masks[i] == id) return;
+	if(p->nmask == p->capmask){ p->capmask = p->capmask ? p->capmask * 2 : 16; p->masks = (uint32_t*)hx_realloc(p->masks, p->capmask * 4); }
+	p->masks[p->nmask++] = id;
+}
+static void pend_closed(pending_t *p, uint64_t v){
+	if(p->nclosed == p->capclosed){ p->capclosed = p->capclosed ? p->capclosed * 2 : 64; p->closed = (uint64_t*)hx_realloc(p->closed, p->capclosed * 8); }
+	p->closed[p->nclosed++] = v;
+}
+static void pend_hit(pending_t *p, const hit_t *h){
+	if(p->nhit == p->caphit){ p->caphit = p->caphit ? p->caphit * 2 : 64; p->hits = (hit_t*)hx_realloc(p->hits, p->caphit * sizeof(hit_t)); }
+	p->hits[p->nhit++] = *h;
+}
+
+static char *cigar_text(const uint32_t *c, uint32_t n){        /* kswx.h:1093-1120 */
+	size_t cap = (size_t)n * 12 + 2, k = 0; char *s = (char*)hx_realloc(NULL, cap);
+	for(uint32_t i = 0; i < n; i++){
+		uint32_t op = c[i] & 0xF, len = c[i] >> 4;
+		if(len == 0) continue;
+		if(op > 2){ fprintf(stderr, " -- CIGAR only support M(0),I(1),D(2) cigar, but met ?(%u) --\n", op); exit(1); }
+		k += (size_t)sprintf(s + k, "%u%c", len, "MID"[op]);
+	}
+	s[k] = 0; return s;
+}
+
+/* ---------------- commit of one query over the batch results (wtzmo.c:806-1130) ---------------- */
+static void commit_query(eng_t *E, uint32_t slot){
+	const wtz_params_c *P = &E->P;
+	pending_t *pd = &E->pend;
+	const uint32_t pbid = E->bq[slot];
+	const int alen = (int)E->rdlen[pbid];
+	pd->rd_id = pbid;
+	const uint32_t nbest = nbest_of(E, pbid);
+	uint32_t bcov = E->rdcovs[pbid];
+	if(bcov >= nbest) return;
+	E->used_queries++;
+	/* candidates: closed filter, exact order, trim (wtzmo.c:813-822) */
+	const uint32_t row = E->row_of[pbid];
+	if(row == 0xFFFFFFFFu){ fprintf(stderr, " -- internal error: no candidate row for read %u --\n", pbid); exit(1); }
+	uint32_t nc = E->nrow[row];
+	cand_t *cand = (cand_t*)hx_realloc(NULL, sizeof(cand_t) * (nc + 1));
+	for(uint32_t i = 0; i < nc; i++){
+		cand[i].e = E->rows[(size_t)row * E->stride + i]; cand[i].pidx = E->rowpair[(size_t)slot * E->stride + i]; cand[i].pad = 0;
+		if(hx_set_has(&E->closed, hx_pair_key(pbid, cand[i].e >> 32))) cand[i].e &= 0xFFFFFFFF00000000ULL;
+	}
+	hx_sort_exact(cand, nc, sizeof(cand_t), gt_cand, NULL);
+	while(nc && (uint32_t)cand[nc - 1].e == 0) nc--;
+	if(E->rows_all){       /* -G: the trimmed, sorted list persists as the reference's rdhits entry */
+		for(uint32_t i = 0; i < nc; i++) E->rows[(size_t)row * E->stride + i] = cand[i].e;
+		E->nrow[row] = nc;
+	}
+	if(P->dot_matrix){
+		for(uint32_t i = 0; i < nc; i++){
+			const uint32_t id2 = (uint32_t)(cand[i].e >> 32);
+			if(cand[i].pidx == 0xFFFFFFFFu){ fprintf(stderr, " -- internal error: pair (%u,%u) missing from the batch plan --\n", pbid, id2); exit(1); }
+			const wtz_pair_summary_t *S = &E->sum[cand[i].pidx];
+			if(!S->gate) continue;
+			E->used_pairs++;
+			pend_closed(pd, hx_pair_key(id2, pbid));
+			int d1 = S->dm_qe - S->dm_qb, d2 = S->dm_te - S->dm_tb;
+			uint32_t ol = (uint32_t)(d1 > d2 ? d1 : d2);
+			if(S->dm_score >= P->min_score && S->dm_score >= (int)(P->min_id * ol)){
+				hit_t H; memset(&H, 0, sizeof H);
+				H.pb1 = pbid; H.pb2 = id2; H.dir2 = (uint32_t)S->dm_dir; H.score = S->dm_score;
+				H.tb = S->dm_tb; H.te = S->dm_te; H.qb = S->dm_qb; H.qe = S->dm_qe; H.mat = S->dm_score; H.aln = (int)ol;
+				pend_hit(pd, &H);
+			}
+		}
+		free(cand);
+		return;
+	}
+	uint16_t *windeps = (uint16_t*)calloc((size_t)alen + 1, 2);
+	float *weights = (float*)hx_realloc(NULL, sizeof(float) * ((size_t)alen + 1));
+	seed_t *seeds = (seed_t*)hx_realloc(NULL, sizeof(seed_t) * (nc + 1)); uint32_t nseed = 0;
+	for(uint32_t i = 0; i < nc; i++){
+		const uint32_t id2 = (uint32_t)(cand[i].e >> 32);
+		if(cand[i].pidx == 0xFFFFFFFFu){ fprintf(stderr, " -- internal error: pair (%u,%u) missing from the batch plan --\n", pbid, id2); exit(1); }
+		const wtz_pair_summary_t *S = &E->sum[cand[i].pidx];
+		if(!S->gate) continue;
+		E->used_pairs++;
+		for(uint32_t dir = 0; dir < 2; dir++){
+			const wtz_winbox_t *bx = E->boxes + E->box_off[(size_t)cand[i].pidx * 2 + dir];
+			for(uint32_t k = 0; k < S->nwin[dir]; k++)
+				for(uint32_t x = (uint32_t)bx[k].beg[0]; (int)x < bx[k].end[0]; x++) windeps[x]++;       /* wtzmo.c:908 */
+		}
+		const uint32_t dir = (S->ovl[0] < S->ovl[1]);
+		if(S->ovl[dir] >= P->ztot){ seed_t s; s.pb2 = id2; s.dir = dir; s.ovl = S->ovl[dir]; s.closed = 0; s.pidx = cand[i].pidx; seeds[nseed++] = s; }
+	}
+	/* repeat weighting: float/double mix exactly as written at wtzmo.c:933-936 */
+	for(int i = 0; i < alen; i++)
+		weights[i] = (windeps[i] <= P->win_rep_norm) ? 1.0 : ((windeps[i] >= P->win_rep_cutoff) ? 0.0 : P->win_rep_norm / (float)windeps[i]);
+	for(int i = 0; i < alen; i++){
+		int df = i < alen / 2 ? alen / 2 - i : i - alen / 2;
+		weights[i] = weights[i] * (0.3 + 0.7 * (df / (alen / 2.0)));
+	}
+	for(uint32_t i = 0; i < nseed; i++){
+		seed_t *s = &seeds[i];
+		const int blen = (int)E->rdlen[s->pb2];
+		const wtz_pair_summary_t *S = &E->sum[s->pidx];
+		const wtz_winbox_t *bx = E->boxes + E->box_off[(size_t)s->pidx * 2 + s->dir];
+		uint32_t ol = 0; double avg;
+		for(uint32_t k = 0; k < S->nwin[s->dir]; k++){
+			avg = (bx[k].end[0] - bx[k].beg[0]) * weights[(bx[k].beg[0] + bx[k].end[0]) / 2];
+			int mid = (int)((bx[k].beg[1] + bx[k].end[1]) / 2);
+			int df = mid < blen / 2 ? blen / 2 - mid : mid - blen / 2;
+			avg = avg * (0.3 + 0.7 * (df / (blen / 2.0)));
+			ol += avg;
+		}
+		s->ovl = ol & 0x1FFFFFFFu;
+		if(ol * P->win_rep_cutoff < P->ztot * P->win_rep_norm) s->closed = 1;                 /* wtzmo.c:964 */
+	}
+	hx_sort_exact(seeds, nseed, sizeof(seed_t), gt_seed, NULL);
+	if(!E->do_align){
+		if(pd->capseed < nseed){ pd->capseed = nseed; pd->seeds = (seed_t*)hx_realloc(pd->seeds, sizeof(seed_t) * nseed); }
+		memcpy(pd->seeds, seeds, sizeof(seed_t) * nseed); pd->nseed = nseed;
+	} else {
+		uint32_t ncand = P->ncand;
+		for(uint32_t i = 0; i < nseed && i < ncand; i++){
+			seed_t *s = &seeds[i];
+			if(s->closed){ ncand++; continue; }
+			pend_closed(pd, hx_pair_key(s->pb2, pbid));
+			const uint32_t item = E->item_of[s->pidx];
+			if(item == 0xFFFFFFFFu || E->it_dir[item] != s->dir){ fprintf(stderr, " -- internal error: alignment of (%u,%u) missing from the batch plan --\n", pbid, s->pb2); exit(1); }
+			E->used_items++;
+			const wtz_aln_result_t *x = &E->aln[item];
+			if(x->n_regs == 0){ s->closed = 1; ncand++; continue; }
+			if(x->score < P->min_score || x->mat < x->aln * P->min_id) continue;
+			hit_t H; memset(&H, 0, sizeof H);
+			H.pb1 = pbid; H.pb2 = s->pb2; H.dir2 = s->dir; H.score = x->score;
+			H.tb = x->tb; H.te = x->te; H.qb = x->qb; H.qe = x->qe; H.mat = x->mat; H.mis = x->mis; H.ins = x->ins; H.del = x->del; H.aln = x->aln;
+			H.cigar = cigar_text(E->cig + x->cigar_off, x->cigar_len);
+			pend_hit(pd, &H);
+			{   /* dovetail / containment bookkeeping (wtzmo.c:1065-1100) */
+				const uint32_t len1 = E->rdlen[H.pb1], len2 = E->rdlen[H.pb2];
+				uint32_t x1 = (uint32_t)(H.tb < H.qb ? H.tb : H.qb);
+				int r1 = (int)len1 - H.te, r2 = (int)len2 - H.qe;
+				uint32_t x2 = (uint32_t)(r1 < r2 ? r1 : r2);
+				if(x1 + x2 <= 200u){
+					uint32_t x3 = ((H.tb == 0 && H.qb) || (H.te == (int)len1 && H.qe < (int)len2));
+					uint32_t x4 = ((H.qb == 0 && H.tb) || (H.qe == (int)len2 && H.te < (int)len1));
+					x1 = len2 + (uint32_t)H.qb - (uint32_t)H.qe;
+					x2 = len1 + (uint32_t)H.tb - (uint32_t)H.te;
+					if(x1 <= 0u && x3 == 0){               /* max_unalign_in_contained = 0, wtzmo.c:174 */
+						if(x2 <= 0u && x4 == 0){
+							if(len1 > len2){ pend_mask(pd, H.pb2); }
+							else if(len1 < len2){ pend_mask(pd, H.pb1); break; }
+							else if(H.pb2 > H.pb1){ pend_mask(pd, H.pb2); continue; }
+							else { pend_mask(pd, H.pb1); break; }
+						} else { pend_mask(pd, H.pb2); continue; }
+						ncand++;
+					} else if(x2 <= 0u && x4 == 0){ pend_mask(pd, H.pb1); break; }
+					bcov++;
+					if(bcov >= nbest) break;
+				}
+			}
+		}
+	}
+	free(cand); free(windeps); free(weights); free(seeds);
+}
+
+/* ---------------- candidate rows ---------------- */
+static void rows_reserve(eng_t *E, uint32_t n){
+	if(n <= E->rows_cap) return;
+	E->rows = (uint64_t*)hx_realloc(E->rows, (size_t)n * E->stride * 8);
+	E->nrow = (uint32_t*)hx_realloc(E->nrow, (size_t)n * 4);
+	E->rows_cap = n;
+}
+
+/* compute candidate rows for `n` query ids (rows 0..n-1), no carry */
+static void candidates_chunk(eng_t *E, const uint32_t *ids, uint32_t n){
+	rows_reserve(E, n);
+	memset(E->nrow, 0, (size_t)n * 4);
+	int rc = wtz_candidates(E->ctx, ids, n, E->rows, E->nrow); DIE_WTZ(rc, "wtz_candidates");
+	for(uint32_t i = 0; i < n; i++) E->row_of[ids[i]] = i;
+}
+
+/* ---------------- one batch: plan -> GPU -> commit ---------------- */
+static void run_batch(eng_t *E){
+	const wtz_params_c *P = &E->P;
+	int rc;
+	/* plan pairs: every row entry whose pair is not closed now */
+	E->npair = 0;
+	if((size_t)E->nbq * E->stride > E->caprowpair){ E->caprowpair = (size_t)E->nbq * E->stride; E->rowpair = (uint32_t*)hx_realloc(E->rowpair, E->caprowpair * 4); }
+	for(uint32_t s = 0; s < E->nbq; s++){
+		const uint32_t q = E->bq[s], row = E->row_of[q];
+		if(row == 0xFFFFFFFFu || E->rdcovs[q] >= nbest_of(E, q)) continue;
+		for(uint32_t k = 0; k < E->nrow[row]; k++){
+			const uint64_t e = E->rows[(size_t)row * E->stride + k];
+			const uint32_t id2 = (uint32_t)(e >> 32);
+			E->rowpair[(size_t)s * E->stride + k] = 0xFFFFFFFFu;
+			if((uint32_t)e == 0 || id2 == 0xFFFFFFFFu) continue;
+			if(hx_set_has(&E->closed, hx_pair_key(q, id2))) continue;
+			if(E->npair == E->cappair){ E->cappair = E->cappair ? E->cappair * 2 : 4096; E->pq = (uint32_t*)hx_realloc(E->pq, E->cappair * 4); E->pc = (uint32_t*)hx_realloc(E->pc, E->cappair * 4); }
+			E->pq[E->npair] = q; E->pc[E->npair] = id2; E->rowpair[(size_t)s * E->stride + k] = E->npair; E->npair++;
+		}
+	}
+	E->spec_pairs += E->npair; E->spec_queries += E->nbq;
+	E->sum = (wtz_pair_summary_t*)hx_realloc(E->sum, sizeof(wtz_pair_summary_t) * (E->npair + 1));
+	rc = wtz_pairs_seed(E->ctx, E->pq, E->pc, E->npair, E->sum); DIE_WTZ(rc, "wtz_pairs_seed");
+	E->nitem = 0; E->ncig = 0;
+	if(!P->dot_matrix){
+		E->box_off = (uint64_t*)hx_realloc(E->box_off, 8 * ((size_t)E->npair * 2 + 1));
+		uint64_t nb = 0;
+		for(uint32_t i = 0; i < E->npair; i++) for(int d = 0; d < 2; d++){ E->box_off[(size_t)i * 2 + d] = nb; nb += E->sum[i].nwin[d]; }
+		E->box_off[(size_t)E->npair * 2] = nb; E->nbox = nb;
+		if(nb > E->capbox){ E->capbox = nb; E->boxes = (wtz_winbox_t*)hx_realloc(E->boxes, sizeof(wtz_winbox_t) * nb); }
+		rc = wtz_pairs_windows(E->ctx, E->boxes, nb); DIE_WTZ(rc, "wtz_pairs_windows");
+		E->item_of = (uint32_t*)hx_realloc(E->item_of, 4 * ((size_t)E->npair + 1));
+		E->it_pair = (uint32_t*)hx_realloc(E->it_pair, 4 * ((size_t)E->npair + 1));
+		E->it_dir = (uint8_t*)hx_realloc(E->it_dir, (size_t)E->npair + 1);
+		for(uint32_t i = 0; i < E->npair; i++){
+			E->item_of[i] = 0xFFFFFFFFu;
+			if(!E->do_align || !E->sum[i].gate) continue;
+			const uint32_t dir = (E->sum[i].ovl[0] < E->sum[i].ovl[1]);
+			if(E->sum[i].ovl[dir] < P->ztot) continue;
+			E->item_of[i] = E->nitem; E->it_pair[E->nitem] = i; E->it_dir[E->nitem] = (uint8_t)dir; E->nitem++;
+		}
+		E->spec_items += E->nitem;
+		if(E->nitem){
+			E->aln = (wtz_aln_result_t*)hx_realloc(E->aln, sizeof(wtz_aln_result_t) * E->nitem);
+			rc = wtz_pairs_align(E->ctx, E->it_pair, E->it_dir, E->nitem, E->aln); DIE_WTZ(rc, "wtz_pairs_align");
+			uint64_t tot = 0; for(uint32_t i = 0; i < E->nitem; i++) tot += E->aln[i].cigar_len;
+			if(tot > E->capcig){ E->capcig = tot; E->cig = (uint32_t*)hx_realloc(E->cig, 4 * tot); }
+			rc = wtz_fetch_cigars(E->ctx, E->cig, tot); DIE_WTZ(rc, "wtz_fetch_cigars");
+			E->ncig = tot;
+		}
+	}
+	/* commit in query order with the reference's one-query masking lag (wtzmo.c:1315-1333) */
+	for(uint32_t s = 0; s < E->nbq; s++){
+		if(E->masked[E->bq[s]]) continue;
+		flush_pending(E);
+		commit_query(E, s);
+	}
+}
+
+static double now_s(void){ struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec; }
+
+int main(int argc, char **argv){
+	eng_t *E = (eng_t*)calloc(1, sizeof(eng_t));
+	wtz_params_c *P = &E->P;
+	strlist_t pbs = {0}, flts = {0}, ovls = {0}, obts = {0}, tbas = {0};
+	char *output = NULL, *pairoutf = NULL, *statsf = NULL;
+	int c, min_rdlen = 0, overwrite = 0, dot_matrix = 0, write_contained = 1, refine = 0, gpu = 0, lib_check = 0;
+	uint64_t pool_gb = 0; float optval;
+	/* defaults: wtzmo.c:1543-1588 */
+	P->w = 50; P->ew = 800; P->W = 3200; P->M = 2; P->X = -5; P->O = -3; P->E = -1; P->T = -50;
+	P->min_score = 200; P->min_id = 0.5f; P->hk = 1; P->hz = 1; P->ksize = 16; P->zsize = 10;
+	P->kwin = 800; P->kovl = 300; P->ksave = 4; P->win_rep_norm = 20; P->win_rep_cutoff = 100; P->ncand = 500; P->nbest = 100;
+	P->ztot = 300; P->zovl = 200; P->max_kmer_freq = 0; P->max_zmer_freq = 64; P->max_kmer_var = 2;
+	P->xvar = 128; P->yvar = 64; P->min_block_len = 160; P->deviation_penalty = 1.0f; P->gap_penalty = 0.05f;
+	E->do_align = 1; E->n_idx = 1; E->n_job = 1; E->i_job = 0; E->max_batch = 512;
+	static struct option lopts[] = { {"stats", required_argument, 0, 1000}, {"gpu", required_argument, 0, 1001}, {"pool-gb", required_argument, 0, 1002},
+		{"batch", required_argument, 0, 1003}, {"lib-check", no_argument, 0, 1004}, {0, 0, 0, 0} };
+	while((c = getopt_long(argc, argv, "ht:P:p:Ni:b:J:I:o:9:S:fCH:k:G:z:Z:U:y:d:r:q:l:K:A:B:r:R:L:F:W:w:e:M:X:O:E:T:s:m:nv", lopts, NULL)) != -1){
+		switch(c){
+			case 1000: statsf = optarg; break;
+			case 1001: gpu = atoi(optarg); break;
+			case 1002: pool_gb = (uint64_t)atoll(optarg); break;
+			case 1003: E->max_batch = (uint32_t)atoi(optarg); if(E->max_batch < 1) E->max_batch = 1; break;
+			case 1004: lib_check = 1; break;
+			case 'h': return usage();
+			case 't': break;
+			case 'P': E->n_job = (uint32_t)atoi(optarg); break;
+			case 'p': E->i_job = (uint32_t)atoi(optarg); break;
+			case 'N': E->do_align = 0; break;
+			case 'i': sl_push(&pbs, optarg); break;
+			case 'b': sl_push(&obts, optarg); break;
+			case 'J': min_rdlen = atoi(optarg); break;
+			case 'I': sl_push(&tbas, optarg); break;
+			case 'o': output = optarg; break;
+			case '9': pairoutf = optarg; break;
+			case 'S': { int v = atoi(optarg); if(v < 1) return usage(); P->ksave = (uint32_t)v; } break;
+			case 'f': overwrite = 1; break;
+			case 'C': write_contained = 0; break;          /* dead switch in the reference: only the side file is suppressed (wtzmo.c:1609,1781) */
+			case 'H': { int hk = atoi(optarg); P->hz = (uint32_t)((hk >> 1) & 1); P->hk = (uint32_t)(hk & 1); } break;
+			case 'k': P->ksize = (uint32_t)atoi(optarg); break;
+			case 'K': P->max_kmer_freq = (uint32_t)atoi(optarg); break;
+			case 'z': P->zsize = (uint32_t)atoi(optarg); break;
+			case 'Z': P->max_zmer_freq = (uint32_t)atoi(optarg); break;
+			case 'U': optval = (float)atof(optarg);
+				if(optval < 0){ dot_matrix = 5; break; }
+				switch(dot_matrix){
+					case 0: P->xvar = (int)optval; break;
+					case 1: P->yvar = (int)optval; break;
+					case 2: P->min_block_len = (int)optval; break;
+					case 3: P->deviation_penalty = optval; break;
+					case 4: P->gap_penalty = optval; break;
+					default: dot_matrix = 5;
+				}
+				dot_matrix++;
+				break;
+			case 'y': P->kwin = (uint32_t)atoi(optarg); break;
+			case 'l': P->max_kmer_var = (uint32_t)atoi(optarg); break;
+			case 'd': P->kovl = (uint32_t)(int)atof(optarg); break;
+			case 'G': E->n_idx = (uint32_t)atoi(optarg); break;
+			case 'r': P->ztot = (uint32_t)(int)atof(optarg); break;
+			case 'R': P->zovl = (uint32_t)(int)atof(optarg); break;
+			case 'q': P->win_rep_cutoff = (float)atoi(optarg); break;
+			case 'A': P->ncand = (uint32_t)atoi(optarg); break;
+			case 'B': P->nbest = (uint32_t)atoi(optarg); break;
+			case 'w': P->w = atoi(optarg); break;
+			case 'e': P->ew = atoi(optarg); break;
+			case 'W': P->W = atoi(optarg); break;
+			case 'M': P->M = atoi(optarg); break;
+			case 'X': P->X = atoi(optarg); break;
+			case 'O': P->O = atoi(optarg); break;
+			case 'E': P->E = atoi(optarg); break;
+			case 'T': P->T = atoi(optarg); break;
+			case 'L': sl_push(&ovls, optarg); break;
+			case 'F': sl_push(&flts, optarg); break;
+			case 's': P->min_score = atoi(optarg); break;
+			case 'm': P->min_id = (float)atof(optarg); break;
+			case 'n': refine = 1; break;
+			case 'v': break;
+			default: return usage();
+		}
+	}
+	if(lib_check){ printf("libwtzmo_hip: %d device(s)\n", wtz_device_count()); return wtz_device_count() > 0 ? 0 : 3; }
+	if(output == NULL) return usage();
+	if(!overwrite && strcmp(output, "-") && access(output, F_OK) == 0){ fprintf(stderr, "File exists! '%s'\n\n", output); return usage(); }
+	if(pbs.n == 0) return usage();
+	if(P->ksize > 32 || P->ksize < 5) return usage();
+	if(P->zsize > 16 || P->zsize < 5) return usage();
+	if(refine){ fprintf(stderr, " -- wtzmo (MI355X): -n (kswx_refine_alignment) is not implemented in this build --\n"); return 2; }
+	if(E->n_idx < 1) E->n_idx = 1;
+	if(E->n_job < 1) E->n_job = 1;
+	P->max_overhang = 2 * P->xvar; P->kstep = P->kwin / 2; P->dot_matrix = dot_matrix;
+
+	/* ---- load reads (wtzmo.c:1691-1729) ---- */
+	hx_str_t name = {0}, seq = {0};
+	hx_reader_t *fr = hx_reader_open(pbs.a, pbs.n);
+	if(fr == NULL){ fprintf(stderr, " -- Cannot open %s --\n", pbs.a[0]); exit(1); }
+	fprintf(stderr, "[wtzmo-mi355x] loading long reads\n");
+	while(hx_reader_seq(fr, &name, &seq)){
+		if((int)seq.n < min_rdlen) continue;
+		hx_store_add(&E->st, name.s ? name.s : "", name.n, seq.s ? seq.s : "", seq.n);
+		E->st.n_rd++;
+	}
+	hx_reader_close(fr);
+	hx_sort_exact(E->st.reads, E->st.n_rd, sizeof(hx_read_t), gt_read, NULL);
+	if(tbas.n){
+		if((fr = hx_reader_open(tbas.a, tbas.n)) == NULL) exit(1);
+		while(hx_reader_seq(fr, &name, &seq)){
+			if((int)seq.n < min_rdlen) continue;
+			hx_store_add(&E->st, name.s ? name.s : "", name.n, seq.s ? seq.s : "", seq.n);
+			E->st.n_qr++;
+		}
+		hx_reader_close(fr);
+	}
+	const uint32_t n_rd = E->st.n_rd, n_all = E->st.n_all;
+	fprintf(stderr, "[wtzmo-mi355x] %u reads (+%u query-only), %llu bp\n", n_rd, E->st.n_qr, (unsigned long long)E->st.nbase);
+	E->masked = (uint8_t*)calloc((size_t)n_all + 1, 1);
+	E->rdcovs = (uint32_t*)calloc((size_t)n_all + 1, 4);
+	hx_names_t nm; hx_names_build(&nm, E->st.reads, n_rd);
+	char *cols[4];
+	if(obts.n){
+		if((fr = hx_reader_open(obts.a, obts.n)) == NULL) exit(1);
+		while(hx_reader_line(fr) != -1){
+			if(fr->line[0] == '#') continue;
+			int nc = 0; char *p = fr->line;
+			while(nc < 4){ cols[nc++] = p; while(*p && *p != '\t' && *p != ' ') p++; if(!*p) break; *p++ = 0; }
+			if(nc < 3) continue;
+			uint32_t id = hx_names_get(&nm, cols[0]); int coff = atoi(cols[1]), clen = atoi(cols[2]);
+			if(id == 0xFFFFFFFFu) continue;
+			hx_read_t *rd = &E->st.reads[id];
+			if(coff < 0 || coff + clen > (int)rd->len) continue;
+			rd->off += (uint64_t)coff; rd->len = (uint32_t)clen;
+		}
+		hx_reader_close(fr);
+	}
+	if(flts.n){
+		if((fr = hx_reader_open(flts.a, flts.n)) == NULL) exit(1);
+		while(hx_reader_line(fr) != -1){
+			if(fr->line[0] == '#') continue;
+			uint32_t id = hx_names_get(&nm, fr->line);
+			if(id != 0xFFFFFFFFu) E->masked[id] = 1;
+		}
+		hx_reader_close(fr);
+	}
+	if(ovls.n){
+		if((fr = hx_reader_open(ovls.a, ovls.n)) == NULL) exit(1);
+		while(hx_reader_line(fr) != -1){
+			if(fr->line[0] == '#') continue;
+			int nc = 0; char *p = fr->line;
+			while(nc < 4){ cols[nc++] = p; while(*p && *p != '\t' && *p != ' ') p++; if(!*p) break; *p++ = 0; }
+			if(nc < 2) continue;
+			uint32_t a = hx_names_get(&nm, cols[0]), b = hx_names_get(&nm, cols[1]);
+			if(a == 0xFFFFFFFFu || b == 0xFFFFFFFFu) continue;
+			hx_set_put(&E->closed, hx_pair_key(a, b));
+		}
+		hx_reader_close(fr);
+	}
+	/* ---- device ---- */
+	E->rdlen = (uint32_t*)hx_realloc(NULL, 4 * ((size_t)n_all + 1));
+	uint64_t *rdoff = (uint64_t*)hx_realloc(NULL, 8 * ((size_t)n_all + 1));
+	{ uint64_t tot = 0; uint32_t nq = E->st.n_qr ? E->st.n_qr : n_rd, b0 = E->st.n_qr ? n_rd : 0;
+	  for(uint32_t i = 0; i < n_all; i++){ E->rdlen[i] = E->st.reads[i].len; rdoff[i] = E->st.reads[i].off; }
+	  for(uint32_t i = 0; i < nq; i++) tot += E->rdlen[b0 + i];
+	  E->avg_rdlen = nq ? (uint32_t)(tot / nq) : 10000; if(E->avg_rdlen == 0) E->avg_rdlen = 1; }        /* wtzmo.c:361-368 */
+	int rc = wtz_ctx_create(gpu, P, pool_gb << 30, &E->ctx); DIE_WTZ(rc, "wtz_ctx_create");
+	rc = wtz_upload_reads(E->ctx, E->st.bits, (E->st.nbase + 31) / 32, rdoff, E->rdlen, n_all); DIE_WTZ(rc, "wtz_upload_reads");
+	E->out = strcmp(output, "-") ? fopen(output, "w") : stdout;
+	if(E->out == NULL){ fprintf(stderr, " -- Cannot write %s --\n", output); exit(1); }
+	E->stride = P->ncand + 1;
+	E->row_of = (uint32_t*)hx_realloc(NULL, 4 * ((size_t)n_all + 1)); memset(E->row_of, 0xFF, 4 * ((size_t)n_all + 1));
+	E->pend.rd_id = 0xFFFFFFFFu;
+	const double t0 = now_s();
+	rc = wtz_zindex_build(E->ctx); DIE_WTZ(rc, "wtz_zindex_build");
+	/* ---- index parts (-G, wtzmo.c:1276-1303) ---- */
+	uint32_t pbbeg = 0, pbend = 0, K = P->max_kmer_freq;
+	wtz_index_stats_t ist;
+	uint32_t *ids = (uint32_t*)hx_realloc(NULL, 4 * ((size_t)n_all + 1));
+	if(E->n_idx > 1){ E->rows_all = 1; rows_reserve(E, n_all); memset(E->nrow, 0, (size_t)n_all * 4); for(uint32_t i = 0; i < n_all; i++) E->row_of[i] = i; }
+	double t_index = 0;
+	for(uint32_t i_idx = 0; i_idx < E->n_idx; i_idx++){
+		pbbeg = pbend; pbend = pbbeg + (n_rd + E->n_idx - 1) / E->n_idx;
+		const double ti = now_s();
+		rc = wtz_index_build(E->ctx, pbbeg, pbend > n_rd ? n_rd : pbend, &K, &ist); DIE_WTZ(rc, "wtz_index_build");
+		t_index += now_s() - ti;
+		fprintf(stderr, "[wtzmo-mi355x] index %u/%u: %llu k-mer occurrences, %llu distinct, %llu kept, cutoff %u\n", i_idx + 1, E->n_idx,
+			(unsigned long long)ist.n_occ, (unsigned long long)ist.n_distinct, (unsigned long long)ist.n_kept, K);
+		if(i_idx + 1 >= E->n_idx) break;
+		/* just_query pass: accumulate candidate heaps of every unmasked read of this job */
+		uint32_t n = 0;
+		for(uint32_t j = 0; j < n_rd; j++){ if((j % E->n_job) != E->i_job) continue; if(E->masked[j]) continue; ids[n++] = j; }
+		for(uint32_t a = 0; a < n; a += 4096){
+			uint32_t m = n - a < 4096 ? n - a : 4096;
+			uint64_t *tmp_rows = (uint64_t*)hx_realloc(NULL, (size_t)m * E->stride * 8); uint32_t *tmp_n = (uint32_t*)hx_realloc(NULL, (size_t)m * 4);
+			for(uint32_t k = 0; k < m; k++){ memcpy(tmp_rows + (size_t)k * E->stride, E->rows + (size_t)ids[a + k] * E->stride, (size_t)E->stride * 8); tmp_n[k] = E->nrow[ids[a + k]]; }
+			rc = wtz_candidates(E->ctx, ids + a, m, tmp_rows, tmp_n); DIE_WTZ(rc, "wtz_candidates");
+			for(uint32_t k = 0; k < m; k++){
+				/* closed filter + exact sort + trim are applied in these passes too (wtzmo.c:813-823) */
+				uint32_t nc = tmp_n[k]; cand_t *cd = (cand_t*)hx_realloc(NULL, sizeof(cand_t) * (nc + 1));
+				for(uint32_t x = 0; x < nc; x++){ cd[x].e = tmp_rows[(size_t)k * E->stride + x]; cd[x].pidx = 0; cd[x].pad = 0;
+					if(hx_set_has(&E->closed, hx_pair_key(ids[a + k], cd[x].e >> 32))) cd[x].e &= 0xFFFFFFFF00000000ULL; }
+				hx_sort_exact(cd, nc, sizeof(cand_t), gt_cand, NULL);
+				while(nc && (uint32_t)cd[nc - 1].e == 0) nc--;
+				for(uint32_t x = 0; x < nc; x++) E->rows[(size_t)ids[a + k] * E->stride + x] = cd[x].e;
+				E->nrow[ids[a + k]] = nc; free(cd);
+			}
+			free(tmp_rows); free(tmp_n);
+		}
+	}
+	/* ---- queries ---- */
+	uint32_t qbeg = E->st.n_qr ? n_rd : 0, qend = E->st.n_qr ? n_rd + E->st.n_qr : n_rd;
+	uint32_t cursor = qbeg, chunk_end = qbeg, B = 8;
+	E->bq = (uint32_t*)hx_realloc(NULL, 4 * ((size_t)E->max_batch + 1));
+	while(cursor < qend){
+		if(cursor >= chunk_end){
+			/* candidate rows for the next chunk of unmasked queries of this job */
+			uint32_t n = 0, j = cursor;
+			for(; j < qend && n < 4096; j++){ if((j % E->n_job) != E->i_job) continue; if(E->masked[j]) continue; if(E->rdcovs[j] >= nbest_of(E, j)) continue; ids[n++] = j; }
+			chunk_end = j;
+			if(E->rows_all){
+				for(uint32_t a = 0; a < n; a += 4096){
+					uint32_t m = n - a < 4096 ? n - a : 4096;
+					uint64_t *tmp_rows = (uint64_t*)hx_realloc(NULL, (size_t)m * E->stride * 8); uint32_t *tmp_n = (uint32_t*)hx_realloc(NULL, (size_t)m * 4);
+					for(uint32_t k = 0; k < m; k++){ memcpy(tmp_rows + (size_t)k * E->stride, E->rows + (size_t)ids[a + k] * E->stride, (size_t)E->stride * 8); tmp_n[k] = E->nrow[ids[a + k]]; }
+					rc = wtz_candidates(E->ctx, ids + a, m, tmp_rows, tmp_n); DIE_WTZ(rc, "wtz_candidates");
+					for(uint32_t k = 0; k < m; k++){ memcpy(E->rows + (size_t)ids[a + k] * E->stride, tmp_rows + (size_t)k * E->stride, (size_t)E->stride * 8); E->nrow[ids[a + k]] = tmp_n[k]; }
+					free(tmp_rows); free(tmp_n);
+				}
+			} else candidates_chunk(E, ids, n);
+		}
+		/* next batch: up to B plannable queries before chunk_end */
+		E->nbq = 0;
+		uint32_t j = cursor;
+		for(; j < chunk_end && E->nbq < B; j++){
+			if((j % E->n_job) != E->i_job) continue;
+			if(E->masked[j]) continue;
+			/* reads whose coverage is already saturated (wtzmo.c:808) need no GPU work but stay in the dispatch
+			 * sequence: their dispatch is what merges the previous query's masks (one-query masking lag) */
+			E->bq[E->nbq++] = j;
+		}
+		cursor = j;
+		if(E->nbq == 0) continue;
+		const uint64_t sq0 = E->spec_queries, uq0 = E->used_queries;
+		run_batch(E);
+		/* adapt: grow while most planned queries were really processed */
+		const uint64_t planned = E->spec_queries - sq0, used = E->used_queries - uq0;
+		if(used * 4 >= planned * 3){ if(B < E->max_batch) B = B * 2 > E->max_batch ? E->max_batch : B * 2; }
+		else if(used * 2 < planned){ if(B > 8) B /= 2; }
+	}
+	flush_pending(E);
+	const double t1 = now_s();
+	if(strcmp(output, "-")) fclose(E->out); else fflush(stdout);
+	wtz_counters_t cn; wtz_get_counters(E->ctx, &cn);
+	fprintf(stderr, "[wtzmo-mi355x] %llu records, %llu pairs aligned, %llu pair-bp, %.3f s (index %.3f s)\n", (unsigned long long)E->nrec, (unsigned long long)E->n_pairs, (unsigned long long)E->pair_bp, t1 - t0, t_index);
+	fprintf(stderr, "[wtzmo-mi355x] speculation: queries %llu/%llu pairs %llu/%llu alignments %llu/%llu (used/planned)\n",
+		(unsigned long long)E->used_queries, (unsigned long long)E->spec_queries, (unsigned long long)E->used_pairs, (unsigned long long)E->spec_pairs, (unsigned long long)E->used_items, (unsigned long long)E->spec_items);
+	fprintf(stderr, "[wtzmo-mi355x] kernel ms: index %.1f zindex %.1f candidates %.1f pairs %.1f winalign %.1f stitch %.1f; cells shift %llu\n",
+		cn.ms_index, cn.ms_zindex, cn.ms_candidates, cn.ms_pairs, cn.ms_winalign, cn.ms_stitch, (unsigned long long)cn.cells_shift);
+	if(statsf){ FILE *sf = fopen(statsf, "w"); if(sf){ fprintf(sf, "%llu\t%llu\t%.6f\t%.6f\n", (unsigned long long)E->n_pairs, (unsigned long long)E->pair_bp, t1 - t0, t_index); fclose(sf); } }
+	if(write_contained && strcmp(output, "-")){
+		char *maskf = (char*)hx_realloc(NULL, strlen(output) + 16); sprintf(maskf, "%s.contained", output);
+		FILE *mf = fopen(maskf, "w");
+		for(uint32_t i = 0; i < n_rd; i++) if(E->masked[i]) fprintf(mf, "%s\n", E->st.reads[i].name);
+		fclose(mf); free(maskf);
+	}
+	if(pairoutf){
+		/* the reference lists the pairs in its hash-table iteration order; here they are sorted (the set is the contract) */
+		FILE *pf = fopen(pairoutf, "w");
+		size_t n = 0; uint64_t *all = (uint64_t*)hx_realloc(NULL, 8 * (E->closed.n + 1));
+		for(size_t i = 0; i < E->closed.cap; i++) if(E->closed.tab[i] != ~0ULL) all[n++] = E->closed.tab[i];
+		for(size_t gap = n / 2; gap > 0; gap /= 2) for(size_t i = gap; i < n; i++){ uint64_t v = all[i]; size_t j = i; while(j >= gap && all[j - gap] > v){ all[j] = all[j - gap]; j -= gap; } all[j] = v; }
+		for(size_t i = 0; i < n; i++) fprintf(pf, "%s\t%s\n", E->st.reads[(uint32_t)(all[i] >> 33)].name, E->st.reads[(uint32_t)((all[i] & 0xFFFFFFFFu) >> 1)].name);
+		fclose(pf); free(all);
+	}
+	wtz_ctx_destroy(E->ctx);
+	return 0;
+}

@@ -1,0 +1,189 @@
+/*
+ * wtz_common.h — shared device/host definitions of the MI355X wtzmo hot path.
+ *
+ * Everything in csrc/wtz_*.h is written as plain C++ functions marked WTZ_HD so that
+ *   (a) hipcc compiles them into the gfx950 kernels of libwtzmo_hip.so (the product), and
+ *   (b) tests/emul/ can compile the very same task bodies with g++ and run each "kernel" as
+ *       a host loop, which lets the host driver, batching and commit logic be debugged in a
+ *       container without a GPU.  (b) is test infrastructure only; nothing in the product
+ *       loads it and the product fails loudly when the HIP library is missing.
+ */
+#ifndef WTZ_COMMON_H
+#define WTZ_COMMON_H
+
+#include <stdint.h>
+#include <stddef.h>
+#include <string.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define WTZ_HD __host__ __device__ __forceinline__
+#define WTZ_HDM __host__ __device__ __forceinline__
+#define WTZ_HDN __host__ __device__ __noinline__
+#define WTZ_D  __device__ __forceinline__
+#else
+#define WTZ_HD static inline
+#define WTZ_HDM inline
+#define WTZ_HDN static
+#define WTZ_D  static inline
+#endif
+
+#define WTZ_MIN(a,b) ((a) < (b) ? (a) : (b))
+#define WTZ_MAX(a,b) ((a) > (b) ? (a) : (b))
+#define WTZ_ABSDIFF(a,b) ((a) < (b) ? (b) - (a) : (a) - (b))
+
+/* ---------------- parameters: the public ABI struct (include/wtzmo_hip.h) ---------------- */
+#include "wtzmo_hip.h"
+typedef wtz_params_c wtz_params_t;
+
+/* ---------------- record types ---------------- */
+/* z-mer match, 16 B like the reference's hzmp_t (hzm_aln.h:54-59): o1 = dir1<<31 | off1, o2 = dir2<<31 | off2,
+ * ll = len2<<16 | len1, gid = group id (dot-matrix engine) */
+typedef struct { uint32_t o1, o2, ll, gid; } wtz_zhit_t;
+#define ZH_OFF1(h) ((h).o1 & 0x7FFFFFFFu)
+#define ZH_OFF2(h) ((h).o2 & 0x7FFFFFFFu)
+#define ZH_DIR1(h) ((h).o1 >> 31)
+#define ZH_DIR2(h) ((h).o2 >> 31)
+#define ZH_LEN1(h) ((h).ll & 0xFFFFu)
+#define ZH_LEN2(h) ((h).ll >> 16)
+#define ZH_STRAND(h) (((h).o1 ^ (h).o2) >> 31)       /* dir1 ^ dir2 */
+
+typedef struct {
+	uint32_t pb2;
+	uint32_t ovl;          /* :29 in the reference */
+	uint8_t  dir, closed; uint16_t pad;
+	int32_t  beg[2], end[2];
+	uint32_t anchors[2];
+} wtz_win_t;               /* wt_seed_t (hzm_aln.h:62-67) */
+
+typedef struct { int32_t score, tb, te, qb, qe, aln, mat, mis, ins, del; } wtz_aln_t;   /* kswx_t (kswx.h:30-34) */
+
+#define WTZ_OVL29(x) ((uint32_t)(x) & 0x1FFFFFFFu)
+
+/* ---------------- 2-bit reads (dna.h:78: base i at bits ((~i)&31)*2 of word i>>5) ---------------- */
+WTZ_HD uint32_t wtz_base_at(const uint64_t *bits, uint64_t i){
+	return (uint32_t)((bits[i >> 5] >> (((~i) & 31u) << 1)) & 3u);
+}
+
+/* reverse complement of a k-mer held in the low 2k bits (dna.h:85-98) */
+WTZ_HD uint64_t wtz_revcomp_kmer(uint64_t x, unsigned k){
+	x = ~x;
+	x = ((x & 0x3333333333333333ULL) << 2) | ((x & 0xCCCCCCCCCCCCCCCCULL) >> 2);
+	x = ((x & 0x0F0F0F0F0F0F0F0FULL) << 4) | ((x & 0xF0F0F0F0F0F0F0F0ULL) >> 4);
+	x = ((x & 0x00FF00FF00FF00FFULL) << 8) | ((x & 0xFF00FF00FF00FF00ULL) >> 8);
+	x = ((x & 0x0000FFFF0000FFFFULL) << 16) | ((x & 0xFFFF0000FFFF0000ULL) >> 16);
+	x = (x << 32) | (x >> 32);
+	return x >> (64 - (k << 1));
+}
+
+WTZ_HD uint32_t wtz_jenkins32(uint32_t key){      /* hashset.h:452-462, k-mer subsample hash (wtzmo.c:35) */
+	key += (key << 12); key ^= (key >> 22);
+	key += (key << 4);  key ^= (key >> 9);
+	key += (key << 10); key ^= (key >> 2);
+	key += (key << 7);  key ^= (key >> 12);
+	return key;
+}
+
+WTZ_HD uint64_t wtz_mix64(uint64_t x){ x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33; return x; }
+
+/* ---------------- device bump pool ----------------
+ * One large HBM arena per context; tasks carve scratch and result arrays out of it with a
+ * single atomic add.  Nothing is freed inside a stage; the host resets `used` between
+ * stages.  Exhaustion sets `overflow` (the stage then reports WTZ_E_POOL, loudly). */
+typedef struct {
+	uint8_t *base;
+	unsigned long long cap;
+	unsigned long long used;
+	int overflow;
+} wtz_pool_t;
+
+WTZ_HD void *wtz_pool_alloc(wtz_pool_t *p, size_t bytes){
+	unsigned long long n = ((unsigned long long)bytes + 15ull) & ~15ull;
+#if defined(__HIP_DEVICE_COMPILE__)
+	unsigned long long o = atomicAdd(&p->used, n);
+#else
+	unsigned long long o = p->used; p->used += n;
+#endif
+	if(o + n > p->cap){ p->overflow = 1; return NULL; }
+	return p->base + o;
+}
+
+/* growable vector living in the pool (old storage is simply abandoned on growth) */
+template<typename T> struct wtz_vec {
+	T *a; uint32_t n, cap; wtz_pool_t *pool; int bad;
+	WTZ_HDM void init(wtz_pool_t *p, uint32_t c){ pool = p; n = 0; cap = 0; a = NULL; bad = 0; if(c) reserve(c); }
+	WTZ_HDM bool reserve(uint32_t want){
+		if(want <= cap) return true;
+		uint32_t c = cap ? cap : 16; while(c < want) c <<= 1;
+		T *b = (T*)wtz_pool_alloc(pool, (size_t)c * sizeof(T));
+		if(b == NULL){ bad = 1; return false; }
+		for(uint32_t i = 0; i < n; i++) b[i] = a[i];
+		a = b; cap = c; return true;
+	}
+	WTZ_HDM bool push(const T &x){ if(n == cap && !reserve(n + 1)) return false; a[n++] = x; return true; }
+};
+
+/*
+ * Exact restatement of the reference's unstable sort (sort.h:104-155): its tie order is
+ * observable in wtzmo's output (SURVEY §8a trap 1), so the product's kernels run the same
+ * swap sequence.  GT is a functor: gt(a,b) != 0 iff "a is greater than b" as written at the
+ * reference call site.
+ */
+template<typename T, typename GT>
+WTZ_HD void wtz_sort_exact(T *v, size_t n, GT gt){
+	if(n < 2) return;
+	uint32_t lo_stk[64], hi_stk[64]; int sp = 0;
+	T piv, tmp;
+	lo_stk[sp] = 0; hi_stk[sp] = (uint32_t)(n - 1); sp++;
+	while(sp){
+		sp--;
+		size_t s = lo_stk[sp], e = hi_stk[sp], m = s + (e - s) / 2;
+		if(gt(v[s], v[m])){ tmp = v[s]; v[s] = v[m]; v[m] = tmp; }
+		if(gt(v[m], v[e])){
+			tmp = v[e]; v[e] = v[m]; v[m] = tmp;
+			if(gt(v[s], v[m])){ tmp = v[s]; v[s] = v[m]; v[m] = tmp; }
+		}
+		piv = v[m];
+		size_t i = s + 1, j = e - 1;
+		for(;;){
+			while(gt(piv, v[i])) i++;
+			while(gt(v[j], piv)) j--;
+			if(i < j){ tmp = v[i]; v[i] = v[j]; v[j] = tmp; i++; j--; }
+			else break;
+		}
+		if(i == j){ i++; j--; }
+		if(j - s > e - i){
+			if(s + 4 < j){ lo_stk[sp] = (uint32_t)s; hi_stk[sp] = (uint32_t)j; sp++; }
+			if(i + 4 < e){ lo_stk[sp] = (uint32_t)i; hi_stk[sp] = (uint32_t)e; sp++; }
+		} else {
+			if(i + 4 < e){ lo_stk[sp] = (uint32_t)i; hi_stk[sp] = (uint32_t)e; sp++; }
+			if(s + 4 < j){ lo_stk[sp] = (uint32_t)s; hi_stk[sp] = (uint32_t)j; sp++; }
+		}
+	}
+	for(size_t i = 0; i < n; i++){
+		bool swapped = false;
+		for(size_t j = n - 1; j > i; j--){
+			if(gt(v[j-1], v[j])){ tmp = v[j-1]; v[j-1] = v[j]; v[j] = tmp; swapped = true; }
+		}
+		if(!swapped) break;
+	}
+}
+
+/* reference binary heap (list.h:78-144); cmp(a,b) returns <0,0,>0 */
+template<typename T, typename CMP>
+WTZ_HD void wtz_heap_push(T *h, uint32_t &n, T x, CMP cmp){
+	uint32_t i = n++; h[i] = x;
+	while(i){ uint32_t p = (i - 1) >> 1; if(cmp(h[i], h[p]) >= 0) break; T t = h[i]; h[i] = h[p]; h[p] = t; i = p; }
+}
+template<typename T, typename CMP>
+WTZ_HD void wtz_heap_sift(T *h, uint32_t n, uint32_t idx, CMP cmp){
+	while((idx << 1) + 1 < n){
+		uint32_t pick = idx, l = (idx << 1) + 1, r = l + 1;
+		if(cmp(h[pick], h[l]) > 0) pick = l;
+		if(r < n && cmp(h[pick], h[r]) > 0) pick = r;
+		if(pick == idx) break;
+		T t = h[idx]; h[idx] = h[pick]; h[pick] = t; idx = pick;
+	}
+}
+
+#endif

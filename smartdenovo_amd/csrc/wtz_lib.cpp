@@ -1,0 +1,439 @@
+/*
+ * wtz_lib.cpp — libwtzmo_hip.so: kernels + stage orchestration + C ABI (include/wtzmo_hip.h).
+ *
+ * Built with:  hipcc -x hip --offload-arch=gfx950 -O3 -ffp-contract=off -shared -fPIC wtz_lib.cpp
+ * (tests/emul/ also compiles this file with g++ -DWTZ_EMUL to run every "kernel" as a host loop; that
+ *  build is a debugging aid for containers without a GPU and is never part of the product.)
+ *
+ * Execution model of this first path: every stage is a flat grid of independent tasks (one lane per
+ * read / query / pair / window), 64-thread workgroups so that each wave is scheduled on its own and
+ * the >= thousands of waves per launch spread over all 256 CUs / 8 XCDs; all per-task scratch and
+ * results are carved from one HBM bump pool (wtz_pool_t) with a single 64-bit atomic per allocation.
+ * The wave-parallel banded-DP kernels (wtz_sw_wave.h) replace the scalar K-sw3 body in wtz_pairs_align.
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <stdarg.h>
+#include <vector>
+#include <algorithm>
+
+#include "wtz_tasks.h"
+
+/* ------------------------------------------------------------------------------------------------ */
+/* device abstraction                                                                               */
+/* ------------------------------------------------------------------------------------------------ */
+static char g_err[512] = "";
+static int wtz_fail(int code, const char *fmt, ...){
+	va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof g_err, fmt, ap); va_end(ap);
+	return code;
+}
+
+#ifndef WTZ_EMUL
+#include <hip/hip_runtime.h>
+#include <rocprim/rocprim.hpp>
+#define WTZ_LAMBDA __device__
+#define HIPCHK(call) do { hipError_t e_ = (call); if(e_ != hipSuccess) return wtz_fail(WTZ_E_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); } while(0)
+
+template<typename F> __global__ void __launch_bounds__(64) wtz_kernel_tasks(uint64_t n, F f){
+	uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if(i < n) f(i);
+}
+template<typename F> static int wtz_launch(hipStream_t st, uint64_t n, F f){
+	if(n == 0) return WTZ_OK;
+	const uint32_t bs = 64;
+	uint64_t nb = (n + bs - 1) / bs;
+	if(nb > 0x7FFFFFFFull) return wtz_fail(WTZ_E_ARG, "grid too large");
+	hipLaunchKernelGGL(wtz_kernel_tasks<F>, dim3((uint32_t)nb), dim3(bs), 0, st, n, f);
+	HIPCHK(hipGetLastError());
+	return WTZ_OK;
+}
+static int dev_alloc(void **p, size_t n){ HIPCHK(hipMalloc(p, n ? n : 16)); return WTZ_OK; }
+static void dev_free(void *p){ if(p) (void)hipFree(p); }
+static int dev_h2d(void *d, const void *h, size_t n){ if(n) HIPCHK(hipMemcpy(d, h, n, hipMemcpyHostToDevice)); return WTZ_OK; }
+static int dev_d2h(void *h, const void *d, size_t n){ if(n) HIPCHK(hipMemcpy(h, d, n, hipMemcpyDeviceToHost)); return WTZ_OK; }
+static int dev_set(void *d, int v, size_t n){ if(n) HIPCHK(hipMemset(d, v, n)); return WTZ_OK; }
+static int dev_sync(){ HIPCHK(hipDeviceSynchronize()); return WTZ_OK; }
+
+struct wtz_timer { hipEvent_t a, b; bool ok;
+	wtz_timer(){ ok = hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess; }
+	~wtz_timer(){ if(ok){ (void)hipEventDestroy(a); (void)hipEventDestroy(b); } }
+	void start(){ if(ok) (void)hipEventRecord(a, 0); }
+	double stop(){ float ms = 0; if(ok){ (void)hipEventRecord(b, 0); (void)hipEventSynchronize(b); (void)hipEventElapsedTime(&ms, a, b); } return ms; } };
+
+static int dev_sort_pairs_u64_u32(uint64_t *keys, uint32_t *vals, uint64_t n, unsigned end_bit){
+	if(n < 2) return WTZ_OK;
+	uint64_t *k2 = NULL; uint32_t *v2 = NULL; void *tmp = NULL; size_t tmp_bytes = 0; int rc;
+	if((rc = dev_alloc((void**)&k2, n * 8))) return rc;
+	if((rc = dev_alloc((void**)&v2, n * 4))){ dev_free(k2); return rc; }
+	rocprim::double_buffer<uint64_t> kb(keys, k2); rocprim::double_buffer<uint32_t> vb(vals, v2);
+	hipError_t e = rocprim::radix_sort_pairs(tmp, tmp_bytes, kb, vb, (size_t)n, 0u, end_bit, 0);
+	if(e == hipSuccess && (rc = dev_alloc(&tmp, tmp_bytes)) == WTZ_OK){
+		e = rocprim::radix_sort_pairs(tmp, tmp_bytes, kb, vb, (size_t)n, 0u, end_bit, 0);
+		if(e == hipSuccess) e = hipDeviceSynchronize();
+		if(e == hipSuccess && kb.current() != keys){ e = hipMemcpy(keys, kb.current(), n * 8, hipMemcpyDeviceToDevice); if(e == hipSuccess) e = hipMemcpy(vals, vb.current(), n * 4, hipMemcpyDeviceToDevice); }
+	}
+	dev_free(tmp); dev_free(k2); dev_free(v2);
+	if(e != hipSuccess) return wtz_fail(WTZ_E_HIP, "radix_sort_pairs failed: %s", hipGetErrorString(e));
+	return rc;
+}
+#else  /* ---------------- host emulation of the launch geometry (tests only) ---------------- */
+#define WTZ_LAMBDA
+typedef int hipStream_t;
+template<typename F> static int wtz_launch(hipStream_t, uint64_t n, F f){ for(uint64_t i = 0; i < n; i++) f(i); return WTZ_OK; }
+static int dev_alloc(void **p, size_t n){ *p = malloc(n ? n : 16); return *p ? WTZ_OK : wtz_fail(WTZ_E_HIP, "malloc(%zu) failed", n); }
+static void dev_free(void *p){ free(p); }
+static int dev_h2d(void *d, const void *h, size_t n){ if(n) memcpy(d, h, n); return WTZ_OK; }
+static int dev_d2h(void *h, const void *d, size_t n){ if(n) memcpy(h, d, n); return WTZ_OK; }
+static int dev_set(void *d, int v, size_t n){ if(n) memset(d, v, n); return WTZ_OK; }
+static int dev_sync(){ return WTZ_OK; }
+#include <time.h>
+struct wtz_timer { struct timespec t0; void start(){ clock_gettime(CLOCK_MONOTONIC, &t0); }
+	double stop(){ struct timespec t1; clock_gettime(CLOCK_MONOTONIC, &t1); return 1e3 * (double)(t1.tv_sec - t0.tv_sec) + 1e-6 * (double)(t1.tv_nsec - t0.tv_nsec); } };
+static int dev_sort_pairs_u64_u32(uint64_t *keys, uint32_t *vals, uint64_t n, unsigned){
+	std::vector<std::pair<uint64_t, uint32_t> > v((size_t)n);
+	for(uint64_t i = 0; i < n; i++) v[(size_t)i] = std::make_pair(keys[i], vals[i]);
+	std::stable_sort(v.begin(), v.end(), [](const std::pair<uint64_t, uint32_t> &a, const std::pair<uint64_t, uint32_t> &b){ return a.first < b.first; });
+	for(uint64_t i = 0; i < n; i++){ keys[i] = v[(size_t)i].first; vals[i] = v[(size_t)i].second; }
+	return WTZ_OK;
+}
+#endif
+
+#define CHK(call) do { int rc_ = (call); if(rc_ != WTZ_OK) return rc_; } while(0)
+
+/* ------------------------------------------------------------------------------------------------ */
+/* context                                                                                          */
+/* ------------------------------------------------------------------------------------------------ */
+struct wtz_ctx {
+	int device;
+	wtz_params_t P; wtz_params_t *dP;
+	/* reads */
+	uint64_t *bits; uint64_t n_words; uint64_t *rdoff; uint32_t *rdlen; uint32_t n_reads;
+	std::vector<uint32_t> h_rdlen;
+	/* k-mer index */
+	wtz_kslot_t *ktab; uint64_t kmask; uint32_t *kseeds; uint64_t n_kocc;
+	/* z index */
+	uint64_t *zoff; uint64_t n_z; wtz_zindex_t Z; bool have_z;
+	/* pool */
+	wtz_pool_t *dpool; uint8_t *pool_base; uint64_t pool_bytes;
+	/* per-batch results */
+	uint32_t *d_qid, *d_cid; wtz_pairres_t *d_pairres; uint32_t n_pairs; std::vector<wtz_pairres_t> h_pairres;
+	wtz_alnres_dev_t *d_alnres; uint32_t n_items; std::vector<wtz_alnres_dev_t> h_alnres;
+	wtz_counters_t cnt;
+};
+
+static wtz_reads_t ctx_reads(const wtz_ctx *c){ wtz_reads_t R; R.bits = c->bits; R.rdoff = c->rdoff; R.rdlen = c->rdlen; R.n_reads = c->n_reads; return R; }
+static wtz_env_t ctx_env(const wtz_ctx *c){ wtz_env_t V; V.R = ctx_reads(c); V.Z = c->Z; V.P = c->dP; V.pool = c->dpool; return V; }
+
+static int pool_reset(wtz_ctx *c){
+	wtz_pool_t p; p.base = c->pool_base; p.cap = c->pool_bytes; p.used = 0; p.overflow = 0;
+	return dev_h2d(c->dpool, &p, sizeof p);
+}
+static int pool_check(wtz_ctx *c, const char *stage){
+	wtz_pool_t p; CHK(dev_d2h(&p, c->dpool, sizeof p));
+	if(p.used > c->cnt.pool_peak) c->cnt.pool_peak = p.used > p.cap ? p.cap : p.used;
+	if(p.overflow) return wtz_fail(WTZ_E_POOL, "%s: device scratch pool exhausted (%llu of %llu bytes requested); use fewer items per call or a larger pool",
+		stage, (unsigned long long)p.used, (unsigned long long)p.cap);
+	return WTZ_OK;
+}
+
+extern "C" const char *wtz_last_error(void){ return g_err; }
+
+extern "C" int wtz_device_count(void){
+#ifndef WTZ_EMUL
+	int n = 0; if(hipGetDeviceCount(&n) != hipSuccess) return 0; return n;
+#else
+	return 1;
+#endif
+}
+
+extern "C" int wtz_ctx_create(int device, const wtz_params_c *params, uint64_t pool_bytes, wtz_ctx_t **out){
+	if(!params || !out) return wtz_fail(WTZ_E_ARG, "null argument");
+	if(params->ksize < 5 || params->ksize > 32 || params->zsize < 5 || params->zsize > 16 || params->ksave < 1) return wtz_fail(WTZ_E_ARG, "k/z/S out of range (wtzmo.c:1658-1660)");
+#ifndef WTZ_EMUL
+	int ndev = 0;
+	if(hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return wtz_fail(WTZ_E_HIP, "no HIP device visible: libwtzmo_hip needs an MI355X (gfx950); there is no CPU fallback");
+	if(device < 0 || device >= ndev) return wtz_fail(WTZ_E_ARG, "device %d out of range (%d visible)", device, ndev);
+	HIPCHK(hipSetDevice(device));
+#endif
+	wtz_ctx *c = new wtz_ctx();
+	c->device = device; c->P = *params; c->dP = NULL;
+	c->bits = NULL; c->rdoff = NULL; c->rdlen = NULL; c->n_reads = 0; c->n_words = 0;
+	c->ktab = NULL; c->kseeds = NULL; c->kmask = 0; c->n_kocc = 0;
+	c->zoff = NULL; c->n_z = 0; memset(&c->Z, 0, sizeof c->Z); c->have_z = false;
+	c->dpool = NULL; c->pool_base = NULL; c->pool_bytes = pool_bytes ? pool_bytes : (4ull << 30);
+	c->d_qid = c->d_cid = NULL; c->d_pairres = NULL; c->n_pairs = 0; c->d_alnres = NULL; c->n_items = 0;
+	memset(&c->cnt, 0, sizeof c->cnt);
+	int rc;
+	if((rc = dev_alloc((void**)&c->dP, sizeof(wtz_params_t))) || (rc = dev_h2d(c->dP, &c->P, sizeof(wtz_params_t))) ||
+	   (rc = dev_alloc((void**)&c->dpool, sizeof(wtz_pool_t))) || (rc = dev_alloc((void**)&c->pool_base, c->pool_bytes)) || (rc = pool_reset(c))){
+		wtz_ctx_destroy(c); return rc;
+	}
+	*out = c;
+	return WTZ_OK;
+}
+
+static void free_kindex(wtz_ctx *c){ dev_free(c->ktab); dev_free(c->kseeds); c->ktab = NULL; c->kseeds = NULL; c->kmask = 0; }
+static void free_zindex(wtz_ctx *c){
+	dev_free(c->zoff); dev_free(c->Z.mer); dev_free(c->Z.pos); dev_free(c->Z.len); dev_free(c->Z.ok); dev_free(c->Z.sidx);
+	dev_free(c->Z.dmer); dev_free(c->Z.dfirst); dev_free(c->Z.dcnt); dev_free(c->Z.dn);
+	c->zoff = NULL; memset(&c->Z, 0, sizeof c->Z); c->have_z = false;
+}
+static void free_batch(wtz_ctx *c){
+	dev_free(c->d_qid); dev_free(c->d_cid); dev_free(c->d_pairres); dev_free(c->d_alnres);
+	c->d_qid = c->d_cid = NULL; c->d_pairres = NULL; c->d_alnres = NULL; c->n_pairs = 0; c->n_items = 0;
+}
+
+extern "C" void wtz_ctx_destroy(wtz_ctx_t *c){
+	if(!c) return;
+	free_batch(c); free_kindex(c); free_zindex(c);
+	dev_free(c->bits); dev_free(c->rdoff); dev_free(c->rdlen);
+	dev_free(c->dP); dev_free(c->dpool); dev_free(c->pool_base);
+	delete c;
+}
+
+extern "C" int wtz_upload_reads(wtz_ctx_t *c, const uint64_t *bits, uint64_t n_words, const uint64_t *rdoff, const uint32_t *rdlen, uint32_t n_reads){
+	if(!c || !bits || !rdoff || !rdlen) return wtz_fail(WTZ_E_ARG, "null argument");
+	dev_free(c->bits); dev_free(c->rdoff); dev_free(c->rdlen); c->bits = NULL; c->rdoff = NULL; c->rdlen = NULL;
+	free_kindex(c); free_zindex(c); free_batch(c);
+	CHK(dev_alloc((void**)&c->bits, (n_words + 2) * 8)); CHK(dev_set(c->bits, 0, (n_words + 2) * 8)); CHK(dev_h2d(c->bits, bits, n_words * 8));
+	CHK(dev_alloc((void**)&c->rdoff, (size_t)n_reads * 8)); CHK(dev_h2d(c->rdoff, rdoff, (size_t)n_reads * 8));
+	CHK(dev_alloc((void**)&c->rdlen, (size_t)n_reads * 4)); CHK(dev_h2d(c->rdlen, rdlen, (size_t)n_reads * 4));
+	c->n_words = n_words; c->n_reads = n_reads; c->h_rdlen.assign(rdlen, rdlen + n_reads);
+	return WTZ_OK;
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* A2: k-mer index                                                                                   */
+/* ------------------------------------------------------------------------------------------------ */
+extern "C" int wtz_index_build(wtz_ctx_t *c, uint32_t id_beg, uint32_t id_end, uint32_t *max_kmer_freq, wtz_index_stats_t *stats){
+	if(!c || !c->bits || !max_kmer_freq) return wtz_fail(WTZ_E_ARG, "reads not uploaded / null argument");
+	if(id_end > c->n_reads) id_end = c->n_reads;
+	if(id_beg > id_end) id_beg = id_end;
+	const uint32_t nr = id_end - id_beg;
+	free_kindex(c);
+	wtz_timer tm; tm.start();
+	const wtz_reads_t R = ctx_reads(c); const uint32_t ksize = c->P.ksize, hk = c->P.hk, ksave = c->P.ksave;
+	uint64_t *d_cnt = NULL; CHK(dev_alloc((void**)&d_cnt, ((size_t)nr + 1) * 8));
+	CHK(wtz_launch(0, nr, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_kcount((uint32_t)t, R, id_beg, ksize, hk, ksave, d_cnt); }));
+	std::vector<uint64_t> h_cnt((size_t)nr + 1);
+	CHK(dev_d2h(h_cnt.data(), d_cnt, (size_t)nr * 8));
+	uint64_t tot = 0; for(uint32_t i = 0; i < nr; i++){ uint64_t v = h_cnt[i]; h_cnt[i] = tot; tot += v; } h_cnt[nr] = tot;
+	CHK(dev_h2d(d_cnt, h_cnt.data(), ((size_t)nr + 1) * 8));
+	uint64_t *d_keys = NULL; uint32_t *d_vals = NULL;
+	CHK(dev_alloc((void**)&d_keys, (tot + 1) * 8)); CHK(dev_alloc((void**)&d_vals, (tot + 1) * 4));
+	CHK(wtz_launch(0, nr, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_kfill((uint32_t)t, R, id_beg, ksize, hk, ksave, d_cnt, d_keys, d_vals); }));
+	CHK(dev_sync());
+	dev_free(d_cnt);
+	CHK(dev_sort_pairs_u64_u32(d_keys, d_vals, tot, 2 * ksize));
+	unsigned long long *d_stat = NULL; CHK(dev_alloc((void**)&d_stat, 4 * 8)); CHK(dev_set(d_stat, 0, 4 * 8));
+	CHK(wtz_launch(0, tot, [=] WTZ_LAMBDA (uint64_t i){ wtz_task_kstats(i, d_keys, tot, d_stat + 0, d_stat + 1); }));
+	unsigned long long h_stat[4]; CHK(dev_d2h(h_stat, d_stat, 4 * 8));
+	const uint64_t ktot = tot - h_stat[0], ktyp = h_stat[1];     /* d_stat[0] accumulates the saturation excess */
+	uint32_t K = *max_kmer_freq;
+	if(K < 2){ uint32_t kavg = (uint32_t)(ktot / (ktyp + 1)); if(kavg < 20) kavg = 20; K = kavg * 5; }       /* wtzmo.c:380-393 */
+	*max_kmer_freq = K;
+	CHK(wtz_launch(0, tot, [=] WTZ_LAMBDA (uint64_t i){ wtz_task_kinsert(i, d_keys, tot, K, (wtz_kslot_t*)NULL, 0, d_stat + 2); }));
+	CHK(dev_d2h(h_stat, d_stat, 4 * 8));
+	const uint64_t n_kept = h_stat[2];
+	uint64_t cap = 1024; while(cap < n_kept * 2 + 2) cap <<= 1;
+	CHK(dev_alloc((void**)&c->ktab, cap * sizeof(wtz_kslot_t))); CHK(dev_set(c->ktab, 0xFF, cap * sizeof(wtz_kslot_t)));
+	c->kmask = cap - 1;
+	wtz_kslot_t *tab = c->ktab; const uint64_t kmask = c->kmask;
+	CHK(wtz_launch(0, tot, [=] WTZ_LAMBDA (uint64_t i){ wtz_task_kinsert(i, d_keys, tot, K, tab, kmask, d_stat + 2); }));
+	CHK(dev_sync());
+	dev_free(d_keys); dev_free(d_stat);
+	c->kseeds = d_vals; c->n_kocc = tot;
+	c->cnt.ms_index += tm.stop();
+	if(stats){
+		stats->n_occ = tot; stats->n_distinct = ktyp; stats->ktot = ktot; stats->n_kept = n_kept; stats->max_kmer_freq = K;
+		uint64_t tl = 0; for(uint32_t i = 0; i < c->n_reads; i++) tl += c->h_rdlen[i];
+		stats->avg_rdlen = c->n_reads ? (uint32_t)(tl / c->n_reads) : 10000;
+	}
+	return WTZ_OK;
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* A5: z-mer index of every read                                                                     */
+/* ------------------------------------------------------------------------------------------------ */
+extern "C" int wtz_zindex_build(wtz_ctx_t *c){
+	if(!c || !c->bits) return wtz_fail(WTZ_E_ARG, "reads not uploaded");
+	free_zindex(c);
+	wtz_timer tm; tm.start();
+	const wtz_reads_t R = ctx_reads(c); const uint32_t nr = c->n_reads, zsize = c->P.zsize, hz = c->P.hz, zcut = c->P.max_zmer_freq;
+	CHK(dev_alloc((void**)&c->zoff, ((size_t)nr + 1) * 8));
+	uint64_t *d_off = c->zoff;
+	CHK(wtz_launch(0, nr, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_zcount((uint32_t)t, R, zsize, hz, d_off); }));
+	std::vector<uint64_t> h((size_t)nr + 1);
+	CHK(dev_d2h(h.data(), d_off, (size_t)nr * 8));
+	uint64_t tot = 0; for(uint32_t i = 0; i < nr; i++){ uint64_t v = h[i]; h[i] = tot; tot += v; } h[nr] = tot;
+	CHK(dev_h2d(d_off, h.data(), ((size_t)nr + 1) * 8));
+	c->n_z = tot;
+	wtz_zindex_t Z; memset(&Z, 0, sizeof Z); Z.zoff = c->zoff;
+	CHK(dev_alloc((void**)&Z.mer, (tot + 1) * 4)); CHK(dev_alloc((void**)&Z.pos, (tot + 1) * 4)); CHK(dev_alloc((void**)&Z.len, (tot + 1) * 2));
+	CHK(dev_alloc((void**)&Z.ok, tot + 1)); CHK(dev_alloc((void**)&Z.sidx, (tot + 1) * 4));
+	CHK(dev_alloc((void**)&Z.dmer, (tot + 1) * 4)); CHK(dev_alloc((void**)&Z.dfirst, (tot + 1) * 4)); CHK(dev_alloc((void**)&Z.dcnt, (tot + 1) * 2));
+	CHK(dev_alloc((void**)&Z.dn, ((size_t)nr + 1) * 4));
+	c->Z = Z;
+	uint64_t *d_tmp = NULL; CHK(dev_alloc((void**)&d_tmp, (tot + 1) * 8));
+	CHK(wtz_launch(0, nr, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_zbuild((uint32_t)t, R, zsize, hz, zcut, Z, d_tmp); }));
+	CHK(dev_sync());
+	dev_free(d_tmp);
+	c->have_z = true;
+	c->cnt.ms_zindex += tm.stop();
+	return WTZ_OK;
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* A3: candidates                                                                                    */
+/* ------------------------------------------------------------------------------------------------ */
+extern "C" int wtz_candidates(wtz_ctx_t *c, const uint32_t *qids, uint32_t nq, uint64_t *cand, uint32_t *ncand_io){
+	if(!c || !c->ktab || !qids || !cand || !ncand_io) return wtz_fail(WTZ_E_ARG, "index not built / null argument");
+	if(nq == 0) return WTZ_OK;
+	for(uint32_t i = 0; i < nq; i++) if(qids[i] >= c->n_reads) return wtz_fail(WTZ_E_ARG, "query id %u out of range", qids[i]);
+	CHK(pool_reset(c));
+	const uint32_t stride = c->P.ncand + 1;
+	uint32_t *d_q = NULL, *d_n = NULL; uint64_t *d_cand = NULL;
+	CHK(dev_alloc((void**)&d_q, (size_t)nq * 4)); CHK(dev_h2d(d_q, qids, (size_t)nq * 4));
+	CHK(dev_alloc((void**)&d_n, (size_t)nq * 4)); CHK(dev_h2d(d_n, ncand_io, (size_t)nq * 4));
+	CHK(dev_alloc((void**)&d_cand, (size_t)nq * stride * 8)); CHK(dev_h2d(d_cand, cand, (size_t)nq * stride * 8));
+	const wtz_reads_t R = ctx_reads(c); const wtz_params_t *dP = c->dP; const wtz_kslot_t *tab = c->ktab; const uint64_t kmask = c->kmask;
+	const uint32_t *seeds = c->kseeds; wtz_pool_t *pool = c->dpool;
+	wtz_timer tm; tm.start();
+	CHK(wtz_launch(0, nq, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_candidates((uint32_t)t, R, d_q, dP, tab, kmask, seeds, pool, d_cand, d_n, stride); }));
+	CHK(dev_sync());
+	c->cnt.ms_candidates += tm.stop(); c->cnt.n_candidates_q += nq;
+	CHK(dev_d2h(cand, d_cand, (size_t)nq * stride * 8)); CHK(dev_d2h(ncand_io, d_n, (size_t)nq * 4));
+	dev_free(d_q); dev_free(d_n); dev_free(d_cand);
+	CHK(pool_check(c, "wtz_candidates"));
+	return WTZ_OK;
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* per-batch pair stages                                                                             */
+/* ------------------------------------------------------------------------------------------------ */
+extern "C" int wtz_batch_begin(wtz_ctx_t *c){
+	if(!c) return wtz_fail(WTZ_E_ARG, "null context");
+	free_batch(c);
+	return pool_reset(c);
+}
+
+extern "C" int wtz_pairs_seed(wtz_ctx_t *c, const uint32_t *qid, const uint32_t *cid, uint32_t n, wtz_pair_summary_t *out){
+	if(!c || !c->have_z || (n && (!qid || !cid || !out))) return wtz_fail(WTZ_E_ARG, "z-index not built / null argument");
+	free_batch(c);
+	CHK(pool_reset(c));
+	if(n == 0){ CHK(dev_alloc((void**)&c->d_pairres, sizeof(wtz_pairres_t))); c->n_pairs = 0; c->h_pairres.clear(); return WTZ_OK; }
+	for(uint32_t i = 0; i < n; i++) if(qid[i] >= c->n_reads || cid[i] >= c->n_reads) return wtz_fail(WTZ_E_ARG, "pair %u: read id out of range", i);
+	CHK(dev_alloc((void**)&c->d_qid, (size_t)n * 4)); CHK(dev_h2d(c->d_qid, qid, (size_t)n * 4));
+	CHK(dev_alloc((void**)&c->d_cid, (size_t)n * 4)); CHK(dev_h2d(c->d_cid, cid, (size_t)n * 4));
+	CHK(dev_alloc((void**)&c->d_pairres, (size_t)n * sizeof(wtz_pairres_t)));
+	const wtz_env_t V = ctx_env(c); const uint32_t *dq = c->d_qid, *dc = c->d_cid; wtz_pairres_t *dr = c->d_pairres;
+	wtz_timer tm; tm.start();
+	CHK(wtz_launch(0, n, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_pair((uint32_t)t, V, dq, dc, dr); }));
+	CHK(dev_sync());
+	c->cnt.ms_pairs += tm.stop(); c->cnt.n_pairs += n;
+	c->n_pairs = n; c->h_pairres.resize(n);
+	CHK(dev_d2h(c->h_pairres.data(), c->d_pairres, (size_t)n * sizeof(wtz_pairres_t)));
+	CHK(pool_check(c, "wtz_pairs_seed"));
+	for(uint32_t i = 0; i < n; i++){
+		const wtz_pairres_t &r = c->h_pairres[i];
+		if(r.bad) return wtz_fail(WTZ_E_POOL, "wtz_pairs_seed: pair %u ran out of scratch", i);
+		wtz_pair_summary_t s; memset(&s, 0, sizeof s);
+		s.n_hits = r.n_hits; s.gate = r.gate; s.ovl[0] = r.ovl[0]; s.ovl[1] = r.ovl[1]; s.nwin[0] = r.nwin[0]; s.nwin[1] = r.nwin[1];
+		s.dm_score = r.dm_score; s.dm_qb = r.dm_qb; s.dm_qe = r.dm_qe; s.dm_tb = r.dm_tb; s.dm_te = r.dm_te; s.dm_dir = r.dm_dir;
+		out[i] = s;
+	}
+	return WTZ_OK;
+}
+
+extern "C" int wtz_pairs_windows(wtz_ctx_t *c, wtz_winbox_t *wins, uint64_t n_wins){
+	if(!c || !c->d_pairres) return wtz_fail(WTZ_E_STATE, "wtz_pairs_windows before wtz_pairs_seed");
+	uint64_t tot = 0; for(uint32_t i = 0; i < c->n_pairs; i++) tot += c->h_pairres[i].nwin[0] + c->h_pairres[i].nwin[1];
+	if(tot != n_wins) return wtz_fail(WTZ_E_ARG, "wtz_pairs_windows: expected room for %llu windows, got %llu", (unsigned long long)tot, (unsigned long long)n_wins);
+	if(tot == 0) return WTZ_OK;
+	if(!wins) return wtz_fail(WTZ_E_ARG, "null output");
+	std::vector<uint64_t> off((size_t)c->n_pairs * 2 + 1);
+	uint64_t o = 0; for(uint32_t i = 0; i < c->n_pairs; i++) for(int d = 0; d < 2; d++){ off[(size_t)i * 2 + d] = o; o += c->h_pairres[i].nwin[d]; }
+	off[(size_t)c->n_pairs * 2] = o;
+	uint64_t *d_off = NULL; wtz_winbox_t *d_w = NULL;
+	CHK(dev_alloc((void**)&d_off, off.size() * 8)); CHK(dev_h2d(d_off, off.data(), off.size() * 8));
+	CHK(dev_alloc((void**)&d_w, (size_t)tot * sizeof(wtz_winbox_t)));
+	const wtz_pairres_t *dr = c->d_pairres;
+	CHK(wtz_launch(0, (uint64_t)c->n_pairs * 2, [=] WTZ_LAMBDA (uint64_t t){
+		const wtz_pairres_t &r = dr[t >> 1]; const uint32_t d = (uint32_t)(t & 1);
+		for(uint32_t k = 0; k < r.nwin[d]; k++){ wtz_winbox_t b; b.beg[0] = r.win[d][k].beg[0]; b.beg[1] = r.win[d][k].beg[1]; b.end[0] = r.win[d][k].end[0]; b.end[1] = r.win[d][k].end[1]; d_w[d_off[t] + k] = b; }
+	}));
+	CHK(dev_sync());
+	CHK(dev_d2h(wins, d_w, (size_t)tot * sizeof(wtz_winbox_t)));
+	dev_free(d_off); dev_free(d_w);
+	return WTZ_OK;
+}
+
+extern "C" int wtz_pairs_align(wtz_ctx_t *c, const uint32_t *pair_idx, const uint8_t *dir, uint32_t m, wtz_aln_result_t *out){
+	if(!c || !c->d_pairres) return wtz_fail(WTZ_E_STATE, "wtz_pairs_align before wtz_pairs_seed");
+	if(m == 0) return WTZ_OK;
+	if(!pair_idx || !dir || !out) return wtz_fail(WTZ_E_ARG, "null argument");
+	dev_free(c->d_alnres); c->d_alnres = NULL; c->n_items = 0;
+	std::vector<wtz_alnitem_t> items(m); std::vector<wtz_wintask_t> wt; uint64_t nreg = 0;
+	std::vector<uint32_t> h_q(c->n_pairs), h_c(c->n_pairs);
+	CHK(dev_d2h(h_q.data(), c->d_qid, (size_t)c->n_pairs * 4)); CHK(dev_d2h(h_c.data(), c->d_cid, (size_t)c->n_pairs * 4));
+	for(uint32_t i = 0; i < m; i++){
+		if(pair_idx[i] >= c->n_pairs || dir[i] > 1) return wtz_fail(WTZ_E_ARG, "align item %u out of range", i);
+		const wtz_pairres_t &r = c->h_pairres[pair_idx[i]];
+		wtz_alnitem_t it; it.q = h_q[pair_idx[i]]; it.c = h_c[pair_idx[i]]; it.dir = dir[i];
+		it.win = r.win[dir[i]]; it.anchors = r.anchors[dir[i]]; it.nwin = r.nwin[dir[i]]; it.regs = (wtz_reg_t*)(uintptr_t)nreg;
+		for(uint32_t k = 0; k < it.nwin; k++){ wtz_wintask_t w; w.item = i; w.widx = k; wt.push_back(w); }
+		nreg += it.nwin; items[i] = it;
+	}
+	wtz_reg_t *d_regs = NULL; wtz_alnitem_t *d_items = NULL; wtz_wintask_t *d_wt = NULL;
+	CHK(dev_alloc((void**)&d_regs, (size_t)(nreg + 1) * sizeof(wtz_reg_t)));
+	for(uint32_t i = 0; i < m; i++) items[i].regs = d_regs + (uintptr_t)items[i].regs;
+	CHK(dev_alloc((void**)&d_items, (size_t)m * sizeof(wtz_alnitem_t))); CHK(dev_h2d(d_items, items.data(), (size_t)m * sizeof(wtz_alnitem_t)));
+	CHK(dev_alloc((void**)&d_wt, (wt.size() + 1) * sizeof(wtz_wintask_t))); CHK(dev_h2d(d_wt, wt.data(), wt.size() * sizeof(wtz_wintask_t)));
+	CHK(dev_alloc((void**)&c->d_alnres, (size_t)m * sizeof(wtz_alnres_dev_t)));
+	const wtz_env_t V = ctx_env(c); wtz_alnres_dev_t *d_res = c->d_alnres;
+	wtz_timer tm; tm.start();
+	CHK(wtz_launch(0, wt.size(), [=] WTZ_LAMBDA (uint64_t t){ wtz_task_winalign((uint32_t)t, V, d_wt, d_items); }));
+	CHK(dev_sync());
+	c->cnt.ms_winalign += tm.stop(); c->cnt.n_winalign += wt.size();
+	tm.start();
+	CHK(wtz_launch(0, m, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_stitch((uint32_t)t, V, d_items, d_res); }));
+	CHK(dev_sync());
+	c->cnt.ms_stitch += tm.stop(); c->cnt.n_stitch += m;
+	c->h_alnres.resize(m); c->n_items = m;
+	CHK(dev_d2h(c->h_alnres.data(), c->d_alnres, (size_t)m * sizeof(wtz_alnres_dev_t)));
+	dev_free(d_regs); dev_free(d_items); dev_free(d_wt);
+	CHK(pool_check(c, "wtz_pairs_align"));
+	uint64_t coff = 0;
+	for(uint32_t i = 0; i < m; i++){
+		const wtz_alnres_dev_t &r = c->h_alnres[i];
+		if(r.bad) return wtz_fail(WTZ_E_POOL, "wtz_pairs_align: item %u ran out of scratch", i);
+		wtz_aln_result_t o; memset(&o, 0, sizeof o);
+		o.score = r.x.score; o.tb = r.x.tb; o.te = r.x.te; o.qb = r.x.qb; o.qe = r.x.qe; o.aln = r.x.aln; o.mat = r.x.mat; o.mis = r.x.mis; o.ins = r.x.ins; o.del = r.x.del;
+		o.n_regs = r.n_regs; o.cigar_len = r.cigar_len; o.cigar_off = coff; coff += r.cigar_len;
+		c->cnt.cells_shift += r.cells_shift; c->cnt.cells_fixed += r.cells_fixed; c->cnt.cells_global += r.cells_global;
+		out[i] = o;
+	}
+	return WTZ_OK;
+}
+
+extern "C" int wtz_fetch_cigars(wtz_ctx_t *c, uint32_t *dst, uint64_t n_ops){
+	if(!c || !c->d_alnres) return wtz_fail(WTZ_E_STATE, "wtz_fetch_cigars before wtz_pairs_align");
+	uint64_t tot = 0; for(uint32_t i = 0; i < c->n_items; i++) tot += c->h_alnres[i].cigar_len;
+	if(tot != n_ops) return wtz_fail(WTZ_E_ARG, "wtz_fetch_cigars: expected room for %llu ops, got %llu", (unsigned long long)tot, (unsigned long long)n_ops);
+	if(tot == 0) return WTZ_OK;
+	if(!dst) return wtz_fail(WTZ_E_ARG, "null output");
+	std::vector<uint64_t> off((size_t)c->n_items + 1);
+	uint64_t o = 0; for(uint32_t i = 0; i < c->n_items; i++){ off[i] = o; o += c->h_alnres[i].cigar_len; } off[c->n_items] = o;
+	uint64_t *d_off = NULL; uint32_t *d_c = NULL;
+	CHK(dev_alloc((void**)&d_off, off.size() * 8)); CHK(dev_h2d(d_off, off.data(), off.size() * 8));
+	CHK(dev_alloc((void**)&d_c, (size_t)tot * 4));
+	const wtz_alnres_dev_t *dr = c->d_alnres;
+	CHK(wtz_launch(0, c->n_items, [=] WTZ_LAMBDA (uint64_t t){ const wtz_alnres_dev_t &r = dr[t]; for(uint32_t k = 0; k < r.cigar_len; k++) d_c[d_off[t] + k] = r.cigar[k]; }));
+	CHK(dev_sync());
+	CHK(dev_d2h(dst, d_c, (size_t)tot * 4));
+	dev_free(d_off); dev_free(d_c);
+	return WTZ_OK;
+}
+
+extern "C" int wtz_get_counters(wtz_ctx_t *c, wtz_counters_t *out){ if(!c || !out) return wtz_fail(WTZ_E_ARG, "null argument"); *out = c->cnt; return WTZ_OK; }
+extern "C" int wtz_reset_counters(wtz_ctx_t *c){ if(!c) return wtz_fail(WTZ_E_ARG, "null context"); memset(&c->cnt, 0, sizeof c->cnt); return WTZ_OK; }

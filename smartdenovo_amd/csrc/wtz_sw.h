@@ -1,0 +1,307 @@
+/*
+ * wtz_sw.h — banded dynamic programs of the zmo engine, scalar (one lane per problem) form.
+ *
+ *   wtz_extend_fixed   K-sw1  kswx.h:234-335  kswx_extend_align_core        (fixed band)
+ *   wtz_extend_shift   K-sw3  kswx.h:101-232  kswx_extend_align_shift_core  (band follows the row arg-max)
+ *   wtz_global_banded  K-sw2  ksw.c:503-586   ksw_global2
+ *   wtz_align_zmer            hzm_aln.h:278-314 hz_align_hzmo
+ *   wtz_align_window   A9     hzm_aln.h:1247-1302 fast_seeds_align_hzmo
+ *
+ * Recurrence (int32, -10000 / -0x40000000 sentinels are part of the semantics):
+ *   m = H(i-1,j-1)+S;  H = max{m,E,F} (ties m>E>F);  E' = max{E+e, m+I+e};  F' = max{F+e, m+D+e}
+ * one trace byte per cell: bits0-1 H source, bit2 E extended, bit5 F extended.
+ * The wave-parallel kernels in wtz_sw_wave.h compute the same cells row by row with lanes
+ * across the band and a max-plus prefix scan for F; these scalar bodies are their on-device
+ * cross-check and the form used for the many tiny K-sw1/K-sw2 problems.
+ */
+#ifndef WTZ_SW_H
+#define WTZ_SW_H
+
+#include "wtz_window.h"
+
+typedef wtz_vec<uint32_t> wtz_cigar_t;
+
+WTZ_HD void wtz_cigar_push(wtz_cigar_t &c, uint32_t op, uint32_t len){          /* kswx.h:39-44 */
+	if(len == 0) return;
+	if(c.n && (c.a[c.n - 1] & 0xF) == op) c.a[c.n - 1] += len << 4;
+	else c.push((len << 4) | op);
+}
+WTZ_HD void wtz_cigar_concat(wtz_cigar_t &c, const uint32_t *src, uint32_t n){  /* kswx.h:46-52 */
+	if(n == 0) return;
+	uint32_t k = 0;
+	if(c.n && (c.a[c.n - 1] & 0xF) == (src[0] & 0xFu)){ c.a[c.n - 1] += src[0] & 0xFFFFFFF0u; k = 1; }
+	if(!c.reserve(c.n + n)) return;
+	for(; k < n; k++) c.a[c.n++] = src[k];
+}
+WTZ_HD void wtz_cigar_reverse(uint32_t *a, uint32_t n){ for(uint32_t i = 0; i < n / 2; i++){ uint32_t t = a[i]; a[i] = a[n - 1 - i]; a[n - 1 - i] = t; } }
+
+/* scratch for one DP: row arrays + trace matrix, (re)carved from the pool on demand */
+typedef struct { int32_t *rh, *re, *zb; uint8_t *z; uint32_t cap_row, cap_zb; uint64_t cap_z; wtz_pool_t *pool; int bad; } wtz_swmem_t;
+WTZ_HD void wtz_swmem_init(wtz_swmem_t &m, wtz_pool_t *pool){ m.rh = m.re = m.zb = NULL; m.z = NULL; m.cap_row = m.cap_zb = 0; m.cap_z = 0; m.pool = pool; m.bad = 0; }
+WTZ_HD bool wtz_swmem_need(wtz_swmem_t &m, uint32_t row, uint32_t zb, uint64_t z){
+	if(row > m.cap_row){ uint32_t c = m.cap_row ? m.cap_row : 64; while(c < row) c <<= 1;
+		m.rh = (int32_t*)wtz_pool_alloc(m.pool, (size_t)c * 4); m.re = (int32_t*)wtz_pool_alloc(m.pool, (size_t)c * 4); m.cap_row = c;
+		if(!m.rh || !m.re){ m.bad = 1; return false; } }
+	if(zb > m.cap_zb){ uint32_t c = m.cap_zb ? m.cap_zb : 64; while(c < zb) c <<= 1; m.zb = (int32_t*)wtz_pool_alloc(m.pool, (size_t)c * 4); m.cap_zb = c; if(!m.zb){ m.bad = 1; return false; } }
+	if(z > m.cap_z){ uint64_t c = m.cap_z ? m.cap_z : 1024; while(c < z) c <<= 1; m.z = (uint8_t*)wtz_pool_alloc(m.pool, (size_t)c); m.cap_z = c; if(!m.z){ m.bad = 1; return false; } }
+	return true;
+}
+
+WTZ_HD void wtz_ext_geometry(int32_t qlen, int32_t tlen, int32_t init_score, int32_t &W, int32_t M, int32_t I, int32_t D, int32_t E, int32_t T, int32_t &ql, int32_t &tl, int32_t &n_col){
+	int32_t w = W;
+	if(w > 0){
+		int32_t mx = ((qlen < tlen) ? qlen : tlen) * M + init_score + (-T);
+		int32_t max_gap = (mx + ((I > D) ? I : D)) / (-E) + 1;
+		if(max_gap < 1) max_gap = 1;
+		if(w > max_gap) w = max_gap;
+	} else w = -w;
+	w = WTZ_MIN(w, WTZ_MAX(qlen, tlen));
+	if(qlen < tlen){ if(qlen + w < tlen){ ql = qlen; tl = qlen + w; } else { ql = qlen; tl = tlen; } }
+	else           { if(tlen + w < qlen){ tl = tlen; ql = tlen + w; } else { tl = tlen; ql = qlen; } }
+	n_col = (tl < 2 * w + 1) ? tl : 2 * w + 1;
+	W = w;
+}
+
+/* sequence accessors: SEQ::at(p, i) returns the 2-bit base at logical index i */
+struct wtz_seq_bytes { const uint8_t *p; int32_t strand; WTZ_HDM uint32_t at(int32_t i) const { return p[i * strand]; } };
+/* 2-bit packed read: logical index i -> base (start + i*strand), complemented when comp */
+struct wtz_seq_packed { const uint64_t *bits; int64_t start; int32_t strand; uint32_t comp;
+	WTZ_HDM uint32_t at(int32_t i) const { uint32_t b = wtz_base_at(bits, (uint64_t)(start + (int64_t)i * strand)); return comp ? (3u - b) : b; } };
+
+/* traceback shared by K-sw1/K-sw3; ZROW(i) = first stored column of row i */
+#define WTZ_EXT_TRACEBACK(ZROW) do { \
+	int32_t i_ = x.qe, j_ = x.te; uint32_t d_ = 0; \
+	while(i_ >= 0 && j_ >= 0){ \
+		d_ = (mem.z[(size_t)i_ * n_col + (j_ - (ZROW))] >> (d_ << 1)) & 0x03; \
+		if(d_ == 0){ if(query.at(i_) == target.at(j_)) x.mat++; else x.mis++; i_--; j_--; } \
+		else if(d_ == 1){ i_--; x.ins++; } \
+		else { j_--; x.del++; } \
+		wtz_cigar_push(cigars, d_, 1); \
+	} \
+	if(i_ >= 0){ x.ins += i_ + 1; wtz_cigar_push(cigars, 1, (uint32_t)(i_ + 1)); } \
+	if(j_ >= 0){ x.del += j_ + 1; wtz_cigar_push(cigars, 2, (uint32_t)(j_ + 1)); } \
+	wtz_cigar_reverse(cigars.a, cigars.n); \
+	x.aln = x.mat + x.mis + x.ins + x.del; x.qe++; x.te++; \
+} while(0)
+
+template<typename SQ, typename ST>
+WTZ_HD wtz_aln_t wtz_extend_fixed(int32_t qlen, const SQ &query, int32_t tlen, const ST &target, int32_t init_score,
+		int32_t W, int32_t M, int32_t X, int32_t I, int32_t D, int32_t E, int32_t T, wtz_swmem_t &mem, wtz_cigar_t &cigars){
+	wtz_aln_t x; memset(&x, 0, sizeof x);
+	int32_t ql, tl, n_col, i, j, jb, je, h1, h, m, e, f, t, mx, mi, mj, imax, mj2, gmax, gi, gj; uint32_t d;
+	if(init_score < 0) init_score = 0;
+	if(qlen <= 0 || tlen <= 0){ x.score = init_score; return x; }
+	wtz_ext_geometry(qlen, tlen, init_score, W, M, I, D, E, T, ql, tl, n_col);
+	if(!wtz_swmem_need(mem, (uint32_t)tl + 2, 0, (uint64_t)ql * n_col)) return x;
+	int32_t *rh = mem.rh, *re = mem.re;
+	rh[0] = init_score; rh[1] = init_score + D + E;
+	for(j = 2; j <= tl; j++) rh[j] = rh[j - 1] + E;
+	for(j = 0; j <= tl; j++) re[j] = -10000;
+	mx = init_score; mi = -1; mj = -1; gmax = 0; gi = -1; gj = -1;
+	for(i = 0; i < ql; i++){
+		jb = i - W; if(jb < 0) jb = 0;
+		je = i + W + 1; if(je > tl) je = tl;
+		h1 = (jb == 0) ? init_score + I + E * (i + 1) : -10000;
+		uint8_t *zi = mem.z + (size_t)i * n_col;
+		imax = 0; mj2 = -1; f = -10000;
+		const uint32_t qb = query.at(i);
+		for(j = jb; j < je; j++){
+			m = rh[j] + ((qb == target.at(j)) ? M : X);
+			rh[j] = h1;
+			e = re[j];
+			d = m >= e ? 0 : 1; h = m >= e ? m : e;
+			d = h >= f ? d : 2; h = h >= f ? h : f;
+			h1 = h;
+			mj2 = imax > h ? mj2 : j;            /* last arg-max (kswx.h:288-289) */
+			imax = imax > h ? imax : h;
+			t = m + I + E; e = e + E; d |= e > t ? 1u << 2 : 0; e = e > t ? e : t; re[j] = e;
+			t = m + D + E; f = f + E; d |= f > t ? 2u << 4 : 0; f = f > t ? f : t;
+			zi[j - jb] = (uint8_t)d;
+		}
+		rh[j] = h1; re[j] = -10000;
+		if(j == tlen && gmax < h1){ gmax = h1; gi = i; gj = j - 1; }
+		if(i + 1 == qlen && gmax < imax){ gmax = imax; gi = i; gj = mj2; }
+		if(imax > mx){ mx = imax; mi = i; mj = mj2; }
+		else if(imax <= 0) break;
+	}
+	if(gmax > 0 && gmax >= mx + T){ x.score = gmax; x.qe = gi; x.te = gj; }
+	else { x.score = mx; x.qe = mi; x.te = mj; }
+	cigars.n = 0;
+	WTZ_EXT_TRACEBACK((i_ > W ? i_ - W : 0));
+	return x;
+}
+
+template<typename SQ, typename ST>
+WTZ_HD wtz_aln_t wtz_extend_shift(int32_t qlen, const SQ &query, int32_t tlen, const ST &target, int32_t init_score,
+		int32_t W, int32_t M, int32_t X, int32_t I, int32_t D, int32_t E, int32_t T, wtz_swmem_t &mem, wtz_cigar_t &cigars, unsigned long long *cells){
+	wtz_aln_t x; memset(&x, 0, sizeof x);
+	int32_t ql, tl, n_col, i, j, jb, je, h1, c, h, m, e, f, t, mx, mi, mj, imax, mj2, gmax, gi, gj; uint32_t d;
+	cigars.n = 0;
+	if(init_score < 0) init_score = 0;
+	if(qlen <= 0 || tlen <= 0){ x.score = init_score; return x; }
+	wtz_ext_geometry(qlen, tlen, init_score, W, M, I, D, E, T, ql, tl, n_col);
+	if(!wtz_swmem_need(mem, (uint32_t)tl + 3, (uint32_t)ql + 2, (uint64_t)ql * n_col)) return x;
+	int32_t *rh = mem.rh, *re = mem.re, *zb = mem.zb;
+	rh[0] = init_score; rh[1] = init_score + D + E;
+	for(j = 2; j <= tl; j++) rh[j] = rh[j - 1] + E;
+	for(j = 0; j <= tl; j++) re[j] = -10000;
+	mx = init_score; mi = -1; mj = -1; gmax = 0; gi = -1; gj = -1;
+	jb = 0; je = tl;
+	unsigned long long ncell = 0;
+	for(i = c = 0; i < ql; i++){
+		if(jb < c - W) jb = c - W;
+		if(je > c + W + 1) je = c + W + 1;
+		if(je > tl) je = tl;
+		h1 = (jb == 0) ? init_score + I + E * (i + 1) : -10000;
+		uint8_t *zi = mem.z + (size_t)i * n_col;
+		zb[i] = jb;
+		imax = 0; mj2 = -1; f = -10000;
+		const uint32_t qb = query.at(i);
+		ncell += (unsigned long long)(je - jb);
+		for(j = jb; j < je; j++){
+			m = rh[j] + ((qb == target.at(j)) ? M : X);
+			rh[j] = h1;
+			e = re[j];
+			if(m >= e){ d = 0; h = m; } else { d = 1; h = e; }
+			if(h < f){ d = 2; h = f; }
+			h1 = h;
+			if(h > imax){ imax = h; mj2 = j; }       /* first arg-max (kswx.h:172) */
+			t = m + I + E; e = e + E; if(e > t) d |= 1u << 2; else e = t; re[j] = e;
+			t = m + D + E; f = f + E; if(f > t) d |= 2u << 4; else f = t;
+			zi[j - jb] = (uint8_t)d;
+		}
+		rh[j] = h1; re[j] = -10000;
+		if(j == tlen && gmax < h1){ gmax = h1; gi = i; gj = j - 1; }
+		if(i + 1 == qlen && gmax < imax){ gmax = imax; gi = i; gj = mj2; }
+		if(imax > mx){ mx = imax; mi = i; mj = mj2; }
+		else if(imax <= 0) break;
+		c++;
+		if(c < mj2){ c++; if(je < tl){ rh[je + 1] = -10000; re[je + 1] = -10000; } }
+		else if(c > mj2){ c--; if(jb){ rh[jb - 1] = -10000; re[jb - 1] = -10000; } }
+		jb = 0; je = tl;
+	}
+	if(cells) *cells += ncell;
+	if(gmax > 0 && gmax >= mx + T){ x.score = gmax; x.qe = gi; x.te = gj; }
+	else { x.score = mx; x.qe = mi; x.te = mj; }
+	WTZ_EXT_TRACEBACK(zb[i_]);
+	return x;
+}
+
+#define WTZ_MINUS_INF (-0x40000000)
+
+/* K-sw2: match score M on equal bases else X (the reference passes a 4x4 matrix with exactly that content,
+ * hzm_aln.h:1354); penalties positive. cigar ops M0/I1/D2. */
+template<typename SQ, typename ST>
+WTZ_HD int32_t wtz_global_banded(int32_t qlen, const SQ &query, int32_t tlen, const ST &target, int32_t M, int32_t X,
+		int32_t o_del, int32_t e_del, int32_t o_ins, int32_t e_ins, int32_t w, wtz_swmem_t &mem, wtz_cigar_t &cig){
+	int32_t i, j, k, oe_del = o_del + e_del, oe_ins = o_ins + e_ins, score, n_col;
+	cig.n = 0;
+	n_col = qlen < 2 * w + 1 ? qlen : 2 * w + 1;
+	if(!wtz_swmem_need(mem, (uint32_t)qlen + 2, 0, (uint64_t)(n_col > 0 ? n_col : 0) * (uint64_t)(tlen > 0 ? tlen : 0) + 8)) return 0;
+	int32_t *H = mem.rh, *Ev = mem.re; uint8_t *z = mem.z;
+	H[0] = 0; Ev[0] = WTZ_MINUS_INF;
+	for(j = 1; j <= qlen && j <= w; ++j){ H[j] = -(o_ins + e_ins * j); Ev[j] = WTZ_MINUS_INF; }
+	for(; j <= qlen; ++j) H[j] = Ev[j] = WTZ_MINUS_INF;
+	for(i = 0; i < tlen; ++i){
+		int32_t f = WTZ_MINUS_INF, h1, beg, end, t;
+		uint8_t *zi = &z[(size_t)i * n_col];
+		beg = i > w ? i - w : 0;
+		end = i + w + 1 < qlen ? i + w + 1 : qlen;
+		h1 = beg == 0 ? -(o_del + e_del * (i + 1)) : WTZ_MINUS_INF;
+		const uint32_t tb = target.at(i);
+		for(j = beg; j < end; ++j){
+			int32_t h, m = H[j], e = Ev[j]; uint32_t d;
+			H[j] = h1;
+			m += (tb == query.at(j)) ? M : X;
+			d = m >= e ? 0 : 1; h = m >= e ? m : e;
+			d = h >= f ? d : 2; h = h >= f ? h : f;
+			h1 = h;
+			t = m - oe_del; e -= e_del; d |= e > t ? 1u << 2 : 0; e = e > t ? e : t; Ev[j] = e;
+			t = m - oe_ins; f -= e_ins; d |= f > t ? 2u << 4 : 0; f = f > t ? f : t;
+			zi[j - beg] = (uint8_t)d;
+		}
+		H[end] = h1; Ev[end] = WTZ_MINUS_INF;
+	}
+	score = H[qlen];
+	{
+		uint32_t which = 0;
+		i = tlen - 1; k = (i + w + 1 < qlen ? i + w + 1 : qlen) - 1;
+		while(i >= 0 && k >= 0){
+			which = (z[(size_t)i * n_col + (k - (i > w ? i - w : 0))] >> (which << 1)) & 3;
+			if(which == 0){ wtz_cigar_push(cig, 0, 1); --i; --k; }
+			else if(which == 1){ wtz_cigar_push(cig, 2, 1); --i; }
+			else { wtz_cigar_push(cig, 1, 1); --k; }
+		}
+		if(i >= 0) wtz_cigar_push(cig, 2, (uint32_t)(i + 1));
+		if(k >= 0) wtz_cigar_push(cig, 1, (uint32_t)(k + 1));
+		wtz_cigar_reverse(cig.a, cig.n);
+	}
+	return score;
+}
+
+/* hzm_aln.h:278-314: run-by-run alignment of a matched z-mer (homopolymer length differences -> I/D) */
+template<typename S1, typename S2>
+WTZ_HD wtz_aln_t wtz_align_zmer(const S1 &pb1, uint32_t len1, const S2 &pb2, uint32_t len2, int32_t M, int32_t I, int32_t D, int32_t E, wtz_cigar_t &cigars){
+	wtz_aln_t x, zero; memset(&zero, 0, sizeof zero); x = zero;
+	uint32_t s0 = 0, s1 = 0, e0, e1, l0, l1;
+	while(s0 < len1 || s1 < len2){
+		if(pb1.at((int32_t)s0) != pb2.at((int32_t)s1)) return zero;
+		e0 = s0 + 1; while(e0 < len1 && pb1.at((int32_t)e0) == pb1.at((int32_t)s0)) e0++;
+		e1 = s1 + 1; while(e1 < len2 && pb2.at((int32_t)e1) == pb2.at((int32_t)s1)) e1++;
+		l0 = e0 - s0; l1 = e1 - s1;
+		if(l0 < l1){
+			x.aln += l1; x.mat += l0; x.ins += l1 - l0; x.score += (int32_t)l0 * M + I + (int32_t)(l1 - l0) * E;
+			wtz_cigar_push(cigars, 0, l0); wtz_cigar_push(cigars, 1, l1 - l0);
+		} else if(l0 == l1){
+			x.aln += l0; x.mat += l0; x.score += (int32_t)l0 * M;
+			wtz_cigar_push(cigars, 0, l0);
+		} else {
+			x.aln += l0; x.mat += l1; x.del += l0 - l1; x.score += (int32_t)l1 * M + D + (int32_t)(l0 - l1) * E;
+			wtz_cigar_push(cigars, 0, l1); wtz_cigar_push(cigars, 2, l0 - l1);
+		}
+		s0 = e0; s1 = e1;
+	}
+	x.te = x.mat + x.del; x.qe = x.mat + x.ins;
+	return x;
+}
+
+/* Reads as the aligner sees them: pb1 = query read forward; pb2 = candidate, reverse-complemented when dir (wtzmo.c:1011-1013) */
+struct wtz_readview { const uint64_t *bits; uint64_t off; uint32_t len; uint32_t rev;
+	WTZ_HDM wtz_seq_packed sub(int32_t from, int32_t strand) const {      /* logical position `from`, walking by strand */
+		wtz_seq_packed s; s.bits = bits;
+		if(!rev){ s.start = (int64_t)off + from; s.strand = strand; s.comp = 0; }
+		else    { s.start = (int64_t)off + (int64_t)len - 1 - from; s.strand = -strand; s.comp = 1; }
+		return s;
+	} };
+
+/* A9 (hzm_aln.h:1247-1302): x accumulates along the anchors of one window; cigar appended to `cigar` */
+WTZ_HD wtz_aln_t wtz_align_window(const wtz_readview &pb1, const wtz_readview &pb2, const wtz_win_t &win, const wtz_zhit_t *anchors,
+		wtz_cigar_t &cigar, wtz_swmem_t &mem, wtz_cigar_t &tmp, const wtz_params_t *P){
+	wtz_aln_t x, y; memset(&x, 0, sizeof x);
+	const int32_t M = P->M, X = P->X, I = P->O, D = P->O, E = P->E, T = P->T;
+	for(uint32_t i = win.anchors[0]; i < win.anchors[1]; i++){
+		const wtz_zhit_t p = anchors[i];
+		const int32_t off1 = (int32_t)ZH_OFF1(p), off2 = (int32_t)ZH_OFF2(p);
+		if(x.aln == 0){ x.tb = x.te = off1; x.qb = x.qe = off2; }
+		if(off1 < x.te) continue;
+		if(off2 < x.qe) continue;
+		tmp.n = 0;
+		y = wtz_extend_fixed(off2 - x.qe, pb2.sub(x.qe, 1), off1 - x.te, pb1.sub(x.te, 1), x.score, P->w, M, X, I, D, E, T, mem, tmp);
+		x.score = y.score;
+		x.aln += y.aln; x.mat += y.mat; x.mis += y.mis; x.ins += y.ins; x.del += y.del;
+		x.te += y.te; x.qe += y.qe;
+		if(x.te < off1){ x.del += off1 - x.te; x.aln += off1 - x.te; wtz_cigar_push(tmp, 2, (uint32_t)(off1 - x.te)); x.te = off1; }
+		if(x.qe < off2){ x.ins += off2 - x.qe; x.aln += off2 - x.qe; wtz_cigar_push(tmp, 1, (uint32_t)(off2 - x.qe)); x.qe = off2; }
+		wtz_cigar_concat(cigar, tmp.a, tmp.n);
+		tmp.n = 0;
+		y = wtz_align_zmer(pb1.sub(off1, 1), ZH_LEN1(p), pb2.sub(off2, 1), ZH_LEN2(p), M, I, D, E, tmp);
+		if(y.aln == 0) return x;
+		x.score += y.score;
+		x.aln += y.aln; x.mat += y.mat; x.mis += y.mis; x.ins += y.ins; x.del += y.del;
+		x.te += y.te; x.qe += y.qe;
+		wtz_cigar_concat(cigar, tmp.a, tmp.n);
+	}
+	return x;
+}
+
+#endif

@@ -1,0 +1,256 @@
+/*
+ * wtz_window.h — per-pair task bodies: z-mer matching (A6), the (off1,off2) ordering, window
+ * detection and window chaining of the zmo engine (A7z).
+ *
+ *   wtz_zmatch            hzm_aln.h:173-224   query_single_read_seeds against the prebuilt tables
+ *   wtz_median            hzm_aln.h:316-343   calculate_median_value
+ *   wtz_scan_windows      hzm_aln.h:410-578   potential_paired_kmers_windows (fast chaining branch)
+ *   wtz_merge_windows     hzm_aln.h:580-656   merge_paired_kmers_window
+ *   wtz_chain_windows     hzm_aln.h:658-713   chaining_wtseedv
+ *
+ * All ordering-sensitive steps use wtz_sort_exact (the reference's unstable sort) because
+ * tie order leaks into the output (SURVEY §8a trap 1).  Integer promotions follow the
+ * reference's bit-fields: offsets/lengths are non-negative and mix with uint32 as unsigned.
+ */
+#ifndef WTZ_WINDOW_H
+#define WTZ_WINDOW_H
+
+#include "wtz_seed.h"
+
+#define WTZ_KWIN_MAX_OFFSET_DEV 50
+
+/* ---- A6: walk the candidate's position-ordered z-mers, look each up in the query's table ---- */
+WTZ_HD bool wtz_zmatch(const wtz_zindex_t &Z, uint32_t q, uint32_t c, uint32_t clen, uint32_t max_var, wtz_vec<wtz_zhit_t> &out){
+	const uint64_t qo = Z.zoff[q], co = Z.zoff[c];
+	const uint32_t cn = (uint32_t)(Z.zoff[c + 1] - co), qd = Z.dn[q];
+	const uint32_t *dmer = Z.dmer + qo;
+	for(uint32_t k = 0; k < cn; k++){
+		if(!Z.ok[co + k]) continue;                       /* per-table-entry hit cap (hzm_aln.h:208-211) */
+		uint32_t m = Z.mer[co + k];
+		uint32_t lo = 0, hi = qd;
+		while(lo < hi){ uint32_t mid = (lo + hi) >> 1; if(dmer[mid] < m) lo = mid + 1; else hi = mid; }
+		if(lo >= qd || dmer[lo] != m) continue;
+		uint32_t cpos = Z.pos[co + k], clen2 = Z.len[co + k];
+		uint32_t first = Z.dfirst[qo + lo], cnt = Z.dcnt[qo + lo];
+		for(uint32_t e = 0; e < cnt; e++){
+			uint32_t qi = Z.sidx[qo + first + e];
+			uint32_t qpos = Z.pos[qo + qi], qlen = Z.len[qo + qi];
+			uint32_t dv = qlen > clen2 ? qlen - clen2 : clen2 - qlen;
+			if(dv > max_var) continue;
+			uint32_t d1 = qpos & 1u, d2 = cpos & 1u;
+			uint32_t off2 = (d1 ^ d2) ? clen - ((cpos >> 1) + clen2) : (cpos >> 1);
+			wtz_zhit_t h; h.o1 = (d1 << 31) | (qpos >> 1); h.o2 = (d2 << 31) | off2; h.ll = (clen2 << 16) | qlen; h.gid = 0;
+			if(!out.push(h)) return false;
+		}
+	}
+	return true;
+}
+
+struct wtz_gt_off12 { WTZ_HDM bool operator()(const wtz_zhit_t &a, const wtz_zhit_t &b) const {
+	uint64_t ka = ((uint64_t)ZH_OFF1(a) << 32) | ZH_OFF2(a), kb = ((uint64_t)ZH_OFF1(b) << 32) | ZH_OFF2(b); return ka > kb; } };
+struct wtz_gt_off1 { WTZ_HDM bool operator()(const wtz_zhit_t &a, const wtz_zhit_t &b) const { return ZH_OFF1(a) > ZH_OFF1(b); } };
+struct wtz_gt_idx_off2 { const wtz_zhit_t *rs; WTZ_HDM bool operator()(uint32_t a, uint32_t b) const { return ZH_OFF2(rs[a]) > ZH_OFF2(rs[b]); } };
+
+WTZ_HD int32_t wtz_median(int32_t *rs, int32_t size){
+	int32_t i, j, key, mid, beg, end, tmp;
+	if(size == 0) return 0;
+	beg = 0; end = size - 1;
+	while(beg < end){
+		mid = beg + (end - beg) / 2;
+		if(rs[beg] > rs[mid]){ tmp = rs[beg]; rs[beg] = rs[mid]; rs[mid] = tmp; }
+		if(rs[mid] > rs[end]){
+			tmp = rs[end]; rs[end] = rs[mid]; rs[mid] = tmp;
+			if(rs[beg] > rs[mid]){ tmp = rs[beg]; rs[beg] = rs[mid]; rs[mid] = tmp; }
+		}
+		key = rs[mid];
+		i = beg + 1; j = end - 1;
+		for(;;){
+			while(key > rs[i]) i++;
+			while(rs[j] > key) j--;
+			if(i < j){ tmp = rs[i]; rs[i] = rs[j]; rs[j] = tmp; i++; j--; }
+			else break;
+		}
+		if(i == j){ i++; j--; }
+		if(i <= size / 2) beg = i; else end = j;
+	}
+	return rs[size / 2];
+}
+
+/* scratch of one (pair,strand) window scan: all sized by the number of matches of the pair */
+typedef struct { uint32_t *ts; int32_t *as; uint32_t *wb, *we, *wo; } wtz_winscratch_t;
+
+WTZ_HD uint32_t wtz_scan_windows(const wtz_zhit_t *rs, uint32_t dir, uint32_t beg, uint32_t end, int32_t bound,
+		wtz_vec<wtz_win_t> &wins, wtz_vec<wtz_zhit_t> &anchors, const wtz_winscratch_t &sc, uint32_t zsize, uint32_t kwin, uint32_t zovl){
+	uint32_t i, j, n = 0, n2, ol, ol2, s, t, lst, ret;
+	while(beg < end){
+		if((ZH_STRAND(rs[beg]) ^ dir) || (int32_t)ZH_OFF1(rs[beg]) < bound) beg++;
+		else break;
+	}
+	for(i = beg; i < end; i++){ if(ZH_STRAND(rs[i]) ^ dir) continue; n++; }
+	if(n * zsize < zovl) return 0;
+	uint32_t *ts = sc.ts;
+	n = 0;
+	for(i = beg; i < end; i++){ if(ZH_STRAND(rs[i]) ^ dir) continue; ts[n++] = i; }
+	wtz_gt_idx_off2 g2; g2.rs = rs;
+	wtz_sort_exact(ts, n, g2);
+	ol = 0; lst = 0; n2 = 0;
+	for(i = j = 0; i < n; i++){
+		const wtz_zhit_t p = rs[ts[i]];
+		while(ZH_OFF2(p) + ZH_LEN2(p) > ZH_OFF2(rs[ts[j]]) + kwin){
+			const wtz_zhit_t p0 = rs[ts[j++]];
+			const wtz_zhit_t p1 = rs[ts[j]];
+			s = ZH_OFF2(p1); t = ZH_OFF2(p0) + ZH_LEN2(p0);
+			ol2 = s < t ? t - s : 0;
+			ol = ol + ol2 - ZH_LEN2(p0);
+		}
+		ol += (ZH_OFF2(p) > lst) ? ZH_LEN2(p) : ZH_OFF2(p) + ZH_LEN2(p) - lst;
+		lst = ZH_OFF2(p) + ZH_LEN2(p);
+		if(ol >= zovl){
+			if(n2 && ( ZH_OFF2(rs[ts[i]]) <= ZH_OFF2(rs[ts[sc.we[n2-1]]]) + kwin / 3 ||
+			           ZH_OFF2(rs[ts[j]]) <= ZH_OFF2(rs[ts[sc.wb[n2-1]]]) + kwin / 3 )){
+				if(ol > sc.wo[n2-1]){ sc.wb[n2-1] = j; sc.we[n2-1] = i; sc.wo[n2-1] = ol; }
+			} else { sc.wb[n2] = j; sc.we[n2] = i; sc.wo[n2] = ol; n2++; }
+		}
+	}
+	ret = 0;
+	for(i = 0; i < n2; i++){
+		const uint32_t size = anchors.n;
+		int32_t offset, off; uint32_t offn = 0;
+		for(j = sc.wb[i]; j <= sc.we[i]; j++){ const wtz_zhit_t p = rs[ts[j]]; sc.as[offn++] = (int32_t)ZH_OFF1(p) - (int32_t)ZH_OFF2(p); }
+		offset = wtz_median(sc.as, (int32_t)offn);
+		ol = lst = 0;
+		for(j = sc.wb[i]; j <= sc.we[i]; j++){
+			const wtz_zhit_t p = rs[ts[j]];
+			off = (int32_t)ZH_OFF1(p) - (int32_t)ZH_OFF2(p);
+			if(off < offset - WTZ_KWIN_MAX_OFFSET_DEV || off > offset + WTZ_KWIN_MAX_OFFSET_DEV) continue;
+			if(!anchors.push(p)) return ret;
+			ol += (ZH_OFF2(p) > lst) ? ZH_LEN2(p) : ZH_OFF2(p) + ZH_LEN2(p) - lst;
+			lst = ZH_OFF2(p) + ZH_LEN2(p);
+		}
+		if(anchors.n == size) continue;
+		wtz_sort_exact(anchors.a + size, (size_t)(anchors.n - size), wtz_gt_off1());
+		wtz_win_t w;
+		w.pb2 = 0; w.closed = 0; w.dir = (uint8_t)dir; w.pad = 0;
+		w.anchors[0] = size; w.anchors[1] = 0;
+		w.beg[0] = w.beg[1] = 0x7FFFFFFF; w.end[0] = w.end[1] = 0;
+		w.ovl = WTZ_OVL29(ol);
+		ol = lst = 0;
+		for(uint32_t k = size; k < anchors.n; k++){
+			const wtz_zhit_t p = anchors.a[k];
+			ol += (ZH_OFF1(p) > lst) ? ZH_LEN1(p) : ZH_OFF1(p) + ZH_LEN1(p) - lst;
+			lst = ZH_OFF1(p) + ZH_LEN1(p);
+			if((int32_t)ZH_OFF1(p) < w.beg[0]) w.beg[0] = (int32_t)ZH_OFF1(p);
+			if((int32_t)(ZH_OFF1(p) + ZH_LEN1(p)) > w.end[0]) w.end[0] = (int32_t)(ZH_OFF1(p) + ZH_LEN1(p));
+			if((int32_t)ZH_OFF2(p) < w.beg[1]) w.beg[1] = (int32_t)ZH_OFF2(p);
+			if((int32_t)(ZH_OFF2(p) + ZH_LEN2(p)) > w.end[1]) w.end[1] = (int32_t)(ZH_OFF2(p) + ZH_LEN2(p));
+		}
+		if(ol * 2 < zovl){
+			anchors.n = size;
+		} else if(ret && (w.end[1] <= (int32_t)((uint32_t)wins.a[wins.n - 1].end[1] + kwin / 3) && ol <= wins.a[wins.n - 1].ovl)){
+			anchors.n = size;
+		} else {
+			ret++;
+			w.ovl = WTZ_OVL29(ol);
+			w.anchors[1] = anchors.n;
+			if(!wins.push(w)) return ret;
+		}
+	}
+	return ret;
+}
+
+/* rs must have one readable (zeroed) element past n_rs: the reference reads it too (hzm_aln.h:626) */
+WTZ_HD uint32_t wtz_merge_windows(const wtz_zhit_t *rs, uint32_t n_rs, uint32_t dir, wtz_vec<wtz_win_t> &wins, wtz_vec<wtz_zhit_t> &anchors,
+		const wtz_winscratch_t &sc, uint32_t zsize, uint32_t kwin, uint32_t kstep, uint32_t zovl){
+	const uint32_t P_off1 = 0x1FFFFFu, P_len1 = 0x3FFu;
+	uint32_t i, j, n, a, ol, ol2, lst, wlst, s, t, ret;
+	uint32_t p_off1, p_len1, p0_off1, p0_len1, p1_off1, p1_len1;
+	int32_t nxt;
+	ol = 0; lst = 0; wlst = 0; ret = 0;
+	for(j = 0; j < n_rs; j++){ if(ZH_STRAND(rs[j]) ^ dir) continue; break; }
+	if(j == n_rs) return 0;
+	p0_off1 = ZH_OFF1(rs[j]); p0_len1 = ZH_LEN1(rs[j]);
+	for(i = j; i <= n_rs; i++){
+		if(i < n_rs){ if(ZH_STRAND(rs[i]) ^ dir) continue; p_off1 = ZH_OFF1(rs[i]); p_len1 = ZH_LEN1(rs[i]); }
+		else { p_off1 = P_off1; p_len1 = P_len1; }
+		if(p_off1 > p0_off1 + kwin){
+			if(ol >= zovl){
+				if((n = wtz_scan_windows(rs, dir, j, i, (int32_t)wlst, wins, anchors, sc, zsize, kwin, zovl))){
+					for(a = 0; a < n; a++){
+						int32_t e0 = wins.a[wins.n + a - n].end[0] + 20;
+						if((int32_t)wlst < e0) wlst = (uint32_t)e0;
+					}
+					ret += n;
+					p0_off1 = p_off1; p0_len1 = p_len1; ol = p_len1; lst = p_off1 + p_len1; j = i;
+				} else {
+					nxt = (int32_t)(p0_off1 + kstep);
+					while((int32_t)p0_off1 < nxt && j < i){
+						++j; p1_off1 = ZH_OFF1(rs[j]); p1_len1 = ZH_LEN1(rs[j]);
+						s = WTZ_MAX(p0_off1, p1_off1);
+						t = WTZ_MIN(p0_off1 + p0_len1, p1_off1 + p1_len1);
+						ol2 = s < t ? t - s : 0;
+						ol = ol + ol2 - p0_len1;
+						p0_off1 = p1_off1; p0_len1 = p1_len1;
+					}
+				}
+			}
+			if(p_off1 == P_off1) break;          /* the sentinel, or a real match at 0x1FFFFF (hzm_aln.h:589,633) */
+			while(p_off1 > p0_off1 + kwin){
+				++j; p1_off1 = ZH_OFF1(rs[j]); p1_len1 = ZH_LEN1(rs[j]);
+				s = WTZ_MAX(p0_off1, p1_off1);
+				t = WTZ_MIN(p0_off1 + p0_len1, p1_off1 + p1_len1);
+				ol2 = s < t ? t - s : 0;
+				ol = ol + ol2 - p0_len1;
+				p0_off1 = p1_off1; p0_len1 = p1_len1;
+			}
+		} else {
+			if(p_off1 >= lst) ol += p_len1;
+			else if((int32_t)(p_off1 + p_len1) > (int32_t)lst) ol += p_off1 + p_len1 - lst;
+			else continue;
+			lst = p_off1 + p_len1;
+		}
+	}
+	return ret;
+}
+
+/* returns the chain weight; members get closed=0, the rest closed=1. mem: 2*n ints */
+WTZ_HD int32_t wtz_chain_windows(wtz_win_t *regs, uint32_t n, int32_t W, int32_t *mem){
+	const int32_t max_overhang = 0; const float band_penalty = 0.05f;
+	int32_t *weight = mem, *back = mem + n;
+	int32_t mw = -1000000, bt = -1, band;
+	for(uint32_t i = 0; i < n; i++){ weight[i] = 0; back[i] = -1; }
+	for(uint32_t i = 0; i < n; i++){
+		wtz_win_t *r1 = &regs[i];
+		r1->closed = 1;
+		weight[i] += (int32_t)r1->ovl;
+		if(weight[i] > mw){ mw = weight[i]; bt = (int32_t)i; }
+		for(uint32_t j = i + 1; j < n; j++){
+			const wtz_win_t *r2 = &regs[j];
+			if(r2->beg[1] + max_overhang < r1->end[1]) continue;
+			if(r2->beg[0] + max_overhang < r1->end[0]) continue;
+			if(r2->beg[0] - r1->end[0] > W && r2->beg[1] - r1->end[1] > W) break;
+			band = WTZ_ABSDIFF(r2->beg[0] - r1->end[0], r2->beg[1] - r1->end[1]);
+			if(band > W) continue;
+			band = (int32_t)((float)band * band_penalty);
+			if(weight[j] < weight[i] - band){ weight[j] = weight[i] - band; back[j] = (int32_t)i; }
+		}
+	}
+	mw = 0;
+	while(bt >= 0){ wtz_win_t *r1 = &regs[bt]; r1->closed = 0; mw += r1->end[0] - r1->beg[0]; bt = back[bt]; }
+	return mw;
+}
+
+/* result of one (query, candidate) pair; the window/anchor arrays live in the pool until the next stage reset */
+typedef struct {
+	uint32_t n_hits;                 /* |cache| (hzm_aln.h:173) */
+	uint32_t gate;                   /* 1 if n_hits*zsize >= ztot (wtzmo.c:857) */
+	uint32_t ovl[2];                 /* SEED[dir].ovl after chaining */
+	uint32_t nwin[2];                /* chain windows kept (0 unless ovl >= ztot) */
+	wtz_win_t  *win[2];
+	wtz_zhit_t *anchors[2];
+	uint32_t nanchors[2];
+	int32_t  bad;                    /* pool exhausted while working on this pair */
+	/* dot-matrix engine result (A7d) */
+	int32_t dm_score, dm_qb, dm_qe, dm_tb, dm_te, dm_dir;
+} wtz_pairres_t;
+
+#endif

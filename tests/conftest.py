@@ -1,0 +1,55 @@
+import hashlib
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run by the driver with -m gpu)")
+
+
+def manifest():
+    return json.load(open(os.path.join(GOLD, "manifest.json")))
+
+
+def case_argv(case):
+    return [a if not a.startswith("@") else os.path.join(GOLD, a[1:]) for a in case["argv"]]
+
+
+def md5_file(path):
+    return hashlib.md5(open(path, "rb").read()).hexdigest() if os.path.exists(path) else None
+
+
+def run_wtzmo_like(exe, case, tmpdir, extra=()):
+    """Run a wtzmo-compatible executable on one golden case; returns (md5 of .ovl, md5 of .contained, 16-col text)."""
+    out = os.path.join(str(tmpdir), "o.ovl")
+    for f in (out, out + ".contained"):
+        if os.path.exists(f):
+            os.remove(f)
+    cmd = [exe, "-i", os.path.join(GOLD, case["input"]), "-fo", out] + case_argv(case) + list(extra)
+    r = subprocess.run(cmd, capture_output=True)
+    assert r.returncode == 0, "%s failed (%d): %s" % (" ".join(cmd), r.returncode, r.stderr.decode()[-2000:])
+    full = open(out, "rb").read()
+    cut = b"\n".join(b"\t".join(l.split(b"\t")[:16]) for l in full.split(b"\n"))
+    return hashlib.md5(full).hexdigest(), md5_file(out + ".contained"), cut
+
+
+@pytest.fixture(scope="session")
+def oracle_exe():
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "wtzmo_oracle"], check=True)
+    return os.path.join(ROOT, "oracle", "wtzmo_oracle")
+
+
+@pytest.fixture(scope="session")
+def gpu_exe():
+    import __graft_entry__ as ge
+    if not (os.path.exists(ge.EXE) and os.path.exists(ge.LIB)):
+        ge.build_product()
+    return ge.EXE

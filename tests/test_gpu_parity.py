@@ -1,0 +1,55 @@
+"""GPU parity tests (-m gpu): the drop-in `wtzmo` executable (host C -> C ABI -> HIP kernels on gfx950) must write
+byte-identical .ovl / .contained files to the real reference `wtzmo -t 1` (committed goldens), to the oracle run live,
+and - where the prebuilt reference binary travelled along - to the reference run live on a larger seeded input."""
+import gzip
+import os
+import subprocess
+
+import pytest
+
+from conftest import GOLD, ROOT, manifest, run_wtzmo_like
+from smartdenovo_amd import synth
+
+pytestmark = pytest.mark.gpu
+CASES = sorted(manifest()["cases"].keys())
+REF = os.path.join(ROOT, "oracle", "_ref", "wtzmo_ref")
+
+
+def test_library_is_the_hip_build(gpu_exe):
+    from smartdenovo_amd import hipabi
+    lib = hipabi.load()
+    assert lib.wtz_device_count() >= 1, "no HIP device: these tests must run on an MI355X"
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_gpu_equals_reference_golden(name, gpu_exe, tmp_path):
+    case = manifest()["cases"][name]
+    md5, cont, cut = run_wtzmo_like(gpu_exe, case, tmp_path)
+    assert cut == gzip.open(os.path.join(GOLD, name + ".ovl16.gz")).read(), "16-column records differ from the reference"
+    assert md5 == case["md5_full"], "full .ovl (incl. CIGAR) differs from the reference"
+    assert cont == case["md5_contained"]
+
+
+@pytest.mark.parametrize("batch", ["1", "7", "4096"])
+def test_batch_size_never_changes_the_output(batch, gpu_exe, tmp_path):
+    """The speculative batch is an execution detail: any batch size must give the `-t 1` records."""
+    case = manifest()["cases"]["zmo"]
+    md5, cont, _ = run_wtzmo_like(gpu_exe, case, tmp_path, extra=["--batch", batch])
+    assert md5 == case["md5_full"] and cont == case["md5_contained"]
+
+
+@pytest.mark.parametrize("engine", ["zmo", "dmo"])
+def test_gpu_equals_oracle_on_fresh_input(engine, gpu_exe, oracle_exe, tmp_path):
+    names, seqs = synth.synth_reads(300000, 12, seed=99, mean_len=9000.0, min_len=1000)
+    fa = os.path.join(str(tmp_path), "r.fa")
+    synth.write_fasta(fa, names, seqs)
+    argv = ["-k", "16", "-s", "200", "-m", "0.6"] if engine == "zmo" else ["-k", "16", "-z", "10", "-Z", "16", "-U", "-1", "-m", "0.1", "-A", "1000"]
+    a, b = os.path.join(str(tmp_path), "gpu.ovl"), os.path.join(str(tmp_path), "ora.ovl")
+    subprocess.run([gpu_exe, "-i", fa, "-fo", a] + argv, check=True, capture_output=True)
+    subprocess.run([oracle_exe, "-i", fa, "-fo", b] + argv, check=True, capture_output=True)
+    assert open(a, "rb").read() == open(b, "rb").read()
+    assert open(a + ".contained", "rb").read() == open(b + ".contained", "rb").read()
+    if os.path.exists(REF):
+        c = os.path.join(str(tmp_path), "ref.ovl")
+        subprocess.run([REF, "-t", "1", "-i", fa, "-fo", c] + argv, check=True, capture_output=True)
+        assert open(a, "rb").read() == open(c, "rb").read()
