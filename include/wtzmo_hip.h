@@ -83,6 +83,8 @@ typedef struct {
 	uint64_t cells_shift, cells_fixed, cells_global;                                  /* DP cell updates as the reference loops execute them */
 	uint64_t bytes_seed_algo;                                                         /* algorithmic bytes of seed lookup */
 	uint64_t pool_peak;
+	double   ms_ext;                                                                  /* K-sw3 wave kernel alone (inside ms_stitch) */
+	uint64_t n_extjobs;
 } wtz_counters_t;
 
 const char *wtz_last_error(void);

@@ -79,11 +79,13 @@ typedef struct {
 	uint32_t *item_of; uint32_t *it_pair; uint8_t *it_dir; uint32_t nitem; wtz_aln_result_t *aln; uint32_t *cig; uint64_t ncig, capcig;
 	pending_t pend;
 	/* stats */
+	double t_gpu, t_commit;
 	uint64_t spec_pairs, used_pairs, spec_items, used_items, spec_queries, used_queries;
 } eng_t;
 
 #define DIE_WTZ(rc, what) do { if((rc) != WTZ_OK){ fprintf(stderr, " -- %s failed: %s --\n", what, wtz_last_error()); exit(1); } } while(0)
 
+static double now_s(void);
 static uint32_t nbest_of(const eng_t *E, uint32_t id){
 	uint32_t nb = (uint32_t)(((size_t)E->P.nbest) * E->rdlen[id] / E->avg_rdlen);      /* wtzmo.c:806-807 */
 	return nb < E->P.nbest ? E->P.nbest : nb;
@@ -146,12 +148,15 @@ static void pend_hit(pending_t *p, const hit_t *h){
 }
 
 static char *cigar_text(const uint32_t *c, uint32_t n){        /* kswx.h:1093-1120 */
-	size_t cap = (size_t)n * 12 + 2, k = 0; char *s = (char*)hx_realloc(NULL, cap);
+	size_t cap = (size_t)n * 11 + 2, k = 0; char *s = (char*)hx_realloc(NULL, cap);
 	for(uint32_t i = 0; i < n; i++){
 		uint32_t op = c[i] & 0xF, len = c[i] >> 4;
 		if(len == 0) continue;
 		if(op > 2){ fprintf(stderr, " -- CIGAR only support M(0),I(1),D(2) cigar, but met ?(%u) --\n", op); exit(1); }
-		k += (size_t)sprintf(s + k, "%u%c", len, "MID"[op]);
+		char d[12]; int nd = 0;
+		while(len){ d[nd++] = (char)('0' + len % 10); len /= 10; }
+		while(nd) s[k++] = d[--nd];
+		s[k++] = "MID"[op];
 	}
 	s[k] = 0; return s;
 }
@@ -308,7 +313,9 @@ static void candidates_chunk(eng_t *E, const uint32_t *ids, uint32_t n){
 }
 
 /* ---------------- one batch: plan -> GPU -> commit ---------------- */
-static void run_batch(eng_t *E){
+/* returns 1 (nothing committed) when the device scratch pool was too small for this batch: the caller retries with fewer queries */
+#define TRY_WTZ(rc, what) do { if((rc) == WTZ_E_POOL) return 1; DIE_WTZ(rc, what); } while(0)
+static int run_batch(eng_t *E){
 	const wtz_params_c *P = &E->P;
 	int rc;
 	/* plan pairs: every row entry whose pair is not closed now */
@@ -328,8 +335,9 @@ static void run_batch(eng_t *E){
 		}
 	}
 	E->spec_pairs += E->npair; E->spec_queries += E->nbq;
+	const double tg0 = now_s();
 	E->sum = (wtz_pair_summary_t*)hx_realloc(E->sum, sizeof(wtz_pair_summary_t) * (E->npair + 1));
-	rc = wtz_pairs_seed(E->ctx, E->pq, E->pc, E->npair, E->sum); DIE_WTZ(rc, "wtz_pairs_seed");
+	rc = wtz_pairs_seed(E->ctx, E->pq, E->pc, E->npair, E->sum); TRY_WTZ(rc, "wtz_pairs_seed");
 	E->nitem = 0; E->ncig = 0;
 	if(!P->dot_matrix){
 		E->box_off = (uint64_t*)hx_realloc(E->box_off, 8 * ((size_t)E->npair * 2 + 1));
@@ -337,7 +345,7 @@ static void run_batch(eng_t *E){
 		for(uint32_t i = 0; i < E->npair; i++) for(int d = 0; d < 2; d++){ E->box_off[(size_t)i * 2 + d] = nb; nb += E->sum[i].nwin[d]; }
 		E->box_off[(size_t)E->npair * 2] = nb; E->nbox = nb;
 		if(nb > E->capbox){ E->capbox = nb; E->boxes = (wtz_winbox_t*)hx_realloc(E->boxes, sizeof(wtz_winbox_t) * nb); }
-		rc = wtz_pairs_windows(E->ctx, E->boxes, nb); DIE_WTZ(rc, "wtz_pairs_windows");
+		rc = wtz_pairs_windows(E->ctx, E->boxes, nb); TRY_WTZ(rc, "wtz_pairs_windows");
 		E->item_of = (uint32_t*)hx_realloc(E->item_of, 4 * ((size_t)E->npair + 1));
 		E->it_pair = (uint32_t*)hx_realloc(E->it_pair, 4 * ((size_t)E->npair + 1));
 		E->it_dir = (uint8_t*)hx_realloc(E->it_dir, (size_t)E->npair + 1);
@@ -351,29 +359,43 @@ static void run_batch(eng_t *E){
 		E->spec_items += E->nitem;
 		if(E->nitem){
 			E->aln = (wtz_aln_result_t*)hx_realloc(E->aln, sizeof(wtz_aln_result_t) * E->nitem);
-			rc = wtz_pairs_align(E->ctx, E->it_pair, E->it_dir, E->nitem, E->aln); DIE_WTZ(rc, "wtz_pairs_align");
+			rc = wtz_pairs_align(E->ctx, E->it_pair, E->it_dir, E->nitem, E->aln); TRY_WTZ(rc, "wtz_pairs_align");
 			uint64_t tot = 0; for(uint32_t i = 0; i < E->nitem; i++) tot += E->aln[i].cigar_len;
 			if(tot > E->capcig){ E->capcig = tot; E->cig = (uint32_t*)hx_realloc(E->cig, 4 * tot); }
-			rc = wtz_fetch_cigars(E->ctx, E->cig, tot); DIE_WTZ(rc, "wtz_fetch_cigars");
+			rc = wtz_fetch_cigars(E->ctx, E->cig, tot); TRY_WTZ(rc, "wtz_fetch_cigars");
 			E->ncig = tot;
 		}
 	}
+	const double tg1 = now_s(); E->t_gpu += tg1 - tg0;
 	/* commit in query order with the reference's one-query masking lag (wtzmo.c:1315-1333) */
 	for(uint32_t s = 0; s < E->nbq; s++){
 		if(E->masked[E->bq[s]]) continue;
 		flush_pending(E);
 		commit_query(E, s);
 	}
+	E->t_commit += now_s() - tg1;
+	return 0;
 }
 
 static double now_s(void){ struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec; }
 
+/* Benchmark hook (bench.py, in-process through libwtzmo_host.so): called with (rep, 0) right before the timed overlap
+ * phase of repetition `rep` starts (reads already resident in HBM) and with (rep, 1) after its output is written. */
+typedef void (*wtzmo_hook_fn)(int rep, int phase);
+static wtzmo_hook_fn g_hook = NULL;
+void wtzmo_set_hook(wtzmo_hook_fn f){ g_hook = f; }
+
+#ifdef WTZ_AS_LIB
+int wtzmo_main(int argc, char **argv){
+	optind = 1;
+#else
 int main(int argc, char **argv){
+#endif
 	eng_t *E = (eng_t*)calloc(1, sizeof(eng_t));
 	wtz_params_c *P = &E->P;
 	strlist_t pbs = {0}, flts = {0}, ovls = {0}, obts = {0}, tbas = {0};
 	char *output = NULL, *pairoutf = NULL, *statsf = NULL;
-	int c, min_rdlen = 0, overwrite = 0, dot_matrix = 0, write_contained = 1, refine = 0, gpu = 0, lib_check = 0;
+	int c, min_rdlen = 0, overwrite = 0, dot_matrix = 0, write_contained = 1, refine = 0, gpu = 0, lib_check = 0, repeat = 1;
 	uint64_t pool_gb = 0; float optval;
 	/* defaults: wtzmo.c:1543-1588 */
 	P->w = 50; P->ew = 800; P->W = 3200; P->M = 2; P->X = -5; P->O = -3; P->E = -1; P->T = -50;
@@ -381,9 +403,9 @@ int main(int argc, char **argv){
 	P->kwin = 800; P->kovl = 300; P->ksave = 4; P->win_rep_norm = 20; P->win_rep_cutoff = 100; P->ncand = 500; P->nbest = 100;
 	P->ztot = 300; P->zovl = 200; P->max_kmer_freq = 0; P->max_zmer_freq = 64; P->max_kmer_var = 2;
 	P->xvar = 128; P->yvar = 64; P->min_block_len = 160; P->deviation_penalty = 1.0f; P->gap_penalty = 0.05f;
-	E->do_align = 1; E->n_idx = 1; E->n_job = 1; E->i_job = 0; E->max_batch = 512;
+	E->do_align = 1; E->n_idx = 1; E->n_job = 1; E->i_job = 0; E->max_batch = 2048;
 	static struct option lopts[] = { {"stats", required_argument, 0, 1000}, {"gpu", required_argument, 0, 1001}, {"pool-gb", required_argument, 0, 1002},
-		{"batch", required_argument, 0, 1003}, {"lib-check", no_argument, 0, 1004}, {0, 0, 0, 0} };
+		{"batch", required_argument, 0, 1003}, {"lib-check", no_argument, 0, 1004}, {"repeat", required_argument, 0, 1005}, {0, 0, 0, 0} };
 	while((c = getopt_long(argc, argv, "ht:P:p:Ni:b:J:I:o:9:S:fCH:k:G:z:Z:U:y:d:r:q:l:K:A:B:r:R:L:F:W:w:e:M:X:O:E:T:s:m:nv", lopts, NULL)) != -1){
 		switch(c){
 			case 1000: statsf = optarg; break;
@@ -391,6 +413,7 @@ int main(int argc, char **argv){
 			case 1002: pool_gb = (uint64_t)atoll(optarg); break;
 			case 1003: E->max_batch = (uint32_t)atoi(optarg); if(E->max_batch < 1) E->max_batch = 1; break;
 			case 1004: lib_check = 1; break;
+			case 1005: repeat = atoi(optarg); if(repeat < 1) repeat = 1; break;
 			case 'h': return usage();
 			case 't': break;
 			case 'P': E->n_job = (uint32_t)atoi(optarg); break;
@@ -537,93 +560,122 @@ int main(int argc, char **argv){
 	E->stride = P->ncand + 1;
 	E->row_of = (uint32_t*)hx_realloc(NULL, 4 * ((size_t)n_all + 1)); memset(E->row_of, 0xFF, 4 * ((size_t)n_all + 1));
 	E->pend.rd_id = 0xFFFFFFFFu;
-	const double t0 = now_s();
-	rc = wtz_zindex_build(E->ctx); DIE_WTZ(rc, "wtz_zindex_build");
-	/* ---- index parts (-G, wtzmo.c:1276-1303) ---- */
-	uint32_t pbbeg = 0, pbend = 0, K = P->max_kmer_freq;
-	wtz_index_stats_t ist;
-	uint32_t *ids = (uint32_t*)hx_realloc(NULL, 4 * ((size_t)n_all + 1));
-	if(E->n_idx > 1){ E->rows_all = 1; rows_reserve(E, n_all); memset(E->nrow, 0, (size_t)n_all * 4); for(uint32_t i = 0; i < n_all; i++) E->row_of[i] = i; }
-	double t_index = 0;
-	for(uint32_t i_idx = 0; i_idx < E->n_idx; i_idx++){
-		pbbeg = pbend; pbend = pbbeg + (n_rd + E->n_idx - 1) / E->n_idx;
-		const double ti = now_s();
-		rc = wtz_index_build(E->ctx, pbbeg, pbend > n_rd ? n_rd : pbend, &K, &ist); DIE_WTZ(rc, "wtz_index_build");
-		t_index += now_s() - ti;
-		fprintf(stderr, "[wtzmo-mi355x] index %u/%u: %llu k-mer occurrences, %llu distinct, %llu kept, cutoff %u\n", i_idx + 1, E->n_idx,
-			(unsigned long long)ist.n_occ, (unsigned long long)ist.n_distinct, (unsigned long long)ist.n_kept, K);
-		if(i_idx + 1 >= E->n_idx) break;
-		/* just_query pass: accumulate candidate heaps of every unmasked read of this job */
-		uint32_t n = 0;
-		for(uint32_t j = 0; j < n_rd; j++){ if((j % E->n_job) != E->i_job) continue; if(E->masked[j]) continue; ids[n++] = j; }
-		for(uint32_t a = 0; a < n; a += 4096){
-			uint32_t m = n - a < 4096 ? n - a : 4096;
-			uint64_t *tmp_rows = (uint64_t*)hx_realloc(NULL, (size_t)m * E->stride * 8); uint32_t *tmp_n = (uint32_t*)hx_realloc(NULL, (size_t)m * 4);
-			for(uint32_t k = 0; k < m; k++){ memcpy(tmp_rows + (size_t)k * E->stride, E->rows + (size_t)ids[a + k] * E->stride, (size_t)E->stride * 8); tmp_n[k] = E->nrow[ids[a + k]]; }
-			rc = wtz_candidates(E->ctx, ids + a, m, tmp_rows, tmp_n); DIE_WTZ(rc, "wtz_candidates");
-			for(uint32_t k = 0; k < m; k++){
-				/* closed filter + exact sort + trim are applied in these passes too (wtzmo.c:813-823) */
-				uint32_t nc = tmp_n[k]; cand_t *cd = (cand_t*)hx_realloc(NULL, sizeof(cand_t) * (nc + 1));
-				for(uint32_t x = 0; x < nc; x++){ cd[x].e = tmp_rows[(size_t)k * E->stride + x]; cd[x].pidx = 0; cd[x].pad = 0;
-					if(hx_set_has(&E->closed, hx_pair_key(ids[a + k], cd[x].e >> 32))) cd[x].e &= 0xFFFFFFFF00000000ULL; }
-				hx_sort_exact(cd, nc, sizeof(cand_t), gt_cand, NULL);
-				while(nc && (uint32_t)cd[nc - 1].e == 0) nc--;
-				for(uint32_t x = 0; x < nc; x++) E->rows[(size_t)ids[a + k] * E->stride + x] = cd[x].e;
-				E->nrow[ids[a + k]] = nc; free(cd);
-			}
-			free(tmp_rows); free(tmp_n);
+	/* --repeat: run the whole overlap phase several times on the reads already resident in HBM (benchmarking) */
+	uint8_t *masked0 = (uint8_t*)hx_realloc(NULL, (size_t)n_all + 1); memcpy(masked0, E->masked, (size_t)n_all + 1);
+	size_t nclosed0 = 0; uint64_t *closed0 = (uint64_t*)hx_realloc(NULL, 8 * (E->closed.n + 1));
+	for(size_t i = 0; i < E->closed.cap; i++) if(E->closed.tab[i] != ~0ULL) closed0[nclosed0++] = E->closed.tab[i];
+	if(statsf){ FILE *sf = fopen(statsf, "w"); if(sf) fclose(sf); }
+	for(int rep = 0; rep < repeat; rep++){
+		if(rep){
+			memcpy(E->masked, masked0, (size_t)n_all + 1); memset(E->rdcovs, 0, 4 * ((size_t)n_all + 1));
+			free(E->closed.tab); memset(&E->closed, 0, sizeof E->closed);
+			for(size_t i = 0; i < nclosed0; i++) hx_set_put(&E->closed, closed0[i]);
+			E->pair_bp = E->n_pairs = E->nrec = 0;
+			E->t_gpu = E->t_commit = 0; E->spec_pairs = E->used_pairs = E->spec_items = E->used_items = E->spec_queries = E->used_queries = 0;
+			memset(E->row_of, 0xFF, 4 * ((size_t)n_all + 1)); E->rows_all = 0;
+			E->pend.rd_id = 0xFFFFFFFFu; E->pend.nhit = E->pend.nmask = E->pend.nclosed = E->pend.nseed = 0;
+			if(strcmp(output, "-")){ E->out = fopen(output, "w"); if(E->out == NULL) exit(1); }
+			wtz_reset_counters(E->ctx);
 		}
-	}
-	/* ---- queries ---- */
-	uint32_t qbeg = E->st.n_qr ? n_rd : 0, qend = E->st.n_qr ? n_rd + E->st.n_qr : n_rd;
-	uint32_t cursor = qbeg, chunk_end = qbeg, B = 8;
-	E->bq = (uint32_t*)hx_realloc(NULL, 4 * ((size_t)E->max_batch + 1));
-	while(cursor < qend){
-		if(cursor >= chunk_end){
-			/* candidate rows for the next chunk of unmasked queries of this job */
-			uint32_t n = 0, j = cursor;
-			for(; j < qend && n < 4096; j++){ if((j % E->n_job) != E->i_job) continue; if(E->masked[j]) continue; if(E->rdcovs[j] >= nbest_of(E, j)) continue; ids[n++] = j; }
-			chunk_end = j;
-			if(E->rows_all){
-				for(uint32_t a = 0; a < n; a += 4096){
-					uint32_t m = n - a < 4096 ? n - a : 4096;
-					uint64_t *tmp_rows = (uint64_t*)hx_realloc(NULL, (size_t)m * E->stride * 8); uint32_t *tmp_n = (uint32_t*)hx_realloc(NULL, (size_t)m * 4);
-					for(uint32_t k = 0; k < m; k++){ memcpy(tmp_rows + (size_t)k * E->stride, E->rows + (size_t)ids[a + k] * E->stride, (size_t)E->stride * 8); tmp_n[k] = E->nrow[ids[a + k]]; }
-					rc = wtz_candidates(E->ctx, ids + a, m, tmp_rows, tmp_n); DIE_WTZ(rc, "wtz_candidates");
-					for(uint32_t k = 0; k < m; k++){ memcpy(E->rows + (size_t)ids[a + k] * E->stride, tmp_rows + (size_t)k * E->stride, (size_t)E->stride * 8); E->nrow[ids[a + k]] = tmp_n[k]; }
-					free(tmp_rows); free(tmp_n);
+		if(g_hook) g_hook(rep, 0);
+		const double t0 = now_s();
+		rc = wtz_zindex_build(E->ctx); DIE_WTZ(rc, "wtz_zindex_build");
+		/* ---- index parts (-G, wtzmo.c:1276-1303) ---- */
+		uint32_t pbbeg = 0, pbend = 0, K = P->max_kmer_freq;
+		wtz_index_stats_t ist;
+		uint32_t *ids = (uint32_t*)hx_realloc(NULL, 4 * ((size_t)n_all + 1));
+		if(E->n_idx > 1){ E->rows_all = 1; rows_reserve(E, n_all); memset(E->nrow, 0, (size_t)n_all * 4); for(uint32_t i = 0; i < n_all; i++) E->row_of[i] = i; }
+		double t_index = 0;
+		for(uint32_t i_idx = 0; i_idx < E->n_idx; i_idx++){
+			pbbeg = pbend; pbend = pbbeg + (n_rd + E->n_idx - 1) / E->n_idx;
+			const double ti = now_s();
+			rc = wtz_index_build(E->ctx, pbbeg, pbend > n_rd ? n_rd : pbend, &K, &ist); DIE_WTZ(rc, "wtz_index_build");
+			t_index += now_s() - ti;
+			fprintf(stderr, "[wtzmo-mi355x] index %u/%u: %llu k-mer occurrences, %llu distinct, %llu kept, cutoff %u\n", i_idx + 1, E->n_idx,
+				(unsigned long long)ist.n_occ, (unsigned long long)ist.n_distinct, (unsigned long long)ist.n_kept, K);
+			if(i_idx + 1 >= E->n_idx) break;
+			/* just_query pass: accumulate candidate heaps of every unmasked read of this job */
+			uint32_t n = 0;
+			for(uint32_t j = 0; j < n_rd; j++){ if((j % E->n_job) != E->i_job) continue; if(E->masked[j]) continue; ids[n++] = j; }
+			for(uint32_t a = 0; a < n; a += 4096){
+				uint32_t m = n - a < 4096 ? n - a : 4096;
+				uint64_t *tmp_rows = (uint64_t*)hx_realloc(NULL, (size_t)m * E->stride * 8); uint32_t *tmp_n = (uint32_t*)hx_realloc(NULL, (size_t)m * 4);
+				for(uint32_t k = 0; k < m; k++){ memcpy(tmp_rows + (size_t)k * E->stride, E->rows + (size_t)ids[a + k] * E->stride, (size_t)E->stride * 8); tmp_n[k] = E->nrow[ids[a + k]]; }
+				rc = wtz_candidates(E->ctx, ids + a, m, tmp_rows, tmp_n); DIE_WTZ(rc, "wtz_candidates");
+				for(uint32_t k = 0; k < m; k++){
+					/* closed filter + exact sort + trim are applied in these passes too (wtzmo.c:813-823) */
+					uint32_t nc = tmp_n[k]; cand_t *cd = (cand_t*)hx_realloc(NULL, sizeof(cand_t) * (nc + 1));
+					for(uint32_t x = 0; x < nc; x++){ cd[x].e = tmp_rows[(size_t)k * E->stride + x]; cd[x].pidx = 0; cd[x].pad = 0;
+						if(hx_set_has(&E->closed, hx_pair_key(ids[a + k], cd[x].e >> 32))) cd[x].e &= 0xFFFFFFFF00000000ULL; }
+					hx_sort_exact(cd, nc, sizeof(cand_t), gt_cand, NULL);
+					while(nc && (uint32_t)cd[nc - 1].e == 0) nc--;
+					for(uint32_t x = 0; x < nc; x++) E->rows[(size_t)ids[a + k] * E->stride + x] = cd[x].e;
+					E->nrow[ids[a + k]] = nc; free(cd);
 				}
-			} else candidates_chunk(E, ids, n);
+				free(tmp_rows); free(tmp_n);
+			}
 		}
-		/* next batch: up to B plannable queries before chunk_end */
-		E->nbq = 0;
-		uint32_t j = cursor;
-		for(; j < chunk_end && E->nbq < B; j++){
-			if((j % E->n_job) != E->i_job) continue;
-			if(E->masked[j]) continue;
-			/* reads whose coverage is already saturated (wtzmo.c:808) need no GPU work but stay in the dispatch
-			 * sequence: their dispatch is what merges the previous query's masks (one-query masking lag) */
-			E->bq[E->nbq++] = j;
+		/* ---- queries ---- */
+		uint32_t qbeg = E->st.n_qr ? n_rd : 0, qend = E->st.n_qr ? n_rd + E->st.n_qr : n_rd;
+		uint32_t cursor = qbeg, chunk_end = qbeg, B = E->max_batch < 64 ? E->max_batch : 64;
+		E->bq = (uint32_t*)hx_realloc(NULL, 4 * ((size_t)E->max_batch + 1));
+		while(cursor < qend){
+			if(cursor >= chunk_end){
+				/* candidate rows for the next chunk of unmasked queries of this job */
+				uint32_t n = 0, j = cursor;
+				for(; j < qend && n < 4096; j++){ if((j % E->n_job) != E->i_job) continue; if(E->masked[j]) continue; if(E->rdcovs[j] >= nbest_of(E, j)) continue; ids[n++] = j; }
+				chunk_end = j;
+				if(E->rows_all){
+					for(uint32_t a = 0; a < n; a += 4096){
+						uint32_t m = n - a < 4096 ? n - a : 4096;
+						uint64_t *tmp_rows = (uint64_t*)hx_realloc(NULL, (size_t)m * E->stride * 8); uint32_t *tmp_n = (uint32_t*)hx_realloc(NULL, (size_t)m * 4);
+						for(uint32_t k = 0; k < m; k++){ memcpy(tmp_rows + (size_t)k * E->stride, E->rows + (size_t)ids[a + k] * E->stride, (size_t)E->stride * 8); tmp_n[k] = E->nrow[ids[a + k]]; }
+						rc = wtz_candidates(E->ctx, ids + a, m, tmp_rows, tmp_n); DIE_WTZ(rc, "wtz_candidates");
+						for(uint32_t k = 0; k < m; k++){ memcpy(E->rows + (size_t)ids[a + k] * E->stride, tmp_rows + (size_t)k * E->stride, (size_t)E->stride * 8); E->nrow[ids[a + k]] = tmp_n[k]; }
+						free(tmp_rows); free(tmp_n);
+					}
+				} else candidates_chunk(E, ids, n);
+			}
+			/* next batch: up to B plannable queries before chunk_end */
+			E->nbq = 0;
+			uint32_t j = cursor;
+			for(; j < chunk_end && E->nbq < B; j++){
+				if((j % E->n_job) != E->i_job) continue;
+				if(E->masked[j]) continue;
+				/* reads whose coverage is already saturated (wtzmo.c:808) need no GPU work but stay in the dispatch
+				 * sequence: their dispatch is what merges the previous query's masks (one-query masking lag) */
+				E->bq[E->nbq++] = j;
+			}
+			cursor = j;
+			if(E->nbq == 0) continue;
+			const uint64_t sq0 = E->spec_queries, uq0 = E->used_queries;
+			if(run_batch(E)){
+				if(E->nbq <= 1){ fprintf(stderr, " -- device scratch pool too small even for one query: %s (use --pool-gb) --\n", wtz_last_error()); exit(1); }
+				fprintf(stderr, "[wtzmo-mi355x] scratch pool exhausted with %u queries in flight; retrying with %u\n", E->nbq, E->nbq / 2);
+				cursor = E->bq[0]; B = E->nbq / 2;
+				continue;
+			}
+			/* adapt: grow while most planned queries were really processed */
+			const uint64_t planned = E->spec_queries - sq0, used = E->used_queries - uq0;
+			if(used * 4 >= planned * 3){ if(B < E->max_batch) B = B * 4 > E->max_batch ? E->max_batch : B * 4; }
+			else if(used * 2 < planned){ if(B > 8) B /= 2; }
+			if(B > E->max_batch) B = E->max_batch;
 		}
-		cursor = j;
-		if(E->nbq == 0) continue;
-		const uint64_t sq0 = E->spec_queries, uq0 = E->used_queries;
-		run_batch(E);
-		/* adapt: grow while most planned queries were really processed */
-		const uint64_t planned = E->spec_queries - sq0, used = E->used_queries - uq0;
-		if(used * 4 >= planned * 3){ if(B < E->max_batch) B = B * 2 > E->max_batch ? E->max_batch : B * 2; }
-		else if(used * 2 < planned){ if(B > 8) B /= 2; }
-	}
-	flush_pending(E);
-	const double t1 = now_s();
-	if(strcmp(output, "-")) fclose(E->out); else fflush(stdout);
-	wtz_counters_t cn; wtz_get_counters(E->ctx, &cn);
-	fprintf(stderr, "[wtzmo-mi355x] %llu records, %llu pairs aligned, %llu pair-bp, %.3f s (index %.3f s)\n", (unsigned long long)E->nrec, (unsigned long long)E->n_pairs, (unsigned long long)E->pair_bp, t1 - t0, t_index);
+		flush_pending(E);
+		const double t1 = now_s();
+		if(strcmp(output, "-")) fclose(E->out); else fflush(stdout);
+		if(g_hook) g_hook(rep, 1);
+		wtz_counters_t cn; wtz_get_counters(E->ctx, &cn);
+		fprintf(stderr, "[wtzmo-mi355x] %llu records, %llu pairs aligned, %llu pair-bp, %.3f s (index %.3f s)\n", (unsigned long long)E->nrec, (unsigned long long)E->n_pairs, (unsigned long long)E->pair_bp, t1 - t0, t_index);
+		fprintf(stderr, "[wtzmo-mi355x] host seconds: in GPU-stage calls %.3f, commit %.3f\n", E->t_gpu, E->t_commit);
 	fprintf(stderr, "[wtzmo-mi355x] speculation: queries %llu/%llu pairs %llu/%llu alignments %llu/%llu (used/planned)\n",
-		(unsigned long long)E->used_queries, (unsigned long long)E->spec_queries, (unsigned long long)E->used_pairs, (unsigned long long)E->spec_pairs, (unsigned long long)E->used_items, (unsigned long long)E->spec_items);
-	fprintf(stderr, "[wtzmo-mi355x] kernel ms: index %.1f zindex %.1f candidates %.1f pairs %.1f winalign %.1f stitch %.1f; cells shift %llu\n",
-		cn.ms_index, cn.ms_zindex, cn.ms_candidates, cn.ms_pairs, cn.ms_winalign, cn.ms_stitch, (unsigned long long)cn.cells_shift);
-	if(statsf){ FILE *sf = fopen(statsf, "w"); if(sf){ fprintf(sf, "%llu\t%llu\t%.6f\t%.6f\n", (unsigned long long)E->n_pairs, (unsigned long long)E->pair_bp, t1 - t0, t_index); fclose(sf); } }
+			(unsigned long long)E->used_queries, (unsigned long long)E->spec_queries, (unsigned long long)E->used_pairs, (unsigned long long)E->spec_pairs, (unsigned long long)E->used_items, (unsigned long long)E->spec_items);
+		fprintf(stderr, "[wtzmo-mi355x] kernel ms: index %.1f zindex %.1f candidates %.1f pairs %.1f winalign %.1f stitch %.1f (K-sw3 wave %.1f); cells shift %llu; pool peak %.2f GB\n",
+			cn.ms_index, cn.ms_zindex, cn.ms_candidates, cn.ms_pairs, cn.ms_winalign, cn.ms_stitch, cn.ms_ext, (unsigned long long)cn.cells_shift, cn.pool_peak / 1073741824.0);
+		if(statsf){ FILE *sf = fopen(statsf, "a"); if(sf){ fprintf(sf, "%llu\t%llu\t%.6f\t%.6f\t%.3f\t%.3f\t%.3f\t%.3f\t%.3f\t%.3f\t%llu\t%llu\t%llu\t%llu\t%llu\t%.3f\t%llu\t%llu\t%llu\n", (unsigned long long)E->n_pairs, (unsigned long long)E->pair_bp, t1 - t0, t_index,
+				cn.ms_index, cn.ms_zindex, cn.ms_candidates, cn.ms_pairs, cn.ms_winalign, cn.ms_stitch, (unsigned long long)cn.cells_shift, (unsigned long long)cn.cells_fixed, (unsigned long long)cn.cells_global, (unsigned long long)cn.bytes_seed_algo, (unsigned long long)E->nrec,
+				cn.ms_ext, (unsigned long long)cn.n_extjobs, (unsigned long long)E->used_queries, (unsigned long long)cn.pool_peak); fclose(sf); } }
+	}
 	if(write_contained && strcmp(output, "-")){
 		char *maskf = (char*)hx_realloc(NULL, strlen(output) + 16); sprintf(maskf, "%s.contained", output);
 		FILE *mf = fopen(maskf, "w");

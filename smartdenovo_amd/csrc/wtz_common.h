@@ -108,6 +108,29 @@ WTZ_HD void *wtz_pool_alloc(wtz_pool_t *p, size_t bytes){
 	return p->base + o;
 }
 
+/* ---------------- wave-cooperative helpers ----------------
+ * Tasks launched with wtz_launch_coop run with all 64 lanes of one wavefront; the host emulation runs them with
+ * one lane.  Uniform values (pointers, counts) are produced by lane 0 and broadcast. */
+#if defined(__HIP_DEVICE_COMPILE__)
+#define WTZ_LANE ((uint32_t)(threadIdx.x & 63u))
+#define WTZ_NLANES 64u
+WTZ_D uint32_t wtz_coop_excl_scan(uint32_t v, uint32_t *total){
+	uint32_t x = v; const uint32_t lane = WTZ_LANE;
+	#pragma unroll
+	for(int d = 1; d < 64; d <<= 1){ uint32_t y = __shfl_up(x, d, 64); if(lane >= (uint32_t)d) x += y; }
+	*total = __shfl(x, 63, 64);
+	return x - v;
+}
+WTZ_D uint64_t wtz_coop_bcast64(uint64_t v){ return (uint64_t)__shfl((unsigned long long)v, 0, 64); }
+WTZ_D uint32_t wtz_coop_bcast32(uint32_t v){ return (uint32_t)__shfl((int)v, 0, 64); }
+#else
+#define WTZ_LANE 0u
+#define WTZ_NLANES 1u
+static inline uint32_t wtz_coop_excl_scan(uint32_t v, uint32_t *total){ *total = v; return 0; }
+static inline uint64_t wtz_coop_bcast64(uint64_t v){ return v; }
+static inline uint32_t wtz_coop_bcast32(uint32_t v){ return v; }
+#endif
+
 /* growable vector living in the pool (old storage is simply abandoned on growth) */
 template<typename T> struct wtz_vec {
 	T *a; uint32_t n, cap; wtz_pool_t *pool; int bad;

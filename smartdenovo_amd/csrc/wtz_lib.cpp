@@ -34,16 +34,45 @@ static int wtz_fail(int code, const char *fmt, ...){
 #define WTZ_LAMBDA __device__
 #define HIPCHK(call) do { hipError_t e_ = (call); if(e_ != hipSuccess) return wtz_fail(WTZ_E_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); } while(0)
 
-template<typename F> __global__ void __launch_bounds__(64) wtz_kernel_tasks(uint64_t n, F f){
+/* TAG only names the kernel (rocprofv3 shows wtz_kernel_tasks<K_pair_seed, ...>) */
+template<typename TAG, typename F> __global__ void __launch_bounds__(64) wtz_kernel_tasks(uint64_t n, F f){
 	uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if(i < n) f(i);
 }
-template<typename F> static int wtz_launch(hipStream_t st, uint64_t n, F f){
+template<typename TAG, typename F> static int wtz_launch(hipStream_t st, uint64_t n, F f){
 	if(n == 0) return WTZ_OK;
 	const uint32_t bs = 64;
 	uint64_t nb = (n + bs - 1) / bs;
 	if(nb > 0x7FFFFFFFull) return wtz_fail(WTZ_E_ARG, "grid too large");
-	hipLaunchKernelGGL(wtz_kernel_tasks<F>, dim3((uint32_t)nb), dim3(bs), 0, st, n, f);
+	hipLaunchKernelGGL((wtz_kernel_tasks<TAG, F>), dim3((uint32_t)nb), dim3(bs), 0, st, n, f);
+	HIPCHK(hipGetLastError());
+	return WTZ_OK;
+}
+/* Heavy, data-dependent tasks (whole pairs / windows / queries): one task per WAVEFRONT, executed by lane 0.  A flat
+ * thread-per-task grid serialises up to 64 divergent control flows inside every wave; these tasks are chains of
+ * dependent memory operations, so what hides their latency is the number of resident waves (up to 32 per CU, 8192 on
+ * the chip), not the lanes of one wave.  Stages whose inner loops are regular get wave-cooperative kernels instead
+ * (wtz_sw_wave.h). */
+template<typename TAG, typename F> __global__ void __launch_bounds__(64) wtz_kernel_wave_tasks(uint64_t n, F f){
+	const uint64_t i = blockIdx.x;
+	if(i < n && threadIdx.x == 0) f(i);
+}
+/* wave-cooperative tasks: every lane of the wavefront enters the task body (WTZ_LANE / wtz_coop_* inside) */
+template<typename TAG, typename F> __global__ void __launch_bounds__(64) wtz_kernel_coop_tasks(uint64_t n, F f){
+	const uint64_t i = blockIdx.x;
+	if(i < n) f(i);
+}
+template<typename TAG, typename F> static int wtz_launch_coop(hipStream_t st, uint64_t n, F f){
+	if(n == 0) return WTZ_OK;
+	if(n > 0x7FFFFFFFull) return wtz_fail(WTZ_E_ARG, "grid too large");
+	hipLaunchKernelGGL((wtz_kernel_coop_tasks<TAG, F>), dim3((uint32_t)n), dim3(64), WTZ_WAVE_LDS_BYTES, st, n, f);
+	HIPCHK(hipGetLastError());
+	return WTZ_OK;
+}
+template<typename TAG, typename F> static int wtz_launch_wave(hipStream_t st, uint64_t n, F f){
+	if(n == 0) return WTZ_OK;
+	if(n > 0x7FFFFFFFull) return wtz_fail(WTZ_E_ARG, "grid too large");
+	hipLaunchKernelGGL((wtz_kernel_wave_tasks<TAG, F>), dim3((uint32_t)n), dim3(64), WTZ_WAVE_LDS_BYTES, st, n, f);
 	HIPCHK(hipGetLastError());
 	return WTZ_OK;
 }
@@ -79,7 +108,9 @@ static int dev_sort_pairs_u64_u32(uint64_t *keys, uint32_t *vals, uint64_t n, un
 #else  /* ---------------- host emulation of the launch geometry (tests only) ---------------- */
 #define WTZ_LAMBDA
 typedef int hipStream_t;
-template<typename F> static int wtz_launch(hipStream_t, uint64_t n, F f){ for(uint64_t i = 0; i < n; i++) f(i); return WTZ_OK; }
+template<typename TAG, typename F> static int wtz_launch(hipStream_t, uint64_t n, F f){ for(uint64_t i = 0; i < n; i++) f(i); return WTZ_OK; }
+template<typename TAG, typename F> static int wtz_launch_wave(hipStream_t st, uint64_t n, F f){ return wtz_launch<TAG>(st, n, f); }
+template<typename TAG, typename F> static int wtz_launch_coop(hipStream_t st, uint64_t n, F f){ return wtz_launch<TAG>(st, n, f); }
 static int dev_alloc(void **p, size_t n){ *p = malloc(n ? n : 16); return *p ? WTZ_OK : wtz_fail(WTZ_E_HIP, "malloc(%zu) failed", n); }
 static void dev_free(void *p){ free(p); }
 static int dev_h2d(void *d, const void *h, size_t n){ if(n) memcpy(d, h, n); return WTZ_OK; }
@@ -97,6 +128,23 @@ static int dev_sort_pairs_u64_u32(uint64_t *keys, uint32_t *vals, uint64_t n, un
 	return WTZ_OK;
 }
 #endif
+
+struct K_candidates;
+struct K_extjob_scalar;
+struct K_gap;
+struct K_kcount;
+struct K_kfill;
+struct K_kinsert;
+struct K_kstats;
+struct K_pack_cigars;
+struct K_pack_windows;
+struct K_pair;
+struct K_stitch_fin;
+struct K_stitch_left;
+struct K_stitch_mid;
+struct K_winalign;
+struct K_zbuild;
+struct K_zcount;
 
 #define CHK(call) do { int rc_ = (call); if(rc_ != WTZ_OK) return rc_; } while(0)
 
@@ -161,6 +209,13 @@ extern "C" int wtz_ctx_create(int device, const wtz_params_c *params, uint64_t p
 	c->ktab = NULL; c->kseeds = NULL; c->kmask = 0; c->n_kocc = 0;
 	c->zoff = NULL; c->n_z = 0; memset(&c->Z, 0, sizeof c->Z); c->have_z = false;
 	c->dpool = NULL; c->pool_base = NULL; c->pool_bytes = pool_bytes ? pool_bytes : (4ull << 30);
+#ifndef WTZ_EMUL
+	if(!pool_bytes){      /* default: half of the free HBM, at most 24 GB - per-batch scratch and results of the speculative stages */
+		size_t fr = 0, tot = 0;
+		if(hipMemGetInfo(&fr, &tot) == hipSuccess && fr / 2 > c->pool_bytes) c->pool_bytes = (uint64_t)(fr / 2);
+		if(c->pool_bytes > (24ull << 30)) c->pool_bytes = 24ull << 30;      /* the host driver halves its batch on WTZ_E_POOL */
+	}
+#endif
 	c->d_qid = c->d_cid = NULL; c->d_pairres = NULL; c->n_pairs = 0; c->d_alnres = NULL; c->n_items = 0;
 	memset(&c->cnt, 0, sizeof c->cnt);
 	int rc;
@@ -214,32 +269,32 @@ extern "C" int wtz_index_build(wtz_ctx_t *c, uint32_t id_beg, uint32_t id_end, u
 	wtz_timer tm; tm.start();
 	const wtz_reads_t R = ctx_reads(c); const uint32_t ksize = c->P.ksize, hk = c->P.hk, ksave = c->P.ksave;
 	uint64_t *d_cnt = NULL; CHK(dev_alloc((void**)&d_cnt, ((size_t)nr + 1) * 8));
-	CHK(wtz_launch(0, nr, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_kcount((uint32_t)t, R, id_beg, ksize, hk, ksave, d_cnt); }));
+	CHK(wtz_launch<K_kcount>(0, nr, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_kcount((uint32_t)t, R, id_beg, ksize, hk, ksave, d_cnt); }));
 	std::vector<uint64_t> h_cnt((size_t)nr + 1);
 	CHK(dev_d2h(h_cnt.data(), d_cnt, (size_t)nr * 8));
 	uint64_t tot = 0; for(uint32_t i = 0; i < nr; i++){ uint64_t v = h_cnt[i]; h_cnt[i] = tot; tot += v; } h_cnt[nr] = tot;
 	CHK(dev_h2d(d_cnt, h_cnt.data(), ((size_t)nr + 1) * 8));
 	uint64_t *d_keys = NULL; uint32_t *d_vals = NULL;
 	CHK(dev_alloc((void**)&d_keys, (tot + 1) * 8)); CHK(dev_alloc((void**)&d_vals, (tot + 1) * 4));
-	CHK(wtz_launch(0, nr, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_kfill((uint32_t)t, R, id_beg, ksize, hk, ksave, d_cnt, d_keys, d_vals); }));
+	CHK(wtz_launch<K_kfill>(0, nr, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_kfill((uint32_t)t, R, id_beg, ksize, hk, ksave, d_cnt, d_keys, d_vals); }));
 	CHK(dev_sync());
 	dev_free(d_cnt);
 	CHK(dev_sort_pairs_u64_u32(d_keys, d_vals, tot, 2 * ksize));
 	unsigned long long *d_stat = NULL; CHK(dev_alloc((void**)&d_stat, 4 * 8)); CHK(dev_set(d_stat, 0, 4 * 8));
-	CHK(wtz_launch(0, tot, [=] WTZ_LAMBDA (uint64_t i){ wtz_task_kstats(i, d_keys, tot, d_stat + 0, d_stat + 1); }));
+	CHK(wtz_launch<K_kstats>(0, tot, [=] WTZ_LAMBDA (uint64_t i){ wtz_task_kstats(i, d_keys, tot, d_stat + 0, d_stat + 1); }));
 	unsigned long long h_stat[4]; CHK(dev_d2h(h_stat, d_stat, 4 * 8));
 	const uint64_t ktot = tot - h_stat[0], ktyp = h_stat[1];     /* d_stat[0] accumulates the saturation excess */
 	uint32_t K = *max_kmer_freq;
 	if(K < 2){ uint32_t kavg = (uint32_t)(ktot / (ktyp + 1)); if(kavg < 20) kavg = 20; K = kavg * 5; }       /* wtzmo.c:380-393 */
 	*max_kmer_freq = K;
-	CHK(wtz_launch(0, tot, [=] WTZ_LAMBDA (uint64_t i){ wtz_task_kinsert(i, d_keys, tot, K, (wtz_kslot_t*)NULL, 0, d_stat + 2); }));
+	CHK(wtz_launch<K_kinsert>(0, tot, [=] WTZ_LAMBDA (uint64_t i){ wtz_task_kinsert(i, d_keys, tot, K, (wtz_kslot_t*)NULL, 0, d_stat + 2); }));
 	CHK(dev_d2h(h_stat, d_stat, 4 * 8));
 	const uint64_t n_kept = h_stat[2];
 	uint64_t cap = 1024; while(cap < n_kept * 2 + 2) cap <<= 1;
 	CHK(dev_alloc((void**)&c->ktab, cap * sizeof(wtz_kslot_t))); CHK(dev_set(c->ktab, 0xFF, cap * sizeof(wtz_kslot_t)));
 	c->kmask = cap - 1;
 	wtz_kslot_t *tab = c->ktab; const uint64_t kmask = c->kmask;
-	CHK(wtz_launch(0, tot, [=] WTZ_LAMBDA (uint64_t i){ wtz_task_kinsert(i, d_keys, tot, K, tab, kmask, d_stat + 2); }));
+	CHK(wtz_launch<K_kinsert>(0, tot, [=] WTZ_LAMBDA (uint64_t i){ wtz_task_kinsert(i, d_keys, tot, K, tab, kmask, d_stat + 2); }));
 	CHK(dev_sync());
 	dev_free(d_keys); dev_free(d_stat);
 	c->kseeds = d_vals; c->n_kocc = tot;
@@ -262,7 +317,7 @@ extern "C" int wtz_zindex_build(wtz_ctx_t *c){
 	const wtz_reads_t R = ctx_reads(c); const uint32_t nr = c->n_reads, zsize = c->P.zsize, hz = c->P.hz, zcut = c->P.max_zmer_freq;
 	CHK(dev_alloc((void**)&c->zoff, ((size_t)nr + 1) * 8));
 	uint64_t *d_off = c->zoff;
-	CHK(wtz_launch(0, nr, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_zcount((uint32_t)t, R, zsize, hz, d_off); }));
+	CHK(wtz_launch<K_zcount>(0, nr, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_zcount((uint32_t)t, R, zsize, hz, d_off); }));
 	std::vector<uint64_t> h((size_t)nr + 1);
 	CHK(dev_d2h(h.data(), d_off, (size_t)nr * 8));
 	uint64_t tot = 0; for(uint32_t i = 0; i < nr; i++){ uint64_t v = h[i]; h[i] = tot; tot += v; } h[nr] = tot;
@@ -275,7 +330,7 @@ extern "C" int wtz_zindex_build(wtz_ctx_t *c){
 	CHK(dev_alloc((void**)&Z.dn, ((size_t)nr + 1) * 4));
 	c->Z = Z;
 	uint64_t *d_tmp = NULL; CHK(dev_alloc((void**)&d_tmp, (tot + 1) * 8));
-	CHK(wtz_launch(0, nr, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_zbuild((uint32_t)t, R, zsize, hz, zcut, Z, d_tmp); }));
+	CHK(wtz_launch_wave<K_zbuild>(0, nr, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_zbuild((uint32_t)t, R, zsize, hz, zcut, Z, d_tmp); }));
 	CHK(dev_sync());
 	dev_free(d_tmp);
 	c->have_z = true;
@@ -298,9 +353,11 @@ extern "C" int wtz_candidates(wtz_ctx_t *c, const uint32_t *qids, uint32_t nq, u
 	CHK(dev_alloc((void**)&d_cand, (size_t)nq * stride * 8)); CHK(dev_h2d(d_cand, cand, (size_t)nq * stride * 8));
 	const wtz_reads_t R = ctx_reads(c); const wtz_params_t *dP = c->dP; const wtz_kslot_t *tab = c->ktab; const uint64_t kmask = c->kmask;
 	const uint32_t *seeds = c->kseeds; wtz_pool_t *pool = c->dpool;
+	unsigned long long *d_bytes = NULL; CHK(dev_alloc((void**)&d_bytes, 8)); CHK(dev_set(d_bytes, 0, 8));
 	wtz_timer tm; tm.start();
-	CHK(wtz_launch(0, nq, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_candidates((uint32_t)t, R, d_q, dP, tab, kmask, seeds, pool, d_cand, d_n, stride); }));
+	CHK(wtz_launch_wave<K_candidates>(0, nq, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_candidates((uint32_t)t, R, d_q, dP, tab, kmask, seeds, pool, d_cand, d_n, stride, d_bytes); }));
 	CHK(dev_sync());
+	{ unsigned long long hb = 0; CHK(dev_d2h(&hb, d_bytes, 8)); c->cnt.bytes_seed_algo += hb; dev_free(d_bytes); }
 	c->cnt.ms_candidates += tm.stop(); c->cnt.n_candidates_q += nq;
 	CHK(dev_d2h(cand, d_cand, (size_t)nq * stride * 8)); CHK(dev_d2h(ncand_io, d_n, (size_t)nq * 4));
 	dev_free(d_q); dev_free(d_n); dev_free(d_cand);
@@ -328,7 +385,7 @@ extern "C" int wtz_pairs_seed(wtz_ctx_t *c, const uint32_t *qid, const uint32_t 
 	CHK(dev_alloc((void**)&c->d_pairres, (size_t)n * sizeof(wtz_pairres_t)));
 	const wtz_env_t V = ctx_env(c); const uint32_t *dq = c->d_qid, *dc = c->d_cid; wtz_pairres_t *dr = c->d_pairres;
 	wtz_timer tm; tm.start();
-	CHK(wtz_launch(0, n, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_pair((uint32_t)t, V, dq, dc, dr); }));
+	CHK(wtz_launch_coop<K_pair>(0, n, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_pair((uint32_t)t, V, dq, dc, dr); }));
 	CHK(dev_sync());
 	c->cnt.ms_pairs += tm.stop(); c->cnt.n_pairs += n;
 	c->n_pairs = n; c->h_pairres.resize(n);
@@ -358,7 +415,7 @@ extern "C" int wtz_pairs_windows(wtz_ctx_t *c, wtz_winbox_t *wins, uint64_t n_wi
 	CHK(dev_alloc((void**)&d_off, off.size() * 8)); CHK(dev_h2d(d_off, off.data(), off.size() * 8));
 	CHK(dev_alloc((void**)&d_w, (size_t)tot * sizeof(wtz_winbox_t)));
 	const wtz_pairres_t *dr = c->d_pairres;
-	CHK(wtz_launch(0, (uint64_t)c->n_pairs * 2, [=] WTZ_LAMBDA (uint64_t t){
+	CHK(wtz_launch<K_pack_windows>(0, (uint64_t)c->n_pairs * 2, [=] WTZ_LAMBDA (uint64_t t){
 		const wtz_pairres_t &r = dr[t >> 1]; const uint32_t d = (uint32_t)(t & 1);
 		for(uint32_t k = 0; k < r.nwin[d]; k++){ wtz_winbox_t b; b.beg[0] = r.win[d][k].beg[0]; b.beg[1] = r.win[d][k].beg[1]; b.end[0] = r.win[d][k].end[0]; b.end[1] = r.win[d][k].end[1]; d_w[d_off[t] + k] = b; }
 	}));
@@ -366,6 +423,51 @@ extern "C" int wtz_pairs_windows(wtz_ctx_t *c, wtz_winbox_t *wins, uint64_t n_wi
 	CHK(dev_d2h(wins, d_w, (size_t)tot * sizeof(wtz_winbox_t)));
 	dev_free(d_off); dev_free(d_w);
 	return WTZ_OK;
+}
+
+/* K-sw3 jobs of a batch: one wavefront per job (wtz_sw_wave.h).  WTZ_SW_SCALAR=1 forces the scalar body,
+ * WTZ_SW_CHECK=1 runs both and fails loudly on any difference (on-device cross-check). */
+static int run_extjobs(wtz_ctx *c, const wtz_env_t &V, wtz_extjob_t *d_jobs, uint32_t m){
+	if(m == 0) return WTZ_OK;
+#ifdef WTZ_EMUL
+	return wtz_launch_wave<K_extjob_scalar>(0, m, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_extjob_scalar((uint32_t)t, V, d_jobs); });
+#else
+	static int mode = -1;
+	if(mode < 0){ mode = 0; if(getenv("WTZ_SW_SCALAR") && atoi(getenv("WTZ_SW_SCALAR"))) mode = 1; if(getenv("WTZ_SW_CHECK") && atoi(getenv("WTZ_SW_CHECK"))) mode = 2; }
+	if(mode == 1) return wtz_launch_wave<K_extjob_scalar>(0, m, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_extjob_scalar((uint32_t)t, V, d_jobs); });
+	std::vector<wtz_extjob_t> ref;
+	if(mode == 2){
+		wtz_extjob_t *d_copy = NULL; CHK(dev_alloc((void**)&d_copy, (size_t)m * sizeof(wtz_extjob_t)));
+		HIPCHK(hipMemcpy(d_copy, d_jobs, (size_t)m * sizeof(wtz_extjob_t), hipMemcpyDeviceToDevice));
+		CHK(wtz_launch_wave<K_extjob_scalar>(0, m, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_extjob_scalar((uint32_t)t, V, d_copy); }));
+		CHK(dev_sync());
+		ref.resize(m); CHK(dev_d2h(ref.data(), d_copy, (size_t)m * sizeof(wtz_extjob_t)));
+		dev_free(d_copy);
+	}
+	{
+		wtz_timer te; te.start();
+		hipLaunchKernelGGL((wtz_kernel_extjobs<2048, 1032>), dim3(m), dim3(64), 0, 0, d_jobs, (const uint32_t*)NULL, m, V.P, V.pool);
+		HIPCHK(hipGetLastError());
+		c->cnt.ms_ext += te.stop(); c->cnt.n_extjobs += m;
+	}
+	if(mode == 2){
+		CHK(dev_sync());
+		std::vector<wtz_extjob_t> got(m); CHK(dev_d2h(got.data(), d_jobs, (size_t)m * sizeof(wtz_extjob_t)));
+		for(uint32_t i = 0; i < m; i++){
+			if(!got[i].valid) continue;
+			if(memcmp(&got[i].x, &ref[i].x, sizeof(wtz_aln_t)) || got[i].cigar_len != ref[i].cigar_len || got[i].cells != ref[i].cells)
+				return wtz_fail(WTZ_E_STATE, "K-sw3 wave kernel differs from the scalar body on job %u: qlen %d tlen %d init %d W %d; score %d/%d qe %d/%d te %d/%d aln %d/%d cigar %u/%u cells %llu/%llu",
+					i, got[i].qlen, got[i].tlen, got[i].init_score, got[i].W, got[i].x.score, ref[i].x.score, got[i].x.qe, ref[i].x.qe, got[i].x.te, ref[i].x.te,
+					got[i].x.aln, ref[i].x.aln, got[i].cigar_len, ref[i].cigar_len, (unsigned long long)got[i].cells, (unsigned long long)ref[i].cells);
+			if(got[i].cigar_len){
+				std::vector<uint32_t> a(got[i].cigar_len), b(got[i].cigar_len);
+				CHK(dev_d2h(a.data(), got[i].cigar, a.size() * 4)); CHK(dev_d2h(b.data(), ref[i].cigar, b.size() * 4));
+				if(a != b) return wtz_fail(WTZ_E_STATE, "K-sw3 wave kernel: CIGAR differs on job %u", i);
+			}
+		}
+	}
+	return WTZ_OK;
+#endif
 }
 
 extern "C" int wtz_pairs_align(wtz_ctx_t *c, const uint32_t *pair_idx, const uint8_t *dir, uint32_t m, wtz_aln_result_t *out){
@@ -392,12 +494,25 @@ extern "C" int wtz_pairs_align(wtz_ctx_t *c, const uint32_t *pair_idx, const uin
 	CHK(dev_alloc((void**)&c->d_alnres, (size_t)m * sizeof(wtz_alnres_dev_t)));
 	const wtz_env_t V = ctx_env(c); wtz_alnres_dev_t *d_res = c->d_alnres;
 	wtz_timer tm; tm.start();
-	CHK(wtz_launch(0, wt.size(), [=] WTZ_LAMBDA (uint64_t t){ wtz_task_winalign((uint32_t)t, V, d_wt, d_items); }));
+	CHK(wtz_launch_coop<K_winalign>(0, wt.size(), [=] WTZ_LAMBDA (uint64_t t){ wtz_task_winalign((uint32_t)t, V, d_wt, d_items); }));
 	CHK(dev_sync());
 	c->cnt.ms_winalign += tm.stop(); c->cnt.n_winalign += wt.size();
 	tm.start();
-	CHK(wtz_launch(0, m, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_stitch((uint32_t)t, V, d_items, d_res); }));
-	CHK(dev_sync());
+	{
+		wtz_stitch_state_t *d_st = NULL; wtz_extjob_t *d_jl = NULL, *d_jr = NULL;
+		CHK(dev_alloc((void**)&d_st, (size_t)m * sizeof(wtz_stitch_state_t)));
+		CHK(dev_alloc((void**)&d_jl, (size_t)m * sizeof(wtz_extjob_t))); CHK(dev_alloc((void**)&d_jr, (size_t)m * sizeof(wtz_extjob_t)));
+		wtz_gapres_t *d_gaps = NULL; CHK(dev_alloc((void**)&d_gaps, (size_t)(nreg + 1) * sizeof(wtz_gapres_t)));
+		const uint64_t nwt = wt.size();
+		CHK(wtz_launch_wave<K_stitch_left>(0, m, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_stitch_left((uint32_t)t, V, d_items, d_st, d_jl); }));
+		CHK(wtz_launch_wave<K_gap>(0, nwt, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_gap((uint32_t)t, V, d_wt, d_items, d_gaps); }));
+		CHK(run_extjobs(c, V, d_jl, m));
+		CHK(wtz_launch_wave<K_stitch_mid>(0, m, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_stitch_mid((uint32_t)t, V, d_items, d_st, d_jl, d_jr, d_gaps); }));
+		CHK(run_extjobs(c, V, d_jr, m));
+		CHK(wtz_launch_wave<K_stitch_fin>(0, m, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_stitch_fin((uint32_t)t, V, d_items, d_st, d_jl, d_jr, d_res); }));
+		CHK(dev_sync());
+		dev_free(d_st); dev_free(d_jl); dev_free(d_jr); dev_free(d_gaps);
+	}
 	c->cnt.ms_stitch += tm.stop(); c->cnt.n_stitch += m;
 	c->h_alnres.resize(m); c->n_items = m;
 	CHK(dev_d2h(c->h_alnres.data(), c->d_alnres, (size_t)m * sizeof(wtz_alnres_dev_t)));
@@ -428,7 +543,7 @@ extern "C" int wtz_fetch_cigars(wtz_ctx_t *c, uint32_t *dst, uint64_t n_ops){
 	CHK(dev_alloc((void**)&d_off, off.size() * 8)); CHK(dev_h2d(d_off, off.data(), off.size() * 8));
 	CHK(dev_alloc((void**)&d_c, (size_t)tot * 4));
 	const wtz_alnres_dev_t *dr = c->d_alnres;
-	CHK(wtz_launch(0, c->n_items, [=] WTZ_LAMBDA (uint64_t t){ const wtz_alnres_dev_t &r = dr[t]; for(uint32_t k = 0; k < r.cigar_len; k++) d_c[d_off[t] + k] = r.cigar[k]; }));
+	CHK(wtz_launch<K_pack_cigars>(0, c->n_items, [=] WTZ_LAMBDA (uint64_t t){ const wtz_alnres_dev_t &r = dr[t]; for(uint32_t k = 0; k < r.cigar_len; k++) d_c[d_off[t] + k] = r.cigar[k]; }));
 	CHK(dev_sync());
 	CHK(dev_d2h(dst, d_c, (size_t)tot * 4));
 	dev_free(d_off); dev_free(d_c);

@@ -219,8 +219,8 @@ WTZ_HD void wtz_task_zbuild(uint32_t r, wtz_reads_t R, uint32_t zsize, uint32_t 
 /* ================= K-seed ================= */
 typedef struct { uint32_t key, ol, lst; } wtz_gacc_t;        /* per (rd<<1|dir): running union length */
 
-struct wtz_scount_f { const wtz_kslot_t *tab; uint64_t mask; uint64_t tot;
-	WTZ_HDM void operator()(uint64_t mer, uint32_t, uint32_t, uint32_t){ uint64_t o; uint32_t c; if(wtz_kprobe(tab, mask, mer, &o, &c)) tot += c; } };
+struct wtz_scount_f { const wtz_kslot_t *tab; uint64_t mask; uint64_t tot; uint64_t nprobe;
+	WTZ_HDM void operator()(uint64_t mer, uint32_t, uint32_t, uint32_t){ uint64_t o; uint32_t c; nprobe++; if(wtz_kprobe(tab, mask, mer, &o, &c)) tot += c; } };
 
 struct wtz_sacc_f {
 	const wtz_kslot_t *tab; uint64_t mask; const uint32_t *seeds; const uint32_t *rdlen;
@@ -269,10 +269,19 @@ WTZ_HD void wtz_cand_tail(const uint64_t *groups, uint32_t ng, uint32_t kovl, ui
 
 /* task: candidates of query qids[t]; cand_out row stride = ncand + 1 */
 WTZ_HD void wtz_task_candidates(uint32_t t, wtz_reads_t R, const uint32_t *qids, const wtz_params_t *P,
-		const wtz_kslot_t *tab, uint64_t tmask, const uint32_t *seeds, wtz_pool_t *pool, uint64_t *cand_out, uint32_t *ncand_out, uint32_t stride){
+		const wtz_kslot_t *tab, uint64_t tmask, const uint32_t *seeds, wtz_pool_t *pool, uint64_t *cand_out, uint32_t *ncand_out, uint32_t stride,
+		unsigned long long *algo_bytes){
 	const uint32_t pbid = qids[t];
-	wtz_scount_f cf; cf.tab = tab; cf.mask = tmask; cf.tot = 0;
+	wtz_scount_f cf; cf.tab = tab; cf.mask = tmask; cf.tot = 0; cf.nprobe = 0;
 	wtz_kmer_walk(R, pbid, P->ksize, P->hk, P->ksave, cf);
+	{   /* algorithmic bytes of seed lookup: L/4 read + 16 B per probe + 4 B per seed entry */
+		unsigned long long b = (unsigned long long)R.rdlen[pbid] / 4 + 16ull * cf.nprobe + 4ull * cf.tot;
+#if defined(__HIP_DEVICE_COMPILE__)
+		atomicAdd(algo_bytes, b);
+#else
+		*algo_bytes += b;
+#endif
+	}
 	uint32_t cap = 16; while((uint64_t)cap < cf.tot * 2 + 2) cap <<= 1;
 	uint64_t *heap = cand_out + (size_t)t * stride;
 	wtz_gacc_t *map = (wtz_gacc_t*)wtz_pool_alloc(pool, (size_t)cap * sizeof(wtz_gacc_t));

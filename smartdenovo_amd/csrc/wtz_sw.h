@@ -38,6 +38,12 @@ WTZ_HD void wtz_cigar_reverse(uint32_t *a, uint32_t n){ for(uint32_t i = 0; i < 
 /* scratch for one DP: row arrays + trace matrix, (re)carved from the pool on demand */
 typedef struct { int32_t *rh, *re, *zb; uint8_t *z; uint32_t cap_row, cap_zb; uint64_t cap_z; wtz_pool_t *pool; int bad; } wtz_swmem_t;
 WTZ_HD void wtz_swmem_init(wtz_swmem_t &m, wtz_pool_t *pool){ m.rh = m.re = m.zb = NULL; m.z = NULL; m.cap_row = m.cap_zb = 0; m.cap_z = 0; m.pool = pool; m.bad = 0; }
+/* row arrays of the scalar DP bodies in the wave's LDS slice when they fit (flat addressing): the H/E rows are
+ * touched twice per cell by a single lane, so their latency, not bandwidth, bounds K-sw1 / K-sw2 */
+WTZ_HD void wtz_swmem_init_lds(wtz_swmem_t &m, wtz_pool_t *pool, int32_t *lds, uint32_t lds_ints){
+	wtz_swmem_init(m, pool);
+	if(lds && lds_ints >= 128){ m.rh = lds; m.re = lds + lds_ints / 2; m.cap_row = lds_ints / 2; }
+}
 WTZ_HD bool wtz_swmem_need(wtz_swmem_t &m, uint32_t row, uint32_t zb, uint64_t z){
 	if(row > m.cap_row){ uint32_t c = m.cap_row ? m.cap_row : 64; while(c < row) c <<= 1;
 		m.rh = (int32_t*)wtz_pool_alloc(m.pool, (size_t)c * 4); m.re = (int32_t*)wtz_pool_alloc(m.pool, (size_t)c * 4); m.cap_row = c;

@@ -1,0 +1,354 @@
+/*
+ * wtz_sw_wave.h — the extension DPs with one 64-lane wavefront per problem:
+ *     MODE 0  K-sw3  kswx_extend_align_shift_core  kswx.h:101-232   (band follows the row arg-max)
+ *     MODE 1  K-sw1  kswx_extend_align_core        kswx.h:234-335   (fixed band around the diagonal)
+ *
+ * Why row-wise and not anti-diagonal: in K-sw3 the band centre of row i+1 depends on the arg-max of row i
+ * (kswx.h:186-199), so rows are inherently sequential; inside a row, however, the reference's recurrence opens
+ * gaps from m (the diagonal value), not from H:
+ *        m_j = H(i-1,j-1) + S          E'_j = max(E_j + e, m_j + I + e)        F_{j+1} = max(F_j + e, m_j + D + e)
+ * so F along the row is a max-plus prefix scan of values that depend on the previous row only, exact in int32.
+ * A row is therefore: (1) every lane computes m for its C consecutive columns and a local scan aggregate,
+ * (2) one 6-step cross-lane max-scan over the 64 lane aggregates gives each lane its carry-in, (3) every lane
+ * finishes H / E' / F / trace bits for its columns, (4) a 6-step (value, column) reduction yields the row maximum
+ * and its arg-max (FIRST for K-sw3, LAST for K-sw1: kswx.h:172 vs 288-289), which moves the K-sw3 band.
+ *
+ * Data layout (per wave, LDS): Hs[P], Es[P] int32 rings indexed by absolute column & (P-1) (P >= band+2); lanes own
+ * column blocks of odd width C so the stride-C ds_read/ds_write are bank-conflict free; the target segment is staged
+ * once as 2-bit codes in logical order (strand / complement resolved) so that a lane fetches its <= 31 bases with two
+ * ds_read_b64.  Trace bytes go to HBM in a lane-transposed layout (row, kk/4, lane, kk%4): each of the ceil(C/4)
+ * stores per row writes 256 contiguous bytes; rows are carved from the pool 64 at a time (most extensions stop long
+ * before ql rows) and a task reuses its chunks across the many small K-sw1 problems of a window.
+ * Semantics reproduced exactly: -10000 sentinels outside the band, H(i,-1)/H(-1,j) boundary values, arg-max tie
+ * rules, gmax/max end rule with T, early exit when a row maximum is <= 0, the per-row band start of K-sw3.
+ */
+#ifndef WTZ_SW_WAVE_H
+#define WTZ_SW_WAVE_H
+
+#include "wtz_sw.h"
+
+typedef struct {
+	wtz_seq_packed q, t;        /* logical views: index 0 is the base next to the seed, walking outwards */
+	int32_t qlen, tlen, init_score, W;      /* W as passed to kswx_extend_align_shift_core (negative = exact band) */
+	uint32_t item;              /* owner (stitch item) */
+	uint32_t valid;             /* 0: nothing to do */
+	/* results */
+	wtz_aln_t x; uint32_t *cigar; uint32_t cigar_len; int32_t bad; unsigned long long cells;
+} wtz_extjob_t;
+
+#ifdef __HIPCC__
+
+#define WTZ_TRACE_MAXCHUNK 1024          /* 64-row chunks: up to 65536 rows per problem */
+
+/* reusable trace storage of one task (pointers live in the pool so that lane 0 can chase them during traceback) */
+typedef struct { uint8_t **chunk; int32_t *zb; uint32_t n_chunk, zrow, cap_rows; } wtz_trace_t;
+
+/* LDS view handed to the wave DP: rings of PM+1 ints (PM = size-1 mask), target buffer of tw 64-bit words */
+typedef struct { int32_t *Hs, *Es; uint64_t *tb; int32_t PM; int32_t tw; } wtz_wave_lds_t;
+
+WTZ_D int32_t wtz_wave_max_scan_excl(int32_t v, int32_t ident){
+	const int lane = (int)(threadIdx.x & 63);
+	int32_t x = v;
+	#pragma unroll
+	for(int d = 1; d < 64; d <<= 1){ int32_t y = __shfl_up(x, d, 64); if(lane >= d) x = x > y ? x : y; }
+	int32_t e = __shfl_up(x, 1, 64);
+	return lane == 0 ? ident : e;
+}
+
+WTZ_D bool wtz_wave_fits(const wtz_wave_lds_t &L, int32_t n_col, int32_t tl, int32_t ql){
+	return n_col + 2 <= L.PM + 1 && n_col <= 64 * 31 && (tl + 63) / 32 + 1 <= L.tw && (ql + 63) / 64 <= WTZ_TRACE_MAXCHUNK;
+}
+
+WTZ_D wtz_aln_t wtz_bcast_aln(wtz_aln_t x){
+	wtz_aln_t r;
+	r.score = __shfl(x.score, 0, 64); r.tb = __shfl(x.tb, 0, 64); r.te = __shfl(x.te, 0, 64); r.qb = __shfl(x.qb, 0, 64); r.qe = __shfl(x.qe, 0, 64);
+	r.aln = __shfl(x.aln, 0, 64); r.mat = __shfl(x.mat, 0, 64); r.mis = __shfl(x.mis, 0, 64); r.ins = __shfl(x.ins, 0, 64); r.del = __shfl(x.del, 0, 64);
+	return r;
+}
+
+/* make sure the trace has chunks for `zrow`-byte rows; lane 0 allocates, everybody learns the table address.
+ * returns false on pool exhaustion (uniform) */
+WTZ_D bool wtz_trace_prepare(wtz_trace_t &tr, wtz_pool_t *pool, uint32_t zrow, int32_t ql, bool need_zb){
+	const int lane = (int)(threadIdx.x & 63);
+	if(tr.chunk == NULL || tr.zrow != zrow){
+		unsigned long long a = 0;
+		if(lane == 0) a = (unsigned long long)(uintptr_t)wtz_pool_alloc(pool, (size_t)WTZ_TRACE_MAXCHUNK * 8);
+		a = __shfl(a, 0, 64);
+		tr.chunk = (uint8_t**)(uintptr_t)a; tr.n_chunk = 0; tr.zrow = zrow;
+		if(tr.chunk == NULL) return false;
+	}
+	if(need_zb && (tr.zb == NULL || tr.cap_rows < (uint32_t)ql + 2)){
+		unsigned long long a = 0;
+		if(lane == 0) a = (unsigned long long)(uintptr_t)wtz_pool_alloc(pool, (size_t)(ql + 2) * 4);
+		a = __shfl(a, 0, 64);
+		tr.zb = (int32_t*)(uintptr_t)a; tr.cap_rows = (uint32_t)ql + 2;
+		if(tr.zb == NULL) return false;
+	}
+	return true;
+}
+
+/*
+ * The DP.  All 64 lanes call it with identical arguments; the result x is identical on all lanes; the CIGAR is
+ * pushed into `cigars` on lane 0 only (cleared first).  *ok is false when the pool ran dry.
+ */
+template<int MODE, typename SQ, typename ST>
+WTZ_D wtz_aln_t wtz_extend_wave(int32_t qlen, const SQ &query, int32_t tlen, const ST &target, int32_t init_score, int32_t W,
+		int32_t M, int32_t X, int32_t I, int32_t D, int32_t E, int32_t T, const wtz_wave_lds_t &L, wtz_trace_t &tr, wtz_pool_t *pool,
+		wtz_cigar_t &cigars, unsigned long long *cells, bool *ok){
+	const int lane = (int)(threadIdx.x & 63);
+	const int32_t PM = L.PM;
+	wtz_aln_t x; memset(&x, 0, sizeof x);
+	*ok = true;
+	if(lane == 0) cigars.n = 0;
+	if(init_score < 0) init_score = 0;
+	if(qlen <= 0 || tlen <= 0){ x.score = init_score; return x; }
+	int32_t ql, tl, n_col;
+	wtz_ext_geometry(qlen, tlen, init_score, W, M, I, D, E, T, ql, tl, n_col);
+	const int32_t C0 = (n_col + 63) / 64, C = (C0 | 1);          /* odd block width: conflict-free LDS stride */
+	const int32_t C4 = (C + 3) / 4;                               /* trace dwords per lane per row */
+	const uint32_t zrow = (uint32_t)C4 * 256u;
+	if(!wtz_trace_prepare(tr, pool, zrow, ql, MODE == 0)){ *ok = false; return x; }
+	uint8_t **zchunk = tr.chunk; int32_t *zb = tr.zb;
+	uint8_t *z = NULL;
+	/* stage the target segment [0, tl) as 2-bit codes */
+	{
+		const int32_t nw = (tl + 31) / 32 + 1;
+		for(int32_t w = lane; w < nw; w += 64){
+			uint64_t v = 0; const int32_t b0 = w * 32;
+			for(int32_t k = 0; k < 32 && b0 + k < tl; k++) v |= ((uint64_t)target.at(b0 + k)) << (2 * k);
+			L.tb[w] = v;
+		}
+	}
+	int32_t mx = init_score, mi = -1, mj = -1, gmax = 0, gi = -1, gj = -1;
+	int32_t jbp = 0, jep = 0;                 /* band of the previous row: Hs/Es valid on [jbp, jep) */
+	int32_t c = 0, i;
+	unsigned long long ncell = 0;
+	const int32_t CE = C * E;
+	for(i = 0; i < ql; i++){
+		if((i & 63) == 0){
+			const uint32_t ci = (uint32_t)i >> 6;
+			unsigned long long za = 0;
+			if(ci < tr.n_chunk){ z = zchunk[ci]; }
+			else {
+				if(lane == 0){ uint8_t *p = (uint8_t*)wtz_pool_alloc(pool, (size_t)zrow * 64); zchunk[ci] = p; za = (unsigned long long)(uintptr_t)p; }
+				za = __shfl(za, 0, 64);
+				z = (uint8_t*)(uintptr_t)za;
+				if(z == NULL){ *ok = false; break; }
+				tr.n_chunk = ci + 1;
+			}
+		}
+		int32_t jb, je;
+		if(MODE == 0){
+			jb = 0; je = tl;
+			if(jb < c - W) jb = c - W;
+			if(je > c + W + 1) je = c + W + 1;
+			if(je > tl) je = tl;
+		} else {
+			jb = i - W; if(jb < 0) jb = 0;
+			je = i + W + 1; if(je > tl) je = tl;
+		}
+		const uint32_t qbase = query.at(i);
+		const int32_t j0 = jb + lane * C;                /* first column of this lane */
+		uint64_t tbits;                                   /* the lane's target bases: columns j0 .. j0+C-1 (<= 31) */
+		{
+			const int32_t jj = j0 < tl ? j0 : (tl > 0 ? tl - 1 : 0);
+			const int32_t w = jj >> 5, sh = (jj & 31) * 2;
+			const uint64_t w0 = L.tb[w], w1 = L.tb[w + 1];
+			tbits = sh ? ((w0 >> sh) | (w1 << (64 - sh))) : w0;
+		}
+		/* ---- pass 1: m_j into Hs[j], local F aggregate ---- */
+		int32_t agg = -0x3FFFFFFF;          /* max_k ( m_k + D + E + (C-1-k)*E ) */
+		{
+			int32_t saved = 0;
+			for(int32_t k = 0; k < C; k++){
+				const int32_t j = j0 + k;
+				if(j < je){
+					int32_t pred;
+					if(k == 0){
+						if(i == 0) pred = (j == 0) ? init_score : init_score + D + E * j;          /* rh[] initialisation, kswx.h:143-144 */
+						else if(j - 1 >= jbp && j - 1 < jep) pred = L.Hs[(j - 1) & PM];
+						else pred = (j == 0) ? init_score + I + E * i : -10000;
+					} else {
+						if(i == 0) pred = init_score + D + E * j;
+						else pred = saved;
+					}
+					saved = (i > 0 && j >= jbp && j < jep) ? L.Hs[j & PM] : -10000;       /* H(i-1, j) for the next column, before it is overwritten */
+					const uint32_t tbase = (uint32_t)(tbits >> (2 * k)) & 3u;
+					const int32_t m = pred + ((qbase == tbase) ? M : X);
+					L.Hs[j & PM] = m;
+					const int32_t cand = m + D + E + (C - 1 - k) * E;
+					agg = agg > cand ? agg : cand;
+				}
+			}
+		}
+		/* ---- cross-lane exclusive max-plus scan: carry-in F for the lane's first column ---- */
+		int32_t f_in;
+		{
+			const int32_t g = agg - lane * CE;
+			const int32_t pm = wtz_wave_max_scan_excl(g, -0x3FFFFFFF);
+			const int32_t from_prev = (lane == 0) ? -0x3FFFFFFF : pm + (lane - 1) * CE;
+			const int32_t from_init = -10000 + lane * CE;                     /* F at column jb is -10000 (kswx.h:157) */
+			f_in = from_prev > from_init ? from_prev : from_init;
+		}
+		/* ---- pass 2: H, E', F, trace ---- */
+		int32_t best = -0x7FFFFFFF, bestj = (MODE == 0) ? 0x7FFFFFFF : -1, h_last = 0;
+		{
+			int32_t f = f_in; uint32_t zword = 0;
+			uint32_t *zr = (uint32_t*)(z + (size_t)(i & 63) * zrow) + lane;
+			for(int32_t k = 0; k < C; k++){
+				const int32_t j = j0 + k;
+				if(j < je){
+					const int32_t m = L.Hs[j & PM];
+					int32_t e = (j >= jbp && j < jep) ? L.Es[j & PM] : -10000;
+					uint32_t d; int32_t h;
+					if(m >= e){ d = 0; h = m; } else { d = 1; h = e; }
+					if(h < f){ d = 2; h = f; }
+					if(MODE == 0){ if(h > best){ best = h; bestj = j; } }
+					else         { if(h >= best){ best = h; bestj = j; } }
+					h_last = h;
+					int32_t t = m + I + E; e = e + E; if(e > t) d |= 1u << 2; else e = t;
+					t = m + D + E; f = f + E; if(f > t) d |= 2u << 4; else f = t;
+					L.Hs[j & PM] = h; L.Es[j & PM] = e;
+					zword |= d << (8 * (k & 3));
+				}
+				if((k & 3) == 3 || k == C - 1){ zr[(size_t)(k >> 2) * 64] = zword; zword = 0; }
+			}
+		}
+		ncell += (unsigned long long)(je - jb);
+		/* ---- row maximum and its arg-max ---- */
+		#pragma unroll
+		for(int d = 32; d >= 1; d >>= 1){
+			const int32_t ob = __shfl_xor(best, d, 64), oj = __shfl_xor(bestj, d, 64);
+			if(MODE == 0){ if(ob > best || (ob == best && oj < bestj)){ best = ob; bestj = oj; } }
+			else         { if(ob > best || (ob == best && oj > bestj)){ best = ob; bestj = oj; } }
+		}
+		int32_t imax = 0, mj2 = -1;
+		if(MODE == 0){ if(best > 0){ imax = best; mj2 = bestj; } }            /* first j with the maximum, only if > 0 (kswx.h:172) */
+		else         { if(best >= 0){ imax = best; mj2 = bestj; } }           /* last j with h >= running max >= 0 (kswx.h:288-289) */
+		const int32_t lastlane = (je - 1 - jb) / C;
+		const int32_t h1 = __shfl(h_last, lastlane, 64);                      /* H(i, je-1) */
+		if(MODE == 0 && lane == 0) zb[i] = jb;
+		if(je == tlen && gmax < h1){ gmax = h1; gi = i; gj = je - 1; }
+		if(i + 1 == qlen && gmax < imax){ gmax = imax; gi = i; gj = mj2; }
+		jbp = jb; jep = je;
+		if(imax > mx){ mx = imax; mi = i; mj = mj2; }
+		else if(imax <= 0) break;
+		if(MODE == 0){ c++; if(c < mj2) c++; else if(c > mj2) c--; }
+	}
+	if(cells && lane == 0) *cells += ncell;
+	if(!*ok) return x;
+	if(gmax > 0 && gmax >= mx + T){ x.score = gmax; x.qe = gi; x.te = gj; }
+	else { x.score = mx; x.qe = mi; x.te = mj; }
+	/* ---- traceback by lane 0 (reads trace bytes stored by the other lanes of this wave) ---- */
+	__threadfence();
+	if(lane == 0){
+		int32_t i_ = x.qe, j_ = x.te; uint32_t d_ = 0;
+		while(i_ >= 0 && j_ >= 0){
+			const int32_t rowb = (MODE == 0) ? zb[i_] : (i_ > W ? i_ - W : 0);
+			const int32_t col = j_ - rowb;
+			const int32_t ln = col / C, kk = col - ln * C;
+			const uint8_t zv = zchunk[i_ >> 6][(size_t)(i_ & 63) * zrow + (size_t)(kk >> 2) * 256 + (size_t)ln * 4 + (kk & 3)];
+			d_ = (zv >> (d_ << 1)) & 0x03;
+			if(d_ == 0){ if(query.at(i_) == target.at(j_)) x.mat++; else x.mis++; i_--; j_--; }
+			else if(d_ == 1){ i_--; x.ins++; }
+			else { j_--; x.del++; }
+			wtz_cigar_push(cigars, d_, 1);
+		}
+		if(i_ >= 0){ x.ins += i_ + 1; wtz_cigar_push(cigars, 1, (uint32_t)(i_ + 1)); }
+		if(j_ >= 0){ x.del += j_ + 1; wtz_cigar_push(cigars, 2, (uint32_t)(j_ + 1)); }
+		wtz_cigar_reverse(cigars.a, cigars.n);
+		x.aln = x.mat + x.mis + x.ins + x.del; x.qe++; x.te++;
+	}
+	return wtz_bcast_aln(x);
+}
+
+/* ---- K-sw3 jobs: one wave (64 threads) per job; jobs that do not fit the LDS rings run the scalar body on lane 0 ---- */
+template<int P, int TW>
+__global__ void __launch_bounds__(64) wtz_kernel_extjobs(wtz_extjob_t *jobs, const uint32_t *order, uint32_t n, const wtz_params_t *Pm, wtz_pool_t *pool){
+	__shared__ int32_t sHs[P]; __shared__ int32_t sEs[P]; __shared__ uint64_t stb[TW];
+	const uint32_t b = blockIdx.x;
+	if(b >= n) return;
+	wtz_extjob_t *job = &jobs[order ? order[b] : b];
+	if(!job->valid) return;
+	const int lane = (int)(threadIdx.x & 63);
+	int32_t init_score = job->init_score < 0 ? 0 : job->init_score;
+	if(job->qlen <= 0 || job->tlen <= 0){
+		if(lane == 0){ wtz_aln_t x; memset(&x, 0, sizeof x); x.score = init_score; job->x = x; job->cigar = NULL; job->cigar_len = 0; job->bad = 0; job->cells = 0; }
+		return;
+	}
+	wtz_wave_lds_t L; L.Hs = sHs; L.Es = sEs; L.tb = stb; L.PM = P - 1; L.tw = TW;
+	int32_t W = job->W, ql, tl, n_col;
+	wtz_ext_geometry(job->qlen, job->tlen, init_score, W, Pm->M, Pm->O, Pm->O, Pm->E, Pm->T, ql, tl, n_col);
+	if(wtz_wave_fits(L, n_col, tl, ql)){
+		wtz_trace_t tr; tr.chunk = NULL; tr.zb = NULL; tr.n_chunk = 0; tr.zrow = 0; tr.cap_rows = 0;
+		wtz_cigar_t cg; if(lane == 0) cg.init(pool, 64);
+		unsigned long long cells = 0; bool ok = true;
+		wtz_aln_t x = wtz_extend_wave<0>(job->qlen, job->q, job->tlen, job->t, job->init_score, job->W, Pm->M, Pm->X, Pm->O, Pm->O, Pm->E, Pm->T, L, tr, pool, cg, &cells, &ok);
+		if(lane == 0){ job->x = x; job->cigar = cg.a; job->cigar_len = cg.n; job->bad = (!ok || cg.bad); job->cells = cells; }
+	} else if(lane == 0){
+		wtz_swmem_t mem; wtz_swmem_init(mem, pool);
+		wtz_cigar_t cg; cg.init(pool, 64);
+		unsigned long long cells = 0;
+		wtz_aln_t x = wtz_extend_shift(job->qlen, job->q, job->tlen, job->t, job->init_score, job->W, Pm->M, Pm->X, Pm->O, Pm->O, Pm->E, Pm->T, mem, cg, &cells);
+		job->x = x; job->cigar = cg.a; job->cigar_len = cg.n; job->bad = (mem.bad || cg.bad); job->cells = cells;
+	}
+}
+
+/* ---- A9 with the K-sw1 gaps run by the whole wave (hzm_aln.h:1247-1302).  Every lane follows the anchor loop with
+ *      the same x; CIGAR bookkeeping and the run-by-run z-mer alignment stay on lane 0.  lds: >= 8 KB. ---- */
+WTZ_D wtz_aln_t wtz_align_window_wave(const wtz_readview &pb1, const wtz_readview &pb2, const wtz_win_t &win, const wtz_zhit_t *anchors,
+		wtz_cigar_t &cigar, wtz_cigar_t &tmp, const wtz_params_t *P, wtz_pool_t *pool, int32_t *lds, unsigned long long *cells, bool *ok){
+	const int lane = (int)(threadIdx.x & 63);
+	const int32_t M = P->M, X = P->X, I = P->O, D = P->O, E = P->E, T = P->T;
+	wtz_wave_lds_t L; L.Hs = lds; L.Es = lds + 512; L.tb = (uint64_t*)(lds + 1024); L.PM = 511; L.tw = 128;      /* 2 KB + 2 KB + 1 KB */
+	wtz_trace_t tr; tr.chunk = NULL; tr.zb = NULL; tr.n_chunk = 0; tr.zrow = 0; tr.cap_rows = 0;
+	wtz_swmem_t mem; wtz_swmem_init(mem, pool);
+	wtz_aln_t x, y; memset(&x, 0, sizeof x);
+	*ok = true;
+	for(uint32_t i = win.anchors[0]; i < win.anchors[1]; i++){
+		const wtz_zhit_t p = anchors[i];
+		const int32_t off1 = (int32_t)ZH_OFF1(p), off2 = (int32_t)ZH_OFF2(p);
+		if(x.aln == 0){ x.tb = x.te = off1; x.qb = x.qe = off2; }
+		if(off1 < x.te) continue;
+		if(off2 < x.qe) continue;
+		const int32_t qlen = off2 - x.qe, tlen = off1 - x.te;
+		{
+			int32_t init = x.score < 0 ? 0 : x.score, W = P->w, ql, tl, n_col; bool okk = true;
+			bool fits = false;
+			if(qlen > 0 && tlen > 0){ wtz_ext_geometry(qlen, tlen, init, W, M, I, D, E, T, ql, tl, n_col); fits = wtz_wave_fits(L, n_col, tl, ql); }
+			if(qlen <= 0 || tlen <= 0 || fits){
+				y = wtz_extend_wave<1>(qlen, pb2.sub(x.qe, 1), tlen, pb1.sub(x.te, 1), x.score, P->w, M, X, I, D, E, T, L, tr, pool, tmp, cells, &okk);
+			} else {
+				if(lane == 0){ tmp.n = 0; y = wtz_extend_fixed(qlen, pb2.sub(x.qe, 1), tlen, pb1.sub(x.te, 1), x.score, P->w, M, X, I, D, E, T, mem, tmp); if(mem.bad) okk = false; }
+				y = wtz_bcast_aln(y);
+				okk = __shfl((int)okk, 0, 64) != 0;
+			}
+			if(!okk){ *ok = false; return x; }
+		}
+		int32_t stop = 0;
+		if(lane == 0){
+			x.score = y.score;
+			x.aln += y.aln; x.mat += y.mat; x.mis += y.mis; x.ins += y.ins; x.del += y.del;
+			x.te += y.te; x.qe += y.qe;
+			if(x.te < off1){ x.del += off1 - x.te; x.aln += off1 - x.te; wtz_cigar_push(tmp, 2, (uint32_t)(off1 - x.te)); x.te = off1; }
+			if(x.qe < off2){ x.ins += off2 - x.qe; x.aln += off2 - x.qe; wtz_cigar_push(tmp, 1, (uint32_t)(off2 - x.qe)); x.qe = off2; }
+			wtz_cigar_concat(cigar, tmp.a, tmp.n);
+			tmp.n = 0;
+			y = wtz_align_zmer(pb1.sub(off1, 1), ZH_LEN1(p), pb2.sub(off2, 1), ZH_LEN2(p), M, I, D, E, tmp);
+			if(y.aln == 0) stop = 1;
+			else {
+				x.score += y.score;
+				x.aln += y.aln; x.mat += y.mat; x.mis += y.mis; x.ins += y.ins; x.del += y.del;
+				x.te += y.te; x.qe += y.qe;
+				wtz_cigar_concat(cigar, tmp.a, tmp.n);
+			}
+		}
+		x = wtz_bcast_aln(x);
+		stop = __shfl(stop, 0, 64);
+		if(stop) return x;
+	}
+	return x;
+}
+
+#endif /* __HIPCC__ */
+#endif

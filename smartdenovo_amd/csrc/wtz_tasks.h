@@ -11,34 +11,43 @@
 #define WTZ_TASKS_H
 
 #include "wtz_sw.h"
+#include "wtz_sw_wave.h"
 #include "wtz_dotmatrix.h"
 
 typedef struct {
 	wtz_reads_t R; wtz_zindex_t Z; const wtz_params_t *P; wtz_pool_t *pool;
 } wtz_env_t;
 
+#define WTZ_WAVE_LDS_BYTES 8192
+/* the LDS slice of the wave running the current task (wave-task kernels carry WTZ_WAVE_LDS_BYTES of dynamic LDS) */
+#if defined(__HIP_DEVICE_COMPILE__)
+WTZ_D int32_t *wtz_wave_scratch(){ extern __shared__ int32_t wtz_dyn_lds[]; return wtz_dyn_lds; }
+#else
+static inline int32_t *wtz_wave_scratch(){ return NULL; }
+#endif
+
+/* all lanes of the wavefront enter; the z-mer matching is cooperative, the order-sensitive remainder runs on lane 0 */
 WTZ_HD void wtz_task_pair(uint32_t t, const wtz_env_t &V, const uint32_t *qid, const uint32_t *cid, wtz_pairres_t *res){
 	const wtz_params_t *P = V.P;
 	const uint32_t q = qid[t], c = cid[t];
 	wtz_pairres_t r; memset(&r, 0, sizeof r);
-	wtz_vec<wtz_zhit_t> cache; cache.init(V.pool, 0);
-	{   /* size the match list from the candidate's z-mer count to avoid regrowth in the common case */
-		uint32_t cn = (uint32_t)(V.Z.zoff[c + 1] - V.Z.zoff[c]);
-		cache.reserve(cn / 2 + 64);
-	}
-	if(!wtz_zmatch(V.Z, q, c, V.R.rdlen[c], P->max_kmer_var, cache)){ r.bad = 1; res[t] = r; return; }
-	r.n_hits = cache.n;
-	if(cache.n * P->zsize < P->ztot){ r.gate = 0; res[t] = r; return; }
+	wtz_zhit_t *hits = NULL; uint32_t n = 0;
+	const bool ok = wtz_zmatch_coop(V.Z, q, c, V.R.rdlen[c], P->max_kmer_var, V.pool, &hits, &n);
+#if defined(__HIP_DEVICE_COMPILE__)
+	__threadfence_block();
+#endif
+	if(WTZ_LANE != 0) return;
+	if(!ok){ r.bad = 1; res[t] = r; return; }
+	r.n_hits = n;
+	if(n * P->zsize < P->ztot){ r.gate = 0; res[t] = r; return; }
 	r.gate = 1;
+	wtz_vec<wtz_zhit_t> cache; cache.a = hits; cache.n = n; cache.cap = n + 2; cache.pool = V.pool; cache.bad = 0;
 	if(P->dot_matrix){
 		wtz_dm_result_t d = wtz_dot_matrix_align(cache, V.pool, (int32_t)V.R.rdlen[q], (int32_t)V.R.rdlen[c], P, &r.bad);
 		r.dm_score = d.score; r.dm_qb = d.qb; r.dm_qe = d.qe; r.dm_tb = d.tb; r.dm_te = d.te; r.dm_dir = d.dir;
 		res[t] = r; return;
 	}
-	if(!cache.reserve(cache.n + 1)){ r.bad = 1; res[t] = r; return; }
-	memset(&cache.a[cache.n], 0, sizeof(wtz_zhit_t));            /* the element the reference reads past the end */
 	wtz_sort_exact(cache.a, (size_t)cache.n, wtz_gt_off12());       /* process_hzmps, hzm_aln.h:1184-1186 */
-	const uint32_t n = cache.n;
 	wtz_winscratch_t sc;
 	sc.ts = (uint32_t*)wtz_pool_alloc(V.pool, (size_t)(n + 1) * 4 * 5);
 	if(sc.ts == NULL){ r.bad = 1; res[t] = r; return; }
@@ -69,7 +78,7 @@ typedef struct {                 /* one chain window to align */
 	uint32_t widx;               /* window index inside the pair's chain */
 } wtz_wintask_t;
 
-typedef struct { wtz_aln_t x; uint32_t *cigar; uint32_t cigar_len; uint32_t pass; } wtz_reg_t;   /* aln_reg_t + pass flag (wtzmo.c:1026) */
+typedef struct { wtz_aln_t x; uint32_t *cigar; uint32_t cigar_len; uint32_t pass; unsigned long long cells; } wtz_reg_t;   /* aln_reg_t + pass flag (wtzmo.c:1026) */
 
 typedef struct {                 /* one (pair,strand) to align */
 	uint32_t q, c, dir;
@@ -84,107 +93,181 @@ typedef struct {
 
 WTZ_HD wtz_readview wtz_view(const wtz_reads_t &R, uint32_t id, uint32_t rev){ wtz_readview v; v.bits = R.bits; v.off = R.rdoff[id]; v.len = R.rdlen[id]; v.rev = rev; return v; }
 
+/* launched wave-cooperatively: on the GPU the K-sw1 gaps between anchors are computed by the whole wavefront
+ * (wtz_align_window_wave), the host emulation runs the scalar body */
 WTZ_HD void wtz_task_winalign(uint32_t t, const wtz_env_t &V, const wtz_wintask_t *tasks, const wtz_alnitem_t *items){
 	const wtz_params_t *P = V.P;
 	const wtz_alnitem_t &it = items[tasks[t].item];
 	const wtz_win_t &w = it.win[tasks[t].widx];
 	wtz_reg_t reg; memset(&reg, 0, sizeof reg);
-	wtz_cigar_t cigar, tmp; cigar.init(V.pool, 64); tmp.init(V.pool, 64);
-	wtz_swmem_t mem; wtz_swmem_init(mem, V.pool);
+	wtz_cigar_t cigar, tmp;
+	cigar.init(V.pool, WTZ_LANE == 0 ? 64 : 0); tmp.init(V.pool, WTZ_LANE == 0 ? 64 : 0);
+	unsigned long long cells = 0;
+	int32_t bad = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+	bool ok = true;
+	reg.x = wtz_align_window_wave(wtz_view(V.R, it.q, 0), wtz_view(V.R, it.c, it.dir), w, it.anchors, cigar, tmp, P, V.pool, wtz_wave_scratch(), &cells, &ok);
+	if(!ok) bad = 1;
+	if(WTZ_LANE != 0) return;
+#else
+	wtz_swmem_t mem; wtz_swmem_init_lds(mem, V.pool, wtz_wave_scratch(), WTZ_WAVE_LDS_BYTES / 4);
 	reg.x = wtz_align_window(wtz_view(V.R, it.q, 0), wtz_view(V.R, it.c, it.dir), w, it.anchors, cigar, mem, tmp, P);
-	reg.cigar = cigar.a; reg.cigar_len = cigar.n;
+	if(mem.bad) bad = 1;
+#endif
+	reg.cigar = cigar.a; reg.cigar_len = cigar.n; reg.cells = cells;
 	reg.pass = !(reg.x.aln * 2 < (int32_t)P->zovl || (float)reg.x.mat < (float)reg.x.aln * P->min_id);
-	if(cigar.bad || tmp.bad || mem.bad) reg.pass = 2;        /* pool exhausted */
+	if(cigar.bad || tmp.bad || bad) reg.pass = 2;        /* pool exhausted */
 	it.regs[tasks[t].widx] = reg;
 }
 
-/* A10 for one item; hzm_aln.h:1345-1486 with esti_regs = {0, len1} (wtzmo.c:1030) */
-WTZ_HD void wtz_task_stitch(uint32_t t, const wtz_env_t &V, const wtz_alnitem_t *items, wtz_alnres_dev_t *out){
+/*
+ * A10 (hzm_aln.h:1345-1486 with esti_regs = {0, len1}, wtzmo.c:1030) as three per-item phases around the two
+ * K-sw3 extension jobs of an item, so that the extensions of a whole batch run as one wave-per-job launch:
+ *   left  : pick the passing windows, describe the left extension (needs only the first window's score)
+ *   mid   : fold the left result, fill the gaps between windows with K-sw2, describe the right extension
+ *           (its init score is the running total, hzm_aln.h:1456)
+ *   fin   : fold the right result, final kswx_t + CIGAR
+ * The band-doubling loops around both extensions start at w = ew and stop at "w >= ew" (hzm_aln.h:1361-1374,
+ * 1456-1468): exactly one call each.
+ */
+typedef struct { wtz_aln_t x; wtz_cigar_t cigar; uint32_t first, nreg; int32_t bad; unsigned long long cells_global; } wtz_stitch_state_t;
+
+/* K-sw2 between two consecutive passing windows (hzm_aln.h:1386-1447), one task per window slot so that all gaps of a
+ * batch run side by side; stored at the slot of the RIGHT window of the gap */
+typedef struct { int32_t score, aln, mat, mis, ins, del; uint32_t *cigar; uint32_t cigar_len; int32_t bad, valid; } wtz_gapres_t;
+
+WTZ_HD void wtz_task_gap(uint32_t t, const wtz_env_t &V, const wtz_wintask_t *tasks, const wtz_alnitem_t *items, wtz_gapres_t *gaps){
+	const wtz_params_t *P = V.P;
+	const wtz_alnitem_t &it = items[tasks[t].item];
+	const uint32_t k = tasks[t].widx;
+	wtz_gapres_t g; memset(&g, 0, sizeof g);
+	wtz_gapres_t *slot = gaps + (it.regs - items[0].regs) + k;        /* regs of all items are one contiguous array */
+	if(k == 0 || it.regs[k].pass != 1){ *slot = g; return; }
+	int32_t prev = -1;
+	for(int32_t j = (int32_t)k - 1; j >= 0; j--) if(it.regs[j].pass == 1){ prev = j; break; }
+	if(prev < 0){ *slot = g; return; }
+	const int32_t M = P->M, X = P->X, I = P->O, D = P->O, E = P->E;
+	const wtz_reg_t *reg1 = &it.regs[prev], *reg2 = &it.regs[k];
+	const wtz_readview pb1 = wtz_view(V.R, it.q, 0), pb2 = wtz_view(V.R, it.c, it.dir);
+	const int32_t dq = reg2->x.qb - reg1->x.qe, dt = reg2->x.tb - reg1->x.te;
+	const wtz_seq_packed q = pb2.sub(reg1->x.qe, 1), tt = pb1.sub(reg1->x.te, 1);
+	wtz_cigar_t tmp; tmp.init(V.pool, 32);
+	wtz_swmem_t mem; wtz_swmem_init_lds(mem, V.pool, wtz_wave_scratch(), WTZ_WAVE_LDS_BYTES / 4);
+	int32_t w = P->w, score;
+	for(;;){
+		if(w < WTZ_ABSDIFF(dq, dt)){ w <<= 1; continue; }
+		score = wtz_global_banded(dq, q, dt, tt, M, X, -I, -E, -D, -E, w, mem, tmp);
+		if(score < 0 && w < P->W && w < WTZ_MAX(dq, dt)) w <<= 1;
+		else break;
+	}
+	g.score = score; g.valid = 1;
+	int32_t x1 = 0, x2 = 0;
+	for(uint32_t idx = 0; idx < tmp.n; idx++){
+		int32_t op = (int32_t)(tmp.a[idx] & 0xF), len = (int32_t)(tmp.a[idx] >> 4);
+		g.aln += len;
+		if(op == 0){ for(int32_t j = 0; j < len; j++){ if(q.at(x1 + j) == tt.at(x2 + j)) g.mat++; else g.mis++; } x1 += len; x2 += len; }
+		else if(op == 1){ x1 += len; g.ins += len; }
+		else if(op == 2){ x2 += len; g.del += len; }
+	}
+	g.cigar = tmp.a; g.cigar_len = tmp.n; g.bad = (tmp.bad || mem.bad);
+	*slot = g;
+}
+
+WTZ_HD void wtz_task_stitch_left(uint32_t t, const wtz_env_t &V, const wtz_alnitem_t *items, wtz_stitch_state_t *sts, wtz_extjob_t *jobs){
 	const wtz_params_t *P = V.P;
 	const wtz_alnitem_t &it = items[t];
-	const int32_t M = P->M, X = P->X, I = P->O, D = P->O, E = P->E, T = P->T, ew = P->ew;
-	wtz_alnres_dev_t r; memset(&r, 0, sizeof r);
+	wtz_stitch_state_t st; memset(&st, 0, sizeof st);
+	wtz_extjob_t jb; memset(&jb, 0, sizeof jb); jb.item = t;
+	st.first = 0xFFFFFFFFu;
+	for(uint32_t k = 0; k < it.nwin; k++){ if(it.regs[k].pass == 2) st.bad = 1; if(it.regs[k].pass == 1){ if(st.first == 0xFFFFFFFFu) st.first = k; st.nreg++; } }
+	if(st.nreg && !st.bad){
+		st.cigar.init(V.pool, 256);
+		st.x = it.regs[st.first].x;
+		if(st.x.qb && st.x.tb){
+			const wtz_readview pb1 = wtz_view(V.R, it.q, 0), pb2 = wtz_view(V.R, it.c, it.dir);
+			jb.valid = 1; jb.qlen = st.x.qb; jb.tlen = st.x.tb; jb.q = pb2.sub(st.x.qb - 1, -1); jb.t = pb1.sub(st.x.tb - 1, -1);
+			jb.init_score = st.x.score + 100 * P->M; jb.W = -P->ew;
+		}
+	}
+	sts[t] = st; jobs[t] = jb;
+}
+
+WTZ_HD void wtz_task_stitch_mid(uint32_t t, const wtz_env_t &V, const wtz_alnitem_t *items, wtz_stitch_state_t *sts, const wtz_extjob_t *jobsL, wtz_extjob_t *jobsR, const wtz_gapres_t *gaps){
+	const wtz_params_t *P = V.P;
+	const wtz_alnitem_t &it = items[t];
+	const int32_t M = P->M;
+	wtz_stitch_state_t st = sts[t];
+	wtz_extjob_t jr; memset(&jr, 0, sizeof jr); jr.item = t;
+	if(st.nreg == 0 || st.bad){ jobsR[t] = jr; return; }
 	const wtz_readview pb1 = wtz_view(V.R, it.q, 0), pb2 = wtz_view(V.R, it.c, it.dir);
 	const int32_t len1 = (int32_t)pb1.len, len2 = (int32_t)pb2.len;
-	const int32_t esti0 = 0, esti1 = len1;
-	uint32_t first = 0xFFFFFFFFu, nreg = 0;
-	for(uint32_t k = 0; k < it.nwin; k++){ if(it.regs[k].pass == 2) r.bad = 1; if(it.regs[k].pass == 1){ if(first == 0xFFFFFFFFu) first = k; nreg++; } }
-	r.n_regs = nreg;
-	if(nreg == 0 || r.bad){ out[t] = r; return; }
-	wtz_cigar_t cigar, tmp; cigar.init(V.pool, 256); tmp.init(V.pool, 64);
-	wtz_swmem_t mem; wtz_swmem_init(mem, V.pool);
-	wtz_aln_t x = it.regs[first].x, y; memset(&y, 0, sizeof y);
-	const int32_t init_score = 100 * M;
-	int32_t w, max_gap, score;
-	if(x.qb && x.tb){
-		w = ew;
-		max_gap = ((WTZ_MIN(x.qb, x.tb) * M + x.score + init_score + (-T)) + (I < D ? D : I)) / (-E) + 1;
-		if(max_gap < w) max_gap = w;
-		for(;;){
-			tmp.n = 0;
-			y = wtz_extend_shift(x.qb, pb2.sub(x.qb - 1, -1), x.tb, pb1.sub(x.tb - 1, -1), x.score + init_score, -w, M, X, I, D, E, T, mem, tmp, &r.cells_shift);
-			if(y.qe == x.qb || y.te == x.tb) break;
-			if(x.tb - y.te <= esti0) break;
-			if(w >= ew || w >= max_gap) break;
-			w <<= 1;
-		}
-		x.score = y.score - init_score;
+	const wtz_gapres_t *gp = gaps + (it.regs - items[0].regs);
+	wtz_aln_t x = st.x;
+	if(jobsL[t].valid){
+		const wtz_extjob_t &jl = jobsL[t];
+		if(jl.bad) st.bad = 1;
+		const wtz_aln_t y = jl.x;
+		x.score = y.score - 100 * M;
 		x.aln += y.aln; x.mat += y.mat; x.mis += y.mis; x.ins += y.ins; x.del += y.del;
 		x.qb -= y.qe; x.tb -= y.te;
-		wtz_cigar_reverse(tmp.a, tmp.n);
-		wtz_cigar_concat(cigar, tmp.a, tmp.n);
+		if(jl.cigar_len){ wtz_cigar_reverse(jl.cigar, jl.cigar_len); wtz_cigar_concat(st.cigar, jl.cigar, jl.cigar_len); }
 	}
-	wtz_cigar_concat(cigar, it.regs[first].cigar, it.regs[first].cigar_len);
-	const wtz_reg_t *reg1 = &it.regs[first];
-	for(uint32_t k = first + 1; k < it.nwin; k++){
+	wtz_cigar_concat(st.cigar, it.regs[st.first].cigar, it.regs[st.first].cigar_len);
+	for(uint32_t k = st.first + 1; k < it.nwin; k++){
 		if(it.regs[k].pass != 1) continue;
 		const wtz_reg_t *reg2 = &it.regs[k];
-		const int32_t dq = reg2->x.qb - reg1->x.qe, dt = reg2->x.tb - reg1->x.te;
-		const wtz_seq_packed q = pb2.sub(reg1->x.qe, 1), tt = pb1.sub(reg1->x.te, 1);
-		w = P->w;
-		for(;;){
-			if(w < WTZ_ABSDIFF(dq, dt)){ w <<= 1; continue; }
-			score = wtz_global_banded(dq, q, dt, tt, M, X, -I, -E, -D, -E, w, mem, tmp);
-			if(score < 0 && w < P->W && w < WTZ_MAX(dq, dt)) w <<= 1;
-			else break;
-		}
-		x.score += score;
-		x.qe = reg2->x.qb; x.te = reg2->x.tb;
-		int32_t x1 = 0, x2 = 0;
-		for(uint32_t idx = 0; idx < tmp.n; idx++){
-			int32_t op = (int32_t)(tmp.a[idx] & 0xF), len = (int32_t)(tmp.a[idx] >> 4);
-			x.aln += len;
-			if(op == 0){ for(int32_t j = 0; j < len; j++){ if(q.at(x1 + j) == tt.at(x2 + j)) x.mat++; else x.mis++; } x1 += len; x2 += len; }
-			else if(op == 1){ x1 += len; x.ins += len; }
-			else if(op == 2){ x2 += len; x.del += len; }
-		}
-		wtz_cigar_concat(cigar, tmp.a, tmp.n);
+		const wtz_gapres_t &g = gp[k];
+		if(!g.valid || g.bad) st.bad = 1;
+		x.score += g.score;
+		x.aln += g.aln; x.mat += g.mat; x.mis += g.mis; x.ins += g.ins; x.del += g.del;
+		wtz_cigar_concat(st.cigar, g.cigar, g.cigar_len);
 		x.score += reg2->x.score;
 		x.aln += reg2->x.aln; x.mat += reg2->x.mat; x.mis += reg2->x.mis; x.ins += reg2->x.ins; x.del += reg2->x.del;
 		x.qe = reg2->x.qe; x.te = reg2->x.te;
-		wtz_cigar_concat(cigar, reg2->cigar, reg2->cigar_len);
-		reg1 = reg2;
+		wtz_cigar_concat(st.cigar, reg2->cigar, reg2->cigar_len);
 	}
+	if(st.cigar.bad) st.bad = 1;
 	if(x.te < len1 && x.qe < len2){
-		w = ew;
-		max_gap = ((WTZ_MIN(len2 - x.qe, len1 - x.te) * M + x.score + (-T)) + (I < D ? D : I)) / (-E) + 1;
-		if(max_gap < w) max_gap = w;
-		for(;;){
-			tmp.n = 0;
-			y = wtz_extend_shift(len2 - x.qe, pb2.sub(x.qe, 1), len1 - x.te, pb1.sub(x.te, 1), x.score, -w, M, X, I, D, E, T, mem, tmp, &r.cells_shift);
-			if(y.qe == len2 - x.qe || y.te == len1 - x.te) break;
-			if(x.te + y.te >= esti1) break;
-			if(w >= ew || w >= max_gap) break;
-			w <<= 1;
-		}
-		x.score = y.score;
-		x.aln += y.aln; x.mat += y.mat; x.mis += y.mis; x.ins += y.ins; x.del += y.del;
-		x.qe += y.qe; x.te += y.te;
-		wtz_cigar_concat(cigar, tmp.a, tmp.n);
+		jr.valid = 1; jr.qlen = len2 - x.qe; jr.tlen = len1 - x.te; jr.q = pb2.sub(x.qe, 1); jr.t = pb1.sub(x.te, 1);
+		jr.init_score = x.score; jr.W = -P->ew;
 	}
-	r.x = x; r.cigar = cigar.a; r.cigar_len = cigar.n;
-	if(cigar.bad || tmp.bad || mem.bad) r.bad = 1;
+	st.x = x; sts[t] = st; jobsR[t] = jr;
+}
+
+WTZ_HD void wtz_task_stitch_fin(uint32_t t, const wtz_env_t &V, const wtz_alnitem_t *items, wtz_stitch_state_t *sts, const wtz_extjob_t *jobsL, const wtz_extjob_t *jobsR, wtz_alnres_dev_t *out){
+	wtz_stitch_state_t st = sts[t];
+	wtz_alnres_dev_t r; memset(&r, 0, sizeof r);
+	r.n_regs = st.nreg; r.bad = st.bad;
+	for(uint32_t k = 0; k < items[t].nwin; k++) r.cells_fixed += items[t].regs[k].cells;
+	if(st.nreg && !st.bad){
+		wtz_aln_t x = st.x;
+		if(jobsR[t].valid){
+			const wtz_extjob_t &jr = jobsR[t];
+			if(jr.bad) r.bad = 1;
+			const wtz_aln_t y = jr.x;
+			x.score = y.score;
+			x.aln += y.aln; x.mat += y.mat; x.mis += y.mis; x.ins += y.ins; x.del += y.del;
+			x.qe += y.qe; x.te += y.te;
+			wtz_cigar_concat(st.cigar, jr.cigar, jr.cigar_len);
+			r.cells_shift += jr.cells;
+		}
+		if(jobsL[t].valid) r.cells_shift += jobsL[t].cells;
+		if(st.cigar.bad) r.bad = 1;
+		r.x = x; r.cigar = st.cigar.a; r.cigar_len = st.cigar.n;
+	}
 	out[t] = r;
+}
+
+/* scalar execution of one extension job: host emulation, over-size jobs, and the on-device cross-check */
+WTZ_HD void wtz_task_extjob_scalar(uint32_t t, const wtz_env_t &V, wtz_extjob_t *jobs){
+	const wtz_params_t *P = V.P;
+	wtz_extjob_t &jb = jobs[t];
+	if(!jb.valid) return;
+	wtz_swmem_t mem; wtz_swmem_init(mem, V.pool);
+	wtz_cigar_t cg; cg.init(V.pool, 64);
+	unsigned long long cells = 0;
+	jb.x = wtz_extend_shift(jb.qlen, jb.q, jb.tlen, jb.t, jb.init_score, jb.W, P->M, P->X, P->O, P->O, P->E, P->T, mem, cg, &cells);
+	jb.cigar = cg.a; jb.cigar_len = cg.n; jb.bad = (mem.bad || cg.bad); jb.cells = cells;
 }
 
 #endif

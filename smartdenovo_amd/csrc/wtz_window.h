@@ -46,6 +46,75 @@ WTZ_HD bool wtz_zmatch(const wtz_zindex_t &Z, uint32_t q, uint32_t c, uint32_t c
 	return true;
 }
 
+/* A6, wave-cooperative: lanes take consecutive candidate z-mers, the matches of a 64-z-mer chunk are written in
+ * candidate-position order through an exclusive scan of the per-lane match counts (emission order is part of the
+ * contract: hzm_aln.h:212-221).  Two passes: count (the dense index of each z-mer is cached), allocate exactly, fill.
+ * Returns the match list through *out / *n_out on every lane; false when the pool is exhausted. */
+WTZ_HD bool wtz_zmatch_coop(const wtz_zindex_t &Z, uint32_t q, uint32_t c, uint32_t clen, uint32_t max_var, wtz_pool_t *pool, wtz_zhit_t **out, uint32_t *n_out){
+	const uint64_t qo = Z.zoff[q], co = Z.zoff[c];
+	const uint32_t cn = (uint32_t)(Z.zoff[c + 1] - co), qd = Z.dn[q];
+	const uint32_t *dmer = Z.dmer + qo;
+	const uint32_t lane = WTZ_LANE;
+	uint64_t pa = 0;
+	if(lane == 0) pa = (uint64_t)(uintptr_t)wtz_pool_alloc(pool, (size_t)(cn + 1) * 8);
+	pa = wtz_coop_bcast64(pa);
+	uint32_t *found = (uint32_t*)(uintptr_t)pa;
+	if(found == NULL) return false;
+	uint32_t *kcnt = found + (cn + 1);
+	uint32_t total = 0;
+	for(uint32_t k0 = 0; k0 < cn; k0 += WTZ_NLANES){
+		const uint32_t k = k0 + lane;
+		uint32_t cnt = 0, idx = 0xFFFFFFFFu;
+		if(k < cn && Z.ok[co + k]){
+			const uint32_t m = Z.mer[co + k];
+			uint32_t lo = 0, hi = qd;
+			while(lo < hi){ uint32_t mid = (lo + hi) >> 1; if(dmer[mid] < m) lo = mid + 1; else hi = mid; }
+			if(lo < qd && dmer[lo] == m){
+				idx = lo;
+				const uint32_t clen2 = Z.len[co + k], first = Z.dfirst[qo + lo], n = Z.dcnt[qo + lo];
+				for(uint32_t e = 0; e < n; e++){
+					const uint32_t qlen = Z.len[qo + Z.sidx[qo + first + e]];
+					const uint32_t dv = qlen > clen2 ? qlen - clen2 : clen2 - qlen;
+					if(dv <= max_var) cnt++;
+				}
+			}
+		}
+		if(k < cn){ found[k] = idx; kcnt[k] = cnt; }
+		uint32_t chunk; (void)wtz_coop_excl_scan(cnt, &chunk);
+		total += chunk;
+	}
+	pa = 0;
+	if(lane == 0) pa = (uint64_t)(uintptr_t)wtz_pool_alloc(pool, (size_t)(total + 2) * sizeof(wtz_zhit_t));
+	pa = wtz_coop_bcast64(pa);
+	wtz_zhit_t *hits = (wtz_zhit_t*)(uintptr_t)pa;
+	if(hits == NULL) return false;
+	uint32_t base = 0;
+	for(uint32_t k0 = 0; k0 < cn; k0 += WTZ_NLANES){
+		const uint32_t k = k0 + lane;
+		const uint32_t cnt = k < cn ? kcnt[k] : 0;
+		uint32_t chunk; uint32_t o = base + wtz_coop_excl_scan(cnt, &chunk);
+		if(cnt){
+			const uint32_t lo = found[k];
+			const uint32_t cpos = Z.pos[co + k], clen2 = Z.len[co + k];
+			const uint32_t first = Z.dfirst[qo + lo], n = Z.dcnt[qo + lo];
+			for(uint32_t e = 0; e < n; e++){
+				const uint32_t qi = Z.sidx[qo + first + e];
+				const uint32_t qpos = Z.pos[qo + qi], qlen = Z.len[qo + qi];
+				const uint32_t dv = qlen > clen2 ? qlen - clen2 : clen2 - qlen;
+				if(dv > max_var) continue;
+				const uint32_t d1 = qpos & 1u, d2 = cpos & 1u;
+				const uint32_t off2 = (d1 ^ d2) ? clen - ((cpos >> 1) + clen2) : (cpos >> 1);
+				wtz_zhit_t h; h.o1 = (d1 << 31) | (qpos >> 1); h.o2 = (d2 << 31) | off2; h.ll = (clen2 << 16) | qlen; h.gid = 0;
+				hits[o++] = h;
+			}
+		}
+		base += chunk;
+	}
+	if(lane == 0){ wtz_zhit_t z0; z0.o1 = z0.o2 = z0.ll = z0.gid = 0; hits[total] = z0; hits[total + 1] = z0; }   /* the element the reference reads past the end */
+	*out = hits; *n_out = total;
+	return true;
+}
+
 struct wtz_gt_off12 { WTZ_HDM bool operator()(const wtz_zhit_t &a, const wtz_zhit_t &b) const {
 	uint64_t ka = ((uint64_t)ZH_OFF1(a) << 32) | ZH_OFF2(a), kb = ((uint64_t)ZH_OFF1(b) << 32) | ZH_OFF2(b); return ka > kb; } };
 struct wtz_gt_off1 { WTZ_HDM bool operator()(const wtz_zhit_t &a, const wtz_zhit_t &b) const { return ZH_OFF1(a) > ZH_OFF1(b); } };
