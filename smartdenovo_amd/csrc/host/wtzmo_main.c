@@ -70,7 +70,7 @@ typedef struct {
 	uint64_t pair_bp, n_pairs, nrec;
 	/* candidate rows */
 	uint64_t *rows; uint32_t *nrow; uint32_t *row_of; uint32_t stride; uint32_t rows_cap; int rows_all;
-	uint32_t max_batch;
+	uint32_t max_batch, first_batch;
 	/* batch */
 	uint32_t *bq; uint32_t nbq;
 	uint32_t *pq, *pc; uint32_t npair, cappair;
@@ -403,9 +403,9 @@ int main(int argc, char **argv){
 	P->kwin = 800; P->kovl = 300; P->ksave = 4; P->win_rep_norm = 20; P->win_rep_cutoff = 100; P->ncand = 500; P->nbest = 100;
 	P->ztot = 300; P->zovl = 200; P->max_kmer_freq = 0; P->max_zmer_freq = 64; P->max_kmer_var = 2;
 	P->xvar = 128; P->yvar = 64; P->min_block_len = 160; P->deviation_penalty = 1.0f; P->gap_penalty = 0.05f;
-	E->do_align = 1; E->n_idx = 1; E->n_job = 1; E->i_job = 0; E->max_batch = 2048;
+	E->do_align = 1; E->n_idx = 1; E->n_job = 1; E->i_job = 0; E->max_batch = 2048; E->first_batch = 256;
 	static struct option lopts[] = { {"stats", required_argument, 0, 1000}, {"gpu", required_argument, 0, 1001}, {"pool-gb", required_argument, 0, 1002},
-		{"batch", required_argument, 0, 1003}, {"lib-check", no_argument, 0, 1004}, {"repeat", required_argument, 0, 1005}, {0, 0, 0, 0} };
+		{"batch", required_argument, 0, 1003}, {"lib-check", no_argument, 0, 1004}, {"repeat", required_argument, 0, 1005}, {"first-batch", required_argument, 0, 1006}, {0, 0, 0, 0} };
 	while((c = getopt_long(argc, argv, "ht:P:p:Ni:b:J:I:o:9:S:fCH:k:G:z:Z:U:y:d:r:q:l:K:A:B:r:R:L:F:W:w:e:M:X:O:E:T:s:m:nv", lopts, NULL)) != -1){
 		switch(c){
 			case 1000: statsf = optarg; break;
@@ -414,6 +414,7 @@ int main(int argc, char **argv){
 			case 1003: E->max_batch = (uint32_t)atoi(optarg); if(E->max_batch < 1) E->max_batch = 1; break;
 			case 1004: lib_check = 1; break;
 			case 1005: repeat = atoi(optarg); if(repeat < 1) repeat = 1; break;
+			case 1006: E->first_batch = (uint32_t)atoi(optarg); if(E->first_batch < 1) E->first_batch = 1; break;
 			case 'h': return usage();
 			case 't': break;
 			case 'P': E->n_job = (uint32_t)atoi(optarg); break;
@@ -617,7 +618,7 @@ int main(int argc, char **argv){
 		}
 		/* ---- queries ---- */
 		uint32_t qbeg = E->st.n_qr ? n_rd : 0, qend = E->st.n_qr ? n_rd + E->st.n_qr : n_rd;
-		uint32_t cursor = qbeg, chunk_end = qbeg, B = E->max_batch < 64 ? E->max_batch : 64;
+		uint32_t cursor = qbeg, chunk_end = qbeg, B = E->max_batch < E->first_batch ? E->max_batch : E->first_batch;
 		E->bq = (uint32_t*)hx_realloc(NULL, 4 * ((size_t)E->max_batch + 1));
 		while(cursor < qend){
 			if(cursor >= chunk_end){

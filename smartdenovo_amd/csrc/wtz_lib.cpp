@@ -131,6 +131,7 @@ static int dev_sort_pairs_u64_u32(uint64_t *keys, uint32_t *vals, uint64_t n, un
 
 struct K_candidates;
 struct K_extjob_scalar;
+struct K_misc;
 struct K_gap;
 struct K_kcount;
 struct K_kfill;
@@ -444,11 +445,23 @@ static int run_extjobs(wtz_ctx *c, const wtz_env_t &V, wtz_extjob_t *d_jobs, uin
 		ref.resize(m); CHK(dev_d2h(ref.data(), d_copy, (size_t)m * sizeof(wtz_extjob_t)));
 		dev_free(d_copy);
 	}
+	/* longest-processing-time-first: the rows of an extension are sequential, so the longest job bounds the launch;
+	 * start the long ones first (key = query-side length, the row count upper bound) */
+	uint32_t *d_order = NULL;
+	{
+		int32_t *d_key = NULL; CHK(dev_alloc((void**)&d_key, (size_t)m * 4));
+		CHK(wtz_launch<K_misc>(0, m, [=] WTZ_LAMBDA (uint64_t t){ d_key[t] = d_jobs[t].valid ? d_jobs[t].qlen : -1; }));
+		std::vector<int32_t> key(m); CHK(dev_d2h(key.data(), d_key, (size_t)m * 4)); dev_free(d_key);
+		std::vector<uint32_t> ord(m); for(uint32_t i = 0; i < m; i++) ord[i] = i;
+		std::stable_sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t b){ return key[a] > key[b]; });
+		CHK(dev_alloc((void**)&d_order, (size_t)m * 4)); CHK(dev_h2d(d_order, ord.data(), (size_t)m * 4));
+	}
 	{
 		wtz_timer te; te.start();
-		hipLaunchKernelGGL((wtz_kernel_extjobs<2048, 1032>), dim3(m), dim3(64), 0, 0, d_jobs, (const uint32_t*)NULL, m, V.P, V.pool);
+		hipLaunchKernelGGL((wtz_kernel_extjobs<2048, 1032>), dim3(m), dim3(64), 0, 0, d_jobs, (const uint32_t*)d_order, m, V.P, V.pool);
 		HIPCHK(hipGetLastError());
 		c->cnt.ms_ext += te.stop(); c->cnt.n_extjobs += m;
+		dev_free(d_order);
 	}
 	if(mode == 2){
 		CHK(dev_sync());
@@ -505,7 +518,7 @@ extern "C" int wtz_pairs_align(wtz_ctx_t *c, const uint32_t *pair_idx, const uin
 		wtz_gapres_t *d_gaps = NULL; CHK(dev_alloc((void**)&d_gaps, (size_t)(nreg + 1) * sizeof(wtz_gapres_t)));
 		const uint64_t nwt = wt.size();
 		CHK(wtz_launch_wave<K_stitch_left>(0, m, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_stitch_left((uint32_t)t, V, d_items, d_st, d_jl); }));
-		CHK(wtz_launch_wave<K_gap>(0, nwt, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_gap((uint32_t)t, V, d_wt, d_items, d_gaps); }));
+		CHK(wtz_launch_coop<K_gap>(0, nwt, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_gap((uint32_t)t, V, d_wt, d_items, d_gaps); }));
 		CHK(run_extjobs(c, V, d_jl, m));
 		CHK(wtz_launch_wave<K_stitch_mid>(0, m, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_stitch_mid((uint32_t)t, V, d_items, d_st, d_jl, d_jr, d_gaps); }));
 		CHK(run_extjobs(c, V, d_jr, m));

@@ -46,13 +46,31 @@ typedef struct { uint8_t **chunk; int32_t *zb; uint32_t n_chunk, zrow, cap_rows;
 /* LDS view handed to the wave DP: rings of PM+1 ints (PM = size-1 mask), target buffer of tw 64-bit words */
 typedef struct { int32_t *Hs, *Es; uint64_t *tb; int32_t PM; int32_t tw; } wtz_wave_lds_t;
 
+/* ---- wavefront-wide max scan / arg-max reduction on the DPP data path (no LDS round trip) ----
+ * gfx9-family DPP controls: row_shr:n = 0x110+n (inside a row of 16 lanes), row_bcast:15 = 0x142 (lane 15 of each row to
+ * the next row), row_bcast:31 = 0x143 (lane 31 to rows 2-3), wave_shr:1 = 0x138.  Lanes without a source keep `old`. */
+template<int CTRL, int ROWMASK>
+WTZ_D int32_t wtz_dpp_mov(int32_t old, int32_t src){ return __builtin_amdgcn_update_dpp(old, src, CTRL, ROWMASK, 0xF, false); }
+
 WTZ_D int32_t wtz_wave_max_scan_excl(int32_t v, int32_t ident){
-	const int lane = (int)(threadIdx.x & 63);
-	int32_t x = v;
-	#pragma unroll
-	for(int d = 1; d < 64; d <<= 1){ int32_t y = __shfl_up(x, d, 64); if(lane >= d) x = x > y ? x : y; }
-	int32_t e = __shfl_up(x, 1, 64);
-	return lane == 0 ? ident : e;
+	int32_t x = v, t;
+	t = wtz_dpp_mov<0x111, 0xF>(ident, x); x = x > t ? x : t;
+	t = wtz_dpp_mov<0x112, 0xF>(ident, x); x = x > t ? x : t;
+	t = wtz_dpp_mov<0x114, 0xF>(ident, x); x = x > t ? x : t;
+	t = wtz_dpp_mov<0x118, 0xF>(ident, x); x = x > t ? x : t;
+	t = wtz_dpp_mov<0x142, 0xA>(ident, x); x = x > t ? x : t;
+	t = wtz_dpp_mov<0x143, 0xC>(ident, x); x = x > t ? x : t;
+	return wtz_dpp_mov<0x138, 0xF>(ident, x);              /* inclusive -> exclusive: shift the whole wave by one lane */
+}
+
+/* all-lanes maximum of a signed 64-bit key (hi:int32 value, lo:uint32 tie-break), result in every lane */
+WTZ_D void wtz_wave_max_key(int32_t &hi, uint32_t &lo){
+	const int32_t ih = (int32_t)0x80000000; const int32_t il = 0;
+#define WTZ_KEYSTEP(CTRL, RM) { const int32_t th = wtz_dpp_mov<CTRL, RM>(ih, hi); const uint32_t tl = (uint32_t)wtz_dpp_mov<CTRL, RM>(il, (int32_t)lo); \
+	if(th > hi || (th == hi && tl > lo)){ hi = th; lo = tl; } }
+	WTZ_KEYSTEP(0x111, 0xF) WTZ_KEYSTEP(0x112, 0xF) WTZ_KEYSTEP(0x114, 0xF) WTZ_KEYSTEP(0x118, 0xF) WTZ_KEYSTEP(0x142, 0xA) WTZ_KEYSTEP(0x143, 0xC)
+#undef WTZ_KEYSTEP
+	hi = __builtin_amdgcn_readlane(hi, 63); lo = (uint32_t)__builtin_amdgcn_readlane((int32_t)lo, 63);
 }
 
 WTZ_D bool wtz_wave_fits(const wtz_wave_lds_t &L, int32_t n_col, int32_t tl, int32_t ql){
@@ -216,17 +234,13 @@ WTZ_D wtz_aln_t wtz_extend_wave(int32_t qlen, const SQ &query, int32_t tlen, con
 		}
 		ncell += (unsigned long long)(je - jb);
 		/* ---- row maximum and its arg-max ---- */
-		#pragma unroll
-		for(int d = 32; d >= 1; d >>= 1){
-			const int32_t ob = __shfl_xor(best, d, 64), oj = __shfl_xor(bestj, d, 64);
-			if(MODE == 0){ if(ob > best || (ob == best && oj < bestj)){ best = ob; bestj = oj; } }
-			else         { if(ob > best || (ob == best && oj > bestj)){ best = ob; bestj = oj; } }
-		}
+		if(MODE == 0){ uint32_t lo = 0x7FFFFFFFu - (uint32_t)bestj; wtz_wave_max_key(best, lo); bestj = (int32_t)(0x7FFFFFFFu - lo); }   /* smallest column */
+		else         { uint32_t lo = (uint32_t)(bestj + 1); wtz_wave_max_key(best, lo); bestj = (int32_t)lo - 1; }                          /* largest column */
 		int32_t imax = 0, mj2 = -1;
 		if(MODE == 0){ if(best > 0){ imax = best; mj2 = bestj; } }            /* first j with the maximum, only if > 0 (kswx.h:172) */
 		else         { if(best >= 0){ imax = best; mj2 = bestj; } }           /* last j with h >= running max >= 0 (kswx.h:288-289) */
 		const int32_t lastlane = (je - 1 - jb) / C;
-		const int32_t h1 = __shfl(h_last, lastlane, 64);                      /* H(i, je-1) */
+		const int32_t h1 = __builtin_amdgcn_readlane(h_last, __builtin_amdgcn_readfirstlane(lastlane));                      /* H(i, je-1) */
 		if(MODE == 0 && lane == 0) zb[i] = jb;
 		if(je == tlen && gmax < h1){ gmax = h1; gi = i; gj = je - 1; }
 		if(i + 1 == qlen && gmax < imax){ gmax = imax; gi = i; gj = mj2; }
@@ -262,6 +276,187 @@ WTZ_D wtz_aln_t wtz_extend_wave(int32_t qlen, const SQ &query, int32_t tlen, con
 	return wtz_bcast_aln(x);
 }
 
+/*
+ * K-sw3, register-tiled rows.  Same algorithm and results as wtz_extend_wave<0>, but a lane keeps its block of the
+ * previous row (H and E of <= CMAX columns) in VGPRs: per row it issues all its LDS reads back to back (one
+ * latency), computes m / F-scan / H / E' / trace entirely in registers, and issues all LDS writes back to back.
+ * The LDS rings are only the hand-over medium between rows (the band moves, so column ownership changes).
+ * This cuts the row latency - which is what bounds the longest extension of a batch - by the C dependent
+ * ds_read -> ds_write round trips of the loop form.
+ */
+template<int CMAX, typename SQ, typename ST>
+WTZ_D wtz_aln_t wtz_extend_shift_wave_rt(int32_t qlen, const SQ &query, int32_t tlen, const ST &target, int32_t init_score, int32_t W,
+		int32_t M, int32_t X, int32_t I, int32_t D, int32_t E, int32_t T, const wtz_wave_lds_t &L, wtz_trace_t &tr, wtz_pool_t *pool,
+		wtz_cigar_t &cigars, unsigned long long *cells, bool *ok){
+	const int lane = (int)(threadIdx.x & 63);
+	const int32_t PM = L.PM;
+	wtz_aln_t x; memset(&x, 0, sizeof x);
+	*ok = true;
+	if(lane == 0) cigars.n = 0;
+	if(init_score < 0) init_score = 0;
+	if(qlen <= 0 || tlen <= 0){ x.score = init_score; return x; }
+	int32_t ql, tl, n_col;
+	wtz_ext_geometry(qlen, tlen, init_score, W, M, I, D, E, T, ql, tl, n_col);
+	const int32_t C0 = (n_col + 63) / 64, C = (C0 | 1);
+	const int32_t C4 = (C + 3) / 4;
+	const uint32_t zrow = (uint32_t)C4 * 256u;
+	if(!wtz_trace_prepare(tr, pool, zrow, ql, true)){ *ok = false; return x; }
+	uint8_t **zchunk = tr.chunk; int32_t *zb = tr.zb;
+	uint8_t *z = NULL;
+	{
+		const int32_t nw = (tl + 31) / 32 + 1;
+		for(int32_t w = lane; w < nw; w += 64){
+			uint64_t v = 0; const int32_t b0 = w * 32;
+			for(int32_t k = 0; k < 32 && b0 + k < tl; k++) v |= ((uint64_t)target.at(b0 + k)) << (2 * k);
+			L.tb[w] = v;
+		}
+	}
+	int32_t mx = init_score, mi = -1, mj = -1, gmax = 0, gi = -1, gj = -1;
+	int32_t jbp = 0, jep = 0, c = 0, i;
+	unsigned long long ncell = 0;
+	const int32_t CE = C * E;
+	for(i = 0; i < ql; i++){
+		if((i & 63) == 0){
+			const uint32_t ci = (uint32_t)i >> 6;
+			unsigned long long za = 0;
+			if(ci < tr.n_chunk){ z = zchunk[ci]; }
+			else {
+				if(lane == 0){ uint8_t *p = (uint8_t*)wtz_pool_alloc(pool, (size_t)zrow * 64); zchunk[ci] = p; za = (unsigned long long)(uintptr_t)p; }
+				za = __shfl(za, 0, 64);
+				z = (uint8_t*)(uintptr_t)za;
+				if(z == NULL){ *ok = false; break; }
+				tr.n_chunk = ci + 1;
+			}
+		}
+		int32_t jb = 0, je = tl;
+		if(jb < c - W) jb = c - W;
+		if(je > c + W + 1) je = c + W + 1;
+		if(je > tl) je = tl;
+		const uint32_t qbase = query.at(i);
+		const int32_t j0 = jb + lane * C;
+		uint64_t tbits;
+		{
+			const int32_t jj = j0 < tl ? j0 : (tl > 0 ? tl - 1 : 0);
+			const int32_t w = jj >> 5, sh = (jj & 31) * 2;
+			const uint64_t w0 = L.tb[w], w1 = L.tb[w + 1];
+			tbits = sh ? ((w0 >> sh) | (w1 << (64 - sh))) : w0;
+		}
+		/* ---- load phase: previous-row H and E of the lane's columns, plus H(i-1, j0-1) ---- */
+		int32_t hv[CMAX], ev[CMAX];
+		int32_t pred0;
+		if(i == 0) pred0 = (j0 == 0) ? init_score : init_score + D + E * j0;
+		else if(j0 - 1 >= jbp && j0 - 1 < jep) pred0 = L.Hs[(j0 - 1) & PM];
+		else pred0 = (j0 == 0) ? init_score + I + E * i : -10000;
+		#pragma unroll
+		for(int k = 0; k < CMAX; k++){
+			const int32_t j = j0 + k;
+			const bool live = (k < C) && (i > 0) && (j >= jbp) && (j < jep);
+			hv[k] = live ? L.Hs[j & PM] : -10000;
+			ev[k] = live ? L.Es[j & PM] : -10000;
+		}
+		/* ---- m in place (descending k: m_k needs the OLD H of column k-1) and the local F aggregate ---- */
+		int32_t agg = -0x3FFFFFFF;
+		#pragma unroll
+		for(int k = CMAX - 1; k >= 0; k--){
+			const int32_t j = j0 + k;
+			int32_t pred;
+			if(k == 0) pred = pred0;
+			else pred = (i == 0) ? init_score + D + E * j : hv[k - 1];
+			const uint32_t tbase = (uint32_t)(tbits >> (2 * k)) & 3u;
+			const int32_t m = pred + ((qbase == tbase) ? M : X);
+			hv[k] = m;
+			if(k < C && j < je){ const int32_t cand = m + D + E + (C - 1 - k) * E; agg = agg > cand ? agg : cand; }
+		}
+		int32_t f;
+		{
+			const int32_t g = agg - lane * CE;
+			const int32_t pm = wtz_wave_max_scan_excl(g, -0x3FFFFFFF);
+			const int32_t from_prev = (lane == 0) ? -0x3FFFFFFF : pm + (lane - 1) * CE;
+			const int32_t from_init = -10000 + lane * CE;
+			f = from_prev > from_init ? from_prev : from_init;
+		}
+		/* ---- H, E', F, trace in registers ---- */
+		int32_t best = -0x7FFFFFFF, bestj = 0x7FFFFFFF, h_last = 0;
+		uint32_t zw[(CMAX + 3) / 4];
+		#pragma unroll
+		for(int q4 = 0; q4 < (CMAX + 3) / 4; q4++) zw[q4] = 0;
+		#pragma unroll
+		for(int k = 0; k < CMAX; k++){
+			const int32_t j = j0 + k;
+			if(k < C && j < je){
+				const int32_t m = hv[k];
+				int32_t e = ev[k];
+				uint32_t d; int32_t h;
+				if(m >= e){ d = 0; h = m; } else { d = 1; h = e; }
+				if(h < f){ d = 2; h = f; }
+				if(h > best){ best = h; bestj = j; }
+				h_last = h;
+				int32_t t = m + I + E; e = e + E; if(e > t) d |= 1u << 2; else e = t;
+				t = m + D + E; f = f + E; if(f > t) d |= 2u << 4; else f = t;
+				hv[k] = h; ev[k] = e;
+				if(qbase == ((uint32_t)(tbits >> (2 * k)) & 3u)) d |= 0x80u;       /* bit 7: bases equal (saves two sequence loads per traceback step) */
+				zw[k >> 2] |= d << (8 * (k & 3));
+			}
+		}
+		/* ---- store phase ---- */
+		#pragma unroll
+		for(int k = 0; k < CMAX; k++){
+			const int32_t j = j0 + k;
+			if(k < C && j < je){ L.Hs[j & PM] = hv[k]; L.Es[j & PM] = ev[k]; }
+		}
+		{
+			uint32_t *zr = (uint32_t*)(z + (size_t)(i & 63) * zrow) + lane;
+			#pragma unroll
+			for(int q4 = 0; q4 < (CMAX + 3) / 4; q4++) if(q4 < C4) zr[(size_t)q4 * 64] = zw[q4];
+		}
+		ncell += (unsigned long long)(je - jb);
+		{ uint32_t lo = 0x7FFFFFFFu - (uint32_t)bestj; wtz_wave_max_key(best, lo); bestj = (int32_t)(0x7FFFFFFFu - lo); }     /* max value, then smallest column */
+		int32_t imax = 0, mj2 = -1;
+		if(best > 0){ imax = best; mj2 = bestj; }
+		const int32_t lastlane = (je - 1 - jb) / C;
+		const int32_t h1 = __builtin_amdgcn_readlane(h_last, __builtin_amdgcn_readfirstlane(lastlane));
+		if(lane == 0) zb[i] = jb;
+		if(je == tlen && gmax < h1){ gmax = h1; gi = i; gj = je - 1; }
+		if(i + 1 == qlen && gmax < imax){ gmax = imax; gi = i; gj = mj2; }
+		jbp = jb; jep = je;
+		if(imax > mx){ mx = imax; mi = i; mj = mj2; }
+		else if(imax <= 0) break;
+		c++; if(c < mj2) c++; else if(c > mj2) c--;
+	}
+	if(cells && lane == 0) *cells += ncell;
+	if(!*ok) return x;
+	if(gmax > 0 && gmax >= mx + T){ x.score = gmax; x.qe = gi; x.te = gj; }
+	else { x.score = mx; x.qe = mi; x.te = mj; }
+	__threadfence();
+	if(lane == 0){
+		/* traceback: one dependent trace-byte load per step; the band start of the previous row is fetched alongside, the chunk
+		 * base only every 64 rows, match/mismatch comes from bit 7 of the byte, the CIGAR run is kept in registers */
+		int32_t i_ = x.qe, j_ = x.te; uint32_t d_ = 0;
+		int32_t chunk_i = -1; const uint8_t *cbase = NULL;
+		int32_t zbi = (i_ >= 0) ? zb[i_] : 0;
+		uint32_t run_op = 0xFFu, run_len = 0;
+		while(i_ >= 0 && j_ >= 0){
+			if((i_ >> 6) != chunk_i){ chunk_i = i_ >> 6; cbase = zchunk[chunk_i]; }
+			const int32_t col = j_ - zbi;
+			const int32_t ln = col / C, kk = col - ln * C;
+			const uint8_t zv = cbase[(size_t)(i_ & 63) * zrow + (size_t)(kk >> 2) * 256 + (size_t)ln * 4 + (kk & 3)];
+			const int32_t zb_prev = (i_ > 0) ? zb[i_ - 1] : 0;
+			d_ = (zv >> (d_ << 1)) & 0x03;
+			if(d_ == 0){ if(zv & 0x80u) x.mat++; else x.mis++; i_--; j_--; zbi = zb_prev; }
+			else if(d_ == 1){ i_--; x.ins++; zbi = zb_prev; }
+			else { j_--; x.del++; }
+			if(d_ == run_op) run_len++;
+			else { if(run_len) wtz_cigar_push(cigars, run_op, run_len); run_op = d_; run_len = 1; }
+		}
+		if(run_len) wtz_cigar_push(cigars, run_op, run_len);
+		if(i_ >= 0){ x.ins += i_ + 1; wtz_cigar_push(cigars, 1, (uint32_t)(i_ + 1)); }
+		if(j_ >= 0){ x.del += j_ + 1; wtz_cigar_push(cigars, 2, (uint32_t)(j_ + 1)); }
+		wtz_cigar_reverse(cigars.a, cigars.n);
+		x.aln = x.mat + x.mis + x.ins + x.del; x.qe++; x.te++;
+	}
+	return wtz_bcast_aln(x);
+}
+
 /* ---- K-sw3 jobs: one wave (64 threads) per job; jobs that do not fit the LDS rings run the scalar body on lane 0 ---- */
 template<int P, int TW>
 __global__ void __launch_bounds__(64) wtz_kernel_extjobs(wtz_extjob_t *jobs, const uint32_t *order, uint32_t n, const wtz_params_t *Pm, wtz_pool_t *pool){
@@ -283,7 +478,11 @@ __global__ void __launch_bounds__(64) wtz_kernel_extjobs(wtz_extjob_t *jobs, con
 		wtz_trace_t tr; tr.chunk = NULL; tr.zb = NULL; tr.n_chunk = 0; tr.zrow = 0; tr.cap_rows = 0;
 		wtz_cigar_t cg; if(lane == 0) cg.init(pool, 64);
 		unsigned long long cells = 0; bool ok = true;
-		wtz_aln_t x = wtz_extend_wave<0>(job->qlen, job->q, job->tlen, job->t, job->init_score, job->W, Pm->M, Pm->X, Pm->O, Pm->O, Pm->E, Pm->T, L, tr, pool, cg, &cells, &ok);
+		const int32_t Cw = (((n_col + 63) / 64) | 1);
+		wtz_aln_t x;
+		if(Cw <= 8)       x = wtz_extend_shift_wave_rt<8>(job->qlen, job->q, job->tlen, job->t, job->init_score, job->W, Pm->M, Pm->X, Pm->O, Pm->O, Pm->E, Pm->T, L, tr, pool, cg, &cells, &ok);
+		else if(Cw <= 16) x = wtz_extend_shift_wave_rt<16>(job->qlen, job->q, job->tlen, job->t, job->init_score, job->W, Pm->M, Pm->X, Pm->O, Pm->O, Pm->E, Pm->T, L, tr, pool, cg, &cells, &ok);
+		else              x = wtz_extend_shift_wave_rt<32>(job->qlen, job->q, job->tlen, job->t, job->init_score, job->W, Pm->M, Pm->X, Pm->O, Pm->O, Pm->E, Pm->T, L, tr, pool, cg, &cells, &ok);
 		if(lane == 0){ job->x = x; job->cigar = cg.a; job->cigar_len = cg.n; job->bad = (!ok || cg.bad); job->cells = cells; }
 	} else if(lane == 0){
 		wtz_swmem_t mem; wtz_swmem_init(mem, pool);
@@ -348,6 +547,130 @@ WTZ_D wtz_aln_t wtz_align_window_wave(const wtz_readview &pb1, const wtz_readvie
 		if(stop) return x;
 	}
 	return x;
+}
+
+/* ---- K-sw2, ksw_global2 (ksw.c:503-586), one wavefront per problem: rows run over the target, lanes over the query band.
+ *      Same cell recurrence as the extensions with MINUS_INF sentinels, the lh3 first-row / first-column initialisation,
+ *      no early exit; the score is H(tlen-1, qlen-1) and the traceback starts from that cell.  CIGAR on lane 0. ---- */
+template<typename SQ, typename ST>
+WTZ_D int32_t wtz_global_wave(int32_t qlen, const SQ &query, int32_t tlen, const ST &target, int32_t M, int32_t X,
+		int32_t o_del, int32_t e_del, int32_t o_ins, int32_t e_ins, int32_t w, const wtz_wave_lds_t &L, wtz_trace_t &tr, wtz_pool_t *pool,
+		wtz_cigar_t &cig, bool *ok){
+	const int lane = (int)(threadIdx.x & 63);
+	const int32_t PM = L.PM, oe_del = o_del + e_del, oe_ins = o_ins + e_ins;
+	*ok = true;
+	if(lane == 0) cig.n = 0;
+	const int32_t n_col = qlen < 2 * w + 1 ? qlen : 2 * w + 1;
+	const int32_t C0 = (n_col + 63) / 64, C = (C0 | 1), C4 = (C + 3) / 4;
+	const uint32_t zrow = (uint32_t)C4 * 256u;
+	if(!wtz_trace_prepare(tr, pool, zrow, tlen, false)){ *ok = false; return 0; }
+	uint8_t **zchunk = tr.chunk; uint8_t *z = NULL;
+	{   /* stage the query [0, qlen) as 2-bit codes */
+		const int32_t nw = (qlen + 31) / 32 + 1;
+		for(int32_t ww = lane; ww < nw; ww += 64){
+			uint64_t v = 0; const int32_t b0 = ww * 32;
+			for(int32_t k = 0; k < 32 && b0 + k < qlen; k++) v |= ((uint64_t)query.at(b0 + k)) << (2 * k);
+			L.tb[ww] = v;
+		}
+	}
+	int32_t begp = 0, endp = 0, i, h_lastrow = 0, end_last = 0;
+	const int32_t CE = C * (-e_ins);
+	for(i = 0; i < tlen; i++){
+		if((i & 63) == 0){
+			const uint32_t ci = (uint32_t)i >> 6;
+			unsigned long long za = 0;
+			if(ci < tr.n_chunk){ z = zchunk[ci]; }
+			else {
+				if(lane == 0){ uint8_t *p = (uint8_t*)wtz_pool_alloc(pool, (size_t)zrow * 64); zchunk[ci] = p; za = (unsigned long long)(uintptr_t)p; }
+				za = __shfl(za, 0, 64);
+				z = (uint8_t*)(uintptr_t)za;
+				if(z == NULL){ *ok = false; return 0; }
+				tr.n_chunk = ci + 1;
+			}
+		}
+		const int32_t beg = i > w ? i - w : 0;
+		const int32_t end = i + w + 1 < qlen ? i + w + 1 : qlen;
+		const uint32_t tbase = target.at(i);
+		const int32_t j0 = beg + lane * C;
+		uint64_t qbits;
+		{
+			const int32_t jj = j0 < qlen ? j0 : (qlen > 0 ? qlen - 1 : 0);
+			const int32_t ww = jj >> 5, sh = (jj & 31) * 2;
+			const uint64_t w0 = L.tb[ww], w1 = L.tb[ww + 1];
+			qbits = sh ? ((w0 >> sh) | (w1 << (64 - sh))) : w0;
+		}
+		int32_t agg = -0x7F000000;
+		{
+			int32_t saved = 0;
+			for(int32_t k = 0; k < C; k++){
+				const int32_t j = j0 + k;
+				if(j < end){
+					int32_t pred;
+					if(i == 0){ pred = (j == 0) ? 0 : ((j <= w) ? -(o_ins + e_ins * j) : WTZ_MINUS_INF); }       /* eh[] initialisation, ksw.c:519-523 */
+					else if(k == 0){
+						if(j - 1 >= begp && j - 1 < endp) pred = L.Hs[(j - 1) & PM];
+						else pred = (j == 0) ? -(o_del + e_del * i) : WTZ_MINUS_INF;
+					} else pred = saved;
+					saved = (i > 0 && j >= begp && j < endp) ? L.Hs[j & PM] : WTZ_MINUS_INF;
+					const uint32_t qb = (uint32_t)(qbits >> (2 * k)) & 3u;
+					const int32_t m = pred + ((tbase == qb) ? M : X);
+					L.Hs[j & PM] = m;
+					const int32_t cand = m - oe_ins + (C - 1 - k) * (-e_ins);
+					agg = agg > cand ? agg : cand;
+				}
+			}
+		}
+		int32_t f_in;
+		{
+			const int32_t g = agg - lane * CE;
+			const int32_t pm = wtz_wave_max_scan_excl(g, -0x7F000000);
+			const int32_t from_prev = (lane == 0) ? -0x7F000000 : pm + (lane - 1) * CE;
+			const int32_t from_init = WTZ_MINUS_INF + lane * CE;
+			f_in = from_prev > from_init ? from_prev : from_init;
+		}
+		int32_t h_last = 0;
+		{
+			int32_t f = f_in; uint32_t zword = 0;
+			uint32_t *zr = (uint32_t*)(z + (size_t)(i & 63) * zrow) + lane;
+			for(int32_t k = 0; k < C; k++){
+				const int32_t j = j0 + k;
+				if(j < end){
+					const int32_t m = L.Hs[j & PM];
+					int32_t e = (j >= begp && j < endp) ? L.Es[j & PM] : WTZ_MINUS_INF;
+					uint32_t d; int32_t h;
+					if(m >= e){ d = 0; h = m; } else { d = 1; h = e; }
+					if(h < f){ d = 2; h = f; }
+					h_last = h;
+					int32_t t = m - oe_del; e -= e_del; if(e > t) d |= 1u << 2; else e = t;
+					t = m - oe_ins; f -= e_ins; if(f > t) d |= 2u << 4; else f = t;
+					L.Hs[j & PM] = h; L.Es[j & PM] = e;
+					zword |= d << (8 * (k & 3));
+				}
+				if((k & 3) == 3 || k == C - 1){ zr[(size_t)(k >> 2) * 64] = zword; zword = 0; }
+			}
+		}
+		if(end > beg){ const int32_t lastlane = (end - 1 - beg) / C; h_lastrow = __builtin_amdgcn_readlane(h_last, __builtin_amdgcn_readfirstlane(lastlane)); }
+		begp = beg; endp = end; end_last = end;
+	}
+	const int32_t score = (end_last == qlen) ? h_lastrow : ((qlen <= w) ? -(o_ins + e_ins * qlen) : WTZ_MINUS_INF);
+	__threadfence();
+	if(lane == 0){
+		uint32_t which = 0;
+		int32_t ii = tlen - 1, k = (ii + w + 1 < qlen ? ii + w + 1 : qlen) - 1;
+		while(ii >= 0 && k >= 0){
+			const int32_t col = k - (ii > w ? ii - w : 0);
+			const int32_t ln = col / C, kk = col - ln * C;
+			const uint8_t zv = zchunk[ii >> 6][(size_t)(ii & 63) * zrow + (size_t)(kk >> 2) * 256 + (size_t)ln * 4 + (kk & 3)];
+			which = (zv >> (which << 1)) & 3;
+			if(which == 0){ wtz_cigar_push(cig, 0, 1); --ii; --k; }
+			else if(which == 1){ wtz_cigar_push(cig, 2, 1); --ii; }
+			else { wtz_cigar_push(cig, 1, 1); --k; }
+		}
+		if(ii >= 0) wtz_cigar_push(cig, 2, (uint32_t)(ii + 1));
+		if(k >= 0) wtz_cigar_push(cig, 1, (uint32_t)(k + 1));
+		wtz_cigar_reverse(cig.a, cig.n);
+	}
+	return score;
 }
 
 #endif /* __HIPCC__ */

@@ -142,24 +142,53 @@ WTZ_HD void wtz_task_gap(uint32_t t, const wtz_env_t &V, const wtz_wintask_t *ta
 	const uint32_t k = tasks[t].widx;
 	wtz_gapres_t g; memset(&g, 0, sizeof g);
 	wtz_gapres_t *slot = gaps + (it.regs - items[0].regs) + k;        /* regs of all items are one contiguous array */
-	if(k == 0 || it.regs[k].pass != 1){ *slot = g; return; }
+	if(k == 0 || it.regs[k].pass != 1){ if(WTZ_LANE == 0) *slot = g; return; }
 	int32_t prev = -1;
 	for(int32_t j = (int32_t)k - 1; j >= 0; j--) if(it.regs[j].pass == 1){ prev = j; break; }
-	if(prev < 0){ *slot = g; return; }
+	if(prev < 0){ if(WTZ_LANE == 0) *slot = g; return; }
 	const int32_t M = P->M, X = P->X, I = P->O, D = P->O, E = P->E;
 	const wtz_reg_t *reg1 = &it.regs[prev], *reg2 = &it.regs[k];
 	const wtz_readview pb1 = wtz_view(V.R, it.q, 0), pb2 = wtz_view(V.R, it.c, it.dir);
 	const int32_t dq = reg2->x.qb - reg1->x.qe, dt = reg2->x.tb - reg1->x.te;
 	const wtz_seq_packed q = pb2.sub(reg1->x.qe, 1), tt = pb1.sub(reg1->x.te, 1);
-	wtz_cigar_t tmp; tmp.init(V.pool, 32);
-	wtz_swmem_t mem; wtz_swmem_init_lds(mem, V.pool, wtz_wave_scratch(), WTZ_WAVE_LDS_BYTES / 4);
-	int32_t w = P->w, score;
-	for(;;){
-		if(w < WTZ_ABSDIFF(dq, dt)){ w <<= 1; continue; }
-		score = wtz_global_banded(dq, q, dt, tt, M, X, -I, -E, -D, -E, w, mem, tmp);
-		if(score < 0 && w < P->W && w < WTZ_MAX(dq, dt)) w <<= 1;
-		else break;
+	wtz_cigar_t tmp; tmp.init(V.pool, WTZ_LANE == 0 ? 32 : 0);
+	int32_t w = P->w, score, bad = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+	{   /* the whole wavefront computes the banded global alignment; band doubling is uniform (score is broadcast) */
+		int32_t *lds = wtz_wave_scratch();
+		wtz_wave_lds_t L; L.Hs = lds; L.Es = lds + 512; L.tb = (uint64_t*)(lds + 1024); L.PM = 511; L.tw = 128;
+		wtz_trace_t tr; tr.chunk = NULL; tr.zb = NULL; tr.n_chunk = 0; tr.zrow = 0; tr.cap_rows = 0;
+		wtz_swmem_t mem; wtz_swmem_init(mem, V.pool);
+		for(;;){
+			if(w < WTZ_ABSDIFF(dq, dt)){ w <<= 1; continue; }
+			const int32_t n_col = dq < 2 * w + 1 ? dq : 2 * w + 1;
+			if(dq > 0 && dt > 0 && n_col + 2 <= 512 && (dq + 63) / 32 + 1 <= 128 && (dt + 63) / 64 <= WTZ_TRACE_MAXCHUNK){
+				bool ok = true;
+				score = wtz_global_wave(dq, q, dt, tt, M, X, -I, -E, -D, -E, w, L, tr, V.pool, tmp, &ok);
+				if(!ok) bad = 1;
+			} else {
+				score = 0;
+				if(WTZ_LANE == 0){ score = wtz_global_banded(dq, q, dt, tt, M, X, -I, -E, -D, -E, w, mem, tmp); if(mem.bad) bad = 1; }
+			}
+			score = __shfl(score, 0, 64);
+			if(__shfl(bad, 0, 64)){ bad = 1; break; }
+			if(score < 0 && w < P->W && w < WTZ_MAX(dq, dt)) w <<= 1;
+			else break;
+		}
 	}
+	if(WTZ_LANE != 0) return;
+#else
+	{
+		wtz_swmem_t mem; wtz_swmem_init_lds(mem, V.pool, wtz_wave_scratch(), WTZ_WAVE_LDS_BYTES / 4);
+		for(;;){
+			if(w < WTZ_ABSDIFF(dq, dt)){ w <<= 1; continue; }
+			score = wtz_global_banded(dq, q, dt, tt, M, X, -I, -E, -D, -E, w, mem, tmp);
+			if(score < 0 && w < P->W && w < WTZ_MAX(dq, dt)) w <<= 1;
+			else break;
+		}
+		if(mem.bad) bad = 1;
+	}
+#endif
 	g.score = score; g.valid = 1;
 	int32_t x1 = 0, x2 = 0;
 	for(uint32_t idx = 0; idx < tmp.n; idx++){
@@ -169,7 +198,7 @@ WTZ_HD void wtz_task_gap(uint32_t t, const wtz_env_t &V, const wtz_wintask_t *ta
 		else if(op == 1){ x1 += len; g.ins += len; }
 		else if(op == 2){ x2 += len; g.del += len; }
 	}
-	g.cigar = tmp.a; g.cigar_len = tmp.n; g.bad = (tmp.bad || mem.bad);
+	g.cigar = tmp.a; g.cigar_len = tmp.n; g.bad = (tmp.bad || bad);
 	*slot = g;
 }
 
