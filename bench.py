@@ -64,7 +64,9 @@ def cpu_baseline(engine_argv, genome, coverage, seed, tmp):
             name = line[1:].strip()
         else:
             lens[name] = len(line.strip())
-    ncpu = os.cpu_count() or 1
+    # the reference's index build is O(threads x bases) (every thread scans every read, wtzmo.c:272): on the 256-thread GPU host
+    # -t 256 is 4x SLOWER than -t 32 (56 s vs 13.8 s on the full E. coli-shape set), so the baseline uses min(32, cores)
+    ncpu = min(32, os.cpu_count() or 1)
     out = os.path.join(tmp, "cpu.ovl")
     if os.path.exists(ref):
         pairs = os.path.join(tmp, "cpu.pairs")
@@ -99,7 +101,7 @@ def main():
     ap.add_argument("--engine", choices=["zmo", "dmo"], default="zmo")
     ap.add_argument("--max-batch", type=int, default=0)
     ap.add_argument("--pool-gb", type=int, default=96)
-    ap.add_argument("--cpu-genome", type=int, default=1150000, help="genome length of the bounded CPU-baseline sample")
+    ap.add_argument("--cpu-genome", type=int, default=2300000, help="genome length of the bounded CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
 
@@ -118,6 +120,7 @@ def main():
         dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
 
     import __graft_entry__ as ge
+    from smartdenovo_amd import multigpu
     if rank == 0 and not (os.path.exists(ge.HOSTLIB) and os.path.exists(ge.LIB)):
         ge.build_product()
     tmp = os.environ.get("WTZ_BENCH_TMP", os.path.join(tempfile.gettempdir(), "wtz_bench"))
@@ -138,8 +141,7 @@ def main():
     argv = ["wtzmo", "--gpu", str(local), "-i", fa, "-fo", out, "--repeat", str(W + K), "--stats", stats, "--pool-gb", str(a.pool_gb)] + eng
     if a.max_batch:
         argv += ["--batch", str(a.max_batch)]
-    if world > 1:
-        argv += ["-P", str(world), "-p", str(rank)]
+    argv += multigpu.stripe_argv(world, rank)
 
     host = C.CDLL(ge.HOSTLIB)
     T = {"t0": None, "t1": None, "gathered": 0}
@@ -152,18 +154,10 @@ def main():
             torch.cuda.synchronize()
             T["t0"] = time.perf_counter()
         if phase == 1:
-            if dist:   # RCCL gather of this step's overlap records to rank 0 (records are text lines; volume ~ MBs)
-                data = torch.frombuffer(bytearray(open(out, "rb").read() or b"\n"), dtype=torch.uint8).cuda()
-                sz = torch.tensor([data.numel()], dtype=torch.int64, device="cuda")
-                szs = [torch.zeros_like(sz) for _ in range(world)]
-                dist.all_gather(szs, sz)
-                mx = int(max(int(s.item()) for s in szs))
-                pad = torch.zeros(mx, dtype=torch.uint8, device="cuda")
-                pad[:data.numel()] = data
-                bufs = [torch.empty(mx, dtype=torch.uint8, device="cuda") for _ in range(world)]
-                dist.all_gather(bufs, pad)
+            if dist:   # RCCL gather of this step's overlap records (text lines; volume ~ MBs) inside the timed region
+                blobs = multigpu.gather_records(dist, open(out, "rb").read(), "cuda")
                 if rank == 0:
-                    T["gathered"] = sum(int(s.item()) for s in szs)
+                    T["gathered"] = sum(len(b) for b in blobs)
             if rep == W + K - 1:
                 torch.cuda.synchronize()
                 if dist:
