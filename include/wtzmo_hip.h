@@ -92,6 +92,9 @@ int  wtz_device_count(void);
 
 int  wtz_ctx_create(int device, const wtz_params_c *params, uint64_t pool_bytes, wtz_ctx_t **out);
 void wtz_ctx_destroy(wtz_ctx_t *ctx);
+/* second context on the same GPU sharing the parent's reads + indexes (read-only), with its own HIP stream, scratch pool and
+ * batch state: one per host thread that keeps a batch in flight. pool_bytes 0 = same as the parent. */
+int  wtz_ctx_clone(wtz_ctx_t *parent, uint64_t pool_bytes, wtz_ctx_t **out);
 
 /* bits: 2-bit packed bases, 32 per word, base i at bits ((~i)&31)*2 of word i>>5 (dna.h:78);
  * rdoff/rdlen per read in READ-ID order (id = rank by length DESC under the reference's sort, wtzmo.c:1708). */

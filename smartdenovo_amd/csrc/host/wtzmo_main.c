@@ -22,6 +22,7 @@
 #include <getopt.h>
 #include <unistd.h>
 #include <time.h>
+#include <pthread.h>
 #include "wtz_host.h"
 
 static int usage(void){
@@ -68,20 +69,33 @@ typedef struct {
 	uint32_t *rdlen; uint32_t avg_rdlen;
 	wtz_ctx_t *ctx; FILE *out;
 	uint64_t pair_bp, n_pairs, nrec;
-	/* candidate rows */
-	uint64_t *rows; uint32_t *nrow; uint32_t *row_of; uint32_t stride; uint32_t rows_cap; int rows_all;
-	uint32_t max_batch, first_batch;
-	/* batch */
-	uint32_t *bq; uint32_t nbq;
-	uint32_t *pq, *pc; uint32_t npair, cappair;
-	uint32_t *rowpair; size_t caprowpair;      /* pair index per (batch query slot, row entry) */
-	wtz_pair_summary_t *sum; uint64_t *box_off; wtz_winbox_t *boxes; uint64_t nbox, capbox;
-	uint32_t *item_of; uint32_t *it_pair; uint8_t *it_dir; uint32_t nitem; wtz_aln_result_t *aln; uint32_t *cig; uint64_t ncig, capcig;
+	/* candidate rows carried across -G index parts (the reference's rdhits), else NULL */
+	uint64_t *rows; uint32_t *nrow; uint32_t stride; int rows_all;
+	uint32_t max_batch, first_batch, n_workers;
+	/* pipeline: batches are planned in query order by whichever worker is free, computed on that worker's context
+	 * (own HIP stream + scratch pool) and committed strictly in sequence */
+	pthread_mutex_t mu; pthread_cond_t cv;
+	uint32_t cursor, qend, B; uint64_t next_seq, commit_seq;
 	pending_t pend;
 	/* stats */
 	double t_gpu, t_commit;
-	uint64_t spec_pairs, used_pairs, spec_items, used_items, spec_queries, used_queries;
+	uint64_t spec_pairs, used_pairs, spec_items, used_items, spec_queries, used_queries, n_batches;
+	double extra_ms[5]; uint64_t extra_u64[6];      /* counters of the cloned contexts */
 } eng_t;
+
+typedef struct {       /* one batch in flight */
+	eng_t *E; wtz_ctx_t *ctx; uint64_t seq;
+	uint32_t *bq; uint32_t nbq, capbq;         /* queries in dispatch order */
+	uint8_t *want;                              /* slot needs GPU work (not saturated when planned) */
+	uint64_t *rows; uint32_t *nrow;             /* candidate heap arrays per slot (stride E->stride) */
+	uint32_t *ids;
+	uint32_t *pq, *pc; uint32_t npair, cappair;
+	uint32_t *rowpair; size_t caprowpair;       /* pair index per (slot, row entry) */
+	wtz_pair_summary_t *sum; uint64_t *box_off; wtz_winbox_t *boxes; uint64_t nbox, capbox;
+	uint32_t *item_of; uint32_t *it_pair; uint8_t *it_dir; uint32_t nitem; wtz_aln_result_t *aln; uint32_t *cig; uint64_t ncig, capcig;
+	uint64_t spec_queries, used_queries;
+	int holds_turn;
+} batch_t;
 
 #define DIE_WTZ(rc, what) do { if((rc) != WTZ_OK){ fprintf(stderr, " -- %s failed: %s --\n", what, wtz_last_error()); exit(1); } } while(0)
 
@@ -162,36 +176,35 @@ static char *cigar_text(const uint32_t *c, uint32_t n){        /* kswx.h:1093-11
 }
 
 /* ---------------- commit of one query over the batch results (wtzmo.c:806-1130) ---------------- */
-static void commit_query(eng_t *E, uint32_t slot){
+static void commit_query(eng_t *E, batch_t *b, uint32_t slot){
 	const wtz_params_c *P = &E->P;
 	pending_t *pd = &E->pend;
-	const uint32_t pbid = E->bq[slot];
+	const uint32_t pbid = b->bq[slot];
 	const int alen = (int)E->rdlen[pbid];
 	pd->rd_id = pbid;
 	const uint32_t nbest = nbest_of(E, pbid);
 	uint32_t bcov = E->rdcovs[pbid];
 	if(bcov >= nbest) return;
-	E->used_queries++;
+	E->used_queries++; b->used_queries++;
 	/* candidates: closed filter, exact order, trim (wtzmo.c:813-822) */
-	const uint32_t row = E->row_of[pbid];
-	if(row == 0xFFFFFFFFu){ fprintf(stderr, " -- internal error: no candidate row for read %u --\n", pbid); exit(1); }
-	uint32_t nc = E->nrow[row];
+	if(!b->want[slot]){ fprintf(stderr, " -- internal error: no candidate row for read %u --\n", pbid); exit(1); }
+	uint32_t nc = b->nrow[slot];
 	cand_t *cand = (cand_t*)hx_realloc(NULL, sizeof(cand_t) * (nc + 1));
 	for(uint32_t i = 0; i < nc; i++){
-		cand[i].e = E->rows[(size_t)row * E->stride + i]; cand[i].pidx = E->rowpair[(size_t)slot * E->stride + i]; cand[i].pad = 0;
+		cand[i].e = b->rows[(size_t)slot * E->stride + i]; cand[i].pidx = b->rowpair[(size_t)slot * E->stride + i]; cand[i].pad = 0;
 		if(hx_set_has(&E->closed, hx_pair_key(pbid, cand[i].e >> 32))) cand[i].e &= 0xFFFFFFFF00000000ULL;
 	}
 	hx_sort_exact(cand, nc, sizeof(cand_t), gt_cand, NULL);
 	while(nc && (uint32_t)cand[nc - 1].e == 0) nc--;
 	if(E->rows_all){       /* -G: the trimmed, sorted list persists as the reference's rdhits entry */
-		for(uint32_t i = 0; i < nc; i++) E->rows[(size_t)row * E->stride + i] = cand[i].e;
-		E->nrow[row] = nc;
+		for(uint32_t i = 0; i < nc; i++) E->rows[(size_t)pbid * E->stride + i] = cand[i].e;
+		E->nrow[pbid] = nc;
 	}
 	if(P->dot_matrix){
 		for(uint32_t i = 0; i < nc; i++){
 			const uint32_t id2 = (uint32_t)(cand[i].e >> 32);
 			if(cand[i].pidx == 0xFFFFFFFFu){ fprintf(stderr, " -- internal error: pair (%u,%u) missing from the batch plan --\n", pbid, id2); exit(1); }
-			const wtz_pair_summary_t *S = &E->sum[cand[i].pidx];
+			const wtz_pair_summary_t *S = &b->sum[cand[i].pidx];
 			if(!S->gate) continue;
 			E->used_pairs++;
 			pend_closed(pd, hx_pair_key(id2, pbid));
@@ -213,11 +226,11 @@ static void commit_query(eng_t *E, uint32_t slot){
 	for(uint32_t i = 0; i < nc; i++){
 		const uint32_t id2 = (uint32_t)(cand[i].e >> 32);
 		if(cand[i].pidx == 0xFFFFFFFFu){ fprintf(stderr, " -- internal error: pair (%u,%u) missing from the batch plan --\n", pbid, id2); exit(1); }
-		const wtz_pair_summary_t *S = &E->sum[cand[i].pidx];
+		const wtz_pair_summary_t *S = &b->sum[cand[i].pidx];
 		if(!S->gate) continue;
 		E->used_pairs++;
 		for(uint32_t dir = 0; dir < 2; dir++){
-			const wtz_winbox_t *bx = E->boxes + E->box_off[(size_t)cand[i].pidx * 2 + dir];
+			const wtz_winbox_t *bx = b->boxes + b->box_off[(size_t)cand[i].pidx * 2 + dir];
 			for(uint32_t k = 0; k < S->nwin[dir]; k++)
 				for(uint32_t x = (uint32_t)bx[k].beg[0]; (int)x < bx[k].end[0]; x++) windeps[x]++;       /* wtzmo.c:908 */
 		}
@@ -234,8 +247,8 @@ static void commit_query(eng_t *E, uint32_t slot){
 	for(uint32_t i = 0; i < nseed; i++){
 		seed_t *s = &seeds[i];
 		const int blen = (int)E->rdlen[s->pb2];
-		const wtz_pair_summary_t *S = &E->sum[s->pidx];
-		const wtz_winbox_t *bx = E->boxes + E->box_off[(size_t)s->pidx * 2 + s->dir];
+		const wtz_pair_summary_t *S = &b->sum[s->pidx];
+		const wtz_winbox_t *bx = b->boxes + b->box_off[(size_t)s->pidx * 2 + s->dir];
 		uint32_t ol = 0; double avg;
 		for(uint32_t k = 0; k < S->nwin[s->dir]; k++){
 			avg = (bx[k].end[0] - bx[k].beg[0]) * weights[(bx[k].beg[0] + bx[k].end[0]) / 2];
@@ -257,16 +270,16 @@ static void commit_query(eng_t *E, uint32_t slot){
 			seed_t *s = &seeds[i];
 			if(s->closed){ ncand++; continue; }
 			pend_closed(pd, hx_pair_key(s->pb2, pbid));
-			const uint32_t item = E->item_of[s->pidx];
-			if(item == 0xFFFFFFFFu || E->it_dir[item] != s->dir){ fprintf(stderr, " -- internal error: alignment of (%u,%u) missing from the batch plan --\n", pbid, s->pb2); exit(1); }
+			const uint32_t item = b->item_of[s->pidx];
+			if(item == 0xFFFFFFFFu || b->it_dir[item] != s->dir){ fprintf(stderr, " -- internal error: alignment of (%u,%u) missing from the batch plan --\n", pbid, s->pb2); exit(1); }
 			E->used_items++;
-			const wtz_aln_result_t *x = &E->aln[item];
+			const wtz_aln_result_t *x = &b->aln[item];
 			if(x->n_regs == 0){ s->closed = 1; ncand++; continue; }
 			if(x->score < P->min_score || x->mat < x->aln * P->min_id) continue;
 			hit_t H; memset(&H, 0, sizeof H);
 			H.pb1 = pbid; H.pb2 = s->pb2; H.dir2 = s->dir; H.score = x->score;
 			H.tb = x->tb; H.te = x->te; H.qb = x->qb; H.qe = x->qe; H.mat = x->mat; H.mis = x->mis; H.ins = x->ins; H.del = x->del; H.aln = x->aln;
-			H.cigar = cigar_text(E->cig + x->cigar_off, x->cigar_len);
+			H.cigar = cigar_text(b->cig + x->cigar_off, x->cigar_len);
 			pend_hit(pd, &H);
 			{   /* dovetail / containment bookkeeping (wtzmo.c:1065-1100) */
 				const uint32_t len1 = E->rdlen[H.pb1], len2 = E->rdlen[H.pb2];
@@ -296,85 +309,150 @@ static void commit_query(eng_t *E, uint32_t slot){
 	free(cand); free(windeps); free(weights); free(seeds);
 }
 
-/* ---------------- candidate rows ---------------- */
-static void rows_reserve(eng_t *E, uint32_t n){
-	if(n <= E->rows_cap) return;
-	E->rows = (uint64_t*)hx_realloc(E->rows, (size_t)n * E->stride * 8);
-	E->nrow = (uint32_t*)hx_realloc(E->nrow, (size_t)n * 4);
-	E->rows_cap = n;
-}
-
-/* compute candidate rows for `n` query ids (rows 0..n-1), no carry */
-static void candidates_chunk(eng_t *E, const uint32_t *ids, uint32_t n){
-	rows_reserve(E, n);
-	memset(E->nrow, 0, (size_t)n * 4);
-	int rc = wtz_candidates(E->ctx, ids, n, E->rows, E->nrow); DIE_WTZ(rc, "wtz_candidates");
-	for(uint32_t i = 0; i < n; i++) E->row_of[ids[i]] = i;
-}
-
 /* ---------------- one batch: plan -> GPU -> commit ---------------- */
-/* returns 1 (nothing committed) when the device scratch pool was too small for this batch: the caller retries with fewer queries */
 #define TRY_WTZ(rc, what) do { if((rc) == WTZ_E_POOL) return 1; DIE_WTZ(rc, what); } while(0)
-static int run_batch(eng_t *E){
-	const wtz_params_c *P = &E->P;
-	int rc;
-	/* plan pairs: every row entry whose pair is not closed now */
-	E->npair = 0;
-	if((size_t)E->nbq * E->stride > E->caprowpair){ E->caprowpair = (size_t)E->nbq * E->stride; E->rowpair = (uint32_t*)hx_realloc(E->rowpair, E->caprowpair * 4); }
-	for(uint32_t s = 0; s < E->nbq; s++){
-		const uint32_t q = E->bq[s], row = E->row_of[q];
-		if(row == 0xFFFFFFFFu || E->rdcovs[q] >= nbest_of(E, q)) continue;
-		for(uint32_t k = 0; k < E->nrow[row]; k++){
-			const uint64_t e = E->rows[(size_t)row * E->stride + k];
+
+/* under E->mu: pairs of slots [s0,s1) whose candidate pair is not closed right now */
+static void plan_pairs(eng_t *E, batch_t *b, uint32_t s0, uint32_t s1){
+	b->npair = 0;
+	if((size_t)b->nbq * E->stride > b->caprowpair){ b->caprowpair = (size_t)b->nbq * E->stride; b->rowpair = (uint32_t*)hx_realloc(b->rowpair, b->caprowpair * 4); }
+	for(uint32_t s = s0; s < s1; s++){
+		const uint32_t q = b->bq[s];
+		if(!b->want[s] || E->masked[q] || E->rdcovs[q] >= nbest_of(E, q)) continue;
+		for(uint32_t k = 0; k < b->nrow[s]; k++){
+			const uint64_t e = b->rows[(size_t)s * E->stride + k];
 			const uint32_t id2 = (uint32_t)(e >> 32);
-			E->rowpair[(size_t)s * E->stride + k] = 0xFFFFFFFFu;
+			b->rowpair[(size_t)s * E->stride + k] = 0xFFFFFFFFu;
 			if((uint32_t)e == 0 || id2 == 0xFFFFFFFFu) continue;
 			if(hx_set_has(&E->closed, hx_pair_key(q, id2))) continue;
-			if(E->npair == E->cappair){ E->cappair = E->cappair ? E->cappair * 2 : 4096; E->pq = (uint32_t*)hx_realloc(E->pq, E->cappair * 4); E->pc = (uint32_t*)hx_realloc(E->pc, E->cappair * 4); }
-			E->pq[E->npair] = q; E->pc[E->npair] = id2; E->rowpair[(size_t)s * E->stride + k] = E->npair; E->npair++;
+			if(b->npair == b->cappair){ b->cappair = b->cappair ? b->cappair * 2 : 4096; b->pq = (uint32_t*)hx_realloc(b->pq, b->cappair * 4); b->pc = (uint32_t*)hx_realloc(b->pc, b->cappair * 4); }
+			b->pq[b->npair] = q; b->pc[b->npair] = id2; b->rowpair[(size_t)s * E->stride + k] = b->npair; b->npair++;
 		}
 	}
-	E->spec_pairs += E->npair; E->spec_queries += E->nbq;
-	const double tg0 = now_s();
-	E->sum = (wtz_pair_summary_t*)hx_realloc(E->sum, sizeof(wtz_pair_summary_t) * (E->npair + 1));
-	rc = wtz_pairs_seed(E->ctx, E->pq, E->pc, E->npair, E->sum); TRY_WTZ(rc, "wtz_pairs_seed");
-	E->nitem = 0; E->ncig = 0;
+}
+
+/* no lock held: the speculative device stages of the planned pairs. 1 = scratch pool too small, nothing changed */
+static int gpu_stages(eng_t *E, batch_t *b){
+	const wtz_params_c *P = &E->P;
+	int rc;
+	b->sum = (wtz_pair_summary_t*)hx_realloc(b->sum, sizeof(wtz_pair_summary_t) * (b->npair + 1));
+	rc = wtz_pairs_seed(b->ctx, b->pq, b->pc, b->npair, b->sum); TRY_WTZ(rc, "wtz_pairs_seed");
+	b->nitem = 0; b->ncig = 0;
 	if(!P->dot_matrix){
-		E->box_off = (uint64_t*)hx_realloc(E->box_off, 8 * ((size_t)E->npair * 2 + 1));
+		b->box_off = (uint64_t*)hx_realloc(b->box_off, 8 * ((size_t)b->npair * 2 + 1));
 		uint64_t nb = 0;
-		for(uint32_t i = 0; i < E->npair; i++) for(int d = 0; d < 2; d++){ E->box_off[(size_t)i * 2 + d] = nb; nb += E->sum[i].nwin[d]; }
-		E->box_off[(size_t)E->npair * 2] = nb; E->nbox = nb;
-		if(nb > E->capbox){ E->capbox = nb; E->boxes = (wtz_winbox_t*)hx_realloc(E->boxes, sizeof(wtz_winbox_t) * nb); }
-		rc = wtz_pairs_windows(E->ctx, E->boxes, nb); TRY_WTZ(rc, "wtz_pairs_windows");
-		E->item_of = (uint32_t*)hx_realloc(E->item_of, 4 * ((size_t)E->npair + 1));
-		E->it_pair = (uint32_t*)hx_realloc(E->it_pair, 4 * ((size_t)E->npair + 1));
-		E->it_dir = (uint8_t*)hx_realloc(E->it_dir, (size_t)E->npair + 1);
-		for(uint32_t i = 0; i < E->npair; i++){
-			E->item_of[i] = 0xFFFFFFFFu;
-			if(!E->do_align || !E->sum[i].gate) continue;
-			const uint32_t dir = (E->sum[i].ovl[0] < E->sum[i].ovl[1]);
-			if(E->sum[i].ovl[dir] < P->ztot) continue;
-			E->item_of[i] = E->nitem; E->it_pair[E->nitem] = i; E->it_dir[E->nitem] = (uint8_t)dir; E->nitem++;
+		for(uint32_t i = 0; i < b->npair; i++) for(int d = 0; d < 2; d++){ b->box_off[(size_t)i * 2 + d] = nb; nb += b->sum[i].nwin[d]; }
+		b->box_off[(size_t)b->npair * 2] = nb; b->nbox = nb;
+		if(nb > b->capbox){ b->capbox = nb; b->boxes = (wtz_winbox_t*)hx_realloc(b->boxes, sizeof(wtz_winbox_t) * nb); }
+		rc = wtz_pairs_windows(b->ctx, b->boxes, nb); TRY_WTZ(rc, "wtz_pairs_windows");
+		b->item_of = (uint32_t*)hx_realloc(b->item_of, 4 * ((size_t)b->npair + 1));
+		b->it_pair = (uint32_t*)hx_realloc(b->it_pair, 4 * ((size_t)b->npair + 1));
+		b->it_dir = (uint8_t*)hx_realloc(b->it_dir, (size_t)b->npair + 1);
+		for(uint32_t i = 0; i < b->npair; i++){
+			b->item_of[i] = 0xFFFFFFFFu;
+			if(!E->do_align || !b->sum[i].gate) continue;
+			const uint32_t dir = (b->sum[i].ovl[0] < b->sum[i].ovl[1]);
+			if(b->sum[i].ovl[dir] < P->ztot) continue;
+			b->item_of[i] = b->nitem; b->it_pair[b->nitem] = i; b->it_dir[b->nitem] = (uint8_t)dir; b->nitem++;
 		}
-		E->spec_items += E->nitem;
-		if(E->nitem){
-			E->aln = (wtz_aln_result_t*)hx_realloc(E->aln, sizeof(wtz_aln_result_t) * E->nitem);
-			rc = wtz_pairs_align(E->ctx, E->it_pair, E->it_dir, E->nitem, E->aln); TRY_WTZ(rc, "wtz_pairs_align");
-			uint64_t tot = 0; for(uint32_t i = 0; i < E->nitem; i++) tot += E->aln[i].cigar_len;
-			if(tot > E->capcig){ E->capcig = tot; E->cig = (uint32_t*)hx_realloc(E->cig, 4 * tot); }
-			rc = wtz_fetch_cigars(E->ctx, E->cig, tot); TRY_WTZ(rc, "wtz_fetch_cigars");
-			E->ncig = tot;
+		if(b->nitem){
+			b->aln = (wtz_aln_result_t*)hx_realloc(b->aln, sizeof(wtz_aln_result_t) * b->nitem);
+			rc = wtz_pairs_align(b->ctx, b->it_pair, b->it_dir, b->nitem, b->aln); TRY_WTZ(rc, "wtz_pairs_align");
+			uint64_t tot = 0; for(uint32_t i = 0; i < b->nitem; i++) tot += b->aln[i].cigar_len;
+			if(tot > b->capcig){ b->capcig = tot; b->cig = (uint32_t*)hx_realloc(b->cig, 4 * tot); }
+			rc = wtz_fetch_cigars(b->ctx, b->cig, tot); TRY_WTZ(rc, "wtz_fetch_cigars");
+			b->ncig = tot;
 		}
 	}
-	const double tg1 = now_s(); E->t_gpu += tg1 - tg0;
+	return 0;
+}
+
+/* slots [s0,s1): plan pairs, run the device stages, commit in query order when it is this batch's turn. A range whose
+ * scratch demand exceeds the pool is split in two (the second half is planned after the first half is committed). */
+static void process_range(eng_t *E, batch_t *b, uint32_t s0, uint32_t s1){
+	pthread_mutex_lock(&E->mu);
+	plan_pairs(E, b, s0, s1);
+	pthread_mutex_unlock(&E->mu);
+	const double tg0 = now_s();
+	const int again = gpu_stages(E, b);
+	const double tg1 = now_s();
+	if(again){
+		if(s1 - s0 <= 1){ fprintf(stderr, " -- device scratch pool too small even for one query: %s (use --pool-gb) --\n", wtz_last_error()); exit(1); }
+		fprintf(stderr, "[wtzmo-mi355x] scratch pool exhausted with %u queries in flight; splitting the batch\n", s1 - s0);
+		const uint32_t mid = s0 + (s1 - s0) / 2;
+		process_range(E, b, s0, mid);
+		process_range(E, b, mid, s1);
+		return;
+	}
+	pthread_mutex_lock(&E->mu);
+	E->t_gpu += tg1 - tg0;
+	while(!b->holds_turn && E->commit_seq != b->seq) pthread_cond_wait(&E->cv, &E->mu);
+	b->holds_turn = 1;
+	E->spec_pairs += b->npair; E->spec_items += b->nitem;
 	/* commit in query order with the reference's one-query masking lag (wtzmo.c:1315-1333) */
-	for(uint32_t s = 0; s < E->nbq; s++){
-		if(E->masked[E->bq[s]]) continue;
+	for(uint32_t s = s0; s < s1; s++){
+		if(E->masked[b->bq[s]]) continue;
 		flush_pending(E);
-		commit_query(E, s);
+		commit_query(E, b, s);
 	}
 	E->t_commit += now_s() - tg1;
-	return 0;
+	pthread_mutex_unlock(&E->mu);
+}
+
+static void *worker_main(void *arg){
+	batch_t *b = (batch_t*)arg; eng_t *E = b->E;
+	for(;;){
+		/* ---- take the next batch of queries (id order) ---- */
+		pthread_mutex_lock(&E->mu);
+		if(E->cursor >= E->qend){ pthread_mutex_unlock(&E->mu); break; }
+		const uint32_t B = E->B;
+		if(B + 1 > b->capbq){ b->capbq = B + 1; b->bq = (uint32_t*)hx_realloc(b->bq, 4 * (size_t)b->capbq); b->want = (uint8_t*)hx_realloc(b->want, b->capbq); b->ids = (uint32_t*)hx_realloc(b->ids, 4 * (size_t)b->capbq);
+			b->rows = (uint64_t*)hx_realloc(b->rows, (size_t)b->capbq * E->stride * 8); b->nrow = (uint32_t*)hx_realloc(b->nrow, 4 * (size_t)b->capbq); }
+		b->nbq = 0;
+		uint32_t j = E->cursor, nwant = 0;
+		for(; j < E->qend && b->nbq < B; j++){
+			if((j % E->n_job) != E->i_job) continue;
+			if(E->masked[j]) continue;
+			/* reads whose coverage is already saturated (wtzmo.c:808) need no GPU work but stay in the dispatch sequence:
+			 * their dispatch is what merges the previous query's masks (one-query masking lag) */
+			const int sat = E->rdcovs[j] >= nbest_of(E, j);
+			b->want[b->nbq] = (uint8_t)!sat; b->nrow[b->nbq] = 0;
+			if(!sat){
+				if(E->rows_all){ memcpy(b->rows + (size_t)b->nbq * E->stride, E->rows + (size_t)j * E->stride, (size_t)E->stride * 8); b->nrow[b->nbq] = E->nrow[j]; }
+				nwant++;
+			}
+			b->bq[b->nbq++] = j;
+		}
+		E->cursor = j;
+		b->seq = E->next_seq++; b->holds_turn = 0; b->spec_queries = b->nbq; b->used_queries = 0;
+		E->spec_queries += b->nbq; E->n_batches++;
+		if(E->B < E->max_batch) E->B = E->B * 4 > E->max_batch ? E->max_batch : E->B * 4;      /* ramp-up; corrected at commit */
+		pthread_mutex_unlock(&E->mu);
+		/* ---- candidate heaps of the batch's queries (A3) ---- */
+		if(nwant){
+			uint32_t n = 0;
+			for(uint32_t s = 0; s < b->nbq; s++) if(b->want[s]) b->ids[n++] = b->bq[s];
+			uint64_t *rows = (uint64_t*)hx_realloc(NULL, (size_t)n * E->stride * 8); uint32_t *nr = (uint32_t*)hx_realloc(NULL, 4 * (size_t)n);
+			n = 0;
+			for(uint32_t s = 0; s < b->nbq; s++) if(b->want[s]){ memcpy(rows + (size_t)n * E->stride, b->rows + (size_t)s * E->stride, (size_t)b->nrow[s] * 8); nr[n] = b->nrow[s]; n++; }
+			const double tg0 = now_s();
+			int rc = wtz_candidates(b->ctx, b->ids, n, rows, nr); DIE_WTZ(rc, "wtz_candidates");
+			const double tg1 = now_s();
+			n = 0;
+			for(uint32_t s = 0; s < b->nbq; s++) if(b->want[s]){ memcpy(b->rows + (size_t)s * E->stride, rows + (size_t)n * E->stride, (size_t)E->stride * 8); b->nrow[s] = nr[n]; n++; }
+			free(rows); free(nr);
+			pthread_mutex_lock(&E->mu); E->t_gpu += tg1 - tg0; pthread_mutex_unlock(&E->mu);
+		}
+		if(b->nbq) process_range(E, b, 0, b->nbq);
+		/* ---- hand the turn to the next batch ---- */
+		pthread_mutex_lock(&E->mu);
+		while(!b->holds_turn && E->commit_seq != b->seq) pthread_cond_wait(&E->cv, &E->mu);
+		E->commit_seq = b->seq + 1;
+		if(b->used_queries * 2 < b->spec_queries && E->B > E->first_batch){ E->B /= 2; if(E->B < 8) E->B = 8; }   /* too much discarded work */
+		pthread_cond_broadcast(&E->cv);
+		pthread_mutex_unlock(&E->mu);
+	}
+	return NULL;
 }
 
 static double now_s(void){ struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec; }
@@ -403,9 +481,10 @@ int main(int argc, char **argv){
 	P->kwin = 800; P->kovl = 300; P->ksave = 4; P->win_rep_norm = 20; P->win_rep_cutoff = 100; P->ncand = 500; P->nbest = 100;
 	P->ztot = 300; P->zovl = 200; P->max_kmer_freq = 0; P->max_zmer_freq = 64; P->max_kmer_var = 2;
 	P->xvar = 128; P->yvar = 64; P->min_block_len = 160; P->deviation_penalty = 1.0f; P->gap_penalty = 0.05f;
-	E->do_align = 1; E->n_idx = 1; E->n_job = 1; E->i_job = 0; E->max_batch = 2048; E->first_batch = 256;
+	E->do_align = 1; E->n_idx = 1; E->n_job = 1; E->i_job = 0; E->max_batch = 2048; E->first_batch = 256; E->n_workers = 2;
+	pthread_mutex_init(&E->mu, NULL); pthread_cond_init(&E->cv, NULL);
 	static struct option lopts[] = { {"stats", required_argument, 0, 1000}, {"gpu", required_argument, 0, 1001}, {"pool-gb", required_argument, 0, 1002},
-		{"batch", required_argument, 0, 1003}, {"lib-check", no_argument, 0, 1004}, {"repeat", required_argument, 0, 1005}, {"first-batch", required_argument, 0, 1006}, {0, 0, 0, 0} };
+		{"batch", required_argument, 0, 1003}, {"lib-check", no_argument, 0, 1004}, {"repeat", required_argument, 0, 1005}, {"first-batch", required_argument, 0, 1006}, {"workers", required_argument, 0, 1007}, {0, 0, 0, 0} };
 	while((c = getopt_long(argc, argv, "ht:P:p:Ni:b:J:I:o:9:S:fCH:k:G:z:Z:U:y:d:r:q:l:K:A:B:r:R:L:F:W:w:e:M:X:O:E:T:s:m:nv", lopts, NULL)) != -1){
 		switch(c){
 			case 1000: statsf = optarg; break;
@@ -415,6 +494,7 @@ int main(int argc, char **argv){
 			case 1004: lib_check = 1; break;
 			case 1005: repeat = atoi(optarg); if(repeat < 1) repeat = 1; break;
 			case 1006: E->first_batch = (uint32_t)atoi(optarg); if(E->first_batch < 1) E->first_batch = 1; break;
+			case 1007: E->n_workers = (uint32_t)atoi(optarg); if(E->n_workers < 1) E->n_workers = 1; if(E->n_workers > 8) E->n_workers = 8; break;
 			case 'h': return usage();
 			case 't': break;
 			case 'P': E->n_job = (uint32_t)atoi(optarg); break;
@@ -559,7 +639,6 @@ int main(int argc, char **argv){
 	E->out = strcmp(output, "-") ? fopen(output, "w") : stdout;
 	if(E->out == NULL){ fprintf(stderr, " -- Cannot write %s --\n", output); exit(1); }
 	E->stride = P->ncand + 1;
-	E->row_of = (uint32_t*)hx_realloc(NULL, 4 * ((size_t)n_all + 1)); memset(E->row_of, 0xFF, 4 * ((size_t)n_all + 1));
 	E->pend.rd_id = 0xFFFFFFFFu;
 	/* --repeat: run the whole overlap phase several times on the reads already resident in HBM (benchmarking) */
 	uint8_t *masked0 = (uint8_t*)hx_realloc(NULL, (size_t)n_all + 1); memcpy(masked0, E->masked, (size_t)n_all + 1);
@@ -573,7 +652,7 @@ int main(int argc, char **argv){
 			for(size_t i = 0; i < nclosed0; i++) hx_set_put(&E->closed, closed0[i]);
 			E->pair_bp = E->n_pairs = E->nrec = 0;
 			E->t_gpu = E->t_commit = 0; E->spec_pairs = E->used_pairs = E->spec_items = E->used_items = E->spec_queries = E->used_queries = 0;
-			memset(E->row_of, 0xFF, 4 * ((size_t)n_all + 1)); E->rows_all = 0;
+			E->rows_all = 0; E->n_batches = 0;
 			E->pend.rd_id = 0xFFFFFFFFu; E->pend.nhit = E->pend.nmask = E->pend.nclosed = E->pend.nseed = 0;
 			if(strcmp(output, "-")){ E->out = fopen(output, "w"); if(E->out == NULL) exit(1); }
 			wtz_reset_counters(E->ctx);
@@ -585,7 +664,7 @@ int main(int argc, char **argv){
 		uint32_t pbbeg = 0, pbend = 0, K = P->max_kmer_freq;
 		wtz_index_stats_t ist;
 		uint32_t *ids = (uint32_t*)hx_realloc(NULL, 4 * ((size_t)n_all + 1));
-		if(E->n_idx > 1){ E->rows_all = 1; rows_reserve(E, n_all); memset(E->nrow, 0, (size_t)n_all * 4); for(uint32_t i = 0; i < n_all; i++) E->row_of[i] = i; }
+		if(E->n_idx > 1){ E->rows_all = 1; E->rows = (uint64_t*)hx_realloc(E->rows, (size_t)n_all * E->stride * 8); E->nrow = (uint32_t*)hx_realloc(E->nrow, (size_t)n_all * 4); memset(E->nrow, 0, (size_t)n_all * 4); }
 		double t_index = 0;
 		for(uint32_t i_idx = 0; i_idx < E->n_idx; i_idx++){
 			pbbeg = pbend; pbend = pbbeg + (n_rd + E->n_idx - 1) / E->n_idx;
@@ -616,61 +695,46 @@ int main(int argc, char **argv){
 				free(tmp_rows); free(tmp_n);
 			}
 		}
-		/* ---- queries ---- */
-		uint32_t qbeg = E->st.n_qr ? n_rd : 0, qend = E->st.n_qr ? n_rd + E->st.n_qr : n_rd;
-		uint32_t cursor = qbeg, chunk_end = qbeg, B = E->max_batch < E->first_batch ? E->max_batch : E->first_batch;
-		E->bq = (uint32_t*)hx_realloc(NULL, 4 * ((size_t)E->max_batch + 1));
-		while(cursor < qend){
-			if(cursor >= chunk_end){
-				/* candidate rows for the next chunk of unmasked queries of this job */
-				uint32_t n = 0, j = cursor;
-				for(; j < qend && n < 4096; j++){ if((j % E->n_job) != E->i_job) continue; if(E->masked[j]) continue; if(E->rdcovs[j] >= nbest_of(E, j)) continue; ids[n++] = j; }
-				chunk_end = j;
-				if(E->rows_all){
-					for(uint32_t a = 0; a < n; a += 4096){
-						uint32_t m = n - a < 4096 ? n - a : 4096;
-						uint64_t *tmp_rows = (uint64_t*)hx_realloc(NULL, (size_t)m * E->stride * 8); uint32_t *tmp_n = (uint32_t*)hx_realloc(NULL, (size_t)m * 4);
-						for(uint32_t k = 0; k < m; k++){ memcpy(tmp_rows + (size_t)k * E->stride, E->rows + (size_t)ids[a + k] * E->stride, (size_t)E->stride * 8); tmp_n[k] = E->nrow[ids[a + k]]; }
-						rc = wtz_candidates(E->ctx, ids + a, m, tmp_rows, tmp_n); DIE_WTZ(rc, "wtz_candidates");
-						for(uint32_t k = 0; k < m; k++){ memcpy(E->rows + (size_t)ids[a + k] * E->stride, tmp_rows + (size_t)k * E->stride, (size_t)E->stride * 8); E->nrow[ids[a + k]] = tmp_n[k]; }
-						free(tmp_rows); free(tmp_n);
-					}
-				} else candidates_chunk(E, ids, n);
+		/* ---- queries: pipelined batches on n_workers contexts (own stream + pool each, indexes shared) ---- */
+		{
+			const uint32_t qbeg = E->st.n_qr ? n_rd : 0;
+			E->qend = E->st.n_qr ? n_rd + E->st.n_qr : n_rd;
+			E->cursor = qbeg; E->B = E->max_batch < E->first_batch ? E->max_batch : E->first_batch;
+			E->next_seq = 0; E->commit_seq = 0;
+			uint32_t nw = E->rows_all ? 1 : E->n_workers;          /* -G keeps per-read heaps that the commit rewrites: one batch at a time */
+			batch_t *bs = (batch_t*)calloc(nw, sizeof(batch_t)); pthread_t *th = (pthread_t*)calloc(nw, sizeof(pthread_t));
+			for(uint32_t w = 0; w < nw; w++){
+				bs[w].E = E;
+				if(w == 0) bs[w].ctx = E->ctx;
+				else { rc = wtz_ctx_clone(E->ctx, pool_gb << 30, &bs[w].ctx); DIE_WTZ(rc, "wtz_ctx_clone"); }
 			}
-			/* next batch: up to B plannable queries before chunk_end */
-			E->nbq = 0;
-			uint32_t j = cursor;
-			for(; j < chunk_end && E->nbq < B; j++){
-				if((j % E->n_job) != E->i_job) continue;
-				if(E->masked[j]) continue;
-				/* reads whose coverage is already saturated (wtzmo.c:808) need no GPU work but stay in the dispatch
-				 * sequence: their dispatch is what merges the previous query's masks (one-query masking lag) */
-				E->bq[E->nbq++] = j;
+			for(uint32_t w = 1; w < nw; w++) pthread_create(&th[w], NULL, worker_main, &bs[w]);
+			worker_main(&bs[0]);
+			for(uint32_t w = 1; w < nw; w++) pthread_join(th[w], NULL);
+			for(uint32_t w = 0; w < nw; w++){
+				wtz_counters_t cw; wtz_get_counters(bs[w].ctx, &cw);
+				if(w){ E->extra_ms[0] += cw.ms_candidates; E->extra_ms[1] += cw.ms_pairs; E->extra_ms[2] += cw.ms_winalign; E->extra_ms[3] += cw.ms_stitch; E->extra_ms[4] += cw.ms_ext;
+					E->extra_u64[0] += cw.cells_shift; E->extra_u64[1] += cw.cells_fixed; E->extra_u64[2] += cw.cells_global; E->extra_u64[3] += cw.bytes_seed_algo; E->extra_u64[4] += cw.n_extjobs;
+					if(cw.pool_peak > E->extra_u64[5]) E->extra_u64[5] = cw.pool_peak;
+					wtz_ctx_destroy(bs[w].ctx); }
+				free(bs[w].bq); free(bs[w].want); free(bs[w].ids); free(bs[w].rows); free(bs[w].nrow); free(bs[w].pq); free(bs[w].pc); free(bs[w].rowpair); free(bs[w].sum);
+				free(bs[w].box_off); free(bs[w].boxes); free(bs[w].item_of); free(bs[w].it_pair); free(bs[w].it_dir); free(bs[w].aln); free(bs[w].cig);
 			}
-			cursor = j;
-			if(E->nbq == 0) continue;
-			const uint64_t sq0 = E->spec_queries, uq0 = E->used_queries;
-			if(run_batch(E)){
-				if(E->nbq <= 1){ fprintf(stderr, " -- device scratch pool too small even for one query: %s (use --pool-gb) --\n", wtz_last_error()); exit(1); }
-				fprintf(stderr, "[wtzmo-mi355x] scratch pool exhausted with %u queries in flight; retrying with %u\n", E->nbq, E->nbq / 2);
-				cursor = E->bq[0]; B = E->nbq / 2;
-				continue;
-			}
-			/* adapt: grow while most planned queries were really processed */
-			const uint64_t planned = E->spec_queries - sq0, used = E->used_queries - uq0;
-			if(used * 4 >= planned * 3){ if(B < E->max_batch) B = B * 4 > E->max_batch ? E->max_batch : B * 4; }
-			else if(used * 2 < planned){ if(B > 8) B /= 2; }
-			if(B > E->max_batch) B = E->max_batch;
+			free(bs); free(th);
 		}
 		flush_pending(E);
 		const double t1 = now_s();
 		if(strcmp(output, "-")) fclose(E->out); else fflush(stdout);
 		if(g_hook) g_hook(rep, 1);
 		wtz_counters_t cn; wtz_get_counters(E->ctx, &cn);
+		cn.ms_candidates += E->extra_ms[0]; cn.ms_pairs += E->extra_ms[1]; cn.ms_winalign += E->extra_ms[2]; cn.ms_stitch += E->extra_ms[3]; cn.ms_ext += E->extra_ms[4];
+		cn.cells_shift += E->extra_u64[0]; cn.cells_fixed += E->extra_u64[1]; cn.cells_global += E->extra_u64[2]; cn.bytes_seed_algo += E->extra_u64[3]; cn.n_extjobs += E->extra_u64[4];
+		if(E->extra_u64[5] > cn.pool_peak) cn.pool_peak = E->extra_u64[5];
+		memset(E->extra_ms, 0, sizeof E->extra_ms); memset(E->extra_u64, 0, sizeof E->extra_u64);
 		fprintf(stderr, "[wtzmo-mi355x] %llu records, %llu pairs aligned, %llu pair-bp, %.3f s (index %.3f s)\n", (unsigned long long)E->nrec, (unsigned long long)E->n_pairs, (unsigned long long)E->pair_bp, t1 - t0, t_index);
 		fprintf(stderr, "[wtzmo-mi355x] host seconds: in GPU-stage calls %.3f, commit %.3f\n", E->t_gpu, E->t_commit);
-	fprintf(stderr, "[wtzmo-mi355x] speculation: queries %llu/%llu pairs %llu/%llu alignments %llu/%llu (used/planned)\n",
-			(unsigned long long)E->used_queries, (unsigned long long)E->spec_queries, (unsigned long long)E->used_pairs, (unsigned long long)E->spec_pairs, (unsigned long long)E->used_items, (unsigned long long)E->spec_items);
+	fprintf(stderr, "[wtzmo-mi355x] %llu batches on %u worker context(s); speculation: queries %llu/%llu pairs %llu/%llu alignments %llu/%llu (used/planned)\n",
+			(unsigned long long)E->n_batches, E->rows_all ? 1u : E->n_workers, (unsigned long long)E->used_queries, (unsigned long long)E->spec_queries, (unsigned long long)E->used_pairs, (unsigned long long)E->spec_pairs, (unsigned long long)E->used_items, (unsigned long long)E->spec_items);
 		fprintf(stderr, "[wtzmo-mi355x] kernel ms: index %.1f zindex %.1f candidates %.1f pairs %.1f winalign %.1f stitch %.1f (K-sw3 wave %.1f); cells shift %llu; pool peak %.2f GB\n",
 			cn.ms_index, cn.ms_zindex, cn.ms_candidates, cn.ms_pairs, cn.ms_winalign, cn.ms_stitch, cn.ms_ext, (unsigned long long)cn.cells_shift, cn.pool_peak / 1073741824.0);
 		if(statsf){ FILE *sf = fopen(statsf, "a"); if(sf){ fprintf(sf, "%llu\t%llu\t%.6f\t%.6f\t%.3f\t%.3f\t%.3f\t%.3f\t%.3f\t%.3f\t%llu\t%llu\t%llu\t%llu\t%llu\t%.3f\t%llu\t%llu\t%llu\n", (unsigned long long)E->n_pairs, (unsigned long long)E->pair_bp, t1 - t0, t_index,

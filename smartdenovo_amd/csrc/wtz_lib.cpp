@@ -22,7 +22,7 @@
 /* ------------------------------------------------------------------------------------------------ */
 /* device abstraction                                                                               */
 /* ------------------------------------------------------------------------------------------------ */
-static char g_err[512] = "";
+static thread_local char g_err[512] = "";
 static int wtz_fail(int code, const char *fmt, ...){
 	va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof g_err, fmt, ap); va_end(ap);
 	return code;
@@ -32,6 +32,9 @@ static int wtz_fail(int code, const char *fmt, ...){
 #include <hip/hip_runtime.h>
 #include <rocprim/rocprim.hpp>
 #define WTZ_LAMBDA __device__
+/* every context owns a non-blocking HIP stream; the API entry points make it current for the calling host thread, so that
+ * two host threads can drive two contexts (two batches in flight) whose kernels and copies overlap on the device */
+static thread_local hipStream_t g_stream = 0;
 #define HIPCHK(call) do { hipError_t e_ = (call); if(e_ != hipSuccess) return wtz_fail(WTZ_E_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); } while(0)
 
 /* TAG only names the kernel (rocprofv3 shows wtz_kernel_tasks<K_pair_seed, ...>) */
@@ -44,7 +47,7 @@ template<typename TAG, typename F> static int wtz_launch(hipStream_t st, uint64_
 	const uint32_t bs = 64;
 	uint64_t nb = (n + bs - 1) / bs;
 	if(nb > 0x7FFFFFFFull) return wtz_fail(WTZ_E_ARG, "grid too large");
-	hipLaunchKernelGGL((wtz_kernel_tasks<TAG, F>), dim3((uint32_t)nb), dim3(bs), 0, st, n, f);
+	(void)st; hipLaunchKernelGGL((wtz_kernel_tasks<TAG, F>), dim3((uint32_t)nb), dim3(bs), 0, g_stream, n, f);
 	HIPCHK(hipGetLastError());
 	return WTZ_OK;
 }
@@ -62,32 +65,50 @@ template<typename TAG, typename F> __global__ void __launch_bounds__(64) wtz_ker
 	const uint64_t i = blockIdx.x;
 	if(i < n) f(i);
 }
-template<typename TAG, typename F> static int wtz_launch_coop(hipStream_t st, uint64_t n, F f){
+template<typename TAG, typename F> static int wtz_launch_coop(hipStream_t st, uint64_t n, F f, uint32_t lds_bytes = WTZ_WAVE_LDS_BYTES){
 	if(n == 0) return WTZ_OK;
 	if(n > 0x7FFFFFFFull) return wtz_fail(WTZ_E_ARG, "grid too large");
-	hipLaunchKernelGGL((wtz_kernel_coop_tasks<TAG, F>), dim3((uint32_t)n), dim3(64), WTZ_WAVE_LDS_BYTES, st, n, f);
+	(void)st; hipLaunchKernelGGL((wtz_kernel_coop_tasks<TAG, F>), dim3((uint32_t)n), dim3(64), lds_bytes, g_stream, n, f);
 	HIPCHK(hipGetLastError());
 	return WTZ_OK;
 }
 template<typename TAG, typename F> static int wtz_launch_wave(hipStream_t st, uint64_t n, F f){
 	if(n == 0) return WTZ_OK;
 	if(n > 0x7FFFFFFFull) return wtz_fail(WTZ_E_ARG, "grid too large");
-	hipLaunchKernelGGL((wtz_kernel_wave_tasks<TAG, F>), dim3((uint32_t)n), dim3(64), WTZ_WAVE_LDS_BYTES, st, n, f);
+	(void)st; hipLaunchKernelGGL((wtz_kernel_wave_tasks<TAG, F>), dim3((uint32_t)n), dim3(64), WTZ_WAVE_LDS_BYTES, g_stream, n, f);
 	HIPCHK(hipGetLastError());
 	return WTZ_OK;
 }
-static int dev_alloc(void **p, size_t n){ HIPCHK(hipMalloc(p, n ? n : 16)); return WTZ_OK; }
-static void dev_free(void *p){ if(p) (void)hipFree(p); }
-static int dev_h2d(void *d, const void *h, size_t n){ if(n) HIPCHK(hipMemcpy(d, h, n, hipMemcpyHostToDevice)); return WTZ_OK; }
-static int dev_d2h(void *h, const void *d, size_t n){ if(n) HIPCHK(hipMemcpy(h, d, n, hipMemcpyDeviceToHost)); return WTZ_OK; }
-static int dev_set(void *d, int v, size_t n){ if(n) HIPCHK(hipMemset(d, v, n)); return WTZ_OK; }
-static int dev_sync(){ HIPCHK(hipDeviceSynchronize()); return WTZ_OK; }
+/* transient buffers: stream-ordered allocation (no device-wide synchronisation, memory is recycled by the HIP mem pool);
+ * long-lived buffers (reads, indexes, scratch pool): plain hipMalloc */
+/* transient device buffers come from a per-context arena (host-side bump pointer over one persistent allocation, released
+ * stack-wise when the API call returns): no hipMalloc/hipFree - and therefore no device-wide synchronisation - on the batch
+ * path, which is what lets two contexts overlap.  Requests that do not fit fall back to hipMalloc and are freed at release. */
+struct wtz_arena { uint8_t *base; size_t cap, top; std::vector<void*> overflow; };
+static thread_local wtz_arena *g_arena = NULL;
+static int dev_alloc(void **p, size_t n){
+	n = (n + 255) & ~(size_t)255; if(n == 0) n = 256;
+	if(g_arena && g_arena->top + n <= g_arena->cap){ *p = g_arena->base + g_arena->top; g_arena->top += n; return WTZ_OK; }
+	HIPCHK(hipMalloc(p, n));
+	if(g_arena) g_arena->overflow.push_back(*p);
+	return WTZ_OK;
+}
+static void dev_free(void *){ /* released by the arena scope of the API call */ }
+struct wtz_arena_scope { wtz_arena *a; size_t mark; size_t nover;
+	wtz_arena_scope(wtz_arena *ar) : a(ar), mark(ar ? ar->top : 0), nover(ar ? ar->overflow.size() : 0) { g_arena = ar; }
+	~wtz_arena_scope(){ if(!a) return; if(a->overflow.size() > nover){ (void)hipStreamSynchronize(g_stream); while(a->overflow.size() > nover){ (void)hipFree(a->overflow.back()); a->overflow.pop_back(); } } a->top = mark; } };
+static int dev_alloc_persist(void **p, size_t n){ HIPCHK(hipMalloc(p, n ? n : 16)); return WTZ_OK; }
+static void dev_free_persist(void *p){ if(p) (void)hipFree(p); }
+static int dev_h2d(void *d, const void *h, size_t n){ if(n){ HIPCHK(hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, g_stream)); HIPCHK(hipStreamSynchronize(g_stream)); } return WTZ_OK; }
+static int dev_d2h(void *h, const void *d, size_t n){ if(n){ HIPCHK(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, g_stream)); HIPCHK(hipStreamSynchronize(g_stream)); } return WTZ_OK; }
+static int dev_set(void *d, int v, size_t n){ if(n) HIPCHK(hipMemsetAsync(d, v, n, g_stream)); return WTZ_OK; }
+static int dev_sync(){ HIPCHK(hipStreamSynchronize(g_stream)); return WTZ_OK; }
 
 struct wtz_timer { hipEvent_t a, b; bool ok;
 	wtz_timer(){ ok = hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess; }
 	~wtz_timer(){ if(ok){ (void)hipEventDestroy(a); (void)hipEventDestroy(b); } }
-	void start(){ if(ok) (void)hipEventRecord(a, 0); }
-	double stop(){ float ms = 0; if(ok){ (void)hipEventRecord(b, 0); (void)hipEventSynchronize(b); (void)hipEventElapsedTime(&ms, a, b); } return ms; } };
+	void start(){ if(ok) (void)hipEventRecord(a, g_stream); }
+	double stop(){ float ms = 0; if(ok){ (void)hipEventRecord(b, g_stream); (void)hipEventSynchronize(b); (void)hipEventElapsedTime(&ms, a, b); } return ms; } };
 
 static int dev_sort_pairs_u64_u32(uint64_t *keys, uint32_t *vals, uint64_t n, unsigned end_bit){
 	if(n < 2) return WTZ_OK;
@@ -95,11 +116,11 @@ static int dev_sort_pairs_u64_u32(uint64_t *keys, uint32_t *vals, uint64_t n, un
 	if((rc = dev_alloc((void**)&k2, n * 8))) return rc;
 	if((rc = dev_alloc((void**)&v2, n * 4))){ dev_free(k2); return rc; }
 	rocprim::double_buffer<uint64_t> kb(keys, k2); rocprim::double_buffer<uint32_t> vb(vals, v2);
-	hipError_t e = rocprim::radix_sort_pairs(tmp, tmp_bytes, kb, vb, (size_t)n, 0u, end_bit, 0);
+	hipError_t e = rocprim::radix_sort_pairs(tmp, tmp_bytes, kb, vb, (size_t)n, 0u, end_bit, g_stream);
 	if(e == hipSuccess && (rc = dev_alloc(&tmp, tmp_bytes)) == WTZ_OK){
-		e = rocprim::radix_sort_pairs(tmp, tmp_bytes, kb, vb, (size_t)n, 0u, end_bit, 0);
-		if(e == hipSuccess) e = hipDeviceSynchronize();
-		if(e == hipSuccess && kb.current() != keys){ e = hipMemcpy(keys, kb.current(), n * 8, hipMemcpyDeviceToDevice); if(e == hipSuccess) e = hipMemcpy(vals, vb.current(), n * 4, hipMemcpyDeviceToDevice); }
+		e = rocprim::radix_sort_pairs(tmp, tmp_bytes, kb, vb, (size_t)n, 0u, end_bit, g_stream);
+		if(e == hipSuccess) e = hipStreamSynchronize(g_stream);
+		if(e == hipSuccess && kb.current() != keys){ e = hipMemcpyAsync(keys, kb.current(), n * 8, hipMemcpyDeviceToDevice, g_stream); if(e == hipSuccess) e = hipMemcpyAsync(vals, vb.current(), n * 4, hipMemcpyDeviceToDevice, g_stream); if(e == hipSuccess) e = hipStreamSynchronize(g_stream); }
 	}
 	dev_free(tmp); dev_free(k2); dev_free(v2);
 	if(e != hipSuccess) return wtz_fail(WTZ_E_HIP, "radix_sort_pairs failed: %s", hipGetErrorString(e));
@@ -110,9 +131,13 @@ static int dev_sort_pairs_u64_u32(uint64_t *keys, uint32_t *vals, uint64_t n, un
 typedef int hipStream_t;
 template<typename TAG, typename F> static int wtz_launch(hipStream_t, uint64_t n, F f){ for(uint64_t i = 0; i < n; i++) f(i); return WTZ_OK; }
 template<typename TAG, typename F> static int wtz_launch_wave(hipStream_t st, uint64_t n, F f){ return wtz_launch<TAG>(st, n, f); }
-template<typename TAG, typename F> static int wtz_launch_coop(hipStream_t st, uint64_t n, F f){ return wtz_launch<TAG>(st, n, f); }
+template<typename TAG, typename F> static int wtz_launch_coop(hipStream_t st, uint64_t n, F f, uint32_t = 0){ return wtz_launch<TAG>(st, n, f); }
 static int dev_alloc(void **p, size_t n){ *p = malloc(n ? n : 16); return *p ? WTZ_OK : wtz_fail(WTZ_E_HIP, "malloc(%zu) failed", n); }
 static void dev_free(void *p){ free(p); }
+static int dev_alloc_persist(void **p, size_t n){ return dev_alloc(p, n); }
+static void dev_free_persist(void *p){ free(p); }
+struct wtz_arena { int unused; };
+struct wtz_arena_scope { std::vector<void*> *keep; wtz_arena_scope(wtz_arena*){ } };
 static int dev_h2d(void *d, const void *h, size_t n){ if(n) memcpy(d, h, n); return WTZ_OK; }
 static int dev_d2h(void *h, const void *d, size_t n){ if(n) memcpy(h, d, n); return WTZ_OK; }
 static int dev_set(void *d, int v, size_t n){ if(n) memset(d, v, n); return WTZ_OK; }
@@ -154,6 +179,12 @@ struct K_zcount;
 /* ------------------------------------------------------------------------------------------------ */
 struct wtz_ctx {
 	int device;
+#ifndef WTZ_EMUL
+	hipStream_t stream;
+#endif
+	bool shares_indexes;      /* clone: reads / k-mer table / z-index belong to the parent context */
+	wtz_arena arena;          /* transient device buffers of the API call in progress */
+	uint32_t cap_pairs, cap_items;     /* grow-only capacity of the per-batch result arrays */
 	wtz_params_t P; wtz_params_t *dP;
 	/* reads */
 	uint64_t *bits; uint64_t n_words; uint64_t *rdoff; uint32_t *rdlen; uint32_t n_reads;
@@ -167,8 +198,15 @@ struct wtz_ctx {
 	/* per-batch results */
 	uint32_t *d_qid, *d_cid; wtz_pairres_t *d_pairres; uint32_t n_pairs; std::vector<wtz_pairres_t> h_pairres;
 	wtz_alnres_dev_t *d_alnres; uint32_t n_items; std::vector<wtz_alnres_dev_t> h_alnres;
+	bool have_pairs, have_items;
 	wtz_counters_t cnt;
 };
+
+#ifndef WTZ_EMUL
+#define CTX_ENTER(c) (void)hipSetDevice((c)->device); g_stream = (c)->stream; wtz_arena_scope arena_scope_(&(c)->arena)
+#else
+#define CTX_ENTER(c) wtz_arena_scope arena_scope_(&(c)->arena)
+#endif
 
 static wtz_reads_t ctx_reads(const wtz_ctx *c){ wtz_reads_t R; R.bits = c->bits; R.rdoff = c->rdoff; R.rdlen = c->rdlen; R.n_reads = c->n_reads; return R; }
 static wtz_env_t ctx_env(const wtz_ctx *c){ wtz_env_t V; V.R = ctx_reads(c); V.Z = c->Z; V.P = c->dP; V.pool = c->dpool; return V; }
@@ -205,7 +243,12 @@ extern "C" int wtz_ctx_create(int device, const wtz_params_c *params, uint64_t p
 	HIPCHK(hipSetDevice(device));
 #endif
 	wtz_ctx *c = new wtz_ctx();
-	c->device = device; c->P = *params; c->dP = NULL;
+	c->device = device; c->P = *params; c->dP = NULL; c->shares_indexes = false;
+#ifndef WTZ_EMUL
+	c->stream = 0;
+	if(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess){ delete c; return wtz_fail(WTZ_E_HIP, "hipStreamCreate failed"); }
+	g_stream = c->stream;
+#endif
 	c->bits = NULL; c->rdoff = NULL; c->rdlen = NULL; c->n_reads = 0; c->n_words = 0;
 	c->ktab = NULL; c->kseeds = NULL; c->kmask = 0; c->n_kocc = 0;
 	c->zoff = NULL; c->n_z = 0; memset(&c->Z, 0, sizeof c->Z); c->have_z = false;
@@ -217,43 +260,94 @@ extern "C" int wtz_ctx_create(int device, const wtz_params_c *params, uint64_t p
 		if(c->pool_bytes > (24ull << 30)) c->pool_bytes = 24ull << 30;      /* the host driver halves its batch on WTZ_E_POOL */
 	}
 #endif
-	c->d_qid = c->d_cid = NULL; c->d_pairres = NULL; c->n_pairs = 0; c->d_alnres = NULL; c->n_items = 0;
+	c->d_qid = c->d_cid = NULL; c->d_pairres = NULL; c->n_pairs = 0; c->d_alnres = NULL; c->n_items = 0; c->have_pairs = c->have_items = false;
 	memset(&c->cnt, 0, sizeof c->cnt);
+	c->cap_pairs = c->cap_items = 0;
+#ifndef WTZ_EMUL
+	c->arena.base = NULL; c->arena.cap = 0; c->arena.top = 0;
+	{ void *ab = NULL; const size_t acap = (size_t)3 << 29;      /* 1.5 GB */
+	  if(hipMalloc(&ab, acap) == hipSuccess){ c->arena.base = (uint8_t*)ab; c->arena.cap = acap; } }
+#endif
 	int rc;
-	if((rc = dev_alloc((void**)&c->dP, sizeof(wtz_params_t))) || (rc = dev_h2d(c->dP, &c->P, sizeof(wtz_params_t))) ||
-	   (rc = dev_alloc((void**)&c->dpool, sizeof(wtz_pool_t))) || (rc = dev_alloc((void**)&c->pool_base, c->pool_bytes)) || (rc = pool_reset(c))){
+	if((rc = dev_alloc_persist((void**)&c->dP, sizeof(wtz_params_t))) || (rc = dev_h2d(c->dP, &c->P, sizeof(wtz_params_t))) ||
+	   (rc = dev_alloc_persist((void**)&c->dpool, sizeof(wtz_pool_t))) || (rc = dev_alloc_persist((void**)&c->pool_base, c->pool_bytes)) || (rc = pool_reset(c))){
 		wtz_ctx_destroy(c); return rc;
 	}
 	*out = c;
 	return WTZ_OK;
 }
 
-static void free_kindex(wtz_ctx *c){ dev_free(c->ktab); dev_free(c->kseeds); c->ktab = NULL; c->kseeds = NULL; c->kmask = 0; }
+static void free_kindex(wtz_ctx *c){ if(!c->shares_indexes){ dev_free_persist(c->ktab); dev_free_persist(c->kseeds); } c->ktab = NULL; c->kseeds = NULL; c->kmask = 0; }
 static void free_zindex(wtz_ctx *c){
-	dev_free(c->zoff); dev_free(c->Z.mer); dev_free(c->Z.pos); dev_free(c->Z.len); dev_free(c->Z.ok); dev_free(c->Z.sidx);
-	dev_free(c->Z.dmer); dev_free(c->Z.dfirst); dev_free(c->Z.dcnt); dev_free(c->Z.dn);
+	if(!c->shares_indexes){
+		dev_free_persist(c->zoff); dev_free_persist(c->Z.mer); dev_free_persist(c->Z.pos); dev_free_persist(c->Z.len); dev_free_persist(c->Z.ok); dev_free_persist(c->Z.sidx);
+		dev_free_persist(c->Z.dmer); dev_free_persist(c->Z.dfirst); dev_free_persist(c->Z.dcnt); dev_free_persist(c->Z.dn);
+	}
 	c->zoff = NULL; memset(&c->Z, 0, sizeof c->Z); c->have_z = false;
 }
-static void free_batch(wtz_ctx *c){
-	dev_free(c->d_qid); dev_free(c->d_cid); dev_free(c->d_pairres); dev_free(c->d_alnres);
-	c->d_qid = c->d_cid = NULL; c->d_pairres = NULL; c->d_alnres = NULL; c->n_pairs = 0; c->n_items = 0;
+static void free_batch(wtz_ctx *c){ c->n_pairs = 0; c->n_items = 0; c->have_pairs = false; c->have_items = false; }
+static void free_batch_storage(wtz_ctx *c){
+	dev_free_persist(c->d_qid); dev_free_persist(c->d_cid); dev_free_persist(c->d_pairres); dev_free_persist(c->d_alnres);
+	c->d_qid = c->d_cid = NULL; c->d_pairres = NULL; c->d_alnres = NULL; c->cap_pairs = c->cap_items = 0; free_batch(c);
+}
+static int reserve_pairs(wtz_ctx *c, uint32_t n){
+	if(n <= c->cap_pairs && c->d_pairres) return WTZ_OK;
+	uint32_t cap = c->cap_pairs ? c->cap_pairs : 4096; while(cap < n) cap *= 2;
+	(void)dev_sync();
+	dev_free_persist(c->d_qid); dev_free_persist(c->d_cid); dev_free_persist(c->d_pairres); c->d_qid = c->d_cid = NULL; c->d_pairres = NULL; c->cap_pairs = 0;
+	CHK(dev_alloc_persist((void**)&c->d_qid, (size_t)cap * 4)); CHK(dev_alloc_persist((void**)&c->d_cid, (size_t)cap * 4));
+	CHK(dev_alloc_persist((void**)&c->d_pairres, (size_t)cap * sizeof(wtz_pairres_t)));
+	c->cap_pairs = cap; return WTZ_OK;
+}
+static int reserve_items(wtz_ctx *c, uint32_t m){
+	if(m <= c->cap_items && c->d_alnres) return WTZ_OK;
+	uint32_t cap = c->cap_items ? c->cap_items : 4096; while(cap < m) cap *= 2;
+	(void)dev_sync();
+	dev_free_persist(c->d_alnres); c->d_alnres = NULL; c->cap_items = 0;
+	CHK(dev_alloc_persist((void**)&c->d_alnres, (size_t)cap * sizeof(wtz_alnres_dev_t)));
+	c->cap_items = cap; return WTZ_OK;
 }
 
 extern "C" void wtz_ctx_destroy(wtz_ctx_t *c){
 	if(!c) return;
-	free_batch(c); free_kindex(c); free_zindex(c);
-	dev_free(c->bits); dev_free(c->rdoff); dev_free(c->rdlen);
-	dev_free(c->dP); dev_free(c->dpool); dev_free(c->pool_base);
+	{ CTX_ENTER(c); (void)dev_sync(); }
+	free_batch_storage(c); free_kindex(c); free_zindex(c);
+#ifndef WTZ_EMUL
+	if(c->arena.base) (void)hipFree(c->arena.base);
+#endif
+	if(!c->shares_indexes){ dev_free_persist(c->bits); dev_free_persist(c->rdoff); dev_free_persist(c->rdlen); }
+	dev_free_persist(c->dP); dev_free_persist(c->dpool); dev_free_persist(c->pool_base);
+#ifndef WTZ_EMUL
+	if(c->stream) (void)hipStreamDestroy(c->stream);
+#endif
 	delete c;
+}
+
+/* A second context on the same GPU that SHARES the parent's read-only device data (reads, k-mer table, z-index) and has its
+ * own stream, scratch pool and per-batch state: lets a host thread keep another batch in flight.  The parent must outlive the
+ * clone and must not rebuild its indexes while clones are in use (re-clone after wtz_index_build / wtz_zindex_build). */
+extern "C" int wtz_ctx_clone(wtz_ctx_t *p, uint64_t pool_bytes, wtz_ctx_t **out){
+	if(!p || !out) return wtz_fail(WTZ_E_ARG, "null argument");
+	wtz_ctx_t *c = NULL;
+	int rc = wtz_ctx_create(p->device, &p->P, pool_bytes ? pool_bytes : p->pool_bytes, &c);
+	if(rc) return rc;
+	c->shares_indexes = true;
+	c->bits = p->bits; c->n_words = p->n_words; c->rdoff = p->rdoff; c->rdlen = p->rdlen; c->n_reads = p->n_reads; c->h_rdlen = p->h_rdlen;
+	c->ktab = p->ktab; c->kmask = p->kmask; c->kseeds = p->kseeds; c->n_kocc = p->n_kocc;
+	c->zoff = p->zoff; c->n_z = p->n_z; c->Z = p->Z; c->have_z = p->have_z;
+	*out = c;
+	return WTZ_OK;
 }
 
 extern "C" int wtz_upload_reads(wtz_ctx_t *c, const uint64_t *bits, uint64_t n_words, const uint64_t *rdoff, const uint32_t *rdlen, uint32_t n_reads){
 	if(!c || !bits || !rdoff || !rdlen) return wtz_fail(WTZ_E_ARG, "null argument");
-	dev_free(c->bits); dev_free(c->rdoff); dev_free(c->rdlen); c->bits = NULL; c->rdoff = NULL; c->rdlen = NULL;
+	CTX_ENTER(c);
+	if(c->shares_indexes) return wtz_fail(WTZ_E_STATE, "wtz_upload_reads on a cloned context");
+	dev_free_persist(c->bits); dev_free_persist(c->rdoff); dev_free_persist(c->rdlen); c->bits = NULL; c->rdoff = NULL; c->rdlen = NULL;
 	free_kindex(c); free_zindex(c); free_batch(c);
-	CHK(dev_alloc((void**)&c->bits, (n_words + 2) * 8)); CHK(dev_set(c->bits, 0, (n_words + 2) * 8)); CHK(dev_h2d(c->bits, bits, n_words * 8));
-	CHK(dev_alloc((void**)&c->rdoff, (size_t)n_reads * 8)); CHK(dev_h2d(c->rdoff, rdoff, (size_t)n_reads * 8));
-	CHK(dev_alloc((void**)&c->rdlen, (size_t)n_reads * 4)); CHK(dev_h2d(c->rdlen, rdlen, (size_t)n_reads * 4));
+	CHK(dev_alloc_persist((void**)&c->bits, (n_words + 2) * 8)); CHK(dev_set(c->bits, 0, (n_words + 2) * 8)); CHK(dev_h2d(c->bits, bits, n_words * 8));
+	CHK(dev_alloc_persist((void**)&c->rdoff, (size_t)n_reads * 8)); CHK(dev_h2d(c->rdoff, rdoff, (size_t)n_reads * 8));
+	CHK(dev_alloc_persist((void**)&c->rdlen, (size_t)n_reads * 4)); CHK(dev_h2d(c->rdlen, rdlen, (size_t)n_reads * 4));
 	c->n_words = n_words; c->n_reads = n_reads; c->h_rdlen.assign(rdlen, rdlen + n_reads);
 	return WTZ_OK;
 }
@@ -266,6 +360,8 @@ extern "C" int wtz_index_build(wtz_ctx_t *c, uint32_t id_beg, uint32_t id_end, u
 	if(id_end > c->n_reads) id_end = c->n_reads;
 	if(id_beg > id_end) id_beg = id_end;
 	const uint32_t nr = id_end - id_beg;
+	CTX_ENTER(c);
+	if(c->shares_indexes) return wtz_fail(WTZ_E_STATE, "wtz_index_build on a cloned context");
 	free_kindex(c);
 	wtz_timer tm; tm.start();
 	const wtz_reads_t R = ctx_reads(c); const uint32_t ksize = c->P.ksize, hk = c->P.hk, ksave = c->P.ksave;
@@ -276,7 +372,7 @@ extern "C" int wtz_index_build(wtz_ctx_t *c, uint32_t id_beg, uint32_t id_end, u
 	uint64_t tot = 0; for(uint32_t i = 0; i < nr; i++){ uint64_t v = h_cnt[i]; h_cnt[i] = tot; tot += v; } h_cnt[nr] = tot;
 	CHK(dev_h2d(d_cnt, h_cnt.data(), ((size_t)nr + 1) * 8));
 	uint64_t *d_keys = NULL; uint32_t *d_vals = NULL;
-	CHK(dev_alloc((void**)&d_keys, (tot + 1) * 8)); CHK(dev_alloc((void**)&d_vals, (tot + 1) * 4));
+	CHK(dev_alloc((void**)&d_keys, (tot + 1) * 8)); CHK(dev_alloc_persist((void**)&d_vals, (tot + 1) * 4));
 	CHK(wtz_launch<K_kfill>(0, nr, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_kfill((uint32_t)t, R, id_beg, ksize, hk, ksave, d_cnt, d_keys, d_vals); }));
 	CHK(dev_sync());
 	dev_free(d_cnt);
@@ -292,7 +388,7 @@ extern "C" int wtz_index_build(wtz_ctx_t *c, uint32_t id_beg, uint32_t id_end, u
 	CHK(dev_d2h(h_stat, d_stat, 4 * 8));
 	const uint64_t n_kept = h_stat[2];
 	uint64_t cap = 1024; while(cap < n_kept * 2 + 2) cap <<= 1;
-	CHK(dev_alloc((void**)&c->ktab, cap * sizeof(wtz_kslot_t))); CHK(dev_set(c->ktab, 0xFF, cap * sizeof(wtz_kslot_t)));
+	CHK(dev_alloc_persist((void**)&c->ktab, cap * sizeof(wtz_kslot_t))); CHK(dev_set(c->ktab, 0xFF, cap * sizeof(wtz_kslot_t)));
 	c->kmask = cap - 1;
 	wtz_kslot_t *tab = c->ktab; const uint64_t kmask = c->kmask;
 	CHK(wtz_launch<K_kinsert>(0, tot, [=] WTZ_LAMBDA (uint64_t i){ wtz_task_kinsert(i, d_keys, tot, K, tab, kmask, d_stat + 2); }));
@@ -313,10 +409,12 @@ extern "C" int wtz_index_build(wtz_ctx_t *c, uint32_t id_beg, uint32_t id_end, u
 /* ------------------------------------------------------------------------------------------------ */
 extern "C" int wtz_zindex_build(wtz_ctx_t *c){
 	if(!c || !c->bits) return wtz_fail(WTZ_E_ARG, "reads not uploaded");
+	CTX_ENTER(c);
+	if(c->shares_indexes) return wtz_fail(WTZ_E_STATE, "wtz_zindex_build on a cloned context");
 	free_zindex(c);
 	wtz_timer tm; tm.start();
 	const wtz_reads_t R = ctx_reads(c); const uint32_t nr = c->n_reads, zsize = c->P.zsize, hz = c->P.hz, zcut = c->P.max_zmer_freq;
-	CHK(dev_alloc((void**)&c->zoff, ((size_t)nr + 1) * 8));
+	CHK(dev_alloc_persist((void**)&c->zoff, ((size_t)nr + 1) * 8));
 	uint64_t *d_off = c->zoff;
 	CHK(wtz_launch<K_zcount>(0, nr, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_zcount((uint32_t)t, R, zsize, hz, d_off); }));
 	std::vector<uint64_t> h((size_t)nr + 1);
@@ -325,10 +423,10 @@ extern "C" int wtz_zindex_build(wtz_ctx_t *c){
 	CHK(dev_h2d(d_off, h.data(), ((size_t)nr + 1) * 8));
 	c->n_z = tot;
 	wtz_zindex_t Z; memset(&Z, 0, sizeof Z); Z.zoff = c->zoff;
-	CHK(dev_alloc((void**)&Z.mer, (tot + 1) * 4)); CHK(dev_alloc((void**)&Z.pos, (tot + 1) * 4)); CHK(dev_alloc((void**)&Z.len, (tot + 1) * 2));
-	CHK(dev_alloc((void**)&Z.ok, tot + 1)); CHK(dev_alloc((void**)&Z.sidx, (tot + 1) * 4));
-	CHK(dev_alloc((void**)&Z.dmer, (tot + 1) * 4)); CHK(dev_alloc((void**)&Z.dfirst, (tot + 1) * 4)); CHK(dev_alloc((void**)&Z.dcnt, (tot + 1) * 2));
-	CHK(dev_alloc((void**)&Z.dn, ((size_t)nr + 1) * 4));
+	CHK(dev_alloc_persist((void**)&Z.mer, (tot + 1) * 4)); CHK(dev_alloc_persist((void**)&Z.pos, (tot + 1) * 4)); CHK(dev_alloc_persist((void**)&Z.len, (tot + 1) * 2));
+	CHK(dev_alloc_persist((void**)&Z.ok, tot + 1)); CHK(dev_alloc_persist((void**)&Z.sidx, (tot + 1) * 4));
+	CHK(dev_alloc_persist((void**)&Z.dmer, (tot + 1) * 4)); CHK(dev_alloc_persist((void**)&Z.dfirst, (tot + 1) * 4)); CHK(dev_alloc_persist((void**)&Z.dcnt, (tot + 1) * 2));
+	CHK(dev_alloc_persist((void**)&Z.dn, ((size_t)nr + 1) * 4));
 	c->Z = Z;
 	uint64_t *d_tmp = NULL; CHK(dev_alloc((void**)&d_tmp, (tot + 1) * 8));
 	CHK(wtz_launch_wave<K_zbuild>(0, nr, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_zbuild((uint32_t)t, R, zsize, hz, zcut, Z, d_tmp); }));
@@ -345,6 +443,7 @@ extern "C" int wtz_zindex_build(wtz_ctx_t *c){
 extern "C" int wtz_candidates(wtz_ctx_t *c, const uint32_t *qids, uint32_t nq, uint64_t *cand, uint32_t *ncand_io){
 	if(!c || !c->ktab || !qids || !cand || !ncand_io) return wtz_fail(WTZ_E_ARG, "index not built / null argument");
 	if(nq == 0) return WTZ_OK;
+	CTX_ENTER(c);
 	for(uint32_t i = 0; i < nq; i++) if(qids[i] >= c->n_reads) return wtz_fail(WTZ_E_ARG, "query id %u out of range", qids[i]);
 	CHK(pool_reset(c));
 	const uint32_t stride = c->P.ncand + 1;
@@ -371,27 +470,35 @@ extern "C" int wtz_candidates(wtz_ctx_t *c, const uint32_t *qids, uint32_t nq, u
 /* ------------------------------------------------------------------------------------------------ */
 extern "C" int wtz_batch_begin(wtz_ctx_t *c){
 	if(!c) return wtz_fail(WTZ_E_ARG, "null context");
+	CTX_ENTER(c);
 	free_batch(c);
 	return pool_reset(c);
 }
 
 extern "C" int wtz_pairs_seed(wtz_ctx_t *c, const uint32_t *qid, const uint32_t *cid, uint32_t n, wtz_pair_summary_t *out){
 	if(!c || !c->have_z || (n && (!qid || !cid || !out))) return wtz_fail(WTZ_E_ARG, "z-index not built / null argument");
+	CTX_ENTER(c);
 	free_batch(c);
 	CHK(pool_reset(c));
-	if(n == 0){ CHK(dev_alloc((void**)&c->d_pairres, sizeof(wtz_pairres_t))); c->n_pairs = 0; c->h_pairres.clear(); return WTZ_OK; }
+	if(n == 0){ c->n_pairs = 0; c->h_pairres.clear(); c->have_pairs = true; return WTZ_OK; }
 	for(uint32_t i = 0; i < n; i++) if(qid[i] >= c->n_reads || cid[i] >= c->n_reads) return wtz_fail(WTZ_E_ARG, "pair %u: read id out of range", i);
-	CHK(dev_alloc((void**)&c->d_qid, (size_t)n * 4)); CHK(dev_h2d(c->d_qid, qid, (size_t)n * 4));
-	CHK(dev_alloc((void**)&c->d_cid, (size_t)n * 4)); CHK(dev_h2d(c->d_cid, cid, (size_t)n * 4));
-	CHK(dev_alloc((void**)&c->d_pairres, (size_t)n * sizeof(wtz_pairres_t)));
+	CHK(reserve_pairs(c, n));
+	CHK(dev_h2d(c->d_qid, qid, (size_t)n * 4)); CHK(dev_h2d(c->d_cid, cid, (size_t)n * 4));
 	const wtz_env_t V = ctx_env(c); const uint32_t *dq = c->d_qid, *dc = c->d_cid; wtz_pairres_t *dr = c->d_pairres;
 	wtz_timer tm; tm.start();
-	CHK(wtz_launch_coop<K_pair>(0, n, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_pair((uint32_t)t, V, dq, dc, dr); }));
+	CHK(wtz_launch_coop<K_pair>(0, n, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_pair((uint32_t)t, V, dq, dc, dr); }, WTZ_PAIR_LDS_BYTES));
 	CHK(dev_sync());
 	c->cnt.ms_pairs += tm.stop(); c->cnt.n_pairs += n;
-	c->n_pairs = n; c->h_pairres.resize(n);
+	c->n_pairs = n; c->h_pairres.resize(n); c->have_pairs = true;
 	CHK(dev_d2h(c->h_pairres.data(), c->d_pairres, (size_t)n * sizeof(wtz_pairres_t)));
 	CHK(pool_check(c, "wtz_pairs_seed"));
+	if(getenv("WTZ_PROFILE_PAIR")){
+		uint64_t sum[4] = {0, 0, 0, 0}; uint32_t mx[4] = {0, 0, 0, 0}, arg = 0;
+		for(uint32_t i = 0; i < n; i++){ for(int k = 0; k < 4; k++){ sum[k] += c->h_pairres[i].tick[k]; if(c->h_pairres[i].tick[k] > mx[k]){ mx[k] = c->h_pairres[i].tick[k]; if(k == 3) arg = i; } } }
+		fprintf(stderr, "[pair-profile] n=%u kticks sum match/sort/win/total %llu/%llu/%llu/%llu max %u/%u/%u/%u; slowest pair: hits %u (its match/sort/win %u/%u/%u)\n", n,
+			(unsigned long long)sum[0], (unsigned long long)sum[1], (unsigned long long)sum[2], (unsigned long long)sum[3], mx[0], mx[1], mx[2], mx[3],
+			c->h_pairres[arg].n_hits, c->h_pairres[arg].tick[0], c->h_pairres[arg].tick[1], c->h_pairres[arg].tick[2]);
+	}
 	for(uint32_t i = 0; i < n; i++){
 		const wtz_pairres_t &r = c->h_pairres[i];
 		if(r.bad) return wtz_fail(WTZ_E_POOL, "wtz_pairs_seed: pair %u ran out of scratch", i);
@@ -404,7 +511,8 @@ extern "C" int wtz_pairs_seed(wtz_ctx_t *c, const uint32_t *qid, const uint32_t 
 }
 
 extern "C" int wtz_pairs_windows(wtz_ctx_t *c, wtz_winbox_t *wins, uint64_t n_wins){
-	if(!c || !c->d_pairres) return wtz_fail(WTZ_E_STATE, "wtz_pairs_windows before wtz_pairs_seed");
+	if(!c || !c->have_pairs) return wtz_fail(WTZ_E_STATE, "wtz_pairs_windows before wtz_pairs_seed");
+	CTX_ENTER(c);
 	uint64_t tot = 0; for(uint32_t i = 0; i < c->n_pairs; i++) tot += c->h_pairres[i].nwin[0] + c->h_pairres[i].nwin[1];
 	if(tot != n_wins) return wtz_fail(WTZ_E_ARG, "wtz_pairs_windows: expected room for %llu windows, got %llu", (unsigned long long)tot, (unsigned long long)n_wins);
 	if(tot == 0) return WTZ_OK;
@@ -439,7 +547,7 @@ static int run_extjobs(wtz_ctx *c, const wtz_env_t &V, wtz_extjob_t *d_jobs, uin
 	std::vector<wtz_extjob_t> ref;
 	if(mode == 2){
 		wtz_extjob_t *d_copy = NULL; CHK(dev_alloc((void**)&d_copy, (size_t)m * sizeof(wtz_extjob_t)));
-		HIPCHK(hipMemcpy(d_copy, d_jobs, (size_t)m * sizeof(wtz_extjob_t), hipMemcpyDeviceToDevice));
+		HIPCHK(hipMemcpyAsync(d_copy, d_jobs, (size_t)m * sizeof(wtz_extjob_t), hipMemcpyDeviceToDevice, g_stream));
 		CHK(wtz_launch_wave<K_extjob_scalar>(0, m, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_extjob_scalar((uint32_t)t, V, d_copy); }));
 		CHK(dev_sync());
 		ref.resize(m); CHK(dev_d2h(ref.data(), d_copy, (size_t)m * sizeof(wtz_extjob_t)));
@@ -458,7 +566,7 @@ static int run_extjobs(wtz_ctx *c, const wtz_env_t &V, wtz_extjob_t *d_jobs, uin
 	}
 	{
 		wtz_timer te; te.start();
-		hipLaunchKernelGGL((wtz_kernel_extjobs<2048, 1032>), dim3(m), dim3(64), 0, 0, d_jobs, (const uint32_t*)d_order, m, V.P, V.pool);
+		hipLaunchKernelGGL((wtz_kernel_extjobs<2048, 1032>), dim3(m), dim3(64), 0, g_stream, d_jobs, (const uint32_t*)d_order, m, V.P, V.pool);
 		HIPCHK(hipGetLastError());
 		c->cnt.ms_ext += te.stop(); c->cnt.n_extjobs += m;
 		dev_free(d_order);
@@ -484,10 +592,12 @@ static int run_extjobs(wtz_ctx *c, const wtz_env_t &V, wtz_extjob_t *d_jobs, uin
 }
 
 extern "C" int wtz_pairs_align(wtz_ctx_t *c, const uint32_t *pair_idx, const uint8_t *dir, uint32_t m, wtz_aln_result_t *out){
-	if(!c || !c->d_pairres) return wtz_fail(WTZ_E_STATE, "wtz_pairs_align before wtz_pairs_seed");
+	if(!c || !c->have_pairs) return wtz_fail(WTZ_E_STATE, "wtz_pairs_align before wtz_pairs_seed");
 	if(m == 0) return WTZ_OK;
+	CTX_ENTER(c);
 	if(!pair_idx || !dir || !out) return wtz_fail(WTZ_E_ARG, "null argument");
-	dev_free(c->d_alnres); c->d_alnres = NULL; c->n_items = 0;
+	c->n_items = 0; c->have_items = false;
+	CHK(reserve_items(c, m));
 	std::vector<wtz_alnitem_t> items(m); std::vector<wtz_wintask_t> wt; uint64_t nreg = 0;
 	std::vector<uint32_t> h_q(c->n_pairs), h_c(c->n_pairs);
 	CHK(dev_d2h(h_q.data(), c->d_qid, (size_t)c->n_pairs * 4)); CHK(dev_d2h(h_c.data(), c->d_cid, (size_t)c->n_pairs * 4));
@@ -504,7 +614,6 @@ extern "C" int wtz_pairs_align(wtz_ctx_t *c, const uint32_t *pair_idx, const uin
 	for(uint32_t i = 0; i < m; i++) items[i].regs = d_regs + (uintptr_t)items[i].regs;
 	CHK(dev_alloc((void**)&d_items, (size_t)m * sizeof(wtz_alnitem_t))); CHK(dev_h2d(d_items, items.data(), (size_t)m * sizeof(wtz_alnitem_t)));
 	CHK(dev_alloc((void**)&d_wt, (wt.size() + 1) * sizeof(wtz_wintask_t))); CHK(dev_h2d(d_wt, wt.data(), wt.size() * sizeof(wtz_wintask_t)));
-	CHK(dev_alloc((void**)&c->d_alnres, (size_t)m * sizeof(wtz_alnres_dev_t)));
 	const wtz_env_t V = ctx_env(c); wtz_alnres_dev_t *d_res = c->d_alnres;
 	wtz_timer tm; tm.start();
 	CHK(wtz_launch_coop<K_winalign>(0, wt.size(), [=] WTZ_LAMBDA (uint64_t t){ wtz_task_winalign((uint32_t)t, V, d_wt, d_items); }));
@@ -527,7 +636,7 @@ extern "C" int wtz_pairs_align(wtz_ctx_t *c, const uint32_t *pair_idx, const uin
 		dev_free(d_st); dev_free(d_jl); dev_free(d_jr); dev_free(d_gaps);
 	}
 	c->cnt.ms_stitch += tm.stop(); c->cnt.n_stitch += m;
-	c->h_alnres.resize(m); c->n_items = m;
+	c->h_alnres.resize(m); c->n_items = m; c->have_items = true;
 	CHK(dev_d2h(c->h_alnres.data(), c->d_alnres, (size_t)m * sizeof(wtz_alnres_dev_t)));
 	dev_free(d_regs); dev_free(d_items); dev_free(d_wt);
 	CHK(pool_check(c, "wtz_pairs_align"));
@@ -545,7 +654,8 @@ extern "C" int wtz_pairs_align(wtz_ctx_t *c, const uint32_t *pair_idx, const uin
 }
 
 extern "C" int wtz_fetch_cigars(wtz_ctx_t *c, uint32_t *dst, uint64_t n_ops){
-	if(!c || !c->d_alnres) return wtz_fail(WTZ_E_STATE, "wtz_fetch_cigars before wtz_pairs_align");
+	if(!c || !c->have_items) return wtz_fail(WTZ_E_STATE, "wtz_fetch_cigars before wtz_pairs_align");
+	CTX_ENTER(c);
 	uint64_t tot = 0; for(uint32_t i = 0; i < c->n_items; i++) tot += c->h_alnres[i].cigar_len;
 	if(tot != n_ops) return wtz_fail(WTZ_E_ARG, "wtz_fetch_cigars: expected room for %llu ops, got %llu", (unsigned long long)tot, (unsigned long long)n_ops);
 	if(tot == 0) return WTZ_OK;

@@ -19,6 +19,7 @@ typedef struct {
 } wtz_env_t;
 
 #define WTZ_WAVE_LDS_BYTES 8192
+#define WTZ_PAIR_LDS_BYTES 16384     /* K_pair: LDS slice of the small exact sorts (2048 words) */
 /* the LDS slice of the wave running the current task (wave-task kernels carry WTZ_WAVE_LDS_BYTES of dynamic LDS) */
 #if defined(__HIP_DEVICE_COMPILE__)
 WTZ_D int32_t *wtz_wave_scratch(){ extern __shared__ int32_t wtz_dyn_lds[]; return wtz_dyn_lds; }
@@ -32,12 +33,25 @@ WTZ_HD void wtz_task_pair(uint32_t t, const wtz_env_t &V, const uint32_t *qid, c
 	const uint32_t q = qid[t], c = cid[t];
 	wtz_pairres_t r; memset(&r, 0, sizeof r);
 	wtz_zhit_t *hits = NULL; uint32_t n = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+#define WTZ_TICK() ((uint64_t)clock64())
+#else
+#define WTZ_TICK() ((uint64_t)0)
+#endif
+	const uint64_t tk0 = WTZ_TICK();
 	const bool ok = wtz_zmatch_coop(V.Z, q, c, V.R.rdlen[c], P->max_kmer_var, V.pool, &hits, &n);
+	const uint64_t tk1 = WTZ_TICK();
+	wtz_zhit_t *sorted = NULL;
 #if defined(__HIP_DEVICE_COMPILE__)
 	__threadfence_block();
+	if(ok && !P->dot_matrix && n * P->zsize >= P->ztot){      /* uniform: the (off1,off2) order of the zmo engine, wave-parallel when tie-free */
+		int pbad = 0;
+		sorted = wtz_sort_hits_wave(hits, n, V.pool, (uint64_t*)wtz_wave_scratch(), WTZ_PAIR_LDS_BYTES / 8, &pbad);
+		if(pbad) r.bad = 1;
+	}
 #endif
 	if(WTZ_LANE != 0) return;
-	if(!ok){ r.bad = 1; res[t] = r; return; }
+	if(!ok || r.bad){ r.bad = 1; res[t] = r; return; }
 	r.n_hits = n;
 	if(n * P->zsize < P->ztot){ r.gate = 0; res[t] = r; return; }
 	r.gate = 1;
@@ -47,11 +61,15 @@ WTZ_HD void wtz_task_pair(uint32_t t, const wtz_env_t &V, const uint32_t *qid, c
 		r.dm_score = d.score; r.dm_qb = d.qb; r.dm_qe = d.qe; r.dm_tb = d.tb; r.dm_te = d.te; r.dm_dir = d.dir;
 		res[t] = r; return;
 	}
-	wtz_sort_exact(cache.a, (size_t)cache.n, wtz_gt_off12());       /* process_hzmps, hzm_aln.h:1184-1186 */
+	if(sorted) cache.a = sorted;                                        /* tie-free: the unique ascending order */
+	else wtz_sort_exact(cache.a, (size_t)cache.n, wtz_gt_off12());       /* process_hzmps, hzm_aln.h:1184-1186, swap-exact */
+	const uint64_t tk2 = WTZ_TICK();
 	wtz_winscratch_t sc;
-	sc.ts = (uint32_t*)wtz_pool_alloc(V.pool, (size_t)(n + 1) * 4 * 5);
+	sc.ts = (uint32_t*)wtz_pool_alloc(V.pool, (size_t)(n + 2) * (4 * 5 + 8 + sizeof(wtz_zhit_t)) + 16);
 	if(sc.ts == NULL){ r.bad = 1; res[t] = r; return; }
-	sc.as = (int32_t*)(sc.ts + (n + 1)); sc.wb = sc.ts + 2 * (n + 1); sc.we = sc.ts + 3 * (n + 1); sc.wo = sc.ts + 4 * (n + 1);
+	sc.as = (int32_t*)(sc.ts + (n + 2)); sc.wb = sc.ts + 2 * (n + 2); sc.we = sc.ts + 3 * (n + 2); sc.wo = sc.ts + 4 * (n + 2);
+	sc.tk = (uint64_t*)(sc.ts + 5 * (n + 2) + ((5 * (n + 2)) & 1)); sc.ztmp = (wtz_zhit_t*)(sc.tk + (n + 2));
+	sc.lds = (uint64_t*)wtz_wave_scratch(); sc.lds_u64 = sc.lds ? WTZ_PAIR_LDS_BYTES / 8 : 0;
 	for(uint32_t dir = 0; dir < 2; dir++){
 		wtz_vec<wtz_win_t> wins; wins.init(V.pool, 16);
 		wtz_vec<wtz_zhit_t> anchors; anchors.init(V.pool, n + 16);
@@ -69,6 +87,7 @@ WTZ_HD void wtz_task_pair(uint32_t t, const wtz_env_t &V, const uint32_t *qid, c
 		for(uint32_t j = 0; j < wins.n; j++){ if(wins.a[j].closed) continue; wins.a[k++] = wins.a[j]; }
 		r.nwin[dir] = k; r.win[dir] = wins.a; r.anchors[dir] = anchors.a; r.nanchors[dir] = anchors.n;
 	}
+	{ const uint64_t tk3 = WTZ_TICK(); r.tick[0] = (uint32_t)((tk1 - tk0) >> 10); r.tick[1] = (uint32_t)((tk2 - tk1) >> 10); r.tick[2] = (uint32_t)((tk3 - tk2) >> 10); r.tick[3] = (uint32_t)((tk3 - tk0) >> 10); }
 	res[t] = r;
 }
 

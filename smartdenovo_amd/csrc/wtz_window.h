@@ -120,6 +120,70 @@ struct wtz_gt_off12 { WTZ_HDM bool operator()(const wtz_zhit_t &a, const wtz_zhi
 struct wtz_gt_off1 { WTZ_HDM bool operator()(const wtz_zhit_t &a, const wtz_zhit_t &b) const { return ZH_OFF1(a) > ZH_OFF1(b); } };
 struct wtz_gt_idx_off2 { const wtz_zhit_t *rs; WTZ_HDM bool operator()(uint32_t a, uint32_t b) const { return ZH_OFF2(rs[a]) > ZH_OFF2(rs[b]); } };
 
+#if defined(__HIP_DEVICE_COMPILE__)
+/*
+ * process_hzmps (hzm_aln.h:1184-1186) on the whole wavefront.  The reference orders the matches by (off1,off2) with its
+ * UNSTABLE sort; only exact key ties (cross-strand coincidences) make the result depend on the swap sequence.  So: bitonic
+ * sort of packed words off1:24 | off2:24 | index:16 by all 64 lanes (LDS when it fits, else the pool), then a tie scan -
+ * no ties means the ascending order is unique and equals the reference's; any tie makes the caller run the swap-exact
+ * sequential sort instead.  Returns the sorted copy (with the two zeroed sentinels) or NULL (tie / too large / pool).
+ */
+WTZ_D wtz_zhit_t *wtz_sort_hits_wave(const wtz_zhit_t *hits, uint32_t n, wtz_pool_t *pool, uint64_t *lds, uint32_t lds_u64, int *pool_bad){
+	const uint32_t lane = WTZ_LANE;
+	*pool_bad = 0;
+	if(n < 2 || n > 65535u) return NULL;
+	uint32_t np = 64; while(np < n) np <<= 1;
+	uint64_t *w;
+	if(lds && np <= lds_u64) w = lds;
+	else {
+		uint64_t a = 0;
+		if(lane == 0) a = (uint64_t)(uintptr_t)wtz_pool_alloc(pool, (size_t)np * 8);
+		a = wtz_coop_bcast64(a);
+		w = (uint64_t*)(uintptr_t)a;
+		if(w == NULL){ *pool_bad = 1; return NULL; }
+	}
+	for(uint32_t i = lane; i < np; i += 64)
+		w[i] = i < n ? (((uint64_t)ZH_OFF1(hits[i]) << 40) | ((uint64_t)ZH_OFF2(hits[i]) << 16) | i) : ~0ull;
+	__threadfence_block();
+	for(uint32_t k = 2; k <= np; k <<= 1){
+		for(uint32_t j = k >> 1; j > 0; j >>= 1){
+			for(uint32_t t0 = 0; t0 < np / 2; t0 += 256){
+				uint64_t a[4], b[4]; uint32_t ia[4];
+				#pragma unroll
+				for(int u = 0; u < 4; u++){
+					const uint32_t t = t0 + u * 64 + lane;
+					const uint32_t i = ((t / j) * (j << 1)) + (t % j);
+					ia[u] = i;
+					if(t < np / 2){ a[u] = w[i]; b[u] = w[i + j]; } else { a[u] = 0; b[u] = 0; }
+				}
+				#pragma unroll
+				for(int u = 0; u < 4; u++){
+					const uint32_t t = t0 + u * 64 + lane;
+					if(t < np / 2){
+						const bool asc = ((ia[u] & k) == 0);
+						if((a[u] > b[u]) == asc){ w[ia[u]] = b[u]; w[ia[u] + j] = a[u]; }
+					}
+				}
+			}
+			__threadfence_block();
+		}
+	}
+	uint32_t tie = 0;
+	for(uint32_t i = lane; i + 1 < n; i += 64) if((w[i] >> 16) == (w[i + 1] >> 16)) tie = 1;
+	uint32_t any; (void)wtz_coop_excl_scan(tie, &any);
+	if(any) return NULL;
+	uint64_t oa = 0;
+	if(lane == 0) oa = (uint64_t)(uintptr_t)wtz_pool_alloc(pool, (size_t)(n + 2) * sizeof(wtz_zhit_t));
+	oa = wtz_coop_bcast64(oa);
+	wtz_zhit_t *out = (wtz_zhit_t*)(uintptr_t)oa;
+	if(out == NULL){ *pool_bad = 1; return NULL; }
+	for(uint32_t i = lane; i < n; i += 64) out[i] = hits[(uint32_t)(w[i] & 0xFFFFu)];
+	if(lane == 0){ wtz_zhit_t z0; z0.o1 = z0.o2 = z0.ll = z0.gid = 0; out[n] = z0; out[n + 1] = z0; }
+	__threadfence_block();
+	return out;
+}
+#endif
+
 WTZ_HD int32_t wtz_median(int32_t *rs, int32_t size){
 	int32_t i, j, key, mid, beg, end, tmp;
 	if(size == 0) return 0;
@@ -145,8 +209,11 @@ WTZ_HD int32_t wtz_median(int32_t *rs, int32_t size){
 	return rs[size / 2];
 }
 
-/* scratch of one (pair,strand) window scan: all sized by the number of matches of the pair */
-typedef struct { uint32_t *ts; int32_t *as; uint32_t *wb, *we, *wo; } wtz_winscratch_t;
+/* scratch of one (pair,strand) window scan: all sized by the number of matches of the pair.  `lds` (may be NULL) is the
+ * wave's LDS slice: the small order-sensitive sorts / the quick-select run there when they fit - they are chains of
+ * dependent loads on a single lane, so it is the access latency (LDS ~64 clk vs L2 ~500 clk) that matters */
+typedef struct { uint32_t *ts; int32_t *as; uint32_t *wb, *we, *wo; uint64_t *tk; wtz_zhit_t *ztmp; uint64_t *lds; uint32_t lds_u64; } wtz_winscratch_t;
+struct wtz_gt_hi32 { WTZ_HDM bool operator()(uint64_t a, uint64_t b) const { return (uint32_t)(a >> 32) > (uint32_t)(b >> 32); } };
 
 WTZ_HD uint32_t wtz_scan_windows(const wtz_zhit_t *rs, uint32_t dir, uint32_t beg, uint32_t end, int32_t bound,
 		wtz_vec<wtz_win_t> &wins, wtz_vec<wtz_zhit_t> &anchors, const wtz_winscratch_t &sc, uint32_t zsize, uint32_t kwin, uint32_t zovl){
@@ -158,10 +225,14 @@ WTZ_HD uint32_t wtz_scan_windows(const wtz_zhit_t *rs, uint32_t dir, uint32_t be
 	for(i = beg; i < end; i++){ if(ZH_STRAND(rs[i]) ^ dir) continue; n++; }
 	if(n * zsize < zovl) return 0;
 	uint32_t *ts = sc.ts;
-	n = 0;
-	for(i = beg; i < end; i++){ if(ZH_STRAND(rs[i]) ^ dir) continue; ts[n++] = i; }
-	wtz_gt_idx_off2 g2; g2.rs = rs;
-	wtz_sort_exact(ts, n, g2);
+	{   /* hzm_aln.h:449: indices ordered by off2 under the unstable sort.  Sorting (off2<<32 | index) words with a comparator
+	     * that looks at off2 only performs the same swaps as sorting the indices through the indirection */
+		uint64_t *tk = (sc.lds && n <= sc.lds_u64) ? sc.lds : sc.tk;
+		n = 0;
+		for(i = beg; i < end; i++){ if(ZH_STRAND(rs[i]) ^ dir) continue; tk[n++] = ((uint64_t)ZH_OFF2(rs[i]) << 32) | i; }
+		wtz_sort_exact(tk, (size_t)n, wtz_gt_hi32());
+		for(i = 0; i < n; i++) ts[i] = (uint32_t)tk[i];
+	}
 	ol = 0; lst = 0; n2 = 0;
 	for(i = j = 0; i < n; i++){
 		const wtz_zhit_t p = rs[ts[i]];
@@ -185,8 +256,9 @@ WTZ_HD uint32_t wtz_scan_windows(const wtz_zhit_t *rs, uint32_t dir, uint32_t be
 	for(i = 0; i < n2; i++){
 		const uint32_t size = anchors.n;
 		int32_t offset, off; uint32_t offn = 0;
-		for(j = sc.wb[i]; j <= sc.we[i]; j++){ const wtz_zhit_t p = rs[ts[j]]; sc.as[offn++] = (int32_t)ZH_OFF1(p) - (int32_t)ZH_OFF2(p); }
-		offset = wtz_median(sc.as, (int32_t)offn);
+		int32_t *as = (sc.lds && (sc.we[i] - sc.wb[i] + 1) <= sc.lds_u64 * 2) ? (int32_t*)sc.lds : sc.as;
+		for(j = sc.wb[i]; j <= sc.we[i]; j++){ const wtz_zhit_t p = rs[ts[j]]; as[offn++] = (int32_t)ZH_OFF1(p) - (int32_t)ZH_OFF2(p); }
+		offset = wtz_median(as, (int32_t)offn);
 		ol = lst = 0;
 		for(j = sc.wb[i]; j <= sc.we[i]; j++){
 			const wtz_zhit_t p = rs[ts[j]];
@@ -197,7 +269,13 @@ WTZ_HD uint32_t wtz_scan_windows(const wtz_zhit_t *rs, uint32_t dir, uint32_t be
 			lst = ZH_OFF2(p) + ZH_LEN2(p);
 		}
 		if(anchors.n == size) continue;
-		wtz_sort_exact(anchors.a + size, (size_t)(anchors.n - size), wtz_gt_off1());
+		{   /* hzm_aln.h:519: anchors ordered by off1 under the unstable sort, done on (off1<<32 | position) words, then permuted */
+			const uint32_t cnt = anchors.n - size;
+			uint64_t *ak = (sc.lds && cnt <= sc.lds_u64) ? sc.lds : sc.tk;
+			for(uint32_t k = 0; k < cnt; k++){ ak[k] = ((uint64_t)ZH_OFF1(anchors.a[size + k]) << 32) | k; sc.ztmp[k] = anchors.a[size + k]; }
+			wtz_sort_exact(ak, (size_t)cnt, wtz_gt_hi32());
+			for(uint32_t k = 0; k < cnt; k++) anchors.a[size + k] = sc.ztmp[(uint32_t)ak[k]];
+		}
 		wtz_win_t w;
 		w.pb2 = 0; w.closed = 0; w.dir = (uint8_t)dir; w.pad = 0;
 		w.anchors[0] = size; w.anchors[1] = 0;
@@ -320,6 +398,7 @@ typedef struct {
 	int32_t  bad;                    /* pool exhausted while working on this pair */
 	/* dot-matrix engine result (A7d) */
 	int32_t dm_score, dm_qb, dm_qe, dm_tb, dm_te, dm_dir;
+	uint32_t tick[4];               /* shader-clock ticks / 1024 spent in: matching, exact sort, windows+chain, total (profiling aid) */
 } wtz_pairres_t;
 
 #endif
