@@ -75,6 +75,9 @@ typedef struct {
 	uint32_t n_regs;         /* windows that passed wtzmo.c:1026; 0 means "regs->size == 0" (wtzmo.c:1029) */
 	uint32_t cigar_len;      /* number of (len<<4|op) words, op M0/I1/D2 */
 	uint64_t cigar_off;      /* offset of this item's CIGAR inside the buffer returned by wtz_fetch_cigars */
+	uint32_t text_len;       /* length of the CIGAR as text ("%d[MID]"..., kswx_cigar2string kswx.h:1093-1120), no terminator */
+	uint32_t pad;
+	uint64_t text_off;       /* offset inside the buffer returned by wtz_fetch_cigar_text */
 } wtz_aln_result_t;
 
 typedef struct {
@@ -123,6 +126,8 @@ int  wtz_pairs_windows(wtz_ctx_t *ctx, wtz_winbox_t *wins, uint64_t n_wins);
 /* A9 + A10 for m (pair index into the last wtz_pairs_seed, strand) items. */
 int  wtz_pairs_align(wtz_ctx_t *ctx, const uint32_t *pair_idx, const uint8_t *dir, uint32_t m, wtz_aln_result_t *out);
 int  wtz_fetch_cigars(wtz_ctx_t *ctx, uint32_t *dst, uint64_t n_ops);
+/* the same CIGARs already rendered as text on the device (what the .ovl column 17 holds): sum of text_len bytes */
+int  wtz_fetch_cigar_text(wtz_ctx_t *ctx, char *dst, uint64_t n_bytes);
 
 int  wtz_get_counters(wtz_ctx_t *ctx, wtz_counters_t *out);
 int  wtz_reset_counters(wtz_ctx_t *ctx);

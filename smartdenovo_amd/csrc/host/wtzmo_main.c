@@ -92,7 +92,7 @@ typedef struct {       /* one batch in flight */
 	uint32_t *pq, *pc; uint32_t npair, cappair;
 	uint32_t *rowpair; size_t caprowpair;       /* pair index per (slot, row entry) */
 	wtz_pair_summary_t *sum; uint64_t *box_off; wtz_winbox_t *boxes; uint64_t nbox, capbox;
-	uint32_t *item_of; uint32_t *it_pair; uint8_t *it_dir; uint32_t nitem; wtz_aln_result_t *aln; uint32_t *cig; uint64_t ncig, capcig;
+	uint32_t *item_of; uint32_t *it_pair; uint8_t *it_dir; uint32_t nitem; wtz_aln_result_t *aln; char *cig; uint64_t ncig, capcig;
 	uint64_t spec_queries, used_queries;
 	int holds_turn;
 } batch_t;
@@ -161,7 +161,7 @@ static void pend_hit(pending_t *p, const hit_t *h){
 	p->hits[p->nhit++] = *h;
 }
 
-static char *cigar_text(const uint32_t *c, uint32_t n){        /* kswx.h:1093-1120 */
+__attribute__((unused)) static char *cigar_text(const uint32_t *c, uint32_t n){        /* kswx.h:1093-1120 */
 	size_t cap = (size_t)n * 11 + 2, k = 0; char *s = (char*)hx_realloc(NULL, cap);
 	for(uint32_t i = 0; i < n; i++){
 		uint32_t op = c[i] & 0xF, len = c[i] >> 4;
@@ -279,7 +279,7 @@ static void commit_query(eng_t *E, batch_t *b, uint32_t slot){
 			hit_t H; memset(&H, 0, sizeof H);
 			H.pb1 = pbid; H.pb2 = s->pb2; H.dir2 = s->dir; H.score = x->score;
 			H.tb = x->tb; H.te = x->te; H.qb = x->qb; H.qe = x->qe; H.mat = x->mat; H.mis = x->mis; H.ins = x->ins; H.del = x->del; H.aln = x->aln;
-			H.cigar = cigar_text(b->cig + x->cigar_off, x->cigar_len);
+			H.cigar = (char*)hx_realloc(NULL, (size_t)x->text_len + 1); memcpy(H.cigar, b->cig + x->text_off, x->text_len); H.cigar[x->text_len] = 0;
 			pend_hit(pd, &H);
 			{   /* dovetail / containment bookkeeping (wtzmo.c:1065-1100) */
 				const uint32_t len1 = E->rdlen[H.pb1], len2 = E->rdlen[H.pb2];
@@ -358,9 +358,9 @@ static int gpu_stages(eng_t *E, batch_t *b){
 		if(b->nitem){
 			b->aln = (wtz_aln_result_t*)hx_realloc(b->aln, sizeof(wtz_aln_result_t) * b->nitem);
 			rc = wtz_pairs_align(b->ctx, b->it_pair, b->it_dir, b->nitem, b->aln); TRY_WTZ(rc, "wtz_pairs_align");
-			uint64_t tot = 0; for(uint32_t i = 0; i < b->nitem; i++) tot += b->aln[i].cigar_len;
-			if(tot > b->capcig){ b->capcig = tot; b->cig = (uint32_t*)hx_realloc(b->cig, 4 * tot); }
-			rc = wtz_fetch_cigars(b->ctx, b->cig, tot); TRY_WTZ(rc, "wtz_fetch_cigars");
+			uint64_t tot = 0; for(uint32_t i = 0; i < b->nitem; i++) tot += b->aln[i].text_len;
+			if(tot > b->capcig){ b->capcig = tot; b->cig = (char*)hx_realloc(b->cig, tot + 1); }
+			rc = wtz_fetch_cigar_text(b->ctx, b->cig, tot); TRY_WTZ(rc, "wtz_fetch_cigar_text");     /* rendered on the device */
 			b->ncig = tot;
 		}
 	}
@@ -481,7 +481,7 @@ int main(int argc, char **argv){
 	P->kwin = 800; P->kovl = 300; P->ksave = 4; P->win_rep_norm = 20; P->win_rep_cutoff = 100; P->ncand = 500; P->nbest = 100;
 	P->ztot = 300; P->zovl = 200; P->max_kmer_freq = 0; P->max_zmer_freq = 64; P->max_kmer_var = 2;
 	P->xvar = 128; P->yvar = 64; P->min_block_len = 160; P->deviation_penalty = 1.0f; P->gap_penalty = 0.05f;
-	E->do_align = 1; E->n_idx = 1; E->n_job = 1; E->i_job = 0; E->max_batch = 2048; E->first_batch = 256; E->n_workers = 2;
+	E->do_align = 1; E->n_idx = 1; E->n_job = 1; E->i_job = 0; E->max_batch = 2048; E->first_batch = 256; E->n_workers = 1;
 	pthread_mutex_init(&E->mu, NULL); pthread_cond_init(&E->cv, NULL);
 	static struct option lopts[] = { {"stats", required_argument, 0, 1000}, {"gpu", required_argument, 0, 1001}, {"pool-gb", required_argument, 0, 1002},
 		{"batch", required_argument, 0, 1003}, {"lib-check", no_argument, 0, 1004}, {"repeat", required_argument, 0, 1005}, {"first-batch", required_argument, 0, 1006}, {"workers", required_argument, 0, 1007}, {0, 0, 0, 0} };
@@ -638,6 +638,7 @@ int main(int argc, char **argv){
 	rc = wtz_upload_reads(E->ctx, E->st.bits, (E->st.nbase + 31) / 32, rdoff, E->rdlen, n_all); DIE_WTZ(rc, "wtz_upload_reads");
 	E->out = strcmp(output, "-") ? fopen(output, "w") : stdout;
 	if(E->out == NULL){ fprintf(stderr, " -- Cannot write %s --\n", output); exit(1); }
+	setvbuf(E->out, NULL, _IOFBF, 8u << 20);
 	E->stride = P->ncand + 1;
 	E->pend.rd_id = 0xFFFFFFFFu;
 	/* --repeat: run the whole overlap phase several times on the reads already resident in HBM (benchmarking) */
@@ -654,7 +655,7 @@ int main(int argc, char **argv){
 			E->t_gpu = E->t_commit = 0; E->spec_pairs = E->used_pairs = E->spec_items = E->used_items = E->spec_queries = E->used_queries = 0;
 			E->rows_all = 0; E->n_batches = 0;
 			E->pend.rd_id = 0xFFFFFFFFu; E->pend.nhit = E->pend.nmask = E->pend.nclosed = E->pend.nseed = 0;
-			if(strcmp(output, "-")){ E->out = fopen(output, "w"); if(E->out == NULL) exit(1); }
+			if(strcmp(output, "-")){ E->out = fopen(output, "w"); if(E->out == NULL) exit(1); setvbuf(E->out, NULL, _IOFBF, 8u << 20); }
 			wtz_reset_counters(E->ctx);
 		}
 		if(g_hook) g_hook(rep, 0);

@@ -69,10 +69,10 @@ WTZ_HD void wtz_band_advance(const wtz_diag_t *diags, uint32_t &doff, uint32_t d
 
 typedef struct { wtz_vec<wtz_zhit_t> dst; wtz_vec<wtz_win_t> regs[2]; wtz_vec<wtz_diag_t> diags; wtz_vec<uint32_t> block, grps; } wtz_dmscratch_t;
 
-WTZ_HD void wtz_denoise(wtz_zhit_t *rs, uint32_t n_rs, wtz_dmscratch_t &S, int32_t xvar, int32_t yvar, int32_t min_linear_len){
+WTZ_HD void wtz_denoise(wtz_zhit_t *rs, uint32_t n_rs, wtz_dmscratch_t &S, int32_t xvar, int32_t yvar, int32_t min_linear_len, bool presorted){
 	uint32_t i, j, k, doff, dcnt = 0, gid;
 	int32_t len, lst, lst_offset = 0, end_offset;
-	wtz_sort_exact(rs, (size_t)n_rs, wtz_gt_zdiag());
+	if(!presorted) wtz_sort_exact(rs, (size_t)n_rs, wtz_gt_zdiag());      /* hzm_aln.h:728; done by the wavefront when tie-free */
 	S.diags.reserve(2); if(S.diags.a){ S.diags.a[0].offset = 0; S.diags.a[0].off = 0; S.diags.a[0].cnt = 0; }
 	for(uint32_t dir = 0; dir < 2; dir++){
 		S.diags.n = 0; S.dst.n = 0; S.regs[dir].n = 0;
@@ -261,13 +261,13 @@ WTZ_HD int32_t wtz_chain_blocks(int32_t pblen1, int32_t pblen2, wtz_vec<wtz_win_
 	return mw;
 }
 
-WTZ_HD wtz_dm_result_t wtz_dot_matrix_align(wtz_vec<wtz_zhit_t> &cache, wtz_pool_t *pool, int32_t pblen1, int32_t pblen2, const wtz_params_t *P, int32_t *bad){
+WTZ_HD wtz_dm_result_t wtz_dot_matrix_align(wtz_vec<wtz_zhit_t> &cache, wtz_pool_t *pool, int32_t pblen1, int32_t pblen2, const wtz_params_t *P, int32_t *bad, bool presorted){
 	wtz_dm_result_t ret; int32_t weight[2]; uint32_t d;
 	wtz_dmscratch_t S;
 	S.dst.init(pool, cache.n / 2 + 16); S.regs[0].init(pool, 16); S.regs[1].init(pool, 16);
 	S.diags.init(pool, 64); S.block.init(pool, 64); S.grps.init(pool, 16);
 	/* dst of strand 0 is consumed before strand 1 reuses it: regs only keep bounds */
-	wtz_denoise(cache.a, cache.n, S, P->xvar, P->yvar, P->min_block_len);
+	wtz_denoise(cache.a, cache.n, S, P->xvar, P->yvar, P->min_block_len, presorted);
 	wtz_merge_blocks(S.regs[0], S, P->xvar, 2 * P->yvar);
 	wtz_merge_blocks(S.regs[1], S, P->xvar, 2 * P->yvar);
 	weight[0] = wtz_chain_blocks(pblen1, pblen2, S.regs[0], pool, P->xvar, P->max_overhang, P->deviation_penalty, P->gap_penalty, bad);

@@ -23,6 +23,8 @@
 /* device abstraction                                                                               */
 /* ------------------------------------------------------------------------------------------------ */
 static thread_local char g_err[512] = "";
+#define CHK(call) do { int rc_ = (call); if(rc_ != WTZ_OK) return rc_; } while(0)
+#define CHK0(call) CHK(call)
 static int wtz_fail(int code, const char *fmt, ...){
 	va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof g_err, fmt, ap); va_end(ap);
 	return code;
@@ -126,6 +128,18 @@ static int dev_sort_pairs_u64_u32(uint64_t *keys, uint32_t *vals, uint64_t n, un
 	if(e != hipSuccess) return wtz_fail(WTZ_E_HIP, "radix_sort_pairs failed: %s", hipGetErrorString(e));
 	return rc;
 }
+static int dev_exclusive_scan_u32(const uint32_t *in, uint32_t *out, uint64_t n){
+	if(n == 0) return WTZ_OK;
+	void *tmp = NULL; size_t tmp_bytes = 0;
+	hipError_t e = rocprim::exclusive_scan(tmp, tmp_bytes, in, out, 0u, (size_t)n, rocprim::plus<uint32_t>(), g_stream);
+	if(e != hipSuccess) return wtz_fail(WTZ_E_HIP, "exclusive_scan failed: %s", hipGetErrorString(e));
+	CHK0(dev_alloc(&tmp, tmp_bytes));
+	e = rocprim::exclusive_scan(tmp, tmp_bytes, in, out, 0u, (size_t)n, rocprim::plus<uint32_t>(), g_stream);
+	if(e == hipSuccess) e = hipStreamSynchronize(g_stream);
+	dev_free(tmp);
+	if(e != hipSuccess) return wtz_fail(WTZ_E_HIP, "exclusive_scan failed: %s", hipGetErrorString(e));
+	return WTZ_OK;
+}
 #else  /* ---------------- host emulation of the launch geometry (tests only) ---------------- */
 #define WTZ_LAMBDA
 typedef int hipStream_t;
@@ -145,6 +159,7 @@ static int dev_sync(){ return WTZ_OK; }
 #include <time.h>
 struct wtz_timer { struct timespec t0; void start(){ clock_gettime(CLOCK_MONOTONIC, &t0); }
 	double stop(){ struct timespec t1; clock_gettime(CLOCK_MONOTONIC, &t1); return 1e3 * (double)(t1.tv_sec - t0.tv_sec) + 1e-6 * (double)(t1.tv_nsec - t0.tv_nsec); } };
+static int dev_exclusive_scan_u32(const uint32_t *in, uint32_t *out, uint64_t n){ uint32_t a = 0; for(uint64_t i = 0; i < n; i++){ uint32_t v = in[i]; out[i] = a; a += v; } return WTZ_OK; }
 static int dev_sort_pairs_u64_u32(uint64_t *keys, uint32_t *vals, uint64_t n, unsigned){
 	std::vector<std::pair<uint64_t, uint32_t> > v((size_t)n);
 	for(uint64_t i = 0; i < n; i++) v[(size_t)i] = std::make_pair(keys[i], vals[i]);
@@ -156,6 +171,7 @@ static int dev_sort_pairs_u64_u32(uint64_t *keys, uint32_t *vals, uint64_t n, un
 
 struct K_candidates;
 struct K_extjob_scalar;
+struct K_cigar_text;
 struct K_misc;
 struct K_gap;
 struct K_kcount;
@@ -169,10 +185,13 @@ struct K_stitch_fin;
 struct K_stitch_left;
 struct K_stitch_mid;
 struct K_winalign;
-struct K_zbuild;
+struct K_zfill;
+struct K_zrun;
+struct K_zdistinct;
+struct K_zdn;
 struct K_zcount;
 
-#define CHK(call) do { int rc_ = (call); if(rc_ != WTZ_OK) return rc_; } while(0)
+
 
 /* ------------------------------------------------------------------------------------------------ */
 /* context                                                                                          */
@@ -428,10 +447,21 @@ extern "C" int wtz_zindex_build(wtz_ctx_t *c){
 	CHK(dev_alloc_persist((void**)&Z.dmer, (tot + 1) * 4)); CHK(dev_alloc_persist((void**)&Z.dfirst, (tot + 1) * 4)); CHK(dev_alloc_persist((void**)&Z.dcnt, (tot + 1) * 2));
 	CHK(dev_alloc_persist((void**)&Z.dn, ((size_t)nr + 1) * 4));
 	c->Z = Z;
-	uint64_t *d_tmp = NULL; CHK(dev_alloc((void**)&d_tmp, (tot + 1) * 8));
-	CHK(wtz_launch_wave<K_zbuild>(0, nr, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_zbuild((uint32_t)t, R, zsize, hz, zcut, Z, d_tmp); }));
-	CHK(dev_sync());
-	dev_free(d_tmp);
+	{
+		uint64_t *d_key = NULL; uint32_t *d_flag = NULL, *d_cnt = NULL, *d_dpos = NULL; uint32_t *d_val = Z.sidx;
+		CHK(dev_alloc((void**)&d_key, (tot + 1) * 8));
+		CHK(wtz_launch<K_zfill>(0, nr, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_zfill((uint32_t)t, R, zsize, hz, Z, d_key, d_val); }));
+		unsigned rbits = 1; while((1ull << rbits) < (uint64_t)nr + 1) rbits++;
+		CHK(dev_sort_pairs_u64_u32(d_key, d_val, tot, 32 + rbits));          /* stable: positions ascend inside a (read, mer) run */
+		CHK(dev_alloc((void**)&d_flag, (tot + 2) * 4)); CHK(dev_alloc((void**)&d_cnt, (tot + 2) * 4)); CHK(dev_alloc((void**)&d_dpos, (tot + 2) * 4));
+		CHK(dev_set(d_flag, 0, (tot + 2) * 4));
+		CHK(wtz_launch<K_zrun>(0, tot, [=] WTZ_LAMBDA (uint64_t i){ wtz_task_zrun(i, d_key, d_val, tot, zcut, Z, d_flag, d_cnt); }));
+		CHK(dev_exclusive_scan_u32(d_flag, d_dpos, tot + 1));
+		CHK(wtz_launch<K_zdistinct>(0, tot, [=] WTZ_LAMBDA (uint64_t i){ wtz_task_zdistinct(i, d_key, d_flag, d_cnt, d_dpos, Z); }));
+		CHK(wtz_launch<K_zdn>(0, nr, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_zdn((uint32_t)t, d_dpos, Z); }));
+		CHK(dev_sync());
+		dev_free(d_key); dev_free(d_flag); dev_free(d_cnt); dev_free(d_dpos);
+	}
 	c->have_z = true;
 	c->cnt.ms_zindex += tm.stop();
 	return WTZ_OK;
@@ -455,7 +485,7 @@ extern "C" int wtz_candidates(wtz_ctx_t *c, const uint32_t *qids, uint32_t nq, u
 	const uint32_t *seeds = c->kseeds; wtz_pool_t *pool = c->dpool;
 	unsigned long long *d_bytes = NULL; CHK(dev_alloc((void**)&d_bytes, 8)); CHK(dev_set(d_bytes, 0, 8));
 	wtz_timer tm; tm.start();
-	CHK(wtz_launch_wave<K_candidates>(0, nq, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_candidates((uint32_t)t, R, d_q, dP, tab, kmask, seeds, pool, d_cand, d_n, stride, d_bytes); }));
+	CHK(wtz_launch_coop<K_candidates>(0, nq, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_candidates((uint32_t)t, R, d_q, dP, tab, kmask, seeds, pool, d_cand, d_n, stride, d_bytes); }));
 	CHK(dev_sync());
 	{ unsigned long long hb = 0; CHK(dev_d2h(&hb, d_bytes, 8)); c->cnt.bytes_seed_algo += hb; dev_free(d_bytes); }
 	c->cnt.ms_candidates += tm.stop(); c->cnt.n_candidates_q += nq;
@@ -640,13 +670,13 @@ extern "C" int wtz_pairs_align(wtz_ctx_t *c, const uint32_t *pair_idx, const uin
 	CHK(dev_d2h(c->h_alnres.data(), c->d_alnres, (size_t)m * sizeof(wtz_alnres_dev_t)));
 	dev_free(d_regs); dev_free(d_items); dev_free(d_wt);
 	CHK(pool_check(c, "wtz_pairs_align"));
-	uint64_t coff = 0;
+	uint64_t coff = 0, toff = 0;
 	for(uint32_t i = 0; i < m; i++){
 		const wtz_alnres_dev_t &r = c->h_alnres[i];
 		if(r.bad) return wtz_fail(WTZ_E_POOL, "wtz_pairs_align: item %u ran out of scratch", i);
 		wtz_aln_result_t o; memset(&o, 0, sizeof o);
 		o.score = r.x.score; o.tb = r.x.tb; o.te = r.x.te; o.qb = r.x.qb; o.qe = r.x.qe; o.aln = r.x.aln; o.mat = r.x.mat; o.mis = r.x.mis; o.ins = r.x.ins; o.del = r.x.del;
-		o.n_regs = r.n_regs; o.cigar_len = r.cigar_len; o.cigar_off = coff; coff += r.cigar_len;
+		o.n_regs = r.n_regs; o.cigar_len = r.cigar_len; o.cigar_off = coff; coff += r.cigar_len; o.text_len = r.text_len; o.text_off = toff; toff += r.text_len;
 		c->cnt.cells_shift += r.cells_shift; c->cnt.cells_fixed += r.cells_fixed; c->cnt.cells_global += r.cells_global;
 		out[i] = o;
 	}
@@ -670,6 +700,26 @@ extern "C" int wtz_fetch_cigars(wtz_ctx_t *c, uint32_t *dst, uint64_t n_ops){
 	CHK(dev_sync());
 	CHK(dev_d2h(dst, d_c, (size_t)tot * 4));
 	dev_free(d_off); dev_free(d_c);
+	return WTZ_OK;
+}
+
+extern "C" int wtz_fetch_cigar_text(wtz_ctx_t *c, char *dst, uint64_t n_bytes){
+	if(!c || !c->have_items) return wtz_fail(WTZ_E_STATE, "wtz_fetch_cigar_text before wtz_pairs_align");
+	CTX_ENTER(c);
+	uint64_t tot = 0; for(uint32_t i = 0; i < c->n_items; i++) tot += c->h_alnres[i].text_len;
+	if(tot != n_bytes) return wtz_fail(WTZ_E_ARG, "wtz_fetch_cigar_text: expected room for %llu bytes, got %llu", (unsigned long long)tot, (unsigned long long)n_bytes);
+	if(tot == 0) return WTZ_OK;
+	if(!dst) return wtz_fail(WTZ_E_ARG, "null output");
+	std::vector<uint64_t> off((size_t)c->n_items + 1);
+	uint64_t o = 0; for(uint32_t i = 0; i < c->n_items; i++){ off[i] = o; o += c->h_alnres[i].text_len; } off[c->n_items] = o;
+	uint64_t *d_off = NULL; char *d_t = NULL;
+	CHK(dev_alloc((void**)&d_off, off.size() * 8)); CHK(dev_h2d(d_off, off.data(), off.size() * 8));
+	CHK(dev_alloc((void**)&d_t, (size_t)tot + 16));
+	const wtz_alnres_dev_t *dr = c->d_alnres;
+	CHK(wtz_launch<K_cigar_text>(0, c->n_items, [=] WTZ_LAMBDA (uint64_t t){ const wtz_alnres_dev_t &r = dr[t]; if(r.text_len) wtz_cigar_text_write(r.cigar, r.cigar_len, d_t + d_off[t]); }));
+	CHK(dev_sync());
+	CHK(dev_d2h(dst, d_t, (size_t)tot));
+	dev_free(d_off); dev_free(d_t);
 	return WTZ_OK;
 }
 

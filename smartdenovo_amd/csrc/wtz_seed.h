@@ -192,29 +192,48 @@ WTZ_HD void wtz_heapsort_u64(uint64_t *a, uint32_t n){
 	}
 }
 
-/* task: build all z-mer views of read r. tmpkey is a u64 scratch array parallel to the slices. */
-WTZ_HD void wtz_task_zbuild(uint32_t r, wtz_reads_t R, uint32_t zsize, uint32_t hz, uint32_t max_kcnt, wtz_zindex_t Z, uint64_t *tmpkey){
-	const uint64_t o = Z.zoff[r]; const uint32_t n = (uint32_t)(Z.zoff[r + 1] - o);
-	wtz_zfill_f f; f.mer = Z.mer + o; f.pos = Z.pos + o; f.len = Z.len + o; f.key = tmpkey + o; f.k = 0;
+/*
+ * The z-index of ALL reads is built with device-wide primitives instead of one sort per read:
+ *   K_zfill    lane per read   : position-ordered mer / pos / len and the sort key (read<<32 | mer), value = position
+ *   radix sort (rocPRIM, stable): by (read, mer); positions stay ascending inside a run  ==  (mer, off) order (hzm_aln.h:101)
+ *   K_zrun     lane per element: run heads, run lengths, the candidate-side cap `ok` (occurrence rank < max_kcnt)
+ *   exclusive scan of the retained-head flags -> dense index of every distinct z-mer inside its read (the rank_bitvec of
+ *   hzm_aln.h:107-114)
+ *   K_zdistinct lane per element: dmer / dfirst / dcnt, and dn per read
+ */
+struct wtz_zfill2_f { uint32_t *mer, *pos; uint16_t *len; uint64_t *key; uint32_t *val; uint32_t k; uint64_t rid;
+	WTZ_HDM void operator()(uint32_t m, uint32_t d, uint32_t o, uint32_t l){ mer[k] = m; pos[k] = (o << 1) | d; len[k] = (uint16_t)l; key[k] = (rid << 32) | m; val[k] = k; k++; } };
+
+WTZ_HD void wtz_task_zfill(uint32_t r, wtz_reads_t R, uint32_t zsize, uint32_t hz, wtz_zindex_t Z, uint64_t *key, uint32_t *val){
+	const uint64_t o = Z.zoff[r];
+	wtz_zfill2_f f; f.mer = Z.mer + o; f.pos = Z.pos + o; f.len = Z.len + o; f.key = key + o; f.val = val + o; f.k = 0; f.rid = r;
 	wtz_zmer_walk(R, r, zsize, hz, f);
-	wtz_heapsort_u64(tmpkey + o, n);          /* (mer, position) is a total order: any sort is exact (hzm_aln.h:101) */
-	uint32_t nd = 0;
-	for(uint32_t i = 0; i < n; ){
-		uint32_t m = (uint32_t)(tmpkey[o + i] >> 32), j = i;
-		while(j < n && (uint32_t)(tmpkey[o + j] >> 32) == m){
-			uint32_t k = (uint32_t)(tmpkey[o + j] & 0xFFFFFFFFu);
-			Z.sidx[o + j] = k;
-			uint32_t rank = j - i;
-			/* u8 counter in the reference: with max_kcnt > 255 the cap can never trigger before the counter wraps */
-			Z.ok[o + k] = (max_kcnt > 255u) ? 1 : (rank < max_kcnt ? 1 : 0);
-			j++;
-		}
-		uint32_t c = j - i;
-		if(c && c < max_kcnt){ Z.dmer[o + nd] = m; Z.dfirst[o + nd] = i; Z.dcnt[o + nd] = (uint16_t)WTZ_MIN(c, 0xFFFFu); nd++; }
-		i = j;
-	}
-	Z.dn[r] = nd;
 }
+
+/* element i of the (read, mer)-sorted array: flag[i] = 1 for the head of a retained run, cnt[i] = its length */
+WTZ_HD void wtz_task_zrun(uint64_t i, const uint64_t *key, const uint32_t *val, uint64_t n, uint32_t max_kcnt, wtz_zindex_t Z, uint32_t *flag, uint32_t *cnt){
+	const uint64_t k = key[i];
+	const uint64_t o = Z.zoff[(uint32_t)(k >> 32)];
+	/* occurrence rank inside the run (bounded backward scan): the candidate-side cap of hzm_aln.h:208-211; the reference
+	 * counts in a u8, so with max_kcnt > 255 the cap can never trigger before the counter wraps */
+	uint32_t rank = 0;
+	while(rank < max_kcnt && i > rank && key[i - rank - 1] == k) rank++;
+	Z.ok[o + val[i]] = (max_kcnt > 255u) ? 1 : (rank < max_kcnt ? 1 : 0);
+	if(i && key[i - 1] == k){ flag[i] = 0; cnt[i] = 0; return; }
+	const uint64_t c = wtz_run_end(key, n, i) - i;
+	cnt[i] = (uint32_t)WTZ_MIN(c, (uint64_t)0xFFFFu);
+	flag[i] = (c && c < max_kcnt) ? 1u : 0u;                 /* kept iff 0 < count < max_kcnt (hzm_aln.h:107) */
+}
+
+WTZ_HD void wtz_task_zdistinct(uint64_t i, const uint64_t *key, const uint32_t *flag, const uint32_t *cnt, const uint32_t *dpos, wtz_zindex_t Z){
+	if(!flag[i]) return;
+	const uint32_t r = (uint32_t)(key[i] >> 32);
+	const uint64_t o = Z.zoff[r];
+	const uint32_t d = dpos[i] - dpos[o];
+	Z.dmer[o + d] = (uint32_t)key[i]; Z.dfirst[o + d] = (uint32_t)(i - o); Z.dcnt[o + d] = (uint16_t)cnt[i];
+}
+
+WTZ_HD void wtz_task_zdn(uint32_t r, const uint32_t *dpos, wtz_zindex_t Z){ Z.dn[r] = dpos[Z.zoff[r + 1]] - dpos[Z.zoff[r]]; }
 
 /* ================= K-seed ================= */
 typedef struct { uint32_t key, ol, lst; } wtz_gacc_t;        /* per (rd<<1|dir): running union length */
@@ -267,39 +286,147 @@ WTZ_HD void wtz_cand_tail(const uint64_t *groups, uint32_t ng, uint32_t kovl, ui
 	*hn = n;
 }
 
-/* task: candidates of query qids[t]; cand_out row stride = ncand + 1 */
+/* bitonic sort of np (power of two) u64 words by the whole wavefront; the host emulation uses the in-lane heapsort */
+WTZ_HD void wtz_coop_sort_u64(uint64_t *w, uint32_t np){
+#if defined(__HIP_DEVICE_COMPILE__)
+	const uint32_t lane = WTZ_LANE;
+	__threadfence_block();
+	for(uint32_t k = 2; k <= np; k <<= 1){
+		for(uint32_t j = k >> 1; j > 0; j >>= 1){
+			for(uint32_t t0 = 0; t0 < np / 2; t0 += 256){
+				uint64_t a[4], b[4]; uint32_t ia[4];
+				#pragma unroll
+				for(int u = 0; u < 4; u++){
+					const uint32_t t = t0 + u * 64 + lane;
+					const uint32_t i = ((t / j) * (j << 1)) + (t % j);
+					ia[u] = i;
+					if(t < np / 2){ a[u] = w[i]; b[u] = w[i + j]; } else { a[u] = 0; b[u] = 0; }
+				}
+				#pragma unroll
+				for(int u = 0; u < 4; u++){
+					const uint32_t t = t0 + u * 64 + lane;
+					if(t < np / 2){ const bool asc = ((ia[u] & k) == 0); if((a[u] > b[u]) == asc){ w[ia[u]] = b[u]; w[ia[u] + j] = a[u]; } }
+				}
+			}
+			__threadfence_block();
+		}
+	}
+#else
+	wtz_heapsort_u64(w, np);
+#endif
+}
+
+struct wtz_kq_f { uint64_t *mer; uint32_t *qoff, *qlen; uint32_t n;
+	WTZ_HDM void operator()(uint64_t m, uint32_t, uint32_t qo, uint32_t qe){ uint32_t l = qe - qo; if(l > 0xFFFFu) l = 0xFFFFu; mer[n] = m; qoff[n] = qo; qlen[n] = l; n++; } };
+
+/*
+ * task (wave-cooperative): candidates of query qids[t]; cand_out row stride = ncand + 1.
+ *   A  lane 0 walks the read once and lists its sampled k-mers (the hp-compressed walk is a serial recurrence)
+ *   B  all lanes probe the hash (one 16-byte slot load per k-mer) and lay out the seed runs with an exclusive scan
+ *   C  all lanes expand (read<<1|strand, query offset, length) tuples, dropping self hits and reads longer than 1.2x
+ *      (wtzmo.c:488-489); tuple sequence numbers follow query-offset order
+ *   D  wave-wide bitonic sort of (key<<32 | sequence): per (read,strand) group the tuples stay in query-offset order,
+ *      which is the order the reference's k-way heap merge delivers them in (wtzmo.c:44-57)
+ *   E  all lanes: group heads -> union length `ol` of each group (wtzmo.c:558-560), compacted in key order
+ *   F  lane 0 replays the strand merge + candidate heap with its quirks (wtzmo.c:516-571)
+ */
 WTZ_HD void wtz_task_candidates(uint32_t t, wtz_reads_t R, const uint32_t *qids, const wtz_params_t *P,
 		const wtz_kslot_t *tab, uint64_t tmask, const uint32_t *seeds, wtz_pool_t *pool, uint64_t *cand_out, uint32_t *ncand_out, uint32_t stride,
 		unsigned long long *algo_bytes){
-	const uint32_t pbid = qids[t];
-	wtz_scount_f cf; cf.tab = tab; cf.mask = tmask; cf.tot = 0; cf.nprobe = 0;
-	wtz_kmer_walk(R, pbid, P->ksize, P->hk, P->ksave, cf);
-	{   /* algorithmic bytes of seed lookup: L/4 read + 16 B per probe + 4 B per seed entry */
-		unsigned long long b = (unsigned long long)R.rdlen[pbid] / 4 + 16ull * cf.nprobe + 4ull * cf.tot;
+	const uint32_t pbid = qids[t], lane = WTZ_LANE;
+	const uint32_t L = R.rdlen[pbid];
+	const uint32_t pblen_up = (uint32_t)(L * 1.2);                       /* double multiply, wtzmo.c:445 */
+	/* ---- A ---- */
+	uint64_t pa = 0; uint32_t nk = 0;
+	if(lane == 0){
+		uint8_t *mem = (uint8_t*)wtz_pool_alloc(pool, (size_t)(L + 2) * 16 + (size_t)(L + 2) * 12);
+		pa = (uint64_t)(uintptr_t)mem;
+		if(mem){
+			wtz_kq_f f; f.mer = (uint64_t*)mem; f.qoff = (uint32_t*)(mem + (size_t)(L + 2) * 8); f.qlen = f.qoff + (L + 2); f.n = 0;
+			wtz_kmer_walk(R, pbid, P->ksize, P->hk, P->ksave, f);
+			nk = f.n;
+		}
+	}
+	pa = wtz_coop_bcast64(pa); nk = wtz_coop_bcast32(nk);
+	if(pa == 0){ if(lane == 0) ncand_out[t] = 0xFFFFFFFFu; return; }
+	uint8_t *mem = (uint8_t*)(uintptr_t)pa;
+	const uint64_t *kmer = (const uint64_t*)mem; const uint32_t *kqoff = (const uint32_t*)(mem + (size_t)(L + 2) * 8), *kqlen = kqoff + (L + 2);
+	uint64_t *koff = (uint64_t*)(mem + (size_t)(L + 2) * 16);               /* seed run start per k-mer */
+	uint32_t *ktoff = (uint32_t*)(koff + (L + 2));                           /* tuple offset per k-mer (cnt kept in the high part of koff) */
+	/* ---- B ---- */
+	uint32_t T = 0;
+	for(uint32_t e0 = 0; e0 < nk; e0 += WTZ_NLANES){
+		const uint32_t e = e0 + lane;
+		uint64_t o = 0; uint32_t c = 0;
+		if(e < nk){ if(!wtz_kprobe(tab, tmask, kmer[e], &o, &c)){ o = 0; c = 0; } }
+		uint32_t chunk; const uint32_t ex = wtz_coop_excl_scan(c, &chunk);
+		if(e < nk){ koff[e] = (o << 16) | c; ktoff[e] = T + ex; }
+		T += chunk;
+	}
+	if(lane == 0){
+		const unsigned long long bytes = (unsigned long long)L / 4 + 16ull * nk + 4ull * T;      /* SURVEY 8d */
 #if defined(__HIP_DEVICE_COMPILE__)
-		atomicAdd(algo_bytes, b);
+		atomicAdd(algo_bytes, bytes);
 #else
-		*algo_bytes += b;
+		*algo_bytes += bytes;
 #endif
 	}
-	uint32_t cap = 16; while((uint64_t)cap < cf.tot * 2 + 2) cap <<= 1;
-	uint64_t *heap = cand_out + (size_t)t * stride;
-	wtz_gacc_t *map = (wtz_gacc_t*)wtz_pool_alloc(pool, (size_t)cap * sizeof(wtz_gacc_t));
-	if(map == NULL){ ncand_out[t] = 0xFFFFFFFFu; return; }
-	for(uint32_t i = 0; i < cap; i++) map[i].key = 0xFFFFFFFFu;
-	wtz_sacc_f af; af.tab = tab; af.mask = tmask; af.seeds = seeds; af.rdlen = R.rdlen; af.pbid = pbid;
-	af.pblen_up = (uint32_t)(R.rdlen[pbid] * 1.2);                       /* double multiply, wtzmo.c:445 */
-	af.map = map; af.mmask = cap - 1; af.nkeys = 0;
-	wtz_kmer_walk(R, pbid, P->ksize, P->hk, P->ksave, af);
-	/* compact (key, ol) in place over the map storage, sort by key */
-	uint64_t *g = (uint64_t*)wtz_pool_alloc(pool, (size_t)(af.nkeys + 1) * 8);
-	if(g == NULL){ ncand_out[t] = 0xFFFFFFFFu; return; }
+	/* ---- C ---- */
+	uint32_t np = 64; while(np < T) np <<= 1;
+	pa = 0;
+	if(lane == 0) pa = (uint64_t)(uintptr_t)wtz_pool_alloc(pool, (size_t)np * 8 + (size_t)(T + 2) * 8 + (size_t)(T + 2) * 8);
+	pa = wtz_coop_bcast64(pa);
+	if(pa == 0){ if(lane == 0) ncand_out[t] = 0xFFFFFFFFu; return; }
+	uint64_t *tup = (uint64_t*)(uintptr_t)pa, *tv = tup + np, *grp = tv + (T + 2);
+	for(uint32_t i = T + lane; i < np; i += WTZ_NLANES) tup[i] = ~0ull;
+#if defined(__HIP_DEVICE_COMPILE__)
+	__threadfence_block();
+#endif
+	for(uint32_t e = lane; e < nk; e += WTZ_NLANES){
+		const uint32_t c = (uint32_t)(koff[e] & 0xFFFFu); const uint64_t o = koff[e] >> 16;
+		const uint32_t base = ktoff[e];
+		const uint64_t v = ((uint64_t)kqoff[e] << 16) | kqlen[e];
+		for(uint32_t k = 0; k < c; k++){
+			const uint32_t sd = seeds[o + k];
+			const bool drop = ((sd >> 1) == pbid) || (R.rdlen[sd >> 1] > pblen_up);          /* wtzmo.c:488-489 */
+			tup[base + k] = drop ? ~0ull : (((uint64_t)sd << 32) | (base + k));
+			tv[base + k] = v;
+		}
+	}
+	/* ---- D ---- */
+	wtz_coop_sort_u64(tup, np);
+	/* ---- E ---- */
 	uint32_t ng = 0;
-	for(uint32_t i = 0; i < cap; i++) if(map[i].key != 0xFFFFFFFFu) g[ng++] = ((uint64_t)map[i].key << 32) | map[i].ol;
-	wtz_heapsort_u64(g, ng);
-	uint32_t hn = ncand_out[t];                 /* heap carried across index parts (-G), 0 otherwise */
-	wtz_cand_tail(g, ng, P->kovl, P->ncand, heap, &hn);
-	ncand_out[t] = hn;
+	for(uint32_t i0 = 0; i0 < T; i0 += WTZ_NLANES){
+		const uint32_t i = i0 + lane;
+		uint32_t head = 0; uint64_t g = 0;
+		if(i < T && tup[i] != ~0ull){
+			const uint32_t key = (uint32_t)(tup[i] >> 32);
+			if(i == 0 || (uint32_t)(tup[i - 1] >> 32) != key){
+				head = 1;
+				uint32_t ol = 0, lst = 0;
+				for(uint32_t r = i; r < T && tup[r] != ~0ull && (uint32_t)(tup[r] >> 32) == key; r++){
+					const uint64_t v = tv[(uint32_t)tup[r]];
+					const uint32_t qo = (uint32_t)(v >> 16), ql = (uint32_t)(v & 0xFFFFu);
+					if(qo >= lst) ol += ql; else ol += qo + ql - lst;                           /* wtzmo.c:558-559 */
+					lst = qo + ql;
+				}
+				g = ((uint64_t)key << 32) | ol;
+			}
+		}
+		uint32_t chunk; const uint32_t ex = wtz_coop_excl_scan(head, &chunk);
+		if(head) grp[ng + ex] = g;
+		ng += chunk;
+	}
+#if defined(__HIP_DEVICE_COMPILE__)
+	__threadfence_block();
+#endif
+	/* ---- F ---- */
+	if(lane == 0){
+		uint32_t hn = ncand_out[t];                 /* heap carried across index parts (-G), 0 otherwise */
+		wtz_cand_tail(grp, ng, P->kovl, P->ncand, cand_out + (size_t)t * stride, &hn);
+		ncand_out[t] = hn;
+	}
 }
 
 #endif

@@ -44,9 +44,10 @@ WTZ_HD void wtz_task_pair(uint32_t t, const wtz_env_t &V, const uint32_t *qid, c
 	wtz_zhit_t *sorted = NULL;
 #if defined(__HIP_DEVICE_COMPILE__)
 	__threadfence_block();
-	if(ok && !P->dot_matrix && n * P->zsize >= P->ztot){      /* uniform: the (off1,off2) order of the zmo engine, wave-parallel when tie-free */
+	if(ok && n * P->zsize >= P->ztot){      /* uniform: the first ordering of either engine, wave-parallel when tie-free */
 		int pbad = 0;
-		sorted = wtz_sort_hits_wave(hits, n, V.pool, (uint64_t*)wtz_wave_scratch(), WTZ_PAIR_LDS_BYTES / 8, &pbad);
+		if(P->dot_matrix) sorted = wtz_sort_hits_wave<1>(hits, n, V.pool, (uint64_t*)wtz_wave_scratch(), WTZ_PAIR_LDS_BYTES / 8, &pbad);
+		else              sorted = wtz_sort_hits_wave<0>(hits, n, V.pool, (uint64_t*)wtz_wave_scratch(), WTZ_PAIR_LDS_BYTES / 8, &pbad);
 		if(pbad) r.bad = 1;
 	}
 #endif
@@ -57,7 +58,8 @@ WTZ_HD void wtz_task_pair(uint32_t t, const wtz_env_t &V, const uint32_t *qid, c
 	r.gate = 1;
 	wtz_vec<wtz_zhit_t> cache; cache.a = hits; cache.n = n; cache.cap = n + 2; cache.pool = V.pool; cache.bad = 0;
 	if(P->dot_matrix){
-		wtz_dm_result_t d = wtz_dot_matrix_align(cache, V.pool, (int32_t)V.R.rdlen[q], (int32_t)V.R.rdlen[c], P, &r.bad);
+		if(sorted) cache.a = sorted;
+		wtz_dm_result_t d = wtz_dot_matrix_align(cache, V.pool, (int32_t)V.R.rdlen[q], (int32_t)V.R.rdlen[c], P, &r.bad, sorted != NULL);
 		r.dm_score = d.score; r.dm_qb = d.qb; r.dm_qe = d.qe; r.dm_tb = d.tb; r.dm_te = d.te; r.dm_dir = d.dir;
 		res[t] = r; return;
 	}
@@ -108,7 +110,25 @@ typedef struct {                 /* one (pair,strand) to align */
 typedef struct {
 	wtz_aln_t x; uint32_t n_regs; uint32_t cigar_len; uint32_t *cigar; int32_t bad;
 	unsigned long long cells_shift, cells_fixed, cells_global;
+	uint32_t text_len;
 } wtz_alnres_dev_t;
+
+WTZ_HD uint32_t wtz_cigar_text_len(const uint32_t *c, uint32_t n){       /* kswx.h:1093-1120: zero-length ops are skipped */
+	uint32_t k = 0;
+	for(uint32_t i = 0; i < n; i++){ uint32_t len = c[i] >> 4; if(len == 0) continue; uint32_t d = 1; while(len >= 10){ len /= 10; d++; } k += d + 1; }
+	return k;
+}
+WTZ_HD void wtz_cigar_text_write(const uint32_t *c, uint32_t n, char *s){
+	uint32_t k = 0;
+	for(uint32_t i = 0; i < n; i++){
+		uint32_t op = c[i] & 0xF, len = c[i] >> 4;
+		if(len == 0) continue;
+		char d[12]; int nd = 0;
+		while(len){ d[nd++] = (char)('0' + len % 10); len /= 10; }
+		while(nd) s[k++] = d[--nd];
+		s[k++] = op == 0 ? 'M' : (op == 1 ? 'I' : 'D');
+	}
+}
 
 WTZ_HD wtz_readview wtz_view(const wtz_reads_t &R, uint32_t id, uint32_t rev){ wtz_readview v; v.bits = R.bits; v.off = R.rdoff[id]; v.len = R.rdlen[id]; v.rev = rev; return v; }
 
@@ -301,7 +321,7 @@ WTZ_HD void wtz_task_stitch_fin(uint32_t t, const wtz_env_t &V, const wtz_alnite
 		}
 		if(jobsL[t].valid) r.cells_shift += jobsL[t].cells;
 		if(st.cigar.bad) r.bad = 1;
-		r.x = x; r.cigar = st.cigar.a; r.cigar_len = st.cigar.n;
+		r.x = x; r.cigar = st.cigar.a; r.cigar_len = st.cigar.n; r.text_len = wtz_cigar_text_len(st.cigar.a, st.cigar.n);
 	}
 	out[t] = r;
 }

@@ -128,10 +128,12 @@ struct wtz_gt_idx_off2 { const wtz_zhit_t *rs; WTZ_HDM bool operator()(uint32_t 
  * no ties means the ascending order is unique and equals the reference's; any tie makes the caller run the swap-exact
  * sequential sort instead.  Returns the sorted copy (with the two zeroed sentinels) or NULL (tie / too large / pool).
  */
+template<int BYDIAG>
 WTZ_D wtz_zhit_t *wtz_sort_hits_wave(const wtz_zhit_t *hits, uint32_t n, wtz_pool_t *pool, uint64_t *lds, uint32_t lds_u64, int *pool_bad){
 	const uint32_t lane = WTZ_LANE;
 	*pool_bad = 0;
-	if(n < 2 || n > 65535u) return NULL;
+	if(n < 2 || n > (BYDIAG ? 32767u : 65535u)) return NULL;
+	const int SH = BYDIAG ? 15 : 16;             /* index bits below the key */
 	uint32_t np = 64; while(np < n) np <<= 1;
 	uint64_t *w;
 	if(lds && np <= lds_u64) w = lds;
@@ -142,8 +144,14 @@ WTZ_D wtz_zhit_t *wtz_sort_hits_wave(const wtz_zhit_t *hits, uint32_t n, wtz_poo
 		w = (uint64_t*)(uintptr_t)a;
 		if(w == NULL){ *pool_bad = 1; return NULL; }
 	}
-	for(uint32_t i = lane; i < np; i += 64)
-		w[i] = i < n ? (((uint64_t)ZH_OFF1(hits[i]) << 40) | ((uint64_t)ZH_OFF2(hits[i]) << 16) | i) : ~0ull;
+	for(uint32_t i = lane; i < np; i += 64){
+		uint64_t v = ~0ull;
+		if(i < n){
+			if(BYDIAG) v = ((uint64_t)((int64_t)ZH_OFF1(hits[i]) - (int64_t)ZH_OFF2(hits[i]) + (1 << 24)) << 39) | ((uint64_t)ZH_OFF1(hits[i]) << 15) | i;   /* denoising_hzmps order, hzm_aln.h:728 */
+			else       v = ((uint64_t)ZH_OFF1(hits[i]) << 40) | ((uint64_t)ZH_OFF2(hits[i]) << 16) | i;                                                              /* process_hzmps order, hzm_aln.h:1185 */
+		}
+		w[i] = v;
+	}
 	__threadfence_block();
 	for(uint32_t k = 2; k <= np; k <<= 1){
 		for(uint32_t j = k >> 1; j > 0; j >>= 1){
@@ -169,7 +177,7 @@ WTZ_D wtz_zhit_t *wtz_sort_hits_wave(const wtz_zhit_t *hits, uint32_t n, wtz_poo
 		}
 	}
 	uint32_t tie = 0;
-	for(uint32_t i = lane; i + 1 < n; i += 64) if((w[i] >> 16) == (w[i + 1] >> 16)) tie = 1;
+	for(uint32_t i = lane; i + 1 < n; i += 64) if((w[i] >> SH) == (w[i + 1] >> SH)) tie = 1;
 	uint32_t any; (void)wtz_coop_excl_scan(tie, &any);
 	if(any) return NULL;
 	uint64_t oa = 0;
@@ -177,7 +185,7 @@ WTZ_D wtz_zhit_t *wtz_sort_hits_wave(const wtz_zhit_t *hits, uint32_t n, wtz_poo
 	oa = wtz_coop_bcast64(oa);
 	wtz_zhit_t *out = (wtz_zhit_t*)(uintptr_t)oa;
 	if(out == NULL){ *pool_bad = 1; return NULL; }
-	for(uint32_t i = lane; i < n; i += 64) out[i] = hits[(uint32_t)(w[i] & 0xFFFFu)];
+	for(uint32_t i = lane; i < n; i += 64) out[i] = hits[(uint32_t)(w[i] & ((1u << SH) - 1u))];
 	if(lane == 0){ wtz_zhit_t z0; z0.o1 = z0.o2 = z0.ll = z0.gid = 0; out[n] = z0; out[n + 1] = z0; }
 	__threadfence_block();
 	return out;

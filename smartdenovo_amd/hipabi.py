@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "libwtzmo_hip.so")
 SYMBOLS = [
     "wtz_last_error", "wtz_device_count", "wtz_ctx_create", "wtz_ctx_destroy", "wtz_ctx_clone", "wtz_upload_reads",
     "wtz_index_build", "wtz_zindex_build", "wtz_candidates", "wtz_batch_begin", "wtz_pairs_seed",
-    "wtz_pairs_windows", "wtz_pairs_align", "wtz_fetch_cigars", "wtz_get_counters", "wtz_reset_counters",
+    "wtz_pairs_windows", "wtz_pairs_align", "wtz_fetch_cigars", "wtz_fetch_cigar_text", "wtz_get_counters", "wtz_reset_counters",
 ]
 
 
@@ -51,7 +51,8 @@ PAIR_SUMMARY = np.dtype([("n_hits", "<u4"), ("gate", "<u4"), ("ovl", "<u4", 2), 
                          ("dm_score", "<i4"), ("dm_qb", "<i4"), ("dm_qe", "<i4"), ("dm_tb", "<i4"), ("dm_te", "<i4"), ("dm_dir", "<i4")])
 WINBOX = np.dtype([("beg", "<i4", 2), ("end", "<i4", 2)])
 ALN_RESULT = np.dtype([("score", "<i4"), ("tb", "<i4"), ("te", "<i4"), ("qb", "<i4"), ("qe", "<i4"), ("aln", "<i4"), ("mat", "<i4"),
-                       ("mis", "<i4"), ("ins", "<i4"), ("del", "<i4"), ("n_regs", "<u4"), ("cigar_len", "<u4"), ("cigar_off", "<u8")])
+                       ("mis", "<i4"), ("ins", "<i4"), ("del", "<i4"), ("n_regs", "<u4"), ("cigar_len", "<u4"), ("cigar_off", "<u8"),
+                       ("text_len", "<u4"), ("pad", "<u4"), ("text_off", "<u8")])
 
 
 class Counters(C.Structure):
