@@ -122,13 +122,25 @@ WTZ_D uint32_t wtz_coop_excl_scan(uint32_t v, uint32_t *total){
 	return x - v;
 }
 WTZ_D uint64_t wtz_coop_bcast64(uint64_t v){ return (uint64_t)__shfl((unsigned long long)v, 0, 64); }
-WTZ_D uint32_t wtz_coop_bcast32(uint32_t v){ return (uint32_t)__shfl((int)v, 0, 64); }
+WTZ_D uint32_t wtz_coop_bcast32(uint32_t v){ return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+/* rank of this lane among the lanes whose predicate holds (ballot + mbcnt: no cross-lane data movement), and their number */
+WTZ_D uint32_t wtz_coop_rank(bool keep, uint32_t *total){
+	const unsigned long long m = __ballot(keep);
+	*total = (uint32_t)__popcll(m);
+	return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+/* value of lane `l` (l uniform) */
+WTZ_D uint32_t wtz_coop_lane32(uint32_t v, uint32_t l){ return (uint32_t)__builtin_amdgcn_readlane((int)v, __builtin_amdgcn_readfirstlane((int)l)); }
+#define WTZ_WAVE_SYNC() __threadfence_block()
 #else
 #define WTZ_LANE 0u
 #define WTZ_NLANES 1u
 static inline uint32_t wtz_coop_excl_scan(uint32_t v, uint32_t *total){ *total = v; return 0; }
 static inline uint64_t wtz_coop_bcast64(uint64_t v){ return v; }
 static inline uint32_t wtz_coop_bcast32(uint32_t v){ return v; }
+static inline uint32_t wtz_coop_rank(bool keep, uint32_t *total){ *total = keep ? 1u : 0u; return 0; }
+static inline uint32_t wtz_coop_lane32(uint32_t v, uint32_t){ return v; }
+#define WTZ_WAVE_SYNC() do {} while(0)
 #endif
 
 /* growable vector living in the pool (old storage is simply abandoned on growth) */

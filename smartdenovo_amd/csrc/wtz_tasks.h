@@ -51,35 +51,48 @@ WTZ_HD void wtz_task_pair(uint32_t t, const wtz_env_t &V, const uint32_t *qid, c
 		if(pbad) r.bad = 1;
 	}
 #endif
-	if(WTZ_LANE != 0) return;
-	if(!ok || r.bad){ r.bad = 1; res[t] = r; return; }
+	const uint32_t lane = WTZ_LANE;
+	if(!ok || r.bad){ r.bad = 1; if(lane == 0) res[t] = r; return; }
 	r.n_hits = n;
-	if(n * P->zsize < P->ztot){ r.gate = 0; res[t] = r; return; }
+	if(n * P->zsize < P->ztot){ r.gate = 0; if(lane == 0) res[t] = r; return; }
 	r.gate = 1;
-	wtz_vec<wtz_zhit_t> cache; cache.a = hits; cache.n = n; cache.cap = n + 2; cache.pool = V.pool; cache.bad = 0;
 	if(P->dot_matrix){
-		if(sorted) cache.a = sorted;
+		if(lane != 0) return;
+		wtz_vec<wtz_zhit_t> cache; cache.a = sorted ? sorted : hits; cache.n = n; cache.cap = n + 2; cache.pool = V.pool; cache.bad = 0;
 		wtz_dm_result_t d = wtz_dot_matrix_align(cache, V.pool, (int32_t)V.R.rdlen[q], (int32_t)V.R.rdlen[c], P, &r.bad, sorted != NULL);
 		r.dm_score = d.score; r.dm_qb = d.qb; r.dm_qe = d.qe; r.dm_tb = d.tb; r.dm_te = d.te; r.dm_dir = d.dir;
 		res[t] = r; return;
 	}
-	if(sorted) cache.a = sorted;                                        /* tie-free: the unique ascending order */
-	else wtz_sort_exact(cache.a, (size_t)cache.n, wtz_gt_off12());       /* process_hzmps, hzm_aln.h:1184-1186, swap-exact */
+	/* zmo: every lane follows the window merge (uniform control flow); the vectors belong to lane 0 */
+	if(sorted) hits = sorted;                                                             /* tie-free: the unique ascending order */
+	else { if(lane == 0) wtz_sort_exact(hits, (size_t)n, wtz_gt_off12()); WTZ_WAVE_SYNC(); }   /* process_hzmps, hzm_aln.h:1184-1186, swap-exact */
 	const uint64_t tk2 = WTZ_TICK();
 	wtz_winscratch_t sc;
-	sc.ts = (uint32_t*)wtz_pool_alloc(V.pool, (size_t)(n + 2) * (4 * 5 + 8 + sizeof(wtz_zhit_t)) + 16);
-	if(sc.ts == NULL){ r.bad = 1; res[t] = r; return; }
+	{
+		uint64_t pa = 0;
+		if(lane == 0) pa = (uint64_t)(uintptr_t)wtz_pool_alloc(V.pool, (size_t)(n + 2) * (4 * 5 + 8 + sizeof(wtz_zhit_t)) + 16);
+		pa = wtz_coop_bcast64(pa);
+		sc.ts = (uint32_t*)(uintptr_t)pa;
+	}
+	if(sc.ts == NULL){ r.bad = 1; if(lane == 0) res[t] = r; return; }
 	sc.as = (int32_t*)(sc.ts + (n + 2)); sc.wb = sc.ts + 2 * (n + 2); sc.we = sc.ts + 3 * (n + 2); sc.wo = sc.ts + 4 * (n + 2);
 	sc.tk = (uint64_t*)(sc.ts + 5 * (n + 2) + ((5 * (n + 2)) & 1)); sc.ztmp = (wtz_zhit_t*)(sc.tk + (n + 2));
-	sc.lds = (uint64_t*)wtz_wave_scratch(); sc.lds_u64 = sc.lds ? WTZ_PAIR_LDS_BYTES / 8 : 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+	sc.lds = (uint64_t*)wtz_wave_scratch();
+#else
+	static thread_local uint64_t emul_lds[WTZ_PAIR_LDS_BYTES / 8];     /* host emulation: the LDS slice of the (single-lane) wave */
+	sc.lds = emul_lds;
+#endif
+	sc.lds_u64 = WTZ_PAIR_LDS_BYTES / 8;
 	for(uint32_t dir = 0; dir < 2; dir++){
-		wtz_vec<wtz_win_t> wins; wins.init(V.pool, 16);
-		wtz_vec<wtz_zhit_t> anchors; anchors.init(V.pool, n + 16);
-		if(wtz_merge_windows(cache.a, n, dir, wins, anchors, sc, P->zsize, P->kwin, P->kstep, P->zovl) == 0){
-			if(wins.bad || anchors.bad) r.bad = 1;
-			continue;
-		}
+		wtz_vec<wtz_win_t> wins; wtz_vec<wtz_zhit_t> anchors;
+		wins.a = NULL; wins.n = wins.cap = 0; wins.pool = V.pool; wins.bad = 0;
+		anchors.a = NULL; anchors.n = anchors.cap = 0; anchors.pool = V.pool; anchors.bad = 0;
+		if(lane == 0){ wins.init(V.pool, 16); anchors.init(V.pool, n + 16); }
+		const uint32_t nw = wtz_merge_windows_coop(hits, n, dir, wins, anchors, sc, P->zsize, P->kwin, P->kstep, P->zovl);
+		if(lane != 0) continue;
 		if(wins.bad || anchors.bad){ r.bad = 1; continue; }
+		if(nw == 0) continue;
 		int32_t *mem = (int32_t*)wtz_pool_alloc(V.pool, (size_t)wins.n * 8 + 8);
 		if(mem == NULL){ r.bad = 1; continue; }
 		r.ovl[dir] = WTZ_OVL29(wtz_chain_windows(wins.a, wins.n, P->W, mem));
@@ -89,6 +102,7 @@ WTZ_HD void wtz_task_pair(uint32_t t, const wtz_env_t &V, const uint32_t *qid, c
 		for(uint32_t j = 0; j < wins.n; j++){ if(wins.a[j].closed) continue; wins.a[k++] = wins.a[j]; }
 		r.nwin[dir] = k; r.win[dir] = wins.a; r.anchors[dir] = anchors.a; r.nanchors[dir] = anchors.n;
 	}
+	if(lane != 0) return;
 	{ const uint64_t tk3 = WTZ_TICK(); r.tick[0] = (uint32_t)((tk1 - tk0) >> 10); r.tick[1] = (uint32_t)((tk2 - tk1) >> 10); r.tick[2] = (uint32_t)((tk3 - tk2) >> 10); r.tick[3] = (uint32_t)((tk3 - tk0) >> 10); }
 	res[t] = r;
 }

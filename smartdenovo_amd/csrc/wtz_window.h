@@ -367,6 +367,210 @@ WTZ_HD uint32_t wtz_merge_windows(const wtz_zhit_t *rs, uint32_t n_rs, uint32_t 
 	return ret;
 }
 
+/*
+ * Wave-cooperative form of the two functions above (same results).  What bounds a pair here is not arithmetic but the
+ * latency of dependent loads on a single lane, so:
+ *   - the merge loop reads the (off1,off2)-ordered matches through two 64-entry register windows (one hit per lane,
+ *     fetched with one coalesced load; the uniform cursor reads them with v_readlane);
+ *   - a window scan compacts its strand-filtered matches with ballot ranks, orders them by off2 with the wave-wide
+ *     bitonic network (any off2 tie makes lane 0 redo the swap-exact sort from the original order - tie order is
+ *     observable), and gathers them ONCE into LDS; the sequential sweep / median / anchor ordering of lane 0 then run
+ *     out of LDS and registers only.
+ * Vectors (`wins`, `anchors`) are owned by lane 0; counts and the window extent the merge loop needs are broadcast.
+ * A scan whose matches do not fit the LDS slice (np + 2n + 2 > lds_u64 words) falls back to the scalar body on lane 0.
+ */
+typedef struct { uint32_t base, o1, o2, ll; } wtz_hitcur_t;        /* lane l holds match base + l */
+WTZ_HD void wtz_hitcur_get(wtz_hitcur_t &c, const wtz_zhit_t *rs, uint32_t lim, uint32_t i, uint32_t &o1, uint32_t &o2, uint32_t &ll){
+	if(i - c.base >= WTZ_NLANES){           /* uniform; also true for i < base */
+		c.base = i;
+		const uint32_t idx = i + WTZ_LANE;
+		if(idx <= lim){ const wtz_zhit_t h = rs[idx]; c.o1 = h.o1; c.o2 = h.o2; c.ll = h.ll; } else { c.o1 = c.o2 = c.ll = 0; }
+	}
+	const uint32_t l = i - c.base;
+	o1 = wtz_coop_lane32(c.o1, l); o2 = wtz_coop_lane32(c.o2, l); ll = wtz_coop_lane32(c.ll, l);
+}
+
+WTZ_HD uint32_t wtz_scan_windows_coop(const wtz_zhit_t *rs, uint32_t dir, uint32_t beg, uint32_t end, int32_t bound,
+		wtz_vec<wtz_win_t> &wins, wtz_vec<wtz_zhit_t> &anchors, const wtz_winscratch_t &sc, uint32_t zsize, uint32_t kwin, uint32_t zovl, int32_t *max_e0){
+	const uint32_t lane = WTZ_LANE;
+	uint64_t *K = sc.lds;
+	uint32_t n = 0, ret = 0; int32_t me0 = -0x7FFFFFFF;
+	/* ---- strand / bound filter (the prefix skip of hzm_aln.h:425-431 is the same predicate: off1 is non-decreasing) ---- */
+	for(int pass = 0; pass < 2; pass++){
+		n = 0;
+		for(uint32_t b0 = beg; b0 < end; b0 += WTZ_NLANES){
+			const uint32_t idx = b0 + lane;
+			bool keep = false; uint32_t o2 = 0;
+			if(idx < end){ const uint32_t o1 = rs[idx].o1; o2 = rs[idx].o2; keep = (((o1 ^ o2) >> 31) == dir) && ((int32_t)(o1 & 0x7FFFFFFFu) >= bound); }
+			uint32_t tot; const uint32_t pos = wtz_coop_rank(keep, &tot);
+			if(pass && keep) K[n + pos] = ((uint64_t)(o2 & 0x7FFFFFFFu) << 32) | idx;
+			n += tot;
+		}
+		if(pass) break;
+		if(n * zsize < zovl) return 0;
+		uint32_t np0 = 64; while(np0 < n) np0 <<= 1;
+		if(K == NULL || np0 + 2 * n + 2 > sc.lds_u64){       /* does not fit: scalar body on lane 0 */
+			uint32_t r = 0; int32_t e = -0x7FFFFFFF;
+			if(lane == 0){
+				r = wtz_scan_windows(rs, dir, beg, end, bound, wins, anchors, sc, zsize, kwin, zovl);
+				for(uint32_t a = 0; a < r; a++){ const int32_t e0 = wins.a[wins.n + a - r].end[0]; if(e < e0) e = e0; }
+			}
+			*max_e0 = (int32_t)wtz_coop_bcast32((uint32_t)e);
+			return wtz_coop_bcast32(r);
+		}
+	}
+	uint32_t np = 64; while(np < n) np <<= 1;
+	for(uint32_t i = n + lane; i < np; i += WTZ_NLANES) K[i] = ~0ull;
+	WTZ_WAVE_SYNC();
+	wtz_coop_sort_u64(K, np);
+	{
+		bool tie = false;
+		for(uint32_t i = lane; i + 1 < n; i += WTZ_NLANES) if((K[i] >> 32) == (K[i + 1] >> 32)) tie = true;
+		uint32_t any; (void)wtz_coop_rank(tie, &any);
+		if(any){        /* off2 ties: the reference's swap sequence decides, from the original order (hzm_aln.h:449) */
+			uint32_t m = 0;
+			for(uint32_t b0 = beg; b0 < end; b0 += WTZ_NLANES){
+				const uint32_t idx = b0 + lane;
+				bool keep = false; uint32_t o2 = 0;
+				if(idx < end){ const uint32_t o1 = rs[idx].o1; o2 = rs[idx].o2; keep = (((o1 ^ o2) >> 31) == dir) && ((int32_t)(o1 & 0x7FFFFFFFu) >= bound); }
+				uint32_t tot; const uint32_t pos = wtz_coop_rank(keep, &tot);
+				if(keep) K[m + pos] = ((uint64_t)(o2 & 0x7FFFFFFFu) << 32) | idx;
+				m += tot;
+			}
+			WTZ_WAVE_SYNC();
+			if(lane == 0) wtz_sort_exact(K, (size_t)n, wtz_gt_hi32());
+			WTZ_WAVE_SYNC();
+		}
+	}
+	wtz_zhit_t *S = (wtz_zhit_t*)(K + np);
+	for(uint32_t x = lane; x < n; x += WTZ_NLANES) S[x] = rs[(uint32_t)K[x]];
+	WTZ_WAVE_SYNC();
+	if(lane == 0){
+		uint32_t i, j, n2 = 0, ol = 0, ol2, lst = 0, s, t;
+		uint32_t lwo = 0, lwb_o2 = 0, lwe_o2 = 0;        /* the open window: overlap and off2 of its two ends */
+		for(i = j = 0; i < n; i++){
+			const wtz_zhit_t p = S[i];
+			while(ZH_OFF2(p) + ZH_LEN2(p) > ZH_OFF2(S[j]) + kwin){
+				const wtz_zhit_t p0 = S[j++];
+				const wtz_zhit_t p1 = S[j];
+				s = ZH_OFF2(p1); t = ZH_OFF2(p0) + ZH_LEN2(p0);
+				ol2 = s < t ? t - s : 0;
+				ol = ol + ol2 - ZH_LEN2(p0);
+			}
+			ol += (ZH_OFF2(p) > lst) ? ZH_LEN2(p) : ZH_OFF2(p) + ZH_LEN2(p) - lst;
+			lst = ZH_OFF2(p) + ZH_LEN2(p);
+			if(ol >= zovl){
+				const uint32_t jo2 = ZH_OFF2(S[j]);
+				if(n2 && (ZH_OFF2(p) <= lwe_o2 + kwin / 3 || jo2 <= lwb_o2 + kwin / 3)){
+					if(ol > lwo){ sc.wb[n2-1] = j; sc.we[n2-1] = i; lwo = ol; lwb_o2 = jo2; lwe_o2 = ZH_OFF2(p); }
+				} else { sc.wb[n2] = j; sc.we[n2] = i; lwo = ol; lwb_o2 = jo2; lwe_o2 = ZH_OFF2(p); n2++; }
+			}
+		}
+		int32_t last_end1 = 0; uint32_t last_ovl = 0;
+		for(uint32_t wi = 0; wi < n2; wi++){
+			const uint32_t size = anchors.n, wb = sc.wb[wi], we = sc.we[wi];
+			int32_t offset, off; uint32_t offn = 0, cnt = 0;
+			int32_t *as = (int32_t*)K;
+			for(j = wb; j <= we; j++){ const wtz_zhit_t p = S[j]; as[offn++] = (int32_t)ZH_OFF1(p) - (int32_t)ZH_OFF2(p); }
+			offset = wtz_median(as, (int32_t)offn);
+			uint64_t *ak = K;                     /* `as` is dead: (off1<<32 | position in S) of the members, hzm_aln.h:519 */
+			for(j = wb; j <= we; j++){
+				const wtz_zhit_t p = S[j];
+				off = (int32_t)ZH_OFF1(p) - (int32_t)ZH_OFF2(p);
+				if(off < offset - WTZ_KWIN_MAX_OFFSET_DEV || off > offset + WTZ_KWIN_MAX_OFFSET_DEV) continue;
+				ak[cnt++] = ((uint64_t)ZH_OFF1(p) << 32) | j;
+			}
+			if(cnt == 0) continue;
+			wtz_sort_exact(ak, (size_t)cnt, wtz_gt_hi32());
+			if(!anchors.reserve(size + cnt)) break;
+			wtz_win_t w;
+			w.pb2 = 0; w.closed = 0; w.dir = (uint8_t)dir; w.pad = 0;
+			w.anchors[0] = size; w.anchors[1] = 0;
+			w.beg[0] = w.beg[1] = 0x7FFFFFFF; w.end[0] = w.end[1] = 0;
+			ol = lst = 0;
+			for(uint32_t k = 0; k < cnt; k++){
+				const wtz_zhit_t p = S[(uint32_t)ak[k]];
+				anchors.a[size + k] = p;
+				ol += (ZH_OFF1(p) > lst) ? ZH_LEN1(p) : ZH_OFF1(p) + ZH_LEN1(p) - lst;
+				lst = ZH_OFF1(p) + ZH_LEN1(p);
+				if((int32_t)ZH_OFF1(p) < w.beg[0]) w.beg[0] = (int32_t)ZH_OFF1(p);
+				if((int32_t)(ZH_OFF1(p) + ZH_LEN1(p)) > w.end[0]) w.end[0] = (int32_t)(ZH_OFF1(p) + ZH_LEN1(p));
+				if((int32_t)ZH_OFF2(p) < w.beg[1]) w.beg[1] = (int32_t)ZH_OFF2(p);
+				if((int32_t)(ZH_OFF2(p) + ZH_LEN2(p)) > w.end[1]) w.end[1] = (int32_t)(ZH_OFF2(p) + ZH_LEN2(p));
+			}
+			if(ol * 2 < zovl) continue;
+			if(ret && (w.end[1] <= (int32_t)((uint32_t)last_end1 + kwin / 3) && ol <= last_ovl)) continue;
+			ret++;
+			anchors.n = size + cnt;
+			w.ovl = WTZ_OVL29(ol);
+			w.anchors[1] = anchors.n;
+			if(!wins.push(w)) break;
+			last_end1 = w.end[1]; last_ovl = w.ovl;
+			if(me0 < w.end[0]) me0 = w.end[0];
+		}
+	}
+	WTZ_WAVE_SYNC();
+	*max_e0 = (int32_t)wtz_coop_bcast32((uint32_t)me0);
+	return wtz_coop_bcast32(ret);
+}
+
+WTZ_HD uint32_t wtz_merge_windows_coop(const wtz_zhit_t *rs, uint32_t n_rs, uint32_t dir, wtz_vec<wtz_win_t> &wins, wtz_vec<wtz_zhit_t> &anchors,
+		const wtz_winscratch_t &sc, uint32_t zsize, uint32_t kwin, uint32_t kstep, uint32_t zovl){
+	const uint32_t P_off1 = 0x1FFFFFu, P_len1 = 0x3FFu, lim = n_rs + 1;
+	uint32_t i, j, n, ol, ol2, lst, wlst, s, t, ret, o1, o2, ll;
+	uint32_t p_off1, p_len1, p0_off1, p0_len1, p1_off1, p1_len1;
+	int32_t nxt;
+	wtz_hitcur_t ci, cj; ci.base = cj.base = 0x80000000u; ci.o1 = ci.o2 = ci.ll = cj.o1 = cj.o2 = cj.ll = 0;
+	ol = 0; lst = 0; wlst = 0; ret = 0;
+	for(j = 0; j < n_rs; j++){ wtz_hitcur_get(cj, rs, lim, j, o1, o2, ll); if(((o1 ^ o2) >> 31) ^ dir) continue; break; }
+	if(j == n_rs) return 0;
+	wtz_hitcur_get(cj, rs, lim, j, o1, o2, ll);
+	p0_off1 = o1 & 0x7FFFFFFFu; p0_len1 = ll & 0xFFFFu;
+	p_off1 = p_len1 = 0;
+	for(i = j; i <= n_rs; i++){
+		if(i < n_rs){
+			wtz_hitcur_get(ci, rs, lim, i, o1, o2, ll);
+			if(((o1 ^ o2) >> 31) ^ dir) continue;
+			p_off1 = o1 & 0x7FFFFFFFu; p_len1 = ll & 0xFFFFu;
+		} else { p_off1 = P_off1; p_len1 = P_len1; }
+		if(p_off1 > p0_off1 + kwin){
+			if(ol >= zovl){
+				int32_t me0 = 0;
+				if((n = wtz_scan_windows_coop(rs, dir, j, i, (int32_t)wlst, wins, anchors, sc, zsize, kwin, zovl, &me0))){
+					if((int32_t)wlst < me0 + 20) wlst = (uint32_t)(me0 + 20);
+					ret += n;
+					p0_off1 = p_off1; p0_len1 = p_len1; ol = p_len1; lst = p_off1 + p_len1; j = i;
+				} else {
+					nxt = (int32_t)(p0_off1 + kstep);
+					while((int32_t)p0_off1 < nxt && j < i){
+						++j; wtz_hitcur_get(cj, rs, lim, j, o1, o2, ll); p1_off1 = o1 & 0x7FFFFFFFu; p1_len1 = ll & 0xFFFFu;
+						s = WTZ_MAX(p0_off1, p1_off1);
+						t = WTZ_MIN(p0_off1 + p0_len1, p1_off1 + p1_len1);
+						ol2 = s < t ? t - s : 0;
+						ol = ol + ol2 - p0_len1;
+						p0_off1 = p1_off1; p0_len1 = p1_len1;
+					}
+				}
+			}
+			if(p_off1 == P_off1) break;
+			while(p_off1 > p0_off1 + kwin){
+				++j; wtz_hitcur_get(cj, rs, lim, j, o1, o2, ll); p1_off1 = o1 & 0x7FFFFFFFu; p1_len1 = ll & 0xFFFFu;
+				s = WTZ_MAX(p0_off1, p1_off1);
+				t = WTZ_MIN(p0_off1 + p0_len1, p1_off1 + p1_len1);
+				ol2 = s < t ? t - s : 0;
+				ol = ol + ol2 - p0_len1;
+				p0_off1 = p1_off1; p0_len1 = p1_len1;
+			}
+		} else {
+			if(p_off1 >= lst) ol += p_len1;
+			else if((int32_t)(p_off1 + p_len1) > (int32_t)lst) ol += p_off1 + p_len1 - lst;
+			else continue;
+			lst = p_off1 + p_len1;
+		}
+	}
+	return ret;
+}
+
 /* returns the chain weight; members get closed=0, the rest closed=1. mem: 2*n ints */
 WTZ_HD int32_t wtz_chain_windows(wtz_win_t *regs, uint32_t n, int32_t W, int32_t *mem){
 	const int32_t max_overhang = 0; const float band_penalty = 0.05f;
