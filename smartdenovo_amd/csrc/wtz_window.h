@@ -176,8 +176,15 @@ WTZ_D wtz_zhit_t *wtz_sort_hits_wave(const wtz_zhit_t *hits, uint32_t n, wtz_poo
 			__threadfence_block();
 		}
 	}
+	/* equal keys: the swap sequence of the reference decides - except, for the (off1,off2) order of the zmo engine, when the
+	 * tied matches also agree in len1.  Those are cross-strand twins of ONE query z-mer; merge_paired_kmers_window reads
+	 * other-strand matches only through (off1, len1) (hzm_aln.h:615-650) and filters by strand everywhere else, so their
+	 * relative order cannot be observed (runs of three or more equal keys still take the exact path) */
 	uint32_t tie = 0;
-	for(uint32_t i = lane; i + 1 < n; i += 64) if((w[i] >> SH) == (w[i + 1] >> SH)) tie = 1;
+	for(uint32_t i = lane; i + 1 < n; i += 64) if((w[i] >> SH) == (w[i + 1] >> SH)){
+		if(BYDIAG) tie = 1;
+		else { const wtz_zhit_t &a = hits[(uint32_t)(w[i] & 0xFFFFu)], &b = hits[(uint32_t)(w[i + 1] & 0xFFFFu)]; if(ZH_LEN1(a) != ZH_LEN1(b) || ZH_STRAND(a) == ZH_STRAND(b) || (i + 2 < n && (w[i] >> SH) == (w[i + 2] >> SH))) tie = 1; }
+	}
 	uint32_t any; (void)wtz_coop_excl_scan(tie, &any);
 	if(any) return NULL;
 	uint64_t oa = 0;
