@@ -261,13 +261,18 @@ WTZ_HD int32_t wtz_chain_blocks(int32_t pblen1, int32_t pblen2, wtz_vec<wtz_win_
 	return mw;
 }
 
-WTZ_HD wtz_dm_result_t wtz_dot_matrix_align(wtz_vec<wtz_zhit_t> &cache, wtz_pool_t *pool, int32_t pblen1, int32_t pblen2, const wtz_params_t *P, int32_t *bad, bool presorted){
+WTZ_HD wtz_dm_result_t wtz_dot_matrix_align(wtz_vec<wtz_zhit_t> &cache, wtz_pool_t *pool, int32_t pblen1, int32_t pblen2, const wtz_params_t *P, int32_t *bad, bool presorted, uint64_t *tick_denoise){
 	wtz_dm_result_t ret; int32_t weight[2]; uint32_t d;
 	wtz_dmscratch_t S;
 	S.dst.init(pool, cache.n / 2 + 16); S.regs[0].init(pool, 16); S.regs[1].init(pool, 16);
 	S.diags.init(pool, 64); S.block.init(pool, 64); S.grps.init(pool, 16);
 	/* dst of strand 0 is consumed before strand 1 reuses it: regs only keep bounds */
 	wtz_denoise(cache.a, cache.n, S, P->xvar, P->yvar, P->min_block_len, presorted);
+#if defined(__HIP_DEVICE_COMPILE__)
+	*tick_denoise = (uint64_t)clock64();
+#else
+	*tick_denoise = 0;
+#endif
 	wtz_merge_blocks(S.regs[0], S, P->xvar, 2 * P->yvar);
 	wtz_merge_blocks(S.regs[1], S, P->xvar, 2 * P->yvar);
 	weight[0] = wtz_chain_blocks(pblen1, pblen2, S.regs[0], pool, P->xvar, P->max_overhang, P->deviation_penalty, P->gap_penalty, bad);

@@ -38,6 +38,7 @@ typedef struct {
 
 #ifdef __HIPCC__
 
+#define WTZ_WINALIGN_LDS_BYTES 8192      /* LDS slice of a window-alignment wave (== WTZ_WAVE_LDS_BYTES) */
 #define WTZ_TRACE_MAXCHUNK 1024          /* 64-row chunks: up to 65536 rows per problem */
 
 /* reusable trace storage of one task (pointers live in the pool so that lane 0 can chase them during traceback) */
@@ -493,13 +494,168 @@ __global__ void __launch_bounds__(64) wtz_kernel_extjobs(wtz_extjob_t *jobs, con
 	}
 }
 
+/*
+ * K-sw1 for the small problems between two anchors of a window (80 % have a band of <= 64 columns, 96 % <= 128 rows):
+ * the whole DP state lives in registers.  Lane l owns the C band-relative columns l*C .. l*C+C-1; the fixed band moves
+ * right by exactly one column per row once i > W, so the hand-over between rows is a register rotation plus one
+ * wave_shl DPP per array (no LDS rings).  The query is staged as 32-base words in VGPRs (the row's base comes from a
+ * v_readlane), the target as 32-base words in LDS; the trace is kept in LDS at 4 bits per cell (two rows per byte), so
+ * the traceback of lane 0 never leaves the CU.  Results are those of wtz_extend_wave<1> / kswx_extend_align_core.
+ * Requirements (checked by the caller): n_col <= 64*C, ((ql+1)/2)*64*C <= ztr_bytes, (tl+63)/32+1 <= tb words, ql <= 2048.
+ */
+WTZ_D int32_t wtz_dpp_wave_shl1(int32_t old, int32_t src){ return __builtin_amdgcn_update_dpp(old, src, 0x130, 0xF, 0xF, false); }
+WTZ_D int32_t wtz_dpp_wave_shr1(int32_t old, int32_t src){ return __builtin_amdgcn_update_dpp(old, src, 0x138, 0xF, 0xF, false); }
+
+template<int C>
+WTZ_D wtz_aln_t wtz_extend_fixed_reg(int32_t qlen, const wtz_seq_packed &query, int32_t tlen, const wtz_seq_packed &target, int32_t init_score,
+		int32_t ql, int32_t tl, int32_t W, int32_t M, int32_t X, int32_t I, int32_t D, int32_t E, int32_t T,
+		uint64_t *tb, uint8_t *ztr, wtz_cigar_t &cigars, unsigned long long *cells){
+	const int lane = (int)(threadIdx.x & 63);
+	wtz_aln_t x; memset(&x, 0, sizeof x);
+	if(lane == 0) cigars.n = 0;
+	if(init_score < 0) init_score = 0;
+	/* ---- stage both sequences ---- */
+	{
+		const int32_t nw = (tl + 31) / 32 + 1;
+		for(int32_t w = lane; w < nw; w += 64) tb[w] = wtz_pack32(target, w * 32, tl);
+	}
+	const uint64_t qw = wtz_pack32(query, lane * 32, ql);
+	const uint32_t qw_lo = (uint32_t)qw, qw_hi = (uint32_t)(qw >> 32);
+	__threadfence_block();
+	int32_t hp[C], ep[C]; uint32_t nibp[C];
+	#pragma unroll
+	for(int k = 0; k < C; k++){ hp[k] = -10000; ep[k] = -10000; nibp[k] = 0; }
+	int32_t mx = init_score, mi = -1, mj = -1, gmax = 0, gi = -1, gj = -1;
+	int32_t jbp = 0, i, i_done = -1;
+	unsigned long long ncell = 0;
+	const int32_t CE = C * E;
+	const uint32_t zrow = 64u * C;
+	for(i = 0; i < ql; i++){
+		int32_t jb = i - W; if(jb < 0) jb = 0;
+		int32_t je = i + W + 1; if(je > tl) je = tl;
+		const int32_t qs = __builtin_amdgcn_readfirstlane(i >> 5);
+		const uint32_t qsel = ((i & 16) ? (uint32_t)__builtin_amdgcn_readlane((int)qw_hi, qs) : (uint32_t)__builtin_amdgcn_readlane((int)qw_lo, qs));
+		const uint32_t qbase = (qsel >> ((i & 15) * 2)) & 3u;
+		const int32_t j0 = jb + lane * C;
+		uint32_t tbits;                                   /* the lane's <= C target bases */
+		{
+			const int32_t jj = j0 < tl ? j0 : (tl > 0 ? tl - 1 : 0);
+			const int32_t w = jj >> 5, sh = (jj & 31) * 2;
+			const uint64_t w0 = tb[w], w1 = tb[w + 1];
+			tbits = (uint32_t)(sh ? ((w0 >> sh) | (w1 << (64 - sh))) : w0);
+		}
+		/* ---- predecessors from the previous row's registers ---- */
+		int32_t pred[C], ein[C];
+		if(i == 0){
+			#pragma unroll
+			for(int k = 0; k < C; k++){ const int32_t j = j0 + k; pred[k] = (j == 0) ? init_score : init_score + D + E * j; ein[k] = -10000; }     /* rh[] / re[] initialisation, kswx.h:143-146 */
+		} else if(jb != jbp){                 /* band moved right by one: H(i-1,j-1) is the lane's own column, E(i-1,j) the next one */
+			const int32_t nxt = wtz_dpp_wave_shl1(-10000, ep[0]);
+			#pragma unroll
+			for(int k = 0; k < C; k++){ pred[k] = hp[k]; ein[k] = (k + 1 < C) ? ep[k + 1] : nxt; }
+		} else {                              /* band still starts at column 0 */
+			int32_t prv = wtz_dpp_wave_shr1(-10000, hp[C - 1]);
+			if(lane == 0) prv = init_score + I + E * i;                 /* H(i-1,-1), kswx.h:262 */
+			#pragma unroll
+			for(int k = 0; k < C; k++){ pred[k] = k ? hp[k - 1] : prv; ein[k] = ep[k]; }
+		}
+		/* ---- m and the lane's F aggregate ---- */
+		int32_t mv[C]; int32_t agg = -0x3FFFFFFF;
+		#pragma unroll
+		for(int k = 0; k < C; k++){
+			const uint32_t tbase = (tbits >> (2 * k)) & 3u;
+			mv[k] = pred[k] + ((qbase == tbase) ? M : X);
+			if(j0 + k < je){ const int32_t cand = mv[k] + D + E + (C - 1 - k) * E; agg = agg > cand ? agg : cand; }
+		}
+		int32_t f;
+		{
+			const int32_t g = agg - lane * CE;
+			const int32_t pm = wtz_wave_max_scan_excl(g, -0x3FFFFFFF);
+			const int32_t from_prev = (lane == 0) ? -0x3FFFFFFF : pm + (lane - 1) * CE;
+			const int32_t from_init = -10000 + lane * CE;
+			f = from_prev > from_init ? from_prev : from_init;
+		}
+		/* ---- H, E', F, trace nibble ---- */
+		int32_t best = -0x7FFFFFFF, bestj = -1, h_last = 0;
+		#pragma unroll
+		for(int k = 0; k < C; k++){
+			const int32_t j = j0 + k;
+			uint32_t nib = 0;
+			if(j < je){
+				const int32_t m = mv[k];
+				int32_t e = ein[k];
+				uint32_t d; int32_t h;
+				if(m >= e){ d = 0; h = m; } else { d = 1; h = e; }
+				if(h < f){ d = 2; h = f; }
+				if(h >= best){ best = h; bestj = j; }
+				h_last = h;
+				int32_t t = m + I + E; e = e + E; if(e > t) d |= 4u; else e = t;
+				t = m + D + E; f = f + E; if(f > t) d |= 8u; else f = t;
+				hp[k] = h; ep[k] = e; nib = d;
+			} else { hp[k] = -10000; ep[k] = -10000; }
+			if(i & 1) ztr[(size_t)(i >> 1) * zrow + lane * C + k] = (uint8_t)(nibp[k] | (nib << 4));
+			else nibp[k] = nib;
+		}
+		i_done = i;
+		ncell += (unsigned long long)(je - jb);
+		{ uint32_t lo = (uint32_t)(bestj + 1); wtz_wave_max_key(best, lo); bestj = (int32_t)lo - 1; }      /* largest column with the maximum */
+		int32_t imax = 0, mj2 = -1;
+		if(best >= 0){ imax = best; mj2 = bestj; }           /* kswx.h:288-289 */
+		const int32_t lastlane = (je - 1 - jb) / C;
+		const int32_t h1 = __builtin_amdgcn_readlane(h_last, __builtin_amdgcn_readfirstlane(lastlane));
+		if(je == tlen && gmax < h1){ gmax = h1; gi = i; gj = je - 1; }
+		if(i + 1 == qlen && gmax < imax){ gmax = imax; gi = i; gj = mj2; }
+		jbp = jb;
+		if(imax > mx){ mx = imax; mi = i; mj = mj2; }
+		else if(imax <= 0) break;
+	}
+	if(i_done >= 0 && !(i_done & 1)){          /* the last row was the first of its byte pair */
+		#pragma unroll
+		for(int k = 0; k < C; k++) ztr[(size_t)(i_done >> 1) * zrow + lane * C + k] = (uint8_t)nibp[k];
+	}
+	if(cells && lane == 0) *cells += ncell;
+	if(gmax > 0 && gmax >= mx + T){ x.score = gmax; x.qe = gi; x.te = gj; }
+	else { x.score = mx; x.qe = mi; x.te = mj; }
+	__threadfence_block();
+	if(lane == 0){
+		int32_t i_ = x.qe, j_ = x.te; uint32_t d_ = 0;
+		uint32_t run_op = 0xFFu, run_len = 0;
+		while(i_ >= 0 && j_ >= 0){
+			const int32_t col = j_ - (i_ > W ? i_ - W : 0);
+			const uint32_t zv = ztr[(size_t)(i_ >> 1) * zrow + col];
+			const uint32_t nib = (zv >> ((i_ & 1) * 4)) & 0xFu;
+			if(d_ == 0) d_ = nib & 3u; else if(d_ == 1) d_ = (nib & 4u) ? 1u : 0u; else d_ = (nib & 8u) ? 2u : 0u;
+			if(d_ == 0){
+				const uint32_t qv = (i_ & 16) ? (uint32_t)__builtin_amdgcn_readlane((int)qw_hi, i_ >> 5) : (uint32_t)__builtin_amdgcn_readlane((int)qw_lo, i_ >> 5);
+				const uint32_t qb = (qv >> ((i_ & 15) * 2)) & 3u;
+				const uint32_t tq = (uint32_t)(tb[j_ >> 5] >> ((j_ & 31) * 2)) & 3u;
+				if(qb == tq) x.mat++; else x.mis++;
+				i_--; j_--;
+			}
+			else if(d_ == 1){ i_--; x.ins++; }
+			else { j_--; x.del++; }
+			if(d_ == run_op) run_len++;
+			else { if(run_len) wtz_cigar_push(cigars, run_op, run_len); run_op = d_; run_len = 1; }
+		}
+		if(run_len) wtz_cigar_push(cigars, run_op, run_len);
+		if(i_ >= 0){ x.ins += i_ + 1; wtz_cigar_push(cigars, 1, (uint32_t)(i_ + 1)); }
+		if(j_ >= 0){ x.del += j_ + 1; wtz_cigar_push(cigars, 2, (uint32_t)(j_ + 1)); }
+		wtz_cigar_reverse(cigars.a, cigars.n);
+		x.aln = x.mat + x.mis + x.ins + x.del; x.qe++; x.te++;
+	}
+	return wtz_bcast_aln(x);
+}
+
 /* ---- A9 with the K-sw1 gaps run by the whole wave (hzm_aln.h:1247-1302).  Every lane follows the anchor loop with
  *      the same x; CIGAR bookkeeping and the run-by-run z-mer alignment stay on lane 0.  lds: >= 8 KB. ---- */
 WTZ_D wtz_aln_t wtz_align_window_wave(const wtz_readview &pb1, const wtz_readview &pb2, const wtz_win_t &win, const wtz_zhit_t *anchors,
 		wtz_cigar_t &cigar, wtz_cigar_t &tmp, const wtz_params_t *P, wtz_pool_t *pool, int32_t *lds, unsigned long long *cells, bool *ok){
 	const int lane = (int)(threadIdx.x & 63);
 	const int32_t M = P->M, X = P->X, I = P->O, D = P->O, E = P->E, T = P->T;
-	wtz_wave_lds_t L; L.Hs = lds; L.Es = lds + 512; L.tb = (uint64_t*)(lds + 1024); L.PM = 511; L.tw = 128;      /* 2 KB + 2 KB + 1 KB */
+	/* LDS slice: 128 target words (1 KB), then either the H/E rings of the general wave DP (2 x 2 KB) or the 4-bit trace
+	 * of the register DP (7 KB) */
+	wtz_wave_lds_t L; L.tb = (uint64_t*)lds; L.Hs = lds + 256; L.Es = lds + 768; L.PM = 511; L.tw = 128;
+	uint8_t *ztr = (uint8_t*)(lds + 256); const int32_t ztr_bytes = WTZ_WINALIGN_LDS_BYTES - 1024;
 	wtz_trace_t tr; tr.chunk = NULL; tr.zb = NULL; tr.n_chunk = 0; tr.zrow = 0; tr.cap_rows = 0;
 	wtz_swmem_t mem; wtz_swmem_init(mem, pool);
 	wtz_aln_t x, y; memset(&x, 0, sizeof x);
@@ -515,7 +671,11 @@ WTZ_D wtz_aln_t wtz_align_window_wave(const wtz_readview &pb1, const wtz_readvie
 			int32_t init = x.score < 0 ? 0 : x.score, W = P->w, ql, tl, n_col; bool okk = true;
 			bool fits = false;
 			if(qlen > 0 && tlen > 0){ wtz_ext_geometry(qlen, tlen, init, W, M, I, D, E, T, ql, tl, n_col); fits = wtz_wave_fits(L, n_col, tl, ql); }
-			if(qlen <= 0 || tlen <= 0 || fits){
+			if(fits && n_col <= 64 && ((ql + 1) / 2) * 64 <= ztr_bytes && ql <= 2048){
+				y = wtz_extend_fixed_reg<1>(qlen, pb2.sub(x.qe, 1), tlen, pb1.sub(x.te, 1), x.score, ql, tl, W, M, X, I, D, E, T, L.tb, ztr, tmp, cells);
+			} else if(fits && n_col <= 128 && ((ql + 1) / 2) * 128 <= ztr_bytes && ql <= 2048){
+				y = wtz_extend_fixed_reg<2>(qlen, pb2.sub(x.qe, 1), tlen, pb1.sub(x.te, 1), x.score, ql, tl, W, M, X, I, D, E, T, L.tb, ztr, tmp, cells);
+			} else if(qlen <= 0 || tlen <= 0 || fits){
 				y = wtz_extend_wave<1>(qlen, pb2.sub(x.qe, 1), tlen, pb1.sub(x.te, 1), x.score, P->w, M, X, I, D, E, T, L, tr, pool, tmp, cells, &okk);
 			} else {
 				if(lane == 0){ tmp.n = 0; y = wtz_extend_fixed(qlen, pb2.sub(x.qe, 1), tlen, pb1.sub(x.te, 1), x.score, P->w, M, X, I, D, E, T, mem, tmp); if(mem.bad) okk = false; }
