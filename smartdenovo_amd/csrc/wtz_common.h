@@ -143,6 +143,16 @@ static inline uint32_t wtz_coop_lane32(uint32_t v, uint32_t){ return v; }
 #define WTZ_WAVE_SYNC() do {} while(0)
 #endif
 
+/* phase profiler (WTZ_PROFILE_PAIR=1 prints it): shader-clock ticks accumulated per phase by lane 0 of each task */
+#if defined(__HIPCC__)
+__device__ unsigned long long wtz_prof[16];
+#define WTZ_PROF_T() ((unsigned long long)clock64())
+#define WTZ_PROF_ADD(slot, t0) do { if(WTZ_LANE == 0) atomicAdd(&wtz_prof[slot], (unsigned long long)clock64() - (t0)); } while(0)
+#else
+#define WTZ_PROF_T() 0ull
+#define WTZ_PROF_ADD(slot, t0) do { (void)(t0); } while(0)
+#endif
+
 /* growable vector living in the pool (old storage is simply abandoned on growth) */
 template<typename T> struct wtz_vec {
 	T *a; uint32_t n, cap; wtz_pool_t *pool; int bad;

@@ -34,10 +34,41 @@ static int wtz_fail(int code, const char *fmt, ...){
 #include <hip/hip_runtime.h>
 #include <rocprim/rocprim.hpp>
 #define WTZ_LAMBDA __device__
+#ifndef WTZ_OCC_WINALIGN
+#define WTZ_OCC_WINALIGN 4
+#endif
+#ifndef WTZ_OCC_PAIR
+#define WTZ_OCC_PAIR 4
+#endif
+#ifndef WTZ_OCC_GAP
+#define WTZ_OCC_GAP 5
+#endif
 /* every context owns a non-blocking HIP stream; the API entry points make it current for the calling host thread, so that
  * two host threads can drive two contexts (two batches in flight) whose kernels and copies overlap on the device */
 static thread_local hipStream_t g_stream = 0;
 #define HIPCHK(call) do { hipError_t e_ = (call); if(e_ != hipSuccess) return wtz_fail(WTZ_E_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); } while(0)
+
+struct K_candidates;
+struct K_extjob_scalar;
+struct K_cigar_text;
+struct K_misc;
+struct K_gap;
+struct K_kcount;
+struct K_kfill;
+struct K_kinsert;
+struct K_kstats;
+struct K_pack_cigars;
+struct K_pack_windows;
+struct K_pair;
+struct K_stitch_fin;
+struct K_stitch_left;
+struct K_stitch_mid;
+struct K_winalign;
+struct K_zfill;
+struct K_zrun;
+struct K_zdistinct;
+struct K_zdn;
+struct K_zcount;
 
 /* TAG only names the kernel (rocprofv3 shows wtz_kernel_tasks<K_pair_seed, ...>) */
 template<typename TAG, typename F> __global__ void __launch_bounds__(64) wtz_kernel_tasks(uint64_t n, F f){
@@ -62,8 +93,14 @@ template<typename TAG, typename F> __global__ void __launch_bounds__(64) wtz_ker
 	const uint64_t i = blockIdx.x;
 	if(i < n && threadIdx.x == 0) f(i);
 }
-/* wave-cooperative tasks: every lane of the wavefront enters the task body (WTZ_LANE / wtz_coop_* inside) */
-template<typename TAG, typename F> __global__ void __launch_bounds__(64) wtz_kernel_coop_tasks(uint64_t n, F f){
+/* wave-cooperative tasks: every lane of the wavefront enters the task body (WTZ_LANE / wtz_coop_* inside).
+ * These kernels are latency-bound chains: resident waves per SIMD are their throughput, so a TAG can ask the register
+ * allocator for a minimum occupancy (wtz_occ<TAG>::waves) instead of the 512-VGPR budget a 64-thread block would get. */
+template<typename TAG> struct wtz_occ { static constexpr int waves = 1; };
+template<> struct wtz_occ<K_winalign> { static constexpr int waves = WTZ_OCC_WINALIGN; };
+template<> struct wtz_occ<K_pair> { static constexpr int waves = WTZ_OCC_PAIR; };
+template<> struct wtz_occ<K_gap> { static constexpr int waves = WTZ_OCC_GAP; };
+template<typename TAG, typename F> __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(wtz_occ<TAG>::waves, 8))) wtz_kernel_coop_tasks(uint64_t n, F f){
 	const uint64_t i = blockIdx.x;
 	if(i < n) f(i);
 }
@@ -169,27 +206,7 @@ static int dev_sort_pairs_u64_u32(uint64_t *keys, uint32_t *vals, uint64_t n, un
 }
 #endif
 
-struct K_candidates;
-struct K_extjob_scalar;
-struct K_cigar_text;
-struct K_misc;
-struct K_gap;
-struct K_kcount;
-struct K_kfill;
-struct K_kinsert;
-struct K_kstats;
-struct K_pack_cigars;
-struct K_pack_windows;
-struct K_pair;
-struct K_stitch_fin;
-struct K_stitch_left;
-struct K_stitch_mid;
-struct K_winalign;
-struct K_zfill;
-struct K_zrun;
-struct K_zdistinct;
-struct K_zdn;
-struct K_zcount;
+
 
 
 
@@ -646,7 +663,7 @@ extern "C" int wtz_pairs_align(wtz_ctx_t *c, const uint32_t *pair_idx, const uin
 	CHK(dev_alloc((void**)&d_wt, (wt.size() + 1) * sizeof(wtz_wintask_t))); CHK(dev_h2d(d_wt, wt.data(), wt.size() * sizeof(wtz_wintask_t)));
 	const wtz_env_t V = ctx_env(c); wtz_alnres_dev_t *d_res = c->d_alnres;
 	wtz_timer tm; tm.start();
-	CHK(wtz_launch_coop<K_winalign>(0, wt.size(), [=] WTZ_LAMBDA (uint64_t t){ wtz_task_winalign((uint32_t)t, V, d_wt, d_items); }));
+	CHK(wtz_launch_coop<K_winalign>(0, wt.size(), [=] WTZ_LAMBDA (uint64_t t){ wtz_task_winalign((uint32_t)t, V, d_wt, d_items); }, WTZ_WINALIGN_LDS_BYTES));
 	CHK(dev_sync());
 	c->cnt.ms_winalign += tm.stop(); c->cnt.n_winalign += wt.size();
 	tm.start();
@@ -723,5 +740,20 @@ extern "C" int wtz_fetch_cigar_text(wtz_ctx_t *c, char *dst, uint64_t n_bytes){
 	return WTZ_OK;
 }
 
-extern "C" int wtz_get_counters(wtz_ctx_t *c, wtz_counters_t *out){ if(!c || !out) return wtz_fail(WTZ_E_ARG, "null argument"); *out = c->cnt; return WTZ_OK; }
+extern "C" int wtz_get_counters(wtz_ctx_t *c, wtz_counters_t *out){
+	if(!c || !out) return wtz_fail(WTZ_E_ARG, "null argument");
+	*out = c->cnt;
+#if !defined(WTZ_EMUL)
+	if(getenv("WTZ_PROFILE_PAIR")){        /* device phase profiler: Mticks per slot since the last report */
+		unsigned long long h[16], z[16]; memset(z, 0, sizeof z);
+		if(hipMemcpyFromSymbol(h, HIP_SYMBOL(wtz_prof), sizeof h) == hipSuccess){
+			fprintf(stderr, "[phase-profile] Mticks:");
+			for(int k = 0; k < 16; k++) fprintf(stderr, " %d:%.1f", k, (double)h[k] / 1e6);
+			fprintf(stderr, "\n");
+			(void)hipMemcpyToSymbol(HIP_SYMBOL(wtz_prof), z, sizeof z);
+		}
+	}
+#endif
+	return WTZ_OK;
+}
 extern "C" int wtz_reset_counters(wtz_ctx_t *c){ if(!c) return wtz_fail(WTZ_E_ARG, "null context"); memset(&c->cnt, 0, sizeof c->cnt); return WTZ_OK; }

@@ -509,11 +509,12 @@ WTZ_D int32_t wtz_dpp_wave_shr1(int32_t old, int32_t src){ return __builtin_amdg
 template<int C>
 WTZ_D wtz_aln_t wtz_extend_fixed_reg(int32_t qlen, const wtz_seq_packed &query, int32_t tlen, const wtz_seq_packed &target, int32_t init_score,
 		int32_t ql, int32_t tl, int32_t W, int32_t M, int32_t X, int32_t I, int32_t D, int32_t E, int32_t T,
-		uint64_t *tb, uint8_t *ztr, wtz_cigar_t &cigars, unsigned long long *cells){
+		uint64_t *tb, uint8_t *ztr, uint32_t *runs, uint32_t *n_runs, unsigned long long *cells){
 	const int lane = (int)(threadIdx.x & 63);
 	wtz_aln_t x; memset(&x, 0, sizeof x);
-	if(lane == 0) cigars.n = 0;
+	*n_runs = 0;
 	if(init_score < 0) init_score = 0;
+	const unsigned long long pt_stage = WTZ_PROF_T();
 	/* ---- stage both sequences ---- */
 	{
 		const int32_t nw = (tl + 31) / 32 + 1;
@@ -522,6 +523,8 @@ WTZ_D wtz_aln_t wtz_extend_fixed_reg(int32_t qlen, const wtz_seq_packed &query, 
 	const uint64_t qw = wtz_pack32(query, lane * 32, ql);
 	const uint32_t qw_lo = (uint32_t)qw, qw_hi = (uint32_t)(qw >> 32);
 	__threadfence_block();
+	WTZ_PROF_ADD(5, pt_stage);
+	const unsigned long long pt_rows = WTZ_PROF_T();
 	int32_t hp[C], ep[C]; uint32_t nibp[C];
 	#pragma unroll
 	for(int k = 0; k < C; k++){ hp[k] = -10000; ep[k] = -10000; nibp[k] = 0; }
@@ -617,9 +620,12 @@ WTZ_D wtz_aln_t wtz_extend_fixed_reg(int32_t qlen, const wtz_seq_packed &query, 
 	if(gmax > 0 && gmax >= mx + T){ x.score = gmax; x.qe = gi; x.te = gj; }
 	else { x.score = mx; x.qe = mi; x.te = mj; }
 	__threadfence_block();
+	WTZ_PROF_ADD(2, pt_rows);
+	if(lane == 0) atomicAdd(&wtz_prof[4], (unsigned long long)(i_done + 1));
+	const unsigned long long pt_tb = WTZ_PROF_T();
 	if(lane == 0){
 		int32_t i_ = x.qe, j_ = x.te; uint32_t d_ = 0;
-		uint32_t run_op = 0xFFu, run_len = 0;
+		uint32_t run_op = 0xFFu, run_len = 0, nr = 0;
 		while(i_ >= 0 && j_ >= 0){
 			const int32_t col = j_ - (i_ > W ? i_ - W : 0);
 			const uint32_t zv = ztr[(size_t)(i_ >> 1) * zrow + col];
@@ -635,15 +641,56 @@ WTZ_D wtz_aln_t wtz_extend_fixed_reg(int32_t qlen, const wtz_seq_packed &query, 
 			else if(d_ == 1){ i_--; x.ins++; }
 			else { j_--; x.del++; }
 			if(d_ == run_op) run_len++;
-			else { if(run_len) wtz_cigar_push(cigars, run_op, run_len); run_op = d_; run_len = 1; }
+			else { if(run_len) runs[nr++] = (run_len << 4) | run_op; run_op = d_; run_len = 1; }
 		}
-		if(run_len) wtz_cigar_push(cigars, run_op, run_len);
-		if(i_ >= 0){ x.ins += i_ + 1; wtz_cigar_push(cigars, 1, (uint32_t)(i_ + 1)); }
-		if(j_ >= 0){ x.del += j_ + 1; wtz_cigar_push(cigars, 2, (uint32_t)(j_ + 1)); }
-		wtz_cigar_reverse(cigars.a, cigars.n);
+		/* the two leading gaps (kswx.h:321-322) merge with the open run when the operation agrees (kswx_push_cigar) */
+		if(i_ >= 0){ x.ins += i_ + 1; if(run_len && run_op == 1u) run_len += (uint32_t)(i_ + 1); else { if(run_len) runs[nr++] = (run_len << 4) | run_op; run_op = 1u; run_len = (uint32_t)(i_ + 1); } }
+		if(j_ >= 0){ x.del += j_ + 1; if(run_len && run_op == 2u) run_len += (uint32_t)(j_ + 1); else { if(run_len) runs[nr++] = (run_len << 4) | run_op; run_op = 2u; run_len = (uint32_t)(j_ + 1); } }
+		if(run_len) runs[nr++] = (run_len << 4) | run_op;
+		*n_runs = nr;                              /* in traceback order: the caller replays them backwards */
 		x.aln = x.mat + x.mis + x.ins + x.del; x.qe++; x.te++;
 	}
+	WTZ_PROF_ADD(3, pt_tb);
 	return wtz_bcast_aln(x);
+}
+
+/* lane-0 CIGAR writer: the open run stays in a register, so appending never reads memory back (kswx_push_cigar merges) */
+typedef struct { wtz_cigar_t *v; uint32_t tail; } wtz_cigw_t;
+WTZ_D void wtz_cigw_push(wtz_cigw_t &w, uint32_t op, uint32_t len){
+	if(len == 0) return;
+	if(w.tail && (w.tail & 0xFu) == op) w.tail += len << 4;
+	else { if(w.tail) w.v->push(w.tail); w.tail = (len << 4) | op; }
+}
+WTZ_D void wtz_cigw_finish(wtz_cigw_t &w){ if(w.tail){ w.v->push(w.tail); w.tail = 0; } }
+
+/* up to 64 bases of a view in two registers */
+struct wtz_seq_reg2 { uint64_t w0, w1; WTZ_D uint32_t at(int32_t i) const { return (uint32_t)(((i < 32) ? (w0 >> (2 * i)) : (w1 >> (2 * (i - 32)))) & 3u); } };
+/* hz_align_hzmo (hzm_aln.h:278-314) over register-resident sequences; W == NULL only scores (the caller emits on a second
+ * call once the z-mer is known to align: a mismatching z-mer must leave the CIGAR untouched) */
+template<typename S1, typename S2>
+WTZ_D wtz_aln_t wtz_align_zmer_w(const S1 &pb1, uint32_t len1, const S2 &pb2, uint32_t len2, int32_t M, int32_t I, int32_t D, int32_t E, wtz_cigw_t *W){
+	wtz_aln_t x, zero; memset(&zero, 0, sizeof zero); x = zero;
+	uint32_t s0 = 0, s1 = 0, e0, e1, l0, l1;
+	while(s0 < len1 || s1 < len2){
+		const uint32_t b0 = pb1.at((int32_t)s0);
+		if(b0 != pb2.at((int32_t)s1)) return zero;
+		e0 = s0 + 1; while(e0 < len1 && pb1.at((int32_t)e0) == b0) e0++;
+		e1 = s1 + 1; while(e1 < len2 && pb2.at((int32_t)e1) == b0) e1++;
+		l0 = e0 - s0; l1 = e1 - s1;
+		if(l0 < l1){
+			x.aln += l1; x.mat += l0; x.ins += l1 - l0; x.score += (int32_t)l0 * M + I + (int32_t)(l1 - l0) * E;
+			if(W){ wtz_cigw_push(*W, 0, l0); wtz_cigw_push(*W, 1, l1 - l0); }
+		} else if(l0 == l1){
+			x.aln += l0; x.mat += l0; x.score += (int32_t)l0 * M;
+			if(W) wtz_cigw_push(*W, 0, l0);
+		} else {
+			x.aln += l0; x.mat += l1; x.del += l0 - l1; x.score += (int32_t)l1 * M + D + (int32_t)(l0 - l1) * E;
+			if(W){ wtz_cigw_push(*W, 0, l1); wtz_cigw_push(*W, 2, l0 - l1); }
+		}
+		s0 = e0; s1 = e1;
+	}
+	x.te = x.mat + x.del; x.qe = x.mat + x.ins;
+	return x;
 }
 
 /* ---- A9 with the K-sw1 gaps run by the whole wave (hzm_aln.h:1247-1302).  Every lane follows the anchor loop with
@@ -653,12 +700,13 @@ WTZ_D wtz_aln_t wtz_align_window_wave(const wtz_readview &pb1, const wtz_readvie
 	const int lane = (int)(threadIdx.x & 63);
 	const int32_t M = P->M, X = P->X, I = P->O, D = P->O, E = P->E, T = P->T;
 	/* LDS slice: 128 target words (1 KB), then either the H/E rings of the general wave DP (2 x 2 KB) or the 4-bit trace
-	 * of the register DP (7 KB) */
+	 * of the register DP with its run list at the top end (7 KB) */
 	wtz_wave_lds_t L; L.tb = (uint64_t*)lds; L.Hs = lds + 256; L.Es = lds + 768; L.PM = 511; L.tw = 128;
 	uint8_t *ztr = (uint8_t*)(lds + 256); const int32_t ztr_bytes = WTZ_WINALIGN_LDS_BYTES - 1024;
 	wtz_trace_t tr; tr.chunk = NULL; tr.zb = NULL; tr.n_chunk = 0; tr.zrow = 0; tr.cap_rows = 0;
 	wtz_swmem_t mem; wtz_swmem_init(mem, pool);
 	wtz_aln_t x, y; memset(&x, 0, sizeof x);
+	wtz_cigw_t Wc; Wc.v = &cigar; Wc.tail = 0;
 	*ok = true;
 	for(uint32_t i = win.anchors[0]; i < win.anchors[1]; i++){
 		const wtz_zhit_t p = anchors[i];
@@ -667,45 +715,70 @@ WTZ_D wtz_aln_t wtz_align_window_wave(const wtz_readview &pb1, const wtz_readvie
 		if(off1 < x.te) continue;
 		if(off2 < x.qe) continue;
 		const int32_t qlen = off2 - x.qe, tlen = off1 - x.te;
+		const unsigned long long pt0 = WTZ_PROF_T();
+		uint32_t n_runs = 0; uint32_t *runs = NULL; bool lds_runs = false;
 		{
-			int32_t init = x.score < 0 ? 0 : x.score, W = P->w, ql, tl, n_col; bool okk = true;
+			int32_t init = x.score < 0 ? 0 : x.score, W = P->w, ql = 0, tl = 0, n_col = 0; bool okk = true;
 			bool fits = false;
 			if(qlen > 0 && tlen > 0){ wtz_ext_geometry(qlen, tlen, init, W, M, I, D, E, T, ql, tl, n_col); fits = wtz_wave_fits(L, n_col, tl, ql); }
-			if(fits && n_col <= 64 && ((ql + 1) / 2) * 64 <= ztr_bytes && ql <= 2048){
-				y = wtz_extend_fixed_reg<1>(qlen, pb2.sub(x.qe, 1), tlen, pb1.sub(x.te, 1), x.score, ql, tl, W, M, X, I, D, E, T, L.tb, ztr, tmp, cells);
-			} else if(fits && n_col <= 128 && ((ql + 1) / 2) * 128 <= ztr_bytes && ql <= 2048){
-				y = wtz_extend_fixed_reg<2>(qlen, pb2.sub(x.qe, 1), tlen, pb1.sub(x.te, 1), x.score, ql, tl, W, M, X, I, D, E, T, L.tb, ztr, tmp, cells);
+			const int32_t run_bytes = 4 * (ql + tl + 4);
+			if(fits && n_col <= 64 && ((ql + 1) / 2) * 64 + run_bytes <= ztr_bytes){
+				runs = (uint32_t*)(ztr + ztr_bytes - run_bytes); lds_runs = true;
+				y = wtz_extend_fixed_reg<1>(qlen, pb2.sub(x.qe, 1), tlen, pb1.sub(x.te, 1), x.score, ql, tl, W, M, X, I, D, E, T, L.tb, ztr, runs, &n_runs, cells);
+			} else if(fits && n_col <= 128 && ((ql + 1) / 2) * 128 + run_bytes <= ztr_bytes){
+				runs = (uint32_t*)(ztr + ztr_bytes - run_bytes); lds_runs = true;
+				y = wtz_extend_fixed_reg<2>(qlen, pb2.sub(x.qe, 1), tlen, pb1.sub(x.te, 1), x.score, ql, tl, W, M, X, I, D, E, T, L.tb, ztr, runs, &n_runs, cells);
 			} else if(qlen <= 0 || tlen <= 0 || fits){
+				const unsigned long long ptw = WTZ_PROF_T();
 				y = wtz_extend_wave<1>(qlen, pb2.sub(x.qe, 1), tlen, pb1.sub(x.te, 1), x.score, P->w, M, X, I, D, E, T, L, tr, pool, tmp, cells, &okk);
+				if(qlen <= 0 || tlen <= 0){ WTZ_PROF_ADD(11, ptw); if(lane == 0) atomicAdd(&wtz_prof[12], 1ull); }
+				else { WTZ_PROF_ADD(9, ptw); if(lane == 0){ atomicAdd(&wtz_prof[7], 1ull); atomicAdd(&wtz_prof[13], (unsigned long long)ql); atomicAdd(&wtz_prof[14], (unsigned long long)n_col); } }
 			} else {
+				const unsigned long long ptw = WTZ_PROF_T();
 				if(lane == 0){ tmp.n = 0; y = wtz_extend_fixed(qlen, pb2.sub(x.qe, 1), tlen, pb1.sub(x.te, 1), x.score, P->w, M, X, I, D, E, T, mem, tmp); if(mem.bad) okk = false; }
 				y = wtz_bcast_aln(y);
 				okk = __shfl((int)okk, 0, 64) != 0;
+				WTZ_PROF_ADD(10, ptw); if(lane == 0) atomicAdd(&wtz_prof[8], 1ull);
 			}
+			if(lds_runs && lane == 0) atomicAdd(&wtz_prof[6], 1ull);
 			if(!okk){ *ok = false; return x; }
 		}
+		WTZ_PROF_ADD(0, pt0);
+		const unsigned long long pt1 = WTZ_PROF_T();
 		int32_t stop = 0;
 		if(lane == 0){
 			x.score = y.score;
 			x.aln += y.aln; x.mat += y.mat; x.mis += y.mis; x.ins += y.ins; x.del += y.del;
 			x.te += y.te; x.qe += y.qe;
-			if(x.te < off1){ x.del += off1 - x.te; x.aln += off1 - x.te; wtz_cigar_push(tmp, 2, (uint32_t)(off1 - x.te)); x.te = off1; }
-			if(x.qe < off2){ x.ins += off2 - x.qe; x.aln += off2 - x.qe; wtz_cigar_push(tmp, 1, (uint32_t)(off2 - x.qe)); x.qe = off2; }
-			wtz_cigar_concat(cigar, tmp.a, tmp.n);
-			tmp.n = 0;
-			y = wtz_align_zmer(pb1.sub(off1, 1), ZH_LEN1(p), pb2.sub(off2, 1), ZH_LEN2(p), M, I, D, E, tmp);
+			if(lds_runs){ for(uint32_t k = n_runs; k-- > 0;){ const uint32_t r = runs[k]; wtz_cigw_push(Wc, r & 0xFu, r >> 4); } }
+			else { for(uint32_t k = 0; k < tmp.n; k++){ const uint32_t r = tmp.a[k]; wtz_cigw_push(Wc, r & 0xFu, r >> 4); } }
+			if(x.te < off1){ x.del += off1 - x.te; x.aln += off1 - x.te; wtz_cigw_push(Wc, 2, (uint32_t)(off1 - x.te)); x.te = off1; }
+			if(x.qe < off2){ x.ins += off2 - x.qe; x.aln += off2 - x.qe; wtz_cigw_push(Wc, 1, (uint32_t)(off2 - x.qe)); x.qe = off2; }
+			const uint32_t len1 = ZH_LEN1(p), len2 = ZH_LEN2(p);
+			const wtz_seq_packed z1 = pb1.sub(off1, 1), z2 = pb2.sub(off2, 1);
+			if(len1 <= 64 && len2 <= 64){
+				wtz_seq_reg2 r1, r2;
+				r1.w0 = wtz_pack32(z1, 0, (int32_t)len1); r1.w1 = wtz_pack32(z1, 32, (int32_t)len1);
+				r2.w0 = wtz_pack32(z2, 0, (int32_t)len2); r2.w1 = wtz_pack32(z2, 32, (int32_t)len2);
+				y = wtz_align_zmer_w(r1, len1, r2, len2, M, I, D, E, (wtz_cigw_t*)NULL);
+				if(y.aln) (void)wtz_align_zmer_w(r1, len1, r2, len2, M, I, D, E, &Wc);
+			} else {
+				y = wtz_align_zmer_w(z1, len1, z2, len2, M, I, D, E, (wtz_cigw_t*)NULL);
+				if(y.aln) (void)wtz_align_zmer_w(z1, len1, z2, len2, M, I, D, E, &Wc);
+			}
 			if(y.aln == 0) stop = 1;
 			else {
 				x.score += y.score;
 				x.aln += y.aln; x.mat += y.mat; x.mis += y.mis; x.ins += y.ins; x.del += y.del;
 				x.te += y.te; x.qe += y.qe;
-				wtz_cigar_concat(cigar, tmp.a, tmp.n);
 			}
 		}
 		x = wtz_bcast_aln(x);
 		stop = __shfl(stop, 0, 64);
-		if(stop) return x;
+		WTZ_PROF_ADD(1, pt1);
+		if(stop) break;
 	}
+	if(lane == 0) wtz_cigw_finish(Wc);
 	return x;
 }
 
