@@ -143,14 +143,17 @@ static inline uint32_t wtz_coop_lane32(uint32_t v, uint32_t){ return v; }
 #define WTZ_WAVE_SYNC() do {} while(0)
 #endif
 
-/* phase profiler (WTZ_PROFILE_PAIR=1 prints it): shader-clock ticks accumulated per phase by lane 0 of each task */
-#if defined(__HIPCC__)
+/* phase profiler, compiled in only with -DWTZ_PROFILE (its same-address atomics perturb the kernels it measures):
+ * shader-clock ticks / event counts accumulated per slot by lane 0 of each task; WTZ_PROFILE_PAIR=1 prints them */
+#if defined(__HIPCC__) && defined(WTZ_PROFILE)
 __device__ unsigned long long wtz_prof[16];
 #define WTZ_PROF_T() ((unsigned long long)clock64())
 #define WTZ_PROF_ADD(slot, t0) do { if(WTZ_LANE == 0) atomicAdd(&wtz_prof[slot], (unsigned long long)clock64() - (t0)); } while(0)
+#define WTZ_PROF_CNT(slot, v) do { if(WTZ_LANE == 0) atomicAdd(&wtz_prof[slot], (unsigned long long)(v)); } while(0)
 #else
 #define WTZ_PROF_T() 0ull
 #define WTZ_PROF_ADD(slot, t0) do { (void)(t0); } while(0)
+#define WTZ_PROF_CNT(slot, v) do { } while(0)
 #endif
 
 /* growable vector living in the pool (old storage is simply abandoned on growth) */

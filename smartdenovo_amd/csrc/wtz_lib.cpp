@@ -30,24 +30,7 @@ static int wtz_fail(int code, const char *fmt, ...){
 	return code;
 }
 
-#ifndef WTZ_EMUL
-#include <hip/hip_runtime.h>
-#include <rocprim/rocprim.hpp>
-#define WTZ_LAMBDA __device__
-#ifndef WTZ_OCC_WINALIGN
-#define WTZ_OCC_WINALIGN 4
-#endif
-#ifndef WTZ_OCC_PAIR
-#define WTZ_OCC_PAIR 4
-#endif
-#ifndef WTZ_OCC_GAP
-#define WTZ_OCC_GAP 5
-#endif
-/* every context owns a non-blocking HIP stream; the API entry points make it current for the calling host thread, so that
- * two host threads can drive two contexts (two batches in flight) whose kernels and copies overlap on the device */
-static thread_local hipStream_t g_stream = 0;
-#define HIPCHK(call) do { hipError_t e_ = (call); if(e_ != hipSuccess) return wtz_fail(WTZ_E_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); } while(0)
-
+/* kernel name tags (rocprofv3 shows wtz_kernel_*<K_pair, ...>) */
 struct K_candidates;
 struct K_extjob_scalar;
 struct K_cigar_text;
@@ -69,6 +52,26 @@ struct K_zrun;
 struct K_zdistinct;
 struct K_zdn;
 struct K_zcount;
+
+#ifndef WTZ_EMUL
+#include <hip/hip_runtime.h>
+#include <rocprim/rocprim.hpp>
+#define WTZ_LAMBDA __device__
+#ifndef WTZ_OCC_WINALIGN
+#define WTZ_OCC_WINALIGN 1
+#endif
+#ifndef WTZ_OCC_PAIR
+#define WTZ_OCC_PAIR 1
+#endif
+#ifndef WTZ_OCC_GAP
+#define WTZ_OCC_GAP 1
+#endif
+/* every context owns a non-blocking HIP stream; the API entry points make it current for the calling host thread, so that
+ * two host threads can drive two contexts (two batches in flight) whose kernels and copies overlap on the device */
+static thread_local hipStream_t g_stream = 0;
+#define HIPCHK(call) do { hipError_t e_ = (call); if(e_ != hipSuccess) return wtz_fail(WTZ_E_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); } while(0)
+
+
 
 /* TAG only names the kernel (rocprofv3 shows wtz_kernel_tasks<K_pair_seed, ...>) */
 template<typename TAG, typename F> __global__ void __launch_bounds__(64) wtz_kernel_tasks(uint64_t n, F f){
@@ -743,7 +746,7 @@ extern "C" int wtz_fetch_cigar_text(wtz_ctx_t *c, char *dst, uint64_t n_bytes){
 extern "C" int wtz_get_counters(wtz_ctx_t *c, wtz_counters_t *out){
 	if(!c || !out) return wtz_fail(WTZ_E_ARG, "null argument");
 	*out = c->cnt;
-#if !defined(WTZ_EMUL)
+#if !defined(WTZ_EMUL) && defined(WTZ_PROFILE)
 	if(getenv("WTZ_PROFILE_PAIR")){        /* device phase profiler: Mticks per slot since the last report */
 		unsigned long long h[16], z[16]; memset(z, 0, sizeof z);
 		if(hipMemcpyFromSymbol(h, HIP_SYMBOL(wtz_prof), sizeof h) == hipSuccess){

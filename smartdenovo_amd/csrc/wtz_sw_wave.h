@@ -36,9 +36,10 @@ typedef struct {
 	wtz_aln_t x; uint32_t *cigar; uint32_t cigar_len; int32_t bad; unsigned long long cells;
 } wtz_extjob_t;
 
+#define WTZ_WINALIGN_LDS_BYTES 8192      /* LDS slice of a window-alignment wave (== WTZ_WAVE_LDS_BYTES) */
+
 #ifdef __HIPCC__
 
-#define WTZ_WINALIGN_LDS_BYTES 8192      /* LDS slice of a window-alignment wave (== WTZ_WAVE_LDS_BYTES) */
 #define WTZ_TRACE_MAXCHUNK 1024          /* 64-row chunks: up to 65536 rows per problem */
 
 /* reusable trace storage of one task (pointers live in the pool so that lane 0 can chase them during traceback) */
@@ -62,6 +63,19 @@ WTZ_D int32_t wtz_wave_max_scan_excl(int32_t v, int32_t ident){
 	t = wtz_dpp_mov<0x142, 0xA>(ident, x); x = x > t ? x : t;
 	t = wtz_dpp_mov<0x143, 0xC>(ident, x); x = x > t ? x : t;
 	return wtz_dpp_mov<0x138, 0xF>(ident, x);              /* inclusive -> exclusive: shift the whole wave by one lane */
+}
+
+/* all-lanes maximum of an int32, result uniform */
+WTZ_D int32_t wtz_wave_max_i32(int32_t v){
+	const int32_t ident = (int32_t)0x80000000;
+	int32_t x = v, t;
+	t = wtz_dpp_mov<0x111, 0xF>(ident, x); x = x > t ? x : t;
+	t = wtz_dpp_mov<0x112, 0xF>(ident, x); x = x > t ? x : t;
+	t = wtz_dpp_mov<0x114, 0xF>(ident, x); x = x > t ? x : t;
+	t = wtz_dpp_mov<0x118, 0xF>(ident, x); x = x > t ? x : t;
+	t = wtz_dpp_mov<0x142, 0xA>(ident, x); x = x > t ? x : t;
+	t = wtz_dpp_mov<0x143, 0xC>(ident, x); x = x > t ? x : t;
+	return __builtin_amdgcn_readlane(x, 63);
 }
 
 /* all-lanes maximum of a signed 64-bit key (hi:int32 value, lo:uint32 tie-break), result in every lane */
@@ -525,50 +539,62 @@ WTZ_D wtz_aln_t wtz_extend_fixed_reg(int32_t qlen, const wtz_seq_packed &query, 
 	__threadfence_block();
 	WTZ_PROF_ADD(5, pt_stage);
 	const unsigned long long pt_rows = WTZ_PROF_T();
+	/* The row loop is written for instruction count: every cell update is branch-free (max / compare-select), the row
+	 * maximum and its LAST arg-max come out of ONE integer max-reduction over packed keys h*128 + band column (the caller
+	 * guarantees |h| < 2^23), the lane's target bases sit in a 16-base register window that is shifted once per row and
+	 * refilled from LDS every 16-C rows, and the row's query base is scalar. */
 	int32_t hp[C], ep[C]; uint32_t nibp[C];
 	#pragma unroll
 	for(int k = 0; k < C; k++){ hp[k] = -10000; ep[k] = -10000; nibp[k] = 0; }
 	int32_t mx = init_score, mi = -1, mj = -1, gmax = 0, gi = -1, gj = -1;
 	int32_t jbp = 0, i, i_done = -1;
 	unsigned long long ncell = 0;
-	const int32_t CE = C * E;
+	const int32_t CE = C * E, IE = I + E, DE = D + E;
 	const uint32_t zrow = 64u * C;
+	const uint32_t *tb32 = (const uint32_t*)tb;
+	uint32_t tw = 0; int32_t tw_left = 0; uint32_t qcur = 0;
+	const int32_t colrel0 = lane * C;
 	for(i = 0; i < ql; i++){
 		int32_t jb = i - W; if(jb < 0) jb = 0;
 		int32_t je = i + W + 1; if(je > tl) je = tl;
-		const int32_t qs = __builtin_amdgcn_readfirstlane(i >> 5);
-		const uint32_t qsel = ((i & 16) ? (uint32_t)__builtin_amdgcn_readlane((int)qw_hi, qs) : (uint32_t)__builtin_amdgcn_readlane((int)qw_lo, qs));
-		const uint32_t qbase = (qsel >> ((i & 15) * 2)) & 3u;
-		const int32_t j0 = jb + lane * C;
-		uint32_t tbits;                                   /* the lane's <= C target bases */
-		{
+		if((i & 15) == 0){
+			const int32_t qs = __builtin_amdgcn_readfirstlane(i >> 5);
+			qcur = (i & 16) ? (uint32_t)__builtin_amdgcn_readlane((int)qw_hi, qs) : (uint32_t)__builtin_amdgcn_readlane((int)qw_lo, qs);
+		}
+		const uint32_t qbase = (qcur >> ((i & 15) * 2)) & 3u;
+		const int32_t j0 = jb + colrel0;
+		const bool moved = (i > 0) && (jb != jbp);
+		if(moved){ tw >>= 2; tw_left--; }
+		if(i == 0 || tw_left < C){
 			const int32_t jj = j0 < tl ? j0 : (tl > 0 ? tl - 1 : 0);
-			const int32_t w = jj >> 5, sh = (jj & 31) * 2;
-			const uint64_t w0 = tb[w], w1 = tb[w + 1];
-			tbits = (uint32_t)(sh ? ((w0 >> sh) | (w1 << (64 - sh))) : w0);
+			const uint32_t lo = tb32[jj >> 4], hi = tb32[(jj >> 4) + 1];
+			tw = __builtin_amdgcn_alignbit(hi, lo, (uint32_t)(jj & 15) * 2u);
+			tw_left = 16;
 		}
 		/* ---- predecessors from the previous row's registers ---- */
 		int32_t pred[C], ein[C];
 		if(i == 0){
 			#pragma unroll
 			for(int k = 0; k < C; k++){ const int32_t j = j0 + k; pred[k] = (j == 0) ? init_score : init_score + D + E * j; ein[k] = -10000; }     /* rh[] / re[] initialisation, kswx.h:143-146 */
-		} else if(jb != jbp){                 /* band moved right by one: H(i-1,j-1) is the lane's own column, E(i-1,j) the next one */
+		} else if(moved){                     /* band moved right by one: H(i-1,j-1) is the lane's own column, E(i-1,j) the next one */
 			const int32_t nxt = wtz_dpp_wave_shl1(-10000, ep[0]);
 			#pragma unroll
 			for(int k = 0; k < C; k++){ pred[k] = hp[k]; ein[k] = (k + 1 < C) ? ep[k + 1] : nxt; }
 		} else {                              /* band still starts at column 0 */
 			int32_t prv = wtz_dpp_wave_shr1(-10000, hp[C - 1]);
-			if(lane == 0) prv = init_score + I + E * i;                 /* H(i-1,-1), kswx.h:262 */
+			prv = (lane == 0) ? init_score + I + E * i : prv;           /* H(i-1,-1), kswx.h:262 */
 			#pragma unroll
 			for(int k = 0; k < C; k++){ pred[k] = k ? hp[k - 1] : prv; ein[k] = ep[k]; }
 		}
 		/* ---- m and the lane's F aggregate ---- */
-		int32_t mv[C]; int32_t agg = -0x3FFFFFFF;
+		int32_t mv[C]; bool valid[C]; int32_t agg = -0x3FFFFFFF;
 		#pragma unroll
 		for(int k = 0; k < C; k++){
-			const uint32_t tbase = (tbits >> (2 * k)) & 3u;
+			const uint32_t tbase = (tw >> (2 * k)) & 3u;
 			mv[k] = pred[k] + ((qbase == tbase) ? M : X);
-			if(j0 + k < je){ const int32_t cand = mv[k] + D + E + (C - 1 - k) * E; agg = agg > cand ? agg : cand; }
+			valid[k] = (j0 + k < je);
+			const int32_t cand = mv[k] + DE + (C - 1 - k) * E;
+			agg = (valid[k] && cand > agg) ? cand : agg;
 		}
 		int32_t f;
 		{
@@ -579,34 +605,40 @@ WTZ_D wtz_aln_t wtz_extend_fixed_reg(int32_t qlen, const wtz_seq_packed &query, 
 			f = from_prev > from_init ? from_prev : from_init;
 		}
 		/* ---- H, E', F, trace nibble ---- */
-		int32_t best = -0x7FFFFFFF, bestj = -1, h_last = 0;
+		int32_t key = (int32_t)0x80000000;
 		#pragma unroll
 		for(int k = 0; k < C; k++){
-			const int32_t j = j0 + k;
-			uint32_t nib = 0;
-			if(j < je){
-				const int32_t m = mv[k];
-				int32_t e = ein[k];
-				uint32_t d; int32_t h;
-				if(m >= e){ d = 0; h = m; } else { d = 1; h = e; }
-				if(h < f){ d = 2; h = f; }
-				if(h >= best){ best = h; bestj = j; }
-				h_last = h;
-				int32_t t = m + I + E; e = e + E; if(e > t) d |= 4u; else e = t;
-				t = m + D + E; f = f + E; if(f > t) d |= 8u; else f = t;
-				hp[k] = h; ep[k] = e; nib = d;
-			} else { hp[k] = -10000; ep[k] = -10000; }
-			if(i & 1) ztr[(size_t)(i >> 1) * zrow + lane * C + k] = (uint8_t)(nibp[k] | (nib << 4));
+			const int32_t m = mv[k], e = ein[k];
+			int32_t h = m > e ? m : e;
+			uint32_t nib = (m >= e) ? 0u : 1u;
+			nib = (h < f) ? 2u : nib;
+			h = h > f ? h : f;
+			const int32_t te = m + IE, e2 = e + E;
+			nib |= (e2 > te) ? 4u : 0u;
+			const int32_t en = e2 > te ? e2 : te;
+			const int32_t tf = m + DE, f2 = f + E;
+			nib |= (f2 > tf) ? 8u : 0u;
+			f = f2 > tf ? f2 : tf;
+			hp[k] = valid[k] ? h : -10000; ep[k] = valid[k] ? en : -10000;
+			nib = valid[k] ? nib : 0u;
+			const int32_t kk = h * 128 + (colrel0 + k);
+			key = (valid[k] && kk > key) ? kk : key;
+			if(i & 1) ztr[(size_t)(i >> 1) * zrow + colrel0 + k] = (uint8_t)(nibp[k] | (nib << 4));
 			else nibp[k] = nib;
 		}
 		i_done = i;
 		ncell += (unsigned long long)(je - jb);
-		{ uint32_t lo = (uint32_t)(bestj + 1); wtz_wave_max_key(best, lo); bestj = (int32_t)lo - 1; }      /* largest column with the maximum */
+		key = wtz_wave_max_i32(key);
 		int32_t imax = 0, mj2 = -1;
-		if(best >= 0){ imax = best; mj2 = bestj; }           /* kswx.h:288-289 */
-		const int32_t lastlane = (je - 1 - jb) / C;
-		const int32_t h1 = __builtin_amdgcn_readlane(h_last, __builtin_amdgcn_readfirstlane(lastlane));
-		if(je == tlen && gmax < h1){ gmax = h1; gi = i; gj = je - 1; }
+		if((key >> 7) >= 0){ imax = key >> 7; mj2 = jb + (key & 127); }           /* last j with h >= running max >= 0, kswx.h:288-289 */
+		if(je == tlen){
+			const int32_t idx = je - 1 - jb;
+			int32_t hsel = hp[0];
+			#pragma unroll
+			for(int k = 1; k < C; k++) hsel = (idx % C == k) ? hp[k] : hsel;
+			const int32_t h1 = __builtin_amdgcn_readlane(hsel, __builtin_amdgcn_readfirstlane(idx / C));      /* H(i, je-1) */
+			if(gmax < h1){ gmax = h1; gi = i; gj = je - 1; }
+		}
 		if(i + 1 == qlen && gmax < imax){ gmax = imax; gi = i; gj = mj2; }
 		jbp = jb;
 		if(imax > mx){ mx = imax; mi = i; mj = mj2; }
@@ -621,7 +653,7 @@ WTZ_D wtz_aln_t wtz_extend_fixed_reg(int32_t qlen, const wtz_seq_packed &query, 
 	else { x.score = mx; x.qe = mi; x.te = mj; }
 	__threadfence_block();
 	WTZ_PROF_ADD(2, pt_rows);
-	if(lane == 0) atomicAdd(&wtz_prof[4], (unsigned long long)(i_done + 1));
+	WTZ_PROF_CNT(4, i_done + 1);
 	const unsigned long long pt_tb = WTZ_PROF_T();
 	if(lane == 0){
 		int32_t i_ = x.qe, j_ = x.te; uint32_t d_ = 0;
@@ -722,25 +754,26 @@ WTZ_D wtz_aln_t wtz_align_window_wave(const wtz_readview &pb1, const wtz_readvie
 			bool fits = false;
 			if(qlen > 0 && tlen > 0){ wtz_ext_geometry(qlen, tlen, init, W, M, I, D, E, T, ql, tl, n_col); fits = wtz_wave_fits(L, n_col, tl, ql); }
 			const int32_t run_bytes = 4 * (ql + tl + 4);
-			if(fits && n_col <= 64 && ((ql + 1) / 2) * 64 + run_bytes <= ztr_bytes){
+			const bool packable = fits && (init + M * (ql < tl ? ql : tl) < (1 << 23));      /* h*128 + column keys of the register DP */
+			if(packable && n_col <= 64 && ((ql + 1) / 2) * 64 + run_bytes <= ztr_bytes){
 				runs = (uint32_t*)(ztr + ztr_bytes - run_bytes); lds_runs = true;
 				y = wtz_extend_fixed_reg<1>(qlen, pb2.sub(x.qe, 1), tlen, pb1.sub(x.te, 1), x.score, ql, tl, W, M, X, I, D, E, T, L.tb, ztr, runs, &n_runs, cells);
-			} else if(fits && n_col <= 128 && ((ql + 1) / 2) * 128 + run_bytes <= ztr_bytes){
+			} else if(packable && n_col <= 128 && ((ql + 1) / 2) * 128 + run_bytes <= ztr_bytes){
 				runs = (uint32_t*)(ztr + ztr_bytes - run_bytes); lds_runs = true;
 				y = wtz_extend_fixed_reg<2>(qlen, pb2.sub(x.qe, 1), tlen, pb1.sub(x.te, 1), x.score, ql, tl, W, M, X, I, D, E, T, L.tb, ztr, runs, &n_runs, cells);
 			} else if(qlen <= 0 || tlen <= 0 || fits){
 				const unsigned long long ptw = WTZ_PROF_T();
 				y = wtz_extend_wave<1>(qlen, pb2.sub(x.qe, 1), tlen, pb1.sub(x.te, 1), x.score, P->w, M, X, I, D, E, T, L, tr, pool, tmp, cells, &okk);
-				if(qlen <= 0 || tlen <= 0){ WTZ_PROF_ADD(11, ptw); if(lane == 0) atomicAdd(&wtz_prof[12], 1ull); }
-				else { WTZ_PROF_ADD(9, ptw); if(lane == 0){ atomicAdd(&wtz_prof[7], 1ull); atomicAdd(&wtz_prof[13], (unsigned long long)ql); atomicAdd(&wtz_prof[14], (unsigned long long)n_col); } }
+				if(qlen <= 0 || tlen <= 0){ WTZ_PROF_ADD(11, ptw); WTZ_PROF_CNT(12, 1); }
+				else { WTZ_PROF_ADD(9, ptw); WTZ_PROF_CNT(7, 1); WTZ_PROF_CNT(13, ql); WTZ_PROF_CNT(14, n_col); }
 			} else {
 				const unsigned long long ptw = WTZ_PROF_T();
 				if(lane == 0){ tmp.n = 0; y = wtz_extend_fixed(qlen, pb2.sub(x.qe, 1), tlen, pb1.sub(x.te, 1), x.score, P->w, M, X, I, D, E, T, mem, tmp); if(mem.bad) okk = false; }
 				y = wtz_bcast_aln(y);
 				okk = __shfl((int)okk, 0, 64) != 0;
-				WTZ_PROF_ADD(10, ptw); if(lane == 0) atomicAdd(&wtz_prof[8], 1ull);
+				WTZ_PROF_ADD(10, ptw); WTZ_PROF_CNT(8, 1);
 			}
-			if(lds_runs && lane == 0) atomicAdd(&wtz_prof[6], 1ull);
+			if(lds_runs) WTZ_PROF_CNT(6, 1);
 			if(!okk){ *ok = false; return x; }
 		}
 		WTZ_PROF_ADD(0, pt0);
