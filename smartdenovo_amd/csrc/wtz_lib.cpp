@@ -58,7 +58,7 @@ struct K_zcount;
 #include <rocprim/rocprim.hpp>
 #define WTZ_LAMBDA __device__
 #ifndef WTZ_OCC_WINALIGN
-#define WTZ_OCC_WINALIGN 1
+#define WTZ_OCC_WINALIGN 3
 #endif
 #ifndef WTZ_OCC_PAIR
 #define WTZ_OCC_PAIR 1

@@ -36,7 +36,9 @@ typedef struct {
 	wtz_aln_t x; uint32_t *cigar; uint32_t cigar_len; int32_t bad; unsigned long long cells;
 } wtz_extjob_t;
 
-#define WTZ_WINALIGN_LDS_BYTES 8192      /* LDS slice of a window-alignment wave (== WTZ_WAVE_LDS_BYTES) */
+#ifndef WTZ_WINALIGN_LDS_BYTES
+#define WTZ_WINALIGN_LDS_BYTES 12288     /* LDS slice of a window-alignment wave (measured best with 3 waves/SIMD) */
+#endif
 
 #ifdef __HIPCC__
 
@@ -523,7 +525,7 @@ WTZ_D int32_t wtz_dpp_wave_shr1(int32_t old, int32_t src){ return __builtin_amdg
 template<int C>
 WTZ_D wtz_aln_t wtz_extend_fixed_reg(int32_t qlen, const wtz_seq_packed &query, int32_t tlen, const wtz_seq_packed &target, int32_t init_score,
 		int32_t ql, int32_t tl, int32_t W, int32_t M, int32_t X, int32_t I, int32_t D, int32_t E, int32_t T,
-		uint64_t *tb, uint8_t *ztr, uint32_t *runs, uint32_t *n_runs, unsigned long long *cells){
+		uint64_t *tb, uint8_t *ztr, uint32_t zrow, uint32_t *runs, uint32_t *n_runs, unsigned long long *cells){
 	const int lane = (int)(threadIdx.x & 63);
 	wtz_aln_t x; memset(&x, 0, sizeof x);
 	*n_runs = 0;
@@ -550,7 +552,6 @@ WTZ_D wtz_aln_t wtz_extend_fixed_reg(int32_t qlen, const wtz_seq_packed &query, 
 	int32_t jbp = 0, i, i_done = -1;
 	unsigned long long ncell = 0;
 	const int32_t CE = C * E, IE = I + E, DE = D + E;
-	const uint32_t zrow = 64u * C;
 	const uint32_t *tb32 = (const uint32_t*)tb;
 	uint32_t tw = 0; int32_t tw_left = 0; uint32_t qcur = 0;
 	const int32_t colrel0 = lane * C;
@@ -623,7 +624,7 @@ WTZ_D wtz_aln_t wtz_extend_fixed_reg(int32_t qlen, const wtz_seq_packed &query, 
 			nib = valid[k] ? nib : 0u;
 			const int32_t kk = h * 128 + (colrel0 + k);
 			key = (valid[k] && kk > key) ? kk : key;
-			if(i & 1) ztr[(size_t)(i >> 1) * zrow + colrel0 + k] = (uint8_t)(nibp[k] | (nib << 4));
+			if(i & 1){ if((uint32_t)(colrel0 + k) < zrow) ztr[(size_t)(i >> 1) * zrow + colrel0 + k] = (uint8_t)(nibp[k] | (nib << 4)); }
 			else nibp[k] = nib;
 		}
 		i_done = i;
@@ -646,7 +647,7 @@ WTZ_D wtz_aln_t wtz_extend_fixed_reg(int32_t qlen, const wtz_seq_packed &query, 
 	}
 	if(i_done >= 0 && !(i_done & 1)){          /* the last row was the first of its byte pair */
 		#pragma unroll
-		for(int k = 0; k < C; k++) ztr[(size_t)(i_done >> 1) * zrow + lane * C + k] = (uint8_t)nibp[k];
+		for(int k = 0; k < C; k++) if((uint32_t)(lane * C + k) < zrow) ztr[(size_t)(i_done >> 1) * zrow + lane * C + k] = (uint8_t)nibp[k];
 	}
 	if(cells && lane == 0) *cells += ncell;
 	if(gmax > 0 && gmax >= mx + T){ x.score = gmax; x.qe = gi; x.te = gj; }
@@ -755,12 +756,13 @@ WTZ_D wtz_aln_t wtz_align_window_wave(const wtz_readview &pb1, const wtz_readvie
 			if(qlen > 0 && tlen > 0){ wtz_ext_geometry(qlen, tlen, init, W, M, I, D, E, T, ql, tl, n_col); fits = wtz_wave_fits(L, n_col, tl, ql); }
 			const int32_t run_bytes = 4 * (ql + tl + 4);
 			const bool packable = fits && (init + M * (ql < tl ? ql : tl) < (1 << 23));      /* h*128 + column keys of the register DP */
-			if(packable && n_col <= 64 && ((ql + 1) / 2) * 64 + run_bytes <= ztr_bytes){
+			const int32_t zrow = (n_col + 3) & ~3;                 /* trace bytes per row pair: one nibble pair per band column */
+			if(packable && n_col <= 64 && ((ql + 1) / 2) * zrow + run_bytes <= ztr_bytes){
 				runs = (uint32_t*)(ztr + ztr_bytes - run_bytes); lds_runs = true;
-				y = wtz_extend_fixed_reg<1>(qlen, pb2.sub(x.qe, 1), tlen, pb1.sub(x.te, 1), x.score, ql, tl, W, M, X, I, D, E, T, L.tb, ztr, runs, &n_runs, cells);
-			} else if(packable && n_col <= 128 && ((ql + 1) / 2) * 128 + run_bytes <= ztr_bytes){
+				y = wtz_extend_fixed_reg<1>(qlen, pb2.sub(x.qe, 1), tlen, pb1.sub(x.te, 1), x.score, ql, tl, W, M, X, I, D, E, T, L.tb, ztr, (uint32_t)zrow, runs, &n_runs, cells);
+			} else if(packable && n_col <= 128 && ((ql + 1) / 2) * zrow + run_bytes <= ztr_bytes){
 				runs = (uint32_t*)(ztr + ztr_bytes - run_bytes); lds_runs = true;
-				y = wtz_extend_fixed_reg<2>(qlen, pb2.sub(x.qe, 1), tlen, pb1.sub(x.te, 1), x.score, ql, tl, W, M, X, I, D, E, T, L.tb, ztr, runs, &n_runs, cells);
+				y = wtz_extend_fixed_reg<2>(qlen, pb2.sub(x.qe, 1), tlen, pb1.sub(x.te, 1), x.score, ql, tl, W, M, X, I, D, E, T, L.tb, ztr, (uint32_t)zrow, runs, &n_runs, cells);
 			} else if(qlen <= 0 || tlen <= 0 || fits){
 				const unsigned long long ptw = WTZ_PROF_T();
 				y = wtz_extend_wave<1>(qlen, pb2.sub(x.qe, 1), tlen, pb1.sub(x.te, 1), x.score, P->w, M, X, I, D, E, T, L, tr, pool, tmp, cells, &okk);
