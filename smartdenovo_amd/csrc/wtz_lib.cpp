@@ -616,7 +616,13 @@ static int run_extjobs(wtz_ctx *c, const wtz_env_t &V, wtz_extjob_t *d_jobs, uin
 	}
 	{
 		wtz_timer te; te.start();
-		hipLaunchKernelGGL((wtz_kernel_extjobs<2048, 1032>), dim3(m), dim3(64), 0, g_stream, d_jobs, (const uint32_t*)d_order, m, V.P, V.pool);
+		static int use_reg = -1;
+		if(use_reg < 0) use_reg = !(getenv("WTZ_SW_NOREG") && atoi(getenv("WTZ_SW_NOREG")));
+		if(use_reg){
+			hipLaunchKernelGGL((wtz_kernel_extjobs_reg<1032>), dim3(m), dim3(64), 0, g_stream, d_jobs, (const uint32_t*)d_order, m, V.P, V.pool);
+			HIPCHK(hipGetLastError());
+		}
+		hipLaunchKernelGGL((wtz_kernel_extjobs<2048, 1032>), dim3(m), dim3(64), 0, g_stream, d_jobs, (const uint32_t*)d_order, m, V.P, V.pool);     /* whatever the register DP left */
 		HIPCHK(hipGetLastError());
 		c->cnt.ms_ext += te.stop(); c->cnt.n_extjobs += m;
 		dev_free(d_order);

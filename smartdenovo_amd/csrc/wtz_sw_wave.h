@@ -32,10 +32,14 @@ typedef struct {
 	int32_t qlen, tlen, init_score, W;      /* W as passed to kswx_extend_align_shift_core (negative = exact band) */
 	uint32_t item;              /* owner (stitch item) */
 	uint32_t valid;             /* 0: nothing to do */
+	uint32_t done;              /* set by the register-DP kernel; the general kernel then skips the job */
 	/* results */
 	wtz_aln_t x; uint32_t *cigar; uint32_t cigar_len; int32_t bad; unsigned long long cells;
 } wtz_extjob_t;
 
+#ifndef WTZ_OCC_EXTREG
+#define WTZ_OCC_EXTREG 1
+#endif
 #ifndef WTZ_WINALIGN_LDS_BYTES
 #define WTZ_WINALIGN_LDS_BYTES 12288     /* LDS slice of a window-alignment wave (measured best with 3 waves/SIMD) */
 #endif
@@ -55,6 +59,10 @@ typedef struct { int32_t *Hs, *Es; uint64_t *tb; int32_t PM; int32_t tw; } wtz_w
  * the next row), row_bcast:31 = 0x143 (lane 31 to rows 2-3), wave_shr:1 = 0x138.  Lanes without a source keep `old`. */
 template<int CTRL, int ROWMASK>
 WTZ_D int32_t wtz_dpp_mov(int32_t old, int32_t src){ return __builtin_amdgcn_update_dpp(old, src, CTRL, ROWMASK, 0xF, false); }
+
+/* neighbour lane's value: wave_shl:1 = from lane+1, wave_shr:1 = from lane-1; the edge lane keeps `old` */
+WTZ_D int32_t wtz_dpp_wave_shl1(int32_t old, int32_t src){ return __builtin_amdgcn_update_dpp(old, src, 0x130, 0xF, 0xF, false); }
+WTZ_D int32_t wtz_dpp_wave_shr1(int32_t old, int32_t src){ return __builtin_amdgcn_update_dpp(old, src, 0x138, 0xF, 0xF, false); }
 
 WTZ_D int32_t wtz_wave_max_scan_excl(int32_t v, int32_t ident){
 	int32_t x = v, t;
@@ -474,6 +482,212 @@ WTZ_D wtz_aln_t wtz_extend_shift_wave_rt(int32_t qlen, const SQ &query, int32_t 
 	return wtz_bcast_aln(x);
 }
 
+/*
+ * K-sw3 with the DP rows entirely in registers (the form the job kernel runs; wtz_extend_shift_wave_rt above is its
+ * fallback and on-device cross-check).  Lane l owns the C band-relative columns l*C .. l*C+C-1.  The band start moves
+ * by s = 0, 1 or 2 columns per row (kswx.h:186-199), so H(i-1,j-1) and E(i-1,j) of the new frame are the lane's own
+ * registers at a compile-time offset (k+s-1, k+s) plus at most two values of the next lane / one of the previous lane,
+ * fetched with wave_shl / wave_shr DPP moves: three fully unrolled row bodies, no LDS hand-over.  Cells are branch-free;
+ * the row maximum and its FIRST arg-max come from one max-reduction over keys h*2048 + (2047 - band column) (callers
+ * guarantee |h| < 2^20); the query row base is scalar (32-base words in VGPRs, v_readlane every 16 rows); LDS holds only
+ * the 2-bit target.  Trace bytes, band starts and traceback are those of the rt form.
+ */
+template<int CMAX, int S>
+WTZ_D void wtz_shift_row_inputs(int32_t (&hv)[CMAX], int32_t (&ev)[CMAX], int lane, int32_t bnd){
+	/* rewrite hv := H(i-1, j-1), ev := E(i-1, j) for the new frame j = j0_old + S + k, in place */
+	if(S == 0){
+		int32_t prv = wtz_dpp_wave_shr1(-10000, hv[CMAX - 1]);
+		prv = (lane == 0) ? bnd : prv;
+		#pragma unroll
+		for(int k = CMAX - 1; k > 0; k--) hv[k] = hv[k - 1];
+		hv[0] = prv;
+	} else if(S == 1){
+		const int32_t ne0 = wtz_dpp_wave_shl1(-10000, ev[0]);
+		#pragma unroll
+		for(int k = 0; k + 1 < CMAX; k++) ev[k] = ev[k + 1];
+		ev[CMAX - 1] = ne0;
+	} else {
+		const int32_t nh0 = wtz_dpp_wave_shl1(-10000, hv[0]);
+		const int32_t ne0 = wtz_dpp_wave_shl1(-10000, ev[0]), ne1 = wtz_dpp_wave_shl1(-10000, ev[1]);
+		#pragma unroll
+		for(int k = 0; k + 1 < CMAX; k++) hv[k] = hv[k + 1];
+		hv[CMAX - 1] = nh0;
+		#pragma unroll
+		for(int k = 0; k + 2 < CMAX; k++) ev[k] = ev[k + 2];
+		ev[CMAX - 2] = ne0; ev[CMAX - 1] = ne1;
+	}
+}
+
+template<int CMAX>
+WTZ_D wtz_aln_t wtz_extend_shift_reg(int32_t qlen, const wtz_seq_packed &query, int32_t tlen, const wtz_seq_packed &target, int32_t init_score,
+		int32_t ql, int32_t tl, int32_t W, int32_t M, int32_t X, int32_t I, int32_t D, int32_t E, int32_t T,
+		uint64_t *tb, wtz_trace_t &tr, wtz_pool_t *pool, wtz_cigar_t &cigars, unsigned long long *cells, bool *ok){
+	const int lane = (int)(threadIdx.x & 63);
+	wtz_aln_t x; memset(&x, 0, sizeof x);
+	*ok = true;
+	if(lane == 0) cigars.n = 0;
+	if(init_score < 0) init_score = 0;
+	constexpr int C = CMAX;                       /* the lane block is exactly CMAX wide: 64*CMAX >= n_col */
+	constexpr int C4 = (C + 3) / 4;
+	const uint32_t zrow = (uint32_t)C4 * 256u;
+	if(!wtz_trace_prepare(tr, pool, zrow, ql, true)){ *ok = false; return x; }
+	uint8_t **zchunk = tr.chunk; int32_t *zb = tr.zb;
+	uint8_t *z = NULL;
+	{
+		const int32_t nw = (tl + 31) / 32 + 1;
+		for(int32_t w = lane; w < nw; w += 64) tb[w] = wtz_pack32(target, w * 32, tl);
+	}
+	__threadfence_block();
+	int32_t hv[C], ev[C];
+	#pragma unroll
+	for(int k = 0; k < C; k++){ hv[k] = -10000; ev[k] = -10000; }
+	int32_t mx = init_score, mi = -1, mj = -1, gmax = 0, gi = -1, gj = -1;
+	int32_t jbp = 0, c = 0, i;
+	unsigned long long ncell = 0;
+	const int32_t CE = C * E, IE = I + E, DE = D + E;
+	uint32_t qw_lo = 0, qw_hi = 0, qcur = 0;
+	const int32_t colrel0 = lane * C;
+	for(i = 0; i < ql; i++){
+		if((i & 63) == 0){
+			const uint32_t ci = (uint32_t)i >> 6;
+			unsigned long long za = 0;
+			if(ci < tr.n_chunk){ z = zchunk[ci]; }
+			else {
+				if(lane == 0){ uint8_t *p = (uint8_t*)wtz_pool_alloc(pool, (size_t)zrow * 64); zchunk[ci] = p; za = (unsigned long long)(uintptr_t)p; }
+				za = __shfl(za, 0, 64);
+				z = (uint8_t*)(uintptr_t)za;
+				if(z == NULL){ *ok = false; break; }
+				tr.n_chunk = ci + 1;
+			}
+			if((i & 2047) == 0){ const uint64_t qw = wtz_pack32(query, i + lane * 32, ql); qw_lo = (uint32_t)qw; qw_hi = (uint32_t)(qw >> 32); }
+		}
+		int32_t jb = 0, je = tl;
+		if(jb < c - W) jb = c - W;
+		if(je > c + W + 1) je = c + W + 1;
+		if(je > tl) je = tl;
+		if((i & 15) == 0){
+			const int32_t qs = __builtin_amdgcn_readfirstlane((i & 2047) >> 5);
+			qcur = (i & 16) ? (uint32_t)__builtin_amdgcn_readlane((int)qw_hi, qs) : (uint32_t)__builtin_amdgcn_readlane((int)qw_lo, qs);
+		}
+		const uint32_t qbase = (qcur >> ((i & 15) * 2)) & 3u;
+		const int32_t j0 = jb + colrel0;
+		uint64_t tbits;
+		{
+			const int32_t jj = j0 < tl ? j0 : (tl > 0 ? tl - 1 : 0);
+			const int32_t w = jj >> 5, sh = (jj & 31) * 2;
+			const uint64_t w0 = tb[w], w1 = tb[w + 1];
+			tbits = sh ? ((w0 >> sh) | (w1 << (64 - sh))) : w0;
+		}
+		/* ---- previous row into the new frame ---- */
+		if(i == 0){
+			#pragma unroll
+			for(int k = 0; k < C; k++){ const int32_t j = j0 + k; hv[k] = (j == 0) ? init_score : init_score + D + E * j; }     /* rh[] initialisation, kswx.h:143-144; E stays -10000 */
+		} else {
+			const int32_t s = jb - jbp;
+			const int32_t bnd = (jb == 0) ? init_score + I + E * i : -10000;      /* H(i-1, jb-1): outside the previous band unless it is column -1 */
+			if(s == 0) wtz_shift_row_inputs<C, 0>(hv, ev, lane, bnd);
+			else if(s == 1) wtz_shift_row_inputs<C, 1>(hv, ev, lane, bnd);
+			else wtz_shift_row_inputs<C, 2>(hv, ev, lane, bnd);
+		}
+		/* ---- m in place, the lane's F aggregate ---- */
+		int32_t agg = -0x3FFFFFFF;
+		#pragma unroll
+		for(int k = 0; k < C; k++){
+			const uint32_t tbase = (uint32_t)(tbits >> (2 * k)) & 3u;
+			const int32_t m = hv[k] + ((qbase == tbase) ? M : X);
+			hv[k] = m;
+			const int32_t cand = m + DE + (C - 1 - k) * E;
+			agg = ((j0 + k < je) && cand > agg) ? cand : agg;
+		}
+		int32_t f;
+		{
+			const int32_t g = agg - lane * CE;
+			const int32_t pm = wtz_wave_max_scan_excl(g, -0x3FFFFFFF);
+			const int32_t from_prev = (lane == 0) ? -0x3FFFFFFF : pm + (lane - 1) * CE;
+			const int32_t from_init = -10000 + lane * CE;
+			f = from_prev > from_init ? from_prev : from_init;
+		}
+		/* ---- H, E', F, trace byte (bit 7: bases equal) ---- */
+		int32_t key = (int32_t)0x80000000;
+		uint32_t zw[C4];
+		#pragma unroll
+		for(int q4 = 0; q4 < C4; q4++) zw[q4] = 0;
+		#pragma unroll
+		for(int k = 0; k < C; k++){
+			const bool valid = (j0 + k < je);
+			const int32_t m = hv[k], e = ev[k];
+			int32_t h = m > e ? m : e;
+			uint32_t d = (m >= e) ? 0u : 1u;
+			d = (h < f) ? 2u : d;
+			h = h > f ? h : f;
+			const int32_t te = m + IE, e2 = e + E;
+			d |= (e2 > te) ? (1u << 2) : 0u;
+			const int32_t en = e2 > te ? e2 : te;
+			const int32_t tf = m + DE, f2 = f + E;
+			d |= (f2 > tf) ? (2u << 4) : 0u;
+			f = f2 > tf ? f2 : tf;
+			d |= (qbase == ((uint32_t)(tbits >> (2 * k)) & 3u)) ? 0x80u : 0u;
+			hv[k] = valid ? h : -10000; ev[k] = valid ? en : -10000;
+			const int32_t kk = h * 2048 + (2047 - (colrel0 + k));
+			key = (valid && kk > key) ? kk : key;
+			zw[k >> 2] |= (valid ? d : 0u) << (8 * (k & 3));
+		}
+		{
+			uint32_t *zr = (uint32_t*)(z + (size_t)(i & 63) * zrow) + lane;
+			#pragma unroll
+			for(int q4 = 0; q4 < C4; q4++) zr[(size_t)q4 * 64] = zw[q4];
+		}
+		ncell += (unsigned long long)(je - jb);
+		key = wtz_wave_max_i32(key);
+		int32_t imax = 0, mj2 = -1;
+		if((key >> 11) > 0){ imax = key >> 11; mj2 = jb + (2047 - (key & 2047)); }       /* first j with the maximum, only if > 0 (kswx.h:172) */
+		if(lane == 0) zb[i] = jb;
+		if(je == tlen){
+			const int32_t idx = je - 1 - jb, kl = idx % C;
+			int32_t hsel = hv[0];
+			#pragma unroll
+			for(int k = 1; k < C; k++) hsel = (kl == k) ? hv[k] : hsel;
+			const int32_t h1 = __builtin_amdgcn_readlane(hsel, __builtin_amdgcn_readfirstlane(idx / C));      /* H(i, je-1) */
+			if(gmax < h1){ gmax = h1; gi = i; gj = je - 1; }
+		}
+		if(i + 1 == qlen && gmax < imax){ gmax = imax; gi = i; gj = mj2; }
+		jbp = jb;
+		if(imax > mx){ mx = imax; mi = i; mj = mj2; }
+		else if(imax <= 0) break;
+		c++; if(c < mj2) c++; else if(c > mj2) c--;
+	}
+	if(cells && lane == 0) *cells += ncell;
+	if(!*ok) return x;
+	if(gmax > 0 && gmax >= mx + T){ x.score = gmax; x.qe = gi; x.te = gj; }
+	else { x.score = mx; x.qe = mi; x.te = mj; }
+	__threadfence();
+	if(lane == 0){
+		int32_t i_ = x.qe, j_ = x.te; uint32_t d_ = 0;
+		int32_t chunk_i = -1; const uint8_t *cbase = NULL;
+		int32_t zbi = (i_ >= 0) ? zb[i_] : 0;
+		uint32_t run_op = 0xFFu, run_len = 0;
+		while(i_ >= 0 && j_ >= 0){
+			if((i_ >> 6) != chunk_i){ chunk_i = i_ >> 6; cbase = zchunk[chunk_i]; }
+			const int32_t col = j_ - zbi;
+			const int32_t ln = col / C, kk = col - ln * C;
+			const uint8_t zv = cbase[(size_t)(i_ & 63) * zrow + (size_t)(kk >> 2) * 256 + (size_t)ln * 4 + (kk & 3)];
+			const int32_t zb_prev = (i_ > 0) ? zb[i_ - 1] : 0;
+			d_ = (zv >> (d_ << 1)) & 0x03;
+			if(d_ == 0){ if(zv & 0x80u) x.mat++; else x.mis++; i_--; j_--; zbi = zb_prev; }
+			else if(d_ == 1){ i_--; x.ins++; zbi = zb_prev; }
+			else { j_--; x.del++; }
+			if(d_ == run_op) run_len++;
+			else { if(run_len) wtz_cigar_push(cigars, run_op, run_len); run_op = d_; run_len = 1; }
+		}
+		if(run_len) wtz_cigar_push(cigars, run_op, run_len);
+		if(i_ >= 0){ x.ins += i_ + 1; wtz_cigar_push(cigars, 1, (uint32_t)(i_ + 1)); }
+		if(j_ >= 0){ x.del += j_ + 1; wtz_cigar_push(cigars, 2, (uint32_t)(j_ + 1)); }
+		wtz_cigar_reverse(cigars.a, cigars.n);
+		x.aln = x.mat + x.mis + x.ins + x.del; x.qe++; x.te++;
+	}
+	return wtz_bcast_aln(x);
+}
+
 /* ---- K-sw3 jobs: one wave (64 threads) per job; jobs that do not fit the LDS rings run the scalar body on lane 0 ---- */
 template<int P, int TW>
 __global__ void __launch_bounds__(64) wtz_kernel_extjobs(wtz_extjob_t *jobs, const uint32_t *order, uint32_t n, const wtz_params_t *Pm, wtz_pool_t *pool){
@@ -481,7 +695,7 @@ __global__ void __launch_bounds__(64) wtz_kernel_extjobs(wtz_extjob_t *jobs, con
 	const uint32_t b = blockIdx.x;
 	if(b >= n) return;
 	wtz_extjob_t *job = &jobs[order ? order[b] : b];
-	if(!job->valid) return;
+	if(!job->valid || job->done) return;
 	const int lane = (int)(threadIdx.x & 63);
 	int32_t init_score = job->init_score < 0 ? 0 : job->init_score;
 	if(job->qlen <= 0 || job->tlen <= 0){
@@ -510,6 +724,41 @@ __global__ void __launch_bounds__(64) wtz_kernel_extjobs(wtz_extjob_t *jobs, con
 	}
 }
 
+/* K-sw3 jobs through the register DP: LDS carries only the 2-bit target.  Jobs outside its envelope (band wider than
+ * 64*32 columns, target longer than the LDS words, scores beyond the packed-key range) are left for wtz_kernel_extjobs. */
+template<int TW>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WTZ_OCC_EXTREG, 8))) wtz_kernel_extjobs_reg(wtz_extjob_t *jobs, const uint32_t *order, uint32_t n, const wtz_params_t *Pm, wtz_pool_t *pool){
+	__shared__ uint64_t stb[TW];
+	const uint32_t b = blockIdx.x;
+	if(b >= n) return;
+	wtz_extjob_t *job = &jobs[order ? order[b] : b];
+	if(!job->valid) return;
+	const int lane = (int)(threadIdx.x & 63);
+	if(job->qlen <= 0 || job->tlen <= 0) return;
+	const int32_t init_score = job->init_score < 0 ? 0 : job->init_score;
+	int32_t W = job->W, ql, tl, n_col;
+	wtz_ext_geometry(job->qlen, job->tlen, init_score, W, Pm->M, Pm->O, Pm->O, Pm->E, Pm->T, ql, tl, n_col);
+	const int32_t Cw = (n_col + 63) / 64;
+	if(Cw > 32 || (tl + 63) / 32 + 1 > TW || (ql + 63) / 64 > WTZ_TRACE_MAXCHUNK) return;
+	if((long long)init_score + (long long)Pm->M * (ql < tl ? ql : tl) >= (1 << 20)) return;
+	wtz_trace_t tr; tr.chunk = NULL; tr.zb = NULL; tr.n_chunk = 0; tr.zrow = 0; tr.cap_rows = 0;
+	wtz_cigar_t cg; cg.a = NULL; cg.n = cg.cap = 0; cg.pool = pool; cg.bad = 0;
+	if(lane == 0) cg.init(pool, 64);
+	unsigned long long cells = 0; bool ok = true;
+	wtz_aln_t x;
+#define WTZ_EXTREG_CASE(CM) x = wtz_extend_shift_reg<CM>(job->qlen, job->q, job->tlen, job->t, job->init_score, ql, tl, W, Pm->M, Pm->X, Pm->O, Pm->O, Pm->E, Pm->T, stb, tr, pool, cg, &cells, &ok)
+	if(Cw <= 4) WTZ_EXTREG_CASE(4);
+	else if(Cw <= 8) WTZ_EXTREG_CASE(8);
+	else if(Cw <= 12) WTZ_EXTREG_CASE(12);
+	else if(Cw <= 16) WTZ_EXTREG_CASE(16);
+	else if(Cw <= 20) WTZ_EXTREG_CASE(20);
+	else if(Cw <= 24) WTZ_EXTREG_CASE(24);
+	else if(Cw <= 28) WTZ_EXTREG_CASE(28);
+	else WTZ_EXTREG_CASE(32);
+#undef WTZ_EXTREG_CASE
+	if(lane == 0){ job->x = x; job->cigar = cg.a; job->cigar_len = cg.n; job->bad = (!ok || cg.bad); job->cells = cells; job->done = 1; }
+}
+
 /*
  * K-sw1 for the small problems between two anchors of a window (80 % have a band of <= 64 columns, 96 % <= 128 rows):
  * the whole DP state lives in registers.  Lane l owns the C band-relative columns l*C .. l*C+C-1; the fixed band moves
@@ -519,8 +768,6 @@ __global__ void __launch_bounds__(64) wtz_kernel_extjobs(wtz_extjob_t *jobs, con
  * the traceback of lane 0 never leaves the CU.  Results are those of wtz_extend_wave<1> / kswx_extend_align_core.
  * Requirements (checked by the caller): n_col <= 64*C, ((ql+1)/2)*64*C <= ztr_bytes, (tl+63)/32+1 <= tb words, ql <= 2048.
  */
-WTZ_D int32_t wtz_dpp_wave_shl1(int32_t old, int32_t src){ return __builtin_amdgcn_update_dpp(old, src, 0x130, 0xF, 0xF, false); }
-WTZ_D int32_t wtz_dpp_wave_shr1(int32_t old, int32_t src){ return __builtin_amdgcn_update_dpp(old, src, 0x138, 0xF, 0xF, false); }
 
 template<int C>
 WTZ_D wtz_aln_t wtz_extend_fixed_reg(int32_t qlen, const wtz_seq_packed &query, int32_t tlen, const wtz_seq_packed &target, int32_t init_score,
