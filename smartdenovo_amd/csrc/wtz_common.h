@@ -150,10 +150,12 @@ __device__ unsigned long long wtz_prof[16];
 #define WTZ_PROF_T() ((unsigned long long)clock64())
 #define WTZ_PROF_ADD(slot, t0) do { if(WTZ_LANE == 0) atomicAdd(&wtz_prof[slot], (unsigned long long)clock64() - (t0)); } while(0)
 #define WTZ_PROF_CNT(slot, v) do { if(WTZ_LANE == 0) atomicAdd(&wtz_prof[slot], (unsigned long long)(v)); } while(0)
+#define WTZ_PROF_MAX(slot, t0) do { if(WTZ_LANE == 0) atomicMax(&wtz_prof[slot], (unsigned long long)clock64() - (t0)); } while(0)
 #else
 #define WTZ_PROF_T() 0ull
 #define WTZ_PROF_ADD(slot, t0) do { (void)(t0); } while(0)
 #define WTZ_PROF_CNT(slot, v) do { } while(0)
+#define WTZ_PROF_MAX(slot, t0) do { (void)(t0); } while(0)
 #endif
 
 /* growable vector living in the pool (old storage is simply abandoned on growth) */

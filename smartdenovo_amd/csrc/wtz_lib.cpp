@@ -605,11 +605,12 @@ static int run_extjobs(wtz_ctx *c, const wtz_env_t &V, wtz_extjob_t *d_jobs, uin
 	}
 	/* longest-processing-time-first: the rows of an extension are sequential, so the longest job bounds the launch;
 	 * start the long ones first (key = query-side length, the row count upper bound) */
-	uint32_t *d_order = NULL;
+	uint32_t *d_order = NULL; unsigned long long ext_sum = 0; int32_t ext_max = 0;
 	{
 		int32_t *d_key = NULL; CHK(dev_alloc((void**)&d_key, (size_t)m * 4));
 		CHK(wtz_launch<K_misc>(0, m, [=] WTZ_LAMBDA (uint64_t t){ d_key[t] = d_jobs[t].valid ? d_jobs[t].qlen : -1; }));
 		std::vector<int32_t> key(m); CHK(dev_d2h(key.data(), d_key, (size_t)m * 4)); dev_free(d_key);
+		for(uint32_t i = 0; i < m; i++) if(key[i] > 0){ ext_sum += (unsigned long long)key[i]; if(key[i] > ext_max) ext_max = key[i]; }
 		std::vector<uint32_t> ord(m); for(uint32_t i = 0; i < m; i++) ord[i] = i;
 		std::stable_sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t b){ return key[a] > key[b]; });
 		CHK(dev_alloc((void**)&d_order, (size_t)m * 4)); CHK(dev_h2d(d_order, ord.data(), (size_t)m * 4));
@@ -624,7 +625,9 @@ static int run_extjobs(wtz_ctx *c, const wtz_env_t &V, wtz_extjob_t *d_jobs, uin
 		}
 		hipLaunchKernelGGL((wtz_kernel_extjobs<2048, 1032>), dim3(m), dim3(64), 0, g_stream, d_jobs, (const uint32_t*)d_order, m, V.P, V.pool);     /* whatever the register DP left */
 		HIPCHK(hipGetLastError());
-		c->cnt.ms_ext += te.stop(); c->cnt.n_extjobs += m;
+		const double ms_l = te.stop();
+		c->cnt.ms_ext += ms_l; c->cnt.n_extjobs += m;
+		if(getenv("WTZ_PROFILE_PAIR")) fprintf(stderr, "[ext-profile] %u jobs, rows (upper bound) sum %llu max %d, %.2f ms\n", m, ext_sum, ext_max, ms_l);
 		dev_free(d_order);
 	}
 	if(mode == 2){

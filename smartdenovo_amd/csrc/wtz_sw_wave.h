@@ -279,7 +279,7 @@ WTZ_D wtz_aln_t wtz_extend_wave(int32_t qlen, const SQ &query, int32_t tlen, con
 	if(gmax > 0 && gmax >= mx + T){ x.score = gmax; x.qe = gi; x.te = gj; }
 	else { x.score = mx; x.qe = mi; x.te = mj; }
 	/* ---- traceback by lane 0 (reads trace bytes stored by the other lanes of this wave) ---- */
-	__threadfence();
+	__threadfence_block();     /* the trace was written by lanes of THIS wave: ordering inside the wave is enough (an agent-scope fence would write back the whole L2) */
 	if(lane == 0){
 		int32_t i_ = x.qe, j_ = x.te; uint32_t d_ = 0;
 		while(i_ >= 0 && j_ >= 0){
@@ -452,7 +452,7 @@ WTZ_D wtz_aln_t wtz_extend_shift_wave_rt(int32_t qlen, const SQ &query, int32_t 
 	if(!*ok) return x;
 	if(gmax > 0 && gmax >= mx + T){ x.score = gmax; x.qe = gi; x.te = gj; }
 	else { x.score = mx; x.qe = mi; x.te = mj; }
-	__threadfence();
+	__threadfence_block();     /* the trace was written by lanes of THIS wave: ordering inside the wave is enough (an agent-scope fence would write back the whole L2) */
 	if(lane == 0){
 		/* traceback: one dependent trace-byte load per step; the band start of the previous row is fetched alongside, the chunk
 		 * base only every 64 rows, match/mismatch comes from bit 7 of the byte, the CIGAR run is kept in registers */
@@ -481,6 +481,15 @@ WTZ_D wtz_aln_t wtz_extend_shift_wave_rt(int32_t qlen, const SQ &query, int32_t 
 	}
 	return wtz_bcast_aln(x);
 }
+
+/* lane-0 CIGAR writer: the open run stays in a register, so appending never reads memory back (kswx_push_cigar merges) */
+typedef struct { wtz_cigar_t *v; uint32_t tail; } wtz_cigw_t;
+WTZ_D void wtz_cigw_push(wtz_cigw_t &w, uint32_t op, uint32_t len){
+	if(len == 0) return;
+	if(w.tail && (w.tail & 0xFu) == op) w.tail += len << 4;
+	else { if(w.tail) w.v->push(w.tail); w.tail = (len << 4) | op; }
+}
+WTZ_D void wtz_cigw_finish(wtz_cigw_t &w){ if(w.tail){ w.v->push(w.tail); w.tail = 0; } }
 
 /*
  * K-sw3 with the DP rows entirely in registers (the form the job kernel runs; wtz_extend_shift_wave_rt above is its
@@ -660,31 +669,60 @@ WTZ_D wtz_aln_t wtz_extend_shift_reg(int32_t qlen, const wtz_seq_packed &query, 
 	if(!*ok) return x;
 	if(gmax > 0 && gmax >= mx + T){ x.score = gmax; x.qe = gi; x.te = gj; }
 	else { x.score = mx; x.qe = mi; x.te = mj; }
-	__threadfence();
-	if(lane == 0){
+	__threadfence_block();     /* the trace was written by lanes of THIS wave: ordering inside the wave is enough (an agent-scope fence would write back the whole L2) */
+	const unsigned long long pt_tb3 = WTZ_PROF_T(); (void)pt_tb3;
+	/* ---- traceback.  Lane 0 walks, but never against HBM latency: for the 64 rows below the current cell every lane
+	 * copies one row's trace bytes of the WC absolute columns ending at the current column into LDS (the target words are
+	 * dead by now); the walk leaves the block after 64 rows or - rarely - through its left edge, and the next block is
+	 * staged.  Runs go through the register-tail writer and are reversed once at the end. ---- */
+	{
+		constexpr int WC = 124;
+		uint8_t *S = (uint8_t*)tb;
 		int32_t i_ = x.qe, j_ = x.te; uint32_t d_ = 0;
-		int32_t chunk_i = -1; const uint8_t *cbase = NULL;
-		int32_t zbi = (i_ >= 0) ? zb[i_] : 0;
 		uint32_t run_op = 0xFFu, run_len = 0;
+		wtz_cigw_t Wr; Wr.v = &cigars; Wr.tail = 0;
 		while(i_ >= 0 && j_ >= 0){
-			if((i_ >> 6) != chunk_i){ chunk_i = i_ >> 6; cbase = zchunk[chunk_i]; }
-			const int32_t col = j_ - zbi;
-			const int32_t ln = col / C, kk = col - ln * C;
-			const uint8_t zv = cbase[(size_t)(i_ & 63) * zrow + (size_t)(kk >> 2) * 256 + (size_t)ln * 4 + (kk & 3)];
-			const int32_t zb_prev = (i_ > 0) ? zb[i_ - 1] : 0;
-			d_ = (zv >> (d_ << 1)) & 0x03;
-			if(d_ == 0){ if(zv & 0x80u) x.mat++; else x.mis++; i_--; j_--; zbi = zb_prev; }
-			else if(d_ == 1){ i_--; x.ins++; zbi = zb_prev; }
-			else { j_--; x.del++; }
-			if(d_ == run_op) run_len++;
-			else { if(run_len) wtz_cigar_push(cigars, run_op, run_len); run_op = d_; run_len = 1; }
+			const int32_t i0 = i_, jlo = j_ - (WC - 1);
+			{
+				const int32_t r = i0 - lane;
+				if(r >= 0){
+					const int32_t zbr = zb[r];
+					const uint8_t *rowp = zchunk[r >> 6] + (size_t)(r & 63) * zrow;
+					for(int32_t t = 0; t < WC; t++){
+						const int32_t cc = jlo + t - zbr;
+						uint8_t v = 0;
+						if(cc >= 0 && cc < 64 * C){ const int32_t ln = cc / C, kk = cc - ln * C; v = rowp[(size_t)(kk >> 2) * 256 + (size_t)ln * 4 + (kk & 3)]; }
+						S[lane * WC + t] = v;
+					}
+				}
+			}
+			__threadfence_block();
+			if(lane == 0){
+				while(i_ >= 0 && j_ >= 0){
+					const int32_t rr = i0 - i_, t = j_ - jlo;
+					if(rr >= 64 || t < 0) break;
+					const uint32_t zv = S[rr * WC + t];
+					d_ = (zv >> (d_ << 1)) & 0x03;
+					if(d_ == 0){ if(zv & 0x80u) x.mat++; else x.mis++; i_--; j_--; }
+					else if(d_ == 1){ i_--; x.ins++; }
+					else { j_--; x.del++; }
+					if(d_ == run_op) run_len++;
+					else { if(run_len) wtz_cigw_push(Wr, run_op, run_len); run_op = d_; run_len = 1; }
+				}
+			}
+			i_ = __builtin_amdgcn_readfirstlane(i_); j_ = __builtin_amdgcn_readfirstlane(j_);
+			__threadfence_block();
 		}
-		if(run_len) wtz_cigar_push(cigars, run_op, run_len);
-		if(i_ >= 0){ x.ins += i_ + 1; wtz_cigar_push(cigars, 1, (uint32_t)(i_ + 1)); }
-		if(j_ >= 0){ x.del += j_ + 1; wtz_cigar_push(cigars, 2, (uint32_t)(j_ + 1)); }
-		wtz_cigar_reverse(cigars.a, cigars.n);
-		x.aln = x.mat + x.mis + x.ins + x.del; x.qe++; x.te++;
+		if(lane == 0){
+			if(run_len) wtz_cigw_push(Wr, run_op, run_len);
+			if(i_ >= 0){ x.ins += i_ + 1; wtz_cigw_push(Wr, 1, (uint32_t)(i_ + 1)); }
+			if(j_ >= 0){ x.del += j_ + 1; wtz_cigw_push(Wr, 2, (uint32_t)(j_ + 1)); }
+			wtz_cigw_finish(Wr);
+			wtz_cigar_reverse(cigars.a, cigars.n);
+			x.aln = x.mat + x.mis + x.ins + x.del; x.qe++; x.te++;
+		}
 	}
+	WTZ_PROF_ADD(9, pt_tb3);
 	return wtz_bcast_aln(x);
 }
 
@@ -735,6 +773,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WTZ_OCC
 	if(!job->valid) return;
 	const int lane = (int)(threadIdx.x & 63);
 	if(job->qlen <= 0 || job->tlen <= 0) return;
+	const unsigned long long pt_job = WTZ_PROF_T(); (void)pt_job;
 	const int32_t init_score = job->init_score < 0 ? 0 : job->init_score;
 	int32_t W = job->W, ql, tl, n_col;
 	wtz_ext_geometry(job->qlen, job->tlen, init_score, W, Pm->M, Pm->O, Pm->O, Pm->E, Pm->T, ql, tl, n_col);
@@ -757,6 +796,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WTZ_OCC
 	else WTZ_EXTREG_CASE(32);
 #undef WTZ_EXTREG_CASE
 	if(lane == 0){ job->x = x; job->cigar = cg.a; job->cigar_len = cg.n; job->bad = (!ok || cg.bad); job->cells = cells; job->done = 1; }
+	WTZ_PROF_ADD(8, pt_job); WTZ_PROF_MAX(15, pt_job); WTZ_PROF_CNT(10, 1);
 }
 
 /*
@@ -933,15 +973,6 @@ WTZ_D wtz_aln_t wtz_extend_fixed_reg(int32_t qlen, const wtz_seq_packed &query, 
 	WTZ_PROF_ADD(3, pt_tb);
 	return wtz_bcast_aln(x);
 }
-
-/* lane-0 CIGAR writer: the open run stays in a register, so appending never reads memory back (kswx_push_cigar merges) */
-typedef struct { wtz_cigar_t *v; uint32_t tail; } wtz_cigw_t;
-WTZ_D void wtz_cigw_push(wtz_cigw_t &w, uint32_t op, uint32_t len){
-	if(len == 0) return;
-	if(w.tail && (w.tail & 0xFu) == op) w.tail += len << 4;
-	else { if(w.tail) w.v->push(w.tail); w.tail = (len << 4) | op; }
-}
-WTZ_D void wtz_cigw_finish(wtz_cigw_t &w){ if(w.tail){ w.v->push(w.tail); w.tail = 0; } }
 
 /* up to 64 bases of a view in two registers */
 struct wtz_seq_reg2 { uint64_t w0, w1; WTZ_D uint32_t at(int32_t i) const { return (uint32_t)(((i < 32) ? (w0 >> (2 * i)) : (w1 >> (2 * (i - 32)))) & 3u); } };
@@ -1168,7 +1199,7 @@ WTZ_D int32_t wtz_global_wave(int32_t qlen, const SQ &query, int32_t tlen, const
 		begp = beg; endp = end; end_last = end;
 	}
 	const int32_t score = (end_last == qlen) ? h_lastrow : ((qlen <= w) ? -(o_ins + e_ins * qlen) : WTZ_MINUS_INF);
-	__threadfence();
+	__threadfence_block();     /* the trace was written by lanes of THIS wave: ordering inside the wave is enough (an agent-scope fence would write back the whole L2) */
 	if(lane == 0){
 		uint32_t which = 0;
 		int32_t ii = tlen - 1, k = (ii + w + 1 < qlen ? ii + w + 1 : qlen) - 1;

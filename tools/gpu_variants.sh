@@ -12,6 +12,6 @@ for f in "$@"; do
   echo "== flags: [$f]"
   for e in zmo ${WTZ_ENGINES}; do
     if [ $e = zmo ]; then A="-k 16 -s 200 -m 0.6"; else A="-k 16 -z 10 -Z 16 -U -1 -m 0.1 -A 1000"; fi
-    bin/wtzmo --pool-gb 60 -i /tmp/ecoli.fa -fo /tmp/v.ovl $A 2>&1 | grep -E "records,|kernel ms"; md5sum /tmp/v.ovl | cut -c1-32
+    bin/wtzmo --pool-gb 60 -i /tmp/ecoli.fa -fo /tmp/v.ovl $A 2>&1 | grep -E "records,|kernel ms|phase-profile"; md5sum /tmp/v.ovl | cut -c1-32
   done
 done
