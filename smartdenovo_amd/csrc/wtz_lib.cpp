@@ -686,7 +686,7 @@ extern "C" int wtz_pairs_align(wtz_ctx_t *c, const uint32_t *pair_idx, const uin
 		wtz_gapres_t *d_gaps = NULL; CHK(dev_alloc((void**)&d_gaps, (size_t)(nreg + 1) * sizeof(wtz_gapres_t)));
 		const uint64_t nwt = wt.size();
 		CHK(wtz_launch_wave<K_stitch_left>(0, m, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_stitch_left((uint32_t)t, V, d_items, d_st, d_jl); }));
-		CHK(wtz_launch_coop<K_gap>(0, nwt, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_gap((uint32_t)t, V, d_wt, d_items, d_gaps); }));
+		CHK(wtz_launch_coop<K_gap>(0, nwt, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_gap((uint32_t)t, V, d_wt, d_items, d_gaps); }, WTZ_GAP_LDS_BYTES));
 		CHK(run_extjobs(c, V, d_jl, m));
 		CHK(wtz_launch_wave<K_stitch_mid>(0, m, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_stitch_mid((uint32_t)t, V, d_items, d_st, d_jl, d_jr, d_gaps); }));
 		CHK(run_extjobs(c, V, d_jr, m));

@@ -1219,5 +1219,144 @@ WTZ_D int32_t wtz_global_wave(int32_t qlen, const SQ &query, int32_t tlen, const
 	return score;
 }
 
+/*
+ * K-sw2 (ksw_global2) for gaps whose band fits two columns per lane: the register form of wtz_global_wave.  Rows run over
+ * the target (its row base is scalar, from 32-base words held in VGPRs), lanes over the query band (2-bit words in LDS);
+ * the fixed band moves right by one column per row once i > w, so the hand-over is the same DPP move as in K-sw1; the
+ * trace is 4 bits per cell in LDS.  Besides the CIGAR runs (traceback order, in `runs`) it returns the match / mismatch
+ * counts of the M runs, which the caller would otherwise have to recount base by base (hzm_aln.h:1424-1436).
+ * Requirements (caller): n_col <= 64*C, ((tlen+1)/2)*zrow + 4*(qlen+tlen+4) <= LDS trace bytes, (qlen+63)/32+1 <= qb words.
+ */
+template<int C>
+WTZ_D int32_t wtz_global_reg(int32_t qlen, const wtz_seq_packed &query, int32_t tlen, const wtz_seq_packed &target, int32_t M, int32_t X,
+		int32_t o_del, int32_t e_del, int32_t o_ins, int32_t e_ins, int32_t w, uint64_t *qb, uint8_t *ztr, uint32_t zrow,
+		uint32_t *runs, uint32_t *n_runs, int32_t *n_mat, int32_t *n_mis){
+	const int lane = (int)(threadIdx.x & 63);
+	const int32_t oe_del = o_del + e_del, oe_ins = o_ins + e_ins;
+	*n_runs = 0; *n_mat = 0; *n_mis = 0;
+	{
+		const int32_t nw = (qlen + 31) / 32 + 1;
+		for(int32_t ww = lane; ww < nw; ww += 64) qb[ww] = wtz_pack32(query, ww * 32, qlen);
+	}
+	__threadfence_block();
+	const uint32_t *qb32 = (const uint32_t*)qb;
+	int32_t hp[C], ep[C]; uint32_t nibp[C];
+	#pragma unroll
+	for(int k = 0; k < C; k++){ hp[k] = WTZ_MINUS_INF; ep[k] = WTZ_MINUS_INF; nibp[k] = 0; }
+	const int32_t CE = C * (-e_ins);
+	const int32_t colrel0 = lane * C;
+	uint32_t tw_lo = 0, tw_hi = 0, tcur = 0, qwin = 0; int32_t qwin_left = 0;
+	int32_t begp = 0, i, h_lastrow = 0, end_last = 0;
+	for(i = 0; i < tlen; i++){
+		const int32_t beg = i > w ? i - w : 0;
+		const int32_t end = i + w + 1 < qlen ? i + w + 1 : qlen;
+		if((i & 2047) == 0){ const uint64_t v = wtz_pack32(target, i + lane * 32, tlen); tw_lo = (uint32_t)v; tw_hi = (uint32_t)(v >> 32); }
+		if((i & 15) == 0){
+			const int32_t ts = __builtin_amdgcn_readfirstlane((i & 2047) >> 5);
+			tcur = (i & 16) ? (uint32_t)__builtin_amdgcn_readlane((int)tw_hi, ts) : (uint32_t)__builtin_amdgcn_readlane((int)tw_lo, ts);
+		}
+		const uint32_t tbase = (tcur >> ((i & 15) * 2)) & 3u;
+		const int32_t j0 = beg + colrel0;
+		const bool moved = (i > 0) && (beg != begp);
+		if(moved){ qwin >>= 2; qwin_left--; }
+		if(i == 0 || qwin_left < C){
+			const int32_t jj = j0 < qlen ? j0 : (qlen > 0 ? qlen - 1 : 0);
+			const uint32_t lo = qb32[jj >> 4], hi = qb32[(jj >> 4) + 1];
+			qwin = __builtin_amdgcn_alignbit(hi, lo, (uint32_t)(jj & 15) * 2u);
+			qwin_left = 16;
+		}
+		int32_t pred[C], ein[C];
+		if(i == 0){
+			#pragma unroll
+			for(int k = 0; k < C; k++){ const int32_t j = j0 + k; pred[k] = (j == 0) ? 0 : ((j <= w) ? -(o_ins + e_ins * j) : WTZ_MINUS_INF); ein[k] = WTZ_MINUS_INF; }      /* eh[] initialisation, ksw.c:519-523 */
+		} else if(moved){
+			const int32_t nxt = wtz_dpp_wave_shl1(WTZ_MINUS_INF, ep[0]);
+			#pragma unroll
+			for(int k = 0; k < C; k++){ pred[k] = hp[k]; ein[k] = (k + 1 < C) ? ep[k + 1] : nxt; }
+		} else {
+			int32_t prv = wtz_dpp_wave_shr1(WTZ_MINUS_INF, hp[C - 1]);
+			prv = (lane == 0) ? -(o_del + e_del * i) : prv;             /* first column, ksw.c:533 */
+			#pragma unroll
+			for(int k = 0; k < C; k++){ pred[k] = k ? hp[k - 1] : prv; ein[k] = ep[k]; }
+		}
+		int32_t mv[C]; bool valid[C]; int32_t agg = -0x7F000000;
+		#pragma unroll
+		for(int k = 0; k < C; k++){
+			const uint32_t qbase = (qwin >> (2 * k)) & 3u;
+			mv[k] = pred[k] + ((tbase == qbase) ? M : X);
+			valid[k] = (j0 + k < end);
+			const int32_t cand = mv[k] - oe_ins + (C - 1 - k) * (-e_ins);
+			agg = (valid[k] && cand > agg) ? cand : agg;
+		}
+		int32_t f;
+		{
+			const int32_t g = agg - lane * CE;
+			const int32_t pm = wtz_wave_max_scan_excl(g, -0x7F000000);
+			const int32_t from_prev = (lane == 0) ? -0x7F000000 : pm + (lane - 1) * CE;
+			const int32_t from_init = WTZ_MINUS_INF + lane * CE;
+			f = from_prev > from_init ? from_prev : from_init;
+		}
+		#pragma unroll
+		for(int k = 0; k < C; k++){
+			const int32_t m = mv[k], e = ein[k];
+			int32_t h = m > e ? m : e;
+			uint32_t nib = (m >= e) ? 0u : 1u;
+			nib = (h < f) ? 2u : nib;
+			h = h > f ? h : f;
+			const int32_t te = m - oe_del, e2 = e - e_del;
+			nib |= (e2 > te) ? 4u : 0u;
+			const int32_t en = e2 > te ? e2 : te;
+			const int32_t tf = m - oe_ins, f2 = f - e_ins;
+			nib |= (f2 > tf) ? 8u : 0u;
+			f = f2 > tf ? f2 : tf;
+			hp[k] = valid[k] ? h : WTZ_MINUS_INF; ep[k] = valid[k] ? en : WTZ_MINUS_INF;
+			nib = valid[k] ? nib : 0u;
+			if(i & 1){ if((uint32_t)(colrel0 + k) < zrow) ztr[(size_t)(i >> 1) * zrow + colrel0 + k] = (uint8_t)(nibp[k] | (nib << 4)); }
+			else nibp[k] = nib;
+		}
+		if(end > beg && i + 1 == tlen){
+			const int32_t idx = end - 1 - beg;
+			int32_t hsel = hp[0];
+			#pragma unroll
+			for(int k = 1; k < C; k++) hsel = (idx % C == k) ? hp[k] : hsel;
+			h_lastrow = __builtin_amdgcn_readlane(hsel, __builtin_amdgcn_readfirstlane(idx / C));
+		}
+		begp = beg; end_last = end;
+	}
+	if(tlen > 0 && !((tlen - 1) & 1)){
+		#pragma unroll
+		for(int k = 0; k < C; k++) if((uint32_t)(colrel0 + k) < zrow) ztr[(size_t)((tlen - 1) >> 1) * zrow + colrel0 + k] = (uint8_t)nibp[k];
+	}
+	const int32_t score = (end_last == qlen) ? h_lastrow : ((qlen <= w) ? -(o_ins + e_ins * qlen) : WTZ_MINUS_INF);
+	__threadfence_block();
+	if(lane == 0){
+		uint32_t which = 0, nr = 0, run_op = 0xFFu, run_len = 0; int32_t mat = 0, mis = 0;
+		int32_t ii = tlen - 1, k = (ii + w + 1 < qlen ? ii + w + 1 : qlen) - 1;
+		while(ii >= 0 && k >= 0){
+			const int32_t col = k - (ii > w ? ii - w : 0);
+			const uint32_t zv = ztr[(size_t)(ii >> 1) * zrow + col];
+			const uint32_t nib = (zv >> ((ii & 1) * 4)) & 0xFu;
+			if(which == 0) which = nib & 3u; else if(which == 1) which = (nib & 4u) ? 1u : 0u; else which = (nib & 8u) ? 2u : 0u;
+			uint32_t op;
+			if(which == 0){
+				const uint32_t qv = (uint32_t)(qb[k >> 5] >> ((k & 31) * 2)) & 3u;
+				const int32_t ts = (ii & 2047) >> 5;
+				const uint32_t tv = (ii & 16) ? (uint32_t)__builtin_amdgcn_readlane((int)tw_hi, ts) : (uint32_t)__builtin_amdgcn_readlane((int)tw_lo, ts);
+				if(qv == ((tv >> ((ii & 15) * 2)) & 3u)) mat++; else mis++;
+				op = 0; --ii; --k;
+			}
+			else if(which == 1){ op = 2; --ii; }
+			else { op = 1; --k; }
+			if(op == run_op) run_len++;
+			else { if(run_len) runs[nr++] = (run_len << 4) | run_op; run_op = op; run_len = 1; }
+		}
+		if(ii >= 0){ if(run_len && run_op == 2u) run_len += (uint32_t)(ii + 1); else { if(run_len) runs[nr++] = (run_len << 4) | run_op; run_op = 2u; run_len = (uint32_t)(ii + 1); } }
+		if(k >= 0){ if(run_len && run_op == 1u) run_len += (uint32_t)(k + 1); else { if(run_len) runs[nr++] = (run_len << 4) | run_op; run_op = 1u; run_len = (uint32_t)(k + 1); } }
+		if(run_len) runs[nr++] = (run_len << 4) | run_op;
+		*n_runs = nr; *n_mat = mat; *n_mis = mis;
+	}
+	return score;
+}
+
 #endif /* __HIPCC__ */
 #endif

@@ -19,6 +19,9 @@ typedef struct {
 } wtz_env_t;
 
 #define WTZ_WAVE_LDS_BYTES 8192
+#ifndef WTZ_GAP_LDS_BYTES
+#define WTZ_GAP_LDS_BYTES 12288      /* LDS slice of a gap-filling (K-sw2) wave */
+#endif
 #define WTZ_PAIR_LDS_BYTES 16384     /* K_pair: LDS slice of the small exact sorts (2048 words) */
 /* the LDS slice of the wave running the current task (wave-task kernels carry WTZ_WAVE_LDS_BYTES of dynamic LDS) */
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -210,15 +213,25 @@ WTZ_HD void wtz_task_gap(uint32_t t, const wtz_env_t &V, const wtz_wintask_t *ta
 	wtz_cigar_t tmp; tmp.init(V.pool, WTZ_LANE == 0 ? 32 : 0);
 	int32_t w = P->w, score, bad = 0;
 #if defined(__HIP_DEVICE_COMPILE__)
+	bool from_reg = false; uint32_t n_runs = 0; uint32_t *runs = NULL; int32_t r_mat = 0, r_mis = 0;
 	{   /* the whole wavefront computes the banded global alignment; band doubling is uniform (score is broadcast) */
 		int32_t *lds = wtz_wave_scratch();
-		wtz_wave_lds_t L; L.Hs = lds; L.Es = lds + 512; L.tb = (uint64_t*)(lds + 1024); L.PM = 511; L.tw = 128;
+		/* LDS slice: 128 sequence words (1 KB), then either the H/E rings of the general wave DP or the 4-bit trace of the
+		 * register DP with its run list at the top end */
+		wtz_wave_lds_t L; L.tb = (uint64_t*)lds; L.Hs = lds + 256; L.Es = lds + 768; L.PM = 511; L.tw = 128;
+		uint8_t *ztr = (uint8_t*)(lds + 256); const int32_t ztr_bytes = WTZ_GAP_LDS_BYTES - 1024;
 		wtz_trace_t tr; tr.chunk = NULL; tr.zb = NULL; tr.n_chunk = 0; tr.zrow = 0; tr.cap_rows = 0;
 		wtz_swmem_t mem; wtz_swmem_init(mem, V.pool);
 		for(;;){
 			if(w < WTZ_ABSDIFF(dq, dt)){ w <<= 1; continue; }
 			const int32_t n_col = dq < 2 * w + 1 ? dq : 2 * w + 1;
-			if(dq > 0 && dt > 0 && n_col + 2 <= 512 && (dq + 63) / 32 + 1 <= 128 && (dt + 63) / 64 <= WTZ_TRACE_MAXCHUNK){
+			const int32_t zrow = (n_col + 3) & ~3, run_bytes = 4 * (dq + dt + 4);
+			from_reg = false;
+			if(dq > 0 && dt > 0 && n_col <= 128 && dt <= 2048 && (dq + 63) / 32 + 1 <= 128 && ((dt + 1) / 2) * zrow + run_bytes <= ztr_bytes){
+				runs = (uint32_t*)(ztr + ztr_bytes - run_bytes); from_reg = true;
+				if(n_col <= 64) score = wtz_global_reg<1>(dq, q, dt, tt, M, X, -I, -E, -D, -E, w, L.tb, ztr, (uint32_t)zrow, runs, &n_runs, &r_mat, &r_mis);
+				else            score = wtz_global_reg<2>(dq, q, dt, tt, M, X, -I, -E, -D, -E, w, L.tb, ztr, (uint32_t)zrow, runs, &n_runs, &r_mat, &r_mis);
+			} else if(dq > 0 && dt > 0 && n_col + 2 <= 512 && (dq + 63) / 32 + 1 <= 128 && (dt + 63) / 64 <= WTZ_TRACE_MAXCHUNK){
 				bool ok = true;
 				score = wtz_global_wave(dq, q, dt, tt, M, X, -I, -E, -D, -E, w, L, tr, V.pool, tmp, &ok);
 				if(!ok) bad = 1;
@@ -233,6 +246,19 @@ WTZ_HD void wtz_task_gap(uint32_t t, const wtz_env_t &V, const wtz_wintask_t *ta
 		}
 	}
 	if(WTZ_LANE != 0) return;
+	if(from_reg){     /* runs are in traceback order; match / mismatch counts came with them */
+		g.score = score; g.valid = 1; g.mat = r_mat; g.mis = r_mis;
+		tmp.n = 0;
+		for(uint32_t k = n_runs; k-- > 0;){
+			const uint32_t r = runs[k], op = r & 0xFu; const int32_t len = (int32_t)(r >> 4);
+			tmp.push(r);
+			g.aln += len;
+			if(op == 1) g.ins += len; else if(op == 2) g.del += len;
+		}
+		g.cigar = tmp.a; g.cigar_len = tmp.n; g.bad = (tmp.bad || bad);
+		*slot = g;
+		return;
+	}
 #else
 	{
 		wtz_swmem_t mem; wtz_swmem_init_lds(mem, V.pool, wtz_wave_scratch(), WTZ_WAVE_LDS_BYTES / 4);
