@@ -105,6 +105,70 @@ static uint32_t nbest_of(const eng_t *E, uint32_t id){
 	return nb < E->P.nbest ? E->P.nbest : nb;
 }
 
+/* ---------------- output: records are formatted into large chunks by the commit and written by a writer thread,
+ * so that the ~12 KB-per-record CIGAR text leaves the critical path (the next batch's GPU stages run meanwhile) ---- */
+typedef struct ochunk { char *buf; size_t n, cap; struct ochunk *next; } ochunk_t;
+typedef struct {
+	FILE *fp; pthread_t th; pthread_mutex_t mu; pthread_cond_t cv;
+	ochunk_t *head, *tail, *freelist, *cur; int done, started;
+} owriter_t;
+static owriter_t g_ow;
+#define OCHUNK_BYTES ((size_t)16 << 20)
+
+static void *owriter_main(void *arg){
+	owriter_t *w = (owriter_t*)arg;
+	for(;;){
+		pthread_mutex_lock(&w->mu);
+		while(w->head == NULL && !w->done) pthread_cond_wait(&w->cv, &w->mu);
+		ochunk_t *c = w->head;
+		if(c == NULL){ pthread_mutex_unlock(&w->mu); break; }
+		w->head = c->next; if(w->head == NULL) w->tail = NULL;
+		pthread_mutex_unlock(&w->mu);
+		if(c->n && fwrite(c->buf, 1, c->n, w->fp) != c->n){ fprintf(stderr, " -- write error --\n"); exit(1); }
+		pthread_mutex_lock(&w->mu);
+		c->n = 0; c->next = w->freelist; w->freelist = c;
+		pthread_mutex_unlock(&w->mu);
+	}
+	return NULL;
+}
+static void out_start(FILE *fp){
+	owriter_t *w = &g_ow;
+	if(!w->started){ pthread_mutex_init(&w->mu, NULL); pthread_cond_init(&w->cv, NULL); }
+	w->fp = fp; w->head = w->tail = NULL; w->cur = NULL; w->done = 0; w->started = 1;
+	pthread_create(&w->th, NULL, owriter_main, w);
+}
+static void out_submit(owriter_t *w){
+	if(w->cur == NULL) return;
+	pthread_mutex_lock(&w->mu);
+	w->cur->next = NULL;
+	if(w->tail) w->tail->next = w->cur; else w->head = w->cur;
+	w->tail = w->cur; w->cur = NULL;
+	pthread_cond_signal(&w->cv);
+	pthread_mutex_unlock(&w->mu);
+}
+/* room for `need` more bytes in the current chunk */
+static char *out_space(size_t need){
+	owriter_t *w = &g_ow;
+	if(w->cur && w->cur->n + need > w->cur->cap) out_submit(w);
+	if(w->cur == NULL){
+		pthread_mutex_lock(&w->mu);
+		ochunk_t **pp = &w->freelist, *c = NULL;
+		for(; *pp; pp = &(*pp)->next) if((*pp)->cap >= need){ c = *pp; *pp = c->next; break; }
+		pthread_mutex_unlock(&w->mu);
+		if(c == NULL){ c = (ochunk_t*)hx_realloc(NULL, sizeof(ochunk_t)); c->cap = need > OCHUNK_BYTES ? need : OCHUNK_BYTES; c->buf = (char*)hx_realloc(NULL, c->cap); }
+		c->n = 0; c->next = NULL; w->cur = c;
+	}
+	return w->cur->buf + w->cur->n;
+}
+static void out_advance(size_t n){ g_ow.cur->n += n; }
+/* everything formatted so far is on the stream when this returns */
+static void out_finish(void){
+	owriter_t *w = &g_ow;
+	out_submit(w);
+	pthread_mutex_lock(&w->mu); w->done = 1; pthread_cond_signal(&w->cv); pthread_mutex_unlock(&w->mu);
+	pthread_join(w->th, NULL);
+}
+
 /* ---------------- record writer + state merge (wtzmo.c:1170-1249, 1319-1329) ---------------- */
 static void flush_pending(eng_t *E){
 	pending_t *p = &E->pend;
@@ -114,9 +178,9 @@ static void flush_pending(eng_t *E){
 			for(size_t i = 0; i < p->nseed; i++){
 				const seed_t *s = &p->seeds[i];
 				if(s->closed) continue;
-				fprintf(E->out, "# %s\t%c\t%d", reads[p->rd_id].name, '+', reads[p->rd_id].len);
-				fprintf(E->out, "\t%s\t%c\t%d", reads[s->pb2].name, "+-"[s->dir], reads[s->pb2].len);
-				fprintf(E->out, "\t%d\n", s->ovl);
+				char *o = out_space(strlen(reads[p->rd_id].name) + strlen(reads[s->pb2].name) + 96);
+				out_advance((size_t)sprintf(o, "# %s\t%c\t%d\t%s\t%c\t%d\t%d\n", reads[p->rd_id].name, '+', reads[p->rd_id].len,
+					reads[s->pb2].name, "+-"[s->dir], reads[s->pb2].len, s->ovl));
 			}
 		} else {
 			for(size_t j = 0; j < p->nhit; j++){
@@ -127,11 +191,7 @@ static void flush_pending(eng_t *E){
 				int r1 = (int)reads[h->pb1].len - h->te, r2 = (int)reads[h->pb2].len - h->qe;
 				uint32_t x2 = (uint32_t)(r1 < r2 ? r1 : r2);
 				if(x1 + x2 <= 200u){ E->rdcovs[h->pb1]++; E->rdcovs[h->pb2]++; }          /* max_unalign_in_dovetail, wtzmo.c:175 */
-				fprintf(E->out, "%s\t%c\t%d\t%d\t%d", reads[h->pb1].name, '+', reads[h->pb1].len, h->tb, h->te);
-				fprintf(E->out, "\t%s\t%c\t%d\t%d\t%d", reads[h->pb2].name, "+-"[h->dir2], reads[h->pb2].len, h->qb, h->qe);
-				fprintf(E->out, "\t%d\t%0.3f\t%d\t%d\t%d\t%d", h->score, 1.0 * h->mat / h->aln, h->mat, h->mis, h->ins, h->del);
-				if(h->cigar){ fprintf(E->out, "\t%s\n", h->cigar); free(h->cigar); h->cigar = NULL; }
-				else fprintf(E->out, "\t0M\n");
+				/* the record text itself was formatted when the hit was committed (emit_record): same order, same bytes */
 			}
 		}
 	}
@@ -159,6 +219,18 @@ static void pend_closed(pending_t *p, uint64_t v){
 static void pend_hit(pending_t *p, const hit_t *h){
 	if(p->nhit == p->caphit){ p->caphit = p->caphit ? p->caphit * 2 : 64; p->hits = (hit_t*)hx_realloc(p->hits, p->caphit * sizeof(hit_t)); }
 	p->hits[p->nhit++] = *h;
+}
+
+/* one .ovl line (print_hits_wtzmo, wtzmo.c:1170-1249) into the output stream; cigar == NULL prints "0M" */
+static void emit_record(eng_t *E, const hit_t *h, const char *cigar, size_t cigar_len){
+	const hx_read_t *reads = E->st.reads;
+	const int aln = h->aln == 0 ? 1 : h->aln;
+	char *o = out_space(strlen(reads[h->pb1].name) + strlen(reads[h->pb2].name) + 256 + cigar_len);
+	size_t k = (size_t)sprintf(o, "%s\t%c\t%d\t%d\t%d\t%s\t%c\t%d\t%d\t%d\t%d\t%0.3f\t%d\t%d\t%d\t%d\t", reads[h->pb1].name, '+', reads[h->pb1].len, h->tb, h->te,
+		reads[h->pb2].name, "+-"[h->dir2], reads[h->pb2].len, h->qb, h->qe, h->score, 1.0 * h->mat / aln, h->mat, h->mis, h->ins, h->del);
+	if(cigar){ memcpy(o + k, cigar, cigar_len); k += cigar_len; } else { o[k++] = '0'; o[k++] = 'M'; }
+	o[k++] = '\n';
+	out_advance(k);
 }
 
 __attribute__((unused)) static char *cigar_text(const uint32_t *c, uint32_t n){        /* kswx.h:1093-1120 */
@@ -215,12 +287,14 @@ static void commit_query(eng_t *E, batch_t *b, uint32_t slot){
 				H.pb1 = pbid; H.pb2 = id2; H.dir2 = (uint32_t)S->dm_dir; H.score = S->dm_score;
 				H.tb = S->dm_tb; H.te = S->dm_te; H.qb = S->dm_qb; H.qe = S->dm_qe; H.mat = S->dm_score; H.aln = (int)ol;
 				pend_hit(pd, &H);
+				emit_record(E, &H, NULL, 0);
 			}
 		}
 		free(cand);
 		return;
 	}
 	uint16_t *windeps = (uint16_t*)calloc((size_t)alen + 1, 2);
+	int32_t *wdiff = (int32_t*)calloc((size_t)alen + 2, 4);
 	float *weights = (float*)hx_realloc(NULL, sizeof(float) * ((size_t)alen + 1));
 	seed_t *seeds = (seed_t*)hx_realloc(NULL, sizeof(seed_t) * (nc + 1)); uint32_t nseed = 0;
 	for(uint32_t i = 0; i < nc; i++){
@@ -231,12 +305,14 @@ static void commit_query(eng_t *E, batch_t *b, uint32_t slot){
 		E->used_pairs++;
 		for(uint32_t dir = 0; dir < 2; dir++){
 			const wtz_winbox_t *bx = b->boxes + b->box_off[(size_t)cand[i].pidx * 2 + dir];
-			for(uint32_t k = 0; k < S->nwin[dir]; k++)
-				for(uint32_t x = (uint32_t)bx[k].beg[0]; (int)x < bx[k].end[0]; x++) windeps[x]++;       /* wtzmo.c:908 */
+			for(uint32_t k = 0; k < S->nwin[dir]; k++){       /* wtzmo.c:908 increments windeps over [beg,end): kept as +1/-1 marks, summed below */
+				if(bx[k].beg[0] < bx[k].end[0]){ wdiff[bx[k].beg[0]]++; wdiff[bx[k].end[0]]--; }
+			}
 		}
 		const uint32_t dir = (S->ovl[0] < S->ovl[1]);
 		if(S->ovl[dir] >= P->ztot){ seed_t s; s.pb2 = id2; s.dir = dir; s.ovl = S->ovl[dir]; s.closed = 0; s.pidx = cand[i].pidx; seeds[nseed++] = s; }
 	}
+	{ int32_t run = 0; for(int i = 0; i < alen; i++){ run += wdiff[i]; windeps[i] = (uint16_t)run; } }       /* uint16 wrap-around as in the reference's u2i counters */
 	/* repeat weighting: float/double mix exactly as written at wtzmo.c:933-936 */
 	for(int i = 0; i < alen; i++)
 		weights[i] = (windeps[i] <= P->win_rep_norm) ? 1.0 : ((windeps[i] >= P->win_rep_cutoff) ? 0.0 : P->win_rep_norm / (float)windeps[i]);
@@ -279,8 +355,8 @@ static void commit_query(eng_t *E, batch_t *b, uint32_t slot){
 			hit_t H; memset(&H, 0, sizeof H);
 			H.pb1 = pbid; H.pb2 = s->pb2; H.dir2 = s->dir; H.score = x->score;
 			H.tb = x->tb; H.te = x->te; H.qb = x->qb; H.qe = x->qe; H.mat = x->mat; H.mis = x->mis; H.ins = x->ins; H.del = x->del; H.aln = x->aln;
-			H.cigar = (char*)hx_realloc(NULL, (size_t)x->text_len + 1); memcpy(H.cigar, b->cig + x->text_off, x->text_len); H.cigar[x->text_len] = 0;
 			pend_hit(pd, &H);
+			emit_record(E, &H, b->cig + x->text_off, x->text_len);
 			{   /* dovetail / containment bookkeeping (wtzmo.c:1065-1100) */
 				const uint32_t len1 = E->rdlen[H.pb1], len2 = E->rdlen[H.pb2];
 				uint32_t x1 = (uint32_t)(H.tb < H.qb ? H.tb : H.qb);
@@ -306,7 +382,7 @@ static void commit_query(eng_t *E, batch_t *b, uint32_t slot){
 			}
 		}
 	}
-	free(cand); free(windeps); free(weights); free(seeds);
+	free(cand); free(windeps); free(wdiff); free(weights); free(seeds);
 }
 
 /* ---------------- one batch: plan -> GPU -> commit ---------------- */
@@ -658,6 +734,7 @@ int main(int argc, char **argv){
 			if(strcmp(output, "-")){ E->out = fopen(output, "w"); if(E->out == NULL) exit(1); setvbuf(E->out, NULL, _IOFBF, 8u << 20); }
 			wtz_reset_counters(E->ctx);
 		}
+		out_start(E->out);
 		if(g_hook) g_hook(rep, 0);
 		const double t0 = now_s();
 		rc = wtz_zindex_build(E->ctx); DIE_WTZ(rc, "wtz_zindex_build");
@@ -724,6 +801,7 @@ int main(int argc, char **argv){
 			free(bs); free(th);
 		}
 		flush_pending(E);
+		out_finish();
 		const double t1 = now_s();
 		if(strcmp(output, "-")) fclose(E->out); else fflush(stdout);
 		if(g_hook) g_hook(rep, 1);
