@@ -204,16 +204,29 @@ def main():
                    "parity": "records identical to `wtzmo -t 1%s` (tests/test_gpu_parity.py)" % ("" if world == 1 else " -P N -p rank` per rank")},
         "pairs_per_step": n_pairs // K, "pair_bp_per_step": pair_bp // K, "records_last_step": int(last[14]),
         "kernel_ms_last_step": dict(ms, ksw3_wave=ms_ext),
-        "roofline": {"kernel": "wtz_kernel_extjobs (K-sw3 shifting-band extension, one wavefront per problem)",
+        "roofline": {"kernel": "wtz_kernel_extjobs_reg (K-sw3 shifting-band extension, one wavefront per problem, DP rows in registers)",
                      "bound": "valu_int32", "achieved": cells_shift * OPS_PER_CELL / (ms_ext * 1e-3) / 1e12 if ms_ext > 0 else None,
                      "peak": INT32_VALU_PEAK_TOPS, "unit": "Tint32op/s",
                      "frac": (cells_shift * OPS_PER_CELL / (ms_ext * 1e-3) / 1e12 / INT32_VALU_PEAK_TOPS) if ms_ext > 0 else None,
                      "cell_updates_per_s": cells_shift / (ms_ext * 1e-3) if ms_ext > 0 else None, "cells": cells_shift,
                      "backtrack_GBps": cells_shift / (ms_ext * 1e-3) / 1e9 if ms_ext > 0 else None, "traffic": None},
-        "roofline_seed": {"kernel": "wtz_kernel_tasks<K_candidates> (hzm seed lookup + candidate heap)", "bound": "hbm",
+        "roofline_seed": {"kernel": "wtz_kernel_coop_tasks<K_candidates> (hzm seed lookup + candidate heap)", "bound": "hbm",
                           "achieved": seed_bytes / (ms["candidates"] * 1e-3) / 1e9 if ms["candidates"] > 0 else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                           "frac": (seed_bytes / (ms["candidates"] * 1e-3) / 1e9 / HBM_PEAK_GBS) if ms["candidates"] > 0 else None, "algorithmic_bytes": seed_bytes, "traffic": None},
     }
+    # HBM traffic of the two roofline kernels: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command, condensed by
+    # tools/summarize_profiles.py into profiles/ (per launch = per-kernel total / dispatches; FETCH_SIZE doubled as the gfx950 guide says)
+    try:
+        import csv
+        for row in csv.DictReader(open(os.path.join(ROOT, "profiles", "r01_%s_pmc_per_kernel.csv" % a.engine))):
+            per_launch = float(row["hbm_bytes_est"]) / max(1, int(row["dispatches"]))
+            if row["kernel"] == "wtz_kernel_extjobs_reg":
+                res["roofline"]["traffic"] = per_launch
+                res["roofline"]["traffic_note"] = "HBM bytes per launch from profiles/r01_%s_pmc_per_kernel.csv (separate --pmc passes)" % a.engine
+            if row["kernel"] == "K_candidates":
+                res["roofline_seed"]["traffic"] = per_launch
+    except Exception:
+        pass
     if world > 1:
         res["gathered_record_bytes"] = T["gathered"]
     if world == 1 and not a.no_cpu_baseline:
