@@ -69,12 +69,12 @@ WTZ_HD void wtz_band_advance(const wtz_diag_t *diags, uint32_t &doff, uint32_t d
 
 typedef struct { wtz_vec<wtz_zhit_t> dst; wtz_vec<wtz_win_t> regs[2]; wtz_vec<wtz_diag_t> diags; wtz_vec<uint32_t> block, grps; } wtz_dmscratch_t;
 
-WTZ_HD void wtz_denoise(wtz_zhit_t *rs, uint32_t n_rs, wtz_dmscratch_t &S, int32_t xvar, int32_t yvar, int32_t min_linear_len, bool presorted){
+/* one strand of denoising_hzmps (hzm_aln.h:731-889) over the diagonal-ordered matches */
+WTZ_HD void wtz_denoise_dir(wtz_zhit_t *rs, uint32_t n_rs, uint32_t dir, wtz_dmscratch_t &S, int32_t xvar, int32_t yvar, int32_t min_linear_len){
 	uint32_t i, j, k, doff, dcnt = 0, gid;
 	int32_t len, lst, lst_offset = 0, end_offset;
-	if(!presorted) wtz_sort_exact(rs, (size_t)n_rs, wtz_gt_zdiag());      /* hzm_aln.h:728; done by the wavefront when tie-free */
-	S.diags.reserve(2); if(S.diags.a){ S.diags.a[0].offset = 0; S.diags.a[0].off = 0; S.diags.a[0].cnt = 0; }
-	for(uint32_t dir = 0; dir < 2; dir++){
+	S.diags.reserve(2); if(S.diags.a && S.diags.n == 0){ S.diags.a[0].offset = 0; S.diags.a[0].off = 0; S.diags.a[0].cnt = 0; }
+	{
 		S.diags.n = 0; S.dst.n = 0; S.regs[dir].n = 0;
 		bool have = false;
 		for(i = 0; i < n_rs; i++){
@@ -159,6 +159,248 @@ WTZ_HD void wtz_denoise(wtz_zhit_t *rs, uint32_t n_rs, wtz_dmscratch_t &S, int32
 	}
 }
 
+/*
+ * The same strand pass with the wavefront and LDS (same results).  denoising_hzmps is a chain of small order-sensitive
+ * steps; run from HBM by one lane it costs ~10 dependent loads per match.  Here all lanes build a compact image of the
+ * strand in LDS - per match (off1<<10 | len1), its index in rs, its group id; per distinct diagonal (offset, first match,
+ * number of band members) - and lane 0 runs the band loop / group merging on that image only.  The grouped matches are
+ * then ordered by (group, off1) with the wave-wide bitonic network (an equal key makes lane 0 redo the swap-exact sort
+ * from the original order), gathered into LDS and folded into blocks.  Returns false without having changed anything
+ * when the strand does not fit the LDS slice (the caller then runs wtz_denoise_dir on lane 0).
+ */
+#define WTZ_DM_BCAP 512u      /* members of one diagonal band */
+#define WTZ_DM_GCAP 512u      /* linear groups of one strand */
+struct wtz_gt_blk_off1 { const uint32_t *T; WTZ_HDM bool operator()(uint16_t a, uint16_t b) const { return (T[a] >> 10) > (T[b] >> 10); } };
+struct wtz_gt_hi48 { WTZ_HDM bool operator()(uint64_t a, uint64_t b) const { return (a >> 16) > (b >> 16); } };
+
+WTZ_HD bool wtz_denoise_dir_coop(const wtz_zhit_t *rs, uint32_t n_rs, uint32_t dir, wtz_dmscratch_t &S, int32_t xvar, int32_t yvar, int32_t min_linear_len,
+		uint8_t *lds, uint32_t lds_bytes, wtz_pool_t *pool, int32_t *bad){
+	const uint32_t lane = WTZ_LANE;
+	if(lds == NULL || n_rs > 65535u) return false;
+	/* ---- how many matches of this strand ---- */
+	uint32_t nf = 0;
+	for(uint32_t b0 = 0; b0 < n_rs; b0 += WTZ_NLANES){
+		const uint32_t idx = b0 + lane;
+		const bool keep = idx < n_rs && ZH_STRAND(rs[idx]) == dir;
+		uint32_t tot; (void)wtz_coop_rank(keep, &tot); nf += tot;
+	}
+	const uint32_t fixed = 2u * WTZ_DM_BCAP + 2u * WTZ_DM_GCAP + 16u;
+	if(8u * (nf + 2u) + 8u * 2u + fixed > lds_bytes) return false;
+	uint32_t *T = (uint32_t*)lds;                         /* diagonal, later off1<<10 | len1 */
+	uint16_t *ridx = (uint16_t*)(T + (nf + 2u));          /* index in rs */
+	uint16_t *gid = ridx + (nf + 2u);                     /* group id of the match */
+	{
+		uint32_t n = 0;
+		for(uint32_t b0 = 0; b0 < n_rs; b0 += WTZ_NLANES){
+			const uint32_t idx = b0 + lane;
+			bool keep = false; int32_t dg = 0;
+			if(idx < n_rs){ const wtz_zhit_t h = rs[idx]; keep = ZH_STRAND(h) == dir; dg = (int32_t)ZH_OFF1(h) - (int32_t)ZH_OFF2(h); }
+			uint32_t tot; const uint32_t pos = wtz_coop_rank(keep, &tot);
+			if(keep){ T[n + pos] = (uint32_t)dg; ridx[n + pos] = (uint16_t)idx; gid[n + pos] = 0; }
+			n += tot;
+		}
+	}
+	WTZ_WAVE_SYNC();
+	/* ---- distinct diagonals of the strand (consecutive equal offsets, hzm_aln.h:733-744) ---- */
+	uint32_t nd = 0;
+	for(uint32_t x0 = 0; x0 < nf; x0 += WTZ_NLANES){
+		const uint32_t x = x0 + lane;
+		const bool head = x < nf && (x == 0 || T[x] != T[x - 1]);
+		uint32_t tot; (void)wtz_coop_rank(head, &tot); nd += tot;
+	}
+	const uint32_t off_d = (8u * (nf + 2u) + 7u) & ~7u;
+	if(off_d + 8u * (nd + 2u) + fixed > lds_bytes) return false;
+	int32_t *Doff = (int32_t*)(lds + off_d);              /* diagonal offset */
+	uint16_t *Dfo = (uint16_t*)(Doff + (nd + 2u));        /* first match (strand-compacted position) */
+	uint16_t *Dmc = Dfo + (nd + 2u);                      /* matches the band loop takes from it */
+	uint16_t *blk = Dmc + (nd + 2u);
+	uint16_t *grp = blk + WTZ_DM_BCAP;
+	{
+		uint32_t n = 0;
+		for(uint32_t x0 = 0; x0 < nf; x0 += WTZ_NLANES){
+			const uint32_t x = x0 + lane;
+			const bool head = x < nf && (x == 0 || T[x] != T[x - 1]);
+			uint32_t tot; const uint32_t pos = wtz_coop_rank(head, &tot);
+			if(head){ Doff[n + pos] = (int32_t)T[x]; Dfo[n + pos] = (uint16_t)x; }
+			n += tot;
+		}
+		if(lane == 0){ Dfo[nd] = (uint16_t)nf; Doff[nd] = 0; if(nd == 0){ Doff[0] = 0; Dfo[0] = 0; Dmc[0] = 0; } }
+	}
+	WTZ_WAVE_SYNC();
+	/* the reference walks cnt consecutive rs entries from the diagonal's first match and keeps those of the strand
+	 * (hzm_aln.h:771-776): of the diagonal's matches, the ones whose rs index is below first + cnt */
+	for(uint32_t h0 = 0; h0 < nd; h0 += WTZ_NLANES){
+		const uint32_t h = h0 + lane;
+		if(h < nd){
+			const uint32_t fo = Dfo[h], cnt = (uint32_t)Dfo[h + 1] - fo, base = ridx[fo];
+			uint32_t m = 0; while(m < cnt && (uint32_t)ridx[fo + m] - base < cnt) m++;
+			Dmc[h] = (uint16_t)m;
+		}
+	}
+	WTZ_WAVE_SYNC();
+	for(uint32_t x0 = 0; x0 < nf; x0 += WTZ_NLANES){
+		const uint32_t x = x0 + lane;
+		if(x < nf){ const wtz_zhit_t h = rs[ridx[x]]; T[x] = (ZH_OFF1(h) << 10) | (ZH_LEN1(h) & 0x3FFu); }
+	}
+	WTZ_WAVE_SYNC();
+	/* ---- band loop on lane 0, LDS only ---- */
+	uint32_t fail = 0, ngrp = 1;
+	if(lane == 0){
+		uint32_t doff = 0, dcnt = 0; int32_t lst_offset = 0, end_offset = -0x7FFFFFFF;
+		grp[0] = 0;
+		for(;;){
+			/* wtz_band_next over Doff[] */
+			if(!(doff < n_rs)) break;
+			lst_offset = Doff[doff];
+			dcnt = 0;
+			for(;;){
+				if(Doff[dcnt + doff] > lst_offset + yvar) break;
+				if(dcnt + doff + 1 >= nd) break;
+				dcnt++;
+			}
+			if(dcnt == 0) break;
+			if(Doff[doff + dcnt] == end_offset){ doff += dcnt; continue; }
+			end_offset = Doff[doff + dcnt];
+			uint32_t nb = 0;
+			for(uint32_t i = 0; i < dcnt && !fail; i++){
+				const uint32_t fo = Dfo[i + doff], mc = Dmc[i + doff];
+				if(nb + mc > WTZ_DM_BCAP){ fail = 1; break; }
+				for(uint32_t j = 0; j < mc; j++) blk[nb++] = (uint16_t)(fo + j);
+			}
+			if(fail) break;
+			wtz_gt_blk_off1 g1; g1.T = T;
+			wtz_sort_exact(blk, (size_t)nb, g1);
+			int32_t p0_off1 = 0, p0_len1 = 0, p_off1, p_len1, len;
+			if(nb){ p0_off1 = (int32_t)(T[blk[0]] >> 10); p0_len1 = (int32_t)(T[blk[0]] & 0x3FFu); len = p0_len1; } else len = 0;
+			uint32_t j = 0;
+			for(uint32_t i = 1; i <= nb; i++){
+				if(i == nb){ p_off1 = WTZ_SEED_OFF_MAX; p_len1 = 0; }
+				else { p_off1 = (int32_t)(T[blk[i]] >> 10); p_len1 = (int32_t)(T[blk[i]] & 0x3FFu); }
+				if(p_off1 <= p0_off1 + p0_len1){
+					len += (p_off1 + p_len1) - (p0_off1 + p0_len1);
+				} else if(p_off1 <= p0_off1 + p0_len1 + xvar){
+					len += (p_off1 + p_len1) - (p0_off1 + p0_len1);
+				} else {
+					if(len >= min_linear_len){
+						uint32_t g0 = 0;
+						for(uint32_t k = j; k < i; k++){
+							const uint32_t g = gid[blk[k]];
+							if(g){ if(g0 == 0) g0 = grp[g]; else if(g0 > grp[g]) g0 = grp[g]; }
+						}
+						if(g0 == 0){ if(ngrp >= WTZ_DM_GCAP){ fail = 1; break; } g0 = ngrp; grp[ngrp++] = (uint16_t)g0; }
+						else { for(uint32_t k = j; k < i; k++){ const uint32_t g = gid[blk[k]]; if(g) grp[g] = (uint16_t)g0; } }
+						for(; j < i; j++) gid[blk[j]] = (uint16_t)g0;
+					}
+					j = i;
+					len = p0_len1;
+				}
+				p0_off1 = p_off1; p0_len1 = p_len1;
+			}
+			if(fail) break;
+			/* wtz_band_advance */
+			uint32_t a;
+			for(a = doff; a < doff + dcnt; a++) if(Doff[a] > lst_offset + yvar / 2) break;
+			doff = a;
+		}
+		if(!fail){      /* wtz_tidy_groups */
+			for(uint32_t i = 1; i < ngrp; i++){
+				if(grp[i] < i) continue;
+				for(uint32_t j = i + 1; j < ngrp; j++){
+					if(grp[j] != i) continue;
+					for(uint32_t k = j + 1; k < ngrp; k++) if(grp[k] == j) grp[k] = (uint16_t)i;
+				}
+			}
+		}
+	}
+	fail = wtz_coop_bcast32(fail);
+	if(fail) return false;
+	WTZ_WAVE_SYNC();
+	/* ---- grouped matches, ordered by (group, off1) (hzm_aln.h:848-857) ---- */
+	uint32_t n_dst = 0;
+	for(uint32_t x0 = 0; x0 < nf; x0 += WTZ_NLANES){
+		const uint32_t x = x0 + lane;
+		const bool keep = x < nf && gid[x] != 0;
+		uint32_t tot; (void)wtz_coop_rank(keep, &tot); n_dst += tot;
+	}
+	if(lane == 0) S.regs[dir].n = 0;
+	if(n_dst == 0) return true;
+	uint32_t np = 64; while(np < n_dst) np <<= 1;
+	uint64_t ka = 0;
+	if(lane == 0) ka = (uint64_t)(uintptr_t)wtz_pool_alloc(pool, (size_t)np * 8 + (size_t)(n_dst + 1) * sizeof(wtz_zhit_t));
+	ka = wtz_coop_bcast64(ka);
+	uint64_t *K = (uint64_t*)(uintptr_t)ka;
+	if(K == NULL){ *bad = 1; return true; }
+	wtz_zhit_t *dstv = (wtz_zhit_t*)(K + np);
+	for(int pass = 0; pass < 2; pass++){
+		uint32_t n = 0;
+		for(uint32_t x0 = 0; x0 < nf; x0 += WTZ_NLANES){
+			const uint32_t x = x0 + lane;
+			const bool keep = x < nf && gid[x] != 0;
+			uint32_t tot; const uint32_t pos = wtz_coop_rank(keep, &tot);
+			if(keep) K[n + pos] = ((uint64_t)grp[gid[x]] << 37) | ((uint64_t)(T[x] >> 10) << 16) | x;
+			n += tot;
+		}
+		WTZ_WAVE_SYNC();
+		if(pass == 0){
+			for(uint32_t i = n_dst + lane; i < np; i += WTZ_NLANES) K[i] = ~0ull;
+			WTZ_WAVE_SYNC();
+			wtz_coop_sort_u64(K, np);
+			bool tie = false;
+			for(uint32_t i = lane; i + 1 < n_dst; i += WTZ_NLANES) if((K[i] >> 16) == (K[i + 1] >> 16)) tie = true;
+			uint32_t any; (void)wtz_coop_rank(tie, &any);
+			if(!any) break;
+		} else {
+			if(lane == 0) wtz_sort_exact(K, (size_t)n_dst, wtz_gt_hi48());       /* equal (group, off1): the reference's swap sequence decides */
+			WTZ_WAVE_SYNC();
+		}
+	}
+	/* the strand image is dead: gather the ordered matches (with their final group id) */
+	for(uint32_t y = lane; y < n_dst; y += WTZ_NLANES){
+		wtz_zhit_t h = rs[ridx[(uint32_t)(K[y] & 0xFFFFu)]];
+		h.gid = (uint32_t)(K[y] >> 37);
+		dstv[y] = h;
+	}
+	WTZ_WAVE_SYNC();
+	const bool in_lds = (size_t)n_dst * sizeof(wtz_zhit_t) <= (size_t)lds_bytes;
+	const wtz_zhit_t *dv = dstv;
+	if(in_lds){
+		wtz_zhit_t *L = (wtz_zhit_t*)lds;
+		for(uint32_t y = lane; y < n_dst; y += WTZ_NLANES) L[y] = dstv[y];
+		WTZ_WAVE_SYNC();
+		dv = L;
+	}
+	if(lane == 0){
+		uint32_t j = 0;
+		for(uint32_t i = 1; i <= n_dst; i++){
+			if(i < n_dst && dv[i].gid == dv[j].gid) continue;
+			wtz_win_t seed;
+			seed.pb2 = 0; seed.closed = 0; seed.dir = (uint8_t)dir; seed.pad = 0;
+			seed.anchors[0] = j; seed.anchors[1] = i;
+			seed.beg[0] = seed.beg[1] = 0x7FFFFFFF; seed.end[0] = seed.end[1] = 0; seed.ovl = 0;
+			int32_t lst = 0;
+			for(uint32_t k = j; k < i; k++){
+				const wtz_zhit_t p = dv[k];
+				const int32_t o1 = (int32_t)ZH_OFF1(p), l1 = (int32_t)ZH_LEN1(p), o2 = (int32_t)ZH_OFF2(p), l2 = (int32_t)ZH_LEN2(p);
+				if(o1 < seed.beg[0]) seed.beg[0] = o1;
+				if(o1 + l1 > seed.end[0]) seed.end[0] = o1 + l1;
+				if(o2 < seed.beg[1]) seed.beg[1] = o2;
+				if(o2 + l2 > seed.end[1]) seed.end[1] = o2 + l2;
+				seed.ovl = WTZ_OVL29(seed.ovl + (uint32_t)((o1 > lst) ? l1 : o1 + l1 - lst));
+				lst = o1 + l1;
+			}
+			if(!(seed.end[0] - seed.beg[0] < min_linear_len)){ if(!S.regs[dir].push(seed)) break; }
+			j = i;
+		}
+	}
+	WTZ_WAVE_SYNC();
+	return true;
+}
+
+WTZ_HD void wtz_denoise(wtz_zhit_t *rs, uint32_t n_rs, wtz_dmscratch_t &S, int32_t xvar, int32_t yvar, int32_t min_linear_len, bool presorted){
+	if(!presorted) wtz_sort_exact(rs, (size_t)n_rs, wtz_gt_zdiag());      /* hzm_aln.h:728; done by the wavefront when tie-free */
+	for(uint32_t dir = 0; dir < 2; dir++) wtz_denoise_dir(rs, n_rs, dir, S, xvar, yvar, min_linear_len);
+}
+
 WTZ_HD void wtz_merge_blocks(wtz_vec<wtz_win_t> &rv, wtz_dmscratch_t &S, int32_t xvar, int32_t yvar){
 	wtz_win_t *regs = rv.a; const uint32_t n = rv.n;
 	uint32_t i, j, k, doff, dcnt = 0, gid;
@@ -222,11 +464,12 @@ WTZ_HD void wtz_merge_blocks(wtz_vec<wtz_win_t> &rv, wtz_dmscratch_t &S, int32_t
 
 WTZ_HD int32_t wtz_w30(int32_t v){ return (int32_t)((uint32_t)v << 2) >> 2; }     /* node_t.weight:30, hzm_aln.h:1057 */
 
-WTZ_HD int32_t wtz_chain_blocks(int32_t pblen1, int32_t pblen2, wtz_vec<wtz_win_t> &rv, wtz_pool_t *pool, int32_t tail_margin, int32_t max_overhang, float band_penalty, float gap_penalty, int32_t *bad){
+WTZ_HD int32_t wtz_chain_blocks(int32_t pblen1, int32_t pblen2, wtz_vec<wtz_win_t> &rv, wtz_pool_t *pool, int32_t tail_margin, int32_t max_overhang, float band_penalty, float gap_penalty, int32_t *bad,
+		int32_t *fast_mem = NULL, uint32_t fast_ints = 0){
 	wtz_win_t *regs = rv.a; const uint32_t n = rv.n; uint32_t i, j;
 	int32_t mw, bt, band, gap, weight, W, score;
 	wtz_sort_exact(regs, (size_t)n, wtz_gt_wbeg0());
-	int32_t *mem = (int32_t*)wtz_pool_alloc(pool, (size_t)(4 * n + 4) * 4);
+	int32_t *mem = (fast_mem && 4 * n + 4 <= fast_ints) ? fast_mem : (int32_t*)wtz_pool_alloc(pool, (size_t)(4 * n + 4) * 4);
 	if(mem == NULL){ *bad = 1; return 0; }
 	int32_t *nw = mem, *nbt = mem + n, *nhead = mem + 2 * n, *ntail = mem + 3 * n;
 	for(i = 0; i < n; i++){
@@ -261,22 +504,56 @@ WTZ_HD int32_t wtz_chain_blocks(int32_t pblen1, int32_t pblen2, wtz_vec<wtz_win_
 	return mw;
 }
 
-WTZ_HD wtz_dm_result_t wtz_dot_matrix_align(wtz_vec<wtz_zhit_t> &cache, wtz_pool_t *pool, int32_t pblen1, int32_t pblen2, const wtz_params_t *P, int32_t *bad, bool presorted, uint64_t *tick_denoise){
+/* Entered by every lane of the wavefront (lane 0 alone in the host emulation); the result is valid on lane 0.
+ * `lds`: the wave's LDS slice - the strand images of the denoise pass first, then the handful of blocks and the scratch
+ * vectors of block merging / chaining (they are chains of tiny order-sensitive sorts: latency, not bandwidth). */
+WTZ_HD wtz_dm_result_t wtz_dot_matrix_align(wtz_vec<wtz_zhit_t> &cache, wtz_pool_t *pool, int32_t pblen1, int32_t pblen2, const wtz_params_t *P, int32_t *bad, bool presorted, uint64_t *tick_denoise,
+		uint8_t *lds, uint32_t lds_bytes){
 	wtz_dm_result_t ret; int32_t weight[2]; uint32_t d;
+	memset(&ret, 0, sizeof ret);
+	const uint32_t lane = WTZ_LANE;
 	wtz_dmscratch_t S;
-	S.dst.init(pool, cache.n / 2 + 16); S.regs[0].init(pool, 16); S.regs[1].init(pool, 16);
-	S.diags.init(pool, 64); S.block.init(pool, 64); S.grps.init(pool, 16);
+	S.dst.a = NULL; S.dst.n = S.dst.cap = 0; S.dst.pool = pool; S.dst.bad = 0;
+	S.regs[0] = S.regs[1] = wtz_vec<wtz_win_t>(); S.regs[0].a = S.regs[1].a = NULL; S.regs[0].n = S.regs[0].cap = S.regs[1].n = S.regs[1].cap = 0; S.regs[0].pool = S.regs[1].pool = pool; S.regs[0].bad = S.regs[1].bad = 0;
+	S.diags.a = NULL; S.diags.n = S.diags.cap = 0; S.diags.pool = pool; S.diags.bad = 0;
+	S.block.a = NULL; S.block.n = S.block.cap = 0; S.block.pool = pool; S.block.bad = 0;
+	S.grps.a = NULL; S.grps.n = S.grps.cap = 0; S.grps.pool = pool; S.grps.bad = 0;
+	if(lane == 0){
+		S.dst.init(pool, cache.n / 2 + 16); S.regs[0].init(pool, 16); S.regs[1].init(pool, 16);
+		S.diags.init(pool, 64); S.block.init(pool, 64); S.grps.init(pool, 16);
+		if(!presorted) wtz_sort_exact(cache.a, (size_t)cache.n, wtz_gt_zdiag());      /* hzm_aln.h:728; done by the wavefront when tie-free */
+	}
+	WTZ_WAVE_SYNC();
 	/* dst of strand 0 is consumed before strand 1 reuses it: regs only keep bounds */
-	wtz_denoise(cache.a, cache.n, S, P->xvar, P->yvar, P->min_block_len, presorted);
+	for(uint32_t dir = 0; dir < 2; dir++){
+		if(!wtz_denoise_dir_coop(cache.a, cache.n, dir, S, P->xvar, P->yvar, P->min_block_len, lds, lds_bytes, pool, bad)){
+			if(lane == 0) wtz_denoise_dir(cache.a, cache.n, dir, S, P->xvar, P->yvar, P->min_block_len);
+			WTZ_WAVE_SYNC();
+		}
+	}
 #if defined(__HIP_DEVICE_COMPILE__)
 	*tick_denoise = (uint64_t)clock64();
 #else
 	*tick_denoise = 0;
 #endif
+	if(lane != 0) return ret;
+	/* blocks + scratch of the merge / chain passes into LDS when they are few (the usual case) */
+	int32_t *chain_mem = NULL; uint32_t chain_ints = 0;
+	if(lds && lds_bytes >= 12288u && S.regs[0].n <= 64u && S.regs[1].n <= 64u){
+		wtz_win_t *r0 = (wtz_win_t*)lds, *r1 = r0 + 64;
+		for(uint32_t i = 0; i < S.regs[0].n; i++) r0[i] = S.regs[0].a[i];
+		for(uint32_t i = 0; i < S.regs[1].n; i++) r1[i] = S.regs[1].a[i];
+		S.regs[0].a = r0; S.regs[0].cap = 64; S.regs[1].a = r1; S.regs[1].cap = 64;
+		uint8_t *q = (uint8_t*)(r1 + 64);
+		S.diags.a = (wtz_diag_t*)q; S.diags.n = 0; S.diags.cap = 72; q += 72 * sizeof(wtz_diag_t);
+		S.block.a = (uint32_t*)q; S.block.n = 0; S.block.cap = 128; q += 128 * 4;
+		S.grps.a = (uint32_t*)q; S.grps.n = 0; S.grps.cap = 128; q += 128 * 4;
+		chain_mem = (int32_t*)q; chain_ints = 4 * 64 + 4;
+	}
 	wtz_merge_blocks(S.regs[0], S, P->xvar, 2 * P->yvar);
 	wtz_merge_blocks(S.regs[1], S, P->xvar, 2 * P->yvar);
-	weight[0] = wtz_chain_blocks(pblen1, pblen2, S.regs[0], pool, P->xvar, P->max_overhang, P->deviation_penalty, P->gap_penalty, bad);
-	weight[1] = wtz_chain_blocks(pblen1, pblen2, S.regs[1], pool, P->xvar, P->max_overhang, P->deviation_penalty, P->gap_penalty, bad);
+	weight[0] = wtz_chain_blocks(pblen1, pblen2, S.regs[0], pool, P->xvar, P->max_overhang, P->deviation_penalty, P->gap_penalty, bad, chain_mem, chain_ints);
+	weight[1] = wtz_chain_blocks(pblen1, pblen2, S.regs[1], pool, P->xvar, P->max_overhang, P->deviation_penalty, P->gap_penalty, bad, chain_mem, chain_ints);
 	if(S.dst.bad || S.regs[0].bad || S.regs[1].bad || S.diags.bad || S.block.bad || S.grps.bad) *bad = 1;
 	d = (weight[0] < weight[1]);
 	ret.score = weight[d];

@@ -536,7 +536,7 @@ extern "C" int wtz_pairs_seed(wtz_ctx_t *c, const uint32_t *qid, const uint32_t 
 	CHK(dev_h2d(c->d_qid, qid, (size_t)n * 4)); CHK(dev_h2d(c->d_cid, cid, (size_t)n * 4));
 	const wtz_env_t V = ctx_env(c); const uint32_t *dq = c->d_qid, *dc = c->d_cid; wtz_pairres_t *dr = c->d_pairres;
 	wtz_timer tm; tm.start();
-	CHK(wtz_launch_coop<K_pair>(0, n, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_pair((uint32_t)t, V, dq, dc, dr); }, WTZ_PAIR_LDS_BYTES));
+	CHK(wtz_launch_coop<K_pair>(0, n, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_pair((uint32_t)t, V, dq, dc, dr); }, c->P.dot_matrix ? WTZ_PAIR_DM_LDS_BYTES : WTZ_PAIR_LDS_BYTES));
 	CHK(dev_sync());
 	c->cnt.ms_pairs += tm.stop(); c->cnt.n_pairs += n;
 	c->n_pairs = n; c->h_pairres.resize(n); c->have_pairs = true;

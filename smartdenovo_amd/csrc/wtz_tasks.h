@@ -22,7 +22,10 @@ typedef struct {
 #ifndef WTZ_GAP_LDS_BYTES
 #define WTZ_GAP_LDS_BYTES 12288      /* LDS slice of a gap-filling (K-sw2) wave */
 #endif
-#define WTZ_PAIR_LDS_BYTES 16384     /* K_pair: LDS slice of the small exact sorts (2048 words) */
+#define WTZ_PAIR_LDS_BYTES 16384     /* K_pair, zmo: LDS slice of the window scans */
+#ifndef WTZ_PAIR_DM_LDS_BYTES
+#define WTZ_PAIR_DM_LDS_BYTES 16384  /* K_pair, dmo: LDS slice of the strand images */
+#endif
 /* the LDS slice of the wave running the current task (wave-task kernels carry WTZ_WAVE_LDS_BYTES of dynamic LDS) */
 #if defined(__HIP_DEVICE_COMPILE__)
 WTZ_D int32_t *wtz_wave_scratch(){ extern __shared__ int32_t wtz_dyn_lds[]; return wtz_dyn_lds; }
@@ -60,11 +63,17 @@ WTZ_HD void wtz_task_pair(uint32_t t, const wtz_env_t &V, const uint32_t *qid, c
 	if(n * P->zsize < P->ztot){ r.gate = 0; if(lane == 0) res[t] = r; return; }
 	r.gate = 1;
 	if(P->dot_matrix){
-		if(lane != 0) return;
 		wtz_vec<wtz_zhit_t> cache; cache.a = sorted ? sorted : hits; cache.n = n; cache.cap = n + 2; cache.pool = V.pool; cache.bad = 0;
 		const uint64_t tk2 = WTZ_TICK();
 		uint64_t tkd = 0;
-		wtz_dm_result_t d = wtz_dot_matrix_align(cache, V.pool, (int32_t)V.R.rdlen[q], (int32_t)V.R.rdlen[c], P, &r.bad, sorted != NULL, &tkd);
+#if defined(__HIP_DEVICE_COMPILE__)
+		uint8_t *dlds = (uint8_t*)wtz_wave_scratch();
+#else
+		static thread_local uint64_t emul_dm_lds[WTZ_PAIR_DM_LDS_BYTES / 8];
+		uint8_t *dlds = (uint8_t*)emul_dm_lds;
+#endif
+		wtz_dm_result_t d = wtz_dot_matrix_align(cache, V.pool, (int32_t)V.R.rdlen[q], (int32_t)V.R.rdlen[c], P, &r.bad, sorted != NULL, &tkd, dlds, WTZ_PAIR_DM_LDS_BYTES);
+		if(lane != 0) return;
 		r.dm_score = d.score; r.dm_qb = d.qb; r.dm_qe = d.qe; r.dm_tb = d.tb; r.dm_te = d.te; r.dm_dir = d.dir;
 		{ const uint64_t tk3 = WTZ_TICK(); r.tick[0] = (uint32_t)((tk1 - tk0) >> 10); r.tick[1] = (uint32_t)((tk2 - tk1) >> 10); r.tick[2] = (uint32_t)((tkd - tk2) >> 10); r.tick[3] = (uint32_t)((tk3 - tk0) >> 10); }   /* dmo: [2] = denoise */
 		res[t] = r; return;
