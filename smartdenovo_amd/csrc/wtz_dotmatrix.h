@@ -168,10 +168,35 @@ WTZ_HD void wtz_denoise_dir(wtz_zhit_t *rs, uint32_t n_rs, uint32_t dir, wtz_dms
  * from the original order), gathered into LDS and folded into blocks.  Returns false without having changed anything
  * when the strand does not fit the LDS slice (the caller then runs wtz_denoise_dir on lane 0).
  */
-#define WTZ_DM_BCAP 512u      /* members of one diagonal band */
-#define WTZ_DM_GCAP 512u      /* linear groups of one strand */
+#define WTZ_DM_BCAP(lds_bytes) ((lds_bytes) >= 65536u ? 4096u : 512u)      /* members of one diagonal band the LDS list holds */
+#define WTZ_DM_GCAP 255u      /* linear groups of one strand (one byte per match) */
 struct wtz_gt_blk_off1 { const uint32_t *T; WTZ_HDM bool operator()(uint16_t a, uint16_t b) const { return (T[a] >> 10) > (T[b] >> 10); } };
 struct wtz_gt_hi48 { WTZ_HDM bool operator()(uint64_t a, uint64_t b) const { return (a >> 16) > (b >> 16); } };
+
+/* LDS bytes the strand image of wtz_denoise_dir_coop needs (matches and distinct diagonals of the strand counted by the wave) */
+WTZ_HD uint32_t wtz_denoise_lds_need(const wtz_zhit_t *rs, uint32_t n_rs, uint32_t dir, uint32_t lds_bytes){
+	const uint32_t lane = WTZ_LANE;
+	uint32_t nf = 0, nd = 0; int32_t last_dg = 0; uint32_t have = 0;
+	for(uint32_t b0 = 0; b0 < n_rs; b0 += WTZ_NLANES){
+		const uint32_t idx = b0 + lane;
+		bool keep = false; int32_t dg = 0;
+		if(idx < n_rs){ const wtz_zhit_t h = rs[idx]; keep = ZH_STRAND(h) == dir; dg = (int32_t)ZH_OFF1(h) - (int32_t)ZH_OFF2(h); }
+#if defined(__HIP_DEVICE_COMPILE__)
+		const unsigned long long m = __ballot(keep);
+		const unsigned long long below = m & ((1ull << lane) - 1ull);
+		const int prevl = below ? 63 - __clzll((long long)below) : -1;
+		const int32_t pdg = __shfl(dg, prevl < 0 ? 0 : prevl, 64);
+		const bool head = keep && (prevl >= 0 ? (pdg != dg) : (!have || last_dg != dg));
+		nf += (uint32_t)__popcll(m);
+		nd += (uint32_t)__popcll(__ballot(head));
+		if(m){ const int ll = 63 - __clzll((long long)m); last_dg = __shfl(dg, ll, 64); have = 1; }
+#else
+		if(keep){ nf++; if(!have || last_dg != dg) nd++; last_dg = dg; have = 1; }
+#endif
+	}
+	const uint32_t fixed = 2u * WTZ_DM_BCAP(lds_bytes) + 2u * WTZ_DM_GCAP + 32u;
+	return ((5u * (nf + 4u) + 7u) & ~7u) + 8u * (nd + 2u) + fixed;
+}
 
 WTZ_HD bool wtz_denoise_dir_coop(const wtz_zhit_t *rs, uint32_t n_rs, uint32_t dir, wtz_dmscratch_t &S, int32_t xvar, int32_t yvar, int32_t min_linear_len,
 		uint8_t *lds, uint32_t lds_bytes, wtz_pool_t *pool, int32_t *bad){
@@ -184,11 +209,19 @@ WTZ_HD bool wtz_denoise_dir_coop(const wtz_zhit_t *rs, uint32_t n_rs, uint32_t d
 		const bool keep = idx < n_rs && ZH_STRAND(rs[idx]) == dir;
 		uint32_t tot; (void)wtz_coop_rank(keep, &tot); nf += tot;
 	}
-	const uint32_t fixed = 2u * WTZ_DM_BCAP + 2u * WTZ_DM_GCAP + 16u;
-	if(8u * (nf + 2u) + 8u * 2u + fixed > lds_bytes) return false;
-	uint32_t *T = (uint32_t*)lds;                         /* diagonal, later off1<<10 | len1 */
-	uint16_t *ridx = (uint16_t*)(T + (nf + 2u));          /* index in rs */
-	uint16_t *gid = ridx + (nf + 2u);                     /* group id of the match */
+	/* LDS image: per match 4 B (diagonal, later off1<<10 | len1) + 1 B (group id); per distinct diagonal 4 B (offset) +
+	 * 2 B (first match) + 2 B (band members); the band member list and the group table.  The rs index of a match is only
+	 * needed by the parallel passes: it lives in the pool. */
+	const uint32_t bcap = WTZ_DM_BCAP(lds_bytes);
+	const uint32_t fixed = 2u * bcap + 2u * WTZ_DM_GCAP + 32u;
+	if(5u * (nf + 4u) + 8u * 2u + fixed > lds_bytes) return false;
+	uint64_t ra = 0;
+	if(lane == 0) ra = (uint64_t)(uintptr_t)wtz_pool_alloc(pool, (size_t)(nf + 2u) * 2u);
+	ra = wtz_coop_bcast64(ra);
+	uint16_t *ridx = (uint16_t*)(uintptr_t)ra;            /* index in rs (pool) */
+	if(ridx == NULL){ *bad = 1; if(lane == 0) S.regs[dir].n = 0; return true; }
+	uint32_t *T = (uint32_t*)lds;
+	uint8_t *gid = (uint8_t*)(T + (nf + 2u));             /* group id of the match */
 	{
 		uint32_t n = 0;
 		for(uint32_t b0 = 0; b0 < n_rs; b0 += WTZ_NLANES){
@@ -208,13 +241,13 @@ WTZ_HD bool wtz_denoise_dir_coop(const wtz_zhit_t *rs, uint32_t n_rs, uint32_t d
 		const bool head = x < nf && (x == 0 || T[x] != T[x - 1]);
 		uint32_t tot; (void)wtz_coop_rank(head, &tot); nd += tot;
 	}
-	const uint32_t off_d = (8u * (nf + 2u) + 7u) & ~7u;
+	const uint32_t off_d = (5u * (nf + 4u) + 7u) & ~7u;
 	if(off_d + 8u * (nd + 2u) + fixed > lds_bytes) return false;
 	int32_t *Doff = (int32_t*)(lds + off_d);              /* diagonal offset */
 	uint16_t *Dfo = (uint16_t*)(Doff + (nd + 2u));        /* first match (strand-compacted position) */
 	uint16_t *Dmc = Dfo + (nd + 2u);                      /* matches the band loop takes from it */
 	uint16_t *blk = Dmc + (nd + 2u);
-	uint16_t *grp = blk + WTZ_DM_BCAP;
+	uint16_t *grp = blk + bcap;
 	{
 		uint32_t n = 0;
 		for(uint32_t x0 = 0; x0 < nf; x0 += WTZ_NLANES){
@@ -243,14 +276,21 @@ WTZ_HD bool wtz_denoise_dir_coop(const wtz_zhit_t *rs, uint32_t n_rs, uint32_t d
 		if(x < nf){ const wtz_zhit_t h = rs[ridx[x]]; T[x] = (ZH_OFF1(h) << 10) | (ZH_LEN1(h) & 0x3FFu); }
 	}
 	WTZ_WAVE_SYNC();
-	/* ---- band loop on lane 0, LDS only ---- */
-	uint32_t fail = 0, ngrp = 1;
+	/* ---- the bands.  Their sequence (hzm_aln.h:748-769, 832-834) depends on the diagonal offsets only, so lane 0 lists
+	 * them first; whether a band can change anything - it must contain a linear run of >= min_linear_len - is then decided
+	 * for all bands in parallel (small bands exactly, by replaying the sweep in registers; larger ones are simply kept), and
+	 * only the productive bands go through the sequential group merging. ---- */
+	uint64_t ba = 0;
+	if(lane == 0) ba = (uint64_t)(uintptr_t)wtz_pool_alloc(pool, (size_t)(nd + 2u) * 8u);
+	ba = wtz_coop_bcast64(ba);
+	uint32_t *bands = (uint32_t*)(uintptr_t)ba;           /* doff<<16 | dcnt per band, then the productive subset */
+	if(bands == NULL){ *bad = 1; if(lane == 0) S.regs[dir].n = 0; return true; }
+	uint32_t *prod = bands + (nd + 2u);
+	uint32_t nbands = 0;
 	if(lane == 0){
 		uint32_t doff = 0, dcnt = 0; int32_t lst_offset = 0, end_offset = -0x7FFFFFFF;
-		grp[0] = 0;
 		for(;;){
-			/* wtz_band_next over Doff[] */
-			if(!(doff < n_rs)) break;
+			if(!(doff < n_rs)) break;                    /* wtz_band_next over Doff[] */
 			lst_offset = Doff[doff];
 			dcnt = 0;
 			for(;;){
@@ -261,15 +301,81 @@ WTZ_HD bool wtz_denoise_dir_coop(const wtz_zhit_t *rs, uint32_t n_rs, uint32_t d
 			if(dcnt == 0) break;
 			if(Doff[doff + dcnt] == end_offset){ doff += dcnt; continue; }
 			end_offset = Doff[doff + dcnt];
+			bands[nbands++] = (doff << 16) | dcnt;
+			uint32_t a;                                   /* wtz_band_advance */
+			for(a = doff; a < doff + dcnt; a++) if(Doff[a] > lst_offset + yvar / 2) break;
+			doff = a;
+		}
+	}
+	nbands = wtz_coop_bcast32(nbands);
+	WTZ_WAVE_SYNC();
+	uint32_t nprod = 0;
+	for(uint32_t b0 = 0; b0 < nbands; b0 += WTZ_NLANES){
+		const uint32_t b = b0 + lane;
+		bool keep = false;
+		if(b < nbands){
+			const uint32_t doff = bands[b] >> 16, dcnt = bands[b] & 0xFFFFu;
 			uint32_t nb = 0;
+			for(uint32_t i = 0; i < dcnt && nb <= 8u; i++) nb += Dmc[doff + i];
+			if(nb > 8u) keep = true;
+			else if(nb){
+				uint32_t v[8]; uint32_t m = 0;
+				for(uint32_t i = 0; i < dcnt; i++){ const uint32_t fo = Dfo[doff + i], mc = Dmc[doff + i]; for(uint32_t j = 0; j < mc; j++){ const uint32_t t = T[fo + j]; uint32_t q = m++; while(q && (v[q - 1] >> 10) > (t >> 10)){ v[q] = v[q - 1]; q--; } v[q] = t; } }
+				for(uint32_t i = 0; i + 1 < m; i++) if((v[i] >> 10) == (v[i + 1] >> 10)) keep = true;      /* equal off1: order-sensitive, leave it to the exact path */
+				if(!keep){
+					int32_t p0o = (int32_t)(v[0] >> 10), p0l = (int32_t)(v[0] & 0x3FFu), len = p0l;
+					for(uint32_t i = 1; i <= m; i++){
+						const int32_t po = (i == m) ? WTZ_SEED_OFF_MAX : (int32_t)(v[i] >> 10), pl = (i == m) ? 0 : (int32_t)(v[i] & 0x3FFu);
+						if(po <= p0o + p0l || po <= p0o + p0l + xvar) len += (po + pl) - (p0o + p0l);
+						else { if(len >= min_linear_len) keep = true; len = p0l; }
+						p0o = po; p0l = pl;
+					}
+				}
+			}
+		}
+		uint32_t tot; const uint32_t pos = wtz_coop_rank(keep, &tot);
+		if(keep) prod[nprod + pos] = bands[b];
+		nprod += tot;
+	}
+	WTZ_WAVE_SYNC();
+	/* ---- productive bands in order: members by off1 (wave-wide when large and tie-free), sweep + group merging on lane 0 ---- */
+	uint32_t fail = 0, ngrp = 1;
+	if(lane == 0) grp[0] = 0;
+	uint64_t *SK = NULL;                                  /* bitonic scratch of the large bands (pool) */
+	for(uint32_t pb = 0; pb < nprod && !fail; pb++){
+		const uint32_t doff = prod[pb] >> 16, dcnt = prod[pb] & 0xFFFFu;
+		uint32_t nb = 0;
+		if(lane == 0){
 			for(uint32_t i = 0; i < dcnt && !fail; i++){
 				const uint32_t fo = Dfo[i + doff], mc = Dmc[i + doff];
-				if(nb + mc > WTZ_DM_BCAP){ fail = 1; break; }
+				if(nb + mc > bcap){ fail = 1; break; }
 				for(uint32_t j = 0; j < mc; j++) blk[nb++] = (uint16_t)(fo + j);
 			}
-			if(fail) break;
-			wtz_gt_blk_off1 g1; g1.T = T;
-			wtz_sort_exact(blk, (size_t)nb, g1);
+		}
+		fail = wtz_coop_bcast32(fail); nb = wtz_coop_bcast32(nb);
+		if(fail) break;
+		WTZ_WAVE_SYNC();
+		bool sorted_by_wave = false;
+		if(nb > 48u){
+			if(SK == NULL){
+				uint64_t sa = 0;
+				if(lane == 0) sa = (uint64_t)(uintptr_t)wtz_pool_alloc(pool, (size_t)bcap * 8u);
+				SK = (uint64_t*)(uintptr_t)wtz_coop_bcast64(sa);
+			}
+			if(SK){
+				uint32_t np2 = 64; while(np2 < nb) np2 <<= 1;
+				for(uint32_t i = lane; i < np2; i += WTZ_NLANES) SK[i] = i < nb ? (((uint64_t)(T[blk[i]] >> 10) << 16) | blk[i]) : ~0ull;
+				WTZ_WAVE_SYNC();
+				wtz_coop_sort_u64(SK, np2);
+				bool tie = false;
+				for(uint32_t i = lane; i + 1 < nb; i += WTZ_NLANES) if((SK[i] >> 16) == (SK[i + 1] >> 16)) tie = true;
+				uint32_t any; (void)wtz_coop_rank(tie, &any);
+				if(!any){ for(uint32_t i = lane; i < nb; i += WTZ_NLANES) blk[i] = (uint16_t)(SK[i] & 0xFFFFu); sorted_by_wave = true; }
+				WTZ_WAVE_SYNC();
+			}
+		}
+		if(lane == 0){
+			if(!sorted_by_wave){ wtz_gt_blk_off1 g1; g1.T = T; wtz_sort_exact(blk, (size_t)nb, g1); }
 			int32_t p0_off1 = 0, p0_len1 = 0, p_off1, p_len1, len;
 			if(nb){ p0_off1 = (int32_t)(T[blk[0]] >> 10); p0_len1 = (int32_t)(T[blk[0]] & 0x3FFu); len = p0_len1; } else len = 0;
 			uint32_t j = 0;
@@ -289,26 +395,23 @@ WTZ_HD bool wtz_denoise_dir_coop(const wtz_zhit_t *rs, uint32_t n_rs, uint32_t d
 						}
 						if(g0 == 0){ if(ngrp >= WTZ_DM_GCAP){ fail = 1; break; } g0 = ngrp; grp[ngrp++] = (uint16_t)g0; }
 						else { for(uint32_t k = j; k < i; k++){ const uint32_t g = gid[blk[k]]; if(g) grp[g] = (uint16_t)g0; } }
-						for(; j < i; j++) gid[blk[j]] = (uint16_t)g0;
+						for(; j < i; j++) gid[blk[j]] = (uint8_t)g0;
 					}
 					j = i;
 					len = p0_len1;
 				}
 				p0_off1 = p_off1; p0_len1 = p_len1;
 			}
-			if(fail) break;
-			/* wtz_band_advance */
-			uint32_t a;
-			for(a = doff; a < doff + dcnt; a++) if(Doff[a] > lst_offset + yvar / 2) break;
-			doff = a;
 		}
-		if(!fail){      /* wtz_tidy_groups */
-			for(uint32_t i = 1; i < ngrp; i++){
-				if(grp[i] < i) continue;
-				for(uint32_t j = i + 1; j < ngrp; j++){
-					if(grp[j] != i) continue;
-					for(uint32_t k = j + 1; k < ngrp; k++) if(grp[k] == j) grp[k] = (uint16_t)i;
-				}
+		fail = wtz_coop_bcast32(fail);
+		WTZ_WAVE_SYNC();
+	}
+	if(lane == 0 && !fail){      /* wtz_tidy_groups */
+		for(uint32_t i = 1; i < ngrp; i++){
+			if(grp[i] < i) continue;
+			for(uint32_t j = i + 1; j < ngrp; j++){
+				if(grp[j] != i) continue;
+				for(uint32_t k = j + 1; k < ngrp; k++) if(grp[k] == j) grp[k] = (uint16_t)i;
 			}
 		}
 	}
@@ -508,10 +611,14 @@ WTZ_HD int32_t wtz_chain_blocks(int32_t pblen1, int32_t pblen2, wtz_vec<wtz_win_
  * `lds`: the wave's LDS slice - the strand images of the denoise pass first, then the handful of blocks and the scratch
  * vectors of block merging / chaining (they are chains of tiny order-sensitive sorts: latency, not bandwidth). */
 WTZ_HD wtz_dm_result_t wtz_dot_matrix_align(wtz_vec<wtz_zhit_t> &cache, wtz_pool_t *pool, int32_t pblen1, int32_t pblen2, const wtz_params_t *P, int32_t *bad, bool presorted, uint64_t *tick_denoise,
-		uint8_t *lds, uint32_t lds_bytes){
+		uint8_t *lds, uint32_t lds_bytes, bool defer_if_large){
 	wtz_dm_result_t ret; int32_t weight[2]; uint32_t d;
 	memset(&ret, 0, sizeof ret);
 	const uint32_t lane = WTZ_LANE;
+	if(defer_if_large && presorted && cache.n <= 65535u){      /* a later launch with a larger LDS slice takes the pair */
+		const uint32_t need0 = wtz_denoise_lds_need(cache.a, cache.n, 0, lds_bytes), need1 = wtz_denoise_lds_need(cache.a, cache.n, 1, lds_bytes);
+		if((need0 > need1 ? need0 : need1) > lds_bytes){ ret.dir = -2; ret.score = (int32_t)(need0 > need1 ? need0 : need1); return ret; }
+	}
 	wtz_dmscratch_t S;
 	S.dst.a = NULL; S.dst.n = S.dst.cap = 0; S.dst.pool = pool; S.dst.bad = 0;
 	S.regs[0] = S.regs[1] = wtz_vec<wtz_win_t>(); S.regs[0].a = S.regs[1].a = NULL; S.regs[0].n = S.regs[0].cap = S.regs[1].n = S.regs[1].cap = 0; S.regs[0].pool = S.regs[1].pool = pool; S.regs[0].bad = S.regs[1].bad = 0;
@@ -526,10 +633,14 @@ WTZ_HD wtz_dm_result_t wtz_dot_matrix_align(wtz_vec<wtz_zhit_t> &cache, wtz_pool
 	WTZ_WAVE_SYNC();
 	/* dst of strand 0 is consumed before strand 1 reuses it: regs only keep bounds */
 	for(uint32_t dir = 0; dir < 2; dir++){
+		const unsigned long long ptd = WTZ_PROF_T();
 		if(!wtz_denoise_dir_coop(cache.a, cache.n, dir, S, P->xvar, P->yvar, P->min_block_len, lds, lds_bytes, pool, bad)){
+			if(defer_if_large && presorted && cache.n <= 65535u){ ret.dir = -2; ret.score = 0; return ret; }      /* band / group table overflow: retry with the larger slice */
+			const unsigned long long ptf = WTZ_PROF_T();
 			if(lane == 0) wtz_denoise_dir(cache.a, cache.n, dir, S, P->xvar, P->yvar, P->min_block_len);
 			WTZ_WAVE_SYNC();
-		}
+			WTZ_PROF_ADD(3, ptf); WTZ_PROF_CNT(1, 1); WTZ_PROF_CNT(5, cache.n);
+		} else { WTZ_PROF_ADD(2, ptd); WTZ_PROF_CNT(0, 1); WTZ_PROF_CNT(4, cache.n); }
 	}
 #if defined(__HIP_DEVICE_COMPILE__)
 	*tick_denoise = (uint64_t)clock64();
@@ -550,10 +661,12 @@ WTZ_HD wtz_dm_result_t wtz_dot_matrix_align(wtz_vec<wtz_zhit_t> &cache, wtz_pool
 		S.grps.a = (uint32_t*)q; S.grps.n = 0; S.grps.cap = 128; q += 128 * 4;
 		chain_mem = (int32_t*)q; chain_ints = 4 * 64 + 4;
 	}
+	const unsigned long long ptm = WTZ_PROF_T();
 	wtz_merge_blocks(S.regs[0], S, P->xvar, 2 * P->yvar);
 	wtz_merge_blocks(S.regs[1], S, P->xvar, 2 * P->yvar);
 	weight[0] = wtz_chain_blocks(pblen1, pblen2, S.regs[0], pool, P->xvar, P->max_overhang, P->deviation_penalty, P->gap_penalty, bad, chain_mem, chain_ints);
 	weight[1] = wtz_chain_blocks(pblen1, pblen2, S.regs[1], pool, P->xvar, P->max_overhang, P->deviation_penalty, P->gap_penalty, bad, chain_mem, chain_ints);
+	WTZ_PROF_ADD(6, ptm);
 	if(S.dst.bad || S.regs[0].bad || S.regs[1].bad || S.diags.bad || S.block.bad || S.grps.bad) *bad = 1;
 	d = (weight[0] < weight[1]);
 	ret.score = weight[d];

@@ -30,6 +30,12 @@ static int wtz_fail(int code, const char *fmt, ...){
 	return code;
 }
 
+#ifndef WTZ_PAIR_DM_LDS_TIER2
+#define WTZ_PAIR_DM_LDS_TIER2 65536u
+#endif
+#ifndef WTZ_PAIR_DM_LDS_TIER3
+#define WTZ_PAIR_DM_LDS_TIER3 (160u * 1024u - 512u)
+#endif
 /* kernel name tags (rocprofv3 shows wtz_kernel_*<K_pair, ...>) */
 struct K_candidates;
 struct K_extjob_scalar;
@@ -43,6 +49,7 @@ struct K_kstats;
 struct K_pack_cigars;
 struct K_pack_windows;
 struct K_pair;
+struct K_pair_big;
 struct K_stitch_fin;
 struct K_stitch_left;
 struct K_stitch_mid;
@@ -110,6 +117,7 @@ template<typename TAG, typename F> __global__ void __launch_bounds__(64) __attri
 template<typename TAG, typename F> static int wtz_launch_coop(hipStream_t st, uint64_t n, F f, uint32_t lds_bytes = WTZ_WAVE_LDS_BYTES){
 	if(n == 0) return WTZ_OK;
 	if(n > 0x7FFFFFFFull) return wtz_fail(WTZ_E_ARG, "grid too large");
+	if(lds_bytes > 65536u){ HIPCHK(hipFuncSetAttribute((const void*)&wtz_kernel_coop_tasks<TAG, F>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)); }      /* opt in to more than 64 KB of dynamic LDS */
 	(void)st; hipLaunchKernelGGL((wtz_kernel_coop_tasks<TAG, F>), dim3((uint32_t)n), dim3(64), lds_bytes, g_stream, n, f);
 	HIPCHK(hipGetLastError());
 	return WTZ_OK;
@@ -538,9 +546,26 @@ extern "C" int wtz_pairs_seed(wtz_ctx_t *c, const uint32_t *qid, const uint32_t 
 	wtz_timer tm; tm.start();
 	CHK(wtz_launch_coop<K_pair>(0, n, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_pair((uint32_t)t, V, dq, dc, dr); }, c->P.dot_matrix ? WTZ_PAIR_DM_LDS_BYTES : WTZ_PAIR_LDS_BYTES));
 	CHK(dev_sync());
-	c->cnt.ms_pairs += tm.stop(); c->cnt.n_pairs += n;
 	c->n_pairs = n; c->h_pairres.resize(n); c->have_pairs = true;
 	CHK(dev_d2h(c->h_pairres.data(), c->d_pairres, (size_t)n * sizeof(wtz_pairres_t)));
+	if(c->P.dot_matrix){
+		/* pairs whose strand images exceed the LDS slice of K_pair are finished by launches with larger slices: few pairs,
+		 * but they are the long ones that would otherwise bound the batch from a single lane */
+		const uint32_t tiers[2] = { WTZ_PAIR_DM_LDS_TIER2, WTZ_PAIR_DM_LDS_TIER3 };
+		for(int tier = 0; tier < 2; tier++){
+			std::vector<uint32_t> list;
+			for(uint32_t i = 0; i < n; i++) if(c->h_pairres[i].gate && c->h_pairres[i].dm_dir == -2 && !c->h_pairres[i].bad) list.push_back(i);
+			if(list.empty()) break;
+			uint32_t *d_list = NULL; CHK(dev_alloc((void**)&d_list, list.size() * 4)); CHK(dev_h2d(d_list, list.data(), list.size() * 4));
+			const uint32_t lb = tiers[tier]; const bool last = (tier == 1);
+			CHK(wtz_launch_coop<K_pair_big>(0, list.size(), [=] WTZ_LAMBDA (uint64_t t){ wtz_task_pair_dm_big((uint32_t)t, V, d_list, dq, dc, dr, lb, last); }, lb));
+			CHK(dev_sync());
+			dev_free(d_list);
+			CHK(dev_d2h(c->h_pairres.data(), c->d_pairres, (size_t)n * sizeof(wtz_pairres_t)));
+			if(getenv("WTZ_PROFILE_PAIR")) fprintf(stderr, "[pair-profile] dmo tier %d (%u KB LDS): %zu pairs\n", tier + 2, lb >> 10, list.size());
+		}
+	}
+	c->cnt.ms_pairs += tm.stop(); c->cnt.n_pairs += n;
 	CHK(pool_check(c, "wtz_pairs_seed"));
 	if(getenv("WTZ_PROFILE_PAIR")){
 		uint64_t sum[4] = {0, 0, 0, 0}; uint32_t mx[4] = {0, 0, 0, 0}, arg = 0;

@@ -72,8 +72,9 @@ WTZ_HD void wtz_task_pair(uint32_t t, const wtz_env_t &V, const uint32_t *qid, c
 		static thread_local uint64_t emul_dm_lds[WTZ_PAIR_DM_LDS_BYTES / 8];
 		uint8_t *dlds = (uint8_t*)emul_dm_lds;
 #endif
-		wtz_dm_result_t d = wtz_dot_matrix_align(cache, V.pool, (int32_t)V.R.rdlen[q], (int32_t)V.R.rdlen[c], P, &r.bad, sorted != NULL, &tkd, dlds, WTZ_PAIR_DM_LDS_BYTES);
+		wtz_dm_result_t d = wtz_dot_matrix_align(cache, V.pool, (int32_t)V.R.rdlen[q], (int32_t)V.R.rdlen[c], P, &r.bad, sorted != NULL, &tkd, dlds, WTZ_PAIR_DM_LDS_BYTES, true);
 		if(lane != 0) return;
+		if(d.dir == -2){ r.anchors[0] = cache.a; r.nanchors[0] = cache.n; }       /* deferred: the ordered matches stay in the pool for wtz_task_pair_dm_big */
 		r.dm_score = d.score; r.dm_qb = d.qb; r.dm_qe = d.qe; r.dm_tb = d.tb; r.dm_te = d.te; r.dm_dir = d.dir;
 		{ const uint64_t tk3 = WTZ_TICK(); r.tick[0] = (uint32_t)((tk1 - tk0) >> 10); r.tick[1] = (uint32_t)((tk2 - tk1) >> 10); r.tick[2] = (uint32_t)((tkd - tk2) >> 10); r.tick[3] = (uint32_t)((tk3 - tk0) >> 10); }   /* dmo: [2] = denoise */
 		res[t] = r; return;
@@ -120,6 +121,26 @@ WTZ_HD void wtz_task_pair(uint32_t t, const wtz_env_t &V, const uint32_t *qid, c
 	if(lane != 0) return;
 	{ const uint64_t tk3 = WTZ_TICK(); r.tick[0] = (uint32_t)((tk1 - tk0) >> 10); r.tick[1] = (uint32_t)((tk2 - tk1) >> 10); r.tick[2] = (uint32_t)((tk3 - tk2) >> 10); r.tick[3] = (uint32_t)((tk3 - tk0) >> 10); }
 	res[t] = r;
+}
+
+/* dmo pairs whose strand images did not fit the LDS slice of K_pair: same alignment over the already ordered matches, launched
+ * with a larger slice (`lds_bytes`); `last` = no larger launch follows, so nothing is deferred again */
+WTZ_HD void wtz_task_pair_dm_big(uint32_t t, const wtz_env_t &V, const uint32_t *list, const uint32_t *qid, const uint32_t *cid, wtz_pairres_t *res, uint32_t lds_bytes, bool last){
+	const wtz_params_t *P = V.P;
+	const uint32_t pi = list[t], q = qid[pi], c = cid[pi];
+	wtz_pairres_t r = res[pi];
+	wtz_vec<wtz_zhit_t> cache; cache.a = r.anchors[0]; cache.n = r.nanchors[0]; cache.cap = cache.n + 2; cache.pool = V.pool; cache.bad = 0;
+	uint64_t tkd = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+	uint8_t *dlds = (uint8_t*)wtz_wave_scratch();
+	wtz_dm_result_t d = wtz_dot_matrix_align(cache, V.pool, (int32_t)V.R.rdlen[q], (int32_t)V.R.rdlen[c], P, &r.bad, true, &tkd, dlds, lds_bytes, !last);
+#else
+	(void)lds_bytes; (void)last;
+	wtz_dm_result_t d = wtz_dot_matrix_align(cache, V.pool, (int32_t)V.R.rdlen[q], (int32_t)V.R.rdlen[c], P, &r.bad, true, &tkd, (uint8_t*)NULL, 0, false);
+#endif
+	if(WTZ_LANE != 0) return;
+	r.dm_score = d.score; r.dm_qb = d.qb; r.dm_qe = d.qe; r.dm_tb = d.tb; r.dm_te = d.te; r.dm_dir = d.dir;
+	res[pi] = r;
 }
 
 /* ---------------- alignment ---------------- */
