@@ -129,6 +129,11 @@ WTZ_D uint32_t wtz_coop_rank(bool keep, uint32_t *total){
 	*total = (uint32_t)__popcll(m);
 	return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
 }
+/* minimum over all lanes, uniform */
+WTZ_D uint32_t wtz_coop_min32(uint32_t v){
+	for(int d = 32; d > 0; d >>= 1){ const uint32_t y = (uint32_t)__shfl_xor((int)v, d, 64); v = y < v ? y : v; }
+	return v;
+}
 /* value of lane `l` (l uniform) */
 WTZ_D uint32_t wtz_coop_lane32(uint32_t v, uint32_t l){ return (uint32_t)__builtin_amdgcn_readlane((int)v, __builtin_amdgcn_readfirstlane((int)l)); }
 #define WTZ_WAVE_SYNC() __threadfence_block()
@@ -140,6 +145,7 @@ static inline uint64_t wtz_coop_bcast64(uint64_t v){ return v; }
 static inline uint32_t wtz_coop_bcast32(uint32_t v){ return v; }
 static inline uint32_t wtz_coop_rank(bool keep, uint32_t *total){ *total = keep ? 1u : 0u; return 0; }
 static inline uint32_t wtz_coop_lane32(uint32_t v, uint32_t){ return v; }
+static inline uint32_t wtz_coop_min32(uint32_t v){ return v; }
 #define WTZ_WAVE_SYNC() do {} while(0)
 #endif
 

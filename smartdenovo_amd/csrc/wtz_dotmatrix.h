@@ -168,7 +168,7 @@ WTZ_HD void wtz_denoise_dir(wtz_zhit_t *rs, uint32_t n_rs, uint32_t dir, wtz_dms
  * from the original order), gathered into LDS and folded into blocks.  Returns false without having changed anything
  * when the strand does not fit the LDS slice (the caller then runs wtz_denoise_dir on lane 0).
  */
-#define WTZ_DM_BCAP(lds_bytes) ((lds_bytes) >= 65536u ? 4096u : 512u)      /* members of one diagonal band the LDS list holds */
+#define WTZ_DM_BCAP(lds_bytes) ((lds_bytes) >= 65536u ? 2048u : ((lds_bytes) >= 24576u ? 1024u : 512u))      /* members of one diagonal band the LDS list holds */
 #define WTZ_DM_GCAP 255u      /* linear groups of one strand (one byte per match) */
 struct wtz_gt_blk_off1 { const uint32_t *T; WTZ_HDM bool operator()(uint16_t a, uint16_t b) const { return (T[a] >> 10) > (T[b] >> 10); } };
 struct wtz_gt_hi48 { WTZ_HDM bool operator()(uint64_t a, uint64_t b) const { return (a >> 16) > (b >> 16); } };
@@ -194,7 +194,7 @@ WTZ_HD uint32_t wtz_denoise_lds_need(const wtz_zhit_t *rs, uint32_t n_rs, uint32
 		if(keep){ nf++; if(!have || last_dg != dg) nd++; last_dg = dg; have = 1; }
 #endif
 	}
-	const uint32_t fixed = 2u * WTZ_DM_BCAP(lds_bytes) + 2u * WTZ_DM_GCAP + 32u;
+	const uint32_t fixed = 8u * WTZ_DM_BCAP(lds_bytes) + 2u * WTZ_DM_GCAP + 40u;
 	return ((5u * (nf + 4u) + 7u) & ~7u) + 8u * (nd + 2u) + fixed;
 }
 
@@ -213,7 +213,7 @@ WTZ_HD bool wtz_denoise_dir_coop(const wtz_zhit_t *rs, uint32_t n_rs, uint32_t d
 	 * 2 B (first match) + 2 B (band members); the band member list and the group table.  The rs index of a match is only
 	 * needed by the parallel passes: it lives in the pool. */
 	const uint32_t bcap = WTZ_DM_BCAP(lds_bytes);
-	const uint32_t fixed = 2u * bcap + 2u * WTZ_DM_GCAP + 32u;
+	const uint32_t fixed = 8u * bcap + 2u * WTZ_DM_GCAP + 40u;
 	if(5u * (nf + 4u) + 8u * 2u + fixed > lds_bytes) return false;
 	uint64_t ra = 0;
 	if(lane == 0) ra = (uint64_t)(uintptr_t)wtz_pool_alloc(pool, (size_t)(nf + 2u) * 2u);
@@ -246,8 +246,10 @@ WTZ_HD bool wtz_denoise_dir_coop(const wtz_zhit_t *rs, uint32_t n_rs, uint32_t d
 	int32_t *Doff = (int32_t*)(lds + off_d);              /* diagonal offset */
 	uint16_t *Dfo = (uint16_t*)(Doff + (nd + 2u));        /* first match (strand-compacted position) */
 	uint16_t *Dmc = Dfo + (nd + 2u);                      /* matches the band loop takes from it */
-	uint16_t *blk = Dmc + (nd + 2u);
-	uint16_t *grp = blk + bcap;
+	uint32_t *bk = (uint32_t*)(((uintptr_t)(Dmc + (nd + 2u)) + 3u) & ~(uintptr_t)3u);      /* band keys; later run heads */
+	uint16_t *blk = (uint16_t*)(bk + bcap);               /* band members, diagonal order */
+	uint16_t *sblk = blk + bcap;                           /* band members, off1 order */
+	uint16_t *grp = sblk + bcap;
 	{
 		uint32_t n = 0;
 		for(uint32_t x0 = 0; x0 < nf; x0 += WTZ_NLANES){
@@ -338,74 +340,108 @@ WTZ_HD bool wtz_denoise_dir_coop(const wtz_zhit_t *rs, uint32_t n_rs, uint32_t d
 		nprod += tot;
 	}
 	WTZ_WAVE_SYNC();
-	/* ---- productive bands in order: members by off1 (wave-wide when large and tie-free), sweep + group merging on lane 0 ---- */
+	/* ---- productive bands in order, each on the whole wave:
+	 *   members (diagonal order) -> bk[] = off1<<11 | position in the band, bitonic in LDS -> members by off1; an equal off1
+	 *   makes lane 0 run the swap-exact sort instead (hzm_aln.h:777);
+	 *   run breaks are local (a member starts a run iff it lies more than xvar beyond the previous member's end), and the
+	 *   length the reference accumulates for run [j,i) telescopes to len1(j-1) + end(i-1) - end(j) (len1(0) for the first
+	 *   run: hzm_aln.h:780-828 resets `len` to the PREVIOUS match's length) - so all runs of the band are measured at once;
+	 *   only the runs of >= min_linear_len matches' worth go through the sequential group merging, each as a wave-wide
+	 *   min-reduction + scatter. ---- */
 	uint32_t fail = 0, ngrp = 1;
 	if(lane == 0) grp[0] = 0;
-	uint64_t *SK = NULL;                                  /* bitonic scratch of the large bands (pool) */
+	WTZ_WAVE_SYNC();
 	for(uint32_t pb = 0; pb < nprod && !fail; pb++){
 		const uint32_t doff = prod[pb] >> 16, dcnt = prod[pb] & 0xFFFFu;
+		/* members in diagonal order */
 		uint32_t nb = 0;
-		if(lane == 0){
-			for(uint32_t i = 0; i < dcnt && !fail; i++){
-				const uint32_t fo = Dfo[i + doff], mc = Dmc[i + doff];
-				if(nb + mc > bcap){ fail = 1; break; }
-				for(uint32_t j = 0; j < mc; j++) blk[nb++] = (uint16_t)(fo + j);
-			}
+		for(uint32_t d0 = 0; d0 < dcnt; d0 += WTZ_NLANES){
+			const uint32_t dd = d0 + lane;
+			uint32_t fo = 0, mc = 0;
+			if(dd < dcnt){ fo = Dfo[doff + dd]; mc = Dmc[doff + dd]; }
+			uint32_t tot; const uint32_t ex = wtz_coop_excl_scan(mc, &tot);
+			if(nb + tot <= bcap){ for(uint32_t j = 0; j < mc; j++) blk[nb + ex + j] = (uint16_t)(fo + j); }
+			nb += tot;
 		}
-		fail = wtz_coop_bcast32(fail); nb = wtz_coop_bcast32(nb);
-		if(fail) break;
+		if(nb > bcap){ fail = 1; break; }
 		WTZ_WAVE_SYNC();
-		bool sorted_by_wave = false;
-		if(nb > 48u){
-			if(SK == NULL){
-				uint64_t sa = 0;
-				if(lane == 0) sa = (uint64_t)(uintptr_t)wtz_pool_alloc(pool, (size_t)bcap * 8u);
-				SK = (uint64_t*)(uintptr_t)wtz_coop_bcast64(sa);
-			}
-			if(SK){
-				uint32_t np2 = 64; while(np2 < nb) np2 <<= 1;
-				for(uint32_t i = lane; i < np2; i += WTZ_NLANES) SK[i] = i < nb ? (((uint64_t)(T[blk[i]] >> 10) << 16) | blk[i]) : ~0ull;
+		uint32_t np2 = 64; while(np2 < nb) np2 <<= 1;
+		for(uint32_t i = lane; i < np2; i += WTZ_NLANES) bk[i] = i < nb ? (((T[blk[i]] >> 10) << 11) | i) : 0xFFFFFFFFu;
+		WTZ_WAVE_SYNC();
+		wtz_coop_sort_u32(bk, np2);
+		{
+			bool tie = false;
+			for(uint32_t i = lane; i + 1 < nb; i += WTZ_NLANES) if((bk[i] >> 11) == (bk[i + 1] >> 11)) tie = true;
+			uint32_t any; (void)wtz_coop_rank(tie, &any);
+			if(any){
+				if(lane == 0){ wtz_gt_blk_off1 g1; g1.T = T; wtz_sort_exact(blk, (size_t)nb, g1); }
 				WTZ_WAVE_SYNC();
-				wtz_coop_sort_u64(SK, np2);
-				bool tie = false;
-				for(uint32_t i = lane; i + 1 < nb; i += WTZ_NLANES) if((SK[i] >> 16) == (SK[i + 1] >> 16)) tie = true;
-				uint32_t any; (void)wtz_coop_rank(tie, &any);
-				if(!any){ for(uint32_t i = lane; i < nb; i += WTZ_NLANES) blk[i] = (uint16_t)(SK[i] & 0xFFFFu); sorted_by_wave = true; }
-				WTZ_WAVE_SYNC();
+				for(uint32_t i = lane; i < nb; i += WTZ_NLANES) sblk[i] = blk[i];
+			} else {
+				for(uint32_t i = lane; i < nb; i += WTZ_NLANES) sblk[i] = blk[bk[i] & 0x7FFu];
 			}
 		}
-		if(lane == 0){
-			if(!sorted_by_wave){ wtz_gt_blk_off1 g1; g1.T = T; wtz_sort_exact(blk, (size_t)nb, g1); }
-			int32_t p0_off1 = 0, p0_len1 = 0, p_off1, p_len1, len;
-			if(nb){ p0_off1 = (int32_t)(T[blk[0]] >> 10); p0_len1 = (int32_t)(T[blk[0]] & 0x3FFu); len = p0_len1; } else len = 0;
-			uint32_t j = 0;
-			for(uint32_t i = 1; i <= nb; i++){
-				if(i == nb){ p_off1 = WTZ_SEED_OFF_MAX; p_len1 = 0; }
-				else { p_off1 = (int32_t)(T[blk[i]] >> 10); p_len1 = (int32_t)(T[blk[i]] & 0x3FFu); }
-				if(p_off1 <= p0_off1 + p0_len1){
-					len += (p_off1 + p_len1) - (p0_off1 + p0_len1);
-				} else if(p_off1 <= p0_off1 + p0_len1 + xvar){
-					len += (p_off1 + p_len1) - (p0_off1 + p0_len1);
-				} else {
-					if(len >= min_linear_len){
-						uint32_t g0 = 0;
-						for(uint32_t k = j; k < i; k++){
-							const uint32_t g = gid[blk[k]];
-							if(g){ if(g0 == 0) g0 = grp[g]; else if(g0 > grp[g]) g0 = grp[g]; }
-						}
-						if(g0 == 0){ if(ngrp >= WTZ_DM_GCAP){ fail = 1; break; } g0 = ngrp; grp[ngrp++] = (uint16_t)g0; }
-						else { for(uint32_t k = j; k < i; k++){ const uint32_t g = gid[blk[k]]; if(g) grp[g] = (uint16_t)g0; } }
-						for(; j < i; j++) gid[blk[j]] = (uint8_t)g0;
-					}
-					j = i;
-					len = p0_len1;
+		WTZ_WAVE_SYNC();
+		/* run heads: position 0 and every break; heads[] reuses the key words */
+		uint16_t *heads = (uint16_t*)bk;
+		uint32_t nrun = 0;
+		for(uint32_t i0 = 0; i0 < nb; i0 += WTZ_NLANES){
+			const uint32_t i = i0 + lane;
+			bool head = false;
+			if(i < nb){
+				if(i == 0) head = true;
+				else {
+					const uint32_t tp = T[sblk[i - 1]], tc = T[sblk[i]];
+					const int32_t pe = (int32_t)(tp >> 10) + (int32_t)(tp & 0x3FFu), o = (int32_t)(tc >> 10);
+					head = !(o <= pe || o <= pe + xvar);
 				}
-				p0_off1 = p_off1; p0_len1 = p_len1;
 			}
+			uint32_t tot; const uint32_t pos = wtz_coop_rank(head, &tot);
+			/* heads[] aliases bk[]: everything read from bk is already in sblk */
+			if(head) heads[nrun + pos] = (uint16_t)i;
+			nrun += tot;
 		}
-		fail = wtz_coop_bcast32(fail);
 		WTZ_WAVE_SYNC();
+		if(lane == 0) heads[nrun] = (uint16_t)nb;
+		WTZ_WAVE_SYNC();
+		/* productive runs, in order */
+		uint16_t *pruns = heads + (nrun + 2u);
+		uint32_t npr = 0;
+		for(uint32_t r0 = 0; r0 < nrun; r0 += WTZ_NLANES){
+			const uint32_t r = r0 + lane;
+			bool keep = false;
+			if(r < nrun){
+				const uint32_t j = heads[r], i = heads[r + 1];
+				const uint32_t tj = T[sblk[j]], tl = T[sblk[i - 1]];
+				const int32_t l0 = (int32_t)(T[sblk[j ? j - 1 : 0]] & 0x3FFu);
+				const int32_t len = l0 + ((int32_t)(tl >> 10) + (int32_t)(tl & 0x3FFu)) - ((int32_t)(tj >> 10) + (int32_t)(tj & 0x3FFu));
+				keep = len >= min_linear_len;
+			}
+			uint32_t tot; const uint32_t pos = wtz_coop_rank(keep, &tot);
+			if(keep) pruns[npr + pos] = (uint16_t)r;
+			npr += tot;
+		}
+		WTZ_WAVE_SYNC();
+		for(uint32_t q = 0; q < npr && !fail; q++){
+			const uint32_t r = pruns[q], j = heads[r], i = heads[r + 1];
+			uint32_t gmin = 0xFFFFFFFFu;
+			for(uint32_t k = j + lane; k < i; k += WTZ_NLANES){ const uint32_t g = gid[sblk[k]]; if(g){ const uint32_t v = grp[g]; gmin = v < gmin ? v : gmin; } }
+			gmin = wtz_coop_min32(gmin);
+			uint32_t g0;
+			if(gmin == 0xFFFFFFFFu){
+				if(ngrp >= WTZ_DM_GCAP){ fail = 1; break; }
+				g0 = ngrp; if(lane == 0) grp[ngrp] = (uint16_t)g0; ngrp++;
+			} else {
+				g0 = gmin;
+				WTZ_WAVE_SYNC();
+				for(uint32_t k = j + lane; k < i; k += WTZ_NLANES){ const uint32_t g = gid[sblk[k]]; if(g) grp[g] = (uint16_t)g0; }
+			}
+			WTZ_WAVE_SYNC();
+			for(uint32_t k = j + lane; k < i; k += WTZ_NLANES) gid[sblk[k]] = (uint8_t)g0;
+			WTZ_WAVE_SYNC();
+		}
 	}
+	fail = wtz_coop_bcast32(fail);
 	if(lane == 0 && !fail){      /* wtz_tidy_groups */
 		for(uint32_t i = 1; i < ngrp; i++){
 			if(grp[i] < i) continue;

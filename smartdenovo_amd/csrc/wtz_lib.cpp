@@ -544,8 +544,10 @@ extern "C" int wtz_pairs_seed(wtz_ctx_t *c, const uint32_t *qid, const uint32_t 
 	CHK(dev_h2d(c->d_qid, qid, (size_t)n * 4)); CHK(dev_h2d(c->d_cid, cid, (size_t)n * 4));
 	const wtz_env_t V = ctx_env(c); const uint32_t *dq = c->d_qid, *dc = c->d_cid; wtz_pairres_t *dr = c->d_pairres;
 	wtz_timer tm; tm.start();
+	wtz_timer t1; t1.start();
 	CHK(wtz_launch_coop<K_pair>(0, n, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_pair((uint32_t)t, V, dq, dc, dr); }, c->P.dot_matrix ? WTZ_PAIR_DM_LDS_BYTES : WTZ_PAIR_LDS_BYTES));
 	CHK(dev_sync());
+	{ const double ms1 = t1.stop(); if(getenv("WTZ_PROFILE_PAIR")) fprintf(stderr, "[pair-profile] K_pair first launch: %u pairs, %.1f ms\n", n, ms1); }
 	c->n_pairs = n; c->h_pairres.resize(n); c->have_pairs = true;
 	CHK(dev_d2h(c->h_pairres.data(), c->d_pairres, (size_t)n * sizeof(wtz_pairres_t)));
 	if(c->P.dot_matrix){
@@ -558,11 +560,13 @@ extern "C" int wtz_pairs_seed(wtz_ctx_t *c, const uint32_t *qid, const uint32_t 
 			if(list.empty()) break;
 			uint32_t *d_list = NULL; CHK(dev_alloc((void**)&d_list, list.size() * 4)); CHK(dev_h2d(d_list, list.data(), list.size() * 4));
 			const uint32_t lb = tiers[tier]; const bool last = (tier == 1);
+			wtz_timer tt; tt.start();
 			CHK(wtz_launch_coop<K_pair_big>(0, list.size(), [=] WTZ_LAMBDA (uint64_t t){ wtz_task_pair_dm_big((uint32_t)t, V, d_list, dq, dc, dr, lb, last); }, lb));
 			CHK(dev_sync());
+			const double ms_t = tt.stop();
 			dev_free(d_list);
 			CHK(dev_d2h(c->h_pairres.data(), c->d_pairres, (size_t)n * sizeof(wtz_pairres_t)));
-			if(getenv("WTZ_PROFILE_PAIR")) fprintf(stderr, "[pair-profile] dmo tier %d (%u KB LDS): %zu pairs\n", tier + 2, lb >> 10, list.size());
+			if(getenv("WTZ_PROFILE_PAIR")) fprintf(stderr, "[pair-profile] dmo tier %d (%u KB LDS): %zu pairs, %.1f ms\n", tier + 2, lb >> 10, list.size(), ms_t);
 		}
 	}
 	c->cnt.ms_pairs += tm.stop(); c->cnt.n_pairs += n;

@@ -316,6 +316,36 @@ WTZ_HD void wtz_coop_sort_u64(uint64_t *w, uint32_t np){
 #endif
 }
 
+/* the same network over 32-bit words (LDS-resident band keys of the dot-matrix engine) */
+WTZ_HD void wtz_coop_sort_u32(uint32_t *w, uint32_t np){
+#if defined(__HIP_DEVICE_COMPILE__)
+	const uint32_t lane = WTZ_LANE;
+	__threadfence_block();
+	for(uint32_t k = 2; k <= np; k <<= 1){
+		for(uint32_t j = k >> 1; j > 0; j >>= 1){
+			for(uint32_t t0 = 0; t0 < np / 2; t0 += 256){
+				uint32_t a[4], b[4], ia[4];
+				#pragma unroll
+				for(int u = 0; u < 4; u++){
+					const uint32_t t = t0 + u * 64 + lane;
+					const uint32_t i = ((t / j) * (j << 1)) + (t % j);
+					ia[u] = i;
+					if(t < np / 2){ a[u] = w[i]; b[u] = w[i + j]; } else { a[u] = 0; b[u] = 0; }
+				}
+				#pragma unroll
+				for(int u = 0; u < 4; u++){
+					const uint32_t t = t0 + u * 64 + lane;
+					if(t < np / 2){ const bool asc = ((ia[u] & k) == 0); if((a[u] > b[u]) == asc){ w[ia[u]] = b[u]; w[ia[u] + j] = a[u]; } }
+				}
+			}
+			__threadfence_block();
+		}
+	}
+#else
+	for(uint32_t i = 1; i < np; i++){ uint32_t v = w[i], q = i; while(q && w[q - 1] > v){ w[q] = w[q - 1]; q--; } w[q] = v; }
+#endif
+}
+
 struct wtz_kq_f { uint64_t *mer; uint32_t *qoff, *qlen; uint32_t n;
 	WTZ_HDM void operator()(uint64_t m, uint32_t, uint32_t qo, uint32_t qe){ uint32_t l = qe - qo; if(l > 0xFFFFu) l = 0xFFFFu; mer[n] = m; qoff[n] = qo; qlen[n] = l; n++; } };
 

@@ -24,7 +24,7 @@ typedef struct {
 #endif
 #define WTZ_PAIR_LDS_BYTES 16384     /* K_pair, zmo: LDS slice of the window scans */
 #ifndef WTZ_PAIR_DM_LDS_BYTES
-#define WTZ_PAIR_DM_LDS_BYTES 16384  /* K_pair, dmo: LDS slice of the strand images */
+#define WTZ_PAIR_DM_LDS_BYTES 24576  /* K_pair, dmo: LDS slice of the strand images */
 #endif
 /* the LDS slice of the wave running the current task (wave-task kernels carry WTZ_WAVE_LDS_BYTES of dynamic LDS) */
 #if defined(__HIP_DEVICE_COMPILE__)
