@@ -173,48 +173,59 @@ WTZ_HD void wtz_denoise_dir(wtz_zhit_t *rs, uint32_t n_rs, uint32_t dir, wtz_dms
 struct wtz_gt_blk_off1 { const uint32_t *T; WTZ_HDM bool operator()(uint16_t a, uint16_t b) const { return (T[a] >> 10) > (T[b] >> 10); } };
 struct wtz_gt_hi48 { WTZ_HDM bool operator()(uint64_t a, uint64_t b) const { return (a >> 16) > (b >> 16); } };
 
-/* LDS bytes the strand image of wtz_denoise_dir_coop needs (matches and distinct diagonals of the strand counted by the wave) */
-WTZ_HD uint32_t wtz_denoise_lds_need(const wtz_zhit_t *rs, uint32_t n_rs, uint32_t dir, uint32_t lds_bytes){
+/* matches (nf) and distinct diagonals (nd) of both strands of the diagonal-ordered match list, in one pass of the wave:
+ * a match opens a new diagonal iff the previous match OF ITS STRAND has another offset (hzm_aln.h:733-744) */
+typedef struct { uint32_t nf[2], nd[2]; } wtz_dm_counts_t;
+WTZ_HD wtz_dm_counts_t wtz_dm_counts(const wtz_zhit_t *rs, uint32_t n_rs){
+	wtz_dm_counts_t c; c.nf[0] = c.nf[1] = c.nd[0] = c.nd[1] = 0;
 	const uint32_t lane = WTZ_LANE;
-	uint32_t nf = 0, nd = 0; int32_t last_dg = 0; uint32_t have = 0;
-	for(uint32_t b0 = 0; b0 < n_rs; b0 += WTZ_NLANES){
-		const uint32_t idx = b0 + lane;
-		bool keep = false; int32_t dg = 0;
-		if(idx < n_rs){ const wtz_zhit_t h = rs[idx]; keep = ZH_STRAND(h) == dir; dg = (int32_t)ZH_OFF1(h) - (int32_t)ZH_OFF2(h); }
+	int32_t last_dg[2] = {0, 0}; uint32_t have[2] = {0, 0};
+	for(uint32_t b0 = 0; b0 < n_rs; b0 += 4 * WTZ_NLANES){
+		wtz_zhit_t hh[4];
+		#pragma unroll
+		for(int u = 0; u < 4; u++){ const uint32_t idx = b0 + u * WTZ_NLANES + lane; if(idx < n_rs) hh[u] = rs[idx]; else { hh[u].o1 = hh[u].o2 = hh[u].ll = hh[u].gid = 0; } }
+		#pragma unroll
+		for(int u = 0; u < 4; u++){
+			const uint32_t idx = b0 + u * WTZ_NLANES + lane;
+			const bool in = idx < n_rs;
+			const uint32_t st = ZH_STRAND(hh[u]);
+			const int32_t dg = (int32_t)ZH_OFF1(hh[u]) - (int32_t)ZH_OFF2(hh[u]);
+			#pragma unroll
+			for(uint32_t dir = 0; dir < 2; dir++){
+				const bool keep = in && st == dir;
 #if defined(__HIP_DEVICE_COMPILE__)
-		const unsigned long long m = __ballot(keep);
-		const unsigned long long below = m & ((1ull << lane) - 1ull);
-		const int prevl = below ? 63 - __clzll((long long)below) : -1;
-		const int32_t pdg = __shfl(dg, prevl < 0 ? 0 : prevl, 64);
-		const bool head = keep && (prevl >= 0 ? (pdg != dg) : (!have || last_dg != dg));
-		nf += (uint32_t)__popcll(m);
-		nd += (uint32_t)__popcll(__ballot(head));
-		if(m){ const int ll = 63 - __clzll((long long)m); last_dg = __shfl(dg, ll, 64); have = 1; }
+				const unsigned long long m = __ballot(keep);
+				if(m == 0) continue;
+				const unsigned long long below = m & ((1ull << lane) - 1ull);
+				const int prevl = below ? 63 - __clzll((long long)below) : -1;
+				const int32_t pdg = __shfl(dg, prevl < 0 ? 0 : prevl, 64);
+				const bool head = keep && (prevl >= 0 ? (pdg != dg) : (!have[dir] || last_dg[dir] != dg));
+				c.nf[dir] += (uint32_t)__popcll(m);
+				c.nd[dir] += (uint32_t)__popcll(__ballot(head));
+				last_dg[dir] = __shfl(dg, 63 - __clzll((long long)m), 64); have[dir] = 1;
 #else
-		if(keep){ nf++; if(!have || last_dg != dg) nd++; last_dg = dg; have = 1; }
+				if(keep){ c.nf[dir]++; if(!have[dir] || last_dg[dir] != dg) c.nd[dir]++; last_dg[dir] = dg; have[dir] = 1; }
 #endif
+			}
+		}
 	}
+	return c;
+}
+/* LDS bytes of the strand image of wtz_denoise_dir_coop */
+WTZ_HD uint32_t wtz_denoise_lds_need(uint32_t nf, uint32_t nd, uint32_t lds_bytes){
 	const uint32_t fixed = 8u * WTZ_DM_BCAP(lds_bytes) + 2u * WTZ_DM_GCAP + 40u;
 	return ((5u * (nf + 4u) + 7u) & ~7u) + 8u * (nd + 2u) + fixed;
 }
 
-WTZ_HD bool wtz_denoise_dir_coop(const wtz_zhit_t *rs, uint32_t n_rs, uint32_t dir, wtz_dmscratch_t &S, int32_t xvar, int32_t yvar, int32_t min_linear_len,
+WTZ_HD bool wtz_denoise_dir_coop(const wtz_zhit_t *rs, uint32_t n_rs, uint32_t dir, uint32_t nf, uint32_t nd, wtz_dmscratch_t &S, int32_t xvar, int32_t yvar, int32_t min_linear_len,
 		uint8_t *lds, uint32_t lds_bytes, wtz_pool_t *pool, int32_t *bad){
 	const uint32_t lane = WTZ_LANE;
 	if(lds == NULL || n_rs > 65535u) return false;
-	/* ---- how many matches of this strand ---- */
-	uint32_t nf = 0;
-	for(uint32_t b0 = 0; b0 < n_rs; b0 += WTZ_NLANES){
-		const uint32_t idx = b0 + lane;
-		const bool keep = idx < n_rs && ZH_STRAND(rs[idx]) == dir;
-		uint32_t tot; (void)wtz_coop_rank(keep, &tot); nf += tot;
-	}
-	/* LDS image: per match 4 B (diagonal, later off1<<10 | len1) + 1 B (group id); per distinct diagonal 4 B (offset) +
-	 * 2 B (first match) + 2 B (band members); the band member list and the group table.  The rs index of a match is only
-	 * needed by the parallel passes: it lives in the pool. */
+	/* LDS image: per match 4 B (off1<<10 | len1) + 1 B (group id); per distinct diagonal 4 B (offset) + 2 B (first match) +
+	 * 2 B (band members); band keys / member lists and the group table.  The rs index of a match is only needed by the
+	 * parallel passes: it lives in the pool. */
 	const uint32_t bcap = WTZ_DM_BCAP(lds_bytes);
-	const uint32_t fixed = 8u * bcap + 2u * WTZ_DM_GCAP + 40u;
-	if(5u * (nf + 4u) + 8u * 2u + fixed > lds_bytes) return false;
+	if(wtz_denoise_lds_need(nf, nd, lds_bytes) > lds_bytes) return false;
 	uint64_t ra = 0;
 	if(lane == 0) ra = (uint64_t)(uintptr_t)wtz_pool_alloc(pool, (size_t)(nf + 2u) * 2u);
 	ra = wtz_coop_bcast64(ra);
@@ -222,27 +233,7 @@ WTZ_HD bool wtz_denoise_dir_coop(const wtz_zhit_t *rs, uint32_t n_rs, uint32_t d
 	if(ridx == NULL){ *bad = 1; if(lane == 0) S.regs[dir].n = 0; return true; }
 	uint32_t *T = (uint32_t*)lds;
 	uint8_t *gid = (uint8_t*)(T + (nf + 2u));             /* group id of the match */
-	{
-		uint32_t n = 0;
-		for(uint32_t b0 = 0; b0 < n_rs; b0 += WTZ_NLANES){
-			const uint32_t idx = b0 + lane;
-			bool keep = false; int32_t dg = 0;
-			if(idx < n_rs){ const wtz_zhit_t h = rs[idx]; keep = ZH_STRAND(h) == dir; dg = (int32_t)ZH_OFF1(h) - (int32_t)ZH_OFF2(h); }
-			uint32_t tot; const uint32_t pos = wtz_coop_rank(keep, &tot);
-			if(keep){ T[n + pos] = (uint32_t)dg; ridx[n + pos] = (uint16_t)idx; gid[n + pos] = 0; }
-			n += tot;
-		}
-	}
-	WTZ_WAVE_SYNC();
-	/* ---- distinct diagonals of the strand (consecutive equal offsets, hzm_aln.h:733-744) ---- */
-	uint32_t nd = 0;
-	for(uint32_t x0 = 0; x0 < nf; x0 += WTZ_NLANES){
-		const uint32_t x = x0 + lane;
-		const bool head = x < nf && (x == 0 || T[x] != T[x - 1]);
-		uint32_t tot; (void)wtz_coop_rank(head, &tot); nd += tot;
-	}
 	const uint32_t off_d = (5u * (nf + 4u) + 7u) & ~7u;
-	if(off_d + 8u * (nd + 2u) + fixed > lds_bytes) return false;
 	int32_t *Doff = (int32_t*)(lds + off_d);              /* diagonal offset */
 	uint16_t *Dfo = (uint16_t*)(Doff + (nd + 2u));        /* first match (strand-compacted position) */
 	uint16_t *Dmc = Dfo + (nd + 2u);                      /* matches the band loop takes from it */
@@ -250,14 +241,38 @@ WTZ_HD bool wtz_denoise_dir_coop(const wtz_zhit_t *rs, uint32_t n_rs, uint32_t d
 	uint16_t *blk = (uint16_t*)(bk + bcap);               /* band members, diagonal order */
 	uint16_t *sblk = blk + bcap;                           /* band members, off1 order */
 	uint16_t *grp = sblk + bcap;
-	{
-		uint32_t n = 0;
-		for(uint32_t x0 = 0; x0 < nf; x0 += WTZ_NLANES){
-			const uint32_t x = x0 + lane;
-			const bool head = x < nf && (x == 0 || T[x] != T[x - 1]);
-			uint32_t tot; const uint32_t pos = wtz_coop_rank(head, &tot);
-			if(head){ Doff[n + pos] = (int32_t)T[x]; Dfo[n + pos] = (uint16_t)x; }
-			n += tot;
+	{   /* one pass: matches of the strand compacted in order, diagonal heads (hzm_aln.h:733-744) ranked in order */
+		uint32_t n = 0, h = 0; int32_t last_dg = 0; uint32_t have = 0;
+		for(uint32_t b0 = 0; b0 < n_rs; b0 += 4 * WTZ_NLANES){
+			wtz_zhit_t hh[4];
+			#pragma unroll
+			for(int u = 0; u < 4; u++){ const uint32_t idx = b0 + u * WTZ_NLANES + lane; if(idx < n_rs) hh[u] = rs[idx]; else { hh[u].o1 = hh[u].o2 = hh[u].ll = hh[u].gid = 0; } }
+			#pragma unroll
+			for(int u = 0; u < 4; u++){
+				const uint32_t idx = b0 + u * WTZ_NLANES + lane;
+				const bool keep = idx < n_rs && ZH_STRAND(hh[u]) == dir;
+				const int32_t dg = (int32_t)ZH_OFF1(hh[u]) - (int32_t)ZH_OFF2(hh[u]);
+				uint32_t tot; const uint32_t pos = wtz_coop_rank(keep, &tot);
+				if(tot == 0) continue;
+				bool head;
+#if defined(__HIP_DEVICE_COMPILE__)
+				{
+					const unsigned long long m = __ballot(keep);
+					const unsigned long long below = m & ((1ull << lane) - 1ull);
+					const int prevl = below ? 63 - __clzll((long long)below) : -1;
+					const int32_t pdg = __shfl(dg, prevl < 0 ? 0 : prevl, 64);
+					head = keep && (prevl >= 0 ? (pdg != dg) : (!have || last_dg != dg));
+					last_dg = __shfl(dg, 63 - __clzll((long long)m), 64); have = 1;
+				}
+#else
+				head = keep && (!have || last_dg != dg);
+				if(keep){ last_dg = dg; have = 1; }
+#endif
+				uint32_t htot; const uint32_t hpos = wtz_coop_rank(head, &htot);
+				if(keep){ T[n + pos] = (ZH_OFF1(hh[u]) << 10) | (ZH_LEN1(hh[u]) & 0x3FFu); gid[n + pos] = 0; ridx[n + pos] = (uint16_t)idx; }
+				if(head){ Doff[h + hpos] = dg; Dfo[h + hpos] = (uint16_t)(n + pos); }
+				n += tot; h += htot;
+			}
 		}
 		if(lane == 0){ Dfo[nd] = (uint16_t)nf; Doff[nd] = 0; if(nd == 0){ Doff[0] = 0; Dfo[0] = 0; Dmc[0] = 0; } }
 	}
@@ -267,15 +282,14 @@ WTZ_HD bool wtz_denoise_dir_coop(const wtz_zhit_t *rs, uint32_t n_rs, uint32_t d
 	for(uint32_t h0 = 0; h0 < nd; h0 += WTZ_NLANES){
 		const uint32_t h = h0 + lane;
 		if(h < nd){
-			const uint32_t fo = Dfo[h], cnt = (uint32_t)Dfo[h + 1] - fo, base = ridx[fo];
-			uint32_t m = 0; while(m < cnt && (uint32_t)ridx[fo + m] - base < cnt) m++;
+			const uint32_t fo = Dfo[h], cnt = (uint32_t)Dfo[h + 1] - fo;
+			uint32_t m = cnt;
+			if(cnt > 1u){
+				const uint32_t base = ridx[fo];
+				if((uint32_t)ridx[fo + cnt - 1u] - base >= cnt){ m = 0; while(m < cnt && (uint32_t)ridx[fo + m] - base < cnt) m++; }      /* other-strand matches in between */
+			}
 			Dmc[h] = (uint16_t)m;
 		}
-	}
-	WTZ_WAVE_SYNC();
-	for(uint32_t x0 = 0; x0 < nf; x0 += WTZ_NLANES){
-		const uint32_t x = x0 + lane;
-		if(x < nf){ const wtz_zhit_t h = rs[ridx[x]]; T[x] = (ZH_OFF1(h) << 10) | (ZH_LEN1(h) & 0x3FFu); }
 	}
 	WTZ_WAVE_SYNC();
 	/* ---- the bands.  Their sequence (hzm_aln.h:748-769, 832-834) depends on the diagonal offsets only, so lane 0 lists
@@ -651,9 +665,16 @@ WTZ_HD wtz_dm_result_t wtz_dot_matrix_align(wtz_vec<wtz_zhit_t> &cache, wtz_pool
 	wtz_dm_result_t ret; int32_t weight[2]; uint32_t d;
 	memset(&ret, 0, sizeof ret);
 	const uint32_t lane = WTZ_LANE;
-	if(defer_if_large && presorted && cache.n <= 65535u){      /* a later launch with a larger LDS slice takes the pair */
-		const uint32_t need0 = wtz_denoise_lds_need(cache.a, cache.n, 0, lds_bytes), need1 = wtz_denoise_lds_need(cache.a, cache.n, 1, lds_bytes);
-		if((need0 > need1 ? need0 : need1) > lds_bytes){ ret.dir = -2; ret.score = (int32_t)(need0 > need1 ? need0 : need1); return ret; }
+	if(!presorted){      /* hzm_aln.h:728 on lane 0 (the wave-wide order had an observable tie and no LDS room to replay it) */
+		if(lane == 0) wtz_sort_exact(cache.a, (size_t)cache.n, wtz_gt_zdiag());
+		WTZ_WAVE_SYNC();
+		presorted = true;
+	}
+	wtz_dm_counts_t cnts; cnts.nf[0] = cnts.nf[1] = cnts.nd[0] = cnts.nd[1] = 0;
+	if(cache.n <= 65535u && lds){
+		cnts = wtz_dm_counts(cache.a, cache.n);
+		const uint32_t need0 = wtz_denoise_lds_need(cnts.nf[0], cnts.nd[0], lds_bytes), need1 = wtz_denoise_lds_need(cnts.nf[1], cnts.nd[1], lds_bytes);
+		if(defer_if_large && (need0 > need1 ? need0 : need1) > lds_bytes){ ret.dir = -2; ret.score = (int32_t)(need0 > need1 ? need0 : need1); return ret; }      /* a later launch with a larger LDS slice takes the pair */
 	}
 	wtz_dmscratch_t S;
 	S.dst.a = NULL; S.dst.n = S.dst.cap = 0; S.dst.pool = pool; S.dst.bad = 0;
@@ -664,14 +685,13 @@ WTZ_HD wtz_dm_result_t wtz_dot_matrix_align(wtz_vec<wtz_zhit_t> &cache, wtz_pool
 	if(lane == 0){
 		S.dst.init(pool, cache.n / 2 + 16); S.regs[0].init(pool, 16); S.regs[1].init(pool, 16);
 		S.diags.init(pool, 64); S.block.init(pool, 64); S.grps.init(pool, 16);
-		if(!presorted) wtz_sort_exact(cache.a, (size_t)cache.n, wtz_gt_zdiag());      /* hzm_aln.h:728; done by the wavefront when tie-free */
 	}
 	WTZ_WAVE_SYNC();
 	/* dst of strand 0 is consumed before strand 1 reuses it: regs only keep bounds */
 	for(uint32_t dir = 0; dir < 2; dir++){
 		const unsigned long long ptd = WTZ_PROF_T();
-		if(!wtz_denoise_dir_coop(cache.a, cache.n, dir, S, P->xvar, P->yvar, P->min_block_len, lds, lds_bytes, pool, bad)){
-			if(defer_if_large && presorted && cache.n <= 65535u){ ret.dir = -2; ret.score = 0; return ret; }      /* band / group table overflow: retry with the larger slice */
+		if(!(cache.n <= 65535u && lds && wtz_denoise_dir_coop(cache.a, cache.n, dir, cnts.nf[dir], cnts.nd[dir], S, P->xvar, P->yvar, P->min_block_len, lds, lds_bytes, pool, bad))){
+			if(defer_if_large && cache.n <= 65535u && lds){ ret.dir = -2; ret.score = 0; return ret; }      /* band / group table overflow: retry with the larger slice */
 			const unsigned long long ptf = WTZ_PROF_T();
 			if(lane == 0) wtz_denoise_dir(cache.a, cache.n, dir, S, P->xvar, P->yvar, P->min_block_len);
 			WTZ_WAVE_SYNC();

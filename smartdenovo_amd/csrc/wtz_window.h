@@ -128,6 +128,7 @@ struct wtz_gt_idx_off2 { const wtz_zhit_t *rs; WTZ_HDM bool operator()(uint32_t 
  * no ties means the ascending order is unique and equals the reference's; any tie makes the caller run the swap-exact
  * sequential sort instead.  Returns the sorted copy (with the two zeroed sentinels) or NULL (tie / too large / pool).
  */
+template<int SH> struct wtz_gt_keybits { WTZ_HDM bool operator()(uint64_t a, uint64_t b) const { return (a >> SH) > (b >> SH); } };
 template<int BYDIAG>
 WTZ_D wtz_zhit_t *wtz_sort_hits_wave(const wtz_zhit_t *hits, uint32_t n, wtz_pool_t *pool, uint64_t *lds, uint32_t lds_u64, int *pool_bad){
 	const uint32_t lane = WTZ_LANE;
@@ -186,7 +187,21 @@ WTZ_D wtz_zhit_t *wtz_sort_hits_wave(const wtz_zhit_t *hits, uint32_t n, wtz_poo
 		else { const wtz_zhit_t &a = hits[(uint32_t)(w[i] & 0xFFFFu)], &b = hits[(uint32_t)(w[i + 1] & 0xFFFFu)]; if(ZH_LEN1(a) != ZH_LEN1(b) || ZH_STRAND(a) == ZH_STRAND(b) || (i + 2 < n && (w[i] >> SH) == (w[i + 2] >> SH))) tie = 1; }
 	}
 	uint32_t any; (void)wtz_coop_excl_scan(tie, &any);
-	if(any) return NULL;
+	if(any){
+		/* an observable tie: the reference's swap sequence decides.  When the key words sit in LDS, lane 0 replays it there
+		 * on (key | index) words from the ORIGINAL order - the comparator looks at the key bits only, so the swaps are those of
+		 * sorting the matches themselves - instead of chasing 16-byte records through HBM */
+		if(w != lds) return NULL;
+		for(uint32_t i = lane; i < n; i += 64){
+			uint64_t v;
+			if(BYDIAG) v = ((uint64_t)((int64_t)ZH_OFF1(hits[i]) - (int64_t)ZH_OFF2(hits[i]) + (1 << 24)) << 39) | ((uint64_t)ZH_OFF1(hits[i]) << 15) | i;
+			else       v = ((uint64_t)ZH_OFF1(hits[i]) << 40) | ((uint64_t)ZH_OFF2(hits[i]) << 16) | i;
+			w[i] = v;
+		}
+		__threadfence_block();
+		if(lane == 0){ if(BYDIAG) wtz_sort_exact(w, (size_t)n, wtz_gt_keybits<15>()); else wtz_sort_exact(w, (size_t)n, wtz_gt_keybits<16>()); }
+		__threadfence_block();
+	}
 	uint64_t oa = 0;
 	if(lane == 0) oa = (uint64_t)(uintptr_t)wtz_pool_alloc(pool, (size_t)(n + 2) * sizeof(wtz_zhit_t));
 	oa = wtz_coop_bcast64(oa);
