@@ -412,17 +412,26 @@ extern "C" int wtz_index_build(wtz_ctx_t *c, uint32_t id_beg, uint32_t id_end, u
 	free_kindex(c);
 	wtz_timer tm; tm.start();
 	const wtz_reads_t R = ctx_reads(c); const uint32_t ksize = c->P.ksize, hk = c->P.hk, ksave = c->P.ksave;
-	uint64_t *d_cnt = NULL; CHK(dev_alloc((void**)&d_cnt, ((size_t)nr + 1) * 8));
-	CHK(wtz_launch<K_kcount>(0, nr, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_kcount((uint32_t)t, R, id_beg, ksize, hk, ksave, d_cnt); }));
-	std::vector<uint64_t> h_cnt((size_t)nr + 1);
-	CHK(dev_d2h(h_cnt.data(), d_cnt, (size_t)nr * 8));
-	uint64_t tot = 0; for(uint32_t i = 0; i < nr; i++){ uint64_t v = h_cnt[i]; h_cnt[i] = tot; tot += v; } h_cnt[nr] = tot;
-	CHK(dev_h2d(d_cnt, h_cnt.data(), ((size_t)nr + 1) * 8));
+	/* the walk of a read is a serial recurrence, but it restarts exactly anywhere (wtz_walk_warm_start): one lane per
+	 * WTZ_WALK_CHUNK-base piece instead of one per read, pieces listed in read order */
+	std::vector<uint32_t> p_rid, p_jb;
+	for(uint32_t r = id_beg; r < id_end; r++) for(uint32_t jb = 0; jb == 0 || jb < c->h_rdlen[r]; jb += WTZ_WALK_CHUNK){ p_rid.push_back(r); p_jb.push_back(jb); }
+	const size_t np = p_rid.size();
+	uint32_t *d_prid = NULL, *d_pjb = NULL;
+	CHK(dev_alloc((void**)&d_prid, (np + 1) * 4)); CHK(dev_alloc((void**)&d_pjb, (np + 1) * 4));
+	CHK(dev_h2d(d_prid, p_rid.data(), np * 4)); CHK(dev_h2d(d_pjb, p_jb.data(), np * 4));
+	uint64_t *d_cnt = NULL; CHK(dev_alloc((void**)&d_cnt, (np + 1) * 8));
+	CHK(wtz_launch<K_kcount>(0, np, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_kcount((uint32_t)t, R, d_prid, d_pjb, ksize, hk, ksave, d_cnt); }));
+	std::vector<uint64_t> h_cnt(np + 1);
+	CHK(dev_d2h(h_cnt.data(), d_cnt, np * 8));
+	uint64_t tot = 0; for(size_t i = 0; i < np; i++){ uint64_t v = h_cnt[i]; h_cnt[i] = tot; tot += v; } h_cnt[np] = tot;
+	CHK(dev_h2d(d_cnt, h_cnt.data(), (np + 1) * 8));
 	uint64_t *d_keys = NULL; uint32_t *d_vals = NULL;
 	CHK(dev_alloc((void**)&d_keys, (tot + 1) * 8)); CHK(dev_alloc_persist((void**)&d_vals, (tot + 1) * 4));
-	CHK(wtz_launch<K_kfill>(0, nr, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_kfill((uint32_t)t, R, id_beg, ksize, hk, ksave, d_cnt, d_keys, d_vals); }));
+	CHK(wtz_launch<K_kfill>(0, np, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_kfill((uint32_t)t, R, d_prid, d_pjb, ksize, hk, ksave, d_cnt, d_keys, d_vals); }));
 	CHK(dev_sync());
-	dev_free(d_cnt);
+	dev_free(d_cnt); dev_free(d_prid); dev_free(d_pjb);
+	(void)nr;
 	CHK(dev_sort_pairs_u64_u32(d_keys, d_vals, tot, 2 * ksize));
 	unsigned long long *d_stat = NULL; CHK(dev_alloc((void**)&d_stat, 4 * 8)); CHK(dev_set(d_stat, 0, 4 * 8));
 	CHK(wtz_launch<K_kstats>(0, tot, [=] WTZ_LAMBDA (uint64_t i){ wtz_task_kstats(i, d_keys, tot, d_stat + 0, d_stat + 1); }));
@@ -463,10 +472,18 @@ extern "C" int wtz_zindex_build(wtz_ctx_t *c){
 	const wtz_reads_t R = ctx_reads(c); const uint32_t nr = c->n_reads, zsize = c->P.zsize, hz = c->P.hz, zcut = c->P.max_zmer_freq;
 	CHK(dev_alloc_persist((void**)&c->zoff, ((size_t)nr + 1) * 8));
 	uint64_t *d_off = c->zoff;
-	CHK(wtz_launch<K_zcount>(0, nr, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_zcount((uint32_t)t, R, zsize, hz, d_off); }));
-	std::vector<uint64_t> h((size_t)nr + 1);
-	CHK(dev_d2h(h.data(), d_off, (size_t)nr * 8));
-	uint64_t tot = 0; for(uint32_t i = 0; i < nr; i++){ uint64_t v = h[i]; h[i] = tot; tot += v; } h[nr] = tot;
+	std::vector<uint32_t> p_rid, p_jb; std::vector<size_t> first_piece((size_t)nr + 1);
+	for(uint32_t r = 0; r < nr; r++){ first_piece[r] = p_rid.size(); for(uint32_t jb = 0; jb == 0 || jb < c->h_rdlen[r]; jb += WTZ_WALK_CHUNK){ p_rid.push_back(r); p_jb.push_back(jb); } }
+	const size_t np = p_rid.size(); first_piece[nr] = np;
+	uint32_t *d_prid = NULL, *d_pjb = NULL; uint64_t *d_poff = NULL;
+	CHK(dev_alloc((void**)&d_prid, (np + 1) * 4)); CHK(dev_alloc((void**)&d_pjb, (np + 1) * 4)); CHK(dev_alloc((void**)&d_poff, (np + 1) * 8));
+	CHK(dev_h2d(d_prid, p_rid.data(), np * 4)); CHK(dev_h2d(d_pjb, p_jb.data(), np * 4));
+	CHK(wtz_launch<K_zcount>(0, np, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_zcount((uint32_t)t, R, d_prid, d_pjb, zsize, hz, d_poff); }));
+	std::vector<uint64_t> hp(np + 1), h((size_t)nr + 1);
+	CHK(dev_d2h(hp.data(), d_poff, np * 8));
+	uint64_t tot = 0; for(size_t i = 0; i < np; i++){ uint64_t v = hp[i]; hp[i] = tot; tot += v; } hp[np] = tot;
+	for(uint32_t r = 0; r <= nr; r++) h[r] = hp[first_piece[r]];
+	CHK(dev_h2d(d_poff, hp.data(), (np + 1) * 8));
 	CHK(dev_h2d(d_off, h.data(), ((size_t)nr + 1) * 8));
 	c->n_z = tot;
 	wtz_zindex_t Z; memset(&Z, 0, sizeof Z); Z.zoff = c->zoff;
@@ -478,7 +495,7 @@ extern "C" int wtz_zindex_build(wtz_ctx_t *c){
 	{
 		uint64_t *d_key = NULL; uint32_t *d_flag = NULL, *d_cnt = NULL, *d_dpos = NULL; uint32_t *d_val = Z.sidx;
 		CHK(dev_alloc((void**)&d_key, (tot + 1) * 8));
-		CHK(wtz_launch<K_zfill>(0, nr, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_zfill((uint32_t)t, R, zsize, hz, Z, d_key, d_val); }));
+		CHK(wtz_launch<K_zfill>(0, np, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_zfill((uint32_t)t, R, d_prid, d_pjb, d_poff, zsize, hz, Z, d_key, d_val); }));
 		unsigned rbits = 1; while((1ull << rbits) < (uint64_t)nr + 1) rbits++;
 		CHK(dev_sort_pairs_u64_u32(d_key, d_val, tot, 32 + rbits));          /* stable: positions ascend inside a (read, mer) run */
 		CHK(dev_alloc((void**)&d_flag, (tot + 2) * 4)); CHK(dev_alloc((void**)&d_cnt, (tot + 2) * 4)); CHK(dev_alloc((void**)&d_dpos, (tot + 2) * 4));
@@ -490,6 +507,7 @@ extern "C" int wtz_zindex_build(wtz_ctx_t *c){
 		CHK(dev_sync());
 		dev_free(d_key); dev_free(d_flag); dev_free(d_cnt); dev_free(d_dpos);
 	}
+	dev_free(d_prid); dev_free(d_pjb); dev_free(d_poff);
 	c->have_z = true;
 	c->cnt.ms_zindex += tm.stop();
 	return WTZ_OK;

@@ -31,16 +31,33 @@ typedef struct {
 } wtz_reads_t;
 
 /* ---- shared hp-compressed k-mer walk. F(mer, dir, qoff, qend) is called for every sampled k-mer ---- */
+/* A walk can be cut into independent pieces: the k-mer reported at position j (the first base of its last homopolymer run)
+ * depends on the previous `nruns` runs only, so a piece that reports positions [jb, je) starts `nruns` run starts before jb
+ * with a cold state and simply does not report until it reaches jb. */
+#define WTZ_WALK_CHUNK 1024u
+WTZ_HD uint32_t wtz_walk_warm_start(const wtz_reads_t &R, uint32_t rid, uint32_t hp, uint32_t nruns, uint32_t jb){
+	if(jb == 0) return 0;
+	const uint64_t off = R.rdoff[rid];
+	uint32_t j = jb, cnt = 0;
+	while(j > 0){
+		j--;
+		const bool run_start = (j == 0) || !hp || wtz_base_at(R.bits, off + j) != wtz_base_at(R.bits, off + j - 1);
+		if(run_start && ++cnt >= nruns) break;
+	}
+	return j;
+}
+
 template<typename F>
-WTZ_HD void wtz_kmer_walk(const wtz_reads_t &R, uint32_t rid, uint32_t ksize, uint32_t hk, uint32_t ksave, F &f){
+WTZ_HD void wtz_kmer_walk(const wtz_reads_t &R, uint32_t rid, uint32_t ksize, uint32_t hk, uint32_t ksave, F &f, uint32_t jb = 0, uint32_t je = 0xFFFFFFFFu){
 	const uint64_t mask = 0xFFFFFFFFFFFFFFFFULL >> ((32 - ksize) << 1);
-	const uint64_t off = R.rdoff[rid]; const uint32_t len = R.rdlen[rid];
+	const uint64_t off = R.rdoff[rid]; const uint32_t len = R.rdlen[rid] < je ? R.rdlen[rid] : je;
 	uint32_t ring[32];                      /* start positions of the last ksize hp-runs (hzoff, wtzmo.c:461) */
 	uint64_t kmer = 0; uint32_t i = 0; uint32_t b = 4;
 	uint64_t word = 0;
-	for(uint32_t j = 0; j < len; j++){
+	const uint32_t j_first = wtz_walk_warm_start(R, rid, hk, ksize, jb);
+	for(uint32_t j = j_first; j < len; j++){
 		uint64_t p = off + j;
-		if(j == 0 || (p & 31u) == 0) word = R.bits[p >> 5];
+		if(j == j_first || (p & 31u) == 0) word = R.bits[p >> 5];
 		uint32_t c = (uint32_t)((word >> (((~p) & 31u) << 1)) & 3u);
 		if(hk && c == b) continue;
 		b = c; i++;
@@ -53,6 +70,7 @@ WTZ_HD void wtz_kmer_walk(const wtz_reads_t &R, uint32_t rid, uint32_t ksize, ui
 		uint64_t mer = rev > kmer ? kmer : rev;
 		uint32_t kidx = wtz_jenkins32((uint32_t)mer) % (WTZ_KMER_MOD * ksave);
 		if(kidx >= WTZ_KMER_MOD) continue;
+		if(j < jb) continue;
 		f(mer, dir, ring[(i - ksize) & 31u], j + 1);
 	}
 }
@@ -62,16 +80,16 @@ struct wtz_kcount_f { uint32_t n; WTZ_HDM void operator()(uint64_t, uint32_t, ui
 struct wtz_kfill_f  { uint64_t *keys; uint32_t *vals; uint64_t pos; uint32_t rid;
 	WTZ_HDM void operator()(uint64_t mer, uint32_t dir, uint32_t, uint32_t){ keys[pos] = mer; vals[pos] = (rid << 1) | dir; pos++; } };
 
-/* task: count sampled k-mers of read id_beg + t */
-WTZ_HD void wtz_task_kcount(uint32_t t, wtz_reads_t R, uint32_t id_beg, uint32_t ksize, uint32_t hk, uint32_t ksave, uint64_t *cnt){
+/* task: count sampled k-mers of piece t = (read piece_rid[t], positions [piece_jb[t], +WTZ_WALK_CHUNK)) */
+WTZ_HD void wtz_task_kcount(uint32_t t, wtz_reads_t R, const uint32_t *piece_rid, const uint32_t *piece_jb, uint32_t ksize, uint32_t hk, uint32_t ksave, uint64_t *cnt){
 	wtz_kcount_f f; f.n = 0;
-	wtz_kmer_walk(R, id_beg + t, ksize, hk, ksave, f);
+	wtz_kmer_walk(R, piece_rid[t], ksize, hk, ksave, f, piece_jb[t], piece_jb[t] + WTZ_WALK_CHUNK);
 	cnt[t] = f.n;
 }
-/* task: write (k-mer, rd<<1|dir) of read id_beg + t at offs[t] */
-WTZ_HD void wtz_task_kfill(uint32_t t, wtz_reads_t R, uint32_t id_beg, uint32_t ksize, uint32_t hk, uint32_t ksave, const uint64_t *offs, uint64_t *keys, uint32_t *vals){
-	wtz_kfill_f f; f.keys = keys; f.vals = vals; f.pos = offs[t]; f.rid = id_beg + t;
-	wtz_kmer_walk(R, id_beg + t, ksize, hk, ksave, f);
+/* task: write (k-mer, rd<<1|dir) of piece t at offs[t] (pieces are listed in read order, so the output is the sequential walk's) */
+WTZ_HD void wtz_task_kfill(uint32_t t, wtz_reads_t R, const uint32_t *piece_rid, const uint32_t *piece_jb, uint32_t ksize, uint32_t hk, uint32_t ksave, const uint64_t *offs, uint64_t *keys, uint32_t *vals){
+	wtz_kfill_f f; f.keys = keys; f.vals = vals; f.pos = offs[t]; f.rid = piece_rid[t];
+	wtz_kmer_walk(R, piece_rid[t], ksize, hk, ksave, f, piece_jb[t], piece_jb[t] + WTZ_WALK_CHUNK);
 }
 
 WTZ_HD uint64_t wtz_run_end(const uint64_t *keys, uint64_t n, uint64_t i){     /* first index > i with a different key */
@@ -145,14 +163,15 @@ typedef struct {
 } wtz_zindex_t;
 
 template<typename F>
-WTZ_HD void wtz_zmer_walk(const wtz_reads_t &R, uint32_t rid, uint32_t zsize, uint32_t hz, F &f){
+WTZ_HD void wtz_zmer_walk(const wtz_reads_t &R, uint32_t rid, uint32_t zsize, uint32_t hz, F &f, uint32_t jb = 0, uint32_t je = 0xFFFFFFFFu){
 	const uint64_t mask = 0xFFFFFFFFFFFFFFFFULL >> ((32 - zsize) << 1);
-	const uint64_t off = R.rdoff[rid]; const uint32_t len = R.rdlen[rid];
+	const uint64_t off = R.rdoff[rid]; const uint32_t len = R.rdlen[rid] < je ? R.rdlen[rid] : je;
 	uint32_t ring[16];
 	uint64_t kmer = 0, word = 0; uint32_t i = 0, b = 4;
-	for(uint32_t j = 0; j < len; j++){
+	const uint32_t j_first = wtz_walk_warm_start(R, rid, hz, zsize, jb);
+	for(uint32_t j = j_first; j < len; j++){
 		uint64_t p = off + j;
-		if(j == 0 || (p & 31u) == 0) word = R.bits[p >> 5];
+		if(j == j_first || (p & 31u) == 0) word = R.bits[p >> 5];
 		uint32_t c = (uint32_t)((word >> (((~p) & 31u) << 1)) & 3u);
 		if(hz && c == b) continue;
 		b = c; i++;
@@ -165,6 +184,7 @@ WTZ_HD void wtz_zmer_walk(const wtz_reads_t &R, uint32_t rid, uint32_t zsize, ui
 		uint32_t mer = (uint32_t)(rev > kmer ? kmer : rev);
 		uint32_t zo = ring[(i - zsize) & 15u];
 		uint32_t zl = (j + 1 - zo > 0xFFFFu) ? 0xFFFFu : j + 1 - zo;
+		if(j < jb) continue;
 		f(mer, dir, zo, zl);
 	}
 }
@@ -173,8 +193,8 @@ struct wtz_zcount_f { uint32_t n; WTZ_HDM void operator()(uint32_t, uint32_t, ui
 struct wtz_zfill_f { uint32_t *mer, *pos; uint16_t *len; uint64_t *key; uint32_t k;
 	WTZ_HDM void operator()(uint32_t m, uint32_t d, uint32_t o, uint32_t l){ mer[k] = m; pos[k] = (o << 1) | d; len[k] = (uint16_t)l; key[k] = ((uint64_t)m << 32) | k; k++; } };
 
-WTZ_HD void wtz_task_zcount(uint32_t r, wtz_reads_t R, uint32_t zsize, uint32_t hz, uint64_t *cnt){
-	wtz_zcount_f f; f.n = 0; wtz_zmer_walk(R, r, zsize, hz, f); cnt[r] = f.n;
+WTZ_HD void wtz_task_zcount(uint32_t t, wtz_reads_t R, const uint32_t *piece_rid, const uint32_t *piece_jb, uint32_t zsize, uint32_t hz, uint64_t *cnt){
+	wtz_zcount_f f; f.n = 0; wtz_zmer_walk(R, piece_rid[t], zsize, hz, f, piece_jb[t], piece_jb[t] + WTZ_WALK_CHUNK); cnt[t] = f.n;
 }
 
 WTZ_HD void wtz_heapsort_u64(uint64_t *a, uint32_t n){
@@ -204,10 +224,12 @@ WTZ_HD void wtz_heapsort_u64(uint64_t *a, uint32_t n){
 struct wtz_zfill2_f { uint32_t *mer, *pos; uint16_t *len; uint64_t *key; uint32_t *val; uint32_t k; uint64_t rid;
 	WTZ_HDM void operator()(uint32_t m, uint32_t d, uint32_t o, uint32_t l){ mer[k] = m; pos[k] = (o << 1) | d; len[k] = (uint16_t)l; key[k] = (rid << 32) | m; val[k] = k; k++; } };
 
-WTZ_HD void wtz_task_zfill(uint32_t r, wtz_reads_t R, uint32_t zsize, uint32_t hz, wtz_zindex_t Z, uint64_t *key, uint32_t *val){
+/* piece t writes at poff[t] (absolute); `val` = position of the z-mer inside its read's list */
+WTZ_HD void wtz_task_zfill(uint32_t t, wtz_reads_t R, const uint32_t *piece_rid, const uint32_t *piece_jb, const uint64_t *poff, uint32_t zsize, uint32_t hz, wtz_zindex_t Z, uint64_t *key, uint32_t *val){
+	const uint32_t r = piece_rid[t];
 	const uint64_t o = Z.zoff[r];
-	wtz_zfill2_f f; f.mer = Z.mer + o; f.pos = Z.pos + o; f.len = Z.len + o; f.key = key + o; f.val = val + o; f.k = 0; f.rid = r;
-	wtz_zmer_walk(R, r, zsize, hz, f);
+	wtz_zfill2_f f; f.mer = Z.mer + o; f.pos = Z.pos + o; f.len = Z.len + o; f.key = key + o; f.val = val + o; f.k = (uint32_t)(poff[t] - o); f.rid = r;
+	wtz_zmer_walk(R, r, zsize, hz, f, piece_jb[t], piece_jb[t] + WTZ_WALK_CHUNK);
 }
 
 /* element i of the (read, mer)-sorted array: flag[i] = 1 for the head of a retained run, cnt[i] = its length */
