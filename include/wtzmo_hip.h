@@ -113,6 +113,11 @@ int  wtz_zindex_build(wtz_ctx_t *ctx);
  * (candidate heaps carried across -G index parts, else 0), out = entries after this index part.
  * Rows are the reference's heap arrays verbatim (the caller applies wtzmo.c:813-822). */
 int  wtz_candidates(wtz_ctx_t *ctx, const uint32_t *qids, uint32_t nq, uint64_t *cand, uint32_t *ncand_io);
+/* the same request split in two, so that the caller's sequential work (the commit of the previous batch) overlaps the kernel:
+ * _begin uploads and launches and returns at once; _end waits and fills cand / ncand_out (nq rows as passed to _begin).  No other
+ * call on this context may be made in between. */
+int  wtz_candidates_begin(wtz_ctx_t *ctx, const uint32_t *qids, uint32_t nq, const uint64_t *cand, const uint32_t *ncand_in);
+int  wtz_candidates_end(wtz_ctx_t *ctx, uint64_t *cand, uint32_t *ncand_out);
 
 /* Start a batch: releases all per-batch device results of the previous one. */
 int  wtz_batch_begin(wtz_ctx_t *ctx);

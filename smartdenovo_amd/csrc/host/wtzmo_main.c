@@ -78,7 +78,7 @@ typedef struct {
 	uint32_t cursor, qend, B; uint64_t next_seq, commit_seq;
 	pending_t pend;
 	/* stats */
-	double t_gpu, t_commit;
+	double t_gpu, t_commit, t_call[6];      /* t_call: wall seconds inside wtz_candidates / pairs_seed / pairs_windows / pairs_align / fetch_cigar_text / planning */
 	uint64_t spec_pairs, used_pairs, spec_items, used_items, spec_queries, used_queries, n_batches;
 	double extra_ms[5]; uint64_t extra_u64[6];      /* counters of the cloned contexts */
 } eng_t;
@@ -95,6 +95,8 @@ typedef struct {       /* one batch in flight */
 	uint32_t *item_of; uint32_t *it_pair; uint8_t *it_dir; uint32_t nitem; wtz_aln_result_t *aln; char *cig; uint64_t ncig, capcig;
 	uint64_t spec_queries, used_queries;
 	int holds_turn;
+	/* candidates of the NEXT batch, requested before this batch is committed (single worker, no -G) */
+	int pf_inflight; uint32_t *pf_ids; uint32_t pf_n, pf_cap; uint64_t *pf_rows; uint32_t *pf_nr; uint32_t pf_cursor_end;
 } batch_t;
 
 #define DIE_WTZ(rc, what) do { if((rc) != WTZ_OK){ fprintf(stderr, " -- %s failed: %s --\n", what, wtz_last_error()); exit(1); } } while(0)
@@ -412,7 +414,7 @@ static int gpu_stages(eng_t *E, batch_t *b){
 	const wtz_params_c *P = &E->P;
 	int rc;
 	b->sum = (wtz_pair_summary_t*)hx_realloc(b->sum, sizeof(wtz_pair_summary_t) * (b->npair + 1));
-	rc = wtz_pairs_seed(b->ctx, b->pq, b->pc, b->npair, b->sum); TRY_WTZ(rc, "wtz_pairs_seed");
+	{ const double tc0 = now_s(); rc = wtz_pairs_seed(b->ctx, b->pq, b->pc, b->npair, b->sum); E->t_call[1] += now_s() - tc0; } TRY_WTZ(rc, "wtz_pairs_seed");
 	b->nitem = 0; b->ncig = 0;
 	if(!P->dot_matrix){
 		b->box_off = (uint64_t*)hx_realloc(b->box_off, 8 * ((size_t)b->npair * 2 + 1));
@@ -420,7 +422,7 @@ static int gpu_stages(eng_t *E, batch_t *b){
 		for(uint32_t i = 0; i < b->npair; i++) for(int d = 0; d < 2; d++){ b->box_off[(size_t)i * 2 + d] = nb; nb += b->sum[i].nwin[d]; }
 		b->box_off[(size_t)b->npair * 2] = nb; b->nbox = nb;
 		if(nb > b->capbox){ b->capbox = nb; b->boxes = (wtz_winbox_t*)hx_realloc(b->boxes, sizeof(wtz_winbox_t) * nb); }
-		rc = wtz_pairs_windows(b->ctx, b->boxes, nb); TRY_WTZ(rc, "wtz_pairs_windows");
+		{ const double tc0 = now_s(); rc = wtz_pairs_windows(b->ctx, b->boxes, nb); E->t_call[2] += now_s() - tc0; } TRY_WTZ(rc, "wtz_pairs_windows");
 		b->item_of = (uint32_t*)hx_realloc(b->item_of, 4 * ((size_t)b->npair + 1));
 		b->it_pair = (uint32_t*)hx_realloc(b->it_pair, 4 * ((size_t)b->npair + 1));
 		b->it_dir = (uint8_t*)hx_realloc(b->it_dir, (size_t)b->npair + 1);
@@ -433,14 +435,36 @@ static int gpu_stages(eng_t *E, batch_t *b){
 		}
 		if(b->nitem){
 			b->aln = (wtz_aln_result_t*)hx_realloc(b->aln, sizeof(wtz_aln_result_t) * b->nitem);
-			rc = wtz_pairs_align(b->ctx, b->it_pair, b->it_dir, b->nitem, b->aln); TRY_WTZ(rc, "wtz_pairs_align");
+			{ const double tc0 = now_s(); rc = wtz_pairs_align(b->ctx, b->it_pair, b->it_dir, b->nitem, b->aln); E->t_call[3] += now_s() - tc0; } TRY_WTZ(rc, "wtz_pairs_align");
 			uint64_t tot = 0; for(uint32_t i = 0; i < b->nitem; i++) tot += b->aln[i].text_len;
 			if(tot > b->capcig){ b->capcig = tot; b->cig = (char*)hx_realloc(b->cig, tot + 1); }
-			rc = wtz_fetch_cigar_text(b->ctx, b->cig, tot); TRY_WTZ(rc, "wtz_fetch_cigar_text");     /* rendered on the device */
+			{ const double tc0 = now_s(); rc = wtz_fetch_cigar_text(b->ctx, b->cig, tot); E->t_call[4] += now_s() - tc0; } TRY_WTZ(rc, "wtz_fetch_cigar_text");     /* rendered on the device */
 			b->ncig = tot;
 		}
 	}
 	return 0;
+}
+
+/* Candidate search (A3) depends on the read and the index only, so the next batch's request can be in flight while this
+ * batch is committed on the host.  The next queries are chosen with the masks as they are NOW; whoever the commit masks or
+ * saturates meanwhile is dropped / demoted when the batch is formed - the batch composition is free (any batch size gives
+ * the same output), only the query ORDER and the one-query masking lag are part of the contract. */
+static void prefetch_begin(eng_t *E, batch_t *b){
+	if(E->n_workers != 1 || E->rows_all || E->cursor >= E->qend) return;
+	const uint32_t B = E->B;
+	if(B > b->pf_cap){ b->pf_cap = B; b->pf_ids = (uint32_t*)hx_realloc(b->pf_ids, 4 * (size_t)B); b->pf_rows = (uint64_t*)hx_realloc(b->pf_rows, (size_t)B * E->stride * 8); b->pf_nr = (uint32_t*)hx_realloc(b->pf_nr, 4 * (size_t)B); }
+	uint32_t j = E->cursor, n = 0;
+	for(; j < E->qend && n < B; j++){
+		if((j % E->n_job) != E->i_job) continue;
+		if(E->masked[j]) continue;
+		if(E->rdcovs[j] >= nbest_of(E, j)) continue;        /* already saturated: needs no candidates; it is re-examined when the batch is formed */
+		b->pf_ids[n] = j; b->pf_nr[n] = 0; n++;
+	}
+	b->pf_n = n; b->pf_cursor_end = j;
+	if(n == 0) return;
+	memset(b->pf_rows, 0, (size_t)n * E->stride * 8);
+	int rc = wtz_candidates_begin(b->ctx, b->pf_ids, n, b->pf_rows, b->pf_nr); DIE_WTZ(rc, "wtz_candidates_begin");
+	b->pf_inflight = 1;
 }
 
 /* slots [s0,s1): plan pairs, run the device stages, commit in query order when it is this batch's turn. A range whose
@@ -460,6 +484,7 @@ static void process_range(eng_t *E, batch_t *b, uint32_t s0, uint32_t s1){
 		process_range(E, b, mid, s1);
 		return;
 	}
+	if(s0 == 0 && s1 == b->nbq && !b->pf_inflight){ pthread_mutex_lock(&E->mu); prefetch_begin(E, b); pthread_mutex_unlock(&E->mu); }
 	pthread_mutex_lock(&E->mu);
 	E->t_gpu += tg1 - tg0;
 	while(!b->holds_turn && E->commit_seq != b->seq) pthread_cond_wait(&E->cv, &E->mu);
@@ -482,11 +507,14 @@ static void *worker_main(void *arg){
 		pthread_mutex_lock(&E->mu);
 		if(E->cursor >= E->qend){ pthread_mutex_unlock(&E->mu); break; }
 		const uint32_t B = E->B;
-		if(B + 1 > b->capbq){ b->capbq = B + 1; b->bq = (uint32_t*)hx_realloc(b->bq, 4 * (size_t)b->capbq); b->want = (uint8_t*)hx_realloc(b->want, b->capbq); b->ids = (uint32_t*)hx_realloc(b->ids, 4 * (size_t)b->capbq);
+		const int use_pf = b->pf_inflight;
+		const uint32_t jend = use_pf ? b->pf_cursor_end : E->qend;      /* a prefetched batch covers exactly the reads the prefetch looked at */
+		const uint32_t need = use_pf ? (jend - E->cursor) + 1 : B + 1;  /* saturated reads of the range ride along without candidates */
+		if(need > b->capbq){ b->capbq = need; b->bq = (uint32_t*)hx_realloc(b->bq, 4 * (size_t)b->capbq); b->want = (uint8_t*)hx_realloc(b->want, b->capbq); b->ids = (uint32_t*)hx_realloc(b->ids, 4 * (size_t)b->capbq);
 			b->rows = (uint64_t*)hx_realloc(b->rows, (size_t)b->capbq * E->stride * 8); b->nrow = (uint32_t*)hx_realloc(b->nrow, 4 * (size_t)b->capbq); }
 		b->nbq = 0;
 		uint32_t j = E->cursor, nwant = 0;
-		for(; j < E->qend && b->nbq < B; j++){
+		for(; j < jend && (use_pf || b->nbq < B); j++){
 			if((j % E->n_job) != E->i_job) continue;
 			if(E->masked[j]) continue;
 			/* reads whose coverage is already saturated (wtzmo.c:808) need no GPU work but stay in the dispatch sequence:
@@ -505,7 +533,20 @@ static void *worker_main(void *arg){
 		if(E->B < E->max_batch) E->B = E->B * 4 > E->max_batch ? E->max_batch : E->B * 4;      /* ramp-up; corrected at commit */
 		pthread_mutex_unlock(&E->mu);
 		/* ---- candidate heaps of the batch's queries (A3) ---- */
-		if(nwant){
+		if(use_pf){
+			const double tg0 = now_s();
+			int rc = wtz_candidates_end(b->ctx, b->pf_rows, b->pf_nr); DIE_WTZ(rc, "wtz_candidates_end");
+			const double tg1 = now_s();
+			b->pf_inflight = 0;
+			uint32_t k = 0;
+			for(uint32_t s = 0; s < b->nbq; s++){
+				if(!b->want[s]) continue;
+				while(k < b->pf_n && b->pf_ids[k] < b->bq[s]) k++;
+				if(k >= b->pf_n || b->pf_ids[k] != b->bq[s]){ fprintf(stderr, " -- internal error: read %u has no prefetched candidates --\n", b->bq[s]); exit(1); }
+				memcpy(b->rows + (size_t)s * E->stride, b->pf_rows + (size_t)k * E->stride, (size_t)E->stride * 8); b->nrow[s] = b->pf_nr[k];
+			}
+			pthread_mutex_lock(&E->mu); E->t_gpu += tg1 - tg0; E->t_call[0] += tg1 - tg0; pthread_mutex_unlock(&E->mu);
+		} else if(nwant){
 			uint32_t n = 0;
 			for(uint32_t s = 0; s < b->nbq; s++) if(b->want[s]) b->ids[n++] = b->bq[s];
 			uint64_t *rows = (uint64_t*)hx_realloc(NULL, (size_t)n * E->stride * 8); uint32_t *nr = (uint32_t*)hx_realloc(NULL, 4 * (size_t)n);
@@ -517,7 +558,7 @@ static void *worker_main(void *arg){
 			n = 0;
 			for(uint32_t s = 0; s < b->nbq; s++) if(b->want[s]){ memcpy(b->rows + (size_t)s * E->stride, rows + (size_t)n * E->stride, (size_t)E->stride * 8); b->nrow[s] = nr[n]; n++; }
 			free(rows); free(nr);
-			pthread_mutex_lock(&E->mu); E->t_gpu += tg1 - tg0; pthread_mutex_unlock(&E->mu);
+			pthread_mutex_lock(&E->mu); E->t_gpu += tg1 - tg0; E->t_call[0] += tg1 - tg0; pthread_mutex_unlock(&E->mu);
 		}
 		if(b->nbq) process_range(E, b, 0, b->nbq);
 		/* ---- hand the turn to the next batch ---- */
@@ -728,7 +769,7 @@ int main(int argc, char **argv){
 			free(E->closed.tab); memset(&E->closed, 0, sizeof E->closed);
 			for(size_t i = 0; i < nclosed0; i++) hx_set_put(&E->closed, closed0[i]);
 			E->pair_bp = E->n_pairs = E->nrec = 0;
-			E->t_gpu = E->t_commit = 0; E->spec_pairs = E->used_pairs = E->spec_items = E->used_items = E->spec_queries = E->used_queries = 0;
+			E->t_gpu = E->t_commit = 0; memset(E->t_call, 0, sizeof E->t_call); E->spec_pairs = E->used_pairs = E->spec_items = E->used_items = E->spec_queries = E->used_queries = 0;
 			E->rows_all = 0; E->n_batches = 0;
 			E->pend.rd_id = 0xFFFFFFFFu; E->pend.nhit = E->pend.nmask = E->pend.nclosed = E->pend.nseed = 0;
 			if(strcmp(output, "-")){ E->out = fopen(output, "w"); if(E->out == NULL) exit(1); setvbuf(E->out, NULL, _IOFBF, 8u << 20); }
@@ -796,7 +837,7 @@ int main(int argc, char **argv){
 					if(cw.pool_peak > E->extra_u64[5]) E->extra_u64[5] = cw.pool_peak;
 					wtz_ctx_destroy(bs[w].ctx); }
 				free(bs[w].bq); free(bs[w].want); free(bs[w].ids); free(bs[w].rows); free(bs[w].nrow); free(bs[w].pq); free(bs[w].pc); free(bs[w].rowpair); free(bs[w].sum);
-				free(bs[w].box_off); free(bs[w].boxes); free(bs[w].item_of); free(bs[w].it_pair); free(bs[w].it_dir); free(bs[w].aln); free(bs[w].cig);
+				free(bs[w].box_off); free(bs[w].boxes); free(bs[w].item_of); free(bs[w].it_pair); free(bs[w].it_dir); free(bs[w].aln); free(bs[w].cig); free(bs[w].pf_ids); free(bs[w].pf_rows); free(bs[w].pf_nr);
 			}
 			free(bs); free(th);
 		}
@@ -812,6 +853,7 @@ int main(int argc, char **argv){
 		memset(E->extra_ms, 0, sizeof E->extra_ms); memset(E->extra_u64, 0, sizeof E->extra_u64);
 		fprintf(stderr, "[wtzmo-mi355x] %llu records, %llu pairs aligned, %llu pair-bp, %.3f s (index %.3f s)\n", (unsigned long long)E->nrec, (unsigned long long)E->n_pairs, (unsigned long long)E->pair_bp, t1 - t0, t_index);
 		fprintf(stderr, "[wtzmo-mi355x] host seconds: in GPU-stage calls %.3f, commit %.3f\n", E->t_gpu, E->t_commit);
+		fprintf(stderr, "[wtzmo-mi355x] wall seconds per call: candidates %.3f pairs_seed %.3f pairs_windows %.3f pairs_align %.3f cigar_text %.3f\n", E->t_call[0], E->t_call[1], E->t_call[2], E->t_call[3], E->t_call[4]);
 	fprintf(stderr, "[wtzmo-mi355x] %llu batches on %u worker context(s); speculation: queries %llu/%llu pairs %llu/%llu alignments %llu/%llu (used/planned)\n",
 			(unsigned long long)E->n_batches, E->rows_all ? 1u : E->n_workers, (unsigned long long)E->used_queries, (unsigned long long)E->spec_queries, (unsigned long long)E->used_pairs, (unsigned long long)E->spec_pairs, (unsigned long long)E->used_items, (unsigned long long)E->spec_items);
 		fprintf(stderr, "[wtzmo-mi355x] kernel ms: index %.1f zindex %.1f candidates %.1f pairs %.1f winalign %.1f stitch %.1f (K-sw3 wave %.1f); cells shift %llu; pool peak %.2f GB\n",

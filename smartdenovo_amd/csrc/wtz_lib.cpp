@@ -158,7 +158,9 @@ struct wtz_timer { hipEvent_t a, b; bool ok;
 	wtz_timer(){ ok = hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess; }
 	~wtz_timer(){ if(ok){ (void)hipEventDestroy(a); (void)hipEventDestroy(b); } }
 	void start(){ if(ok) (void)hipEventRecord(a, g_stream); }
-	double stop(){ float ms = 0; if(ok){ (void)hipEventRecord(b, g_stream); (void)hipEventSynchronize(b); (void)hipEventElapsedTime(&ms, a, b); } return ms; } };
+	double stop(){ float ms = 0; if(ok){ (void)hipEventRecord(b, g_stream); (void)hipEventSynchronize(b); (void)hipEventElapsedTime(&ms, a, b); } return ms; }
+	void lap(){ if(ok) (void)hipEventRecord(b, g_stream); }                 /* end mark now, read later */
+	double read(){ float ms = 0; if(ok){ (void)hipEventSynchronize(b); (void)hipEventElapsedTime(&ms, a, b); } return ms; } };
 
 static int dev_sort_pairs_u64_u32(uint64_t *keys, uint32_t *vals, uint64_t n, unsigned end_bit){
 	if(n < 2) return WTZ_OK;
@@ -206,7 +208,8 @@ static int dev_set(void *d, int v, size_t n){ if(n) memset(d, v, n); return WTZ_
 static int dev_sync(){ return WTZ_OK; }
 #include <time.h>
 struct wtz_timer { struct timespec t0; void start(){ clock_gettime(CLOCK_MONOTONIC, &t0); }
-	double stop(){ struct timespec t1; clock_gettime(CLOCK_MONOTONIC, &t1); return 1e3 * (double)(t1.tv_sec - t0.tv_sec) + 1e-6 * (double)(t1.tv_nsec - t0.tv_nsec); } };
+	double stop(){ struct timespec t1; clock_gettime(CLOCK_MONOTONIC, &t1); return 1e3 * (double)(t1.tv_sec - t0.tv_sec) + 1e-6 * (double)(t1.tv_nsec - t0.tv_nsec); }
+	double lapv = 0; void lap(){ lapv = stop(); } double read(){ return lapv; } };
 static int dev_exclusive_scan_u32(const uint32_t *in, uint32_t *out, uint64_t n){ uint32_t a = 0; for(uint64_t i = 0; i < n; i++){ uint32_t v = in[i]; out[i] = a; a += v; } return WTZ_OK; }
 static int dev_sort_pairs_u64_u32(uint64_t *keys, uint32_t *vals, uint64_t n, unsigned){
 	std::vector<std::pair<uint64_t, uint32_t> > v((size_t)n);
@@ -246,6 +249,8 @@ struct wtz_ctx {
 	uint32_t *d_qid, *d_cid; wtz_pairres_t *d_pairres; uint32_t n_pairs; std::vector<wtz_pairres_t> h_pairres;
 	wtz_alnres_dev_t *d_alnres; uint32_t n_items; std::vector<wtz_alnres_dev_t> h_alnres;
 	bool have_pairs, have_items;
+	/* candidate request in flight (wtz_candidates_begin / _end) */
+	uint32_t *cq_q = NULL, *cq_nc = NULL; uint64_t *cq_cand = NULL; unsigned long long *cq_bytes = NULL; uint32_t cq_cap = 0, cq_n = 0; bool cq_pending = false; wtz_timer cq_tm;
 	wtz_counters_t cnt;
 };
 
@@ -359,6 +364,7 @@ extern "C" void wtz_ctx_destroy(wtz_ctx_t *c){
 	if(!c) return;
 	{ CTX_ENTER(c); (void)dev_sync(); }
 	free_batch_storage(c); free_kindex(c); free_zindex(c);
+	dev_free_persist(c->cq_q); dev_free_persist(c->cq_nc); dev_free_persist(c->cq_cand); dev_free_persist(c->cq_bytes);
 #ifndef WTZ_EMUL
 	if(c->arena.base) (void)hipFree(c->arena.base);
 #endif
@@ -516,29 +522,57 @@ extern "C" int wtz_zindex_build(wtz_ctx_t *c){
 /* ------------------------------------------------------------------------------------------------ */
 /* A3: candidates                                                                                    */
 /* ------------------------------------------------------------------------------------------------ */
-extern "C" int wtz_candidates(wtz_ctx_t *c, const uint32_t *qids, uint32_t nq, uint64_t *cand, uint32_t *ncand_io){
-	if(!c || !c->ktab || !qids || !cand || !ncand_io) return wtz_fail(WTZ_E_ARG, "index not built / null argument");
-	if(nq == 0) return WTZ_OK;
+/* asynchronous form: _begin uploads and launches on the context's stream and returns; _end waits and fetches.  Nothing else
+ * may run on the context in between (the scratch pool is the kernel's); the host is free meanwhile. */
+extern "C" int wtz_candidates_begin(wtz_ctx_t *c, const uint32_t *qids, uint32_t nq, const uint64_t *cand, const uint32_t *ncand_in){
+	if(!c || !c->ktab || !qids || !cand || !ncand_in) return wtz_fail(WTZ_E_ARG, "index not built / null argument");
+	if(c->cq_pending) return wtz_fail(WTZ_E_STATE, "wtz_candidates_begin: a request is already in flight");
+	c->cq_n = nq;
+	if(nq == 0){ c->cq_pending = true; return WTZ_OK; }
 	CTX_ENTER(c);
 	for(uint32_t i = 0; i < nq; i++) if(qids[i] >= c->n_reads) return wtz_fail(WTZ_E_ARG, "query id %u out of range", qids[i]);
 	CHK(pool_reset(c));
 	const uint32_t stride = c->P.ncand + 1;
-	uint32_t *d_q = NULL, *d_n = NULL; uint64_t *d_cand = NULL;
-	CHK(dev_alloc((void**)&d_q, (size_t)nq * 4)); CHK(dev_h2d(d_q, qids, (size_t)nq * 4));
-	CHK(dev_alloc((void**)&d_n, (size_t)nq * 4)); CHK(dev_h2d(d_n, ncand_io, (size_t)nq * 4));
-	CHK(dev_alloc((void**)&d_cand, (size_t)nq * stride * 8)); CHK(dev_h2d(d_cand, cand, (size_t)nq * stride * 8));
+	if(nq > c->cq_cap){
+		(void)dev_sync();
+		dev_free_persist(c->cq_q); dev_free_persist(c->cq_nc); dev_free_persist(c->cq_cand); dev_free_persist(c->cq_bytes);
+		uint32_t cap = c->cq_cap ? c->cq_cap : 1024; while(cap < nq) cap *= 2;
+		CHK(dev_alloc_persist((void**)&c->cq_q, (size_t)cap * 4)); CHK(dev_alloc_persist((void**)&c->cq_nc, (size_t)cap * 4));
+		CHK(dev_alloc_persist((void**)&c->cq_cand, (size_t)cap * stride * 8)); CHK(dev_alloc_persist((void**)&c->cq_bytes, 8));
+		c->cq_cap = cap;
+	}
+	uint32_t *d_q = c->cq_q, *d_n = c->cq_nc; uint64_t *d_cand = c->cq_cand; unsigned long long *d_bytes = c->cq_bytes;
+	CHK(dev_h2d(d_q, qids, (size_t)nq * 4)); CHK(dev_h2d(d_n, ncand_in, (size_t)nq * 4)); CHK(dev_h2d(d_cand, cand, (size_t)nq * stride * 8));
+	CHK(dev_set(d_bytes, 0, 8));
 	const wtz_reads_t R = ctx_reads(c); const wtz_params_t *dP = c->dP; const wtz_kslot_t *tab = c->ktab; const uint64_t kmask = c->kmask;
 	const uint32_t *seeds = c->kseeds; wtz_pool_t *pool = c->dpool;
-	unsigned long long *d_bytes = NULL; CHK(dev_alloc((void**)&d_bytes, 8)); CHK(dev_set(d_bytes, 0, 8));
-	wtz_timer tm; tm.start();
+	c->cq_tm.start();
 	CHK(wtz_launch_coop<K_candidates>(0, nq, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_candidates((uint32_t)t, R, d_q, dP, tab, kmask, seeds, pool, d_cand, d_n, stride, d_bytes); }));
+	c->cq_tm.lap();
+	c->cq_pending = true;
+	return WTZ_OK;
+}
+extern "C" int wtz_candidates_end(wtz_ctx_t *c, uint64_t *cand, uint32_t *ncand_out){
+	if(!c || !c->cq_pending) return wtz_fail(WTZ_E_STATE, "wtz_candidates_end without wtz_candidates_begin");
+	c->cq_pending = false;
+	const uint32_t nq = c->cq_n;
+	if(nq == 0) return WTZ_OK;
+	if(!cand || !ncand_out) return wtz_fail(WTZ_E_ARG, "null argument");
+	CTX_ENTER(c);
+	const uint32_t stride = c->P.ncand + 1;
 	CHK(dev_sync());
-	{ unsigned long long hb = 0; CHK(dev_d2h(&hb, d_bytes, 8)); c->cnt.bytes_seed_algo += hb; dev_free(d_bytes); }
-	c->cnt.ms_candidates += tm.stop(); c->cnt.n_candidates_q += nq;
-	CHK(dev_d2h(cand, d_cand, (size_t)nq * stride * 8)); CHK(dev_d2h(ncand_io, d_n, (size_t)nq * 4));
-	dev_free(d_q); dev_free(d_n); dev_free(d_cand);
+	c->cnt.ms_candidates += c->cq_tm.read(); c->cnt.n_candidates_q += nq;
+	{ unsigned long long hb = 0; CHK(dev_d2h(&hb, c->cq_bytes, 8)); c->cnt.bytes_seed_algo += hb; }
+	CHK(dev_d2h(cand, c->cq_cand, (size_t)nq * stride * 8)); CHK(dev_d2h(ncand_out, c->cq_nc, (size_t)nq * 4));
 	CHK(pool_check(c, "wtz_candidates"));
 	return WTZ_OK;
+}
+extern "C" int wtz_candidates(wtz_ctx_t *c, const uint32_t *qids, uint32_t nq, uint64_t *cand, uint32_t *ncand_io){
+	if(!c || !c->ktab || !qids || !cand || !ncand_io) return wtz_fail(WTZ_E_ARG, "index not built / null argument");
+	if(nq == 0) return WTZ_OK;
+	int rc = wtz_candidates_begin(c, qids, nq, cand, ncand_io);
+	if(rc != WTZ_OK) return rc;
+	return wtz_candidates_end(c, cand, ncand_io);
 }
 
 /* ------------------------------------------------------------------------------------------------ */
