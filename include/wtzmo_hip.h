@@ -14,7 +14,8 @@
  *   wtz_pairs_seed       <- query_single_read_seeds + process_hzmps + merge_paired_kmers_window +
  *                           chaining_wtseedv | dot_matrix_align_hzmps hzm_aln.h:173-224, 580-713, 1134-1186
  *   wtz_pairs_align      <- fast_seeds_align_hzmo + global_align_regs_hzmo (kswx_extend_align_core,
- *                           kswx_extend_align_shift_core, ksw_global2) hzm_aln.h:1247-1486, kswx.h:101-335, ksw.c:503-586
+ *                           kswx_extend_align_shift_core, ksw_global2) hzm_aln.h:1247-1486, kswx.h:101-335, ksw.c:503-586;
+ *                           with params.refine also kswx_refine_alignment kswx.h:483-659
  *
  * Everything returned is integer and bit-exact against `wtzmo -t 1`.  The order-dependent state of
  * the reference (closed pairs, contained-read masking, per-read coverage: wtzmo.c:806-822, 1065-1100,
@@ -47,6 +48,7 @@ typedef struct {
 	int32_t  min_score; float min_id;
 	int32_t  dot_matrix, xvar, yvar, min_block_len, max_overhang;
 	float    deviation_penalty, gap_penalty;
+	int32_t  refine;         /* -n: kswx_refine_alignment after stitching (wtzmo.c:1031-1034) */
 } wtz_params_c;
 
 typedef struct wtz_ctx wtz_ctx_t;

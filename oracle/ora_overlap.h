@@ -16,6 +16,7 @@
 
 #include "ora_index.h"
 #include "ora_align.h"
+#include "ora_refine.h"
 #include "ora_dotmatrix.h"
 
 typedef struct {
@@ -102,7 +103,7 @@ typedef struct {
 	ora_ztable_t zt; vec_u8 kcnts; vec_zhit cache, anchors, anchors2;
 	vec_win windows, windows2; ora_winscratch_t wsc; vec_i32 chainmem;
 	vec_u16 windeps; vec_f32 weights;
-	vec_u8 pb1, pb2; vec_u32 cigar_cache, cigars, tmp_cigar; vec_reg regs; ora_swmem_t swmem;
+	vec_u8 pb1, pb2; vec_u32 cigar_cache, cigars, tmp_cigar; vec_reg regs; ora_swmem_t swmem; ora_refmem_t refmem;
 	vec_u8 text; vec_u32 maskset;
 	ora_dm_scratch_t dm;
 	ora_win_t SEED[2];
@@ -244,6 +245,10 @@ static void ora_worker_run(ora_ctx_t *C, ora_worker_t *K, uint32_t pbid, uint32_
 		ora_aln_t x = ora_stitch_windows(alen, blen, K->regs.a, K->regs.n, esti, K->pb1.a, K->pb2.a, K->cigar_cache.a, &K->cigars, &K->swmem, &K->tmp_cigar,
 			P->W, P->ew, P->w, P->M, P->X, P->O, P->O, P->E, P->T);
 		K->regs.n = 0;
+		if(P->refine){       /* wtzmo.c:1031-1034: the stitched CIGAR becomes the guide of the re-alignment */
+			K->cigar_cache.n = 0; vec_u32_append(&K->cigar_cache, K->cigars.a, K->cigars.n);
+			x = ora_refine_alignment(K->pb2.a, x.qb, K->pb1.a, x.tb, (int)P->w, P->M, P->X, P->O, P->O, P->E, K->cigar_cache.a, K->cigar_cache.n, &K->refmem, &K->cigars);
+		}
 		if(x.score < P->min_score || x.mat < x.aln * P->min_id) continue;
 		ora_hit_t H; memset(&H, 0, sizeof H);
 		K->text.n = 0; ora_cigar_text(&K->text, K->cigars.a, K->cigars.n); vec_u8_push(&K->text, 0);

@@ -124,7 +124,6 @@ int main(int argc, char **argv){
 	if(pbs.n == 0) return usage();
 	if(P->ksize > 32 || P->ksize < 5) return usage();
 	if(P->zsize > 16 || P->zsize < 5) return usage();
-	if(P->refine){ fprintf(stderr, "wtzmo_oracle: -n (kswx_refine_alignment, A11) is not restated yet\n"); return 2; }
 	P->max_overhang = 2 * P->xvar;
 	P->kstep = P->kwin / 2;
 	P->dot_matrix = dot_matrix;

@@ -675,7 +675,7 @@ int main(int argc, char **argv){
 	if(pbs.n == 0) return usage();
 	if(P->ksize > 32 || P->ksize < 5) return usage();
 	if(P->zsize > 16 || P->zsize < 5) return usage();
-	if(refine){ fprintf(stderr, " -- wtzmo (MI355X): -n (kswx_refine_alignment) is not implemented in this build --\n"); return 2; }
+	P->refine = refine;
 	if(E->n_idx < 1) E->n_idx = 1;
 	if(E->n_job < 1) E->n_job = 1;
 	P->max_overhang = 2 * P->xvar; P->kstep = P->kwin / 2; P->dot_matrix = dot_matrix;

@@ -50,6 +50,7 @@ struct K_pack_cigars;
 struct K_pack_windows;
 struct K_pair;
 struct K_pair_big;
+struct K_refine;
 struct K_stitch_fin;
 struct K_stitch_left;
 struct K_stitch_mid;
@@ -772,6 +773,7 @@ extern "C" int wtz_pairs_align(wtz_ctx_t *c, const uint32_t *pair_idx, const uin
 		CHK(wtz_launch_wave<K_stitch_mid>(0, m, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_stitch_mid((uint32_t)t, V, d_items, d_st, d_jl, d_jr, d_gaps); }));
 		CHK(run_extjobs(c, V, d_jr, m));
 		CHK(wtz_launch_wave<K_stitch_fin>(0, m, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_stitch_fin((uint32_t)t, V, d_items, d_st, d_jl, d_jr, d_res); }));
+		if(c->P.refine) CHK(wtz_launch_coop<K_refine>(0, m, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_refine((uint32_t)t, V, d_items, d_res); }, WTZ_REFINE_LDS_BYTES));
 		CHK(dev_sync());
 		dev_free(d_st); dev_free(d_jl); dev_free(d_jr); dev_free(d_gaps);
 	}

@@ -1358,5 +1358,240 @@ WTZ_D int32_t wtz_global_reg(int32_t qlen, const wtz_seq_packed &query, int32_t 
 	return score;
 }
 
+/*
+ * A11, the optional `-n` pass: kswx_refine_alignment (kswx.h:483-659) on one wavefront.
+ *   band   lane 0 derives the per-row half-width zw[] and the band [zb, ze) from the stitched CIGAR exactly as the reference
+ *          does (the `zw[qx] += len` of a deletion is overwritten by the next M/I row and has no effect), then the running
+ *          max / min trims; rows keep a byte offset into a band-relative trace (the reference's ql x tl matrix is only ever
+ *          touched inside the band);
+ *   rows   the wave DP of wtz_extend_wave (LDS H/E rings indexed by absolute column, DPP max-scan for F) with the global
+ *          boundary: H(-1,-1) = 0, everything else outside the previous row's band is -10000 - which is what the
+ *          reference's never re-initialised rh[] / re[] rows hold, because zb and ze are non-decreasing;
+ *   trace  lane 0 walks from (ql-1, tl-1) through LDS-staged blocks of 64 rows x 124 columns.
+ * query = candidate view from qb, target = query-read view from tb (wtzmo.c:1033).  Returns false when the pool ran dry.
+ * Fallback inside: none needed for band widths up to 64*31 columns; wider bands (an indel of > 900 bases) run the DP rows on
+ * lane 0 with the same rings.
+ */
+WTZ_D bool wtz_refine_wave(const wtz_seq_packed &query, int32_t qb, const wtz_seq_packed &target, int32_t tb, int32_t W, int32_t M, int32_t X, int32_t I, int32_t D, int32_t E,
+		const uint32_t *cig, uint32_t ncig, const wtz_wave_lds_t &L, wtz_pool_t *pool, wtz_cigar_t &out, wtz_aln_t *res){
+	const int lane = (int)(threadIdx.x & 63);
+	const int32_t PM = L.PM;
+	wtz_aln_t y; memset(&y, 0, sizeof y);
+	if(lane == 0) out.n = 0;
+	int32_t qe = qb, te = tb;
+	for(uint32_t i = 0; i < ncig; i++){ const uint32_t op = cig[i] & 0xFu; const int32_t len = (int32_t)(cig[i] >> 4); if(op == 0){ qe += len; te += len; } else if(op == 1) qe += len; else te += len; }
+	const int32_t ql = qe - qb, tl = te - tb;
+	if(ql == 0 || tl == 0){ *res = y; return true; }        /* KSWX_NULL, empty CIGAR */
+	/* ---- band ---- */
+	unsigned long long ba = 0;
+	if(lane == 0) ba = (unsigned long long)(uintptr_t)wtz_pool_alloc(pool, (size_t)(ql + 2) * (4 * 3 + 8));
+	ba = __shfl(ba, 0, 64);
+	int32_t *zw = (int32_t*)(uintptr_t)ba;
+	if(zw == NULL) return false;
+	int32_t *zb = zw + (ql + 2), *ze = zb + (ql + 2); unsigned long long *zoff = (unsigned long long*)(ze + (ql + 2));
+	for(int32_t i = lane; i < ql + 2; i += 64) zw[i] = 0;
+	__threadfence_block();
+	unsigned long long ztot = 0; int32_t maxw = 0;
+	if(lane == 0){
+		int32_t qx = 0, tx = 0;
+		for(uint32_t i = 0; i < ncig; i++){
+			const uint32_t op = cig[i] & 0xFu; const int32_t len = (int32_t)(cig[i] >> 4);
+			if(op == 0){ for(int32_t j = 0; j < len; j++) zw[qx++] = W; }
+			else if(op == 1){ for(int32_t j = 0; j < len; j++) zw[qx++] = W + len; }
+		}
+		qx = 0;
+		for(uint32_t i = 0; i < ncig; i++){
+			const uint32_t op = cig[i] & 0xFu; const int32_t len = (int32_t)(cig[i] >> 4);
+			if(op == 0) qx += len;
+			else if(op == 1){
+				for(int32_t j = 1; j < len && j < qx; j++) zw[qx - j] += len - j;
+				qx += len - 1;
+				for(int32_t j = 1; j < len && j + qx < ql; j++) zw[qx + j] += len - j;
+				qx++;
+			} else {
+				for(int32_t j = 1; j < len && j < qx; j++) zw[qx - j] += len - j;
+				for(int32_t j = 1; j < len && j + qx < ql; j++) zw[qx + j] += len - j;
+			}
+		}
+		qx = 0;
+		for(uint32_t i = 0; i < ncig; i++){
+			const uint32_t op = cig[i] & 0xFu; const int32_t len = (int32_t)(cig[i] >> 4);
+			if(op == 0 || op == 1){
+				for(int32_t j = 0; j < len; j++){
+					int32_t b = tx - zw[qx]; if(b < 0) b = 0;
+					int32_t e = tx + 1 + zw[qx]; if(e > tl) e = tl;
+					zb[qx] = b; ze[qx] = e;
+					if(op == 0) tx++;
+					qx++;
+				}
+			} else tx += len;
+		}
+		int32_t b = 0; for(int32_t i = 0; i < ql; i++){ if(zb[i] < b) zb[i] = b; else if(zb[i] > b) b = zb[i]; }
+		int32_t e = tl; for(int32_t i = ql - 1; i >= 0; i--){ if(ze[i] > e) ze[i] = e; else if(ze[i] < e) e = ze[i]; }
+		for(int32_t i = 0; i < ql; i++){ const int32_t w = ze[i] > zb[i] ? ze[i] - zb[i] : 0; zoff[i] = ztot; ztot += (unsigned long long)w; if(w > maxw) maxw = w; }
+	}
+	ztot = __shfl(ztot, 0, 64); maxw = __shfl(maxw, 0, 64);
+	unsigned long long za = 0;
+	if(lane == 0) za = (unsigned long long)(uintptr_t)wtz_pool_alloc(pool, (size_t)ztot + 64);
+	za = __shfl(za, 0, 64);
+	uint8_t *z = (uint8_t*)(uintptr_t)za;
+	if(z == NULL) return false;
+	__threadfence_block();
+	/* ---- rows ---- */
+	const int32_t C = (((maxw + 63) / 64) | 1);
+	const bool wave_rows = (maxw + 2 <= PM + 1) && C <= 31 && (tl + 63) / 32 + 1 <= L.tw;
+	int32_t h_last_row = -10000;
+	if(wave_rows){
+		const int32_t nw = (tl + 31) / 32 + 1;
+		for(int32_t w = lane; w < nw; w += 64) L.tb[w] = wtz_pack32(target, w * 32, tl);
+		__threadfence_block();
+		int32_t jbp = 0, jep = 0; uint32_t qw_lo = 0, qw_hi = 0, qcur = 0;
+		const int32_t CE = C * E;
+		for(int32_t i = 0; i < ql; i++){
+			if((i & 2047) == 0){ const uint64_t qw = wtz_pack32(query, i + lane * 32, ql); qw_lo = (uint32_t)qw; qw_hi = (uint32_t)(qw >> 32); }
+			if((i & 15) == 0){ const int32_t qs = __builtin_amdgcn_readfirstlane((i & 2047) >> 5); qcur = (i & 16) ? (uint32_t)__builtin_amdgcn_readlane((int)qw_hi, qs) : (uint32_t)__builtin_amdgcn_readlane((int)qw_lo, qs); }
+			const uint32_t qbase = (qcur >> ((i & 15) * 2)) & 3u;
+			const int32_t jb = zb[i], je = ze[i];
+			const int32_t j0 = jb + lane * C;
+			uint64_t tbits;
+			{
+				const int32_t jj = j0 < tl ? j0 : (tl > 0 ? tl - 1 : 0);
+				const int32_t w = jj >> 5, sh = (jj & 31) * 2;
+				const uint64_t w0 = L.tb[w], w1 = L.tb[w + 1];
+				tbits = sh ? ((w0 >> sh) | (w1 << (64 - sh))) : w0;
+			}
+			int32_t agg = -0x3FFFFFFF;
+			{
+				int32_t saved = 0;
+				for(int32_t k = 0; k < C; k++){
+					const int32_t j = j0 + k;
+					if(j < je){
+						int32_t pred;
+						if(k == 0){
+							if(i == 0) pred = (j == 0) ? 0 : -10000;                                  /* rh[0] = 0, rh[1..] = -10000 (kswx.h:613-615) */
+							else pred = (j - 1 >= jbp && j - 1 < jep) ? L.Hs[(j - 1) & PM] : -10000;
+						} else pred = (i == 0) ? -10000 : saved;
+						saved = (i > 0 && j >= jbp && j < jep) ? L.Hs[j & PM] : -10000;
+						const uint32_t tbase = (uint32_t)(tbits >> (2 * k)) & 3u;
+						const int32_t m = pred + ((qbase == tbase) ? M : X);
+						L.Hs[j & PM] = m;
+						const int32_t cand = m + D + E + (C - 1 - k) * E;
+						agg = agg > cand ? agg : cand;
+					}
+				}
+			}
+			int32_t f;
+			{
+				const int32_t g = agg - lane * CE;
+				const int32_t pm = wtz_wave_max_scan_excl(g, -0x3FFFFFFF);
+				const int32_t from_prev = (lane == 0) ? -0x3FFFFFFF : pm + (lane - 1) * CE;
+				const int32_t from_init = -10000 + lane * CE;
+				f = from_prev > from_init ? from_prev : from_init;
+			}
+			int32_t h_last = 0;
+			uint8_t *zi = z + zoff[i];
+			for(int32_t k = 0; k < C; k++){
+				const int32_t j = j0 + k;
+				if(j < je){
+					const int32_t m = L.Hs[j & PM];
+					int32_t e = (i > 0 && j >= jbp && j < jep) ? L.Es[j & PM] : -10000;
+					uint32_t d; int32_t h;
+					if(m >= e){ d = 0; h = m; } else { d = 1; h = e; }
+					if(h < f){ d = 2; h = f; }
+					h_last = h;
+					int32_t t = m + I + E; e = e + E; if(e > t) d |= 1u << 2; else e = t;
+					t = m + D + E; f = f + E; if(f > t) d |= 2u << 4; else f = t;
+					if(qbase == ((uint32_t)(tbits >> (2 * k)) & 3u)) d |= 0x80u;
+					L.Hs[j & PM] = h; L.Es[j & PM] = e;
+					zi[j - jb] = (uint8_t)d;
+				}
+			}
+			if(je > jb && i + 1 == ql){ const int32_t lastlane = (je - 1 - jb) / C; h_last_row = __builtin_amdgcn_readlane(h_last, __builtin_amdgcn_readfirstlane(lastlane)); }
+			jbp = jb; jep = je;
+		}
+	} else {
+		/* very wide band: the same rows on lane 0, straight from the reference's loop with pool-resident rh / re */
+		unsigned long long ra = 0;
+		if(lane == 0) ra = (unsigned long long)(uintptr_t)wtz_pool_alloc(pool, (size_t)(tl + 2) * 8);
+		ra = __shfl(ra, 0, 64);
+		int32_t *rh = (int32_t*)(uintptr_t)ra;
+		if(rh == NULL) return false;
+		if(lane == 0){
+			int32_t *re = rh + (tl + 2);
+			rh[0] = 0; for(int32_t j = 1; j <= tl; j++) rh[j] = -10000;
+			for(int32_t j = 0; j <= tl; j++) re[j] = -10000;
+			for(int32_t i = 0; i < ql; i++){
+				const uint32_t qc = query.at(i);
+				int32_t h1 = -10000, f = -10000, j;
+				uint8_t *zi = z + zoff[i];
+				for(j = zb[i]; j < ze[i]; j++){
+					const bool eq = (qc == target.at(j));
+					int32_t m = rh[j] + (eq ? M : X), e, h, t; uint32_t d;
+					rh[j] = h1;
+					e = re[j];
+					if(m >= e){ d = 0; h = m; } else { d = 1; h = e; }
+					if(h < f){ d = 2; h = f; }
+					h1 = h;
+					t = m + I + E; e = e + E; if(e > t) d |= 1u << 2; else e = t;
+					re[j] = e;
+					t = m + D + E; f = f + E; if(f > t) d |= 2u << 4; else f = t;
+					if(eq) d |= 0x80u;
+					zi[j - zb[i]] = (uint8_t)d;
+				}
+				rh[j] = h1; re[j] = -10000;
+			}
+			h_last_row = rh[tl];
+		}
+		h_last_row = __shfl(h_last_row, 0, 64);
+	}
+	y.qb = qb; y.qe = qe; y.tb = tb; y.te = te;
+	y.score = wave_rows ? ((ze[ql - 1] == tl && ze[ql - 1] > zb[ql - 1]) ? h_last_row : -10000) : h_last_row;       /* rh[tl] */
+	__threadfence_block();
+	/* ---- traceback through LDS-staged blocks (the rings / target words are dead) ---- */
+	{
+		constexpr int WC = 124;
+		uint8_t *S = (uint8_t*)L.tb;
+		int32_t i_ = ql - 1, j_ = tl - 1; uint32_t d_ = 0;
+		uint32_t run_op = 0xFFu, run_len = 0;
+		wtz_cigw_t Wr; Wr.v = &out; Wr.tail = 0;
+		while(i_ >= 0 && j_ >= 0){
+			const int32_t i0 = i_, jlo = j_ - (WC - 1);
+			{
+				const int32_t r = i0 - lane;
+				if(r >= 0){
+					const int32_t b = zb[r], e = ze[r]; const uint8_t *rowp = z + zoff[r];
+					for(int32_t t = 0; t < WC; t++){ const int32_t jj = jlo + t; S[lane * WC + t] = (jj >= b && jj < e) ? rowp[jj - b] : (uint8_t)0; }
+				}
+			}
+			__threadfence_block();
+			if(lane == 0){
+				while(i_ >= 0 && j_ >= 0){
+					const int32_t rr = i0 - i_, t = j_ - jlo;
+					if(rr >= 64 || t < 0) break;
+					const uint32_t zv = S[rr * WC + t];
+					d_ = (zv >> (d_ << 1)) & 0x03;
+					if(d_ == 0){ if(zv & 0x80u) y.mat++; else y.mis++; i_--; j_--; }
+					else if(d_ == 1){ i_--; y.ins++; }
+					else { j_--; y.del++; }
+					if(d_ == run_op) run_len++;
+					else { if(run_len) wtz_cigw_push(Wr, run_op, run_len); run_op = d_; run_len = 1; }
+				}
+			}
+			i_ = __builtin_amdgcn_readfirstlane(i_); j_ = __builtin_amdgcn_readfirstlane(j_);
+			__threadfence_block();
+		}
+		if(lane == 0){
+			if(run_len) wtz_cigw_push(Wr, run_op, run_len);
+			if(i_ >= 0){ y.ins += i_ + 1; wtz_cigw_push(Wr, 1, (uint32_t)(i_ + 1)); }
+			if(j_ >= 0){ y.del += j_ + 1; wtz_cigw_push(Wr, 2, (uint32_t)(j_ + 1)); }
+			wtz_cigw_finish(Wr);
+			wtz_cigar_reverse(out.a, out.n);
+			y.aln = y.mat + y.mis + y.ins + y.del;
+		}
+	}
+	*res = wtz_bcast_aln(y);
+	return true;
+}
+
 #endif /* __HIPCC__ */
 #endif

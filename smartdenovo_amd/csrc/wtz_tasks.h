@@ -399,6 +399,111 @@ WTZ_HD void wtz_task_stitch_fin(uint32_t t, const wtz_env_t &V, const wtz_alnite
 	out[t] = r;
 }
 
+/* A11 (-n): re-align the stitched overlap of item t inside the band drawn around its own CIGAR (wtzmo.c:1031-1034) and replace
+ * result + CIGAR.  Wave-cooperative on the GPU; the host emulation has no wave and runs the plain loops. */
+#define WTZ_REFINE_LDS_BYTES (2048 * 4 * 2 + 1032 * 8)
+#if !defined(__HIP_DEVICE_COMPILE__)
+static inline bool wtz_refine_scalar(const wtz_seq_packed &query, int32_t qb, const wtz_seq_packed &target, int32_t tb, int32_t W, int32_t M, int32_t X, int32_t I, int32_t D, int32_t E,
+		const uint32_t *cig, uint32_t ncig, wtz_pool_t *pool, wtz_cigar_t &out, wtz_aln_t *res){
+	wtz_aln_t y; memset(&y, 0, sizeof y);
+	out.n = 0;
+	int32_t qe = qb, te = tb;
+	for(uint32_t i = 0; i < ncig; i++){ const uint32_t op = cig[i] & 0xFu; const int32_t len = (int32_t)(cig[i] >> 4); if(op == 0){ qe += len; te += len; } else if(op == 1) qe += len; else te += len; }
+	const int32_t ql = qe - qb, tl = te - tb;
+	if(ql == 0 || tl == 0){ *res = y; return true; }
+	int32_t *zw = (int32_t*)wtz_pool_alloc(pool, (size_t)(ql + 2) * (4 * 3 + 8) + (size_t)(tl + 2) * 8);
+	if(zw == NULL) return false;
+	int32_t *zb = zw + (ql + 2), *ze = zb + (ql + 2); unsigned long long *zoff = (unsigned long long*)(ze + (ql + 2));
+	int32_t *rh = (int32_t*)(zoff + (ql + 2)), *re = rh + (tl + 2);
+	for(int32_t i = 0; i < ql + 2; i++) zw[i] = 0;
+	int32_t qx = 0, tx = 0;
+	for(uint32_t i = 0; i < ncig; i++){
+		const uint32_t op = cig[i] & 0xFu; const int32_t len = (int32_t)(cig[i] >> 4);
+		if(op == 0){ for(int32_t j = 0; j < len; j++) zw[qx++] = W; } else if(op == 1){ for(int32_t j = 0; j < len; j++) zw[qx++] = W + len; }
+	}
+	qx = 0;
+	for(uint32_t i = 0; i < ncig; i++){
+		const uint32_t op = cig[i] & 0xFu; const int32_t len = (int32_t)(cig[i] >> 4);
+		if(op == 0) qx += len;
+		else if(op == 1){ for(int32_t j = 1; j < len && j < qx; j++) zw[qx - j] += len - j; qx += len - 1; for(int32_t j = 1; j < len && j + qx < ql; j++) zw[qx + j] += len - j; qx++; }
+		else { for(int32_t j = 1; j < len && j < qx; j++) zw[qx - j] += len - j; for(int32_t j = 1; j < len && j + qx < ql; j++) zw[qx + j] += len - j; }
+	}
+	qx = 0;
+	for(uint32_t i = 0; i < ncig; i++){
+		const uint32_t op = cig[i] & 0xFu; const int32_t len = (int32_t)(cig[i] >> 4);
+		if(op == 0 || op == 1){ for(int32_t j = 0; j < len; j++){ int32_t b = tx - zw[qx]; if(b < 0) b = 0; int32_t e = tx + 1 + zw[qx]; if(e > tl) e = tl; zb[qx] = b; ze[qx] = e; if(op == 0) tx++; qx++; } }
+		else tx += len;
+	}
+	{ int32_t b = 0; for(int32_t i = 0; i < ql; i++){ if(zb[i] < b) zb[i] = b; else if(zb[i] > b) b = zb[i]; } }
+	{ int32_t e = tl; for(int32_t i = ql - 1; i >= 0; i--){ if(ze[i] > e) ze[i] = e; else if(ze[i] < e) e = ze[i]; } }
+	unsigned long long ztot = 0;
+	for(int32_t i = 0; i < ql; i++){ zoff[i] = ztot; ztot += (unsigned long long)(ze[i] > zb[i] ? ze[i] - zb[i] : 0); }
+	uint8_t *z = (uint8_t*)wtz_pool_alloc(pool, (size_t)ztot + 64);
+	if(z == NULL) return false;
+	rh[0] = 0; for(int32_t j = 1; j <= tl; j++) rh[j] = -10000;
+	for(int32_t j = 0; j <= tl; j++) re[j] = -10000;
+	for(int32_t i = 0; i < ql; i++){
+		const uint32_t qc = query.at(i);
+		int32_t h1 = -10000, f = -10000, j;
+		uint8_t *zi = z + zoff[i];
+		for(j = zb[i]; j < ze[i]; j++){
+			const bool eq = (qc == target.at(j));
+			int32_t m = rh[j] + (eq ? M : X), e, h, t; uint32_t d;
+			rh[j] = h1;
+			e = re[j];
+			if(m >= e){ d = 0; h = m; } else { d = 1; h = e; }
+			if(h < f){ d = 2; h = f; }
+			h1 = h;
+			t = m + I + E; e = e + E; if(e > t) d |= 1u << 2; else e = t;
+			re[j] = e;
+			t = m + D + E; f = f + E; if(f > t) d |= 2u << 4; else f = t;
+			if(eq) d |= 0x80u;
+			zi[j - zb[i]] = (uint8_t)d;
+		}
+		rh[j] = h1; re[j] = -10000;
+	}
+	y.qb = qb; y.qe = qe; y.tb = tb; y.te = te; y.score = rh[tl];
+	int32_t i_ = ql - 1, j_ = tl - 1; uint32_t d_ = 0;
+	while(i_ >= 0 && j_ >= 0){
+		const uint32_t zv = (j_ >= zb[i_] && j_ < ze[i_]) ? z[zoff[i_] + (unsigned long long)(j_ - zb[i_])] : 0u;
+		d_ = (zv >> (d_ << 1)) & 0x03;
+		if(d_ == 0){ if(zv & 0x80u) y.mat++; else y.mis++; i_--; j_--; }
+		else if(d_ == 1){ i_--; y.ins++; }
+		else { j_--; y.del++; }
+		wtz_cigar_push(out, d_, 1);
+	}
+	if(i_ >= 0){ y.ins += i_ + 1; wtz_cigar_push(out, 1, (uint32_t)(i_ + 1)); }
+	if(j_ >= 0){ y.del += j_ + 1; wtz_cigar_push(out, 2, (uint32_t)(j_ + 1)); }
+	wtz_cigar_reverse(out.a, out.n);
+	y.aln = y.mat + y.mis + y.ins + y.del;
+	*res = y;
+	return true;
+}
+#endif
+
+WTZ_HD void wtz_task_refine(uint32_t t, const wtz_env_t &V, const wtz_alnitem_t *items, wtz_alnres_dev_t *res){
+	const wtz_params_t *P = V.P;
+	wtz_alnres_dev_t r = res[t];
+	if(r.n_regs == 0 || r.bad) return;
+	const wtz_alnitem_t &it = items[t];
+	const wtz_readview pb1 = wtz_view(V.R, it.q, 0), pb2 = wtz_view(V.R, it.c, it.dir);
+	wtz_cigar_t out; out.a = NULL; out.n = out.cap = 0; out.pool = V.pool; out.bad = 0;
+	if(WTZ_LANE == 0) out.init(V.pool, r.cigar_len + 64);
+	wtz_aln_t y; memset(&y, 0, sizeof y);
+	bool ok;
+#if defined(__HIP_DEVICE_COMPILE__)
+	int32_t *lds = wtz_wave_scratch();
+	wtz_wave_lds_t L; L.Hs = lds; L.Es = lds + 2048; L.tb = (uint64_t*)(lds + 4096); L.PM = 2047; L.tw = 1032;
+	ok = wtz_refine_wave(pb2.sub(r.x.qb, 1), r.x.qb, pb1.sub(r.x.tb, 1), r.x.tb, P->w, P->M, P->X, P->O, P->O, P->E, r.cigar, r.cigar_len, L, V.pool, out, &y);
+	if(WTZ_LANE != 0) return;
+#else
+	ok = wtz_refine_scalar(pb2.sub(r.x.qb, 1), r.x.qb, pb1.sub(r.x.tb, 1), r.x.tb, P->w, P->M, P->X, P->O, P->O, P->E, r.cigar, r.cigar_len, V.pool, out, &y);
+#endif
+	if(!ok || out.bad){ r.bad = 1; res[t] = r; return; }
+	r.x = y; r.cigar = out.a; r.cigar_len = out.n; r.text_len = wtz_cigar_text_len(out.a, out.n);
+	res[t] = r;
+}
+
 /* scalar execution of one extension job: host emulation, over-size jobs, and the on-device cross-check */
 WTZ_HD void wtz_task_extjob_scalar(uint32_t t, const wtz_env_t &V, wtz_extjob_t *jobs){
 	const wtz_params_t *P = V.P;

@@ -63,6 +63,8 @@ CASES = [
     ("zmo_L", "tiny.fa.gz", ZMO + ["-L", "@pairs.txt"]),
     ("zmo_F", "tiny.fa.gz", ZMO + ["-F", "@mask.txt"]),
     ("zmo_b", "tiny.fa.gz", ZMO + ["-b", "@clips.txt"]),
+    ("zmo_n", "tiny.fa.gz", ZMO + ["-n"]),                                   # A11: kswx_refine_alignment
+    ("zmo_n_w20", "tiny.fa.gz", ZMO + ["-n", "-w", "20", "-M", "3", "-X", "-4"]),
 ]
 
 
