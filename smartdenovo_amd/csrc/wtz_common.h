@@ -129,6 +129,22 @@ WTZ_D uint32_t wtz_coop_rank(bool keep, uint32_t *total){
 	*total = (uint32_t)__popcll(m);
 	return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
 }
+/* bitonic sort of one u64 key per lane across the wavefront (ascending by lane), registers + ds_bpermute only */
+WTZ_D uint64_t wtz_wave_sort64(uint64_t v){
+	const uint32_t lane = WTZ_LANE;
+	#pragma unroll
+	for(uint32_t k = 2; k <= 64; k <<= 1){
+		#pragma unroll
+		for(uint32_t j = k >> 1; j > 0; j >>= 1){
+			const uint32_t olo = (uint32_t)__shfl_xor((int)(uint32_t)v, (int)j, 64), ohi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), (int)j, 64);
+			const uint64_t o = ((uint64_t)ohi << 32) | olo;
+			const bool take_min = (((lane & k) == 0) == ((lane & j) == 0));
+			const uint64_t mn = v < o ? v : o, mx = v < o ? o : v;
+			v = take_min ? mn : mx;
+		}
+	}
+	return v;
+}
 /* minimum over all lanes, uniform */
 WTZ_D uint32_t wtz_coop_min32(uint32_t v){
 	for(int d = 32; d > 0; d >>= 1){ const uint32_t y = (uint32_t)__shfl_xor((int)v, d, 64); v = y < v ? y : v; }
@@ -152,7 +168,7 @@ static inline uint32_t wtz_coop_min32(uint32_t v){ return v; }
 /* phase profiler, compiled in only with -DWTZ_PROFILE (its same-address atomics perturb the kernels it measures):
  * shader-clock ticks / event counts accumulated per slot by lane 0 of each task; WTZ_PROFILE_PAIR=1 prints them */
 #if defined(__HIPCC__) && defined(WTZ_PROFILE)
-__device__ unsigned long long wtz_prof[16];
+__device__ unsigned long long wtz_prof[32];
 #define WTZ_PROF_T() ((unsigned long long)clock64())
 #define WTZ_PROF_ADD(slot, t0) do { if(WTZ_LANE == 0) atomicAdd(&wtz_prof[slot], (unsigned long long)clock64() - (t0)); } while(0)
 #define WTZ_PROF_CNT(slot, v) do { if(WTZ_LANE == 0) atomicAdd(&wtz_prof[slot], (unsigned long long)(v)); } while(0)

@@ -417,6 +417,7 @@ WTZ_HD uint32_t wtz_scan_windows_coop(const wtz_zhit_t *rs, uint32_t dir, uint32
 	const uint32_t lane = WTZ_LANE;
 	uint64_t *K = sc.lds;
 	uint32_t n = 0, ret = 0; int32_t me0 = -0x7FFFFFFF;
+	const unsigned long long pw0 = WTZ_PROF_T(); (void)pw0;
 	/* ---- strand / bound filter (the prefix skip of hzm_aln.h:425-431 is the same predicate: off1 is non-decreasing) ---- */
 	for(int pass = 0; pass < 2; pass++){
 		n = 0;
@@ -441,7 +442,26 @@ WTZ_HD uint32_t wtz_scan_windows_coop(const wtz_zhit_t *rs, uint32_t dir, uint32
 			return wtz_coop_bcast32(r);
 		}
 	}
+	WTZ_PROF_ADD(16, pw0); WTZ_PROF_CNT(21, 1); WTZ_PROF_CNT(22, n);
+	const unsigned long long pw1 = WTZ_PROF_T(); (void)pw1;
 	uint32_t np = 64; while(np < n) np <<= 1;
+#if defined(__HIP_DEVICE_COMPILE__)
+	bool in_regs = false;
+	if(n <= 64u){
+		/* one key per lane: the order comes out of registers; K[] keeps the ORIGINAL order for the exact path */
+		WTZ_WAVE_SYNC();
+		const uint64_t v = wtz_wave_sort64(lane < n ? K[lane] : ~0ull);
+		const uint32_t nhi = (uint32_t)__shfl_down((int)(uint32_t)(v >> 32), 1, 64);
+		const bool tie = lane + 1 < n && (uint32_t)(v >> 32) == nhi;
+		uint32_t any; (void)wtz_coop_rank(tie, &any);
+		if(any){ if(lane == 0) wtz_sort_exact(K, (size_t)n, wtz_gt_hi32()); }      /* off2 ties: the reference's swap sequence decides (hzm_aln.h:449) */
+		else if(lane < n) K[lane] = v;
+		WTZ_WAVE_SYNC();
+		in_regs = true;
+	}
+	if(!in_regs)
+#endif
+	{
 	for(uint32_t i = n + lane; i < np; i += WTZ_NLANES) K[i] = ~0ull;
 	WTZ_WAVE_SYNC();
 	wtz_coop_sort_u64(K, np);
@@ -464,9 +484,15 @@ WTZ_HD uint32_t wtz_scan_windows_coop(const wtz_zhit_t *rs, uint32_t dir, uint32
 			WTZ_WAVE_SYNC();
 		}
 	}
+	}
+	WTZ_PROF_ADD(17, pw1);
+	const unsigned long long pw2 = WTZ_PROF_T(); (void)pw2;
 	wtz_zhit_t *S = (wtz_zhit_t*)(K + np);
 	for(uint32_t x = lane; x < n; x += WTZ_NLANES) S[x] = rs[(uint32_t)K[x]];
 	WTZ_WAVE_SYNC();
+	WTZ_PROF_ADD(18, pw2);
+	const unsigned long long pw3 = WTZ_PROF_T(); (void)pw3;
+	unsigned long long pw4 = 0; (void)pw4;
 	if(lane == 0){
 		uint32_t i, j, n2 = 0, ol = 0, ol2, lst = 0, s, t;
 		uint32_t lwo = 0, lwb_o2 = 0, lwe_o2 = 0;        /* the open window: overlap and off2 of its two ends */
@@ -488,6 +514,7 @@ WTZ_HD uint32_t wtz_scan_windows_coop(const wtz_zhit_t *rs, uint32_t dir, uint32
 				} else { sc.wb[n2] = j; sc.we[n2] = i; lwo = ol; lwb_o2 = jo2; lwe_o2 = ZH_OFF2(p); n2++; }
 			}
 		}
+		WTZ_PROF_ADD(19, pw3); pw4 = WTZ_PROF_T(); WTZ_PROF_CNT(23, n2);
 		int32_t last_end1 = 0; uint32_t last_ovl = 0;
 		for(uint32_t wi = 0; wi < n2; wi++){
 			const uint32_t size = anchors.n, wb = sc.wb[wi], we = sc.we[wi];
@@ -531,6 +558,7 @@ WTZ_HD uint32_t wtz_scan_windows_coop(const wtz_zhit_t *rs, uint32_t dir, uint32
 			if(me0 < w.end[0]) me0 = w.end[0];
 		}
 	}
+	WTZ_PROF_ADD(20, pw4);
 	WTZ_WAVE_SYNC();
 	*max_e0 = (int32_t)wtz_coop_bcast32((uint32_t)me0);
 	return wtz_coop_bcast32(ret);
