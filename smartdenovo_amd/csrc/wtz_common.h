@@ -154,14 +154,21 @@ WTZ_D uint32_t wtz_coop_min32(uint32_t v){
 WTZ_D uint32_t wtz_coop_lane32(uint32_t v, uint32_t l){ return (uint32_t)__builtin_amdgcn_readlane((int)v, __builtin_amdgcn_readfirstlane((int)l)); }
 #define WTZ_WAVE_SYNC() __threadfence_block()
 #else
+/* single-lane forms for the host emulation; under hipcc's host pass they must also be callable from the (unused) host
+ * instantiation of device functions */
+#if defined(__HIPCC__)
+#define WTZ_COOP_HOST __host__ __device__ static inline
+#else
+#define WTZ_COOP_HOST static inline
+#endif
 #define WTZ_LANE 0u
 #define WTZ_NLANES 1u
-static inline uint32_t wtz_coop_excl_scan(uint32_t v, uint32_t *total){ *total = v; return 0; }
-static inline uint64_t wtz_coop_bcast64(uint64_t v){ return v; }
-static inline uint32_t wtz_coop_bcast32(uint32_t v){ return v; }
-static inline uint32_t wtz_coop_rank(bool keep, uint32_t *total){ *total = keep ? 1u : 0u; return 0; }
-static inline uint32_t wtz_coop_lane32(uint32_t v, uint32_t){ return v; }
-static inline uint32_t wtz_coop_min32(uint32_t v){ return v; }
+WTZ_COOP_HOST uint32_t wtz_coop_excl_scan(uint32_t v, uint32_t *total){ *total = v; return 0; }
+WTZ_COOP_HOST uint64_t wtz_coop_bcast64(uint64_t v){ return v; }
+WTZ_COOP_HOST uint32_t wtz_coop_bcast32(uint32_t v){ return v; }
+WTZ_COOP_HOST uint32_t wtz_coop_rank(bool keep, uint32_t *total){ *total = keep ? 1u : 0u; return 0; }
+WTZ_COOP_HOST uint32_t wtz_coop_lane32(uint32_t v, uint32_t){ return v; }
+WTZ_COOP_HOST uint32_t wtz_coop_min32(uint32_t v){ return v; }
 #define WTZ_WAVE_SYNC() do {} while(0)
 #endif
 

@@ -1378,10 +1378,13 @@ WTZ_D bool wtz_refine_wave(const wtz_seq_packed &query, int32_t qb, const wtz_se
 	const int32_t PM = L.PM;
 	wtz_aln_t y; memset(&y, 0, sizeof y);
 	if(lane == 0) out.n = 0;
+	const unsigned long long pr0 = WTZ_PROF_T(); (void)pr0;
 	int32_t qe = qb, te = tb;
 	for(uint32_t i = 0; i < ncig; i++){ const uint32_t op = cig[i] & 0xFu; const int32_t len = (int32_t)(cig[i] >> 4); if(op == 0){ qe += len; te += len; } else if(op == 1) qe += len; else te += len; }
 	const int32_t ql = qe - qb, tl = te - tb;
 	if(ql == 0 || tl == 0){ *res = y; return true; }        /* KSWX_NULL, empty CIGAR */
+	WTZ_PROF_ADD(24, pr0);
+	const unsigned long long pr1 = WTZ_PROF_T(); (void)pr1;
 	/* ---- band ---- */
 	unsigned long long ba = 0;
 	if(lane == 0) ba = (unsigned long long)(uintptr_t)wtz_pool_alloc(pool, (size_t)(ql + 2) * (4 * 3 + 8));
@@ -1392,51 +1395,113 @@ WTZ_D bool wtz_refine_wave(const wtz_seq_packed &query, int32_t qb, const wtz_se
 	for(int32_t i = lane; i < ql + 2; i += 64) zw[i] = 0;
 	__threadfence_block();
 	unsigned long long ztot = 0; int32_t maxw = 0;
-	if(lane == 0){
-		int32_t qx = 0, tx = 0;
-		for(uint32_t i = 0; i < ncig; i++){
-			const uint32_t op = cig[i] & 0xFu; const int32_t len = (int32_t)(cig[i] >> 4);
-			if(op == 0){ for(int32_t j = 0; j < len; j++) zw[qx++] = W; }
-			else if(op == 1){ for(int32_t j = 0; j < len; j++) zw[qx++] = W + len; }
-		}
-		qx = 0;
-		for(uint32_t i = 0; i < ncig; i++){
-			const uint32_t op = cig[i] & 0xFu; const int32_t len = (int32_t)(cig[i] >> 4);
-			if(op == 0) qx += len;
-			else if(op == 1){
-				for(int32_t j = 1; j < len && j < qx; j++) zw[qx - j] += len - j;
-				qx += len - 1;
-				for(int32_t j = 1; j < len && j + qx < ql; j++) zw[qx + j] += len - j;
-				qx++;
-			} else {
-				for(int32_t j = 1; j < len && j < qx; j++) zw[qx - j] += len - j;
-				for(int32_t j = 1; j < len && j + qx < ql; j++) zw[qx + j] += len - j;
+	{
+		/* every pass of the reference over the CIGAR (kswx.h:536-611) is data-parallel once each operation knows its first row /
+		 * first column: one exclusive scan; rows are then written per operation, the widening sums are order-free (atomicAdd),
+		 * and the two trims are a running maximum and a suffix minimum */
+		unsigned long long pa = 0;
+		if(lane == 0) pa = (unsigned long long)(uintptr_t)wtz_pool_alloc(pool, (size_t)(ncig + 2) * 8);
+		pa = __shfl(pa, 0, 64);
+		uint32_t *qx0 = (uint32_t*)(uintptr_t)pa;
+		if(qx0 == NULL) return false;
+		uint32_t *tx0 = qx0 + (ncig + 2);
+		{
+			uint32_t cq = 0, ct = 0;
+			for(uint32_t i0 = 0; i0 < ncig; i0 += 64){
+				const uint32_t i = i0 + lane;
+				uint32_t dq = 0, dt = 0;
+				if(i < ncig){ const uint32_t op = cig[i] & 0xFu, len = cig[i] >> 4; dq = (op == 0 || op == 1) ? len : 0; dt = (op == 0 || op == 2) ? len : 0; }
+				uint32_t tq, tt; const uint32_t eq = wtz_coop_excl_scan(dq, &tq), et = wtz_coop_excl_scan(dt, &tt);
+				if(i < ncig){ qx0[i] = cq + eq; tx0[i] = ct + et; }
+				cq += tq; ct += tt;
 			}
 		}
-		qx = 0;
-		for(uint32_t i = 0; i < ncig; i++){
-			const uint32_t op = cig[i] & 0xFu; const int32_t len = (int32_t)(cig[i] >> 4);
-			if(op == 0 || op == 1){
-				for(int32_t j = 0; j < len; j++){
-					int32_t b = tx - zw[qx]; if(b < 0) b = 0;
-					int32_t e = tx + 1 + zw[qx]; if(e > tl) e = tl;
-					zb[qx] = b; ze[qx] = e;
-					if(op == 0) tx++;
-					qx++;
-				}
-			} else tx += len;
+		__threadfence_block();
+		for(uint32_t i0 = 0; i0 < ncig; i0 += 64){        /* basic half-width: W on M rows, W + len on the rows of an insertion */
+			const uint32_t i = i0 + lane;
+			if(i < ncig){
+				const uint32_t op = cig[i] & 0xFu; const int32_t len = (int32_t)(cig[i] >> 4);
+				if(op == 0){ for(int32_t j = 0; j < len; j++) zw[qx0[i] + j] = W; }
+				else if(op == 1){ for(int32_t j = 0; j < len; j++) zw[qx0[i] + j] = W + len; }
+			}
 		}
-		int32_t b = 0; for(int32_t i = 0; i < ql; i++){ if(zb[i] < b) zb[i] = b; else if(zb[i] > b) b = zb[i]; }
-		int32_t e = tl; for(int32_t i = ql - 1; i >= 0; i--){ if(ze[i] > e) ze[i] = e; else if(ze[i] < e) e = ze[i]; }
-		for(int32_t i = 0; i < ql; i++){ const int32_t w = ze[i] > zb[i] ? ze[i] - zb[i] : 0; zoff[i] = ztot; ztot += (unsigned long long)w; if(w > maxw) maxw = w; }
+		__threadfence_block();
+		for(uint32_t i0 = 0; i0 < ncig; i0 += 64){        /* widening around indels */
+			const uint32_t i = i0 + lane;
+			if(i < ncig){
+				const uint32_t op = cig[i] & 0xFu; const int32_t len = (int32_t)(cig[i] >> 4);
+				int32_t qx = (int32_t)qx0[i];
+				if(op == 1){
+					for(int32_t j = 1; j < len && j < qx; j++) atomicAdd(&zw[qx - j], len - j);
+					qx += len - 1;
+					for(int32_t j = 1; j < len && j + qx < ql; j++) atomicAdd(&zw[qx + j], len - j);
+				} else if(op == 2){
+					for(int32_t j = 1; j < len && j < qx; j++) atomicAdd(&zw[qx - j], len - j);
+					for(int32_t j = 1; j < len && j + qx < ql; j++) atomicAdd(&zw[qx + j], len - j);
+				}
+			}
+		}
+		__threadfence_block();
+		for(uint32_t i0 = 0; i0 < ncig; i0 += 64){        /* band of every row */
+			const uint32_t i = i0 + lane;
+			if(i < ncig){
+				const uint32_t op = cig[i] & 0xFu; const int32_t len = (int32_t)(cig[i] >> 4);
+				if(op == 0 || op == 1){
+					for(int32_t j = 0; j < len; j++){
+						const int32_t row = (int32_t)qx0[i] + j, tx = (int32_t)tx0[i] + (op == 0 ? j : 0);
+						const int32_t hw = __hip_atomic_load(&zw[row], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      /* the sums were made at L2 */
+						int32_t b = tx - hw; if(b < 0) b = 0;
+						int32_t e = tx + 1 + hw; if(e > tl) e = tl;
+						zb[row] = b; ze[row] = e;
+					}
+				}
+			}
+		}
+		__threadfence_block();
+		{   /* zb: running maximum (starting from 0) */
+			int32_t carry = 0;
+			for(int32_t r0 = 0; r0 < ql; r0 += 64){
+				const int32_t r = r0 + lane;
+				const int32_t v = r < ql ? zb[r] : -0x7FFFFFFF;
+				int32_t ex = wtz_wave_max_scan_excl(v, -0x7FFFFFFF);
+				int32_t inc = ex > v ? ex : v; inc = inc > carry ? inc : carry;
+				if(r < ql) zb[r] = inc;
+				carry = __builtin_amdgcn_readlane(inc, 63);
+			}
+		}
+		{   /* ze: suffix minimum (starting from tl), as a running maximum of the negated values from the end */
+			int32_t carry = -tl;
+			for(int32_t r0 = 0; r0 < ql; r0 += 64){
+				const int32_t r = ql - 1 - (r0 + lane);
+				const int32_t v = r >= 0 ? -ze[r] : -0x7FFFFFFF;
+				int32_t ex = wtz_wave_max_scan_excl(v, -0x7FFFFFFF);
+				int32_t inc = ex > v ? ex : v; inc = inc > carry ? inc : carry;
+				if(r >= 0) ze[r] = -inc;
+				carry = __builtin_amdgcn_readlane(inc, 63);
+			}
+		}
+		__threadfence_block();
+		{   /* trace row offsets and the widest row */
+			uint32_t carry = 0;
+			for(int32_t r0 = 0; r0 < ql; r0 += 64){
+				const int32_t r = r0 + lane;
+				const uint32_t w = (r < ql && ze[r] > zb[r]) ? (uint32_t)(ze[r] - zb[r]) : 0u;
+				uint32_t tot; const uint32_t ex = wtz_coop_excl_scan(w, &tot);
+				if(r < ql) zoff[r] = (unsigned long long)carry + ex;
+				carry += tot;
+				int32_t mw = (int32_t)w; mw = wtz_wave_max_i32(mw); maxw = mw > maxw ? mw : maxw;
+			}
+			ztot = carry;
+		}
 	}
-	ztot = __shfl(ztot, 0, 64); maxw = __shfl(maxw, 0, 64);
 	unsigned long long za = 0;
 	if(lane == 0) za = (unsigned long long)(uintptr_t)wtz_pool_alloc(pool, (size_t)ztot + 64);
 	za = __shfl(za, 0, 64);
 	uint8_t *z = (uint8_t*)(uintptr_t)za;
 	if(z == NULL) return false;
 	__threadfence_block();
+	WTZ_PROF_ADD(25, pr1);
+	const unsigned long long pr2 = WTZ_PROF_T(); (void)pr2;
 	/* ---- rows ---- */
 	const int32_t C = (((maxw + 63) / 64) | 1);
 	const bool wave_rows = (maxw + 2 <= PM + 1) && C <= 31 && (tl + 63) / 32 + 1 <= L.tw;
@@ -1446,12 +1511,20 @@ WTZ_D bool wtz_refine_wave(const wtz_seq_packed &query, int32_t qb, const wtz_se
 		for(int32_t w = lane; w < nw; w += 64) L.tb[w] = wtz_pack32(target, w * 32, tl);
 		__threadfence_block();
 		int32_t jbp = 0, jep = 0; uint32_t qw_lo = 0, qw_hi = 0, qcur = 0;
+		int32_t rb = 0, re_ = 0; uint32_t ro_lo = 0, ro_hi = 0;
 		const int32_t CE = C * E;
 		for(int32_t i = 0; i < ql; i++){
 			if((i & 2047) == 0){ const uint64_t qw = wtz_pack32(query, i + lane * 32, ql); qw_lo = (uint32_t)qw; qw_hi = (uint32_t)(qw >> 32); }
 			if((i & 15) == 0){ const int32_t qs = __builtin_amdgcn_readfirstlane((i & 2047) >> 5); qcur = (i & 16) ? (uint32_t)__builtin_amdgcn_readlane((int)qw_hi, qs) : (uint32_t)__builtin_amdgcn_readlane((int)qw_lo, qs); }
 			const uint32_t qbase = (qcur >> ((i & 15) * 2)) & 3u;
-			const int32_t jb = zb[i], je = ze[i];
+			if((i & 63) == 0){      /* band and trace offset of the next 64 rows: one coalesced load each, then v_readlane per row */
+				const int32_t r = i + lane;
+				rb = r < ql ? zb[r] : 0; re_ = r < ql ? ze[r] : 0;
+				const unsigned long long zo = r < ql ? zoff[r] : 0ull; ro_lo = (uint32_t)zo; ro_hi = (uint32_t)(zo >> 32);
+			}
+			const int32_t rl = __builtin_amdgcn_readfirstlane(i & 63);
+			const int32_t jb = __builtin_amdgcn_readlane(rb, rl), je = __builtin_amdgcn_readlane(re_, rl);
+			const unsigned long long zrow_off = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)ro_hi, rl) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)ro_lo, rl);
 			const int32_t j0 = jb + lane * C;
 			uint64_t tbits;
 			{
@@ -1489,7 +1562,7 @@ WTZ_D bool wtz_refine_wave(const wtz_seq_packed &query, int32_t qb, const wtz_se
 				f = from_prev > from_init ? from_prev : from_init;
 			}
 			int32_t h_last = 0;
-			uint8_t *zi = z + zoff[i];
+			uint8_t *zi = z + zrow_off;
 			for(int32_t k = 0; k < C; k++){
 				const int32_t j = j0 + k;
 				if(j < je){
@@ -1547,6 +1620,8 @@ WTZ_D bool wtz_refine_wave(const wtz_seq_packed &query, int32_t qb, const wtz_se
 	y.qb = qb; y.qe = qe; y.tb = tb; y.te = te;
 	y.score = wave_rows ? ((ze[ql - 1] == tl && ze[ql - 1] > zb[ql - 1]) ? h_last_row : -10000) : h_last_row;       /* rh[tl] */
 	__threadfence_block();
+	WTZ_PROF_ADD(26, pr2); WTZ_PROF_CNT(29, ql); WTZ_PROF_CNT(30, 1);
+	const unsigned long long pr3 = WTZ_PROF_T(); (void)pr3;
 	/* ---- traceback through LDS-staged blocks (the rings / target words are dead) ---- */
 	{
 		constexpr int WC = 124;
@@ -1589,6 +1664,7 @@ WTZ_D bool wtz_refine_wave(const wtz_seq_packed &query, int32_t qb, const wtz_se
 			y.aln = y.mat + y.mis + y.ins + y.del;
 		}
 	}
+	WTZ_PROF_ADD(27, pr3);
 	*res = wtz_bcast_aln(y);
 	return true;
 }

@@ -62,26 +62,43 @@ WTZ_HD bool wtz_zmatch_coop(const wtz_zindex_t &Z, uint32_t q, uint32_t c, uint3
 	if(found == NULL) return false;
 	uint32_t *kcnt = found + (cn + 1);
 	uint32_t total = 0;
-	for(uint32_t k0 = 0; k0 < cn; k0 += WTZ_NLANES){
-		const uint32_t k = k0 + lane;
-		uint32_t cnt = 0, idx = 0xFFFFFFFFu;
-		if(k < cn && Z.ok[co + k]){
-			const uint32_t m = Z.mer[co + k];
-			uint32_t lo = 0, hi = qd;
-			while(lo < hi){ uint32_t mid = (lo + hi) >> 1; if(dmer[mid] < m) lo = mid + 1; else hi = mid; }
-			if(lo < qd && dmer[lo] == m){
-				idx = lo;
-				const uint32_t clen2 = Z.len[co + k], first = Z.dfirst[qo + lo], n = Z.dcnt[qo + lo];
+	/* four candidate z-mers per lane and iteration: the binary searches are chains of dependent loads, so four independent
+	 * chains in flight per lane (stepped in lockstep) hide most of their latency */
+	for(uint32_t k0 = 0; k0 < cn; k0 += 4 * WTZ_NLANES){
+		uint32_t m[4], lo[4], hi[4]; bool act[4];
+		#pragma unroll
+		for(int u = 0; u < 4; u++){
+			const uint32_t k = k0 + u * WTZ_NLANES + lane;
+			act[u] = k < cn && Z.ok[co + k];
+			m[u] = act[u] ? Z.mer[co + k] : 0u;
+			lo[u] = 0; hi[u] = act[u] ? qd : 0u;
+		}
+		for(;;){
+			bool any = false;
+			uint32_t mid[4], dv[4];
+			#pragma unroll
+			for(int u = 0; u < 4; u++){ mid[u] = (lo[u] + hi[u]) >> 1; dv[u] = (lo[u] < hi[u]) ? dmer[mid[u]] : 0u; }
+			#pragma unroll
+			for(int u = 0; u < 4; u++){ if(lo[u] < hi[u]){ if(dv[u] < m[u]) lo[u] = mid[u] + 1; else hi[u] = mid[u]; any = any || (lo[u] < hi[u]); } }
+			if(!any) break;
+		}
+		#pragma unroll
+		for(int u = 0; u < 4; u++){
+			const uint32_t k = k0 + u * WTZ_NLANES + lane;
+			uint32_t cnt = 0, idx = 0xFFFFFFFFu;
+			if(act[u] && lo[u] < qd && dmer[lo[u]] == m[u]){
+				idx = lo[u];
+				const uint32_t clen2 = Z.len[co + k], first = Z.dfirst[qo + idx], n = Z.dcnt[qo + idx];
 				for(uint32_t e = 0; e < n; e++){
 					const uint32_t qlen = Z.len[qo + Z.sidx[qo + first + e]];
-					const uint32_t dv = qlen > clen2 ? qlen - clen2 : clen2 - qlen;
-					if(dv <= max_var) cnt++;
+					const uint32_t dvv = qlen > clen2 ? qlen - clen2 : clen2 - qlen;
+					if(dvv <= max_var) cnt++;
 				}
 			}
+			if(k < cn){ found[k] = idx; kcnt[k] = cnt; }
+			uint32_t chunk; (void)wtz_coop_excl_scan(cnt, &chunk);
+			total += chunk;
 		}
-		if(k < cn){ found[k] = idx; kcnt[k] = cnt; }
-		uint32_t chunk; (void)wtz_coop_excl_scan(cnt, &chunk);
-		total += chunk;
 	}
 	pa = 0;
 	if(lane == 0) pa = (uint64_t)(uintptr_t)wtz_pool_alloc(pool, (size_t)(total + 2) * sizeof(wtz_zhit_t));

@@ -55,8 +55,17 @@ def emul_exe():
     return os.path.join(ROOT, "tests", "emul", "wtzmo_emul")
 
 
-@pytest.mark.parametrize("name", ["zmo", "dmo", "zmo_G2", "zmo_N", "zmo_A5", "zmo_B2", "zmo_edge_fq", "zmo_L", "zmo_b", "dmo_U2", "zmo_P2p1"])
+@pytest.mark.parametrize("name", ["zmo", "dmo", "zmo_G2", "zmo_N", "zmo_A5", "zmo_B2", "zmo_edge_fq", "zmo_L", "zmo_b", "dmo_U2", "zmo_P2p1", "zmo_n"])
 def test_host_logic_on_emulated_device(name, emul_exe, tmp_path):
     case = manifest()["cases"][name]
     md5, cont, _ = run_wtzmo_like(emul_exe, case, tmp_path, extra=["--batch", "16"])
     assert md5 == case["md5_full"] and cont == case["md5_contained"]
+
+
+def test_word_level_base_packing(tmp_path):
+    """wtz_pack32 (two 64-bit loads + funnel shift per 32 bases, both strands, complement) == 32 single-base extractions."""
+    exe = os.path.join(str(tmp_path), "check_pack32")
+    subprocess.run(["g++", "-std=c++17", "-O1", "-DWTZ_EMUL", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "smartdenovo_amd", "csrc"),
+                    "-o", exe, os.path.join(ROOT, "tests", "emul", "check_pack32.cpp")], check=True)
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 0 and " 0 bad" in r.stdout, r.stdout + r.stderr
