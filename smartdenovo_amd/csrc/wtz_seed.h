@@ -389,22 +389,30 @@ WTZ_HD void wtz_task_candidates(uint32_t t, wtz_reads_t R, const uint32_t *qids,
 	const uint32_t L = R.rdlen[pbid];
 	const uint32_t pblen_up = (uint32_t)(L * 1.2);                       /* double multiply, wtzmo.c:445 */
 	/* ---- A ---- */
+	const unsigned long long pcA = WTZ_PROF_T(); (void)pcA;
 	uint64_t pa = 0; uint32_t nk = 0;
-	if(lane == 0){
-		uint8_t *mem = (uint8_t*)wtz_pool_alloc(pool, (size_t)(L + 2) * 16 + (size_t)(L + 2) * 12);
-		pa = (uint64_t)(uintptr_t)mem;
-		if(mem){
-			wtz_kq_f f; f.mer = (uint64_t*)mem; f.qoff = (uint32_t*)(mem + (size_t)(L + 2) * 8); f.qlen = f.qoff + (L + 2); f.n = 0;
-			wtz_kmer_walk(R, pbid, P->ksize, P->hk, P->ksave, f);
-			nk = f.n;
-		}
-	}
-	pa = wtz_coop_bcast64(pa); nk = wtz_coop_bcast32(nk);
+	if(lane == 0) pa = (uint64_t)(uintptr_t)wtz_pool_alloc(pool, (size_t)(L + 2) * 16 + (size_t)(L + 2) * 12);
+	pa = wtz_coop_bcast64(pa);
 	if(pa == 0){ if(lane == 0) ncand_out[t] = 0xFFFFFFFFu; return; }
 	uint8_t *mem = (uint8_t*)(uintptr_t)pa;
+	{   /* every lane walks one piece of the read (exact restart: wtz_walk_warm_start), counts, then writes at its offset */
+		const uint32_t PL = (L + WTZ_NLANES - 1) / WTZ_NLANES;
+		const uint32_t jb = lane * PL, je = jb + PL;
+		uint32_t cnt = 0;
+		if(jb < L || (lane == 0 && L == 0)){ wtz_kcount_f fc; fc.n = 0; wtz_kmer_walk(R, pbid, P->ksize, P->hk, P->ksave, fc, jb, je); cnt = fc.n; }
+		uint32_t tot; const uint32_t ex = wtz_coop_excl_scan(cnt, &tot);
+		nk = tot;
+		if(cnt){
+			wtz_kq_f f; f.mer = (uint64_t*)mem; f.qoff = (uint32_t*)(mem + (size_t)(L + 2) * 8); f.qlen = f.qoff + (L + 2); f.n = ex;
+			wtz_kmer_walk(R, pbid, P->ksize, P->hk, P->ksave, f, jb, je);
+		}
+	}
+	WTZ_WAVE_SYNC();
 	const uint64_t *kmer = (const uint64_t*)mem; const uint32_t *kqoff = (const uint32_t*)(mem + (size_t)(L + 2) * 8), *kqlen = kqoff + (L + 2);
 	uint64_t *koff = (uint64_t*)(mem + (size_t)(L + 2) * 16);               /* seed run start per k-mer */
 	uint32_t *ktoff = (uint32_t*)(koff + (L + 2));                           /* tuple offset per k-mer (cnt kept in the high part of koff) */
+	WTZ_PROF_ADD(24, pcA);
+	const unsigned long long pcB = WTZ_PROF_T(); (void)pcB;
 	/* ---- B ---- */
 	uint32_t T = 0;
 	for(uint32_t e0 = 0; e0 < nk; e0 += WTZ_NLANES){
@@ -423,6 +431,8 @@ WTZ_HD void wtz_task_candidates(uint32_t t, wtz_reads_t R, const uint32_t *qids,
 		*algo_bytes += bytes;
 #endif
 	}
+	WTZ_PROF_ADD(25, pcB); WTZ_PROF_CNT(30, T); WTZ_PROF_CNT(31, nk);
+	const unsigned long long pcC = WTZ_PROF_T(); (void)pcC;
 	/* ---- C ---- */
 	uint32_t np = 64; while(np < T) np <<= 1;
 	pa = 0;
@@ -445,8 +455,12 @@ WTZ_HD void wtz_task_candidates(uint32_t t, wtz_reads_t R, const uint32_t *qids,
 			tv[base + k] = v;
 		}
 	}
+	WTZ_PROF_ADD(26, pcC);
+	const unsigned long long pcD = WTZ_PROF_T(); (void)pcD;
 	/* ---- D ---- */
 	wtz_coop_sort_u64(tup, np);
+	WTZ_PROF_ADD(27, pcD);
+	const unsigned long long pcE = WTZ_PROF_T(); (void)pcE;
 	/* ---- E ---- */
 	uint32_t ng = 0;
 	for(uint32_t i0 = 0; i0 < T; i0 += WTZ_NLANES){
@@ -473,12 +487,15 @@ WTZ_HD void wtz_task_candidates(uint32_t t, wtz_reads_t R, const uint32_t *qids,
 #if defined(__HIP_DEVICE_COMPILE__)
 	__threadfence_block();
 #endif
+	WTZ_PROF_ADD(28, pcE);
+	const unsigned long long pcF = WTZ_PROF_T(); (void)pcF;
 	/* ---- F ---- */
 	if(lane == 0){
 		uint32_t hn = ncand_out[t];                 /* heap carried across index parts (-G), 0 otherwise */
 		wtz_cand_tail(grp, ng, P->kovl, P->ncand, cand_out + (size_t)t * stride, &hn);
 		ncand_out[t] = hn;
 	}
+	WTZ_PROF_ADD(29, pcF);
 }
 
 #endif
