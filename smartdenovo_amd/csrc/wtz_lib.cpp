@@ -30,6 +30,9 @@ static int wtz_fail(int code, const char *fmt, ...){
 	return code;
 }
 
+#ifndef WTZ_CAND_LDS_BYTES
+#define WTZ_CAND_LDS_BYTES 16384u     /* LDS window of the candidate-tuple sort */
+#endif
 #ifndef WTZ_PAIR_DM_LDS_TIER2
 #define WTZ_PAIR_DM_LDS_TIER2 65536u
 #endif
@@ -548,7 +551,11 @@ extern "C" int wtz_candidates_begin(wtz_ctx_t *c, const uint32_t *qids, uint32_t
 	const wtz_reads_t R = ctx_reads(c); const wtz_params_t *dP = c->dP; const wtz_kslot_t *tab = c->ktab; const uint64_t kmask = c->kmask;
 	const uint32_t *seeds = c->kseeds; wtz_pool_t *pool = c->dpool;
 	c->cq_tm.start();
-	CHK(wtz_launch_coop<K_candidates>(0, nq, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_candidates((uint32_t)t, R, d_q, dP, tab, kmask, seeds, pool, d_cand, d_n, stride, d_bytes); }));
+#ifndef WTZ_EMUL
+	CHK(wtz_launch_coop<K_candidates>(0, nq, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_candidates((uint32_t)t, R, d_q, dP, tab, kmask, seeds, pool, d_cand, d_n, stride, d_bytes, (uint64_t*)wtz_wave_scratch(), WTZ_CAND_LDS_BYTES / 8); }, WTZ_CAND_LDS_BYTES));
+#else
+	CHK(wtz_launch_coop<K_candidates>(0, nq, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_candidates((uint32_t)t, R, d_q, dP, tab, kmask, seeds, pool, d_cand, d_n, stride, d_bytes, (uint64_t*)NULL, 0); }));
+#endif
 	c->cq_tm.lap();
 	c->cq_pending = true;
 	return WTZ_OK;

@@ -338,6 +338,77 @@ WTZ_HD void wtz_coop_sort_u64(uint64_t *w, uint32_t np){
 #endif
 }
 
+/* Bitonic sort of np (power of two) u64 words that live in HBM, through an LDS window of `ln` words (power of two): chunks
+ * of ln words are sorted entirely in LDS, and of every later merge stage only the exchanges at distance >= ln touch HBM; the
+ * rest of the stage runs on LDS-resident chunks again.  ~log2(np/ln)^2/2 + 2 log2(np/ln) passes over HBM instead of
+ * log2(np)^2/2. */
+#if defined(__HIP_DEVICE_COMPILE__)
+WTZ_D void wtz_bitonic_lds_steps(uint64_t *a, uint32_t n, uint32_t g0, uint32_t k, uint32_t jstart){
+	const uint32_t lane = WTZ_LANE;
+	for(uint32_t j = jstart; j > 0; j >>= 1){
+		for(uint32_t t0 = 0; t0 < n / 2; t0 += 256){
+			uint64_t x[4], y[4]; uint32_t ia[4];
+			#pragma unroll
+			for(int u = 0; u < 4; u++){
+				const uint32_t t = t0 + u * 64 + lane;
+				const uint32_t i = ((t / j) * (j << 1)) + (t % j);
+				ia[u] = i;
+				if(t < n / 2){ x[u] = a[i]; y[u] = a[i + j]; } else { x[u] = 0; y[u] = 0; }
+			}
+			#pragma unroll
+			for(int u = 0; u < 4; u++){
+				const uint32_t t = t0 + u * 64 + lane;
+				if(t < n / 2){ const bool asc = (((g0 + ia[u]) & k) == 0); if((x[u] > y[u]) == asc){ a[ia[u]] = y[u]; a[ia[u] + j] = x[u]; } }
+			}
+		}
+		__threadfence_block();
+	}
+}
+#endif
+WTZ_HD void wtz_coop_sort_u64_windowed(uint64_t *w, uint32_t np, uint64_t *lds, uint32_t ln){
+#if defined(__HIP_DEVICE_COMPILE__)
+	const uint32_t lane = WTZ_LANE;
+	if(lds == NULL || ln < 128u){ wtz_coop_sort_u64(w, np); return; }
+	__threadfence_block();
+	if(np <= ln){
+		for(uint32_t i = lane; i < np; i += 64) lds[i] = w[i];
+		__threadfence_block();
+		for(uint32_t k = 2; k <= np; k <<= 1) wtz_bitonic_lds_steps(lds, np, 0, k, k >> 1);
+		for(uint32_t i = lane; i < np; i += 64) w[i] = lds[i];
+		__threadfence_block();
+		return;
+	}
+	for(uint32_t c0 = 0; c0 < np; c0 += ln){        /* chunks sorted in LDS (direction of the last stage from the global index) */
+		for(uint32_t i = lane; i < ln; i += 64) lds[i] = w[c0 + i];
+		__threadfence_block();
+		for(uint32_t k = 2; k <= ln; k <<= 1) wtz_bitonic_lds_steps(lds, ln, c0, k, k >> 1);
+		for(uint32_t i = lane; i < ln; i += 64) w[c0 + i] = lds[i];
+		__threadfence_block();
+	}
+	for(uint32_t k = ln << 1; k <= np; k <<= 1){
+		for(uint32_t j = k >> 1; j >= ln; j >>= 1){   /* long-distance exchanges in HBM */
+			for(uint32_t t = lane; t < np / 2; t += 64){
+				const uint32_t i = ((t / j) * (j << 1)) + (t % j);
+				const uint64_t x = w[i], y = w[i + j];
+				const bool asc = ((i & k) == 0);
+				if((x > y) == asc){ w[i] = y; w[i + j] = x; }
+			}
+			__threadfence_block();
+		}
+		for(uint32_t c0 = 0; c0 < np; c0 += ln){    /* the rest of the stage inside LDS */
+			for(uint32_t i = lane; i < ln; i += 64) lds[i] = w[c0 + i];
+			__threadfence_block();
+			wtz_bitonic_lds_steps(lds, ln, c0, k, ln >> 1);
+			for(uint32_t i = lane; i < ln; i += 64) w[c0 + i] = lds[i];
+			__threadfence_block();
+		}
+	}
+#else
+	(void)lds; (void)ln;
+	wtz_heapsort_u64(w, np);
+#endif
+}
+
 /* the same network over 32-bit words (LDS-resident band keys of the dot-matrix engine) */
 WTZ_HD void wtz_coop_sort_u32(uint32_t *w, uint32_t np){
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -384,7 +455,7 @@ struct wtz_kq_f { uint64_t *mer; uint32_t *qoff, *qlen; uint32_t n;
  */
 WTZ_HD void wtz_task_candidates(uint32_t t, wtz_reads_t R, const uint32_t *qids, const wtz_params_t *P,
 		const wtz_kslot_t *tab, uint64_t tmask, const uint32_t *seeds, wtz_pool_t *pool, uint64_t *cand_out, uint32_t *ncand_out, uint32_t stride,
-		unsigned long long *algo_bytes){
+		unsigned long long *algo_bytes, uint64_t *lds, uint32_t lds_words){
 	const uint32_t pbid = qids[t], lane = WTZ_LANE;
 	const uint32_t L = R.rdlen[pbid];
 	const uint32_t pblen_up = (uint32_t)(L * 1.2);                       /* double multiply, wtzmo.c:445 */
@@ -458,7 +529,7 @@ WTZ_HD void wtz_task_candidates(uint32_t t, wtz_reads_t R, const uint32_t *qids,
 	WTZ_PROF_ADD(26, pcC);
 	const unsigned long long pcD = WTZ_PROF_T(); (void)pcD;
 	/* ---- D ---- */
-	wtz_coop_sort_u64(tup, np);
+	wtz_coop_sort_u64_windowed(tup, np, lds, lds_words);
 	WTZ_PROF_ADD(27, pcD);
 	const unsigned long long pcE = WTZ_PROF_T(); (void)pcE;
 	/* ---- E ---- */

@@ -30,7 +30,7 @@ typedef struct {
 #if defined(__HIP_DEVICE_COMPILE__)
 WTZ_D int32_t *wtz_wave_scratch(){ extern __shared__ int32_t wtz_dyn_lds[]; return wtz_dyn_lds; }
 #else
-static inline int32_t *wtz_wave_scratch(){ return NULL; }
+WTZ_COOP_HOST int32_t *wtz_wave_scratch(){ return NULL; }
 #endif
 
 /* all lanes of the wavefront enter; the z-mer matching is cooperative, the order-sensitive remainder runs on lane 0 */
