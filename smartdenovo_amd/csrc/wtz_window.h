@@ -171,28 +171,10 @@ WTZ_D wtz_zhit_t *wtz_sort_hits_wave(const wtz_zhit_t *hits, uint32_t n, wtz_poo
 		w[i] = v;
 	}
 	__threadfence_block();
-	for(uint32_t k = 2; k <= np; k <<= 1){
-		for(uint32_t j = k >> 1; j > 0; j >>= 1){
-			for(uint32_t t0 = 0; t0 < np / 2; t0 += 256){
-				uint64_t a[4], b[4]; uint32_t ia[4];
-				#pragma unroll
-				for(int u = 0; u < 4; u++){
-					const uint32_t t = t0 + u * 64 + lane;
-					const uint32_t i = ((t / j) * (j << 1)) + (t % j);
-					ia[u] = i;
-					if(t < np / 2){ a[u] = w[i]; b[u] = w[i + j]; } else { a[u] = 0; b[u] = 0; }
-				}
-				#pragma unroll
-				for(int u = 0; u < 4; u++){
-					const uint32_t t = t0 + u * 64 + lane;
-					if(t < np / 2){
-						const bool asc = ((ia[u] & k) == 0);
-						if((a[u] > b[u]) == asc){ w[ia[u]] = b[u]; w[ia[u] + j] = a[u]; }
-					}
-				}
-			}
-			__threadfence_block();
-		}
+	if(w == lds) wtz_coop_sort_u64(w, np);
+	else {       /* key words in HBM: sort through the LDS window (largest power of two that fits) */
+		uint32_t ln = 128; while(lds && ln * 2 <= lds_u64) ln <<= 1;
+		wtz_coop_sort_u64_windowed(w, np, lds, lds ? ln : 0);
 	}
 	/* equal keys: the swap sequence of the reference decides - except, for the (off1,off2) order of the zmo engine, when the
 	 * tied matches also agree in len1.  Those are cross-strand twins of ONE query z-mer; merge_paired_kmers_window reads
