@@ -168,7 +168,10 @@ WTZ_HD void wtz_denoise_dir(wtz_zhit_t *rs, uint32_t n_rs, uint32_t dir, wtz_dms
  * from the original order), gathered into LDS and folded into blocks.  Returns false without having changed anything
  * when the strand does not fit the LDS slice (the caller then runs wtz_denoise_dir on lane 0).
  */
-#define WTZ_DM_BCAP(lds_bytes) ((lds_bytes) >= 65536u ? 2048u : ((lds_bytes) >= 24576u ? 1024u : 512u))      /* members of one diagonal band the LDS list holds */
+#ifndef WTZ_DM_BCAP_BIG_AT
+#define WTZ_DM_BCAP_BIG_AT 49152u
+#endif
+#define WTZ_DM_BCAP(lds_bytes) ((lds_bytes) >= WTZ_DM_BCAP_BIG_AT ? 2048u : ((lds_bytes) >= 24576u ? 1024u : 512u))      /* members of one diagonal band the LDS list holds */
 #define WTZ_DM_GCAP 255u      /* linear groups of one strand (one byte per match) */
 struct wtz_gt_blk_off1 { const uint32_t *T; WTZ_HDM bool operator()(uint16_t a, uint16_t b) const { return (T[a] >> 10) > (T[b] >> 10); } };
 struct wtz_gt_hi48 { WTZ_HDM bool operator()(uint64_t a, uint64_t b) const { return (a >> 16) > (b >> 16); } };

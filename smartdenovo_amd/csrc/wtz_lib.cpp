@@ -34,7 +34,7 @@ static int wtz_fail(int code, const char *fmt, ...){
 #define WTZ_CAND_LDS_BYTES 16384u     /* LDS window of the candidate-tuple sort */
 #endif
 #ifndef WTZ_PAIR_DM_LDS_TIER2
-#define WTZ_PAIR_DM_LDS_TIER2 65536u
+#define WTZ_PAIR_DM_LDS_TIER2 49152u
 #endif
 #ifndef WTZ_PAIR_DM_LDS_TIER3
 #define WTZ_PAIR_DM_LDS_TIER3 (160u * 1024u - 512u)
