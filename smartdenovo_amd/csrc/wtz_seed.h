@@ -103,31 +103,40 @@ WTZ_HD uint64_t wtz_run_end(const uint64_t *keys, uint64_t n, uint64_t i){     /
 /* task over sorted occurrences: at run heads count distinct k-mers (ktyp) and the excess of runs over the
  * reference's saturating 16-bit counter (wtzmo.c:276), so that ktot = n_occ - excess (wtzmo.c:380-388) */
 WTZ_HD void wtz_task_kstats(uint64_t i, const uint64_t *keys, uint64_t n, unsigned long long *excess, unsigned long long *ktyp){
-	if(i && keys[i - 1] == keys[i]) return;
+	const bool head = !(i && keys[i - 1] == keys[i]);
+#if defined(__HIP_DEVICE_COMPILE__)
+	{   /* one atomic per wavefront, not per run head: they all hit the same address */
+		const unsigned long long m = __ballot(head);
+		if(m && (threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(m)) atomicAdd(ktyp, (unsigned long long)__popcll(m));
+	}
+#else
+	if(head) *ktyp += 1;
+#endif
+	if(!head) return;
 	uint64_t c = wtz_run_end(keys, n, i) - i;
 #if defined(__HIP_DEVICE_COMPILE__)
 	if(c > 0xFFFFu) atomicAdd(excess, (unsigned long long)(c - 0xFFFFu));
-	atomicAdd(ktyp, 1ull);
 #else
 	if(c > 0xFFFFu) *excess += c - 0xFFFFu;
-	*ktyp += 1;
 #endif
 }
 
 /* task: run heads with 2 <= cnt <= K are counted (tab == NULL) or inserted into the hash (wtzmo.c:396-411) */
 WTZ_HD void wtz_task_kinsert(uint64_t i, const uint64_t *keys, uint64_t n, uint32_t K, wtz_kslot_t *tab, uint64_t cap_mask, unsigned long long *n_kept){
-	if(i && keys[i - 1] == keys[i]) return;
-	uint64_t c = wtz_run_end(keys, n, i) - i;
-	if(c > 0xFFFFu) c = 0xFFFFu;
-	if(c > K || c <= 1) return;
+	const bool head = !(i && keys[i - 1] == keys[i]);
+	uint64_t c = 0;
+	if(head){ c = wtz_run_end(keys, n, i) - i; if(c > 0xFFFFu) c = 0xFFFFu; }
+	const bool kept = head && !(c > K || c <= 1);
 	if(tab == NULL){
 #if defined(__HIP_DEVICE_COMPILE__)
-		atomicAdd(n_kept, 1ull);
+		const unsigned long long m = __ballot(kept);      /* one atomic per wavefront */
+		if(m && (threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(m)) atomicAdd(n_kept, (unsigned long long)__popcll(m));
 #else
-		*n_kept += 1;
+		if(kept) *n_kept += 1;
 #endif
 		return;
 	}
+	if(!kept) return;
 	uint64_t h = wtz_mix64(keys[i]) & cap_mask;
 	for(;;){
 #if defined(__HIP_DEVICE_COMPILE__)
