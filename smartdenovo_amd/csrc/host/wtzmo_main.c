@@ -249,6 +249,14 @@ __attribute__((unused)) static char *cigar_text(const uint32_t *c, uint32_t n){ 
 	s[k] = 0; return s;
 }
 
+/* weights[i] of wtzmo.c:933-936: float = (depth rule); then float = float * (double positional factor) */
+static inline float rep_weight(const uint16_t *windeps, const wtz_params_c *P, int alen, int i){
+	float w = (windeps[i] <= P->win_rep_norm) ? 1.0 : ((windeps[i] >= P->win_rep_cutoff) ? 0.0 : P->win_rep_norm / (float)windeps[i]);
+	int df = i < alen / 2 ? alen / 2 - i : i - alen / 2;
+	w = w * (0.3 + 0.7 * (df / (alen / 2.0)));
+	return w;
+}
+
 /* ---------------- commit of one query over the batch results (wtzmo.c:806-1130) ---------------- */
 static void commit_query(eng_t *E, batch_t *b, uint32_t slot){
 	const wtz_params_c *P = &E->P;
@@ -297,7 +305,6 @@ static void commit_query(eng_t *E, batch_t *b, uint32_t slot){
 	}
 	uint16_t *windeps = (uint16_t*)calloc((size_t)alen + 1, 2);
 	int32_t *wdiff = (int32_t*)calloc((size_t)alen + 2, 4);
-	float *weights = (float*)hx_realloc(NULL, sizeof(float) * ((size_t)alen + 1));
 	seed_t *seeds = (seed_t*)hx_realloc(NULL, sizeof(seed_t) * (nc + 1)); uint32_t nseed = 0;
 	for(uint32_t i = 0; i < nc; i++){
 		const uint32_t id2 = (uint32_t)(cand[i].e >> 32);
@@ -315,13 +322,8 @@ static void commit_query(eng_t *E, batch_t *b, uint32_t slot){
 		if(S->ovl[dir] >= P->ztot){ seed_t s; s.pb2 = id2; s.dir = dir; s.ovl = S->ovl[dir]; s.closed = 0; s.pidx = cand[i].pidx; seeds[nseed++] = s; }
 	}
 	{ int32_t run = 0; for(int i = 0; i < alen; i++){ run += wdiff[i]; windeps[i] = (uint16_t)run; } }       /* uint16 wrap-around as in the reference's u2i counters */
-	/* repeat weighting: float/double mix exactly as written at wtzmo.c:933-936 */
-	for(int i = 0; i < alen; i++)
-		weights[i] = (windeps[i] <= P->win_rep_norm) ? 1.0 : ((windeps[i] >= P->win_rep_cutoff) ? 0.0 : P->win_rep_norm / (float)windeps[i]);
-	for(int i = 0; i < alen; i++){
-		int df = i < alen / 2 ? alen / 2 - i : i - alen / 2;
-		weights[i] = weights[i] * (0.3 + 0.7 * (df / (alen / 2.0)));
-	}
+	/* repeat weighting: the reference fills weights[0..alen) (wtzmo.c:933-936) but only reads the entry at the middle of each
+	 * window (954): evaluated on demand by rep_weight() with the same float/double mix */
 	for(uint32_t i = 0; i < nseed; i++){
 		seed_t *s = &seeds[i];
 		const int blen = (int)E->rdlen[s->pb2];
@@ -329,7 +331,7 @@ static void commit_query(eng_t *E, batch_t *b, uint32_t slot){
 		const wtz_winbox_t *bx = b->boxes + b->box_off[(size_t)s->pidx * 2 + s->dir];
 		uint32_t ol = 0; double avg;
 		for(uint32_t k = 0; k < S->nwin[s->dir]; k++){
-			avg = (bx[k].end[0] - bx[k].beg[0]) * weights[(bx[k].beg[0] + bx[k].end[0]) / 2];
+			avg = (bx[k].end[0] - bx[k].beg[0]) * rep_weight(windeps, P, alen, (bx[k].beg[0] + bx[k].end[0]) / 2);
 			int mid = (int)((bx[k].beg[1] + bx[k].end[1]) / 2);
 			int df = mid < blen / 2 ? blen / 2 - mid : mid - blen / 2;
 			avg = avg * (0.3 + 0.7 * (df / (blen / 2.0)));
@@ -384,7 +386,7 @@ static void commit_query(eng_t *E, batch_t *b, uint32_t slot){
 			}
 		}
 	}
-	free(cand); free(windeps); free(wdiff); free(weights); free(seeds);
+	free(cand); free(windeps); free(wdiff); free(seeds);
 }
 
 /* ---------------- one batch: plan -> GPU -> commit ---------------- */

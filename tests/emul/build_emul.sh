@@ -3,7 +3,7 @@
 # TEST INFRASTRUCTURE ONLY: lets the host driver / batching / commit logic be exercised without a GPU.
 set -e
 HERE=$(cd "$(dirname "$0")" && pwd); ROOT=$(cd "$HERE/../.." && pwd)
-g++ -std=c++17 -O2 -g -DWTZ_EMUL -ffp-contract=off -Wall -Wno-unused-function -I"$ROOT/include" -shared -fPIC \
+g++ -std=c++17 -O2 -g -DWTZ_EMUL -ffp-contract=off -Wall -Wno-unused-function -Wno-unknown-pragmas -I"$ROOT/include" -shared -fPIC \
     -o "$HERE/libwtz_emul.so" "$ROOT/smartdenovo_amd/csrc/wtz_lib.cpp"
 gcc -std=gnu11 -O2 -g -ffp-contract=off -Wall -Wextra -Wno-unused-parameter -Wno-sign-compare -I"$ROOT/include" \
     -o "$HERE/wtzmo_emul" "$ROOT/smartdenovo_amd/csrc/host/wtzmo_main.c" -L"$HERE" -lwtz_emul -Wl,-rpath,'$ORIGIN' -lstdc++ -lm -lpthread
