@@ -777,9 +777,9 @@ extern "C" int wtz_pairs_align(wtz_ctx_t *c, const uint32_t *pair_idx, const uin
 		CHK(wtz_launch_wave<K_stitch_left>(0, m, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_stitch_left((uint32_t)t, V, d_items, d_st, d_jl); }));
 		CHK(wtz_launch_coop<K_gap>(0, nwt, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_gap((uint32_t)t, V, d_wt, d_items, d_gaps); }, WTZ_GAP_LDS_BYTES));
 		CHK(run_extjobs(c, V, d_jl, m));
-		CHK(wtz_launch_wave<K_stitch_mid>(0, m, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_stitch_mid((uint32_t)t, V, d_items, d_st, d_jl, d_jr, d_gaps); }));
+		CHK(wtz_launch_coop<K_stitch_mid>(0, m, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_stitch_mid((uint32_t)t, V, d_items, d_st, d_jl, d_jr, d_gaps); }));
 		CHK(run_extjobs(c, V, d_jr, m));
-		CHK(wtz_launch_wave<K_stitch_fin>(0, m, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_stitch_fin((uint32_t)t, V, d_items, d_st, d_jl, d_jr, d_res); }));
+		CHK(wtz_launch_coop<K_stitch_fin>(0, m, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_stitch_fin((uint32_t)t, V, d_items, d_st, d_jl, d_jr, d_res); }));
 		if(c->P.refine) CHK(wtz_launch_coop<K_refine>(0, m, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_refine((uint32_t)t, V, d_items, d_res); }, WTZ_REFINE_LDS_BYTES));
 		CHK(dev_sync());
 		dev_free(d_st); dev_free(d_jl); dev_free(d_jr); dev_free(d_gaps);
@@ -835,7 +835,7 @@ extern "C" int wtz_fetch_cigar_text(wtz_ctx_t *c, char *dst, uint64_t n_bytes){
 	CHK(dev_alloc((void**)&d_off, off.size() * 8)); CHK(dev_h2d(d_off, off.data(), off.size() * 8));
 	CHK(dev_alloc((void**)&d_t, (size_t)tot + 16));
 	const wtz_alnres_dev_t *dr = c->d_alnres;
-	CHK(wtz_launch<K_cigar_text>(0, c->n_items, [=] WTZ_LAMBDA (uint64_t t){ const wtz_alnres_dev_t &r = dr[t]; if(r.text_len) wtz_cigar_text_write(r.cigar, r.cigar_len, d_t + d_off[t]); }));
+	CHK(wtz_launch_coop<K_cigar_text>(0, c->n_items, [=] WTZ_LAMBDA (uint64_t t){ const wtz_alnres_dev_t &r = dr[t]; if(r.text_len) wtz_cigar_text_write_coop(r.cigar, r.cigar_len, d_t + d_off[t]); }));
 	CHK(dev_sync());
 	CHK(dev_d2h(dst, d_t, (size_t)tot));
 	dev_free(d_off); dev_free(d_t);

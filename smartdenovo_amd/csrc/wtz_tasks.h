@@ -180,6 +180,60 @@ WTZ_HD void wtz_cigar_text_write(const uint32_t *c, uint32_t n, char *s){
 	}
 }
 
+/* ---- the same CIGAR plumbing with the whole wavefront (all lanes call with identical arguments; vectors are kept
+ *      identical on every lane, storage comes from lane 0).  Lists are a few thousand operations per overlap: looping over
+ *      them on one lane costs a dependent HBM access per operation. ---- */
+WTZ_HD bool wtz_cigar_reserve_coop(wtz_cigar_t &c, uint32_t want){
+	if(want <= c.cap) return true;
+	uint32_t cap = c.cap ? c.cap : 16; while(cap < want) cap <<= 1;
+	uint64_t a = 0;
+	if(WTZ_LANE == 0) a = (uint64_t)(uintptr_t)wtz_pool_alloc(c.pool, (size_t)cap * 4);
+	a = wtz_coop_bcast64(a);
+	uint32_t *b = (uint32_t*)(uintptr_t)a;
+	if(b == NULL){ c.bad = 1; return false; }
+	for(uint32_t i = WTZ_LANE; i < c.n; i += WTZ_NLANES) b[i] = c.a[i];
+	WTZ_WAVE_SYNC();
+	c.a = b; c.cap = cap; return true;
+}
+WTZ_HD void wtz_cigar_concat_coop(wtz_cigar_t &c, const uint32_t *src, uint32_t n){      /* kswx.h:46-52 */
+	if(n == 0) return;
+	uint32_t k0 = 0;
+	if(c.n && (c.a[c.n - 1] & 0xFu) == (src[0] & 0xFu)){ if(WTZ_LANE == 0) c.a[c.n - 1] += src[0] & 0xFFFFFFF0u; k0 = 1; }
+	if(!wtz_cigar_reserve_coop(c, c.n + n)) return;
+	for(uint32_t k = k0 + WTZ_LANE; k < n; k += WTZ_NLANES) c.a[c.n + k - k0] = src[k];
+	c.n += n - k0;
+	WTZ_WAVE_SYNC();
+}
+WTZ_HD void wtz_cigar_reverse_coop(uint32_t *a, uint32_t n){
+	for(uint32_t i = WTZ_LANE; i < n / 2; i += WTZ_NLANES){ const uint32_t t = a[i]; a[i] = a[n - 1 - i]; a[n - 1 - i] = t; }
+	WTZ_WAVE_SYNC();
+}
+WTZ_HD uint32_t wtz_cigar_text_len_coop(const uint32_t *c, uint32_t n){
+	uint32_t tot = 0;
+	for(uint32_t i0 = 0; i0 < n; i0 += WTZ_NLANES){
+		const uint32_t i = i0 + WTZ_LANE;
+		uint32_t k = 0;
+		if(i < n){ uint32_t len = c[i] >> 4; if(len){ uint32_t d = 1; while(len >= 10){ len /= 10; d++; } k = d + 1; } }
+		uint32_t t; (void)wtz_coop_excl_scan(k, &t); tot += t;
+	}
+	return tot;
+}
+WTZ_HD void wtz_cigar_text_write_coop(const uint32_t *c, uint32_t n, char *s){
+	uint32_t base = 0;
+	for(uint32_t i0 = 0; i0 < n; i0 += WTZ_NLANES){
+		const uint32_t i = i0 + WTZ_LANE;
+		uint32_t k = 0, op = 0, len = 0;
+		if(i < n){ op = c[i] & 0xFu; len = c[i] >> 4; if(len){ uint32_t l2 = len, d = 1; while(l2 >= 10){ l2 /= 10; d++; } k = d + 1; } }
+		uint32_t t; const uint32_t ex = wtz_coop_excl_scan(k, &t);
+		if(k){
+			char *o = s + base + ex; uint32_t p = k - 1;
+			o[p] = op == 0 ? 'M' : (op == 1 ? 'I' : 'D');
+			while(p){ o[--p] = (char)('0' + len % 10); len /= 10; }
+		}
+		base += t;
+	}
+}
+
 WTZ_HD wtz_readview wtz_view(const wtz_reads_t &R, uint32_t id, uint32_t rev){ wtz_readview v; v.bits = R.bits; v.off = R.rdoff[id]; v.len = R.rdlen[id]; v.rev = rev; return v; }
 
 /* launched wave-cooperatively: on the GPU the K-sw1 gaps between anchors are computed by the whole wavefront
@@ -337,9 +391,10 @@ WTZ_HD void wtz_task_stitch_mid(uint32_t t, const wtz_env_t &V, const wtz_alnite
 	const wtz_params_t *P = V.P;
 	const wtz_alnitem_t &it = items[t];
 	const int32_t M = P->M;
+	const bool l0 = (WTZ_LANE == 0);
 	wtz_stitch_state_t st = sts[t];
 	wtz_extjob_t jr; memset(&jr, 0, sizeof jr); jr.item = t;
-	if(st.nreg == 0 || st.bad){ jobsR[t] = jr; return; }
+	if(st.nreg == 0 || st.bad){ if(l0) jobsR[t] = jr; return; }
 	const wtz_readview pb1 = wtz_view(V.R, it.q, 0), pb2 = wtz_view(V.R, it.c, it.dir);
 	const int32_t len1 = (int32_t)pb1.len, len2 = (int32_t)pb2.len;
 	const wtz_gapres_t *gp = gaps + (it.regs - items[0].regs);
@@ -351,9 +406,9 @@ WTZ_HD void wtz_task_stitch_mid(uint32_t t, const wtz_env_t &V, const wtz_alnite
 		x.score = y.score - 100 * M;
 		x.aln += y.aln; x.mat += y.mat; x.mis += y.mis; x.ins += y.ins; x.del += y.del;
 		x.qb -= y.qe; x.tb -= y.te;
-		if(jl.cigar_len){ wtz_cigar_reverse(jl.cigar, jl.cigar_len); wtz_cigar_concat(st.cigar, jl.cigar, jl.cigar_len); }
+		if(jl.cigar_len){ wtz_cigar_reverse_coop(jl.cigar, jl.cigar_len); wtz_cigar_concat_coop(st.cigar, jl.cigar, jl.cigar_len); }
 	}
-	wtz_cigar_concat(st.cigar, it.regs[st.first].cigar, it.regs[st.first].cigar_len);
+	wtz_cigar_concat_coop(st.cigar, it.regs[st.first].cigar, it.regs[st.first].cigar_len);
 	for(uint32_t k = st.first + 1; k < it.nwin; k++){
 		if(it.regs[k].pass != 1) continue;
 		const wtz_reg_t *reg2 = &it.regs[k];
@@ -361,18 +416,18 @@ WTZ_HD void wtz_task_stitch_mid(uint32_t t, const wtz_env_t &V, const wtz_alnite
 		if(!g.valid || g.bad) st.bad = 1;
 		x.score += g.score;
 		x.aln += g.aln; x.mat += g.mat; x.mis += g.mis; x.ins += g.ins; x.del += g.del;
-		wtz_cigar_concat(st.cigar, g.cigar, g.cigar_len);
+		wtz_cigar_concat_coop(st.cigar, g.cigar, g.cigar_len);
 		x.score += reg2->x.score;
 		x.aln += reg2->x.aln; x.mat += reg2->x.mat; x.mis += reg2->x.mis; x.ins += reg2->x.ins; x.del += reg2->x.del;
 		x.qe = reg2->x.qe; x.te = reg2->x.te;
-		wtz_cigar_concat(st.cigar, reg2->cigar, reg2->cigar_len);
+		wtz_cigar_concat_coop(st.cigar, reg2->cigar, reg2->cigar_len);
 	}
 	if(st.cigar.bad) st.bad = 1;
 	if(x.te < len1 && x.qe < len2){
 		jr.valid = 1; jr.qlen = len2 - x.qe; jr.tlen = len1 - x.te; jr.q = pb2.sub(x.qe, 1); jr.t = pb1.sub(x.te, 1);
 		jr.init_score = x.score; jr.W = -P->ew;
 	}
-	st.x = x; sts[t] = st; jobsR[t] = jr;
+	if(l0){ st.x = x; sts[t] = st; jobsR[t] = jr; }
 }
 
 WTZ_HD void wtz_task_stitch_fin(uint32_t t, const wtz_env_t &V, const wtz_alnitem_t *items, wtz_stitch_state_t *sts, const wtz_extjob_t *jobsL, const wtz_extjob_t *jobsR, wtz_alnres_dev_t *out){
@@ -389,14 +444,14 @@ WTZ_HD void wtz_task_stitch_fin(uint32_t t, const wtz_env_t &V, const wtz_alnite
 			x.score = y.score;
 			x.aln += y.aln; x.mat += y.mat; x.mis += y.mis; x.ins += y.ins; x.del += y.del;
 			x.qe += y.qe; x.te += y.te;
-			wtz_cigar_concat(st.cigar, jr.cigar, jr.cigar_len);
+			wtz_cigar_concat_coop(st.cigar, jr.cigar, jr.cigar_len);
 			r.cells_shift += jr.cells;
 		}
 		if(jobsL[t].valid) r.cells_shift += jobsL[t].cells;
 		if(st.cigar.bad) r.bad = 1;
-		r.x = x; r.cigar = st.cigar.a; r.cigar_len = st.cigar.n; r.text_len = wtz_cigar_text_len(st.cigar.a, st.cigar.n);
+		r.x = x; r.cigar = st.cigar.a; r.cigar_len = st.cigar.n; r.text_len = wtz_cigar_text_len_coop(st.cigar.a, st.cigar.n);
 	}
-	out[t] = r;
+	if(WTZ_LANE == 0) out[t] = r;
 }
 
 /* A11 (-n): re-align the stitched overlap of item t inside the band drawn around its own CIGAR (wtzmo.c:1031-1034) and replace
