@@ -108,6 +108,17 @@ WTZ_HD void *wtz_pool_alloc(wtz_pool_t *p, size_t bytes){
 	return p->base + o;
 }
 
+/* Pointers into the pool are generic (flat) by type.  A flat store inside a loop that also reads LDS forces the compiler to
+ * wait for the store to COMPLETE before the next LDS access (a flat address might be LDS), i.e. one HBM write latency per DP
+ * row.  Stores through an explicit global-address-space pointer have no such ordering with LDS. */
+#if defined(__HIP_DEVICE_COMPILE__)
+#define WTZ_GLOBAL_AS __attribute__((address_space(1)))
+template<typename T> WTZ_D WTZ_GLOBAL_AS T *wtz_as_global(T *p){ return (WTZ_GLOBAL_AS T*)p; }
+#elif defined(__HIPCC__)
+#define WTZ_GLOBAL_AS
+template<typename T> __host__ __device__ static inline T *wtz_as_global(T *p){ return p; }
+#endif
+
 /* ---------------- wave-cooperative helpers ----------------
  * Tasks launched with wtz_launch_coop run with all 64 lanes of one wavefront; the host emulation runs them with
  * one lane.  Uniform values (pointers, counts) are produced by lane 0 and broadcast. */

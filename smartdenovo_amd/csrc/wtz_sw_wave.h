@@ -556,37 +556,45 @@ WTZ_D wtz_aln_t wtz_extend_shift_reg(int32_t qlen, const wtz_seq_packed &query, 
 	const int32_t CE = C * E, IE = I + E, DE = D + E;
 	uint32_t qw_lo = 0, qw_hi = 0, qcur = 0;
 	const int32_t colrel0 = lane * C;
+	int32_t jb_n = 0, je_n = tl; uint64_t tbits_n;
+	{
+		if(je_n > W + 1) je_n = W + 1;              /* row 0: c = 0 */
+		if(je_n > tl) je_n = tl;
+		const int32_t jj = colrel0 < tl ? colrel0 : (tl > 0 ? tl - 1 : 0);
+		const int32_t w = jj >> 5, sh = (jj & 31) * 2;
+		const uint64_t w0 = tb[w], w1 = tb[w + 1];
+		tbits_n = sh ? ((w0 >> sh) | (w1 << (64 - sh))) : w0;
+	}
+	__builtin_amdgcn_s_waitcnt(0x0F70);              /* vmcnt(0) before the loop: a load still pending at loop entry would otherwise be waited for inside every row */
 	for(i = 0; i < ql; i++){
 		if((i & 63) == 0){
+			/* Every branch of this block is wave-uniform BY CONSTRUCTION (readfirstlane) and the block ends in an explicit vmcnt(0): the
+			 * wait-count pass works on the structurised CFG, and one vector load it believes may still be in flight when the row body
+			 * starts makes every row wait for vmcnt(0) -- i.e. for the previous row's trace stores, the latency this kernel hides. */
 			const uint32_t ci = (uint32_t)i >> 6;
 			unsigned long long za = 0;
-			if(ci < tr.n_chunk){ z = zchunk[ci]; }
+			const int have = __builtin_amdgcn_readfirstlane(ci < tr.n_chunk ? 1 : 0);
+			if(have) za = (unsigned long long)(uintptr_t)wtz_as_global(zchunk)[ci];
 			else {
-				if(lane == 0){ uint8_t *p = (uint8_t*)wtz_pool_alloc(pool, (size_t)zrow * 64); zchunk[ci] = p; za = (unsigned long long)(uintptr_t)p; }
+				if(lane == 0){ uint8_t *p = (uint8_t*)wtz_pool_alloc(pool, (size_t)zrow * 64); wtz_as_global(zchunk)[ci] = p; za = (unsigned long long)(uintptr_t)p; }
 				za = __shfl(za, 0, 64);
-				z = (uint8_t*)(uintptr_t)za;
-				if(z == NULL){ *ok = false; break; }
-				tr.n_chunk = ci + 1;
 			}
+			const uint32_t zlo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)za), zhi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(za >> 32));
+			z = (uint8_t*)(uintptr_t)(((unsigned long long)zhi << 32) | zlo);
+			if((zlo | zhi) == 0){ *ok = false; break; }
+			if(!have) tr.n_chunk = ci + 1;
 			if((i & 2047) == 0){ const uint64_t qw = wtz_pack32(query, i + lane * 32, ql); qw_lo = (uint32_t)qw; qw_hi = (uint32_t)(qw >> 32); }
+			__builtin_amdgcn_s_waitcnt(0x0F70);          /* vmcnt(0), once per 64 rows */
 		}
-		int32_t jb = 0, je = tl;
-		if(jb < c - W) jb = c - W;
-		if(je > c + W + 1) je = c + W + 1;
-		if(je > tl) je = tl;
+		/* band and target bases of THIS row were prepared at the end of the previous iteration (see below) */
+		const int32_t jb = jb_n, je = je_n;
 		if((i & 15) == 0){
 			const int32_t qs = __builtin_amdgcn_readfirstlane((i & 2047) >> 5);
 			qcur = (i & 16) ? (uint32_t)__builtin_amdgcn_readlane((int)qw_hi, qs) : (uint32_t)__builtin_amdgcn_readlane((int)qw_lo, qs);
 		}
 		const uint32_t qbase = (qcur >> ((i & 15) * 2)) & 3u;
 		const int32_t j0 = jb + colrel0;
-		uint64_t tbits;
-		{
-			const int32_t jj = j0 < tl ? j0 : (tl > 0 ? tl - 1 : 0);
-			const int32_t w = jj >> 5, sh = (jj & 31) * 2;
-			const uint64_t w0 = tb[w], w1 = tb[w + 1];
-			tbits = sh ? ((w0 >> sh) | (w1 << (64 - sh))) : w0;
-		}
+		const uint64_t tbits = tbits_n;
 		/* ---- previous row into the new frame ---- */
 		if(i == 0){
 			#pragma unroll
@@ -641,16 +649,11 @@ WTZ_D wtz_aln_t wtz_extend_shift_reg(int32_t qlen, const wtz_seq_packed &query, 
 			key = (valid && kk > key) ? kk : key;
 			zw[k >> 2] |= (valid ? d : 0u) << (8 * (k & 3));
 		}
-		{
-			uint32_t *zr = (uint32_t*)(z + (size_t)(i & 63) * zrow) + lane;
-			#pragma unroll
-			for(int q4 = 0; q4 < C4; q4++) zr[(size_t)q4 * 64] = zw[q4];
-		}
 		ncell += (unsigned long long)(je - jb);
 		key = wtz_wave_max_i32(key);
 		int32_t imax = 0, mj2 = -1;
 		if((key >> 11) > 0){ imax = key >> 11; mj2 = jb + (2047 - (key & 2047)); }       /* first j with the maximum, only if > 0 (kswx.h:172) */
-		if(lane == 0) zb[i] = jb;
+		if(lane == 0) wtz_as_global(zb)[i] = jb;
 		if(je == tlen){
 			const int32_t idx = je - 1 - jb, kl = idx % C;
 			int32_t hsel = hv[0];
@@ -661,9 +664,29 @@ WTZ_D wtz_aln_t wtz_extend_shift_reg(int32_t qlen, const wtz_seq_packed &query, 
 		}
 		if(i + 1 == qlen && gmax < imax){ gmax = imax; gi = i; gj = mj2; }
 		jbp = jb;
+		bool stop = false;
 		if(imax > mx){ mx = imax; mi = i; mj = mj2; }
-		else if(imax <= 0) break;
-		c++; if(c < mj2) c++; else if(c > mj2) c--;
+		else if(imax <= 0) stop = true;
+		if(!stop){
+			c++; if(c < mj2) c++; else if(c > mj2) c--;
+			/* next row's band and its target bases (LDS) BEFORE this row's trace goes out: the wait the compiler puts in front of
+			 * an LDS read then only covers the stores of the previous row, which have had a whole row to complete */
+			jb_n = 0; je_n = tl;
+			if(jb_n < c - W) jb_n = c - W;
+			if(je_n > c + W + 1) je_n = c + W + 1;
+			if(je_n > tl) je_n = tl;
+			const int32_t j0n = jb_n + colrel0;
+			const int32_t jj = j0n < tl ? j0n : (tl > 0 ? tl - 1 : 0);
+			const int32_t w = jj >> 5, sh = (jj & 31) * 2;
+			const uint64_t w0 = tb[w], w1 = tb[w + 1];
+			tbits_n = sh ? ((w0 >> sh) | (w1 << (64 - sh))) : w0;
+		}
+		{
+			WTZ_GLOBAL_AS uint32_t *zr = wtz_as_global((uint32_t*)(z + (size_t)(i & 63) * zrow) + lane);
+			#pragma unroll
+			for(int q4 = 0; q4 < C4; q4++) zr[(size_t)q4 * 64] = zw[q4];
+		}
+		if(stop) break;
 	}
 	if(cells && lane == 0) *cells += ncell;
 	if(!*ok) return x;
