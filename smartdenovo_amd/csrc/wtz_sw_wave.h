@@ -501,6 +501,13 @@ WTZ_D void wtz_cigw_finish(wtz_cigw_t &w){ if(w.tail){ w.v->push(w.tail); w.tail
  * guarantee |h| < 2^20); the query row base is scalar (32-base words in VGPRs, v_readlane every 16 rows); LDS holds only
  * the 2-bit target.  Trace bytes, band starts and traceback are those of the rt form.
  */
+template<int V> struct wtz_ic { static constexpr int value = V; };
+template<int I, int N, typename F> WTZ_D void wtz_static_for(F &&f){ if constexpr(I < N){ f(wtz_ic<I>{}); wtz_static_for<I + 1, N>(f); } }
+/* a*b + c with 24-bit a, b in ONE VALU op; the asm keeps the compiler from turning a 0/1 factor into compare+select or from
+ * hoisting the (wave-uniform) product into a scalar register per cell */
+WTZ_D int32_t wtz_mad24(int32_t a, int32_t b, int32_t c){ int32_t r; asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+template<int K>
+WTZ_D int32_t wtz_mad24_imm(int32_t b, int32_t c){ int32_t r; asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "n"(K), "v"(b), "v"(c)); return r; }
 template<int CMAX, int S>
 WTZ_D void wtz_shift_row_inputs(int32_t (&hv)[CMAX], int32_t (&ev)[CMAX], int lane, int32_t bnd){
 	/* rewrite hv := H(i-1, j-1), ev := E(i-1, j) for the new frame j = j0_old + S + k, in place */
@@ -606,16 +613,31 @@ WTZ_D wtz_aln_t wtz_extend_shift_reg(int32_t qlen, const wtz_seq_packed &query, 
 			else if(s == 1) wtz_shift_row_inputs<C, 1>(hv, ev, lane, bnd);
 			else wtz_shift_row_inputs<C, 2>(hv, ev, lane, bnd);
 		}
+		/* The cells are instruction-issue bound (a lone wave retires one VALU op per 4 cycles), so every op per cell counts:
+		 *  - base equality comes from one 64-bit XOR per row (eqw: bit 2k set where query base == target base k), not a compare per cell;
+		 *  - the lane's F aggregate needs no validity mask: the cells right of the band end only feed lanes right of the band end;
+		 *  - the four decisions are pushed into the trace byte as the sign bit of a difference (v_sub + v_alignbit), no compare/select;
+		 *  - the arg-max key is taken from the masked H (the stored -10000 never wins) and the lane's column offset is added once.
+		 * Trace byte of this kernel (decoded when the traceback stages it): bit 4 m<e, bit 3 max(m,e)<f, bit 2 E extended, bit 1 F extended, bit 0 bases equal. */
+		const int32_t nv = je - j0;                        /* cell k of this lane is inside the band iff k < nv */
+		uint32_t eq_lo, eq_hi;
+		{
+			const uint32_t qrep = 0x55555555u * qbase;
+			const uint32_t x_lo = (uint32_t)tbits ^ qrep, x_hi = (uint32_t)(tbits >> 32) ^ qrep;
+			eq_lo = ~(x_lo | (x_lo >> 1)) & 0x55555555u; eq_hi = ~(x_hi | (x_hi >> 1)) & 0x55555555u;
+		}
+		const int32_t MX = M - X, nE = -E;
 		/* ---- m in place, the lane's F aggregate ---- */
 		int32_t agg = -0x3FFFFFFF;
-		#pragma unroll
-		for(int k = 0; k < C; k++){
-			const uint32_t tbase = (uint32_t)(tbits >> (2 * k)) & 3u;
-			const int32_t m = hv[k] + ((qbase == tbase) ? M : X);
+		wtz_static_for<0, C>([&](auto kc){
+			constexpr int k = decltype(kc)::value;
+			const int32_t b = (int32_t)(((k < 16 ? eq_lo : eq_hi) >> (2 * (k & 15))) & 1u);
+			const int32_t m = wtz_mad24(b, MX, hv[k]) + X;
 			hv[k] = m;
-			const int32_t cand = m + DE + (C - 1 - k) * E;
-			agg = ((j0 + k < je) && cand > agg) ? cand : agg;
-		}
+			const int32_t cand = wtz_mad24_imm<k>(nE, m);          /* m - k*E: the common DE + (C-1)*E is added after the loop */
+			agg = cand > agg ? cand : agg;
+		});
+		agg += DE + (C - 1) * E;
 		int32_t f;
 		{
 			const int32_t g = agg - lane * CE;
@@ -624,31 +646,35 @@ WTZ_D wtz_aln_t wtz_extend_shift_reg(int32_t qlen, const wtz_seq_packed &query, 
 			const int32_t from_init = -10000 + lane * CE;
 			f = from_prev > from_init ? from_prev : from_init;
 		}
-		/* ---- H, E', F, trace byte (bit 7: bases equal) ---- */
-		int32_t key = (int32_t)0x80000000;
+		/* ---- H, E', F, trace byte ---- */
+		int32_t key = -0x40000000, kg = -0x40000000;
 		uint32_t zw[C4];
 		#pragma unroll
 		for(int q4 = 0; q4 < C4; q4++) zw[q4] = 0;
 		#pragma unroll
 		for(int k = 0; k < C; k++){
-			const bool valid = (j0 + k < je);
+			const bool valid = (k < nv);
 			const int32_t m = hv[k], e = ev[k];
-			int32_t h = m > e ? m : e;
-			uint32_t d = (m >= e) ? 0u : 1u;
-			d = (h < f) ? 2u : d;
-			h = h > f ? h : f;
+			const int32_t h0 = m > e ? m : e;
+			uint32_t d = (uint32_t)(m - e) >> 31;                                              /* m < e */
+			d = __builtin_amdgcn_alignbit(d, (uint32_t)(h0 - f), 31);                          /* max(m,e) < f */
+			const int32_t h = h0 > f ? h0 : f;
 			const int32_t te = m + IE, e2 = e + E;
-			d |= (e2 > te) ? (1u << 2) : 0u;
+			d = __builtin_amdgcn_alignbit(d, (uint32_t)(te - e2), 31);                         /* e + E > m + I + E */
 			const int32_t en = e2 > te ? e2 : te;
 			const int32_t tf = m + DE, f2 = f + E;
-			d |= (f2 > tf) ? (2u << 4) : 0u;
+			d = __builtin_amdgcn_alignbit(d, (uint32_t)(tf - f2), 31);                         /* f + E > m + D + E */
 			f = f2 > tf ? f2 : tf;
-			d |= (qbase == ((uint32_t)(tbits >> (2 * k)) & 3u)) ? 0x80u : 0u;
-			hv[k] = valid ? h : -10000; ev[k] = valid ? en : -10000;
-			const int32_t kk = h * 2048 + (2047 - (colrel0 + k));
-			key = (valid && kk > key) ? kk : key;
+			d = (d << 1) | (((k < 16 ? eq_lo : eq_hi) >> (2 * (k & 15))) & 1u);
+			const int32_t hm = valid ? h : -10000;
+			hv[k] = hm; ev[k] = valid ? en : -10000;
+			/* arg-max key h*2048 + (2047 - column): inside a group of 16 cells the column term is an inline constant of v_lshl_add_u32 */
+			const int32_t kk = (int32_t)(((uint32_t)hm << 11) + (uint32_t)(-(k & 15)));
+			kg = kk > kg ? kk : kg;
+			if((k & 15) == 15 || k == C - 1){ const int32_t t = kg - (k & ~15); key = t > key ? t : key; kg = -0x40000000; }
 			zw[k >> 2] |= (valid ? d : 0u) << (8 * (k & 3));
 		}
+		key += 2047 - colrel0;
 		ncell += (unsigned long long)(je - jb);
 		key = wtz_wave_max_i32(key);
 		int32_t imax = 0, mj2 = -1;
@@ -714,7 +740,13 @@ WTZ_D wtz_aln_t wtz_extend_shift_reg(int32_t qlen, const wtz_seq_packed &query, 
 					for(int32_t t = 0; t < WC; t++){
 						const int32_t cc = jlo + t - zbr;
 						uint8_t v = 0;
-						if(cc >= 0 && cc < 64 * C){ const int32_t ln = cc / C, kk = cc - ln * C; v = rowp[(size_t)(kk >> 2) * 256 + (size_t)ln * 4 + (kk & 3)]; }
+						if(cc >= 0 && cc < 64 * C){
+							const int32_t ln = cc / C, kk = cc - ln * C;
+							const uint32_t r5 = rowp[(size_t)(kk >> 2) * 256 + (size_t)ln * 4 + (kk & 3)];
+							/* the kernel's 5 decision bits -> the walker's byte: bits 1:0 move from H, bits 3:2 from E, bits 5:4 from F, bit 7 bases equal */
+							const uint32_t dirh = (r5 & 8u) ? 2u : ((r5 >> 4) & 1u);
+							v = (uint8_t)(dirh | (r5 & 4u) | ((r5 & 2u) << 4) | ((r5 & 1u) << 7));
+						}
 						S[lane * WC + t] = v;
 					}
 				}
