@@ -114,9 +114,13 @@ WTZ_HD void *wtz_pool_alloc(wtz_pool_t *p, size_t bytes){
 #if defined(__HIP_DEVICE_COMPILE__)
 #define WTZ_GLOBAL_AS __attribute__((address_space(1)))
 template<typename T> WTZ_D WTZ_GLOBAL_AS T *wtz_as_global(T *p){ return (WTZ_GLOBAL_AS T*)p; }
+#define WTZ_LDS_AS __attribute__((address_space(3)))
+template<typename T> WTZ_D WTZ_LDS_AS T *wtz_as_lds(T *p){ return (WTZ_LDS_AS T*)p; }
 #elif defined(__HIPCC__)
 #define WTZ_GLOBAL_AS
 template<typename T> __host__ __device__ static inline T *wtz_as_global(T *p){ return p; }
+#define WTZ_LDS_AS
+template<typename T> __host__ __device__ static inline T *wtz_as_lds(T *p){ return p; }
 #endif
 
 /* ---------------- wave-cooperative helpers ----------------

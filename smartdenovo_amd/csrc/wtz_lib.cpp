@@ -235,6 +235,7 @@ struct wtz_ctx {
 	int device;
 #ifndef WTZ_EMUL
 	hipStream_t stream;
+	hipStream_t stream_mw = 0; hipEvent_t ev_mw_fork = 0, ev_mw_join = 0;      /* side stream of the multi-wave K-sw3 launch */
 #endif
 	bool shares_indexes;      /* clone: reads / k-mer table / z-index belong to the parent context */
 	wtz_arena arena;          /* transient device buffers of the API call in progress */
@@ -303,6 +304,8 @@ extern "C" int wtz_ctx_create(int device, const wtz_params_c *params, uint64_t p
 #ifndef WTZ_EMUL
 	c->stream = 0;
 	if(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess){ delete c; return wtz_fail(WTZ_E_HIP, "hipStreamCreate failed"); }
+	if(hipStreamCreateWithFlags(&c->stream_mw, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->ev_mw_fork, hipEventDisableTiming) != hipSuccess
+			|| hipEventCreateWithFlags(&c->ev_mw_join, hipEventDisableTiming) != hipSuccess){ delete c; return wtz_fail(WTZ_E_HIP, "hipStreamCreate failed"); }
 	g_stream = c->stream;
 #endif
 	c->bits = NULL; c->rdoff = NULL; c->rdlen = NULL; c->n_reads = 0; c->n_words = 0;
@@ -375,6 +378,7 @@ extern "C" void wtz_ctx_destroy(wtz_ctx_t *c){
 	if(!c->shares_indexes){ dev_free_persist(c->bits); dev_free_persist(c->rdoff); dev_free_persist(c->rdlen); }
 	dev_free_persist(c->dP); dev_free_persist(c->dpool); dev_free_persist(c->pool_base);
 #ifndef WTZ_EMUL
+	if(c->stream_mw){ (void)hipStreamDestroy(c->stream_mw); (void)hipEventDestroy(c->ev_mw_fork); (void)hipEventDestroy(c->ev_mw_join); }
 	if(c->stream) (void)hipStreamDestroy(c->stream);
 #endif
 	delete c;
@@ -694,7 +698,9 @@ static int run_extjobs(wtz_ctx *c, const wtz_env_t &V, wtz_extjob_t *d_jobs, uin
 	}
 	/* longest-processing-time-first: the rows of an extension are sequential, so the longest job bounds the launch;
 	 * start the long ones first (key = query-side length, the row count upper bound) */
-	uint32_t *d_order = NULL; unsigned long long ext_sum = 0; int32_t ext_max = 0;
+	uint32_t *d_order = NULL; unsigned long long ext_sum = 0; int32_t ext_max = 0; uint32_t n_mw = 0;
+	static int mw_min = -1;
+	if(mw_min < 0) mw_min = getenv("WTZ_SW_MW_MIN") ? atoi(getenv("WTZ_SW_MW_MIN")) : 512;        /* measured flat between 128 and 1024 (tools/gpu_mw_sweep.sh); 0 = one wave per job always */
 	{
 		int32_t *d_key = NULL; CHK(dev_alloc((void**)&d_key, (size_t)m * 4));
 		CHK(wtz_launch<K_misc>(0, m, [=] WTZ_LAMBDA (uint64_t t){ d_key[t] = d_jobs[t].valid ? d_jobs[t].qlen : -1; }));
@@ -703,20 +709,40 @@ static int run_extjobs(wtz_ctx *c, const wtz_env_t &V, wtz_extjob_t *d_jobs, uin
 		std::vector<uint32_t> ord(m); for(uint32_t i = 0; i < m; i++) ord[i] = i;
 		std::stable_sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t b){ return key[a] > key[b]; });
 		CHK(dev_alloc((void**)&d_order, (size_t)m * 4)); CHK(dev_h2d(d_order, ord.data(), (size_t)m * 4));
+		static int mw_top = -1;
+		if(mw_top < 0) mw_top = getenv("WTZ_SW_MW_TOP") ? atoi(getenv("WTZ_SW_MW_TOP")) : 1 << 30;
+		if(mw_min > 0) while(n_mw < m && n_mw < (uint32_t)mw_top && key[ord[n_mw]] >= mw_min) n_mw++;          /* the long jobs head the order: four waves each */
 	}
 	{
 		wtz_timer te; te.start();
 		static int use_reg = -1;
 		if(use_reg < 0) use_reg = !(getenv("WTZ_SW_NOREG") && atoi(getenv("WTZ_SW_NOREG")));
 		if(use_reg){
-			hipLaunchKernelGGL((wtz_kernel_extjobs_reg<1032>), dim3(m), dim3(64), 0, g_stream, d_jobs, (const uint32_t*)d_order, m, V.P, V.pool);
-			HIPCHK(hipGetLastError());
+			if(n_mw){
+				/* long jobs on a side stream, concurrently with the one-wave kernel over the rest */
+				HIPCHK(hipEventRecord(c->ev_mw_fork, g_stream)); HIPCHK(hipStreamWaitEvent(c->stream_mw, c->ev_mw_fork, 0));
+				hipLaunchKernelGGL((wtz_kernel_extjobs_mw<1032>), dim3(n_mw), dim3(256), 0, c->stream_mw, d_jobs, (const uint32_t*)d_order, n_mw, V.P, V.pool);
+				HIPCHK(hipGetLastError());
+				HIPCHK(hipEventRecord(c->ev_mw_join, c->stream_mw));
+			}
+			if(m > n_mw){
+				hipLaunchKernelGGL((wtz_kernel_extjobs_reg<1032>), dim3(m - n_mw), dim3(64), 0, g_stream, d_jobs, (const uint32_t*)d_order + n_mw, m - n_mw, V.P, V.pool);
+				HIPCHK(hipGetLastError());
+			}
+			if(n_mw) HIPCHK(hipStreamWaitEvent(g_stream, c->ev_mw_join, 0));
 		}
 		hipLaunchKernelGGL((wtz_kernel_extjobs<2048, 1032>), dim3(m), dim3(64), 0, g_stream, d_jobs, (const uint32_t*)d_order, m, V.P, V.pool);     /* whatever the register DP left */
 		HIPCHK(hipGetLastError());
 		const double ms_l = te.stop();
 		c->cnt.ms_ext += ms_l; c->cnt.n_extjobs += m;
-		if(getenv("WTZ_PROFILE_PAIR")) fprintf(stderr, "[ext-profile] %u jobs, rows (upper bound) sum %llu max %d, %.2f ms\n", m, ext_sum, ext_max, ms_l);
+		if(getenv("WTZ_PROFILE_PAIR")){
+			std::vector<int32_t> key(m); uint32_t nv = 0, n256 = 0, n512 = 0, n1k = 0, n2k = 0, n4k = 0; unsigned long long s512 = 0;
+			CHK(dev_sync());
+			{ std::vector<wtz_extjob_t> jj(m); CHK(dev_d2h(jj.data(), d_jobs, (size_t)m * sizeof(wtz_extjob_t))); uint32_t nd[4] = {0, 0, 0, 0}; for(uint32_t i = 0; i < m; i++){ key[i] = jj[i].valid ? jj[i].x.qe : -1; if(jj[i].valid) nd[jj[i].done & 3]++; }
+			  fprintf(stderr, "[ext-profile] n_mw %u; valid jobs finished by: nobody %u, one-wave %u, four-wave %u, general %u\n", n_mw, nd[0], nd[1], nd[2], nd[3]); }
+			for(uint32_t i = 0; i < m; i++){ if(key[i] < 0) continue; nv++; if(key[i] >= 256) n256++; if(key[i] >= 512){ n512++; s512 += key[i]; } if(key[i] >= 1024) n1k++; if(key[i] >= 2048) n2k++; if(key[i] >= 4096) n4k++; }
+			fprintf(stderr, "[ext-profile] %u jobs (%u valid), rows (upper bound) sum %llu max %d, %.2f ms; qe>=256 %u >=512 %u (sum %llu) >=1k %u >=2k %u >=4k %u\n", m, nv, ext_sum, ext_max, te.stop() + ms_l * 0, n256, n512, s512, n1k, n2k, n4k);
+		}
 		dev_free(d_order);
 	}
 	if(mode == 2){
