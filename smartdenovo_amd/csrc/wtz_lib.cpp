@@ -873,10 +873,10 @@ extern "C" int wtz_get_counters(wtz_ctx_t *c, wtz_counters_t *out){
 	*out = c->cnt;
 #if !defined(WTZ_EMUL) && defined(WTZ_PROFILE)
 	if(getenv("WTZ_PROFILE_PAIR")){        /* device phase profiler: Mticks per slot since the last report */
-		unsigned long long h[32], z[32]; memset(z, 0, sizeof z);
+		unsigned long long h[48], z[48]; memset(z, 0, sizeof z);
 		if(hipMemcpyFromSymbol(h, HIP_SYMBOL(wtz_prof), sizeof h) == hipSuccess){
 			fprintf(stderr, "[phase-profile] Mticks:");
-			for(int k = 0; k < 32; k++) fprintf(stderr, " %d:%.1f", k, (double)h[k] / 1e6);
+			for(int k = 0; k < 48; k++) fprintf(stderr, " %d:%.1f", k, (double)h[k] / 1e6);
 			fprintf(stderr, "\n");
 			(void)hipMemcpyToSymbol(HIP_SYMBOL(wtz_prof), z, sizeof z);
 		}

@@ -1613,12 +1613,15 @@ WTZ_D int32_t wtz_global_wave(int32_t qlen, const SQ &query, int32_t tlen, const
  * the fixed band moves right by one column per row once i > w, so the hand-over is the same DPP move as in K-sw1; the
  * trace is 4 bits per cell in LDS.  Besides the CIGAR runs (traceback order, in `runs`) it returns the match / mismatch
  * counts of the M runs, which the caller would otherwise have to recount base by base (hzm_aln.h:1424-1436).
- * Requirements (caller): n_col <= 64*C, ((tlen+1)/2)*zrow + 4*(qlen+tlen+4) <= LDS trace bytes, (qlen+63)/32+1 <= qb words.
+ * Requirements (caller): n_col <= 64*C, (qlen+63)/32+1 <= qb words; LDS trace (ZG false): ((tlen+1)/2)*zrow + 4*(qlen+tlen+4) <= LDS
+ * trace bytes and tlen <= 2048; pool trace (ZG true): any tlen, `stage` = 4 KB of LDS.
  */
-template<int C>
+template<int C, bool ZG = false>
 WTZ_D int32_t wtz_global_reg(int32_t qlen, const wtz_seq_packed &query, int32_t tlen, const wtz_seq_packed &target, int32_t M, int32_t X,
 		int32_t o_del, int32_t e_del, int32_t o_ins, int32_t e_ins, int32_t w, uint64_t *qb, uint8_t *ztr, uint32_t zrow,
-		uint32_t *runs, uint32_t *n_runs, int32_t *n_mat, int32_t *n_mis){
+		uint32_t *runs, uint32_t *n_runs, int32_t *n_mat, int32_t *n_mis, uint8_t *stage = NULL){
+	/* ZG: the trace does not fit LDS and lives in the pool (HBM); the rows store it through a global-address-space pointer and
+	 * the traceback walks LDS-staged blocks of 32 packed rows (64 DP rows) x the whole band (<= 4 KB in `stage`) */
 	const int lane = (int)(threadIdx.x & 63);
 	const int32_t oe_del = o_del + e_del, oe_ins = o_ins + e_ins;
 	*n_runs = 0; *n_mat = 0; *n_mis = 0;
@@ -1699,7 +1702,12 @@ WTZ_D int32_t wtz_global_reg(int32_t qlen, const wtz_seq_packed &query, int32_t 
 			f = f2 > tf ? f2 : tf;
 			hp[k] = valid[k] ? h : WTZ_MINUS_INF; ep[k] = valid[k] ? en : WTZ_MINUS_INF;
 			nib = valid[k] ? nib : 0u;
-			if(i & 1){ if((uint32_t)(colrel0 + k) < zrow) ztr[(size_t)(i >> 1) * zrow + colrel0 + k] = (uint8_t)(nibp[k] | (nib << 4)); }
+			if(i & 1){
+				if((uint32_t)(colrel0 + k) < zrow){
+					if(ZG) wtz_as_global(ztr)[(size_t)(i >> 1) * zrow + colrel0 + k] = (uint8_t)(nibp[k] | (nib << 4));
+					else ztr[(size_t)(i >> 1) * zrow + colrel0 + k] = (uint8_t)(nibp[k] | (nib << 4));
+				}
+			}
 			else nibp[k] = nib;
 		}
 		if(end > beg && i + 1 == tlen){
@@ -1717,6 +1725,55 @@ WTZ_D int32_t wtz_global_reg(int32_t qlen, const wtz_seq_packed &query, int32_t 
 	}
 	const int32_t score = (end_last == qlen) ? h_lastrow : ((qlen <= w) ? -(o_ins + e_ins * qlen) : WTZ_MINUS_INF);
 	__threadfence_block();
+	if(ZG){
+		uint32_t which = 0, nr = 0, run_op = 0xFFu, run_len = 0; int32_t mat = 0, mis = 0;
+		int32_t ii = tlen - 1, k = (ii + w + 1 < qlen ? ii + w + 1 : qlen) - 1;
+		uint32_t *stage32 = (uint32_t*)stage;
+		const int32_t RB = zrow <= 128 ? 32 : (zrow <= 256 ? 16 : 8);         /* packed rows per staged block: RB * zrow <= 4 KB */
+		int32_t cur_tblk = (tlen - 1) >> 11;                                    /* the 2048-row block of target words the DP loop left in tw_lo / tw_hi */
+		while(ii >= 0 && k >= 0){
+			const int32_t p1 = ii >> 1, p0 = p1 >= RB - 1 ? p1 - (RB - 1) : 0;
+			if((ii >> 11) != cur_tblk){
+				cur_tblk = ii >> 11;
+				const uint64_t v = wtz_pack32(target, (cur_tblk << 11) + lane * 32, tlen); tw_lo = (uint32_t)v; tw_hi = (uint32_t)(v >> 32);
+			}
+			{
+				const uint32_t nd = (uint32_t)(p1 - p0 + 1) * (zrow >> 2);
+				const uint32_t *src = (const uint32_t*)(ztr + (size_t)p0 * zrow);
+				for(uint32_t xw = (uint32_t)lane; xw < nd; xw += 64) stage32[xw] = src[xw];
+			}
+			__threadfence_block();
+			if(lane == 0){
+				while(ii >= 0 && k >= 0 && (ii >> 1) >= p0 && (ii >> 11) == cur_tblk){
+					const int32_t col = k - (ii > w ? ii - w : 0);
+					const uint32_t zv = stage[(size_t)((ii >> 1) - p0) * zrow + col];
+					const uint32_t nib = (zv >> ((ii & 1) * 4)) & 0xFu;
+					if(which == 0) which = nib & 3u; else if(which == 1) which = (nib & 4u) ? 1u : 0u; else which = (nib & 8u) ? 2u : 0u;
+					uint32_t op;
+					if(which == 0){
+						const uint32_t qv = (uint32_t)(qb[k >> 5] >> ((k & 31) * 2)) & 3u;
+						const int32_t ts = (ii & 2047) >> 5;
+						const uint32_t tv = (ii & 16) ? (uint32_t)__builtin_amdgcn_readlane((int)tw_hi, ts) : (uint32_t)__builtin_amdgcn_readlane((int)tw_lo, ts);
+						if(qv == ((tv >> ((ii & 15) * 2)) & 3u)) mat++; else mis++;
+						op = 0; --ii; --k;
+					}
+					else if(which == 1){ op = 2; --ii; }
+					else { op = 1; --k; }
+					if(op == run_op) run_len++;
+					else { if(run_len) runs[nr++] = (run_len << 4) | run_op; run_op = op; run_len = 1; }
+				}
+			}
+			ii = __builtin_amdgcn_readfirstlane(ii); k = __builtin_amdgcn_readfirstlane(k);
+			__threadfence_block();
+		}
+		if(lane == 0){
+			if(ii >= 0){ if(run_len && run_op == 2u) run_len += (uint32_t)(ii + 1); else { if(run_len) runs[nr++] = (run_len << 4) | run_op; run_op = 2u; run_len = (uint32_t)(ii + 1); } }
+			if(k >= 0){ if(run_len && run_op == 1u) run_len += (uint32_t)(k + 1); else { if(run_len) runs[nr++] = (run_len << 4) | run_op; run_op = 1u; run_len = (uint32_t)(k + 1); } }
+			if(run_len) runs[nr++] = (run_len << 4) | run_op;
+			*n_runs = nr; *n_mat = mat; *n_mis = mis;
+		}
+		return score;
+	}
 	if(lane == 0){
 		uint32_t which = 0, nr = 0, run_op = 0xFFu, run_len = 0; int32_t mat = 0, mis = 0;
 		int32_t ii = tlen - 1, k = (ii + w + 1 < qlen ? ii + w + 1 : qlen) - 1;

@@ -284,6 +284,7 @@ WTZ_HD void wtz_task_gap(uint32_t t, const wtz_env_t &V, const wtz_wintask_t *ta
 	const wtz_alnitem_t &it = items[tasks[t].item];
 	const uint32_t k = tasks[t].widx;
 	wtz_gapres_t g; memset(&g, 0, sizeof g);
+	const unsigned long long pt_task = WTZ_PROF_T(); (void)pt_task;
 	wtz_gapres_t *slot = gaps + (it.regs - items[0].regs) + k;        /* regs of all items are one contiguous array */
 	if(k == 0 || it.regs[k].pass != 1){ if(WTZ_LANE == 0) *slot = g; return; }
 	int32_t prev = -1;
@@ -311,17 +312,47 @@ WTZ_HD void wtz_task_gap(uint32_t t, const wtz_env_t &V, const wtz_wintask_t *ta
 			const int32_t n_col = dq < 2 * w + 1 ? dq : 2 * w + 1;
 			const int32_t zrow = (n_col + 3) & ~3, run_bytes = 4 * (dq + dt + 4);
 			from_reg = false;
-			if(dq > 0 && dt > 0 && n_col <= 128 && dt <= 2048 && (dq + 63) / 32 + 1 <= 128 && ((dt + 1) / 2) * zrow + run_bytes <= ztr_bytes){
+			const unsigned long long pt_g = WTZ_PROF_T(); (void)pt_g;
+			const int32_t qwords = (dq + 63) / 32 + 1, qbytes = (qwords * 8 + 15) & ~15;
+			const bool lds_shape = (dq > 0 && dt > 0 && n_col <= 128 && dt <= 2048 && qwords <= 128 && ((dt + 1) / 2) * zrow + run_bytes <= ztr_bytes);
+			const bool reg_shape = lds_shape || (dq > 0 && dt > 0 && n_col <= 512 && qbytes + 4096 <= WTZ_GAP_LDS_BYTES);
+			if(reg_shape && !lds_shape){
+				/* the 4-bit trace does not fit the LDS slice (or the band is wider than 128 columns, or the gap longer than 2048 rows):
+				 * it goes to the pool (HBM) and the traceback stages blocks of it in LDS.  Slice: query words | 4 KB stage | run list
+				 * (when it still fits, else in the pool too) */
+				uint8_t *stg = (uint8_t*)lds + qbytes;
+				const bool runs_lds = (qbytes + 4096 + run_bytes <= WTZ_GAP_LDS_BYTES);
+				unsigned long long za = 0, ra = 0;
+				if(WTZ_LANE == 0){
+					za = (unsigned long long)(uintptr_t)wtz_pool_alloc(V.pool, (size_t)((dt + 1) / 2) * zrow);
+					if(!runs_lds) ra = (unsigned long long)(uintptr_t)wtz_pool_alloc(V.pool, (size_t)run_bytes);
+				}
+				za = __shfl(za, 0, 64); ra = __shfl(ra, 0, 64);
+				if(za == 0 || (!runs_lds && ra == 0)){ bad = 1; score = 0; }
+				else {
+					runs = runs_lds ? (uint32_t*)(stg + 4096) : (uint32_t*)(uintptr_t)ra; from_reg = true;
+					uint8_t *zg = (uint8_t*)(uintptr_t)za;
+					if(n_col <= 64)       score = wtz_global_reg<1, true>(dq, q, dt, tt, M, X, -I, -E, -D, -E, w, L.tb, zg, (uint32_t)zrow, runs, &n_runs, &r_mat, &r_mis, stg);
+					else if(n_col <= 128) score = wtz_global_reg<2, true>(dq, q, dt, tt, M, X, -I, -E, -D, -E, w, L.tb, zg, (uint32_t)zrow, runs, &n_runs, &r_mat, &r_mis, stg);
+					else if(n_col <= 256) score = wtz_global_reg<4, true>(dq, q, dt, tt, M, X, -I, -E, -D, -E, w, L.tb, zg, (uint32_t)zrow, runs, &n_runs, &r_mat, &r_mis, stg);
+					else                  score = wtz_global_reg<8, true>(dq, q, dt, tt, M, X, -I, -E, -D, -E, w, L.tb, zg, (uint32_t)zrow, runs, &n_runs, &r_mat, &r_mis, stg);
+				}
+				WTZ_PROF_ADD(43, pt_g); WTZ_PROF_CNT(44, 1000000); WTZ_PROF_MAX(45, pt_g);
+			} else if(lds_shape){
 				runs = (uint32_t*)(ztr + ztr_bytes - run_bytes); from_reg = true;
 				if(n_col <= 64) score = wtz_global_reg<1>(dq, q, dt, tt, M, X, -I, -E, -D, -E, w, L.tb, ztr, (uint32_t)zrow, runs, &n_runs, &r_mat, &r_mis);
 				else            score = wtz_global_reg<2>(dq, q, dt, tt, M, X, -I, -E, -D, -E, w, L.tb, ztr, (uint32_t)zrow, runs, &n_runs, &r_mat, &r_mis);
+				WTZ_PROF_ADD(32, pt_g); WTZ_PROF_CNT(33, 1000000); WTZ_PROF_MAX(34, pt_g);
 			} else if(dq > 0 && dt > 0 && n_col + 2 <= 512 && (dq + 63) / 32 + 1 <= 128 && (dt + 63) / 64 <= WTZ_TRACE_MAXCHUNK){
 				bool ok = true;
 				score = wtz_global_wave(dq, q, dt, tt, M, X, -I, -E, -D, -E, w, L, tr, V.pool, tmp, &ok);
 				if(!ok) bad = 1;
+				WTZ_PROF_ADD(35, pt_g); WTZ_PROF_CNT(36, 1000000); WTZ_PROF_MAX(37, pt_g);
+				WTZ_PROF_CNT(46, (unsigned long long)dt * 1000); if(n_col > 256) WTZ_PROF_CNT(47, 1000000);
 			} else {
 				score = 0;
 				if(WTZ_LANE == 0){ score = wtz_global_banded(dq, q, dt, tt, M, X, -I, -E, -D, -E, w, mem, tmp); if(mem.bad) bad = 1; }
+				WTZ_PROF_ADD(38, pt_g); WTZ_PROF_CNT(39, 1000000); WTZ_PROF_MAX(40, pt_g);
 			}
 			score = __shfl(score, 0, 64);
 			if(__shfl(bad, 0, 64)){ bad = 1; break; }
@@ -341,6 +372,7 @@ WTZ_HD void wtz_task_gap(uint32_t t, const wtz_env_t &V, const wtz_wintask_t *ta
 		}
 		g.cigar = tmp.a; g.cigar_len = tmp.n; g.bad = (tmp.bad || bad);
 		*slot = g;
+		WTZ_PROF_ADD(41, pt_task); WTZ_PROF_MAX(42, pt_task);
 		return;
 	}
 #else
