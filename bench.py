@@ -13,8 +13,8 @@ gathered on rank 0 with RCCL (all_gather over xGMI) inside the timed region.  To
 
 numerator  = sum over ranks and timed steps of (len(a)+len(b)) over pairs that entered pair alignment
 value      = numerator / wall seconds of the K timed steps (max over ranks) / 1e9
-roofline   = K-sw3 (shifting-band extension, the dominant kernel): DP cell updates exactly as the reference loops execute
-             them x 12 int32 ops per cell / HIP-event time of that kernel, against the int32 VALU peak of the chip
+roofline   = K-sw3 (shifting-band extension, the dominant DP stage; two concurrent kernels): DP cell updates exactly as
+             the reference loops execute them x 12 int32 ops per cell / HIP-event time of the stage, against the int32 VALU peak
 roofline_seed = seed lookup: algorithmic bytes (L/4 + 16 B per probe + 4 B per seed entry) / kernel time vs 8 TB/s
 cpu_baseline  = the REAL reference `wtzmo -t <all cores>` (oracle/_ref, prebuilt) or the oracle port on a bounded sample
 """
@@ -204,7 +204,8 @@ def main():
                    "parity": "records identical to `wtzmo -t 1%s` (tests/test_gpu_parity.py)" % ("" if world == 1 else " -P N -p rank` per rank")},
         "pairs_per_step": n_pairs // K, "pair_bp_per_step": pair_bp // K, "records_last_step": int(last[14]),
         "kernel_ms_last_step": dict(ms, ksw3_wave=ms_ext),
-        "roofline": {"kernel": "wtz_kernel_extjobs_reg (K-sw3 shifting-band extension, one wavefront per problem, DP rows in registers)",
+        "roofline": {"kernel": "K-sw3 shifting-band extension, DP rows in registers: wtz_kernel_extjobs_mw (four wavefronts per long job, side stream) "
+                               "|| wtz_kernel_extjobs_reg (one wavefront per short job); time = HIP events around the pair of launches",
                      "bound": "valu_int32", "achieved": cells_shift * OPS_PER_CELL / (ms_ext * 1e-3) / 1e12 if ms_ext > 0 else None,
                      "peak": INT32_VALU_PEAK_TOPS, "unit": "Tint32op/s",
                      "frac": (cells_shift * OPS_PER_CELL / (ms_ext * 1e-3) / 1e12 / INT32_VALU_PEAK_TOPS) if ms_ext > 0 else None,
@@ -220,9 +221,9 @@ def main():
         import csv
         for row in csv.DictReader(open(os.path.join(ROOT, "profiles", "r01_%s_pmc_per_kernel.csv" % a.engine))):
             per_launch = float(row["hbm_bytes_est"]) / max(1, int(row["dispatches"]))
-            if row["kernel"] == "wtz_kernel_extjobs_reg":
-                res["roofline"]["traffic"] = per_launch
-                res["roofline"]["traffic_note"] = "HBM bytes per launch from profiles/r01_%s_pmc_per_kernel.csv (separate --pmc passes)" % a.engine
+            if row["kernel"] in ("wtz_kernel_extjobs_reg", "wtz_kernel_extjobs_mw"):      # the two kernels of one K-sw3 stage launch
+                res["roofline"]["traffic"] = (res["roofline"]["traffic"] or 0.0) + per_launch
+                res["roofline"]["traffic_note"] = "HBM bytes per stage launch (both kernels) from profiles/r01_%s_pmc_per_kernel.csv (separate --pmc passes)" % a.engine
             if row["kernel"] == "K_candidates":
                 res["roofline_seed"]["traffic"] = per_launch
     except Exception:

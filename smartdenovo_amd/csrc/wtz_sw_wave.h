@@ -1364,8 +1364,8 @@ WTZ_D wtz_aln_t wtz_extend_fixed_reg(int32_t qlen, const wtz_seq_packed &query, 
 
 /* up to 64 bases of a view in two registers */
 struct wtz_seq_reg2 { uint64_t w0, w1; WTZ_D uint32_t at(int32_t i) const { return (uint32_t)(((i < 32) ? (w0 >> (2 * i)) : (w1 >> (2 * (i - 32)))) & 3u); } };
-/* hz_align_hzmo (hzm_aln.h:278-314) over register-resident sequences; W == NULL only scores (the caller emits on a second
- * call once the z-mer is known to align: a mismatching z-mer must leave the CIGAR untouched) */
+/* hz_align_hzmo (hzm_aln.h:278-314) over register-resident sequences; W == NULL only scores.  A mismatching z-mer must leave
+ * the CIGAR untouched: the caller snapshots the writer (open run + vector length) and restores it when aln == 0 */
 template<typename S1, typename S2>
 WTZ_D wtz_aln_t wtz_align_zmer_w(const S1 &pb1, uint32_t len1, const S2 &pb2, uint32_t len2, int32_t M, int32_t I, int32_t D, int32_t E, wtz_cigw_t *W){
 	wtz_aln_t x, zero; memset(&zero, 0, sizeof zero); x = zero;
@@ -1457,16 +1457,18 @@ WTZ_D wtz_aln_t wtz_align_window_wave(const wtz_readview &pb1, const wtz_readvie
 			if(x.qe < off2){ x.ins += off2 - x.qe; x.aln += off2 - x.qe; wtz_cigw_push(Wc, 1, (uint32_t)(off2 - x.qe)); x.qe = off2; }
 			const uint32_t len1 = ZH_LEN1(p), len2 = ZH_LEN2(p);
 			const wtz_seq_packed z1 = pb1.sub(off1, 1), z2 = pb2.sub(off2, 1);
+			/* one pass that writes its runs; a z-mer pair that turns out not to align (aln == 0) is rolled back: the writer's
+			 * state is its open run plus the vector length */
+			const uint32_t keep_tail = Wc.tail, keep_n = cigar.n;
 			if(len1 <= 64 && len2 <= 64){
 				wtz_seq_reg2 r1, r2;
 				r1.w0 = wtz_pack32(z1, 0, (int32_t)len1); r1.w1 = wtz_pack32(z1, 32, (int32_t)len1);
 				r2.w0 = wtz_pack32(z2, 0, (int32_t)len2); r2.w1 = wtz_pack32(z2, 32, (int32_t)len2);
-				y = wtz_align_zmer_w(r1, len1, r2, len2, M, I, D, E, (wtz_cigw_t*)NULL);
-				if(y.aln) (void)wtz_align_zmer_w(r1, len1, r2, len2, M, I, D, E, &Wc);
+				y = wtz_align_zmer_w(r1, len1, r2, len2, M, I, D, E, &Wc);
 			} else {
-				y = wtz_align_zmer_w(z1, len1, z2, len2, M, I, D, E, (wtz_cigw_t*)NULL);
-				if(y.aln) (void)wtz_align_zmer_w(z1, len1, z2, len2, M, I, D, E, &Wc);
+				y = wtz_align_zmer_w(z1, len1, z2, len2, M, I, D, E, &Wc);
 			}
+			if(y.aln == 0){ Wc.tail = keep_tail; cigar.n = keep_n; }
 			if(y.aln == 0) stop = 1;
 			else {
 				x.score += y.score;
