@@ -236,6 +236,7 @@ struct wtz_ctx {
 #ifndef WTZ_EMUL
 	hipStream_t stream;
 	hipStream_t stream_mw = 0; hipEvent_t ev_mw_fork = 0, ev_mw_join = 0;      /* side stream of the multi-wave K-sw3 launch */
+	hipStream_t stream_gap = 0; hipEvent_t ev_gap_fork = 0, ev_gap_join = 0;   /* side stream of K_gap (runs beside the left extensions) */
 #endif
 	bool shares_indexes;      /* clone: reads / k-mer table / z-index belong to the parent context */
 	wtz_arena arena;          /* transient device buffers of the API call in progress */
@@ -306,6 +307,8 @@ extern "C" int wtz_ctx_create(int device, const wtz_params_c *params, uint64_t p
 	if(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess){ delete c; return wtz_fail(WTZ_E_HIP, "hipStreamCreate failed"); }
 	if(hipStreamCreateWithFlags(&c->stream_mw, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->ev_mw_fork, hipEventDisableTiming) != hipSuccess
 			|| hipEventCreateWithFlags(&c->ev_mw_join, hipEventDisableTiming) != hipSuccess){ delete c; return wtz_fail(WTZ_E_HIP, "hipStreamCreate failed"); }
+	if(hipStreamCreateWithFlags(&c->stream_gap, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->ev_gap_fork, hipEventDisableTiming) != hipSuccess
+			|| hipEventCreateWithFlags(&c->ev_gap_join, hipEventDisableTiming) != hipSuccess){ delete c; return wtz_fail(WTZ_E_HIP, "hipStreamCreate failed"); }
 	g_stream = c->stream;
 #endif
 	c->bits = NULL; c->rdoff = NULL; c->rdlen = NULL; c->n_reads = 0; c->n_words = 0;
@@ -379,6 +382,7 @@ extern "C" void wtz_ctx_destroy(wtz_ctx_t *c){
 	dev_free_persist(c->dP); dev_free_persist(c->dpool); dev_free_persist(c->pool_base);
 #ifndef WTZ_EMUL
 	if(c->stream_mw){ (void)hipStreamDestroy(c->stream_mw); (void)hipEventDestroy(c->ev_mw_fork); (void)hipEventDestroy(c->ev_mw_join); }
+	if(c->stream_gap){ (void)hipStreamDestroy(c->stream_gap); (void)hipEventDestroy(c->ev_gap_fork); (void)hipEventDestroy(c->ev_gap_join); }
 	if(c->stream) (void)hipStreamDestroy(c->stream);
 #endif
 	delete c;
@@ -801,8 +805,26 @@ extern "C" int wtz_pairs_align(wtz_ctx_t *c, const uint32_t *pair_idx, const uin
 		wtz_gapres_t *d_gaps = NULL; CHK(dev_alloc((void**)&d_gaps, (size_t)(nreg + 1) * sizeof(wtz_gapres_t)));
 		const uint64_t nwt = wt.size();
 		CHK(wtz_launch_wave<K_stitch_left>(0, m, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_stitch_left((uint32_t)t, V, d_items, d_st, d_jl); }));
+#ifdef WTZ_EMUL
 		CHK(wtz_launch_coop<K_gap>(0, nwt, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_gap((uint32_t)t, V, d_wt, d_items, d_gaps); }, WTZ_GAP_LDS_BYTES));
 		CHK(run_extjobs(c, V, d_jl, m));
+#else
+		{
+			/* the gaps between windows (many short K-sw2 tasks) and the left extensions (few long K-sw3 jobs) are independent: the
+			 * gap kernel can run on its own stream and fill the CUs the extension tail leaves idle; stitch_mid waits for both */
+			/* measured: ~5 ms of 150 on the E. coli shape, inside run-to-run noise, and it folds K_gap's contention into the K-sw3 stage
+			 * time that bench.py reports against the roofline -> opt-in (WTZ_GAP_SIDESTREAM=1) */
+			static int gap_side = -1; if(gap_side < 0) gap_side = (getenv("WTZ_GAP_SIDESTREAM") && atoi(getenv("WTZ_GAP_SIDESTREAM"))) ? 1 : 0;
+			hipStream_t main_stream = g_stream;
+			if(gap_side){ HIPCHK(hipEventRecord(c->ev_gap_fork, main_stream)); HIPCHK(hipStreamWaitEvent(c->stream_gap, c->ev_gap_fork, 0)); g_stream = c->stream_gap; }
+			const int rc_gap = wtz_launch_coop<K_gap>(0, nwt, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_gap((uint32_t)t, V, d_wt, d_items, d_gaps); }, WTZ_GAP_LDS_BYTES);
+			g_stream = main_stream;
+			CHK(rc_gap);
+			if(gap_side) HIPCHK(hipEventRecord(c->ev_gap_join, c->stream_gap));
+			CHK(run_extjobs(c, V, d_jl, m));
+			if(gap_side) HIPCHK(hipStreamWaitEvent(main_stream, c->ev_gap_join, 0));
+		}
+#endif
 		CHK(wtz_launch_coop<K_stitch_mid>(0, m, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_stitch_mid((uint32_t)t, V, d_items, d_st, d_jl, d_jr, d_gaps); }));
 		CHK(run_extjobs(c, V, d_jr, m));
 		CHK(wtz_launch_coop<K_stitch_fin>(0, m, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_stitch_fin((uint32_t)t, V, d_items, d_st, d_jl, d_jr, d_res); }));
