@@ -135,6 +135,11 @@ int  wtz_pairs_align(wtz_ctx_t *ctx, const uint32_t *pair_idx, const uint8_t *di
 int  wtz_fetch_cigars(wtz_ctx_t *ctx, uint32_t *dst, uint64_t n_ops);
 /* the same CIGARs already rendered as text on the device (what the .ovl column 17 holds): sum of text_len bytes */
 int  wtz_fetch_cigar_text(wtz_ctx_t *ctx, char *dst, uint64_t n_bytes);
+/* Page-locked host memory for the buffers the library copies results into (the CIGAR text is ~6 KB per record: a pageable
+ * destination halves the copy rate).  Plain malloc semantics otherwise; NULL on failure.  No reference counterpart: the
+ * reference formats its records in the worker's own heap (wtzmo.c:1064-1095). */
+void *wtz_host_alloc(uint64_t n_bytes);
+void  wtz_host_free(void *p);
 
 int  wtz_get_counters(wtz_ctx_t *ctx, wtz_counters_t *out);
 int  wtz_reset_counters(wtz_ctx_t *ctx);

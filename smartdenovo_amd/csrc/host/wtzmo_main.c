@@ -78,6 +78,7 @@ typedef struct {
 	uint32_t cursor, qend, B; uint64_t next_seq, commit_seq;
 	pending_t pend;
 	/* stats */
+	char *cig_keep[16]; uint64_t cig_keep_cap[16];      /* page-locked CIGAR text buffer of worker w, kept across steps (pinning is the expensive part) */
 	double t_gpu, t_commit, t_call[6];      /* t_call: wall seconds inside wtz_candidates / pairs_seed / pairs_windows / pairs_align / fetch_cigar_text / planning */
 	uint64_t spec_pairs, used_pairs, spec_items, used_items, spec_queries, used_queries, n_batches;
 	double extra_ms[5]; uint64_t extra_u64[6];      /* counters of the cloned contexts */
@@ -439,7 +440,11 @@ static int gpu_stages(eng_t *E, batch_t *b){
 			b->aln = (wtz_aln_result_t*)hx_realloc(b->aln, sizeof(wtz_aln_result_t) * b->nitem);
 			{ const double tc0 = now_s(); rc = wtz_pairs_align(b->ctx, b->it_pair, b->it_dir, b->nitem, b->aln); E->t_call[3] += now_s() - tc0; } TRY_WTZ(rc, "wtz_pairs_align");
 			uint64_t tot = 0; for(uint32_t i = 0; i < b->nitem; i++) tot += b->aln[i].text_len;
-			if(tot > b->capcig){ b->capcig = tot; b->cig = (char*)hx_realloc(b->cig, tot + 1); }
+			if(tot > b->capcig){        /* page-locked, grown geometrically: the buffer is reused by every later batch of this worker */
+				uint64_t cap = b->capcig ? b->capcig : ((uint64_t)16 << 20); while(cap < tot) cap += cap / 2;
+				wtz_host_free(b->cig); b->cig = (char*)wtz_host_alloc(cap + 1); b->capcig = cap;
+				if(!b->cig){ fprintf(stderr, "[wtzmo-mi355x] cannot allocate %llu bytes of page-locked memory for the CIGAR text\n", (unsigned long long)cap); return 1; }
+			}
 			{ const double tc0 = now_s(); rc = wtz_fetch_cigar_text(b->ctx, b->cig, tot); E->t_call[4] += now_s() - tc0; } TRY_WTZ(rc, "wtz_fetch_cigar_text");     /* rendered on the device */
 			b->ncig = tot;
 		}
@@ -500,6 +505,13 @@ static void process_range(eng_t *E, batch_t *b, uint32_t s0, uint32_t s1){
 	}
 	E->t_commit += now_s() - tg1;
 	pthread_mutex_unlock(&E->mu);
+}
+
+static void *pin_main(void *arg){
+	eng_t *E = (eng_t*)arg;
+	E->cig_keep[0] = (char*)wtz_host_alloc(E->cig_keep_cap[0] + 1);
+	if(!E->cig_keep[0]) E->cig_keep_cap[0] = 0;
+	return NULL;
 }
 
 static void *worker_main(void *arg){
@@ -755,6 +767,14 @@ int main(int argc, char **argv){
 	  E->avg_rdlen = nq ? (uint32_t)(tot / nq) : 10000; if(E->avg_rdlen == 0) E->avg_rdlen = 1; }        /* wtzmo.c:361-368 */
 	int rc = wtz_ctx_create(gpu, P, pool_gb << 30, &E->ctx); DIE_WTZ(rc, "wtz_ctx_create");
 	rc = wtz_upload_reads(E->ctx, E->st.bits, (E->st.nbase + 31) / 32, rdoff, E->rdlen, n_all); DIE_WTZ(rc, "wtz_upload_reads");
+	/* page-lock the first worker's CIGAR text buffer while the indexes are built (pinning ~100 MB takes about as long as they do) */
+	pthread_t pin_th; int pin_started = 0;
+	if(E->do_align && E->cig_keep[0] == NULL){
+		uint64_t cap = E->st.nbase < ((uint64_t)16 << 20) ? ((uint64_t)16 << 20) : (E->st.nbase > ((uint64_t)256 << 20) ? ((uint64_t)256 << 20) : E->st.nbase);
+		E->cig_keep_cap[0] = cap;
+		pin_started = (pthread_create(&pin_th, NULL, pin_main, E) == 0);
+		if(!pin_started) E->cig_keep_cap[0] = 0;
+	}
 	E->out = strcmp(output, "-") ? fopen(output, "w") : stdout;
 	if(E->out == NULL){ fprintf(stderr, " -- Cannot write %s --\n", output); exit(1); }
 	setvbuf(E->out, NULL, _IOFBF, 8u << 20);
@@ -817,6 +837,7 @@ int main(int argc, char **argv){
 			}
 		}
 		/* ---- queries: pipelined batches on n_workers contexts (own stream + pool each, indexes shared) ---- */
+		if(pin_started){ pthread_join(pin_th, NULL); pin_started = 0; }
 		{
 			const uint32_t qbeg = E->st.n_qr ? n_rd : 0;
 			E->qend = E->st.n_qr ? n_rd + E->st.n_qr : n_rd;
@@ -826,6 +847,7 @@ int main(int argc, char **argv){
 			batch_t *bs = (batch_t*)calloc(nw, sizeof(batch_t)); pthread_t *th = (pthread_t*)calloc(nw, sizeof(pthread_t));
 			for(uint32_t w = 0; w < nw; w++){
 				bs[w].E = E;
+				if(w < 16){ bs[w].cig = E->cig_keep[w]; bs[w].capcig = E->cig_keep_cap[w]; E->cig_keep[w] = NULL; E->cig_keep_cap[w] = 0; }
 				if(w == 0) bs[w].ctx = E->ctx;
 				else { rc = wtz_ctx_clone(E->ctx, pool_gb << 30, &bs[w].ctx); DIE_WTZ(rc, "wtz_ctx_clone"); }
 			}
@@ -839,7 +861,7 @@ int main(int argc, char **argv){
 					if(cw.pool_peak > E->extra_u64[5]) E->extra_u64[5] = cw.pool_peak;
 					wtz_ctx_destroy(bs[w].ctx); }
 				free(bs[w].bq); free(bs[w].want); free(bs[w].ids); free(bs[w].rows); free(bs[w].nrow); free(bs[w].pq); free(bs[w].pc); free(bs[w].rowpair); free(bs[w].sum);
-				free(bs[w].box_off); free(bs[w].boxes); free(bs[w].item_of); free(bs[w].it_pair); free(bs[w].it_dir); free(bs[w].aln); free(bs[w].cig); free(bs[w].pf_ids); free(bs[w].pf_rows); free(bs[w].pf_nr);
+				free(bs[w].box_off); free(bs[w].boxes); free(bs[w].item_of); free(bs[w].it_pair); free(bs[w].it_dir); free(bs[w].aln); if(w < 16){ E->cig_keep[w] = bs[w].cig; E->cig_keep_cap[w] = bs[w].capcig; } else wtz_host_free(bs[w].cig); free(bs[w].pf_ids); free(bs[w].pf_rows); free(bs[w].pf_nr);
 			}
 			free(bs); free(th);
 		}
@@ -879,6 +901,7 @@ int main(int argc, char **argv){
 		for(size_t i = 0; i < n; i++) fprintf(pf, "%s\t%s\n", E->st.reads[(uint32_t)(all[i] >> 33)].name, E->st.reads[(uint32_t)((all[i] & 0xFFFFFFFFu) >> 1)].name);
 		fclose(pf); free(all);
 	}
+	for(int w = 0; w < 16; w++) wtz_host_free(E->cig_keep[w]);
 	wtz_ctx_destroy(E->ctx);
 	return 0;
 }

@@ -890,6 +890,24 @@ extern "C" int wtz_fetch_cigar_text(wtz_ctx_t *c, char *dst, uint64_t n_bytes){
 	return WTZ_OK;
 }
 
+extern "C" void *wtz_host_alloc(uint64_t n_bytes){
+#ifdef WTZ_EMUL
+	return malloc((size_t)(n_bytes ? n_bytes : 1));
+#else
+	void *p = NULL;
+	if(hipHostMalloc(&p, (size_t)(n_bytes ? n_bytes : 1), hipHostMallocDefault) != hipSuccess){ (void)hipGetLastError(); return NULL; }
+	return p;
+#endif
+}
+extern "C" void wtz_host_free(void *p){
+	if(!p) return;
+#ifdef WTZ_EMUL
+	free(p);
+#else
+	(void)hipHostFree(p);
+#endif
+}
+
 extern "C" int wtz_get_counters(wtz_ctx_t *c, wtz_counters_t *out){
 	if(!c || !out) return wtz_fail(WTZ_E_ARG, "null argument");
 	*out = c->cnt;
