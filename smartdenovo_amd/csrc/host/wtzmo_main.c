@@ -23,6 +23,8 @@
 #include <unistd.h>
 #include <time.h>
 #include <pthread.h>
+#include <sys/uio.h>
+#include <errno.h>
 #include "wtz_host.h"
 
 static int usage(void){
@@ -93,7 +95,8 @@ typedef struct {       /* one batch in flight */
 	uint32_t *pq, *pc; uint32_t npair, cappair;
 	uint32_t *rowpair; size_t caprowpair;       /* pair index per (slot, row entry) */
 	wtz_pair_summary_t *sum; uint64_t *box_off; wtz_winbox_t *boxes; uint64_t nbox, capbox;
-	uint32_t *item_of; uint32_t *it_pair; uint8_t *it_dir; uint32_t nitem; wtz_aln_result_t *aln; char *cig; uint64_t ncig, capcig;
+	uint32_t *item_of; uint32_t *it_pair; uint8_t *it_dir; uint32_t nitem; wtz_aln_result_t *aln; char *cig; uint64_t ncig;
+	char *cigs[2]; uint64_t capcigs[2]; int cig_sel, cig_ext, ext_base;      /* two page-locked CIGAR text buffers, alternating per batch; ext ids of the output writer */
 	uint64_t spec_queries, used_queries;
 	int holds_turn;
 	/* candidates of the NEXT batch, requested before this batch is committed (single worker, no -G) */
@@ -108,15 +111,21 @@ static uint32_t nbest_of(const eng_t *E, uint32_t id){
 	return nb < E->P.nbest ? E->P.nbest : nb;
 }
 
-/* ---------------- output: records are formatted into large chunks by the commit and written by a writer thread,
- * so that the ~12 KB-per-record CIGAR text leaves the critical path (the next batch's GPU stages run meanwhile) ---- */
-typedef struct ochunk { char *buf; size_t n, cap; struct ochunk *next; } ochunk_t;
+/* ---------------- output: the commit formats the 16 numeric columns of a record into large chunks; the ~6 KB CIGAR text of a
+ * record is NOT copied: the chunk carries an iovec that points into the page-locked buffer wtz_fetch_cigar_text filled, and a
+ * writer thread hands the whole list to writev().  A worker owns two such buffers and alternates between them per batch; before a
+ * buffer is filled again it waits until every chunk that points into it has been written (ext_busy). ---- */
+#define OW_MAX_EXT 16
+typedef struct ochunk { char *buf; size_t n, cap, bytes; struct iovec *iov; int niov, capiov; unsigned ext_mask; struct ochunk *next; } ochunk_t;
 typedef struct {
-	FILE *fp; pthread_t th; pthread_mutex_t mu; pthread_cond_t cv;
+	FILE *fp; int fd; pthread_t th; pthread_mutex_t mu; pthread_cond_t cv, cv_ext;
 	ochunk_t *head, *tail, *freelist, *cur; int done, started;
+	int ext_busy[OW_MAX_EXT];
 } owriter_t;
 static owriter_t g_ow;
-#define OCHUNK_BYTES ((size_t)16 << 20)
+#define OCHUNK_BYTES ((size_t)4 << 20)
+#define OCHUNK_IOV 16384
+#define OCHUNK_PAYLOAD ((size_t)32 << 20)
 
 static void *owriter_main(void *arg){
 	owriter_t *w = (owriter_t*)arg;
@@ -127,17 +136,29 @@ static void *owriter_main(void *arg){
 		if(c == NULL){ pthread_mutex_unlock(&w->mu); break; }
 		w->head = c->next; if(w->head == NULL) w->tail = NULL;
 		pthread_mutex_unlock(&w->mu);
-		if(c->n && fwrite(c->buf, 1, c->n, w->fp) != c->n){ fprintf(stderr, " -- write error --\n"); exit(1); }
+		for(int i = 0; i < c->niov;){
+			int n = c->niov - i; if(n > 1024) n = 1024;
+			ssize_t r = writev(w->fd, c->iov + i, n);
+			if(r < 0){ if(errno == EINTR) continue; fprintf(stderr, " -- write error --\n"); exit(1); }
+			while(r > 0 && i < c->niov){        /* consume what was written; a partially written entry is advanced in place */
+				if((size_t)r >= c->iov[i].iov_len){ r -= (ssize_t)c->iov[i].iov_len; i++; }
+				else { c->iov[i].iov_base = (char*)c->iov[i].iov_base + r; c->iov[i].iov_len -= (size_t)r; r = 0; }
+			}
+		}
 		pthread_mutex_lock(&w->mu);
-		c->n = 0; c->next = w->freelist; w->freelist = c;
+		for(int e = 0; e < OW_MAX_EXT; e++) if(c->ext_mask & (1u << e)) w->ext_busy[e]--;
+		if(c->ext_mask) pthread_cond_broadcast(&w->cv_ext);
+		c->n = 0; c->niov = 0; c->bytes = 0; c->ext_mask = 0; c->next = w->freelist; w->freelist = c;
 		pthread_mutex_unlock(&w->mu);
 	}
 	return NULL;
 }
 static void out_start(FILE *fp){
 	owriter_t *w = &g_ow;
-	if(!w->started){ pthread_mutex_init(&w->mu, NULL); pthread_cond_init(&w->cv, NULL); }
-	w->fp = fp; w->head = w->tail = NULL; w->cur = NULL; w->done = 0; w->started = 1;
+	if(!w->started){ pthread_mutex_init(&w->mu, NULL); pthread_cond_init(&w->cv, NULL); pthread_cond_init(&w->cv_ext, NULL); }
+	fflush(fp);
+	w->fp = fp; w->fd = fileno(fp); w->head = w->tail = NULL; w->cur = NULL; w->done = 0; w->started = 1;
+	memset(w->ext_busy, 0, sizeof w->ext_busy);
 	pthread_create(&w->th, NULL, owriter_main, w);
 }
 static void out_submit(owriter_t *w){
@@ -149,21 +170,46 @@ static void out_submit(owriter_t *w){
 	pthread_cond_signal(&w->cv);
 	pthread_mutex_unlock(&w->mu);
 }
-/* room for `need` more bytes in the current chunk */
+/* room for `need` more formatted bytes (and a few iovec entries) in the current chunk */
 static char *out_space(size_t need){
 	owriter_t *w = &g_ow;
-	if(w->cur && w->cur->n + need > w->cur->cap) out_submit(w);
+	if(w->cur && (w->cur->n + need > w->cur->cap || w->cur->niov + 4 > w->cur->capiov || w->cur->bytes > OCHUNK_PAYLOAD)) out_submit(w);
 	if(w->cur == NULL){
 		pthread_mutex_lock(&w->mu);
 		ochunk_t **pp = &w->freelist, *c = NULL;
 		for(; *pp; pp = &(*pp)->next) if((*pp)->cap >= need){ c = *pp; *pp = c->next; break; }
 		pthread_mutex_unlock(&w->mu);
-		if(c == NULL){ c = (ochunk_t*)hx_realloc(NULL, sizeof(ochunk_t)); c->cap = need > OCHUNK_BYTES ? need : OCHUNK_BYTES; c->buf = (char*)hx_realloc(NULL, c->cap); }
-		c->n = 0; c->next = NULL; w->cur = c;
+		if(c == NULL){
+			c = (ochunk_t*)hx_realloc(NULL, sizeof(ochunk_t)); c->cap = need > OCHUNK_BYTES ? need : OCHUNK_BYTES; c->buf = (char*)hx_realloc(NULL, c->cap);
+			c->capiov = OCHUNK_IOV; c->iov = (struct iovec*)hx_realloc(NULL, sizeof(struct iovec) * (size_t)c->capiov);
+		}
+		c->n = 0; c->niov = 0; c->bytes = 0; c->ext_mask = 0; c->next = NULL; w->cur = c;
 	}
 	return w->cur->buf + w->cur->n;
 }
-static void out_advance(size_t n){ g_ow.cur->n += n; }
+/* n bytes were formatted at the pointer out_space returned */
+static void out_advance(size_t n){
+	ochunk_t *c = g_ow.cur;
+	char *p = c->buf + c->n;
+	if(c->niov && (char*)c->iov[c->niov - 1].iov_base + c->iov[c->niov - 1].iov_len == p) c->iov[c->niov - 1].iov_len += n;
+	else { c->iov[c->niov].iov_base = p; c->iov[c->niov].iov_len = n; c->niov++; }
+	c->n += n; c->bytes += n;
+}
+/* bytes that live in the external buffer `ext` (page-locked CIGAR text) follow: by reference */
+static void out_ext(const char *p, size_t n, int ext){
+	owriter_t *w = &g_ow; ochunk_t *c = w->cur;
+	c->iov[c->niov].iov_base = (void*)p; c->iov[c->niov].iov_len = n; c->niov++; c->bytes += n;
+	if(!(c->ext_mask & (1u << ext))){ c->ext_mask |= 1u << ext; pthread_mutex_lock(&w->mu); w->ext_busy[ext]++; pthread_mutex_unlock(&w->mu); }
+}
+/* the external buffer `ext` is about to be overwritten: everything that points into it must be on the stream */
+static void out_wait_ext(int ext){
+	owriter_t *w = &g_ow;
+	if(!w->started || ext < 0 || ext >= OW_MAX_EXT) return;
+	if(w->cur && (w->cur->ext_mask & (1u << ext))) out_submit(w);
+	pthread_mutex_lock(&w->mu);
+	while(w->ext_busy[ext] > 0) pthread_cond_wait(&w->cv_ext, &w->mu);
+	pthread_mutex_unlock(&w->mu);
+}
 /* everything formatted so far is on the stream when this returns */
 static void out_finish(void){
 	owriter_t *w = &g_ow;
@@ -225,12 +271,19 @@ static void pend_hit(pending_t *p, const hit_t *h){
 }
 
 /* one .ovl line (print_hits_wtzmo, wtzmo.c:1170-1249) into the output stream; cigar == NULL prints "0M" */
-static void emit_record(eng_t *E, const hit_t *h, const char *cigar, size_t cigar_len){
+static void emit_record(eng_t *E, const hit_t *h, const char *cigar, size_t cigar_len, int ext){
 	const hx_read_t *reads = E->st.reads;
 	const int aln = h->aln == 0 ? 1 : h->aln;
-	char *o = out_space(strlen(reads[h->pb1].name) + strlen(reads[h->pb2].name) + 256 + cigar_len);
+	const int by_ref = (cigar && ext >= 0 && ext < OW_MAX_EXT && cigar_len >= 256);
+	char *o = out_space(strlen(reads[h->pb1].name) + strlen(reads[h->pb2].name) + 256 + (by_ref ? 0 : cigar_len));
 	size_t k = (size_t)sprintf(o, "%s\t%c\t%d\t%d\t%d\t%s\t%c\t%d\t%d\t%d\t%d\t%0.3f\t%d\t%d\t%d\t%d\t", reads[h->pb1].name, '+', reads[h->pb1].len, h->tb, h->te,
 		reads[h->pb2].name, "+-"[h->dir2], reads[h->pb2].len, h->qb, h->qe, h->score, 1.0 * h->mat / aln, h->mat, h->mis, h->ins, h->del);
+	if(by_ref){
+		out_advance(k);
+		out_ext(cigar, cigar_len, ext);
+		o = g_ow.cur->buf + g_ow.cur->n; o[0] = '\n'; out_advance(1);       /* out_space reserved 256 spare bytes */
+		return;
+	}
 	if(cigar){ memcpy(o + k, cigar, cigar_len); k += cigar_len; } else { o[k++] = '0'; o[k++] = 'M'; }
 	o[k++] = '\n';
 	out_advance(k);
@@ -298,7 +351,7 @@ static void commit_query(eng_t *E, batch_t *b, uint32_t slot){
 				H.pb1 = pbid; H.pb2 = id2; H.dir2 = (uint32_t)S->dm_dir; H.score = S->dm_score;
 				H.tb = S->dm_tb; H.te = S->dm_te; H.qb = S->dm_qb; H.qe = S->dm_qe; H.mat = S->dm_score; H.aln = (int)ol;
 				pend_hit(pd, &H);
-				emit_record(E, &H, NULL, 0);
+				emit_record(E, &H, NULL, 0, -1);
 			}
 		}
 		free(cand);
@@ -361,7 +414,7 @@ static void commit_query(eng_t *E, batch_t *b, uint32_t slot){
 			H.pb1 = pbid; H.pb2 = s->pb2; H.dir2 = s->dir; H.score = x->score;
 			H.tb = x->tb; H.te = x->te; H.qb = x->qb; H.qe = x->qe; H.mat = x->mat; H.mis = x->mis; H.ins = x->ins; H.del = x->del; H.aln = x->aln;
 			pend_hit(pd, &H);
-			emit_record(E, &H, b->cig + x->text_off, x->text_len);
+			emit_record(E, &H, b->cig + x->text_off, x->text_len, b->cig_ext);
 			{   /* dovetail / containment bookkeeping (wtzmo.c:1065-1100) */
 				const uint32_t len1 = E->rdlen[H.pb1], len2 = E->rdlen[H.pb2];
 				uint32_t x1 = (uint32_t)(H.tb < H.qb ? H.tb : H.qb);
@@ -440,10 +493,18 @@ static int gpu_stages(eng_t *E, batch_t *b){
 			b->aln = (wtz_aln_result_t*)hx_realloc(b->aln, sizeof(wtz_aln_result_t) * b->nitem);
 			{ const double tc0 = now_s(); rc = wtz_pairs_align(b->ctx, b->it_pair, b->it_dir, b->nitem, b->aln); E->t_call[3] += now_s() - tc0; } TRY_WTZ(rc, "wtz_pairs_align");
 			uint64_t tot = 0; for(uint32_t i = 0; i < b->nitem; i++) tot += b->aln[i].text_len;
-			if(tot > b->capcig){        /* page-locked, grown geometrically: the buffer is reused by every later batch of this worker */
-				uint64_t cap = b->capcig ? b->capcig : ((uint64_t)16 << 20); while(cap < tot) cap += cap / 2;
-				wtz_host_free(b->cig); b->cig = (char*)wtz_host_alloc(cap + 1); b->capcig = cap;
-				if(!b->cig){ fprintf(stderr, "[wtzmo-mi355x] cannot allocate %llu bytes of page-locked memory for the CIGAR text\n", (unsigned long long)cap); return 1; }
+			{
+				/* the other page-locked buffer of this worker: the records of the previous batch may still be waiting for the writer
+				 * thread inside the first one.  Grown geometrically; both are kept for every later batch and step. */
+				const int sel = (b->cig_sel ^= 1);
+				b->cig_ext = b->ext_base >= 0 ? b->ext_base + sel : -1;
+				out_wait_ext(b->cig_ext);
+				if(tot > b->capcigs[sel]){
+					uint64_t cap = b->capcigs[sel] ? b->capcigs[sel] : ((uint64_t)16 << 20); while(cap < tot) cap += cap / 2;
+					wtz_host_free(b->cigs[sel]); b->cigs[sel] = (char*)wtz_host_alloc(cap + 1); b->capcigs[sel] = cap;
+					if(!b->cigs[sel]){ fprintf(stderr, "[wtzmo-mi355x] cannot allocate %llu bytes of page-locked memory for the CIGAR text\n", (unsigned long long)cap); return 1; }
+				}
+				b->cig = b->cigs[sel];
 			}
 			{ const double tc0 = now_s(); rc = wtz_fetch_cigar_text(b->ctx, b->cig, tot); E->t_call[4] += now_s() - tc0; } TRY_WTZ(rc, "wtz_fetch_cigar_text");     /* rendered on the device */
 			b->ncig = tot;
@@ -509,8 +570,10 @@ static void process_range(eng_t *E, batch_t *b, uint32_t s0, uint32_t s1){
 
 static void *pin_main(void *arg){
 	eng_t *E = (eng_t*)arg;
-	E->cig_keep[0] = (char*)wtz_host_alloc(E->cig_keep_cap[0] + 1);
-	if(!E->cig_keep[0]) E->cig_keep_cap[0] = 0;
+	for(int k = 0; k < 2; k++){
+		E->cig_keep[k] = (char*)wtz_host_alloc(E->cig_keep_cap[k] + 1);
+		if(!E->cig_keep[k]) E->cig_keep_cap[k] = 0;
+	}
 	return NULL;
 }
 
@@ -770,10 +833,10 @@ int main(int argc, char **argv){
 	/* page-lock the first worker's CIGAR text buffer while the indexes are built (pinning ~100 MB takes about as long as they do) */
 	pthread_t pin_th; int pin_started = 0;
 	if(E->do_align && E->cig_keep[0] == NULL){
-		uint64_t cap = E->st.nbase < ((uint64_t)16 << 20) ? ((uint64_t)16 << 20) : (E->st.nbase > ((uint64_t)256 << 20) ? ((uint64_t)256 << 20) : E->st.nbase);
-		E->cig_keep_cap[0] = cap;
+		uint64_t cap = E->st.nbase / 4 * 3; if(cap < ((uint64_t)16 << 20)) cap = (uint64_t)16 << 20; if(cap > ((uint64_t)256 << 20)) cap = (uint64_t)256 << 20;
+		E->cig_keep_cap[0] = E->cig_keep_cap[1] = cap;
 		pin_started = (pthread_create(&pin_th, NULL, pin_main, E) == 0);
-		if(!pin_started) E->cig_keep_cap[0] = 0;
+		if(!pin_started) E->cig_keep_cap[0] = E->cig_keep_cap[1] = 0;
 	}
 	E->out = strcmp(output, "-") ? fopen(output, "w") : stdout;
 	if(E->out == NULL){ fprintf(stderr, " -- Cannot write %s --\n", output); exit(1); }
@@ -847,7 +910,8 @@ int main(int argc, char **argv){
 			batch_t *bs = (batch_t*)calloc(nw, sizeof(batch_t)); pthread_t *th = (pthread_t*)calloc(nw, sizeof(pthread_t));
 			for(uint32_t w = 0; w < nw; w++){
 				bs[w].E = E;
-				if(w < 16){ bs[w].cig = E->cig_keep[w]; bs[w].capcig = E->cig_keep_cap[w]; E->cig_keep[w] = NULL; E->cig_keep_cap[w] = 0; }
+				bs[w].ext_base = w < 8 ? (int)w * 2 : -1;
+				if(w < 8) for(int k = 0; k < 2; k++){ bs[w].cigs[k] = E->cig_keep[w * 2 + k]; bs[w].capcigs[k] = E->cig_keep_cap[w * 2 + k]; E->cig_keep[w * 2 + k] = NULL; E->cig_keep_cap[w * 2 + k] = 0; }
 				if(w == 0) bs[w].ctx = E->ctx;
 				else { rc = wtz_ctx_clone(E->ctx, pool_gb << 30, &bs[w].ctx); DIE_WTZ(rc, "wtz_ctx_clone"); }
 			}
@@ -861,7 +925,7 @@ int main(int argc, char **argv){
 					if(cw.pool_peak > E->extra_u64[5]) E->extra_u64[5] = cw.pool_peak;
 					wtz_ctx_destroy(bs[w].ctx); }
 				free(bs[w].bq); free(bs[w].want); free(bs[w].ids); free(bs[w].rows); free(bs[w].nrow); free(bs[w].pq); free(bs[w].pc); free(bs[w].rowpair); free(bs[w].sum);
-				free(bs[w].box_off); free(bs[w].boxes); free(bs[w].item_of); free(bs[w].it_pair); free(bs[w].it_dir); free(bs[w].aln); if(w < 16){ E->cig_keep[w] = bs[w].cig; E->cig_keep_cap[w] = bs[w].capcig; } else wtz_host_free(bs[w].cig); free(bs[w].pf_ids); free(bs[w].pf_rows); free(bs[w].pf_nr);
+				free(bs[w].box_off); free(bs[w].boxes); free(bs[w].item_of); free(bs[w].it_pair); free(bs[w].it_dir); free(bs[w].aln); for(int k = 0; k < 2; k++){ if(w < 8){ E->cig_keep[w * 2 + k] = bs[w].cigs[k]; E->cig_keep_cap[w * 2 + k] = bs[w].capcigs[k]; } else wtz_host_free(bs[w].cigs[k]); } free(bs[w].pf_ids); free(bs[w].pf_rows); free(bs[w].pf_nr);
 			}
 			free(bs); free(th);
 		}

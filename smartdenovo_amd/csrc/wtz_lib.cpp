@@ -64,6 +64,9 @@ struct K_zdistinct;
 struct K_zdn;
 struct K_zcount;
 
+#include <chrono>
+static double wtz_wall(){ return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
 #ifndef WTZ_EMUL
 #include <hip/hip_runtime.h>
 #include <rocprim/rocprim.hpp>
@@ -775,6 +778,8 @@ extern "C" int wtz_pairs_align(wtz_ctx_t *c, const uint32_t *pair_idx, const uin
 	CTX_ENTER(c);
 	if(!pair_idx || !dir || !out) return wtz_fail(WTZ_E_ARG, "null argument");
 	c->n_items = 0; c->have_items = false;
+	const bool prof_wall = getenv("WTZ_PROFILE_PAIR") != NULL; double tw[6] = {0, 0, 0, 0, 0, 0}; double tw0 = prof_wall ? wtz_wall() : 0;
+	auto lapw = [&](int k){ if(prof_wall){ const double t = wtz_wall(); tw[k] += t - tw0; tw0 = t; } };
 	CHK(reserve_items(c, m));
 	std::vector<wtz_alnitem_t> items(m); std::vector<wtz_wintask_t> wt; uint64_t nreg = 0;
 	std::vector<uint32_t> h_q(c->n_pairs), h_c(c->n_pairs);
@@ -793,10 +798,12 @@ extern "C" int wtz_pairs_align(wtz_ctx_t *c, const uint32_t *pair_idx, const uin
 	CHK(dev_alloc((void**)&d_items, (size_t)m * sizeof(wtz_alnitem_t))); CHK(dev_h2d(d_items, items.data(), (size_t)m * sizeof(wtz_alnitem_t)));
 	CHK(dev_alloc((void**)&d_wt, (wt.size() + 1) * sizeof(wtz_wintask_t))); CHK(dev_h2d(d_wt, wt.data(), wt.size() * sizeof(wtz_wintask_t)));
 	const wtz_env_t V = ctx_env(c); wtz_alnres_dev_t *d_res = c->d_alnres;
+	lapw(0);
 	wtz_timer tm; tm.start();
 	CHK(wtz_launch_coop<K_winalign>(0, wt.size(), [=] WTZ_LAMBDA (uint64_t t){ wtz_task_winalign((uint32_t)t, V, d_wt, d_items); }, WTZ_WINALIGN_LDS_BYTES));
 	CHK(dev_sync());
 	c->cnt.ms_winalign += tm.stop(); c->cnt.n_winalign += wt.size();
+	lapw(1);
 	tm.start();
 	{
 		wtz_stitch_state_t *d_st = NULL; wtz_extjob_t *d_jl = NULL, *d_jr = NULL;
@@ -833,6 +840,7 @@ extern "C" int wtz_pairs_align(wtz_ctx_t *c, const uint32_t *pair_idx, const uin
 		dev_free(d_st); dev_free(d_jl); dev_free(d_jr); dev_free(d_gaps);
 	}
 	c->cnt.ms_stitch += tm.stop(); c->cnt.n_stitch += m;
+	lapw(2);
 	c->h_alnres.resize(m); c->n_items = m; c->have_items = true;
 	CHK(dev_d2h(c->h_alnres.data(), c->d_alnres, (size_t)m * sizeof(wtz_alnres_dev_t)));
 	dev_free(d_regs); dev_free(d_items); dev_free(d_wt);
@@ -847,6 +855,8 @@ extern "C" int wtz_pairs_align(wtz_ctx_t *c, const uint32_t *pair_idx, const uin
 		c->cnt.cells_shift += r.cells_shift; c->cnt.cells_fixed += r.cells_fixed; c->cnt.cells_global += r.cells_global;
 		out[i] = o;
 	}
+	lapw(3);
+	if(prof_wall) fprintf(stderr, "[align-profile] %u items: host wall ms prep %.2f winalign %.2f stitch %.2f results %.2f\n", m, tw[0] * 1e3, tw[1] * 1e3, tw[2] * 1e3, tw[3] * 1e3);
 	return WTZ_OK;
 }
 
