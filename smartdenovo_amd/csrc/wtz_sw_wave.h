@@ -1197,11 +1197,14 @@ __global__ void __launch_bounds__(256) wtz_kernel_extjobs_mw(wtz_extjob_t *jobs,
  * Requirements (checked by the caller): n_col <= 64*C, ((ql+1)/2)*64*C <= ztr_bytes, (tl+63)/32+1 <= tb words, ql <= 2048.
  */
 
-template<int C>
+/* ZG: the trace does not fit LDS and lives in the pool (HBM): the rows store it through a global-address-space pointer (one
+ * contiguous zrow-byte piece per row pair), the traceback walks LDS-staged blocks of 64 DP rows x the whole band (`stage`, 4 KB) */
+template<int C, bool ZG = false>
 WTZ_D wtz_aln_t wtz_extend_fixed_reg(int32_t qlen, const wtz_seq_packed &query, int32_t tlen, const wtz_seq_packed &target, int32_t init_score,
 		int32_t ql, int32_t tl, int32_t W, int32_t M, int32_t X, int32_t I, int32_t D, int32_t E, int32_t T,
-		uint64_t *tb, uint8_t *ztr, uint32_t zrow, uint32_t *runs, uint32_t *n_runs, unsigned long long *cells){
+		uint64_t *tb, uint8_t *ztr, uint32_t zrow, uint32_t *runs, uint32_t *n_runs, unsigned long long *cells, uint8_t *stage = NULL){
 	const int lane = (int)(threadIdx.x & 63);
+	constexpr int KB = C <= 2 ? 7 : 9;           /* bits of the band column inside the packed arg-max key (callers check |h| < 2^(31-KB)) */
 	wtz_aln_t x; memset(&x, 0, sizeof x);
 	*n_runs = 0;
 	if(init_score < 0) init_score = 0;
@@ -1297,16 +1300,21 @@ WTZ_D wtz_aln_t wtz_extend_fixed_reg(int32_t qlen, const wtz_seq_packed &query, 
 			f = f2 > tf ? f2 : tf;
 			hp[k] = valid[k] ? h : -10000; ep[k] = valid[k] ? en : -10000;
 			nib = valid[k] ? nib : 0u;
-			const int32_t kk = h * 128 + (colrel0 + k);
+			const int32_t kk = h * (1 << KB) + (colrel0 + k);
 			key = (valid[k] && kk > key) ? kk : key;
-			if(i & 1){ if((uint32_t)(colrel0 + k) < zrow) ztr[(size_t)(i >> 1) * zrow + colrel0 + k] = (uint8_t)(nibp[k] | (nib << 4)); }
+			if(i & 1){
+				if((uint32_t)(colrel0 + k) < zrow){
+					if(ZG) wtz_as_global(ztr)[(size_t)(i >> 1) * zrow + colrel0 + k] = (uint8_t)(nibp[k] | (nib << 4));
+					else ztr[(size_t)(i >> 1) * zrow + colrel0 + k] = (uint8_t)(nibp[k] | (nib << 4));
+				}
+			}
 			else nibp[k] = nib;
 		}
 		i_done = i;
 		ncell += (unsigned long long)(je - jb);
 		key = wtz_wave_max_i32(key);
 		int32_t imax = 0, mj2 = -1;
-		if((key >> 7) >= 0){ imax = key >> 7; mj2 = jb + (key & 127); }           /* last j with h >= running max >= 0, kswx.h:288-289 */
+		if((key >> KB) >= 0){ imax = key >> KB; mj2 = jb + (key & ((1 << KB) - 1)); }           /* last j with h >= running max >= 0, kswx.h:288-289 */
 		if(je == tlen){
 			const int32_t idx = je - 1 - jb;
 			int32_t hsel = hp[0];
@@ -1331,6 +1339,49 @@ WTZ_D wtz_aln_t wtz_extend_fixed_reg(int32_t qlen, const wtz_seq_packed &query, 
 	WTZ_PROF_ADD(2, pt_rows);
 	WTZ_PROF_CNT(4, i_done + 1);
 	const unsigned long long pt_tb = WTZ_PROF_T();
+	if(ZG){
+		int32_t i_ = x.qe, j_ = x.te; uint32_t d_ = 0;
+		uint32_t run_op = 0xFFu, run_len = 0, nr = 0;
+		uint32_t *stage32 = (uint32_t*)stage;
+		const int32_t RB = zrow <= 128 ? 32 : (zrow <= 256 ? 16 : 8);         /* packed rows per staged block: RB * zrow <= 4 KB */
+		while(i_ >= 0 && j_ >= 0){
+			const int32_t p1 = i_ >> 1, p0 = p1 >= RB - 1 ? p1 - (RB - 1) : 0;
+			{
+				const uint32_t nd = (uint32_t)(p1 - p0 + 1) * (zrow >> 2);
+				const uint32_t *src = (const uint32_t*)(ztr + (size_t)p0 * zrow);
+				for(uint32_t xw = (uint32_t)lane; xw < nd; xw += 64) stage32[xw] = src[xw];
+			}
+			__threadfence_block();
+			if(lane == 0){
+				while(i_ >= 0 && j_ >= 0 && (i_ >> 1) >= p0){
+					const int32_t col = j_ - (i_ > W ? i_ - W : 0);
+					const uint32_t zv = stage[(size_t)((i_ >> 1) - p0) * zrow + col];
+					const uint32_t nib = (zv >> ((i_ & 1) * 4)) & 0xFu;
+					if(d_ == 0) d_ = nib & 3u; else if(d_ == 1) d_ = (nib & 4u) ? 1u : 0u; else d_ = (nib & 8u) ? 2u : 0u;
+					if(d_ == 0){
+						const uint32_t qv = (i_ & 16) ? (uint32_t)__builtin_amdgcn_readlane((int)qw_hi, i_ >> 5) : (uint32_t)__builtin_amdgcn_readlane((int)qw_lo, i_ >> 5);
+						const uint32_t qb = (qv >> ((i_ & 15) * 2)) & 3u;
+						const uint32_t tq = (uint32_t)(tb[j_ >> 5] >> ((j_ & 31) * 2)) & 3u;
+						if(qb == tq) x.mat++; else x.mis++;
+						i_--; j_--;
+					}
+					else if(d_ == 1){ i_--; x.ins++; }
+					else { j_--; x.del++; }
+					if(d_ == run_op) run_len++;
+					else { if(run_len) runs[nr++] = (run_len << 4) | run_op; run_op = d_; run_len = 1; }
+				}
+			}
+			i_ = __builtin_amdgcn_readfirstlane(i_); j_ = __builtin_amdgcn_readfirstlane(j_);
+			__threadfence_block();
+		}
+		if(lane == 0){
+			if(i_ >= 0){ x.ins += i_ + 1; if(run_len && run_op == 1u) run_len += (uint32_t)(i_ + 1); else { if(run_len) runs[nr++] = (run_len << 4) | run_op; run_op = 1u; run_len = (uint32_t)(i_ + 1); } }
+			if(j_ >= 0){ x.del += j_ + 1; if(run_len && run_op == 2u) run_len += (uint32_t)(j_ + 1); else { if(run_len) runs[nr++] = (run_len << 4) | run_op; run_op = 2u; run_len = (uint32_t)(j_ + 1); } }
+			if(run_len) runs[nr++] = (run_len << 4) | run_op;
+			*n_runs = nr;
+			x.aln = x.mat + x.mis + x.ins + x.del; x.qe++; x.te++;
+		}
+	} else
 	if(lane == 0){
 		int32_t i_ = x.qe, j_ = x.te; uint32_t d_ = 0;
 		uint32_t run_op = 0xFFu, run_len = 0, nr = 0;
@@ -1418,24 +1469,34 @@ WTZ_D wtz_aln_t wtz_align_window_wave(const wtz_readview &pb1, const wtz_readvie
 		uint32_t n_runs = 0; uint32_t *runs = NULL; bool lds_runs = false;
 		{
 			int32_t init = x.score < 0 ? 0 : x.score, W = P->w, ql = 0, tl = 0, n_col = 0; bool okk = true;
-			bool fits = false;
-			if(qlen > 0 && tlen > 0){ wtz_ext_geometry(qlen, tlen, init, W, M, I, D, E, T, ql, tl, n_col); fits = wtz_wave_fits(L, n_col, tl, ql); }
+			if(qlen > 0 && tlen > 0) wtz_ext_geometry(qlen, tlen, init, W, M, I, D, E, T, ql, tl, n_col);
 			const int32_t run_bytes = 4 * (ql + tl + 4);
-			const bool packable = fits && (init + M * (ql < tl ? ql : tl) < (1 << 23));      /* h*128 + column keys of the register DP */
 			const int32_t zrow = (n_col + 3) & ~3;                 /* trace bytes per row pair: one nibble pair per band column */
-			if(packable && n_col <= 64 && ((ql + 1) / 2) * zrow + run_bytes <= ztr_bytes){
+			const int32_t hmax = init + M * (ql < tl ? ql : tl);                 /* bound of |h|: the register DP packs h and the band column into one int32 key */
+			const bool shape = (qlen > 0 && tlen > 0 && ql <= 2048 && (tl + 63) / 32 + 1 <= L.tw);
+			const bool lds_fit = shape && n_col <= 128 && hmax < (1 << 23) && ((ql + 1) / 2) * zrow + run_bytes <= ztr_bytes;
+			const bool pool_fit = shape && !lds_fit && n_col <= 512 && hmax < (n_col <= 128 ? (1 << 23) : (1 << 21)) && 4096 + run_bytes <= ztr_bytes;
+			if(lds_fit){
 				runs = (uint32_t*)(ztr + ztr_bytes - run_bytes); lds_runs = true;
-				y = wtz_extend_fixed_reg<1>(qlen, pb2.sub(x.qe, 1), tlen, pb1.sub(x.te, 1), x.score, ql, tl, W, M, X, I, D, E, T, L.tb, ztr, (uint32_t)zrow, runs, &n_runs, cells);
-			} else if(packable && n_col <= 128 && ((ql + 1) / 2) * zrow + run_bytes <= ztr_bytes){
+				if(n_col <= 64) y = wtz_extend_fixed_reg<1>(qlen, pb2.sub(x.qe, 1), tlen, pb1.sub(x.te, 1), x.score, ql, tl, W, M, X, I, D, E, T, L.tb, ztr, (uint32_t)zrow, runs, &n_runs, cells);
+				else            y = wtz_extend_fixed_reg<2>(qlen, pb2.sub(x.qe, 1), tlen, pb1.sub(x.te, 1), x.score, ql, tl, W, M, X, I, D, E, T, L.tb, ztr, (uint32_t)zrow, runs, &n_runs, cells);
+			} else if(pool_fit){
+				/* the 4-bit trace does not fit the LDS slice (or the band is wider than 128 columns): trace in the pool, traceback through a
+				 * 4 KB LDS stage, run list in LDS above the stage */
+				unsigned long long za = 0;
+				if(lane == 0) za = (unsigned long long)(uintptr_t)wtz_pool_alloc(pool, (size_t)((ql + 1) / 2) * zrow);
+				za = __shfl(za, 0, 64);
+				if(za == 0){ *ok = false; return x; }
+				uint8_t *zg = (uint8_t*)(uintptr_t)za;
 				runs = (uint32_t*)(ztr + ztr_bytes - run_bytes); lds_runs = true;
-				y = wtz_extend_fixed_reg<2>(qlen, pb2.sub(x.qe, 1), tlen, pb1.sub(x.te, 1), x.score, ql, tl, W, M, X, I, D, E, T, L.tb, ztr, (uint32_t)zrow, runs, &n_runs, cells);
-			} else if(qlen <= 0 || tlen <= 0 || fits){
-				const unsigned long long ptw = WTZ_PROF_T();
-				y = wtz_extend_wave<1>(qlen, pb2.sub(x.qe, 1), tlen, pb1.sub(x.te, 1), x.score, P->w, M, X, I, D, E, T, L, tr, pool, tmp, cells, &okk);
-				if(qlen <= 0 || tlen <= 0){ WTZ_PROF_ADD(11, ptw); WTZ_PROF_CNT(12, 1); }
-				else { WTZ_PROF_ADD(9, ptw); WTZ_PROF_CNT(7, 1); WTZ_PROF_CNT(13, ql); WTZ_PROF_CNT(14, n_col); }
+				if(n_col <= 64)       y = wtz_extend_fixed_reg<1, true>(qlen, pb2.sub(x.qe, 1), tlen, pb1.sub(x.te, 1), x.score, ql, tl, W, M, X, I, D, E, T, L.tb, zg, (uint32_t)zrow, runs, &n_runs, cells, ztr);
+				else if(n_col <= 128) y = wtz_extend_fixed_reg<2, true>(qlen, pb2.sub(x.qe, 1), tlen, pb1.sub(x.te, 1), x.score, ql, tl, W, M, X, I, D, E, T, L.tb, zg, (uint32_t)zrow, runs, &n_runs, cells, ztr);
+				else if(n_col <= 256) y = wtz_extend_fixed_reg<4, true>(qlen, pb2.sub(x.qe, 1), tlen, pb1.sub(x.te, 1), x.score, ql, tl, W, M, X, I, D, E, T, L.tb, zg, (uint32_t)zrow, runs, &n_runs, cells, ztr);
+				else                  y = wtz_extend_fixed_reg<8, true>(qlen, pb2.sub(x.qe, 1), tlen, pb1.sub(x.te, 1), x.score, ql, tl, W, M, X, I, D, E, T, L.tb, zg, (uint32_t)zrow, runs, &n_runs, cells, ztr);
+				WTZ_PROF_ADD(9, pt0); WTZ_PROF_CNT(7, 1); WTZ_PROF_CNT(13, ql); WTZ_PROF_CNT(14, n_col);
 			} else {
-				const unsigned long long ptw = WTZ_PROF_T();
+				/* empty problems and whatever is outside the register DP's envelope (rows > 2048, band > 512 columns, huge scores): the scalar body */
+				const unsigned long long ptw = WTZ_PROF_T(); (void)ptw;
 				if(lane == 0){ tmp.n = 0; y = wtz_extend_fixed(qlen, pb2.sub(x.qe, 1), tlen, pb1.sub(x.te, 1), x.score, P->w, M, X, I, D, E, T, mem, tmp); if(mem.bad) okk = false; }
 				y = wtz_bcast_aln(y);
 				okk = __shfl((int)okk, 0, 64) != 0;

@@ -38,12 +38,21 @@ def test_batch_size_never_changes_the_output(batch, gpu_exe, tmp_path):
     assert md5 == case["md5_full"] and cont == case["md5_contained"]
 
 
-@pytest.mark.parametrize("engine", ["zmo", "dmo"])
+FRESH = {
+    "zmo": ["-k", "16", "-s", "200", "-m", "0.6"],
+    "dmo": ["-k", "16", "-z", "10", "-Z", "16", "-U", "-1", "-m", "0.1", "-A", "1000"],
+    # wide K-sw1 / K-sw2 bands: 4 and 8 band columns per lane in the register DPs, trace in the pool
+    "zmo_w100": ["-k", "16", "-s", "200", "-m", "0.6", "-w", "100"],
+    "zmo_w200": ["-k", "16", "-s", "200", "-m", "0.6", "-w", "200", "-W", "800"],
+}
+
+
+@pytest.mark.parametrize("engine", list(FRESH))
 def test_gpu_equals_oracle_on_fresh_input(engine, gpu_exe, oracle_exe, tmp_path):
     names, seqs = synth.synth_reads(300000, 12, seed=99, mean_len=9000.0, min_len=1000)
     fa = os.path.join(str(tmp_path), "r.fa")
     synth.write_fasta(fa, names, seqs)
-    argv = ["-k", "16", "-s", "200", "-m", "0.6"] if engine == "zmo" else ["-k", "16", "-z", "10", "-Z", "16", "-U", "-1", "-m", "0.1", "-A", "1000"]
+    argv = FRESH[engine]
     a, b = os.path.join(str(tmp_path), "gpu.ovl"), os.path.join(str(tmp_path), "ora.ovl")
     subprocess.run([gpu_exe, "-i", fa, "-fo", a] + argv, check=True, capture_output=True)
     subprocess.run([oracle_exe, "-i", fa, "-fo", b] + argv, check=True, capture_output=True)
