@@ -272,6 +272,7 @@ static void pend_hit(pending_t *p, const hit_t *h){
 
 /* one .ovl line (print_hits_wtzmo, wtzmo.c:1170-1249) into the output stream; cigar == NULL prints "0M" */
 static void emit_record(eng_t *E, const hit_t *h, const char *cigar, size_t cigar_len, int ext){
+	const double te0 = now_s();
 	const hx_read_t *reads = E->st.reads;
 	const int aln = h->aln == 0 ? 1 : h->aln;
 	const int by_ref = (cigar && ext >= 0 && ext < OW_MAX_EXT && cigar_len >= 256);
@@ -282,6 +283,7 @@ static void emit_record(eng_t *E, const hit_t *h, const char *cigar, size_t ciga
 		out_advance(k);
 		out_ext(cigar, cigar_len, ext);
 		o = g_ow.cur->buf + g_ow.cur->n; o[0] = '\n'; out_advance(1);       /* out_space reserved 256 spare bytes */
+		E->t_call[5] += now_s() - te0;
 		return;
 	}
 	if(cigar){ memcpy(o + k, cigar, cigar_len); k += cigar_len; } else { o[k++] = '0'; o[k++] = 'M'; }
@@ -940,7 +942,7 @@ int main(int argc, char **argv){
 		if(E->extra_u64[5] > cn.pool_peak) cn.pool_peak = E->extra_u64[5];
 		memset(E->extra_ms, 0, sizeof E->extra_ms); memset(E->extra_u64, 0, sizeof E->extra_u64);
 		fprintf(stderr, "[wtzmo-mi355x] %llu records, %llu pairs aligned, %llu pair-bp, %.3f s (index %.3f s)\n", (unsigned long long)E->nrec, (unsigned long long)E->n_pairs, (unsigned long long)E->pair_bp, t1 - t0, t_index);
-		fprintf(stderr, "[wtzmo-mi355x] host seconds: in GPU-stage calls %.3f, commit %.3f\n", E->t_gpu, E->t_commit);
+		fprintf(stderr, "[wtzmo-mi355x] host seconds: in GPU-stage calls %.3f, commit %.3f (record formatting %.3f)\n", E->t_gpu, E->t_commit, E->t_call[5]);
 		fprintf(stderr, "[wtzmo-mi355x] wall seconds per call: candidates %.3f pairs_seed %.3f pairs_windows %.3f pairs_align %.3f cigar_text %.3f\n", E->t_call[0], E->t_call[1], E->t_call[2], E->t_call[3], E->t_call[4]);
 	fprintf(stderr, "[wtzmo-mi355x] %llu batches on %u worker context(s); speculation: queries %llu/%llu pairs %llu/%llu alignments %llu/%llu (used/planned)\n",
 			(unsigned long long)E->n_batches, E->rows_all ? 1u : E->n_workers, (unsigned long long)E->used_queries, (unsigned long long)E->spec_queries, (unsigned long long)E->used_pairs, (unsigned long long)E->spec_pairs, (unsigned long long)E->used_items, (unsigned long long)E->spec_items);
