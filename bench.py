@@ -223,6 +223,11 @@ def main():
             per_launch = float(row["hbm_bytes_est"]) / max(1, int(row["dispatches"]))
             if row["kernel"] in ("wtz_kernel_extjobs_reg", "wtz_kernel_extjobs_mw"):      # the two kernels of one K-sw3 stage launch
                 res["roofline"]["traffic"] = (res["roofline"]["traffic"] or 0.0) + per_launch
+                # executed wave-level VALU instructions of the stage (PMC pass of ONE step) x 2 issue cycles on a SIMD-32 / SIMD-cycles of the
+                # live stage time: how much of the chip's VALU issue capacity the exact recurrence really occupies (the nominal 12 ops/cell
+                # of SURVEY 8d undercounts it by ~8x)
+                if ms_ext > 0 and row.get("SQ_INSTS_VALU"):
+                    res["roofline"]["valu_issue_frac_pmc"] = (res["roofline"].get("valu_issue_frac_pmc") or 0.0) + float(row["SQ_INSTS_VALU"]) * 2.0 / (ms_ext * 1e-3 * 2.4e9 * 256 * 4)
                 res["roofline"]["traffic_note"] = "HBM bytes per stage launch (both kernels) from profiles/r01_%s_pmc_per_kernel.csv (separate --pmc passes)" % a.engine
             if row["kernel"] == "K_candidates":
                 res["roofline_seed"]["traffic"] = per_launch

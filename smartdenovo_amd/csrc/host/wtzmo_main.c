@@ -81,7 +81,7 @@ typedef struct {
 	pending_t pend;
 	/* stats */
 	char *cig_keep[16]; uint64_t cig_keep_cap[16];      /* page-locked CIGAR text buffer of worker w, kept across steps (pinning is the expensive part) */
-	double t_gpu, t_commit, t_call[6];      /* t_call: wall seconds inside wtz_candidates / pairs_seed / pairs_windows / pairs_align / fetch_cigar_text / planning */
+	double t_gpu, t_commit, t_call[6], t_io[2];      /* t_io: waiting for the writer thread before a text buffer is reused / at the end of the run */      /* t_call: wall seconds inside wtz_candidates / pairs_seed / pairs_windows / pairs_align / fetch_cigar_text / planning */
 	uint64_t spec_pairs, used_pairs, spec_items, used_items, spec_queries, used_queries, n_batches;
 	double extra_ms[5]; uint64_t extra_u64[6];      /* counters of the cloned contexts */
 } eng_t;
@@ -500,7 +500,7 @@ static int gpu_stages(eng_t *E, batch_t *b){
 				 * thread inside the first one.  Grown geometrically; both are kept for every later batch and step. */
 				const int sel = (b->cig_sel ^= 1);
 				b->cig_ext = b->ext_base >= 0 ? b->ext_base + sel : -1;
-				out_wait_ext(b->cig_ext);
+				{ const double tw0 = now_s(); out_wait_ext(b->cig_ext); E->t_io[0] += now_s() - tw0; }
 				if(tot > b->capcigs[sel]){
 					uint64_t cap = b->capcigs[sel] ? b->capcigs[sel] : ((uint64_t)16 << 20); while(cap < tot) cap += cap / 2;
 					wtz_host_free(b->cigs[sel]); b->cigs[sel] = (char*)wtz_host_alloc(cap + 1); b->capcigs[sel] = cap;
@@ -856,7 +856,7 @@ int main(int argc, char **argv){
 			free(E->closed.tab); memset(&E->closed, 0, sizeof E->closed);
 			for(size_t i = 0; i < nclosed0; i++) hx_set_put(&E->closed, closed0[i]);
 			E->pair_bp = E->n_pairs = E->nrec = 0;
-			E->t_gpu = E->t_commit = 0; memset(E->t_call, 0, sizeof E->t_call); E->spec_pairs = E->used_pairs = E->spec_items = E->used_items = E->spec_queries = E->used_queries = 0;
+			E->t_gpu = E->t_commit = 0; memset(E->t_call, 0, sizeof E->t_call); E->t_io[0] = E->t_io[1] = 0; E->spec_pairs = E->used_pairs = E->spec_items = E->used_items = E->spec_queries = E->used_queries = 0;
 			E->rows_all = 0; E->n_batches = 0;
 			E->pend.rd_id = 0xFFFFFFFFu; E->pend.nhit = E->pend.nmask = E->pend.nclosed = E->pend.nseed = 0;
 			if(strcmp(output, "-")){ E->out = fopen(output, "w"); if(E->out == NULL) exit(1); setvbuf(E->out, NULL, _IOFBF, 8u << 20); }
@@ -932,7 +932,7 @@ int main(int argc, char **argv){
 			free(bs); free(th);
 		}
 		flush_pending(E);
-		out_finish();
+		{ const double tw0 = now_s(); out_finish(); E->t_io[1] += now_s() - tw0; }
 		const double t1 = now_s();
 		if(strcmp(output, "-")) fclose(E->out); else fflush(stdout);
 		if(g_hook) g_hook(rep, 1);
@@ -942,7 +942,7 @@ int main(int argc, char **argv){
 		if(E->extra_u64[5] > cn.pool_peak) cn.pool_peak = E->extra_u64[5];
 		memset(E->extra_ms, 0, sizeof E->extra_ms); memset(E->extra_u64, 0, sizeof E->extra_u64);
 		fprintf(stderr, "[wtzmo-mi355x] %llu records, %llu pairs aligned, %llu pair-bp, %.3f s (index %.3f s)\n", (unsigned long long)E->nrec, (unsigned long long)E->n_pairs, (unsigned long long)E->pair_bp, t1 - t0, t_index);
-		fprintf(stderr, "[wtzmo-mi355x] host seconds: in GPU-stage calls %.3f, commit %.3f (record formatting %.3f)\n", E->t_gpu, E->t_commit, E->t_call[5]);
+		fprintf(stderr, "[wtzmo-mi355x] host seconds: in GPU-stage calls %.3f, commit %.3f (record formatting %.3f); waiting for the output writer: %.3f before buffer reuse, %.3f at the end\n", E->t_gpu, E->t_commit, E->t_call[5], E->t_io[0], E->t_io[1]);
 		fprintf(stderr, "[wtzmo-mi355x] wall seconds per call: candidates %.3f pairs_seed %.3f pairs_windows %.3f pairs_align %.3f cigar_text %.3f\n", E->t_call[0], E->t_call[1], E->t_call[2], E->t_call[3], E->t_call[4]);
 	fprintf(stderr, "[wtzmo-mi355x] %llu batches on %u worker context(s); speculation: queries %llu/%llu pairs %llu/%llu alignments %llu/%llu (used/planned)\n",
 			(unsigned long long)E->n_batches, E->rows_all ? 1u : E->n_workers, (unsigned long long)E->used_queries, (unsigned long long)E->spec_queries, (unsigned long long)E->used_pairs, (unsigned long long)E->spec_pairs, (unsigned long long)E->used_items, (unsigned long long)E->spec_items);
