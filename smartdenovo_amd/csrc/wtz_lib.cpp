@@ -58,6 +58,7 @@ struct K_stitch_fin;
 struct K_stitch_left;
 struct K_stitch_mid;
 struct K_winalign;
+struct K_winalign_big;
 struct K_zfill;
 struct K_zrun;
 struct K_zdistinct;
@@ -800,7 +801,20 @@ extern "C" int wtz_pairs_align(wtz_ctx_t *c, const uint32_t *pair_idx, const uin
 	const wtz_env_t V = ctx_env(c); wtz_alnres_dev_t *d_res = c->d_alnres;
 	lapw(0);
 	wtz_timer tm; tm.start();
+#ifdef WTZ_EMUL
 	CHK(wtz_launch_coop<K_winalign>(0, wt.size(), [=] WTZ_LAMBDA (uint64_t t){ wtz_task_winalign((uint32_t)t, V, d_wt, d_items); }, WTZ_WINALIGN_LDS_BYTES));
+#else
+	{
+		/* first launch: the lean form (register DP with one / two band columns per lane, no scalar body: fewer VGPRs, no spills at three
+		 * waves per SIMD); the few windows with a problem outside it queue themselves and are redone by the full task */
+		uint32_t *d_defer = NULL; CHK(dev_alloc((void**)&d_defer, (wt.size() + 1) * 4)); CHK(dev_set(d_defer, 0, 4));
+		CHK(wtz_launch_coop<K_winalign>(0, wt.size(), [=] WTZ_LAMBDA (uint64_t t){ wtz_task_winalign<false>((uint32_t)t, V, d_wt, d_items, d_defer, NULL); }, WTZ_WINALIGN_LDS_BYTES));
+		uint32_t n_def = 0; CHK(dev_d2h(&n_def, d_defer, 4));
+		if(n_def) CHK(wtz_launch_coop<K_winalign_big>(0, n_def, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_winalign<true>((uint32_t)t, V, d_wt, d_items, NULL, d_defer); }, WTZ_WINALIGN_LDS_BYTES));
+		if(getenv("WTZ_PROFILE_PAIR")) fprintf(stderr, "[winalign-profile] %zu windows, %u redone by the full task\n", wt.size(), n_def);
+		dev_free(d_defer);
+	}
+#endif
 	CHK(dev_sync());
 	c->cnt.ms_winalign += tm.stop(); c->cnt.n_winalign += wt.size();
 	lapw(1);

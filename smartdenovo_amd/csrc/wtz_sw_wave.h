@@ -1445,8 +1445,11 @@ WTZ_D wtz_aln_t wtz_align_zmer_w(const S1 &pb1, uint32_t len1, const S2 &pb2, ui
 
 /* ---- A9 with the K-sw1 gaps run by the whole wave (hzm_aln.h:1247-1302).  Every lane follows the anchor loop with
  *      the same x; CIGAR bookkeeping and the run-by-run z-mer alignment stay on lane 0.  lds: >= 8 KB. ---- */
+/* FULL = false is the form of the first launch: only the one / two-columns-per-lane register DP (and the empty problem) are compiled
+ * in; a window with a problem that needs anything else sets *defer and is redone from scratch by a FULL launch. */
+template<bool FULL = true>
 WTZ_D wtz_aln_t wtz_align_window_wave(const wtz_readview &pb1, const wtz_readview &pb2, const wtz_win_t &win, const wtz_zhit_t *anchors,
-		wtz_cigar_t &cigar, wtz_cigar_t &tmp, const wtz_params_t *P, wtz_pool_t *pool, int32_t *lds, unsigned long long *cells, bool *ok){
+		wtz_cigar_t &cigar, wtz_cigar_t &tmp, const wtz_params_t *P, wtz_pool_t *pool, int32_t *lds, unsigned long long *cells, bool *ok, bool *defer = NULL){
 	const int lane = (int)(threadIdx.x & 63);
 	const int32_t M = P->M, X = P->X, I = P->O, D = P->O, E = P->E, T = P->T;
 	/* LDS slice: 128 target words (1 KB), then either the H/E rings of the general wave DP (2 x 2 KB) or the 4-bit trace
@@ -1476,6 +1479,7 @@ WTZ_D wtz_aln_t wtz_align_window_wave(const wtz_readview &pb1, const wtz_readvie
 			const bool shape = (qlen > 0 && tlen > 0 && ql <= 2048 && (tl + 63) / 32 + 1 <= L.tw);
 			const bool lds_fit = shape && n_col <= 128 && hmax < (1 << 23) && ((ql + 1) / 2) * zrow + run_bytes <= ztr_bytes;
 			const bool pool_fit = shape && !lds_fit && n_col <= 512 && hmax < (n_col <= 128 ? (1 << 23) : (1 << 21)) && 4096 + run_bytes <= ztr_bytes;
+			if(!FULL && !(qlen <= 0 || tlen <= 0) && !(lds_fit || (pool_fit && n_col <= 128))){ *defer = true; return x; }
 			if(lds_fit){
 				runs = (uint32_t*)(ztr + ztr_bytes - run_bytes); lds_runs = true;
 				if(n_col <= 64) y = wtz_extend_fixed_reg<1>(qlen, pb2.sub(x.qe, 1), tlen, pb1.sub(x.te, 1), x.score, ql, tl, W, M, X, I, D, E, T, L.tb, ztr, (uint32_t)zrow, runs, &n_runs, cells);
@@ -1491,11 +1495,16 @@ WTZ_D wtz_aln_t wtz_align_window_wave(const wtz_readview &pb1, const wtz_readvie
 				runs = (uint32_t*)(ztr + ztr_bytes - run_bytes); lds_runs = true;
 				if(n_col <= 64)       y = wtz_extend_fixed_reg<1, true>(qlen, pb2.sub(x.qe, 1), tlen, pb1.sub(x.te, 1), x.score, ql, tl, W, M, X, I, D, E, T, L.tb, zg, (uint32_t)zrow, runs, &n_runs, cells, ztr);
 				else if(n_col <= 128) y = wtz_extend_fixed_reg<2, true>(qlen, pb2.sub(x.qe, 1), tlen, pb1.sub(x.te, 1), x.score, ql, tl, W, M, X, I, D, E, T, L.tb, zg, (uint32_t)zrow, runs, &n_runs, cells, ztr);
-				else if(n_col <= 256) y = wtz_extend_fixed_reg<4, true>(qlen, pb2.sub(x.qe, 1), tlen, pb1.sub(x.te, 1), x.score, ql, tl, W, M, X, I, D, E, T, L.tb, zg, (uint32_t)zrow, runs, &n_runs, cells, ztr);
-				else                  y = wtz_extend_fixed_reg<8, true>(qlen, pb2.sub(x.qe, 1), tlen, pb1.sub(x.te, 1), x.score, ql, tl, W, M, X, I, D, E, T, L.tb, zg, (uint32_t)zrow, runs, &n_runs, cells, ztr);
+				else if constexpr(FULL){
+					if(n_col <= 256) y = wtz_extend_fixed_reg<4, true>(qlen, pb2.sub(x.qe, 1), tlen, pb1.sub(x.te, 1), x.score, ql, tl, W, M, X, I, D, E, T, L.tb, zg, (uint32_t)zrow, runs, &n_runs, cells, ztr);
+					else             y = wtz_extend_fixed_reg<8, true>(qlen, pb2.sub(x.qe, 1), tlen, pb1.sub(x.te, 1), x.score, ql, tl, W, M, X, I, D, E, T, L.tb, zg, (uint32_t)zrow, runs, &n_runs, cells, ztr);
+				}
 				WTZ_PROF_ADD(9, pt0); WTZ_PROF_CNT(7, 1); WTZ_PROF_CNT(13, ql); WTZ_PROF_CNT(14, n_col);
-			} else {
-				/* empty problems and whatever is outside the register DP's envelope (rows > 2048, band > 512 columns, huge scores): the scalar body */
+			} else if(qlen <= 0 || tlen <= 0){
+				/* empty problem (wtz_extend_fixed: score = init, nothing aligned, empty CIGAR) */
+				memset(&y, 0, sizeof y); y.score = init; if(lane == 0) tmp.n = 0;
+			} else if constexpr(FULL){
+				/* whatever is outside the register DP's envelope (rows > 2048, band > 512 columns, huge scores): the scalar body */
 				const unsigned long long ptw = WTZ_PROF_T(); (void)ptw;
 				if(lane == 0){ tmp.n = 0; y = wtz_extend_fixed(qlen, pb2.sub(x.qe, 1), tlen, pb1.sub(x.te, 1), x.score, P->w, M, X, I, D, E, T, mem, tmp); if(mem.bad) okk = false; }
 				y = wtz_bcast_aln(y);

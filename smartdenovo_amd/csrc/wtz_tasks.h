@@ -238,7 +238,9 @@ WTZ_HD wtz_readview wtz_view(const wtz_reads_t &R, uint32_t id, uint32_t rev){ w
 
 /* launched wave-cooperatively: on the GPU the K-sw1 gaps between anchors are computed by the whole wavefront
  * (wtz_align_window_wave), the host emulation runs the scalar body */
-WTZ_HD void wtz_task_winalign(uint32_t t, const wtz_env_t &V, const wtz_wintask_t *tasks, const wtz_alnitem_t *items){
+template<bool FULL = true>
+WTZ_HD void wtz_task_winalign(uint32_t t, const wtz_env_t &V, const wtz_wintask_t *tasks, const wtz_alnitem_t *items, uint32_t *defer = NULL, const uint32_t *list = NULL){
+	if(list) t = list[1 + t];
 	const wtz_params_t *P = V.P;
 	const wtz_alnitem_t &it = items[tasks[t].item];
 	const wtz_win_t &w = it.win[tasks[t].widx];
@@ -248,8 +250,9 @@ WTZ_HD void wtz_task_winalign(uint32_t t, const wtz_env_t &V, const wtz_wintask_
 	unsigned long long cells = 0;
 	int32_t bad = 0;
 #if defined(__HIP_DEVICE_COMPILE__)
-	bool ok = true;
-	reg.x = wtz_align_window_wave(wtz_view(V.R, it.q, 0), wtz_view(V.R, it.c, it.dir), w, it.anchors, cigar, tmp, P, V.pool, wtz_wave_scratch(), &cells, &ok);
+	bool ok = true, dfr = false;
+	reg.x = wtz_align_window_wave<FULL>(wtz_view(V.R, it.q, 0), wtz_view(V.R, it.c, it.dir), w, it.anchors, cigar, tmp, P, V.pool, wtz_wave_scratch(), &cells, &ok, &dfr);
+	if(!FULL && dfr){ if(WTZ_LANE == 0){ const uint32_t idx = atomicAdd(&defer[0], 1u); defer[1 + idx] = t; } return; }
 	if(!ok) bad = 1;
 	if(WTZ_LANE != 0) return;
 #else
