@@ -33,6 +33,7 @@ static int wtz_fail(int code, const char *fmt, ...){
 #ifndef WTZ_CAND_LDS_BYTES
 #define WTZ_CAND_LDS_BYTES 16384u     /* LDS window of the candidate-tuple sort */
 #endif
+static_assert((WTZ_CAND_LDS_BYTES & (WTZ_CAND_LDS_BYTES - 1u)) == 0u && WTZ_CAND_LDS_BYTES >= 4096u, "the windowed bitonic sort of K_candidates needs a power-of-two LDS window");
 #ifndef WTZ_PAIR_DM_LDS_TIER2
 #define WTZ_PAIR_DM_LDS_TIER2 49152u
 #endif
@@ -76,7 +77,7 @@ static double wtz_wall(){ return std::chrono::duration<double>(std::chrono::stea
 #define WTZ_OCC_WINALIGN 3
 #endif
 #ifndef WTZ_OCC_PAIR
-#define WTZ_OCC_PAIR 1
+#define WTZ_OCC_PAIR 5      /* K_pair is latency-bound (14 % VALU issue): five waves per SIMD (102 VGPRs, a few spills) beat three without */
 #endif
 #ifndef WTZ_OCC_GAP
 #define WTZ_OCC_GAP 1

@@ -22,7 +22,9 @@ typedef struct {
 #ifndef WTZ_GAP_LDS_BYTES
 #define WTZ_GAP_LDS_BYTES 12288      /* LDS slice of a gap-filling (K-sw2) wave */
 #endif
-#define WTZ_PAIR_LDS_BYTES 16384     /* K_pair, zmo: LDS slice of the window scans */
+#ifndef WTZ_PAIR_LDS_BYTES
+#define WTZ_PAIR_LDS_BYTES 8192      /* K_pair, zmo: LDS slice of the window scans (measured with WTZ_OCC_PAIR: 16 KB / 1 -> 117 ms, 8 KB / 3 -> 99, 8 KB / 5 -> 90) */
+#endif
 #ifndef WTZ_PAIR_DM_LDS_BYTES
 #define WTZ_PAIR_DM_LDS_BYTES 24576  /* K_pair, dmo: LDS slice of the strand images */
 #endif
