@@ -36,7 +36,13 @@ WTZ_COOP_HOST int32_t *wtz_wave_scratch(){ return NULL; }
 #endif
 
 /* all lanes of the wavefront enter; the z-mer matching is cooperative, the order-sensitive remainder runs on lane 0 */
-WTZ_HD void wtz_task_pair(uint32_t t, const wtz_env_t &V, const uint32_t *qid, const uint32_t *cid, wtz_pairres_t *res){
+/* zmo LDS tiers: `lds_bytes_z` = slice of this launch; `may_defer`: a window scan whose matches exceed it marks the pair (dm_dir = -2)
+ * for a launch with a larger slice (`list` names the pairs of such a launch) instead of running the scalar body on lane 0 */
+#define WTZ_PAIR_LDS_TIER2 32768u
+#define WTZ_PAIR_LDS_TIER3 65536u
+WTZ_HD void wtz_task_pair(uint32_t t, const wtz_env_t &V, const uint32_t *qid, const uint32_t *cid, wtz_pairres_t *res,
+		const uint32_t *list = NULL, uint32_t lds_bytes_z = WTZ_PAIR_LDS_BYTES, bool may_defer = false){
+	if(list) t = list[t];
 	const wtz_params_t *P = V.P;
 	const uint32_t q = qid[t], c = cid[t];
 	wtz_pairres_t r; memset(&r, 0, sizeof r);
@@ -55,7 +61,7 @@ WTZ_HD void wtz_task_pair(uint32_t t, const wtz_env_t &V, const uint32_t *qid, c
 	if(ok && n * P->zsize >= P->ztot){      /* uniform: the first ordering of either engine, wave-parallel when tie-free */
 		int pbad = 0;
 		if(P->dot_matrix) sorted = wtz_sort_hits_wave<1>(hits, n, V.pool, (uint64_t*)wtz_wave_scratch(), WTZ_PAIR_DM_LDS_BYTES / 8, &pbad);
-		else              sorted = wtz_sort_hits_wave<0>(hits, n, V.pool, (uint64_t*)wtz_wave_scratch(), WTZ_PAIR_LDS_BYTES / 8, &pbad);
+		else              sorted = wtz_sort_hits_wave<0>(hits, n, V.pool, (uint64_t*)wtz_wave_scratch(), lds_bytes_z / 8, &pbad);
 		if(pbad) r.bad = 1;
 	}
 #endif
@@ -98,16 +104,18 @@ WTZ_HD void wtz_task_pair(uint32_t t, const wtz_env_t &V, const uint32_t *qid, c
 #if defined(__HIP_DEVICE_COMPILE__)
 	sc.lds = (uint64_t*)wtz_wave_scratch();
 #else
-	static thread_local uint64_t emul_lds[WTZ_PAIR_LDS_BYTES / 8];     /* host emulation: the LDS slice of the (single-lane) wave */
+	static thread_local uint64_t emul_lds[WTZ_PAIR_LDS_TIER3 / 8];     /* host emulation: the LDS slice of the (single-lane) wave */
 	sc.lds = emul_lds;
 #endif
-	sc.lds_u64 = WTZ_PAIR_LDS_BYTES / 8;
+	sc.lds_u64 = lds_bytes_z / 8;
+	uint32_t ovf = 0; sc.overflow = may_defer ? &ovf : NULL;
 	for(uint32_t dir = 0; dir < 2; dir++){
 		wtz_vec<wtz_win_t> wins; wtz_vec<wtz_zhit_t> anchors;
 		wins.a = NULL; wins.n = wins.cap = 0; wins.pool = V.pool; wins.bad = 0;
 		anchors.a = NULL; anchors.n = anchors.cap = 0; anchors.pool = V.pool; anchors.bad = 0;
 		if(lane == 0){ wins.init(V.pool, 16); anchors.init(V.pool, n + 16); }
 		const uint32_t nw = wtz_merge_windows_coop(hits, n, dir, wins, anchors, sc, P->zsize, P->kwin, P->kstep, P->zovl);
+		if(ovf) break;                       /* uniform */
 		if(lane != 0) continue;
 		if(wins.bad || anchors.bad){ r.bad = 1; continue; }
 		if(nw == 0) continue;
@@ -121,6 +129,7 @@ WTZ_HD void wtz_task_pair(uint32_t t, const wtz_env_t &V, const uint32_t *qid, c
 		r.nwin[dir] = k; r.win[dir] = wins.a; r.anchors[dir] = anchors.a; r.nanchors[dir] = anchors.n;
 	}
 	if(lane != 0) return;
+	if(ovf){ wtz_pairres_t d; memset(&d, 0, sizeof d); d.n_hits = n; d.gate = 1; d.dm_dir = -2; res[t] = d; return; }      /* redone by a launch with a larger LDS slice */
 	{ const uint64_t tk3 = WTZ_TICK(); r.tick[0] = (uint32_t)((tk1 - tk0) >> 10); r.tick[1] = (uint32_t)((tk2 - tk1) >> 10); r.tick[2] = (uint32_t)((tk3 - tk2) >> 10); r.tick[3] = (uint32_t)((tk3 - tk0) >> 10); }
 	res[t] = r;
 }

@@ -51,10 +51,22 @@ def _mutate(seq: np.ndarray, err: float, rng: np.random.Generator) -> np.ndarray
 
 def synth_reads(genome_len: int, coverage: float, seed: int = 1, mean_len: float = 10000.0,
                 sigma: float = 0.4, min_len: int = 1000, err: float = 0.15,
-                max_len: int | None = None):
-    """Returns (names, seqs) where seqs is a list of uint8 arrays of 2-bit codes."""
+                max_len: int | None = None, repeats: bool = False):
+    """Returns (names, seqs) where seqs is a list of uint8 arrays of 2-bit codes.
+    repeats: plant tandem arrays (300-bp unit x 40) and dispersed copies of a 6-kb element in the genome, so that pairs of reads
+    have thousands of off-diagonal z-mer matches (the repeat-rich shape the iid genome never produces)."""
     rng = np.random.Generator(np.random.PCG64(seed))
     genome = random_genome(genome_len, rng)
+    if repeats:
+        r2 = np.random.Generator(np.random.PCG64(seed + 7919))
+        unit = r2.integers(0, 4, size=300, dtype=np.uint8)
+        elem = r2.integers(0, 4, size=6000, dtype=np.uint8)
+        for k in range(max(2, genome_len // 60000)):
+            st = int(r2.integers(0, max(1, genome_len - 12000)))
+            arr = np.tile(unit, 40)[: min(12000, genome_len - st)]
+            genome[st:st + arr.size] = arr
+            st = int(r2.integers(0, max(1, genome_len - 6000)))
+            genome[st:st + min(6000, genome_len - st)] = elem[: min(6000, genome_len - st)]
     mu = np.log(mean_len) - 0.5 * sigma * sigma
     target = int(genome_len * coverage)
     names, seqs = [], []
