@@ -46,6 +46,7 @@ struct K_extjob_scalar;
 struct K_cigar_text;
 struct K_misc;
 struct K_gap;
+struct K_gap_wide;
 struct K_kcount;
 struct K_kfill;
 struct K_kinsert;
@@ -618,30 +619,11 @@ extern "C" int wtz_pairs_seed(wtz_ctx_t *c, const uint32_t *qid, const uint32_t 
 	const wtz_env_t V = ctx_env(c); const uint32_t *dq = c->d_qid, *dc = c->d_cid; wtz_pairres_t *dr = c->d_pairres;
 	wtz_timer tm; tm.start();
 	wtz_timer t1; t1.start();
-	CHK(wtz_launch_coop<K_pair>(0, n, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_pair((uint32_t)t, V, dq, dc, dr, NULL, WTZ_PAIR_LDS_BYTES, true); }, c->P.dot_matrix ? WTZ_PAIR_DM_LDS_BYTES : WTZ_PAIR_LDS_BYTES));
+	CHK(wtz_launch_coop<K_pair>(0, n, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_pair((uint32_t)t, V, dq, dc, dr); }, c->P.dot_matrix ? WTZ_PAIR_DM_LDS_BYTES : WTZ_PAIR_LDS_BYTES));
 	CHK(dev_sync());
 	{ const double ms1 = t1.stop(); if(getenv("WTZ_PROFILE_PAIR")) fprintf(stderr, "[pair-profile] K_pair first launch: %u pairs, %.1f ms\n", n, ms1); }
 	c->n_pairs = n; c->h_pairres.resize(n); c->have_pairs = true;
 	CHK(dev_d2h(c->h_pairres.data(), c->d_pairres, (size_t)n * sizeof(wtz_pairres_t)));
-	if(!c->P.dot_matrix){
-		/* zmo: a pair with a window scan larger than the 8 KB slice of K_pair is redone with 32 KB, then 64 KB (only there the scalar body
-		 * of a scan may run): the small slice is what lets five waves per SIMD run, the tiers keep repeat-rich pairs off lane 0 */
-		const uint32_t tiers[2] = { WTZ_PAIR_LDS_TIER2, WTZ_PAIR_LDS_TIER3 };
-		for(int tier = 0; tier < 2; tier++){
-			std::vector<uint32_t> list;
-			for(uint32_t i = 0; i < n; i++) if(c->h_pairres[i].gate && c->h_pairres[i].dm_dir == -2 && !c->h_pairres[i].bad) list.push_back(i);
-			if(list.empty()) break;
-			uint32_t *d_list = NULL; CHK(dev_alloc((void**)&d_list, list.size() * 4)); CHK(dev_h2d(d_list, list.data(), list.size() * 4));
-			const uint32_t lb = tiers[tier]; const bool more = (tier == 0);
-			wtz_timer tt; tt.start();
-			CHK(wtz_launch_coop<K_pair_big>(0, list.size(), [=] WTZ_LAMBDA (uint64_t t){ wtz_task_pair((uint32_t)t, V, dq, dc, dr, d_list, lb, more); }, lb));
-			CHK(dev_sync());
-			const double ms_t = tt.stop();
-			dev_free(d_list);
-			CHK(dev_d2h(c->h_pairres.data(), c->d_pairres, (size_t)n * sizeof(wtz_pairres_t)));
-			if(getenv("WTZ_PROFILE_PAIR")) fprintf(stderr, "[pair-profile] zmo tier %d (%u KB LDS): %zu pairs, %.1f ms\n", tier + 2, lb >> 10, list.size(), ms_t);
-		}
-	}
 	if(c->P.dot_matrix){
 		/* pairs whose strand images exceed the LDS slice of K_pair are finished by launches with larger slices: few pairs,
 		 * but they are the long ones that would otherwise bound the batch from a single lane */
@@ -858,7 +840,14 @@ extern "C" int wtz_pairs_align(wtz_ctx_t *c, const uint32_t *pair_idx, const uin
 			static int gap_side = -1; if(gap_side < 0) gap_side = (getenv("WTZ_GAP_SIDESTREAM") && atoi(getenv("WTZ_GAP_SIDESTREAM"))) ? 1 : 0;
 			hipStream_t main_stream = g_stream;
 			if(gap_side){ HIPCHK(hipEventRecord(c->ev_gap_fork, main_stream)); HIPCHK(hipStreamWaitEvent(c->stream_gap, c->ev_gap_fork, 0)); g_stream = c->stream_gap; }
-			const int rc_gap = wtz_launch_coop<K_gap>(0, nwt, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_gap((uint32_t)t, V, d_wt, d_items, d_gaps); }, WTZ_GAP_LDS_BYTES);
+			uint32_t *d_defer = NULL; CHK(dev_alloc((void**)&d_defer, (size_t)(nwt + 1) * 4)); CHK(dev_set(d_defer, 0, 4));
+			int rc_gap = wtz_launch_coop<K_gap>(0, nwt, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_gap((uint32_t)t, V, d_wt, d_items, d_gaps, d_defer, NULL, 0u); }, WTZ_GAP_LDS_BYTES);
+			if(rc_gap == WTZ_OK){
+				/* gaps whose band outgrew the register forms (repeats): the LDS-ring wave DP with 8192-column rings, 72 KB of LDS per wave */
+				uint32_t n_def = 0; rc_gap = dev_d2h(&n_def, d_defer, 4);
+				if(rc_gap == WTZ_OK && n_def) rc_gap = wtz_launch_coop<K_gap_wide>(0, n_def, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_gap((uint32_t)t, V, d_wt, d_items, d_gaps, NULL, d_defer, (uint32_t)WTZ_GAP_WIDE_LDS_BYTES); }, WTZ_GAP_WIDE_LDS_BYTES);
+				if(rc_gap == WTZ_OK && getenv("WTZ_PROFILE_PAIR")){ rc_gap = dev_sync(); fprintf(stderr, "[gap-profile] %llu window slots, %u wide gaps redone with 72 KB of LDS\n", (unsigned long long)nwt, n_def); }
+			}
 			g_stream = main_stream;
 			CHK(rc_gap);
 			if(gap_side) HIPCHK(hipEventRecord(c->ev_gap_join, c->stream_gap));

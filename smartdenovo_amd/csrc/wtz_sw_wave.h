@@ -1598,18 +1598,19 @@ WTZ_D int32_t wtz_global_wave(int32_t qlen, const SQ &query, int32_t tlen, const
 		const int32_t end = i + w + 1 < qlen ? i + w + 1 : qlen;
 		const uint32_t tbase = target.at(i);
 		const int32_t j0 = beg + lane * C;
-		uint64_t qbits;
-		{
-			const int32_t jj = j0 < qlen ? j0 : (qlen > 0 ? qlen - 1 : 0);
-			const int32_t ww = jj >> 5, sh = (jj & 31) * 2;
-			const uint64_t w0 = L.tb[ww], w1 = L.tb[ww + 1];
-			qbits = sh ? ((w0 >> sh) | (w1 << (64 - sh))) : w0;
-		}
+		uint64_t qbits = 0;
 		int32_t agg = -0x7F000000;
 		{
 			int32_t saved = 0;
 			for(int32_t k = 0; k < C; k++){
 				const int32_t j = j0 + k;
+				if((k & 31) == 0){        /* the lane's next 32 query bases (bands wider than 64 x 32 columns have more than 32 columns per lane) */
+					const int32_t jq = j0 + k;
+					const int32_t jj = jq < qlen ? jq : (qlen > 0 ? qlen - 1 : 0);
+					const int32_t ww = jj >> 5, sh = (jj & 31) * 2;
+					const uint64_t w0 = L.tb[ww], w1 = L.tb[ww + 1];
+					qbits = sh ? ((w0 >> sh) | (w1 << (64 - sh))) : w0;
+				}
 				if(j < end){
 					int32_t pred;
 					if(i == 0){ pred = (j == 0) ? 0 : ((j <= w) ? -(o_ins + e_ins * j) : WTZ_MINUS_INF); }       /* eh[] initialisation, ksw.c:519-523 */
@@ -1618,7 +1619,7 @@ WTZ_D int32_t wtz_global_wave(int32_t qlen, const SQ &query, int32_t tlen, const
 						else pred = (j == 0) ? -(o_del + e_del * i) : WTZ_MINUS_INF;
 					} else pred = saved;
 					saved = (i > 0 && j >= begp && j < endp) ? L.Hs[j & PM] : WTZ_MINUS_INF;
-					const uint32_t qb = (uint32_t)(qbits >> (2 * k)) & 3u;
+					const uint32_t qb = (uint32_t)(qbits >> (2 * (k & 31))) & 3u;
 					const int32_t m = pred + ((tbase == qb) ? M : X);
 					L.Hs[j & PM] = m;
 					const int32_t cand = m - oe_ins + (C - 1 - k) * (-e_ins);

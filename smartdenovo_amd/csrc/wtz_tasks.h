@@ -36,13 +36,7 @@ WTZ_COOP_HOST int32_t *wtz_wave_scratch(){ return NULL; }
 #endif
 
 /* all lanes of the wavefront enter; the z-mer matching is cooperative, the order-sensitive remainder runs on lane 0 */
-/* zmo LDS tiers: `lds_bytes_z` = slice of this launch; `may_defer`: a window scan whose matches exceed it marks the pair (dm_dir = -2)
- * for a launch with a larger slice (`list` names the pairs of such a launch) instead of running the scalar body on lane 0 */
-#define WTZ_PAIR_LDS_TIER2 32768u
-#define WTZ_PAIR_LDS_TIER3 65536u
-WTZ_HD void wtz_task_pair(uint32_t t, const wtz_env_t &V, const uint32_t *qid, const uint32_t *cid, wtz_pairres_t *res,
-		const uint32_t *list = NULL, uint32_t lds_bytes_z = WTZ_PAIR_LDS_BYTES, bool may_defer = false){
-	if(list) t = list[t];
+WTZ_HD void wtz_task_pair(uint32_t t, const wtz_env_t &V, const uint32_t *qid, const uint32_t *cid, wtz_pairres_t *res){
 	const wtz_params_t *P = V.P;
 	const uint32_t q = qid[t], c = cid[t];
 	wtz_pairres_t r; memset(&r, 0, sizeof r);
@@ -61,7 +55,7 @@ WTZ_HD void wtz_task_pair(uint32_t t, const wtz_env_t &V, const uint32_t *qid, c
 	if(ok && n * P->zsize >= P->ztot){      /* uniform: the first ordering of either engine, wave-parallel when tie-free */
 		int pbad = 0;
 		if(P->dot_matrix) sorted = wtz_sort_hits_wave<1>(hits, n, V.pool, (uint64_t*)wtz_wave_scratch(), WTZ_PAIR_DM_LDS_BYTES / 8, &pbad);
-		else              sorted = wtz_sort_hits_wave<0>(hits, n, V.pool, (uint64_t*)wtz_wave_scratch(), lds_bytes_z / 8, &pbad);
+		else              sorted = wtz_sort_hits_wave<0>(hits, n, V.pool, (uint64_t*)wtz_wave_scratch(), WTZ_PAIR_LDS_BYTES / 8, &pbad);
 		if(pbad) r.bad = 1;
 	}
 #endif
@@ -104,18 +98,16 @@ WTZ_HD void wtz_task_pair(uint32_t t, const wtz_env_t &V, const uint32_t *qid, c
 #if defined(__HIP_DEVICE_COMPILE__)
 	sc.lds = (uint64_t*)wtz_wave_scratch();
 #else
-	static thread_local uint64_t emul_lds[WTZ_PAIR_LDS_TIER3 / 8];     /* host emulation: the LDS slice of the (single-lane) wave */
+	static thread_local uint64_t emul_lds[WTZ_PAIR_LDS_BYTES / 8];     /* host emulation: the LDS slice of the (single-lane) wave */
 	sc.lds = emul_lds;
 #endif
-	sc.lds_u64 = lds_bytes_z / 8;
-	uint32_t ovf = 0; sc.overflow = may_defer ? &ovf : NULL;
+	sc.lds_u64 = WTZ_PAIR_LDS_BYTES / 8;
 	for(uint32_t dir = 0; dir < 2; dir++){
 		wtz_vec<wtz_win_t> wins; wtz_vec<wtz_zhit_t> anchors;
 		wins.a = NULL; wins.n = wins.cap = 0; wins.pool = V.pool; wins.bad = 0;
 		anchors.a = NULL; anchors.n = anchors.cap = 0; anchors.pool = V.pool; anchors.bad = 0;
 		if(lane == 0){ wins.init(V.pool, 16); anchors.init(V.pool, n + 16); }
 		const uint32_t nw = wtz_merge_windows_coop(hits, n, dir, wins, anchors, sc, P->zsize, P->kwin, P->kstep, P->zovl);
-		if(ovf) break;                       /* uniform */
 		if(lane != 0) continue;
 		if(wins.bad || anchors.bad){ r.bad = 1; continue; }
 		if(nw == 0) continue;
@@ -129,7 +121,6 @@ WTZ_HD void wtz_task_pair(uint32_t t, const wtz_env_t &V, const uint32_t *qid, c
 		r.nwin[dir] = k; r.win[dir] = wins.a; r.anchors[dir] = anchors.a; r.nanchors[dir] = anchors.n;
 	}
 	if(lane != 0) return;
-	if(ovf){ wtz_pairres_t d; memset(&d, 0, sizeof d); d.n_hits = n; d.gate = 1; d.dm_dir = -2; res[t] = d; return; }      /* redone by a launch with a larger LDS slice */
 	{ const uint64_t tk3 = WTZ_TICK(); r.tick[0] = (uint32_t)((tk1 - tk0) >> 10); r.tick[1] = (uint32_t)((tk2 - tk1) >> 10); r.tick[2] = (uint32_t)((tk3 - tk2) >> 10); r.tick[3] = (uint32_t)((tk3 - tk0) >> 10); }
 	res[t] = r;
 }
@@ -293,7 +284,14 @@ typedef struct { wtz_aln_t x; wtz_cigar_t cigar; uint32_t first, nreg; int32_t b
  * batch run side by side; stored at the slot of the RIGHT window of the gap */
 typedef struct { int32_t score, aln, mat, mis, ins, del; uint32_t *cigar; uint32_t cigar_len; int32_t bad, valid; } wtz_gapres_t;
 
-WTZ_HD void wtz_task_gap(uint32_t t, const wtz_env_t &V, const wtz_wintask_t *tasks, const wtz_alnitem_t *items, wtz_gapres_t *gaps){
+/* A gap whose band outgrows every register form (band doubling up to -W 3200 inside repeats: thousands of columns) used to run the
+ * scalar body on lane 0 - seconds per gap.  The first launch (`wide_lds` = 0) now appends such a gap to `defer` ([0] = count) and a
+ * second launch with WTZ_GAP_WIDE_LDS_BYTES of LDS per wave (`list` names its tasks) runs the LDS-ring wave DP with rings of 8192
+ * columns and room for 32 k query bases; only what exceeds even that stays on the scalar body. */
+#define WTZ_GAP_WIDE_LDS_BYTES (8192 + 2 * 8192 * 4)
+WTZ_HD void wtz_task_gap(uint32_t t, const wtz_env_t &V, const wtz_wintask_t *tasks, const wtz_alnitem_t *items, wtz_gapres_t *gaps,
+		uint32_t *defer = NULL, const uint32_t *list = NULL, uint32_t wide_lds = 0){
+	if(list) t = list[1 + t];
 	const wtz_params_t *P = V.P;
 	const wtz_alnitem_t &it = items[tasks[t].item];
 	const uint32_t k = tasks[t].widx;
@@ -318,6 +316,8 @@ WTZ_HD void wtz_task_gap(uint32_t t, const wtz_env_t &V, const wtz_wintask_t *ta
 		/* LDS slice: 128 sequence words (1 KB), then either the H/E rings of the general wave DP or the 4-bit trace of the
 		 * register DP with its run list at the top end */
 		wtz_wave_lds_t L; L.tb = (uint64_t*)lds; L.Hs = lds + 256; L.Es = lds + 768; L.PM = 511; L.tw = 128;
+		wtz_wave_lds_t LW = L;           /* the wide launch: 1024 query words, then two rings of 8192 columns */
+		if(wide_lds >= WTZ_GAP_WIDE_LDS_BYTES){ LW.Hs = lds + 2048; LW.Es = lds + 2048 + 8192; LW.PM = 8191; LW.tw = 1024; }
 		uint8_t *ztr = (uint8_t*)(lds + 256); const int32_t ztr_bytes = WTZ_GAP_LDS_BYTES - 1024;
 		wtz_trace_t tr; tr.chunk = NULL; tr.zb = NULL; tr.n_chunk = 0; tr.zrow = 0; tr.cap_rows = 0;
 		wtz_swmem_t mem; wtz_swmem_init(mem, V.pool);
@@ -357,10 +357,24 @@ WTZ_HD void wtz_task_gap(uint32_t t, const wtz_env_t &V, const wtz_wintask_t *ta
 				if(n_col <= 64) score = wtz_global_reg<1>(dq, q, dt, tt, M, X, -I, -E, -D, -E, w, L.tb, ztr, (uint32_t)zrow, runs, &n_runs, &r_mat, &r_mis);
 				else            score = wtz_global_reg<2>(dq, q, dt, tt, M, X, -I, -E, -D, -E, w, L.tb, ztr, (uint32_t)zrow, runs, &n_runs, &r_mat, &r_mis);
 				WTZ_PROF_ADD(32, pt_g); WTZ_PROF_CNT(33, 1000000); WTZ_PROF_MAX(34, pt_g);
-			} else if(dq > 0 && dt > 0 && n_col + 2 <= 512 && (dq + 63) / 32 + 1 <= 128 && (dt + 63) / 64 <= WTZ_TRACE_MAXCHUNK){
+			} else if(defer && dq > 0 && dt > 0 && !(n_col + 2 <= 512 && qwords <= 128) && n_col + 2 <= 8192 && qwords <= 1024 && (dt + 63) / 64 <= WTZ_TRACE_MAXCHUNK){
+				if(WTZ_LANE == 0){ const uint32_t idx = atomicAdd(&defer[0], 1u); defer[1 + idx] = t; }       /* uniform: the wide launch redoes this gap */
+				return;
+			} else if(dq > 0 && dt > 0 && n_col + 2 <= LW.PM + 1 && qwords <= LW.tw && (dt + 63) / 64 <= WTZ_TRACE_MAXCHUNK){
 				bool ok = true;
-				score = wtz_global_wave(dq, q, dt, tt, M, X, -I, -E, -D, -E, w, L, tr, V.pool, tmp, &ok);
+				score = wtz_global_wave(dq, q, dt, tt, M, X, -I, -E, -D, -E, w, LW, tr, V.pool, tmp, &ok);
 				if(!ok) bad = 1;
+#ifdef WTZ_GAP_CHECK
+				if(ok && WTZ_LANE == 0){
+					wtz_cigar_t t2; t2.init(V.pool, 32); wtz_swmem_t m2; wtz_swmem_init(m2, V.pool);
+					const int32_t s2 = wtz_global_banded(dq, q, dt, tt, M, X, -I, -E, -D, -E, w, m2, t2);
+					bool same = (s2 == __shfl(score, 0, 64) || true) && !m2.bad;
+					uint32_t firstdiff = 0xFFFFFFFFu;
+					if(!m2.bad){ if(t2.n != tmp.n) firstdiff = 0xFFFFFFFEu; else for(uint32_t z9 = 0; z9 < t2.n; z9++) if(t2.a[z9] != tmp.a[z9]){ firstdiff = z9; break; } }
+					if(!m2.bad && (s2 != score || firstdiff != 0xFFFFFFFFu)) printf("[gap-check] dq %d dt %d w %d n_col %d: score wave %d scalar %d; cigar n %u / %u first diff %u\n", dq, dt, w, n_col, score, s2, tmp.n, t2.n, firstdiff);
+					(void)same;
+				}
+#endif
 				WTZ_PROF_ADD(35, pt_g); WTZ_PROF_CNT(36, 1000000); WTZ_PROF_MAX(37, pt_g);
 				WTZ_PROF_CNT(46, (unsigned long long)dt * 1000); if(n_col > 256) WTZ_PROF_CNT(47, 1000000);
 			} else {

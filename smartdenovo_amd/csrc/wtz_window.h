@@ -241,9 +241,7 @@ WTZ_HD int32_t wtz_median(int32_t *rs, int32_t size){
 /* scratch of one (pair,strand) window scan: all sized by the number of matches of the pair.  `lds` (may be NULL) is the
  * wave's LDS slice: the small order-sensitive sorts / the quick-select run there when they fit - they are chains of
  * dependent loads on a single lane, so it is the access latency (LDS ~64 clk vs L2 ~500 clk) that matters */
-typedef struct { uint32_t *ts; int32_t *as; uint32_t *wb, *we, *wo; uint64_t *tk; wtz_zhit_t *ztmp; uint64_t *lds; uint32_t lds_u64;
-	uint32_t *overflow;      /* != NULL: a scan that does not fit the LDS slice sets it and gives up (the pair is redone with a larger slice) instead of running the scalar body */
-} wtz_winscratch_t;
+typedef struct { uint32_t *ts; int32_t *as; uint32_t *wb, *we, *wo; uint64_t *tk; wtz_zhit_t *ztmp; uint64_t *lds; uint32_t lds_u64; } wtz_winscratch_t;
 struct wtz_gt_hi32 { WTZ_HDM bool operator()(uint64_t a, uint64_t b) const { return (uint32_t)(a >> 32) > (uint32_t)(b >> 32); } };
 
 WTZ_HD uint32_t wtz_scan_windows(const wtz_zhit_t *rs, uint32_t dir, uint32_t beg, uint32_t end, int32_t bound,
@@ -433,9 +431,6 @@ WTZ_HD uint32_t wtz_scan_windows_coop(const wtz_zhit_t *rs, uint32_t dir, uint32
 		if(pass) break;
 		if(n * zsize < zovl) return 0;
 		uint32_t np0 = 64; while(np0 < n) np0 <<= 1;
-		/* a moderately oversized scan still runs the scalar body here (a few hundred matches: well under a millisecond, and the pair stays
-		 * inside this launch); only scans of repeat-rich pairs (> 1024 matches, n log n on one lane) send the pair to a larger slice */
-		if(K != NULL && np0 + 2 * n + 2 > sc.lds_u64 && sc.overflow && n > 1024u){ *sc.overflow = 1u; *max_e0 = 0; return 0; }       /* uniform: every lane sets its own copy */
 		if(K == NULL || np0 + 2 * n + 2 > sc.lds_u64){       /* does not fit: scalar body on lane 0 */
 			uint32_t r = 0; int32_t e = -0x7FFFFFFF;
 			if(lane == 0){
@@ -587,7 +582,6 @@ WTZ_HD uint32_t wtz_merge_windows_coop(const wtz_zhit_t *rs, uint32_t n_rs, uint
 			if(((o1 ^ o2) >> 31) ^ dir) continue;
 			p_off1 = o1 & 0x7FFFFFFFu; p_len1 = ll & 0xFFFFu;
 		} else { p_off1 = P_off1; p_len1 = P_len1; }
-		if(sc.overflow && *sc.overflow) return ret;
 		if(p_off1 > p0_off1 + kwin){
 			if(ol >= zovl){
 				int32_t me0 = 0;

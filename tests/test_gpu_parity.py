@@ -67,15 +67,13 @@ def test_gpu_equals_oracle_on_fresh_input(engine, gpu_exe, oracle_exe, tmp_path)
 @pytest.mark.gpu
 @pytest.mark.parametrize("engine", ["zmo", "dmo"])
 def test_gpu_equals_oracle_on_repeat_rich_input(engine, gpu_exe, oracle_exe, tmp_path):
-    """Tandem arrays + dispersed repeats: window scans with thousands of matches (zmo LDS tiers), large strand images (dmo tiers)."""
+    """Tandem arrays + dispersed repeats: window scans with thousands of matches, gaps whose band doubles, large strand images (dmo tiers)."""
     names, seqs = synth.synth_reads(150000, 10, seed=123, mean_len=9000.0, min_len=1000, repeats=True)
     fa = os.path.join(str(tmp_path), "r.fa")
     synth.write_fasta(fa, names, seqs)
     argv = FRESH[engine]
     a, b = os.path.join(str(tmp_path), "gpu.ovl"), os.path.join(str(tmp_path), "ora.ovl")
-    r = subprocess.run([gpu_exe, "-i", fa, "-fo", a] + argv, check=True, capture_output=True, env=dict(os.environ, WTZ_PROFILE_PAIR="1"))
+    subprocess.run([gpu_exe, "-i", fa, "-fo", a] + argv, check=True, capture_output=True)
     subprocess.run([oracle_exe, "-i", fa, "-fo", b] + argv, check=True, capture_output=True)
     assert open(a, "rb").read() == open(b, "rb").read()
     assert open(a + ".contained", "rb").read() == open(b + ".contained", "rb").read()
-    if engine == "zmo":
-        assert b"zmo tier" in r.stderr, "the input was meant to exercise the LDS tiers of K_pair"
