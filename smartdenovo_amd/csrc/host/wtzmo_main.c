@@ -98,6 +98,7 @@ typedef struct {       /* one batch in flight */
 	uint32_t *item_of; uint32_t *it_pair; uint8_t *it_dir; uint32_t nitem; wtz_aln_result_t *aln; char *cig; uint64_t ncig;
 	char *cigs[2]; uint64_t capcigs[2]; int cig_sel, cig_ext, ext_base;      /* two page-locked CIGAR text buffers, alternating per batch; ext ids of the output writer */
 	uint64_t spec_queries, used_queries;
+	double t_call[6], t_io0;                   /* wall seconds of this worker's device calls since the last fold into E (under E->mu) */
 	int holds_turn;
 	/* candidates of the NEXT batch, requested before this batch is committed (single worker, no -G) */
 	int pf_inflight; uint32_t *pf_ids; uint32_t pf_n, pf_cap; uint64_t *pf_rows; uint32_t *pf_nr; uint32_t pf_cursor_end;
@@ -201,11 +202,13 @@ static void out_ext(const char *p, size_t n, int ext){
 	c->iov[c->niov].iov_base = (void*)p; c->iov[c->niov].iov_len = n; c->niov++; c->bytes += n;
 	if(!(c->ext_mask & (1u << ext))){ c->ext_mask |= 1u << ext; pthread_mutex_lock(&w->mu); w->ext_busy[ext]++; pthread_mutex_unlock(&w->mu); }
 }
-/* the external buffer `ext` is about to be overwritten: everything that points into it must be on the stream */
+/* the external buffer `ext` is about to be overwritten: everything that points into it must be on the stream.  The chunk under
+ * construction (g_ow.cur) belongs to whoever holds E->mu (the committing worker) and is never looked at here: every commit hands
+ * its chunk to the writer before it gives up E->mu (process_range), so all references into a worker's buffer are already queued
+ * when that worker comes back to refill it. */
 static void out_wait_ext(int ext){
 	owriter_t *w = &g_ow;
 	if(!w->started || ext < 0 || ext >= OW_MAX_EXT) return;
-	if(w->cur && (w->cur->ext_mask & (1u << ext))) out_submit(w);
 	pthread_mutex_lock(&w->mu);
 	while(w->ext_busy[ext] > 0) pthread_cond_wait(&w->cv_ext, &w->mu);
 	pthread_mutex_unlock(&w->mu);
@@ -348,7 +351,8 @@ static void commit_query(eng_t *E, batch_t *b, uint32_t slot){
 			pend_closed(pd, hx_pair_key(id2, pbid));
 			int d1 = S->dm_qe - S->dm_qb, d2 = S->dm_te - S->dm_tb;
 			uint32_t ol = (uint32_t)(d1 > d2 ? d1 : d2);
-			if(S->dm_score >= P->min_score && S->dm_score >= (int)(P->min_id * ol)){
+			/* -N: print_hits_wtzmo gets the (empty) seed list and drops the dot-matrix hits unprinted and uncounted (wtzmo.c:1175-1210, 1319) */
+			if(E->do_align && S->dm_score >= P->min_score && S->dm_score >= (int)(P->min_id * ol)){
 				hit_t H; memset(&H, 0, sizeof H);
 				H.pb1 = pbid; H.pb2 = id2; H.dir2 = (uint32_t)S->dm_dir; H.score = S->dm_score;
 				H.tb = S->dm_tb; H.te = S->dm_te; H.qb = S->dm_qb; H.qe = S->dm_qe; H.mat = S->dm_score; H.aln = (int)ol;
@@ -472,7 +476,7 @@ static int gpu_stages(eng_t *E, batch_t *b){
 	const wtz_params_c *P = &E->P;
 	int rc;
 	b->sum = (wtz_pair_summary_t*)hx_realloc(b->sum, sizeof(wtz_pair_summary_t) * (b->npair + 1));
-	{ const double tc0 = now_s(); rc = wtz_pairs_seed(b->ctx, b->pq, b->pc, b->npair, b->sum); E->t_call[1] += now_s() - tc0; } TRY_WTZ(rc, "wtz_pairs_seed");
+	{ const double tc0 = now_s(); rc = wtz_pairs_seed(b->ctx, b->pq, b->pc, b->npair, b->sum); b->t_call[1] += now_s() - tc0; } TRY_WTZ(rc, "wtz_pairs_seed");
 	b->nitem = 0; b->ncig = 0;
 	if(!P->dot_matrix){
 		b->box_off = (uint64_t*)hx_realloc(b->box_off, 8 * ((size_t)b->npair * 2 + 1));
@@ -480,7 +484,7 @@ static int gpu_stages(eng_t *E, batch_t *b){
 		for(uint32_t i = 0; i < b->npair; i++) for(int d = 0; d < 2; d++){ b->box_off[(size_t)i * 2 + d] = nb; nb += b->sum[i].nwin[d]; }
 		b->box_off[(size_t)b->npair * 2] = nb; b->nbox = nb;
 		if(nb > b->capbox){ b->capbox = nb; b->boxes = (wtz_winbox_t*)hx_realloc(b->boxes, sizeof(wtz_winbox_t) * nb); }
-		{ const double tc0 = now_s(); rc = wtz_pairs_windows(b->ctx, b->boxes, nb); E->t_call[2] += now_s() - tc0; } TRY_WTZ(rc, "wtz_pairs_windows");
+		{ const double tc0 = now_s(); rc = wtz_pairs_windows(b->ctx, b->boxes, nb); b->t_call[2] += now_s() - tc0; } TRY_WTZ(rc, "wtz_pairs_windows");
 		b->item_of = (uint32_t*)hx_realloc(b->item_of, 4 * ((size_t)b->npair + 1));
 		b->it_pair = (uint32_t*)hx_realloc(b->it_pair, 4 * ((size_t)b->npair + 1));
 		b->it_dir = (uint8_t*)hx_realloc(b->it_dir, (size_t)b->npair + 1);
@@ -493,14 +497,14 @@ static int gpu_stages(eng_t *E, batch_t *b){
 		}
 		if(b->nitem){
 			b->aln = (wtz_aln_result_t*)hx_realloc(b->aln, sizeof(wtz_aln_result_t) * b->nitem);
-			{ const double tc0 = now_s(); rc = wtz_pairs_align(b->ctx, b->it_pair, b->it_dir, b->nitem, b->aln); E->t_call[3] += now_s() - tc0; } TRY_WTZ(rc, "wtz_pairs_align");
+			{ const double tc0 = now_s(); rc = wtz_pairs_align(b->ctx, b->it_pair, b->it_dir, b->nitem, b->aln); b->t_call[3] += now_s() - tc0; } TRY_WTZ(rc, "wtz_pairs_align");
 			uint64_t tot = 0; for(uint32_t i = 0; i < b->nitem; i++) tot += b->aln[i].text_len;
 			{
 				/* the other page-locked buffer of this worker: the records of the previous batch may still be waiting for the writer
 				 * thread inside the first one.  Grown geometrically; both are kept for every later batch and step. */
 				const int sel = (b->cig_sel ^= 1);
 				b->cig_ext = b->ext_base >= 0 ? b->ext_base + sel : -1;
-				{ const double tw0 = now_s(); out_wait_ext(b->cig_ext); E->t_io[0] += now_s() - tw0; }
+				{ const double tw0 = now_s(); out_wait_ext(b->cig_ext); b->t_io0 += now_s() - tw0; }
 				if(tot > b->capcigs[sel]){
 					uint64_t cap = b->capcigs[sel] ? b->capcigs[sel] : ((uint64_t)16 << 20); while(cap < tot) cap += cap / 2;
 					wtz_host_free(b->cigs[sel]); b->cigs[sel] = (char*)wtz_host_alloc(cap + 1); b->capcigs[sel] = cap;
@@ -508,7 +512,7 @@ static int gpu_stages(eng_t *E, batch_t *b){
 				}
 				b->cig = b->cigs[sel];
 			}
-			{ const double tc0 = now_s(); rc = wtz_fetch_cigar_text(b->ctx, b->cig, tot); E->t_call[4] += now_s() - tc0; } TRY_WTZ(rc, "wtz_fetch_cigar_text");     /* rendered on the device */
+			{ const double tc0 = now_s(); rc = wtz_fetch_cigar_text(b->ctx, b->cig, tot); b->t_call[4] += now_s() - tc0; } TRY_WTZ(rc, "wtz_fetch_cigar_text");     /* rendered on the device */
 			b->ncig = tot;
 		}
 	}
@@ -557,6 +561,8 @@ static void process_range(eng_t *E, batch_t *b, uint32_t s0, uint32_t s1){
 	if(s0 == 0 && s1 == b->nbq && !b->pf_inflight){ pthread_mutex_lock(&E->mu); prefetch_begin(E, b); pthread_mutex_unlock(&E->mu); }
 	pthread_mutex_lock(&E->mu);
 	E->t_gpu += tg1 - tg0;
+	for(int k = 0; k < 5; k++){ E->t_call[k] += b->t_call[k]; b->t_call[k] = 0; }
+	E->t_io[0] += b->t_io0; b->t_io0 = 0;
 	while(!b->holds_turn && E->commit_seq != b->seq) pthread_cond_wait(&E->cv, &E->mu);
 	b->holds_turn = 1;
 	E->spec_pairs += b->npair; E->spec_items += b->nitem;
@@ -566,6 +572,7 @@ static void process_range(eng_t *E, batch_t *b, uint32_t s0, uint32_t s1){
 		flush_pending(E);
 		commit_query(E, b, s);
 	}
+	out_submit(&g_ow);      /* nothing of this batch stays in the chunk under construction (see out_wait_ext) */
 	E->t_commit += now_s() - tg1;
 	pthread_mutex_unlock(&E->mu);
 }
@@ -670,7 +677,7 @@ int main(int argc, char **argv){
 	strlist_t pbs = {0}, flts = {0}, ovls = {0}, obts = {0}, tbas = {0};
 	char *output = NULL, *pairoutf = NULL, *statsf = NULL;
 	int c, min_rdlen = 0, overwrite = 0, dot_matrix = 0, write_contained = 1, refine = 0, gpu = 0, lib_check = 0, repeat = 1;
-	uint64_t pool_gb = 0; float optval;
+	uint64_t pool_gb = 0, pool_mb = 0; float optval;
 	/* defaults: wtzmo.c:1543-1588 */
 	P->w = 50; P->ew = 800; P->W = 3200; P->M = 2; P->X = -5; P->O = -3; P->E = -1; P->T = -50;
 	P->min_score = 200; P->min_id = 0.5f; P->hk = 1; P->hz = 1; P->ksize = 16; P->zsize = 10;
@@ -680,7 +687,7 @@ int main(int argc, char **argv){
 	E->do_align = 1; E->n_idx = 1; E->n_job = 1; E->i_job = 0; E->max_batch = 2048; E->first_batch = 256; E->n_workers = 1;
 	pthread_mutex_init(&E->mu, NULL); pthread_cond_init(&E->cv, NULL);
 	static struct option lopts[] = { {"stats", required_argument, 0, 1000}, {"gpu", required_argument, 0, 1001}, {"pool-gb", required_argument, 0, 1002},
-		{"batch", required_argument, 0, 1003}, {"lib-check", no_argument, 0, 1004}, {"repeat", required_argument, 0, 1005}, {"first-batch", required_argument, 0, 1006}, {"workers", required_argument, 0, 1007}, {0, 0, 0, 0} };
+		{"batch", required_argument, 0, 1003}, {"lib-check", no_argument, 0, 1004}, {"repeat", required_argument, 0, 1005}, {"first-batch", required_argument, 0, 1006}, {"workers", required_argument, 0, 1007}, {"pool-mb", required_argument, 0, 1008}, {0, 0, 0, 0} };
 	while((c = getopt_long(argc, argv, "ht:P:p:Ni:b:J:I:o:9:S:fCH:k:G:z:Z:U:y:d:r:q:l:K:A:B:r:R:L:F:W:w:e:M:X:O:E:T:s:m:nv", lopts, NULL)) != -1){
 		switch(c){
 			case 1000: statsf = optarg; break;
@@ -690,6 +697,7 @@ int main(int argc, char **argv){
 			case 1004: lib_check = 1; break;
 			case 1005: repeat = atoi(optarg); if(repeat < 1) repeat = 1; break;
 			case 1006: E->first_batch = (uint32_t)atoi(optarg); if(E->first_batch < 1) E->first_batch = 1; E->first_batch_set = 1; break;
+			case 1008: pool_mb = (uint64_t)atoll(optarg); break;      /* test hook: a pool small enough to force the batch-splitting path */
 			case 1007: E->n_workers = (uint32_t)atoi(optarg); if(E->n_workers < 1) E->n_workers = 1; if(E->n_workers > 8) E->n_workers = 8; break;
 			case 'h': return usage();
 			case 't': break;
@@ -824,13 +832,14 @@ int main(int argc, char **argv){
 		hx_reader_close(fr);
 	}
 	/* ---- device ---- */
+	const uint64_t pool_bytes = pool_mb ? pool_mb << 20 : pool_gb << 30;
 	E->rdlen = (uint32_t*)hx_realloc(NULL, 4 * ((size_t)n_all + 1));
 	uint64_t *rdoff = (uint64_t*)hx_realloc(NULL, 8 * ((size_t)n_all + 1));
 	{ uint64_t tot = 0; uint32_t nq = E->st.n_qr ? E->st.n_qr : n_rd, b0 = E->st.n_qr ? n_rd : 0;
 	  for(uint32_t i = 0; i < n_all; i++){ E->rdlen[i] = E->st.reads[i].len; rdoff[i] = E->st.reads[i].off; }
 	  for(uint32_t i = 0; i < nq; i++) tot += E->rdlen[b0 + i];
 	  E->avg_rdlen = nq ? (uint32_t)(tot / nq) : 10000; if(E->avg_rdlen == 0) E->avg_rdlen = 1; }        /* wtzmo.c:361-368 */
-	int rc = wtz_ctx_create(gpu, P, pool_gb << 30, &E->ctx); DIE_WTZ(rc, "wtz_ctx_create");
+	int rc = wtz_ctx_create(gpu, P, pool_bytes, &E->ctx); DIE_WTZ(rc, "wtz_ctx_create");
 	rc = wtz_upload_reads(E->ctx, E->st.bits, (E->st.nbase + 31) / 32, rdoff, E->rdlen, n_all); DIE_WTZ(rc, "wtz_upload_reads");
 	/* page-lock the first worker's CIGAR text buffer while the indexes are built (pinning ~100 MB takes about as long as they do) */
 	pthread_t pin_th; int pin_started = 0;
@@ -922,7 +931,7 @@ int main(int argc, char **argv){
 				bs[w].ext_base = w < 8 ? (int)w * 2 : -1;
 				if(w < 8) for(int k = 0; k < 2; k++){ bs[w].cigs[k] = E->cig_keep[w * 2 + k]; bs[w].capcigs[k] = E->cig_keep_cap[w * 2 + k]; E->cig_keep[w * 2 + k] = NULL; E->cig_keep_cap[w * 2 + k] = 0; }
 				if(w == 0) bs[w].ctx = E->ctx;
-				else { rc = wtz_ctx_clone(E->ctx, pool_gb << 30, &bs[w].ctx); DIE_WTZ(rc, "wtz_ctx_clone"); }
+				else { rc = wtz_ctx_clone(E->ctx, pool_bytes, &bs[w].ctx); DIE_WTZ(rc, "wtz_ctx_clone"); }
 			}
 			for(uint32_t w = 1; w < nw; w++) pthread_create(&th[w], NULL, worker_main, &bs[w]);
 			worker_main(&bs[0]);

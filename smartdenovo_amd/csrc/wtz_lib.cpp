@@ -264,6 +264,7 @@ struct wtz_ctx {
 	/* candidate request in flight (wtz_candidates_begin / _end) */
 	uint32_t *cq_q = NULL, *cq_nc = NULL; uint64_t *cq_cand = NULL; unsigned long long *cq_bytes = NULL; uint32_t cq_cap = 0, cq_n = 0; bool cq_pending = false; wtz_timer cq_tm;
 	wtz_counters_t cnt;
+	int env_sw_mode = 0, env_mw_min = 512, env_mw_top = 1 << 30, env_use_reg = 1, env_gap_side = 0; bool env_profile = false;     /* WTZ_* debugging switches, read in wtz_ctx_create */
 };
 
 #ifndef WTZ_EMUL
@@ -310,12 +311,6 @@ extern "C" int wtz_ctx_create(int device, const wtz_params_c *params, uint64_t p
 	c->device = device; c->P = *params; c->dP = NULL; c->shares_indexes = false;
 #ifndef WTZ_EMUL
 	c->stream = 0;
-	if(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess){ delete c; return wtz_fail(WTZ_E_HIP, "hipStreamCreate failed"); }
-	if(hipStreamCreateWithFlags(&c->stream_mw, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->ev_mw_fork, hipEventDisableTiming) != hipSuccess
-			|| hipEventCreateWithFlags(&c->ev_mw_join, hipEventDisableTiming) != hipSuccess){ delete c; return wtz_fail(WTZ_E_HIP, "hipStreamCreate failed"); }
-	if(hipStreamCreateWithFlags(&c->stream_gap, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->ev_gap_fork, hipEventDisableTiming) != hipSuccess
-			|| hipEventCreateWithFlags(&c->ev_gap_join, hipEventDisableTiming) != hipSuccess){ delete c; return wtz_fail(WTZ_E_HIP, "hipStreamCreate failed"); }
-	g_stream = c->stream;
 #endif
 	c->bits = NULL; c->rdoff = NULL; c->rdlen = NULL; c->n_reads = 0; c->n_words = 0;
 	c->ktab = NULL; c->kseeds = NULL; c->kmask = 0; c->n_kocc = 0;
@@ -335,6 +330,22 @@ extern "C" int wtz_ctx_create(int device, const wtz_params_c *params, uint64_t p
 	c->arena.base = NULL; c->arena.cap = 0; c->arena.top = 0;
 	{ void *ab = NULL; const size_t acap = (size_t)3 << 29;      /* 1.5 GB */
 	  if(hipMalloc(&ab, acap) == hipSuccess){ c->arena.base = (uint8_t*)ab; c->arena.cap = acap; } }
+#endif
+#ifndef WTZ_EMUL
+	/* every failure from here on unwinds through wtz_ctx_destroy (all fields are initialised; it skips what does not exist yet) */
+	if(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess
+			|| hipStreamCreateWithFlags(&c->stream_mw, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->ev_mw_fork, hipEventDisableTiming) != hipSuccess
+			|| hipEventCreateWithFlags(&c->ev_mw_join, hipEventDisableTiming) != hipSuccess
+			|| hipStreamCreateWithFlags(&c->stream_gap, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->ev_gap_fork, hipEventDisableTiming) != hipSuccess
+			|| hipEventCreateWithFlags(&c->ev_gap_join, hipEventDisableTiming) != hipSuccess){ wtz_ctx_destroy(c); return wtz_fail(WTZ_E_HIP, "hipStreamCreate / hipEventCreate failed"); }
+	g_stream = c->stream;
+	/* debugging switches are read once per context, not lazily from worker threads */
+	c->env_sw_mode = 0; if(getenv("WTZ_SW_SCALAR") && atoi(getenv("WTZ_SW_SCALAR"))) c->env_sw_mode = 1; if(getenv("WTZ_SW_CHECK") && atoi(getenv("WTZ_SW_CHECK"))) c->env_sw_mode = 2;
+	c->env_mw_min = getenv("WTZ_SW_MW_MIN") ? atoi(getenv("WTZ_SW_MW_MIN")) : 512;        /* measured flat between 128 and 1024 (tools/gpu_mw_sweep.sh); 0 = one wave per job always */
+	c->env_mw_top = getenv("WTZ_SW_MW_TOP") ? atoi(getenv("WTZ_SW_MW_TOP")) : 1 << 30;
+	c->env_use_reg = !(getenv("WTZ_SW_NOREG") && atoi(getenv("WTZ_SW_NOREG")));
+	c->env_gap_side = (getenv("WTZ_GAP_SIDESTREAM") && atoi(getenv("WTZ_GAP_SIDESTREAM"))) ? 1 : 0;
+	c->env_profile = getenv("WTZ_PROFILE_PAIR") != NULL;
 #endif
 	int rc;
 	if((rc = dev_alloc_persist((void**)&c->dP, sizeof(wtz_params_t))) || (rc = dev_h2d(c->dP, &c->P, sizeof(wtz_params_t))) ||
@@ -387,8 +398,9 @@ extern "C" void wtz_ctx_destroy(wtz_ctx_t *c){
 	if(!c->shares_indexes){ dev_free_persist(c->bits); dev_free_persist(c->rdoff); dev_free_persist(c->rdlen); }
 	dev_free_persist(c->dP); dev_free_persist(c->dpool); dev_free_persist(c->pool_base);
 #ifndef WTZ_EMUL
-	if(c->stream_mw){ (void)hipStreamDestroy(c->stream_mw); (void)hipEventDestroy(c->ev_mw_fork); (void)hipEventDestroy(c->ev_mw_join); }
-	if(c->stream_gap){ (void)hipStreamDestroy(c->stream_gap); (void)hipEventDestroy(c->ev_gap_fork); (void)hipEventDestroy(c->ev_gap_join); }
+	if(c->stream_mw) (void)hipStreamDestroy(c->stream_mw);
+	if(c->stream_gap) (void)hipStreamDestroy(c->stream_gap);
+	{ hipEvent_t evs[4] = { c->ev_mw_fork, c->ev_mw_join, c->ev_gap_fork, c->ev_gap_join }; for(int k = 0; k < 4; k++) if(evs[k]) (void)hipEventDestroy(evs[k]); }
 	if(c->stream) (void)hipStreamDestroy(c->stream);
 #endif
 	delete c;
@@ -621,7 +633,7 @@ extern "C" int wtz_pairs_seed(wtz_ctx_t *c, const uint32_t *qid, const uint32_t 
 	wtz_timer t1; t1.start();
 	CHK(wtz_launch_coop<K_pair>(0, n, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_pair((uint32_t)t, V, dq, dc, dr); }, c->P.dot_matrix ? WTZ_PAIR_DM_LDS_BYTES : WTZ_PAIR_LDS_BYTES));
 	CHK(dev_sync());
-	{ const double ms1 = t1.stop(); if(getenv("WTZ_PROFILE_PAIR")) fprintf(stderr, "[pair-profile] K_pair first launch: %u pairs, %.1f ms\n", n, ms1); }
+	{ const double ms1 = t1.stop(); if(c->env_profile) fprintf(stderr, "[pair-profile] K_pair first launch: %u pairs, %.1f ms\n", n, ms1); }
 	c->n_pairs = n; c->h_pairres.resize(n); c->have_pairs = true;
 	CHK(dev_d2h(c->h_pairres.data(), c->d_pairres, (size_t)n * sizeof(wtz_pairres_t)));
 	if(c->P.dot_matrix){
@@ -640,12 +652,12 @@ extern "C" int wtz_pairs_seed(wtz_ctx_t *c, const uint32_t *qid, const uint32_t 
 			const double ms_t = tt.stop();
 			dev_free(d_list);
 			CHK(dev_d2h(c->h_pairres.data(), c->d_pairres, (size_t)n * sizeof(wtz_pairres_t)));
-			if(getenv("WTZ_PROFILE_PAIR")) fprintf(stderr, "[pair-profile] dmo tier %d (%u KB LDS): %zu pairs, %.1f ms\n", tier + 2, lb >> 10, list.size(), ms_t);
+			if(c->env_profile) fprintf(stderr, "[pair-profile] dmo tier %d (%u KB LDS): %zu pairs, %.1f ms\n", tier + 2, lb >> 10, list.size(), ms_t);
 		}
 	}
 	c->cnt.ms_pairs += tm.stop(); c->cnt.n_pairs += n;
 	CHK(pool_check(c, "wtz_pairs_seed"));
-	if(getenv("WTZ_PROFILE_PAIR")){
+	if(c->env_profile){
 		uint64_t sum[4] = {0, 0, 0, 0}; uint32_t mx[4] = {0, 0, 0, 0}, arg = 0;
 		for(uint32_t i = 0; i < n; i++){ for(int k = 0; k < 4; k++){ sum[k] += c->h_pairres[i].tick[k]; if(c->h_pairres[i].tick[k] > mx[k]){ mx[k] = c->h_pairres[i].tick[k]; if(k == 3) arg = i; } } }
 		fprintf(stderr, "[pair-profile] n=%u kticks sum match/sort/win/total %llu/%llu/%llu/%llu max %u/%u/%u/%u; slowest pair: hits %u (its match/sort/win %u/%u/%u)\n", n,
@@ -694,8 +706,7 @@ static int run_extjobs(wtz_ctx *c, const wtz_env_t &V, wtz_extjob_t *d_jobs, uin
 #ifdef WTZ_EMUL
 	return wtz_launch_wave<K_extjob_scalar>(0, m, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_extjob_scalar((uint32_t)t, V, d_jobs); });
 #else
-	static int mode = -1;
-	if(mode < 0){ mode = 0; if(getenv("WTZ_SW_SCALAR") && atoi(getenv("WTZ_SW_SCALAR"))) mode = 1; if(getenv("WTZ_SW_CHECK") && atoi(getenv("WTZ_SW_CHECK"))) mode = 2; }
+	const int mode = c->env_sw_mode;
 	if(mode == 1) return wtz_launch_wave<K_extjob_scalar>(0, m, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_extjob_scalar((uint32_t)t, V, d_jobs); });
 	std::vector<wtz_extjob_t> ref;
 	if(mode == 2){
@@ -709,8 +720,7 @@ static int run_extjobs(wtz_ctx *c, const wtz_env_t &V, wtz_extjob_t *d_jobs, uin
 	/* longest-processing-time-first: the rows of an extension are sequential, so the longest job bounds the launch;
 	 * start the long ones first (key = query-side length, the row count upper bound) */
 	uint32_t *d_order = NULL; unsigned long long ext_sum = 0; int32_t ext_max = 0; uint32_t n_mw = 0;
-	static int mw_min = -1;
-	if(mw_min < 0) mw_min = getenv("WTZ_SW_MW_MIN") ? atoi(getenv("WTZ_SW_MW_MIN")) : 512;        /* measured flat between 128 and 1024 (tools/gpu_mw_sweep.sh); 0 = one wave per job always */
+	const int mw_min = c->env_mw_min;
 	{
 		int32_t *d_key = NULL; CHK(dev_alloc((void**)&d_key, (size_t)m * 4));
 		CHK(wtz_launch<K_misc>(0, m, [=] WTZ_LAMBDA (uint64_t t){ d_key[t] = d_jobs[t].valid ? d_jobs[t].qlen : -1; }));
@@ -719,14 +729,12 @@ static int run_extjobs(wtz_ctx *c, const wtz_env_t &V, wtz_extjob_t *d_jobs, uin
 		std::vector<uint32_t> ord(m); for(uint32_t i = 0; i < m; i++) ord[i] = i;
 		std::stable_sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t b){ return key[a] > key[b]; });
 		CHK(dev_alloc((void**)&d_order, (size_t)m * 4)); CHK(dev_h2d(d_order, ord.data(), (size_t)m * 4));
-		static int mw_top = -1;
-		if(mw_top < 0) mw_top = getenv("WTZ_SW_MW_TOP") ? atoi(getenv("WTZ_SW_MW_TOP")) : 1 << 30;
+		const int mw_top = c->env_mw_top;
 		if(mw_min > 0) while(n_mw < m && n_mw < (uint32_t)mw_top && key[ord[n_mw]] >= mw_min) n_mw++;          /* the long jobs head the order: four waves each */
 	}
 	{
 		wtz_timer te; te.start();
-		static int use_reg = -1;
-		if(use_reg < 0) use_reg = !(getenv("WTZ_SW_NOREG") && atoi(getenv("WTZ_SW_NOREG")));
+		const int use_reg = c->env_use_reg;
 		if(use_reg){
 			if(n_mw){
 				/* long jobs on a side stream, concurrently with the one-wave kernel over the rest */
@@ -745,7 +753,7 @@ static int run_extjobs(wtz_ctx *c, const wtz_env_t &V, wtz_extjob_t *d_jobs, uin
 		HIPCHK(hipGetLastError());
 		const double ms_l = te.stop();
 		c->cnt.ms_ext += ms_l; c->cnt.n_extjobs += m;
-		if(getenv("WTZ_PROFILE_PAIR")){
+		if(c->env_profile){
 			std::vector<int32_t> key(m); uint32_t nv = 0, n256 = 0, n512 = 0, n1k = 0, n2k = 0, n4k = 0; unsigned long long s512 = 0;
 			CHK(dev_sync());
 			{ std::vector<wtz_extjob_t> jj(m); CHK(dev_d2h(jj.data(), d_jobs, (size_t)m * sizeof(wtz_extjob_t))); uint32_t nd[4] = {0, 0, 0, 0}; for(uint32_t i = 0; i < m; i++){ key[i] = jj[i].valid ? jj[i].x.qe : -1; if(jj[i].valid) nd[jj[i].done & 3]++; }
@@ -781,7 +789,7 @@ extern "C" int wtz_pairs_align(wtz_ctx_t *c, const uint32_t *pair_idx, const uin
 	CTX_ENTER(c);
 	if(!pair_idx || !dir || !out) return wtz_fail(WTZ_E_ARG, "null argument");
 	c->n_items = 0; c->have_items = false;
-	const bool prof_wall = getenv("WTZ_PROFILE_PAIR") != NULL; double tw[6] = {0, 0, 0, 0, 0, 0}; double tw0 = prof_wall ? wtz_wall() : 0;
+	const bool prof_wall = c->env_profile; double tw[6] = {0, 0, 0, 0, 0, 0}; double tw0 = prof_wall ? wtz_wall() : 0;
 	auto lapw = [&](int k){ if(prof_wall){ const double t = wtz_wall(); tw[k] += t - tw0; tw0 = t; } };
 	CHK(reserve_items(c, m));
 	std::vector<wtz_alnitem_t> items(m); std::vector<wtz_wintask_t> wt; uint64_t nreg = 0;
@@ -813,7 +821,7 @@ extern "C" int wtz_pairs_align(wtz_ctx_t *c, const uint32_t *pair_idx, const uin
 		CHK(wtz_launch_coop<K_winalign>(0, wt.size(), [=] WTZ_LAMBDA (uint64_t t){ wtz_task_winalign<false>((uint32_t)t, V, d_wt, d_items, d_defer, NULL); }, WTZ_WINALIGN_LDS_BYTES));
 		uint32_t n_def = 0; CHK(dev_d2h(&n_def, d_defer, 4));
 		if(n_def) CHK(wtz_launch_coop<K_winalign_big>(0, n_def, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_winalign<true>((uint32_t)t, V, d_wt, d_items, NULL, d_defer); }, WTZ_WINALIGN_LDS_BYTES));
-		if(getenv("WTZ_PROFILE_PAIR")) fprintf(stderr, "[winalign-profile] %zu windows, %u redone by the full task\n", wt.size(), n_def);
+		if(c->env_profile) fprintf(stderr, "[winalign-profile] %zu windows, %u redone by the full task\n", wt.size(), n_def);
 		dev_free(d_defer);
 	}
 #endif
@@ -837,7 +845,7 @@ extern "C" int wtz_pairs_align(wtz_ctx_t *c, const uint32_t *pair_idx, const uin
 			 * gap kernel can run on its own stream and fill the CUs the extension tail leaves idle; stitch_mid waits for both */
 			/* measured: ~5 ms of 150 on the E. coli shape, inside run-to-run noise, and it folds K_gap's contention into the K-sw3 stage
 			 * time that bench.py reports against the roofline -> opt-in (WTZ_GAP_SIDESTREAM=1) */
-			static int gap_side = -1; if(gap_side < 0) gap_side = (getenv("WTZ_GAP_SIDESTREAM") && atoi(getenv("WTZ_GAP_SIDESTREAM"))) ? 1 : 0;
+			const int gap_side = c->env_gap_side;
 			hipStream_t main_stream = g_stream;
 			if(gap_side){ HIPCHK(hipEventRecord(c->ev_gap_fork, main_stream)); HIPCHK(hipStreamWaitEvent(c->stream_gap, c->ev_gap_fork, 0)); g_stream = c->stream_gap; }
 			uint32_t *d_defer = NULL; CHK(dev_alloc((void**)&d_defer, (size_t)(nwt + 1) * 4)); CHK(dev_set(d_defer, 0, 4));
@@ -846,7 +854,7 @@ extern "C" int wtz_pairs_align(wtz_ctx_t *c, const uint32_t *pair_idx, const uin
 				/* gaps whose band outgrew the register forms (repeats): the LDS-ring wave DP with 8192-column rings, 72 KB of LDS per wave */
 				uint32_t n_def = 0; rc_gap = dev_d2h(&n_def, d_defer, 4);
 				if(rc_gap == WTZ_OK && n_def) rc_gap = wtz_launch_coop<K_gap_wide>(0, n_def, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_gap((uint32_t)t, V, d_wt, d_items, d_gaps, NULL, d_defer, (uint32_t)WTZ_GAP_WIDE_LDS_BYTES); }, WTZ_GAP_WIDE_LDS_BYTES);
-				if(rc_gap == WTZ_OK && getenv("WTZ_PROFILE_PAIR")){ rc_gap = dev_sync(); fprintf(stderr, "[gap-profile] %llu window slots, %u wide gaps redone with 72 KB of LDS\n", (unsigned long long)nwt, n_def); }
+				if(rc_gap == WTZ_OK && c->env_profile){ rc_gap = dev_sync(); fprintf(stderr, "[gap-profile] %llu window slots, %u wide gaps redone with 72 KB of LDS\n", (unsigned long long)nwt, n_def); }
 			}
 			g_stream = main_stream;
 			CHK(rc_gap);
@@ -945,7 +953,7 @@ extern "C" int wtz_get_counters(wtz_ctx_t *c, wtz_counters_t *out){
 	if(!c || !out) return wtz_fail(WTZ_E_ARG, "null argument");
 	*out = c->cnt;
 #if !defined(WTZ_EMUL) && defined(WTZ_PROFILE)
-	if(getenv("WTZ_PROFILE_PAIR")){        /* device phase profiler: Mticks per slot since the last report */
+	if(c->env_profile){        /* device phase profiler: Mticks per slot since the last report */
 		unsigned long long h[48], z[48]; memset(z, 0, sizeof z);
 		if(hipMemcpyFromSymbol(h, HIP_SYMBOL(wtz_prof), sizeof h) == hipSuccess){
 			fprintf(stderr, "[phase-profile] Mticks:");

@@ -45,11 +45,15 @@ WTZ_HD void wtz_swmem_init_lds(wtz_swmem_t &m, wtz_pool_t *pool, int32_t *lds, u
 	if(lds && lds_ints >= 128){ m.rh = lds; m.re = lds + lds_ints / 2; m.cap_row = lds_ints / 2; }
 }
 WTZ_HD bool wtz_swmem_need(wtz_swmem_t &m, uint32_t row, uint32_t zb, uint64_t z){
+	/* a failed request is sticky: the capacities only grow after BOTH pointers of a request exist, so a later problem of the same
+	 * task can never run on a NULL row buffer after the pool ran dry (the task reports `bad`, the stage WTZ_E_POOL) */
+	if(m.bad) return false;
 	if(row > m.cap_row){ uint32_t c = m.cap_row ? m.cap_row : 64; while(c < row) c <<= 1;
-		m.rh = (int32_t*)wtz_pool_alloc(m.pool, (size_t)c * 4); m.re = (int32_t*)wtz_pool_alloc(m.pool, (size_t)c * 4); m.cap_row = c;
-		if(!m.rh || !m.re){ m.bad = 1; return false; } }
-	if(zb > m.cap_zb){ uint32_t c = m.cap_zb ? m.cap_zb : 64; while(c < zb) c <<= 1; m.zb = (int32_t*)wtz_pool_alloc(m.pool, (size_t)c * 4); m.cap_zb = c; if(!m.zb){ m.bad = 1; return false; } }
-	if(z > m.cap_z){ uint64_t c = m.cap_z ? m.cap_z : 1024; while(c < z) c <<= 1; m.z = (uint8_t*)wtz_pool_alloc(m.pool, (size_t)c); m.cap_z = c; if(!m.z){ m.bad = 1; return false; } }
+		int32_t *rh = (int32_t*)wtz_pool_alloc(m.pool, (size_t)c * 4), *re = (int32_t*)wtz_pool_alloc(m.pool, (size_t)c * 4);
+		if(!rh || !re){ m.bad = 1; return false; }
+		m.rh = rh; m.re = re; m.cap_row = c; }
+	if(zb > m.cap_zb){ uint32_t c = m.cap_zb ? m.cap_zb : 64; while(c < zb) c <<= 1; int32_t *p = (int32_t*)wtz_pool_alloc(m.pool, (size_t)c * 4); if(!p){ m.bad = 1; return false; } m.zb = p; m.cap_zb = c; }
+	if(z > m.cap_z){ uint64_t c = m.cap_z ? m.cap_z : 1024; while(c < z) c <<= 1; uint8_t *p = (uint8_t*)wtz_pool_alloc(m.pool, (size_t)c); if(!p){ m.bad = 1; return false; } m.z = p; m.cap_z = c; }
 	return true;
 }
 

@@ -1907,9 +1907,11 @@ WTZ_D bool wtz_refine_wave(const wtz_seq_packed &query, int32_t qb, const wtz_se
 	unsigned long long ba = 0;
 	if(lane == 0) ba = (unsigned long long)(uintptr_t)wtz_pool_alloc(pool, (size_t)(ql + 2) * (4 * 3 + 8));
 	ba = __shfl(ba, 0, 64);
-	int32_t *zw = (int32_t*)(uintptr_t)ba;
-	if(zw == NULL) return false;
-	int32_t *zb = zw + (ql + 2), *ze = zb + (ql + 2); unsigned long long *zoff = (unsigned long long*)(ze + (ql + 2));
+	if(ba == 0) return false;
+	/* the 64-bit array leads the (16-byte aligned) block so that it is 8-byte aligned for every ql */
+	unsigned long long *zoff = (unsigned long long*)(uintptr_t)ba;
+	int32_t *zw = (int32_t*)(zoff + (ql + 2));
+	int32_t *zb = zw + (ql + 2), *ze = zb + (ql + 2);
 	for(int32_t i = lane; i < ql + 2; i += 64) zw[i] = 0;
 	__threadfence_block();
 	unsigned long long ztot = 0; int32_t maxw = 0;

@@ -528,8 +528,10 @@ static inline bool wtz_refine_scalar(const wtz_seq_packed &query, int32_t qb, co
 	if(ql == 0 || tl == 0){ *res = y; return true; }
 	int32_t *zw = (int32_t*)wtz_pool_alloc(pool, (size_t)(ql + 2) * (4 * 3 + 8) + (size_t)(tl + 2) * 8);
 	if(zw == NULL) return false;
-	int32_t *zb = zw + (ql + 2), *ze = zb + (ql + 2); unsigned long long *zoff = (unsigned long long*)(ze + (ql + 2));
-	int32_t *rh = (int32_t*)(zoff + (ql + 2)), *re = rh + (tl + 2);
+	/* the 64-bit array leads the (16-byte aligned) block so that it is 8-byte aligned for every ql */
+	unsigned long long *zoff = (unsigned long long*)zw; zw = (int32_t*)(zoff + (ql + 2));
+	int32_t *zb = zw + (ql + 2), *ze = zb + (ql + 2);
+	int32_t *rh = ze + (ql + 2), *re = rh + (tl + 2);
 	for(int32_t i = 0; i < ql + 2; i++) zw[i] = 0;
 	int32_t qx = 0, tx = 0;
 	for(uint32_t i = 0; i < ncig; i++){

@@ -19,8 +19,17 @@ def manifest():
     return json.load(open(os.path.join(GOLD, "manifest.json")))
 
 
-def case_argv(case):
-    return [a if not a.startswith("@") else os.path.join(GOLD, a[1:]) for a in case["argv"]]
+def case_argv(case, outdir=None):
+    """'@name' = a side input under tests/golden/, '@out:name' = a side OUTPUT written next to the .ovl"""
+    return [os.path.join(str(outdir or "."), a[5:]) if a.startswith("@out:") else (a if not a.startswith("@") else os.path.join(GOLD, a[1:])) for a in case["argv"]]
+
+
+def pairs_md5(tmpdir):
+    """md5 of the sorted lines of the -9 file (the reference writes it in hash-table order: the set is the contract)"""
+    p = os.path.join(str(tmpdir), "pairs")
+    if not os.path.exists(p):
+        return None
+    return hashlib.md5(b"\n".join(sorted(open(p, "rb").read().split(b"\n")))).hexdigest()
 
 
 def md5_file(path):
@@ -30,14 +39,15 @@ def md5_file(path):
 def run_wtzmo_like(exe, case, tmpdir, extra=()):
     """Run a wtzmo-compatible executable on one golden case; returns (md5 of .ovl, md5 of .contained, 16-col text)."""
     out = os.path.join(str(tmpdir), "o.ovl")
-    for f in (out, out + ".contained"):
+    for f in (out, out + ".contained", os.path.join(str(tmpdir), "pairs")):
         if os.path.exists(f):
             os.remove(f)
-    cmd = [exe, "-i", os.path.join(GOLD, case["input"]), "-fo", out] + case_argv(case) + list(extra)
+    cmd = [exe, "-i", os.path.join(GOLD, case["input"]), "-fo", out] + case_argv(case, tmpdir) + list(extra)
     r = subprocess.run(cmd, capture_output=True)
     assert r.returncode == 0, "%s failed (%d): %s" % (" ".join(cmd), r.returncode, r.stderr.decode()[-2000:])
     full = open(out, "rb").read()
     cut = b"\n".join(b"\t".join(l.split(b"\t")[:16]) for l in full.split(b"\n"))
+    assert pairs_md5(tmpdir) == case.get("md5_pairs_sorted"), "-9 pair set differs from the reference"
     return hashlib.md5(full).hexdigest(), md5_file(out + ".contained"), cut
 
 

@@ -65,6 +65,14 @@ CASES = [
     ("zmo_b", "tiny.fa.gz", ZMO + ["-b", "@clips.txt"]),
     ("zmo_n", "tiny.fa.gz", ZMO + ["-n"]),                                   # A11: kswx_refine_alignment
     ("zmo_n_w20", "tiny.fa.gz", ZMO + ["-n", "-w", "20", "-M", "3", "-X", "-4"]),
+    # -N with the dot-matrix engine: print_hits_wtzmo walks the (empty) seed list, so the .ovl is EMPTY (wtzmo.c:1175-1210, 1319)
+    ("dmo_N", "tiny.fa.gz", DMO + ["-N"]),
+    # -I: query-only reads (wtzmo.c:1714-1729): the n_qr path, avg_rdlen over the query reads (361-368), query range 1304-1308
+    ("zmo_I", "tiny.fa.gz", ZMO + ["-I", "@edge.fa.gz"]),
+    ("dmo_I", "tiny.fa.gz", DMO + ["-I", "@edge.fa.gz"]),
+    # -9: the tested-pairs file (wtzmo.c:1793-1804); the reference lists it in hash-table order, so the SET is pinned (md5 of the sorted lines)
+    ("zmo_9", "tiny.fa.gz", ZMO + ["-9", "@out:pairs"]),
+    ("dmo_9", "tiny.fa.gz", DMO + ["-9", "@out:pairs"]),
 ]
 
 
@@ -133,12 +141,14 @@ def run_case(name, inp, extra):
     extra = [a if a != "@even" else str(EVEN_J[0]) for a in extra]
     with tempfile.TemporaryDirectory() as td:
         out = os.path.join(td, "o.ovl")
-        argv = [a if not a.startswith("@") else os.path.join(HERE, a[1:]) for a in extra]
+        argv = [os.path.join(td, a[5:]) if a.startswith("@out:") else (a if not a.startswith("@") else os.path.join(HERE, a[1:])) for a in extra]
         cmd = [REF, "-t", "1", "-i", os.path.join(HERE, inp), "-fo", out] + argv
         subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
         full = open(out, "rb").read()
         cont_path = out + ".contained"
         cont = open(cont_path, "rb").read() if os.path.exists(cont_path) else None
+        pairs_path = os.path.join(td, "pairs")
+        pairs = sorted(open(pairs_path, "rb").read().split(b"\n")) if os.path.exists(pairs_path) else None
     lines = full.split(b"\n")
     cut = b"\n".join(b"\t".join(l.split(b"\t")[:16]) for l in lines)
     with gzip.GzipFile(os.path.join(HERE, name + ".ovl16.gz"), "wb", mtime=0) as fh:
@@ -151,6 +161,8 @@ def run_case(name, inp, extra):
         "md5_full": md5(full),
         "md5_contained": md5(cont) if cont is not None else None,
         "contained": cont.decode().split() if cont is not None else None,
+        "md5_pairs_sorted": md5(b"\n".join(pairs)) if pairs is not None else None,
+        "pairs": len([p for p in pairs if p]) if pairs is not None else None,
     }
 
 

@@ -38,6 +38,31 @@ def test_batch_size_never_changes_the_output(batch, gpu_exe, tmp_path):
     assert md5 == case["md5_full"] and cont == case["md5_contained"]
 
 
+@pytest.mark.parametrize("name", ["zmo", "dmo"])
+def test_two_worker_contexts_same_output(name, gpu_exe, tmp_path):
+    """--workers 2: wtz_ctx_clone, two HIP streams / scratch pools, batches committed strictly in sequence."""
+    case = manifest()["cases"][name]
+    md5, cont, _ = run_wtzmo_like(gpu_exe, case, tmp_path, extra=["--workers", "2", "--batch", "8"])
+    assert md5 == case["md5_full"] and cont == case["md5_contained"]
+
+
+def test_scratch_pool_exhaustion_is_survived_or_loud(gpu_exe, tmp_path):
+    """WTZ_E_POOL on the device: a batch that does not fit is halved (same output); a pool too small for one query is a loud
+    exit(1) - never a memory fault, never a wrong file."""
+    import hashlib
+    case = manifest()["cases"]["zmo"]
+    split_ok = 0
+    for mb in (4, 16, 48, 96, 160, 256, 512):
+        out = os.path.join(str(tmp_path), "o%d.ovl" % mb)
+        r = subprocess.run([gpu_exe, "-i", os.path.join(GOLD, case["input"]), "-fo", out, "--pool-mb", str(mb)] + case["argv"], capture_output=True)
+        if r.returncode == 0:
+            assert hashlib.md5(open(out, "rb").read()).hexdigest() == case["md5_full"], "pool %d MB: wrong output" % mb
+            split_ok += b"splitting the batch" in r.stderr
+        else:
+            assert r.returncode == 1 and b"scratch pool" in r.stderr, "pool %d MB: rc %d, %s" % (mb, r.returncode, r.stderr.decode()[-500:])
+    assert split_ok >= 1, "no pool size exercised the batch-splitting path"
+
+
 FRESH = {
     "zmo": ["-k", "16", "-s", "200", "-m", "0.6"],
     "dmo": ["-k", "16", "-z", "10", "-Z", "16", "-U", "-1", "-m", "0.1", "-A", "1000"],

@@ -35,7 +35,11 @@ def test_two_rank_striping_and_gather(tmp_path):
     base = m["zmo"]
     w = os.path.join(str(tmp_path), "worker.py")
     open(w, "w").write(WORKER)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29577")
+    import socket
+    with socket.socket() as sk:      # a free port, not a fixed one (shared hosts)
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     procs = []
     for r in range(2):
         e = dict(env, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r))
