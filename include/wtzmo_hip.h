@@ -141,6 +141,35 @@ int  wtz_fetch_cigar_text(wtz_ctx_t *ctx, char *dst, uint64_t n_bytes);
 void *wtz_host_alloc(uint64_t n_bytes);
 void  wtz_host_free(void *p);
 
+/* ---- TEST-ONLY entry: function-level parity of every device form of the three banded DPs against vectors dumped from the
+ * reference's own routines (tests/golden/dp_vectors.npz, tests/test_gpu_dp_forms.py).  One DP problem per element on sequences taken
+ * from the uploaded reads; nothing in the product path calls it.
+ *   kind WTZ_DP_SHIFT  <- kswx_extend_align_shift_core kswx.h:101-232   (W as passed to it: negative = exact band)
+ *        WTZ_DP_FIXED  <- kswx_extend_align_core       kswx.h:234-335   (band = params.w, as the path always calls it)
+ *        WTZ_DP_GLOBAL <- ksw_global2                  ksw.c:503-586    (W = band width of this ONE call; gap costs from params)
+ *   form 0 = the form the product would pick (for WTZ_DP_SHIFT: the whole run_extjobs dispatch); otherwise
+ *        WTZ_DP_SHIFT : 1 one-wave register kernel, 2 four-wave kernel, 3 LDS-ring kernel (+ its scalar fallback), 4 scalar body
+ *        WTZ_DP_FIXED / WTZ_DP_GLOBAL : C | 16*pool  (C = 1, 2, 4, 8 band columns per lane; +16 = 4-bit trace in the pool instead of LDS),
+ *                       255 scalar body; WTZ_DP_GLOBAL also 32 = LDS-ring wave DP, 33 = the same with the 72 KB slice of the wide launch
+ *   out[i].form_used = the form that produced the result, 0 = the forced form does not cover this problem (result untouched). */
+#define WTZ_DP_SHIFT  0
+#define WTZ_DP_FIXED  1
+#define WTZ_DP_GLOBAL 2
+typedef struct {
+	uint32_t q_read, t_read;        /* read ids */
+	uint32_t q_rev, t_rev;          /* 1 = reverse-complement view of the read (the candidate's strand '-') */
+	int32_t  q_from, t_from;        /* logical position of base 0 of the problem inside the view */
+	int32_t  q_strand, t_strand;    /* +1 / -1: walking direction from there (left extensions walk backwards) */
+	int32_t  q_len, t_len, init_score, W;
+} wtz_dp_problem_t;
+typedef struct {
+	int32_t  score, tb, te, qb, qe, aln, mat, mis, ins, del;      /* kswx_t; WTZ_DP_GLOBAL: score, aln, mat, mis, ins, del */
+	uint32_t cigar_len, form_used;
+	uint64_t cigar_off;             /* offset (in words) of this problem's CIGAR inside `cigar` */
+	uint64_t cells;                 /* DP cells as the reference loops execute them (extensions) */
+} wtz_dp_result_t;
+int  wtz_test_dp(wtz_ctx_t *ctx, int32_t kind, int32_t form, const wtz_dp_problem_t *problems, uint32_t n, wtz_dp_result_t *out, uint32_t *cigar, uint64_t cigar_cap);
+
 int  wtz_get_counters(wtz_ctx_t *ctx, wtz_counters_t *out);
 int  wtz_reset_counters(wtz_ctx_t *ctx);
 

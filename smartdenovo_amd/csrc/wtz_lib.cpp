@@ -931,6 +931,8 @@ extern "C" int wtz_fetch_cigar_text(wtz_ctx_t *c, char *dst, uint64_t n_bytes){
 	return WTZ_OK;
 }
 
+#include "wtz_testdp.h"
+
 extern "C" void *wtz_host_alloc(uint64_t n_bytes){
 #ifdef WTZ_EMUL
 	return malloc((size_t)(n_bytes ? n_bytes : 1));

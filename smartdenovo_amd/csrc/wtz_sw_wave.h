@@ -1443,6 +1443,81 @@ WTZ_D wtz_aln_t wtz_align_zmer_w(const S1 &pb1, uint32_t len1, const S2 &pb2, ui
 	return x;
 }
 
+/* ---- one K-sw1 problem on the wavefront: picks the device form from the problem's shape (register DP with 1 / 2 / 4 / 8 band columns
+ *      per lane, 4-bit trace in the LDS slice or in the pool; the scalar body for what is outside every envelope) and runs it.
+ *      TEST = true is the form of wtz_test_dp (function-level parity vectors): `force` then names the form instead
+ *      (C | 16 = trace in the pool, 255 = scalar body) and R.form = -1 reports a problem outside the forced form's envelope.
+ *      LDS slice: 128 target words (1 KB) at L.tb, then the 4-bit trace with its run list at the top end (ztr, ztr_bytes). ---- */
+typedef struct { wtz_aln_t y; uint32_t *runs; uint32_t n_runs; bool lds_runs, ok, defer; int form; } wtz_fixres_t;
+#define WTZ_FORM_SCALAR 255
+template<bool FULL, bool TEST>
+WTZ_D void wtz_fixed_problem_wave(int32_t qlen, const wtz_seq_packed &q, int32_t tlen, const wtz_seq_packed &t, int32_t score_in, const wtz_params_t *P,
+		const wtz_wave_lds_t &L, uint8_t *ztr, int32_t ztr_bytes, wtz_cigar_t &tmp, wtz_swmem_t &mem, wtz_pool_t *pool, unsigned long long *cells, int force, wtz_fixres_t &R){
+	const int lane = (int)(threadIdx.x & 63);
+	const int32_t M = P->M, X = P->X, I = P->O, D = P->O, E = P->E, T = P->T;
+	wtz_aln_t y; memset(&y, 0, sizeof y);
+	R.runs = NULL; R.n_runs = 0; R.lds_runs = false; R.ok = true; R.defer = false; R.form = 0;
+	const unsigned long long pt0 = WTZ_PROF_T(); (void)pt0;
+	int32_t init = score_in < 0 ? 0 : score_in, W = P->w, ql = 0, tl = 0, n_col = 0; bool okk = true;
+	if(qlen > 0 && tlen > 0) wtz_ext_geometry(qlen, tlen, init, W, M, I, D, E, T, ql, tl, n_col);
+	const int32_t run_bytes = 4 * (ql + tl + 4);
+	const int32_t zrow = (n_col + 3) & ~3;                 /* trace bytes per row pair: one nibble pair per band column */
+	const int32_t hmax = init + M * (ql < tl ? ql : tl);                 /* bound of |h|: the register DP packs h and the band column into one int32 key */
+	const bool shape = (qlen > 0 && tlen > 0 && ql <= 2048 && (tl + 63) / 32 + 1 <= L.tw);
+	bool lds_fit = shape && n_col <= 128 && hmax < (1 << 23) && ((ql + 1) / 2) * zrow + run_bytes <= ztr_bytes;
+	bool pool_fit = shape && !lds_fit && n_col <= 512 && hmax < (n_col <= 128 ? (1 << 23) : (1 << 21)) && 4096 + run_bytes <= ztr_bytes;
+	int32_t cmin = n_col <= 64 ? 1 : (n_col <= 128 ? 2 : (n_col <= 256 ? 4 : 8));       /* band columns per lane */
+	bool scalar = false;
+	if constexpr(TEST){
+		if(force == WTZ_FORM_SCALAR){ lds_fit = pool_fit = false; scalar = true; }
+		else if(force){
+			const int32_t fc = force & 15; const bool zg = (force & 16) != 0;
+			const bool key_ok = hmax < (fc <= 2 ? (1 << 23) : (1 << 21));
+			const bool can = shape && (fc == 1 || fc == 2 || fc == 4 || fc == 8) && fc >= cmin && n_col <= 64 * fc && key_ok && (FULL || fc <= 2)
+				&& (zg ? (4096 + run_bytes <= ztr_bytes) : (((ql + 1) / 2) * zrow + run_bytes <= ztr_bytes && fc <= 2));
+			if(!can && !(qlen <= 0 || tlen <= 0)){ R.form = -1; R.y = y; return; }
+			lds_fit = can && !zg; pool_fit = can && zg; cmin = fc;
+		}
+	}
+	if(!FULL && !(qlen <= 0 || tlen <= 0) && !(lds_fit || (pool_fit && n_col <= 128))){ R.defer = true; R.y = y; return; }
+	if(lds_fit){
+		R.runs = (uint32_t*)(ztr + ztr_bytes - run_bytes); R.lds_runs = true; R.form = cmin;
+		if(cmin == 1) y = wtz_extend_fixed_reg<1>(qlen, q, tlen, t, score_in, ql, tl, W, M, X, I, D, E, T, L.tb, ztr, (uint32_t)zrow, R.runs, &R.n_runs, cells);
+		else          y = wtz_extend_fixed_reg<2>(qlen, q, tlen, t, score_in, ql, tl, W, M, X, I, D, E, T, L.tb, ztr, (uint32_t)zrow, R.runs, &R.n_runs, cells);
+	} else if(pool_fit){
+		/* the 4-bit trace does not fit the LDS slice (or the band is wider than 128 columns): trace in the pool, traceback through a
+		 * 4 KB LDS stage, run list in LDS above the stage */
+		unsigned long long za = 0;
+		if(lane == 0) za = (unsigned long long)(uintptr_t)wtz_pool_alloc(pool, (size_t)((ql + 1) / 2) * zrow);
+		za = __shfl(za, 0, 64);
+		if(za == 0){ R.ok = false; R.y = y; return; }
+		uint8_t *zg = (uint8_t*)(uintptr_t)za;
+		R.runs = (uint32_t*)(ztr + ztr_bytes - run_bytes); R.lds_runs = true; R.form = cmin | 16;
+		if(cmin == 1)      y = wtz_extend_fixed_reg<1, true>(qlen, q, tlen, t, score_in, ql, tl, W, M, X, I, D, E, T, L.tb, zg, (uint32_t)zrow, R.runs, &R.n_runs, cells, ztr);
+		else if(cmin == 2) y = wtz_extend_fixed_reg<2, true>(qlen, q, tlen, t, score_in, ql, tl, W, M, X, I, D, E, T, L.tb, zg, (uint32_t)zrow, R.runs, &R.n_runs, cells, ztr);
+		else if constexpr(FULL){
+			if(cmin == 4) y = wtz_extend_fixed_reg<4, true>(qlen, q, tlen, t, score_in, ql, tl, W, M, X, I, D, E, T, L.tb, zg, (uint32_t)zrow, R.runs, &R.n_runs, cells, ztr);
+			else          y = wtz_extend_fixed_reg<8, true>(qlen, q, tlen, t, score_in, ql, tl, W, M, X, I, D, E, T, L.tb, zg, (uint32_t)zrow, R.runs, &R.n_runs, cells, ztr);
+		}
+		WTZ_PROF_ADD(9, pt0); WTZ_PROF_CNT(7, 1); WTZ_PROF_CNT(13, ql); WTZ_PROF_CNT(14, n_col);
+	} else if(qlen <= 0 || tlen <= 0){
+		/* empty problem (wtz_extend_fixed: score = init, nothing aligned, empty CIGAR) */
+		memset(&y, 0, sizeof y); y.score = init; if(lane == 0) tmp.n = 0;
+	} else if constexpr(FULL){
+		/* whatever is outside the register DP's envelope (rows > 2048, band > 512 columns, huge scores): the scalar body */
+		(void)scalar;
+		const unsigned long long ptw = WTZ_PROF_T(); (void)ptw;
+		R.form = WTZ_FORM_SCALAR;
+		if(lane == 0){ tmp.n = 0; y = wtz_extend_fixed(qlen, q, tlen, t, score_in, P->w, M, X, I, D, E, T, mem, tmp); if(mem.bad) okk = false; }
+		y = wtz_bcast_aln(y);
+		okk = __shfl((int)okk, 0, 64) != 0;
+		WTZ_PROF_ADD(10, ptw); WTZ_PROF_CNT(8, 1);
+	}
+	if(R.lds_runs) WTZ_PROF_CNT(6, 1);
+	if(!okk) R.ok = false;
+	R.y = y;
+}
+
 /* ---- A9 with the K-sw1 gaps run by the whole wave (hzm_aln.h:1247-1302).  Every lane follows the anchor loop with
  *      the same x; CIGAR bookkeeping and the run-by-run z-mer alignment stay on lane 0.  lds: >= 8 KB. ---- */
 /* FULL = false is the form of the first launch: only the one / two-columns-per-lane register DP (and the empty problem) are compiled
@@ -1451,12 +1526,10 @@ template<bool FULL = true>
 WTZ_D wtz_aln_t wtz_align_window_wave(const wtz_readview &pb1, const wtz_readview &pb2, const wtz_win_t &win, const wtz_zhit_t *anchors,
 		wtz_cigar_t &cigar, wtz_cigar_t &tmp, const wtz_params_t *P, wtz_pool_t *pool, int32_t *lds, unsigned long long *cells, bool *ok, bool *defer = NULL){
 	const int lane = (int)(threadIdx.x & 63);
-	const int32_t M = P->M, X = P->X, I = P->O, D = P->O, E = P->E, T = P->T;
-	/* LDS slice: 128 target words (1 KB), then either the H/E rings of the general wave DP (2 x 2 KB) or the 4-bit trace
-	 * of the register DP with its run list at the top end (7 KB) */
+	const int32_t M = P->M, I = P->O, D = P->O, E = P->E;
+	/* LDS slice: 128 target words (1 KB), then the 4-bit trace of the register DP with its run list at the top end (7 KB) */
 	wtz_wave_lds_t L; L.tb = (uint64_t*)lds; L.Hs = lds + 256; L.Es = lds + 768; L.PM = 511; L.tw = 128;
 	uint8_t *ztr = (uint8_t*)(lds + 256); const int32_t ztr_bytes = WTZ_WINALIGN_LDS_BYTES - 1024;
-	wtz_trace_t tr; tr.chunk = NULL; tr.zb = NULL; tr.n_chunk = 0; tr.zrow = 0; tr.cap_rows = 0;
 	wtz_swmem_t mem; wtz_swmem_init(mem, pool);
 	wtz_aln_t x, y; memset(&x, 0, sizeof x);
 	wtz_cigw_t Wc; Wc.v = &cigar; Wc.tail = 0;
@@ -1469,51 +1542,12 @@ WTZ_D wtz_aln_t wtz_align_window_wave(const wtz_readview &pb1, const wtz_readvie
 		if(off2 < x.qe) continue;
 		const int32_t qlen = off2 - x.qe, tlen = off1 - x.te;
 		const unsigned long long pt0 = WTZ_PROF_T();
-		uint32_t n_runs = 0; uint32_t *runs = NULL; bool lds_runs = false;
-		{
-			int32_t init = x.score < 0 ? 0 : x.score, W = P->w, ql = 0, tl = 0, n_col = 0; bool okk = true;
-			if(qlen > 0 && tlen > 0) wtz_ext_geometry(qlen, tlen, init, W, M, I, D, E, T, ql, tl, n_col);
-			const int32_t run_bytes = 4 * (ql + tl + 4);
-			const int32_t zrow = (n_col + 3) & ~3;                 /* trace bytes per row pair: one nibble pair per band column */
-			const int32_t hmax = init + M * (ql < tl ? ql : tl);                 /* bound of |h|: the register DP packs h and the band column into one int32 key */
-			const bool shape = (qlen > 0 && tlen > 0 && ql <= 2048 && (tl + 63) / 32 + 1 <= L.tw);
-			const bool lds_fit = shape && n_col <= 128 && hmax < (1 << 23) && ((ql + 1) / 2) * zrow + run_bytes <= ztr_bytes;
-			const bool pool_fit = shape && !lds_fit && n_col <= 512 && hmax < (n_col <= 128 ? (1 << 23) : (1 << 21)) && 4096 + run_bytes <= ztr_bytes;
-			if(!FULL && !(qlen <= 0 || tlen <= 0) && !(lds_fit || (pool_fit && n_col <= 128))){ *defer = true; return x; }
-			if(lds_fit){
-				runs = (uint32_t*)(ztr + ztr_bytes - run_bytes); lds_runs = true;
-				if(n_col <= 64) y = wtz_extend_fixed_reg<1>(qlen, pb2.sub(x.qe, 1), tlen, pb1.sub(x.te, 1), x.score, ql, tl, W, M, X, I, D, E, T, L.tb, ztr, (uint32_t)zrow, runs, &n_runs, cells);
-				else            y = wtz_extend_fixed_reg<2>(qlen, pb2.sub(x.qe, 1), tlen, pb1.sub(x.te, 1), x.score, ql, tl, W, M, X, I, D, E, T, L.tb, ztr, (uint32_t)zrow, runs, &n_runs, cells);
-			} else if(pool_fit){
-				/* the 4-bit trace does not fit the LDS slice (or the band is wider than 128 columns): trace in the pool, traceback through a
-				 * 4 KB LDS stage, run list in LDS above the stage */
-				unsigned long long za = 0;
-				if(lane == 0) za = (unsigned long long)(uintptr_t)wtz_pool_alloc(pool, (size_t)((ql + 1) / 2) * zrow);
-				za = __shfl(za, 0, 64);
-				if(za == 0){ *ok = false; return x; }
-				uint8_t *zg = (uint8_t*)(uintptr_t)za;
-				runs = (uint32_t*)(ztr + ztr_bytes - run_bytes); lds_runs = true;
-				if(n_col <= 64)       y = wtz_extend_fixed_reg<1, true>(qlen, pb2.sub(x.qe, 1), tlen, pb1.sub(x.te, 1), x.score, ql, tl, W, M, X, I, D, E, T, L.tb, zg, (uint32_t)zrow, runs, &n_runs, cells, ztr);
-				else if(n_col <= 128) y = wtz_extend_fixed_reg<2, true>(qlen, pb2.sub(x.qe, 1), tlen, pb1.sub(x.te, 1), x.score, ql, tl, W, M, X, I, D, E, T, L.tb, zg, (uint32_t)zrow, runs, &n_runs, cells, ztr);
-				else if constexpr(FULL){
-					if(n_col <= 256) y = wtz_extend_fixed_reg<4, true>(qlen, pb2.sub(x.qe, 1), tlen, pb1.sub(x.te, 1), x.score, ql, tl, W, M, X, I, D, E, T, L.tb, zg, (uint32_t)zrow, runs, &n_runs, cells, ztr);
-					else             y = wtz_extend_fixed_reg<8, true>(qlen, pb2.sub(x.qe, 1), tlen, pb1.sub(x.te, 1), x.score, ql, tl, W, M, X, I, D, E, T, L.tb, zg, (uint32_t)zrow, runs, &n_runs, cells, ztr);
-				}
-				WTZ_PROF_ADD(9, pt0); WTZ_PROF_CNT(7, 1); WTZ_PROF_CNT(13, ql); WTZ_PROF_CNT(14, n_col);
-			} else if(qlen <= 0 || tlen <= 0){
-				/* empty problem (wtz_extend_fixed: score = init, nothing aligned, empty CIGAR) */
-				memset(&y, 0, sizeof y); y.score = init; if(lane == 0) tmp.n = 0;
-			} else if constexpr(FULL){
-				/* whatever is outside the register DP's envelope (rows > 2048, band > 512 columns, huge scores): the scalar body */
-				const unsigned long long ptw = WTZ_PROF_T(); (void)ptw;
-				if(lane == 0){ tmp.n = 0; y = wtz_extend_fixed(qlen, pb2.sub(x.qe, 1), tlen, pb1.sub(x.te, 1), x.score, P->w, M, X, I, D, E, T, mem, tmp); if(mem.bad) okk = false; }
-				y = wtz_bcast_aln(y);
-				okk = __shfl((int)okk, 0, 64) != 0;
-				WTZ_PROF_ADD(10, ptw); WTZ_PROF_CNT(8, 1);
-			}
-			if(lds_runs) WTZ_PROF_CNT(6, 1);
-			if(!okk){ *ok = false; return x; }
-		}
+		wtz_fixres_t R;
+		wtz_fixed_problem_wave<FULL, false>(qlen, pb2.sub(x.qe, 1), tlen, pb1.sub(x.te, 1), x.score, P, L, ztr, ztr_bytes, tmp, mem, pool, cells, 0, R);
+		if(!FULL && R.defer){ *defer = true; return x; }
+		if(!R.ok){ *ok = false; return x; }
+		y = R.y;
+		const uint32_t n_runs = R.n_runs; const uint32_t *runs = R.runs; const bool lds_runs = R.lds_runs;
 		WTZ_PROF_ADD(0, pt0);
 		const unsigned long long pt1 = WTZ_PROF_T();
 		int32_t stop = 0;

@@ -289,6 +289,101 @@ typedef struct { int32_t score, aln, mat, mis, ins, del; uint32_t *cigar; uint32
  * second launch with WTZ_GAP_WIDE_LDS_BYTES of LDS per wave (`list` names its tasks) runs the LDS-ring wave DP with rings of 8192
  * columns and room for 32 k query bases; only what exceeds even that stays on the scalar body. */
 #define WTZ_GAP_WIDE_LDS_BYTES (8192 + 2 * 8192 * 4)
+typedef struct { int32_t score; bool from_reg, want_defer; int32_t bad; uint32_t *runs; uint32_t n_runs; int32_t r_mat, r_mis; int form; } wtz_gapdp_t;
+#define WTZ_FORM_RING 32
+#if defined(__HIP_DEVICE_COMPILE__)
+/* ---- one K-sw2 problem (ksw_global2 at ONE band width w) on the wavefront: picks the device form from the shape - register DP with
+ *      1 / 2 / 4 / 8 band columns per lane (4-bit trace in the LDS slice or in the pool), the LDS-ring wave DP (narrow slice, or the
+ *      72 KB slice of the wide launch), the scalar body - and runs it.  TEST = true (wtz_test_dp, function-level parity vectors): `force`
+ *      names the form (C | 16 = trace in the pool, 32 = LDS-ring wave DP, 255 = scalar body); R.form = -1 = outside that form's envelope. ---- */
+template<bool TEST>
+WTZ_D void wtz_gap_problem_wave(int32_t dq, const wtz_seq_packed &q, int32_t dt, const wtz_seq_packed &tt, const wtz_params_t *P, int32_t w,
+		int32_t *lds, uint32_t wide_lds, bool may_defer, wtz_pool_t *pool, wtz_cigar_t &tmp, wtz_trace_t &tr, wtz_swmem_t &mem, int force, wtz_gapdp_t &R){
+	const int32_t M = P->M, X = P->X, I = P->O, D = P->O, E = P->E;
+	/* LDS slice: 128 sequence words (1 KB), then either the H/E rings of the general wave DP or the 4-bit trace of the
+	 * register DP with its run list at the top end */
+	wtz_wave_lds_t L; L.tb = (uint64_t*)lds; L.Hs = lds + 256; L.Es = lds + 768; L.PM = 511; L.tw = 128;
+	wtz_wave_lds_t LW = L;           /* the wide launch: 1024 query words, then two rings of 8192 columns */
+	if(wide_lds >= WTZ_GAP_WIDE_LDS_BYTES){ LW.Hs = lds + 2048; LW.Es = lds + 2048 + 8192; LW.PM = 8191; LW.tw = 1024; }
+	uint8_t *ztr = (uint8_t*)(lds + 256); const int32_t ztr_bytes = WTZ_GAP_LDS_BYTES - 1024;
+	R.score = 0; R.from_reg = false; R.want_defer = false; R.bad = 0; R.runs = NULL; R.n_runs = 0; R.r_mat = R.r_mis = 0; R.form = 0;
+	int32_t score = 0;
+	const int32_t n_col = dq < 2 * w + 1 ? dq : 2 * w + 1;
+	const int32_t zrow = (n_col + 3) & ~3, run_bytes = 4 * (dq + dt + 4);
+	const unsigned long long pt_g = WTZ_PROF_T(); (void)pt_g;
+	const int32_t qwords = (dq + 63) / 32 + 1, qbytes = (qwords * 8 + 15) & ~15;
+	bool lds_shape = (dq > 0 && dt > 0 && n_col <= 128 && dt <= 2048 && qwords <= 128 && ((dt + 1) / 2) * zrow + run_bytes <= ztr_bytes);
+	bool reg_shape = lds_shape || (dq > 0 && dt > 0 && n_col <= 512 && qbytes + 4096 <= WTZ_GAP_LDS_BYTES);
+	int32_t cmin = n_col <= 64 ? 1 : (n_col <= 128 ? 2 : (n_col <= 256 ? 4 : 8));
+	bool ring_ok = true, scalar_only = false;
+	if constexpr(TEST){
+		if(force == 255){ lds_shape = reg_shape = false; ring_ok = false; scalar_only = true; may_defer = false; }
+		else if(force == WTZ_FORM_RING){ lds_shape = reg_shape = false; may_defer = false; }
+		else if(force){
+			const int32_t fc = force & 15; const bool zg = (force & 16) != 0;
+			const bool can = (fc == 1 || fc == 2 || fc == 4 || fc == 8) && fc >= cmin && n_col <= 64 * fc && (zg ? (dq > 0 && dt > 0 && qbytes + 4096 <= WTZ_GAP_LDS_BYTES) : (lds_shape && fc <= 2));
+			if(!can){ R.form = -1; return; }
+			lds_shape = !zg; reg_shape = true; cmin = fc;
+		}
+	}
+	if(reg_shape && !lds_shape){
+		/* the 4-bit trace does not fit the LDS slice (or the band is wider than 128 columns, or the gap longer than 2048 rows):
+		 * it goes to the pool (HBM) and the traceback stages blocks of it in LDS.  Slice: query words | 4 KB stage | run list
+		 * (when it still fits, else in the pool too) */
+		uint8_t *stg = (uint8_t*)lds + qbytes;
+		const bool runs_lds = (qbytes + 4096 + run_bytes <= WTZ_GAP_LDS_BYTES);
+		unsigned long long za = 0, ra = 0;
+		if(WTZ_LANE == 0){
+			za = (unsigned long long)(uintptr_t)wtz_pool_alloc(pool, (size_t)((dt + 1) / 2) * zrow);
+			if(!runs_lds) ra = (unsigned long long)(uintptr_t)wtz_pool_alloc(pool, (size_t)run_bytes);
+		}
+		za = __shfl(za, 0, 64); ra = __shfl(ra, 0, 64);
+		if(za == 0 || (!runs_lds && ra == 0)){ R.bad = 1; score = 0; }
+		else {
+			R.runs = runs_lds ? (uint32_t*)(stg + 4096) : (uint32_t*)(uintptr_t)ra; R.from_reg = true; R.form = cmin | 16;
+			uint8_t *zg = (uint8_t*)(uintptr_t)za;
+			if(cmin == 1)      score = wtz_global_reg<1, true>(dq, q, dt, tt, M, X, -I, -E, -D, -E, w, L.tb, zg, (uint32_t)zrow, R.runs, &R.n_runs, &R.r_mat, &R.r_mis, stg);
+			else if(cmin == 2) score = wtz_global_reg<2, true>(dq, q, dt, tt, M, X, -I, -E, -D, -E, w, L.tb, zg, (uint32_t)zrow, R.runs, &R.n_runs, &R.r_mat, &R.r_mis, stg);
+			else if(cmin == 4) score = wtz_global_reg<4, true>(dq, q, dt, tt, M, X, -I, -E, -D, -E, w, L.tb, zg, (uint32_t)zrow, R.runs, &R.n_runs, &R.r_mat, &R.r_mis, stg);
+			else               score = wtz_global_reg<8, true>(dq, q, dt, tt, M, X, -I, -E, -D, -E, w, L.tb, zg, (uint32_t)zrow, R.runs, &R.n_runs, &R.r_mat, &R.r_mis, stg);
+		}
+		WTZ_PROF_ADD(43, pt_g); WTZ_PROF_CNT(44, 1000000); WTZ_PROF_MAX(45, pt_g);
+	} else if(lds_shape){
+		R.runs = (uint32_t*)(ztr + ztr_bytes - run_bytes); R.from_reg = true; R.form = cmin;
+		if(cmin == 1) score = wtz_global_reg<1>(dq, q, dt, tt, M, X, -I, -E, -D, -E, w, L.tb, ztr, (uint32_t)zrow, R.runs, &R.n_runs, &R.r_mat, &R.r_mis);
+		else          score = wtz_global_reg<2>(dq, q, dt, tt, M, X, -I, -E, -D, -E, w, L.tb, ztr, (uint32_t)zrow, R.runs, &R.n_runs, &R.r_mat, &R.r_mis);
+		WTZ_PROF_ADD(32, pt_g); WTZ_PROF_CNT(33, 1000000); WTZ_PROF_MAX(34, pt_g);
+	} else if(may_defer && dq > 0 && dt > 0 && !(n_col + 2 <= 512 && qwords <= 128) && n_col + 2 <= 8192 && qwords <= 1024 && (dt + 63) / 64 <= WTZ_TRACE_MAXCHUNK){
+		R.want_defer = true;       /* uniform: the wide launch redoes this gap */
+		return;
+	} else if(ring_ok && dq > 0 && dt > 0 && n_col + 2 <= LW.PM + 1 && qwords <= LW.tw && (dt + 63) / 64 <= WTZ_TRACE_MAXCHUNK){
+		bool ok = true;
+		R.form = WTZ_FORM_RING;
+		score = wtz_global_wave(dq, q, dt, tt, M, X, -I, -E, -D, -E, w, LW, tr, pool, tmp, &ok);
+		if(!ok) R.bad = 1;
+#ifdef WTZ_GAP_CHECK
+		if(ok && WTZ_LANE == 0){
+			wtz_cigar_t t2; t2.init(pool, 32); wtz_swmem_t m2; wtz_swmem_init(m2, pool);
+			const int32_t s2 = wtz_global_banded(dq, q, dt, tt, M, X, -I, -E, -D, -E, w, m2, t2);
+			uint32_t firstdiff = 0xFFFFFFFFu;
+			if(!m2.bad){ if(t2.n != tmp.n) firstdiff = 0xFFFFFFFEu; else for(uint32_t z9 = 0; z9 < t2.n; z9++) if(t2.a[z9] != tmp.a[z9]){ firstdiff = z9; break; } }
+			if(!m2.bad && (s2 != score || firstdiff != 0xFFFFFFFFu)) printf("[gap-check] dq %d dt %d w %d n_col %d: score wave %d scalar %d; cigar n %u / %u first diff %u\n", dq, dt, w, n_col, score, s2, tmp.n, t2.n, firstdiff);
+		}
+#endif
+		WTZ_PROF_ADD(35, pt_g); WTZ_PROF_CNT(36, 1000000); WTZ_PROF_MAX(37, pt_g);
+		WTZ_PROF_CNT(46, (unsigned long long)dt * 1000); if(n_col > 256) WTZ_PROF_CNT(47, 1000000);
+	} else {
+		if constexpr(TEST){ if(force == WTZ_FORM_RING){ R.form = -1; return; } }
+		(void)scalar_only;
+		score = 0; R.form = 255;
+		if(WTZ_LANE == 0){ score = wtz_global_banded(dq, q, dt, tt, M, X, -I, -E, -D, -E, w, mem, tmp); if(mem.bad) R.bad = 1; }
+		WTZ_PROF_ADD(38, pt_g); WTZ_PROF_CNT(39, 1000000); WTZ_PROF_MAX(40, pt_g);
+	}
+	R.score = __shfl(score, 0, 64);
+	R.bad = __shfl(R.bad, 0, 64) ? 1 : 0;
+}
+#endif
+
 WTZ_HD void wtz_task_gap(uint32_t t, const wtz_env_t &V, const wtz_wintask_t *tasks, const wtz_alnitem_t *items, wtz_gapres_t *gaps,
 		uint32_t *defer = NULL, const uint32_t *list = NULL, uint32_t wide_lds = 0){
 	if(list) t = list[1 + t];
@@ -312,78 +407,20 @@ WTZ_HD void wtz_task_gap(uint32_t t, const wtz_env_t &V, const wtz_wintask_t *ta
 #if defined(__HIP_DEVICE_COMPILE__)
 	bool from_reg = false; uint32_t n_runs = 0; uint32_t *runs = NULL; int32_t r_mat = 0, r_mis = 0;
 	{   /* the whole wavefront computes the banded global alignment; band doubling is uniform (score is broadcast) */
+		(void)M; (void)X; (void)I; (void)D; (void)E;
 		int32_t *lds = wtz_wave_scratch();
-		/* LDS slice: 128 sequence words (1 KB), then either the H/E rings of the general wave DP or the 4-bit trace of the
-		 * register DP with its run list at the top end */
-		wtz_wave_lds_t L; L.tb = (uint64_t*)lds; L.Hs = lds + 256; L.Es = lds + 768; L.PM = 511; L.tw = 128;
-		wtz_wave_lds_t LW = L;           /* the wide launch: 1024 query words, then two rings of 8192 columns */
-		if(wide_lds >= WTZ_GAP_WIDE_LDS_BYTES){ LW.Hs = lds + 2048; LW.Es = lds + 2048 + 8192; LW.PM = 8191; LW.tw = 1024; }
-		uint8_t *ztr = (uint8_t*)(lds + 256); const int32_t ztr_bytes = WTZ_GAP_LDS_BYTES - 1024;
 		wtz_trace_t tr; tr.chunk = NULL; tr.zb = NULL; tr.n_chunk = 0; tr.zrow = 0; tr.cap_rows = 0;
 		wtz_swmem_t mem; wtz_swmem_init(mem, V.pool);
 		for(;;){
 			if(w < WTZ_ABSDIFF(dq, dt)){ w <<= 1; continue; }
-			const int32_t n_col = dq < 2 * w + 1 ? dq : 2 * w + 1;
-			const int32_t zrow = (n_col + 3) & ~3, run_bytes = 4 * (dq + dt + 4);
-			from_reg = false;
-			const unsigned long long pt_g = WTZ_PROF_T(); (void)pt_g;
-			const int32_t qwords = (dq + 63) / 32 + 1, qbytes = (qwords * 8 + 15) & ~15;
-			const bool lds_shape = (dq > 0 && dt > 0 && n_col <= 128 && dt <= 2048 && qwords <= 128 && ((dt + 1) / 2) * zrow + run_bytes <= ztr_bytes);
-			const bool reg_shape = lds_shape || (dq > 0 && dt > 0 && n_col <= 512 && qbytes + 4096 <= WTZ_GAP_LDS_BYTES);
-			if(reg_shape && !lds_shape){
-				/* the 4-bit trace does not fit the LDS slice (or the band is wider than 128 columns, or the gap longer than 2048 rows):
-				 * it goes to the pool (HBM) and the traceback stages blocks of it in LDS.  Slice: query words | 4 KB stage | run list
-				 * (when it still fits, else in the pool too) */
-				uint8_t *stg = (uint8_t*)lds + qbytes;
-				const bool runs_lds = (qbytes + 4096 + run_bytes <= WTZ_GAP_LDS_BYTES);
-				unsigned long long za = 0, ra = 0;
-				if(WTZ_LANE == 0){
-					za = (unsigned long long)(uintptr_t)wtz_pool_alloc(V.pool, (size_t)((dt + 1) / 2) * zrow);
-					if(!runs_lds) ra = (unsigned long long)(uintptr_t)wtz_pool_alloc(V.pool, (size_t)run_bytes);
-				}
-				za = __shfl(za, 0, 64); ra = __shfl(ra, 0, 64);
-				if(za == 0 || (!runs_lds && ra == 0)){ bad = 1; score = 0; }
-				else {
-					runs = runs_lds ? (uint32_t*)(stg + 4096) : (uint32_t*)(uintptr_t)ra; from_reg = true;
-					uint8_t *zg = (uint8_t*)(uintptr_t)za;
-					if(n_col <= 64)       score = wtz_global_reg<1, true>(dq, q, dt, tt, M, X, -I, -E, -D, -E, w, L.tb, zg, (uint32_t)zrow, runs, &n_runs, &r_mat, &r_mis, stg);
-					else if(n_col <= 128) score = wtz_global_reg<2, true>(dq, q, dt, tt, M, X, -I, -E, -D, -E, w, L.tb, zg, (uint32_t)zrow, runs, &n_runs, &r_mat, &r_mis, stg);
-					else if(n_col <= 256) score = wtz_global_reg<4, true>(dq, q, dt, tt, M, X, -I, -E, -D, -E, w, L.tb, zg, (uint32_t)zrow, runs, &n_runs, &r_mat, &r_mis, stg);
-					else                  score = wtz_global_reg<8, true>(dq, q, dt, tt, M, X, -I, -E, -D, -E, w, L.tb, zg, (uint32_t)zrow, runs, &n_runs, &r_mat, &r_mis, stg);
-				}
-				WTZ_PROF_ADD(43, pt_g); WTZ_PROF_CNT(44, 1000000); WTZ_PROF_MAX(45, pt_g);
-			} else if(lds_shape){
-				runs = (uint32_t*)(ztr + ztr_bytes - run_bytes); from_reg = true;
-				if(n_col <= 64) score = wtz_global_reg<1>(dq, q, dt, tt, M, X, -I, -E, -D, -E, w, L.tb, ztr, (uint32_t)zrow, runs, &n_runs, &r_mat, &r_mis);
-				else            score = wtz_global_reg<2>(dq, q, dt, tt, M, X, -I, -E, -D, -E, w, L.tb, ztr, (uint32_t)zrow, runs, &n_runs, &r_mat, &r_mis);
-				WTZ_PROF_ADD(32, pt_g); WTZ_PROF_CNT(33, 1000000); WTZ_PROF_MAX(34, pt_g);
-			} else if(defer && dq > 0 && dt > 0 && !(n_col + 2 <= 512 && qwords <= 128) && n_col + 2 <= 8192 && qwords <= 1024 && (dt + 63) / 64 <= WTZ_TRACE_MAXCHUNK){
-				if(WTZ_LANE == 0){ const uint32_t idx = atomicAdd(&defer[0], 1u); defer[1 + idx] = t; }       /* uniform: the wide launch redoes this gap */
+			wtz_gapdp_t G;
+			wtz_gap_problem_wave<false>(dq, q, dt, tt, P, w, lds, wide_lds, defer != NULL, V.pool, tmp, tr, mem, 0, G);
+			if(G.want_defer){
+				if(WTZ_LANE == 0){ const uint32_t idx = atomicAdd(&defer[0], 1u); defer[1 + idx] = t; }
 				return;
-			} else if(dq > 0 && dt > 0 && n_col + 2 <= LW.PM + 1 && qwords <= LW.tw && (dt + 63) / 64 <= WTZ_TRACE_MAXCHUNK){
-				bool ok = true;
-				score = wtz_global_wave(dq, q, dt, tt, M, X, -I, -E, -D, -E, w, LW, tr, V.pool, tmp, &ok);
-				if(!ok) bad = 1;
-#ifdef WTZ_GAP_CHECK
-				if(ok && WTZ_LANE == 0){
-					wtz_cigar_t t2; t2.init(V.pool, 32); wtz_swmem_t m2; wtz_swmem_init(m2, V.pool);
-					const int32_t s2 = wtz_global_banded(dq, q, dt, tt, M, X, -I, -E, -D, -E, w, m2, t2);
-					bool same = (s2 == __shfl(score, 0, 64) || true) && !m2.bad;
-					uint32_t firstdiff = 0xFFFFFFFFu;
-					if(!m2.bad){ if(t2.n != tmp.n) firstdiff = 0xFFFFFFFEu; else for(uint32_t z9 = 0; z9 < t2.n; z9++) if(t2.a[z9] != tmp.a[z9]){ firstdiff = z9; break; } }
-					if(!m2.bad && (s2 != score || firstdiff != 0xFFFFFFFFu)) printf("[gap-check] dq %d dt %d w %d n_col %d: score wave %d scalar %d; cigar n %u / %u first diff %u\n", dq, dt, w, n_col, score, s2, tmp.n, t2.n, firstdiff);
-					(void)same;
-				}
-#endif
-				WTZ_PROF_ADD(35, pt_g); WTZ_PROF_CNT(36, 1000000); WTZ_PROF_MAX(37, pt_g);
-				WTZ_PROF_CNT(46, (unsigned long long)dt * 1000); if(n_col > 256) WTZ_PROF_CNT(47, 1000000);
-			} else {
-				score = 0;
-				if(WTZ_LANE == 0){ score = wtz_global_banded(dq, q, dt, tt, M, X, -I, -E, -D, -E, w, mem, tmp); if(mem.bad) bad = 1; }
-				WTZ_PROF_ADD(38, pt_g); WTZ_PROF_CNT(39, 1000000); WTZ_PROF_MAX(40, pt_g);
 			}
-			score = __shfl(score, 0, 64);
-			if(__shfl(bad, 0, 64)){ bad = 1; break; }
+			score = G.score; from_reg = G.from_reg; runs = G.runs; n_runs = G.n_runs; r_mat = G.r_mat; r_mis = G.r_mis;
+			if(G.bad){ bad = 1; break; }
 			if(score < 0 && w < P->W && w < WTZ_MAX(dq, dt)) w <<= 1;
 			else break;
 		}

@@ -17,6 +17,7 @@ SYMBOLS = [
     "wtz_last_error", "wtz_device_count", "wtz_ctx_create", "wtz_ctx_destroy", "wtz_ctx_clone", "wtz_upload_reads",
     "wtz_index_build", "wtz_zindex_build", "wtz_candidates", "wtz_candidates_begin", "wtz_candidates_end", "wtz_batch_begin", "wtz_pairs_seed",
     "wtz_pairs_windows", "wtz_pairs_align", "wtz_fetch_cigars", "wtz_fetch_cigar_text", "wtz_host_alloc", "wtz_host_free", "wtz_get_counters", "wtz_reset_counters",
+    "wtz_test_dp",
 ]
 
 
@@ -55,6 +56,13 @@ ALN_RESULT = np.dtype([("score", "<i4"), ("tb", "<i4"), ("te", "<i4"), ("qb", "<
                        ("text_len", "<u4"), ("pad", "<u4"), ("text_off", "<u8")])
 
 
+DP_PROBLEM = np.dtype([("q_read", "<u4"), ("t_read", "<u4"), ("q_rev", "<u4"), ("t_rev", "<u4"), ("q_from", "<i4"), ("t_from", "<i4"),
+                       ("q_strand", "<i4"), ("t_strand", "<i4"), ("q_len", "<i4"), ("t_len", "<i4"), ("init_score", "<i4"), ("W", "<i4")])
+DP_RESULT = np.dtype([("score", "<i4"), ("tb", "<i4"), ("te", "<i4"), ("qb", "<i4"), ("qe", "<i4"), ("aln", "<i4"), ("mat", "<i4"),
+                      ("mis", "<i4"), ("ins", "<i4"), ("del", "<i4"), ("cigar_len", "<u4"), ("form_used", "<u4"), ("cigar_off", "<u8"), ("cells", "<u8")])
+DP_SHIFT, DP_FIXED, DP_GLOBAL = 0, 1, 2
+
+
 class Counters(C.Structure):
     _fields_ = [(n, C.c_double) for n in ("ms_index", "ms_zindex", "ms_candidates", "ms_pairs", "ms_winalign", "ms_stitch")] + \
                [(n, C.c_uint64) for n in ("n_candidates_q", "n_pairs", "n_winalign", "n_stitch", "cells_shift", "cells_fixed",
@@ -83,6 +91,7 @@ def load(path: str | None = None) -> C.CDLL:
     lib.wtz_fetch_cigars.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
     lib.wtz_get_counters.argtypes = [C.c_void_p, C.POINTER(Counters)]
     lib.wtz_reset_counters.argtypes = [C.c_void_p]
+    lib.wtz_test_dp.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint64]
     return lib
 
 
@@ -173,6 +182,14 @@ class Context:
         cig = np.zeros(tot, dtype=np.uint32)
         self._chk(self.lib.wtz_fetch_cigars(self.h, cig.ctypes.data, tot))
         return out, cig
+
+    def test_dp(self, kind, form, problems, cigar_cap=1 << 22):
+        """TEST-ONLY: run DP problems through one device form; returns (results, list of CIGAR arrays)."""
+        problems = np.ascontiguousarray(problems, dtype=DP_PROBLEM)
+        out = np.zeros(problems.size, dtype=DP_RESULT)
+        cig = np.zeros(cigar_cap, dtype=np.uint32)
+        self._chk(self.lib.wtz_test_dp(self.h, kind, form, problems.ctypes.data, problems.size, out.ctypes.data, cig.ctypes.data, cig.size))
+        return out, [cig[int(o):int(o) + int(n)].copy() for o, n in zip(out["cigar_off"], out["cigar_len"])]
 
     def counters(self) -> Counters:
         c = Counters()

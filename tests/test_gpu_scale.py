@@ -1,0 +1,69 @@
+"""Parity at BASELINE scale (-m gpu): the seeded synthetic read sets of BASELINE.json configs[1] (E. coli shape, 115 Mbp), a
+yeast-genome-size set (360 Mbp), configs[2] (1.2 Gbp of reads) and a repeat-rich set are regenerated here with
+smartdenovo_amd/synth.py (the md5 of the FASTA must match the one the goldens were made from) and run through the drop-in
+`wtzmo`; the md5 of the full .ovl (incl. CIGAR), the record count, the .contained file and the number / total length of the
+pairs that entered pair alignment must equal what the REAL reference `wtzmo -t 1` produced in the build container
+(tests/golden/big_manifest.json, made by tests/golden/make_big_goldens.py).  Only checksums are stored: the files are 0.2 - 3 GB."""
+import hashlib
+import json
+import os
+import subprocess
+
+import pytest
+
+from conftest import GOLD, ROOT
+
+pytestmark = pytest.mark.gpu
+MAN = json.load(open(os.path.join(GOLD, "big_manifest.json")))
+TMP = os.environ.get("WTZ_BENCH_TMP", "/tmp/wtz_bench")
+CASES = sorted(MAN["cases"])
+
+
+def file_md5(path):
+    h = hashlib.md5()
+    n = 0
+    with open(path, "rb") as fh:
+        while True:
+            b = fh.read(1 << 24)
+            if not b:
+                break
+            h.update(b)
+            n += b.count(b"\n")
+    return h.hexdigest(), n
+
+
+def reads_of(name):
+    """regenerate the input (cached per box run; bench.py uses the same files)"""
+    from smartdenovo_amd import synth
+    s = MAN["sets"][name]
+    os.makedirs(TMP, exist_ok=True)
+    fa = os.path.join(TMP, "reads_G%d_c%g_s%d%s.fa" % (s["genome"], s["coverage"], s["seed"], "_rep" if s["repeats"] else ""))
+    if not (os.path.exists(fa) and os.path.exists(fa + ".meta")):
+        names, seqs = synth.synth_reads(s["genome"], s["coverage"], seed=s["seed"], repeats=s["repeats"])
+        md5 = synth.write_fasta(fa + ".tmp", names, seqs)
+        os.replace(fa + ".tmp", fa)
+        json.dump({"reads": len(names), "bases": int(sum(x.size for x in seqs)), "md5": md5}, open(fa + ".meta", "w"))
+    meta = json.load(open(fa + ".meta"))
+    assert meta["md5"] == s["md5_fasta"] and meta["reads"] == s["reads"], "synthetic generator drifted: the goldens were made from different bytes"
+    return fa
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_gpu_equals_reference_at_scale(name, gpu_exe):
+    case = MAN["cases"][name]
+    fa = reads_of(case["set"])
+    out = os.path.join(TMP, "scale_%s.ovl" % name)
+    stats = out + ".stats"
+    for f in (out, out + ".contained", stats):
+        if os.path.exists(f):
+            os.remove(f)
+    r = subprocess.run([gpu_exe, "-i", fa, "-fo", out, "--stats", stats] + case["argv"], capture_output=True)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    assert b"splitting the batch" not in r.stderr, "the planned batch size must fit the scratch pool (no WTZ_E_POOL retries)"
+    md5, nrec = file_md5(out)
+    assert nrec == case["records"], "%d records, the reference wrote %d" % (nrec, case["records"])
+    assert md5 == case["md5_full"], "full .ovl (incl. CIGAR) differs from reference wtzmo -t 1"
+    assert file_md5(out + ".contained")[0] == case["md5_contained"]
+    row = open(stats).read().split("\n")[0].split("\t")
+    assert (int(row[0]), int(row[1])) == (case["pairs"], case["pair_bp"]), "pairs entering pair alignment (the bench numerator) differ from the reference's -9 set"
+    os.remove(out)
