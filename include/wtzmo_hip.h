@@ -170,6 +170,13 @@ typedef struct {
 } wtz_dp_result_t;
 int  wtz_test_dp(wtz_ctx_t *ctx, int32_t kind, int32_t form, const wtz_dp_problem_t *problems, uint32_t n, wtz_dp_result_t *out, uint32_t *cigar, uint64_t cigar_cap);
 
+/* Scratch accounting, so that the caller can size its batches to the pool instead of discovering the limit by WTZ_E_POOL:
+ * the context's scratch is cut into a main pool (everything that lives for the batch: match lists, windows, CIGARs) and a transient
+ * pool (K-sw3 trace matrices; the library sizes its own launch groups to it).  main_used = bytes of the main pool in use after the
+ * last stage call (wtz_pairs_seed / wtz_pairs_align), transient_peak = high-water mark of the transient pool during it. */
+typedef struct { uint64_t main_cap, main_used, transient_cap, transient_peak; } wtz_pool_info_t;
+int  wtz_pool_info(wtz_ctx_t *ctx, wtz_pool_info_t *out);
+
 int  wtz_get_counters(wtz_ctx_t *ctx, wtz_counters_t *out);
 int  wtz_reset_counters(wtz_ctx_t *ctx);
 

@@ -78,6 +78,9 @@ typedef struct {
 	 * (own HIP stream + scratch pool) and committed strictly in sequence */
 	pthread_mutex_t mu; pthread_cond_t cv;
 	uint32_t cursor, qend, B; uint64_t next_seq, commit_seq;
+	/* planned batch sizing: main-pool bytes a pair has needed so far (largest seen, reads are processed longest first), so that the pairs of
+	 * a range are cut to fit the pool BEFORE the device stages run; WTZ_E_POOL and the halving below it remain as the safety net */
+	double bytes_per_pair; uint64_t main_cap; uint64_t n_split, n_ranges;
 	pending_t pend;
 	/* stats */
 	char *cig_keep[16]; uint64_t cig_keep_cap[16];      /* page-locked CIGAR text buffer of worker w, kept across steps (pinning is the expensive part) */
@@ -550,7 +553,18 @@ static void process_range(eng_t *E, batch_t *b, uint32_t s0, uint32_t s1){
 	const double tg0 = now_s();
 	const int again = gpu_stages(E, b);
 	const double tg1 = now_s();
+	if(!again && b->npair){
+		wtz_pool_info_t pi;
+		if(wtz_pool_info(b->ctx, &pi) == WTZ_OK){
+			pthread_mutex_lock(&E->mu);
+			E->main_cap = pi.main_cap;
+			const double bpp = (double)pi.main_used / (double)b->npair;
+			if(b->npair >= 8 && bpp > E->bytes_per_pair) E->bytes_per_pair = bpp;
+			pthread_mutex_unlock(&E->mu);
+		}
+	}
 	if(again){
+		pthread_mutex_lock(&E->mu); E->n_split++; E->bytes_per_pair = (E->bytes_per_pair > 0 ? E->bytes_per_pair : 1048576.0) * 2.0; pthread_mutex_unlock(&E->mu);
 		if(s1 - s0 <= 1){ fprintf(stderr, " -- device scratch pool too small even for one query: %s (use --pool-gb) --\n", wtz_last_error()); exit(1); }
 		fprintf(stderr, "[wtzmo-mi355x] scratch pool exhausted with %u queries in flight; splitting the batch\n", s1 - s0);
 		const uint32_t mid = s0 + (s1 - s0) / 2;
@@ -558,7 +572,7 @@ static void process_range(eng_t *E, batch_t *b, uint32_t s0, uint32_t s1){
 		process_range(E, b, mid, s1);
 		return;
 	}
-	if(s0 == 0 && s1 == b->nbq && !b->pf_inflight){ pthread_mutex_lock(&E->mu); prefetch_begin(E, b); pthread_mutex_unlock(&E->mu); }
+	if(s1 == b->nbq && !b->pf_inflight){ pthread_mutex_lock(&E->mu); prefetch_begin(E, b); pthread_mutex_unlock(&E->mu); }
 	pthread_mutex_lock(&E->mu);
 	E->t_gpu += tg1 - tg0;
 	for(int k = 0; k < 5; k++){ E->t_call[k] += b->t_call[k]; b->t_call[k] = 0; }
@@ -575,6 +589,24 @@ static void process_range(eng_t *E, batch_t *b, uint32_t s0, uint32_t s1){
 	out_submit(&g_ow);      /* nothing of this batch stays in the chunk under construction (see out_wait_ext) */
 	E->t_commit += now_s() - tg1;
 	pthread_mutex_unlock(&E->mu);
+}
+
+/* the slots of a batch in ranges whose pairs (candidate rows are their upper bound) fit the main scratch pool at the measured bytes per pair */
+static void process_batch(eng_t *E, batch_t *b){
+	uint32_t s0 = 0;
+	while(s0 < b->nbq){
+		pthread_mutex_lock(&E->mu);
+		const double bpp = E->bytes_per_pair > 0 ? E->bytes_per_pair : 1048576.0;      /* prior before the first measurement: 1 MB per pair */
+		const double cap = E->main_cap ? (double)E->main_cap : 0.0;
+		pthread_mutex_unlock(&E->mu);
+		uint64_t budget = cap > 0 ? (uint64_t)(0.7 * cap / bpp) : ~0ull;
+		if(budget < 16) budget = 16;
+		uint32_t s1 = s0; uint64_t acc = 0;
+		while(s1 < b->nbq && (s1 == s0 || acc + (b->want[s1] ? b->nrow[s1] : 0) <= budget)){ acc += b->want[s1] ? b->nrow[s1] : 0; s1++; }
+		process_range(E, b, s0, s1);
+		pthread_mutex_lock(&E->mu); E->n_ranges++; pthread_mutex_unlock(&E->mu);
+		s0 = s1;
+	}
 }
 
 static void *pin_main(void *arg){
@@ -646,7 +678,7 @@ static void *worker_main(void *arg){
 			free(rows); free(nr);
 			pthread_mutex_lock(&E->mu); E->t_gpu += tg1 - tg0; E->t_call[0] += tg1 - tg0; pthread_mutex_unlock(&E->mu);
 		}
-		if(b->nbq) process_range(E, b, 0, b->nbq);
+		if(b->nbq) process_batch(E, b);
 		/* ---- hand the turn to the next batch ---- */
 		pthread_mutex_lock(&E->mu);
 		while(!b->holds_turn && E->commit_seq != b->seq) pthread_cond_wait(&E->cv, &E->mu);
@@ -840,6 +872,7 @@ int main(int argc, char **argv){
 	  for(uint32_t i = 0; i < nq; i++) tot += E->rdlen[b0 + i];
 	  E->avg_rdlen = nq ? (uint32_t)(tot / nq) : 10000; if(E->avg_rdlen == 0) E->avg_rdlen = 1; }        /* wtzmo.c:361-368 */
 	int rc = wtz_ctx_create(gpu, P, pool_bytes, &E->ctx); DIE_WTZ(rc, "wtz_ctx_create");
+	{ wtz_pool_info_t pi; if(wtz_pool_info(E->ctx, &pi) == WTZ_OK) E->main_cap = pi.main_cap; }
 	rc = wtz_upload_reads(E->ctx, E->st.bits, (E->st.nbase + 31) / 32, rdoff, E->rdlen, n_all); DIE_WTZ(rc, "wtz_upload_reads");
 	/* page-lock the first worker's CIGAR text buffer while the indexes are built (pinning ~100 MB takes about as long as they do) */
 	pthread_t pin_th; int pin_started = 0;
@@ -866,7 +899,7 @@ int main(int argc, char **argv){
 			for(size_t i = 0; i < nclosed0; i++) hx_set_put(&E->closed, closed0[i]);
 			E->pair_bp = E->n_pairs = E->nrec = 0;
 			E->t_gpu = E->t_commit = 0; memset(E->t_call, 0, sizeof E->t_call); E->t_io[0] = E->t_io[1] = 0; E->spec_pairs = E->used_pairs = E->spec_items = E->used_items = E->spec_queries = E->used_queries = 0;
-			E->rows_all = 0; E->n_batches = 0;
+			E->rows_all = 0; E->n_batches = 0; E->n_split = 0; E->n_ranges = 0;
 			E->pend.rd_id = 0xFFFFFFFFu; E->pend.nhit = E->pend.nmask = E->pend.nclosed = E->pend.nseed = 0;
 			if(strcmp(output, "-")){ E->out = fopen(output, "w"); if(E->out == NULL) exit(1); setvbuf(E->out, NULL, _IOFBF, 8u << 20); }
 			wtz_reset_counters(E->ctx);
@@ -960,8 +993,9 @@ int main(int argc, char **argv){
 		fprintf(stderr, "[wtzmo-mi355x] %llu records, %llu pairs aligned, %llu pair-bp, %.3f s (index %.3f s)\n", (unsigned long long)E->nrec, (unsigned long long)E->n_pairs, (unsigned long long)E->pair_bp, t1 - t0, t_index);
 		fprintf(stderr, "[wtzmo-mi355x] host seconds: in GPU-stage calls %.3f, commit %.3f (record formatting %.3f); waiting for the output writer: %.3f before buffer reuse, %.3f at the end\n", E->t_gpu, E->t_commit, E->t_call[5], E->t_io[0], E->t_io[1]);
 		fprintf(stderr, "[wtzmo-mi355x] wall seconds per call: candidates %.3f pairs_seed %.3f pairs_windows %.3f pairs_align %.3f cigar_text %.3f\n", E->t_call[0], E->t_call[1], E->t_call[2], E->t_call[3], E->t_call[4]);
-	fprintf(stderr, "[wtzmo-mi355x] %llu batches on %u worker context(s); speculation: queries %llu/%llu pairs %llu/%llu alignments %llu/%llu (used/planned)\n",
-			(unsigned long long)E->n_batches, E->rows_all ? 1u : E->n_workers, (unsigned long long)E->used_queries, (unsigned long long)E->spec_queries, (unsigned long long)E->used_pairs, (unsigned long long)E->spec_pairs, (unsigned long long)E->used_items, (unsigned long long)E->spec_items);
+	if(E->n_split) fprintf(stderr, "[wtzmo-mi355x] %llu range(s) had to be split after a scratch-pool overflow (planned at %.0f KB per pair)\n", (unsigned long long)E->n_split, E->bytes_per_pair / 1024.0);
+	fprintf(stderr, "[wtzmo-mi355x] %llu batches in %llu ranges on %u worker context(s); speculation: queries %llu/%llu pairs %llu/%llu alignments %llu/%llu (used/planned)\n",
+			(unsigned long long)E->n_batches, (unsigned long long)E->n_ranges, E->rows_all ? 1u : E->n_workers, (unsigned long long)E->used_queries, (unsigned long long)E->spec_queries, (unsigned long long)E->used_pairs, (unsigned long long)E->spec_pairs, (unsigned long long)E->used_items, (unsigned long long)E->spec_items);
 		fprintf(stderr, "[wtzmo-mi355x] kernel ms: index %.1f zindex %.1f candidates %.1f pairs %.1f winalign %.1f stitch %.1f (K-sw3 wave %.1f); cells shift %llu; pool peak %.2f GB\n",
 			cn.ms_index, cn.ms_zindex, cn.ms_candidates, cn.ms_pairs, cn.ms_winalign, cn.ms_stitch, cn.ms_ext, (unsigned long long)cn.cells_shift, cn.pool_peak / 1073741824.0);
 		if(statsf){ FILE *sf = fopen(statsf, "a"); if(sf){ fprintf(sf, "%llu\t%llu\t%.6f\t%.6f\t%.3f\t%.3f\t%.3f\t%.3f\t%.3f\t%.3f\t%llu\t%llu\t%llu\t%llu\t%llu\t%.3f\t%llu\t%llu\t%llu\n", (unsigned long long)E->n_pairs, (unsigned long long)E->pair_bp, t1 - t0, t_index,

@@ -95,10 +95,20 @@ typedef struct {
 	unsigned long long cap;
 	unsigned long long used;
 	int overflow;
+	/* fault injection (WTZ_POOL_FAIL_AT=<n>, tests only): the n-th and every later request of a stage fails as if the pool were full */
+	unsigned int fail_at, nalloc;
 } wtz_pool_t;
 
 WTZ_HD void *wtz_pool_alloc(wtz_pool_t *p, size_t bytes){
 	unsigned long long n = ((unsigned long long)bytes + 15ull) & ~15ull;
+	if(p->fail_at){
+#if defined(__HIP_DEVICE_COMPILE__)
+		const unsigned int k = atomicAdd(&p->nalloc, 1u);
+#else
+		const unsigned int k = p->nalloc++;
+#endif
+		if(k + 1u >= p->fail_at){ p->overflow = 1; return NULL; }
+	}
 #if defined(__HIP_DEVICE_COMPILE__)
 	unsigned long long o = atomicAdd(&p->used, n);
 #else

@@ -25,6 +25,7 @@
 static thread_local char g_err[512] = "";
 #define CHK(call) do { int rc_ = (call); if(rc_ != WTZ_OK) return rc_; } while(0)
 #define CHK0(call) CHK(call)
+#define STAGE(c, name) do { if((c)->env_trace){ (void)dev_sync(); fprintf(stderr, "[stage] %s\n", name); fflush(stderr); } } while(0)
 static int wtz_fail(int code, const char *fmt, ...){
 	va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof g_err, fmt, ap); va_end(ap);
 	return code;
@@ -256,7 +257,10 @@ struct wtz_ctx {
 	/* z index */
 	uint64_t *zoff; uint64_t n_z; wtz_zindex_t Z; bool have_z;
 	/* pool */
-	wtz_pool_t *dpool; uint8_t *pool_base; uint64_t pool_bytes;
+	/* scratch: ONE allocation of pool_bytes, cut in two bump pools: dpool[0] = results and scratch that live for the batch (match lists,
+	 * windows, anchors, CIGARs), dpool[1] = the transient pool of the K-sw3 trace matrices, reset after every launch group of extension
+	 * jobs (run_extjobs sizes the groups from the jobs' geometry, so its demand is planned, not discovered by exhaustion) */
+	wtz_pool_t *dpool; uint8_t *pool_base; uint64_t pool_bytes, main_bytes;
 	/* per-batch results */
 	uint32_t *d_qid, *d_cid; wtz_pairres_t *d_pairres; uint32_t n_pairs; std::vector<wtz_pairres_t> h_pairres;
 	wtz_alnres_dev_t *d_alnres; uint32_t n_items; std::vector<wtz_alnres_dev_t> h_alnres;
@@ -264,6 +268,10 @@ struct wtz_ctx {
 	/* candidate request in flight (wtz_candidates_begin / _end) */
 	uint32_t *cq_q = NULL, *cq_nc = NULL; uint64_t *cq_cand = NULL; unsigned long long *cq_bytes = NULL; uint32_t cq_cap = 0, cq_n = 0; bool cq_pending = false; wtz_timer cq_tm;
 	wtz_counters_t cnt;
+	uint64_t tpool_peak_call = 0, main_used_call = 0;      /* transient-pool high-water mark / main-pool bytes of the API call in progress */
+	bool env_trace = false;      /* WTZ_STAGE_TRACE: name every device stage on stderr before it is launched (locating a device fault) */
+	bool env_fail_once = false;      /* WTZ_POOL_FAIL_ONCE: the injected failure hits one stage call only (the retry must then succeed) */
+	unsigned env_fail_at = 0, env_tfail_at = 0;      /* WTZ_POOL_FAIL_AT / WTZ_TPOOL_FAIL_AT: fault injection into the main / transient pool */
 	int env_sw_mode = 0, env_mw_min = 512, env_mw_top = 1 << 30, env_use_reg = 1, env_gap_side = 0; bool env_profile = false;     /* WTZ_* debugging switches, read in wtz_ctx_create */
 };
 
@@ -276,13 +284,32 @@ struct wtz_ctx {
 static wtz_reads_t ctx_reads(const wtz_ctx *c){ wtz_reads_t R; R.bits = c->bits; R.rdoff = c->rdoff; R.rdlen = c->rdlen; R.n_reads = c->n_reads; return R; }
 static wtz_env_t ctx_env(const wtz_ctx *c){ wtz_env_t V; V.R = ctx_reads(c); V.Z = c->Z; V.P = c->dP; V.pool = c->dpool; return V; }
 
+static int tpool_reset(wtz_ctx *c){
+	wtz_pool_t p; p.base = c->pool_base + c->main_bytes; p.cap = c->pool_bytes - c->main_bytes; p.used = 0; p.overflow = 0; p.fail_at = c->env_tfail_at; p.nalloc = 0;
+	return dev_h2d(c->dpool + 1, &p, sizeof p);
+}
 static int pool_reset(wtz_ctx *c){
-	wtz_pool_t p; p.base = c->pool_base; p.cap = c->pool_bytes; p.used = 0; p.overflow = 0;
-	return dev_h2d(c->dpool, &p, sizeof p);
+	wtz_pool_t p; p.base = c->pool_base; p.cap = c->main_bytes; p.used = 0; p.overflow = 0; p.fail_at = c->env_fail_at; p.nalloc = 0;
+	CHK(dev_h2d(c->dpool, &p, sizeof p));
+	c->tpool_peak_call = 0;
+	return tpool_reset(c);
+}
+/* the transient pool after a launch group: remember its high-water mark, fail on exhaustion */
+static int tpool_check(wtz_ctx *c, const char *stage){
+	wtz_pool_t p; CHK(dev_d2h(&p, c->dpool + 1, sizeof p));
+	const uint64_t u = p.used > p.cap ? p.cap : p.used;
+	if(u > c->tpool_peak_call) c->tpool_peak_call = u;
+	if(p.overflow && c->env_fail_once) c->env_tfail_at = 0;
+	if(p.overflow) return wtz_fail(WTZ_E_POOL, "%s: transient trace pool exhausted (%llu of %llu bytes requested); use a larger pool",
+		stage, (unsigned long long)p.used, (unsigned long long)p.cap);
+	return WTZ_OK;
 }
 static int pool_check(wtz_ctx *c, const char *stage){
 	wtz_pool_t p; CHK(dev_d2h(&p, c->dpool, sizeof p));
-	if(p.used > c->cnt.pool_peak) c->cnt.pool_peak = p.used > p.cap ? p.cap : p.used;
+	const uint64_t u = (p.used > p.cap ? p.cap : p.used);
+	c->main_used_call = u;
+	if(u + c->tpool_peak_call > c->cnt.pool_peak) c->cnt.pool_peak = u + c->tpool_peak_call;
+	if(p.overflow && c->env_fail_once) c->env_fail_at = 0;       /* injected failure: only the first stage call that gets that far */
 	if(p.overflow) return wtz_fail(WTZ_E_POOL, "%s: device scratch pool exhausted (%llu of %llu bytes requested); use fewer items per call or a larger pool",
 		stage, (unsigned long long)p.used, (unsigned long long)p.cap);
 	return WTZ_OK;
@@ -317,12 +344,13 @@ extern "C" int wtz_ctx_create(int device, const wtz_params_c *params, uint64_t p
 	c->zoff = NULL; c->n_z = 0; memset(&c->Z, 0, sizeof c->Z); c->have_z = false;
 	c->dpool = NULL; c->pool_base = NULL; c->pool_bytes = pool_bytes ? pool_bytes : (4ull << 30);
 #ifndef WTZ_EMUL
-	if(!pool_bytes){      /* default: half of the free HBM, at most 24 GB - per-batch scratch and results of the speculative stages */
+	if(!pool_bytes){      /* default: a third of the free HBM, at most 64 GB (288 GB per MI355X; the reads and both indexes of a 1.2 Gbp set take ~25 GB) */
 		size_t fr = 0, tot = 0;
-		if(hipMemGetInfo(&fr, &tot) == hipSuccess && fr / 2 > c->pool_bytes) c->pool_bytes = (uint64_t)(fr / 2);
-		if(c->pool_bytes > (24ull << 30)) c->pool_bytes = 24ull << 30;      /* the host driver halves its batch on WTZ_E_POOL */
+		if(hipMemGetInfo(&fr, &tot) == hipSuccess && fr / 3 > c->pool_bytes) c->pool_bytes = (uint64_t)(fr / 3);
+		if(c->pool_bytes > (64ull << 30)) c->pool_bytes = 64ull << 30;      /* the host driver sizes its batches to the pool (wtz_pool_info) */
 	}
 #endif
+	c->pool_bytes &= ~(uint64_t)4095; c->main_bytes = (c->pool_bytes / 2) & ~(uint64_t)4095;
 	c->d_qid = c->d_cid = NULL; c->d_pairres = NULL; c->n_pairs = 0; c->d_alnres = NULL; c->n_items = 0; c->have_pairs = c->have_items = false;
 	memset(&c->cnt, 0, sizeof c->cnt);
 	c->cap_pairs = c->cap_items = 0;
@@ -347,9 +375,13 @@ extern "C" int wtz_ctx_create(int device, const wtz_params_c *params, uint64_t p
 	c->env_gap_side = (getenv("WTZ_GAP_SIDESTREAM") && atoi(getenv("WTZ_GAP_SIDESTREAM"))) ? 1 : 0;
 	c->env_profile = getenv("WTZ_PROFILE_PAIR") != NULL;
 #endif
+	c->env_trace = getenv("WTZ_STAGE_TRACE") != NULL;
+	c->env_fail_once = getenv("WTZ_POOL_FAIL_ONCE") != NULL;
+	c->env_fail_at = getenv("WTZ_POOL_FAIL_AT") ? (unsigned)atoi(getenv("WTZ_POOL_FAIL_AT")) : 0u;
+	c->env_tfail_at = getenv("WTZ_TPOOL_FAIL_AT") ? (unsigned)atoi(getenv("WTZ_TPOOL_FAIL_AT")) : 0u;
 	int rc;
 	if((rc = dev_alloc_persist((void**)&c->dP, sizeof(wtz_params_t))) || (rc = dev_h2d(c->dP, &c->P, sizeof(wtz_params_t))) ||
-	   (rc = dev_alloc_persist((void**)&c->dpool, sizeof(wtz_pool_t))) || (rc = dev_alloc_persist((void**)&c->pool_base, c->pool_bytes)) || (rc = pool_reset(c))){
+	   (rc = dev_alloc_persist((void**)&c->dpool, 2 * sizeof(wtz_pool_t))) || (rc = dev_alloc_persist((void**)&c->pool_base, c->pool_bytes)) || (rc = pool_reset(c))){
 		wtz_ctx_destroy(c); return rc;
 	}
 	*out = c;
@@ -576,6 +608,7 @@ extern "C" int wtz_candidates_begin(wtz_ctx_t *c, const uint32_t *qids, uint32_t
 	CHK(dev_set(d_bytes, 0, 8));
 	const wtz_reads_t R = ctx_reads(c); const wtz_params_t *dP = c->dP; const wtz_kslot_t *tab = c->ktab; const uint64_t kmask = c->kmask;
 	const uint32_t *seeds = c->kseeds; wtz_pool_t *pool = c->dpool;
+	STAGE(c, "K_candidates");
 	c->cq_tm.start();
 #ifndef WTZ_EMUL
 	CHK(wtz_launch_coop<K_candidates>(0, nq, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_candidates((uint32_t)t, R, d_q, dP, tab, kmask, seeds, pool, d_cand, d_n, stride, d_bytes, (uint64_t*)wtz_wave_scratch(), WTZ_CAND_LDS_BYTES / 8); }, WTZ_CAND_LDS_BYTES));
@@ -619,6 +652,21 @@ extern "C" int wtz_batch_begin(wtz_ctx_t *c){
 	return pool_reset(c);
 }
 
+#if defined(WTZ_DEBUG_CRUMBS) && !defined(WTZ_EMUL)
+#include <signal.h>
+#include <unistd.h>
+static unsigned int *g_crumbs = NULL; static uint32_t g_crumbs_n = 0; static const uint32_t *g_crumbs_q = NULL, *g_crumbs_c = NULL;
+static void wtz_crumbs_dump(int sig){
+	unsigned hist[256]; memset(hist, 0, sizeof hist); unsigned shown = 0;
+	for(uint32_t i = 0; i < g_crumbs_n; i++) hist[g_crumbs[i] & 0xFF]++;
+	fprintf(stderr, "[crumbs] signal %d, %u pairs; tasks per last point:", sig, g_crumbs_n);
+	for(int k = 0; k < 256; k++) if(hist[k]) fprintf(stderr, " %d:%u", k, hist[k]);
+	fprintf(stderr, "\n");
+	for(uint32_t i = 0; i < g_crumbs_n && shown < 16; i++) if((g_crumbs[i] & 0xFF) != 0xFF && (g_crumbs[i] & 0xFF) != 0){ fprintf(stderr, "[crumbs]   pair %u (q %u, c %u): point %u, hits %u\n", i, g_crumbs_q[i], g_crumbs_c[i], g_crumbs[i] & 0xFF, g_crumbs[i] >> 8); shown++; }
+	fflush(stderr); _exit(86);
+}
+#endif
+
 extern "C" int wtz_pairs_seed(wtz_ctx_t *c, const uint32_t *qid, const uint32_t *cid, uint32_t n, wtz_pair_summary_t *out){
 	if(!c || !c->have_z || (n && (!qid || !cid || !out))) return wtz_fail(WTZ_E_ARG, "z-index not built / null argument");
 	CTX_ENTER(c);
@@ -631,7 +679,33 @@ extern "C" int wtz_pairs_seed(wtz_ctx_t *c, const uint32_t *qid, const uint32_t 
 	const wtz_env_t V = ctx_env(c); const uint32_t *dq = c->d_qid, *dc = c->d_cid; wtz_pairres_t *dr = c->d_pairres;
 	wtz_timer tm; tm.start();
 	wtz_timer t1; t1.start();
+	STAGE(c, "K_pair");
+#if defined(WTZ_DEBUG_CRUMBS) && !defined(WTZ_EMUL)
+	unsigned int *h_crumbs = NULL;
+	if(getenv("WTZ_DEBUG_CRUMBS")){
+		HIPCHK(hipHostMalloc((void**)&h_crumbs, (size_t)n * 4, hipHostMallocCoherent | hipHostMallocMapped)); memset(h_crumbs, 0, (size_t)n * 4);
+		unsigned int *dptr = NULL; HIPCHK(hipHostGetDevicePointer((void**)&dptr, h_crumbs, 0));
+		HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(wtz_crumbs), &dptr, sizeof dptr));
+		g_crumbs = h_crumbs; g_crumbs_n = n; g_crumbs_q = qid; g_crumbs_c = cid;
+		signal(SIGABRT, wtz_crumbs_dump); signal(SIGPIPE, wtz_crumbs_dump); signal(SIGSEGV, wtz_crumbs_dump); signal(SIGBUS, wtz_crumbs_dump); signal(SIGTERM, wtz_crumbs_dump);
+	}
+#endif
 	CHK(wtz_launch_coop<K_pair>(0, n, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_pair((uint32_t)t, V, dq, dc, dr); }, c->P.dot_matrix ? WTZ_PAIR_DM_LDS_BYTES : WTZ_PAIR_LDS_BYTES));
+#if defined(WTZ_DEBUG_CRUMBS) && !defined(WTZ_EMUL)
+	if(h_crumbs){
+		const double t0 = wtz_wall(); const double limit = atof(getenv("WTZ_DEBUG_CRUMBS")) > 1 ? atof(getenv("WTZ_DEBUG_CRUMBS")) : 20.0;
+		while(hipStreamQuery(g_stream) == hipErrorNotReady && wtz_wall() - t0 < limit){ struct timespec ts = {0, 50000000}; nanosleep(&ts, NULL); }
+		if(hipStreamQuery(g_stream) == hipErrorNotReady){
+			unsigned hist[256]; memset(hist, 0, sizeof hist); unsigned shown = 0;
+			for(uint32_t i = 0; i < n; i++) hist[h_crumbs[i] & 0xFF]++;
+			fprintf(stderr, "[crumbs] K_pair still running after %.0f s, %u pairs; tasks per last point:", limit, n);
+			for(int k = 0; k < 256; k++) if(hist[k]) fprintf(stderr, " %d:%u", k, hist[k]);
+			fprintf(stderr, "\n");
+			for(uint32_t i = 0; i < n && shown < 12; i++) if((h_crumbs[i] & 0xFF) != 0xFF && (h_crumbs[i] & 0xFF) != 0){ fprintf(stderr, "[crumbs]   pair %u (q %u, c %u): point %u, hits %u\n", i, qid[i], cid[i], h_crumbs[i] & 0xFF, h_crumbs[i] >> 8); shown++; }
+			fflush(stderr); _exit(86);
+		}
+	}
+#endif
 	CHK(dev_sync());
 	{ const double ms1 = t1.stop(); if(c->env_profile) fprintf(stderr, "[pair-profile] K_pair first launch: %u pairs, %.1f ms\n", n, ms1); }
 	c->n_pairs = n; c->h_pairres.resize(n); c->have_pairs = true;
@@ -647,6 +721,7 @@ extern "C" int wtz_pairs_seed(wtz_ctx_t *c, const uint32_t *qid, const uint32_t 
 			uint32_t *d_list = NULL; CHK(dev_alloc((void**)&d_list, list.size() * 4)); CHK(dev_h2d(d_list, list.data(), list.size() * 4));
 			const uint32_t lb = tiers[tier]; const bool last = (tier == 1);
 			wtz_timer tt; tt.start();
+			STAGE(c, "K_pair_big");
 			CHK(wtz_launch_coop<K_pair_big>(0, list.size(), [=] WTZ_LAMBDA (uint64_t t){ wtz_task_pair_dm_big((uint32_t)t, V, d_list, dq, dc, dr, lb, last); }, lb));
 			CHK(dev_sync());
 			const double ms_t = tt.stop();
@@ -721,45 +796,81 @@ static int run_extjobs(wtz_ctx *c, const wtz_env_t &V, wtz_extjob_t *d_jobs, uin
 	 * start the long ones first (key = query-side length, the row count upper bound) */
 	uint32_t *d_order = NULL; unsigned long long ext_sum = 0; int32_t ext_max = 0; uint32_t n_mw = 0;
 	const int mw_min = c->env_mw_min;
+	std::vector<uint32_t> ord(m); std::vector<uint64_t> need(m);
 	{
-		int32_t *d_key = NULL; CHK(dev_alloc((void**)&d_key, (size_t)m * 4));
-		CHK(wtz_launch<K_misc>(0, m, [=] WTZ_LAMBDA (uint64_t t){ d_key[t] = d_jobs[t].valid ? d_jobs[t].qlen : -1; }));
-		std::vector<int32_t> key(m); CHK(dev_d2h(key.data(), d_key, (size_t)m * 4)); dev_free(d_key);
-		for(uint32_t i = 0; i < m; i++) if(key[i] > 0){ ext_sum += (unsigned long long)key[i]; if(key[i] > ext_max) ext_max = key[i]; }
-		std::vector<uint32_t> ord(m); for(uint32_t i = 0; i < m; i++) ord[i] = i;
+		/* (qlen, tlen, init_score, W) of every job: the order key, and the job's geometry = an upper bound of its trace bytes */
+		int32_t *d_key = NULL; CHK(dev_alloc((void**)&d_key, (size_t)m * 16));
+		CHK(wtz_launch<K_misc>(0, m, [=] WTZ_LAMBDA (uint64_t t){ const wtz_extjob_t &j = d_jobs[t]; d_key[4 * t] = j.valid ? j.qlen : -1; d_key[4 * t + 1] = j.tlen; d_key[4 * t + 2] = j.init_score; d_key[4 * t + 3] = j.W; }));
+		std::vector<int32_t> key4((size_t)m * 4); CHK(dev_d2h(key4.data(), d_key, (size_t)m * 16)); dev_free(d_key);
+		std::vector<int32_t> key(m);
+		for(uint32_t i = 0; i < m; i++){ key[i] = key4[(size_t)i * 4]; if(key[i] > 0){ ext_sum += (unsigned long long)key[i]; if(key[i] > ext_max) ext_max = key[i]; } }
+		for(uint32_t i = 0; i < m; i++) ord[i] = i;
 		std::stable_sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t b){ return key[a] > key[b]; });
 		CHK(dev_alloc((void**)&d_order, (size_t)m * 4)); CHK(dev_h2d(d_order, ord.data(), (size_t)m * 4));
 		const int mw_top = c->env_mw_top;
 		if(mw_min > 0) while(n_mw < m && n_mw < (uint32_t)mw_top && key[ord[n_mw]] >= mw_min) n_mw++;          /* the long jobs head the order: four waves each */
+		for(uint32_t i = 0; i < m; i++){
+			const int32_t qlen = key4[(size_t)i * 4], tlen = key4[(size_t)i * 4 + 1];
+			need[i] = 0;
+			if(qlen <= 0 || tlen <= 0) continue;
+			int32_t init = key4[(size_t)i * 4 + 2] < 0 ? 0 : key4[(size_t)i * 4 + 2], W = key4[(size_t)i * 4 + 3], ql, tl, n_col;
+			wtz_ext_geometry(qlen, tlen, init, W, c->P.M, c->P.O, c->P.O, c->P.E, c->P.T, ql, tl, n_col);
+			/* rows come 64 at a time; a row of the trace is the widest of the three wave forms: one-wave register kernel (4-column steps),
+			 * four-wave kernel (256 lanes), LDS-ring kernel (odd columns per lane) */
+			const uint64_t c_reg = ((uint64_t)(n_col + 63) / 64 + 3) / 4, c_mw = ((uint64_t)(n_col + 255) / 256 + 3) / 4 * 4, c_gen = ((((uint64_t)(n_col + 63) / 64) | 1) + 3) / 4;
+			uint64_t zrow = (c_reg > c_gen ? c_reg : c_gen) * 256; if(c_mw * 256 > zrow) zrow = c_mw * 256;
+			uint64_t nb = ((uint64_t)(ql + 63) / 64) * 64 * zrow + (uint64_t)WTZ_TRACE_MAXCHUNK * 8 + (uint64_t)(ql + 2) * 4 + 256;
+			if((n_col + 63) / 64 > 32 || (tl + 63) / 32 + 1 > 1032){      /* outside the wave forms: the scalar body's row arrays and byte matrix, grown in powers of two */
+				uint64_t z = 1024; while(z < (uint64_t)ql * (uint64_t)n_col) z <<= 1;
+				uint64_t r = 64; while(r < (uint64_t)tl + 3) r <<= 1;
+				uint64_t zb = 64; while(zb < (uint64_t)ql + 2) zb <<= 1;
+				nb = z + 8 * r + 4 * zb + 256;
+			}
+			need[i] = nb;
+		}
 	}
 	{
 		wtz_timer te; te.start();
 		const int use_reg = c->env_use_reg;
-		if(use_reg){
-			if(n_mw){
-				/* long jobs on a side stream, concurrently with the one-wave kernel over the rest */
-				HIPCHK(hipEventRecord(c->ev_mw_fork, g_stream)); HIPCHK(hipStreamWaitEvent(c->stream_mw, c->ev_mw_fork, 0));
-				hipLaunchKernelGGL((wtz_kernel_extjobs_mw<1032>), dim3(n_mw), dim3(256), 0, c->stream_mw, d_jobs, (const uint32_t*)d_order, n_mw, V.P, V.pool);
-				HIPCHK(hipGetLastError());
-				HIPCHK(hipEventRecord(c->ev_mw_join, c->stream_mw));
+		/* launch groups: consecutive jobs of the order whose trace upper bounds fit the transient pool together; the pool is reset
+		 * between groups (the CIGARs went to the main pool).  One group is the normal case. */
+		const uint64_t budget = (c->pool_bytes - c->main_bytes) / 16 * 15;
+		uint32_t g0 = 0, n_groups = 0;
+		while(g0 < m){
+			uint32_t g1 = g0; uint64_t acc = 0;
+			while(g1 < m && (g1 == g0 || acc + need[ord[g1]] <= budget)){ acc += need[ord[g1]]; g1++; }
+			CHK(tpool_reset(c));      /* the traces of the previous group / the previous stage are dead: their CIGARs are in the main pool */
+			const uint32_t mw0 = g0 < n_mw ? g0 : n_mw, mw1 = g1 < n_mw ? g1 : n_mw;       /* four-wave jobs of the group: order[mw0, mw1) */
+			const uint32_t r0 = g0 > n_mw ? g0 : n_mw, r1 = g1 > n_mw ? g1 : n_mw;         /* one-wave jobs: order[r0, r1) */
+			if(use_reg){
+				if(mw1 > mw0){
+					/* long jobs on a side stream, concurrently with the one-wave kernel over the rest */
+					HIPCHK(hipEventRecord(c->ev_mw_fork, g_stream)); HIPCHK(hipStreamWaitEvent(c->stream_mw, c->ev_mw_fork, 0));
+					hipLaunchKernelGGL((wtz_kernel_extjobs_mw<1032>), dim3(mw1 - mw0), dim3(256), 0, c->stream_mw, d_jobs, (const uint32_t*)d_order + mw0, mw1 - mw0, V.P, V.pool, V.pool + 1);
+					HIPCHK(hipGetLastError());
+					HIPCHK(hipEventRecord(c->ev_mw_join, c->stream_mw));
+				}
+				if(r1 > r0){
+					hipLaunchKernelGGL((wtz_kernel_extjobs_reg<1032>), dim3(r1 - r0), dim3(64), 0, g_stream, d_jobs, (const uint32_t*)d_order + r0, r1 - r0, V.P, V.pool, V.pool + 1);
+					HIPCHK(hipGetLastError());
+				}
+				if(mw1 > mw0) HIPCHK(hipStreamWaitEvent(g_stream, c->ev_mw_join, 0));
 			}
-			if(m > n_mw){
-				hipLaunchKernelGGL((wtz_kernel_extjobs_reg<1032>), dim3(m - n_mw), dim3(64), 0, g_stream, d_jobs, (const uint32_t*)d_order + n_mw, m - n_mw, V.P, V.pool);
-				HIPCHK(hipGetLastError());
-			}
-			if(n_mw) HIPCHK(hipStreamWaitEvent(g_stream, c->ev_mw_join, 0));
+			hipLaunchKernelGGL((wtz_kernel_extjobs<2048, 1032>), dim3(g1 - g0), dim3(64), 0, g_stream, d_jobs, (const uint32_t*)d_order + g0, g1 - g0, V.P, V.pool, V.pool + 1);     /* whatever the register DP left */
+			HIPCHK(hipGetLastError());
+			if(g1 < m || n_groups){ CHK(dev_sync()); CHK(tpool_check(c, "K-sw3 extension jobs")); }
+			g0 = g1; n_groups++;
 		}
-		hipLaunchKernelGGL((wtz_kernel_extjobs<2048, 1032>), dim3(m), dim3(64), 0, g_stream, d_jobs, (const uint32_t*)d_order, m, V.P, V.pool);     /* whatever the register DP left */
-		HIPCHK(hipGetLastError());
 		const double ms_l = te.stop();
+		CHK(tpool_check(c, "K-sw3 extension jobs"));
 		c->cnt.ms_ext += ms_l; c->cnt.n_extjobs += m;
 		if(c->env_profile){
 			std::vector<int32_t> key(m); uint32_t nv = 0, n256 = 0, n512 = 0, n1k = 0, n2k = 0, n4k = 0; unsigned long long s512 = 0;
 			CHK(dev_sync());
 			{ std::vector<wtz_extjob_t> jj(m); CHK(dev_d2h(jj.data(), d_jobs, (size_t)m * sizeof(wtz_extjob_t))); uint32_t nd[4] = {0, 0, 0, 0}; for(uint32_t i = 0; i < m; i++){ key[i] = jj[i].valid ? jj[i].x.qe : -1; if(jj[i].valid) nd[jj[i].done & 3]++; }
-			  fprintf(stderr, "[ext-profile] n_mw %u; valid jobs finished by: nobody %u, one-wave %u, four-wave %u, general %u\n", n_mw, nd[0], nd[1], nd[2], nd[3]); }
+			  fprintf(stderr, "[ext-profile] n_mw %u; %u launch group(s); valid jobs finished by: nobody %u, one-wave %u, four-wave %u, general %u\n", n_mw, n_groups, nd[0], nd[1], nd[2], nd[3]); }
 			for(uint32_t i = 0; i < m; i++){ if(key[i] < 0) continue; nv++; if(key[i] >= 256) n256++; if(key[i] >= 512){ n512++; s512 += key[i]; } if(key[i] >= 1024) n1k++; if(key[i] >= 2048) n2k++; if(key[i] >= 4096) n4k++; }
-			fprintf(stderr, "[ext-profile] %u jobs (%u valid), rows (upper bound) sum %llu max %d, %.2f ms; qe>=256 %u >=512 %u (sum %llu) >=1k %u >=2k %u >=4k %u\n", m, nv, ext_sum, ext_max, te.stop() + ms_l * 0, n256, n512, s512, n1k, n2k, n4k);
+			fprintf(stderr, "[ext-profile] %u jobs (%u valid), rows (upper bound) sum %llu max %d, %.2f ms; qe>=256 %u >=512 %u (sum %llu) >=1k %u >=2k %u >=4k %u; transient pool peak %.2f GB\n", m, nv, ext_sum, ext_max, ms_l, n256, n512, s512, n1k, n2k, n4k, c->tpool_peak_call / 1073741824.0);
 		}
 		dev_free(d_order);
 	}
@@ -818,6 +929,7 @@ extern "C" int wtz_pairs_align(wtz_ctx_t *c, const uint32_t *pair_idx, const uin
 		/* first launch: the lean form (register DP with one / two band columns per lane, no scalar body: fewer VGPRs, no spills at three
 		 * waves per SIMD); the few windows with a problem outside it queue themselves and are redone by the full task */
 		uint32_t *d_defer = NULL; CHK(dev_alloc((void**)&d_defer, (wt.size() + 1) * 4)); CHK(dev_set(d_defer, 0, 4));
+		STAGE(c, "K_winalign");
 		CHK(wtz_launch_coop<K_winalign>(0, wt.size(), [=] WTZ_LAMBDA (uint64_t t){ wtz_task_winalign<false>((uint32_t)t, V, d_wt, d_items, d_defer, NULL); }, WTZ_WINALIGN_LDS_BYTES));
 		uint32_t n_def = 0; CHK(dev_d2h(&n_def, d_defer, 4));
 		if(n_def) CHK(wtz_launch_coop<K_winalign_big>(0, n_def, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_winalign<true>((uint32_t)t, V, d_wt, d_items, NULL, d_defer); }, WTZ_WINALIGN_LDS_BYTES));
@@ -835,6 +947,7 @@ extern "C" int wtz_pairs_align(wtz_ctx_t *c, const uint32_t *pair_idx, const uin
 		CHK(dev_alloc((void**)&d_jl, (size_t)m * sizeof(wtz_extjob_t))); CHK(dev_alloc((void**)&d_jr, (size_t)m * sizeof(wtz_extjob_t)));
 		wtz_gapres_t *d_gaps = NULL; CHK(dev_alloc((void**)&d_gaps, (size_t)(nreg + 1) * sizeof(wtz_gapres_t)));
 		const uint64_t nwt = wt.size();
+		STAGE(c, "K_stitch_left");
 		CHK(wtz_launch_wave<K_stitch_left>(0, m, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_stitch_left((uint32_t)t, V, d_items, d_st, d_jl); }));
 #ifdef WTZ_EMUL
 		CHK(wtz_launch_coop<K_gap>(0, nwt, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_gap((uint32_t)t, V, d_wt, d_items, d_gaps); }, WTZ_GAP_LDS_BYTES));
@@ -849,6 +962,7 @@ extern "C" int wtz_pairs_align(wtz_ctx_t *c, const uint32_t *pair_idx, const uin
 			hipStream_t main_stream = g_stream;
 			if(gap_side){ HIPCHK(hipEventRecord(c->ev_gap_fork, main_stream)); HIPCHK(hipStreamWaitEvent(c->stream_gap, c->ev_gap_fork, 0)); g_stream = c->stream_gap; }
 			uint32_t *d_defer = NULL; CHK(dev_alloc((void**)&d_defer, (size_t)(nwt + 1) * 4)); CHK(dev_set(d_defer, 0, 4));
+			STAGE(c, "K_gap");
 			int rc_gap = wtz_launch_coop<K_gap>(0, nwt, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_gap((uint32_t)t, V, d_wt, d_items, d_gaps, d_defer, NULL, 0u); }, WTZ_GAP_LDS_BYTES);
 			if(rc_gap == WTZ_OK){
 				/* gaps whose band outgrew the register forms (repeats): the LDS-ring wave DP with 8192-column rings, 72 KB of LDS per wave */
@@ -859,13 +973,18 @@ extern "C" int wtz_pairs_align(wtz_ctx_t *c, const uint32_t *pair_idx, const uin
 			g_stream = main_stream;
 			CHK(rc_gap);
 			if(gap_side) HIPCHK(hipEventRecord(c->ev_gap_join, c->stream_gap));
+			STAGE(c, "extjobs left");
 			CHK(run_extjobs(c, V, d_jl, m));
 			if(gap_side) HIPCHK(hipStreamWaitEvent(main_stream, c->ev_gap_join, 0));
 		}
 #endif
+		STAGE(c, "K_stitch_mid");
 		CHK(wtz_launch_coop<K_stitch_mid>(0, m, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_stitch_mid((uint32_t)t, V, d_items, d_st, d_jl, d_jr, d_gaps); }));
+		STAGE(c, "extjobs right");
 		CHK(run_extjobs(c, V, d_jr, m));
+		STAGE(c, "K_stitch_fin");
 		CHK(wtz_launch_coop<K_stitch_fin>(0, m, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_stitch_fin((uint32_t)t, V, d_items, d_st, d_jl, d_jr, d_res); }));
+		if(c->P.refine) STAGE(c, "K_refine");
 		if(c->P.refine) CHK(wtz_launch_coop<K_refine>(0, m, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_refine((uint32_t)t, V, d_items, d_res); }, WTZ_REFINE_LDS_BYTES));
 		CHK(dev_sync());
 		dev_free(d_st); dev_free(d_jl); dev_free(d_jr); dev_free(d_gaps);
@@ -924,6 +1043,7 @@ extern "C" int wtz_fetch_cigar_text(wtz_ctx_t *c, char *dst, uint64_t n_bytes){
 	CHK(dev_alloc((void**)&d_off, off.size() * 8)); CHK(dev_h2d(d_off, off.data(), off.size() * 8));
 	CHK(dev_alloc((void**)&d_t, (size_t)tot + 16));
 	const wtz_alnres_dev_t *dr = c->d_alnres;
+	STAGE(c, "K_cigar_text");
 	CHK(wtz_launch_coop<K_cigar_text>(0, c->n_items, [=] WTZ_LAMBDA (uint64_t t){ const wtz_alnres_dev_t &r = dr[t]; if(r.text_len) wtz_cigar_text_write_coop(r.cigar, r.cigar_len, d_t + d_off[t]); }));
 	CHK(dev_sync());
 	CHK(dev_d2h(dst, d_t, (size_t)tot));
@@ -949,6 +1069,12 @@ extern "C" void wtz_host_free(void *p){
 #else
 	(void)hipHostFree(p);
 #endif
+}
+
+extern "C" int wtz_pool_info(wtz_ctx_t *c, wtz_pool_info_t *out){
+	if(!c || !out) return wtz_fail(WTZ_E_ARG, "null argument");
+	out->main_cap = c->main_bytes; out->main_used = c->main_used_call; out->transient_cap = c->pool_bytes - c->main_bytes; out->transient_peak = c->tpool_peak_call;
+	return WTZ_OK;
 }
 
 extern "C" int wtz_get_counters(wtz_ctx_t *c, wtz_counters_t *out){

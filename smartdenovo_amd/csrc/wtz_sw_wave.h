@@ -783,7 +783,7 @@ WTZ_D wtz_aln_t wtz_extend_shift_reg(int32_t qlen, const wtz_seq_packed &query, 
 
 /* ---- K-sw3 jobs: one wave (64 threads) per job; jobs that do not fit the LDS rings run the scalar body on lane 0 ---- */
 template<int P, int TW>
-__global__ void __launch_bounds__(64) wtz_kernel_extjobs(wtz_extjob_t *jobs, const uint32_t *order, uint32_t n, const wtz_params_t *Pm, wtz_pool_t *pool){
+__global__ void __launch_bounds__(64) wtz_kernel_extjobs(wtz_extjob_t *jobs, const uint32_t *order, uint32_t n, const wtz_params_t *Pm, wtz_pool_t *pool, wtz_pool_t *tpool){
 	__shared__ int32_t sHs[P]; __shared__ int32_t sEs[P]; __shared__ uint64_t stb[TW];
 	const uint32_t b = blockIdx.x;
 	if(b >= n) return;
@@ -804,12 +804,12 @@ __global__ void __launch_bounds__(64) wtz_kernel_extjobs(wtz_extjob_t *jobs, con
 		unsigned long long cells = 0; bool ok = true;
 		const int32_t Cw = (((n_col + 63) / 64) | 1);
 		wtz_aln_t x;
-		if(Cw <= 8)       x = wtz_extend_shift_wave_rt<8>(job->qlen, job->q, job->tlen, job->t, job->init_score, job->W, Pm->M, Pm->X, Pm->O, Pm->O, Pm->E, Pm->T, L, tr, pool, cg, &cells, &ok);
-		else if(Cw <= 16) x = wtz_extend_shift_wave_rt<16>(job->qlen, job->q, job->tlen, job->t, job->init_score, job->W, Pm->M, Pm->X, Pm->O, Pm->O, Pm->E, Pm->T, L, tr, pool, cg, &cells, &ok);
-		else              x = wtz_extend_shift_wave_rt<32>(job->qlen, job->q, job->tlen, job->t, job->init_score, job->W, Pm->M, Pm->X, Pm->O, Pm->O, Pm->E, Pm->T, L, tr, pool, cg, &cells, &ok);
+		if(Cw <= 8)       x = wtz_extend_shift_wave_rt<8>(job->qlen, job->q, job->tlen, job->t, job->init_score, job->W, Pm->M, Pm->X, Pm->O, Pm->O, Pm->E, Pm->T, L, tr, tpool, cg, &cells, &ok);
+		else if(Cw <= 16) x = wtz_extend_shift_wave_rt<16>(job->qlen, job->q, job->tlen, job->t, job->init_score, job->W, Pm->M, Pm->X, Pm->O, Pm->O, Pm->E, Pm->T, L, tr, tpool, cg, &cells, &ok);
+		else              x = wtz_extend_shift_wave_rt<32>(job->qlen, job->q, job->tlen, job->t, job->init_score, job->W, Pm->M, Pm->X, Pm->O, Pm->O, Pm->E, Pm->T, L, tr, tpool, cg, &cells, &ok);
 		if(lane == 0){ job->x = x; job->cigar = cg.a; job->cigar_len = cg.n; job->bad = (!ok || cg.bad); job->cells = cells; job->done = 3; }
 	} else if(lane == 0){
-		wtz_swmem_t mem; wtz_swmem_init(mem, pool);
+		wtz_swmem_t mem; wtz_swmem_init(mem, tpool);
 		wtz_cigar_t cg; cg.init(pool, 64);
 		unsigned long long cells = 0;
 		wtz_aln_t x = wtz_extend_shift(job->qlen, job->q, job->tlen, job->t, job->init_score, job->W, Pm->M, Pm->X, Pm->O, Pm->O, Pm->E, Pm->T, mem, cg, &cells);
@@ -820,7 +820,7 @@ __global__ void __launch_bounds__(64) wtz_kernel_extjobs(wtz_extjob_t *jobs, con
 /* K-sw3 jobs through the register DP: LDS carries only the 2-bit target.  Jobs outside its envelope (band wider than
  * 64*32 columns, target longer than the LDS words, scores beyond the packed-key range) are left for wtz_kernel_extjobs. */
 template<int TW>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WTZ_OCC_EXTREG, 8))) wtz_kernel_extjobs_reg(wtz_extjob_t *jobs, const uint32_t *order, uint32_t n, const wtz_params_t *Pm, wtz_pool_t *pool){
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WTZ_OCC_EXTREG, 8))) wtz_kernel_extjobs_reg(wtz_extjob_t *jobs, const uint32_t *order, uint32_t n, const wtz_params_t *Pm, wtz_pool_t *pool, wtz_pool_t *tpool){
 	__shared__ uint64_t stb[TW];
 	const uint32_t b = blockIdx.x;
 	if(b >= n) return;
@@ -840,7 +840,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WTZ_OCC
 	if(lane == 0) cg.init(pool, 64);
 	unsigned long long cells = 0; bool ok = true;
 	wtz_aln_t x;
-#define WTZ_EXTREG_CASE(CM) x = wtz_extend_shift_reg<CM>(job->qlen, job->q, job->tlen, job->t, job->init_score, ql, tl, W, Pm->M, Pm->X, Pm->O, Pm->O, Pm->E, Pm->T, stb, tr, pool, cg, &cells, &ok)
+#define WTZ_EXTREG_CASE(CM) x = wtz_extend_shift_reg<CM>(job->qlen, job->q, job->tlen, job->t, job->init_score, ql, tl, W, Pm->M, Pm->X, Pm->O, Pm->O, Pm->E, Pm->T, stb, tr, tpool, cg, &cells, &ok)
 	if(Cw <= 4) WTZ_EXTREG_CASE(4);
 	else if(Cw <= 8) WTZ_EXTREG_CASE(8);
 	else if(Cw <= 12) WTZ_EXTREG_CASE(12);
@@ -1160,7 +1160,7 @@ WTZ_D wtz_aln_t wtz_extend_shift_mw(int32_t qlen, const wtz_seq_packed &query, i
 
 /* K-sw3 jobs on four waves each (the long ones: `order` lists them).  Jobs outside the envelope stay !done for wtz_kernel_extjobs. */
 template<int TW>
-__global__ void __launch_bounds__(256) wtz_kernel_extjobs_mw(wtz_extjob_t *jobs, const uint32_t *order, uint32_t n, const wtz_params_t *Pm, wtz_pool_t *pool){
+__global__ void __launch_bounds__(256) wtz_kernel_extjobs_mw(wtz_extjob_t *jobs, const uint32_t *order, uint32_t n, const wtz_params_t *Pm, wtz_pool_t *pool, wtz_pool_t *tpool){
 	__shared__ uint64_t stb[TW]; __shared__ wtz_mw_shared_t shm;
 	const uint32_t b = blockIdx.x;
 	if(b >= n) return;
@@ -1178,7 +1178,7 @@ __global__ void __launch_bounds__(256) wtz_kernel_extjobs_mw(wtz_extjob_t *jobs,
 	if(tid == 0) cg.init(pool, 64);
 	unsigned long long cells = 0; bool ok = true;
 	wtz_aln_t x;
-#define WTZ_EXTMW_CASE(CM) x = wtz_extend_shift_mw<CM, 4>(job->qlen, job->q, job->tlen, job->t, job->init_score, ql, tl, W, Pm->M, Pm->X, Pm->O, Pm->O, Pm->E, Pm->T, stb, &shm, pool, cg, &cells, &ok)
+#define WTZ_EXTMW_CASE(CM) x = wtz_extend_shift_mw<CM, 4>(job->qlen, job->q, job->tlen, job->t, job->init_score, ql, tl, W, Pm->M, Pm->X, Pm->O, Pm->O, Pm->E, Pm->T, stb, &shm, tpool, cg, &cells, &ok)
 	if(Cw <= 2) WTZ_EXTMW_CASE(2);
 	else if(Cw <= 4) WTZ_EXTMW_CASE(4);
 	else if(Cw <= 7) WTZ_EXTMW_CASE(7);

@@ -35,6 +35,16 @@ WTZ_D int32_t *wtz_wave_scratch(){ extern __shared__ int32_t wtz_dyn_lds[]; retu
 WTZ_COOP_HOST int32_t *wtz_wave_scratch(){ return NULL; }
 #endif
 
+/* -DWTZ_DEBUG_CRUMBS: every pair task leaves its last reached point in a host-visible array, so that a hung or faulting K_pair launch
+ * can be located from the host (WTZ_DEBUG_CRUMBS=1 makes wtz_pairs_seed poll instead of waiting and report the stragglers) */
+#if defined(WTZ_DEBUG_CRUMBS) && defined(__HIPCC__)
+__device__ unsigned int *wtz_crumbs = NULL;
+#endif
+#if defined(WTZ_DEBUG_CRUMBS) && defined(__HIP_DEVICE_COMPILE__)
+#define WTZ_CRUMB(t, code) do { if(wtz_crumbs && WTZ_LANE == 0) __hip_atomic_store(&wtz_crumbs[t], (unsigned int)(code), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); } while(0)
+#else
+#define WTZ_CRUMB(t, code) do { } while(0)
+#endif
 /* all lanes of the wavefront enter; the z-mer matching is cooperative, the order-sensitive remainder runs on lane 0 */
 WTZ_HD void wtz_task_pair(uint32_t t, const wtz_env_t &V, const uint32_t *qid, const uint32_t *cid, wtz_pairres_t *res){
 	const wtz_params_t *P = V.P;
@@ -47,8 +57,10 @@ WTZ_HD void wtz_task_pair(uint32_t t, const wtz_env_t &V, const uint32_t *qid, c
 #define WTZ_TICK() ((uint64_t)0)
 #endif
 	const uint64_t tk0 = WTZ_TICK();
+	WTZ_CRUMB(t, 1);
 	const bool ok = wtz_zmatch_coop(V.Z, q, c, V.R.rdlen[c], P->max_kmer_var, V.pool, &hits, &n);
 	const uint64_t tk1 = WTZ_TICK();
+	WTZ_CRUMB(t, 2 | (n << 8));
 	wtz_zhit_t *sorted = NULL;
 #if defined(__HIP_DEVICE_COMPILE__)
 	__threadfence_block();
@@ -60,9 +72,10 @@ WTZ_HD void wtz_task_pair(uint32_t t, const wtz_env_t &V, const uint32_t *qid, c
 	}
 #endif
 	const uint32_t lane = WTZ_LANE;
-	if(!ok || r.bad){ r.bad = 1; if(lane == 0) res[t] = r; return; }
+	WTZ_CRUMB(t, 3 | (n << 8));
+	if(!ok || r.bad){ r.bad = 1; if(lane == 0) res[t] = r; WTZ_CRUMB(t, 0xFF); return; }
 	r.n_hits = n;
-	if(n * P->zsize < P->ztot){ r.gate = 0; if(lane == 0) res[t] = r; return; }
+	if(n * P->zsize < P->ztot){ r.gate = 0; if(lane == 0) res[t] = r; WTZ_CRUMB(t, 0xFF); return; }
 	r.gate = 1;
 	if(P->dot_matrix){
 		wtz_vec<wtz_zhit_t> cache; cache.a = sorted ? sorted : hits; cache.n = n; cache.cap = n + 2; cache.pool = V.pool; cache.bad = 0;
@@ -83,7 +96,8 @@ WTZ_HD void wtz_task_pair(uint32_t t, const wtz_env_t &V, const uint32_t *qid, c
 	}
 	/* zmo: every lane follows the window merge (uniform control flow); the vectors belong to lane 0 */
 	if(sorted) hits = sorted;                                                             /* tie-free: the unique ascending order */
-	else { if(lane == 0) wtz_sort_exact(hits, (size_t)n, wtz_gt_off12()); WTZ_WAVE_SYNC(); }   /* process_hzmps, hzm_aln.h:1184-1186, swap-exact */
+	else { WTZ_CRUMB(t, 4 | (n << 8)); if(lane == 0) wtz_sort_exact(hits, (size_t)n, wtz_gt_off12()); WTZ_WAVE_SYNC(); }   /* process_hzmps, hzm_aln.h:1184-1186, swap-exact */
+	WTZ_CRUMB(t, 5 | (n << 8));
 	const uint64_t tk2 = WTZ_TICK();
 	wtz_winscratch_t sc;
 	{
@@ -92,7 +106,7 @@ WTZ_HD void wtz_task_pair(uint32_t t, const wtz_env_t &V, const uint32_t *qid, c
 		pa = wtz_coop_bcast64(pa);
 		sc.ts = (uint32_t*)(uintptr_t)pa;
 	}
-	if(sc.ts == NULL){ r.bad = 1; if(lane == 0) res[t] = r; return; }
+	if(sc.ts == NULL){ r.bad = 1; if(lane == 0) res[t] = r; WTZ_CRUMB(t, 0xFF); return; }
 	sc.as = (int32_t*)(sc.ts + (n + 2)); sc.wb = sc.ts + 2 * (n + 2); sc.we = sc.ts + 3 * (n + 2); sc.wo = sc.ts + 4 * (n + 2);
 	sc.tk = (uint64_t*)(sc.ts + 5 * (n + 2) + ((5 * (n + 2)) & 1)); sc.ztmp = (wtz_zhit_t*)(sc.tk + (n + 2));
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -107,8 +121,10 @@ WTZ_HD void wtz_task_pair(uint32_t t, const wtz_env_t &V, const uint32_t *qid, c
 		wins.a = NULL; wins.n = wins.cap = 0; wins.pool = V.pool; wins.bad = 0;
 		anchors.a = NULL; anchors.n = anchors.cap = 0; anchors.pool = V.pool; anchors.bad = 0;
 		if(lane == 0){ wins.init(V.pool, 16); anchors.init(V.pool, n + 16); }
+		WTZ_CRUMB(t, (6 + dir) | (n << 8));
 		const uint32_t nw = wtz_merge_windows_coop(hits, n, dir, wins, anchors, sc, P->zsize, P->kwin, P->kstep, P->zovl);
 		if(lane != 0) continue;
+		WTZ_CRUMB(t, (8 + dir) | (n << 8));
 		if(wins.bad || anchors.bad){ r.bad = 1; continue; }
 		if(nw == 0) continue;
 		int32_t *mem = (int32_t*)wtz_pool_alloc(V.pool, (size_t)wins.n * 8 + 8);
@@ -123,6 +139,7 @@ WTZ_HD void wtz_task_pair(uint32_t t, const wtz_env_t &V, const uint32_t *qid, c
 	if(lane != 0) return;
 	{ const uint64_t tk3 = WTZ_TICK(); r.tick[0] = (uint32_t)((tk1 - tk0) >> 10); r.tick[1] = (uint32_t)((tk2 - tk1) >> 10); r.tick[2] = (uint32_t)((tk3 - tk2) >> 10); r.tick[3] = (uint32_t)((tk3 - tk0) >> 10); }
 	res[t] = r;
+	WTZ_CRUMB(t, 0xFF);
 }
 
 /* dmo pairs whose strand images did not fit the LDS slice of K_pair: same alignment over the already ordered matches, launched

@@ -325,10 +325,10 @@ WTZ_HD uint32_t wtz_scan_windows(const wtz_zhit_t *rs, uint32_t dir, uint32_t be
 		} else if(ret && (w.end[1] <= (int32_t)((uint32_t)wins.a[wins.n - 1].end[1] + kwin / 3) && ol <= wins.a[wins.n - 1].ovl)){
 			anchors.n = size;
 		} else {
-			ret++;
 			w.ovl = WTZ_OVL29(ol);
 			w.anchors[1] = anchors.n;
-			if(!wins.push(w)) return ret;
+			if(!wins.push(w)) return ret;        /* pool exhausted: only windows that ARE in the vector are counted (callers index wins.a[wins.n - ret ...]) */
+			ret++;
 		}
 	}
 	return ret;
@@ -548,11 +548,11 @@ WTZ_HD uint32_t wtz_scan_windows_coop(const wtz_zhit_t *rs, uint32_t dir, uint32
 			}
 			if(ol * 2 < zovl) continue;
 			if(ret && (w.end[1] <= (int32_t)((uint32_t)last_end1 + kwin / 3) && ol <= last_ovl)) continue;
-			ret++;
 			anchors.n = size + cnt;
 			w.ovl = WTZ_OVL29(ol);
 			w.anchors[1] = anchors.n;
-			if(!wins.push(w)) break;
+			if(!wins.push(w)) break;             /* pool exhausted: count only what is in the vector */
+			ret++;
 			last_end1 = w.end[1]; last_ovl = w.ovl;
 			if(me0 < w.end[0]) me0 = w.end[0];
 		}

@@ -67,7 +67,7 @@ def test_scratch_pool_exhaustion_splits_the_batch(emul_exe, tmp_path):
     is unchanged.  (A task that ran out of scratch once used to go on with a NULL row buffer: wtz_swmem_need is sticky now.)"""
     case = manifest()["cases"]["zmo"]
     out = os.path.join(str(tmp_path), "o.ovl")
-    r = subprocess.run([emul_exe, "-i", os.path.join(ROOT, "tests", "golden", case["input"]), "-fo", out, "--pool-mb", "96"] + case["argv"], capture_output=True)
+    r = subprocess.run([emul_exe, "-i", os.path.join(ROOT, "tests", "golden", case["input"]), "-fo", out, "--pool-mb", "192"] + case["argv"], capture_output=True)
     assert r.returncode == 0, r.stderr.decode()[-2000:]
     assert b"splitting the batch" in r.stderr
     import hashlib
