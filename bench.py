@@ -1,22 +1,28 @@
 #!/usr/bin/env python3
 """bench.py — headline metric of BASELINE.json: Gbp of candidate pairs aligned per second (wtzmo all-vs-all).
 
-One "step" = one complete overlap phase of the drop-in wtzmo (k-mer index + z-mer index build, candidate search,
-pair seeding / windows / chaining, banded SW, in-order commit, .ovl writing) over the synthetic E. coli-shape read set
-(4.6 Mbp genome, 25x, mean 10 kb, 15 % error: BASELINE.json configs[1]) with the 2-bit reads ALREADY RESIDENT IN HBM.
-The host driver runs in-process (libwtzmo_host.so = the C `wtzmo` main built as a shared object) so that exactly K
-steps are bracketed by barrier + torch.cuda.synchronize() on both sides.
+One "step" = one complete overlap phase of the drop-in wtzmo (z-mer index + k-mer index build, candidate search, pair seeding /
+windows / chaining, banded SW, in-order commit, .ovl writing) over the synthetic read set of BASELINE.json configs[2] - the
+configuration the metric is quoted on: 1.2 Gbp of PacBio-shape reads (12 Mbp iid genome x100, lognormal mean 10 kb, 15 % error,
+seed 29) with the 2-bit reads and both indexes RESIDENT IN HBM of one MI355X (`--workload ecoli` = configs[1], 115 Mbp).  The output of
+exactly this input is pinned to the reference: tests/test_gpu_scale.py compares its md5 with `wtzmo -t 1` (tests/golden/big_manifest.json).
+The host driver runs in-process (libwtzmo_host.so = the C `wtzmo` main built as a shared object) so that exactly K steps are
+bracketed by barrier + torch.cuda.synchronize() on both sides.
 
-N > 1: one process per GPU (torchrun), the query set is sharded by the reference's own job striping (-P N -p rank,
-wtzmo.c:1291,1314) with reads + index replicated in every GPU's HBM, no data-path collective; the overlap records are
-gathered on rank 0 with RCCL (all_gather over xGMI) inside the timed region.  Total work is fixed -> "strong" scaling.
+N > 1: one process per GPU (torchrun); the reads and both indexes are replicated in every GPU's HBM and the query set is sharded by
+the reference's own job striping (-P N -p rank, wtzmo.c:1291,1314), no data-path collective; the overlap records are gathered on rank 0
+with RCCL inside the timed region.  Each stripe does the work of `wtzmo -P N -p rank`, whose union is MORE pair alignments than the
+single job's (no cross-stripe masking: SURVEY 8e), so the numerator is counted per rank and summed, and "scaling" says "weak":
+per-GPU work is whatever the stripe needs, not 1/N of the single job.
 
 numerator  = sum over ranks and timed steps of (len(a)+len(b)) over pairs that entered pair alignment
 value      = numerator / wall seconds of the K timed steps (max over ranks) / 1e9
-roofline   = K-sw3 (shifting-band extension, the dominant DP stage; two concurrent kernels): DP cell updates exactly as
-             the reference loops execute them x 12 int32 ops per cell / HIP-event time of the stage, against the int32 VALU peak
-roofline_seed = seed lookup: algorithmic bytes (L/4 + 16 B per probe + 4 B per seed entry) / kernel time vs 8 TB/s
-cpu_baseline  = the REAL reference `wtzmo -t <all cores>` (oracle/_ref, prebuilt) or the oracle port on a bounded sample
+roofline      = K-sw3 (shifting-band extension, the dominant DP stage; two concurrent kernels): DP cells exactly as the reference loops
+                execute them x 12 int32 ops per cell / HIP-event time of the stage launches, against the int32 VALU peak
+roofline_sw1  = K-sw1 (fixed-band extension between anchors, K_winalign), roofline_sw2 = K-sw2 (global banded, K_gap): same pricing
+roofline_seed = seed lookup (K_candidates): algorithmic bytes (L/4 + 16 B per probe + 4 B per seed entry) / kernel time vs 8 TB/s
+cpu_baseline  = the REAL reference `wtzmo -t <cores>` (oracle/_ref, prebuilt) on a bounded sample of the same workload shape (same
+                coverage, smaller genome), its overlap phase timed like the GPU's (from "calculating overlaps" to exit; FASTA load excluded)
 """
 from __future__ import annotations
 
@@ -37,6 +43,13 @@ DMO = ["-k", "16", "-z", "10", "-Z", "16", "-U", "-1", "-m", "0.1", "-A", "1000"
 INT32_VALU_PEAK_TOPS = 256 * 4 * 32 * 2.4e9 / 1e12      # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz = 78.6 Tint32op/s
 HBM_PEAK_GBS = 8000.0
 OPS_PER_CELL = 12                                        # SURVEY 8d nominal op count of one DP cell update
+# seeds / sizes are those of tests/golden/big_manifest.json, so the md5 parity of exactly these inputs is a driver-run test
+WORKLOADS = {
+    "yeast100": dict(genome=12000000, coverage=100.0, seed=29, cpu_genome=600000,
+                     name="BASELINE configs[2]: 1.2 Gbp of synthetic PacBio-shape reads (12 Mbp iid genome x100)"),
+    "ecoli": dict(genome=4600000, coverage=25.0, seed=11, cpu_genome=2300000,
+                  name="BASELINE configs[1]: E. coli-shape synthetic PacBio reads (4.6 Mbp iid genome x25)"),
+}
 
 
 def gen_reads(path, genome, coverage, seed):
@@ -70,17 +83,24 @@ def cpu_baseline(engine_argv, genome, coverage, seed, tmp):
     out = os.path.join(tmp, "cpu.ovl")
     if os.path.exists(ref):
         pairs = os.path.join(tmp, "cpu.pairs")
-        t0 = time.time()
-        subprocess.run([ref, "-t", str(ncpu), "-i", fa, "-fo", out, "-9", pairs] + engine_argv, check=True,
-                       stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-        dt = time.time() - t0
+        t0 = time.perf_counter()
+        pr = subprocess.Popen([ref, "-t", str(ncpu), "-i", fa, "-fo", out, "-9", pairs] + engine_argv, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+        t_ovl = None
+        for line in pr.stderr:          # "[date] calculating overlaps, N threads" opens overlap_wtzmo (index build included, FASTA load excluded)
+            if t_ovl is None and b"calculating overlaps" in line:
+                t_ovl = time.perf_counter()
+        rc = pr.wait()
+        t1 = time.perf_counter()
+        if rc != 0 or t_ovl is None:
+            raise RuntimeError("reference wtzmo failed (rc %d)" % rc)
+        dt = t1 - t_ovl
         bp = 0
         for line in open(pairs):
             a, b = line.split()
             bp += lens[a] + lens[b]
         return {"value": bp / dt / 1e9, "unit": "Gbp pair-bp/s", "cores": ncpu, "kind": "reference",
-                "sample": "reference wtzmo -t %d on synthetic %d bp genome x%g (%d reads, %d bp), whole process wall %.2f s incl. FASTA load"
-                          % (ncpu, genome, coverage, meta["reads"], meta["bases"], dt)}
+                "sample": "reference wtzmo -t %d on the same generator with a %d bp genome x%g (%d reads, %d bp): overlap phase %.2f s (whole process %.2f s incl. FASTA load), %d pair-bp"
+                          % (ncpu, genome, coverage, meta["reads"], meta["bases"], dt, t1 - t0, bp)}
     if not os.path.exists(ora):
         subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "wtzmo_oracle"], check=True)
     st = os.path.join(tmp, "cpu.stats")
@@ -95,15 +115,18 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--genome", type=int, default=4600000, help="synthetic genome length (E. coli shape)")
-    ap.add_argument("--coverage", type=float, default=25.0)
-    ap.add_argument("--seed", type=int, default=11)
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="yeast100", help="yeast100 = BASELINE configs[2] (1.2 Gbp of reads), ecoli = configs[1]")
+    ap.add_argument("--genome", type=int, default=0, help="override: synthetic genome length")
+    ap.add_argument("--coverage", type=float, default=0.0)
+    ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--engine", choices=["zmo", "dmo"], default="zmo")
     ap.add_argument("--max-batch", type=int, default=0)
-    ap.add_argument("--pool-gb", type=int, default=96)
-    ap.add_argument("--cpu-genome", type=int, default=2300000, help="genome length of the bounded CPU-baseline sample")
+    ap.add_argument("--pool-gb", type=int, default=0, help="device scratch (0 = the library's default: a third of the free HBM, at most 64 GB)")
+    ap.add_argument("--cpu-genome", type=int, default=0, help="genome length of the bounded CPU-baseline sample (same coverage)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
+    wl = WORKLOADS[a.workload]
+    a.genome = a.genome or wl["genome"]; a.coverage = a.coverage or wl["coverage"]; a.seed = a.seed or wl["seed"]; a.cpu_genome = a.cpu_genome or wl["cpu_genome"]
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -138,7 +161,7 @@ def main():
     out = os.path.join(tmp, "bench_r%d.ovl" % rank)
     stats = os.path.join(tmp, "bench_r%d.stats" % rank)
     W, K = a.warmup, a.steps
-    argv = ["wtzmo", "--gpu", str(local), "-i", fa, "-fo", out, "--repeat", str(W + K), "--stats", stats, "--pool-gb", str(a.pool_gb)] + eng
+    argv = ["wtzmo", "--gpu", str(local), "-i", fa, "-fo", out, "--repeat", str(W + K), "--stats", stats] + (["--pool-gb", str(a.pool_gb)] if a.pool_gb else []) + eng
     if a.max_batch:
         argv += ["--batch", str(a.max_batch)]
     argv += multigpu.stripe_argv(world, rank)
@@ -190,47 +213,65 @@ def main():
         return
     value = pair_bp / dt / 1e9
     ms = {k: float(last[4 + i]) for i, k in enumerate(["index", "zindex", "candidates", "pairs", "winalign", "stitch"])}
-    cells_shift = int(last[10])
+    cells_shift, cells_fixed, cells_global = int(last[10]), int(last[11]), int(last[12])
     seed_bytes = int(last[13])
     ms_ext = float(last[15])
+    ms_gap = float(last[19]) if len(last) > 19 else 0.0
+    n_ranges, n_split = (int(last[20]), int(last[21])) if len(last) > 21 else (0, 0)
+
+    def valu_roofline(kernel, cells, ms_k, extra=None):
+        ach = cells * OPS_PER_CELL / (ms_k * 1e-3) / 1e12 if ms_k > 0 else None
+        r = {"kernel": kernel, "bound": "valu_int32", "achieved": ach, "peak": INT32_VALU_PEAK_TOPS, "unit": "Tint32op/s",
+             "frac": ach / INT32_VALU_PEAK_TOPS if ach is not None else None, "cell_updates_per_s": cells / (ms_k * 1e-3) if ms_k > 0 else None,
+             "cells_per_step": cells, "kernel_ms_per_step": ms_k, "ops_per_cell": OPS_PER_CELL, "traffic": None}
+        r.update(extra or {})
+        return r
+
     res = {
         "metric": "Gbp of candidate pairs aligned/sec (wtzmo all-vs-all)",
         "value": value, "unit": "Gbp/s", "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3,
-        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
-        "config": {"workload": "E. coli-shape synthetic PacBio reads (BASELINE configs[1]): %d bp iid genome x%g, lognormal mean 10 kb, 15%% error (ins:del:sub 50:30:20)"
-                               % (a.genome, a.coverage),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+        "config": {"workload": "%s: %d bp iid genome x%g, seed %d, lognormal mean 10 kb, 15%% error (ins:del:sub 50:30:20)" % (WORKLOADS[a.workload]["name"], a.genome, a.coverage, a.seed),
                    "reads": meta["reads"], "read_bases": meta["bases"], "engine": a.engine, "argv": " ".join(eng),
-                   "parallelism": "1 GPU" if world == 1 else "query striping -P %d (reads + index replicated per GPU), RCCL gather of records" % world,
-                   "parity": "records identical to `wtzmo -t 1%s` (tests/test_gpu_parity.py)" % ("" if world == 1 else " -P N -p rank` per rank")},
+                   "parallelism": "1 GPU" if world == 1 else "query striping -P %d (reads + both indexes replicated per GPU), RCCL gather of the records on rank 0" % world,
+                   "parity": "this input's .ovl md5 == reference `wtzmo -t 1%s` (tests/test_gpu_scale.py, tests/golden/big_manifest.json)" % ("" if world == 1 else " -P N -p rank` per rank"),
+                   "scratch": "%d batch ranges planned to the pool, %d split after a pool overflow" % (n_ranges, n_split)},
         "pairs_per_step": n_pairs // K, "pair_bp_per_step": pair_bp // K, "records_last_step": int(last[14]),
-        "kernel_ms_last_step": dict(ms, ksw3_wave=ms_ext),
-        "roofline": {"kernel": "K-sw3 shifting-band extension, DP rows in registers: wtz_kernel_extjobs_mw (four wavefronts per long job, side stream) "
-                               "|| wtz_kernel_extjobs_reg (one wavefront per short job); time = HIP events around the pair of launches",
-                     "bound": "valu_int32", "achieved": cells_shift * OPS_PER_CELL / (ms_ext * 1e-3) / 1e12 if ms_ext > 0 else None,
-                     "peak": INT32_VALU_PEAK_TOPS, "unit": "Tint32op/s",
-                     "frac": (cells_shift * OPS_PER_CELL / (ms_ext * 1e-3) / 1e12 / INT32_VALU_PEAK_TOPS) if ms_ext > 0 else None,
-                     "cell_updates_per_s": cells_shift / (ms_ext * 1e-3) if ms_ext > 0 else None, "cells": cells_shift,
-                     "backtrack_GBps": cells_shift / (ms_ext * 1e-3) / 1e9 if ms_ext > 0 else None, "traffic": None},
+        "kernel_ms_last_step": dict(ms, ksw3_wave=ms_ext, ksw2_gap=ms_gap),
+        "roofline": valu_roofline("K-sw3 shifting-band extension (kswx_extend_align_shift_core), DP rows in registers: wtz_kernel_extjobs_mw (four wavefronts per long "
+                                  "job, side stream) || wtz_kernel_extjobs_reg (one wavefront per short job); time = HIP events around the launches of the stage",
+                                  cells_shift, ms_ext, {"backtrack_GBps": cells_shift / (ms_ext * 1e-3) / 1e9 if ms_ext > 0 else None}),
+        "roofline_sw1": valu_roofline("K-sw1 fixed-band extension between anchors (kswx_extend_align_core) inside wtz_kernel_coop_tasks<K_winalign>; the kernel time "
+                                      "includes the z-mer run alignment and the CIGAR assembly of each window", cells_fixed, ms["winalign"]),
+        "roofline_sw2": valu_roofline("K-sw2 global banded alignment of the gaps between windows (ksw_global2 incl. every band-doubling call) in "
+                                      "wtz_kernel_coop_tasks<K_gap> (+ K_gap_wide)", cells_global, ms_gap),
         "roofline_seed": {"kernel": "wtz_kernel_coop_tasks<K_candidates> (hzm seed lookup + candidate heap)", "bound": "hbm",
                           "achieved": seed_bytes / (ms["candidates"] * 1e-3) / 1e9 if ms["candidates"] > 0 else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                          "frac": (seed_bytes / (ms["candidates"] * 1e-3) / 1e9 / HBM_PEAK_GBS) if ms["candidates"] > 0 else None, "algorithmic_bytes": seed_bytes, "traffic": None},
+                          "frac": (seed_bytes / (ms["candidates"] * 1e-3) / 1e9 / HBM_PEAK_GBS) if ms["candidates"] > 0 else None,
+                          "algorithmic_bytes_per_step": seed_bytes, "kernel_ms_per_step": ms["candidates"], "traffic": None},
     }
-    # HBM traffic of the two roofline kernels: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command, condensed by
-    # tools/summarize_profiles.py into profiles/ (per launch = per-kernel total / dispatches; FETCH_SIZE doubled as the gfx950 guide says)
+    # HBM traffic: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command with --steps 1 --warmup 0 (so totals are per step),
+    # condensed by tools/summarize_profiles.py into profiles/ (FETCH_SIZE doubled as the gfx950 guide says).  `traffic` is per LAUNCH like
+    # `achieved` (total / dispatches), `traffic_per_step` the total next to the per-step algorithmic bytes.
     try:
         import csv
-        for row in csv.DictReader(open(os.path.join(ROOT, "profiles", "r01_%s_pmc_per_kernel.csv" % a.engine))):
-            per_launch = float(row["hbm_bytes_est"]) / max(1, int(row["dispatches"]))
-            if row["kernel"] in ("wtz_kernel_extjobs_reg", "wtz_kernel_extjobs_mw"):      # the two kernels of one K-sw3 stage launch
-                res["roofline"]["traffic"] = (res["roofline"]["traffic"] or 0.0) + per_launch
-                # executed wave-level VALU instructions of the stage (PMC pass of ONE step) x 2 issue cycles on a SIMD-32 / SIMD-cycles of the
-                # live stage time: how much of the chip's VALU issue capacity the exact recurrence really occupies (the nominal 12 ops/cell
-                # of SURVEY 8d undercounts it by ~8x)
-                if ms_ext > 0 and row.get("SQ_INSTS_VALU"):
-                    res["roofline"]["valu_issue_frac_pmc"] = (res["roofline"].get("valu_issue_frac_pmc") or 0.0) + float(row["SQ_INSTS_VALU"]) * 2.0 / (ms_ext * 1e-3 * 2.4e9 * 256 * 4)
-                res["roofline"]["traffic_note"] = "HBM bytes per stage launch (both kernels) from profiles/r01_%s_pmc_per_kernel.csv (separate --pmc passes)" % a.engine
-            if row["kernel"] == "K_candidates":
-                res["roofline_seed"]["traffic"] = per_launch
+        src = os.path.join(ROOT, "profiles", "r02_%s_%s_pmc_per_kernel.csv" % (a.workload, a.engine))
+        kmap = {"wtz_kernel_extjobs_reg": "roofline", "wtz_kernel_extjobs_mw": "roofline", "K_winalign": "roofline_sw1", "K_gap": "roofline_sw2", "K_candidates": "roofline_seed"}
+        for row in csv.DictReader(open(src)):
+            key = kmap.get(row["kernel"])
+            if key is None:
+                continue
+            tot = float(row["hbm_bytes_est"])
+            R = res[key]
+            R["traffic_per_step"] = (R.get("traffic_per_step") or 0.0) + tot
+            R["traffic"] = (R["traffic"] or 0.0) + tot / max(1, int(row["dispatches"]))
+            R["traffic_note"] = "PMC (2 x FETCH_SIZE + WRITE_SIZE) from %s" % os.path.relpath(src, ROOT)
+            if key != "roofline_seed" and row.get("SQ_INSTS_VALU") and R["kernel_ms_per_step"] > 0:
+                # wave-level VALU instructions of one step x 2 issue cycles on a SIMD-32 / SIMD-cycles of the live kernel time
+                R["valu_issue_frac_pmc"] = (R.get("valu_issue_frac_pmc") or 0.0) + float(row["SQ_INSTS_VALU"]) * 2.0 / (R["kernel_ms_per_step"] * 1e-3 * 2.4e9 * 256 * 4)
+        for key in ("roofline", "roofline_sw1", "roofline_sw2"):
+            if res[key].get("traffic_per_step"):
+                res[key]["algorithmic_trace_bytes_per_step"] = res[key]["cells_per_step"]       # the reference's layout: 1 trace byte per cell
     except Exception:
         pass
     if world > 1:

@@ -90,6 +90,7 @@ typedef struct {
 	uint64_t pool_peak;
 	double   ms_ext;                                                                  /* K-sw3 wave kernel alone (inside ms_stitch) */
 	uint64_t n_extjobs;
+	double   ms_gap;                                                                  /* K-sw2 gap kernels alone (inside ms_stitch) */
 } wtz_counters_t;
 
 const char *wtz_last_error(void);

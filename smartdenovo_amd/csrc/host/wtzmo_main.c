@@ -86,7 +86,7 @@ typedef struct {
 	char *cig_keep[16]; uint64_t cig_keep_cap[16];      /* page-locked CIGAR text buffer of worker w, kept across steps (pinning is the expensive part) */
 	double t_gpu, t_commit, t_call[6], t_io[2];      /* t_io: waiting for the writer thread before a text buffer is reused / at the end of the run */      /* t_call: wall seconds inside wtz_candidates / pairs_seed / pairs_windows / pairs_align / fetch_cigar_text / planning */
 	uint64_t spec_pairs, used_pairs, spec_items, used_items, spec_queries, used_queries, n_batches;
-	double extra_ms[5]; uint64_t extra_u64[6];      /* counters of the cloned contexts */
+	double extra_ms[6]; uint64_t extra_u64[6];      /* counters of the cloned contexts */
 } eng_t;
 
 typedef struct {       /* one batch in flight */
@@ -596,8 +596,11 @@ static void process_batch(eng_t *E, batch_t *b){
 	uint32_t s0 = 0;
 	while(s0 < b->nbq){
 		pthread_mutex_lock(&E->mu);
-		const double bpp = E->bytes_per_pair > 0 ? E->bytes_per_pair : 1048576.0;      /* prior before the first measurement: 1 MB per pair */
+		/* before the first measurement: a small probe range (about 2000 pairs, never more than 1 MB per pair allows) - repeat-rich reads
+		 * need tens of MB per pair where iid reads need a few hundred KB, and the longest reads come first */
 		const double cap = E->main_cap ? (double)E->main_cap : 0.0;
+		const double prior = cap / 2048.0 > 1048576.0 ? cap / 2048.0 : 1048576.0;
+		const double bpp = E->bytes_per_pair > 0 ? E->bytes_per_pair : prior;
 		pthread_mutex_unlock(&E->mu);
 		uint64_t budget = cap > 0 ? (uint64_t)(0.7 * cap / bpp) : ~0ull;
 		if(budget < 16) budget = 16;
@@ -971,7 +974,7 @@ int main(int argc, char **argv){
 			for(uint32_t w = 1; w < nw; w++) pthread_join(th[w], NULL);
 			for(uint32_t w = 0; w < nw; w++){
 				wtz_counters_t cw; wtz_get_counters(bs[w].ctx, &cw);
-				if(w){ E->extra_ms[0] += cw.ms_candidates; E->extra_ms[1] += cw.ms_pairs; E->extra_ms[2] += cw.ms_winalign; E->extra_ms[3] += cw.ms_stitch; E->extra_ms[4] += cw.ms_ext;
+				if(w){ E->extra_ms[0] += cw.ms_candidates; E->extra_ms[1] += cw.ms_pairs; E->extra_ms[2] += cw.ms_winalign; E->extra_ms[3] += cw.ms_stitch; E->extra_ms[4] += cw.ms_ext; E->extra_ms[5] += cw.ms_gap;
 					E->extra_u64[0] += cw.cells_shift; E->extra_u64[1] += cw.cells_fixed; E->extra_u64[2] += cw.cells_global; E->extra_u64[3] += cw.bytes_seed_algo; E->extra_u64[4] += cw.n_extjobs;
 					if(cw.pool_peak > E->extra_u64[5]) E->extra_u64[5] = cw.pool_peak;
 					wtz_ctx_destroy(bs[w].ctx); }
@@ -986,7 +989,7 @@ int main(int argc, char **argv){
 		if(strcmp(output, "-")) fclose(E->out); else fflush(stdout);
 		if(g_hook) g_hook(rep, 1);
 		wtz_counters_t cn; wtz_get_counters(E->ctx, &cn);
-		cn.ms_candidates += E->extra_ms[0]; cn.ms_pairs += E->extra_ms[1]; cn.ms_winalign += E->extra_ms[2]; cn.ms_stitch += E->extra_ms[3]; cn.ms_ext += E->extra_ms[4];
+		cn.ms_candidates += E->extra_ms[0]; cn.ms_pairs += E->extra_ms[1]; cn.ms_winalign += E->extra_ms[2]; cn.ms_stitch += E->extra_ms[3]; cn.ms_ext += E->extra_ms[4]; cn.ms_gap += E->extra_ms[5];
 		cn.cells_shift += E->extra_u64[0]; cn.cells_fixed += E->extra_u64[1]; cn.cells_global += E->extra_u64[2]; cn.bytes_seed_algo += E->extra_u64[3]; cn.n_extjobs += E->extra_u64[4];
 		if(E->extra_u64[5] > cn.pool_peak) cn.pool_peak = E->extra_u64[5];
 		memset(E->extra_ms, 0, sizeof E->extra_ms); memset(E->extra_u64, 0, sizeof E->extra_u64);
@@ -996,11 +999,11 @@ int main(int argc, char **argv){
 	if(E->n_split) fprintf(stderr, "[wtzmo-mi355x] %llu range(s) had to be split after a scratch-pool overflow (planned at %.0f KB per pair)\n", (unsigned long long)E->n_split, E->bytes_per_pair / 1024.0);
 	fprintf(stderr, "[wtzmo-mi355x] %llu batches in %llu ranges on %u worker context(s); speculation: queries %llu/%llu pairs %llu/%llu alignments %llu/%llu (used/planned)\n",
 			(unsigned long long)E->n_batches, (unsigned long long)E->n_ranges, E->rows_all ? 1u : E->n_workers, (unsigned long long)E->used_queries, (unsigned long long)E->spec_queries, (unsigned long long)E->used_pairs, (unsigned long long)E->spec_pairs, (unsigned long long)E->used_items, (unsigned long long)E->spec_items);
-		fprintf(stderr, "[wtzmo-mi355x] kernel ms: index %.1f zindex %.1f candidates %.1f pairs %.1f winalign %.1f stitch %.1f (K-sw3 wave %.1f); cells shift %llu; pool peak %.2f GB\n",
-			cn.ms_index, cn.ms_zindex, cn.ms_candidates, cn.ms_pairs, cn.ms_winalign, cn.ms_stitch, cn.ms_ext, (unsigned long long)cn.cells_shift, cn.pool_peak / 1073741824.0);
-		if(statsf){ FILE *sf = fopen(statsf, "a"); if(sf){ fprintf(sf, "%llu\t%llu\t%.6f\t%.6f\t%.3f\t%.3f\t%.3f\t%.3f\t%.3f\t%.3f\t%llu\t%llu\t%llu\t%llu\t%llu\t%.3f\t%llu\t%llu\t%llu\n", (unsigned long long)E->n_pairs, (unsigned long long)E->pair_bp, t1 - t0, t_index,
+		fprintf(stderr, "[wtzmo-mi355x] kernel ms: index %.1f zindex %.1f candidates %.1f pairs %.1f winalign %.1f stitch %.1f (K-sw3 wave %.1f, K-sw2 gaps %.1f); cells shift %llu fixed %llu global %llu; pool peak %.2f GB\n",
+			cn.ms_index, cn.ms_zindex, cn.ms_candidates, cn.ms_pairs, cn.ms_winalign, cn.ms_stitch, cn.ms_ext, cn.ms_gap, (unsigned long long)cn.cells_shift, (unsigned long long)cn.cells_fixed, (unsigned long long)cn.cells_global, cn.pool_peak / 1073741824.0);
+		if(statsf){ FILE *sf = fopen(statsf, "a"); if(sf){ fprintf(sf, "%llu\t%llu\t%.6f\t%.6f\t%.3f\t%.3f\t%.3f\t%.3f\t%.3f\t%.3f\t%llu\t%llu\t%llu\t%llu\t%llu\t%.3f\t%llu\t%llu\t%llu\t%.3f\t%llu\t%llu\n", (unsigned long long)E->n_pairs, (unsigned long long)E->pair_bp, t1 - t0, t_index,
 				cn.ms_index, cn.ms_zindex, cn.ms_candidates, cn.ms_pairs, cn.ms_winalign, cn.ms_stitch, (unsigned long long)cn.cells_shift, (unsigned long long)cn.cells_fixed, (unsigned long long)cn.cells_global, (unsigned long long)cn.bytes_seed_algo, (unsigned long long)E->nrec,
-				cn.ms_ext, (unsigned long long)cn.n_extjobs, (unsigned long long)E->used_queries, (unsigned long long)cn.pool_peak); fclose(sf); } }
+				cn.ms_ext, (unsigned long long)cn.n_extjobs, (unsigned long long)E->used_queries, (unsigned long long)cn.pool_peak, cn.ms_gap, (unsigned long long)E->n_ranges, (unsigned long long)E->n_split); fclose(sf); } }
 	}
 	if(write_contained && strcmp(output, "-")){
 		char *maskf = (char*)hx_realloc(NULL, strlen(output) + 16); sprintf(maskf, "%s.contained", output);

@@ -963,6 +963,7 @@ extern "C" int wtz_pairs_align(wtz_ctx_t *c, const uint32_t *pair_idx, const uin
 			if(gap_side){ HIPCHK(hipEventRecord(c->ev_gap_fork, main_stream)); HIPCHK(hipStreamWaitEvent(c->stream_gap, c->ev_gap_fork, 0)); g_stream = c->stream_gap; }
 			uint32_t *d_defer = NULL; CHK(dev_alloc((void**)&d_defer, (size_t)(nwt + 1) * 4)); CHK(dev_set(d_defer, 0, 4));
 			STAGE(c, "K_gap");
+			wtz_timer tgap; tgap.start();
 			int rc_gap = wtz_launch_coop<K_gap>(0, nwt, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_gap((uint32_t)t, V, d_wt, d_items, d_gaps, d_defer, NULL, 0u); }, WTZ_GAP_LDS_BYTES);
 			if(rc_gap == WTZ_OK){
 				/* gaps whose band outgrew the register forms (repeats): the LDS-ring wave DP with 8192-column rings, 72 KB of LDS per wave */
@@ -970,12 +971,14 @@ extern "C" int wtz_pairs_align(wtz_ctx_t *c, const uint32_t *pair_idx, const uin
 				if(rc_gap == WTZ_OK && n_def) rc_gap = wtz_launch_coop<K_gap_wide>(0, n_def, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_gap((uint32_t)t, V, d_wt, d_items, d_gaps, NULL, d_defer, (uint32_t)WTZ_GAP_WIDE_LDS_BYTES); }, WTZ_GAP_WIDE_LDS_BYTES);
 				if(rc_gap == WTZ_OK && c->env_profile){ rc_gap = dev_sync(); fprintf(stderr, "[gap-profile] %llu window slots, %u wide gaps redone with 72 KB of LDS\n", (unsigned long long)nwt, n_def); }
 			}
+			if(rc_gap == WTZ_OK && !gap_side){ tgap.lap(); }
 			g_stream = main_stream;
 			CHK(rc_gap);
 			if(gap_side) HIPCHK(hipEventRecord(c->ev_gap_join, c->stream_gap));
 			STAGE(c, "extjobs left");
 			CHK(run_extjobs(c, V, d_jl, m));
 			if(gap_side) HIPCHK(hipStreamWaitEvent(main_stream, c->ev_gap_join, 0));
+			else c->cnt.ms_gap += tgap.read();      /* after the extension jobs: no extra synchronisation for the lap */
 		}
 #endif
 		STAGE(c, "K_stitch_mid");

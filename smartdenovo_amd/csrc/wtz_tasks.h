@@ -299,7 +299,13 @@ typedef struct { wtz_aln_t x; wtz_cigar_t cigar; uint32_t first, nreg; int32_t b
 
 /* K-sw2 between two consecutive passing windows (hzm_aln.h:1386-1447), one task per window slot so that all gaps of a
  * batch run side by side; stored at the slot of the RIGHT window of the gap */
-typedef struct { int32_t score, aln, mat, mis, ins, del; uint32_t *cigar; uint32_t cigar_len; int32_t bad, valid; } wtz_gapres_t;
+typedef struct { int32_t score, aln, mat, mis, ins, del; uint32_t *cigar; uint32_t cigar_len; int32_t bad, valid; unsigned long long cells; } wtz_gapres_t;
+/* DP cells of ONE ksw_global2 call as its loops execute them: row i of the target covers query columns [max(i-w,0), min(i+w+1,qlen)) (ksw.c:529-533) */
+WTZ_HD unsigned long long wtz_global_cells(int32_t qlen, int32_t tlen, int32_t w){
+	unsigned long long n = 0;
+	for(int32_t i = 0; i < tlen; i++){ const int32_t beg = i > w ? i - w : 0; int32_t end = i + w + 1; if(end > qlen) end = qlen; if(end > beg) n += (unsigned long long)(end - beg); }
+	return n;
+}
 
 /* A gap whose band outgrows every register form (band doubling up to -W 3200 inside repeats: thousands of columns) used to run the
  * scalar body on lane 0 - seconds per gap.  The first launch (`wide_lds` = 0) now appends such a gap to `defer` ([0] = count) and a
@@ -437,6 +443,7 @@ WTZ_HD void wtz_task_gap(uint32_t t, const wtz_env_t &V, const wtz_wintask_t *ta
 				return;
 			}
 			score = G.score; from_reg = G.from_reg; runs = G.runs; n_runs = G.n_runs; r_mat = G.r_mat; r_mis = G.r_mis;
+			if(WTZ_LANE == 0) g.cells += wtz_global_cells(dq, dt, w);         /* every call of the band-doubling loop counts (hzm_aln.h:1400-1417) */
 			if(G.bad){ bad = 1; break; }
 			if(score < 0 && w < P->W && w < WTZ_MAX(dq, dt)) w <<= 1;
 			else break;
@@ -463,6 +470,7 @@ WTZ_HD void wtz_task_gap(uint32_t t, const wtz_env_t &V, const wtz_wintask_t *ta
 		for(;;){
 			if(w < WTZ_ABSDIFF(dq, dt)){ w <<= 1; continue; }
 			score = wtz_global_banded(dq, q, dt, tt, M, X, -I, -E, -D, -E, w, mem, tmp);
+			g.cells += wtz_global_cells(dq, dt, w);
 			if(score < 0 && w < P->W && w < WTZ_MAX(dq, dt)) w <<= 1;
 			else break;
 		}
@@ -528,6 +536,7 @@ WTZ_HD void wtz_task_stitch_mid(uint32_t t, const wtz_env_t &V, const wtz_alnite
 		const wtz_reg_t *reg2 = &it.regs[k];
 		const wtz_gapres_t &g = gp[k];
 		if(!g.valid || g.bad) st.bad = 1;
+		st.cells_global += g.cells;
 		x.score += g.score;
 		x.aln += g.aln; x.mat += g.mat; x.mis += g.mis; x.ins += g.ins; x.del += g.del;
 		wtz_cigar_concat_coop(st.cigar, g.cigar, g.cigar_len);
@@ -547,7 +556,7 @@ WTZ_HD void wtz_task_stitch_mid(uint32_t t, const wtz_env_t &V, const wtz_alnite
 WTZ_HD void wtz_task_stitch_fin(uint32_t t, const wtz_env_t &V, const wtz_alnitem_t *items, wtz_stitch_state_t *sts, const wtz_extjob_t *jobsL, const wtz_extjob_t *jobsR, wtz_alnres_dev_t *out){
 	wtz_stitch_state_t st = sts[t];
 	wtz_alnres_dev_t r; memset(&r, 0, sizeof r);
-	r.n_regs = st.nreg; r.bad = st.bad;
+	r.n_regs = st.nreg; r.bad = st.bad; r.cells_global = st.cells_global;
 	for(uint32_t k = 0; k < items[t].nwin; k++) r.cells_fixed += items[t].regs[k].cells;
 	if(st.nreg && !st.bad){
 		wtz_aln_t x = st.x;

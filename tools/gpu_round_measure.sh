@@ -1,23 +1,25 @@
 #!/bin/bash
-# Round measurement on the GPU box: default bench line (with CPU baseline), dmo bench line, kernel-trace stats, PMC passes.
-# usage: tools/gpu_round_measure.sh <tag>     (outputs under gpurun_out/<tag>/)
-TAG=${1:-r01}
+# Round measurement on the GPU box: default bench line (configs[2], with CPU baseline), dmo bench line, E. coli-shape line, kernel-trace stats, PMC passes.
+# usage: tools/gpu_round_measure.sh <tag> [workload]     (outputs under gpurun_out/<tag>/; summaries are copied to profiles/ by hand)
+TAG=${1:-r02}
+WL=${2:-yeast100}
 R=$GRAFT_REPO_ROOT; [ -z "$R" ] && R=$(pwd)
 O=$R/gpurun_out/$TAG; mkdir -p $O
 export TMPDIR=/tmp
 cd $R
-( time python bench.py ) > $O/bench_zmo.json 2> $O/bench_zmo.err
-tail -1 $O/bench_zmo.json | cut -c1-600
+( time python bench.py --workload $WL ) > $O/bench_zmo.json 2> $O/bench_zmo.err
+tail -1 $O/bench_zmo.json | cut -c1-700
 grep real $O/bench_zmo.err
-python bench.py --engine dmo > $O/bench_dmo.json 2> $O/bench_dmo.err
+python bench.py --workload $WL --engine dmo > $O/bench_dmo.json 2> $O/bench_dmo.err
 tail -1 $O/bench_dmo.json | cut -c1-300
+[ $WL != ecoli ] && { python bench.py --workload ecoli --no-cpu-baseline > $O/bench_ecoli_zmo.json 2> $O/bench_ecoli_zmo.err; tail -1 $O/bench_ecoli_zmo.json | cut -c1-300; }
 cd /tmp
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_zmo -o zmo -- python $R/bench.py --no-cpu-baseline > $O/trace_zmo.log 2>&1
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_dmo -o dmo -- python $R/bench.py --engine dmo --no-cpu-baseline > $O/trace_dmo.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_zmo -o zmo -- python $R/bench.py --workload $WL --no-cpu-baseline > $O/trace_zmo.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_dmo -o dmo -- python $R/bench.py --workload $WL --engine dmo --no-cpu-baseline > $O/trace_dmo.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 1200 rocprofv3 --pmc $c --output-format csv -d $O/pmc_$c -o zmo -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $O/pmc_$c.log 2>&1
+  timeout 1500 rocprofv3 --pmc $c --output-format csv -d $O/pmc_$c -o zmo -- python $R/bench.py --workload $WL --steps 1 --warmup 0 --no-cpu-baseline > $O/pmc_$c.log 2>&1
 done
-timeout 1200 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY --output-format csv -d $O/pmc_SQ -o zmo -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $O/pmc_SQ.log 2>&1
+timeout 1500 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY --output-format csv -d $O/pmc_SQ -o zmo -- python $R/bench.py --workload $WL --steps 1 --warmup 0 --no-cpu-baseline > $O/pmc_SQ.log 2>&1
 cd $R
 python tools/summarize_profiles.py $O $O/summary
 # keep the merge-back small: raw per-dispatch traces are dropped, the summaries stay
