@@ -61,6 +61,7 @@ struct K_stitch_fin;
 struct K_stitch_left;
 struct K_stitch_mid;
 struct K_winalign;
+struct K_winalign4;
 struct K_winalign_big;
 struct K_zfill;
 struct K_zrun;
@@ -130,6 +131,19 @@ template<typename TAG, typename F> static int wtz_launch_coop(hipStream_t st, ui
 	if(n > 0x7FFFFFFFull) return wtz_fail(WTZ_E_ARG, "grid too large");
 	if(lds_bytes > 65536u){ HIPCHK(hipFuncSetAttribute((const void*)&wtz_kernel_coop_tasks<TAG, F>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)); }      /* opt in to more than 64 KB of dynamic LDS */
 	(void)st; hipLaunchKernelGGL((wtz_kernel_coop_tasks<TAG, F>), dim3((uint32_t)n), dim3(64), lds_bytes, g_stream, n, f);
+	HIPCHK(hipGetLastError());
+	return WTZ_OK;
+}
+/* four tasks per wavefront: one per 16-lane group (wtz_sw_grp.h); f gets the index of the block's first task */
+template<typename TAG, typename F> __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 8))) wtz_kernel_grp_tasks(uint64_t n, F f){
+	const uint64_t i = (uint64_t)blockIdx.x * 4;
+	if(i < n) f(i);
+}
+template<typename TAG, typename F> static int wtz_launch_grp(uint64_t n, F f, uint32_t lds_bytes){
+	if(n == 0) return WTZ_OK;
+	const uint64_t nb = (n + 3) / 4;
+	if(nb > 0x7FFFFFFFull) return wtz_fail(WTZ_E_ARG, "grid too large");
+	hipLaunchKernelGGL((wtz_kernel_grp_tasks<TAG, F>), dim3((uint32_t)nb), dim3(64), lds_bytes, g_stream, n, f);
 	HIPCHK(hipGetLastError());
 	return WTZ_OK;
 }
@@ -269,6 +283,7 @@ struct wtz_ctx {
 	uint32_t *cq_q = NULL, *cq_nc = NULL; uint64_t *cq_cand = NULL; unsigned long long *cq_bytes = NULL; uint32_t cq_cap = 0, cq_n = 0; bool cq_pending = false; wtz_timer cq_tm;
 	wtz_counters_t cnt;
 	uint64_t tpool_peak_call = 0, main_used_call = 0;      /* transient-pool high-water mark / main-pool bytes of the API call in progress */
+	int env_grp4 = 0;            /* WTZ_WINALIGN4=1: four windows per wavefront first (wtz_sw_grp.h; bit-exact, measured 2x SLOWER than one window per wave: see DESIGN.md) */
 	bool env_trace = false;      /* WTZ_STAGE_TRACE: name every device stage on stderr before it is launched (locating a device fault) */
 	bool env_fail_once = false;      /* WTZ_POOL_FAIL_ONCE: the injected failure hits one stage call only (the retry must then succeed) */
 	unsigned env_fail_at = 0, env_tfail_at = 0;      /* WTZ_POOL_FAIL_AT / WTZ_TPOOL_FAIL_AT: fault injection into the main / transient pool */
@@ -376,6 +391,7 @@ extern "C" int wtz_ctx_create(int device, const wtz_params_c *params, uint64_t p
 	c->env_profile = getenv("WTZ_PROFILE_PAIR") != NULL;
 #endif
 	c->env_trace = getenv("WTZ_STAGE_TRACE") != NULL;
+	c->env_grp4 = (getenv("WTZ_WINALIGN4") && atoi(getenv("WTZ_WINALIGN4")) != 0);
 	c->env_fail_once = getenv("WTZ_POOL_FAIL_ONCE") != NULL;
 	c->env_fail_at = getenv("WTZ_POOL_FAIL_AT") ? (unsigned)atoi(getenv("WTZ_POOL_FAIL_AT")) : 0u;
 	c->env_tfail_at = getenv("WTZ_TPOOL_FAIL_AT") ? (unsigned)atoi(getenv("WTZ_TPOOL_FAIL_AT")) : 0u;
@@ -926,14 +942,26 @@ extern "C" int wtz_pairs_align(wtz_ctx_t *c, const uint32_t *pair_idx, const uin
 	CHK(wtz_launch_coop<K_winalign>(0, wt.size(), [=] WTZ_LAMBDA (uint64_t t){ wtz_task_winalign((uint32_t)t, V, d_wt, d_items); }, WTZ_WINALIGN_LDS_BYTES));
 #else
 	{
-		/* first launch: the lean form (register DP with one / two band columns per lane, no scalar body: fewer VGPRs, no spills at three
-		 * waves per SIMD); the few windows with a problem outside it queue themselves and are redone by the full task */
-		uint32_t *d_defer = NULL; CHK(dev_alloc((void**)&d_defer, (wt.size() + 1) * 4)); CHK(dev_set(d_defer, 0, 4));
+		/* first launch: FOUR windows per wavefront (one per 16-lane group, wtz_sw_grp.h); a window with a problem outside the group form's
+		 * envelope queues itself for the one-window-per-wave kernel: its lean form first (register DP with one / two band columns per lane,
+		 * no scalar body: fewer VGPRs), then - for what that form defers in turn - the full task */
+		const uint64_t nwt0 = wt.size();
+		uint32_t *d_defer4 = NULL, *d_defer = NULL;
+		CHK(dev_alloc((void**)&d_defer4, (nwt0 + 1) * 4)); CHK(dev_set(d_defer4, 0, 4));
+		CHK(dev_alloc((void**)&d_defer, (nwt0 + 1) * 4)); CHK(dev_set(d_defer, 0, 4));
 		STAGE(c, "K_winalign");
-		CHK(wtz_launch_coop<K_winalign>(0, wt.size(), [=] WTZ_LAMBDA (uint64_t t){ wtz_task_winalign<false>((uint32_t)t, V, d_wt, d_items, d_defer, NULL); }, WTZ_WINALIGN_LDS_BYTES));
-		uint32_t n_def = 0; CHK(dev_d2h(&n_def, d_defer, 4));
+		uint32_t n_def4 = 0, n_def = 0;
+		if(c->env_grp4){
+			CHK(wtz_launch_grp<K_winalign4>(nwt0, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_winalign4((uint32_t)t, (uint32_t)nwt0, V, d_wt, d_items, d_defer4); }, WTZ_WINALIGN4_LDS_BYTES));
+			CHK(dev_d2h(&n_def4, d_defer4, 4));
+			if(n_def4) CHK(wtz_launch_coop<K_winalign>(0, n_def4, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_winalign<false>((uint32_t)t, V, d_wt, d_items, d_defer, d_defer4); }, WTZ_WINALIGN_LDS_BYTES));
+		} else {
+			CHK(wtz_launch_coop<K_winalign>(0, nwt0, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_winalign<false>((uint32_t)t, V, d_wt, d_items, d_defer, NULL); }, WTZ_WINALIGN_LDS_BYTES));
+		}
+		CHK(dev_d2h(&n_def, d_defer, 4));
 		if(n_def) CHK(wtz_launch_coop<K_winalign_big>(0, n_def, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_winalign<true>((uint32_t)t, V, d_wt, d_items, NULL, d_defer); }, WTZ_WINALIGN_LDS_BYTES));
-		if(c->env_profile) fprintf(stderr, "[winalign-profile] %zu windows, %u redone by the full task\n", wt.size(), n_def);
+		if(c->env_profile) fprintf(stderr, "[winalign-profile] %zu windows, %u left by the four-per-wave form, %u redone by the full task\n", wt.size(), n_def4, n_def);
+		dev_free(d_defer4);
 		dev_free(d_defer);
 	}
 #endif

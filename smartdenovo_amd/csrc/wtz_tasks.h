@@ -12,6 +12,7 @@
 
 #include "wtz_sw.h"
 #include "wtz_sw_wave.h"
+#include "wtz_sw_grp.h"
 #include "wtz_dotmatrix.h"
 
 typedef struct {
@@ -284,6 +285,30 @@ WTZ_HD void wtz_task_winalign(uint32_t t, const wtz_env_t &V, const wtz_wintask_
 	if(cigar.bad || tmp.bad || bad) reg.pass = 2;        /* pool exhausted */
 	it.regs[tasks[t].widx] = reg;
 }
+
+#if defined(__HIPCC__)
+/* four windows per wavefront (wtz_sw_grp.h): group g of the block takes window task t_base + g; a window outside the group form's
+ * envelope is appended to `defer` ([0] = count) and redone by the one-window-per-wave kernel */
+WTZ_D void wtz_task_winalign4(uint32_t t_base, uint32_t n, const wtz_env_t &V, const wtz_wintask_t *tasks, const wtz_alnitem_t *items, uint32_t *defer){
+	const uint32_t g = threadIdx.x >> 4, gl = threadIdx.x & 15u;
+	const uint32_t t = t_base + g;
+	if(t >= n) return;
+	const wtz_params_t *P = V.P;
+	const wtz_alnitem_t &it = items[tasks[t].item];
+	const wtz_win_t &w = it.win[tasks[t].widx];
+	wtz_reg_t reg; memset(&reg, 0, sizeof reg);
+	wtz_cigar_t cigar; cigar.init(V.pool, gl == 0 ? 64 : 0);
+	unsigned long long cells = 0;
+	bool ok = true, dfr = false;
+	reg.x = wtz_align_window_grp(wtz_view(V.R, it.q, 0), wtz_view(V.R, it.c, it.dir), w, it.anchors, cigar, P, V.pool, (uint8_t*)wtz_wave_scratch() + (size_t)g * WTZ_GRP_LDS_BYTES, &cells, &ok, &dfr);
+	if(gl != 0) return;
+	if(dfr){ const uint32_t idx = atomicAdd(&defer[0], 1u); defer[1 + idx] = t; return; }
+	reg.cigar = cigar.a; reg.cigar_len = cigar.n; reg.cells = cells;
+	reg.pass = !(reg.x.aln * 2 < (int32_t)P->zovl || (float)reg.x.mat < (float)reg.x.aln * P->min_id);
+	if(cigar.bad || !ok) reg.pass = 2;        /* pool exhausted */
+	it.regs[tasks[t].widx] = reg;
+}
+#endif
 
 /*
  * A10 (hzm_aln.h:1345-1486 with esti_regs = {0, len1}, wtzmo.c:1030) as three per-item phases around the two
