@@ -41,7 +41,7 @@ static int usage(void){
 	" -z <int> -Z <int> -l <int> -y <int> -R <int> -r <int> -q <int>  z-mer windows [10,64,2,800,200,300,100]\n"
 	" -U <float>x5 | -U -1   dot-matrix engine    -A <int> -B <int> candidates / best [500,100]\n"
 	" -w -e -W -M -X -O -E -T  alignment [50,800,3200,2,-5,-3,-1,-50]   -s <int> -m <float> [200,0.5]\n"
-	" --gpu <int> --pool-gb <int> --batch <int> --stats <file>\n");
+	" --gpu <int> | --gpus <int> (one process, N GPUs, ONE .ovl identical to -t 1)  --pool-gb <int> --batch <int> --stats <file>\n");
 	return 1;
 }
 
@@ -65,11 +65,12 @@ typedef struct {      /* results of the query processed last, not yet merged int
 	seed_t *seeds; size_t nseed, capseed;
 } pending_t;
 
-typedef struct {
+typedef struct eng_s {
 	wtz_params_c P; int do_align; uint32_t n_idx, n_job, i_job;
 	hx_store_t st; uint8_t *masked; uint32_t *rdcovs; hx_set_t closed;
 	uint32_t *rdlen; uint32_t avg_rdlen;
 	wtz_ctx_t *ctx; FILE *out;
+	uint32_t ndev; int devs[8]; wtz_ctx_t *ctxs[8];      /* --gpus N / --gpu-list: one context per device, reads + both indexes replicated; ctx == ctxs[0] */
 	uint64_t pair_bp, n_pairs, nrec;
 	/* candidate rows carried across -G index parts (the reference's rdhits), else NULL */
 	uint64_t *rows; uint32_t *nrow; uint32_t stride; int rows_all;
@@ -89,19 +90,33 @@ typedef struct {
 	double extra_ms[6]; uint64_t extra_u64[6];      /* counters of the cloned contexts */
 } eng_t;
 
+/* The pairs of a range are dealt round-robin to the PARTS of a batch, one part per GPU (--gpus N; one part otherwise): pair g of the
+ * plan is local pair g / nparts of part g % nparts.  Every device stage is pure in its pairs, so a part runs pair seeding, windows,
+ * alignment and CIGAR rendering of its share on its own context, all parts side by side on their own host threads; the commit reads
+ * the results through PART_OF / LOCAL_OF in the plan's order, i.e. the output does not depend on the number of parts. */
+typedef struct {
+	wtz_ctx_t *ctx;
+	uint32_t *pq, *pc; uint32_t npair, cappair;
+	wtz_pair_summary_t *sum; uint64_t *box_off; wtz_winbox_t *boxes; uint64_t nbox, capbox;
+	uint32_t *item_of; uint32_t *it_pair; uint8_t *it_dir; uint32_t nitem; wtz_aln_result_t *aln; char *cig; uint64_t ncig;
+	char *cigs[2]; uint64_t capcigs[2]; int cig_sel, cig_ext, ext_base;      /* two page-locked CIGAR text buffers, alternating per range; ext ids of the output writer */
+	double t_call[6], t_io0;                   /* wall seconds of this part's device calls since the last fold into E (under E->mu) */
+	struct eng_s *E; int again;                /* result of the last part_stages run (1 = scratch pool too small) */
+	uint32_t *cq_ids, *cq_nr; uint64_t *cq_rows; uint32_t cq_n, cq_cap;      /* this device's share (every nparts-th query) of the candidate request in flight */
+} part_t;
+#define PART_OF(b, g) (&(b)->parts[(g) % (b)->nparts])
+#define LOCAL_OF(b, g) ((g) / (b)->nparts)
+
 typedef struct {       /* one batch in flight */
-	eng_t *E; wtz_ctx_t *ctx; uint64_t seq;
+	eng_t *E; wtz_ctx_t *ctx; uint64_t seq;    /* ctx: the context of the candidate requests (= parts[0].ctx) */
 	uint32_t *bq; uint32_t nbq, capbq;         /* queries in dispatch order */
 	uint8_t *want;                              /* slot needs GPU work (not saturated when planned) */
 	uint64_t *rows; uint32_t *nrow;             /* candidate heap arrays per slot (stride E->stride) */
 	uint32_t *ids;
-	uint32_t *pq, *pc; uint32_t npair, cappair;
-	uint32_t *rowpair; size_t caprowpair;       /* pair index per (slot, row entry) */
-	wtz_pair_summary_t *sum; uint64_t *box_off; wtz_winbox_t *boxes; uint64_t nbox, capbox;
-	uint32_t *item_of; uint32_t *it_pair; uint8_t *it_dir; uint32_t nitem; wtz_aln_result_t *aln; char *cig; uint64_t ncig;
-	char *cigs[2]; uint64_t capcigs[2]; int cig_sel, cig_ext, ext_base;      /* two page-locked CIGAR text buffers, alternating per batch; ext ids of the output writer */
+	part_t *parts; uint32_t nparts;
+	uint32_t npair, nitem;                      /* pairs / alignment items of the range over all parts */
+	uint32_t *rowpair; size_t caprowpair;       /* pair index (in plan order) per (slot, row entry) */
 	uint64_t spec_queries, used_queries;
-	double t_call[6], t_io0;                   /* wall seconds of this worker's device calls since the last fold into E (under E->mu) */
 	int holds_turn;
 	/* candidates of the NEXT batch, requested before this batch is committed (single worker, no -G) */
 	int pf_inflight; uint32_t *pf_ids; uint32_t pf_n, pf_cap; uint64_t *pf_rows; uint32_t *pf_nr; uint32_t pf_cursor_end;
@@ -348,7 +363,7 @@ static void commit_query(eng_t *E, batch_t *b, uint32_t slot){
 		for(uint32_t i = 0; i < nc; i++){
 			const uint32_t id2 = (uint32_t)(cand[i].e >> 32);
 			if(cand[i].pidx == 0xFFFFFFFFu){ fprintf(stderr, " -- internal error: pair (%u,%u) missing from the batch plan --\n", pbid, id2); exit(1); }
-			const wtz_pair_summary_t *S = &b->sum[cand[i].pidx];
+			const wtz_pair_summary_t *S = &PART_OF(b, cand[i].pidx)->sum[LOCAL_OF(b, cand[i].pidx)];
 			if(!S->gate) continue;
 			E->used_pairs++;
 			pend_closed(pd, hx_pair_key(id2, pbid));
@@ -372,11 +387,12 @@ static void commit_query(eng_t *E, batch_t *b, uint32_t slot){
 	for(uint32_t i = 0; i < nc; i++){
 		const uint32_t id2 = (uint32_t)(cand[i].e >> 32);
 		if(cand[i].pidx == 0xFFFFFFFFu){ fprintf(stderr, " -- internal error: pair (%u,%u) missing from the batch plan --\n", pbid, id2); exit(1); }
-		const wtz_pair_summary_t *S = &b->sum[cand[i].pidx];
+		const part_t *pt = PART_OF(b, cand[i].pidx); const uint32_t li = LOCAL_OF(b, cand[i].pidx);
+		const wtz_pair_summary_t *S = &pt->sum[li];
 		if(!S->gate) continue;
 		E->used_pairs++;
 		for(uint32_t dir = 0; dir < 2; dir++){
-			const wtz_winbox_t *bx = b->boxes + b->box_off[(size_t)cand[i].pidx * 2 + dir];
+			const wtz_winbox_t *bx = pt->boxes + pt->box_off[(size_t)li * 2 + dir];
 			for(uint32_t k = 0; k < S->nwin[dir]; k++){       /* wtzmo.c:908 increments windeps over [beg,end): kept as +1/-1 marks, summed below */
 				if(bx[k].beg[0] < bx[k].end[0]){ wdiff[bx[k].beg[0]]++; wdiff[bx[k].end[0]]--; }
 			}
@@ -390,8 +406,9 @@ static void commit_query(eng_t *E, batch_t *b, uint32_t slot){
 	for(uint32_t i = 0; i < nseed; i++){
 		seed_t *s = &seeds[i];
 		const int blen = (int)E->rdlen[s->pb2];
-		const wtz_pair_summary_t *S = &b->sum[s->pidx];
-		const wtz_winbox_t *bx = b->boxes + b->box_off[(size_t)s->pidx * 2 + s->dir];
+		const part_t *pt = PART_OF(b, s->pidx); const uint32_t li = LOCAL_OF(b, s->pidx);
+		const wtz_pair_summary_t *S = &pt->sum[li];
+		const wtz_winbox_t *bx = pt->boxes + pt->box_off[(size_t)li * 2 + s->dir];
 		uint32_t ol = 0; double avg;
 		for(uint32_t k = 0; k < S->nwin[s->dir]; k++){
 			avg = (bx[k].end[0] - bx[k].beg[0]) * rep_weight(windeps, P, alen, (bx[k].beg[0] + bx[k].end[0]) / 2);
@@ -413,17 +430,18 @@ static void commit_query(eng_t *E, batch_t *b, uint32_t slot){
 			seed_t *s = &seeds[i];
 			if(s->closed){ ncand++; continue; }
 			pend_closed(pd, hx_pair_key(s->pb2, pbid));
-			const uint32_t item = b->item_of[s->pidx];
-			if(item == 0xFFFFFFFFu || b->it_dir[item] != s->dir){ fprintf(stderr, " -- internal error: alignment of (%u,%u) missing from the batch plan --\n", pbid, s->pb2); exit(1); }
+			const part_t *pt = PART_OF(b, s->pidx);
+			const uint32_t item = pt->item_of[LOCAL_OF(b, s->pidx)];
+			if(item == 0xFFFFFFFFu || pt->it_dir[item] != s->dir){ fprintf(stderr, " -- internal error: alignment of (%u,%u) missing from the batch plan --\n", pbid, s->pb2); exit(1); }
 			E->used_items++;
-			const wtz_aln_result_t *x = &b->aln[item];
+			const wtz_aln_result_t *x = &pt->aln[item];
 			if(x->n_regs == 0){ s->closed = 1; ncand++; continue; }
 			if(x->score < P->min_score || x->mat < x->aln * P->min_id) continue;
 			hit_t H; memset(&H, 0, sizeof H);
 			H.pb1 = pbid; H.pb2 = s->pb2; H.dir2 = s->dir; H.score = x->score;
 			H.tb = x->tb; H.te = x->te; H.qb = x->qb; H.qe = x->qe; H.mat = x->mat; H.mis = x->mis; H.ins = x->ins; H.del = x->del; H.aln = x->aln;
 			pend_hit(pd, &H);
-			emit_record(E, &H, b->cig + x->text_off, x->text_len, b->cig_ext);
+			emit_record(E, &H, pt->cig + x->text_off, x->text_len, pt->cig_ext);
 			{   /* dovetail / containment bookkeeping (wtzmo.c:1065-1100) */
 				const uint32_t len1 = E->rdlen[H.pb1], len2 = E->rdlen[H.pb2];
 				uint32_t x1 = (uint32_t)(H.tb < H.qb ? H.tb : H.qb);
@@ -458,6 +476,7 @@ static void commit_query(eng_t *E, batch_t *b, uint32_t slot){
 /* under E->mu: pairs of slots [s0,s1) whose candidate pair is not closed right now */
 static void plan_pairs(eng_t *E, batch_t *b, uint32_t s0, uint32_t s1){
 	b->npair = 0;
+	for(uint32_t d = 0; d < b->nparts; d++) b->parts[d].npair = 0;
 	if((size_t)b->nbq * E->stride > b->caprowpair){ b->caprowpair = (size_t)b->nbq * E->stride; b->rowpair = (uint32_t*)hx_realloc(b->rowpair, b->caprowpair * 4); }
 	for(uint32_t s = s0; s < s1; s++){
 		const uint32_t q = b->bq[s];
@@ -468,19 +487,22 @@ static void plan_pairs(eng_t *E, batch_t *b, uint32_t s0, uint32_t s1){
 			b->rowpair[(size_t)s * E->stride + k] = 0xFFFFFFFFu;
 			if((uint32_t)e == 0 || id2 == 0xFFFFFFFFu) continue;
 			if(hx_set_has(&E->closed, hx_pair_key(q, id2))) continue;
-			if(b->npair == b->cappair){ b->cappair = b->cappair ? b->cappair * 2 : 4096; b->pq = (uint32_t*)hx_realloc(b->pq, b->cappair * 4); b->pc = (uint32_t*)hx_realloc(b->pc, b->cappair * 4); }
-			b->pq[b->npair] = q; b->pc[b->npair] = id2; b->rowpair[(size_t)s * E->stride + k] = b->npair; b->npair++;
+			part_t *pt = PART_OF(b, b->npair);              /* round-robin: pair g is local pair g / nparts of part g % nparts */
+			if(pt->npair == pt->cappair){ pt->cappair = pt->cappair ? pt->cappair * 2 : 4096; pt->pq = (uint32_t*)hx_realloc(pt->pq, pt->cappair * 4); pt->pc = (uint32_t*)hx_realloc(pt->pc, pt->cappair * 4); }
+			pt->pq[pt->npair] = q; pt->pc[pt->npair] = id2; pt->npair++;
+			b->rowpair[(size_t)s * E->stride + k] = b->npair; b->npair++;
 		}
 	}
 }
 
-/* no lock held: the speculative device stages of the planned pairs. 1 = scratch pool too small, nothing changed */
-static int gpu_stages(eng_t *E, batch_t *b){
+/* no lock held: the speculative device stages of ONE part's pairs on its context. 1 = scratch pool too small, nothing changed */
+static int part_stages(eng_t *E, part_t *b){
 	const wtz_params_c *P = &E->P;
 	int rc;
+	b->nitem = 0; b->ncig = 0;
+	if(b->npair == 0) return 0;
 	b->sum = (wtz_pair_summary_t*)hx_realloc(b->sum, sizeof(wtz_pair_summary_t) * (b->npair + 1));
 	{ const double tc0 = now_s(); rc = wtz_pairs_seed(b->ctx, b->pq, b->pc, b->npair, b->sum); b->t_call[1] += now_s() - tc0; } TRY_WTZ(rc, "wtz_pairs_seed");
-	b->nitem = 0; b->ncig = 0;
 	if(!P->dot_matrix){
 		b->box_off = (uint64_t*)hx_realloc(b->box_off, 8 * ((size_t)b->npair * 2 + 1));
 		uint64_t nb = 0;
@@ -522,6 +544,18 @@ static int gpu_stages(eng_t *E, batch_t *b){
 	return 0;
 }
 
+static void *part_main(void *arg){ part_t *pt = (part_t*)arg; pt->again = part_stages(pt->E, pt); return NULL; }
+/* all parts of the range side by side (one host thread per extra part); 1 = some part's scratch pool was too small */
+static int gpu_stages(eng_t *E, batch_t *b){
+	pthread_t th[16];
+	for(uint32_t d = 1; d < b->nparts; d++){ b->parts[d].E = E; if(pthread_create(&th[d], NULL, part_main, &b->parts[d]) != 0){ fprintf(stderr, " -- cannot start a device thread --\n"); exit(1); } }
+	b->parts[0].E = E; b->parts[0].again = part_stages(E, &b->parts[0]);
+	int again = b->parts[0].again;
+	for(uint32_t d = 1; d < b->nparts; d++){ pthread_join(th[d], NULL); again |= b->parts[d].again; }
+	b->nitem = 0; for(uint32_t d = 0; d < b->nparts; d++) b->nitem += b->parts[d].nitem;
+	return again;
+}
+
 /* Candidate search (A3) depends on the read and the index only, so the next batch's request can be in flight while this
  * batch is committed on the host.  The next queries are chosen with the masks as they are NOW; whoever the commit masks or
  * saturates meanwhile is dropped / demoted when the batch is formed - the batch composition is free (any batch size gives
@@ -540,7 +574,20 @@ static void prefetch_begin(eng_t *E, batch_t *b){
 	b->pf_n = n; b->pf_cursor_end = j;
 	if(n == 0) return;
 	memset(b->pf_rows, 0, (size_t)n * E->stride * 8);
-	int rc = wtz_candidates_begin(b->ctx, b->pf_ids, n, b->pf_rows, b->pf_nr); DIE_WTZ(rc, "wtz_candidates_begin");
+	if(b->nparts == 1){
+		int rc = wtz_candidates_begin(b->ctx, b->pf_ids, n, b->pf_rows, b->pf_nr); DIE_WTZ(rc, "wtz_candidates_begin");
+	} else {
+		/* the seed lookup is pure per query: query k of the request goes to device k % nparts (the launches return at once) */
+		for(uint32_t d = 0; d < b->nparts; d++){
+			part_t *pt = &b->parts[d];
+			const uint32_t m = (n + b->nparts - 1 - d) / b->nparts;
+			if(m > pt->cq_cap){ pt->cq_cap = m; pt->cq_ids = (uint32_t*)hx_realloc(pt->cq_ids, 4 * (size_t)m); pt->cq_nr = (uint32_t*)hx_realloc(pt->cq_nr, 4 * (size_t)m); pt->cq_rows = (uint64_t*)hx_realloc(pt->cq_rows, (size_t)m * E->stride * 8); }
+			pt->cq_n = m;
+			for(uint32_t k = 0; k < m; k++){ pt->cq_ids[k] = b->pf_ids[(size_t)k * b->nparts + d]; pt->cq_nr[k] = 0; }
+			if(m) memset(pt->cq_rows, 0, (size_t)m * E->stride * 8);
+			int rc = wtz_candidates_begin(pt->ctx, pt->cq_ids, m, pt->cq_rows, pt->cq_nr); DIE_WTZ(rc, "wtz_candidates_begin");
+		}
+	}
 	b->pf_inflight = 1;
 }
 
@@ -554,12 +601,13 @@ static void process_range(eng_t *E, batch_t *b, uint32_t s0, uint32_t s1){
 	const int again = gpu_stages(E, b);
 	const double tg1 = now_s();
 	if(!again && b->npair){
-		wtz_pool_info_t pi;
-		if(wtz_pool_info(b->ctx, &pi) == WTZ_OK){
+		for(uint32_t d = 0; d < b->nparts; d++){
+			wtz_pool_info_t pi; const part_t *pt = &b->parts[d];
+			if(pt->npair == 0 || wtz_pool_info(pt->ctx, &pi) != WTZ_OK) continue;
 			pthread_mutex_lock(&E->mu);
-			E->main_cap = pi.main_cap;
-			const double bpp = (double)pi.main_used / (double)b->npair;
-			if(b->npair >= 8 && bpp > E->bytes_per_pair) E->bytes_per_pair = bpp;
+			E->main_cap = pi.main_cap * b->nparts;                  /* the range is dealt over nparts pools */
+			const double bpp = (double)pi.main_used / (double)pt->npair;
+			if(pt->npair >= 8 && bpp > E->bytes_per_pair) E->bytes_per_pair = bpp;
 			pthread_mutex_unlock(&E->mu);
 		}
 	}
@@ -575,8 +623,7 @@ static void process_range(eng_t *E, batch_t *b, uint32_t s0, uint32_t s1){
 	if(s1 == b->nbq && !b->pf_inflight){ pthread_mutex_lock(&E->mu); prefetch_begin(E, b); pthread_mutex_unlock(&E->mu); }
 	pthread_mutex_lock(&E->mu);
 	E->t_gpu += tg1 - tg0;
-	for(int k = 0; k < 5; k++){ E->t_call[k] += b->t_call[k]; b->t_call[k] = 0; }
-	E->t_io[0] += b->t_io0; b->t_io0 = 0;
+	for(uint32_t d = 0; d < b->nparts; d++){ part_t *pt = &b->parts[d]; for(int k = 0; k < 5; k++){ if(d == 0) E->t_call[k] += pt->t_call[k]; pt->t_call[k] = 0; } E->t_io[0] += pt->t_io0; pt->t_io0 = 0; }
 	while(!b->holds_turn && E->commit_seq != b->seq) pthread_cond_wait(&E->cv, &E->mu);
 	b->holds_turn = 1;
 	E->spec_pairs += b->npair; E->spec_items += b->nitem;
@@ -610,6 +657,16 @@ static void process_batch(eng_t *E, batch_t *b){
 		pthread_mutex_lock(&E->mu); E->n_ranges++; pthread_mutex_unlock(&E->mu);
 		s0 = s1;
 	}
+}
+
+/* both index builds of one more device (replicated indexes, --gpus) */
+typedef struct { wtz_ctx_t *ctx; uint32_t n_rd, K; int rc; char err[256]; } ixjob_t;
+static void *ixjob_main(void *arg){
+	ixjob_t *j = (ixjob_t*)arg; wtz_index_stats_t ist;
+	j->rc = wtz_zindex_build(j->ctx);
+	if(j->rc == WTZ_OK) j->rc = wtz_index_build(j->ctx, 0, j->n_rd, &j->K, &ist);
+	if(j->rc != WTZ_OK){ strncpy(j->err, wtz_last_error(), sizeof j->err - 1); j->err[sizeof j->err - 1] = 0; }
+	return NULL;
 }
 
 static void *pin_main(void *arg){
@@ -656,7 +713,13 @@ static void *worker_main(void *arg){
 		/* ---- candidate heaps of the batch's queries (A3) ---- */
 		if(use_pf){
 			const double tg0 = now_s();
-			int rc = wtz_candidates_end(b->ctx, b->pf_rows, b->pf_nr); DIE_WTZ(rc, "wtz_candidates_end");
+			int rc = WTZ_OK;
+			if(b->nparts == 1){ rc = wtz_candidates_end(b->ctx, b->pf_rows, b->pf_nr); DIE_WTZ(rc, "wtz_candidates_end"); }
+			else for(uint32_t d = 0; d < b->nparts; d++){
+				part_t *pt = &b->parts[d];
+				rc = wtz_candidates_end(pt->ctx, pt->cq_rows, pt->cq_nr); DIE_WTZ(rc, "wtz_candidates_end");
+				for(uint32_t k = 0; k < pt->cq_n; k++){ const size_t g = (size_t)k * b->nparts + d; memcpy(b->pf_rows + g * E->stride, pt->cq_rows + (size_t)k * E->stride, (size_t)E->stride * 8); b->pf_nr[g] = pt->cq_nr[k]; }
+			}
 			const double tg1 = now_s();
 			b->pf_inflight = 0;
 			uint32_t k = 0;
@@ -713,6 +776,7 @@ int main(int argc, char **argv){
 	char *output = NULL, *pairoutf = NULL, *statsf = NULL;
 	int c, min_rdlen = 0, overwrite = 0, dot_matrix = 0, write_contained = 1, refine = 0, gpu = 0, lib_check = 0, repeat = 1;
 	uint64_t pool_gb = 0, pool_mb = 0; float optval;
+	int n_gpus = 1; const char *gpu_list = NULL;
 	/* defaults: wtzmo.c:1543-1588 */
 	P->w = 50; P->ew = 800; P->W = 3200; P->M = 2; P->X = -5; P->O = -3; P->E = -1; P->T = -50;
 	P->min_score = 200; P->min_id = 0.5f; P->hk = 1; P->hz = 1; P->ksize = 16; P->zsize = 10;
@@ -722,7 +786,7 @@ int main(int argc, char **argv){
 	E->do_align = 1; E->n_idx = 1; E->n_job = 1; E->i_job = 0; E->max_batch = 2048; E->first_batch = 256; E->n_workers = 1;
 	pthread_mutex_init(&E->mu, NULL); pthread_cond_init(&E->cv, NULL);
 	static struct option lopts[] = { {"stats", required_argument, 0, 1000}, {"gpu", required_argument, 0, 1001}, {"pool-gb", required_argument, 0, 1002},
-		{"batch", required_argument, 0, 1003}, {"lib-check", no_argument, 0, 1004}, {"repeat", required_argument, 0, 1005}, {"first-batch", required_argument, 0, 1006}, {"workers", required_argument, 0, 1007}, {"pool-mb", required_argument, 0, 1008}, {0, 0, 0, 0} };
+		{"batch", required_argument, 0, 1003}, {"lib-check", no_argument, 0, 1004}, {"repeat", required_argument, 0, 1005}, {"first-batch", required_argument, 0, 1006}, {"workers", required_argument, 0, 1007}, {"pool-mb", required_argument, 0, 1008}, {"gpus", required_argument, 0, 1010}, {"gpu-list", required_argument, 0, 1011}, {0, 0, 0, 0} };
 	while((c = getopt_long(argc, argv, "ht:P:p:Ni:b:J:I:o:9:S:fCH:k:G:z:Z:U:y:d:r:q:l:K:A:B:r:R:L:F:W:w:e:M:X:O:E:T:s:m:nv", lopts, NULL)) != -1){
 		switch(c){
 			case 1000: statsf = optarg; break;
@@ -732,6 +796,8 @@ int main(int argc, char **argv){
 			case 1004: lib_check = 1; break;
 			case 1005: repeat = atoi(optarg); if(repeat < 1) repeat = 1; break;
 			case 1006: E->first_batch = (uint32_t)atoi(optarg); if(E->first_batch < 1) E->first_batch = 1; E->first_batch_set = 1; break;
+			case 1010: n_gpus = atoi(optarg); if(n_gpus < 1) n_gpus = 1; if(n_gpus > 8) n_gpus = 8; break;
+			case 1011: gpu_list = optarg; break;      /* explicit device ids, e.g. 0,1,2,3 (an id may repeat: two contexts on one GPU, used by the tests) */
 			case 1008: pool_mb = (uint64_t)atoll(optarg); break;      /* test hook: a pool small enough to force the batch-splitting path */
 			case 1007: E->n_workers = (uint32_t)atoi(optarg); if(E->n_workers < 1) E->n_workers = 1; if(E->n_workers > 8) E->n_workers = 8; break;
 			case 'h': return usage();
@@ -874,9 +940,21 @@ int main(int argc, char **argv){
 	  for(uint32_t i = 0; i < n_all; i++){ E->rdlen[i] = E->st.reads[i].len; rdoff[i] = E->st.reads[i].off; }
 	  for(uint32_t i = 0; i < nq; i++) tot += E->rdlen[b0 + i];
 	  E->avg_rdlen = nq ? (uint32_t)(tot / nq) : 10000; if(E->avg_rdlen == 0) E->avg_rdlen = 1; }        /* wtzmo.c:361-368 */
-	int rc = wtz_ctx_create(gpu, P, pool_bytes, &E->ctx); DIE_WTZ(rc, "wtz_ctx_create");
-	{ wtz_pool_info_t pi; if(wtz_pool_info(E->ctx, &pi) == WTZ_OK) E->main_cap = pi.main_cap; }
-	rc = wtz_upload_reads(E->ctx, E->st.bits, (E->st.nbase + 31) / 32, rdoff, E->rdlen, n_all); DIE_WTZ(rc, "wtz_upload_reads");
+	/* devices: --gpu <id> (one), --gpus N (ids 0..N-1) or --gpu-list; every device gets the reads and builds both indexes (replicated) */
+	E->ndev = 0;
+	if(gpu_list){ const char *q = gpu_list; while(*q && E->ndev < 8){ E->devs[E->ndev++] = atoi(q); while(*q && *q != ',') q++; if(*q == ',') q++; } }
+	else if(n_gpus > 1){ for(int d = 0; d < n_gpus; d++) E->devs[E->ndev++] = d; }
+	if(E->ndev == 0){ E->devs[0] = gpu; E->ndev = 1; }
+	if(E->ndev > 1 && (E->n_idx > 1 || E->n_workers > 1)){
+		fprintf(stderr, "[wtzmo-mi355x] -G / --workers run on one device: --gpus ignored\n"); E->ndev = 1;
+	}
+	int rc;
+	for(uint32_t d = 0; d < E->ndev; d++){
+		rc = wtz_ctx_create(E->devs[d], P, pool_bytes, &E->ctxs[d]); DIE_WTZ(rc, "wtz_ctx_create");
+		rc = wtz_upload_reads(E->ctxs[d], E->st.bits, (E->st.nbase + 31) / 32, rdoff, E->rdlen, n_all); DIE_WTZ(rc, "wtz_upload_reads");
+	}
+	E->ctx = E->ctxs[0];
+	{ wtz_pool_info_t pi; if(wtz_pool_info(E->ctx, &pi) == WTZ_OK) E->main_cap = pi.main_cap * E->ndev; }
 	/* page-lock the first worker's CIGAR text buffer while the indexes are built (pinning ~100 MB takes about as long as they do) */
 	pthread_t pin_th; int pin_started = 0;
 	if(E->do_align && E->cig_keep[0] == NULL){
@@ -910,6 +988,8 @@ int main(int argc, char **argv){
 		out_start(E->out);
 		if(g_hook) g_hook(rep, 0);
 		const double t0 = now_s();
+		pthread_t ixth[8]; ixjob_t ixj[8];
+		for(uint32_t d = 1; d < E->ndev; d++){ ixj[d].ctx = E->ctxs[d]; ixj[d].n_rd = n_rd; ixj[d].K = P->max_kmer_freq; if(pthread_create(&ixth[d], NULL, ixjob_main, &ixj[d]) != 0) exit(1); }
 		rc = wtz_zindex_build(E->ctx); DIE_WTZ(rc, "wtz_zindex_build");
 		/* ---- index parts (-G, wtzmo.c:1276-1303) ---- */
 		uint32_t pbbeg = 0, pbend = 0, K = P->max_kmer_freq;
@@ -946,6 +1026,7 @@ int main(int argc, char **argv){
 				free(tmp_rows); free(tmp_n);
 			}
 		}
+		for(uint32_t d = 1; d < E->ndev; d++){ pthread_join(ixth[d], NULL); if(ixj[d].rc != WTZ_OK){ fprintf(stderr, " -- index build on device %d failed: %s --\n", E->devs[d], ixj[d].err); exit(1); } }
 		/* ---- queries: pipelined batches on n_workers contexts (own stream + pool each, indexes shared) ---- */
 		if(pin_started){ pthread_join(pin_th, NULL); pin_started = 0; }
 		{
@@ -962,24 +1043,38 @@ int main(int argc, char **argv){
 			E->next_seq = 0; E->commit_seq = 0;
 			uint32_t nw = E->rows_all ? 1 : E->n_workers;          /* -G keeps per-read heaps that the commit rewrites: one batch at a time */
 			batch_t *bs = (batch_t*)calloc(nw, sizeof(batch_t)); pthread_t *th = (pthread_t*)calloc(nw, sizeof(pthread_t));
+			const uint32_t nparts = nw == 1 ? E->ndev : 1;
 			for(uint32_t w = 0; w < nw; w++){
 				bs[w].E = E;
-				bs[w].ext_base = w < 8 ? (int)w * 2 : -1;
-				if(w < 8) for(int k = 0; k < 2; k++){ bs[w].cigs[k] = E->cig_keep[w * 2 + k]; bs[w].capcigs[k] = E->cig_keep_cap[w * 2 + k]; E->cig_keep[w * 2 + k] = NULL; E->cig_keep_cap[w * 2 + k] = 0; }
-				if(w == 0) bs[w].ctx = E->ctx;
-				else { rc = wtz_ctx_clone(E->ctx, pool_bytes, &bs[w].ctx); DIE_WTZ(rc, "wtz_ctx_clone"); }
+				bs[w].nparts = nparts; bs[w].parts = (part_t*)calloc(nparts, sizeof(part_t));
+				for(uint32_t d = 0; d < nparts; d++){
+					part_t *pt = &bs[w].parts[d]; const uint32_t slot = w * nparts + d;
+					pt->ext_base = slot < 8 ? (int)slot * 2 : -1;
+					if(slot < 8) for(int k = 0; k < 2; k++){ pt->cigs[k] = E->cig_keep[slot * 2 + k]; pt->capcigs[k] = E->cig_keep_cap[slot * 2 + k]; E->cig_keep[slot * 2 + k] = NULL; E->cig_keep_cap[slot * 2 + k] = 0; }
+					if(w == 0) pt->ctx = E->ctxs[d];
+					else { rc = wtz_ctx_clone(E->ctx, pool_bytes, &pt->ctx); DIE_WTZ(rc, "wtz_ctx_clone"); }
+				}
+				bs[w].ctx = bs[w].parts[0].ctx;
 			}
 			for(uint32_t w = 1; w < nw; w++) pthread_create(&th[w], NULL, worker_main, &bs[w]);
 			worker_main(&bs[0]);
 			for(uint32_t w = 1; w < nw; w++) pthread_join(th[w], NULL);
 			for(uint32_t w = 0; w < nw; w++){
-				wtz_counters_t cw; wtz_get_counters(bs[w].ctx, &cw);
-				if(w){ E->extra_ms[0] += cw.ms_candidates; E->extra_ms[1] += cw.ms_pairs; E->extra_ms[2] += cw.ms_winalign; E->extra_ms[3] += cw.ms_stitch; E->extra_ms[4] += cw.ms_ext; E->extra_ms[5] += cw.ms_gap;
-					E->extra_u64[0] += cw.cells_shift; E->extra_u64[1] += cw.cells_fixed; E->extra_u64[2] += cw.cells_global; E->extra_u64[3] += cw.bytes_seed_algo; E->extra_u64[4] += cw.n_extjobs;
-					if(cw.pool_peak > E->extra_u64[5]) E->extra_u64[5] = cw.pool_peak;
-					wtz_ctx_destroy(bs[w].ctx); }
-				free(bs[w].bq); free(bs[w].want); free(bs[w].ids); free(bs[w].rows); free(bs[w].nrow); free(bs[w].pq); free(bs[w].pc); free(bs[w].rowpair); free(bs[w].sum);
-				free(bs[w].box_off); free(bs[w].boxes); free(bs[w].item_of); free(bs[w].it_pair); free(bs[w].it_dir); free(bs[w].aln); for(int k = 0; k < 2; k++){ if(w < 8){ E->cig_keep[w * 2 + k] = bs[w].cigs[k]; E->cig_keep_cap[w * 2 + k] = bs[w].capcigs[k]; } else wtz_host_free(bs[w].cigs[k]); } free(bs[w].pf_ids); free(bs[w].pf_rows); free(bs[w].pf_nr);
+				for(uint32_t d = 0; d < nparts; d++){
+					part_t *pt = &bs[w].parts[d]; const uint32_t slot = w * nparts + d;
+					if(w || d){      /* counters of the other contexts: work adds up, kernel times of parallel devices do not (the longest counts) */
+						wtz_counters_t cw; wtz_get_counters(pt->ctx, &cw);
+						if(w){ E->extra_ms[0] += cw.ms_candidates; E->extra_ms[1] += cw.ms_pairs; E->extra_ms[2] += cw.ms_winalign; E->extra_ms[3] += cw.ms_stitch; E->extra_ms[4] += cw.ms_ext; E->extra_ms[5] += cw.ms_gap; }
+						E->extra_u64[0] += cw.cells_shift; E->extra_u64[1] += cw.cells_fixed; E->extra_u64[2] += cw.cells_global; E->extra_u64[3] += cw.bytes_seed_algo; E->extra_u64[4] += cw.n_extjobs;
+						if(cw.pool_peak > E->extra_u64[5]) E->extra_u64[5] = cw.pool_peak;
+						if(w) wtz_ctx_destroy(pt->ctx); else wtz_reset_counters(pt->ctx);
+					}
+					free(pt->cq_ids); free(pt->cq_nr); free(pt->cq_rows);
+					free(pt->pq); free(pt->pc); free(pt->sum); free(pt->box_off); free(pt->boxes); free(pt->item_of); free(pt->it_pair); free(pt->it_dir); free(pt->aln);
+					for(int k = 0; k < 2; k++){ if(slot < 8){ E->cig_keep[slot * 2 + k] = pt->cigs[k]; E->cig_keep_cap[slot * 2 + k] = pt->capcigs[k]; } else wtz_host_free(pt->cigs[k]); }
+				}
+				free(bs[w].parts);
+				free(bs[w].bq); free(bs[w].want); free(bs[w].ids); free(bs[w].rows); free(bs[w].nrow); free(bs[w].rowpair); free(bs[w].pf_ids); free(bs[w].pf_rows); free(bs[w].pf_nr);
 			}
 			free(bs); free(th);
 		}
@@ -1021,6 +1116,6 @@ int main(int argc, char **argv){
 		fclose(pf); free(all);
 	}
 	for(int w = 0; w < 16; w++) wtz_host_free(E->cig_keep[w]);
-	wtz_ctx_destroy(E->ctx);
+	for(uint32_t d = 0; d < E->ndev; d++) wtz_ctx_destroy(E->ctxs[d]);
 	return 0;
 }

@@ -85,6 +85,15 @@ def test_two_worker_contexts_same_output(name, emul_exe, tmp_path):
     assert md5 == case["md5_full"] and cont == case["md5_contained"]
 
 
+@pytest.mark.parametrize("name,devs", [("zmo", "0,0"), ("dmo", "0,0"), ("zmo", "0,0,0"), ("zmo_I", "0,0")])
+def test_multi_device_central_commit(name, devs, emul_exe, tmp_path):
+    """--gpus N / --gpu-list: one process, one context per device, the pairs of every range dealt round-robin to the devices, ONE
+    in-order commit: the output equals `wtzmo -t 1` (the plain golden, not the -P stripes) for any number of devices."""
+    case = manifest()["cases"][name]
+    md5, cont, _ = run_wtzmo_like(emul_exe, case, tmp_path, extra=["--gpu-list", devs, "--batch", "16"])
+    assert md5 == case["md5_full"] and cont == case["md5_contained"]
+
+
 def test_word_level_base_packing(tmp_path):
     """wtz_pack32 (two 64-bit loads + funnel shift per 32 bases, both strands, complement) == 32 single-base extractions."""
     exe = os.path.join(str(tmp_path), "check_pack32")

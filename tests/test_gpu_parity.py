@@ -47,6 +47,15 @@ def test_two_worker_contexts_same_output(name, gpu_exe, tmp_path):
     assert md5 == case["md5_full"] and cont == case["md5_contained"]
 
 
+@pytest.mark.parametrize("name,devs", [("zmo", "0,0"), ("dmo", "0,0"), ("zmo_n", "0,0,0")])
+def test_multi_device_central_commit(name, devs, gpu_exe, tmp_path):
+    """--gpu-list 0,0: two (three) contexts on this box's one GPU stand in for --gpus N: pairs dealt round-robin to the contexts, both
+    indexes built per context, ONE in-order commit -> the plain `wtzmo -t 1` golden, not the union of -P stripes."""
+    case = manifest()["cases"][name]
+    md5, cont, _ = run_wtzmo_like(gpu_exe, case, tmp_path, extra=["--gpu-list", devs, "--pool-mb", "8192"])
+    assert md5 == case["md5_full"] and cont == case["md5_contained"]
+
+
 def test_scratch_pool_exhaustion_is_survived_or_loud(gpu_exe, tmp_path):
     """WTZ_E_POOL on the device: a batch that does not fit is halved (same output); a pool too small for one query is a loud
     exit(1) - never a memory fault, never a wrong file."""
