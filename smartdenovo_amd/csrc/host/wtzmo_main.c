@@ -90,12 +90,28 @@ typedef struct eng_s {
 	double extra_ms[6]; uint64_t extra_u64[6];      /* counters of the cloned contexts */
 } eng_t;
 
+/* ---- ranks: with one process per GPU (torchrun; bench.py / tests set the exchange hooks through wtzmo_set_dist) the parts of rank 0's
+ * batches live in the OTHER PROCESSES: rank 0 plans and commits (the order-dependent part of `wtzmo -t 1` is one sequential
+ * stream by definition), every rank runs the pure device stages of its share of the pairs / candidate requests on its own GPU with
+ * reads and both indexes replicated, and the results travel to rank 0 (RCCL send / recv when the hooks sit on the nccl backend).
+ * One .ovl, written by rank 0, identical to `wtzmo -t 1` for any number of ranks; total work is fixed (strong scaling). ---- */
+typedef void (*wtz_dist_bcast_fn)(void *buf, uint64_t nbytes);                   /* from rank 0, same nbytes on every rank */
+typedef void (*wtz_dist_send_fn)(const void *buf, uint64_t nbytes, int dst);
+typedef void (*wtz_dist_recv_fn)(void *buf, uint64_t nbytes, int src);
+static struct { int rank, world; wtz_dist_bcast_fn bcast; wtz_dist_send_fn send; wtz_dist_recv_fn recv; } g_dist = { 0, 1, NULL, NULL, NULL };
+void wtzmo_set_dist(int rank, int world, wtz_dist_bcast_fn b, wtz_dist_send_fn sd, wtz_dist_recv_fn rv){
+	g_dist.rank = rank; g_dist.world = world < 1 ? 1 : world; g_dist.bcast = b; g_dist.send = sd; g_dist.recv = rv;
+}
+#define WTZ_DIST_MAX 16
+enum { WTZ_CMD_DONE = 1, WTZ_CMD_PAIRS = 2, WTZ_CMD_CAND_BEGIN = 3, WTZ_CMD_CAND_END = 4 };
+typedef struct { uint64_t cmd, count[WTZ_DIST_MAX]; } wtz_dist_hdr_t;
+
 /* The pairs of a range are dealt round-robin to the PARTS of a batch, one part per GPU (--gpus N; one part otherwise): pair g of the
  * plan is local pair g / nparts of part g % nparts.  Every device stage is pure in its pairs, so a part runs pair seeding, windows,
  * alignment and CIGAR rendering of its share on its own context, all parts side by side on their own host threads; the commit reads
  * the results through PART_OF / LOCAL_OF in the plan's order, i.e. the output does not depend on the number of parts. */
 typedef struct {
-	wtz_ctx_t *ctx;
+	wtz_ctx_t *ctx; int remote;                 /* remote > 0: the part is computed by that rank (ctx == NULL here) */
 	uint32_t *pq, *pc; uint32_t npair, cappair;
 	wtz_pair_summary_t *sum; uint64_t *box_off; wtz_winbox_t *boxes; uint64_t nbox, capbox;
 	uint32_t *item_of; uint32_t *it_pair; uint8_t *it_dir; uint32_t nitem; wtz_aln_result_t *aln; char *cig; uint64_t ncig;
@@ -495,6 +511,35 @@ static void plan_pairs(eng_t *E, batch_t *b, uint32_t s0, uint32_t s1){
 	}
 }
 
+/* the alignment items of a part: the best strand of every pair whose chain passes -r (wtzmo.c:913-914); a pure function of the summaries */
+static void part_plan_items(eng_t *E, part_t *b){
+	const wtz_params_c *P = &E->P;
+	b->item_of = (uint32_t*)hx_realloc(b->item_of, 4 * ((size_t)b->npair + 1));
+	b->it_pair = (uint32_t*)hx_realloc(b->it_pair, 4 * ((size_t)b->npair + 1));
+	b->it_dir = (uint8_t*)hx_realloc(b->it_dir, (size_t)b->npair + 1);
+	b->nitem = 0;
+	for(uint32_t i = 0; i < b->npair; i++){
+		b->item_of[i] = 0xFFFFFFFFu;
+		if(!E->do_align || !b->sum[i].gate) continue;
+		const uint32_t dir = (b->sum[i].ovl[0] < b->sum[i].ovl[1]);
+		if(b->sum[i].ovl[dir] < P->ztot) continue;
+		b->item_of[i] = b->nitem; b->it_pair[b->nitem] = i; b->it_dir[b->nitem] = (uint8_t)dir; b->nitem++;
+	}
+}
+/* the page-locked CIGAR text buffer of the part for this range (two alternate: the records of the previous range may still be
+ * waiting for the writer thread inside the other one); 0 = cannot allocate */
+static int part_text_buffer(part_t *b, uint64_t tot){
+	const int sel = (b->cig_sel ^= 1);
+	b->cig_ext = b->ext_base >= 0 ? b->ext_base + sel : -1;
+	{ const double tw0 = now_s(); out_wait_ext(b->cig_ext); b->t_io0 += now_s() - tw0; }
+	if(tot > b->capcigs[sel]){
+		uint64_t cap = b->capcigs[sel] ? b->capcigs[sel] : ((uint64_t)16 << 20); while(cap < tot) cap += cap / 2;
+		wtz_host_free(b->cigs[sel]); b->cigs[sel] = (char*)wtz_host_alloc(cap + 1); b->capcigs[sel] = cap;
+		if(!b->cigs[sel]){ fprintf(stderr, "[wtzmo-mi355x] cannot allocate %llu bytes of page-locked memory for the CIGAR text\n", (unsigned long long)cap); return 0; }
+	}
+	b->cig = b->cigs[sel];
+	return 1;
+}
 /* no lock held: the speculative device stages of ONE part's pairs on its context. 1 = scratch pool too small, nothing changed */
 static int part_stages(eng_t *E, part_t *b){
 	const wtz_params_c *P = &E->P;
@@ -510,33 +555,12 @@ static int part_stages(eng_t *E, part_t *b){
 		b->box_off[(size_t)b->npair * 2] = nb; b->nbox = nb;
 		if(nb > b->capbox){ b->capbox = nb; b->boxes = (wtz_winbox_t*)hx_realloc(b->boxes, sizeof(wtz_winbox_t) * nb); }
 		{ const double tc0 = now_s(); rc = wtz_pairs_windows(b->ctx, b->boxes, nb); b->t_call[2] += now_s() - tc0; } TRY_WTZ(rc, "wtz_pairs_windows");
-		b->item_of = (uint32_t*)hx_realloc(b->item_of, 4 * ((size_t)b->npair + 1));
-		b->it_pair = (uint32_t*)hx_realloc(b->it_pair, 4 * ((size_t)b->npair + 1));
-		b->it_dir = (uint8_t*)hx_realloc(b->it_dir, (size_t)b->npair + 1);
-		for(uint32_t i = 0; i < b->npair; i++){
-			b->item_of[i] = 0xFFFFFFFFu;
-			if(!E->do_align || !b->sum[i].gate) continue;
-			const uint32_t dir = (b->sum[i].ovl[0] < b->sum[i].ovl[1]);
-			if(b->sum[i].ovl[dir] < P->ztot) continue;
-			b->item_of[i] = b->nitem; b->it_pair[b->nitem] = i; b->it_dir[b->nitem] = (uint8_t)dir; b->nitem++;
-		}
+		part_plan_items(E, b);
 		if(b->nitem){
 			b->aln = (wtz_aln_result_t*)hx_realloc(b->aln, sizeof(wtz_aln_result_t) * b->nitem);
 			{ const double tc0 = now_s(); rc = wtz_pairs_align(b->ctx, b->it_pair, b->it_dir, b->nitem, b->aln); b->t_call[3] += now_s() - tc0; } TRY_WTZ(rc, "wtz_pairs_align");
 			uint64_t tot = 0; for(uint32_t i = 0; i < b->nitem; i++) tot += b->aln[i].text_len;
-			{
-				/* the other page-locked buffer of this worker: the records of the previous batch may still be waiting for the writer
-				 * thread inside the first one.  Grown geometrically; both are kept for every later batch and step. */
-				const int sel = (b->cig_sel ^= 1);
-				b->cig_ext = b->ext_base >= 0 ? b->ext_base + sel : -1;
-				{ const double tw0 = now_s(); out_wait_ext(b->cig_ext); b->t_io0 += now_s() - tw0; }
-				if(tot > b->capcigs[sel]){
-					uint64_t cap = b->capcigs[sel] ? b->capcigs[sel] : ((uint64_t)16 << 20); while(cap < tot) cap += cap / 2;
-					wtz_host_free(b->cigs[sel]); b->cigs[sel] = (char*)wtz_host_alloc(cap + 1); b->capcigs[sel] = cap;
-					if(!b->cigs[sel]){ fprintf(stderr, "[wtzmo-mi355x] cannot allocate %llu bytes of page-locked memory for the CIGAR text\n", (unsigned long long)cap); return 1; }
-				}
-				b->cig = b->cigs[sel];
-			}
+			if(!part_text_buffer(b, tot)) return 1;
 			{ const double tc0 = now_s(); rc = wtz_fetch_cigar_text(b->ctx, b->cig, tot); b->t_call[4] += now_s() - tc0; } TRY_WTZ(rc, "wtz_fetch_cigar_text");     /* rendered on the device */
 			b->ncig = tot;
 		}
@@ -546,7 +570,9 @@ static int part_stages(eng_t *E, part_t *b){
 
 static void *part_main(void *arg){ part_t *pt = (part_t*)arg; pt->again = part_stages(pt->E, pt); return NULL; }
 /* all parts of the range side by side (one host thread per extra part); 1 = some part's scratch pool was too small */
+static int gpu_stages_ranks(eng_t *E, batch_t *b);
 static int gpu_stages(eng_t *E, batch_t *b){
+	if(g_dist.world > 1) return gpu_stages_ranks(E, b);
 	pthread_t th[16];
 	for(uint32_t d = 1; d < b->nparts; d++){ b->parts[d].E = E; if(pthread_create(&th[d], NULL, part_main, &b->parts[d]) != 0){ fprintf(stderr, " -- cannot start a device thread --\n"); exit(1); } }
 	b->parts[0].E = E; b->parts[0].again = part_stages(E, &b->parts[0]);
@@ -554,6 +580,78 @@ static int gpu_stages(eng_t *E, batch_t *b){
 	for(uint32_t d = 1; d < b->nparts; d++){ pthread_join(th[d], NULL); again |= b->parts[d].again; }
 	b->nitem = 0; for(uint32_t d = 0; d < b->nparts; d++) b->nitem += b->parts[d].nitem;
 	return again;
+}
+
+/* rank 0: part r of the range is computed by rank r (part 0 here, meanwhile) */
+static int gpu_stages_ranks(eng_t *E, batch_t *b){
+	const int dm = E->P.dot_matrix;
+	wtz_dist_hdr_t h; memset(&h, 0, sizeof h); h.cmd = WTZ_CMD_PAIRS;
+	for(uint32_t r = 0; r < b->nparts; r++) h.count[r] = b->parts[r].npair;
+	g_dist.bcast(&h, sizeof h);
+	for(uint32_t r = 1; r < b->nparts; r++){ part_t *pt = &b->parts[r]; if(pt->npair){ g_dist.send(pt->pq, 4 * (uint64_t)pt->npair, (int)r); g_dist.send(pt->pc, 4 * (uint64_t)pt->npair, (int)r); } }
+	b->parts[0].E = E;
+	int again = b->parts[0].again = part_stages(E, &b->parts[0]);
+	for(uint32_t r = 1; r < b->nparts; r++){
+		part_t *pt = &b->parts[r];
+		uint64_t rh[4]; g_dist.recv(rh, sizeof rh, (int)r);
+		pt->nitem = 0; pt->ncig = 0; pt->again = (int)rh[0];
+		if(rh[0]){ again = 1; continue; }
+		if(pt->npair == 0) continue;
+		pt->sum = (wtz_pair_summary_t*)hx_realloc(pt->sum, sizeof(wtz_pair_summary_t) * (pt->npair + 1));
+		g_dist.recv(pt->sum, sizeof(wtz_pair_summary_t) * (uint64_t)pt->npair, (int)r);
+		if(dm) continue;
+		pt->box_off = (uint64_t*)hx_realloc(pt->box_off, 8 * ((size_t)pt->npair * 2 + 1));
+		uint64_t nb = 0;
+		for(uint32_t i = 0; i < pt->npair; i++) for(int d = 0; d < 2; d++){ pt->box_off[(size_t)i * 2 + d] = nb; nb += pt->sum[i].nwin[d]; }
+		pt->box_off[(size_t)pt->npair * 2] = nb; pt->nbox = nb;
+		if(nb != rh[1]){ fprintf(stderr, " -- rank %u reports %llu windows, its summaries say %llu --\n", r, (unsigned long long)rh[1], (unsigned long long)nb); exit(1); }
+		if(nb > pt->capbox){ pt->capbox = nb; pt->boxes = (wtz_winbox_t*)hx_realloc(pt->boxes, sizeof(wtz_winbox_t) * nb); }
+		if(nb) g_dist.recv(pt->boxes, sizeof(wtz_winbox_t) * nb, (int)r);
+		part_plan_items(E, pt);
+		if(pt->nitem != rh[2]){ fprintf(stderr, " -- rank %u aligned %llu items, the plan has %u --\n", r, (unsigned long long)rh[2], pt->nitem); exit(1); }
+		if(pt->nitem){
+			pt->aln = (wtz_aln_result_t*)hx_realloc(pt->aln, sizeof(wtz_aln_result_t) * pt->nitem);
+			g_dist.recv(pt->aln, sizeof(wtz_aln_result_t) * (uint64_t)pt->nitem, (int)r);
+			if(!part_text_buffer(pt, rh[3])) exit(1);
+			if(rh[3]) g_dist.recv(pt->cig, rh[3], (int)r);
+			pt->ncig = rh[3];
+		}
+	}
+	b->nitem = 0; for(uint32_t d = 0; d < b->nparts; d++) b->nitem += b->parts[d].nitem;
+	return again;
+}
+
+/* ranks > 0: serve rank 0's requests with this GPU until the overlap phase is over */
+static void remote_loop(eng_t *E, part_t *pt){
+	const int dm = E->P.dot_matrix; const int me = g_dist.rank;
+	pt->E = E;
+	for(;;){
+		wtz_dist_hdr_t h; g_dist.bcast(&h, sizeof h);
+		if(h.cmd == WTZ_CMD_DONE) break;
+		const uint32_t n = (uint32_t)h.count[me];
+		if(h.cmd == WTZ_CMD_PAIRS){
+			if(n > pt->cappair){ pt->cappair = n; pt->pq = (uint32_t*)hx_realloc(pt->pq, 4 * (size_t)n); pt->pc = (uint32_t*)hx_realloc(pt->pc, 4 * (size_t)n); }
+			if(n){ g_dist.recv(pt->pq, 4 * (uint64_t)n, 0); g_dist.recv(pt->pc, 4 * (uint64_t)n, 0); }
+			pt->npair = n;
+			const int again = part_stages(E, pt);
+			uint64_t rh[4] = { (uint64_t)again, pt->nbox, pt->nitem, pt->ncig };
+			if(n == 0 || dm){ rh[1] = 0; rh[2] = 0; rh[3] = 0; }
+			g_dist.send(rh, sizeof rh, 0);
+			if(again || n == 0) continue;
+			g_dist.send(pt->sum, sizeof(wtz_pair_summary_t) * (uint64_t)n, 0);
+			if(dm) continue;
+			if(pt->nbox) g_dist.send(pt->boxes, sizeof(wtz_winbox_t) * pt->nbox, 0);
+			if(pt->nitem){ g_dist.send(pt->aln, sizeof(wtz_aln_result_t) * (uint64_t)pt->nitem, 0); if(pt->ncig) g_dist.send(pt->cig, pt->ncig, 0); }
+		} else if(h.cmd == WTZ_CMD_CAND_BEGIN){
+			if(n > pt->cq_cap){ pt->cq_cap = n; pt->cq_ids = (uint32_t*)hx_realloc(pt->cq_ids, 4 * (size_t)n); pt->cq_nr = (uint32_t*)hx_realloc(pt->cq_nr, 4 * (size_t)n); pt->cq_rows = (uint64_t*)hx_realloc(pt->cq_rows, (size_t)n * E->stride * 8); }
+			pt->cq_n = n;
+			if(n){ g_dist.recv(pt->cq_ids, 4 * (uint64_t)n, 0); memset(pt->cq_rows, 0, (size_t)n * E->stride * 8); memset(pt->cq_nr, 0, 4 * (size_t)n); }
+			int rc = wtz_candidates_begin(pt->ctx, pt->cq_ids, n, pt->cq_rows, pt->cq_nr); DIE_WTZ(rc, "wtz_candidates_begin");
+		} else if(h.cmd == WTZ_CMD_CAND_END){
+			int rc = wtz_candidates_end(pt->ctx, pt->cq_rows, pt->cq_nr); DIE_WTZ(rc, "wtz_candidates_end");
+			if(pt->cq_n){ g_dist.send(pt->cq_rows, (uint64_t)pt->cq_n * E->stride * 8, 0); g_dist.send(pt->cq_nr, 4 * (uint64_t)pt->cq_n, 0); }
+		} else { fprintf(stderr, " -- rank %d: unknown request %llu --\n", me, (unsigned long long)h.cmd); exit(1); }
+	}
 }
 
 /* Candidate search (A3) depends on the read and the index only, so the next batch's request can be in flight while this
@@ -577,7 +675,12 @@ static void prefetch_begin(eng_t *E, batch_t *b){
 	if(b->nparts == 1){
 		int rc = wtz_candidates_begin(b->ctx, b->pf_ids, n, b->pf_rows, b->pf_nr); DIE_WTZ(rc, "wtz_candidates_begin");
 	} else {
-		/* the seed lookup is pure per query: query k of the request goes to device k % nparts (the launches return at once) */
+		/* the seed lookup is pure per query: query k of the request goes to device / rank k % nparts (the launches return at once) */
+		if(g_dist.world > 1){
+			wtz_dist_hdr_t h; memset(&h, 0, sizeof h); h.cmd = WTZ_CMD_CAND_BEGIN;
+			for(uint32_t d = 0; d < b->nparts; d++) h.count[d] = (n + b->nparts - 1 - d) / b->nparts;
+			g_dist.bcast(&h, sizeof h);
+		}
 		for(uint32_t d = 0; d < b->nparts; d++){
 			part_t *pt = &b->parts[d];
 			const uint32_t m = (n + b->nparts - 1 - d) / b->nparts;
@@ -585,6 +688,7 @@ static void prefetch_begin(eng_t *E, batch_t *b){
 			pt->cq_n = m;
 			for(uint32_t k = 0; k < m; k++){ pt->cq_ids[k] = b->pf_ids[(size_t)k * b->nparts + d]; pt->cq_nr[k] = 0; }
 			if(m) memset(pt->cq_rows, 0, (size_t)m * E->stride * 8);
+			if(pt->remote){ if(m) g_dist.send(pt->cq_ids, 4 * (uint64_t)m, pt->remote); continue; }
 			int rc = wtz_candidates_begin(pt->ctx, pt->cq_ids, m, pt->cq_rows, pt->cq_nr); DIE_WTZ(rc, "wtz_candidates_begin");
 		}
 	}
@@ -717,7 +821,9 @@ static void *worker_main(void *arg){
 			if(b->nparts == 1){ rc = wtz_candidates_end(b->ctx, b->pf_rows, b->pf_nr); DIE_WTZ(rc, "wtz_candidates_end"); }
 			else for(uint32_t d = 0; d < b->nparts; d++){
 				part_t *pt = &b->parts[d];
-				rc = wtz_candidates_end(pt->ctx, pt->cq_rows, pt->cq_nr); DIE_WTZ(rc, "wtz_candidates_end");
+				if(d == 0 && g_dist.world > 1){ wtz_dist_hdr_t h; memset(&h, 0, sizeof h); h.cmd = WTZ_CMD_CAND_END; g_dist.bcast(&h, sizeof h); }
+				if(pt->remote){ if(pt->cq_n){ g_dist.recv(pt->cq_rows, (uint64_t)pt->cq_n * E->stride * 8, pt->remote); g_dist.recv(pt->cq_nr, 4 * (uint64_t)pt->cq_n, pt->remote); } }
+				else { rc = wtz_candidates_end(pt->ctx, pt->cq_rows, pt->cq_nr); DIE_WTZ(rc, "wtz_candidates_end"); }
 				for(uint32_t k = 0; k < pt->cq_n; k++){ const size_t g = (size_t)k * b->nparts + d; memcpy(b->pf_rows + g * E->stride, pt->cq_rows + (size_t)k * E->stride, (size_t)E->stride * 8); b->pf_nr[g] = pt->cq_nr[k]; }
 			}
 			const double tg1 = now_s();
@@ -945,6 +1051,10 @@ int main(int argc, char **argv){
 	if(gpu_list){ const char *q = gpu_list; while(*q && E->ndev < 8){ E->devs[E->ndev++] = atoi(q); while(*q && *q != ',') q++; if(*q == ',') q++; } }
 	else if(n_gpus > 1){ for(int d = 0; d < n_gpus; d++) E->devs[E->ndev++] = d; }
 	if(E->ndev == 0){ E->devs[0] = gpu; E->ndev = 1; }
+	if(g_dist.world > 1){
+		if(g_dist.world > WTZ_DIST_MAX || !g_dist.bcast || !g_dist.send || !g_dist.recv){ fprintf(stderr, " -- wtzmo_set_dist: bad rank setup --\n"); exit(1); }
+		if(E->n_idx > 1 || E->n_workers > 1 || E->ndev > 1 || E->n_job > 1){ fprintf(stderr, " -- ranks (one process per GPU) exclude -G, -P, --workers and --gpus --\n"); exit(1); }
+	}
 	if(E->ndev > 1 && (E->n_idx > 1 || E->n_workers > 1)){
 		fprintf(stderr, "[wtzmo-mi355x] -G / --workers run on one device: --gpus ignored\n"); E->ndev = 1;
 	}
@@ -1043,7 +1153,7 @@ int main(int argc, char **argv){
 			E->next_seq = 0; E->commit_seq = 0;
 			uint32_t nw = E->rows_all ? 1 : E->n_workers;          /* -G keeps per-read heaps that the commit rewrites: one batch at a time */
 			batch_t *bs = (batch_t*)calloc(nw, sizeof(batch_t)); pthread_t *th = (pthread_t*)calloc(nw, sizeof(pthread_t));
-			const uint32_t nparts = nw == 1 ? E->ndev : 1;
+			const uint32_t nparts = g_dist.world > 1 ? (uint32_t)g_dist.world : (nw == 1 ? E->ndev : 1);
 			for(uint32_t w = 0; w < nw; w++){
 				bs[w].E = E;
 				bs[w].nparts = nparts; bs[w].parts = (part_t*)calloc(nparts, sizeof(part_t));
@@ -1051,18 +1161,26 @@ int main(int argc, char **argv){
 					part_t *pt = &bs[w].parts[d]; const uint32_t slot = w * nparts + d;
 					pt->ext_base = slot < 8 ? (int)slot * 2 : -1;
 					if(slot < 8) for(int k = 0; k < 2; k++){ pt->cigs[k] = E->cig_keep[slot * 2 + k]; pt->capcigs[k] = E->cig_keep_cap[slot * 2 + k]; E->cig_keep[slot * 2 + k] = NULL; E->cig_keep_cap[slot * 2 + k] = 0; }
-					if(w == 0) pt->ctx = E->ctxs[d];
+					if(g_dist.world > 1){ pt->remote = (int)d; pt->ctx = d == 0 ? E->ctx : NULL; }       /* part r belongs to rank r */
+					else if(w == 0) pt->ctx = E->ctxs[d];
 					else { rc = wtz_ctx_clone(E->ctx, pool_bytes, &pt->ctx); DIE_WTZ(rc, "wtz_ctx_clone"); }
 				}
 				bs[w].ctx = bs[w].parts[0].ctx;
 			}
-			for(uint32_t w = 1; w < nw; w++) pthread_create(&th[w], NULL, worker_main, &bs[w]);
-			worker_main(&bs[0]);
-			for(uint32_t w = 1; w < nw; w++) pthread_join(th[w], NULL);
+			if(g_dist.rank > 0){
+				/* this rank serves rank 0's requests with its GPU; plan, commit and output are rank 0's */
+				part_t *me = &bs[0].parts[0]; me->ctx = E->ctx; me->remote = 0; me->ext_base = -1;
+				remote_loop(E, me);
+			} else {
+				for(uint32_t w = 1; w < nw; w++) pthread_create(&th[w], NULL, worker_main, &bs[w]);
+				worker_main(&bs[0]);
+				for(uint32_t w = 1; w < nw; w++) pthread_join(th[w], NULL);
+				if(g_dist.world > 1){ wtz_dist_hdr_t h; memset(&h, 0, sizeof h); h.cmd = WTZ_CMD_DONE; g_dist.bcast(&h, sizeof h); }
+			}
 			for(uint32_t w = 0; w < nw; w++){
 				for(uint32_t d = 0; d < nparts; d++){
 					part_t *pt = &bs[w].parts[d]; const uint32_t slot = w * nparts + d;
-					if(w || d){      /* counters of the other contexts: work adds up, kernel times of parallel devices do not (the longest counts) */
+					if((w || d) && pt->ctx){      /* counters of the other contexts: work adds up, kernel times of parallel devices do not (the longest counts) */
 						wtz_counters_t cw; wtz_get_counters(pt->ctx, &cw);
 						if(w){ E->extra_ms[0] += cw.ms_candidates; E->extra_ms[1] += cw.ms_pairs; E->extra_ms[2] += cw.ms_winalign; E->extra_ms[3] += cw.ms_stitch; E->extra_ms[4] += cw.ms_ext; E->extra_ms[5] += cw.ms_gap; }
 						E->extra_u64[0] += cw.cells_shift; E->extra_u64[1] += cw.cells_fixed; E->extra_u64[2] += cw.cells_global; E->extra_u64[3] += cw.bytes_seed_algo; E->extra_u64[4] += cw.n_extjobs;

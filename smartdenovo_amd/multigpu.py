@@ -1,29 +1,68 @@
 """Multi-GPU plumbing of the overlap path: one process per GPU (torch.distributed; backend "nccl" is RCCL on ROCm).
 
-The path shards by QUERY (contract 2 "job striping"): rank g of N runs the reference's own
-`wtzmo -P N -p g` striping (wtzmo.c:1291,1314) on reads + indexes replicated in its own HBM, so there is no data-path
-collective; the only exchange is the gather of the finished overlap records, done here with all_gather over xGMI.
-The same functions run with the gloo backend on CPU tensors (tests/test_multi_rank_gloo.py)."""
+Contract (option 1 "central commit"): the order-dependent part of `wtzmo -t 1` (closed pairs, contained-read
+masking, coverage saturation, record order) is one sequential stream by definition, so rank 0 plans and commits; the PURE device
+stages - seed lookup per query, pair seeding / windows / alignment / CIGAR rendering per pair - are dealt round-robin over the
+ranks, each with the reads and both indexes replicated in its own HBM.  Requests (read ids, pair lists: a few bytes per pair) go
+out from rank 0, results (48-byte pair summaries, window boxes, 72-byte alignment results, the CIGAR text) come back with
+send / recv over xGMI.  One .ovl, written by rank 0, identical to `wtzmo -t 1` for ANY number of ranks; total work is fixed.
+
+The C host driver (smartdenovo_amd/csrc/host/wtzmo_main.c, loaded as libwtzmo_host.so) drives the exchange through three hooks
+set with wtzmo_set_dist(rank, world, bcast, send, recv); `RankExchange` implements them on torch.distributed.  The same class
+runs on the gloo backend with CPU tensors (tests/test_multi_rank_gloo.py)."""
 from __future__ import annotations
+
+import ctypes as C
 
 import torch
 
+BCAST = C.CFUNCTYPE(None, C.c_void_p, C.c_uint64)
+SEND = C.CFUNCTYPE(None, C.c_void_p, C.c_uint64, C.c_int)
+RECV = C.CFUNCTYPE(None, C.c_void_p, C.c_uint64, C.c_int)
+_CHUNK = 1 << 30      # bytes per message (int32 element counts inside the collectives)
 
-def stripe_argv(world: int, rank: int):
-    """argv fragment that makes one wtzmo process take its stripe of the queries."""
-    return ["-P", str(world), "-p", str(rank)] if world > 1 else []
+
+def _host_view(ptr, n):
+    return torch.frombuffer((C.c_char * n).from_address(ptr), dtype=torch.uint8)
 
 
-def gather_records(dist, data: bytes, device: str):
-    """All-gather variable-length record blobs; returns the list of per-rank blobs (on every rank)."""
-    world = dist.get_world_size()
-    payload = torch.frombuffer(bytearray(data or b"\n"), dtype=torch.uint8).to(device)
-    n = torch.tensor([len(data)], dtype=torch.int64, device=device)
-    sizes = [torch.zeros_like(n) for _ in range(world)]
-    dist.all_gather(sizes, n)
-    mx = max(1, max(int(s.item()) for s in sizes))
-    pad = torch.zeros(mx, dtype=torch.uint8, device=device)
-    pad[:payload.numel()] = payload
-    bufs = [torch.empty(mx, dtype=torch.uint8, device=device) for _ in range(world)]
-    dist.all_gather(bufs, pad)
-    return [bytes(b[:int(s.item())].cpu().numpy().tobytes()) for b, s in zip(bufs, sizes)]
+class RankExchange:
+    """The three exchange hooks of the host driver on a torch.distributed process group."""
+
+    def __init__(self, dist, device: str):
+        self.dist, self.device = dist, device
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        self.bytes_sent = self.bytes_received = self.messages = 0
+        self._cb = (BCAST(self._bcast), SEND(self._send), RECV(self._recv))      # keep the callbacks alive
+
+    def _bcast(self, ptr, n):
+        for o in range(0, n, _CHUNK):
+            m = min(_CHUNK, n - o)
+            h = _host_view(ptr + o, m)
+            t = h.to(self.device) if self.rank == 0 else torch.empty(m, dtype=torch.uint8, device=self.device)
+            self.dist.broadcast(t, 0)
+            if self.rank != 0:
+                h.copy_(t)
+        self.messages += 1
+
+    def _send(self, ptr, n, dst):
+        for o in range(0, n, _CHUNK):
+            m = min(_CHUNK, n - o)
+            self.dist.send(_host_view(ptr + o, m).to(self.device), dst)
+        self.bytes_sent += n
+        self.messages += 1
+
+    def _recv(self, ptr, n, src):
+        for o in range(0, n, _CHUNK):
+            m = min(_CHUNK, n - o)
+            t = torch.empty(m, dtype=torch.uint8, device=self.device)
+            self.dist.recv(t, src)
+            _host_view(ptr + o, m).copy_(t)
+        self.bytes_received += n
+        self.messages += 1
+
+    def install(self, host_lib):
+        """wtzmo_set_dist on the loaded host driver (libwtzmo_host.so or the emulated one of the tests)"""
+        host_lib.wtzmo_set_dist.argtypes = [C.c_int, C.c_int, BCAST, SEND, RECV]
+        host_lib.wtzmo_set_dist.restype = None
+        host_lib.wtzmo_set_dist(self.rank, self.world, *self._cb)

@@ -7,3 +7,6 @@ g++ -std=c++17 -O2 -g -DWTZ_EMUL -ffp-contract=off -Wall -Wno-unused-function -W
     -o "$HERE/libwtz_emul.so" "$ROOT/smartdenovo_amd/csrc/wtz_lib.cpp"
 gcc -std=gnu11 -O2 -g -ffp-contract=off -Wall -Wextra -Wno-unused-parameter -Wno-sign-compare -I"$ROOT/include" \
     -o "$HERE/wtzmo_emul" "$ROOT/smartdenovo_amd/csrc/host/wtzmo_main.c" -L"$HERE" -lwtz_emul -Wl,-rpath,'$ORIGIN' -lstdc++ -lm -lpthread
+# the same host driver as a shared object (wtzmo_main + wtzmo_set_dist + step hook) on the emulated device layer: rank tests load it with ctypes
+gcc -std=gnu11 -O2 -g -ffp-contract=off -Wall -Wextra -Wno-unused-parameter -Wno-sign-compare -DWTZ_AS_LIB -shared -fPIC -I"$ROOT/include" \
+    -o "$HERE/libwtzmo_host_emul.so" "$ROOT/smartdenovo_amd/csrc/host/wtzmo_main.c" -L"$HERE" -lwtz_emul -Wl,-rpath,'$ORIGIN' -lstdc++ -lm -lpthread

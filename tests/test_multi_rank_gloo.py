@@ -1,8 +1,10 @@
-"""N > 1 path on CPU: two processes (gloo), each running its query stripe (-P 2 -p rank) through the host driver on the
-emulated device layer, then the all_gather of the record blobs used by bench.py.  Each rank's output must equal the
-reference golden of `wtzmo -t 1 -P 2 -p rank`, and every rank must see both blobs."""
+"""N > 1 path on CPU: world_size 2 and 3 (gloo), every rank running the host driver (the C `wtzmo` main as a shared object) on the
+emulated device layer with the exchange hooks of smartdenovo_amd/multigpu.py.  Rank 0 plans and commits, all ranks compute their
+share of the pairs and of the candidate requests: the ONE .ovl rank 0 writes must be the reference's plain `wtzmo -t 1` golden
+(not the union of -P stripes), the other ranks write nothing, and records must really have travelled."""
 import hashlib
 import os
+import socket
 import subprocess
 import sys
 
@@ -11,43 +13,49 @@ import pytest
 from conftest import GOLD, ROOT, case_argv, manifest
 
 WORKER = r'''
-import os, sys, hashlib, subprocess
+import os, sys, ctypes as C
 sys.path.insert(0, sys.argv[1])
 import torch, torch.distributed as dist
 from smartdenovo_amd import multigpu
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dist.init_process_group(backend="gloo", rank=rank, world_size=world)
-exe, inp, outdir = sys.argv[2], sys.argv[3], sys.argv[4]
-argv = sys.argv[5:]
-out = os.path.join(outdir, "r%d.ovl" % rank)
-subprocess.run([exe, "-i", inp, "-fo", out] + argv + multigpu.stripe_argv(world, rank), check=True, capture_output=True)
+lib, inp, outdir = sys.argv[2], sys.argv[3], sys.argv[4]
+argv = ["wtzmo", "-i", inp, "-fo", os.path.join(outdir, "r%d.ovl" % rank), "--batch", "16"] + sys.argv[5:]
+host = C.CDLL(lib)
+x = multigpu.RankExchange(dist, "cpu")
+x.install(host)
+cargv = (C.c_char_p * (len(argv) + 1))(*[s.encode() for s in argv], None)
+host.wtzmo_main.argtypes = [C.c_int, C.POINTER(C.c_char_p)]
+rc = host.wtzmo_main(len(argv), cargv)
+open(os.path.join(outdir, "x%d.txt" % rank), "w").write("%d %d %d %d" % (rc, x.bytes_sent, x.bytes_received, x.messages))
 dist.barrier()
-blobs = multigpu.gather_records(dist, open(out, "rb").read(), "cpu")
-open(os.path.join(outdir, "gathered_r%d.txt" % rank), "w").write(" ".join(hashlib.md5(b).hexdigest() for b in blobs))
 dist.destroy_process_group()
 '''
 
 
-def test_two_rank_striping_and_gather(tmp_path):
+@pytest.mark.parametrize("name,world", [("zmo", 2), ("dmo", 2), ("zmo", 3), ("zmo_n", 2)])
+def test_ranks_central_commit(name, world, tmp_path):
     subprocess.run([os.path.join(ROOT, "tests", "emul", "build_emul.sh")], check=True)
-    exe = os.path.join(ROOT, "tests", "emul", "wtzmo_emul")
-    m = manifest()["cases"]
-    base = m["zmo"]
+    lib = os.path.join(ROOT, "tests", "emul", "libwtzmo_host_emul.so")
+    case = manifest()["cases"][name]
     w = os.path.join(str(tmp_path), "worker.py")
     open(w, "w").write(WORKER)
-    import socket
     with socket.socket() as sk:      # a free port, not a fixed one (shared hosts)
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     procs = []
-    for r in range(2):
-        e = dict(env, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r))
-        procs.append(subprocess.Popen([sys.executable, w, ROOT, exe, os.path.join(GOLD, base["input"]), str(tmp_path)] + case_argv(base), env=e))
+    for r in range(world):
+        e = dict(env, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, w, ROOT, lib, os.path.join(GOLD, case["input"]), str(tmp_path)] + case_argv(case), env=e))
     for p in procs:
         assert p.wait(timeout=900) == 0
-    want = [m["zmo_P2p0"]["md5_full"], m["zmo_P2p1"]["md5_full"]]
-    for r in range(2):
-        got = hashlib.md5(open(os.path.join(str(tmp_path), "r%d.ovl" % r), "rb").read()).hexdigest()
-        assert got == want[r], "rank %d stripe differs from reference -P 2 -p %d" % (r, r)
-        assert open(os.path.join(str(tmp_path), "gathered_r%d.txt" % r)).read().split() == want
+    got = hashlib.md5(open(os.path.join(str(tmp_path), "r0.ovl"), "rb").read()).hexdigest()
+    assert got == case["md5_full"], "rank 0's .ovl differs from reference wtzmo -t 1"
+    assert hashlib.md5(open(os.path.join(str(tmp_path), "r0.ovl.contained"), "rb").read()).hexdigest() == case["md5_contained"]
+    stats = [[int(v) for v in open(os.path.join(str(tmp_path), "x%d.txt" % r)).read().split()] for r in range(world)]
+    assert all(s[0] == 0 for s in stats)
+    for r in range(1, world):
+        assert os.path.getsize(os.path.join(str(tmp_path), "r%d.ovl" % r)) == 0, "only rank 0 writes records"
+        assert stats[r][1] > 1000, "rank %d computed nothing" % r       # bytes it sent back to rank 0
+    assert stats[0][2] == sum(s[1] for s in stats[1:]) and stats[0][2] > 0
