@@ -213,6 +213,57 @@ static int hx_set_put(hx_set_t *s, uint64_t v){       /* returns 1 if newly inse
 	while(s->tab[i] != ~0ULL){ if(s->tab[i] == v) return 0; i = (i + 1) & m; }
 	s->tab[i] = v; s->n++; return 1;
 }
+/* ---- the ORDER of the -9 pair file.  The reference writes closed_alns in the iteration order of its own hash set (wtzmo.c:1797-1801):
+ * slot order of an open-addressing table (hashset.h:64-432: linear probing, Jenkins 64-bit hash of the key modulo a size taken from a
+ * fixed list, growth at load 0.67 by an in-place re-insertion that displaces not-yet-moved keys).  The slot a key ends up in depends only
+ * on the sequence of insertions, so the file is reproduced by replaying that sequence into a model of the table that tracks slots only. */
+static const uint64_t hx_ref_sizes[] = {      /* hashset.h:30-44 (sys_prime_list): the table sizes the reference can take - a format constant */
+	0x7ULL, 0xfULL, 0x1fULL, 0x43ULL, 0x89ULL, 0x115ULL, 0x22dULL, 0x45dULL, 0x8bdULL, 0x1181ULL, 0x2303ULL, 0x4609ULL, 0x8c17ULL, 0x1183dULL, 0x2307bULL,
+	0x460fdULL, 0x8c201ULL, 0x118411ULL, 0x230833ULL, 0x461069ULL, 0x8c20e1ULL, 0x11841cbULL, 0x2308397ULL, 0x461075bULL, 0x8c20ecbULL, 0x11841da5ULL,
+	0x23083b61ULL, 0x461076c7ULL, 0x8c20ed91ULL, 0x11841db31ULL, 0x23083b673ULL, 0x461076d1bULL, 0x8c20eda41ULL, 0x11841db48dULL, 0x23083b6937ULL,
+	0x461076d27fULL, 0x8c20eda50dULL, 0x11841db4a59ULL, 0x23083b694ebULL, 0x461076d29f1ULL, 0x8c20eda5441ULL };
+static uint64_t hx_ref_size_for(uint64_t n){
+	const size_t last = sizeof hx_ref_sizes / sizeof hx_ref_sizes[0] - 1; size_t i = 0;
+	while(i < last && n > hx_ref_sizes[i]) i++;
+	return hx_ref_sizes[i];
+}
+static inline uint64_t hx_ref_hash(uint64_t k){       /* hashset.h:464-474 */
+	k += ~(k << 32); k ^= (k >> 22); k += ~(k << 13); k ^= (k >> 8); k += (k << 3); k ^= (k >> 15); k += ~(k << 27); k ^= (k >> 31);
+	return k;
+}
+typedef struct { uint64_t *slot; uint8_t *full; uint64_t size, count, limit; } hx_refslots_t;
+static void hx_refslots_init(hx_refslots_t *t, uint64_t hint){
+	t->size = hx_ref_size_for(hint); t->count = 0; t->limit = (uint64_t)((float)t->size * 0.67f);
+	t->slot = (uint64_t*)hx_realloc(NULL, 8 * t->size); t->full = (uint8_t*)calloc(t->size, 1);
+}
+static void hx_refslots_grow(hx_refslots_t *t){
+	uint64_t n = t->size;
+	do { n = hx_ref_size_for(n * 2); } while((float)n * 0.67f < (float)(t->count + 1));
+	const uint64_t old = t->size;
+	t->slot = (uint64_t*)hx_realloc(t->slot, 8 * n);
+	uint8_t *waiting = t->full;                      /* keys still sitting at their OLD slot */
+	uint8_t *full = (uint8_t*)calloc(n, 1);
+	for(uint64_t i = 0; i < old; i++){
+		if(!waiting[i]) continue;
+		uint64_t key = t->slot[i]; waiting[i] = 0;
+		for(;;){
+			uint64_t h = hx_ref_hash(key) % n;
+			while(full[h]) h = (h + 1) % n;
+			full[h] = 1;
+			if(h < old && waiting[h]){ const uint64_t evicted = t->slot[h]; t->slot[h] = key; key = evicted; waiting[h] = 0; }      /* its turn comes now */
+			else { t->slot[h] = key; break; }
+		}
+	}
+	free(waiting);
+	t->full = full; t->size = n; t->limit = (uint64_t)((float)n * 0.67f);
+}
+static void hx_refslots_put(hx_refslots_t *t, uint64_t key){      /* the caller inserts every key once (new keys only) */
+	if(t->count + 1 > t->limit) hx_refslots_grow(t);
+	uint64_t h = hx_ref_hash(key) % t->size;
+	while(t->full[h]) h = h + 1 == t->size ? 0 : h + 1;
+	t->full[h] = 1; t->slot[h] = key; t->count++;
+}
+
 static inline uint64_t hx_pair_key(uint64_t a, uint64_t b){ return a < b ? ((a << 33) | (b << 1)) : ((b << 33) | (a << 1)); }   /* wtzmo.c:83-84 */
 
 typedef struct { uint32_t *tab; size_t cap; const hx_read_t *reads; } hx_names_t;

@@ -69,6 +69,7 @@ typedef struct eng_s {
 	wtz_params_c P; int do_align; uint32_t n_idx, n_job, i_job;
 	hx_store_t st; uint8_t *masked; uint32_t *rdcovs; hx_set_t closed;
 	uint32_t *rdlen; uint32_t avg_rdlen;
+	uint64_t *closed_order; size_t n_order, cap_order; int keep_order;      /* -9: the pairs in the order they entered closed_alns (the file is a replay of it) */
 	wtz_ctx_t *ctx; FILE *out;
 	uint32_t ndev; int devs[8]; wtz_ctx_t *ctxs[8];      /* --gpus N / --gpu-list: one context per device, reads + both indexes replicated; ctx == ctxs[0] */
 	uint64_t pair_bp, n_pairs, nrec;
@@ -256,6 +257,11 @@ static void out_finish(void){
 }
 
 /* ---------------- record writer + state merge (wtzmo.c:1170-1249, 1319-1329) ---------------- */
+static void order_push(eng_t *E, uint64_t v){
+	if(!E->keep_order) return;
+	if(E->n_order == E->cap_order){ E->cap_order = E->cap_order ? E->cap_order * 2 : 4096; E->closed_order = (uint64_t*)hx_realloc(E->closed_order, 8 * E->cap_order); }
+	E->closed_order[E->n_order++] = v;
+}
 static void flush_pending(eng_t *E){
 	pending_t *p = &E->pend;
 	const hx_read_t *reads = E->st.reads;
@@ -286,6 +292,7 @@ static void flush_pending(eng_t *E){
 	p->nmask = 0;
 	for(size_t i = 0; i < p->nclosed; i++){
 		if(hx_set_put(&E->closed, p->closed[i])){
+			order_push(E, p->closed[i]);
 			uint32_t a = (uint32_t)(p->closed[i] >> 33), b = (uint32_t)((p->closed[i] & 0xFFFFFFFFu) >> 1);
 			E->pair_bp += (uint64_t)E->rdlen[a] + E->rdlen[b]; E->n_pairs++;
 		}
@@ -963,6 +970,7 @@ int main(int argc, char **argv){
 			default: return usage();
 		}
 	}
+	E->keep_order = pairoutf != NULL;
 	if(lib_check){ printf("libwtzmo_hip: %d device(s)\n", wtz_device_count()); return wtz_device_count() > 0 ? 0 : 3; }
 	if(output == NULL) return usage();
 	if(!overwrite && strcmp(output, "-") && access(output, F_OK) == 0){ fprintf(stderr, "File exists! '%s'\n\n", output); return usage(); }
@@ -1034,7 +1042,7 @@ int main(int argc, char **argv){
 			if(nc < 2) continue;
 			uint32_t a = hx_names_get(&nm, cols[0]), b = hx_names_get(&nm, cols[1]);
 			if(a == 0xFFFFFFFFu || b == 0xFFFFFFFFu) continue;
-			hx_set_put(&E->closed, hx_pair_key(a, b));
+			if(hx_set_put(&E->closed, hx_pair_key(a, b))) order_push(E, hx_pair_key(a, b));
 		}
 		hx_reader_close(fr);
 	}
@@ -1080,6 +1088,7 @@ int main(int argc, char **argv){
 	E->pend.rd_id = 0xFFFFFFFFu;
 	/* --repeat: run the whole overlap phase several times on the reads already resident in HBM (benchmarking) */
 	uint8_t *masked0 = (uint8_t*)hx_realloc(NULL, (size_t)n_all + 1); memcpy(masked0, E->masked, (size_t)n_all + 1);
+	const size_t n_order0 = E->n_order;      /* the -L preloads */
 	size_t nclosed0 = 0; uint64_t *closed0 = (uint64_t*)hx_realloc(NULL, 8 * (E->closed.n + 1));
 	for(size_t i = 0; i < E->closed.cap; i++) if(E->closed.tab[i] != ~0ULL) closed0[nclosed0++] = E->closed.tab[i];
 	if(statsf){ FILE *sf = fopen(statsf, "w"); if(sf) fclose(sf); }
@@ -1088,6 +1097,7 @@ int main(int argc, char **argv){
 			memcpy(E->masked, masked0, (size_t)n_all + 1); memset(E->rdcovs, 0, 4 * ((size_t)n_all + 1));
 			free(E->closed.tab); memset(&E->closed, 0, sizeof E->closed);
 			for(size_t i = 0; i < nclosed0; i++) hx_set_put(&E->closed, closed0[i]);
+			E->n_order = n_order0;
 			E->pair_bp = E->n_pairs = E->nrec = 0;
 			E->t_gpu = E->t_commit = 0; memset(E->t_call, 0, sizeof E->t_call); E->t_io[0] = E->t_io[1] = 0; E->spec_pairs = E->used_pairs = E->spec_items = E->used_items = E->spec_queries = E->used_queries = 0;
 			E->rows_all = 0; E->n_batches = 0; E->n_split = 0; E->n_ranges = 0;
@@ -1225,13 +1235,12 @@ int main(int argc, char **argv){
 		fclose(mf); free(maskf);
 	}
 	if(pairoutf){
-		/* the reference lists the pairs in its hash-table iteration order; here they are sorted (the set is the contract) */
+		/* the reference lists the pairs in the iteration order of its hash set: replay the insertions (wtz_host.h, hx_refslots) */
 		FILE *pf = fopen(pairoutf, "w");
-		size_t n = 0; uint64_t *all = (uint64_t*)hx_realloc(NULL, 8 * (E->closed.n + 1));
-		for(size_t i = 0; i < E->closed.cap; i++) if(E->closed.tab[i] != ~0ULL) all[n++] = E->closed.tab[i];
-		for(size_t gap = n / 2; gap > 0; gap /= 2) for(size_t i = gap; i < n; i++){ uint64_t v = all[i]; size_t j = i; while(j >= gap && all[j - gap] > v){ all[j] = all[j - gap]; j -= gap; } all[j] = v; }
-		for(size_t i = 0; i < n; i++) fprintf(pf, "%s\t%s\n", E->st.reads[(uint32_t)(all[i] >> 33)].name, E->st.reads[(uint32_t)((all[i] & 0xFFFFFFFFu) >> 1)].name);
-		fclose(pf); free(all);
+		hx_refslots_t T; hx_refslots_init(&T, 1023);                 /* init_u64hash(1023), wtzmo.c:138 */
+		for(size_t i = 0; i < E->n_order; i++) hx_refslots_put(&T, E->closed_order[i]);
+		for(uint64_t k = 0; k < T.size; k++) if(T.full[k]) fprintf(pf, "%s\t%s\n", E->st.reads[(uint32_t)(T.slot[k] >> 33)].name, E->st.reads[(uint32_t)((T.slot[k] & 0xFFFFFFFFu) >> 1)].name);
+		fclose(pf); free(T.slot); free(T.full);
 	}
 	for(int w = 0; w < 16; w++) wtz_host_free(E->cig_keep[w]);
 	for(uint32_t d = 0; d < E->ndev; d++) wtz_ctx_destroy(E->ctxs[d]);

@@ -36,22 +36,22 @@ WTZ_HD void wtz_cigar_concat(wtz_cigar_t &c, const uint32_t *src, uint32_t n){  
 WTZ_HD void wtz_cigar_reverse(uint32_t *a, uint32_t n){ for(uint32_t i = 0; i < n / 2; i++){ uint32_t t = a[i]; a[i] = a[n - 1 - i]; a[n - 1 - i] = t; } }
 
 /* scratch for one DP: row arrays + trace matrix, (re)carved from the pool on demand */
-typedef struct { int32_t *rh, *re, *zb; uint8_t *z; uint32_t cap_row, cap_zb; uint64_t cap_z; wtz_pool_t *pool; int bad; } wtz_swmem_t;
-WTZ_HD void wtz_swmem_init(wtz_swmem_t &m, wtz_pool_t *pool){ m.rh = m.re = m.zb = NULL; m.z = NULL; m.cap_row = m.cap_zb = 0; m.cap_z = 0; m.pool = pool; m.bad = 0; }
+typedef struct { int32_t *rh, *re, *rm, *zb; uint8_t *z; uint32_t cap_row, cap_zb; uint64_t cap_z; wtz_pool_t *pool; int bad; } wtz_swmem_t;
+WTZ_HD void wtz_swmem_init(wtz_swmem_t &m, wtz_pool_t *pool){ m.rh = m.re = m.rm = m.zb = NULL; m.z = NULL; m.cap_row = m.cap_zb = 0; m.cap_z = 0; m.pool = pool; m.bad = 0; }
 /* row arrays of the scalar DP bodies in the wave's LDS slice when they fit (flat addressing): the H/E rows are
  * touched twice per cell by a single lane, so their latency, not bandwidth, bounds K-sw1 / K-sw2 */
 WTZ_HD void wtz_swmem_init_lds(wtz_swmem_t &m, wtz_pool_t *pool, int32_t *lds, uint32_t lds_ints){
 	wtz_swmem_init(m, pool);
-	if(lds && lds_ints >= 128){ m.rh = lds; m.re = lds + lds_ints / 2; m.cap_row = lds_ints / 2; }
+	if(lds && lds_ints >= 192){ m.rh = lds; m.re = lds + lds_ints / 3; m.rm = lds + 2 * (lds_ints / 3); m.cap_row = lds_ints / 3; }
 }
 WTZ_HD bool wtz_swmem_need(wtz_swmem_t &m, uint32_t row, uint32_t zb, uint64_t z){
 	/* a failed request is sticky: the capacities only grow after BOTH pointers of a request exist, so a later problem of the same
 	 * task can never run on a NULL row buffer after the pool ran dry (the task reports `bad`, the stage WTZ_E_POOL) */
 	if(m.bad) return false;
 	if(row > m.cap_row){ uint32_t c = m.cap_row ? m.cap_row : 64; while(c < row) c <<= 1;
-		int32_t *rh = (int32_t*)wtz_pool_alloc(m.pool, (size_t)c * 4), *re = (int32_t*)wtz_pool_alloc(m.pool, (size_t)c * 4);
-		if(!rh || !re){ m.bad = 1; return false; }
-		m.rh = rh; m.re = re; m.cap_row = c; }
+		int32_t *rh = (int32_t*)wtz_pool_alloc(m.pool, (size_t)c * 4), *re = (int32_t*)wtz_pool_alloc(m.pool, (size_t)c * 4), *rm = (int32_t*)wtz_pool_alloc(m.pool, (size_t)c * 4);
+		if(!rh || !re || !rm){ m.bad = 1; return false; }
+		m.rh = rh; m.re = re; m.rm = rm; m.cap_row = c; }
 	if(zb > m.cap_zb){ uint32_t c = m.cap_zb ? m.cap_zb : 64; while(c < zb) c <<= 1; int32_t *p = (int32_t*)wtz_pool_alloc(m.pool, (size_t)c * 4); if(!p){ m.bad = 1; return false; } m.zb = p; m.cap_zb = c; }
 	if(z > m.cap_z){ uint64_t c = m.cap_z ? m.cap_z : 1024; while(c < z) c <<= 1; uint8_t *p = (uint8_t*)wtz_pool_alloc(m.pool, (size_t)c); if(!p){ m.bad = 1; return false; } m.z = p; m.cap_z = c; }
 	return true;
@@ -110,174 +110,166 @@ WTZ_HD uint64_t wtz_pack32(const wtz_seq_packed &s, int32_t b0, int32_t len){
 	return v;
 }
 
-/* traceback shared by K-sw1/K-sw3; ZROW(i) = first stored column of row i */
-#define WTZ_EXT_TRACEBACK(ZROW) do { \
-	int32_t i_ = x.qe, j_ = x.te; uint32_t d_ = 0; \
-	while(i_ >= 0 && j_ >= 0){ \
-		d_ = (mem.z[(size_t)i_ * n_col + (j_ - (ZROW))] >> (d_ << 1)) & 0x03; \
-		if(d_ == 0){ if(query.at(i_) == target.at(j_)) x.mat++; else x.mis++; i_--; j_--; } \
-		else if(d_ == 1){ i_--; x.ins++; } \
-		else { j_--; x.del++; } \
-		wtz_cigar_push(cigars, d_, 1); \
-	} \
-	if(i_ >= 0){ x.ins += i_ + 1; wtz_cigar_push(cigars, 1, (uint32_t)(i_ + 1)); } \
-	if(j_ >= 0){ x.del += j_ + 1; wtz_cigar_push(cigars, 2, (uint32_t)(j_ + 1)); } \
-	wtz_cigar_reverse(cigars.a, cigars.n); \
-	x.aln = x.mat + x.mis + x.ins + x.del; x.qe++; x.te++; \
-} while(0)
+/*
+ * Scalar forms of the three banded DPs (one lane per problem).  They are the host emulation's DP, the on-device cross-check of the wave
+ * kernels (WTZ_SW_CHECK) and the place where problems outside every wave envelope end up (bands of thousands of columns, targets beyond
+ * the LDS words).  Written the way the wave kernels compute a row, not the way the reference's fused loop does:
+ *     pass 1   diag[] : the diagonal term  H(i-1, j-1) + score(q_i, t_j)  of every band column (independent per column)
+ *     pass 2   one left-to-right sweep that carries the horizontal gap state: H = max{diag, V, G},  V' = max{V+e, diag+o},  G' = max{G+e, diag+o'}
+ * `feed[j]` hands H(i-1, j-1) to row i (so feed[0] is the boundary column -1), `vgap[j]` is the vertical gap state of column j; cells a
+ * row does not touch keep the sentinel the band rules give them.  Trace: one byte per cell, bits 1:0 = source of H (0 diagonal, 1 vertical
+ * gap, 2 horizontal gap), bit 2 = vertical gap extended, bit 3 = horizontal gap extended (the nibble of the register kernels).
+ */
+#define WTZ_TR_VEXT 4u
+#define WTZ_TR_GEXT 8u
 
+/* walk a byte trace back from (row r, column c): ROWBEG(i) = first band column of row i.  op: 0 = aligned pair, 1 = row only, 2 = column only */
+template<typename ROWBEG, typename EMIT>
+WTZ_HD void wtz_trace_walk(const uint8_t *z, int32_t n_col, int32_t &r, int32_t &c, ROWBEG rowbeg, EMIT emit){
+	uint32_t state = 0;
+	while(r >= 0 && c >= 0){
+		const uint32_t t = z[(size_t)r * n_col + (c - rowbeg(r))];
+		if(state == 0) state = t & 3u; else if(state == 1) state = (t & WTZ_TR_VEXT) ? 1u : 0u; else state = (t & WTZ_TR_GEXT) ? 2u : 0u;
+		emit(state, r, c);
+		if(state == 0){ r--; c--; } else if(state == 1) r--; else c--;
+	}
+}
+
+/* K-sw1 (FOLLOW = false: the band is fixed around the diagonal, the row's LAST arg-max counts, kswx.h:234-335) and
+ * K-sw3 (FOLLOW = true: the band centre follows the row's FIRST arg-max by +-1, kswx.h:101-232) */
+template<bool FOLLOW, typename SQ, typename ST>
+WTZ_HD wtz_aln_t wtz_extend_scalar(int32_t qlen, const SQ &query, int32_t tlen, const ST &target, int32_t init_score,
+		int32_t W, int32_t M, int32_t X, int32_t I, int32_t D, int32_t E, int32_t T, wtz_swmem_t &mem, wtz_cigar_t &cigars, unsigned long long *cells){
+	wtz_aln_t x; memset(&x, 0, sizeof x);
+	cigars.n = 0;
+	if(init_score < 0) init_score = 0;
+	if(qlen <= 0 || tlen <= 0){ x.score = init_score; return x; }
+	int32_t rows, cols, n_col;
+	wtz_ext_geometry(qlen, tlen, init_score, W, M, I, D, E, T, rows, cols, n_col);
+	if(!wtz_swmem_need(mem, (uint32_t)cols + 3, FOLLOW ? (uint32_t)rows + 2 : 0, (uint64_t)rows * n_col)) return x;
+	int32_t *feed = mem.rh, *vgap = mem.re, *diag = mem.rm, *first_col = mem.zb;
+	const int32_t open_v = I + E, open_g = D + E, NEG = -10000;
+	feed[0] = init_score;                                            /* H(-1,-1) */
+	for(int32_t j = 1; j <= cols; j++) feed[j] = init_score + D + E * j;       /* H(-1, j-1): a leading horizontal gap */
+	for(int32_t j = 0; j <= cols; j++) vgap[j] = NEG;
+	int32_t best = init_score, best_r = -1, best_c = -1;             /* running maximum over the rows */
+	int32_t edge = 0, edge_r = -1, edge_c = -1;                      /* best cell on the last column / last row (the T end rule) */
+	int32_t centre = 0;
+	unsigned long long ncell = 0;
+	for(int32_t i = 0; i < rows; i++){
+		int32_t jb, je;
+		if(FOLLOW){ jb = centre - W > 0 ? centre - W : 0; je = centre + W + 1 < cols ? centre + W + 1 : cols; first_col[i] = jb; }
+		else      { jb = i - W > 0 ? i - W : 0; je = i + W + 1 < cols ? i + W + 1 : cols; }
+		uint8_t *zi = mem.z + (size_t)i * n_col;
+		ncell += (unsigned long long)(je - jb);
+		/* pass 1 */
+		const uint32_t qb = query.at(i);
+		for(int32_t j = jb; j < je; j++) diag[j - jb] = feed[j] + ((qb == target.at(j)) ? M : X);
+		/* pass 2 */
+		int32_t left = (jb == 0) ? init_score + I + E * (i + 1) : NEG;       /* H(i, jb-1): column -1 is a leading vertical gap */
+		int32_t g = NEG, row_max = 0, row_arg = -1;
+		for(int32_t j = jb; j < je; j++){
+			const int32_t m = diag[j - jb], v = vgap[j];
+			uint32_t t = m >= v ? 0u : 1u;
+			int32_t h = m >= v ? m : v;
+			if(h < g){ t = 2u; h = g; }
+			feed[j] = left; left = h;                                    /* column j+1 of the next row needs H(i, j) */
+			if(FOLLOW){ if(h > row_max){ row_max = h; row_arg = j; } }    /* first arg-max, kswx.h:172 */
+			else if(h >= row_max){ row_max = h; row_arg = j; }            /* last arg-max at or above 0, kswx.h:288-289 */
+			const int32_t vo = m + open_v, ve = v + E;
+			if(ve > vo) t |= WTZ_TR_VEXT;
+			vgap[j] = ve > vo ? ve : vo;
+			const int32_t go = m + open_g, ge = g + E;
+			if(ge > go) t |= WTZ_TR_GEXT;
+			g = ge > go ? ge : go;
+			zi[j - jb] = (uint8_t)t;
+		}
+		feed[je] = left; vgap[je] = NEG;
+		if(je == tlen && edge < left){ edge = left; edge_r = i; edge_c = je - 1; }
+		if(i + 1 == qlen && edge < row_max){ edge = row_max; edge_r = i; edge_c = row_arg; }
+		if(row_max > best){ best = row_max; best_r = i; best_c = row_arg; }
+		else if(row_max <= 0) break;                                     /* kswx.h:185 / 302 */
+		if(FOLLOW){
+			/* the band moves by 0, 1 or 2 columns; what enters it from outside the previous band must read as the sentinel */
+			centre++;
+			if(centre < row_arg){ centre++; if(je < cols){ feed[je + 1] = NEG; vgap[je + 1] = NEG; } }
+			else if(centre > row_arg) centre--;
+		}
+	}
+	if(cells) *cells += ncell;
+	if(edge > 0 && edge >= best + T){ x.score = edge; x.qe = edge_r; x.te = edge_c; }
+	else { x.score = best; x.qe = best_r; x.te = best_c; }
+	int32_t r = x.qe, c = x.te;
+	auto emit = [&](uint32_t op, int32_t rr, int32_t cc){
+		if(op == 0){ if(query.at(rr) == target.at(cc)) x.mat++; else x.mis++; } else if(op == 1) x.ins++; else x.del++;
+		wtz_cigar_push(cigars, op, 1);
+	};
+	if(FOLLOW) wtz_trace_walk(mem.z, n_col, r, c, [&](int32_t rr){ return first_col[rr]; }, emit);
+	else       wtz_trace_walk(mem.z, n_col, r, c, [&](int32_t rr){ return rr > W ? rr - W : 0; }, emit);
+	if(r >= 0){ x.ins += r + 1; wtz_cigar_push(cigars, 1, (uint32_t)(r + 1)); }
+	if(c >= 0){ x.del += c + 1; wtz_cigar_push(cigars, 2, (uint32_t)(c + 1)); }
+	wtz_cigar_reverse(cigars.a, cigars.n);
+	x.aln = x.mat + x.mis + x.ins + x.del; x.qe++; x.te++;
+	return x;
+}
 template<typename SQ, typename ST>
 WTZ_HD wtz_aln_t wtz_extend_fixed(int32_t qlen, const SQ &query, int32_t tlen, const ST &target, int32_t init_score,
 		int32_t W, int32_t M, int32_t X, int32_t I, int32_t D, int32_t E, int32_t T, wtz_swmem_t &mem, wtz_cigar_t &cigars){
-	wtz_aln_t x; memset(&x, 0, sizeof x);
-	int32_t ql, tl, n_col, i, j, jb, je, h1, h, m, e, f, t, mx, mi, mj, imax, mj2, gmax, gi, gj; uint32_t d;
-	if(init_score < 0) init_score = 0;
-	if(qlen <= 0 || tlen <= 0){ x.score = init_score; return x; }
-	wtz_ext_geometry(qlen, tlen, init_score, W, M, I, D, E, T, ql, tl, n_col);
-	if(!wtz_swmem_need(mem, (uint32_t)tl + 2, 0, (uint64_t)ql * n_col)) return x;
-	int32_t *rh = mem.rh, *re = mem.re;
-	rh[0] = init_score; rh[1] = init_score + D + E;
-	for(j = 2; j <= tl; j++) rh[j] = rh[j - 1] + E;
-	for(j = 0; j <= tl; j++) re[j] = -10000;
-	mx = init_score; mi = -1; mj = -1; gmax = 0; gi = -1; gj = -1;
-	for(i = 0; i < ql; i++){
-		jb = i - W; if(jb < 0) jb = 0;
-		je = i + W + 1; if(je > tl) je = tl;
-		h1 = (jb == 0) ? init_score + I + E * (i + 1) : -10000;
-		uint8_t *zi = mem.z + (size_t)i * n_col;
-		imax = 0; mj2 = -1; f = -10000;
-		const uint32_t qb = query.at(i);
-		for(j = jb; j < je; j++){
-			m = rh[j] + ((qb == target.at(j)) ? M : X);
-			rh[j] = h1;
-			e = re[j];
-			d = m >= e ? 0 : 1; h = m >= e ? m : e;
-			d = h >= f ? d : 2; h = h >= f ? h : f;
-			h1 = h;
-			mj2 = imax > h ? mj2 : j;            /* last arg-max (kswx.h:288-289) */
-			imax = imax > h ? imax : h;
-			t = m + I + E; e = e + E; d |= e > t ? 1u << 2 : 0; e = e > t ? e : t; re[j] = e;
-			t = m + D + E; f = f + E; d |= f > t ? 2u << 4 : 0; f = f > t ? f : t;
-			zi[j - jb] = (uint8_t)d;
-		}
-		rh[j] = h1; re[j] = -10000;
-		if(j == tlen && gmax < h1){ gmax = h1; gi = i; gj = j - 1; }
-		if(i + 1 == qlen && gmax < imax){ gmax = imax; gi = i; gj = mj2; }
-		if(imax > mx){ mx = imax; mi = i; mj = mj2; }
-		else if(imax <= 0) break;
-	}
-	if(gmax > 0 && gmax >= mx + T){ x.score = gmax; x.qe = gi; x.te = gj; }
-	else { x.score = mx; x.qe = mi; x.te = mj; }
-	cigars.n = 0;
-	WTZ_EXT_TRACEBACK((i_ > W ? i_ - W : 0));
-	return x;
+	return wtz_extend_scalar<false>(qlen, query, tlen, target, init_score, W, M, X, I, D, E, T, mem, cigars, (unsigned long long*)NULL);
 }
-
 template<typename SQ, typename ST>
 WTZ_HD wtz_aln_t wtz_extend_shift(int32_t qlen, const SQ &query, int32_t tlen, const ST &target, int32_t init_score,
 		int32_t W, int32_t M, int32_t X, int32_t I, int32_t D, int32_t E, int32_t T, wtz_swmem_t &mem, wtz_cigar_t &cigars, unsigned long long *cells){
-	wtz_aln_t x; memset(&x, 0, sizeof x);
-	int32_t ql, tl, n_col, i, j, jb, je, h1, c, h, m, e, f, t, mx, mi, mj, imax, mj2, gmax, gi, gj; uint32_t d;
-	cigars.n = 0;
-	if(init_score < 0) init_score = 0;
-	if(qlen <= 0 || tlen <= 0){ x.score = init_score; return x; }
-	wtz_ext_geometry(qlen, tlen, init_score, W, M, I, D, E, T, ql, tl, n_col);
-	if(!wtz_swmem_need(mem, (uint32_t)tl + 3, (uint32_t)ql + 2, (uint64_t)ql * n_col)) return x;
-	int32_t *rh = mem.rh, *re = mem.re, *zb = mem.zb;
-	rh[0] = init_score; rh[1] = init_score + D + E;
-	for(j = 2; j <= tl; j++) rh[j] = rh[j - 1] + E;
-	for(j = 0; j <= tl; j++) re[j] = -10000;
-	mx = init_score; mi = -1; mj = -1; gmax = 0; gi = -1; gj = -1;
-	jb = 0; je = tl;
-	unsigned long long ncell = 0;
-	for(i = c = 0; i < ql; i++){
-		if(jb < c - W) jb = c - W;
-		if(je > c + W + 1) je = c + W + 1;
-		if(je > tl) je = tl;
-		h1 = (jb == 0) ? init_score + I + E * (i + 1) : -10000;
-		uint8_t *zi = mem.z + (size_t)i * n_col;
-		zb[i] = jb;
-		imax = 0; mj2 = -1; f = -10000;
-		const uint32_t qb = query.at(i);
-		ncell += (unsigned long long)(je - jb);
-		for(j = jb; j < je; j++){
-			m = rh[j] + ((qb == target.at(j)) ? M : X);
-			rh[j] = h1;
-			e = re[j];
-			if(m >= e){ d = 0; h = m; } else { d = 1; h = e; }
-			if(h < f){ d = 2; h = f; }
-			h1 = h;
-			if(h > imax){ imax = h; mj2 = j; }       /* first arg-max (kswx.h:172) */
-			t = m + I + E; e = e + E; if(e > t) d |= 1u << 2; else e = t; re[j] = e;
-			t = m + D + E; f = f + E; if(f > t) d |= 2u << 4; else f = t;
-			zi[j - jb] = (uint8_t)d;
-		}
-		rh[j] = h1; re[j] = -10000;
-		if(j == tlen && gmax < h1){ gmax = h1; gi = i; gj = j - 1; }
-		if(i + 1 == qlen && gmax < imax){ gmax = imax; gi = i; gj = mj2; }
-		if(imax > mx){ mx = imax; mi = i; mj = mj2; }
-		else if(imax <= 0) break;
-		c++;
-		if(c < mj2){ c++; if(je < tl){ rh[je + 1] = -10000; re[je + 1] = -10000; } }
-		else if(c > mj2){ c--; if(jb){ rh[jb - 1] = -10000; re[jb - 1] = -10000; } }
-		jb = 0; je = tl;
-	}
-	if(cells) *cells += ncell;
-	if(gmax > 0 && gmax >= mx + T){ x.score = gmax; x.qe = gi; x.te = gj; }
-	else { x.score = mx; x.qe = mi; x.te = mj; }
-	WTZ_EXT_TRACEBACK(zb[i_]);
-	return x;
+	return wtz_extend_scalar<true>(qlen, query, tlen, target, init_score, W, M, X, I, D, E, T, mem, cigars, cells);
 }
 
 #define WTZ_MINUS_INF (-0x40000000)
 
-/* K-sw2: match score M on equal bases else X (the reference passes a 4x4 matrix with exactly that content,
- * hzm_aln.h:1354); penalties positive. cigar ops M0/I1/D2. */
+/* K-sw2, ksw_global2 (ksw.c:503-586): rows run over the TARGET, band columns over the query, no early exit, the score is the corner
+ * cell and the walk starts there; match M on equal bases else X (the reference passes a 4x4 matrix with exactly that content,
+ * hzm_aln.h:1354); penalties positive.  cigar ops M0 / I1 (query only) / D2 (target only). */
 template<typename SQ, typename ST>
 WTZ_HD int32_t wtz_global_banded(int32_t qlen, const SQ &query, int32_t tlen, const ST &target, int32_t M, int32_t X,
 		int32_t o_del, int32_t e_del, int32_t o_ins, int32_t e_ins, int32_t w, wtz_swmem_t &mem, wtz_cigar_t &cig){
-	int32_t i, j, k, oe_del = o_del + e_del, oe_ins = o_ins + e_ins, score, n_col;
 	cig.n = 0;
-	n_col = qlen < 2 * w + 1 ? qlen : 2 * w + 1;
-	if(!wtz_swmem_need(mem, (uint32_t)qlen + 2, 0, (uint64_t)(n_col > 0 ? n_col : 0) * (uint64_t)(tlen > 0 ? tlen : 0) + 8)) return 0;
-	int32_t *H = mem.rh, *Ev = mem.re; uint8_t *z = mem.z;
-	H[0] = 0; Ev[0] = WTZ_MINUS_INF;
-	for(j = 1; j <= qlen && j <= w; ++j){ H[j] = -(o_ins + e_ins * j); Ev[j] = WTZ_MINUS_INF; }
-	for(; j <= qlen; ++j) H[j] = Ev[j] = WTZ_MINUS_INF;
-	for(i = 0; i < tlen; ++i){
-		int32_t f = WTZ_MINUS_INF, h1, beg, end, t;
-		uint8_t *zi = &z[(size_t)i * n_col];
-		beg = i > w ? i - w : 0;
-		end = i + w + 1 < qlen ? i + w + 1 : qlen;
-		h1 = beg == 0 ? -(o_del + e_del * (i + 1)) : WTZ_MINUS_INF;
+	const int32_t n_col = qlen < 2 * w + 1 ? qlen : 2 * w + 1;
+	if(!wtz_swmem_need(mem, (uint32_t)qlen + 3, 0, (uint64_t)(n_col > 0 ? n_col : 0) * (uint64_t)(tlen > 0 ? tlen : 0) + 8)) return 0;
+	int32_t *feed = mem.rh, *vgap = mem.re, *diag = mem.rm; uint8_t *z = mem.z;
+	const int32_t open_v = o_del + e_del, open_g = o_ins + e_ins;
+	/* row -1: a leading query-only gap inside the band, nothing beyond it */
+	feed[0] = 0;
+	for(int32_t j = 1; j <= qlen; j++) feed[j] = j <= w ? -(o_ins + e_ins * j) : WTZ_MINUS_INF;
+	for(int32_t j = 0; j <= qlen; j++) vgap[j] = WTZ_MINUS_INF;
+	for(int32_t i = 0; i < tlen; i++){
+		const int32_t jb = i > w ? i - w : 0, je = i + w + 1 < qlen ? i + w + 1 : qlen;
+		uint8_t *zi = z + (size_t)i * n_col;
 		const uint32_t tb = target.at(i);
-		for(j = beg; j < end; ++j){
-			int32_t h, m = H[j], e = Ev[j]; uint32_t d;
-			H[j] = h1;
-			m += (tb == query.at(j)) ? M : X;
-			d = m >= e ? 0 : 1; h = m >= e ? m : e;
-			d = h >= f ? d : 2; h = h >= f ? h : f;
-			h1 = h;
-			t = m - oe_del; e -= e_del; d |= e > t ? 1u << 2 : 0; e = e > t ? e : t; Ev[j] = e;
-			t = m - oe_ins; f -= e_ins; d |= f > t ? 2u << 4 : 0; f = f > t ? f : t;
-			zi[j - beg] = (uint8_t)d;
+		for(int32_t j = jb; j < je; j++) diag[j - jb] = feed[j] + ((tb == query.at(j)) ? M : X);
+		int32_t left = jb == 0 ? -(o_del + e_del * (i + 1)) : WTZ_MINUS_INF;        /* column -1: a leading target-only gap */
+		int32_t g = WTZ_MINUS_INF;
+		for(int32_t j = jb; j < je; j++){
+			const int32_t m = diag[j - jb], v = vgap[j];
+			uint32_t t = m >= v ? 0u : 1u;
+			int32_t h = m >= v ? m : v;
+			if(h < g){ t = 2u; h = g; }
+			feed[j] = left; left = h;
+			const int32_t vo = m - open_v, ve = v - e_del;
+			if(ve > vo) t |= WTZ_TR_VEXT;
+			vgap[j] = ve > vo ? ve : vo;
+			const int32_t go = m - open_g, ge = g - e_ins;
+			if(ge > go) t |= WTZ_TR_GEXT;
+			g = ge > go ? ge : go;
+			zi[j - jb] = (uint8_t)t;
 		}
-		H[end] = h1; Ev[end] = WTZ_MINUS_INF;
+		feed[je] = left; vgap[je] = WTZ_MINUS_INF;
 	}
-	score = H[qlen];
-	{
-		uint32_t which = 0;
-		i = tlen - 1; k = (i + w + 1 < qlen ? i + w + 1 : qlen) - 1;
-		while(i >= 0 && k >= 0){
-			which = (z[(size_t)i * n_col + (k - (i > w ? i - w : 0))] >> (which << 1)) & 3;
-			if(which == 0){ wtz_cigar_push(cig, 0, 1); --i; --k; }
-			else if(which == 1){ wtz_cigar_push(cig, 2, 1); --i; }
-			else { wtz_cigar_push(cig, 1, 1); --k; }
-		}
-		if(i >= 0) wtz_cigar_push(cig, 2, (uint32_t)(i + 1));
-		if(k >= 0) wtz_cigar_push(cig, 1, (uint32_t)(k + 1));
-		wtz_cigar_reverse(cig.a, cig.n);
-	}
+	const int32_t score = feed[qlen];
+	int32_t r = tlen - 1, c = (r + w + 1 < qlen ? r + w + 1 : qlen) - 1;
+	wtz_trace_walk(z, n_col, r, c, [&](int32_t rr){ return rr > w ? rr - w : 0; },
+		[&](uint32_t op, int32_t, int32_t){ wtz_cigar_push(cig, op == 0 ? 0u : (op == 1 ? 2u : 1u), 1); });      /* a row-only step consumes target: D */
+	if(r >= 0) wtz_cigar_push(cig, 2, (uint32_t)(r + 1));
+	if(c >= 0) wtz_cigar_push(cig, 1, (uint32_t)(c + 1));
+	wtz_cigar_reverse(cig.a, cig.n);
 	return score;
 }
 

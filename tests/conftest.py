@@ -36,7 +36,12 @@ def md5_file(path):
     return hashlib.md5(open(path, "rb").read()).hexdigest() if os.path.exists(path) else None
 
 
-def run_wtzmo_like(exe, case, tmpdir, extra=()):
+def pairs_raw_md5(tmpdir):
+    p = os.path.join(str(tmpdir), "pairs")
+    return md5_file(p)
+
+
+def run_wtzmo_like(exe, case, tmpdir, extra=(), exact_pairs=False):
     """Run a wtzmo-compatible executable on one golden case; returns (md5 of .ovl, md5 of .contained, 16-col text)."""
     out = os.path.join(str(tmpdir), "o.ovl")
     for f in (out, out + ".contained", os.path.join(str(tmpdir), "pairs")):
@@ -48,6 +53,8 @@ def run_wtzmo_like(exe, case, tmpdir, extra=()):
     full = open(out, "rb").read()
     cut = b"\n".join(b"\t".join(l.split(b"\t")[:16]) for l in full.split(b"\n"))
     assert pairs_md5(tmpdir) == case.get("md5_pairs_sorted"), "-9 pair set differs from the reference"
+    if exact_pairs:       # the product also reproduces the ORDER (the oracle writes the set sorted)
+        assert pairs_raw_md5(tmpdir) == case.get("md5_pairs"), "-9 pair file differs from the reference's byte for byte"
     return hashlib.md5(full).hexdigest(), md5_file(out + ".contained"), cut
 
 

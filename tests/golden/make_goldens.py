@@ -148,7 +148,8 @@ def run_case(name, inp, extra):
         cont_path = out + ".contained"
         cont = open(cont_path, "rb").read() if os.path.exists(cont_path) else None
         pairs_path = os.path.join(td, "pairs")
-        pairs = sorted(open(pairs_path, "rb").read().split(b"\n")) if os.path.exists(pairs_path) else None
+        pairs_raw = open(pairs_path, "rb").read() if os.path.exists(pairs_path) else None
+        pairs = sorted(pairs_raw.split(b"\n")) if pairs_raw is not None else None
     lines = full.split(b"\n")
     cut = b"\n".join(b"\t".join(l.split(b"\t")[:16]) for l in lines)
     with gzip.GzipFile(os.path.join(HERE, name + ".ovl16.gz"), "wb", mtime=0) as fh:
@@ -162,6 +163,7 @@ def run_case(name, inp, extra):
         "md5_contained": md5(cont) if cont is not None else None,
         "contained": cont.decode().split() if cont is not None else None,
         "md5_pairs_sorted": md5(b"\n".join(pairs)) if pairs is not None else None,
+        "md5_pairs": md5(pairs_raw) if pairs_raw is not None else None,       # the reference's own order (iteration order of its hash set)
         "pairs": len([p for p in pairs if p]) if pairs is not None else None,
     }
 

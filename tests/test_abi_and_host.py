@@ -58,7 +58,7 @@ def emul_exe():
 @pytest.mark.parametrize("name", ["zmo", "dmo", "zmo_G2", "zmo_N", "zmo_A5", "zmo_B2", "zmo_edge_fq", "zmo_L", "zmo_b", "dmo_U2", "zmo_P2p1", "zmo_n", "dmo_N", "zmo_I", "dmo_I", "zmo_9", "dmo_9"])
 def test_host_logic_on_emulated_device(name, emul_exe, tmp_path):
     case = manifest()["cases"][name]
-    md5, cont, _ = run_wtzmo_like(emul_exe, case, tmp_path, extra=["--batch", "16"])
+    md5, cont, _ = run_wtzmo_like(emul_exe, case, tmp_path, extra=["--batch", "16"], exact_pairs=True)
     assert md5 == case["md5_full"] and cont == case["md5_contained"]
 
 

@@ -25,7 +25,7 @@ def test_library_is_the_hip_build(gpu_exe):
 @pytest.mark.parametrize("name", CASES)
 def test_gpu_equals_reference_golden(name, gpu_exe, tmp_path):
     case = manifest()["cases"][name]
-    md5, cont, cut = run_wtzmo_like(gpu_exe, case, tmp_path)
+    md5, cont, cut = run_wtzmo_like(gpu_exe, case, tmp_path, exact_pairs=True)
     assert cut == gzip.open(os.path.join(GOLD, name + ".ovl16.gz")).read(), "16-column records differ from the reference"
     assert md5 == case["md5_full"], "full .ovl (incl. CIGAR) differs from the reference"
     assert cont == case["md5_contained"]
