@@ -268,6 +268,7 @@ struct wtz_ctx {
 	std::vector<uint32_t> h_rdlen;
 	/* k-mer index */
 	wtz_kslot_t *ktab; uint64_t kmask; uint32_t *kseeds; uint64_t n_kocc;
+	uint32_t idx_beg = 0, idx_end = 0; bool idx_len_sorted = false;      /* read range of the k-mer index; lengths non-increasing inside it (true unless -b clipped reads after the sort) */
 	/* z index */
 	uint64_t *zoff; uint64_t n_z; wtz_zindex_t Z; bool have_z;
 	/* pool */
@@ -280,9 +281,11 @@ struct wtz_ctx {
 	wtz_alnres_dev_t *d_alnres; uint32_t n_items; std::vector<wtz_alnres_dev_t> h_alnres;
 	bool have_pairs, have_items;
 	/* candidate request in flight (wtz_candidates_begin / _end) */
+	uint32_t *cq_thr = NULL;
 	uint32_t *cq_q = NULL, *cq_nc = NULL; uint64_t *cq_cand = NULL; unsigned long long *cq_bytes = NULL; uint32_t cq_cap = 0, cq_n = 0; bool cq_pending = false; wtz_timer cq_tm;
 	wtz_counters_t cnt;
 	uint64_t tpool_peak_call = 0, main_used_call = 0;      /* transient-pool high-water mark / main-pool bytes of the API call in progress */
+	int env_cand_stream = 0;     /* WTZ_CAND_STREAM=1: sort-free candidate accumulation (LDS sketch + survivor table, wtz_seed.h); bit-exact, pays at 25x coverage only: see DESIGN.md */
 	int env_grp4 = 0;            /* WTZ_WINALIGN4=1: four windows per wavefront first (wtz_sw_grp.h; bit-exact, measured 2x SLOWER than one window per wave: see DESIGN.md) */
 	bool env_trace = false;      /* WTZ_STAGE_TRACE: name every device stage on stderr before it is launched (locating a device fault) */
 	bool env_fail_once = false;      /* WTZ_POOL_FAIL_ONCE: the injected failure hits one stage call only (the retry must then succeed) */
@@ -391,6 +394,7 @@ extern "C" int wtz_ctx_create(int device, const wtz_params_c *params, uint64_t p
 	c->env_profile = getenv("WTZ_PROFILE_PAIR") != NULL;
 #endif
 	c->env_trace = getenv("WTZ_STAGE_TRACE") != NULL;
+	c->env_cand_stream = (getenv("WTZ_CAND_STREAM") && atoi(getenv("WTZ_CAND_STREAM")) != 0);
 	c->env_grp4 = (getenv("WTZ_WINALIGN4") && atoi(getenv("WTZ_WINALIGN4")) != 0);
 	c->env_fail_once = getenv("WTZ_POOL_FAIL_ONCE") != NULL;
 	c->env_fail_at = getenv("WTZ_POOL_FAIL_AT") ? (unsigned)atoi(getenv("WTZ_POOL_FAIL_AT")) : 0u;
@@ -439,7 +443,7 @@ extern "C" void wtz_ctx_destroy(wtz_ctx_t *c){
 	if(!c) return;
 	{ CTX_ENTER(c); (void)dev_sync(); }
 	free_batch_storage(c); free_kindex(c); free_zindex(c);
-	dev_free_persist(c->cq_q); dev_free_persist(c->cq_nc); dev_free_persist(c->cq_cand); dev_free_persist(c->cq_bytes);
+	dev_free_persist(c->cq_q); dev_free_persist(c->cq_nc); dev_free_persist(c->cq_cand); dev_free_persist(c->cq_bytes); dev_free_persist(c->cq_thr);
 #ifndef WTZ_EMUL
 	if(c->arena.base) (void)hipFree(c->arena.base);
 #endif
@@ -465,6 +469,7 @@ extern "C" int wtz_ctx_clone(wtz_ctx_t *p, uint64_t pool_bytes, wtz_ctx_t **out)
 	c->shares_indexes = true;
 	c->bits = p->bits; c->n_words = p->n_words; c->rdoff = p->rdoff; c->rdlen = p->rdlen; c->n_reads = p->n_reads; c->h_rdlen = p->h_rdlen;
 	c->ktab = p->ktab; c->kmask = p->kmask; c->kseeds = p->kseeds; c->n_kocc = p->n_kocc;
+	c->idx_beg = p->idx_beg; c->idx_end = p->idx_end; c->idx_len_sorted = p->idx_len_sorted;
 	c->zoff = p->zoff; c->n_z = p->n_z; c->Z = p->Z; c->have_z = p->have_z;
 	*out = c;
 	return WTZ_OK;
@@ -535,6 +540,8 @@ extern "C" int wtz_index_build(wtz_ctx_t *c, uint32_t id_beg, uint32_t id_end, u
 	CHK(dev_sync());
 	dev_free(d_keys); dev_free(d_stat);
 	c->kseeds = d_vals; c->n_kocc = tot;
+	c->idx_beg = id_beg; c->idx_end = id_end; c->idx_len_sorted = true;
+	for(uint32_t r = id_beg; r + 1 < id_end; r++) if(c->h_rdlen[r] < c->h_rdlen[r + 1]){ c->idx_len_sorted = false; break; }
 	c->cnt.ms_index += tm.stop();
 	if(stats){
 		stats->n_occ = tot; stats->n_distinct = ktyp; stats->ktot = ktot; stats->n_kept = n_kept; stats->max_kmer_freq = K;
@@ -613,21 +620,39 @@ extern "C" int wtz_candidates_begin(wtz_ctx_t *c, const uint32_t *qids, uint32_t
 	const uint32_t stride = c->P.ncand + 1;
 	if(nq > c->cq_cap){
 		(void)dev_sync();
-		dev_free_persist(c->cq_q); dev_free_persist(c->cq_nc); dev_free_persist(c->cq_cand); dev_free_persist(c->cq_bytes);
+		dev_free_persist(c->cq_q); dev_free_persist(c->cq_nc); dev_free_persist(c->cq_cand); dev_free_persist(c->cq_bytes); dev_free_persist(c->cq_thr);
 		uint32_t cap = c->cq_cap ? c->cq_cap : 1024; while(cap < nq) cap *= 2;
-		CHK(dev_alloc_persist((void**)&c->cq_q, (size_t)cap * 4)); CHK(dev_alloc_persist((void**)&c->cq_nc, (size_t)cap * 4));
+		CHK(dev_alloc_persist((void**)&c->cq_q, (size_t)cap * 4)); CHK(dev_alloc_persist((void**)&c->cq_nc, (size_t)cap * 4)); CHK(dev_alloc_persist((void**)&c->cq_thr, (size_t)cap * 4));
 		CHK(dev_alloc_persist((void**)&c->cq_cand, (size_t)cap * stride * 8)); CHK(dev_alloc_persist((void**)&c->cq_bytes, 8));
 		c->cq_cap = cap;
 	}
 	uint32_t *d_q = c->cq_q, *d_n = c->cq_nc; uint64_t *d_cand = c->cq_cand; unsigned long long *d_bytes = c->cq_bytes;
 	CHK(dev_h2d(d_q, qids, (size_t)nq * 4)); CHK(dev_h2d(d_n, ncand_in, (size_t)nq * 4)); CHK(dev_h2d(d_cand, cand, (size_t)nq * stride * 8));
 	CHK(dev_set(d_bytes, 0, 8));
+	const uint32_t *d_thr = NULL; (void)d_thr;
+	if(c->idx_len_sorted && c->idx_end > c->idx_beg){
+		/* per query: the first indexed read that is NOT longer than 1.2 x the query (lengths are non-increasing in the id) */
+		std::vector<uint32_t> thr(nq);
+		for(uint32_t i = 0; i < nq; i++){
+			const uint32_t up = (uint32_t)(c->h_rdlen[qids[i]] * 1.2);              /* double multiply, wtzmo.c:445 */
+			uint32_t lo = c->idx_beg, hi = c->idx_end;
+			while(lo < hi){ const uint32_t mid = lo + (hi - lo) / 2; if(c->h_rdlen[mid] > up) lo = mid + 1; else hi = mid; }
+			thr[i] = lo;
+		}
+		CHK(dev_h2d(c->cq_thr, thr.data(), (size_t)nq * 4)); d_thr = c->cq_thr;
+	}
 	const wtz_reads_t R = ctx_reads(c); const wtz_params_t *dP = c->dP; const wtz_kslot_t *tab = c->ktab; const uint64_t kmask = c->kmask;
 	const uint32_t *seeds = c->kseeds; wtz_pool_t *pool = c->dpool;
 	STAGE(c, "K_candidates");
 	c->cq_tm.start();
 #ifndef WTZ_EMUL
-	CHK(wtz_launch_coop<K_candidates>(0, nq, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_candidates((uint32_t)t, R, d_q, dP, tab, kmask, seeds, pool, d_cand, d_n, stride, d_bytes, (uint64_t*)wtz_wave_scratch(), WTZ_CAND_LDS_BYTES / 8); }, WTZ_CAND_LDS_BYTES));
+	{
+		/* LDS per wave: the group table + output list + heap row of the streaming form (the sorting form of a query with too many groups
+		 * uses the largest power-of-two window inside it) */
+		uint32_t lds_b = c->env_cand_stream ? (WTZ_CAND_STREAM_LDS_BYTES(c->P.ncand) + 15u) & ~15u : WTZ_CAND_LDS_BYTES;
+		if(lds_b < WTZ_CAND_LDS_BYTES || lds_b > 64u * 1024u) lds_b = WTZ_CAND_LDS_BYTES;
+		CHK(wtz_launch_coop<K_candidates>(0, nq, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_candidates((uint32_t)t, R, d_q, dP, tab, kmask, seeds, pool, d_cand, d_n, stride, d_bytes, (uint64_t*)wtz_wave_scratch(), lds_b / 8, d_thr); }, lds_b));
+	}
 #else
 	CHK(wtz_launch_coop<K_candidates>(0, nq, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_candidates((uint32_t)t, R, d_q, dP, tab, kmask, seeds, pool, d_cand, d_n, stride, d_bytes, (uint64_t*)NULL, 0); }));
 #endif

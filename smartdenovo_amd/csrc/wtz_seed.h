@@ -448,6 +448,151 @@ WTZ_HD void wtz_coop_sort_u32(uint32_t *w, uint32_t np){
 #endif
 }
 
+#define WTZ_CAND_SKETCH 2048u
+#define WTZ_CAND_TAB 2048u
+#define WTZ_CAND_OUT 512u
+#define WTZ_CAND_STREAM_LDS_BYTES(ncand) ((WTZ_CAND_SKETCH + 3u * WTZ_CAND_TAB) * 4u + WTZ_CAND_OUT * 8u + ((ncand) + 2u) * 8u)
+#if defined(__HIP_DEVICE_COMPILE__)
+/*
+ * Phases C-E of the candidate task without expanding and sorting the tuples.
+ *
+ * The reference's k-way merge (wtzmo.c:500-560) delivers the tuples of one (read, strand) group in query-offset order and folds them with
+ *     ol += (qoff >= lst) ? len : qoff + len - lst;   lst = qoff + len            (u32; a later, shorter k-mer moves lst back)
+ * and only groups with ol >= -d (kovl) ever matter (wtzmo.c:523).  Two facts make a sort-free form exact:
+ *   (1) by induction ol >= len of the last tuple > 0 and every step adds at most len, so 0 < ol <= SUM(len): a group whose lengths sum to
+ *       less than kovl can be dropped without looking at its order.  Most groups of a query are such chance hits of erroneous k-mers
+ *       (~1 500 groups per 10 kb query, ~200 of them real) - a table of ALL groups does not fit LDS, a table of the survivors does;
+ *   (2) the sampled k-mers of the query are listed in query-offset order and the seed run of one k-mer is sorted by (read, strand): walking
+ *       the k-mers in order with the lanes side by side on the entries of a run gives every group its tuples in the reference's order.
+ * Pass 1 (order-free, every lane its own k-mers): LDS sketch  S[hash(read,strand)] += len.  Pass 2 (64 k-mers at a time, every lane its own):
+ * does the run have an entry with S >= kovl?  Pass 3 (those k-mers only, in order, 8 runs in flight): fold the surviving entries into an
+ * LDS hash table of (lst, ol).  Then the groups with ol >= kovl are compacted, put in (read, strand) order and lane 0 replays the strand merge and
+ * the candidate heap (staged in LDS).  Returns false (nothing written) when the survivors overflow the table: the caller then runs the
+ * sorting form.
+ * id_thr: when the indexed reads are in non-increasing length order (always, unless -b clipped them after the sort) "longer than 1.2 x
+ * the query" (wtzmo.c:489) is "read id below id_thr" - no length load per run entry; 0xFFFFFFFF = look the length up.
+ */
+WTZ_D bool wtz_cand_stream(uint32_t t, const wtz_reads_t &R, uint32_t pbid, uint32_t pblen_up, const wtz_params_t *P, const uint32_t *seeds,
+		uint32_t nk, const uint64_t *koff, const uint32_t *kqoff, const uint32_t *kqlen, uint64_t *cand_out, uint32_t *ncand_out, uint32_t stride, uint32_t *lds32, uint32_t id_thr){
+	const uint32_t lane = WTZ_LANE, EMPTY = 0xFFFFFFFFu, MASK = WTZ_CAND_TAB - 1u, SMASK = WTZ_CAND_SKETCH - 1u;
+	uint32_t *sk = lds32, *keys = sk + WTZ_CAND_SKETCH, *lsts = keys + WTZ_CAND_TAB, *ols = lsts + WTZ_CAND_TAB;
+	uint64_t *out = (uint64_t*)(ols + WTZ_CAND_TAB), *heap = out + WTZ_CAND_OUT;
+	const uint32_t kovl = P->kovl;
+	if(P->ncand + 1u > 1024u) return false;
+	for(uint32_t i = lane; i < WTZ_CAND_SKETCH; i += 64) sk[i] = 0u;
+	for(uint32_t i = lane; i < WTZ_CAND_TAB; i += 64) keys[i] = EMPTY;
+	__threadfence_block();
+	auto dropped = [&](uint32_t sd) -> bool {                                  /* wtzmo.c:488-489 */
+		if((sd >> 1) == pbid) return true;
+		if(id_thr != 0xFFFFFFFFu) return (sd >> 1) < id_thr;
+		return R.rdlen[sd >> 1] > pblen_up;
+	};
+	/* ---- pass 1: length sums per (read, strand) hash ---- */
+	for(uint32_t e = lane; e < nk; e += 64){
+		const uint64_t oc = koff[e]; const uint32_t c = (uint32_t)(oc & 0xFFFFu); const uint64_t o = oc >> 16;
+		const uint32_t ql = kqlen[e] < kovl ? kqlen[e] : kovl;                 /* clamped: the sums cannot wrap */
+		uint32_t prev = EMPTY;
+		for(uint32_t k = 0; k < c; k++){
+			const uint32_t sd = seeds[o + k];
+			if(sd != prev && !dropped(sd)) atomicAdd(&sk[(uint32_t)wtz_mix64(sd) & SMASK], ql);       /* an identical neighbour adds 0 to ol */
+			prev = sd;
+		}
+	}
+	__threadfence_block();
+	uint32_t ngrp = 0;
+	/* one run entry per lane: group lookup / insert and the fold of this k-mer's interval */
+	auto fold = [&](uint32_t sd, uint32_t prev, bool in_run, uint32_t qo, uint32_t ql){
+		bool act = in_run && sd != prev && !dropped(sd) && sk[(uint32_t)wtz_mix64(sd) & SMASK] >= kovl;
+		bool fresh = false;
+		if(act){
+			uint32_t h = (uint32_t)wtz_mix64(sd * 0x9E3779B1u) & MASK;
+			for(;;){
+				const uint32_t old = atomicCAS(&keys[h], EMPTY, sd);
+				if(old == EMPTY){ fresh = true; break; }
+				if(old == sd) break;
+				h = (h + 1u) & MASK;
+			}
+			uint32_t lst = fresh ? 0u : lsts[h], ol = fresh ? 0u : ols[h];
+			if(qo >= lst) ol += ql; else ol += qo + ql - lst;                     /* wtzmo.c:558-559 */
+			lsts[h] = qo + ql; ols[h] = ol;
+		}
+		ngrp += (uint32_t)__popcll(__ballot(fresh));
+		__threadfence_block();
+	};
+	/* ---- pass 3 ---- */
+	constexpr int PF = 8;                                /* runs whose first 64 entries are in flight together: the walk is a chain of dependent loads otherwise */
+	for(uint32_t e0 = 0; e0 < nk; e0 += 64){
+		const uint32_t e = e0 + lane;
+		const uint64_t oc = e < nk ? koff[e] : 0ull;
+		uint32_t my_c = (uint32_t)(oc & 0xFFFFu); const uint32_t my_olo = (uint32_t)(oc >> 16), my_ohi = (uint32_t)(oc >> 48);
+		const uint32_t my_q = e < nk ? kqoff[e] : 0u, my_l = e < nk ? kqlen[e] : 0u;
+		{   /* pass 2, every lane its own k-mer: a run without an entry that can reach -d is not walked */
+			bool any = false;
+			for(uint32_t k = 0; k < my_c && !any; k++){ const uint32_t sd = seeds[(oc >> 16) + k]; if(!dropped(sd) && sk[(uint32_t)wtz_mix64(sd) & SMASK] >= kovl) any = true; }
+			if(!any) my_c = 0;
+		}
+		unsigned long long hits = __ballot(my_c != 0);
+		while(hits){
+			int ls[PF]; uint32_t cs[PF], sdv[PF]; uint64_t os[PF];
+			#pragma unroll
+			for(int g = 0; g < PF; g++){
+				ls[g] = -1; cs[g] = 0; os[g] = 0; sdv[g] = EMPTY;
+				if(hits){
+					const int l = __builtin_ctzll(hits); hits &= hits - 1ull; ls[g] = l;
+					cs[g] = (uint32_t)__builtin_amdgcn_readlane((int)my_c, l);
+					os[g] = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)my_ohi, l) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)my_olo, l);
+					if(lane < cs[g]) sdv[g] = seeds[os[g] + lane];
+				}
+			}
+			#pragma unroll
+			for(int g = 0; g < PF; g++){
+				if(ls[g] < 0) continue;                      /* uniform */
+				const uint32_t c = cs[g], qo = (uint32_t)__builtin_amdgcn_readlane((int)my_q, ls[g]), ql = (uint32_t)__builtin_amdgcn_readlane((int)my_l, ls[g]);
+				if(ngrp + 64u > WTZ_CAND_TAB - WTZ_CAND_TAB / 4u){ WTZ_PROF_CNT(46, 1000000); return false; }      /* more survivors than the table takes at load 3/4 */
+				uint32_t sd = sdv[g];
+				uint32_t prev = (uint32_t)__shfl_up((int)sd, 1, 64); if(lane == 0) prev = EMPTY;
+				uint32_t carry = (uint32_t)__builtin_amdgcn_readlane((int)sd, 63);       /* last entry of the previous 64 of this run */
+				fold(sd, prev, lane < c, qo, ql);
+				for(uint32_t k0 = 64; k0 < c; k0 += 64){
+					if(ngrp + 64u > WTZ_CAND_TAB - WTZ_CAND_TAB / 4u){ WTZ_PROF_CNT(46, 1000000); return false; }
+					const uint32_t k = k0 + lane;
+					sd = k < c ? seeds[os[g] + k] : EMPTY;
+					prev = (uint32_t)__shfl_up((int)sd, 1, 64); if(lane == 0) prev = carry;
+					carry = (uint32_t)__builtin_amdgcn_readlane((int)sd, 63);
+					fold(sd, prev, k < c, qo, ql);
+				}
+			}
+		}
+	}
+	/* groups that reach -d, in (read, strand) order */
+	uint32_t ng = 0;
+	for(uint32_t i0 = 0; i0 < WTZ_CAND_TAB; i0 += 64){
+		const uint32_t i = i0 + lane;
+		const bool keep = keys[i] != EMPTY && ols[i] >= kovl;
+		uint32_t tot; const uint32_t pos = wtz_coop_rank(keep, &tot);
+		if(ng + tot > WTZ_CAND_OUT){ WTZ_PROF_CNT(47, 1000000); return false; }
+		if(keep) out[ng + pos] = ((uint64_t)keys[i] << 32) | ols[i];
+		ng += tot;
+	}
+	uint32_t np = 64; while(np < ng) np <<= 1;
+	for(uint32_t i = ng + lane; i < np; i += 64) out[i] = ~0ull;
+	__threadfence_block();
+	wtz_coop_sort_u64(out, np);
+	/* strand merge + candidate heap with its quirks (wtzmo.c:516-571) on lane 0, the heap row staged in LDS */
+	uint32_t hn = ncand_out[t];
+	uint64_t *row = cand_out + (size_t)t * stride;
+	for(uint32_t i = lane; i < hn; i += 64) heap[i] = row[i];
+	__threadfence_block();
+	if(lane == 0) wtz_cand_tail(out, ng, kovl, P->ncand, heap, &hn);
+	hn = wtz_coop_bcast32(hn);
+	__threadfence_block();
+	for(uint32_t i = lane; i < hn; i += 64) row[i] = heap[i];
+	if(lane == 0) ncand_out[t] = hn;
+	WTZ_PROF_CNT(10, 1000000); WTZ_PROF_CNT(11, ngrp * 1000ull); WTZ_PROF_CNT(12, ng * 1000ull);
+	return true;
+}
+#endif
+
 struct wtz_kq_f { uint64_t *mer; uint32_t *qoff, *qlen; uint32_t n;
 	WTZ_HDM void operator()(uint64_t m, uint32_t, uint32_t qo, uint32_t qe){ uint32_t l = qe - qo; if(l > 0xFFFFu) l = 0xFFFFu; mer[n] = m; qoff[n] = qo; qlen[n] = l; n++; } };
 
@@ -464,7 +609,7 @@ struct wtz_kq_f { uint64_t *mer; uint32_t *qoff, *qlen; uint32_t n;
  */
 WTZ_HD void wtz_task_candidates(uint32_t t, wtz_reads_t R, const uint32_t *qids, const wtz_params_t *P,
 		const wtz_kslot_t *tab, uint64_t tmask, const uint32_t *seeds, wtz_pool_t *pool, uint64_t *cand_out, uint32_t *ncand_out, uint32_t stride,
-		unsigned long long *algo_bytes, uint64_t *lds, uint32_t lds_words){
+		unsigned long long *algo_bytes, uint64_t *lds, uint32_t lds_words, const uint32_t *id_thr = NULL){
 	const uint32_t pbid = qids[t], lane = WTZ_LANE;
 	const uint32_t L = R.rdlen[pbid];
 	const uint32_t pblen_up = (uint32_t)(L * 1.2);                       /* double multiply, wtzmo.c:445 */
@@ -513,6 +658,16 @@ WTZ_HD void wtz_task_candidates(uint32_t t, wtz_reads_t R, const uint32_t *qids,
 	}
 	WTZ_PROF_ADD(25, pcB); WTZ_PROF_CNT(30, T); WTZ_PROF_CNT(31, nk);
 	const unsigned long long pcC = WTZ_PROF_T(); (void)pcC;
+#if defined(__HIP_DEVICE_COMPILE__)
+	/* the streaming form (no tuples, no sort) when the launch gave the wave its table; a query with too many groups falls through */
+	if(lds && lds_words * 8u >= WTZ_CAND_STREAM_LDS_BYTES(P->ncand)){
+		WTZ_WAVE_SYNC();
+		if(wtz_cand_stream(t, R, pbid, pblen_up, P, seeds, nk, koff, kqoff, kqlen, cand_out, ncand_out, stride, (uint32_t*)lds, id_thr ? id_thr[t] : 0xFFFFFFFFu)){ WTZ_PROF_ADD(26, pcC); return; }
+		WTZ_WAVE_SYNC();
+		/* the sorting form below wants a power-of-two LDS window */
+		uint32_t w2 = 128; while(w2 * 2 <= lds_words) w2 <<= 1; lds_words = w2;
+	}
+#endif
 	/* ---- C ---- */
 	uint32_t np = 64; while(np < T) np <<= 1;
 	pa = 0;
