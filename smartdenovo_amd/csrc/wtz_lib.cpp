@@ -43,6 +43,7 @@ static_assert((WTZ_CAND_LDS_BYTES & (WTZ_CAND_LDS_BYTES - 1u)) == 0u && WTZ_CAND
 #endif
 /* kernel name tags (rocprofv3 shows wtz_kernel_*<K_pair, ...>) */
 struct K_candidates;
+struct K_candidates_stream;
 struct K_extjob_scalar;
 struct K_cigar_text;
 struct K_misc;
@@ -651,10 +652,12 @@ extern "C" int wtz_candidates_begin(wtz_ctx_t *c, const uint32_t *qids, uint32_t
 		 * uses the largest power-of-two window inside it) */
 		uint32_t lds_b = c->env_cand_stream ? (WTZ_CAND_STREAM_LDS_BYTES(c->P.ncand) + 15u) & ~15u : WTZ_CAND_LDS_BYTES;
 		if(lds_b < WTZ_CAND_LDS_BYTES || lds_b > 64u * 1024u) lds_b = WTZ_CAND_LDS_BYTES;
-		CHK(wtz_launch_coop<K_candidates>(0, nq, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_candidates((uint32_t)t, R, d_q, dP, tab, kmask, seeds, pool, d_cand, d_n, stride, d_bytes, (uint64_t*)wtz_wave_scratch(), lds_b / 8, d_thr); }, lds_b));
+		if(lds_b != WTZ_CAND_LDS_BYTES) CHK(wtz_launch_coop<K_candidates_stream>(0, nq, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_candidates<true>((uint32_t)t, R, d_q, dP, tab, kmask, seeds, pool, d_cand, d_n, stride, d_bytes, (uint64_t*)wtz_wave_scratch(), lds_b / 8, d_thr); }, lds_b));
+		/* the LDS window of the sorting form is a COMPILE-TIME constant: as a run-time value the windowed bitonic network loses its constant strides (26 -> 34 ms) */
+		else CHK(wtz_launch_coop<K_candidates>(0, nq, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_candidates<false>((uint32_t)t, R, d_q, dP, tab, kmask, seeds, pool, d_cand, d_n, stride, d_bytes, (uint64_t*)wtz_wave_scratch(), WTZ_CAND_LDS_BYTES / 8, (const uint32_t*)NULL); }, WTZ_CAND_LDS_BYTES));
 	}
 #else
-	CHK(wtz_launch_coop<K_candidates>(0, nq, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_candidates((uint32_t)t, R, d_q, dP, tab, kmask, seeds, pool, d_cand, d_n, stride, d_bytes, (uint64_t*)NULL, 0); }));
+	CHK(wtz_launch_coop<K_candidates>(0, nq, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_candidates<false>((uint32_t)t, R, d_q, dP, tab, kmask, seeds, pool, d_cand, d_n, stride, d_bytes, (uint64_t*)NULL, 0); }));
 #endif
 	c->cq_tm.lap();
 	c->cq_pending = true;

@@ -607,6 +607,7 @@ struct wtz_kq_f { uint64_t *mer; uint32_t *qoff, *qlen; uint32_t n;
  *   E  all lanes: group heads -> union length `ol` of each group (wtzmo.c:558-560), compacted in key order
  *   F  lane 0 replays the strand merge + candidate heap with its quirks (wtzmo.c:516-571)
  */
+template<bool STREAM = false>
 WTZ_HD void wtz_task_candidates(uint32_t t, wtz_reads_t R, const uint32_t *qids, const wtz_params_t *P,
 		const wtz_kslot_t *tab, uint64_t tmask, const uint32_t *seeds, wtz_pool_t *pool, uint64_t *cand_out, uint32_t *ncand_out, uint32_t stride,
 		unsigned long long *algo_bytes, uint64_t *lds, uint32_t lds_words, const uint32_t *id_thr = NULL){
@@ -659,13 +660,15 @@ WTZ_HD void wtz_task_candidates(uint32_t t, wtz_reads_t R, const uint32_t *qids,
 	WTZ_PROF_ADD(25, pcB); WTZ_PROF_CNT(30, T); WTZ_PROF_CNT(31, nk);
 	const unsigned long long pcC = WTZ_PROF_T(); (void)pcC;
 #if defined(__HIP_DEVICE_COMPILE__)
-	/* the streaming form (no tuples, no sort) when the launch gave the wave its table; a query with too many groups falls through */
-	if(lds && lds_words * 8u >= WTZ_CAND_STREAM_LDS_BYTES(P->ncand)){
+	/* the streaming form (no tuples, no sort) when the launch gave the wave its table; a query with too many groups falls through.
+	 * A separate instantiation: the sorting form keeps its register budget (and occupancy) when the streaming form is not asked for */
+	if(STREAM && lds && lds_words * 8u >= WTZ_CAND_STREAM_LDS_BYTES(P->ncand)){
 		WTZ_WAVE_SYNC();
 		if(wtz_cand_stream(t, R, pbid, pblen_up, P, seeds, nk, koff, kqoff, kqlen, cand_out, ncand_out, stride, (uint32_t*)lds, id_thr ? id_thr[t] : 0xFFFFFFFFu)){ WTZ_PROF_ADD(26, pcC); return; }
 		WTZ_WAVE_SYNC();
-		/* the sorting form below wants a power-of-two LDS window */
-		uint32_t w2 = 128; while(w2 * 2 <= lds_words) w2 <<= 1; lds_words = w2;
+		/* the sorting form below wants a power-of-two LDS window, and wants it as a compile-time constant (constant strides in the
+		 * bitonic network): the sketch + table alone are 32 KB */
+		lds_words = (WTZ_CAND_SKETCH + 3u * WTZ_CAND_TAB) * 4u / 8u;
 	}
 #endif
 	/* ---- C ---- */
