@@ -200,7 +200,7 @@ WTZ_COOP_HOST uint32_t wtz_coop_min32(uint32_t v){ return v; }
 /* phase profiler, compiled in only with -DWTZ_PROFILE (its same-address atomics perturb the kernels it measures):
  * shader-clock ticks / event counts accumulated per slot by lane 0 of each task; WTZ_PROFILE_PAIR=1 prints them */
 #if defined(__HIPCC__) && defined(WTZ_PROFILE)
-__device__ unsigned long long wtz_prof[48];
+__device__ unsigned long long wtz_prof[64];
 #define WTZ_PROF_T() ((unsigned long long)clock64())
 #define WTZ_PROF_ADD(slot, t0) do { if(WTZ_LANE == 0) atomicAdd(&wtz_prof[slot], (unsigned long long)clock64() - (t0)); } while(0)
 #define WTZ_PROF_CNT(slot, v) do { if(WTZ_LANE == 0) atomicAdd(&wtz_prof[slot], (unsigned long long)(v)); } while(0)

@@ -841,6 +841,7 @@ static int run_extjobs(wtz_ctx *c, const wtz_env_t &V, wtz_extjob_t *d_jobs, uin
 	uint32_t *d_order = NULL; unsigned long long ext_sum = 0; int32_t ext_max = 0; uint32_t n_mw = 0;
 	const int mw_min = c->env_mw_min;
 	std::vector<uint32_t> ord(m); std::vector<uint64_t> need(m);
+	unsigned long long geo_n[9] = {0}, geo_rows[9] = {0}, geo_cells[9] = {0};
 	{
 		/* (qlen, tlen, init_score, W) of every job: the order key, and the job's geometry = an upper bound of its trace bytes */
 		int32_t *d_key = NULL; CHK(dev_alloc((void**)&d_key, (size_t)m * 16));
@@ -871,6 +872,12 @@ static int run_extjobs(wtz_ctx *c, const wtz_env_t &V, wtz_extjob_t *d_jobs, uin
 				nb = z + 8 * r + 4 * zb + 256;
 			}
 			need[i] = nb;
+			if(c->env_profile){ const int b = (n_col + 63) / 64 > 32 ? 8 : ((n_col + 63) / 64 - 1) / 4; geo_n[b]++; geo_rows[b] += (unsigned long long)ql; geo_cells[b] += (unsigned long long)ql * (unsigned long long)n_col; }
+		}
+		if(c->env_profile){
+			fprintf(stderr, "[ext-profile] geometry by columns per lane (upper bounds):");
+			for(int b = 0; b < 9; b++) if(geo_n[b]) fprintf(stderr, " C<=%d: %llu jobs %.1f Mrows %.1f Gcells;", b < 8 ? 4 * b + 4 : 999, geo_n[b], (double)geo_rows[b] / 1e6, (double)geo_cells[b] / 1e9);
+			fprintf(stderr, "\n");
 		}
 	}
 	{
@@ -1141,10 +1148,10 @@ extern "C" int wtz_get_counters(wtz_ctx_t *c, wtz_counters_t *out){
 	*out = c->cnt;
 #if !defined(WTZ_EMUL) && defined(WTZ_PROFILE)
 	if(c->env_profile){        /* device phase profiler: Mticks per slot since the last report */
-		unsigned long long h[48], z[48]; memset(z, 0, sizeof z);
+		unsigned long long h[64], z[64]; memset(z, 0, sizeof z);
 		if(hipMemcpyFromSymbol(h, HIP_SYMBOL(wtz_prof), sizeof h) == hipSuccess){
 			fprintf(stderr, "[phase-profile] Mticks:");
-			for(int k = 0; k < 48; k++) fprintf(stderr, " %d:%.1f", k, (double)h[k] / 1e6);
+			for(int k = 0; k < 64; k++) fprintf(stderr, " %d:%.1f", k, (double)h[k] / 1e6);
 			fprintf(stderr, "\n");
 			(void)hipMemcpyToSymbol(HIP_SYMBOL(wtz_prof), z, sizeof z);
 		}

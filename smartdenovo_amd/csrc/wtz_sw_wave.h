@@ -1559,6 +1559,8 @@ WTZ_D wtz_aln_t wtz_align_window_wave(const wtz_readview &pb1, const wtz_readvie
 			else { for(uint32_t k = 0; k < tmp.n; k++){ const uint32_t r = tmp.a[k]; wtz_cigw_push(Wc, r & 0xFu, r >> 4); } }
 			if(x.te < off1){ x.del += off1 - x.te; x.aln += off1 - x.te; wtz_cigw_push(Wc, 2, (uint32_t)(off1 - x.te)); x.te = off1; }
 			if(x.qe < off2){ x.ins += off2 - x.qe; x.aln += off2 - x.qe; wtz_cigw_push(Wc, 1, (uint32_t)(off2 - x.qe)); x.qe = off2; }
+			WTZ_PROF_ADD(48, pt1); WTZ_PROF_CNT(50, 1000); WTZ_PROF_CNT(51, n_runs); WTZ_PROF_CNT(52, (qlen > 0 ? qlen : 0)); WTZ_PROF_CNT(53, (tlen > 0 ? tlen : 0));
+			const unsigned long long pt2 = WTZ_PROF_T(); (void)pt2;
 			const uint32_t len1 = ZH_LEN1(p), len2 = ZH_LEN2(p);
 			const wtz_seq_packed z1 = pb1.sub(off1, 1), z2 = pb2.sub(off2, 1);
 			/* one pass that writes its runs; a z-mer pair that turns out not to align (aln == 0) is rolled back: the writer's
@@ -1579,6 +1581,7 @@ WTZ_D wtz_aln_t wtz_align_window_wave(const wtz_readview &pb1, const wtz_readvie
 				x.aln += y.aln; x.mat += y.mat; x.mis += y.mis; x.ins += y.ins; x.del += y.del;
 				x.te += y.te; x.qe += y.qe;
 			}
+			WTZ_PROF_ADD(49, pt2); WTZ_PROF_CNT(54, len1 + len2);
 		}
 		x = wtz_bcast_aln(x);
 		stop = __shfl(stop, 0, 64);
