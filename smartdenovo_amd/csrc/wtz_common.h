@@ -197,15 +197,27 @@ WTZ_COOP_HOST uint32_t wtz_coop_min32(uint32_t v){ return v; }
 #define WTZ_WAVE_SYNC() do {} while(0)
 #endif
 
-/* phase profiler, compiled in only with -DWTZ_PROFILE (its same-address atomics perturb the kernels it measures):
- * shader-clock ticks / event counts accumulated per slot by lane 0 of each task; WTZ_PROFILE_PAIR=1 prints them */
+/* phase profiler, compiled in only with -DWTZ_PROFILE: shader-clock ticks / event counts per slot, accumulated by lane 0 of each task
+ * in an LDS array of the workgroup (global same-address atomics per event made the profiled kernels 3x slower) and added to the
+ * global slots once, when the task ends (WTZ_PROF_BEGIN / WTZ_PROF_END in the kernel wrappers); WTZ_PROFILE_PAIR=1 prints them */
 #if defined(__HIPCC__) && defined(WTZ_PROFILE)
 __device__ unsigned long long wtz_prof[64];
-#define WTZ_PROF_T() ((unsigned long long)clock64())
-#define WTZ_PROF_ADD(slot, t0) do { if(WTZ_LANE == 0) atomicAdd(&wtz_prof[slot], (unsigned long long)clock64() - (t0)); } while(0)
-#define WTZ_PROF_CNT(slot, v) do { if(WTZ_LANE == 0) atomicAdd(&wtz_prof[slot], (unsigned long long)(v)); } while(0)
-#define WTZ_PROF_MAX(slot, t0) do { if(WTZ_LANE == 0) atomicMax(&wtz_prof[slot], (unsigned long long)clock64() - (t0)); } while(0)
+#if defined(__HIP_DEVICE_COMPILE__)
+static __device__ __forceinline__ unsigned long long *wtz_prof_lds(){ __shared__ unsigned long long a[64]; return a; }
+#define WTZ_PROF_BEGIN() do { if(threadIdx.x < 64) wtz_prof_lds()[threadIdx.x] = 0; __syncthreads(); } while(0)
+#define WTZ_PROF_END() do { __syncthreads(); if(threadIdx.x < 64){ const unsigned long long v_ = wtz_prof_lds()[threadIdx.x]; if(v_){ if(threadIdx.x == 15 || threadIdx.x == 34 || threadIdx.x == 37 || threadIdx.x == 40 || threadIdx.x == 42 || threadIdx.x == 45) atomicMax(&wtz_prof[threadIdx.x], v_); else atomicAdd(&wtz_prof[threadIdx.x], v_); } } } while(0)
 #else
+#define WTZ_PROF_BEGIN() do { } while(0)
+#define WTZ_PROF_END() do { } while(0)
+static __host__ __device__ inline unsigned long long *wtz_prof_lds(){ return NULL; }
+#endif
+#define WTZ_PROF_T() ((unsigned long long)clock64())
+#define WTZ_PROF_ADD(slot, t0) do { if(WTZ_LANE == 0) atomicAdd(&wtz_prof_lds()[slot], (unsigned long long)clock64() - (t0)); } while(0)
+#define WTZ_PROF_CNT(slot, v) do { if(WTZ_LANE == 0) atomicAdd(&wtz_prof_lds()[slot], (unsigned long long)(v)); } while(0)
+#define WTZ_PROF_MAX(slot, t0) do { if(WTZ_LANE == 0) atomicMax(&wtz_prof_lds()[slot], (unsigned long long)clock64() - (t0)); } while(0)
+#else
+#define WTZ_PROF_BEGIN() do { } while(0)
+#define WTZ_PROF_END() do { } while(0)
 #define WTZ_PROF_T() 0ull
 #define WTZ_PROF_ADD(slot, t0) do { (void)(t0); } while(0)
 #define WTZ_PROF_CNT(slot, v) do { } while(0)
@@ -221,7 +233,14 @@ template<typename T> struct wtz_vec {
 		uint32_t c = cap ? cap : 16; while(c < want) c <<= 1;
 		T *b = (T*)wtz_pool_alloc(pool, (size_t)c * sizeof(T));
 		if(b == NULL){ bad = 1; return false; }
-		for(uint32_t i = 0; i < n; i++) b[i] = a[i];
+		{
+			/* old and new storage never overlap: batches of loads, then stores (element by element every store waits for the load behind it) */
+			const T *__restrict__ src = a; T *__restrict__ dst = b;
+			constexpr uint32_t B = sizeof(T) <= 4 ? 4 : (sizeof(T) <= 8 ? 2 : 1);
+			uint32_t i = 0;
+			if(B > 1) for(; i + B <= n; i += B){ T t[B]; for(uint32_t k = 0; k < B; k++) t[k] = src[i + k]; for(uint32_t k = 0; k < B; k++) dst[i + k] = t[k]; }
+			for(; i < n; i++) dst[i] = src[i];
+		}
 		a = b; cap = c; return true;
 	}
 	WTZ_HDM bool push(const T &x){ if(n == cap && !reserve(n + 1)) return false; a[n++] = x; return true; }

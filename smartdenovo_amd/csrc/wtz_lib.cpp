@@ -96,7 +96,9 @@ static thread_local hipStream_t g_stream = 0;
 /* TAG only names the kernel (rocprofv3 shows wtz_kernel_tasks<K_pair_seed, ...>) */
 template<typename TAG, typename F> __global__ void __launch_bounds__(64) wtz_kernel_tasks(uint64_t n, F f){
 	uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	WTZ_PROF_BEGIN();
 	if(i < n) f(i);
+	WTZ_PROF_END();
 }
 template<typename TAG, typename F> static int wtz_launch(hipStream_t st, uint64_t n, F f){
 	if(n == 0) return WTZ_OK;
@@ -114,7 +116,9 @@ template<typename TAG, typename F> static int wtz_launch(hipStream_t st, uint64_
  * (wtz_sw_wave.h). */
 template<typename TAG, typename F> __global__ void __launch_bounds__(64) wtz_kernel_wave_tasks(uint64_t n, F f){
 	const uint64_t i = blockIdx.x;
+	WTZ_PROF_BEGIN();
 	if(i < n && threadIdx.x == 0) f(i);
+	WTZ_PROF_END();
 }
 /* wave-cooperative tasks: every lane of the wavefront enters the task body (WTZ_LANE / wtz_coop_* inside).
  * These kernels are latency-bound chains: resident waves per SIMD are their throughput, so a TAG can ask the register
@@ -125,7 +129,9 @@ template<> struct wtz_occ<K_pair> { static constexpr int waves = WTZ_OCC_PAIR; }
 template<> struct wtz_occ<K_gap> { static constexpr int waves = WTZ_OCC_GAP; };
 template<typename TAG, typename F> __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(wtz_occ<TAG>::waves, 8))) wtz_kernel_coop_tasks(uint64_t n, F f){
 	const uint64_t i = blockIdx.x;
+	WTZ_PROF_BEGIN();
 	if(i < n) f(i);
+	WTZ_PROF_END();
 }
 template<typename TAG, typename F> static int wtz_launch_coop(hipStream_t st, uint64_t n, F f, uint32_t lds_bytes = WTZ_WAVE_LDS_BYTES){
 	if(n == 0) return WTZ_OK;
@@ -138,7 +144,9 @@ template<typename TAG, typename F> static int wtz_launch_coop(hipStream_t st, ui
 /* four tasks per wavefront: one per 16-lane group (wtz_sw_grp.h); f gets the index of the block's first task */
 template<typename TAG, typename F> __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 8))) wtz_kernel_grp_tasks(uint64_t n, F f){
 	const uint64_t i = (uint64_t)blockIdx.x * 4;
+	WTZ_PROF_BEGIN();
 	if(i < n) f(i);
+	WTZ_PROF_END();
 }
 template<typename TAG, typename F> static int wtz_launch_grp(uint64_t n, F f, uint32_t lds_bytes){
 	if(n == 0) return WTZ_OK;

@@ -835,9 +835,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WTZ_OCC
 	const int32_t Cw = (n_col + 63) / 64;
 	if(Cw > 32 || (tl + 63) / 32 + 1 > TW || (ql + 63) / 64 > WTZ_TRACE_MAXCHUNK) return;
 	if((long long)init_score + (long long)Pm->M * (ql < tl ? ql : tl) >= (1 << 20)) return;
+	WTZ_PROF_BEGIN();
 	wtz_trace_t tr; tr.chunk = NULL; tr.zb = NULL; tr.n_chunk = 0; tr.zrow = 0; tr.cap_rows = 0;
 	wtz_cigar_t cg; cg.a = NULL; cg.n = cg.cap = 0; cg.pool = pool; cg.bad = 0;
-	if(lane == 0) cg.init(pool, 64);
+	if(lane == 0) cg.init(pool, (uint32_t)ql / 2u + 16u);
 	unsigned long long cells = 0; bool ok = true;
 	wtz_aln_t x;
 #define WTZ_EXTREG_CASE(CM) x = wtz_extend_shift_reg<CM>(job->qlen, job->q, job->tlen, job->t, job->init_score, ql, tl, W, Pm->M, Pm->X, Pm->O, Pm->O, Pm->E, Pm->T, stb, tr, tpool, cg, &cells, &ok)
@@ -852,6 +853,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WTZ_OCC
 #undef WTZ_EXTREG_CASE
 	if(lane == 0){ job->x = x; job->cigar = cg.a; job->cigar_len = cg.n; job->bad = (!ok || cg.bad); job->cells = cells; job->done = 1; }
 	WTZ_PROF_ADD(8, pt_job); WTZ_PROF_MAX(15, pt_job); WTZ_PROF_CNT(10, 1);
+	WTZ_PROF_END();
 }
 
 /*
@@ -1174,8 +1176,9 @@ __global__ void __launch_bounds__(256) wtz_kernel_extjobs_mw(wtz_extjob_t *jobs,
 	const int32_t Cw = (n_col + 255) / 256;
 	if(Cw > 8 || (tl + 63) / 32 + 1 > TW || (ql + 63) / 64 > WTZ_TRACE_MAXCHUNK) return;
 	if((long long)init_score + (long long)Pm->M * (ql < tl ? ql : tl) >= (1 << 20)) return;
+	WTZ_PROF_BEGIN();
 	wtz_cigar_t cg; cg.a = NULL; cg.n = cg.cap = 0; cg.pool = pool; cg.bad = 0;
-	if(tid == 0) cg.init(pool, 64);
+	if(tid == 0) cg.init(pool, (uint32_t)ql / 2u + 16u);
 	unsigned long long cells = 0; bool ok = true;
 	wtz_aln_t x;
 #define WTZ_EXTMW_CASE(CM) x = wtz_extend_shift_mw<CM, 4>(job->qlen, job->q, job->tlen, job->t, job->init_score, ql, tl, W, Pm->M, Pm->X, Pm->O, Pm->O, Pm->E, Pm->T, stb, &shm, tpool, cg, &cells, &ok)
@@ -1185,6 +1188,7 @@ __global__ void __launch_bounds__(256) wtz_kernel_extjobs_mw(wtz_extjob_t *jobs,
 	else WTZ_EXTMW_CASE(8);
 #undef WTZ_EXTMW_CASE
 	if(tid == 0){ job->x = x; job->cigar = cg.a; job->cigar_len = cg.n; job->bad = (!ok || cg.bad); job->cells = cells; job->done = 2; }
+	WTZ_PROF_END();
 }
 
 /*

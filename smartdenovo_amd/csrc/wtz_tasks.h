@@ -266,7 +266,9 @@ WTZ_HD void wtz_task_winalign(uint32_t t, const wtz_env_t &V, const wtz_wintask_
 	const wtz_win_t &w = it.win[tasks[t].widx];
 	wtz_reg_t reg; memset(&reg, 0, sizeof reg);
 	wtz_cigar_t cigar, tmp;
-	cigar.init(V.pool, WTZ_LANE == 0 ? 64 : 0); tmp.init(V.pool, WTZ_LANE == 0 ? 64 : 0);
+	/* the window's CIGAR is sized from its anchor count (about a dozen runs per anchor): growing it by doubling copied every element
+	 * on lane 0 two or three times per window; tmp only serves the scalar body */
+	cigar.init(V.pool, WTZ_LANE == 0 ? (w.anchors[1] - w.anchors[0]) * 14u + 16u : 0); tmp.init(V.pool, 0);
 	unsigned long long cells = 0;
 	int32_t bad = 0;
 #if defined(__HIP_DEVICE_COMPILE__)
