@@ -491,6 +491,104 @@ WTZ_D void wtz_cigw_push(wtz_cigw_t &w, uint32_t op, uint32_t len){
 }
 WTZ_D void wtz_cigw_finish(wtz_cigw_t &w){ if(w.tail){ w.v->push(w.tail); w.tail = 0; } }
 
+/* ---- traceback of the K-sw3 register forms (one wavefront; NL = lanes of a trace row: 64, or 256 for the four-wave form).
+ * The trace lives in the pool in the lane-transposed layout (row, k/4, lane, k%4).  Lane 0 walks, but never against HBM latency:
+ * for the 64 rows below the current cell the wave copies the dwords of the NLW lanes around the current band-relative column
+ * into LDS - one row per step, lane x takes dword (x / C4, x % C4) of the row, so a step is a few contiguous pieces and the loads
+ * of eight rows are in flight together (the first version fetched byte by byte, each byte waiting for its own round trip: a 64-row
+ * block cost more than the 64 DP rows it traces) - decoded four cells at a time into the walker's bytes, 128 bytes per row in
+ * band-relative column order.  The walker tracks the band-relative column itself (a row's band start moves by 0..2 against the
+ * row above: 64 deltas in LDS), leaves the block after 64 rows or through either edge of the window, and the next block is
+ * staged around the cell it stands on.  Runs go through the register-tail writer and are reversed once at the end.
+ * LDS: 8192 + 64 bytes at `tb` (the target words are dead by now). ---- */
+template<int C, int NL>
+WTZ_D void wtz_shift_traceback(wtz_aln_t &x, uint8_t **zchunk, const int32_t *zb, uint32_t zrow, uint64_t *tb, wtz_cigar_t &cigars){
+	const int lane = (int)(threadIdx.x & 63);
+	constexpr int C4 = (C + 3) / 4;
+	constexpr int NLW = (128 / C) < NL ? (128 / C) : NL;     /* lanes of a row inside the window */
+	constexpr int NDW = NLW * C4, ROWB = NLW * C;
+	static_assert(NDW <= 64 && ROWB <= 128, "window geometry");
+	uint32_t *S32 = (uint32_t*)tb; uint8_t *S8 = (uint8_t*)tb; uint8_t *Sd = S8 + 8192;
+	int32_t i_ = x.qe, j_ = x.te; uint32_t d_ = 0;
+	uint32_t run_op = 0xFFu, run_len = 0;
+	wtz_cigw_t Wr; Wr.v = &cigars; Wr.tail = 0;
+	int32_t cc = 0;
+	if(i_ >= 0) cc = j_ - wtz_as_global(zb)[i_];
+	const int ln_off = lane / C4, q4 = lane % C4;
+	while(i_ >= 0 && j_ >= 0){
+		const int32_t i0 = i_;
+		int32_t L0 = (cc < 0 ? 0 : (cc > NL * C - 1 ? NL * C - 1 : cc)) / C - NLW / 2;
+		if(L0 > NL - NLW) L0 = NL - NLW;
+		if(L0 < 0) L0 = 0;
+		const int32_t CC0 = L0 * C;
+		{
+			const int32_t r = i0 - lane;
+			Sd[lane] = (r >= 1) ? (uint8_t)(wtz_as_global(zb)[r] - wtz_as_global(zb)[r - 1]) : (uint8_t)0;
+		}
+		const int32_t cA = i0 >> 6;
+		const uint8_t *chA = wtz_as_global(zchunk)[cA];
+		const uint8_t *chB = cA > 0 ? wtz_as_global(zchunk)[cA - 1] : chA;
+		const bool act = lane < NDW && (L0 + ln_off) < NL;
+		const uint32_t doff = act ? ((uint32_t)q4 * (uint32_t)NL + (uint32_t)(L0 + ln_off)) * 4u : 0u;
+		const uint32_t pos0 = (uint32_t)ln_off * (uint32_t)C + (uint32_t)q4 * 4u;
+		for(int r8 = 0; r8 < 64; r8 += 8){
+			/* eight rows' loads are issued before the first is used; rows above row 0 re-read row 0 (never walked), idle lanes dword 0 (never stored) */
+			uint32_t w8[8];
+			#pragma unroll
+			for(int u = 0; u < 8; u++){
+				int32_t r = i0 - (r8 + u); if(r < 0) r = 0;
+				const uint8_t *rowp = ((r >> 6) == cA ? chA : chB) + (size_t)(r & 63) * zrow;
+				w8[u] = *wtz_as_global((const uint32_t*)(rowp + doff));
+			}
+			if(act){
+				#pragma unroll
+				for(int u = 0; u < 8; u++){
+					/* the kernel's 5 decision bits -> the walker's byte: bits 1:0 move from H, bits 3:2 from E, bits 5:4 from F, bit 7 bases equal */
+					const uint32_t w = w8[u];
+					const uint32_t a = (w >> 3) & 0x01010101u, b = (w >> 4) & 0x01010101u;
+					const uint32_t v = (a << 1) | (b & (a ^ 0x01010101u)) | (w & 0x04040404u) | ((w & 0x02020202u) << 4) | ((w & 0x01010101u) << 7);
+					const uint32_t pos = (uint32_t)(r8 + u) * 128u + pos0;
+					if constexpr((C & 3) == 0) S32[pos >> 2] = v;
+					else {
+						#pragma unroll
+						for(int k = 0; k < 4; k++) if(q4 * 4 + k < C) S8[pos + k] = (uint8_t)(v >> (8 * k));
+					}
+				}
+			}
+		}
+		__threadfence_block();
+		if(lane == 0){
+			while(i_ >= 0 && j_ >= 0){
+				const int32_t rr = i0 - i_;
+				if(rr >= 64) break;
+				uint32_t zv = 0;
+				if((uint32_t)cc < (uint32_t)(NL * C)){          /* outside the band the kernel stored nothing: a zero byte, as the byte-wise staging had it */
+					const int32_t t = cc - CC0;
+					if((uint32_t)t >= (uint32_t)ROWB) break;
+					zv = S8[rr * 128 + t];
+				}
+				const int32_t sft = (int32_t)Sd[rr];
+				d_ = (zv >> (d_ << 1)) & 0x03;
+				if(d_ == 0){ if(zv & 0x80u) x.mat++; else x.mis++; i_--; j_--; cc += sft - 1; }
+				else if(d_ == 1){ i_--; x.ins++; cc += sft; }
+				else { j_--; x.del++; cc--; }
+				if(d_ == run_op) run_len++;
+				else { if(run_len) wtz_cigw_push(Wr, run_op, run_len); run_op = d_; run_len = 1; }
+			}
+		}
+		i_ = __builtin_amdgcn_readfirstlane(i_); j_ = __builtin_amdgcn_readfirstlane(j_); cc = __builtin_amdgcn_readfirstlane(cc);
+		__threadfence_block();
+	}
+	if(lane == 0){
+		if(run_len) wtz_cigw_push(Wr, run_op, run_len);
+		if(i_ >= 0){ x.ins += i_ + 1; wtz_cigw_push(Wr, 1, (uint32_t)(i_ + 1)); }
+		if(j_ >= 0){ x.del += j_ + 1; wtz_cigw_push(Wr, 2, (uint32_t)(j_ + 1)); }
+		wtz_cigw_finish(Wr);
+		wtz_cigar_reverse(cigars.a, cigars.n);
+		x.aln = x.mat + x.mis + x.ins + x.del; x.qe++; x.te++;
+	}
+}
+
 /*
  * K-sw3 with the DP rows entirely in registers (the form the job kernel runs; wtz_extend_shift_wave_rt above is its
  * fallback and on-device cross-check).  Lane l owns the C band-relative columns l*C .. l*C+C-1.  The band start moves
@@ -720,63 +818,8 @@ WTZ_D wtz_aln_t wtz_extend_shift_reg(int32_t qlen, const wtz_seq_packed &query, 
 	else { x.score = mx; x.qe = mi; x.te = mj; }
 	__threadfence_block();     /* the trace was written by lanes of THIS wave: ordering inside the wave is enough (an agent-scope fence would write back the whole L2) */
 	const unsigned long long pt_tb3 = WTZ_PROF_T(); (void)pt_tb3;
-	/* ---- traceback.  Lane 0 walks, but never against HBM latency: for the 64 rows below the current cell every lane
-	 * copies one row's trace bytes of the WC absolute columns ending at the current column into LDS (the target words are
-	 * dead by now); the walk leaves the block after 64 rows or - rarely - through its left edge, and the next block is
-	 * staged.  Runs go through the register-tail writer and are reversed once at the end. ---- */
-	{
-		constexpr int WC = 124;
-		uint8_t *S = (uint8_t*)tb;
-		int32_t i_ = x.qe, j_ = x.te; uint32_t d_ = 0;
-		uint32_t run_op = 0xFFu, run_len = 0;
-		wtz_cigw_t Wr; Wr.v = &cigars; Wr.tail = 0;
-		while(i_ >= 0 && j_ >= 0){
-			const int32_t i0 = i_, jlo = j_ - (WC - 1);
-			{
-				const int32_t r = i0 - lane;
-				if(r >= 0){
-					const int32_t zbr = zb[r];
-					const uint8_t *rowp = zchunk[r >> 6] + (size_t)(r & 63) * zrow;
-					for(int32_t t = 0; t < WC; t++){
-						const int32_t cc = jlo + t - zbr;
-						uint8_t v = 0;
-						if(cc >= 0 && cc < 64 * C){
-							const int32_t ln = cc / C, kk = cc - ln * C;
-							const uint32_t r5 = rowp[(size_t)(kk >> 2) * 256 + (size_t)ln * 4 + (kk & 3)];
-							/* the kernel's 5 decision bits -> the walker's byte: bits 1:0 move from H, bits 3:2 from E, bits 5:4 from F, bit 7 bases equal */
-							const uint32_t dirh = (r5 & 8u) ? 2u : ((r5 >> 4) & 1u);
-							v = (uint8_t)(dirh | (r5 & 4u) | ((r5 & 2u) << 4) | ((r5 & 1u) << 7));
-						}
-						S[lane * WC + t] = v;
-					}
-				}
-			}
-			__threadfence_block();
-			if(lane == 0){
-				while(i_ >= 0 && j_ >= 0){
-					const int32_t rr = i0 - i_, t = j_ - jlo;
-					if(rr >= 64 || t < 0) break;
-					const uint32_t zv = S[rr * WC + t];
-					d_ = (zv >> (d_ << 1)) & 0x03;
-					if(d_ == 0){ if(zv & 0x80u) x.mat++; else x.mis++; i_--; j_--; }
-					else if(d_ == 1){ i_--; x.ins++; }
-					else { j_--; x.del++; }
-					if(d_ == run_op) run_len++;
-					else { if(run_len) wtz_cigw_push(Wr, run_op, run_len); run_op = d_; run_len = 1; }
-				}
-			}
-			i_ = __builtin_amdgcn_readfirstlane(i_); j_ = __builtin_amdgcn_readfirstlane(j_);
-			__threadfence_block();
-		}
-		if(lane == 0){
-			if(run_len) wtz_cigw_push(Wr, run_op, run_len);
-			if(i_ >= 0){ x.ins += i_ + 1; wtz_cigw_push(Wr, 1, (uint32_t)(i_ + 1)); }
-			if(j_ >= 0){ x.del += j_ + 1; wtz_cigw_push(Wr, 2, (uint32_t)(j_ + 1)); }
-			wtz_cigw_finish(Wr);
-			wtz_cigar_reverse(cigars.a, cigars.n);
-			x.aln = x.mat + x.mis + x.ins + x.del; x.qe++; x.te++;
-		}
-	}
+	WTZ_PROF_CNT(60, i < ql ? i + 1 : ql); WTZ_PROF_CNT(61, 1);
+	wtz_shift_traceback<C, 64>(x, zchunk, zb, zrow, tb, cigars);
 	WTZ_PROF_ADD(9, pt_tb3);
 	return wtz_bcast_aln(x);
 }
@@ -949,6 +992,7 @@ WTZ_D wtz_aln_t wtz_extend_shift_mw(int32_t qlen, const wtz_seq_packed &query, i
 		tbits_n = shb ? ((w0 >> shb) | (w1 << (64 - shb))) : w0;
 	}
 	__builtin_amdgcn_s_waitcnt(0x0F70);
+	const unsigned long long pt_mwrows = WTZ_PROF_T(); (void)pt_mwrows;
 	for(i = 0; i < ql; i++){
 		if((i & 63) == 0){
 			if(tid == 0){ uint8_t *p = (uint8_t*)wtz_pool_alloc(pool, (size_t)zrow * 64); wtz_as_global(zchunk)[(uint32_t)i >> 6] = p; sh->zbase = (unsigned long long)(uintptr_t)p; }
@@ -1103,60 +1147,12 @@ WTZ_D wtz_aln_t wtz_extend_shift_mw(int32_t qlen, const wtz_seq_packed &query, i
 	if(cells && tid == 0) *cells += ncell;
 	__syncthreads();                /* every wave's trace is visible to wave 0; the target words in LDS are dead */
 	if(!*ok || wid != 0) return x;
+	WTZ_PROF_ADD(56, pt_mwrows); WTZ_PROF_CNT(58, i < ql ? i + 1 : ql); WTZ_PROF_CNT(59, 1);
 	if(gmax > 0 && gmax >= mx + T){ x.score = gmax; x.qe = gi; x.te = gj; }
 	else { x.score = mx; x.qe = mi; x.te = mj; }
-	{
-		constexpr int WC = 124;
-		uint8_t *Sb = (uint8_t*)tb;
-		int32_t i_ = x.qe, j_ = x.te; uint32_t d_ = 0;
-		uint32_t run_op = 0xFFu, run_len = 0;
-		wtz_cigw_t Wr; Wr.v = &cigars; Wr.tail = 0;
-		while(i_ >= 0 && j_ >= 0){
-			const int32_t i0 = i_, jlo = j_ - (WC - 1);
-			{
-				const int32_t r = i0 - lane;
-				if(r >= 0){
-					const int32_t zbr = zb[r];
-					const uint8_t *rowp = zchunk[r >> 6] + (size_t)(r & 63) * zrow;
-					for(int32_t t = 0; t < WC; t++){
-						const int32_t cc = jlo + t - zbr;
-						uint8_t v = 0;
-						if(cc >= 0 && cc < NL * C){
-							const int32_t ln = cc / C, kk = cc - ln * C;
-							const uint32_t r5 = rowp[(size_t)(kk >> 2) * (NL * 4) + (size_t)ln * 4 + (kk & 3)];
-							const uint32_t dirh = (r5 & 8u) ? 2u : ((r5 >> 4) & 1u);
-							v = (uint8_t)(dirh | (r5 & 4u) | ((r5 & 2u) << 4) | ((r5 & 1u) << 7));
-						}
-						Sb[lane * WC + t] = v;
-					}
-				}
-			}
-			__threadfence_block();
-			if(lane == 0){
-				while(i_ >= 0 && j_ >= 0){
-					const int32_t rr = i0 - i_, t = j_ - jlo;
-					if(rr >= 64 || t < 0) break;
-					const uint32_t zv = Sb[rr * WC + t];
-					d_ = (zv >> (d_ << 1)) & 0x03;
-					if(d_ == 0){ if(zv & 0x80u) x.mat++; else x.mis++; i_--; j_--; }
-					else if(d_ == 1){ i_--; x.ins++; }
-					else { j_--; x.del++; }
-					if(d_ == run_op) run_len++;
-					else { if(run_len) wtz_cigw_push(Wr, run_op, run_len); run_op = d_; run_len = 1; }
-				}
-			}
-			i_ = __builtin_amdgcn_readfirstlane(i_); j_ = __builtin_amdgcn_readfirstlane(j_);
-			__threadfence_block();
-		}
-		if(lane == 0){
-			if(run_len) wtz_cigw_push(Wr, run_op, run_len);
-			if(i_ >= 0){ x.ins += i_ + 1; wtz_cigw_push(Wr, 1, (uint32_t)(i_ + 1)); }
-			if(j_ >= 0){ x.del += j_ + 1; wtz_cigw_push(Wr, 2, (uint32_t)(j_ + 1)); }
-			wtz_cigw_finish(Wr);
-			wtz_cigar_reverse(cigars.a, cigars.n);
-			x.aln = x.mat + x.mis + x.ins + x.del; x.qe++; x.te++;
-		}
-	}
+	const unsigned long long pt_mwtb = WTZ_PROF_T(); (void)pt_mwtb;
+	wtz_shift_traceback<C, NL>(x, zchunk, zb, zrow, tb, cigars);
+	WTZ_PROF_ADD(57, pt_mwtb);
 	return wtz_bcast_aln(x);
 }
 
@@ -1503,7 +1499,7 @@ WTZ_D void wtz_fixed_problem_wave(int32_t qlen, const wtz_seq_packed &q, int32_t
 			if(cmin == 4) y = wtz_extend_fixed_reg<4, true>(qlen, q, tlen, t, score_in, ql, tl, W, M, X, I, D, E, T, L.tb, zg, (uint32_t)zrow, R.runs, &R.n_runs, cells, ztr);
 			else          y = wtz_extend_fixed_reg<8, true>(qlen, q, tlen, t, score_in, ql, tl, W, M, X, I, D, E, T, L.tb, zg, (uint32_t)zrow, R.runs, &R.n_runs, cells, ztr);
 		}
-		WTZ_PROF_ADD(9, pt0); WTZ_PROF_CNT(7, 1); WTZ_PROF_CNT(13, ql); WTZ_PROF_CNT(14, n_col);
+		WTZ_PROF_ADD(55, pt0); WTZ_PROF_CNT(7, 1); WTZ_PROF_CNT(13, ql); WTZ_PROF_CNT(14, n_col);
 	} else if(qlen <= 0 || tlen <= 0){
 		/* empty problem (wtz_extend_fixed: score = init, nothing aligned, empty CIGAR) */
 		memset(&y, 0, sizeof y); y.score = init; if(lane == 0) tmp.n = 0;

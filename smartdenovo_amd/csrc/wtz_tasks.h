@@ -299,7 +299,7 @@ WTZ_D void wtz_task_winalign4(uint32_t t_base, uint32_t n, const wtz_env_t &V, c
 	const wtz_alnitem_t &it = items[tasks[t].item];
 	const wtz_win_t &w = it.win[tasks[t].widx];
 	wtz_reg_t reg; memset(&reg, 0, sizeof reg);
-	wtz_cigar_t cigar; cigar.init(V.pool, gl == 0 ? 64 : 0);
+	wtz_cigar_t cigar; cigar.init(V.pool, gl == 0 ? (w.anchors[1] - w.anchors[0]) * 14u + 16u : 0);
 	unsigned long long cells = 0;
 	bool ok = true, dfr = false;
 	reg.x = wtz_align_window_grp(wtz_view(V.R, it.q, 0), wtz_view(V.R, it.c, it.dir), w, it.anchors, cigar, P, V.pool, (uint8_t*)wtz_wave_scratch() + (size_t)g * WTZ_GRP_LDS_BYTES, &cells, &ok, &dfr);
