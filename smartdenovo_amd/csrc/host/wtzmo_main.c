@@ -139,7 +139,10 @@ typedef struct {       /* one batch in flight */
 	int pf_inflight; uint32_t *pf_ids; uint32_t pf_n, pf_cap; uint64_t *pf_rows; uint32_t *pf_nr; uint32_t pf_cursor_end;
 } batch_t;
 
-#define DIE_WTZ(rc, what) do { if((rc) != WTZ_OK){ fprintf(stderr, " -- %s failed: %s --\n", what, wtz_last_error()); exit(1); } } while(0)
+/* a device-stage failure ends the process at once: other host threads (index builders, parts) may still be inside HIP calls, and running the
+ * exit handlers / the HIP runtime's teardown under them ends in a segmentation fault instead of exit code 1 */
+#define DIE_NOW() do { fflush(NULL); _exit(1); } while(0)
+#define DIE_WTZ(rc, what) do { if((rc) != WTZ_OK){ fprintf(stderr, " -- %s failed: %s --\n", what, wtz_last_error()); DIE_NOW(); } } while(0)
 
 static double now_s(void);
 static uint32_t nbest_of(const eng_t *E, uint32_t id){
@@ -1146,7 +1149,7 @@ int main(int argc, char **argv){
 				free(tmp_rows); free(tmp_n);
 			}
 		}
-		for(uint32_t d = 1; d < E->ndev; d++){ pthread_join(ixth[d], NULL); if(ixj[d].rc != WTZ_OK){ fprintf(stderr, " -- index build on device %d failed: %s --\n", E->devs[d], ixj[d].err); exit(1); } }
+		for(uint32_t d = 1; d < E->ndev; d++){ pthread_join(ixth[d], NULL); if(ixj[d].rc != WTZ_OK){ fprintf(stderr, " -- index build on device %d failed: %s --\n", E->devs[d], ixj[d].err); DIE_NOW(); } }
 		/* ---- queries: pipelined batches on n_workers contexts (own stream + pool each, indexes shared) ---- */
 		if(pin_started){ pthread_join(pin_th, NULL); pin_started = 0; }
 		{

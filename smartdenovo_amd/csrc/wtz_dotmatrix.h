@@ -165,8 +165,8 @@ WTZ_HD void wtz_denoise_dir(wtz_zhit_t *rs, uint32_t n_rs, uint32_t dir, wtz_dms
  * strand in LDS - per match (off1<<10 | len1), its index in rs, its group id; per distinct diagonal (offset, first match,
  * number of band members) - and lane 0 runs the band loop / group merging on that image only.  The grouped matches are
  * then ordered by (group, off1) with the wave-wide bitonic network (an equal key makes lane 0 redo the swap-exact sort
- * from the original order), gathered into LDS and folded into blocks.  Returns false without having changed anything
- * when the strand does not fit the LDS slice (the caller then runs wtz_denoise_dir on lane 0).
+ * from the original order), gathered into LDS and folded into blocks.  Returns non-zero without having changed anything
+ * when the strand does not fit (the caller retries with a larger slice, then the `big` form, then wtz_denoise_dir on lane 0).
  */
 #ifndef WTZ_DM_BCAP_BIG_AT
 #define WTZ_DM_BCAP_BIG_AT 49152u
@@ -220,27 +220,45 @@ WTZ_HD uint32_t wtz_denoise_lds_need(uint32_t nf, uint32_t nd, uint32_t lds_byte
 	return ((5u * (nf + 4u) + 7u) & ~7u) + 8u * (nd + 2u) + fixed;
 }
 
-WTZ_HD bool wtz_denoise_dir_coop(const wtz_zhit_t *rs, uint32_t n_rs, uint32_t dir, uint32_t nf, uint32_t nd, wtz_dmscratch_t &S, int32_t xvar, int32_t yvar, int32_t min_linear_len,
-		uint8_t *lds, uint32_t lds_bytes, wtz_pool_t *pool, int32_t *bad){
+/* `big` (the last launch only): group ids of two bytes (up to WTZ_DM_GCAP_BIG linear groups instead of 255) and, when the per-match /
+ * per-diagonal image still does not fit the slice next to the band work arrays, the image in the pool (the lane-0 loops then run
+ * against L2 instead of LDS - several times slower than the LDS form, tens of times faster than the scalar body, which pays ~10
+ * dependent HBM loads per match).  Returns 0 when done, else why not: 1 image too large, 2 band list overflow, 3 group table
+ * overflow, 4 not applicable; nothing the caller sees has changed then. */
+#define WTZ_DM_GCAP_BIG 8191u
+WTZ_HD int wtz_denoise_dir_coop(const wtz_zhit_t *rs, uint32_t n_rs, uint32_t dir, uint32_t nf, uint32_t nd, wtz_dmscratch_t &S, int32_t xvar, int32_t yvar, int32_t min_linear_len,
+		uint8_t *lds, uint32_t lds_bytes, wtz_pool_t *pool, int32_t *bad, bool big = false){
 	const uint32_t lane = WTZ_LANE;
-	if(lds == NULL || n_rs > 65535u) return false;
-	/* LDS image: per match 4 B (off1<<10 | len1) + 1 B (group id); per distinct diagonal 4 B (offset) + 2 B (first match) +
-	 * 2 B (band members); band keys / member lists and the group table.  The rs index of a match is only needed by the
+	if(lds == NULL || n_rs > 65535u){ WTZ_PROF_CNT(60, 1000000); return 4; }
+	/* image: per match 4 B (off1<<10 | len1) + 1 B (group id; 2 B when big); per distinct diagonal 4 B (offset) + 2 B (first match) +
+	 * 2 B (band members).  Work arrays: band keys / member lists and the group table.  The rs index of a match is only needed by the
 	 * parallel passes: it lives in the pool. */
-	const uint32_t bcap = WTZ_DM_BCAP(lds_bytes);
-	if(wtz_denoise_lds_need(nf, nd, lds_bytes) > lds_bytes) return false;
+	const uint32_t bcap = WTZ_DM_BCAP(lds_bytes), gcap = big ? WTZ_DM_GCAP_BIG : WTZ_DM_GCAP;
+	const uint32_t off_d = ((big ? 6u : 5u) * (nf + 4u) + 7u) & ~7u;
+	const uint32_t img_bytes = off_d + 8u * (nd + 2u), wrk_bytes = 8u * bcap + 2u * gcap + 40u;
+	uint8_t *img = lds, *wrk = lds + img_bytes;
+	if(!big){ if(wtz_denoise_lds_need(nf, nd, lds_bytes) > lds_bytes){ WTZ_PROF_CNT(61, 1000000); return 1; } }
+	else if(wrk_bytes > lds_bytes) return 1;
+	else if(img_bytes + wrk_bytes > lds_bytes){
+		uint64_t ia = 0;
+		if(lane == 0) ia = (uint64_t)(uintptr_t)wtz_pool_alloc(pool, (size_t)img_bytes + 16u);
+		ia = wtz_coop_bcast64(ia);
+		if(ia == 0){ *bad = 1; if(lane == 0) S.regs[dir].n = 0; return 0; }
+		img = (uint8_t*)(uintptr_t)ia; wrk = lds;
+	}
 	uint64_t ra = 0;
 	if(lane == 0) ra = (uint64_t)(uintptr_t)wtz_pool_alloc(pool, (size_t)(nf + 2u) * 2u);
 	ra = wtz_coop_bcast64(ra);
 	uint16_t *ridx = (uint16_t*)(uintptr_t)ra;            /* index in rs (pool) */
-	if(ridx == NULL){ *bad = 1; if(lane == 0) S.regs[dir].n = 0; return true; }
-	uint32_t *T = (uint32_t*)lds;
-	uint8_t *gid = (uint8_t*)(T + (nf + 2u));             /* group id of the match */
-	const uint32_t off_d = (5u * (nf + 4u) + 7u) & ~7u;
-	int32_t *Doff = (int32_t*)(lds + off_d);              /* diagonal offset */
+	if(ridx == NULL){ *bad = 1; if(lane == 0) S.regs[dir].n = 0; return 0; }
+	uint32_t *T = (uint32_t*)img;
+	uint8_t *gid8 = (uint8_t*)(T + (nf + 2u)); uint16_t *gid16 = (uint16_t*)(T + (nf + 2u));      /* group id of the match */
+#define WTZ_GID(i) (big ? (uint32_t)gid16[i] : (uint32_t)gid8[i])
+#define WTZ_GID_SET(i, v) do { if(big) gid16[i] = (uint16_t)(v); else gid8[i] = (uint8_t)(v); } while(0)
+	int32_t *Doff = (int32_t*)(img + off_d);              /* diagonal offset */
 	uint16_t *Dfo = (uint16_t*)(Doff + (nd + 2u));        /* first match (strand-compacted position) */
 	uint16_t *Dmc = Dfo + (nd + 2u);                      /* matches the band loop takes from it */
-	uint32_t *bk = (uint32_t*)(((uintptr_t)(Dmc + (nd + 2u)) + 3u) & ~(uintptr_t)3u);      /* band keys; later run heads */
+	uint32_t *bk = (uint32_t*)(((uintptr_t)wrk + 3u) & ~(uintptr_t)3u);      /* band keys; later run heads */
 	uint16_t *blk = (uint16_t*)(bk + bcap);               /* band members, diagonal order */
 	uint16_t *sblk = blk + bcap;                           /* band members, off1 order */
 	uint16_t *grp = sblk + bcap;
@@ -272,7 +290,7 @@ WTZ_HD bool wtz_denoise_dir_coop(const wtz_zhit_t *rs, uint32_t n_rs, uint32_t d
 				if(keep){ last_dg = dg; have = 1; }
 #endif
 				uint32_t htot; const uint32_t hpos = wtz_coop_rank(head, &htot);
-				if(keep){ T[n + pos] = (ZH_OFF1(hh[u]) << 10) | (ZH_LEN1(hh[u]) & 0x3FFu); gid[n + pos] = 0; ridx[n + pos] = (uint16_t)idx; }
+				if(keep){ T[n + pos] = (ZH_OFF1(hh[u]) << 10) | (ZH_LEN1(hh[u]) & 0x3FFu); WTZ_GID_SET(n + pos, 0); ridx[n + pos] = (uint16_t)idx; }
 				if(head){ Doff[h + hpos] = dg; Dfo[h + hpos] = (uint16_t)(n + pos); }
 				n += tot; h += htot;
 			}
@@ -303,7 +321,7 @@ WTZ_HD bool wtz_denoise_dir_coop(const wtz_zhit_t *rs, uint32_t n_rs, uint32_t d
 	if(lane == 0) ba = (uint64_t)(uintptr_t)wtz_pool_alloc(pool, (size_t)(nd + 2u) * 8u);
 	ba = wtz_coop_bcast64(ba);
 	uint32_t *bands = (uint32_t*)(uintptr_t)ba;           /* doff<<16 | dcnt per band, then the productive subset */
-	if(bands == NULL){ *bad = 1; if(lane == 0) S.regs[dir].n = 0; return true; }
+	if(bands == NULL){ *bad = 1; if(lane == 0) S.regs[dir].n = 0; return 0; }
 	uint32_t *prod = bands + (nd + 2u);
 	uint32_t nbands = 0;
 	if(lane == 0){
@@ -380,7 +398,7 @@ WTZ_HD bool wtz_denoise_dir_coop(const wtz_zhit_t *rs, uint32_t n_rs, uint32_t d
 			if(nb + tot <= bcap){ for(uint32_t j = 0; j < mc; j++) blk[nb + ex + j] = (uint16_t)(fo + j); }
 			nb += tot;
 		}
-		if(nb > bcap){ fail = 1; break; }
+		if(nb > bcap){ fail = 2; WTZ_PROF_CNT(62, 1000000); break; }
 		WTZ_WAVE_SYNC();
 		uint32_t np2 = 64; while(np2 < nb) np2 <<= 1;
 		for(uint32_t i = lane; i < np2; i += WTZ_NLANES) bk[i] = i < nb ? (((T[blk[i]] >> 10) << 11) | i) : 0xFFFFFFFFu;
@@ -442,19 +460,19 @@ WTZ_HD bool wtz_denoise_dir_coop(const wtz_zhit_t *rs, uint32_t n_rs, uint32_t d
 		for(uint32_t q = 0; q < npr && !fail; q++){
 			const uint32_t r = pruns[q], j = heads[r], i = heads[r + 1];
 			uint32_t gmin = 0xFFFFFFFFu;
-			for(uint32_t k = j + lane; k < i; k += WTZ_NLANES){ const uint32_t g = gid[sblk[k]]; if(g){ const uint32_t v = grp[g]; gmin = v < gmin ? v : gmin; } }
+			for(uint32_t k = j + lane; k < i; k += WTZ_NLANES){ const uint32_t g = WTZ_GID(sblk[k]); if(g){ const uint32_t v = grp[g]; gmin = v < gmin ? v : gmin; } }
 			gmin = wtz_coop_min32(gmin);
 			uint32_t g0;
 			if(gmin == 0xFFFFFFFFu){
-				if(ngrp >= WTZ_DM_GCAP){ fail = 1; break; }
+				if(ngrp >= gcap){ fail = 3; WTZ_PROF_CNT(63, 1000000); break; }
 				g0 = ngrp; if(lane == 0) grp[ngrp] = (uint16_t)g0; ngrp++;
 			} else {
 				g0 = gmin;
 				WTZ_WAVE_SYNC();
-				for(uint32_t k = j + lane; k < i; k += WTZ_NLANES){ const uint32_t g = gid[sblk[k]]; if(g) grp[g] = (uint16_t)g0; }
+				for(uint32_t k = j + lane; k < i; k += WTZ_NLANES){ const uint32_t g = WTZ_GID(sblk[k]); if(g) grp[g] = (uint16_t)g0; }
 			}
 			WTZ_WAVE_SYNC();
-			for(uint32_t k = j + lane; k < i; k += WTZ_NLANES) gid[sblk[k]] = (uint8_t)g0;
+			for(uint32_t k = j + lane; k < i; k += WTZ_NLANES) WTZ_GID_SET(sblk[k], g0);
 			WTZ_WAVE_SYNC();
 		}
 	}
@@ -469,31 +487,31 @@ WTZ_HD bool wtz_denoise_dir_coop(const wtz_zhit_t *rs, uint32_t n_rs, uint32_t d
 		}
 	}
 	fail = wtz_coop_bcast32(fail);
-	if(fail) return false;
+	if(fail) return (int)fail;
 	WTZ_WAVE_SYNC();
 	/* ---- grouped matches, ordered by (group, off1) (hzm_aln.h:848-857) ---- */
 	uint32_t n_dst = 0;
 	for(uint32_t x0 = 0; x0 < nf; x0 += WTZ_NLANES){
 		const uint32_t x = x0 + lane;
-		const bool keep = x < nf && gid[x] != 0;
+		const bool keep = x < nf && WTZ_GID(x) != 0;
 		uint32_t tot; (void)wtz_coop_rank(keep, &tot); n_dst += tot;
 	}
 	if(lane == 0) S.regs[dir].n = 0;
-	if(n_dst == 0) return true;
+	if(n_dst == 0) return 0;
 	uint32_t np = 64; while(np < n_dst) np <<= 1;
 	uint64_t ka = 0;
 	if(lane == 0) ka = (uint64_t)(uintptr_t)wtz_pool_alloc(pool, (size_t)np * 8 + (size_t)(n_dst + 1) * sizeof(wtz_zhit_t));
 	ka = wtz_coop_bcast64(ka);
 	uint64_t *K = (uint64_t*)(uintptr_t)ka;
-	if(K == NULL){ *bad = 1; return true; }
+	if(K == NULL){ *bad = 1; return 0; }
 	wtz_zhit_t *dstv = (wtz_zhit_t*)(K + np);
 	for(int pass = 0; pass < 2; pass++){
 		uint32_t n = 0;
 		for(uint32_t x0 = 0; x0 < nf; x0 += WTZ_NLANES){
 			const uint32_t x = x0 + lane;
-			const bool keep = x < nf && gid[x] != 0;
+			const bool keep = x < nf && WTZ_GID(x) != 0;
 			uint32_t tot; const uint32_t pos = wtz_coop_rank(keep, &tot);
-			if(keep) K[n + pos] = ((uint64_t)grp[gid[x]] << 37) | ((uint64_t)(T[x] >> 10) << 16) | x;
+			if(keep) K[n + pos] = ((uint64_t)grp[WTZ_GID(x)] << 37) | ((uint64_t)(T[x] >> 10) << 16) | x;
 			n += tot;
 		}
 		WTZ_WAVE_SYNC();
@@ -549,7 +567,9 @@ WTZ_HD bool wtz_denoise_dir_coop(const wtz_zhit_t *rs, uint32_t n_rs, uint32_t d
 		}
 	}
 	WTZ_WAVE_SYNC();
-	return true;
+	return 0;
+#undef WTZ_GID
+#undef WTZ_GID_SET
 }
 
 WTZ_HD void wtz_denoise(wtz_zhit_t *rs, uint32_t n_rs, wtz_dmscratch_t &S, int32_t xvar, int32_t yvar, int32_t min_linear_len, bool presorted){
@@ -693,8 +713,13 @@ WTZ_HD wtz_dm_result_t wtz_dot_matrix_align(wtz_vec<wtz_zhit_t> &cache, wtz_pool
 	/* dst of strand 0 is consumed before strand 1 reuses it: regs only keep bounds */
 	for(uint32_t dir = 0; dir < 2; dir++){
 		const unsigned long long ptd = WTZ_PROF_T();
-		if(!(cache.n <= 65535u && lds && wtz_denoise_dir_coop(cache.a, cache.n, dir, cnts.nf[dir], cnts.nd[dir], S, P->xvar, P->yvar, P->min_block_len, lds, lds_bytes, pool, bad))){
-			if(defer_if_large && cache.n <= 65535u && lds){ ret.dir = -2; ret.score = 0; return ret; }      /* band / group table overflow: retry with the larger slice */
+		int why = 4;
+		if(cache.n <= 65535u && lds){
+			why = wtz_denoise_dir_coop(cache.a, cache.n, dir, cnts.nf[dir], cnts.nd[dir], S, P->xvar, P->yvar, P->min_block_len, lds, lds_bytes, pool, bad);
+			if(why && defer_if_large){ ret.dir = -2; ret.score = 0; return ret; }      /* band / group table overflow: retry with the larger slice */
+			if(why) why = wtz_denoise_dir_coop(cache.a, cache.n, dir, cnts.nf[dir], cnts.nd[dir], S, P->xvar, P->yvar, P->min_block_len, lds, lds_bytes, pool, bad, true);      /* last launch: wide group ids, image in the pool if need be */
+		}
+		if(why){
 			const unsigned long long ptf = WTZ_PROF_T();
 			if(lane == 0) wtz_denoise_dir(cache.a, cache.n, dir, S, P->xvar, P->yvar, P->min_block_len);
 			WTZ_WAVE_SYNC();

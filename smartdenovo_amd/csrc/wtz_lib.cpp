@@ -371,10 +371,14 @@ extern "C" int wtz_ctx_create(int device, const wtz_params_c *params, uint64_t p
 	c->zoff = NULL; c->n_z = 0; memset(&c->Z, 0, sizeof c->Z); c->have_z = false;
 	c->dpool = NULL; c->pool_base = NULL; c->pool_bytes = pool_bytes ? pool_bytes : (4ull << 30);
 #ifndef WTZ_EMUL
-	if(!pool_bytes){      /* default: a third of the free HBM, at most 64 GB (288 GB per MI355X; the reads and both indexes of a 1.2 Gbp set take ~25 GB) */
+	if(!pool_bytes){
+		/* default: 45 % of the free HBM, at most 128 GB (288 GB per MI355X; reads + both indexes of a 1.2 Gbp set take ~25 GB).  The host driver
+		 * cuts a batch into ranges that fit the pool (wtz_pool_info) and every stage of a range ends in the tail of its slowest tasks:
+		 * configs[2] runs in 36 ranges / 5.30 s with 64 GB, 22 ranges / 5.17 s with 128 GB, no further gain at 200 GB.  A second context on
+		 * the same device (--workers 2, wtz_ctx_clone) takes 45 % of what is left. */
 		size_t fr = 0, tot = 0;
-		if(hipMemGetInfo(&fr, &tot) == hipSuccess && fr / 3 > c->pool_bytes) c->pool_bytes = (uint64_t)(fr / 3);
-		if(c->pool_bytes > (64ull << 30)) c->pool_bytes = 64ull << 30;      /* the host driver sizes its batches to the pool (wtz_pool_info) */
+		if(hipMemGetInfo(&fr, &tot) == hipSuccess && fr / 20 * 9 > c->pool_bytes) c->pool_bytes = (uint64_t)(fr / 20 * 9);
+		if(c->pool_bytes > (128ull << 30)) c->pool_bytes = 128ull << 30;
 	}
 #endif
 	c->pool_bytes &= ~(uint64_t)4095; c->main_bytes = (c->pool_bytes / 2) & ~(uint64_t)4095;
