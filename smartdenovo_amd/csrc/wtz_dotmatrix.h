@@ -233,7 +233,13 @@ WTZ_HD int wtz_denoise_dir_coop(const wtz_zhit_t *rs, uint32_t n_rs, uint32_t di
 	/* image: per match 4 B (off1<<10 | len1) + 1 B (group id; 2 B when big); per distinct diagonal 4 B (offset) + 2 B (first match) +
 	 * 2 B (band members).  Work arrays: band keys / member lists and the group table.  The rs index of a match is only needed by the
 	 * parallel passes: it lives in the pool. */
-	const uint32_t bcap = WTZ_DM_BCAP(lds_bytes), gcap = big ? WTZ_DM_GCAP_BIG : WTZ_DM_GCAP;
+	const uint32_t bcap = big ? 2048u : WTZ_DM_BCAP(lds_bytes);
+	uint32_t gcap = WTZ_DM_GCAP;
+	if(big){      /* the group table takes what the slice leaves beside the band arrays */
+		if(lds_bytes < 8u * bcap + 40u + 2u * 512u) return 1;
+		gcap = (lds_bytes - 8u * bcap - 40u) / 2u;
+		if(gcap > WTZ_DM_GCAP_BIG) gcap = WTZ_DM_GCAP_BIG;
+	}
 	const uint32_t off_d = ((big ? 6u : 5u) * (nf + 4u) + 7u) & ~7u;
 	const uint32_t img_bytes = off_d + 8u * (nd + 2u), wrk_bytes = 8u * bcap + 2u * gcap + 40u;
 	uint8_t *img = lds, *wrk = lds + img_bytes;
@@ -684,7 +690,7 @@ WTZ_HD int32_t wtz_chain_blocks(int32_t pblen1, int32_t pblen2, wtz_vec<wtz_win_
  * `lds`: the wave's LDS slice - the strand images of the denoise pass first, then the handful of blocks and the scratch
  * vectors of block merging / chaining (they are chains of tiny order-sensitive sorts: latency, not bandwidth). */
 WTZ_HD wtz_dm_result_t wtz_dot_matrix_align(wtz_vec<wtz_zhit_t> &cache, wtz_pool_t *pool, int32_t pblen1, int32_t pblen2, const wtz_params_t *P, int32_t *bad, bool presorted, uint64_t *tick_denoise,
-		uint8_t *lds, uint32_t lds_bytes, bool defer_if_large){
+		uint8_t *lds, uint32_t lds_bytes, bool defer_if_large, bool allow_big){
 	wtz_dm_result_t ret; int32_t weight[2]; uint32_t d;
 	memset(&ret, 0, sizeof ret);
 	const uint32_t lane = WTZ_LANE;
@@ -697,7 +703,7 @@ WTZ_HD wtz_dm_result_t wtz_dot_matrix_align(wtz_vec<wtz_zhit_t> &cache, wtz_pool
 	if(cache.n <= 65535u && lds){
 		cnts = wtz_dm_counts(cache.a, cache.n);
 		const uint32_t need0 = wtz_denoise_lds_need(cnts.nf[0], cnts.nd[0], lds_bytes), need1 = wtz_denoise_lds_need(cnts.nf[1], cnts.nd[1], lds_bytes);
-		if(defer_if_large && (need0 > need1 ? need0 : need1) > lds_bytes){ ret.dir = -2; ret.score = (int32_t)(need0 > need1 ? need0 : need1); return ret; }      /* a later launch with a larger LDS slice takes the pair */
+		if(defer_if_large && !allow_big && (need0 > need1 ? need0 : need1) > lds_bytes){ ret.dir = -2; ret.score = (int32_t)(need0 > need1 ? need0 : need1); return ret; }      /* a later launch with a larger LDS slice takes the pair */
 	}
 	wtz_dmscratch_t S;
 	S.dst.a = NULL; S.dst.n = S.dst.cap = 0; S.dst.pool = pool; S.dst.bad = 0;
@@ -715,9 +721,8 @@ WTZ_HD wtz_dm_result_t wtz_dot_matrix_align(wtz_vec<wtz_zhit_t> &cache, wtz_pool
 		const unsigned long long ptd = WTZ_PROF_T();
 		int why = 4;
 		if(cache.n <= 65535u && lds){
-			why = wtz_denoise_dir_coop(cache.a, cache.n, dir, cnts.nf[dir], cnts.nd[dir], S, P->xvar, P->yvar, P->min_block_len, lds, lds_bytes, pool, bad);
-			if(why && defer_if_large){ ret.dir = -2; ret.score = 0; return ret; }      /* band / group table overflow: retry with the larger slice */
-			if(why) why = wtz_denoise_dir_coop(cache.a, cache.n, dir, cnts.nf[dir], cnts.nd[dir], S, P->xvar, P->yvar, P->min_block_len, lds, lds_bytes, pool, bad, true);      /* last launch: wide group ids, image in the pool if need be */
+			why = wtz_denoise_dir_coop(cache.a, cache.n, dir, cnts.nf[dir], cnts.nd[dir], S, P->xvar, P->yvar, P->min_block_len, lds, lds_bytes, pool, bad, allow_big);      /* allow_big: wide group ids, image in the pool if need be */
+			if(why && defer_if_large){ ret.dir = -2; ret.score = 0; return ret; }      /* band / group table overflow: the next launch takes the pair */
 		}
 		if(why){
 			const unsigned long long ptf = WTZ_PROF_T();

@@ -38,8 +38,15 @@ static_assert((WTZ_CAND_LDS_BYTES & (WTZ_CAND_LDS_BYTES - 1u)) == 0u && WTZ_CAND
 #ifndef WTZ_PAIR_DM_LDS_TIER2
 #define WTZ_PAIR_DM_LDS_TIER2 49152u
 #endif
+/* the last two launches keep only the band work arrays in LDS (the per-match image of a strand goes to the pool when it does not fit):
+ * what a heavy pair needs is resident waves, not LDS - a 159 KB slice meant ONE wave per CU, and the repeat-rich 40 Mbp set spent 14 of
+ * its 15 s there (159 KB: 13.8 s, 76: 7.1, 50: 5.0, 36: 4.1).  Tier 3 = eight waves per CU with room for ~2 000 linear groups per
+ * strand, tier 4 = four waves per CU with 8 191. */
 #ifndef WTZ_PAIR_DM_LDS_TIER3
-#define WTZ_PAIR_DM_LDS_TIER3 (160u * 1024u - 512u)
+#define WTZ_PAIR_DM_LDS_TIER3 20480u
+#endif
+#ifndef WTZ_PAIR_DM_LDS_TIER4
+#define WTZ_PAIR_DM_LDS_TIER4 36864u
 #endif
 /* kernel name tags (rocprofv3 shows wtz_kernel_*<K_pair, ...>) */
 struct K_candidates;
@@ -769,16 +776,18 @@ extern "C" int wtz_pairs_seed(wtz_ctx_t *c, const uint32_t *qid, const uint32_t 
 	if(c->P.dot_matrix){
 		/* pairs whose strand images exceed the LDS slice of K_pair are finished by launches with larger slices: few pairs,
 		 * but they are the long ones that would otherwise bound the batch from a single lane */
-		const uint32_t tiers[2] = { WTZ_PAIR_DM_LDS_TIER2, WTZ_PAIR_DM_LDS_TIER3 };
-		for(int tier = 0; tier < 2; tier++){
+		uint32_t tiers[3] = { WTZ_PAIR_DM_LDS_TIER2, WTZ_PAIR_DM_LDS_TIER3, WTZ_PAIR_DM_LDS_TIER4 };
+		if(getenv("WTZ_DM_TIER3_KB")) tiers[1] = (uint32_t)atoi(getenv("WTZ_DM_TIER3_KB")) << 10;
+		if(getenv("WTZ_DM_TIER4_KB")) tiers[2] = (uint32_t)atoi(getenv("WTZ_DM_TIER4_KB")) << 10;
+		for(int tier = 0; tier < 3; tier++){
 			std::vector<uint32_t> list;
 			for(uint32_t i = 0; i < n; i++) if(c->h_pairres[i].gate && c->h_pairres[i].dm_dir == -2 && !c->h_pairres[i].bad) list.push_back(i);
 			if(list.empty()) break;
 			uint32_t *d_list = NULL; CHK(dev_alloc((void**)&d_list, list.size() * 4)); CHK(dev_h2d(d_list, list.data(), list.size() * 4));
-			const uint32_t lb = tiers[tier]; const bool last = (tier == 1);
+			const uint32_t lb = tiers[tier]; const bool last = (tier == 2), big = (tier >= 1);
 			wtz_timer tt; tt.start();
 			STAGE(c, "K_pair_big");
-			CHK(wtz_launch_coop<K_pair_big>(0, list.size(), [=] WTZ_LAMBDA (uint64_t t){ wtz_task_pair_dm_big((uint32_t)t, V, d_list, dq, dc, dr, lb, last); }, lb));
+			CHK(wtz_launch_coop<K_pair_big>(0, list.size(), [=] WTZ_LAMBDA (uint64_t t){ wtz_task_pair_dm_big((uint32_t)t, V, d_list, dq, dc, dr, lb, last, big); }, lb));
 			CHK(dev_sync());
 			const double ms_t = tt.stop();
 			dev_free(d_list);

@@ -88,7 +88,7 @@ WTZ_HD void wtz_task_pair(uint32_t t, const wtz_env_t &V, const uint32_t *qid, c
 		static thread_local uint64_t emul_dm_lds[WTZ_PAIR_DM_LDS_BYTES / 8];
 		uint8_t *dlds = (uint8_t*)emul_dm_lds;
 #endif
-		wtz_dm_result_t d = wtz_dot_matrix_align(cache, V.pool, (int32_t)V.R.rdlen[q], (int32_t)V.R.rdlen[c], P, &r.bad, sorted != NULL, &tkd, dlds, WTZ_PAIR_DM_LDS_BYTES, true);
+		wtz_dm_result_t d = wtz_dot_matrix_align(cache, V.pool, (int32_t)V.R.rdlen[q], (int32_t)V.R.rdlen[c], P, &r.bad, sorted != NULL, &tkd, dlds, WTZ_PAIR_DM_LDS_BYTES, true, false);
 		if(lane != 0) return;
 		if(d.dir == -2){ r.anchors[0] = cache.a; r.nanchors[0] = cache.n; }       /* deferred: the ordered matches stay in the pool for wtz_task_pair_dm_big */
 		r.dm_score = d.score; r.dm_qb = d.qb; r.dm_qe = d.qe; r.dm_tb = d.tb; r.dm_te = d.te; r.dm_dir = d.dir;
@@ -144,8 +144,9 @@ WTZ_HD void wtz_task_pair(uint32_t t, const wtz_env_t &V, const uint32_t *qid, c
 }
 
 /* dmo pairs whose strand images did not fit the LDS slice of K_pair: same alignment over the already ordered matches, launched
- * with a larger slice (`lds_bytes`); `last` = no larger launch follows, so nothing is deferred again */
-WTZ_HD void wtz_task_pair_dm_big(uint32_t t, const wtz_env_t &V, const uint32_t *list, const uint32_t *qid, const uint32_t *cid, wtz_pairres_t *res, uint32_t lds_bytes, bool last){
+ * with another slice (`lds_bytes`); `big` = the strand image may live in the pool (wtz_denoise_dir_coop); `last` = no further launch
+ * follows, so nothing is deferred again */
+WTZ_HD void wtz_task_pair_dm_big(uint32_t t, const wtz_env_t &V, const uint32_t *list, const uint32_t *qid, const uint32_t *cid, wtz_pairres_t *res, uint32_t lds_bytes, bool last, bool big){
 	const wtz_params_t *P = V.P;
 	const uint32_t pi = list[t], q = qid[pi], c = cid[pi];
 	wtz_pairres_t r = res[pi];
@@ -153,10 +154,10 @@ WTZ_HD void wtz_task_pair_dm_big(uint32_t t, const wtz_env_t &V, const uint32_t 
 	uint64_t tkd = 0;
 #if defined(__HIP_DEVICE_COMPILE__)
 	uint8_t *dlds = (uint8_t*)wtz_wave_scratch();
-	wtz_dm_result_t d = wtz_dot_matrix_align(cache, V.pool, (int32_t)V.R.rdlen[q], (int32_t)V.R.rdlen[c], P, &r.bad, true, &tkd, dlds, lds_bytes, !last);
+	wtz_dm_result_t d = wtz_dot_matrix_align(cache, V.pool, (int32_t)V.R.rdlen[q], (int32_t)V.R.rdlen[c], P, &r.bad, true, &tkd, dlds, lds_bytes, !last, big);
 #else
-	(void)lds_bytes; (void)last;
-	wtz_dm_result_t d = wtz_dot_matrix_align(cache, V.pool, (int32_t)V.R.rdlen[q], (int32_t)V.R.rdlen[c], P, &r.bad, true, &tkd, (uint8_t*)NULL, 0, false);
+	(void)lds_bytes; (void)last; (void)big;
+	wtz_dm_result_t d = wtz_dot_matrix_align(cache, V.pool, (int32_t)V.R.rdlen[q], (int32_t)V.R.rdlen[c], P, &r.bad, true, &tkd, (uint8_t*)NULL, 0, false, false);
 #endif
 	if(WTZ_LANE != 0) return;
 	r.dm_score = d.score; r.dm_qb = d.qb; r.dm_qe = d.qe; r.dm_tb = d.tb; r.dm_te = d.te; r.dm_dir = d.dir;
