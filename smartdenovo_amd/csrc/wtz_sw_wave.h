@@ -1293,15 +1293,17 @@ WTZ_D wtz_aln_t wtz_extend_fixed_reg(int32_t qlen, const wtz_seq_packed &query, 
 		#pragma unroll
 		for(int k = 0; k < C; k++){
 			const int32_t m = mv[k], e = ein[k];
-			int32_t h = m > e ? m : e;
-			uint32_t nib = (m >= e) ? 0u : 1u;
-			nib = (h < f) ? 2u : nib;
-			h = h > f ? h : f;
-			const int32_t te = m + IE, e2 = e + E;
-			nib |= (e2 > te) ? 4u : 0u;
+			const int32_t h0 = m > e ? m : e;
+			const int32_t te = m + IE, e2 = e + E, tf = m + DE, f2 = f + E;
+			/* the four decisions as sign bits of differences (|values| < 2^23: no overflow), shifted in with v_alignbit instead of four
+			 * compare + select pairs: bit 0 m < e, bit 1 max(m,e) < f, bit 2 E extended, bit 3 F extended; the walker reads the move
+			 * from H as min(bits 1:0, 2) */
+			uint32_t nib = (uint32_t)(tf - f2) >> 31;
+			nib = __builtin_amdgcn_alignbit(nib, (uint32_t)(te - e2), 31);
+			nib = __builtin_amdgcn_alignbit(nib, (uint32_t)(h0 - f), 31);
+			nib = __builtin_amdgcn_alignbit(nib, (uint32_t)(m - e), 31);
+			const int32_t h = h0 > f ? h0 : f;
 			const int32_t en = e2 > te ? e2 : te;
-			const int32_t tf = m + DE, f2 = f + E;
-			nib |= (f2 > tf) ? 8u : 0u;
 			f = f2 > tf ? f2 : tf;
 			hp[k] = valid[k] ? h : -10000; ep[k] = valid[k] ? en : -10000;
 			nib = valid[k] ? nib : 0u;
@@ -1362,7 +1364,7 @@ WTZ_D wtz_aln_t wtz_extend_fixed_reg(int32_t qlen, const wtz_seq_packed &query, 
 					const int32_t col = j_ - (i_ > W ? i_ - W : 0);
 					const uint32_t zv = stage[(size_t)((i_ >> 1) - p0) * zrow + col];
 					const uint32_t nib = (zv >> ((i_ & 1) * 4)) & 0xFu;
-					if(d_ == 0) d_ = nib & 3u; else if(d_ == 1) d_ = (nib & 4u) ? 1u : 0u; else d_ = (nib & 8u) ? 2u : 0u;
+					if(d_ == 0){ d_ = nib & 3u; d_ = d_ > 2u ? 2u : d_; } else if(d_ == 1) d_ = (nib & 4u) ? 1u : 0u; else d_ = (nib & 8u) ? 2u : 0u;
 					if(d_ == 0){
 						const uint32_t qv = (i_ & 16) ? (uint32_t)__builtin_amdgcn_readlane((int)qw_hi, i_ >> 5) : (uint32_t)__builtin_amdgcn_readlane((int)qw_lo, i_ >> 5);
 						const uint32_t qb = (qv >> ((i_ & 15) * 2)) & 3u;
@@ -1394,7 +1396,7 @@ WTZ_D wtz_aln_t wtz_extend_fixed_reg(int32_t qlen, const wtz_seq_packed &query, 
 			const int32_t col = j_ - (i_ > W ? i_ - W : 0);
 			const uint32_t zv = ztr[(size_t)(i_ >> 1) * zrow + col];
 			const uint32_t nib = (zv >> ((i_ & 1) * 4)) & 0xFu;
-			if(d_ == 0) d_ = nib & 3u; else if(d_ == 1) d_ = (nib & 4u) ? 1u : 0u; else d_ = (nib & 8u) ? 2u : 0u;
+			if(d_ == 0){ d_ = nib & 3u; d_ = d_ > 2u ? 2u : d_; } else if(d_ == 1) d_ = (nib & 4u) ? 1u : 0u; else d_ = (nib & 8u) ? 2u : 0u;
 			if(d_ == 0){
 				const uint32_t qv = (i_ & 16) ? (uint32_t)__builtin_amdgcn_readlane((int)qw_hi, i_ >> 5) : (uint32_t)__builtin_amdgcn_readlane((int)qw_lo, i_ >> 5);
 				const uint32_t qb = (qv >> ((i_ & 15) * 2)) & 3u;
@@ -1805,15 +1807,15 @@ WTZ_D int32_t wtz_global_reg(int32_t qlen, const wtz_seq_packed &query, int32_t 
 		#pragma unroll
 		for(int k = 0; k < C; k++){
 			const int32_t m = mv[k], e = ein[k];
-			int32_t h = m > e ? m : e;
-			uint32_t nib = (m >= e) ? 0u : 1u;
-			nib = (h < f) ? 2u : nib;
-			h = h > f ? h : f;
-			const int32_t te = m - oe_del, e2 = e - e_del;
-			nib |= (e2 > te) ? 4u : 0u;
+			const int32_t h0 = m > e ? m : e;
+			const int32_t te = m - oe_del, e2 = e - e_del, tf = m - oe_ins, f2 = f - e_ins;
+			/* decisions as sign bits of differences (all values within +-2^30 + a few thousand: no overflow), see wtz_extend_fixed_reg */
+			uint32_t nib = (uint32_t)(tf - f2) >> 31;
+			nib = __builtin_amdgcn_alignbit(nib, (uint32_t)(te - e2), 31);
+			nib = __builtin_amdgcn_alignbit(nib, (uint32_t)(h0 - f), 31);
+			nib = __builtin_amdgcn_alignbit(nib, (uint32_t)(m - e), 31);
+			const int32_t h = h0 > f ? h0 : f;
 			const int32_t en = e2 > te ? e2 : te;
-			const int32_t tf = m - oe_ins, f2 = f - e_ins;
-			nib |= (f2 > tf) ? 8u : 0u;
 			f = f2 > tf ? f2 : tf;
 			hp[k] = valid[k] ? h : WTZ_MINUS_INF; ep[k] = valid[k] ? en : WTZ_MINUS_INF;
 			nib = valid[k] ? nib : 0u;
@@ -1863,7 +1865,7 @@ WTZ_D int32_t wtz_global_reg(int32_t qlen, const wtz_seq_packed &query, int32_t 
 					const int32_t col = k - (ii > w ? ii - w : 0);
 					const uint32_t zv = stage[(size_t)((ii >> 1) - p0) * zrow + col];
 					const uint32_t nib = (zv >> ((ii & 1) * 4)) & 0xFu;
-					if(which == 0) which = nib & 3u; else if(which == 1) which = (nib & 4u) ? 1u : 0u; else which = (nib & 8u) ? 2u : 0u;
+					if(which == 0){ which = nib & 3u; which = which > 2u ? 2u : which; } else if(which == 1) which = (nib & 4u) ? 1u : 0u; else which = (nib & 8u) ? 2u : 0u;
 					uint32_t op;
 					if(which == 0){
 						const uint32_t qv = (uint32_t)(qb[k >> 5] >> ((k & 31) * 2)) & 3u;
@@ -1896,7 +1898,7 @@ WTZ_D int32_t wtz_global_reg(int32_t qlen, const wtz_seq_packed &query, int32_t 
 			const int32_t col = k - (ii > w ? ii - w : 0);
 			const uint32_t zv = ztr[(size_t)(ii >> 1) * zrow + col];
 			const uint32_t nib = (zv >> ((ii & 1) * 4)) & 0xFu;
-			if(which == 0) which = nib & 3u; else if(which == 1) which = (nib & 4u) ? 1u : 0u; else which = (nib & 8u) ? 2u : 0u;
+			if(which == 0){ which = nib & 3u; which = which > 2u ? 2u : which; } else if(which == 1) which = (nib & 4u) ? 1u : 0u; else which = (nib & 8u) ? 2u : 0u;
 			uint32_t op;
 			if(which == 0){
 				const uint32_t qv = (uint32_t)(qb[k >> 5] >> ((k & 31) * 2)) & 3u;
