@@ -873,7 +873,6 @@ static void *worker_main(void *arg){
 }
 
 static double now_s(void){ struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec; }
-static void *unlink_main(void *arg){ unlink((char*)arg); free(arg); return NULL; }
 
 /* Benchmark hook (bench.py, in-process through libwtzmo_host.so): called with (rep, 0) right before the timed overlap
  * phase of repetition `rep` starts (reads already resident in HBM) and with (rep, 1) after its output is written. */
@@ -1096,7 +1095,7 @@ int main(int argc, char **argv){
 	size_t nclosed0 = 0; uint64_t *closed0 = (uint64_t*)hx_realloc(NULL, 8 * (E->closed.n + 1));
 	for(size_t i = 0; i < E->closed.cap; i++) if(E->closed.tab[i] != ~0ULL) closed0[nclosed0++] = E->closed.tab[i];
 	if(statsf){ FILE *sf = fopen(statsf, "w"); if(sf) fclose(sf); }
-	pthread_t unl_th; int unl_started = 0;
+	char *stale[64]; int n_stale = 0;
 	for(int rep = 0; rep < repeat; rep++){
 		if(rep){
 			memcpy(E->masked, masked0, (size_t)n_all + 1); memset(E->rdcovs, 0, 4 * ((size_t)n_all + 1));
@@ -1108,11 +1107,11 @@ int main(int argc, char **argv){
 			E->rows_all = 0; E->n_batches = 0; E->n_split = 0; E->n_ranges = 0;
 			E->pend.rd_id = 0xFFFFFFFFu; E->pend.nhit = E->pend.nmask = E->pend.nclosed = E->pend.nseed = 0;
 			if(strcmp(output, "-")){
-				/* the previous repeat's file (3 GB at configs[2]) is not truncated in place - freeing its pages took ~0.4 s of the next
-				 * repeat's timed region - but renamed and removed by a side thread */
-				if(unl_started){ pthread_join(unl_th, NULL); unl_started = 0; }
-				char *old = (char*)hx_realloc(NULL, strlen(output) + 16); sprintf(old, "%s.prev", output);
-				if(rename(output, old) == 0 && pthread_create(&unl_th, NULL, unlink_main, old) == 0) unl_started = 1; else { unlink(old); free(old); }
+				/* the previous repeat's file (3 GB at configs[2]) is neither truncated in place nor removed now: freeing its pages took ~0.4 s of
+				 * the next repeat's timed region inline, and on a side thread it slowed the device allocations of the index builds (z-index
+				 * 140 -> 800 ms).  It is renamed and removed after the last repeat. */
+				char *old = (char*)hx_realloc(NULL, strlen(output) + 24); sprintf(old, "%s.prev%d", output, rep);
+				if(rename(output, old) == 0 && n_stale < 64) stale[n_stale++] = old; else { unlink(old); free(old); }
 				E->out = fopen(output, "w"); if(E->out == NULL) exit(1); setvbuf(E->out, NULL, _IOFBF, 8u << 20);
 			}
 			wtz_reset_counters(E->ctx);
@@ -1240,7 +1239,7 @@ int main(int argc, char **argv){
 				cn.ms_index, cn.ms_zindex, cn.ms_candidates, cn.ms_pairs, cn.ms_winalign, cn.ms_stitch, (unsigned long long)cn.cells_shift, (unsigned long long)cn.cells_fixed, (unsigned long long)cn.cells_global, (unsigned long long)cn.bytes_seed_algo, (unsigned long long)E->nrec,
 				cn.ms_ext, (unsigned long long)cn.n_extjobs, (unsigned long long)E->used_queries, (unsigned long long)cn.pool_peak, cn.ms_gap, (unsigned long long)E->n_ranges, (unsigned long long)E->n_split); fclose(sf); } }
 	}
-	if(unl_started){ pthread_join(unl_th, NULL); unl_started = 0; }
+	for(int k = 0; k < n_stale; k++){ unlink(stale[k]); free(stale[k]); }
 	if(write_contained && strcmp(output, "-")){
 		char *maskf = (char*)hx_realloc(NULL, strlen(output) + 16); sprintf(maskf, "%s.contained", output);
 		FILE *mf = fopen(maskf, "w");

@@ -995,7 +995,7 @@ extern "C" int wtz_pairs_align(wtz_ctx_t *c, const uint32_t *pair_idx, const uin
 	lapw(0);
 	wtz_timer tm; tm.start();
 #ifdef WTZ_EMUL
-	CHK(wtz_launch_coop<K_winalign>(0, wt.size(), [=] WTZ_LAMBDA (uint64_t t){ wtz_task_winalign((uint32_t)t, V, d_wt, d_items); }, WTZ_WINALIGN_LDS_BYTES));
+	CHK(wtz_launch_coop<K_winalign>(0, wt.size(), [=] WTZ_LAMBDA (uint64_t t){ wtz_task_winalign((uint32_t)t, V, d_wt, d_items); }, WTZ_WINALIGN_LDS_BYTES + WTZ_WINALIGN_QW_BYTES));
 #else
 	{
 		/* first launch: FOUR windows per wavefront (one per 16-lane group, wtz_sw_grp.h); a window with a problem outside the group form's
@@ -1010,12 +1010,12 @@ extern "C" int wtz_pairs_align(wtz_ctx_t *c, const uint32_t *pair_idx, const uin
 		if(c->env_grp4){
 			CHK(wtz_launch_grp<K_winalign4>(nwt0, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_winalign4((uint32_t)t, (uint32_t)nwt0, V, d_wt, d_items, d_defer4); }, WTZ_WINALIGN4_LDS_BYTES));
 			CHK(dev_d2h(&n_def4, d_defer4, 4));
-			if(n_def4) CHK(wtz_launch_coop<K_winalign>(0, n_def4, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_winalign<false>((uint32_t)t, V, d_wt, d_items, d_defer, d_defer4); }, WTZ_WINALIGN_LDS_BYTES));
+			if(n_def4) CHK(wtz_launch_coop<K_winalign>(0, n_def4, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_winalign<false>((uint32_t)t, V, d_wt, d_items, d_defer, d_defer4); }, WTZ_WINALIGN_LDS_BYTES + WTZ_WINALIGN_QW_BYTES));
 		} else {
-			CHK(wtz_launch_coop<K_winalign>(0, nwt0, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_winalign<false>((uint32_t)t, V, d_wt, d_items, d_defer, NULL); }, WTZ_WINALIGN_LDS_BYTES));
+			CHK(wtz_launch_coop<K_winalign>(0, nwt0, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_winalign<false>((uint32_t)t, V, d_wt, d_items, d_defer, NULL); }, WTZ_WINALIGN_LDS_BYTES + WTZ_WINALIGN_QW_BYTES));
 		}
 		CHK(dev_d2h(&n_def, d_defer, 4));
-		if(n_def) CHK(wtz_launch_coop<K_winalign_big>(0, n_def, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_winalign<true>((uint32_t)t, V, d_wt, d_items, NULL, d_defer); }, WTZ_WINALIGN_LDS_BYTES));
+		if(n_def) CHK(wtz_launch_coop<K_winalign_big>(0, n_def, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_winalign<true>((uint32_t)t, V, d_wt, d_items, NULL, d_defer); }, WTZ_WINALIGN_LDS_BYTES + WTZ_WINALIGN_QW_BYTES));
 		if(c->env_profile) fprintf(stderr, "[winalign-profile] %zu windows, %u left by the four-per-wave form, %u redone by the full task\n", wt.size(), n_def4, n_def);
 		dev_free(d_defer4);
 		dev_free(d_defer);

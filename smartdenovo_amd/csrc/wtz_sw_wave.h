@@ -43,6 +43,9 @@ typedef struct {
 #ifndef WTZ_WINALIGN_LDS_BYTES
 #define WTZ_WINALIGN_LDS_BYTES 12288     /* LDS slice of a window-alignment wave (measured best with 3 waves/SIMD) */
 #endif
+#ifndef WTZ_WINALIGN_QW_BYTES
+#define WTZ_WINALIGN_QW_BYTES 512       /* behind the slice: the query of the current K-sw1 problem as 2-bit words, for its traceback */
+#endif
 
 #ifdef __HIPCC__
 
@@ -52,7 +55,7 @@ typedef struct {
 typedef struct { uint8_t **chunk; int32_t *zb; uint32_t n_chunk, zrow, cap_rows; } wtz_trace_t;
 
 /* LDS view handed to the wave DP: rings of PM+1 ints (PM = size-1 mask), target buffer of tw 64-bit words */
-typedef struct { int32_t *Hs, *Es; uint64_t *tb; int32_t PM; int32_t tw; } wtz_wave_lds_t;
+typedef struct { int32_t *Hs, *Es; uint64_t *tb; int32_t PM; int32_t tw; uint32_t *qw; } wtz_wave_lds_t;      /* qw: 512 B for the query words of the K-sw1 traceback (only wtz_fixed_problem_wave reads it) */
 
 /* ---- wavefront-wide max scan / arg-max reduction on the DPP data path (no LDS round trip) ----
  * gfx9-family DPP controls: row_shr:n = 0x110+n (inside a row of 16 lanes), row_bcast:15 = 0x142 (lane 15 of each row to
@@ -1202,12 +1205,40 @@ __global__ void __launch_bounds__(256) wtz_kernel_extjobs_mw(wtz_extjob_t *jobs,
  * Requirements (checked by the caller): n_col <= 64*C, ((ql+1)/2)*64*C <= ztr_bytes, (tl+63)/32+1 <= tb words, ql <= 2048.
  */
 
+/* one step of the K-sw1 / kswx traceback on lane 0, written without branches (the branchy form spent its time in exec-mask
+ * bookkeeping and taken branches, not in arithmetic): next state from the cell's nibble, base equality from the 2-bit words of
+ * both sequences in LDS (read whether the step is diagonal or not), counters and cursor by flag arithmetic; the open run is kept
+ * in runs[nr] and simply rewritten every step. */
+typedef struct { int32_t i, j; uint32_t d, run_op, run_len, nr; int32_t mat, mis, ins, del; } wtz_walk_t;
+WTZ_D void wtz_walk_step(wtz_walk_t &w, uint32_t nib, const uint32_t *qw32, const uint32_t *tb32, uint32_t *runs){
+	const uint32_t h3 = nib & 3u, h = h3 > 2u ? 2u : h3;
+	const uint32_t d = ((h | (nib & 4u) | ((nib & 8u) << 2)) >> (w.d << 1)) & 3u;      /* bits 1:0 move from H, 3:2 from E (0 / 1), 5:4 from F (0 / 2) */
+	const uint32_t qb = (qw32[w.i >> 4] >> ((w.i & 15) * 2)) & 3u, tq = (tb32[w.j >> 4] >> ((w.j & 15) * 2)) & 3u;
+	const uint32_t isd = d == 0 ? 1u : 0u, isi = d == 1 ? 1u : 0u, isl = d == 2 ? 1u : 0u, eq = qb == tq ? 1u : 0u;
+	w.mat += (int32_t)(isd & eq); w.mis += (int32_t)(isd & (eq ^ 1u)); w.ins += (int32_t)isi; w.del += (int32_t)isl;
+	w.i -= (int32_t)(isd | isi); w.j -= (int32_t)(isd | isl);
+	const bool same = d == w.run_op;
+	w.nr += (!same && w.run_len) ? 1u : 0u;
+	w.run_len = same ? w.run_len + 1u : 1u; w.run_op = d; w.d = d;
+	runs[w.nr] = (w.run_len << 4) | d;
+}
+/* the two leading gaps (kswx.h:321-322) merge with the open run when the operation agrees (kswx_push_cigar); closes the list */
+WTZ_D void wtz_walk_finish(wtz_walk_t &w, wtz_aln_t &x, uint32_t *runs, uint32_t *n_runs){
+	uint32_t run_op = w.run_op, run_len = w.run_len, nr = w.nr;
+	x.mat = w.mat; x.mis = w.mis; x.ins = w.ins; x.del = w.del;
+	if(w.i >= 0){ x.ins += w.i + 1; if(run_len && run_op == 1u) run_len += (uint32_t)(w.i + 1); else { if(run_len) runs[nr++] = (run_len << 4) | run_op; run_op = 1u; run_len = (uint32_t)(w.i + 1); } }
+	if(w.j >= 0){ x.del += w.j + 1; if(run_len && run_op == 2u) run_len += (uint32_t)(w.j + 1); else { if(run_len) runs[nr++] = (run_len << 4) | run_op; run_op = 2u; run_len = (uint32_t)(w.j + 1); } }
+	if(run_len) runs[nr++] = (run_len << 4) | run_op;
+	*n_runs = nr;                              /* in traceback order: the caller replays them backwards */
+	x.aln = x.mat + x.mis + x.ins + x.del; x.qe++; x.te++;
+}
+
 /* ZG: the trace does not fit LDS and lives in the pool (HBM): the rows store it through a global-address-space pointer (one
  * contiguous zrow-byte piece per row pair), the traceback walks LDS-staged blocks of 64 DP rows x the whole band (`stage`, 4 KB) */
 template<int C, bool ZG = false>
 WTZ_D wtz_aln_t wtz_extend_fixed_reg(int32_t qlen, const wtz_seq_packed &query, int32_t tlen, const wtz_seq_packed &target, int32_t init_score,
 		int32_t ql, int32_t tl, int32_t W, int32_t M, int32_t X, int32_t I, int32_t D, int32_t E, int32_t T,
-		uint64_t *tb, uint8_t *ztr, uint32_t zrow, uint32_t *runs, uint32_t *n_runs, unsigned long long *cells, uint8_t *stage = NULL){
+		uint64_t *tb, uint32_t *qlds, uint8_t *ztr, uint32_t zrow, uint32_t *runs, uint32_t *n_runs, unsigned long long *cells, uint8_t *stage = NULL){
 	const int lane = (int)(threadIdx.x & 63);
 	constexpr int KB = C <= 2 ? 7 : 9;           /* bits of the band column inside the packed arg-max key (callers check |h| < 2^(31-KB)) */
 	wtz_aln_t x; memset(&x, 0, sizeof x);
@@ -1221,6 +1252,7 @@ WTZ_D wtz_aln_t wtz_extend_fixed_reg(int32_t qlen, const wtz_seq_packed &query, 
 	}
 	const uint64_t qw = wtz_pack32(query, lane * 32, ql);
 	const uint32_t qw_lo = (uint32_t)qw, qw_hi = (uint32_t)(qw >> 32);
+	((uint64_t*)qlds)[lane] = qw;                    /* for the traceback: base i is bits 2*(i&15) of word i>>4 */
 	__threadfence_block();
 	WTZ_PROF_ADD(5, pt_stage);
 	const unsigned long long pt_rows = WTZ_PROF_T();
@@ -1346,11 +1378,11 @@ WTZ_D wtz_aln_t wtz_extend_fixed_reg(int32_t qlen, const wtz_seq_packed &query, 
 	WTZ_PROF_ADD(2, pt_rows);
 	WTZ_PROF_CNT(4, i_done + 1);
 	const unsigned long long pt_tb = WTZ_PROF_T();
+	wtz_walk_t wk; wk.i = x.qe; wk.j = x.te; wk.d = 0; wk.run_op = 0xFFu; wk.run_len = 0; wk.nr = 0; wk.mat = wk.mis = wk.ins = wk.del = 0;
 	if(ZG){
-		int32_t i_ = x.qe, j_ = x.te; uint32_t d_ = 0;
-		uint32_t run_op = 0xFFu, run_len = 0, nr = 0;
 		uint32_t *stage32 = (uint32_t*)stage;
 		const int32_t RB = zrow <= 128 ? 32 : (zrow <= 256 ? 16 : 8);         /* packed rows per staged block: RB * zrow <= 4 KB */
+		int32_t i_ = wk.i, j_ = wk.j;
 		while(i_ >= 0 && j_ >= 0){
 			const int32_t p1 = i_ >> 1, p0 = p1 >= RB - 1 ? p1 - (RB - 1) : 0;
 			{
@@ -1360,61 +1392,24 @@ WTZ_D wtz_aln_t wtz_extend_fixed_reg(int32_t qlen, const wtz_seq_packed &query, 
 			}
 			__threadfence_block();
 			if(lane == 0){
-				while(i_ >= 0 && j_ >= 0 && (i_ >> 1) >= p0){
-					const int32_t col = j_ - (i_ > W ? i_ - W : 0);
-					const uint32_t zv = stage[(size_t)((i_ >> 1) - p0) * zrow + col];
-					const uint32_t nib = (zv >> ((i_ & 1) * 4)) & 0xFu;
-					if(d_ == 0){ d_ = nib & 3u; d_ = d_ > 2u ? 2u : d_; } else if(d_ == 1) d_ = (nib & 4u) ? 1u : 0u; else d_ = (nib & 8u) ? 2u : 0u;
-					if(d_ == 0){
-						const uint32_t qv = (i_ & 16) ? (uint32_t)__builtin_amdgcn_readlane((int)qw_hi, i_ >> 5) : (uint32_t)__builtin_amdgcn_readlane((int)qw_lo, i_ >> 5);
-						const uint32_t qb = (qv >> ((i_ & 15) * 2)) & 3u;
-						const uint32_t tq = (uint32_t)(tb[j_ >> 5] >> ((j_ & 31) * 2)) & 3u;
-						if(qb == tq) x.mat++; else x.mis++;
-						i_--; j_--;
-					}
-					else if(d_ == 1){ i_--; x.ins++; }
-					else { j_--; x.del++; }
-					if(d_ == run_op) run_len++;
-					else { if(run_len) runs[nr++] = (run_len << 4) | run_op; run_op = d_; run_len = 1; }
+				while((wk.i | wk.j) >= 0 && (wk.i >> 1) >= p0){
+					const int32_t col = wk.j - (wk.i > W ? wk.i - W : 0);
+					const uint32_t zv = stage[(size_t)((wk.i >> 1) - p0) * zrow + col];
+					wtz_walk_step(wk, zv >> ((wk.i & 1) * 4), qlds, tb32, runs);
 				}
 			}
-			i_ = __builtin_amdgcn_readfirstlane(i_); j_ = __builtin_amdgcn_readfirstlane(j_);
+			i_ = __builtin_amdgcn_readfirstlane(wk.i); j_ = __builtin_amdgcn_readfirstlane(wk.j);
 			__threadfence_block();
 		}
-		if(lane == 0){
-			if(i_ >= 0){ x.ins += i_ + 1; if(run_len && run_op == 1u) run_len += (uint32_t)(i_ + 1); else { if(run_len) runs[nr++] = (run_len << 4) | run_op; run_op = 1u; run_len = (uint32_t)(i_ + 1); } }
-			if(j_ >= 0){ x.del += j_ + 1; if(run_len && run_op == 2u) run_len += (uint32_t)(j_ + 1); else { if(run_len) runs[nr++] = (run_len << 4) | run_op; run_op = 2u; run_len = (uint32_t)(j_ + 1); } }
-			if(run_len) runs[nr++] = (run_len << 4) | run_op;
-			*n_runs = nr;
-			x.aln = x.mat + x.mis + x.ins + x.del; x.qe++; x.te++;
-		}
+		if(lane == 0) wtz_walk_finish(wk, x, runs, n_runs);
 	} else
 	if(lane == 0){
-		int32_t i_ = x.qe, j_ = x.te; uint32_t d_ = 0;
-		uint32_t run_op = 0xFFu, run_len = 0, nr = 0;
-		while(i_ >= 0 && j_ >= 0){
-			const int32_t col = j_ - (i_ > W ? i_ - W : 0);
-			const uint32_t zv = ztr[(size_t)(i_ >> 1) * zrow + col];
-			const uint32_t nib = (zv >> ((i_ & 1) * 4)) & 0xFu;
-			if(d_ == 0){ d_ = nib & 3u; d_ = d_ > 2u ? 2u : d_; } else if(d_ == 1) d_ = (nib & 4u) ? 1u : 0u; else d_ = (nib & 8u) ? 2u : 0u;
-			if(d_ == 0){
-				const uint32_t qv = (i_ & 16) ? (uint32_t)__builtin_amdgcn_readlane((int)qw_hi, i_ >> 5) : (uint32_t)__builtin_amdgcn_readlane((int)qw_lo, i_ >> 5);
-				const uint32_t qb = (qv >> ((i_ & 15) * 2)) & 3u;
-				const uint32_t tq = (uint32_t)(tb[j_ >> 5] >> ((j_ & 31) * 2)) & 3u;
-				if(qb == tq) x.mat++; else x.mis++;
-				i_--; j_--;
-			}
-			else if(d_ == 1){ i_--; x.ins++; }
-			else { j_--; x.del++; }
-			if(d_ == run_op) run_len++;
-			else { if(run_len) runs[nr++] = (run_len << 4) | run_op; run_op = d_; run_len = 1; }
+		while((wk.i | wk.j) >= 0){
+			const int32_t col = wk.j - (wk.i > W ? wk.i - W : 0);
+			const uint32_t zv = ztr[(size_t)(wk.i >> 1) * zrow + col];
+			wtz_walk_step(wk, zv >> ((wk.i & 1) * 4), qlds, tb32, runs);
 		}
-		/* the two leading gaps (kswx.h:321-322) merge with the open run when the operation agrees (kswx_push_cigar) */
-		if(i_ >= 0){ x.ins += i_ + 1; if(run_len && run_op == 1u) run_len += (uint32_t)(i_ + 1); else { if(run_len) runs[nr++] = (run_len << 4) | run_op; run_op = 1u; run_len = (uint32_t)(i_ + 1); } }
-		if(j_ >= 0){ x.del += j_ + 1; if(run_len && run_op == 2u) run_len += (uint32_t)(j_ + 1); else { if(run_len) runs[nr++] = (run_len << 4) | run_op; run_op = 2u; run_len = (uint32_t)(j_ + 1); } }
-		if(run_len) runs[nr++] = (run_len << 4) | run_op;
-		*n_runs = nr;                              /* in traceback order: the caller replays them backwards */
-		x.aln = x.mat + x.mis + x.ins + x.del; x.qe++; x.te++;
+		wtz_walk_finish(wk, x, runs, n_runs);
 	}
 	WTZ_PROF_ADD(3, pt_tb);
 	return wtz_bcast_aln(x);
@@ -1489,8 +1484,8 @@ WTZ_D void wtz_fixed_problem_wave(int32_t qlen, const wtz_seq_packed &q, int32_t
 	if(!FULL && !(qlen <= 0 || tlen <= 0) && !(lds_fit || (pool_fit && n_col <= 128))){ R.defer = true; R.y = y; return; }
 	if(lds_fit){
 		R.runs = (uint32_t*)(ztr + ztr_bytes - run_bytes); R.lds_runs = true; R.form = cmin;
-		if(cmin == 1) y = wtz_extend_fixed_reg<1>(qlen, q, tlen, t, score_in, ql, tl, W, M, X, I, D, E, T, L.tb, ztr, (uint32_t)zrow, R.runs, &R.n_runs, cells);
-		else          y = wtz_extend_fixed_reg<2>(qlen, q, tlen, t, score_in, ql, tl, W, M, X, I, D, E, T, L.tb, ztr, (uint32_t)zrow, R.runs, &R.n_runs, cells);
+		if(cmin == 1) y = wtz_extend_fixed_reg<1>(qlen, q, tlen, t, score_in, ql, tl, W, M, X, I, D, E, T, L.tb, L.qw, ztr, (uint32_t)zrow, R.runs, &R.n_runs, cells);
+		else          y = wtz_extend_fixed_reg<2>(qlen, q, tlen, t, score_in, ql, tl, W, M, X, I, D, E, T, L.tb, L.qw, ztr, (uint32_t)zrow, R.runs, &R.n_runs, cells);
 	} else if(pool_fit){
 		/* the 4-bit trace does not fit the LDS slice (or the band is wider than 128 columns): trace in the pool, traceback through a
 		 * 4 KB LDS stage, run list in LDS above the stage */
@@ -1500,11 +1495,11 @@ WTZ_D void wtz_fixed_problem_wave(int32_t qlen, const wtz_seq_packed &q, int32_t
 		if(za == 0){ R.ok = false; R.y = y; return; }
 		uint8_t *zg = (uint8_t*)(uintptr_t)za;
 		R.runs = (uint32_t*)(ztr + ztr_bytes - run_bytes); R.lds_runs = true; R.form = cmin | 16;
-		if(cmin == 1)      y = wtz_extend_fixed_reg<1, true>(qlen, q, tlen, t, score_in, ql, tl, W, M, X, I, D, E, T, L.tb, zg, (uint32_t)zrow, R.runs, &R.n_runs, cells, ztr);
-		else if(cmin == 2) y = wtz_extend_fixed_reg<2, true>(qlen, q, tlen, t, score_in, ql, tl, W, M, X, I, D, E, T, L.tb, zg, (uint32_t)zrow, R.runs, &R.n_runs, cells, ztr);
+		if(cmin == 1)      y = wtz_extend_fixed_reg<1, true>(qlen, q, tlen, t, score_in, ql, tl, W, M, X, I, D, E, T, L.tb, L.qw, zg, (uint32_t)zrow, R.runs, &R.n_runs, cells, ztr);
+		else if(cmin == 2) y = wtz_extend_fixed_reg<2, true>(qlen, q, tlen, t, score_in, ql, tl, W, M, X, I, D, E, T, L.tb, L.qw, zg, (uint32_t)zrow, R.runs, &R.n_runs, cells, ztr);
 		else if constexpr(FULL){
-			if(cmin == 4) y = wtz_extend_fixed_reg<4, true>(qlen, q, tlen, t, score_in, ql, tl, W, M, X, I, D, E, T, L.tb, zg, (uint32_t)zrow, R.runs, &R.n_runs, cells, ztr);
-			else          y = wtz_extend_fixed_reg<8, true>(qlen, q, tlen, t, score_in, ql, tl, W, M, X, I, D, E, T, L.tb, zg, (uint32_t)zrow, R.runs, &R.n_runs, cells, ztr);
+			if(cmin == 4) y = wtz_extend_fixed_reg<4, true>(qlen, q, tlen, t, score_in, ql, tl, W, M, X, I, D, E, T, L.tb, L.qw, zg, (uint32_t)zrow, R.runs, &R.n_runs, cells, ztr);
+			else          y = wtz_extend_fixed_reg<8, true>(qlen, q, tlen, t, score_in, ql, tl, W, M, X, I, D, E, T, L.tb, L.qw, zg, (uint32_t)zrow, R.runs, &R.n_runs, cells, ztr);
 		}
 		WTZ_PROF_ADD(55, pt0); WTZ_PROF_CNT(7, 1); WTZ_PROF_CNT(13, ql); WTZ_PROF_CNT(14, n_col);
 	} else if(qlen <= 0 || tlen <= 0){
@@ -1535,7 +1530,7 @@ WTZ_D wtz_aln_t wtz_align_window_wave(const wtz_readview &pb1, const wtz_readvie
 	const int lane = (int)(threadIdx.x & 63);
 	const int32_t M = P->M, I = P->O, D = P->O, E = P->E;
 	/* LDS slice: 128 target words (1 KB), then the 4-bit trace of the register DP with its run list at the top end (7 KB) */
-	wtz_wave_lds_t L; L.tb = (uint64_t*)lds; L.Hs = lds + 256; L.Es = lds + 768; L.PM = 511; L.tw = 128;
+	wtz_wave_lds_t L; L.tb = (uint64_t*)lds; L.Hs = lds + 256; L.Es = lds + 768; L.PM = 511; L.tw = 128; L.qw = (uint32_t*)(lds + WTZ_WINALIGN_LDS_BYTES / 4);
 	uint8_t *ztr = (uint8_t*)(lds + 256); const int32_t ztr_bytes = WTZ_WINALIGN_LDS_BYTES - 1024;
 	wtz_swmem_t mem; wtz_swmem_init(mem, pool);
 	wtz_aln_t x, y; memset(&x, 0, sizeof x);

@@ -32,7 +32,7 @@ static __device__ void wtz_testdp_store(wtz_dpres_dev_t *res, const wtz_aln_t &x
 static __device__ void wtz_task_test_fixed(uint32_t t, const wtz_dpprob_dev_t *pr, const wtz_params_t *P, wtz_pool_t *pool, int force, wtz_dpres_dev_t *res){
 	const wtz_dpprob_dev_t p = pr[t];
 	int32_t *lds = wtz_wave_scratch();
-	wtz_wave_lds_t L; L.tb = (uint64_t*)lds; L.Hs = lds + 256; L.Es = lds + 768; L.PM = 511; L.tw = 128;        /* the slice of wtz_align_window_wave */
+	wtz_wave_lds_t L; L.tb = (uint64_t*)lds; L.Hs = lds + 256; L.Es = lds + 768; L.PM = 511; L.tw = 128; L.qw = (uint32_t*)(lds + WTZ_WINALIGN_LDS_BYTES / 4);        /* the slice of wtz_align_window_wave */
 	uint8_t *ztr = (uint8_t*)(lds + 256); const int32_t ztr_bytes = WTZ_WINALIGN_LDS_BYTES - 1024;
 	wtz_swmem_t mem; wtz_swmem_init(mem, pool);
 	wtz_cigar_t tmp; tmp.init(pool, WTZ_LANE == 0 ? 64 : 0);
@@ -131,7 +131,7 @@ extern "C" int wtz_test_dp(wtz_ctx_t *c, int32_t kind, int32_t form, const wtz_d
 		CHK(dev_alloc((void**)&d_res, (size_t)n * sizeof(wtz_dpres_dev_t))); CHK(dev_set(d_res, 0, (size_t)n * sizeof(wtz_dpres_dev_t)));
 		const wtz_params_t *dP = c->dP; wtz_pool_t *pool = c->dpool;
 		if(kind == WTZ_DP_FIXED){
-			CHK(wtz_launch_coop<K_test_fixed>(0, n, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_test_fixed((uint32_t)t, d_pr, dP, pool, form, d_res); }, WTZ_WINALIGN_LDS_BYTES));
+			CHK(wtz_launch_coop<K_test_fixed>(0, n, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_test_fixed((uint32_t)t, d_pr, dP, pool, form, d_res); }, WTZ_WINALIGN_LDS_BYTES + WTZ_WINALIGN_QW_BYTES));
 		} else if(form == 33){
 			CHK(wtz_launch_coop<K_test_global_wide>(0, n, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_test_global((uint32_t)t, d_pr, dP, pool, form, (uint32_t)WTZ_GAP_WIDE_LDS_BYTES, d_res); }, WTZ_GAP_WIDE_LDS_BYTES));
 		} else {
