@@ -1719,6 +1719,27 @@ WTZ_D int32_t wtz_global_wave(int32_t qlen, const SQ &query, int32_t tlen, const
 	return score;
 }
 
+/* one step of the ksw_global2 traceback on lane 0, without branches (see wtz_walk_step): rows run over the target (its base comes from
+ * the 32-base words held in VGPRs), columns over the query (2-bit words in LDS); `which` 0 / 1 / 2 = from H / E (deletion, row up) /
+ * F (insertion, column left) */
+typedef struct { int32_t ii, k; uint32_t which, run_op, run_len, nr; int32_t mat, mis; } wtz_gwalk_t;
+WTZ_D void wtz_gwalk_step(wtz_gwalk_t &g, uint32_t nib, const uint32_t *qb32, uint32_t tw_lo, uint32_t tw_hi, uint32_t *runs){
+	const uint32_t h3 = nib & 3u, h = h3 > 2u ? 2u : h3;
+	const uint32_t wh = ((h | (nib & 4u) | ((nib & 8u) << 2)) >> (g.which << 1)) & 3u;
+	const uint32_t op = (0x18u >> (wh << 1)) & 3u;                 /* 0 -> M, 1 -> D (2), 2 -> I (1) */
+	const uint32_t qv = (qb32[g.k >> 4] >> ((g.k & 15) * 2)) & 3u;
+	const int ts = __builtin_amdgcn_readfirstlane((g.ii & 2047) >> 5);
+	const uint32_t tlo = (uint32_t)__builtin_amdgcn_readlane((int)tw_lo, ts), thi = (uint32_t)__builtin_amdgcn_readlane((int)tw_hi, ts);
+	const uint32_t tv = (((g.ii & 16) ? thi : tlo) >> ((g.ii & 15) * 2)) & 3u;
+	const uint32_t is0 = wh == 0 ? 1u : 0u, is1 = wh == 1 ? 1u : 0u, is2 = wh == 2 ? 1u : 0u, eq = qv == tv ? 1u : 0u;
+	g.mat += (int32_t)(is0 & eq); g.mis += (int32_t)(is0 & (eq ^ 1u));
+	g.ii -= (int32_t)(is0 | is1); g.k -= (int32_t)(is0 | is2);
+	const bool same = op == g.run_op;
+	g.nr += (!same && g.run_len) ? 1u : 0u;
+	g.run_len = same ? g.run_len + 1u : 1u; g.run_op = op; g.which = wh;
+	runs[g.nr] = (g.run_len << 4) | op;
+}
+
 /*
  * K-sw2 (ksw_global2) for gaps whose band fits two columns per lane: the register form of wtz_global_wave.  Rows run over
  * the target (its row base is scalar, from 32-base words held in VGPRs), lanes over the query band (2-bit words in LDS);
@@ -1838,8 +1859,9 @@ WTZ_D int32_t wtz_global_reg(int32_t qlen, const wtz_seq_packed &query, int32_t 
 	const int32_t score = (end_last == qlen) ? h_lastrow : ((qlen <= w) ? -(o_ins + e_ins * qlen) : WTZ_MINUS_INF);
 	__threadfence_block();
 	if(ZG){
-		uint32_t which = 0, nr = 0, run_op = 0xFFu, run_len = 0; int32_t mat = 0, mis = 0;
-		int32_t ii = tlen - 1, k = (ii + w + 1 < qlen ? ii + w + 1 : qlen) - 1;
+		wtz_gwalk_t g; g.which = 0; g.nr = 0; g.run_op = 0xFFu; g.run_len = 0; g.mat = g.mis = 0;
+		g.ii = tlen - 1; g.k = (g.ii + w + 1 < qlen ? g.ii + w + 1 : qlen) - 1;
+		int32_t ii = g.ii, k = g.k;
 		uint32_t *stage32 = (uint32_t*)stage;
 		const int32_t RB = zrow <= 128 ? 32 : (zrow <= 256 ? 16 : 8);         /* packed rows per staged block: RB * zrow <= 4 KB */
 		int32_t cur_tblk = (tlen - 1) >> 11;                                    /* the 2048-row block of target words the DP loop left in tw_lo / tw_hi */
@@ -1856,57 +1878,34 @@ WTZ_D int32_t wtz_global_reg(int32_t qlen, const wtz_seq_packed &query, int32_t 
 			}
 			__threadfence_block();
 			if(lane == 0){
-				while(ii >= 0 && k >= 0 && (ii >> 1) >= p0 && (ii >> 11) == cur_tblk){
-					const int32_t col = k - (ii > w ? ii - w : 0);
-					const uint32_t zv = stage[(size_t)((ii >> 1) - p0) * zrow + col];
-					const uint32_t nib = (zv >> ((ii & 1) * 4)) & 0xFu;
-					if(which == 0){ which = nib & 3u; which = which > 2u ? 2u : which; } else if(which == 1) which = (nib & 4u) ? 1u : 0u; else which = (nib & 8u) ? 2u : 0u;
-					uint32_t op;
-					if(which == 0){
-						const uint32_t qv = (uint32_t)(qb[k >> 5] >> ((k & 31) * 2)) & 3u;
-						const int32_t ts = (ii & 2047) >> 5;
-						const uint32_t tv = (ii & 16) ? (uint32_t)__builtin_amdgcn_readlane((int)tw_hi, ts) : (uint32_t)__builtin_amdgcn_readlane((int)tw_lo, ts);
-						if(qv == ((tv >> ((ii & 15) * 2)) & 3u)) mat++; else mis++;
-						op = 0; --ii; --k;
-					}
-					else if(which == 1){ op = 2; --ii; }
-					else { op = 1; --k; }
-					if(op == run_op) run_len++;
-					else { if(run_len) runs[nr++] = (run_len << 4) | run_op; run_op = op; run_len = 1; }
+				while((g.ii | g.k) >= 0 && (g.ii >> 1) >= p0 && (g.ii >> 11) == cur_tblk){
+					const int32_t col = g.k - (g.ii > w ? g.ii - w : 0);
+					const uint32_t zv = stage[(size_t)((g.ii >> 1) - p0) * zrow + col];
+					wtz_gwalk_step(g, zv >> ((g.ii & 1) * 4), (const uint32_t*)qb, tw_lo, tw_hi, runs);
 				}
 			}
-			ii = __builtin_amdgcn_readfirstlane(ii); k = __builtin_amdgcn_readfirstlane(k);
+			ii = __builtin_amdgcn_readfirstlane(g.ii); k = __builtin_amdgcn_readfirstlane(g.k);
 			__threadfence_block();
 		}
 		if(lane == 0){
+			uint32_t run_op = g.run_op, run_len = g.run_len, nr = g.nr;
 			if(ii >= 0){ if(run_len && run_op == 2u) run_len += (uint32_t)(ii + 1); else { if(run_len) runs[nr++] = (run_len << 4) | run_op; run_op = 2u; run_len = (uint32_t)(ii + 1); } }
 			if(k >= 0){ if(run_len && run_op == 1u) run_len += (uint32_t)(k + 1); else { if(run_len) runs[nr++] = (run_len << 4) | run_op; run_op = 1u; run_len = (uint32_t)(k + 1); } }
 			if(run_len) runs[nr++] = (run_len << 4) | run_op;
-			*n_runs = nr; *n_mat = mat; *n_mis = mis;
+			*n_runs = nr; *n_mat = g.mat; *n_mis = g.mis;
 		}
 		return score;
 	}
 	if(lane == 0){
-		uint32_t which = 0, nr = 0, run_op = 0xFFu, run_len = 0; int32_t mat = 0, mis = 0;
-		int32_t ii = tlen - 1, k = (ii + w + 1 < qlen ? ii + w + 1 : qlen) - 1;
-		while(ii >= 0 && k >= 0){
-			const int32_t col = k - (ii > w ? ii - w : 0);
-			const uint32_t zv = ztr[(size_t)(ii >> 1) * zrow + col];
-			const uint32_t nib = (zv >> ((ii & 1) * 4)) & 0xFu;
-			if(which == 0){ which = nib & 3u; which = which > 2u ? 2u : which; } else if(which == 1) which = (nib & 4u) ? 1u : 0u; else which = (nib & 8u) ? 2u : 0u;
-			uint32_t op;
-			if(which == 0){
-				const uint32_t qv = (uint32_t)(qb[k >> 5] >> ((k & 31) * 2)) & 3u;
-				const int32_t ts = (ii & 2047) >> 5;
-				const uint32_t tv = (ii & 16) ? (uint32_t)__builtin_amdgcn_readlane((int)tw_hi, ts) : (uint32_t)__builtin_amdgcn_readlane((int)tw_lo, ts);
-				if(qv == ((tv >> ((ii & 15) * 2)) & 3u)) mat++; else mis++;
-				op = 0; --ii; --k;
-			}
-			else if(which == 1){ op = 2; --ii; }
-			else { op = 1; --k; }
-			if(op == run_op) run_len++;
-			else { if(run_len) runs[nr++] = (run_len << 4) | run_op; run_op = op; run_len = 1; }
+		wtz_gwalk_t g; g.which = 0; g.nr = 0; g.run_op = 0xFFu; g.run_len = 0; g.mat = g.mis = 0;
+		g.ii = tlen - 1; g.k = (g.ii + w + 1 < qlen ? g.ii + w + 1 : qlen) - 1;
+		while((g.ii | g.k) >= 0){
+			const int32_t col = g.k - (g.ii > w ? g.ii - w : 0);
+			const uint32_t zv = ztr[(size_t)(g.ii >> 1) * zrow + col];
+			wtz_gwalk_step(g, zv >> ((g.ii & 1) * 4), (const uint32_t*)qb, tw_lo, tw_hi, runs);
 		}
+		const int32_t ii = g.ii, k = g.k; const int32_t mat = g.mat, mis = g.mis;
+		uint32_t run_op = g.run_op, run_len = g.run_len, nr = g.nr;
 		if(ii >= 0){ if(run_len && run_op == 2u) run_len += (uint32_t)(ii + 1); else { if(run_len) runs[nr++] = (run_len << 4) | run_op; run_op = 2u; run_len = (uint32_t)(ii + 1); } }
 		if(k >= 0){ if(run_len && run_op == 1u) run_len += (uint32_t)(k + 1); else { if(run_len) runs[nr++] = (run_len << 4) | run_op; run_op = 1u; run_len = (uint32_t)(k + 1); } }
 		if(run_len) runs[nr++] = (run_len << 4) | run_op;
