@@ -270,6 +270,10 @@ static int dev_sort_pairs_u64_u32(uint64_t *keys, uint32_t *vals, uint64_t n, un
 /* ------------------------------------------------------------------------------------------------ */
 struct wtz_ctx {
 	int device;
+	/* z-index arrays of the previous build, kept for the rebuild (same read set -> same sizes): freeing and re-allocating 19 GB per
+	 * build cost 0.1 - 0.8 s of hipFree / hipMalloc at configs[2], depending on what else the host's memory manager was doing */
+	std::vector<std::pair<void*, size_t> > zparked;
+	std::vector<std::pair<void*, size_t> > zlive;
 #ifndef WTZ_EMUL
 	hipStream_t stream;
 	hipStream_t stream_mw = 0; hipEvent_t ev_mw_fork = 0, ev_mw_join = 0;      /* side stream of the multi-wave K-sw3 launch */
@@ -429,11 +433,21 @@ extern "C" int wtz_ctx_create(int device, const wtz_params_c *params, uint64_t p
 }
 
 static void free_kindex(wtz_ctx *c){ if(!c->shares_indexes){ dev_free_persist(c->ktab); dev_free_persist(c->kseeds); } c->ktab = NULL; c->kseeds = NULL; c->kmask = 0; }
-static void free_zindex(wtz_ctx *c){
-	if(!c->shares_indexes){
-		dev_free_persist(c->zoff); dev_free_persist(c->Z.mer); dev_free_persist(c->Z.pos); dev_free_persist(c->Z.len); dev_free_persist(c->Z.ok); dev_free_persist(c->Z.sidx);
-		dev_free_persist(c->Z.dmer); dev_free_persist(c->Z.dfirst); dev_free_persist(c->Z.dcnt); dev_free_persist(c->Z.dn);
+/* z-index allocation with recycling: a parked buffer of (nearly) the wanted size is taken instead of a fresh hipMalloc */
+static int zalloc(wtz_ctx *c, void **p, size_t n){
+	if(n == 0) n = 16;
+	for(size_t i = 0; i < c->zparked.size(); i++){
+		if(c->zparked[i].second >= n && c->zparked[i].second <= n + n / 8 + 4096){
+			*p = c->zparked[i].first; c->zlive.push_back(c->zparked[i]); c->zparked.erase(c->zparked.begin() + (long)i); return WTZ_OK;
+		}
 	}
+	int rc = dev_alloc_persist(p, n); if(rc) return rc;
+	c->zlive.push_back(std::make_pair(*p, n)); return WTZ_OK;
+}
+static void zpark_all(wtz_ctx *c){ for(size_t i = 0; i < c->zlive.size(); i++) c->zparked.push_back(c->zlive[i]); c->zlive.clear(); }
+static void zflush_parked(wtz_ctx *c){ for(size_t i = 0; i < c->zparked.size(); i++) dev_free_persist(c->zparked[i].first); c->zparked.clear(); }
+static void free_zindex(wtz_ctx *c){
+	if(!c->shares_indexes){ zpark_all(c); zflush_parked(c); }      /* every z-index array comes from zalloc */
 	c->zoff = NULL; memset(&c->Z, 0, sizeof c->Z); c->have_z = false;
 }
 static void free_batch(wtz_ctx *c){ c->n_pairs = 0; c->n_items = 0; c->have_pairs = false; c->have_items = false; }
@@ -578,10 +592,10 @@ extern "C" int wtz_zindex_build(wtz_ctx_t *c){
 	if(!c || !c->bits) return wtz_fail(WTZ_E_ARG, "reads not uploaded");
 	CTX_ENTER(c);
 	if(c->shares_indexes) return wtz_fail(WTZ_E_STATE, "wtz_zindex_build on a cloned context");
-	free_zindex(c);
+	zpark_all(c); c->zoff = NULL; memset(&c->Z, 0, sizeof c->Z); c->have_z = false;      /* the old arrays are recycled below */
 	wtz_timer tm; tm.start();
 	const wtz_reads_t R = ctx_reads(c); const uint32_t nr = c->n_reads, zsize = c->P.zsize, hz = c->P.hz, zcut = c->P.max_zmer_freq;
-	CHK(dev_alloc_persist((void**)&c->zoff, ((size_t)nr + 1) * 8));
+	CHK(zalloc(c, (void**)&c->zoff, ((size_t)nr + 1) * 8));
 	uint64_t *d_off = c->zoff;
 	std::vector<uint32_t> p_rid, p_jb; std::vector<size_t> first_piece((size_t)nr + 1);
 	for(uint32_t r = 0; r < nr; r++){ first_piece[r] = p_rid.size(); for(uint32_t jb = 0; jb == 0 || jb < c->h_rdlen[r]; jb += WTZ_WALK_CHUNK){ p_rid.push_back(r); p_jb.push_back(jb); } }
@@ -598,10 +612,11 @@ extern "C" int wtz_zindex_build(wtz_ctx_t *c){
 	CHK(dev_h2d(d_off, h.data(), ((size_t)nr + 1) * 8));
 	c->n_z = tot;
 	wtz_zindex_t Z; memset(&Z, 0, sizeof Z); Z.zoff = c->zoff;
-	CHK(dev_alloc_persist((void**)&Z.mer, (tot + 1) * 4)); CHK(dev_alloc_persist((void**)&Z.pos, (tot + 1) * 4)); CHK(dev_alloc_persist((void**)&Z.len, (tot + 1) * 2));
-	CHK(dev_alloc_persist((void**)&Z.ok, tot + 1)); CHK(dev_alloc_persist((void**)&Z.sidx, (tot + 1) * 4));
-	CHK(dev_alloc_persist((void**)&Z.dmer, (tot + 1) * 4)); CHK(dev_alloc_persist((void**)&Z.dfirst, (tot + 1) * 4)); CHK(dev_alloc_persist((void**)&Z.dcnt, (tot + 1) * 2));
-	CHK(dev_alloc_persist((void**)&Z.dn, ((size_t)nr + 1) * 4));
+	CHK(zalloc(c, (void**)&Z.mer, (tot + 1) * 4)); CHK(zalloc(c, (void**)&Z.pos, (tot + 1) * 4)); CHK(zalloc(c, (void**)&Z.len, (tot + 1) * 2));
+	CHK(zalloc(c, (void**)&Z.ok, tot + 1)); CHK(zalloc(c, (void**)&Z.sidx, (tot + 1) * 4));
+	CHK(zalloc(c, (void**)&Z.dmer, (tot + 1) * 4)); CHK(zalloc(c, (void**)&Z.dfirst, (tot + 1) * 4)); CHK(zalloc(c, (void**)&Z.dcnt, (tot + 1) * 2));
+	CHK(zalloc(c, (void**)&Z.dn, ((size_t)nr + 1) * 4));
+	zflush_parked(c);                     /* whatever did not fit a request goes back to the driver */
 	c->Z = Z;
 	{
 		uint64_t *d_key = NULL; uint32_t *d_flag = NULL, *d_cnt = NULL, *d_dpos = NULL; uint32_t *d_val = Z.sidx;
