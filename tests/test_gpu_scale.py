@@ -70,3 +70,21 @@ def test_gpu_equals_reference_at_scale(name, gpu_exe):
     if case["set"] != "repeat":
         assert b"splitting the batch" not in r.stderr, "a planned range overflowed the scratch pool"
     os.remove(out)
+
+
+@pytest.mark.parametrize("env", [{"WTZ_DM_TIER3_KB": "18"}, {"WTZ_DM_TIER3_KB": "17", "WTZ_DM_TIER4_KB": "18"}, {"WTZ_DM_TIER3_KB": "159", "WTZ_DM_TIER4_KB": "159"}],
+                         ids=["tier4_used", "scalar_fallback_used", "image_in_lds"])
+def test_dmo_heavy_pair_paths(env, gpu_exe):
+    """dmo on the repeat-rich set through the rarely taken forms of the late K_pair launches: with an 18 KB third slice the
+    group table overflows for a few strands, which the fourth launch finishes (wide table); with both slices that small those strands end
+    in the scalar body; with 159 KB slices the strand images stay in LDS (the first form of this round).  Same .ovl as the reference every time."""
+    case = MAN["cases"]["repeat_dmo"]
+    fa = reads_of(case["set"])
+    out = os.path.join(TMP, "heavy_%s.ovl" % "_".join(sorted(env.values())))
+    r = subprocess.run([gpu_exe, "-i", fa, "-fo", out] + case["argv"], capture_output=True, env=dict(os.environ, WTZ_PROFILE_PAIR="1", **env))
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    md5, nrec = file_md5(out)
+    assert (nrec, md5) == (case["records"], case["md5_full"]), "dmo .ovl differs from reference wtzmo -t 1 with %r" % (env,)
+    if "WTZ_DM_TIER4_KB" not in env:
+        assert b"dmo tier 4" in r.stderr, "no pair reached the fourth launch: the test no longer covers it"
+    os.remove(out)
