@@ -318,14 +318,31 @@ static void pend_hit(pending_t *p, const hit_t *h){
 }
 
 /* one .ovl line (print_hits_wtzmo, wtzmo.c:1170-1249) into the output stream; cigar == NULL prints "0M" */
+static inline size_t put_str(char *o, const char *s){ size_t n = strlen(s); memcpy(o, s, n); return n; }
+static inline size_t put_int(char *o, long long v){          /* as printf("%d") */
+	char t[24]; int n = 0; size_t k = 0;
+	unsigned long long u = v < 0 ? 0ULL - (unsigned long long)v : (unsigned long long)v;
+	do { t[n++] = (char)('0' + u % 10); u /= 10; } while(u);
+	if(v < 0) o[k++] = '-';
+	while(n) o[k++] = t[--n];
+	return k;
+}
 static void emit_record(eng_t *E, const hit_t *h, const char *cigar, size_t cigar_len, int ext){
 	const double te0 = now_s();
 	const hx_read_t *reads = E->st.reads;
 	const int aln = h->aln == 0 ? 1 : h->aln;
 	const int by_ref = (cigar && ext >= 0 && ext < OW_MAX_EXT && cigar_len >= 256);
 	char *o = out_space(strlen(reads[h->pb1].name) + strlen(reads[h->pb2].name) + 256 + (by_ref ? 0 : cigar_len));
-	size_t k = (size_t)sprintf(o, "%s\t%c\t%d\t%d\t%d\t%s\t%c\t%d\t%d\t%d\t%d\t%0.3f\t%d\t%d\t%d\t%d\t", reads[h->pb1].name, '+', reads[h->pb1].len, h->tb, h->te,
-		reads[h->pb2].name, "+-"[h->dir2], reads[h->pb2].len, h->qb, h->qe, h->score, 1.0 * h->mat / aln, h->mat, h->mis, h->ins, h->del);
+	/* the integer columns by hand (a 16-field sprintf per record was half of the commit's formatting time); the identity column stays with
+	 * printf: its rounding of the binary quotient is part of the output */
+	size_t k = 0;
+	k += put_str(o + k, reads[h->pb1].name); o[k++] = '\t'; o[k++] = '+'; o[k++] = '\t';
+	k += put_int(o + k, (long long)reads[h->pb1].len); o[k++] = '\t'; k += put_int(o + k, h->tb); o[k++] = '\t'; k += put_int(o + k, h->te); o[k++] = '\t';
+	k += put_str(o + k, reads[h->pb2].name); o[k++] = '\t'; o[k++] = "+-"[h->dir2]; o[k++] = '\t';
+	k += put_int(o + k, (long long)reads[h->pb2].len); o[k++] = '\t'; k += put_int(o + k, h->qb); o[k++] = '\t'; k += put_int(o + k, h->qe); o[k++] = '\t';
+	k += put_int(o + k, h->score); o[k++] = '\t';
+	k += (size_t)sprintf(o + k, "%0.3f", 1.0 * h->mat / aln); o[k++] = '\t';
+	k += put_int(o + k, h->mat); o[k++] = '\t'; k += put_int(o + k, h->mis); o[k++] = '\t'; k += put_int(o + k, h->ins); o[k++] = '\t'; k += put_int(o + k, h->del); o[k++] = '\t';
 	if(by_ref){
 		out_advance(k);
 		out_ext(cigar, cigar_len, ext);
