@@ -1572,6 +1572,13 @@ WTZ_D wtz_aln_t wtz_align_window_wave(const wtz_readview &pb1, const wtz_readvie
 				wtz_seq_reg2 r1, r2;
 				r1.w0 = wtz_pack32(z1, 0, (int32_t)len1); r1.w1 = wtz_pack32(z1, 32, (int32_t)len1);
 				r2.w0 = wtz_pack32(z2, 0, (int32_t)len2); r2.w1 = wtz_pack32(z2, 32, (int32_t)len2);
+				if(len1 == len2 && r1.w0 == r2.w0 && r1.w1 == r2.w1){
+					/* the two expanded z-mers are the same string (no homopolymer-length difference): every run matches in full, the
+					 * runs merge into one M of the whole length (hzm_aln.h:278-314 run by run gives exactly that) */
+					memset(&y, 0, sizeof y);
+					y.aln = y.mat = (int32_t)len1; y.te = y.qe = (int32_t)len1; y.score = (int32_t)len1 * M;
+					wtz_cigw_push(Wc, 0, len1);
+				} else
 				y = wtz_align_zmer_w(r1, len1, r2, len2, M, I, D, E, &Wc);
 			} else {
 				y = wtz_align_zmer_w(z1, len1, z2, len2, M, I, D, E, &Wc);
