@@ -1209,14 +1209,14 @@ __global__ void __launch_bounds__(256) wtz_kernel_extjobs_mw(wtz_extjob_t *jobs,
  * bookkeeping and taken branches, not in arithmetic): next state from the cell's nibble, base equality from the 2-bit words of
  * both sequences in LDS (read whether the step is diagonal or not), counters and cursor by flag arithmetic; the open run is kept
  * in runs[nr] and simply rewritten every step. */
-typedef struct { int32_t i, j; uint32_t d, run_op, run_len, nr; int32_t mat, mis, ins, del; } wtz_walk_t;
+typedef struct { int32_t i, j; uint32_t d, run_op, run_len, nr; int32_t ndiag, mis, i0, j0; } wtz_walk_t;      /* i0, j0: where the walk started */
 WTZ_D void wtz_walk_step(wtz_walk_t &w, uint32_t nib, const uint32_t *qw32, const uint32_t *tb32, uint32_t *runs){
 	const uint32_t h3 = nib & 3u, h = h3 > 2u ? 2u : h3;
 	const uint32_t d = ((h | (nib & 4u) | ((nib & 8u) << 2)) >> (w.d << 1)) & 3u;      /* bits 1:0 move from H, 3:2 from E (0 / 1), 5:4 from F (0 / 2) */
 	const uint32_t qb = (qw32[w.i >> 4] >> ((w.i & 15) * 2)) & 3u, tq = (tb32[w.j >> 4] >> ((w.j & 15) * 2)) & 3u;
-	const uint32_t isd = d == 0 ? 1u : 0u, isi = d == 1 ? 1u : 0u, isl = d == 2 ? 1u : 0u, eq = qb == tq ? 1u : 0u;
-	w.mat += (int32_t)(isd & eq); w.mis += (int32_t)(isd & (eq ^ 1u)); w.ins += (int32_t)isi; w.del += (int32_t)isl;
-	w.i -= (int32_t)(isd | isi); w.j -= (int32_t)(isd | isl);
+	const uint32_t isd = d == 0 ? 1u : 0u, ne = qb != tq ? 1u : 0u;
+	w.ndiag += (int32_t)isd; w.mis += (int32_t)(isd & ne);          /* insertions / deletions follow from the distance walked (wtz_walk_finish) */
+	w.i -= d != 2 ? 1 : 0; w.j -= d != 1 ? 1 : 0;
 	const bool same = d == w.run_op;
 	w.nr += (!same && w.run_len) ? 1u : 0u;
 	w.run_len = same ? w.run_len + 1u : 1u; w.run_op = d; w.d = d;
@@ -1225,7 +1225,7 @@ WTZ_D void wtz_walk_step(wtz_walk_t &w, uint32_t nib, const uint32_t *qw32, cons
 /* the two leading gaps (kswx.h:321-322) merge with the open run when the operation agrees (kswx_push_cigar); closes the list */
 WTZ_D void wtz_walk_finish(wtz_walk_t &w, wtz_aln_t &x, uint32_t *runs, uint32_t *n_runs){
 	uint32_t run_op = w.run_op, run_len = w.run_len, nr = w.nr;
-	x.mat = w.mat; x.mis = w.mis; x.ins = w.ins; x.del = w.del;
+	x.mat = w.ndiag - w.mis; x.mis = w.mis; x.ins = (w.i0 - w.i) - w.ndiag; x.del = (w.j0 - w.j) - w.ndiag;      /* every step but a deletion moves up, every step but an insertion moves left */
 	if(w.i >= 0){ x.ins += w.i + 1; if(run_len && run_op == 1u) run_len += (uint32_t)(w.i + 1); else { if(run_len) runs[nr++] = (run_len << 4) | run_op; run_op = 1u; run_len = (uint32_t)(w.i + 1); } }
 	if(w.j >= 0){ x.del += w.j + 1; if(run_len && run_op == 2u) run_len += (uint32_t)(w.j + 1); else { if(run_len) runs[nr++] = (run_len << 4) | run_op; run_op = 2u; run_len = (uint32_t)(w.j + 1); } }
 	if(run_len) runs[nr++] = (run_len << 4) | run_op;
@@ -1378,7 +1378,7 @@ WTZ_D wtz_aln_t wtz_extend_fixed_reg(int32_t qlen, const wtz_seq_packed &query, 
 	WTZ_PROF_ADD(2, pt_rows);
 	WTZ_PROF_CNT(4, i_done + 1);
 	const unsigned long long pt_tb = WTZ_PROF_T();
-	wtz_walk_t wk; wk.i = x.qe; wk.j = x.te; wk.d = 0; wk.run_op = 0xFFu; wk.run_len = 0; wk.nr = 0; wk.mat = wk.mis = wk.ins = wk.del = 0;
+	wtz_walk_t wk; wk.i = x.qe; wk.j = x.te; wk.d = 0; wk.run_op = 0xFFu; wk.run_len = 0; wk.nr = 0; wk.ndiag = wk.mis = 0; wk.i0 = wk.i; wk.j0 = wk.j;
 	if(ZG){
 		uint32_t *stage32 = (uint32_t*)stage;
 		const int32_t RB = zrow <= 128 ? 32 : (zrow <= 256 ? 16 : 8);         /* packed rows per staged block: RB * zrow <= 4 KB */
