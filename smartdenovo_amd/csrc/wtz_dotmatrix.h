@@ -721,7 +721,10 @@ WTZ_HD wtz_dm_result_t wtz_dot_matrix_align(wtz_vec<wtz_zhit_t> &cache, wtz_pool
 		const unsigned long long ptd = WTZ_PROF_T();
 		int why = 4;
 		if(cache.n <= 65535u && lds){
-			why = wtz_denoise_dir_coop(cache.a, cache.n, dir, cnts.nf[dir], cnts.nd[dir], S, P->xvar, P->yvar, P->min_block_len, lds, lds_bytes, pool, bad, allow_big);      /* allow_big: wide group ids, image in the pool if need be */
+			/* the strand image in LDS when it fits the slice, else (allow_big) in the pool with wide group ids: the pair stays in this launch */
+			const bool fits = wtz_denoise_lds_need(cnts.nf[dir], cnts.nd[dir], lds_bytes) <= lds_bytes;
+			why = wtz_denoise_dir_coop(cache.a, cache.n, dir, cnts.nf[dir], cnts.nd[dir], S, P->xvar, P->yvar, P->min_block_len, lds, lds_bytes, pool, bad, allow_big && !fits);
+			if(why && allow_big && fits) why = wtz_denoise_dir_coop(cache.a, cache.n, dir, cnts.nf[dir], cnts.nd[dir], S, P->xvar, P->yvar, P->min_block_len, lds, lds_bytes, pool, bad, true);      /* more than 255 groups, or a band beyond the small slice's member list */
 			if(why && defer_if_large){ ret.dir = -2; ret.score = 0; return ret; }      /* band / group table overflow: the next launch takes the pair */
 		}
 		if(why){

@@ -310,7 +310,7 @@ struct wtz_ctx {
 	bool env_trace = false;      /* WTZ_STAGE_TRACE: name every device stage on stderr before it is launched (locating a device fault) */
 	bool env_fail_once = false;      /* WTZ_POOL_FAIL_ONCE: the injected failure hits one stage call only (the retry must then succeed) */
 	unsigned env_fail_at = 0, env_tfail_at = 0;      /* WTZ_POOL_FAIL_AT / WTZ_TPOOL_FAIL_AT: fault injection into the main / transient pool */
-	int env_sw_mode = 0, env_mw_min = 512, env_mw_top = 1 << 30, env_use_reg = 1, env_gap_side = 0; bool env_profile = false;     /* WTZ_* debugging switches, read in wtz_ctx_create */
+	int env_dm_first_big = 1; int env_sw_mode = 0, env_mw_min = 512, env_mw_top = 1 << 30, env_use_reg = 1, env_gap_side = 0; bool env_profile = false;     /* WTZ_* debugging switches, read in wtz_ctx_create */
 };
 
 #ifndef WTZ_EMUL
@@ -320,7 +320,7 @@ struct wtz_ctx {
 #endif
 
 static wtz_reads_t ctx_reads(const wtz_ctx *c){ wtz_reads_t R; R.bits = c->bits; R.rdoff = c->rdoff; R.rdlen = c->rdlen; R.n_reads = c->n_reads; return R; }
-static wtz_env_t ctx_env(const wtz_ctx *c){ wtz_env_t V; V.R = ctx_reads(c); V.Z = c->Z; V.P = c->dP; V.pool = c->dpool; return V; }
+static wtz_env_t ctx_env(const wtz_ctx *c){ wtz_env_t V; V.R = ctx_reads(c); V.Z = c->Z; V.P = c->dP; V.pool = c->dpool; V.dm_first_big = (uint32_t)c->env_dm_first_big; return V; }
 
 static int tpool_reset(wtz_ctx *c){
 	wtz_pool_t p; p.base = c->pool_base + c->main_bytes; p.cap = c->pool_bytes - c->main_bytes; p.used = 0; p.overflow = 0; p.fail_at = c->env_tfail_at; p.nalloc = 0;
@@ -416,6 +416,7 @@ extern "C" int wtz_ctx_create(int device, const wtz_params_c *params, uint64_t p
 	c->env_use_reg = !(getenv("WTZ_SW_NOREG") && atoi(getenv("WTZ_SW_NOREG")));
 	c->env_gap_side = (getenv("WTZ_GAP_SIDESTREAM") && atoi(getenv("WTZ_GAP_SIDESTREAM"))) ? 1 : 0;
 	c->env_profile = getenv("WTZ_PROFILE_PAIR") != NULL;
+	if(getenv("WTZ_DM_FIRST_BIG")) c->env_dm_first_big = atoi(getenv("WTZ_DM_FIRST_BIG"));
 #endif
 	c->env_trace = getenv("WTZ_STAGE_TRACE") != NULL;
 	c->env_cand_stream = (getenv("WTZ_CAND_STREAM") && atoi(getenv("WTZ_CAND_STREAM")) != 0);
@@ -794,7 +795,8 @@ extern "C" int wtz_pairs_seed(wtz_ctx_t *c, const uint32_t *qid, const uint32_t 
 		uint32_t tiers[3] = { WTZ_PAIR_DM_LDS_TIER2, WTZ_PAIR_DM_LDS_TIER3, WTZ_PAIR_DM_LDS_TIER4 };
 		if(getenv("WTZ_DM_TIER3_KB")) tiers[1] = (uint32_t)atoi(getenv("WTZ_DM_TIER3_KB")) << 10;
 		if(getenv("WTZ_DM_TIER4_KB")) tiers[2] = (uint32_t)atoi(getenv("WTZ_DM_TIER4_KB")) << 10;
-		for(int tier = 0; tier < 3; tier++){
+		/* with the pool image allowed in the first launch only what overflowed its group table or band list is left: the last launch's */
+		for(int tier = c->env_dm_first_big ? 2 : 0; tier < 3; tier++){
 			std::vector<uint32_t> list;
 			for(uint32_t i = 0; i < n; i++) if(c->h_pairres[i].gate && c->h_pairres[i].dm_dir == -2 && !c->h_pairres[i].bad) list.push_back(i);
 			if(list.empty()) break;

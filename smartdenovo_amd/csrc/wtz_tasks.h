@@ -17,6 +17,7 @@
 
 typedef struct {
 	wtz_reads_t R; wtz_zindex_t Z; const wtz_params_t *P; wtz_pool_t *pool;
+	uint32_t dm_first_big;       /* dmo: a strand whose image does not fit the slice of the first K_pair launch keeps it in the pool instead of leaving the pair to a later launch */
 } wtz_env_t;
 
 #define WTZ_WAVE_LDS_BYTES 8192
@@ -27,7 +28,9 @@ typedef struct {
 #define WTZ_PAIR_LDS_BYTES 8192      /* K_pair, zmo: LDS slice of the window scans (measured with WTZ_OCC_PAIR: 16 KB / 1 -> 117 ms, 8 KB / 3 -> 99, 8 KB / 5 -> 90) */
 #endif
 #ifndef WTZ_PAIR_DM_LDS_BYTES
-#define WTZ_PAIR_DM_LDS_BYTES 24576  /* K_pair, dmo: LDS slice of the strand images */
+#define WTZ_PAIR_DM_LDS_BYTES 20480  /* K_pair, dmo: LDS slice of the strand images.  A strand that does not fit keeps its image in the pool (dm_first_big), so the
+                                      * slice only has to hold the band work arrays of that form (17.4 KB); configs[2] step with 18 / 20 / 22 / 24 / 32 KB:
+                                      * 12.19 / 12.17 / 12.82 / 12.69 / 15.32 s (13.9 s when such pairs were left to later launches with 24 KB) */
 #endif
 /* the LDS slice of the wave running the current task (wave-task kernels carry WTZ_WAVE_LDS_BYTES of dynamic LDS) */
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -88,7 +91,7 @@ WTZ_HD void wtz_task_pair(uint32_t t, const wtz_env_t &V, const uint32_t *qid, c
 		static thread_local uint64_t emul_dm_lds[WTZ_PAIR_DM_LDS_BYTES / 8];
 		uint8_t *dlds = (uint8_t*)emul_dm_lds;
 #endif
-		wtz_dm_result_t d = wtz_dot_matrix_align(cache, V.pool, (int32_t)V.R.rdlen[q], (int32_t)V.R.rdlen[c], P, &r.bad, sorted != NULL, &tkd, dlds, WTZ_PAIR_DM_LDS_BYTES, true, false);
+		wtz_dm_result_t d = wtz_dot_matrix_align(cache, V.pool, (int32_t)V.R.rdlen[q], (int32_t)V.R.rdlen[c], P, &r.bad, sorted != NULL, &tkd, dlds, WTZ_PAIR_DM_LDS_BYTES, true, V.dm_first_big != 0);
 		if(lane != 0) return;
 		if(d.dir == -2){ r.anchors[0] = cache.a; r.nanchors[0] = cache.n; }       /* deferred: the ordered matches stay in the pool for wtz_task_pair_dm_big */
 		r.dm_score = d.score; r.dm_qb = d.qb; r.dm_qe = d.qe; r.dm_tb = d.tb; r.dm_te = d.te; r.dm_dir = d.dir;

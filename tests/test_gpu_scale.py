@@ -72,15 +72,18 @@ def test_gpu_equals_reference_at_scale(name, gpu_exe):
     os.remove(out)
 
 
-@pytest.mark.parametrize("env", [{"WTZ_DM_TIER3_KB": "18"}, {"WTZ_DM_TIER3_KB": "17", "WTZ_DM_TIER4_KB": "18"}, {"WTZ_DM_TIER3_KB": "159", "WTZ_DM_TIER4_KB": "159"}],
+@pytest.mark.parametrize("env", [{"WTZ_DM_FIRST_BIG": "0", "WTZ_DM_TIER3_KB": "18"}, {"WTZ_DM_FIRST_BIG": "0", "WTZ_DM_TIER3_KB": "17", "WTZ_DM_TIER4_KB": "18"},
+                                 {"WTZ_DM_FIRST_BIG": "0", "WTZ_DM_TIER3_KB": "159", "WTZ_DM_TIER4_KB": "159"}],
                          ids=["tier4_used", "scalar_fallback_used", "image_in_lds"])
 def test_dmo_heavy_pair_paths(env, gpu_exe):
-    """dmo on the repeat-rich set through the rarely taken forms of the late K_pair launches: with an 18 KB third slice the
+    """dmo on the repeat-rich set through the rarely taken forms of the K_pair launches.  By default a strand too large for the
+    first launch's slice keeps its image in the pool and stays in that launch (WTZ_DM_FIRST_BIG=0: it is left to the later launches, the
+    flow these cases force; the default flow is what test_gpu_equals_reference_at_scale[repeat_dmo] runs).  With an 18 KB third slice the
     group table overflows for a few strands, which the fourth launch finishes (wide table); with both slices that small those strands end
     in the scalar body; with 159 KB slices the strand images stay in LDS (the first form of this round).  Same .ovl as the reference every time."""
     case = MAN["cases"]["repeat_dmo"]
     fa = reads_of(case["set"])
-    out = os.path.join(TMP, "heavy_%s.ovl" % "_".join(sorted(env.values())))
+    out = os.path.join(TMP, "heavy_%s.ovl" % "_".join("%s%s" % (k[-7:], v) for k, v in sorted(env.items())))
     r = subprocess.run([gpu_exe, "-i", fa, "-fo", out] + case["argv"], capture_output=True, env=dict(os.environ, WTZ_PROFILE_PAIR="1", **env))
     assert r.returncode == 0, r.stderr.decode()[-3000:]
     md5, nrec = file_md5(out)
