@@ -30,6 +30,7 @@ import argparse
 import ctypes as C
 import json
 import os
+import shutil
 import subprocess
 import sys
 import tempfile
@@ -165,7 +166,19 @@ def main():
         meta = json.load(open(fa + ".meta"))
 
     eng = ZMO if a.engine == "zmo" else DMO
+    if rank == 0:
+        # --repeat keeps at most ONE stale output next to the file being written (wtzmo_main.c: stale_job), whatever W + K is; an .ovl with
+        # CIGARs is ~3 bytes per read base (3.4 GB at configs[2]).  r02's driver run died of ENOSPC after 20 kept files: check, and say so.
+        need = 2 * 3 * meta["bases"] + (1 << 30)
+        free = shutil.disk_usage(tmp).free
+        print("[bench] %s: %.1f GB free, this run needs <= %.1f GB (two outputs of ~%.1f GB at any time, independent of --steps)"
+              % (tmp, free / 1e9, need / 1e9, 3 * meta["bases"] / 1e9), file=sys.stderr)
+        if free < need:
+            sys.exit("bench.py: not enough free space under %s (%.1f GB free, %.1f GB needed); set WTZ_BENCH_TMP" % (tmp, free / 1e9, need / 1e9))
     out = os.path.join(tmp, "bench_r%d.ovl" % rank)
+    for stale in (out, out + ".prev"):          # leftovers of a run that died
+        if os.path.exists(stale):
+            os.remove(stale)
     stats = os.path.join(tmp, "bench_r%d.stats" % rank)
     W, K = a.warmup, a.steps
     argv = ["wtzmo", "--gpu", str(local), "-i", fa, "-fo", out, "--repeat", str(W + K), "--stats", stats] + (["--pool-gb", str(a.pool_gb)] if a.pool_gb else []) + eng
@@ -290,6 +303,9 @@ def main():
         except Exception as e:      # the baseline is reported, never required
             res["cpu_baseline"] = {"value": None, "error": str(e)}
     print(json.dumps(res))
+    for leftover in (out, out + ".prev", out + ".contained"):
+        if os.path.exists(leftover):
+            os.remove(leftover)
     if dist:
         dist.destroy_process_group()
 

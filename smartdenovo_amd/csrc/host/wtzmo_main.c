@@ -25,6 +25,7 @@
 #include <pthread.h>
 #include <sys/uio.h>
 #include <errno.h>
+#include <sys/stat.h>
 #include "wtz_host.h"
 
 static int usage(void){
@@ -144,6 +145,16 @@ typedef struct {       /* one batch in flight */
 #define DIE_NOW() do { fflush(NULL); _exit(1); } while(0)
 #define DIE_WTZ(rc, what) do { if((rc) != WTZ_OK){ fprintf(stderr, " -- %s failed: %s --\n", what, wtz_last_error()); DIE_NOW(); } } while(0)
 
+/* --repeat (benchmarking): the previous repeat's output file is removed by a side thread, see the repeat loop in wtzmo_main */
+typedef struct { char *path; int pending, running; pthread_t th; } stale_job_t;
+static void *stale_main(void *arg){ unlink((const char*)arg); return NULL; }
+static void stale_start(stale_job_t *j){
+	if(!j->pending || j->running) return;
+	if(pthread_create(&j->th, NULL, stale_main, j->path) == 0) j->running = 1; else unlink(j->path);
+	j->pending = 0;
+}
+static void stale_join(stale_job_t *j){ if(j->running){ pthread_join(j->th, NULL); j->running = 0; } }
+
 static double now_s(void);
 static uint32_t nbest_of(const eng_t *E, uint32_t id){
 	uint32_t nb = (uint32_t)(((size_t)E->P.nbest) * E->rdlen[id] / E->avg_rdlen);      /* wtzmo.c:806-807 */
@@ -178,7 +189,7 @@ static void *owriter_main(void *arg){
 		for(int i = 0; i < c->niov;){
 			int n = c->niov - i; if(n > 1024) n = 1024;
 			ssize_t r = writev(w->fd, c->iov + i, n);
-			if(r < 0){ if(errno == EINTR) continue; fprintf(stderr, " -- write error --\n"); exit(1); }
+			if(r < 0){ if(errno == EINTR) continue; fprintf(stderr, " -- write error on the output file: %s --\n", strerror(errno)); DIE_NOW(); }
 			while(r > 0 && i < c->niov){        /* consume what was written; a partially written entry is advanced in place */
 				if((size_t)r >= c->iov[i].iov_len){ r -= (ssize_t)c->iov[i].iov_len; i++; }
 				else { c->iov[i].iov_base = (char*)c->iov[i].iov_base + r; c->iov[i].iov_len -= (size_t)r; r = 0; }
@@ -360,7 +371,7 @@ __attribute__((unused)) static char *cigar_text(const uint32_t *c, uint32_t n){ 
 	for(uint32_t i = 0; i < n; i++){
 		uint32_t op = c[i] & 0xF, len = c[i] >> 4;
 		if(len == 0) continue;
-		if(op > 2){ fprintf(stderr, " -- CIGAR only support M(0),I(1),D(2) cigar, but met ?(%u) --\n", op); exit(1); }
+		if(op > 2){ fprintf(stderr, " -- CIGAR only support M(0),I(1),D(2) cigar, but met ?(%u) --\n", op); DIE_NOW(); }
 		char d[12]; int nd = 0;
 		while(len){ d[nd++] = (char)('0' + len % 10); len /= 10; }
 		while(nd) s[k++] = d[--nd];
@@ -389,7 +400,7 @@ static void commit_query(eng_t *E, batch_t *b, uint32_t slot){
 	if(bcov >= nbest) return;
 	E->used_queries++; b->used_queries++;
 	/* candidates: closed filter, exact order, trim (wtzmo.c:813-822) */
-	if(!b->want[slot]){ fprintf(stderr, " -- internal error: no candidate row for read %u --\n", pbid); exit(1); }
+	if(!b->want[slot]){ fprintf(stderr, " -- internal error: no candidate row for read %u --\n", pbid); DIE_NOW(); }
 	uint32_t nc = b->nrow[slot];
 	cand_t *cand = (cand_t*)hx_realloc(NULL, sizeof(cand_t) * (nc + 1));
 	for(uint32_t i = 0; i < nc; i++){
@@ -405,7 +416,7 @@ static void commit_query(eng_t *E, batch_t *b, uint32_t slot){
 	if(P->dot_matrix){
 		for(uint32_t i = 0; i < nc; i++){
 			const uint32_t id2 = (uint32_t)(cand[i].e >> 32);
-			if(cand[i].pidx == 0xFFFFFFFFu){ fprintf(stderr, " -- internal error: pair (%u,%u) missing from the batch plan --\n", pbid, id2); exit(1); }
+			if(cand[i].pidx == 0xFFFFFFFFu){ fprintf(stderr, " -- internal error: pair (%u,%u) missing from the batch plan --\n", pbid, id2); DIE_NOW(); }
 			const wtz_pair_summary_t *S = &PART_OF(b, cand[i].pidx)->sum[LOCAL_OF(b, cand[i].pidx)];
 			if(!S->gate) continue;
 			E->used_pairs++;
@@ -429,7 +440,7 @@ static void commit_query(eng_t *E, batch_t *b, uint32_t slot){
 	seed_t *seeds = (seed_t*)hx_realloc(NULL, sizeof(seed_t) * (nc + 1)); uint32_t nseed = 0;
 	for(uint32_t i = 0; i < nc; i++){
 		const uint32_t id2 = (uint32_t)(cand[i].e >> 32);
-		if(cand[i].pidx == 0xFFFFFFFFu){ fprintf(stderr, " -- internal error: pair (%u,%u) missing from the batch plan --\n", pbid, id2); exit(1); }
+		if(cand[i].pidx == 0xFFFFFFFFu){ fprintf(stderr, " -- internal error: pair (%u,%u) missing from the batch plan --\n", pbid, id2); DIE_NOW(); }
 		const part_t *pt = PART_OF(b, cand[i].pidx); const uint32_t li = LOCAL_OF(b, cand[i].pidx);
 		const wtz_pair_summary_t *S = &pt->sum[li];
 		if(!S->gate) continue;
@@ -475,7 +486,7 @@ static void commit_query(eng_t *E, batch_t *b, uint32_t slot){
 			pend_closed(pd, hx_pair_key(s->pb2, pbid));
 			const part_t *pt = PART_OF(b, s->pidx);
 			const uint32_t item = pt->item_of[LOCAL_OF(b, s->pidx)];
-			if(item == 0xFFFFFFFFu || pt->it_dir[item] != s->dir){ fprintf(stderr, " -- internal error: alignment of (%u,%u) missing from the batch plan --\n", pbid, s->pb2); exit(1); }
+			if(item == 0xFFFFFFFFu || pt->it_dir[item] != s->dir){ fprintf(stderr, " -- internal error: alignment of (%u,%u) missing from the batch plan --\n", pbid, s->pb2); DIE_NOW(); }
 			E->used_items++;
 			const wtz_aln_result_t *x = &pt->aln[item];
 			if(x->n_regs == 0){ s->closed = 1; ncand++; continue; }
@@ -601,7 +612,7 @@ static int gpu_stages_ranks(eng_t *E, batch_t *b);
 static int gpu_stages(eng_t *E, batch_t *b){
 	if(g_dist.world > 1) return gpu_stages_ranks(E, b);
 	pthread_t th[16];
-	for(uint32_t d = 1; d < b->nparts; d++){ b->parts[d].E = E; if(pthread_create(&th[d], NULL, part_main, &b->parts[d]) != 0){ fprintf(stderr, " -- cannot start a device thread --\n"); exit(1); } }
+	for(uint32_t d = 1; d < b->nparts; d++){ b->parts[d].E = E; if(pthread_create(&th[d], NULL, part_main, &b->parts[d]) != 0){ fprintf(stderr, " -- cannot start a device thread --\n"); DIE_NOW(); } }
 	b->parts[0].E = E; b->parts[0].again = part_stages(E, &b->parts[0]);
 	int again = b->parts[0].again;
 	for(uint32_t d = 1; d < b->nparts; d++){ pthread_join(th[d], NULL); again |= b->parts[d].again; }
@@ -631,15 +642,15 @@ static int gpu_stages_ranks(eng_t *E, batch_t *b){
 		uint64_t nb = 0;
 		for(uint32_t i = 0; i < pt->npair; i++) for(int d = 0; d < 2; d++){ pt->box_off[(size_t)i * 2 + d] = nb; nb += pt->sum[i].nwin[d]; }
 		pt->box_off[(size_t)pt->npair * 2] = nb; pt->nbox = nb;
-		if(nb != rh[1]){ fprintf(stderr, " -- rank %u reports %llu windows, its summaries say %llu --\n", r, (unsigned long long)rh[1], (unsigned long long)nb); exit(1); }
+		if(nb != rh[1]){ fprintf(stderr, " -- rank %u reports %llu windows, its summaries say %llu --\n", r, (unsigned long long)rh[1], (unsigned long long)nb); DIE_NOW(); }
 		if(nb > pt->capbox){ pt->capbox = nb; pt->boxes = (wtz_winbox_t*)hx_realloc(pt->boxes, sizeof(wtz_winbox_t) * nb); }
 		if(nb) g_dist.recv(pt->boxes, sizeof(wtz_winbox_t) * nb, (int)r);
 		part_plan_items(E, pt);
-		if(pt->nitem != rh[2]){ fprintf(stderr, " -- rank %u aligned %llu items, the plan has %u --\n", r, (unsigned long long)rh[2], pt->nitem); exit(1); }
+		if(pt->nitem != rh[2]){ fprintf(stderr, " -- rank %u aligned %llu items, the plan has %u --\n", r, (unsigned long long)rh[2], pt->nitem); DIE_NOW(); }
 		if(pt->nitem){
 			pt->aln = (wtz_aln_result_t*)hx_realloc(pt->aln, sizeof(wtz_aln_result_t) * pt->nitem);
 			g_dist.recv(pt->aln, sizeof(wtz_aln_result_t) * (uint64_t)pt->nitem, (int)r);
-			if(!part_text_buffer(pt, rh[3])) exit(1);
+			if(!part_text_buffer(pt, rh[3])) DIE_NOW();
 			if(rh[3]) g_dist.recv(pt->cig, rh[3], (int)r);
 			pt->ncig = rh[3];
 		}
@@ -677,7 +688,7 @@ static void remote_loop(eng_t *E, part_t *pt){
 		} else if(h.cmd == WTZ_CMD_CAND_END){
 			int rc = wtz_candidates_end(pt->ctx, pt->cq_rows, pt->cq_nr); DIE_WTZ(rc, "wtz_candidates_end");
 			if(pt->cq_n){ g_dist.send(pt->cq_rows, (uint64_t)pt->cq_n * E->stride * 8, 0); g_dist.send(pt->cq_nr, 4 * (uint64_t)pt->cq_n, 0); }
-		} else { fprintf(stderr, " -- rank %d: unknown request %llu --\n", me, (unsigned long long)h.cmd); exit(1); }
+		} else { fprintf(stderr, " -- rank %d: unknown request %llu --\n", me, (unsigned long long)h.cmd); DIE_NOW(); }
 	}
 }
 
@@ -744,7 +755,7 @@ static void process_range(eng_t *E, batch_t *b, uint32_t s0, uint32_t s1){
 	}
 	if(again){
 		pthread_mutex_lock(&E->mu); E->n_split++; E->bytes_per_pair = (E->bytes_per_pair > 0 ? E->bytes_per_pair : 1048576.0) * 2.0; pthread_mutex_unlock(&E->mu);
-		if(s1 - s0 <= 1){ fprintf(stderr, " -- device scratch pool too small even for one query: %s (use --pool-gb) --\n", wtz_last_error()); exit(1); }
+		if(s1 - s0 <= 1){ fprintf(stderr, " -- device scratch pool too small even for one query: %s (use --pool-gb) --\n", wtz_last_error()); DIE_NOW(); }
 		fprintf(stderr, "[wtzmo-mi355x] scratch pool exhausted with %u queries in flight; splitting the batch\n", s1 - s0);
 		const uint32_t mid = s0 + (s1 - s0) / 2;
 		process_range(E, b, s0, mid);
@@ -859,7 +870,7 @@ static void *worker_main(void *arg){
 			for(uint32_t s = 0; s < b->nbq; s++){
 				if(!b->want[s]) continue;
 				while(k < b->pf_n && b->pf_ids[k] < b->bq[s]) k++;
-				if(k >= b->pf_n || b->pf_ids[k] != b->bq[s]){ fprintf(stderr, " -- internal error: read %u has no prefetched candidates --\n", b->bq[s]); exit(1); }
+				if(k >= b->pf_n || b->pf_ids[k] != b->bq[s]){ fprintf(stderr, " -- internal error: read %u has no prefetched candidates --\n", b->bq[s]); DIE_NOW(); }
 				memcpy(b->rows + (size_t)s * E->stride, b->pf_rows + (size_t)k * E->stride, (size_t)E->stride * 8); b->nrow[s] = b->pf_nr[k];
 			}
 			pthread_mutex_lock(&E->mu); E->t_gpu += tg1 - tg0; E->t_call[0] += tg1 - tg0; pthread_mutex_unlock(&E->mu);
@@ -1112,7 +1123,8 @@ int main(int argc, char **argv){
 	size_t nclosed0 = 0; uint64_t *closed0 = (uint64_t*)hx_realloc(NULL, 8 * (E->closed.n + 1));
 	for(size_t i = 0; i < E->closed.cap; i++) if(E->closed.tab[i] != ~0ULL) closed0[nclosed0++] = E->closed.tab[i];
 	if(statsf){ FILE *sf = fopen(statsf, "w"); if(sf) fclose(sf); }
-	char *stale[64]; int n_stale = 0;
+	stale_job_t stale_job; memset(&stale_job, 0, sizeof stale_job);
+	stale_job.path = (char*)hx_realloc(NULL, strlen(output) + 16); sprintf(stale_job.path, "%s.prev", output);
 	for(int rep = 0; rep < repeat; rep++){
 		if(rep){
 			memcpy(E->masked, masked0, (size_t)n_all + 1); memset(E->rdcovs, 0, 4 * ((size_t)n_all + 1));
@@ -1121,15 +1133,21 @@ int main(int argc, char **argv){
 			E->n_order = n_order0;
 			E->pair_bp = E->n_pairs = E->nrec = 0;
 			E->t_gpu = E->t_commit = 0; memset(E->t_call, 0, sizeof E->t_call); E->t_io[0] = E->t_io[1] = 0; E->spec_pairs = E->used_pairs = E->spec_items = E->used_items = E->spec_queries = E->used_queries = 0;
-			E->rows_all = 0; E->n_batches = 0; E->n_split = 0; E->n_ranges = 0;
+			E->rows_all = 0; E->n_batches = 0; E->n_split = 0; E->n_ranges = 0; E->bytes_per_pair = 0;      /* every repeat plans like a cold run: probe range first */
 			E->pend.rd_id = 0xFFFFFFFFu; E->pend.nhit = E->pend.nmask = E->pend.nclosed = E->pend.nseed = 0;
 			if(strcmp(output, "-")){
-				/* the previous repeat's file (3 GB at configs[2]) is neither truncated in place nor removed now: freeing its pages took ~0.4 s of
-				 * the next repeat's timed region inline, and on a side thread it slowed the device allocations of the index builds (z-index
-				 * 140 -> 800 ms).  It is renamed and removed after the last repeat. */
-				char *old = (char*)hx_realloc(NULL, strlen(output) + 24); sprintf(old, "%s.prev%d", output, rep);
-				if(rename(output, old) == 0 && n_stale < 64) stale[n_stale++] = old; else { unlink(old); free(old); }
-				E->out = fopen(output, "w"); if(E->out == NULL) exit(1); setvbuf(E->out, NULL, _IOFBF, 8u << 20);
+				/* the previous repeat's file (3 GB at configs[2]) is neither truncated in place nor removed inline: freeing its pages took
+				 * ~0.4 s of the next repeat's timed region, and on a side thread BESIDE THE INDEX BUILDS it slowed their device allocations
+				 * (z-index 140 -> 800 ms).  A regular file is renamed to <output>.prev and removed by a side thread once this repeat's
+				 * index builds are done (stale_start below): at most ONE stale file exists at any time, whatever --repeat says.  Anything that
+				 * is not a regular file (/dev/null, a FIFO, a symlink) is never renamed: it is simply opened again. */
+				stale_join(&stale_job);
+				struct stat sb;
+				if(lstat(output, &sb) == 0 && S_ISREG(sb.st_mode)){
+					unlink(stale_job.path);
+					if(rename(output, stale_job.path) == 0) stale_job.pending = 1;
+				}
+				E->out = fopen(output, "w"); if(E->out == NULL){ fprintf(stderr, " -- Cannot write %s: %s --\n", output, strerror(errno)); DIE_NOW(); } setvbuf(E->out, NULL, _IOFBF, 8u << 20);
 			}
 			wtz_reset_counters(E->ctx);
 		}
@@ -1137,7 +1155,7 @@ int main(int argc, char **argv){
 		if(g_hook) g_hook(rep, 0);
 		const double t0 = now_s();
 		pthread_t ixth[8]; ixjob_t ixj[8];
-		for(uint32_t d = 1; d < E->ndev; d++){ ixj[d].ctx = E->ctxs[d]; ixj[d].n_rd = n_rd; ixj[d].K = P->max_kmer_freq; if(pthread_create(&ixth[d], NULL, ixjob_main, &ixj[d]) != 0) exit(1); }
+		for(uint32_t d = 1; d < E->ndev; d++){ ixj[d].ctx = E->ctxs[d]; ixj[d].n_rd = n_rd; ixj[d].K = P->max_kmer_freq; if(pthread_create(&ixth[d], NULL, ixjob_main, &ixj[d]) != 0) DIE_NOW(); }
 		rc = wtz_zindex_build(E->ctx); DIE_WTZ(rc, "wtz_zindex_build");
 		/* ---- index parts (-G, wtzmo.c:1276-1303) ---- */
 		uint32_t pbbeg = 0, pbend = 0, K = P->max_kmer_freq;
@@ -1175,6 +1193,7 @@ int main(int argc, char **argv){
 			}
 		}
 		for(uint32_t d = 1; d < E->ndev; d++){ pthread_join(ixth[d], NULL); if(ixj[d].rc != WTZ_OK){ fprintf(stderr, " -- index build on device %d failed: %s --\n", E->devs[d], ixj[d].err); DIE_NOW(); } }
+		stale_start(&stale_job);       /* index builds (and their device allocations) are done: drop the previous repeat's file in the background */
 		/* ---- queries: pipelined batches on n_workers contexts (own stream + pool each, indexes shared) ---- */
 		if(pin_started){ pthread_join(pin_th, NULL); pin_started = 0; }
 		{
@@ -1256,7 +1275,8 @@ int main(int argc, char **argv){
 				cn.ms_index, cn.ms_zindex, cn.ms_candidates, cn.ms_pairs, cn.ms_winalign, cn.ms_stitch, (unsigned long long)cn.cells_shift, (unsigned long long)cn.cells_fixed, (unsigned long long)cn.cells_global, (unsigned long long)cn.bytes_seed_algo, (unsigned long long)E->nrec,
 				cn.ms_ext, (unsigned long long)cn.n_extjobs, (unsigned long long)E->used_queries, (unsigned long long)cn.pool_peak, cn.ms_gap, (unsigned long long)E->n_ranges, (unsigned long long)E->n_split); fclose(sf); } }
 	}
-	for(int k = 0; k < n_stale; k++){ unlink(stale[k]); free(stale[k]); }
+	stale_join(&stale_job); if(stale_job.pending) unlink(stale_job.path);
+	free(stale_job.path);
 	if(write_contained && strcmp(output, "-")){
 		char *maskf = (char*)hx_realloc(NULL, strlen(output) + 16); sprintf(maskf, "%s.contained", output);
 		FILE *mf = fopen(maskf, "w");
