@@ -54,6 +54,9 @@ static ora_aln_t ora_align_window(const uint8_t *pb1, const uint8_t *pb2, const 
 		if((int)p->off1 < x.te) continue;
 		if((int)p->off2 < x.qe) continue;
 		tmp_cigar->n = 0;
+#ifdef ORA_STATS       /* analysis build only (tools/analysis): shape of every K-sw1 problem */
+		fprintf(stderr, "SW1\t%u\t%d\t%d\t%d\n", win->anchors[1] - win->anchors[0], (int)p->off2 - x.qe, (int)p->off1 - x.te, x.score);
+#endif
 		y = ora_extend_fixed((int)p->off2 - x.qe, pb2 + x.qe, (int)p->off1 - x.te, pb1 + x.te, 1, x.score, w, M, X, I, D, E, T, mem, tmp_cigar);
 		x.score = y.score;
 		x.aln += y.aln; x.mat += y.mat; x.mis += y.mis; x.ins += y.ins; x.del += y.del;

@@ -103,12 +103,18 @@ static ora_aln_t ora_extend_fixed(int qlen, const uint8_t *query, int tlen, cons
 	for(j = 2; j <= tl; j++) rh[j] = rh[j - 1] + E;
 	for(j = 0; j <= tl; j++) re[j] = -10000;
 	max = init_score; mi = -1; mj = -1; gmax = 0; gi = -1; gj = -1;
+#ifdef ORA_STATS
+	int st_minrow = 1 << 30, st_break = 0, st_gcand = -(1 << 30);
+#endif
 	for(i = 0; i < ql; i++){
 		jb = i - W; if(jb < 0) jb = 0;
 		je = i + W + 1; if(je > tl) je = tl;
 		h1 = (jb == 0) ? init_score + I + E * (i + 1) : -10000;
 		uint8_t *zi = mem->z.a + (size_t)i * n_col;
 		imax = 0; mj2 = -1; f = -10000;
+#ifdef ORA_STATS
+		int st_rowmax = -(1 << 30);
+#endif
 		for(j = jb; j < je; j++){
 			m = rh[j] + ((query[i * strand] == target[j * strand]) ? M : X);
 			rh[j] = h1;
@@ -118,6 +124,9 @@ static ora_aln_t ora_extend_fixed(int qlen, const uint8_t *query, int tlen, cons
 			d = h >= f ? d : 2;
 			h = h >= f ? h : f;
 			h1 = h;
+#ifdef ORA_STATS
+			if(h > st_rowmax) st_rowmax = h;
+#endif
 			mj2  = imax > h ? mj2 : j;      /* last arg-max: ties take the larger j (kswx.h:288-289); K-sw3 keeps the first */
 			imax = imax > h ? imax : h;
 			t = m + I + E; e = e + E;
@@ -128,11 +137,24 @@ static ora_aln_t ora_extend_fixed(int qlen, const uint8_t *query, int tlen, cons
 			zi[j - jb] = d;
 		}
 		rh[j] = h1; re[j] = -10000;
+#ifdef ORA_STATS
+		if(st_rowmax - init_score < st_minrow) st_minrow = st_rowmax - init_score;
+		if(j == tlen && h1 - init_score > st_gcand) st_gcand = h1 - init_score;
+		if(i + 1 == qlen && st_rowmax - init_score > st_gcand) st_gcand = st_rowmax - init_score;
+#endif
 		if(j == tlen && gmax < h1){ gmax = h1; gi = i; gj = j - 1; }
 		if(i + 1 == qlen && gmax < imax){ gmax = imax; gi = i; gj = mj2; }
 		if(imax > max){ max = imax; mi = i; mj = mj2; }
-		else if(imax <= 0) break;
+		else if(imax <= 0){
+#ifdef ORA_STATS
+			st_break = 1;
+#endif
+			break; }
 	}
+#ifdef ORA_STATS
+	/* shape, init, min over rows of (row max - init), early break, best end-candidate - init (or -inf), max - init */
+	fprintf(stderr, "SW1DP\t%d\t%d\t%d\t%d\t%d\t%d\t%d\t%d\n", ql, tl, n_col, init_score, st_minrow, st_break, st_gcand, max - init_score);
+#endif
 	if(gmax > 0 && gmax >= max + T){ x.score = gmax; x.qe = gi; x.te = gj; }
 	else { x.score = max; x.qe = mi; x.te = mj; }
 	cigars->n = 0;

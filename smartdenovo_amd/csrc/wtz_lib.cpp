@@ -57,6 +57,14 @@ struct K_misc;
 struct K_gap;
 struct K_gap_wide;
 struct K_kcount;
+struct K_lcount;
+struct K_lplan;
+struct K_ldp16;
+struct K_ldp32;
+struct K_ldp64;
+struct K_ldp104;
+struct K_lfold;
+struct K_poolalloc;
 struct K_kfill;
 struct K_kinsert;
 struct K_kstats;
@@ -134,6 +142,11 @@ template<typename TAG> struct wtz_occ { static constexpr int waves = 1; };
 template<> struct wtz_occ<K_winalign> { static constexpr int waves = WTZ_OCC_WINALIGN; };
 template<> struct wtz_occ<K_pair> { static constexpr int waves = WTZ_OCC_PAIR; };
 template<> struct wtz_occ<K_gap> { static constexpr int waves = WTZ_OCC_GAP; };
+/* lane-per-problem K-sw1 (wtz_sw_lane.h): the band lives in 2 x (NC + 1) VGPRs */
+template<> struct wtz_occ<K_ldp16> { static constexpr int waves = 4; };
+template<> struct wtz_occ<K_ldp32> { static constexpr int waves = 4; };
+template<> struct wtz_occ<K_ldp64> { static constexpr int waves = 2; };
+template<> struct wtz_occ<K_ldp104> { static constexpr int waves = 2; };
 template<typename TAG, typename F> __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(wtz_occ<TAG>::waves, 8))) wtz_kernel_coop_tasks(uint64_t n, F f){
 	const uint64_t i = blockIdx.x;
 	WTZ_PROF_BEGIN();
@@ -193,6 +206,7 @@ static void dev_free_persist(void *p){ if(p) (void)hipFree(p); }
 static int dev_h2d(void *d, const void *h, size_t n){ if(n){ HIPCHK(hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, g_stream)); HIPCHK(hipStreamSynchronize(g_stream)); } return WTZ_OK; }
 static int dev_d2h(void *h, const void *d, size_t n){ if(n){ HIPCHK(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, g_stream)); HIPCHK(hipStreamSynchronize(g_stream)); } return WTZ_OK; }
 static int dev_set(void *d, int v, size_t n){ if(n) HIPCHK(hipMemsetAsync(d, v, n, g_stream)); return WTZ_OK; }
+static int dev_d2d(void *d, const void *s, size_t n){ if(n) HIPCHK(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToDevice, g_stream)); return WTZ_OK; }
 static int dev_sync(){ HIPCHK(hipStreamSynchronize(g_stream)); return WTZ_OK; }
 
 struct wtz_timer { hipEvent_t a, b; bool ok;
@@ -246,6 +260,7 @@ struct wtz_arena_scope { std::vector<void*> *keep; wtz_arena_scope(wtz_arena*){ 
 static int dev_h2d(void *d, const void *h, size_t n){ if(n) memcpy(d, h, n); return WTZ_OK; }
 static int dev_d2h(void *h, const void *d, size_t n){ if(n) memcpy(h, d, n); return WTZ_OK; }
 static int dev_set(void *d, int v, size_t n){ if(n) memset(d, v, n); return WTZ_OK; }
+static int dev_d2d(void *d, const void *s, size_t n){ if(n) memcpy(d, s, n); return WTZ_OK; }
 static int dev_sync(){ return WTZ_OK; }
 #include <time.h>
 struct wtz_timer { struct timespec t0; void start(){ clock_gettime(CLOCK_MONOTONIC, &t0); }
@@ -306,6 +321,7 @@ struct wtz_ctx {
 	wtz_counters_t cnt;
 	uint64_t tpool_peak_call = 0, main_used_call = 0;      /* transient-pool high-water mark / main-pool bytes of the API call in progress */
 	int env_cand_stream = 0;     /* WTZ_CAND_STREAM=1: sort-free candidate accumulation (LDS sketch + survivor table, wtz_seed.h); bit-exact, pays at 25x coverage only: see DESIGN.md */
+	int env_lane = 1;            /* WTZ_WINALIGN_LANE=0: the chained wave-per-window kernel for every window (the form before round 3); 2: run both and compare */
 	int env_grp4 = 0;            /* WTZ_WINALIGN4=1: four windows per wavefront first (wtz_sw_grp.h; bit-exact, measured 2x SLOWER than one window per wave: see DESIGN.md) */
 	bool env_trace = false;      /* WTZ_STAGE_TRACE: name every device stage on stderr before it is launched (locating a device fault) */
 	bool env_fail_once = false;      /* WTZ_POOL_FAIL_ONCE: the injected failure hits one stage call only (the retry must then succeed) */
@@ -421,6 +437,7 @@ extern "C" int wtz_ctx_create(int device, const wtz_params_c *params, uint64_t p
 	c->env_trace = getenv("WTZ_STAGE_TRACE") != NULL;
 	c->env_cand_stream = (getenv("WTZ_CAND_STREAM") && atoi(getenv("WTZ_CAND_STREAM")) != 0);
 	c->env_grp4 = (getenv("WTZ_WINALIGN4") && atoi(getenv("WTZ_WINALIGN4")) != 0);
+	if(getenv("WTZ_WINALIGN_LANE")) c->env_lane = atoi(getenv("WTZ_WINALIGN_LANE"));
 	c->env_fail_once = getenv("WTZ_POOL_FAIL_ONCE") != NULL;
 	c->env_fail_at = getenv("WTZ_POOL_FAIL_AT") ? (unsigned)atoi(getenv("WTZ_POOL_FAIL_AT")) : 0u;
 	c->env_tfail_at = getenv("WTZ_TPOOL_FAIL_AT") ? (unsigned)atoi(getenv("WTZ_TPOOL_FAIL_AT")) : 0u;
@@ -983,6 +1000,76 @@ static int run_extjobs(wtz_ctx *c, const wtz_env_t &V, wtz_extjob_t *d_jobs, uin
 #endif
 }
 
+
+/* ------------------------------------------------------------------------------------------------ */
+/* A9 with one lane per K-sw1 problem (wtz_sw_lane.h)                                                */
+/* ------------------------------------------------------------------------------------------------ */
+#ifdef WTZ_EMUL
+#define WTZ_HOST_WAVE 1u
+#else
+#define WTZ_HOST_WAVE 64u
+#endif
+/* a block of the main (0) / transient (1) device pool for a host-side array */
+static int pool_alloc_host(wtz_ctx *c, int which, size_t bytes, void **out){
+	unsigned long long *d_p = NULL; CHK(dev_alloc((void**)&d_p, 8));
+	wtz_pool_t *pool = c->dpool + which;
+	CHK(wtz_launch<K_poolalloc>(0, 1, [=] WTZ_LAMBDA (uint64_t){ *d_p = (unsigned long long)(uintptr_t)wtz_pool_alloc(pool, bytes); }));
+	unsigned long long h = 0; CHK(dev_d2h(&h, d_p, 8)); dev_free(d_p);
+	if(h == 0) return wtz_fail(WTZ_E_POOL, "device scratch pool exhausted (%zu bytes for the K-sw1 problem lists)", bytes);
+	*out = (void*)(uintptr_t)h; return WTZ_OK;
+}
+/* windows d_wt[0, nwt): plan -> shape sort -> relative-mode DP per class -> fold.  d_fb ([0] = count, room for nwt + 1) receives the
+ * windows the chained kernel has to do (outside the envelope, or an absolute test of kswx_extend_align_core would have fired). */
+static int run_winalign_lane(wtz_ctx *c, const wtz_env_t &V, const wtz_wintask_t *d_wt, uint64_t nwt, const wtz_alnitem_t *d_items, uint32_t *d_fb, uint32_t *n_fb){
+	*n_fb = 0;
+	if(nwt == 0) return WTZ_OK;
+	uint32_t *d_na = NULL, *d_woff = NULL;
+	CHK(dev_alloc((void**)&d_na, (nwt + 1) * 4)); CHK(dev_alloc((void**)&d_woff, (nwt + 1) * 4));
+	CHK(dev_set(d_na, 0, (nwt + 1) * 4));
+	CHK(wtz_launch<K_lcount>(0, nwt, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_lcount((uint32_t)t, d_wt, d_items, d_na); }));
+	CHK(dev_exclusive_scan_u32(d_na, d_woff, nwt + 1));
+	uint32_t NS = 0; CHK(dev_d2h(&NS, d_woff + nwt, 4));
+	wtz_lprob_t *d_prob = NULL; uint32_t *d_cap = NULL, *d_roff = NULL, *d_val = NULL, *d_ccnt = NULL; uint64_t *d_key = NULL; uint8_t *d_flag = NULL; wtz_lres_t *d_res = NULL;
+	{   /* per-slot arrays: one block of the main pool */
+		const size_t nsp = (size_t)NS + 64;
+		const size_t b_prob = (nsp * sizeof(wtz_lprob_t) + 255) & ~(size_t)255, b_res = (nsp * sizeof(wtz_lres_t) + 255) & ~(size_t)255, b_u32 = (nsp * 4 + 255) & ~(size_t)255, b_u64 = (nsp * 8 + 255) & ~(size_t)255;
+		uint8_t *blk = NULL; CHK(pool_alloc_host(c, 0, b_prob + b_res + 3 * b_u32 + b_u64, (void**)&blk));
+		d_prob = (wtz_lprob_t*)blk; blk += b_prob; d_res = (wtz_lres_t*)blk; blk += b_res; d_cap = (uint32_t*)blk; blk += b_u32; d_roff = (uint32_t*)blk; blk += b_u32; d_val = (uint32_t*)blk; blk += b_u32; d_key = (uint64_t*)blk;
+	}
+	CHK(dev_alloc((void**)&d_flag, nwt + 16)); CHK(dev_alloc((void**)&d_ccnt, 32)); CHK(dev_set(d_ccnt, 0, 32));
+	CHK(dev_set(d_cap, 0, ((size_t)NS + 1) * 4));
+	CHK(dev_set(d_res, 0, ((size_t)NS + 1) * sizeof(wtz_lres_t)));
+	CHK(wtz_launch<K_lplan>(0, nwt, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_lplan((uint32_t)t, V, d_wt, d_items, d_woff, d_prob, d_cap, d_key, d_val, d_flag, d_ccnt); }));
+	CHK(dev_exclusive_scan_u32(d_cap, d_roff, (uint64_t)NS + 1));
+	uint32_t NR = 0, ccnt[4] = {0, 0, 0, 0};
+	CHK(dev_d2h(&NR, d_roff + NS, 4)); CHK(dev_d2h(ccnt, d_ccnt, 16));
+	uint32_t *d_runs = NULL; CHK(pool_alloc_host(c, 0, ((size_t)NR + 16) * 4, (void**)&d_runs));
+	CHK(dev_sort_pairs_u64_u32(d_key, d_val, NS, 16));                 /* ascending inverted key = widest band first, longest first inside a width */
+	CHK(dev_set(d_fb, 0, 4));
+	{
+		const uint32_t *d_ord = d_val; const wtz_lprob_t *pp = d_prob; const uint32_t *ro = d_roff; uint32_t *rn = d_runs; wtz_lres_t *rs = d_res;
+		uint32_t lo = 0;
+		for(int cls = 3; cls >= 0; cls--){
+			const uint32_t n = ccnt[cls], hi = lo + n;
+			if(n){
+				const uint64_t nw = ((uint64_t)n + WTZ_HOST_WAVE - 1) / WTZ_HOST_WAVE;
+				const uint32_t lo_ = lo;
+				if(cls == 3)      CHK(wtz_launch_coop<K_ldp104>(0, nw, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_ldp<104>((uint32_t)t, V, d_wt, d_items, d_ord, lo_, hi, pp, ro, rn, rs); }, 0));
+				else if(cls == 2) CHK(wtz_launch_coop<K_ldp64>(0, nw, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_ldp<64>((uint32_t)t, V, d_wt, d_items, d_ord, lo_, hi, pp, ro, rn, rs); }, 0));
+				else if(cls == 1) CHK(wtz_launch_coop<K_ldp32>(0, nw, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_ldp<32>((uint32_t)t, V, d_wt, d_items, d_ord, lo_, hi, pp, ro, rn, rs); }, 0));
+				else              CHK(wtz_launch_coop<K_ldp16>(0, nw, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_ldp<16>((uint32_t)t, V, d_wt, d_items, d_ord, lo_, hi, pp, ro, rn, rs); }, 0));
+			}
+			lo = hi;
+		}
+		CHK(wtz_launch<K_lfold>(0, nwt, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_lfold((uint32_t)t, V, d_wt, d_items, d_woff, pp, ro, rn, rs, d_flag, d_fb); }));
+	}
+	CHK(dev_d2h(n_fb, d_fb, 4));
+	if(c->env_profile) fprintf(stderr, "[lane-profile] %llu windows, %u anchor slots, K-sw1 problems by band class <=16 / <=32 / <=64 / <=104: %u / %u / %u / %u, %u run entries, %u windows left to the chained kernel\n",
+		(unsigned long long)nwt, NS, ccnt[0], ccnt[1], ccnt[2], ccnt[3], NR, *n_fb);
+	dev_free(d_na); dev_free(d_woff); dev_free(d_flag); dev_free(d_ccnt);
+	return WTZ_OK;
+}
+
 extern "C" int wtz_pairs_align(wtz_ctx_t *c, const uint32_t *pair_idx, const uint8_t *dir, uint32_t m, wtz_aln_result_t *out){
 	if(!c || !c->have_pairs) return wtz_fail(WTZ_E_STATE, "wtz_pairs_align before wtz_pairs_seed");
 	if(m == 0) return WTZ_OK;
@@ -1003,7 +1090,7 @@ extern "C" int wtz_pairs_align(wtz_ctx_t *c, const uint32_t *pair_idx, const uin
 		for(uint32_t k = 0; k < it.nwin; k++){ wtz_wintask_t w; w.item = i; w.widx = k; wt.push_back(w); }
 		nreg += it.nwin; items[i] = it;
 	}
-	wtz_reg_t *d_regs = NULL; wtz_alnitem_t *d_items = NULL; wtz_wintask_t *d_wt = NULL;
+	wtz_reg_t *d_regs = NULL, *d_regs_chk = NULL; wtz_alnitem_t *d_items = NULL; wtz_wintask_t *d_wt = NULL;
 	CHK(dev_alloc((void**)&d_regs, (size_t)(nreg + 1) * sizeof(wtz_reg_t)));
 	for(uint32_t i = 0; i < m; i++) items[i].regs = d_regs + (uintptr_t)items[i].regs;
 	CHK(dev_alloc((void**)&d_items, (size_t)m * sizeof(wtz_alnitem_t))); CHK(dev_h2d(d_items, items.data(), (size_t)m * sizeof(wtz_alnitem_t)));
@@ -1011,10 +1098,33 @@ extern "C" int wtz_pairs_align(wtz_ctx_t *c, const uint32_t *pair_idx, const uin
 	const wtz_env_t V = ctx_env(c); wtz_alnres_dev_t *d_res = c->d_alnres;
 	lapw(0);
 	wtz_timer tm; tm.start();
+	bool lane_done = false;
+	if(c->env_lane && !c->env_grp4){
+		/* one lane per K-sw1 problem (wtz_sw_lane.h); what it leaves (d_fb) goes through the chained kernel below */
+		const uint64_t nwt0 = wt.size();
+		uint32_t *d_fb = NULL, n_fb = 0;
+		CHK(dev_alloc((void**)&d_fb, (nwt0 + 1) * 4));
+		STAGE(c, "K-sw1 lane pipeline");
+		CHK(run_winalign_lane(c, V, d_wt, nwt0, d_items, d_fb, &n_fb));
 #ifdef WTZ_EMUL
-	CHK(wtz_launch_coop<K_winalign>(0, wt.size(), [=] WTZ_LAMBDA (uint64_t t){ wtz_task_winalign((uint32_t)t, V, d_wt, d_items); }, WTZ_WINALIGN_LDS_BYTES + WTZ_WINALIGN_QW_BYTES));
+		if(n_fb) CHK(wtz_launch_coop<K_winalign>(0, n_fb, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_winalign((uint32_t)t, V, d_wt, d_items, (uint32_t*)NULL, d_fb); }, WTZ_WINALIGN_LDS_BYTES + WTZ_WINALIGN_QW_BYTES));
 #else
-	{
+		if(n_fb){
+			uint32_t *d_defer = NULL, n_def = 0; CHK(dev_alloc((void**)&d_defer, ((size_t)n_fb + 1) * 4)); CHK(dev_set(d_defer, 0, 4));
+			CHK(wtz_launch_coop<K_winalign>(0, n_fb, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_winalign<false>((uint32_t)t, V, d_wt, d_items, d_defer, d_fb); }, WTZ_WINALIGN_LDS_BYTES + WTZ_WINALIGN_QW_BYTES));
+			CHK(dev_d2h(&n_def, d_defer, 4));
+			if(n_def) CHK(wtz_launch_coop<K_winalign_big>(0, n_def, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_winalign<true>((uint32_t)t, V, d_wt, d_items, NULL, d_defer); }, WTZ_WINALIGN_LDS_BYTES + WTZ_WINALIGN_QW_BYTES));
+			dev_free(d_defer);
+		}
+#endif
+		dev_free(d_fb);
+		lane_done = (c->env_lane != 2);
+		if(c->env_lane == 2){ CHK(dev_sync()); CHK(dev_alloc((void**)&d_regs_chk, (size_t)(nreg + 1) * sizeof(wtz_reg_t))); CHK(dev_d2d(d_regs_chk, d_regs, (size_t)nreg * sizeof(wtz_reg_t))); }
+	}
+#ifdef WTZ_EMUL
+	if(!lane_done) CHK(wtz_launch_coop<K_winalign>(0, wt.size(), [=] WTZ_LAMBDA (uint64_t t){ wtz_task_winalign((uint32_t)t, V, d_wt, d_items); }, WTZ_WINALIGN_LDS_BYTES + WTZ_WINALIGN_QW_BYTES));
+#else
+	if(!lane_done){
 		/* first launch: FOUR windows per wavefront (one per 16-lane group, wtz_sw_grp.h); a window with a problem outside the group form's
 		 * envelope queues itself for the one-window-per-wave kernel: its lean form first (register DP with one / two band columns per lane,
 		 * no scalar body: fewer VGPRs), then - for what that form defers in turn - the full task */
@@ -1039,6 +1149,24 @@ extern "C" int wtz_pairs_align(wtz_ctx_t *c, const uint32_t *pair_idx, const uin
 	}
 #endif
 	CHK(dev_sync());
+	if(d_regs_chk){
+		/* WTZ_WINALIGN_LANE=2: every window was aligned by the lane pipeline AND by the chained kernel: any difference is fatal */
+		unsigned int *d_bad = NULL; CHK(dev_alloc((void**)&d_bad, 16)); CHK(dev_set(d_bad, 0, 16));
+		const wtz_reg_t *ra = d_regs, *rb = d_regs_chk;
+		CHK(wtz_launch<K_misc>(0, nreg, [=] WTZ_LAMBDA (uint64_t i){
+			const wtz_reg_t &a = ra[i], &b = rb[i];
+			bool same = a.x.score == b.x.score && a.x.tb == b.x.tb && a.x.te == b.x.te && a.x.qb == b.x.qb && a.x.qe == b.x.qe && a.x.aln == b.x.aln && a.x.mat == b.x.mat && a.x.mis == b.x.mis && a.x.ins == b.x.ins && a.x.del == b.x.del && a.pass == b.pass && a.cigar_len == b.cigar_len && (a.cells == b.cells || a.cells == 0 || b.cells == 0);      /* the host emulation's scalar body does not count cells */
+			if(same) for(uint32_t k = 0; k < a.cigar_len; k++) if(a.cigar[k] != b.cigar[k]){ same = false; break; }
+			if(!same){ const unsigned int z = WTZ_ATOMIC_INC32(&d_bad[0]); if(z == 0) d_bad[1] = (unsigned int)i; }
+		}));
+		unsigned int hb[4]; CHK(dev_d2h(hb, d_bad, 16)); dev_free(d_bad);
+		if(hb[0]){
+			wtz_reg_t a, b; CHK(dev_d2h(&a, d_regs + hb[1], sizeof a)); CHK(dev_d2h(&b, d_regs_chk + hb[1], sizeof b));
+			return wtz_fail(WTZ_E_STATE, "K-sw1 lane pipeline differs from the chained kernel on %u of %llu windows; first: window slot %u chained/lane score %d/%d tb %d/%d te %d/%d qb %d/%d qe %d/%d aln %d/%d mat %d/%d mis %d/%d ins %d/%d del %d/%d cigar %u/%u pass %u/%u cells %llu/%llu",
+				hb[0], (unsigned long long)nreg, hb[1], a.x.score, b.x.score, a.x.tb, b.x.tb, a.x.te, b.x.te, a.x.qb, b.x.qb, a.x.qe, b.x.qe, a.x.aln, b.x.aln, a.x.mat, b.x.mat, a.x.mis, b.x.mis, a.x.ins, b.x.ins, a.x.del, b.x.del, a.cigar_len, b.cigar_len, a.pass, b.pass, a.cells, b.cells);
+		}
+		dev_free(d_regs_chk);
+	}
 	c->cnt.ms_winalign += tm.stop(); c->cnt.n_winalign += wt.size();
 	lapw(1);
 	tm.start();

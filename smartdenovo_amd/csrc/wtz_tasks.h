@@ -13,6 +13,7 @@
 #include "wtz_sw.h"
 #include "wtz_sw_wave.h"
 #include "wtz_sw_grp.h"
+#include "wtz_sw_lane.h"
 #include "wtz_dotmatrix.h"
 
 typedef struct {
@@ -289,6 +290,170 @@ WTZ_HD void wtz_task_winalign(uint32_t t, const wtz_env_t &V, const wtz_wintask_
 	reg.cigar = cigar.a; reg.cigar_len = cigar.n; reg.cells = cells;
 	reg.pass = !(reg.x.aln * 2 < (int32_t)P->zovl || (float)reg.x.mat < (float)reg.x.aln * P->min_id);
 	if(cigar.bad || tmp.bad || bad) reg.pass = 2;        /* pool exhausted */
+	it.regs[tasks[t].widx] = reg;
+}
+
+/* ---------------- A9 with one lane per K-sw1 problem (wtz_sw_lane.h): planner, DP, fold ---------------- */
+#if defined(__HIP_DEVICE_COMPILE__)
+#define WTZ_ATOMIC_INC32(p) atomicAdd((p), 1u)
+#else
+#define WTZ_ATOMIC_INC32(p) ((*(p))++)
+#endif
+/* window t: number of anchors = number of problem slots */
+WTZ_HD void wtz_task_lcount(uint32_t t, const wtz_wintask_t *tasks, const wtz_alnitem_t *items, uint32_t *na){
+	const wtz_alnitem_t &it = items[tasks[t].item];
+	const wtz_win_t &w = it.win[tasks[t].widx];
+	na[t] = w.anchors[1] - w.anchors[0];
+}
+/* The planner walks the anchors of window t like hzm_aln.h:1255-1300 does, without any DP: the gap before a usable anchor ends ON the anchor
+ * (hzm_aln.h:1273-1284 patch whatever the extension left), and the z-mer run alignment moves the cursor by sums of run lengths.  Slot k of
+ * the window = its k-th anchor: the K-sw1 problem in front of it (qlen < 0: none), the room its run list needs, and the sort key
+ * 0xFFFF - (n_col << 9 | rows) (descending shape order; 0xFFFF = no DP).  wflag = 1: the window has a problem outside the lane envelope
+ * (or whose band depends on init_score: only with -w above 48 + 2 min(qlen, tlen)) and is left to the chained kernel. */
+WTZ_HD void wtz_task_lplan(uint32_t t, const wtz_env_t &V, const wtz_wintask_t *tasks, const wtz_alnitem_t *items, const uint32_t *woff,
+		wtz_lprob_t *prob, uint32_t *runcap, uint64_t *key, uint32_t *val, uint8_t *wflag, uint32_t *ccnt){
+	const wtz_params_t *P = V.P;
+	const wtz_alnitem_t &it = items[tasks[t].item];
+	const wtz_win_t &w = it.win[tasks[t].widx];
+	const wtz_readview pb1 = wtz_view(V.R, it.q, 0), pb2 = wtz_view(V.R, it.c, it.dir);
+	const uint32_t base = woff[t], na = w.anchors[1] - w.anchors[0];
+	const int32_t M = P->M, I = P->O, D = P->O, E = P->E, T = P->T;
+	int32_t te = 0, qe = 0; bool first = true, fb = false, ended = false;
+	for(uint32_t k = 0; k < na; k++){
+		wtz_lprob_t pr; pr.win = t; pr.qoff = pr.toff = 0; pr.qlen = -1; pr.tlen = 0; pr.run_off = 0;
+		uint32_t cap = 0; uint64_t ky = 0xFFFFull;
+		if(!ended){
+			const wtz_zhit_t p = it.anchors[w.anchors[0] + k];
+			const int32_t off1 = (int32_t)ZH_OFF1(p), off2 = (int32_t)ZH_OFF2(p);
+			if(first){ te = off1; qe = off2; first = false; }
+			if(off1 >= te && off2 >= qe){
+				pr.qoff = qe; pr.toff = te; pr.qlen = off2 - qe; pr.tlen = off1 - te;
+				if(pr.qlen > 0 && pr.tlen > 0){
+					int32_t W0 = P->w, W1 = P->w, ql, tl, n_col, ql1, tl1, nc1;
+					wtz_ext_geometry(pr.qlen, pr.tlen, 0, W0, M, I, D, E, T, ql, tl, n_col);
+					wtz_ext_geometry(pr.qlen, pr.tlen, 1 << 24, W1, M, I, D, E, T, ql1, tl1, nc1);
+					if(W0 != W1 || n_col > WTZ_LN_MAXCOLS || ql > WTZ_LN_MAXROWS || ql + tl > WTZ_LN_MAXSPAN) fb = true;
+					else { cap = (uint32_t)(ql + tl + 2); ky = 0xFFFFull - (uint64_t)(((uint32_t)n_col << 9) | (uint32_t)ql); }
+				}
+				int32_t dte = 0, dqe = 0;
+				if(!wtz_zmer_advance(pb1.sub(off1, 1), ZH_LEN1(p), pb2.sub(off2, 1), ZH_LEN2(p), &dte, &dqe)) ended = true;      /* hzm_aln.h:1288-1291: the window ends here */
+				else { te = off1 + dte; qe = off2 + dqe; }
+			}
+		}
+		prob[base + k] = pr; runcap[base + k] = cap; key[base + k] = ky; val[base + k] = base + k;
+	}
+	wflag[t] = fb ? 1 : 0;
+	for(uint32_t k = 0; k < na; k++){
+		if(fb){ key[base + k] = 0xFFFFull; runcap[base + k] = 0; }
+		else if(key[base + k] != 0xFFFFull) WTZ_ATOMIC_INC32(&ccnt[wtz_lane_class((int32_t)((0xFFFFu - (uint32_t)key[base + k]) >> 9))]);
+	}
+}
+
+/* one wavefront = WTZ_NLANES problems of the shape-sorted order[lo, hi): relative-mode K-sw1 + traceback, results into the problems' slots */
+template<int NC>
+WTZ_HD void wtz_task_ldp(uint32_t wv, const wtz_env_t &V, const wtz_wintask_t *tasks, const wtz_alnitem_t *items, const uint32_t *order, uint32_t lo, uint32_t hi,
+		const wtz_lprob_t *prob, const uint32_t *runoff, uint32_t *runs, wtz_lres_t *res){
+	const wtz_params_t *P = V.P;
+	const uint32_t idx = lo + wv * WTZ_NLANES + WTZ_LANE;
+	const bool live = idx < hi;
+	const uint32_t slot = live ? order[idx] : 0u;
+	wtz_lprob_t pr; pr.win = 0; pr.qoff = pr.toff = 0; pr.qlen = pr.tlen = 0; pr.run_off = 0;
+	if(live) pr = prob[slot];
+	const int32_t M = P->M, X = P->X, I = P->O, D = P->O, E = P->E, T = P->T;
+	int32_t W = P->w, ql = 0, tl = 0, n_col = 0;
+	wtz_seq_packed q, tt; q.bits = tt.bits = V.R.bits; q.start = tt.start = 0; q.strand = tt.strand = 1; q.comp = tt.comp = 0;
+	if(live){
+		wtz_ext_geometry(pr.qlen, pr.tlen, 0, W, M, I, D, E, T, ql, tl, n_col);
+		const wtz_alnitem_t &it = items[tasks[pr.win].item];
+		q = wtz_view(V.R, it.c, it.dir).sub(pr.qoff, 1); tt = wtz_view(V.R, it.q, 0).sub(pr.toff, 1);
+	}
+	constexpr uint32_t RS = (uint32_t)wtz_lane_geo<NC>::RS;
+	const uint32_t rows_max = (uint32_t)wtz_lane_wmax(ql);
+	uint64_t pa = 0;
+	if(WTZ_LANE == 0) pa = (uint64_t)(uintptr_t)wtz_pool_alloc(V.pool + 1, (size_t)WTZ_NLANES * rows_max * RS * 4 + 16);      /* the wave's trace rows: transient pool */
+	pa = wtz_coop_bcast64(pa);
+	if(pa == 0) return;                       /* the slots stay "not done": the fold reports the pool */
+	uint32_t *tr = (uint32_t*)(uintptr_t)pa + (size_t)WTZ_LANE * rows_max * RS;
+	wtz_lres_t R; memset(&R, 0, sizeof R);
+	wtz_lane_fixed<NC, false>(live, pr.qlen, q, pr.tlen, tt, 0, W, ql, tl, M, X, I, D, E, T, tr, runs + (live ? runoff[slot] : 0u), R);
+	if(live) res[slot] = R;
+}
+
+/* lane-private CIGAR vector with the open run in a register */
+typedef struct { wtz_cigar_t v; uint32_t tail; } wtz_lcig_t;
+WTZ_HD void wtz_lcig_push(wtz_lcig_t &w, uint32_t op, uint32_t len){
+	if(len == 0) return;
+	if(w.tail && (w.tail & 0xFu) == op) w.tail += len << 4;
+	else { if(w.tail) w.v.push(w.tail); w.tail = (len << 4) | op; }
+}
+/* hzm_aln.h:278-314 pushing into the lane writer; aln == 0: the pair does not align (the caller rolls the writer back) */
+template<typename S1, typename S2>
+WTZ_HD wtz_aln_t wtz_align_zmer_lane(const S1 &pb1, uint32_t len1, const S2 &pb2, uint32_t len2, int32_t M, int32_t I, int32_t D, int32_t E, wtz_lcig_t &cw){
+	wtz_aln_t x, zero; memset(&zero, 0, sizeof zero); x = zero;
+	uint32_t s0 = 0, s1 = 0;
+	while(s0 < len1 || s1 < len2){
+		const uint32_t b = pb1.at((int32_t)s0);
+		if(b != pb2.at((int32_t)s1)) return zero;
+		uint32_t e0 = s0 + 1; while(e0 < len1 && pb1.at((int32_t)e0) == b) e0++;
+		uint32_t e1 = s1 + 1; while(e1 < len2 && pb2.at((int32_t)e1) == b) e1++;
+		const uint32_t l0 = e0 - s0, l1 = e1 - s1;
+		if(l0 < l1){ x.aln += l1; x.mat += l0; x.ins += l1 - l0; x.score += (int32_t)l0 * M + I + (int32_t)(l1 - l0) * E; wtz_lcig_push(cw, 0, l0); wtz_lcig_push(cw, 1, l1 - l0); }
+		else if(l0 == l1){ x.aln += l0; x.mat += l0; x.score += (int32_t)l0 * M; wtz_lcig_push(cw, 0, l0); }
+		else { x.aln += l0; x.mat += l1; x.del += l0 - l1; x.score += (int32_t)l1 * M + D + (int32_t)(l0 - l1) * E; wtz_lcig_push(cw, 0, l1); wtz_lcig_push(cw, 2, l0 - l1); }
+		s0 = e0; s1 = e1;
+	}
+	x.te = x.mat + x.del; x.qe = x.mat + x.ins;
+	return x;
+}
+
+/* The fold chains window t (hzm_aln.h:1255-1300) over the results of its problems: init_score of a problem = the score so far, its
+ * relative result is shifted by it - provided none of the absolute tests of kswx_extend_align_core would have fired (see wtz_sw_lane.h):
+ * a + minrow > 0 (no row maximum <= 0: kswx.h:280,302) and, when the end candidate was taken, a + score > 0 (kswx.h:304).  A window that
+ * fails is appended to fblist ([0] = count) for the chained kernel; nothing of it has been published. */
+WTZ_HD void wtz_task_lfold(uint32_t t, const wtz_env_t &V, const wtz_wintask_t *tasks, const wtz_alnitem_t *items, const uint32_t *woff,
+		const wtz_lprob_t *prob, const uint32_t *runoff, const uint32_t *runs, const wtz_lres_t *res, const uint8_t *wflag, uint32_t *fblist){
+	if(wflag[t]){ const uint32_t k = WTZ_ATOMIC_INC32(&fblist[0]); fblist[1 + k] = t; return; }
+	const wtz_params_t *P = V.P;
+	const wtz_alnitem_t &it = items[tasks[t].item];
+	const wtz_win_t &w = it.win[tasks[t].widx];
+	const wtz_readview pb1 = wtz_view(V.R, it.q, 0), pb2 = wtz_view(V.R, it.c, it.dir);
+	const uint32_t base = woff[t], na = w.anchors[1] - w.anchors[0];
+	const int32_t M = P->M, I = P->O, D = P->O, E = P->E;
+	wtz_reg_t reg; memset(&reg, 0, sizeof reg);
+	wtz_lcig_t cw; cw.v.init(V.pool, na * 14u + 16u); cw.tail = 0;
+	wtz_aln_t x; memset(&x, 0, sizeof x);
+	unsigned long long cells = 0; int32_t bad = 0;
+	for(uint32_t k = 0; k < na; k++){
+		const wtz_lprob_t pr = prob[base + k];
+		if(pr.qlen < 0) continue;
+		const wtz_zhit_t p = it.anchors[w.anchors[0] + k];
+		const int32_t off1 = (int32_t)ZH_OFF1(p), off2 = (int32_t)ZH_OFF2(p);
+		if(x.aln == 0){ x.tb = x.te = off1; x.qb = x.qe = off2; }
+		const int32_t a = x.score < 0 ? 0 : x.score;                 /* kswx.h:241 */
+		if(pr.qlen > 0 && pr.tlen > 0){
+			const wtz_lres_t r = res[base + k];
+			if(!(r.flags & WTZ_LR_DONE)){ bad = 1; break; }
+			if(a + r.minrow <= 0 || ((r.flags & WTZ_LR_USEDG) && a + r.score <= 0)){ const uint32_t z = WTZ_ATOMIC_INC32(&fblist[0]); fblist[1 + z] = t; return; }
+			x.score = a + r.score;
+			x.aln += r.mat + r.mis + r.ins + r.del; x.mat += r.mat; x.mis += r.mis; x.ins += r.ins; x.del += r.del;
+			x.te += r.te - 0; x.qe += r.qe - 0;
+			const uint32_t *rr = runs + runoff[base + k];
+			for(uint32_t j = r.n_runs; j-- > 0;){ const uint32_t v = rr[j]; wtz_lcig_push(cw, v & 0xFu, v >> 4); }
+			cells += r.cells;
+		} else x.score = a;                                          /* kswx.h:242: an empty side returns init_score */
+		if(x.te < off1){ x.del += off1 - x.te; x.aln += off1 - x.te; wtz_lcig_push(cw, 2, (uint32_t)(off1 - x.te)); x.te = off1; }
+		if(x.qe < off2){ x.ins += off2 - x.qe; x.aln += off2 - x.qe; wtz_lcig_push(cw, 1, (uint32_t)(off2 - x.qe)); x.qe = off2; }
+		const uint32_t keep_tail = cw.tail, keep_n = cw.v.n;
+		const wtz_aln_t y = wtz_align_zmer_lane(pb1.sub(off1, 1), ZH_LEN1(p), pb2.sub(off2, 1), ZH_LEN2(p), M, I, D, E, cw);
+		if(y.aln == 0){ cw.tail = keep_tail; cw.v.n = keep_n; break; }
+		x.score += y.score;
+		x.aln += y.aln; x.mat += y.mat; x.mis += y.mis; x.ins += y.ins; x.del += y.del;
+		x.te += y.te; x.qe += y.qe;
+	}
+	if(cw.tail){ cw.v.push(cw.tail); cw.tail = 0; }
+	reg.x = x; reg.cigar = cw.v.a; reg.cigar_len = cw.v.n; reg.cells = cells;
+	reg.pass = !(reg.x.aln * 2 < (int32_t)P->zovl || (float)reg.x.mat < (float)reg.x.aln * P->min_id);
+	if(cw.v.bad || bad) reg.pass = 2;
 	it.regs[tasks[t].widx] = reg;
 }
 

@@ -11,6 +11,7 @@
 struct K_test_fixed;
 struct K_test_global;
 struct K_test_global_wide;
+struct K_test_lane;
 
 typedef struct { wtz_seq_packed q, t; int32_t qlen, tlen, init_score, W; } wtz_dpprob_dev_t;
 typedef struct { wtz_aln_t x; uint32_t *cigar; uint32_t cigar_len; int32_t form, bad; unsigned long long cells; } wtz_dpres_dev_t;
@@ -43,6 +44,36 @@ static __device__ void wtz_task_test_fixed(uint32_t t, const wtz_dpprob_dev_t *p
 	if(R.form < 0){ wtz_dpres_dev_t r; memset(&r, 0, sizeof r); r.form = 0; res[t] = r; return; }
 	/* an empty problem is answered in place by every form (score = init, empty CIGAR): report it under the requested name */
 	wtz_testdp_store(&res[t], R.y, R.lds_runs, R.runs, R.n_runs, tmp, pool, R.form ? R.form : (force ? force : 1), !R.ok, cells);
+}
+
+/* form 64: the lane-per-problem K-sw1 (wtz_sw_lane.h) in ABSOLUTE mode - the reference's function for a known init_score; lane 0 of the wave
+ * carries the problem, the other lanes are idle (the product packs 64 problems of one shape class into a wave and runs the relative mode) */
+static __device__ void wtz_task_test_lane(uint32_t t, const wtz_dpprob_dev_t *pr, const wtz_params_t *P, wtz_pool_t *pool, wtz_dpres_dev_t *res){
+	const wtz_dpprob_dev_t p = pr[t];
+	const int32_t M = P->M, X = P->X, I = P->O, D = P->O, E = P->E, T = P->T;
+	const int32_t init = p.init_score < 0 ? 0 : p.init_score;
+	wtz_dpres_dev_t r; memset(&r, 0, sizeof r);
+	if(p.qlen <= 0 || p.tlen <= 0){ r.x.score = init; r.form = 64; if(WTZ_LANE == 0) res[t] = r; return; }
+	int32_t W = P->w, ql, tl, n_col;
+	wtz_ext_geometry(p.qlen, p.tlen, init, W, M, I, D, E, T, ql, tl, n_col);
+	if(n_col > WTZ_LN_MAXCOLS || ql > WTZ_LN_MAXROWS || ql + tl > WTZ_LN_MAXSPAN || init > (1 << 20)){ if(WTZ_LANE == 0) res[t] = r; return; }      /* outside the envelope: declined */
+	const uint32_t RS = wtz_lane_rs(n_col);
+	unsigned long long pa = 0;
+	if(WTZ_LANE == 0) pa = (unsigned long long)(uintptr_t)wtz_pool_alloc(pool, (size_t)ql * RS * 4 + (size_t)(ql + tl + 4) * 4 + 32);
+	pa = __shfl(pa, 0, 64);
+	if(pa == 0){ r.bad = 1; r.form = 64; if(WTZ_LANE == 0) res[t] = r; return; }
+	uint32_t *tr = (uint32_t*)(uintptr_t)pa, *runs = tr + (size_t)ql * RS + 4;
+	const bool live = WTZ_LANE == 0;
+	wtz_lres_t R; memset(&R, 0, sizeof R);
+	if(n_col <= 16)      wtz_lane_fixed<16, true>(live, p.qlen, p.q, p.tlen, p.t, init, W, ql, tl, M, X, I, D, E, T, tr, runs, R);
+	else if(n_col <= 32) wtz_lane_fixed<32, true>(live, p.qlen, p.q, p.tlen, p.t, init, W, ql, tl, M, X, I, D, E, T, tr, runs, R);
+	else if(n_col <= 64) wtz_lane_fixed<64, true>(live, p.qlen, p.q, p.tlen, p.t, init, W, ql, tl, M, X, I, D, E, T, tr, runs, R);
+	else                 wtz_lane_fixed<104, true>(live, p.qlen, p.q, p.tlen, p.t, init, W, ql, tl, M, X, I, D, E, T, tr, runs, R);
+	if(!live) return;
+	wtz_aln_t x; memset(&x, 0, sizeof x);
+	x.score = R.score; x.qe = R.qe; x.te = R.te; x.mat = R.mat; x.mis = R.mis; x.ins = R.ins; x.del = R.del; x.aln = R.mat + R.mis + R.ins + R.del;
+	wtz_cigar_t none; none.a = NULL; none.n = none.cap = 0; none.pool = pool; none.bad = 0;
+	wtz_testdp_store(&res[t], x, true, runs, R.n_runs, none, pool, 64, 0, R.cells);
 }
 
 static __device__ void wtz_task_test_global(uint32_t t, const wtz_dpprob_dev_t *pr, const wtz_params_t *P, wtz_pool_t *pool, int force, uint32_t wide_lds, wtz_dpres_dev_t *res){
@@ -130,7 +161,9 @@ extern "C" int wtz_test_dp(wtz_ctx_t *c, int32_t kind, int32_t form, const wtz_d
 		CHK(dev_alloc((void**)&d_pr, (size_t)n * sizeof(wtz_dpprob_dev_t))); CHK(dev_h2d(d_pr, hp.data(), (size_t)n * sizeof(wtz_dpprob_dev_t)));
 		CHK(dev_alloc((void**)&d_res, (size_t)n * sizeof(wtz_dpres_dev_t))); CHK(dev_set(d_res, 0, (size_t)n * sizeof(wtz_dpres_dev_t)));
 		const wtz_params_t *dP = c->dP; wtz_pool_t *pool = c->dpool;
-		if(kind == WTZ_DP_FIXED){
+		if(kind == WTZ_DP_FIXED && form == 64){
+			CHK(wtz_launch_coop<K_test_lane>(0, n, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_test_lane((uint32_t)t, d_pr, dP, pool, d_res); }, 0));
+		} else if(kind == WTZ_DP_FIXED){
 			CHK(wtz_launch_coop<K_test_fixed>(0, n, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_test_fixed((uint32_t)t, d_pr, dP, pool, form, d_res); }, WTZ_WINALIGN_LDS_BYTES + WTZ_WINALIGN_QW_BYTES));
 		} else if(form == 33){
 			CHK(wtz_launch_coop<K_test_global_wide>(0, n, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_test_global((uint32_t)t, d_pr, dP, pool, form, (uint32_t)WTZ_GAP_WIDE_LDS_BYTES, d_res); }, WTZ_GAP_WIDE_LDS_BYTES));

@@ -96,7 +96,7 @@ def test_fixed_extension_forms(w, vec):
     ctx = make_ctx(vec, w=w)
     total = {}
     try:
-        for form in (0, 1, 2, 17, 18, 20, 24, 255):
+        for form in (0, 1, 2, 17, 18, 20, 24, 64, 255):
             out, cigs = ctx.test_dp(hipabi.DP_FIXED, form, problems(vec, idx))
             ans = check(vec, idx, out, cigs, 1, form, _fixed_must(form, w))
             total[form] = sum(a for a, _ in ans.values())
@@ -108,6 +108,8 @@ def test_fixed_extension_forms(w, vec):
     assert total[0] == len(idx) and total[255] == len(idx)
     if w == 50:     # the path's default band: 1 / 2 columns per lane in LDS, the long problems in the pool, rows > 2048 and the key overflow scalar
         assert {1, 2, 18, 255} <= total["auto_forms"] and total[1] > 0 and total[2] > 0 and total[17] > 0 and total[18] > 0
+    if w in (50, 20, 5):      # form 64 = one lane per problem (wtz_sw_lane.h, absolute mode): everything with a band of <= 104 columns and <= 511 rows
+        assert total[64] > 0.5 * len(idx), "the lane form answered only %d of %d problems" % (total[64], len(idx))
     if w == 100:
         assert total[20] > 0 and 20 in total["auto_forms"]
     if w == 200:
