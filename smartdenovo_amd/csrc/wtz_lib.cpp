@@ -59,11 +59,13 @@ struct K_gap_wide;
 struct K_kcount;
 struct K_lcount;
 struct K_lplan;
-struct K_ldp16;
-struct K_ldp32;
-struct K_ldp64;
-struct K_ldp104;
+struct K_ldp;
+struct K_ltb;
 struct K_lfold;
+struct K_gplan;
+struct K_gdp;
+struct K_gtb;
+struct K_glist;
 struct K_poolalloc;
 struct K_kfill;
 struct K_kinsert;
@@ -143,10 +145,11 @@ template<> struct wtz_occ<K_winalign> { static constexpr int waves = WTZ_OCC_WIN
 template<> struct wtz_occ<K_pair> { static constexpr int waves = WTZ_OCC_PAIR; };
 template<> struct wtz_occ<K_gap> { static constexpr int waves = WTZ_OCC_GAP; };
 /* lane-per-problem K-sw1 (wtz_sw_lane.h): the band lives in 2 x (NC + 1) VGPRs */
-template<> struct wtz_occ<K_ldp16> { static constexpr int waves = 4; };
-template<> struct wtz_occ<K_ldp32> { static constexpr int waves = 4; };
-template<> struct wtz_occ<K_ldp64> { static constexpr int waves = 2; };
-template<> struct wtz_occ<K_ldp104> { static constexpr int waves = 2; };
+template<> struct wtz_occ<K_ldp> { static constexpr int waves = 2; };
+template<> struct wtz_occ<K_gdp> { static constexpr int waves = 2; };
+/* their tracebacks: chains of dependent loads, nothing to keep in registers */
+template<> struct wtz_occ<K_ltb> { static constexpr int waves = 8; };
+template<> struct wtz_occ<K_gtb> { static constexpr int waves = 8; };
 template<typename TAG, typename F> __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(wtz_occ<TAG>::waves, 8))) wtz_kernel_coop_tasks(uint64_t n, F f){
 	const uint64_t i = blockIdx.x;
 	WTZ_PROF_BEGIN();
@@ -321,6 +324,7 @@ struct wtz_ctx {
 	wtz_counters_t cnt;
 	uint64_t tpool_peak_call = 0, main_used_call = 0;      /* transient-pool high-water mark / main-pool bytes of the API call in progress */
 	int env_cand_stream = 0;     /* WTZ_CAND_STREAM=1: sort-free candidate accumulation (LDS sketch + survivor table, wtz_seed.h); bit-exact, pays at 25x coverage only: see DESIGN.md */
+	int env_gap_lane = 1;        /* WTZ_GAP_LANE=0: every gap on a wavefront (the form before round 3) */
 	int env_lane = 1;            /* WTZ_WINALIGN_LANE=0: the chained wave-per-window kernel for every window (the form before round 3); 2: run both and compare */
 	int env_grp4 = 0;            /* WTZ_WINALIGN4=1: four windows per wavefront first (wtz_sw_grp.h; bit-exact, measured 2x SLOWER than one window per wave: see DESIGN.md) */
 	bool env_trace = false;      /* WTZ_STAGE_TRACE: name every device stage on stderr before it is launched (locating a device fault) */
@@ -438,6 +442,7 @@ extern "C" int wtz_ctx_create(int device, const wtz_params_c *params, uint64_t p
 	c->env_cand_stream = (getenv("WTZ_CAND_STREAM") && atoi(getenv("WTZ_CAND_STREAM")) != 0);
 	c->env_grp4 = (getenv("WTZ_WINALIGN4") && atoi(getenv("WTZ_WINALIGN4")) != 0);
 	if(getenv("WTZ_WINALIGN_LANE")) c->env_lane = atoi(getenv("WTZ_WINALIGN_LANE"));
+	if(getenv("WTZ_GAP_LANE")) c->env_gap_lane = atoi(getenv("WTZ_GAP_LANE"));
 	c->env_fail_once = getenv("WTZ_POOL_FAIL_ONCE") != NULL;
 	c->env_fail_at = getenv("WTZ_POOL_FAIL_AT") ? (unsigned)atoi(getenv("WTZ_POOL_FAIL_AT")) : 0u;
 	c->env_tfail_at = getenv("WTZ_TPOOL_FAIL_AT") ? (unsigned)atoi(getenv("WTZ_TPOOL_FAIL_AT")) : 0u;
@@ -550,7 +555,10 @@ extern "C" int wtz_index_build(wtz_ctx_t *c, uint32_t id_beg, uint32_t id_end, u
 	const uint32_t nr = id_end - id_beg;
 	CTX_ENTER(c);
 	if(c->shares_indexes) return wtz_fail(WTZ_E_STATE, "wtz_index_build on a cloned context");
+	const bool prof_ix = c->env_profile; double tix[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tix0 = wtz_wall();
+	auto lapix = [&](int k){ if(prof_ix){ (void)dev_sync(); const double t = wtz_wall(); tix[k] += t - tix0; tix0 = t; } };
 	free_kindex(c);
+	lapix(0);
 	wtz_timer tm; tm.start();
 	const wtz_reads_t R = ctx_reads(c); const uint32_t ksize = c->P.ksize, hk = c->P.hk, ksave = c->P.ksave;
 	/* the walk of a read is a serial recurrence, but it restarts exactly anywhere (wtz_walk_warm_start): one lane per
@@ -561,19 +569,24 @@ extern "C" int wtz_index_build(wtz_ctx_t *c, uint32_t id_beg, uint32_t id_end, u
 	uint32_t *d_prid = NULL, *d_pjb = NULL;
 	CHK(dev_alloc((void**)&d_prid, (np + 1) * 4)); CHK(dev_alloc((void**)&d_pjb, (np + 1) * 4));
 	CHK(dev_h2d(d_prid, p_rid.data(), np * 4)); CHK(dev_h2d(d_pjb, p_jb.data(), np * 4));
+	lapix(1);
 	uint64_t *d_cnt = NULL; CHK(dev_alloc((void**)&d_cnt, (np + 1) * 8));
 	CHK(wtz_launch<K_kcount>(0, np, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_kcount((uint32_t)t, R, d_prid, d_pjb, ksize, hk, ksave, d_cnt); }));
 	std::vector<uint64_t> h_cnt(np + 1);
 	CHK(dev_d2h(h_cnt.data(), d_cnt, np * 8));
 	uint64_t tot = 0; for(size_t i = 0; i < np; i++){ uint64_t v = h_cnt[i]; h_cnt[i] = tot; tot += v; } h_cnt[np] = tot;
 	CHK(dev_h2d(d_cnt, h_cnt.data(), (np + 1) * 8));
+	lapix(2);
 	uint64_t *d_keys = NULL; uint32_t *d_vals = NULL;
 	CHK(dev_alloc((void**)&d_keys, (tot + 1) * 8)); CHK(dev_alloc_persist((void**)&d_vals, (tot + 1) * 4));
+	lapix(3);
 	CHK(wtz_launch<K_kfill>(0, np, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_kfill((uint32_t)t, R, d_prid, d_pjb, ksize, hk, ksave, d_cnt, d_keys, d_vals); }));
 	CHK(dev_sync());
 	dev_free(d_cnt); dev_free(d_prid); dev_free(d_pjb);
 	(void)nr;
+	lapix(4);
 	CHK(dev_sort_pairs_u64_u32(d_keys, d_vals, tot, 2 * ksize));
+	lapix(5);
 	unsigned long long *d_stat = NULL; CHK(dev_alloc((void**)&d_stat, 4 * 8)); CHK(dev_set(d_stat, 0, 4 * 8));
 	CHK(wtz_launch<K_kstats>(0, tot, [=] WTZ_LAMBDA (uint64_t i){ wtz_task_kstats(i, d_keys, tot, d_stat + 0, d_stat + 1); }));
 	unsigned long long h_stat[4]; CHK(dev_d2h(h_stat, d_stat, 4 * 8));
@@ -595,6 +608,8 @@ extern "C" int wtz_index_build(wtz_ctx_t *c, uint32_t id_beg, uint32_t id_end, u
 	c->idx_beg = id_beg; c->idx_end = id_end; c->idx_len_sorted = true;
 	for(uint32_t r = id_beg; r + 1 < id_end; r++) if(c->h_rdlen[r] < c->h_rdlen[r + 1]){ c->idx_len_sorted = false; break; }
 	c->cnt.ms_index += tm.stop();
+	lapix(6);
+	if(prof_ix) fprintf(stderr, "[index-profile] ms: free %.1f pieces+h2d %.1f count %.1f alloc %.1f fill %.1f sort %.1f table %.1f\n", tix[0] * 1e3, tix[1] * 1e3, tix[2] * 1e3, tix[3] * 1e3, tix[4] * 1e3, tix[5] * 1e3, tix[6] * 1e3);
 	if(stats){
 		stats->n_occ = tot; stats->n_distinct = ktyp; stats->ktot = ktot; stats->n_kept = n_kept; stats->max_kmer_freq = K;
 		uint64_t tl = 0; for(uint32_t i = 0; i < c->n_reads; i++) tl += c->h_rdlen[i];
@@ -1023,50 +1038,93 @@ static int pool_alloc_host(wtz_ctx *c, int which, size_t bytes, void **out){
 static int run_winalign_lane(wtz_ctx *c, const wtz_env_t &V, const wtz_wintask_t *d_wt, uint64_t nwt, const wtz_alnitem_t *d_items, uint32_t *d_fb, uint32_t *n_fb){
 	*n_fb = 0;
 	if(nwt == 0) return WTZ_OK;
+	const bool prof = c->env_profile; double tp[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tp0 = 0;
+	if(prof){ (void)dev_sync(); tp0 = wtz_wall(); }
+	auto lap = [&](int k){ if(prof){ (void)dev_sync(); const double t = wtz_wall(); tp[k] += t - tp0; tp0 = t; } };
 	uint32_t *d_na = NULL, *d_woff = NULL;
 	CHK(dev_alloc((void**)&d_na, (nwt + 1) * 4)); CHK(dev_alloc((void**)&d_woff, (nwt + 1) * 4));
 	CHK(dev_set(d_na, 0, (nwt + 1) * 4));
 	CHK(wtz_launch<K_lcount>(0, nwt, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_lcount((uint32_t)t, d_wt, d_items, d_na); }));
 	CHK(dev_exclusive_scan_u32(d_na, d_woff, nwt + 1));
 	uint32_t NS = 0; CHK(dev_d2h(&NS, d_woff + nwt, 4));
-	wtz_lprob_t *d_prob = NULL; uint32_t *d_cap = NULL, *d_roff = NULL, *d_val = NULL, *d_ccnt = NULL; uint64_t *d_key = NULL; uint8_t *d_flag = NULL; wtz_lres_t *d_res = NULL;
+	lap(0);
+	wtz_lprob_t *d_prob = NULL; uint32_t *d_cap = NULL, *d_roff = NULL, *d_val = NULL, *d_ccnt = NULL, *d_uidx = NULL, *d_nu = NULL; uint64_t *d_key = NULL; uint8_t *d_flag = NULL; wtz_lres_t *d_res = NULL;
 	{   /* per-slot arrays: one block of the main pool */
 		const size_t nsp = (size_t)NS + 64;
 		const size_t b_prob = (nsp * sizeof(wtz_lprob_t) + 255) & ~(size_t)255, b_res = (nsp * sizeof(wtz_lres_t) + 255) & ~(size_t)255, b_u32 = (nsp * 4 + 255) & ~(size_t)255, b_u64 = (nsp * 8 + 255) & ~(size_t)255;
-		uint8_t *blk = NULL; CHK(pool_alloc_host(c, 0, b_prob + b_res + 3 * b_u32 + b_u64, (void**)&blk));
-		d_prob = (wtz_lprob_t*)blk; blk += b_prob; d_res = (wtz_lres_t*)blk; blk += b_res; d_cap = (uint32_t*)blk; blk += b_u32; d_roff = (uint32_t*)blk; blk += b_u32; d_val = (uint32_t*)blk; blk += b_u32; d_key = (uint64_t*)blk;
+		uint8_t *blk = NULL; CHK(pool_alloc_host(c, 0, b_prob + b_res + 4 * b_u32 + b_u64, (void**)&blk));
+		d_prob = (wtz_lprob_t*)blk; blk += b_prob; d_res = (wtz_lres_t*)blk; blk += b_res; d_cap = (uint32_t*)blk; blk += b_u32; d_roff = (uint32_t*)blk; blk += b_u32; d_val = (uint32_t*)blk; blk += b_u32; d_uidx = (uint32_t*)blk; blk += b_u32; d_key = (uint64_t*)blk;
 	}
-	CHK(dev_alloc((void**)&d_flag, nwt + 16)); CHK(dev_alloc((void**)&d_ccnt, 32)); CHK(dev_set(d_ccnt, 0, 32));
+	CHK(dev_alloc((void**)&d_flag, nwt + 16)); CHK(dev_alloc((void**)&d_nu, (nwt + 1) * 4)); CHK(dev_alloc((void**)&d_ccnt, 32)); CHK(dev_set(d_ccnt, 0, 32));
 	CHK(dev_set(d_cap, 0, ((size_t)NS + 1) * 4));
 	CHK(dev_set(d_res, 0, ((size_t)NS + 1) * sizeof(wtz_lres_t)));
-	CHK(wtz_launch<K_lplan>(0, nwt, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_lplan((uint32_t)t, V, d_wt, d_items, d_woff, d_prob, d_cap, d_key, d_val, d_flag, d_ccnt); }));
+	CHK(wtz_launch<K_lplan>(0, nwt, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_lplan((uint32_t)t, V, d_wt, d_items, d_woff, d_prob, d_cap, d_key, d_val, d_flag, d_ccnt, d_uidx, d_nu); }));
+	lap(1);
 	CHK(dev_exclusive_scan_u32(d_cap, d_roff, (uint64_t)NS + 1));
 	uint32_t NR = 0, ccnt[4] = {0, 0, 0, 0};
 	CHK(dev_d2h(&NR, d_roff + NS, 4)); CHK(dev_d2h(ccnt, d_ccnt, 16));
 	uint32_t *d_runs = NULL; CHK(pool_alloc_host(c, 0, ((size_t)NR + 16) * 4, (void**)&d_runs));
-	CHK(dev_sort_pairs_u64_u32(d_key, d_val, NS, 16));                 /* ascending inverted key = widest band first, longest first inside a width */
+	lap(2);
+	CHK(dev_sort_pairs_u64_u32(d_key, d_val, NS, 16));
+	lap(3);                 /* ascending inverted key = widest band first, longest first inside a width */
 	CHK(dev_set(d_fb, 0, 4));
 	{
 		const uint32_t *d_ord = d_val; const wtz_lprob_t *pp = d_prob; const uint32_t *ro = d_roff; uint32_t *rn = d_runs; wtz_lres_t *rs = d_res;
-		uint32_t lo = 0;
-		for(int cls = 3; cls >= 0; cls--){
-			const uint32_t n = ccnt[cls], hi = lo + n;
-			if(n){
-				const uint64_t nw = ((uint64_t)n + WTZ_HOST_WAVE - 1) / WTZ_HOST_WAVE;
-				const uint32_t lo_ = lo;
-				if(cls == 3)      CHK(wtz_launch_coop<K_ldp104>(0, nw, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_ldp<104>((uint32_t)t, V, d_wt, d_items, d_ord, lo_, hi, pp, ro, rn, rs); }, 0));
-				else if(cls == 2) CHK(wtz_launch_coop<K_ldp64>(0, nw, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_ldp<64>((uint32_t)t, V, d_wt, d_items, d_ord, lo_, hi, pp, ro, rn, rs); }, 0));
-				else if(cls == 1) CHK(wtz_launch_coop<K_ldp32>(0, nw, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_ldp<32>((uint32_t)t, V, d_wt, d_items, d_ord, lo_, hi, pp, ro, rn, rs); }, 0));
-				else              CHK(wtz_launch_coop<K_ldp16>(0, nw, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_ldp<16>((uint32_t)t, V, d_wt, d_items, d_ord, lo_, hi, pp, ro, rn, rs); }, 0));
-			}
-			lo = hi;
-		}
-		CHK(wtz_launch<K_lfold>(0, nwt, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_lfold((uint32_t)t, V, d_wt, d_items, d_woff, pp, ro, rn, rs, d_flag, d_fb); }));
+		wtz_lclass_t L; uint32_t lo = 0, wv = 0;
+		for(int k = 0; k < 4; k++){ const uint32_t n = ccnt[3 - k]; L.lo[k] = lo; L.hi[k] = lo + n; wv += (n + WTZ_HOST_WAVE - 1) / WTZ_HOST_WAVE; L.wend[k] = wv; lo += n; }
+		uint64_t *d_wtr = NULL; uint32_t *d_wrm = NULL;
+		CHK(dev_alloc((void**)&d_wtr, ((size_t)wv + 1) * 8)); CHK(dev_alloc((void**)&d_wrm, ((size_t)wv + 1) * 4)); CHK(dev_set(d_wtr, 0, ((size_t)wv + 1) * 8));
+		if(wv) CHK(wtz_launch_coop<K_ldp>(0, wv, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_ldp_all((uint32_t)t, L, V, d_wt, d_items, d_ord, pp, rs, d_wtr, d_wrm); }, 0));
+		lap(4);
+		if(wv) CHK(wtz_launch_coop<K_ltb>(0, wv, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_ltb_all((uint32_t)t, L, V, d_wt, d_items, d_ord, pp, ro, rn, rs, d_wtr, d_wrm); }, 0));
+		lap(6);
+		CHK(wtz_launch<K_lfold>(0, nwt, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_lfold((uint32_t)t, V, d_wt, d_items, d_woff, pp, ro, rn, rs, d_flag, d_fb, d_uidx, d_nu); }));
 	}
 	CHK(dev_d2h(n_fb, d_fb, 4));
-	if(c->env_profile) fprintf(stderr, "[lane-profile] %llu windows, %u anchor slots, K-sw1 problems by band class <=16 / <=32 / <=64 / <=104: %u / %u / %u / %u, %u run entries, %u windows left to the chained kernel\n",
-		(unsigned long long)nwt, NS, ccnt[0], ccnt[1], ccnt[2], ccnt[3], NR, *n_fb);
+	lap(5);
+	if(c->env_profile) fprintf(stderr, "[lane-profile] %llu windows, %u anchor slots, K-sw1 problems by band class <=16 / <=32 / <=64 / <=104: %u / %u / %u / %u, %u run entries, %u windows left to the chained kernel; ms: count+scan %.2f plan %.2f scan+alloc %.2f sort %.2f dp %.2f traceback %.2f fold %.2f\n",
+		(unsigned long long)nwt, NS, ccnt[0], ccnt[1], ccnt[2], ccnt[3], NR, *n_fb, tp[0] * 1e3, tp[1] * 1e3, tp[2] * 1e3, tp[3] * 1e3, tp[4] * 1e3, tp[6] * 1e3, tp[5] * 1e3);
 	dev_free(d_na); dev_free(d_woff); dev_free(d_flag); dev_free(d_ccnt);
+	return WTZ_OK;
+}
+
+
+/* K-sw2 gaps of the window slots d_wt[0, nwt) with one lane per gap (wtz_lane_global); d_list ([0] = count, room for nwt + 1) = the slots
+ * the wavefront kernel still has to do (empty sides, bands beyond 104 columns, gaps whose band has to be doubled again) */
+static int run_gap_lane(wtz_ctx *c, const wtz_env_t &V, const wtz_wintask_t *d_wt, uint64_t nwt, const wtz_alnitem_t *d_items, wtz_gapres_t *d_gaps, uint32_t *d_list, uint32_t *n_list){
+	*n_list = 0;
+	if(nwt == 0) return WTZ_OK;
+	wtz_lgap_t *d_gp = NULL; uint32_t *d_cap = NULL, *d_roff = NULL, *d_val = NULL, *d_ccnt = NULL; uint64_t *d_key = NULL; uint8_t *d_done = NULL;
+	{
+		const size_t nsp = (size_t)nwt + 64;
+		const size_t b_gp = (nsp * sizeof(wtz_lgap_t) + 255) & ~(size_t)255, b_u32 = (nsp * 4 + 255) & ~(size_t)255, b_u64 = (nsp * 8 + 255) & ~(size_t)255, b_u8 = (nsp + 255) & ~(size_t)255;
+		uint8_t *blk = NULL; CHK(pool_alloc_host(c, 0, b_gp + 3 * b_u32 + b_u64 + b_u8, (void**)&blk));
+		d_gp = (wtz_lgap_t*)blk; blk += b_gp; d_cap = (uint32_t*)blk; blk += b_u32; d_roff = (uint32_t*)blk; blk += b_u32; d_val = (uint32_t*)blk; blk += b_u32; d_key = (uint64_t*)blk; blk += b_u64; d_done = blk;
+	}
+	CHK(dev_alloc((void**)&d_ccnt, 32)); CHK(dev_set(d_ccnt, 0, 32));
+	CHK(dev_set(d_cap, 0, ((size_t)nwt + 1) * 4));
+	CHK(wtz_launch<K_gplan>(0, nwt, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_gplan((uint32_t)t, V, d_wt, d_items, d_gaps, d_gp, d_cap, d_key, d_val, d_done, d_ccnt); }));
+	CHK(dev_exclusive_scan_u32(d_cap, d_roff, nwt + 1));
+	uint32_t NR = 0, ccnt[4] = {0, 0, 0, 0};
+	CHK(dev_d2h(&NR, d_roff + nwt, 4)); CHK(dev_d2h(ccnt, d_ccnt, 16));
+	uint32_t *d_runs = NULL; CHK(pool_alloc_host(c, 0, ((size_t)NR + 16) * 4, (void**)&d_runs));
+	CHK(dev_sort_pairs_u64_u32(d_key, d_val, nwt, 18));
+	CHK(dev_set(d_list, 0, 4));
+	{
+		const uint32_t *d_ord = d_val; const wtz_lgap_t *gp = d_gp; const uint32_t *ro = d_roff; uint32_t *rn = d_runs; uint8_t *dn = d_done;
+		wtz_lclass_t L; uint32_t lo = 0, wv = 0;
+		for(int k = 0; k < 4; k++){ const uint32_t n = ccnt[3 - k]; L.lo[k] = lo; L.hi[k] = lo + n; wv += (n + WTZ_HOST_WAVE - 1) / WTZ_HOST_WAVE; L.wend[k] = wv; lo += n; }
+		uint64_t *d_wtr = NULL; uint32_t *d_wrm = NULL; wtz_lres_t *d_res = NULL;
+		CHK(dev_alloc((void**)&d_wtr, ((size_t)wv + 1) * 8)); CHK(dev_alloc((void**)&d_wrm, ((size_t)wv + 1) * 4)); CHK(dev_set(d_wtr, 0, ((size_t)wv + 1) * 8));
+		CHK(pool_alloc_host(c, 0, ((size_t)nwt + 1) * sizeof(wtz_lres_t), (void**)&d_res)); CHK(dev_set(d_res, 0, ((size_t)nwt + 1) * sizeof(wtz_lres_t)));
+		if(wv) CHK(wtz_launch_coop<K_gdp>(0, wv, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_gdp_all((uint32_t)t, L, V, d_wt, d_items, d_ord, gp, d_res, d_wtr, d_wrm); }, 0));
+		if(wv) CHK(wtz_launch_coop<K_gtb>(0, wv, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_gtb_all((uint32_t)t, L, V, d_wt, d_items, d_ord, gp, ro, rn, d_res, d_gaps, dn, d_wtr, d_wrm); }, 0));
+		CHK(wtz_launch<K_glist>(0, nwt, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_glist((uint32_t)t, dn, d_list); }));
+	}
+	CHK(dev_d2h(n_list, d_list, 4));
+	if(c->env_profile) fprintf(stderr, "[lane-profile] %llu window slots, K-sw2 gaps by band class <=16 / <=32 / <=64 / <=104: %u / %u / %u / %u, %u left to the wavefront kernel\n",
+		(unsigned long long)nwt, ccnt[0], ccnt[1], ccnt[2], ccnt[3], *n_list);
+	dev_free(d_ccnt);
 	return WTZ_OK;
 }
 
@@ -1155,8 +1213,8 @@ extern "C" int wtz_pairs_align(wtz_ctx_t *c, const uint32_t *pair_idx, const uin
 		const wtz_reg_t *ra = d_regs, *rb = d_regs_chk;
 		CHK(wtz_launch<K_misc>(0, nreg, [=] WTZ_LAMBDA (uint64_t i){
 			const wtz_reg_t &a = ra[i], &b = rb[i];
-			bool same = a.x.score == b.x.score && a.x.tb == b.x.tb && a.x.te == b.x.te && a.x.qb == b.x.qb && a.x.qe == b.x.qe && a.x.aln == b.x.aln && a.x.mat == b.x.mat && a.x.mis == b.x.mis && a.x.ins == b.x.ins && a.x.del == b.x.del && a.pass == b.pass && a.cigar_len == b.cigar_len && (a.cells == b.cells || a.cells == 0 || b.cells == 0);      /* the host emulation's scalar body does not count cells */
-			if(same) for(uint32_t k = 0; k < a.cigar_len; k++) if(a.cigar[k] != b.cigar[k]){ same = false; break; }
+			bool same = a.pass == 2 || b.pass == 2 || (a.x.score == b.x.score && a.x.tb == b.x.tb && a.x.te == b.x.te && a.x.qb == b.x.qb && a.x.qe == b.x.qe && a.x.aln == b.x.aln && a.x.mat == b.x.mat && a.x.mis == b.x.mis && a.x.ins == b.x.ins && a.x.del == b.x.del && a.pass == b.pass && a.cigar_len == b.cigar_len && (a.cells == b.cells || a.cells == 0 || b.cells == 0));      /* pass 2 = scratch exhausted (reported as such); the host emulation's scalar body does not count cells */
+			if(same && a.pass != 2 && b.pass != 2) for(uint32_t k = 0; k < a.cigar_len; k++) if(a.cigar[k] != b.cigar[k]){ same = false; break; }
 			if(!same){ const unsigned int z = WTZ_ATOMIC_INC32(&d_bad[0]); if(z == 0) d_bad[1] = (unsigned int)i; }
 		}));
 		unsigned int hb[4]; CHK(dev_d2h(hb, d_bad, 16)); dev_free(d_bad);
@@ -1178,8 +1236,17 @@ extern "C" int wtz_pairs_align(wtz_ctx_t *c, const uint32_t *pair_idx, const uin
 		const uint64_t nwt = wt.size();
 		STAGE(c, "K_stitch_left");
 		CHK(wtz_launch_wave<K_stitch_left>(0, m, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_stitch_left((uint32_t)t, V, d_items, d_st, d_jl); }));
+		uint32_t *d_glist = NULL, n_glist = (uint32_t)nwt; const bool gap_lane = c->env_gap_lane != 0;
+#ifndef WTZ_EMUL
+		wtz_timer tgap; tgap.start();          /* K-sw2: lane pipeline + wavefront kernel */
+#endif
+		if(gap_lane){
+			CHK(dev_alloc((void**)&d_glist, (size_t)(nwt + 1) * 4));
+			STAGE(c, "K-sw2 lane pipeline");
+			CHK(run_gap_lane(c, V, d_wt, nwt, d_items, d_gaps, d_glist, &n_glist));
+		}
 #ifdef WTZ_EMUL
-		CHK(wtz_launch_coop<K_gap>(0, nwt, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_gap((uint32_t)t, V, d_wt, d_items, d_gaps); }, WTZ_GAP_LDS_BYTES));
+		CHK(wtz_launch_coop<K_gap>(0, n_glist, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_gap((uint32_t)t, V, d_wt, d_items, d_gaps, (uint32_t*)NULL, (const uint32_t*)d_glist); }, WTZ_GAP_LDS_BYTES));
 		CHK(run_extjobs(c, V, d_jl, m));
 #else
 		{
@@ -1192,8 +1259,7 @@ extern "C" int wtz_pairs_align(wtz_ctx_t *c, const uint32_t *pair_idx, const uin
 			if(gap_side){ HIPCHK(hipEventRecord(c->ev_gap_fork, main_stream)); HIPCHK(hipStreamWaitEvent(c->stream_gap, c->ev_gap_fork, 0)); g_stream = c->stream_gap; }
 			uint32_t *d_defer = NULL; CHK(dev_alloc((void**)&d_defer, (size_t)(nwt + 1) * 4)); CHK(dev_set(d_defer, 0, 4));
 			STAGE(c, "K_gap");
-			wtz_timer tgap; tgap.start();
-			int rc_gap = wtz_launch_coop<K_gap>(0, nwt, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_gap((uint32_t)t, V, d_wt, d_items, d_gaps, d_defer, NULL, 0u); }, WTZ_GAP_LDS_BYTES);
+			int rc_gap = wtz_launch_coop<K_gap>(0, n_glist, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_gap((uint32_t)t, V, d_wt, d_items, d_gaps, d_defer, (const uint32_t*)d_glist, 0u); }, WTZ_GAP_LDS_BYTES);
 			if(rc_gap == WTZ_OK){
 				/* gaps whose band outgrew the register forms (repeats): the LDS-ring wave DP with 8192-column rings, 72 KB of LDS per wave */
 				uint32_t n_def = 0; rc_gap = dev_d2h(&n_def, d_defer, 4);

@@ -311,7 +311,7 @@ WTZ_HD void wtz_task_lcount(uint32_t t, const wtz_wintask_t *tasks, const wtz_al
  * 0xFFFF - (n_col << 9 | rows) (descending shape order; 0xFFFF = no DP).  wflag = 1: the window has a problem outside the lane envelope
  * (or whose band depends on init_score: only with -w above 48 + 2 min(qlen, tlen)) and is left to the chained kernel. */
 WTZ_HD void wtz_task_lplan(uint32_t t, const wtz_env_t &V, const wtz_wintask_t *tasks, const wtz_alnitem_t *items, const uint32_t *woff,
-		wtz_lprob_t *prob, uint32_t *runcap, uint64_t *key, uint32_t *val, uint8_t *wflag, uint32_t *ccnt){
+		wtz_lprob_t *prob, uint32_t *runcap, uint64_t *key, uint32_t *val, uint8_t *wflag, uint32_t *ccnt, uint32_t *uidx, uint32_t *nu){
 	const wtz_params_t *P = V.P;
 	const wtz_alnitem_t &it = items[tasks[t].item];
 	const wtz_win_t &w = it.win[tasks[t].widx];
@@ -319,40 +319,71 @@ WTZ_HD void wtz_task_lplan(uint32_t t, const wtz_env_t &V, const wtz_wintask_t *
 	const uint32_t base = woff[t], na = w.anchors[1] - w.anchors[0];
 	const int32_t M = P->M, I = P->O, D = P->O, E = P->E, T = P->T;
 	int32_t te = 0, qe = 0; bool first = true, fb = false, ended = false;
-	for(uint32_t k = 0; k < na; k++){
-		wtz_lprob_t pr; pr.win = t; pr.qoff = pr.toff = 0; pr.qlen = -1; pr.tlen = 0; pr.run_off = 0;
-		uint32_t cap = 0; uint64_t ky = 0xFFFFull;
-		if(!ended){
-			const wtz_zhit_t p = it.anchors[w.anchors[0] + k];
-			const int32_t off1 = (int32_t)ZH_OFF1(p), off2 = (int32_t)ZH_OFF2(p);
-			if(first){ te = off1; qe = off2; first = false; }
-			if(off1 >= te && off2 >= qe){
-				pr.qoff = qe; pr.toff = te; pr.qlen = off2 - qe; pr.tlen = off1 - te;
-				if(pr.qlen > 0 && pr.tlen > 0){
-					int32_t W0 = P->w, W1 = P->w, ql, tl, n_col, ql1, tl1, nc1;
-					wtz_ext_geometry(pr.qlen, pr.tlen, 0, W0, M, I, D, E, T, ql, tl, n_col);
-					wtz_ext_geometry(pr.qlen, pr.tlen, 1 << 24, W1, M, I, D, E, T, ql1, tl1, nc1);
-					if(W0 != W1 || n_col > WTZ_LN_MAXCOLS || ql > WTZ_LN_MAXROWS || ql + tl > WTZ_LN_MAXSPAN) fb = true;
-					else { cap = (uint32_t)(ql + tl + 2); ky = 0xFFFFull - (uint64_t)(((uint32_t)n_col << 9) | (uint32_t)ql); }
-				}
-				int32_t dte = 0, dqe = 0;
-				if(!wtz_zmer_advance(pb1.sub(off1, 1), ZH_LEN1(p), pb2.sub(off2, 1), ZH_LEN2(p), &dte, &dqe)) ended = true;      /* hzm_aln.h:1288-1291: the window ends here */
-				else { te = off1 + dte; qe = off2 + dqe; }
+	uint32_t cc[4] = {0u, 0u, 0u, 0u}, n_used = 0;
+	for(uint32_t k0 = 0; k0 < na; k0 += 4){
+		/* four anchors at a time, and the z-mers of all four speculatively: these loads do not depend on the walk, only their use does (a lane
+		 * uses about one anchor in five, and the lanes of a wave use theirs at different iterations: a load inside the walk costs its latency 64 times) */
+		wtz_zhit_t A[4]; wtz_seq_w2 Z1[4], Z2[4];
+		#pragma unroll
+		for(uint32_t j = 0; j < 4; j++) if(k0 + j < na) A[j] = it.anchors[w.anchors[0] + k0 + j];
+		#pragma unroll
+		for(uint32_t j = 0; j < 4; j++){
+			Z1[j].w0 = Z1[j].w1 = Z2[j].w0 = Z2[j].w1 = 0;
+			if(k0 + j < na && !ended && ZH_LEN1(A[j]) <= 64 && ZH_LEN2(A[j]) <= 64){
+				Z1[j] = wtz_seq_load_w2(pb1.sub((int32_t)ZH_OFF1(A[j]), 1), ZH_LEN1(A[j])); Z2[j] = wtz_seq_load_w2(pb2.sub((int32_t)ZH_OFF2(A[j]), 1), ZH_LEN2(A[j]));
 			}
 		}
-		prob[base + k] = pr; runcap[base + k] = cap; key[base + k] = ky; val[base + k] = base + k;
+		#pragma unroll
+		for(uint32_t j = 0; j < 4; j++){
+			const uint32_t k = k0 + j;
+			if(k >= na) break;
+			wtz_lprob_t pr; pr.win = t; pr.qoff = pr.toff = 0; pr.qlen = -1; pr.tlen = 0; pr.run_off = 0;
+			uint32_t cap = 0; uint64_t ky = 0xFFFFull;
+			if(!ended){
+				const wtz_zhit_t p = A[j];
+				const int32_t off1 = (int32_t)ZH_OFF1(p), off2 = (int32_t)ZH_OFF2(p);
+				if(first){ te = off1; qe = off2; first = false; }
+				if(off1 >= te && off2 >= qe){
+					pr.qoff = qe; pr.toff = te; pr.qlen = off2 - qe; pr.tlen = off1 - te;
+					uidx[base + n_used++] = k;
+					if(pr.qlen > 0 && pr.tlen > 0){
+						int32_t W0 = P->w, W1 = P->w, ql, tl, n_col, ql1, tl1, nc1;
+						wtz_ext_geometry(pr.qlen, pr.tlen, 0, W0, M, I, D, E, T, ql, tl, n_col);
+						wtz_ext_geometry(pr.qlen, pr.tlen, 1 << 24, W1, M, I, D, E, T, ql1, tl1, nc1);
+						if(W0 != W1 || n_col > WTZ_LN_MAXCOLS || ql > WTZ_LN_MAXROWS || ql + tl > WTZ_LN_MAXSPAN) fb = true;
+						else { cap = (uint32_t)(ql + tl + 2); ky = 0xFFFFull - (uint64_t)(((uint32_t)n_col << 9) | (uint32_t)ql); cc[wtz_lane_class(n_col)]++; }
+					}
+					int32_t dte = 0, dqe = 0; bool past = false, ok;
+					const uint32_t len1 = ZH_LEN1(p), len2 = ZH_LEN2(p);
+					if(len1 <= 64 && len2 <= 64) ok = wtz_zmer_advance_w2(Z1[j], len1, Z2[j], len2, &dte, &dqe, &past); else { ok = false; past = true; }
+					if(past) ok = wtz_zmer_advance_slow(pb1.sub(off1, 1), len1, pb2.sub(off2, 1), len2, &dte, &dqe);
+					if(!ok) ended = true;      /* hzm_aln.h:1288-1291: the window ends here */
+					else { te = off1 + dte; qe = off2 + dqe; }
+				}
+			}
+			prob[base + k] = pr; runcap[base + k] = cap; key[base + k] = ky; val[base + k] = base + k;
+		}
 	}
+	nu[t] = n_used;
 	wflag[t] = fb ? 1 : 0;
-	for(uint32_t k = 0; k < na; k++){
-		if(fb){ key[base + k] = 0xFFFFull; runcap[base + k] = 0; }
-		else if(key[base + k] != 0xFFFFull) WTZ_ATOMIC_INC32(&ccnt[wtz_lane_class((int32_t)((0xFFFFu - (uint32_t)key[base + k]) >> 9))]);
+	if(fb){ for(uint32_t k = 0; k < na; k++){ key[base + k] = 0xFFFFull; runcap[base + k] = 0; } }
+	else {
+		#pragma unroll
+		for(int q4 = 0; q4 < 4; q4++) if(cc[q4]){
+#if defined(__HIP_DEVICE_COMPILE__)
+			atomicAdd(&ccnt[q4], cc[q4]);
+#else
+			ccnt[q4] += cc[q4];
+#endif
+		}
 	}
 }
 
-/* one wavefront = WTZ_NLANES problems of the shape-sorted order[lo, hi): relative-mode K-sw1 + traceback, results into the problems' slots */
+/* one wavefront = WTZ_NLANES problems of the shape-sorted order[lo, hi): relative-mode K-sw1, forward part; the wave's trace rows stay in the
+ * transient pool (wtr[gw] = their base, wrm[gw] = rows per lane) for the traceback kernel */
 template<int NC>
-WTZ_HD void wtz_task_ldp(uint32_t wv, const wtz_env_t &V, const wtz_wintask_t *tasks, const wtz_alnitem_t *items, const uint32_t *order, uint32_t lo, uint32_t hi,
-		const wtz_lprob_t *prob, const uint32_t *runoff, uint32_t *runs, wtz_lres_t *res){
+WTZ_HD void wtz_task_ldp(uint32_t gw, uint32_t wv, const wtz_env_t &V, const wtz_wintask_t *tasks, const wtz_alnitem_t *items, const uint32_t *order, uint32_t lo, uint32_t hi,
+		const wtz_lprob_t *prob, wtz_lres_t *res, uint64_t *wtr, uint32_t *wrm){
 	const wtz_params_t *P = V.P;
 	const uint32_t idx = lo + wv * WTZ_NLANES + WTZ_LANE;
 	const bool live = idx < hi;
@@ -370,13 +401,52 @@ WTZ_HD void wtz_task_ldp(uint32_t wv, const wtz_env_t &V, const wtz_wintask_t *t
 	constexpr uint32_t RS = (uint32_t)wtz_lane_geo<NC>::RS;
 	const uint32_t rows_max = (uint32_t)wtz_lane_wmax(ql);
 	uint64_t pa = 0;
-	if(WTZ_LANE == 0) pa = (uint64_t)(uintptr_t)wtz_pool_alloc(V.pool + 1, (size_t)WTZ_NLANES * rows_max * RS * 4 + 16);      /* the wave's trace rows: transient pool */
+	if(WTZ_LANE == 0){
+		pa = (uint64_t)(uintptr_t)wtz_pool_alloc(V.pool + 1, (size_t)WTZ_NLANES * rows_max * RS * 4 + 16);      /* the wave's trace rows: transient pool */
+		wtr[gw] = pa; wrm[gw] = rows_max;
+	}
 	pa = wtz_coop_bcast64(pa);
 	if(pa == 0) return;                       /* the slots stay "not done": the fold reports the pool */
 	uint32_t *tr = (uint32_t*)(uintptr_t)pa + (size_t)WTZ_LANE * rows_max * RS;
 	wtz_lres_t R; memset(&R, 0, sizeof R);
-	wtz_lane_fixed<NC, false>(live, pr.qlen, q, pr.tlen, tt, 0, W, ql, tl, M, X, I, D, E, T, tr, runs + (live ? runoff[slot] : 0u), R);
+	wtz_lane_fixed<NC, false>(live, pr.qlen, q, pr.tlen, tt, 0, W, ql, tl, M, X, I, D, E, T, tr, R);
 	if(live) res[slot] = R;
+}
+/* traceback of the same wave: lane l walks the rows lane l wrote */
+WTZ_HD void wtz_task_ltb(uint32_t gw, uint32_t wv, uint32_t RS, const wtz_env_t &V, const wtz_wintask_t *tasks, const wtz_alnitem_t *items, const uint32_t *order, uint32_t lo, uint32_t hi,
+		const wtz_lprob_t *prob, const uint32_t *runoff, uint32_t *runs, wtz_lres_t *res, const uint64_t *wtr, const uint32_t *wrm){
+	const wtz_params_t *P = V.P;
+	const uint32_t idx = lo + wv * WTZ_NLANES + WTZ_LANE;
+	const uint64_t pa = wtr[gw];
+	if(idx >= hi || pa == 0) return;
+	const uint32_t slot = order[idx];
+	const wtz_lprob_t pr = prob[slot];
+	wtz_lres_t R = res[slot];
+	int32_t W = P->w, ql, tl, n_col;
+	wtz_ext_geometry(pr.qlen, pr.tlen, 0, W, P->M, P->O, P->O, P->E, P->T, ql, tl, n_col);
+	const wtz_alnitem_t &it = items[tasks[pr.win].item];
+	const wtz_seq_packed q = wtz_view(V.R, it.c, it.dir).sub(pr.qoff, 1), tt = wtz_view(V.R, it.q, 0).sub(pr.toff, 1);
+	const uint32_t *tr = (const uint32_t*)(uintptr_t)pa + (size_t)WTZ_LANE * wrm[gw] * RS;
+	wtz_lane_traceback<false>(true, R.qe - 1, R.te - 1, W, RS, q, pr.qlen, tt, pr.tlen, tr, runs + runoff[slot], R);
+	res[slot] = R;
+}
+
+/* the four shape classes in ONE launch (widest band first = longest tasks first): wave wv -> class by the launch's wave ranges */
+typedef struct { uint32_t wend[4], lo[4], hi[4]; } wtz_lclass_t;      /* index 0..3 = band classes 104 / 64 / 32 / 16 */
+WTZ_HD void wtz_task_ldp_all(uint32_t wv, const wtz_lclass_t &L, const wtz_env_t &V, const wtz_wintask_t *tasks, const wtz_alnitem_t *items, const uint32_t *order,
+		const wtz_lprob_t *prob, wtz_lres_t *res, uint64_t *wtr, uint32_t *wrm){
+	uint32_t k = 0; while(k < 3 && wv >= L.wend[k]) k++;
+	const uint32_t wl = wv - (k ? L.wend[k - 1] : 0u);
+	if(k == 0)      wtz_task_ldp<104>(wv, wl, V, tasks, items, order, L.lo[0], L.hi[0], prob, res, wtr, wrm);
+	else if(k == 1) wtz_task_ldp<64>(wv, wl, V, tasks, items, order, L.lo[1], L.hi[1], prob, res, wtr, wrm);
+	else if(k == 2) wtz_task_ldp<32>(wv, wl, V, tasks, items, order, L.lo[2], L.hi[2], prob, res, wtr, wrm);
+	else            wtz_task_ldp<16>(wv, wl, V, tasks, items, order, L.lo[3], L.hi[3], prob, res, wtr, wrm);
+}
+WTZ_HD void wtz_task_ltb_all(uint32_t wv, const wtz_lclass_t &L, const wtz_env_t &V, const wtz_wintask_t *tasks, const wtz_alnitem_t *items, const uint32_t *order,
+		const wtz_lprob_t *prob, const uint32_t *runoff, uint32_t *runs, wtz_lres_t *res, const uint64_t *wtr, const uint32_t *wrm){
+	uint32_t k = 0; while(k < 3 && wv >= L.wend[k]) k++;
+	const uint32_t wl = wv - (k ? L.wend[k - 1] : 0u);
+	wtz_task_ltb(wv, wl, 16u >> k, V, tasks, items, order, L.lo[k], L.hi[k], prob, runoff, runs, res, wtr, wrm);      /* trace dwords per row: 16 / 8 / 4 / 2 */
 }
 
 /* lane-private CIGAR vector with the open run in a register */
@@ -386,12 +456,14 @@ WTZ_HD void wtz_lcig_push(wtz_lcig_t &w, uint32_t op, uint32_t len){
 	if(w.tail && (w.tail & 0xFu) == op) w.tail += len << 4;
 	else { if(w.tail) w.v.push(w.tail); w.tail = (len << 4) | op; }
 }
-/* hzm_aln.h:278-314 pushing into the lane writer; aln == 0: the pair does not align (the caller rolls the writer back) */
+/* hzm_aln.h:278-314 pushing into the lane writer; aln == 0: the pair does not align (the caller rolls the writer back).
+ * *past = true: the loop would read beyond one of the two z-mers (only the base-by-base form can follow the reference there) */
 template<typename S1, typename S2>
-WTZ_HD wtz_aln_t wtz_align_zmer_lane(const S1 &pb1, uint32_t len1, const S2 &pb2, uint32_t len2, int32_t M, int32_t I, int32_t D, int32_t E, wtz_lcig_t &cw){
+WTZ_HD wtz_aln_t wtz_align_zmer_lane_t(const S1 &pb1, uint32_t len1, const S2 &pb2, uint32_t len2, int32_t M, int32_t I, int32_t D, int32_t E, wtz_lcig_t &cw, bool bounded, bool *past){
 	wtz_aln_t x, zero; memset(&zero, 0, sizeof zero); x = zero;
 	uint32_t s0 = 0, s1 = 0;
 	while(s0 < len1 || s1 < len2){
+		if(bounded && (s0 >= len1 || s1 >= len2)){ *past = true; return zero; }
 		const uint32_t b = pb1.at((int32_t)s0);
 		if(b != pb2.at((int32_t)s1)) return zero;
 		uint32_t e0 = s0 + 1; while(e0 < len1 && pb1.at((int32_t)e0) == b) e0++;
@@ -405,13 +477,30 @@ WTZ_HD wtz_aln_t wtz_align_zmer_lane(const S1 &pb1, uint32_t len1, const S2 &pb2
 	x.te = x.mat + x.del; x.qe = x.mat + x.ins;
 	return x;
 }
+WTZ_HD wtz_aln_t wtz_align_zmer_lane(const wtz_seq_packed &pb1, uint32_t len1, const wtz_seq_packed &pb2, uint32_t len2, int32_t M, int32_t I, int32_t D, int32_t E, wtz_lcig_t &cw){
+	bool past = false;
+	if(len1 <= 64 && len2 <= 64){
+		const wtz_seq_w2 r1 = wtz_seq_load_w2(pb1, len1), r2 = wtz_seq_load_w2(pb2, len2);
+		if(len1 == len2 && len1 && r1.w0 == r2.w0 && r1.w1 == r2.w1){        /* the same string: the runs merge into one M of the whole length */
+			wtz_aln_t y; memset(&y, 0, sizeof y);
+			y.aln = y.mat = (int32_t)len1; y.te = y.qe = (int32_t)len1; y.score = (int32_t)len1 * M;
+			wtz_lcig_push(cw, 0, len1);
+			return y;
+		}
+		const uint32_t keep_tail = cw.tail, keep_n = cw.v.n;
+		const wtz_aln_t y = wtz_align_zmer_lane_t(r1, len1, r2, len2, M, I, D, E, cw, true, &past);
+		if(!past) return y;
+		cw.tail = keep_tail; cw.v.n = keep_n;
+	}
+	return wtz_align_zmer_lane_t(pb1, len1, pb2, len2, M, I, D, E, cw, false, &past);
+}
 
 /* The fold chains window t (hzm_aln.h:1255-1300) over the results of its problems: init_score of a problem = the score so far, its
  * relative result is shifted by it - provided none of the absolute tests of kswx_extend_align_core would have fired (see wtz_sw_lane.h):
  * a + minrow > 0 (no row maximum <= 0: kswx.h:280,302) and, when the end candidate was taken, a + score > 0 (kswx.h:304).  A window that
  * fails is appended to fblist ([0] = count) for the chained kernel; nothing of it has been published. */
 WTZ_HD void wtz_task_lfold(uint32_t t, const wtz_env_t &V, const wtz_wintask_t *tasks, const wtz_alnitem_t *items, const uint32_t *woff,
-		const wtz_lprob_t *prob, const uint32_t *runoff, const uint32_t *runs, const wtz_lres_t *res, const uint8_t *wflag, uint32_t *fblist){
+		const wtz_lprob_t *prob, const uint32_t *runoff, const uint32_t *runs, const wtz_lres_t *res, const uint8_t *wflag, uint32_t *fblist, const uint32_t *uidx, const uint32_t *nu){
 	if(wflag[t]){ const uint32_t k = WTZ_ATOMIC_INC32(&fblist[0]); fblist[1 + k] = t; return; }
 	const wtz_params_t *P = V.P;
 	const wtz_alnitem_t &it = items[tasks[t].item];
@@ -423,32 +512,51 @@ WTZ_HD void wtz_task_lfold(uint32_t t, const wtz_env_t &V, const wtz_wintask_t *
 	wtz_lcig_t cw; cw.v.init(V.pool, na * 14u + 16u); cw.tail = 0;
 	wtz_aln_t x; memset(&x, 0, sizeof x);
 	unsigned long long cells = 0; int32_t bad = 0;
-	for(uint32_t k = 0; k < na; k++){
-		const wtz_lprob_t pr = prob[base + k];
-		if(pr.qlen < 0) continue;
-		const wtz_zhit_t p = it.anchors[w.anchors[0] + k];
-		const int32_t off1 = (int32_t)ZH_OFF1(p), off2 = (int32_t)ZH_OFF2(p);
-		if(x.aln == 0){ x.tb = x.te = off1; x.qb = x.qe = off2; }
-		const int32_t a = x.score < 0 ? 0 : x.score;                 /* kswx.h:241 */
-		if(pr.qlen > 0 && pr.tlen > 0){
-			const wtz_lres_t r = res[base + k];
-			if(!(r.flags & WTZ_LR_DONE)){ bad = 1; break; }
-			if(a + r.minrow <= 0 || ((r.flags & WTZ_LR_USEDG) && a + r.score <= 0)){ const uint32_t z = WTZ_ATOMIC_INC32(&fblist[0]); fblist[1 + z] = t; return; }
-			x.score = a + r.score;
-			x.aln += r.mat + r.mis + r.ins + r.del; x.mat += r.mat; x.mis += r.mis; x.ins += r.ins; x.del += r.del;
-			x.te += r.te - 0; x.qe += r.qe - 0;
-			const uint32_t *rr = runs + runoff[base + k];
-			for(uint32_t j = r.n_runs; j-- > 0;){ const uint32_t v = rr[j]; wtz_lcig_push(cw, v & 0xFu, v >> 4); }
-			cells += r.cells;
-		} else x.score = a;                                          /* kswx.h:242: an empty side returns init_score */
-		if(x.te < off1){ x.del += off1 - x.te; x.aln += off1 - x.te; wtz_lcig_push(cw, 2, (uint32_t)(off1 - x.te)); x.te = off1; }
-		if(x.qe < off2){ x.ins += off2 - x.qe; x.aln += off2 - x.qe; wtz_lcig_push(cw, 1, (uint32_t)(off2 - x.qe)); x.qe = off2; }
-		const uint32_t keep_tail = cw.tail, keep_n = cw.v.n;
-		const wtz_aln_t y = wtz_align_zmer_lane(pb1.sub(off1, 1), ZH_LEN1(p), pb2.sub(off2, 1), ZH_LEN2(p), M, I, D, E, cw);
-		if(y.aln == 0){ cw.tail = keep_tail; cw.v.n = keep_n; break; }
-		x.score += y.score;
-		x.aln += y.aln; x.mat += y.mat; x.mis += y.mis; x.ins += y.ins; x.del += y.del;
-		x.te += y.te; x.qe += y.qe;
+	bool stop = false;
+	const uint32_t n_used = nu[t];
+	for(uint32_t u0 = 0; u0 < n_used && !stop; u0 += 2){
+		/* the window's usable anchors (the planner's list) two at a time: slot index, then problem record / result / anchor / z-mer words -
+		 * loads that do not depend on the chain are issued together, ahead of it */
+		uint32_t KK[2]; wtz_lprob_t PR[2]; wtz_lres_t RES[2]; wtz_zhit_t AN[2]; uint32_t RO[2];
+		#pragma unroll
+		for(uint32_t j = 0; j < 2; j++) KK[j] = u0 + j < n_used ? uidx[base + u0 + j] : 0u;
+		#pragma unroll
+		for(uint32_t j = 0; j < 2; j++) if(u0 + j < n_used){ PR[j] = prob[base + KK[j]]; AN[j] = it.anchors[w.anchors[0] + KK[j]]; RES[j] = res[base + KK[j]]; RO[j] = runoff[base + KK[j]]; }
+		#pragma unroll
+		for(uint32_t j = 0; j < 2; j++){
+			if(u0 + j >= n_used || stop) break;
+			const uint32_t k = KK[j];
+			const wtz_lprob_t pr = PR[j];
+			if(pr.qlen < 0) continue;
+			const wtz_zhit_t p = AN[j];
+			const int32_t off1 = (int32_t)ZH_OFF1(p), off2 = (int32_t)ZH_OFF2(p);
+			if(x.aln == 0){ x.tb = x.te = off1; x.qb = x.qe = off2; }
+			const int32_t a = x.score < 0 ? 0 : x.score;                 /* kswx.h:241 */
+			if(pr.qlen > 0 && pr.tlen > 0){
+				const wtz_lres_t r = RES[j];
+				if(!(r.flags & WTZ_LR_DONE)){ bad = 1; stop = true; break; }
+				if(a + r.minrow <= 0 || ((r.flags & WTZ_LR_USEDG) && a + r.score <= 0)){ const uint32_t z = WTZ_ATOMIC_INC32(&fblist[0]); fblist[1 + z] = t; return; }
+				x.score = a + r.score;
+				x.aln += r.mat + r.mis + r.ins + r.del; x.mat += r.mat; x.mis += r.mis; x.ins += r.ins; x.del += r.del;
+				x.te += r.te; x.qe += r.qe;
+				const uint32_t *rr = runs + RO[j];
+				uint32_t jj = r.n_runs;
+				for(; jj >= 4; jj -= 4){      /* batches of loads, then pushes */
+					const uint32_t v0 = rr[jj - 1], v1 = rr[jj - 2], v2 = rr[jj - 3], v3 = rr[jj - 4];
+					wtz_lcig_push(cw, v0 & 0xFu, v0 >> 4); wtz_lcig_push(cw, v1 & 0xFu, v1 >> 4); wtz_lcig_push(cw, v2 & 0xFu, v2 >> 4); wtz_lcig_push(cw, v3 & 0xFu, v3 >> 4);
+				}
+				for(; jj-- > 0;){ const uint32_t v = rr[jj]; wtz_lcig_push(cw, v & 0xFu, v >> 4); }
+				cells += r.cells;
+			} else x.score = a;                                          /* kswx.h:242: an empty side returns init_score */
+			if(x.te < off1){ x.del += off1 - x.te; x.aln += off1 - x.te; wtz_lcig_push(cw, 2, (uint32_t)(off1 - x.te)); x.te = off1; }
+			if(x.qe < off2){ x.ins += off2 - x.qe; x.aln += off2 - x.qe; wtz_lcig_push(cw, 1, (uint32_t)(off2 - x.qe)); x.qe = off2; }
+			const uint32_t keep_tail = cw.tail, keep_n = cw.v.n;
+			const wtz_aln_t y = wtz_align_zmer_lane(pb1.sub(off1, 1), ZH_LEN1(p), pb2.sub(off2, 1), ZH_LEN2(p), M, I, D, E, cw);
+			if(y.aln == 0){ cw.tail = keep_tail; cw.v.n = keep_n; stop = true; break; }
+			x.score += y.score;
+			x.aln += y.aln; x.mat += y.mat; x.mis += y.mis; x.ins += y.ins; x.del += y.del;
+			x.te += y.te; x.qe += y.qe;
+		}
 	}
 	if(cw.tail){ cw.v.push(cw.tail); cw.tail = 0; }
 	reg.x = x; reg.cigar = cw.v.a; reg.cigar_len = cw.v.n; reg.cells = cells;
@@ -685,6 +793,117 @@ WTZ_HD void wtz_task_gap(uint32_t t, const wtz_env_t &V, const wtz_wintask_t *ta
 	g.cigar = tmp.a; g.cigar_len = tmp.n; g.bad = (tmp.bad || bad);
 	*slot = g;
 }
+
+/* ---------------- K-sw2 with one lane per gap (wtz_lane_global) ----------------
+ * The gaps between the passing windows of an item are independent problems (hzm_aln.h:1386-1447).  Slot t of the window list holds the gap in
+ * front of window t (wtz_task_gap): the planner lists the gaps whose FIRST band width - P->w doubled until it covers |dq - dt| - fits the lane
+ * envelope; the DP kernel runs them one per lane, sorted by shape, and publishes a gap unless the reference would double the band again
+ * (score < 0, hzm_aln.h:1410-1416); whatever is not published (done[t] == 0) goes through wtz_task_gap on a wavefront. */
+#define WTZ_LG_MAXROWS 768       /* rows of a lane gap: longer gaps are few and long, a wavefront each serves them better */
+typedef struct { uint32_t slot; int32_t dq, dt, w; } wtz_lgap_t;
+WTZ_HD void wtz_task_gplan(uint32_t t, const wtz_env_t &V, const wtz_wintask_t *tasks, const wtz_alnitem_t *items, wtz_gapres_t *gaps,
+		wtz_lgap_t *gp, uint32_t *runcap, uint64_t *key, uint32_t *val, uint8_t *done, uint32_t *ccnt){
+	const wtz_params_t *P = V.P;
+	const wtz_alnitem_t &it = items[tasks[t].item];
+	const uint32_t k = tasks[t].widx;
+	wtz_lgap_t G; G.slot = t; G.dq = G.dt = 0; G.w = 0;
+	uint32_t cap = 0; uint64_t ky = 0x3FFFFull; uint8_t dn = 0;
+	wtz_gapres_t *slot = gaps + (it.regs - items[0].regs) + k;
+	int32_t prev = -1;
+	if(k && it.regs[k].pass == 1) for(int32_t j = (int32_t)k - 1; j >= 0; j--) if(it.regs[j].pass == 1){ prev = j; break; }
+	if(prev < 0){ wtz_gapres_t g; memset(&g, 0, sizeof g); *slot = g; dn = 1; }       /* no gap in front of this window (wtz_task_gap's early exits) */
+	else {
+		const wtz_reg_t *reg1 = &it.regs[prev], *reg2 = &it.regs[k];
+		const int32_t dq = reg2->x.qb - reg1->x.qe, dt = reg2->x.tb - reg1->x.te;
+		if(dq > 0 && dt > 0){
+			int32_t w = P->w; while(w < WTZ_ABSDIFF(dq, dt)) w <<= 1;
+			const int32_t n_col = dq < 2 * w + 1 ? dq : 2 * w + 1;
+			if(n_col <= WTZ_LN_MAXCOLS && dt <= WTZ_LG_MAXROWS){
+				G.dq = dq; G.dt = dt; G.w = w; cap = (uint32_t)(dq + dt + 2);
+				ky = 0x3FFFFull - (uint64_t)(((uint32_t)n_col << 11) | (uint32_t)dt);
+				WTZ_ATOMIC_INC32(&ccnt[wtz_lane_class(n_col)]);
+			}
+		}
+	}
+	gp[t] = G; runcap[t] = cap; key[t] = ky; val[t] = t; done[t] = dn;
+}
+template<int NC>
+WTZ_HD void wtz_task_gdp(uint32_t gw, uint32_t wv, const wtz_env_t &V, const wtz_wintask_t *tasks, const wtz_alnitem_t *items, const uint32_t *order, uint32_t lo, uint32_t hi,
+		const wtz_lgap_t *gp, wtz_lres_t *res, uint64_t *wtr, uint32_t *wrm){
+	const wtz_params_t *P = V.P;
+	const uint32_t idx = lo + wv * WTZ_NLANES + WTZ_LANE;
+	const bool live = idx < hi;
+	const uint32_t t = live ? order[idx] : 0u;
+	wtz_lgap_t G; G.slot = 0; G.dq = G.dt = 0; G.w = P->w;
+	if(live) G = gp[t];
+	const int32_t M = P->M, X = P->X, I = P->O, D = P->O, E = P->E;
+	wtz_seq_packed q, tt; q.bits = tt.bits = V.R.bits; q.start = tt.start = 0; q.strand = tt.strand = 1; q.comp = tt.comp = 0;
+	if(live){
+		const wtz_alnitem_t &it = items[tasks[t].item];
+		const uint32_t k = tasks[t].widx;
+		int32_t prev = -1;
+		for(int32_t j = (int32_t)k - 1; j >= 0; j--) if(it.regs[j].pass == 1){ prev = j; break; }
+		const wtz_reg_t *reg1 = &it.regs[prev];
+		q = wtz_view(V.R, it.c, it.dir).sub(reg1->x.qe, 1); tt = wtz_view(V.R, it.q, 0).sub(reg1->x.te, 1);
+	}
+	constexpr uint32_t RS = (uint32_t)wtz_lane_geo<NC>::RS;
+	const uint32_t rows_max = (uint32_t)wtz_lane_wmax(G.dt);
+	uint64_t pa = 0;
+	if(WTZ_LANE == 0){
+		pa = (uint64_t)(uintptr_t)wtz_pool_alloc(V.pool + 1, (size_t)WTZ_NLANES * rows_max * RS * 4 + 16);
+		wtr[gw] = pa; wrm[gw] = rows_max;
+	}
+	pa = wtz_coop_bcast64(pa);
+	if(pa == 0) return;                      /* nothing published: the wave kernel takes these gaps (and reports the pool if it is really full) */
+	uint32_t *tr = (uint32_t*)(uintptr_t)pa + (size_t)WTZ_LANE * rows_max * RS;
+	wtz_lres_t R; memset(&R, 0, sizeof R);
+	wtz_lane_global<NC>(live, G.dq, q, G.dt, tt, G.w, M, X, -I, -E, -D, -E, tr, R);
+	if(live) res[t] = R;
+}
+/* traceback + publication of the gaps of the same wave */
+WTZ_HD void wtz_task_gtb(uint32_t gw, uint32_t wv, uint32_t RS, const wtz_env_t &V, const wtz_wintask_t *tasks, const wtz_alnitem_t *items, const uint32_t *order, uint32_t lo, uint32_t hi,
+		const wtz_lgap_t *gp, const uint32_t *runoff, uint32_t *runs, const wtz_lres_t *res, wtz_gapres_t *gaps, uint8_t *done, const uint64_t *wtr, const uint32_t *wrm){
+	const wtz_params_t *P = V.P;
+	const uint32_t idx = lo + wv * WTZ_NLANES + WTZ_LANE;
+	const uint64_t pa = wtr[gw];
+	if(idx >= hi || pa == 0) return;
+	const uint32_t t = order[idx];
+	const wtz_lgap_t G = gp[t];
+	wtz_lres_t R = res[t];
+	if(!(R.flags & WTZ_LR_DONE)) return;
+	if(R.score < 0 && G.w < (int32_t)P->W && G.w < WTZ_MAX(G.dq, G.dt)) return;      /* the reference doubles the band and tries again (hzm_aln.h:1410-1416): wave kernel */
+	const wtz_alnitem_t &it = items[tasks[t].item];
+	const uint32_t k = tasks[t].widx;
+	int32_t prev = -1;
+	for(int32_t j = (int32_t)k - 1; j >= 0; j--) if(it.regs[j].pass == 1){ prev = j; break; }
+	const wtz_reg_t *reg1 = &it.regs[prev];
+	const wtz_seq_packed q = wtz_view(V.R, it.c, it.dir).sub(reg1->x.qe, 1), tt = wtz_view(V.R, it.q, 0).sub(reg1->x.te, 1);
+	const uint32_t *tr = (const uint32_t*)(uintptr_t)pa + (size_t)WTZ_LANE * wrm[gw] * RS;
+	uint32_t *rr = runs + runoff[t];
+	const int32_t r0 = G.dt - 1, c0 = (r0 + G.w + 1 < G.dq ? r0 + G.w + 1 : G.dq) - 1;
+	wtz_lane_traceback<true>(true, r0, c0, G.w, RS, tt, G.dt, q, G.dq, tr, rr, R);
+	wtz_gapres_t g; memset(&g, 0, sizeof g);
+	g.score = R.score; g.valid = 1; g.mat = R.mat; g.mis = R.mis; g.ins = R.ins; g.del = R.del; g.aln = R.mat + R.mis + R.ins + R.del;
+	for(uint32_t a = 0, b = R.n_runs; a + 1 < b; a++, b--){ const uint32_t x = rr[a]; rr[a] = rr[b - 1]; rr[b - 1] = x; }      /* traceback order -> CIGAR order, in place */
+	g.cigar = rr; g.cigar_len = R.n_runs; g.cells = R.cells;
+	gaps[(it.regs - items[0].regs) + k] = g; done[t] = 1;
+}
+WTZ_HD void wtz_task_gdp_all(uint32_t wv, const wtz_lclass_t &L, const wtz_env_t &V, const wtz_wintask_t *tasks, const wtz_alnitem_t *items, const uint32_t *order,
+		const wtz_lgap_t *gp, wtz_lres_t *res, uint64_t *wtr, uint32_t *wrm){
+	uint32_t k = 0; while(k < 3 && wv >= L.wend[k]) k++;
+	const uint32_t wl = wv - (k ? L.wend[k - 1] : 0u);
+	if(k == 0)      wtz_task_gdp<104>(wv, wl, V, tasks, items, order, L.lo[0], L.hi[0], gp, res, wtr, wrm);
+	else if(k == 1) wtz_task_gdp<64>(wv, wl, V, tasks, items, order, L.lo[1], L.hi[1], gp, res, wtr, wrm);
+	else if(k == 2) wtz_task_gdp<32>(wv, wl, V, tasks, items, order, L.lo[2], L.hi[2], gp, res, wtr, wrm);
+	else            wtz_task_gdp<16>(wv, wl, V, tasks, items, order, L.lo[3], L.hi[3], gp, res, wtr, wrm);
+}
+WTZ_HD void wtz_task_gtb_all(uint32_t wv, const wtz_lclass_t &L, const wtz_env_t &V, const wtz_wintask_t *tasks, const wtz_alnitem_t *items, const uint32_t *order,
+		const wtz_lgap_t *gp, const uint32_t *runoff, uint32_t *runs, const wtz_lres_t *res, wtz_gapres_t *gaps, uint8_t *done, const uint64_t *wtr, const uint32_t *wrm){
+	uint32_t k = 0; while(k < 3 && wv >= L.wend[k]) k++;
+	const uint32_t wl = wv - (k ? L.wend[k - 1] : 0u);
+	wtz_task_gtb(wv, wl, 16u >> k, V, tasks, items, order, L.lo[k], L.hi[k], gp, runoff, runs, res, gaps, done, wtr, wrm);
+}
+WTZ_HD void wtz_task_glist(uint32_t t, const uint8_t *done, uint32_t *list){ if(!done[t]){ const uint32_t k = WTZ_ATOMIC_INC32(&list[0]); list[1 + k] = t; } }
 
 WTZ_HD void wtz_task_stitch_left(uint32_t t, const wtz_env_t &V, const wtz_alnitem_t *items, wtz_stitch_state_t *sts, wtz_extjob_t *jobs){
 	const wtz_params_t *P = V.P;

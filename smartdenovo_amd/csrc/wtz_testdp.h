@@ -65,13 +65,41 @@ static __device__ void wtz_task_test_lane(uint32_t t, const wtz_dpprob_dev_t *pr
 	uint32_t *tr = (uint32_t*)(uintptr_t)pa, *runs = tr + (size_t)ql * RS + 4;
 	const bool live = WTZ_LANE == 0;
 	wtz_lres_t R; memset(&R, 0, sizeof R);
-	if(n_col <= 16)      wtz_lane_fixed<16, true>(live, p.qlen, p.q, p.tlen, p.t, init, W, ql, tl, M, X, I, D, E, T, tr, runs, R);
-	else if(n_col <= 32) wtz_lane_fixed<32, true>(live, p.qlen, p.q, p.tlen, p.t, init, W, ql, tl, M, X, I, D, E, T, tr, runs, R);
-	else if(n_col <= 64) wtz_lane_fixed<64, true>(live, p.qlen, p.q, p.tlen, p.t, init, W, ql, tl, M, X, I, D, E, T, tr, runs, R);
-	else                 wtz_lane_fixed<104, true>(live, p.qlen, p.q, p.tlen, p.t, init, W, ql, tl, M, X, I, D, E, T, tr, runs, R);
+	if(n_col <= 16)      wtz_lane_fixed<16, true>(live, p.qlen, p.q, p.tlen, p.t, init, W, ql, tl, M, X, I, D, E, T, tr, R);
+	else if(n_col <= 32) wtz_lane_fixed<32, true>(live, p.qlen, p.q, p.tlen, p.t, init, W, ql, tl, M, X, I, D, E, T, tr, R);
+	else if(n_col <= 64) wtz_lane_fixed<64, true>(live, p.qlen, p.q, p.tlen, p.t, init, W, ql, tl, M, X, I, D, E, T, tr, R);
+	else                 wtz_lane_fixed<104, true>(live, p.qlen, p.q, p.tlen, p.t, init, W, ql, tl, M, X, I, D, E, T, tr, R);
 	if(!live) return;
+	wtz_lane_traceback<false>(true, R.qe - 1, R.te - 1, W, RS, p.q, p.qlen, p.t, p.tlen, tr, runs, R);
 	wtz_aln_t x; memset(&x, 0, sizeof x);
 	x.score = R.score; x.qe = R.qe; x.te = R.te; x.mat = R.mat; x.mis = R.mis; x.ins = R.ins; x.del = R.del; x.aln = R.mat + R.mis + R.ins + R.del;
+	wtz_cigar_t none; none.a = NULL; none.n = none.cap = 0; none.pool = pool; none.bad = 0;
+	wtz_testdp_store(&res[t], x, true, runs, R.n_runs, none, pool, 64, 0, R.cells);
+}
+
+/* form 64 of WTZ_DP_GLOBAL: the lane-per-gap K-sw2 (wtz_lane_global) at the band width the problem names */
+static __device__ void wtz_task_test_lane_global(uint32_t t, const wtz_dpprob_dev_t *pr, const wtz_params_t *P, wtz_pool_t *pool, wtz_dpres_dev_t *res){
+	const wtz_dpprob_dev_t p = pr[t];
+	const int32_t M = P->M, X = P->X, I = P->O, D = P->O, E = P->E;
+	wtz_dpres_dev_t r; memset(&r, 0, sizeof r);
+	const int32_t w = p.W, n_col = p.qlen < 2 * w + 1 ? p.qlen : 2 * w + 1;
+	if(p.qlen <= 0 || p.tlen <= 0 || WTZ_ABSDIFF(p.qlen, p.tlen) > w || n_col > WTZ_LN_MAXCOLS || p.tlen > WTZ_LG_MAXROWS){ if(WTZ_LANE == 0) res[t] = r; return; }     /* declined */
+	const uint32_t RS = wtz_lane_rs(n_col);
+	unsigned long long pa = 0;
+	if(WTZ_LANE == 0) pa = (unsigned long long)(uintptr_t)wtz_pool_alloc(pool, (size_t)p.tlen * RS * 4 + (size_t)(p.qlen + p.tlen + 4) * 4 + 32);
+	pa = __shfl(pa, 0, 64);
+	if(pa == 0){ r.bad = 1; r.form = 64; if(WTZ_LANE == 0) res[t] = r; return; }
+	uint32_t *tr = (uint32_t*)(uintptr_t)pa, *runs = tr + (size_t)p.tlen * RS + 4;
+	const bool live = WTZ_LANE == 0;
+	wtz_lres_t R; memset(&R, 0, sizeof R);
+	if(n_col <= 16)      wtz_lane_global<16>(live, p.qlen, p.q, p.tlen, p.t, w, M, X, -I, -E, -D, -E, tr, R);
+	else if(n_col <= 32) wtz_lane_global<32>(live, p.qlen, p.q, p.tlen, p.t, w, M, X, -I, -E, -D, -E, tr, R);
+	else if(n_col <= 64) wtz_lane_global<64>(live, p.qlen, p.q, p.tlen, p.t, w, M, X, -I, -E, -D, -E, tr, R);
+	else                 wtz_lane_global<104>(live, p.qlen, p.q, p.tlen, p.t, w, M, X, -I, -E, -D, -E, tr, R);
+	if(!live) return;
+	{ const int32_t r0 = p.tlen - 1, c0 = (r0 + w + 1 < p.qlen ? r0 + w + 1 : p.qlen) - 1; wtz_lane_traceback<true>(true, r0, c0, w, RS, p.t, p.tlen, p.q, p.qlen, tr, runs, R); }
+	wtz_aln_t x; memset(&x, 0, sizeof x);
+	x.score = R.score; x.mat = R.mat; x.mis = R.mis; x.ins = R.ins; x.del = R.del; x.aln = R.mat + R.mis + R.ins + R.del;
 	wtz_cigar_t none; none.a = NULL; none.n = none.cap = 0; none.pool = pool; none.bad = 0;
 	wtz_testdp_store(&res[t], x, true, runs, R.n_runs, none, pool, 64, 0, R.cells);
 }
@@ -165,6 +193,8 @@ extern "C" int wtz_test_dp(wtz_ctx_t *c, int32_t kind, int32_t form, const wtz_d
 			CHK(wtz_launch_coop<K_test_lane>(0, n, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_test_lane((uint32_t)t, d_pr, dP, pool, d_res); }, 0));
 		} else if(kind == WTZ_DP_FIXED){
 			CHK(wtz_launch_coop<K_test_fixed>(0, n, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_test_fixed((uint32_t)t, d_pr, dP, pool, form, d_res); }, WTZ_WINALIGN_LDS_BYTES + WTZ_WINALIGN_QW_BYTES));
+		} else if(form == 64){
+			CHK(wtz_launch_coop<K_test_lane>(0, n, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_test_lane_global((uint32_t)t, d_pr, dP, pool, d_res); }, 0));
 		} else if(form == 33){
 			CHK(wtz_launch_coop<K_test_global_wide>(0, n, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_test_global((uint32_t)t, d_pr, dP, pool, form, (uint32_t)WTZ_GAP_WIDE_LDS_BYTES, d_res); }, WTZ_GAP_WIDE_LDS_BYTES));
 		} else {

@@ -121,7 +121,7 @@ def test_global_forms(vec):
     ctx = make_ctx(vec)
     total = {}
     try:
-        for form in (0, 1, 2, 17, 18, 20, 24, 32, 33, 255):
+        for form in (0, 1, 2, 17, 18, 20, 24, 32, 33, 64, 255):
             out, cigs = ctx.test_dp(hipabi.DP_GLOBAL, form, problems(vec, idx))
             ans = check(vec, idx, out, cigs, 2, form, (lambda c: True) if form in (0, 255) else (lambda c: False))
             total[form] = sum(a for a, _ in ans.values())
@@ -137,5 +137,5 @@ def test_global_forms(vec):
     finally:
         ctx.close()
     assert total[0] == len(idx) and total[255] == len(idx)
-    for form in (1, 2, 17, 18, 20, 24, 32, 33):
+    for form in (1, 2, 17, 18, 20, 24, 32, 33, 64):      # 64 = one lane per gap (wtz_lane_global)
         assert total[form] > 0, "form %d answered nothing" % form
