@@ -51,6 +51,7 @@ static_assert((WTZ_CAND_LDS_BYTES & (WTZ_CAND_LDS_BYTES - 1u)) == 0u && WTZ_CAND
 /* kernel name tags (rocprofv3 shows wtz_kernel_*<K_pair, ...>) */
 struct K_candidates;
 struct K_candidates_stream;
+struct K_candidates_wg;
 struct K_extjob_scalar;
 struct K_cigar_text;
 struct K_misc;
@@ -164,6 +165,19 @@ template<typename TAG, typename F> static int wtz_launch_coop(hipStream_t st, ui
 	HIPCHK(hipGetLastError());
 	return WTZ_OK;
 }
+/* one task per WORKGROUP of NT threads (wave-size multiples): every thread enters the task body (WTZ_WG_TID / WTZ_WG_SYNC inside) */
+template<typename TAG, typename F> __global__ void __launch_bounds__(256) wtz_kernel_wg_tasks(uint64_t n, F f){
+	const uint64_t i = blockIdx.x;
+	if(i < n) f(i);
+}
+template<typename TAG, typename F> static int wtz_launch_wg(uint64_t n, F f, uint32_t nthreads, uint32_t lds_bytes){
+	if(n == 0) return WTZ_OK;
+	if(n > 0x7FFFFFFFull) return wtz_fail(WTZ_E_ARG, "grid too large");
+	if(lds_bytes > 65536u){ HIPCHK(hipFuncSetAttribute((const void*)&wtz_kernel_wg_tasks<TAG, F>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)); }
+	hipLaunchKernelGGL((wtz_kernel_wg_tasks<TAG, F>), dim3((uint32_t)n), dim3(nthreads), lds_bytes, g_stream, n, f);
+	HIPCHK(hipGetLastError());
+	return WTZ_OK;
+}
 /* four tasks per wavefront: one per 16-lane group (wtz_sw_grp.h); f gets the index of the block's first task */
 template<typename TAG, typename F> __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 8))) wtz_kernel_grp_tasks(uint64_t n, F f){
 	const uint64_t i = (uint64_t)blockIdx.x * 4;
@@ -254,6 +268,7 @@ typedef int hipStream_t;
 template<typename TAG, typename F> static int wtz_launch(hipStream_t, uint64_t n, F f){ for(uint64_t i = 0; i < n; i++) f(i); return WTZ_OK; }
 template<typename TAG, typename F> static int wtz_launch_wave(hipStream_t st, uint64_t n, F f){ return wtz_launch<TAG>(st, n, f); }
 template<typename TAG, typename F> static int wtz_launch_coop(hipStream_t st, uint64_t n, F f, uint32_t = 0){ return wtz_launch<TAG>(st, n, f); }
+template<typename TAG, typename F> static int wtz_launch_wg(uint64_t n, F f, uint32_t, uint32_t){ for(uint64_t i = 0; i < n; i++) f(i); return WTZ_OK; }
 static int dev_alloc(void **p, size_t n){ *p = malloc(n ? n : 16); return *p ? WTZ_OK : wtz_fail(WTZ_E_HIP, "malloc(%zu) failed", n); }
 static void dev_free(void *p){ free(p); }
 static int dev_alloc_persist(void **p, size_t n){ return dev_alloc(p, n); }
@@ -323,6 +338,7 @@ struct wtz_ctx {
 	uint32_t *cq_q = NULL, *cq_nc = NULL; uint64_t *cq_cand = NULL; unsigned long long *cq_bytes = NULL; uint32_t cq_cap = 0, cq_n = 0; bool cq_pending = false; wtz_timer cq_tm;
 	wtz_counters_t cnt;
 	uint64_t tpool_peak_call = 0, main_used_call = 0;      /* transient-pool high-water mark / main-pool bytes of the API call in progress */
+	int env_cand_wg = 1;         /* WTZ_CAND_WG=0: the one-wavefront-per-query sorting form of the seed lookup (the form before round 3) */
 	int env_cand_stream = 0;     /* WTZ_CAND_STREAM=1: sort-free candidate accumulation (LDS sketch + survivor table, wtz_seed.h); bit-exact, pays at 25x coverage only: see DESIGN.md */
 	int env_gap_lane = 1;        /* WTZ_GAP_LANE=0: every gap on a wavefront (the form before round 3) */
 	int env_lane = 1;            /* WTZ_WINALIGN_LANE=0: the chained wave-per-window kernel for every window (the form before round 3); 2: run both and compare */
@@ -440,6 +456,7 @@ extern "C" int wtz_ctx_create(int device, const wtz_params_c *params, uint64_t p
 #endif
 	c->env_trace = getenv("WTZ_STAGE_TRACE") != NULL;
 	c->env_cand_stream = (getenv("WTZ_CAND_STREAM") && atoi(getenv("WTZ_CAND_STREAM")) != 0);
+	if(getenv("WTZ_CAND_WG")) c->env_cand_wg = atoi(getenv("WTZ_CAND_WG"));
 	c->env_grp4 = (getenv("WTZ_WINALIGN4") && atoi(getenv("WTZ_WINALIGN4")) != 0);
 	if(getenv("WTZ_WINALIGN_LANE")) c->env_lane = atoi(getenv("WTZ_WINALIGN_LANE"));
 	if(getenv("WTZ_GAP_LANE")) c->env_gap_lane = atoi(getenv("WTZ_GAP_LANE"));
@@ -713,6 +730,17 @@ extern "C" int wtz_candidates_begin(wtz_ctx_t *c, const uint32_t *qids, uint32_t
 	const uint32_t *seeds = c->kseeds; wtz_pool_t *pool = c->dpool;
 	STAGE(c, "K_candidates");
 	c->cq_tm.start();
+	if(c->env_cand_wg && !c->env_cand_stream){
+		/* one workgroup per query: partition by target read, sort each bucket in LDS (wtz_task_candidates_wg) */
+		const uint32_t key_hi = c->idx_end << 1;
+#ifdef WTZ_EMUL
+		static thread_local uint32_t emul_cwg_lds[WTZ_CWG_LDS_BYTES / 4 + 16];
+		uint32_t *lds_emul = emul_cwg_lds;
+		CHK(wtz_launch_wg<K_candidates_wg>(nq, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_candidates_wg((uint32_t)t, R, d_q, dP, tab, kmask, seeds, pool, d_cand, d_n, stride, d_bytes, lds_emul, d_thr, key_hi); }, 1u, 0u));
+#else
+		CHK(wtz_launch_wg<K_candidates_wg>(nq, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_candidates_wg((uint32_t)t, R, d_q, dP, tab, kmask, seeds, pool, d_cand, d_n, stride, d_bytes, (uint32_t*)wtz_wave_scratch(), d_thr, key_hi); }, WTZ_CWG_THREADS, WTZ_CWG_LDS_BYTES));
+#endif
+	} else
 #ifndef WTZ_EMUL
 	{
 		/* LDS per wave: the group table + output list + heap row of the streaming form (the sorting form of a query with too many groups

@@ -593,6 +593,262 @@ WTZ_D bool wtz_cand_stream(uint32_t t, const wtz_reads_t &R, uint32_t pbid, uint
 }
 #endif
 
+/* ================= K-seed, workgroup form: partition by target read, sort each bucket in LDS =================
+ *
+ * What the numbers of configs[2] say (tools/analysis/seedstats.c, 100x coverage of a 12 Mbp genome): a query of 15-50 kb has 3-10 k sampled
+ * k-mers that hit, 100-340 k seed entries (tuples), and 60-160 k DISTINCT (read, strand) groups of which only 100-650 reach -d: the
+ * hp-compressed 16-mers of a 12 Mbp genome collide by chance, so nearly every group is a chance hit of one or two k-mers.  One wavefront
+ * per query ordered all tuples with a bitonic network through a 16 KB LDS window: ~700 bytes of HBM traffic per 4-byte seed entry (PMC:
+ * 830 GB per step against 5 GB algorithmic), 0.1 % of the HBM roof.  No LDS table can hold 100 k groups, and a sketch in front of it
+ * saturates at that density (the streaming form above fell back for a third of the long queries).
+ *
+ * This form moves every tuple through HBM exactly once, as an MSD radix step by target read:
+ *   A  the workgroup's threads walk one piece of the read each and list its sampled k-mers (exact restart: wtz_walk_warm_start)
+ *   B  one hash probe per k-mer: seed run (start, length)
+ *   H  histogram of the tuples over 4096 bins of the target key (read << 1 | strand), in LDS; self hits and reads longer than 1.2 x
+ *      the query are dropped here (wtzmo.c:488-489)
+ *   S  exclusive scan -> bin offsets; second pass over the runs scatters (key << 32 | k-mer index) into the pool: the bins come out
+ *      contiguous and in key order
+ *   P  consecutive bins are grouped into buckets of <= WTZ_CWG_CAP tuples; each bucket is sorted in LDS (bitonic, by key then k-mer
+ *      index = query-offset order, the order the reference's k-way merge delivers a group in, wtzmo.c:44-57); then the union-length
+ *      recurrence of wtzmo.c:558-560 - ol += (qoff >= lst) ? len : qoff + len - lst; lst = qoff + len - is evaluated WITHOUT a serial
+ *      walk: after the first tuple lst is simply the end of the previous tuple, so every tuple's addend depends on its predecessor only
+ *      and ol is a segmented sum (u32 arithmetic like the reference's, the wrap-around of a "negative" addend included)
+ *   F  thread 0 replays strand merge + candidate heap with its quirks over the groups that reach -d (wtz_cand_tail), unchanged.
+ * HBM traffic per tuple: 4 B seed entry read twice, 8 B written and read once: ~24 B instead of ~700.
+ */
+#define WTZ_CWG_THREADS 256u
+#define WTZ_CWG_BINS 4096u
+#define WTZ_CWG_CAP 2048u
+#define WTZ_CWG_LDS_BYTES (WTZ_CWG_BINS * 4u + WTZ_CWG_CAP * 8u + 2u * WTZ_CWG_CAP * 4u + 64u * 4u)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define WTZ_WG_TID ((uint32_t)threadIdx.x)
+#define WTZ_WG_N ((uint32_t)blockDim.x)
+#define WTZ_WG_SYNC() __syncthreads()
+#define WTZ_LDS_ADD32(p, v) atomicAdd((p), (v))
+#else
+#define WTZ_WG_TID 0u
+#define WTZ_WG_N 1u
+#define WTZ_WG_SYNC() do {} while(0)
+static inline uint32_t wtz_lds_add32_host(uint32_t *p, uint32_t v){ const uint32_t o = *p; *p += v; return o; }
+#define WTZ_LDS_ADD32(p, v) wtz_lds_add32_host((p), (v))
+#endif
+/* exclusive prefix sum of one value per thread over the workgroup (tmp: 64 LDS words), *total = the sum */
+WTZ_HD uint32_t wtz_wg_excl_scan(uint32_t v, uint32_t *tmp, uint32_t *total){
+#if defined(__HIP_DEVICE_COMPILE__)
+	uint32_t wtot; const uint32_t ex = wtz_coop_excl_scan(v, &wtot);
+	const uint32_t wv = threadIdx.x >> 6, nw = (blockDim.x + 63u) >> 6;
+	__syncthreads();
+	if((threadIdx.x & 63u) == 0) tmp[wv] = wtot;
+	__syncthreads();
+	uint32_t base = 0, tot = 0;
+	for(uint32_t k = 0; k < nw; k++){ const uint32_t x = tmp[k]; if(k < wv) base += x; tot += x; }
+	*total = tot;
+	return base + ex;
+#else
+	(void)tmp; *total = v; return 0;
+#endif
+}
+/* bitonic sort of np (power of two) u64 words in LDS by the whole workgroup */
+WTZ_HD void wtz_wg_sort_u64(uint64_t *a, uint32_t np){
+#if defined(__HIP_DEVICE_COMPILE__)
+	const uint32_t tid = threadIdx.x, nt = blockDim.x;
+	for(uint32_t k = 2; k <= np; k <<= 1){
+		for(uint32_t j = k >> 1; j > 0; j >>= 1){
+			__syncthreads();
+			for(uint32_t t = tid; t < np / 2; t += nt){
+				const uint32_t i = ((t / j) * (j << 1)) + (t % j);
+				const uint64_t x = a[i], y = a[i + j];
+				const bool asc = ((i & k) == 0);
+				if((x > y) == asc){ a[i] = y; a[i + j] = x; }
+			}
+		}
+	}
+	__syncthreads();
+#else
+	wtz_heapsort_u64(a, np);
+#endif
+}
+
+typedef struct { uint32_t qoff, qlen; } wtz_kq_t;
+struct wtz_kq2_f { uint64_t *mer; wtz_kq_t *kq; uint32_t n;
+	WTZ_HDM void operator()(uint64_t m, uint32_t, uint32_t qo, uint32_t qe){ uint32_t l = qe - qo; if(l > 0xFFFFu) l = 0xFFFFu; mer[n] = m; kq[n].qoff = qo; kq[n].qlen = l; n++; } };
+
+WTZ_HD void wtz_task_candidates_wg(uint32_t t, wtz_reads_t R, const uint32_t *qids, const wtz_params_t *P,
+		const wtz_kslot_t *tab, uint64_t tmask, const uint32_t *seeds, wtz_pool_t *pool, uint64_t *cand_out, uint32_t *ncand_out, uint32_t stride,
+		unsigned long long *algo_bytes, uint32_t *lds, const uint32_t *id_thr, uint32_t key_hi){
+	const uint32_t tid = WTZ_WG_TID, nt = WTZ_WG_N;
+	const uint32_t pbid = qids[t], L = R.rdlen[pbid];
+	const uint32_t pblen_up = (uint32_t)(L * 1.2);                       /* double multiply, wtzmo.c:445 */
+	const uint32_t thr = id_thr ? id_thr[t] : 0xFFFFFFFFu;              /* indexed reads in non-increasing length order: "longer than 1.2 x" is "id below thr" */
+	uint32_t *hist = lds;                                                /* WTZ_CWG_BINS counters / cursors, later the per-group sums */
+	uint64_t *sbuf = (uint64_t*)(lds + WTZ_CWG_BINS);                    /* WTZ_CWG_CAP sort slots */
+	uint32_t *ends = lds + WTZ_CWG_BINS + 2u * WTZ_CWG_CAP;              /* end / start of the tuple at each sorted position: 2 x CAP words */
+	uint32_t *tmp = ends + 2u * WTZ_CWG_CAP;                             /* 64 words of scan / broadcast scratch */
+	/* ---- A: the read's sampled k-mers ---- */
+	if(tid == 0){
+		const uint64_t pa = (uint64_t)(uintptr_t)wtz_pool_alloc(pool, (size_t)(L + 2) * 24);
+		tmp[60] = (uint32_t)pa; tmp[61] = (uint32_t)(pa >> 32);
+	}
+	WTZ_WG_SYNC();
+	uint8_t *mem = (uint8_t*)(uintptr_t)(((uint64_t)tmp[61] << 32) | tmp[60]);
+	if(mem == NULL){ if(tid == 0) ncand_out[t] = 0xFFFFFFFFu; return; }
+	uint64_t *kmer = (uint64_t*)mem; wtz_kq_t *kq = (wtz_kq_t*)(mem + (size_t)(L + 2) * 8); uint64_t *koff = (uint64_t*)(mem + (size_t)(L + 2) * 16);
+	uint32_t nk;
+	{
+		const uint32_t PL = (L + nt - 1) / nt;
+		const uint32_t jb = tid * PL, je = jb + PL;
+		uint32_t cnt = 0;
+		if(jb < L || (tid == 0 && L == 0)){ wtz_kcount_f fc; fc.n = 0; wtz_kmer_walk(R, pbid, P->ksize, P->hk, P->ksave, fc, jb, je); cnt = fc.n; }
+		const uint32_t ex = wtz_wg_excl_scan(cnt, tmp, &nk);
+		if(cnt){ wtz_kq2_f f; f.mer = kmer; f.kq = kq; f.n = ex; wtz_kmer_walk(R, pbid, P->ksize, P->hk, P->ksave, f, jb, je); }
+	}
+	WTZ_WG_SYNC();
+	/* ---- B + H: probe, histogram of the kept tuples over the key bins ---- */
+	const uint32_t key_lo = thr != 0xFFFFFFFFu ? thr << 1 : 0u;
+	uint32_t shift = 0; while(((key_hi > key_lo ? key_hi - key_lo : 1u) >> shift) > WTZ_CWG_BINS - 1u) shift++;
+	for(uint32_t i = tid; i < WTZ_CWG_BINS; i += nt) hist[i] = 0;
+	WTZ_WG_SYNC();
+	unsigned long long my_T = 0;
+	for(uint32_t e = tid; e < nk; e += nt){
+		uint64_t o = 0; uint32_t c = 0;
+		if(!wtz_kprobe(tab, tmask, kmer[e], &o, &c)){ o = 0; c = 0; }
+		koff[e] = (o << 16) | c;
+		my_T += c;
+		for(uint32_t k = 0; k < c; k++){
+			const uint32_t sd = seeds[o + k];
+			const bool drop = ((sd >> 1) == pbid) || (thr != 0xFFFFFFFFu ? (sd >> 1) < thr : R.rdlen[sd >> 1] > pblen_up);      /* wtzmo.c:488-489 */
+			if(!drop) WTZ_LDS_ADD32(&hist[(sd - key_lo) >> shift], 1u);
+		}
+	}
+	{   /* algorithmic bytes of this query */
+		uint32_t tot_lo; const uint32_t dummy = wtz_wg_excl_scan((uint32_t)my_T, tmp, &tot_lo); (void)dummy;
+		if(tid == 0){
+			const unsigned long long bytes = (unsigned long long)L / 4 + 16ull * nk + 4ull * tot_lo;
+#if defined(__HIP_DEVICE_COMPILE__)
+			atomicAdd(algo_bytes, bytes);
+#else
+			*algo_bytes += bytes;
+#endif
+		}
+	}
+	WTZ_WG_SYNC();
+	/* ---- S: bin offsets, buckets, scatter ---- */
+	uint32_t Tk = 0;
+	{
+		const uint32_t per = WTZ_CWG_BINS / nt ? WTZ_CWG_BINS / nt : WTZ_CWG_BINS;      /* bins per thread (host emulation: all of them) */
+		uint32_t loc = 0;
+		for(uint32_t i = 0; i < per; i++) if(tid * per + i < WTZ_CWG_BINS) loc += hist[tid * per + i];
+		uint32_t run = wtz_wg_excl_scan(loc, tmp, &Tk);
+		WTZ_WG_SYNC();
+		for(uint32_t i = 0; i < per; i++) if(tid * per + i < WTZ_CWG_BINS){ const uint32_t v = hist[tid * per + i]; hist[tid * per + i] = run; run += v; }
+	}
+	WTZ_WG_SYNC();
+	if(tid == 0){
+		const uint64_t pa = Tk ? (uint64_t)(uintptr_t)wtz_pool_alloc(pool, ((size_t)Tk + 2) * 16) : 1ull;
+		tmp[60] = (uint32_t)pa; tmp[61] = (uint32_t)(pa >> 32);
+	}
+	WTZ_WG_SYNC();
+	uint64_t *tup = (uint64_t*)(uintptr_t)(((uint64_t)tmp[61] << 32) | tmp[60]);
+	if(tup == NULL){ if(tid == 0) ncand_out[t] = 0xFFFFFFFFu; return; }
+	uint64_t *grp = tup + ((size_t)Tk + 2);                                          /* groups that reach -d, in key order (at most one per tuple) */
+	const uint32_t grp_cap = Tk + 2;
+	for(uint32_t e = tid; e < nk; e += nt){
+		const uint32_t c = (uint32_t)(koff[e] & 0xFFFFu); const uint64_t o = koff[e] >> 16;
+		for(uint32_t k = 0; k < c; k++){
+			const uint32_t sd = seeds[o + k];
+			const bool drop = ((sd >> 1) == pbid) || (thr != 0xFFFFFFFFu ? (sd >> 1) < thr : R.rdlen[sd >> 1] > pblen_up);
+			if(!drop){ const uint32_t pos = WTZ_LDS_ADD32(&hist[(sd - key_lo) >> shift], 1u); tup[pos] = ((uint64_t)sd << 32) | e; }
+		}
+	}
+#if defined(__HIP_DEVICE_COMPILE__)
+	__threadfence_block();
+#endif
+	WTZ_WG_SYNC();
+	/* ---- P: per bucket: sort, then the union length of every group ---- */
+	uint32_t ng = 0; int over = 0;
+	const uint32_t kovl = P->kovl;
+	/* buckets = consecutive bins while their tuples fit the sort slots (a bin above CAP is a bucket of its own); after the scatter a bin's cursor
+	 * stands at the start of the next bin, so bin b covers [hist[b - 1], hist[b]) */
+	for(uint32_t bin0 = 0; bin0 < WTZ_CWG_BINS; ){
+		if(tid == 0){
+			const uint32_t s0 = bin0 ? hist[bin0 - 1] : 0u;
+			uint32_t b1 = bin0 + 1;
+			while(b1 < WTZ_CWG_BINS && hist[b1] - s0 <= WTZ_CWG_CAP) b1++;
+			tmp[62] = b1;
+		}
+		WTZ_WG_SYNC();
+		const uint32_t bin1 = tmp[62];
+		const uint32_t t0 = bin0 ? hist[bin0 - 1] : 0u, t1 = hist[bin1 - 1];
+		WTZ_WG_SYNC();
+		bin0 = bin1;
+		const uint32_t n = t1 - t0;
+		if(n == 0) continue;
+		uint64_t *srt = sbuf; uint32_t *en = ends, *qo = ends + WTZ_CWG_CAP;
+		uint32_t np = 64; while(np < n) np <<= 1;
+		if(n > WTZ_CWG_CAP){
+			/* one bin alone holds more than CAP tuples (a read that shares thousands of k-mers with the query: duplicates, repeats): same steps on
+			 * arrays in the pool */
+			if(tid == 0){
+				const uint64_t pa = (uint64_t)(uintptr_t)wtz_pool_alloc(pool, (size_t)np * 16);
+				tmp[60] = (uint32_t)pa; tmp[61] = (uint32_t)(pa >> 32);
+			}
+			WTZ_WG_SYNC();
+			srt = (uint64_t*)(uintptr_t)(((uint64_t)tmp[61] << 32) | tmp[60]);
+			if(srt == NULL){ over = 1; break; }
+			en = (uint32_t*)(srt + np); qo = en + np;
+		}
+		for(uint32_t i = tid; i < np; i += nt) srt[i] = i < n ? tup[t0 + i] : ~0ull;
+#if defined(__HIP_DEVICE_COMPILE__)
+		__threadfence_block();
+#endif
+		WTZ_WG_SYNC();
+		wtz_wg_sort_u64(srt, np);
+		/* query interval of every tuple in sorted order: the walk below then touches LDS only */
+		for(uint32_t i = tid; i < n; i += nt){ const wtz_kq_t q = kq[(uint32_t)srt[i]]; qo[i] = q.qoff; en[i] = q.qoff + q.qlen; }
+#if defined(__HIP_DEVICE_COMPILE__)
+		__threadfence_block();
+#endif
+		WTZ_WG_SYNC();
+		/* the thread at a group's first tuple folds the group (wtzmo.c:558-560); nearly all groups have one or two tuples, the real overlaps a few
+		 * hundred; groups with ol >= -d are appended in key order */
+		for(uint32_t i0 = 0; i0 < n; i0 += nt){
+			const uint32_t i = i0 + tid;
+			uint32_t keep = 0; uint64_t g = 0;
+			if(i < n){
+				const uint32_t key = (uint32_t)(srt[i] >> 32);
+				if(i == 0 || (uint32_t)(srt[i - 1] >> 32) != key){
+					uint32_t ol = 0, lst = 0;
+					for(uint32_t r = i; r < n && (uint32_t)(srt[r] >> 32) == key; r++){
+						const uint32_t q0 = qo[r], e1 = en[r];
+						if(q0 >= lst) ol += e1 - q0; else ol += e1 - lst;       /* wtzmo.c:558-559: len, or off + len - lst (u32 arithmetic) */
+						lst = e1;
+					}
+					if(ol >= kovl){ keep = 1; g = ((uint64_t)key << 32) | ol; }
+				}
+			}
+			uint32_t chunk; const uint32_t ex = wtz_wg_excl_scan(keep, tmp, &chunk);
+			if(keep){ if(ng + ex < grp_cap) grp[ng + ex] = g; else over = 1; }
+			ng += chunk;
+		}
+		WTZ_WG_SYNC();
+	}
+#if defined(__HIP_DEVICE_COMPILE__)
+	over = __syncthreads_or(over);
+#endif
+	if(over || ng > grp_cap){ if(tid == 0) ncand_out[t] = 0xFFFFFFFFu; return; }
+#if defined(__HIP_DEVICE_COMPILE__)
+	__threadfence_block();
+#endif
+	WTZ_WG_SYNC();
+	/* ---- F ---- */
+	if(tid == 0){
+		uint32_t hn = ncand_out[t];                 /* heap carried across index parts (-G), 0 otherwise */
+		wtz_cand_tail(grp, ng, kovl, P->ncand, cand_out + (size_t)t * stride, &hn);
+		ncand_out[t] = hn;
+	}
+}
+
 struct wtz_kq_f { uint64_t *mer; uint32_t *qoff, *qlen; uint32_t n;
 	WTZ_HDM void operator()(uint64_t m, uint32_t, uint32_t qo, uint32_t qe){ uint32_t l = qe - qo; if(l > 0xFFFFu) l = 0xFFFFu; mer[n] = m; qoff[n] = qo; qlen[n] = l; n++; } };
 

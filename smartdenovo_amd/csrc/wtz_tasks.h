@@ -525,7 +525,6 @@ WTZ_HD void wtz_task_lfold(uint32_t t, const wtz_env_t &V, const wtz_wintask_t *
 		#pragma unroll
 		for(uint32_t j = 0; j < 2; j++){
 			if(u0 + j >= n_used || stop) break;
-			const uint32_t k = KK[j];
 			const wtz_lprob_t pr = PR[j];
 			if(pr.qlen < 0) continue;
 			const wtz_zhit_t p = AN[j];
