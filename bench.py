@@ -237,6 +237,7 @@ def main():
     ms_ext = float(last[15])
     ms_gap = float(last[19]) if len(last) > 19 else 0.0
     n_ranges, n_split = (int(last[20]), int(last[21])) if len(last) > 21 else (0, 0)
+    zmer_bytes = int(last[22]) if len(last) > 22 else 0
 
     def valu_roofline(kernel, cells, ms_k, extra=None):
         ach = cells * OPS_PER_CELL / (ms_k * 1e-3) / 1e12 if ms_k > 0 else None
@@ -261,22 +262,33 @@ def main():
         "roofline": valu_roofline("K-sw3 shifting-band extension (kswx_extend_align_shift_core), DP rows in registers: wtz_kernel_extjobs_mw (four wavefronts per long "
                                   "job, side stream) || wtz_kernel_extjobs_reg (one wavefront per short job); time = HIP events around the launches of the stage",
                                   cells_shift, ms_ext, {"backtrack_GBps": cells_shift / (ms_ext * 1e-3) / 1e9 if ms_ext > 0 else None}),
-        "roofline_sw1": valu_roofline("K-sw1 fixed-band extension between anchors (kswx_extend_align_core) inside wtz_kernel_coop_tasks<K_winalign>; the kernel time "
-                                      "includes the z-mer run alignment and the CIGAR assembly of each window", cells_fixed, ms["winalign"]),
-        "roofline_sw2": valu_roofline("K-sw2 global banded alignment of the gaps between windows (ksw_global2 incl. every band-doubling call) in "
-                                      "wtz_kernel_coop_tasks<K_gap> (+ K_gap_wide)", cells_global, ms_gap),
-        "roofline_seed": {"kernel": "wtz_kernel_coop_tasks<K_candidates> (hzm seed lookup + candidate heap)", "bound": "hbm",
+        "roofline_sw1": valu_roofline("K-sw1 fixed-band extension between anchors (kswx_extend_align_core), one LANE per problem: K_lplan -> K_ldp (register DP, relative mode) -> "
+                                      "K_ltb (traceback) -> K_lfold (score chain, z-mer runs, CIGAR) + the chained wave kernel for the windows the fold leaves; the time is the whole stage's", cells_fixed, ms["winalign"]),
+        "roofline_sw2": valu_roofline("K-sw2 global banded alignment of the gaps between windows (ksw_global2 incl. every band-doubling call): one lane per gap (K_gplan / K_gdp / K_gtb), "
+                                      "the rest in wtz_kernel_coop_tasks<K_gap> (+ K_gap_wide)", cells_global, ms_gap),
+        "roofline_zmer": {"kernel": "wtz_kernel_coop_tasks<K_pair> (z-mer matching hzm_aln.h:173-224 + windows / chain or dot-matrix per pair; the time is the whole kernel's)", "bound": "hbm",
+                          "achieved": zmer_bytes / (ms["pairs"] * 1e-3) / 1e9 if ms["pairs"] > 0 else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                          "frac": (zmer_bytes / (ms["pairs"] * 1e-3) / 1e9 / HBM_PEAK_GBS) if ms["pairs"] > 0 else None,
+                          "algorithmic_bytes_per_step": zmer_bytes, "kernel_ms_per_step": ms["pairs"], "traffic": None},
+        "roofline_seed": {"kernel": "wtz_kernel_wg_tasks<K_candidates_wg> (hzm seed lookup: one workgroup per query, tuples partitioned by target read, per-bucket LDS sort, candidate heap)", "bound": "hbm",
                           "achieved": seed_bytes / (ms["candidates"] * 1e-3) / 1e9 if ms["candidates"] > 0 else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                           "frac": (seed_bytes / (ms["candidates"] * 1e-3) / 1e9 / HBM_PEAK_GBS) if ms["candidates"] > 0 else None,
                           "algorithmic_bytes_per_step": seed_bytes, "kernel_ms_per_step": ms["candidates"], "traffic": None},
     }
+    # the nominal peak above is SURVEY 8d's formula (CUs x lanes x clock); what gfx950 ISSUES was measured with tools/ubench/valu_int32.hip
+    # (profiles/r03_valu_int32_ubench.txt): v_add / v_sub ~60 Tlane-op/s, v_max_i32 / v_alignbit / v_mad_i32_i24 / v_lshl_or ~36.6 (half rate)
+    for key in ("roofline", "roofline_sw1", "roofline_sw2"):
+        res[key]["peak_measured_Tops"] = {"v_add_u32": 63.5, "v_max_i32": 36.6}
+    if a.engine == "dmo":       # no banded SW in the dot-matrix engine (SURVEY finding 2): its dominant kernel is K_pair, priced against HBM
+        res["roofline"] = dict(res["roofline_zmer"])
     # HBM traffic: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command with --steps 1 --warmup 0 (so totals are per step),
     # condensed by tools/summarize_profiles.py into profiles/ (FETCH_SIZE doubled as the gfx950 guide says).  `traffic` is per LAUNCH like
     # `achieved` (total / dispatches), `traffic_per_step` the total next to the per-step algorithmic bytes.
     try:
         import csv
-        src = os.path.join(ROOT, "profiles", "r02_%s_%s_pmc_per_kernel.csv" % (a.workload, a.engine))
-        kmap = {"wtz_kernel_extjobs_reg": "roofline", "wtz_kernel_extjobs_mw": "roofline", "K_winalign": "roofline_sw1", "K_gap": "roofline_sw2", "K_candidates": "roofline_seed"}
+        src = os.path.join(ROOT, "profiles", "r03_%s_%s_pmc_per_kernel.csv" % (a.workload, a.engine))
+        kmap = {"wtz_kernel_extjobs_reg": "roofline", "wtz_kernel_extjobs_mw": "roofline", "K_winalign": "roofline_sw1", "K_ldp": "roofline_sw1", "K_ltb": "roofline_sw1", "K_lfold": "roofline_sw1", "K_lplan": "roofline_sw1",
+                "K_gap": "roofline_sw2", "K_gdp": "roofline_sw2", "K_gtb": "roofline_sw2", "K_candidates_wg": "roofline_seed", "K_candidates": "roofline_seed", "K_pair": "roofline_zmer", "K_pair_big": "roofline_zmer"}
         for row in csv.DictReader(open(src)):
             key = kmap.get(row["kernel"])
             if key is None:
@@ -285,8 +297,8 @@ def main():
             R = res[key]
             R["traffic_per_step"] = (R.get("traffic_per_step") or 0.0) + tot
             R["traffic"] = (R["traffic"] or 0.0) + tot / max(1, int(row["dispatches"]))
-            R["traffic_note"] = "PMC (2 x FETCH_SIZE + WRITE_SIZE) from %s" % os.path.relpath(src, ROOT)
-            if key != "roofline_seed" and row.get("SQ_INSTS_VALU") and R["kernel_ms_per_step"] > 0:
+            R["traffic_note"] = "PMC (2 x FETCH_SIZE + WRITE_SIZE) of a --steps 1 run of this command, read from %s (not measured in this run)" % os.path.relpath(src, ROOT)
+            if key not in ("roofline_seed", "roofline_zmer") and row.get("SQ_INSTS_VALU") and R["kernel_ms_per_step"] > 0:
                 # wave-level VALU instructions of one step x 2 issue cycles on a SIMD-32 / SIMD-cycles of the live kernel time
                 R["valu_issue_frac_pmc"] = (R.get("valu_issue_frac_pmc") or 0.0) + float(row["SQ_INSTS_VALU"]) * 2.0 / (R["kernel_ms_per_step"] * 1e-3 * 2.4e9 * 256 * 4)
         for key in ("roofline", "roofline_sw1", "roofline_sw2"):

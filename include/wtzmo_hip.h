@@ -91,6 +91,7 @@ typedef struct {
 	double   ms_ext;                                                                  /* K-sw3 wave kernel alone (inside ms_stitch) */
 	uint64_t n_extjobs;
 	double   ms_gap;                                                                  /* K-sw2 gap kernels alone (inside ms_stitch) */
+	uint64_t bytes_zmer_algo;                                                         /* algorithmic bytes of z-mer matching: candidate L/4 + 16 B per emitted match (hzm_aln.h:173-224) */
 } wtz_counters_t;
 
 const char *wtz_last_error(void);

@@ -89,7 +89,7 @@ typedef struct eng_s {
 	char *cig_keep[16]; uint64_t cig_keep_cap[16];      /* page-locked CIGAR text buffer of worker w, kept across steps (pinning is the expensive part) */
 	double t_gpu, t_commit, t_call[6], t_io[2];      /* t_io: waiting for the writer thread before a text buffer is reused / at the end of the run */      /* t_call: wall seconds inside wtz_candidates / pairs_seed / pairs_windows / pairs_align / fetch_cigar_text / planning */
 	uint64_t spec_pairs, used_pairs, spec_items, used_items, spec_queries, used_queries, n_batches;
-	double extra_ms[6]; uint64_t extra_u64[6];      /* counters of the cloned contexts */
+	double extra_ms[6]; uint64_t extra_u64[7];      /* counters of the cloned contexts */
 } eng_t;
 
 /* ---- ranks: with one process per GPU (torchrun; bench.py / tests set the exchange hooks through wtzmo_set_dist) the parts of rank 0's
@@ -1240,7 +1240,7 @@ int main(int argc, char **argv){
 					if((w || d) && pt->ctx){      /* counters of the other contexts: work adds up, kernel times of parallel devices do not (the longest counts) */
 						wtz_counters_t cw; wtz_get_counters(pt->ctx, &cw);
 						if(w){ E->extra_ms[0] += cw.ms_candidates; E->extra_ms[1] += cw.ms_pairs; E->extra_ms[2] += cw.ms_winalign; E->extra_ms[3] += cw.ms_stitch; E->extra_ms[4] += cw.ms_ext; E->extra_ms[5] += cw.ms_gap; }
-						E->extra_u64[0] += cw.cells_shift; E->extra_u64[1] += cw.cells_fixed; E->extra_u64[2] += cw.cells_global; E->extra_u64[3] += cw.bytes_seed_algo; E->extra_u64[4] += cw.n_extjobs;
+						E->extra_u64[0] += cw.cells_shift; E->extra_u64[1] += cw.cells_fixed; E->extra_u64[2] += cw.cells_global; E->extra_u64[3] += cw.bytes_seed_algo; E->extra_u64[4] += cw.n_extjobs; E->extra_u64[6] += cw.bytes_zmer_algo;
 						if(cw.pool_peak > E->extra_u64[5]) E->extra_u64[5] = cw.pool_peak;
 						if(w) wtz_ctx_destroy(pt->ctx); else wtz_reset_counters(pt->ctx);
 					}
@@ -1260,7 +1260,7 @@ int main(int argc, char **argv){
 		if(g_hook) g_hook(rep, 1);
 		wtz_counters_t cn; wtz_get_counters(E->ctx, &cn);
 		cn.ms_candidates += E->extra_ms[0]; cn.ms_pairs += E->extra_ms[1]; cn.ms_winalign += E->extra_ms[2]; cn.ms_stitch += E->extra_ms[3]; cn.ms_ext += E->extra_ms[4]; cn.ms_gap += E->extra_ms[5];
-		cn.cells_shift += E->extra_u64[0]; cn.cells_fixed += E->extra_u64[1]; cn.cells_global += E->extra_u64[2]; cn.bytes_seed_algo += E->extra_u64[3]; cn.n_extjobs += E->extra_u64[4];
+		cn.cells_shift += E->extra_u64[0]; cn.cells_fixed += E->extra_u64[1]; cn.cells_global += E->extra_u64[2]; cn.bytes_seed_algo += E->extra_u64[3]; cn.n_extjobs += E->extra_u64[4]; cn.bytes_zmer_algo += E->extra_u64[6];
 		if(E->extra_u64[5] > cn.pool_peak) cn.pool_peak = E->extra_u64[5];
 		memset(E->extra_ms, 0, sizeof E->extra_ms); memset(E->extra_u64, 0, sizeof E->extra_u64);
 		fprintf(stderr, "[wtzmo-mi355x] %llu records, %llu pairs aligned, %llu pair-bp, %.3f s (index %.3f s)\n", (unsigned long long)E->nrec, (unsigned long long)E->n_pairs, (unsigned long long)E->pair_bp, t1 - t0, t_index);
@@ -1271,9 +1271,9 @@ int main(int argc, char **argv){
 			(unsigned long long)E->n_batches, (unsigned long long)E->n_ranges, E->rows_all ? 1u : E->n_workers, (unsigned long long)E->used_queries, (unsigned long long)E->spec_queries, (unsigned long long)E->used_pairs, (unsigned long long)E->spec_pairs, (unsigned long long)E->used_items, (unsigned long long)E->spec_items);
 		fprintf(stderr, "[wtzmo-mi355x] kernel ms: index %.1f zindex %.1f candidates %.1f pairs %.1f winalign %.1f stitch %.1f (K-sw3 wave %.1f, K-sw2 gaps %.1f); cells shift %llu fixed %llu global %llu; pool peak %.2f GB\n",
 			cn.ms_index, cn.ms_zindex, cn.ms_candidates, cn.ms_pairs, cn.ms_winalign, cn.ms_stitch, cn.ms_ext, cn.ms_gap, (unsigned long long)cn.cells_shift, (unsigned long long)cn.cells_fixed, (unsigned long long)cn.cells_global, cn.pool_peak / 1073741824.0);
-		if(statsf){ FILE *sf = fopen(statsf, "a"); if(sf){ fprintf(sf, "%llu\t%llu\t%.6f\t%.6f\t%.3f\t%.3f\t%.3f\t%.3f\t%.3f\t%.3f\t%llu\t%llu\t%llu\t%llu\t%llu\t%.3f\t%llu\t%llu\t%llu\t%.3f\t%llu\t%llu\n", (unsigned long long)E->n_pairs, (unsigned long long)E->pair_bp, t1 - t0, t_index,
+		if(statsf){ FILE *sf = fopen(statsf, "a"); if(sf){ fprintf(sf, "%llu\t%llu\t%.6f\t%.6f\t%.3f\t%.3f\t%.3f\t%.3f\t%.3f\t%.3f\t%llu\t%llu\t%llu\t%llu\t%llu\t%.3f\t%llu\t%llu\t%llu\t%.3f\t%llu\t%llu\t%llu\n", (unsigned long long)E->n_pairs, (unsigned long long)E->pair_bp, t1 - t0, t_index,
 				cn.ms_index, cn.ms_zindex, cn.ms_candidates, cn.ms_pairs, cn.ms_winalign, cn.ms_stitch, (unsigned long long)cn.cells_shift, (unsigned long long)cn.cells_fixed, (unsigned long long)cn.cells_global, (unsigned long long)cn.bytes_seed_algo, (unsigned long long)E->nrec,
-				cn.ms_ext, (unsigned long long)cn.n_extjobs, (unsigned long long)E->used_queries, (unsigned long long)cn.pool_peak, cn.ms_gap, (unsigned long long)E->n_ranges, (unsigned long long)E->n_split); fclose(sf); } }
+				cn.ms_ext, (unsigned long long)cn.n_extjobs, (unsigned long long)E->used_queries, (unsigned long long)cn.pool_peak, cn.ms_gap, (unsigned long long)E->n_ranges, (unsigned long long)E->n_split, (unsigned long long)cn.bytes_zmer_algo); fclose(sf); } }
 	}
 	stale_join(&stale_job); if(stale_job.pending) unlink(stale_job.path);
 	free(stale_job.path);

@@ -873,6 +873,7 @@ extern "C" int wtz_pairs_seed(wtz_ctx_t *c, const uint32_t *qid, const uint32_t 
 		}
 	}
 	c->cnt.ms_pairs += tm.stop(); c->cnt.n_pairs += n;
+	for(uint32_t i = 0; i < n; i++) c->cnt.bytes_zmer_algo += (uint64_t)c->h_rdlen[cid[i]] / 4 + 16ull * c->h_pairres[i].n_hits;
 	CHK(pool_check(c, "wtz_pairs_seed"));
 	if(c->env_profile){
 		uint64_t sum[4] = {0, 0, 0, 0}; uint32_t mx[4] = {0, 0, 0, 0}, arg = 0;

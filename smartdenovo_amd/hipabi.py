@@ -67,7 +67,7 @@ class Counters(C.Structure):
     _fields_ = [(n, C.c_double) for n in ("ms_index", "ms_zindex", "ms_candidates", "ms_pairs", "ms_winalign", "ms_stitch")] + \
                [(n, C.c_uint64) for n in ("n_candidates_q", "n_pairs", "n_winalign", "n_stitch", "cells_shift", "cells_fixed",
                                           "cells_global", "bytes_seed_algo", "pool_peak")] + \
-               [("ms_ext", C.c_double), ("n_extjobs", C.c_uint64), ("ms_gap", C.c_double)]
+               [("ms_ext", C.c_double), ("n_extjobs", C.c_uint64), ("ms_gap", C.c_double), ("bytes_zmer_algo", C.c_uint64)]
 
 
 def load(path: str | None = None) -> C.CDLL:
