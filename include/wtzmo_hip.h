@@ -110,6 +110,25 @@ int  wtz_upload_reads(wtz_ctx_t *ctx, const uint64_t *bits, uint64_t n_words, co
 /* A2 over read ids [id_beg, id_end). *max_kmer_freq: in = -K (0/1 = auto), out = resolved cutoff. */
 int  wtz_index_build(wtz_ctx_t *ctx, uint32_t id_beg, uint32_t id_end, uint32_t *max_kmer_freq, wtz_index_stats_t *stats);
 
+/* ---- k-mer index SHARDED by read-id range over several contexts (BASELINE configs[4]; the reference's -G splits the index the
+ * same way, wtzmo.c:1281-1285, but filters each part by its own counts).  To equal the UNSHARDED output the frequency filter (cnt > K or
+ * cnt <= 1, wtzmo.c:401-405) and the automatic cutoff (wtzmo.c:380-393) must see the counts of all shards:
+ *   wtz_index_count        occurrences of the shard's reads [id_beg, id_end), ordered by k-mer; *n_distinct = its distinct sampled k-mers
+ *   wtz_index_counts_fetch those k-mers (ascending) with their occurrence counts in this shard
+ *   ... the caller adds the counts of equal k-mers over the shards (one exchange), derives K ...
+ *   wtz_index_finish       total_cnt[i] = count of the i-th fetched k-mer over ALL shards; builds the shard's table of the k-mers with
+ *                          2 <= min(total, 0xFFFF) <= K, each pointing at the shard's own seed run.
+ * A query is then answered by every shard (wtz_candidate_groups_*): the (read, strand) groups of a query with ol >= -d, as
+ * `(read << 1 | strand) << 32 | ol` in key order.  Shards are contiguous id ranges, so the shards' lists concatenated in shard order are
+ * the unsharded list, and wtz_cand_tail_host replays the strand merge and the candidate heap (wtzmo.c:516-571) over it. */
+int  wtz_index_count(wtz_ctx_t *ctx, uint32_t id_beg, uint32_t id_end, uint64_t *n_distinct, uint64_t *n_occ);
+int  wtz_index_counts_fetch(wtz_ctx_t *ctx, uint64_t *kmers, uint32_t *cnts);
+int  wtz_index_finish(wtz_ctx_t *ctx, const uint32_t *total_cnt, uint32_t K, uint64_t *n_kept);
+int  wtz_candidate_groups_begin(wtz_ctx_t *ctx, const uint32_t *qids, uint32_t nq);
+int  wtz_candidate_groups_end(wtz_ctx_t *ctx, uint32_t *ngroups);                    /* ngroups[i] = groups of query i */
+int  wtz_candidate_groups_fetch(wtz_ctx_t *ctx, uint64_t *groups, uint64_t total);   /* packed in query order; total = sum of ngroups */
+void wtz_cand_tail_host(const uint64_t *groups, uint32_t ng, uint32_t kovl, uint32_t ncand, uint64_t *heap, uint32_t *hn);
+
 /* A5 for every read + the candidate-side occurrence caps of A6. Call once after wtz_upload_reads. */
 int  wtz_zindex_build(wtz_ctx_t *ctx);
 

@@ -72,6 +72,7 @@ typedef struct eng_s {
 	uint32_t *rdlen; uint32_t avg_rdlen;
 	uint64_t *closed_order; size_t n_order, cap_order; int keep_order;      /* -9: the pairs in the order they entered closed_alns (the file is a replay of it) */
 	wtz_ctx_t *ctx; FILE *out;
+	int shard;                  /* --shard-index: the k-mer index is sharded by read-id range over the devices (reads and z-index stay replicated); output == unsharded */
 	uint32_t ndev; int devs[8]; wtz_ctx_t *ctxs[8];      /* --gpus N / --gpu-list: one context per device, reads + both indexes replicated; ctx == ctxs[0] */
 	uint64_t pair_bp, n_pairs, nrec;
 	/* candidate rows carried across -G index parts (the reference's rdhits), else NULL */
@@ -105,7 +106,7 @@ void wtzmo_set_dist(int rank, int world, wtz_dist_bcast_fn b, wtz_dist_send_fn s
 	g_dist.rank = rank; g_dist.world = world < 1 ? 1 : world; g_dist.bcast = b; g_dist.send = sd; g_dist.recv = rv;
 }
 #define WTZ_DIST_MAX 16
-enum { WTZ_CMD_DONE = 1, WTZ_CMD_PAIRS = 2, WTZ_CMD_CAND_BEGIN = 3, WTZ_CMD_CAND_END = 4 };
+enum { WTZ_CMD_DONE = 1, WTZ_CMD_PAIRS = 2, WTZ_CMD_CAND_BEGIN = 3, WTZ_CMD_CAND_END = 4, WTZ_CMD_GRP_BEGIN = 5, WTZ_CMD_GRP_END = 6 };
 typedef struct { uint64_t cmd, count[WTZ_DIST_MAX]; } wtz_dist_hdr_t;
 
 /* The pairs of a range are dealt round-robin to the PARTS of a batch, one part per GPU (--gpus N; one part otherwise): pair g of the
@@ -123,6 +124,7 @@ typedef struct {
 	uint32_t *cq_ids, *cq_nr; uint64_t *cq_rows; uint32_t cq_n, cq_cap;      /* this device's share (every nparts-th query) of the candidate request in flight */
 } part_t;
 #define PART_OF(b, g) (&(b)->parts[(g) % (b)->nparts])
+#define CPART_OF(b, g) (&(b)->cparts[(g) % (b)->nparts])      /* commit side */
 #define LOCAL_OF(b, g) ((g) / (b)->nparts)
 
 typedef struct {       /* one batch in flight */
@@ -132,6 +134,8 @@ typedef struct {       /* one batch in flight */
 	uint64_t *rows; uint32_t *nrow;             /* candidate heap arrays per slot (stride E->stride) */
 	uint32_t *ids;
 	part_t *parts; uint32_t nparts;
+	part_t *cparts, *spare;                     /* cparts: the result arrays the commit reads (== parts unless ranges are pipelined: then the finished range's
+	                                             * arrays are swapped into `spare` and the device stages of the next range fill `parts` meanwhile) */
 	uint32_t npair, nitem;                      /* pairs / alignment items of the range over all parts */
 	uint32_t *rowpair; size_t caprowpair;       /* pair index (in plan order) per (slot, row entry) */
 	uint64_t spec_queries, used_queries;
@@ -417,7 +421,7 @@ static void commit_query(eng_t *E, batch_t *b, uint32_t slot){
 		for(uint32_t i = 0; i < nc; i++){
 			const uint32_t id2 = (uint32_t)(cand[i].e >> 32);
 			if(cand[i].pidx == 0xFFFFFFFFu){ fprintf(stderr, " -- internal error: pair (%u,%u) missing from the batch plan --\n", pbid, id2); DIE_NOW(); }
-			const wtz_pair_summary_t *S = &PART_OF(b, cand[i].pidx)->sum[LOCAL_OF(b, cand[i].pidx)];
+			const wtz_pair_summary_t *S = &CPART_OF(b, cand[i].pidx)->sum[LOCAL_OF(b, cand[i].pidx)];
 			if(!S->gate) continue;
 			E->used_pairs++;
 			pend_closed(pd, hx_pair_key(id2, pbid));
@@ -441,7 +445,7 @@ static void commit_query(eng_t *E, batch_t *b, uint32_t slot){
 	for(uint32_t i = 0; i < nc; i++){
 		const uint32_t id2 = (uint32_t)(cand[i].e >> 32);
 		if(cand[i].pidx == 0xFFFFFFFFu){ fprintf(stderr, " -- internal error: pair (%u,%u) missing from the batch plan --\n", pbid, id2); DIE_NOW(); }
-		const part_t *pt = PART_OF(b, cand[i].pidx); const uint32_t li = LOCAL_OF(b, cand[i].pidx);
+		const part_t *pt = CPART_OF(b, cand[i].pidx); const uint32_t li = LOCAL_OF(b, cand[i].pidx);
 		const wtz_pair_summary_t *S = &pt->sum[li];
 		if(!S->gate) continue;
 		E->used_pairs++;
@@ -460,7 +464,7 @@ static void commit_query(eng_t *E, batch_t *b, uint32_t slot){
 	for(uint32_t i = 0; i < nseed; i++){
 		seed_t *s = &seeds[i];
 		const int blen = (int)E->rdlen[s->pb2];
-		const part_t *pt = PART_OF(b, s->pidx); const uint32_t li = LOCAL_OF(b, s->pidx);
+		const part_t *pt = CPART_OF(b, s->pidx); const uint32_t li = LOCAL_OF(b, s->pidx);
 		const wtz_pair_summary_t *S = &pt->sum[li];
 		const wtz_winbox_t *bx = pt->boxes + pt->box_off[(size_t)li * 2 + s->dir];
 		uint32_t ol = 0; double avg;
@@ -484,7 +488,7 @@ static void commit_query(eng_t *E, batch_t *b, uint32_t slot){
 			seed_t *s = &seeds[i];
 			if(s->closed){ ncand++; continue; }
 			pend_closed(pd, hx_pair_key(s->pb2, pbid));
-			const part_t *pt = PART_OF(b, s->pidx);
+			const part_t *pt = CPART_OF(b, s->pidx);
 			const uint32_t item = pt->item_of[LOCAL_OF(b, s->pidx)];
 			if(item == 0xFFFFFFFFu || pt->it_dir[item] != s->dir){ fprintf(stderr, " -- internal error: alignment of (%u,%u) missing from the batch plan --\n", pbid, s->pb2); DIE_NOW(); }
 			E->used_items++;
@@ -688,6 +692,21 @@ static void remote_loop(eng_t *E, part_t *pt){
 		} else if(h.cmd == WTZ_CMD_CAND_END){
 			int rc = wtz_candidates_end(pt->ctx, pt->cq_rows, pt->cq_nr); DIE_WTZ(rc, "wtz_candidates_end");
 			if(pt->cq_n){ g_dist.send(pt->cq_rows, (uint64_t)pt->cq_n * E->stride * 8, 0); g_dist.send(pt->cq_nr, 4 * (uint64_t)pt->cq_n, 0); }
+		} else if(h.cmd == WTZ_CMD_GRP_BEGIN){
+			/* sharded index: every rank answers every query of the request with the groups of its shard */
+			const uint32_t nq = (uint32_t)h.count[0];
+			if(nq > pt->cq_cap){ pt->cq_cap = nq; pt->cq_ids = (uint32_t*)hx_realloc(pt->cq_ids, 4 * (size_t)nq); pt->cq_nr = (uint32_t*)hx_realloc(pt->cq_nr, 4 * (size_t)nq); pt->cq_rows = (uint64_t*)hx_realloc(pt->cq_rows, (size_t)nq * E->stride * 8); }
+			pt->cq_n = nq;
+			if(nq) g_dist.bcast(pt->cq_ids, 4 * (uint64_t)nq);
+			int rc = wtz_candidate_groups_begin(pt->ctx, pt->cq_ids, nq); DIE_WTZ(rc, "wtz_candidate_groups_begin");
+		} else if(h.cmd == WTZ_CMD_GRP_END){
+			int rc = wtz_candidate_groups_end(pt->ctx, pt->cq_nr); DIE_WTZ(rc, "wtz_candidate_groups_end");
+			uint64_t tot = 0; for(uint32_t k = 0; k < pt->cq_n; k++) tot += pt->cq_nr[k];
+			uint64_t *gr = (uint64_t*)hx_realloc(NULL, 8 * (tot + 1));
+			rc = wtz_candidate_groups_fetch(pt->ctx, gr, tot); DIE_WTZ(rc, "wtz_candidate_groups_fetch");
+			if(pt->cq_n) g_dist.send(pt->cq_nr, 4 * (uint64_t)pt->cq_n, 0);
+			if(tot) g_dist.send(gr, 8 * tot, 0);
+			free(gr);
 		} else { fprintf(stderr, " -- rank %d: unknown request %llu --\n", me, (unsigned long long)h.cmd); DIE_NOW(); }
 	}
 }
@@ -696,6 +715,7 @@ static void remote_loop(eng_t *E, part_t *pt){
  * batch is committed on the host.  The next queries are chosen with the masks as they are NOW; whoever the commit masks or
  * saturates meanwhile is dropped / demoted when the batch is formed - the batch composition is free (any batch size gives
  * the same output), only the query ORDER and the one-query masking lag are part of the contract. */
+static void shard_candidates_begin(eng_t *E, const uint32_t *ids, uint32_t n);
 static void prefetch_begin(eng_t *E, batch_t *b){
 	if(E->n_workers != 1 || E->rows_all || E->cursor >= E->qend) return;
 	const uint32_t B = E->B;
@@ -710,7 +730,8 @@ static void prefetch_begin(eng_t *E, batch_t *b){
 	b->pf_n = n; b->pf_cursor_end = j;
 	if(n == 0) return;
 	memset(b->pf_rows, 0, (size_t)n * E->stride * 8);
-	if(b->nparts == 1){
+	if(E->shard) shard_candidates_begin(E, b->pf_ids, n);
+	else if(b->nparts == 1){
 		int rc = wtz_candidates_begin(b->ctx, b->pf_ids, n, b->pf_rows, b->pf_nr); DIE_WTZ(rc, "wtz_candidates_begin");
 	} else {
 		/* the seed lookup is pure per query: query k of the request goes to device / rank k % nparts (the launches return at once) */
@@ -731,6 +752,114 @@ static void prefetch_begin(eng_t *E, batch_t *b){
 		}
 	}
 	b->pf_inflight = 1;
+}
+
+
+/* ---- k-mer index sharded by read-id range over the devices (--shard-index; include/wtzmo_hip.h).  One exchange: the shards' distinct k-mers
+ * with their counts are merged on the host, the frequency filter and the automatic cutoff (wtzmo.c:380-405) use the TOTAL counts, so the
+ * tables together hold exactly the k-mers of the unsharded index and every seed run is the unsharded run cut at the shard borders. ---- */
+#define SHARD_N(E) (g_dist.world > 1 ? (uint32_t)g_dist.world : (E)->ndev)      /* one shard per device of this process, or per rank (one process per GPU) */
+static void shard_range(const eng_t *E, uint32_t n_rd, uint32_t d, uint32_t *b, uint32_t *e){
+	const uint32_t N = SHARD_N(E), per = (n_rd + N - 1) / N;      /* contiguous id ranges like the reference's -G parts (wtzmo.c:1281-1285) */
+	*b = d * per < n_rd ? d * per : n_rd; *e = (d + 1) * per < n_rd ? (d + 1) * per : n_rd;
+}
+static void shard_index_build(eng_t *E, uint32_t n_rd, uint32_t *K_io){
+	const uint32_t N = SHARD_N(E); const int ranks = g_dist.world > 1, me = g_dist.rank;
+	uint64_t nd[WTZ_DIST_MAX], nocc[WTZ_DIST_MAX], *km[WTZ_DIST_MAX]; uint32_t *lc[WTZ_DIST_MAX], *tc[WTZ_DIST_MAX];
+	memset(km, 0, sizeof km); memset(lc, 0, sizeof lc); memset(tc, 0, sizeof tc);
+	for(uint32_t d = 0; d < N; d++){
+		if(ranks && (int)d != me) continue;                         /* the other ranks count their own shards */
+		wtz_ctx_t *cx = ranks ? E->ctx : E->ctxs[d];
+		uint32_t b, e; shard_range(E, n_rd, d, &b, &e);
+		int rc = wtz_index_count(cx, b, e, &nd[d], &nocc[d]); DIE_WTZ(rc, "wtz_index_count");
+		km[d] = (uint64_t*)hx_realloc(NULL, 8 * (nd[d] + 1)); lc[d] = (uint32_t*)hx_realloc(NULL, 4 * (nd[d] + 1)); tc[d] = (uint32_t*)hx_realloc(NULL, 4 * (nd[d] + 1));
+		rc = wtz_index_counts_fetch(cx, km[d], lc[d]); DIE_WTZ(rc, "wtz_index_counts_fetch");
+	}
+	uint64_t kbuf[4] = {0, 0, 0, 0};      /* K, occurrences, distinct, table entries: rank 0 -> all */
+	if(ranks && me != 0){
+		/* the one exchange of the build: this shard's (k-mer, count) list to rank 0, the total counts of the same k-mers back */
+		uint64_t hd[2] = { nd[me], nocc[me] };
+		g_dist.send(hd, sizeof hd, 0);
+		if(nd[me]){ g_dist.send(km[me], 8 * nd[me], 0); g_dist.send(lc[me], 4 * nd[me], 0); g_dist.recv(tc[me], 4 * nd[me], 0); }
+		g_dist.bcast(kbuf, sizeof kbuf);
+		uint64_t kept = 0; int rc = wtz_index_finish(E->ctx, tc[me], (uint32_t)kbuf[0], &kept); DIE_WTZ(rc, "wtz_index_finish");
+		*K_io = (uint32_t)kbuf[0];
+		free(km[me]); free(lc[me]); free(tc[me]);
+		return;
+	}
+	if(ranks) for(uint32_t r = 1; r < N; r++){
+		uint64_t hd[2]; g_dist.recv(hd, sizeof hd, (int)r); nd[r] = hd[0]; nocc[r] = hd[1];
+		km[r] = (uint64_t*)hx_realloc(NULL, 8 * (nd[r] + 1)); lc[r] = (uint32_t*)hx_realloc(NULL, 4 * (nd[r] + 1)); tc[r] = (uint32_t*)hx_realloc(NULL, 4 * (nd[r] + 1));
+		if(nd[r]){ g_dist.recv(km[r], 8 * nd[r], (int)r); g_dist.recv(lc[r], 4 * nd[r], (int)r); }
+	}
+	/* N-way merge of the ascending lists: total count per k-mer, ktyp = distinct k-mers, ktot = sum of the saturating counts (wtzmo.c:276, 380-388) */
+	uint64_t pos[WTZ_DIST_MAX], ktyp = 0, ktot = 0; memset(pos, 0, sizeof pos);
+	for(;;){
+		uint64_t m = ~0ull; int any = 0;
+		for(uint32_t d = 0; d < N; d++) if(pos[d] < nd[d]){ if(!any || km[d][pos[d]] < m) m = km[d][pos[d]]; any = 1; }
+		if(!any) break;
+		uint64_t tot = 0;
+		for(uint32_t d = 0; d < N; d++) if(pos[d] < nd[d] && km[d][pos[d]] == m) tot += lc[d][pos[d]];
+		const uint32_t t32 = tot > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)tot;
+		for(uint32_t d = 0; d < N; d++) if(pos[d] < nd[d] && km[d][pos[d]] == m){ tc[d][pos[d]] = t32; pos[d]++; }
+		ktyp++; ktot += tot > 0xFFFFu ? 0xFFFFu : tot;
+	}
+	uint32_t K = *K_io;
+	if(K < 2){ uint32_t kavg = (uint32_t)(ktot / (ktyp + 1)); if(kavg < 20) kavg = 20; K = kavg * 5; }       /* wtzmo.c:380-393 */
+	*K_io = K;
+	uint64_t occ = 0, kept_all = 0;
+	for(uint32_t d = 0; d < N; d++){
+		occ += nocc[d];
+		if(ranks && d){ if(nd[d]) g_dist.send(tc[d], 4 * nd[d], (int)d); }
+		else { uint64_t kept = 0; int rc = wtz_index_finish(ranks ? E->ctx : E->ctxs[d], tc[d], K, &kept); DIE_WTZ(rc, "wtz_index_finish"); kept_all += kept; }
+		free(km[d]); free(lc[d]); free(tc[d]);
+	}
+	if(ranks){ kbuf[0] = K; kbuf[1] = occ; kbuf[2] = ktyp; g_dist.bcast(kbuf, sizeof kbuf); }
+	fprintf(stderr, "[wtzmo-mi355x] index in %u shards by read id%s: %llu k-mer occurrences, %llu distinct, %llu table entries%s, cutoff %u\n", N, ranks ? " (one per rank)" : "",
+		(unsigned long long)occ, (unsigned long long)ktyp, (unsigned long long)kept_all, ranks ? " in shard 0" : " over the shards", K);
+}
+/* candidate heaps of n queries against the sharded index: every shard answers every query with its (read, strand) groups (key order); the
+ * shards are ascending id ranges, so their lists in shard order are the unsharded group list, and the heap replay runs over that */
+static void shard_candidates_begin(eng_t *E, const uint32_t *ids, uint32_t n){
+	if(g_dist.world > 1){
+		wtz_dist_hdr_t h; memset(&h, 0, sizeof h); h.cmd = WTZ_CMD_GRP_BEGIN; h.count[0] = n;
+		g_dist.bcast(&h, sizeof h);
+		if(n) g_dist.bcast((void*)ids, 4 * (uint64_t)n);
+		int rc = wtz_candidate_groups_begin(E->ctx, ids, n); DIE_WTZ(rc, "wtz_candidate_groups_begin");
+		return;
+	}
+	for(uint32_t d = 0; d < E->ndev; d++){ int rc = wtz_candidate_groups_begin(E->ctxs[d], ids, n); DIE_WTZ(rc, "wtz_candidate_groups_begin"); }
+}
+static void shard_candidates_end(eng_t *E, uint32_t n, uint64_t *rows, uint32_t *nr){
+	const uint32_t N = SHARD_N(E); const int ranks = g_dist.world > 1;
+	uint32_t *ng[WTZ_DIST_MAX]; uint64_t *gr[WTZ_DIST_MAX], tot[WTZ_DIST_MAX];
+	if(ranks){ wtz_dist_hdr_t h; memset(&h, 0, sizeof h); h.cmd = WTZ_CMD_GRP_END; g_dist.bcast(&h, sizeof h); }
+	for(uint32_t d = 0; d < N; d++){
+		ng[d] = (uint32_t*)hx_realloc(NULL, 4 * ((size_t)n + 1));
+		if(ranks && d){
+			if(n) g_dist.recv(ng[d], 4 * (uint64_t)n, (int)d);
+			tot[d] = 0; for(uint32_t k = 0; k < n; k++) tot[d] += ng[d][k];
+			gr[d] = (uint64_t*)hx_realloc(NULL, 8 * (tot[d] + 1));
+			if(tot[d]) g_dist.recv(gr[d], 8 * tot[d], (int)d);
+			continue;
+		}
+		wtz_ctx_t *cx = ranks ? E->ctx : E->ctxs[d];
+		int rc = wtz_candidate_groups_end(cx, ng[d]); DIE_WTZ(rc, "wtz_candidate_groups_end");
+		tot[d] = 0; for(uint32_t k = 0; k < n; k++) tot[d] += ng[d][k];
+		gr[d] = (uint64_t*)hx_realloc(NULL, 8 * (tot[d] + 1));
+		rc = wtz_candidate_groups_fetch(cx, gr[d], tot[d]); DIE_WTZ(rc, "wtz_candidate_groups_fetch");
+	}
+	uint64_t off[WTZ_DIST_MAX], *join = NULL; size_t capj = 0; memset(off, 0, sizeof off);
+	for(uint32_t k = 0; k < n; k++){
+		size_t m = 0; for(uint32_t d = 0; d < N; d++) m += ng[d][k];
+		if(m + 1 > capj){ capj = (m + 1) * 2; join = (uint64_t*)hx_realloc(join, 8 * capj); }
+		m = 0; for(uint32_t d = 0; d < N; d++){ memcpy(join + m, gr[d] + off[d], 8 * (size_t)ng[d][k]); m += ng[d][k]; off[d] += ng[d][k]; }
+		uint32_t hn = nr[k];
+		wtz_cand_tail_host(join, (uint32_t)m, E->P.kovl, E->P.ncand, rows + (size_t)k * E->stride, &hn);
+		nr[k] = hn;
+	}
+	free(join);
+	for(uint32_t d = 0; d < N; d++){ free(ng[d]); free(gr[d]); }
 }
 
 /* slots [s0,s1): plan pairs, run the device stages, commit in query order when it is this batch's turn. A range whose
@@ -780,33 +909,128 @@ static void process_range(eng_t *E, batch_t *b, uint32_t s0, uint32_t s1){
 	pthread_mutex_unlock(&E->mu);
 }
 
+/* end of the range that starts at slot s0: as many slots as fit the main scratch pool at the measured bytes per pair */
+static uint32_t range_end(eng_t *E, batch_t *b, uint32_t s0){
+	pthread_mutex_lock(&E->mu);
+	/* before the first measurement: a small probe range (about 2000 pairs, never more than 1 MB per pair allows) - repeat-rich reads
+	 * need tens of MB per pair where iid reads need a few hundred KB, and the longest reads come first */
+	const double cap = E->main_cap ? (double)E->main_cap : 0.0;
+	const double prior = cap / 2048.0 > 1048576.0 ? cap / 2048.0 : 1048576.0;
+	const double bpp = E->bytes_per_pair > 0 ? E->bytes_per_pair : prior;
+	pthread_mutex_unlock(&E->mu);
+	uint64_t budget = cap > 0 ? (uint64_t)(0.7 * cap / bpp) : ~0ull;
+	if(budget < 16) budget = 16;
+	uint32_t s1 = s0; uint64_t acc = 0;
+	while(s1 < b->nbq && (s1 == s0 || acc + (b->want[s1] ? b->nrow[s1] : 0) <= budget)){ acc += b->want[s1] ? b->nrow[s1] : 0; s1++; }
+	return s1;
+}
 /* the slots of a batch in ranges whose pairs (candidate rows are their upper bound) fit the main scratch pool at the measured bytes per pair */
-static void process_batch(eng_t *E, batch_t *b){
-	uint32_t s0 = 0;
+static void process_batch_serial(eng_t *E, batch_t *b, uint32_t s0){
 	while(s0 < b->nbq){
-		pthread_mutex_lock(&E->mu);
-		/* before the first measurement: a small probe range (about 2000 pairs, never more than 1 MB per pair allows) - repeat-rich reads
-		 * need tens of MB per pair where iid reads need a few hundred KB, and the longest reads come first */
-		const double cap = E->main_cap ? (double)E->main_cap : 0.0;
-		const double prior = cap / 2048.0 > 1048576.0 ? cap / 2048.0 : 1048576.0;
-		const double bpp = E->bytes_per_pair > 0 ? E->bytes_per_pair : prior;
-		pthread_mutex_unlock(&E->mu);
-		uint64_t budget = cap > 0 ? (uint64_t)(0.7 * cap / bpp) : ~0ull;
-		if(budget < 16) budget = 16;
-		uint32_t s1 = s0; uint64_t acc = 0;
-		while(s1 < b->nbq && (s1 == s0 || acc + (b->want[s1] ? b->nrow[s1] : 0) <= budget)){ acc += b->want[s1] ? b->nrow[s1] : 0; s1++; }
+		const uint32_t s1 = range_end(E, b, s0);
 		process_range(E, b, s0, s1);
 		pthread_mutex_lock(&E->mu); E->n_ranges++; pthread_mutex_unlock(&E->mu);
 		s0 = s1;
 	}
 }
+/* Ranges PIPELINED: while the host commits range r (sequential by definition: 0.36 s of a 3.7 s configs[2] step) the device stages of range
+ * r + 1 run on a helper thread.  Range r + 1 is therefore planned BEFORE range r is committed, i.e. against masks / closed pairs / coverage
+ * one range older: every piece of order-dependent state only removes work, so the plan is a superset of what the commit will
+ * ask for and the output cannot change - a few more speculative pairs are computed.  The finished range's result arrays are swapped into
+ * the batch's spare set (cparts) so that the next range can fill `parts`.  A range that overflows the scratch pool is redone by the serial
+ * path (halving), then the pipeline starts again behind it. */
+typedef struct { eng_t *E; batch_t *b; int again; double t0, t1; pthread_t th; int running; } gpujob_t;
+static void *gpujob_main(void *arg){ gpujob_t *j = (gpujob_t*)arg; j->t0 = now_s(); j->again = gpu_stages(j->E, j->b); j->t1 = now_s(); return NULL; }
+static void gpujob_start(gpujob_t *j, eng_t *E, batch_t *b){ j->E = E; j->b = b; j->again = 0; if(pthread_create(&j->th, NULL, gpujob_main, j) != 0){ fprintf(stderr, " -- cannot start the device-stage thread --\n"); DIE_NOW(); } j->running = 1; }
+static int gpujob_wait(gpujob_t *j){ if(j->running){ pthread_join(j->th, NULL); j->running = 0; } return j->again; }
+#define SWAP_FIELD(T, a, b) do { T t_ = (a); (a) = (b); (b) = t_; } while(0)
+static void process_batch(eng_t *E, batch_t *b){
+	static int overlap = -1;
+	if(overlap < 0){ const char *e = getenv("WTZ_RANGE_OVERLAP"); overlap = e ? atoi(e) : 1; }
+	if(!overlap || E->n_workers != 1 || b->nbq == 0){ b->cparts = b->parts; process_batch_serial(E, b, 0); return; }
+	gpujob_t job; memset(&job, 0, sizeof job);
+	uint32_t s0 = 0, s1 = range_end(E, b, s0);
+	pthread_mutex_lock(&E->mu); plan_pairs(E, b, s0, s1); pthread_mutex_unlock(&E->mu);
+	gpujob_start(&job, E, b);
+	for(;;){
+		const int again = gpujob_wait(&job);
+		if(again){
+			/* scratch pool exhausted: nothing of [s0, s1) is committed and nothing else is in flight: the serial path splits it */
+			b->cparts = b->parts;
+			pthread_mutex_lock(&E->mu); E->n_split++; E->bytes_per_pair = (E->bytes_per_pair > 0 ? E->bytes_per_pair : 1048576.0) * 2.0; pthread_mutex_unlock(&E->mu);
+			if(s1 - s0 <= 1){ fprintf(stderr, " -- device scratch pool too small even for one query: %s (use --pool-gb) --\n", wtz_last_error()); DIE_NOW(); }
+			fprintf(stderr, "[wtzmo-mi355x] scratch pool exhausted with %u queries in flight; splitting the batch\n", s1 - s0);
+			const uint32_t mid = s0 + (s1 - s0) / 2;
+			process_range(E, b, s0, mid); process_range(E, b, mid, s1);
+			pthread_mutex_lock(&E->mu); E->n_ranges++; pthread_mutex_unlock(&E->mu);
+			s0 = s1;
+			if(s0 >= b->nbq) break;
+			s1 = range_end(E, b, s0);
+			pthread_mutex_lock(&E->mu); plan_pairs(E, b, s0, s1); pthread_mutex_unlock(&E->mu);
+			gpujob_start(&job, E, b);
+			continue;
+		}
+		const double tg0 = job.t0, tg1 = job.t1;
+		const uint32_t r_npair = b->npair, r_nitem = b->nitem;
+		if(b->npair){
+			for(uint32_t d = 0; d < b->nparts; d++){
+				wtz_pool_info_t pi; const part_t *pt = &b->parts[d];
+				if(pt->npair == 0 || pt->ctx == NULL || wtz_pool_info(pt->ctx, &pi) != WTZ_OK) continue;
+				pthread_mutex_lock(&E->mu);
+				E->main_cap = pi.main_cap * b->nparts;
+				const double bpp = (double)pi.main_used / (double)pt->npair;
+				if(pt->npair >= 8 && bpp > E->bytes_per_pair) E->bytes_per_pair = bpp;
+				pthread_mutex_unlock(&E->mu);
+			}
+		}
+		/* the finished range's results move to the commit view */
+		for(uint32_t d = 0; d < b->nparts; d++){
+			part_t *p = &b->parts[d], *c = &b->spare[d];
+			SWAP_FIELD(wtz_pair_summary_t*, p->sum, c->sum); SWAP_FIELD(uint64_t*, p->box_off, c->box_off); SWAP_FIELD(wtz_winbox_t*, p->boxes, c->boxes);
+			SWAP_FIELD(uint64_t, p->capbox, c->capbox); SWAP_FIELD(uint64_t, p->nbox, c->nbox);
+			SWAP_FIELD(uint32_t*, p->item_of, c->item_of); SWAP_FIELD(uint32_t*, p->it_pair, c->it_pair); SWAP_FIELD(uint8_t*, p->it_dir, c->it_dir); SWAP_FIELD(wtz_aln_result_t*, p->aln, c->aln);
+			c->cig = p->cig; c->cig_ext = p->cig_ext; c->ncig = p->ncig; c->nitem = p->nitem; c->npair = p->npair;
+		}
+		b->cparts = b->spare;
+		double t_gpu_call[5] = {0, 0, 0, 0, 0}, t_io0 = 0;
+		for(uint32_t d = 0; d < b->nparts; d++){ part_t *pt = &b->parts[d]; for(int k = 0; k < 5; k++){ if(d == 0) t_gpu_call[k] += pt->t_call[k]; pt->t_call[k] = 0; } t_io0 += pt->t_io0; pt->t_io0 = 0; }
+		/* next range: planned now (one range of staleness), computed while this one is committed */
+		const uint32_t n0 = s1;
+		uint32_t n1 = n0;
+		if(n0 < b->nbq){
+			n1 = range_end(E, b, n0);
+			pthread_mutex_lock(&E->mu); plan_pairs(E, b, n0, n1); pthread_mutex_unlock(&E->mu);
+			gpujob_start(&job, E, b);
+		} else if(!b->pf_inflight){ pthread_mutex_lock(&E->mu); prefetch_begin(E, b); pthread_mutex_unlock(&E->mu); }
+		const double tc0 = now_s();
+		pthread_mutex_lock(&E->mu);
+		E->t_gpu += tg1 - tg0;
+		for(int k = 0; k < 5; k++) E->t_call[k] += t_gpu_call[k];
+		E->t_io[0] += t_io0;
+		while(!b->holds_turn && E->commit_seq != b->seq) pthread_cond_wait(&E->cv, &E->mu);
+		b->holds_turn = 1;
+		E->spec_pairs += r_npair; E->spec_items += r_nitem;
+		for(uint32_t s = s0; s < s1; s++){
+			if(E->masked[b->bq[s]]) continue;
+			flush_pending(E);
+			commit_query(E, b, s);
+		}
+		out_submit(&g_ow);
+		E->t_commit += now_s() - tc0;
+		E->n_ranges++;
+		pthread_mutex_unlock(&E->mu);
+		if(n0 >= b->nbq) break;
+		s0 = n0; s1 = n1;
+	}
+	b->cparts = b->parts;
+}
 
 /* both index builds of one more device (replicated indexes, --gpus) */
-typedef struct { wtz_ctx_t *ctx; uint32_t n_rd, K; int rc; char err[256]; } ixjob_t;
+typedef struct { wtz_ctx_t *ctx; uint32_t n_rd, K; int rc; char err[256]; int zonly; } ixjob_t;
 static void *ixjob_main(void *arg){
 	ixjob_t *j = (ixjob_t*)arg; wtz_index_stats_t ist;
 	j->rc = wtz_zindex_build(j->ctx);
-	if(j->rc == WTZ_OK) j->rc = wtz_index_build(j->ctx, 0, j->n_rd, &j->K, &ist);
+	if(j->rc == WTZ_OK && !j->zonly) j->rc = wtz_index_build(j->ctx, 0, j->n_rd, &j->K, &ist);
 	if(j->rc != WTZ_OK){ strncpy(j->err, wtz_last_error(), sizeof j->err - 1); j->err[sizeof j->err - 1] = 0; }
 	return NULL;
 }
@@ -856,7 +1080,8 @@ static void *worker_main(void *arg){
 		if(use_pf){
 			const double tg0 = now_s();
 			int rc = WTZ_OK;
-			if(b->nparts == 1){ rc = wtz_candidates_end(b->ctx, b->pf_rows, b->pf_nr); DIE_WTZ(rc, "wtz_candidates_end"); }
+			if(E->shard) shard_candidates_end(E, b->pf_n, b->pf_rows, b->pf_nr);
+			else if(b->nparts == 1){ rc = wtz_candidates_end(b->ctx, b->pf_rows, b->pf_nr); DIE_WTZ(rc, "wtz_candidates_end"); }
 			else for(uint32_t d = 0; d < b->nparts; d++){
 				part_t *pt = &b->parts[d];
 				if(d == 0 && g_dist.world > 1){ wtz_dist_hdr_t h; memset(&h, 0, sizeof h); h.cmd = WTZ_CMD_CAND_END; g_dist.bcast(&h, sizeof h); }
@@ -881,7 +1106,8 @@ static void *worker_main(void *arg){
 			n = 0;
 			for(uint32_t s = 0; s < b->nbq; s++) if(b->want[s]){ memcpy(rows + (size_t)n * E->stride, b->rows + (size_t)s * E->stride, (size_t)b->nrow[s] * 8); nr[n] = b->nrow[s]; n++; }
 			const double tg0 = now_s();
-			int rc = wtz_candidates(b->ctx, b->ids, n, rows, nr); DIE_WTZ(rc, "wtz_candidates");
+			if(E->shard){ shard_candidates_begin(E, b->ids, n); shard_candidates_end(E, n, rows, nr); }
+			else { int rc = wtz_candidates(b->ctx, b->ids, n, rows, nr); DIE_WTZ(rc, "wtz_candidates"); }
 			const double tg1 = now_s();
 			n = 0;
 			for(uint32_t s = 0; s < b->nbq; s++) if(b->want[s]){ memcpy(b->rows + (size_t)s * E->stride, rows + (size_t)n * E->stride, (size_t)E->stride * 8); b->nrow[s] = nr[n]; n++; }
@@ -930,7 +1156,7 @@ int main(int argc, char **argv){
 	E->do_align = 1; E->n_idx = 1; E->n_job = 1; E->i_job = 0; E->max_batch = 2048; E->first_batch = 256; E->n_workers = 1;
 	pthread_mutex_init(&E->mu, NULL); pthread_cond_init(&E->cv, NULL);
 	static struct option lopts[] = { {"stats", required_argument, 0, 1000}, {"gpu", required_argument, 0, 1001}, {"pool-gb", required_argument, 0, 1002},
-		{"batch", required_argument, 0, 1003}, {"lib-check", no_argument, 0, 1004}, {"repeat", required_argument, 0, 1005}, {"first-batch", required_argument, 0, 1006}, {"workers", required_argument, 0, 1007}, {"pool-mb", required_argument, 0, 1008}, {"gpus", required_argument, 0, 1010}, {"gpu-list", required_argument, 0, 1011}, {0, 0, 0, 0} };
+		{"batch", required_argument, 0, 1003}, {"lib-check", no_argument, 0, 1004}, {"repeat", required_argument, 0, 1005}, {"first-batch", required_argument, 0, 1006}, {"workers", required_argument, 0, 1007}, {"pool-mb", required_argument, 0, 1008}, {"gpus", required_argument, 0, 1010}, {"gpu-list", required_argument, 0, 1011}, {"shard-index", no_argument, 0, 1012}, {0, 0, 0, 0} };
 	while((c = getopt_long(argc, argv, "ht:P:p:Ni:b:J:I:o:9:S:fCH:k:G:z:Z:U:y:d:r:q:l:K:A:B:r:R:L:F:W:w:e:M:X:O:E:T:s:m:nv", lopts, NULL)) != -1){
 		switch(c){
 			case 1000: statsf = optarg; break;
@@ -941,6 +1167,7 @@ int main(int argc, char **argv){
 			case 1005: repeat = atoi(optarg); if(repeat < 1) repeat = 1; break;
 			case 1006: E->first_batch = (uint32_t)atoi(optarg); if(E->first_batch < 1) E->first_batch = 1; E->first_batch_set = 1; break;
 			case 1010: n_gpus = atoi(optarg); if(n_gpus < 1) n_gpus = 1; if(n_gpus > 8) n_gpus = 8; break;
+			case 1012: E->shard = 1; break;           /* k-mer index sharded over the devices of --gpus / --gpu-list (or over the ranks) */
 			case 1011: gpu_list = optarg; break;      /* explicit device ids, e.g. 0,1,2,3 (an id may repeat: two contexts on one GPU, used by the tests) */
 			case 1008: pool_mb = (uint64_t)atoll(optarg); break;      /* test hook: a pool small enough to force the batch-splitting path */
 			case 1007: E->n_workers = (uint32_t)atoi(optarg); if(E->n_workers < 1) E->n_workers = 1; if(E->n_workers > 8) E->n_workers = 8; break;
@@ -1094,6 +1321,7 @@ int main(int argc, char **argv){
 		if(g_dist.world > WTZ_DIST_MAX || !g_dist.bcast || !g_dist.send || !g_dist.recv){ fprintf(stderr, " -- wtzmo_set_dist: bad rank setup --\n"); exit(1); }
 		if(E->n_idx > 1 || E->n_workers > 1 || E->ndev > 1 || E->n_job > 1){ fprintf(stderr, " -- ranks (one process per GPU) exclude -G, -P, --workers and --gpus --\n"); exit(1); }
 	}
+	if(E->shard && (E->n_idx > 1 || E->n_workers > 1)){ fprintf(stderr, " -- --shard-index excludes -G and --workers --\n"); exit(1); }
 	if(E->ndev > 1 && (E->n_idx > 1 || E->n_workers > 1)){
 		fprintf(stderr, "[wtzmo-mi355x] -G / --workers run on one device: --gpus ignored\n"); E->ndev = 1;
 	}
@@ -1155,7 +1383,7 @@ int main(int argc, char **argv){
 		if(g_hook) g_hook(rep, 0);
 		const double t0 = now_s();
 		pthread_t ixth[8]; ixjob_t ixj[8];
-		for(uint32_t d = 1; d < E->ndev; d++){ ixj[d].ctx = E->ctxs[d]; ixj[d].n_rd = n_rd; ixj[d].K = P->max_kmer_freq; if(pthread_create(&ixth[d], NULL, ixjob_main, &ixj[d]) != 0) DIE_NOW(); }
+		for(uint32_t d = 1; d < E->ndev; d++){ ixj[d].ctx = E->ctxs[d]; ixj[d].n_rd = n_rd; ixj[d].K = P->max_kmer_freq; ixj[d].zonly = E->shard; if(pthread_create(&ixth[d], NULL, ixjob_main, &ixj[d]) != 0) DIE_NOW(); }
 		rc = wtz_zindex_build(E->ctx); DIE_WTZ(rc, "wtz_zindex_build");
 		/* ---- index parts (-G, wtzmo.c:1276-1303) ---- */
 		uint32_t pbbeg = 0, pbend = 0, K = P->max_kmer_freq;
@@ -1163,7 +1391,14 @@ int main(int argc, char **argv){
 		uint32_t *ids = (uint32_t*)hx_realloc(NULL, 4 * ((size_t)n_all + 1));
 		if(E->n_idx > 1){ E->rows_all = 1; E->rows = (uint64_t*)hx_realloc(E->rows, (size_t)n_all * E->stride * 8); E->nrow = (uint32_t*)hx_realloc(E->nrow, (size_t)n_all * 4); memset(E->nrow, 0, (size_t)n_all * 4); }
 		double t_index = 0;
-		for(uint32_t i_idx = 0; i_idx < E->n_idx; i_idx++){
+		if(E->shard){
+			/* the other devices' z-index threads use their contexts: join them first */
+			for(uint32_t d = 1; d < E->ndev; d++){ pthread_join(ixth[d], NULL); if(ixj[d].rc != WTZ_OK){ fprintf(stderr, " -- index build on device %d failed: %s --\n", E->devs[d], ixj[d].err); DIE_NOW(); } }
+			const double ti = now_s();
+			shard_index_build(E, n_rd, &K);
+			t_index += now_s() - ti;
+		}
+		for(uint32_t i_idx = 0; i_idx < E->n_idx && !E->shard; i_idx++){
 			pbbeg = pbend; pbend = pbbeg + (n_rd + E->n_idx - 1) / E->n_idx;
 			const double ti = now_s();
 			rc = wtz_index_build(E->ctx, pbbeg, pbend > n_rd ? n_rd : pbend, &K, &ist); DIE_WTZ(rc, "wtz_index_build");
@@ -1192,7 +1427,7 @@ int main(int argc, char **argv){
 				free(tmp_rows); free(tmp_n);
 			}
 		}
-		for(uint32_t d = 1; d < E->ndev; d++){ pthread_join(ixth[d], NULL); if(ixj[d].rc != WTZ_OK){ fprintf(stderr, " -- index build on device %d failed: %s --\n", E->devs[d], ixj[d].err); DIE_NOW(); } }
+		for(uint32_t d = 1; d < E->ndev && !E->shard; d++){ pthread_join(ixth[d], NULL); if(ixj[d].rc != WTZ_OK){ fprintf(stderr, " -- index build on device %d failed: %s --\n", E->devs[d], ixj[d].err); DIE_NOW(); } }
 		stale_start(&stale_job);       /* index builds (and their device allocations) are done: drop the previous repeat's file in the background */
 		/* ---- queries: pipelined batches on n_workers contexts (own stream + pool each, indexes shared) ---- */
 		if(pin_started){ pthread_join(pin_th, NULL); pin_started = 0; }
@@ -1213,7 +1448,7 @@ int main(int argc, char **argv){
 			const uint32_t nparts = g_dist.world > 1 ? (uint32_t)g_dist.world : (nw == 1 ? E->ndev : 1);
 			for(uint32_t w = 0; w < nw; w++){
 				bs[w].E = E;
-				bs[w].nparts = nparts; bs[w].parts = (part_t*)calloc(nparts, sizeof(part_t));
+				bs[w].nparts = nparts; bs[w].parts = (part_t*)calloc(nparts, sizeof(part_t)); bs[w].spare = (part_t*)calloc(nparts, sizeof(part_t)); bs[w].cparts = bs[w].parts;
 				for(uint32_t d = 0; d < nparts; d++){
 					part_t *pt = &bs[w].parts[d]; const uint32_t slot = w * nparts + d;
 					pt->ext_base = slot < 8 ? (int)slot * 2 : -1;
@@ -1248,6 +1483,8 @@ int main(int argc, char **argv){
 					free(pt->pq); free(pt->pc); free(pt->sum); free(pt->box_off); free(pt->boxes); free(pt->item_of); free(pt->it_pair); free(pt->it_dir); free(pt->aln);
 					for(int k = 0; k < 2; k++){ if(slot < 8){ E->cig_keep[slot * 2 + k] = pt->cigs[k]; E->cig_keep_cap[slot * 2 + k] = pt->capcigs[k]; } else wtz_host_free(pt->cigs[k]); }
 				}
+				for(uint32_t d = 0; d < nparts; d++){ part_t *sp = &bs[w].spare[d]; free(sp->sum); free(sp->box_off); free(sp->boxes); free(sp->item_of); free(sp->it_pair); free(sp->it_dir); free(sp->aln); }
+				free(bs[w].spare);
 				free(bs[w].parts);
 				free(bs[w].bq); free(bs[w].want); free(bs[w].ids); free(bs[w].rows); free(bs[w].nrow); free(bs[w].rowpair); free(bs[w].pf_ids); free(bs[w].pf_rows); free(bs[w].pf_nr);
 			}

@@ -70,6 +70,10 @@ struct K_glist;
 struct K_poolalloc;
 struct K_kfill;
 struct K_kinsert;
+struct K_khead;
+struct K_kdistinct;
+struct K_kinsert_total;
+struct K_pack_groups;
 struct K_kstats;
 struct K_pack_cigars;
 struct K_pack_windows;
@@ -321,6 +325,9 @@ struct wtz_ctx {
 	std::vector<uint32_t> h_rdlen;
 	/* k-mer index */
 	wtz_kslot_t *ktab; uint64_t kmask; uint32_t *kseeds; uint64_t n_kocc;
+	/* sharded index build in progress (wtz_index_count ... wtz_index_finish): sorted occurrences and the shard's distinct k-mers */
+	uint64_t *pend_keys = NULL; uint32_t *pend_vals = NULL; uint64_t pend_tot = 0; uint64_t *pend_dk = NULL, *pend_dstart = NULL; uint32_t *pend_dc = NULL; uint64_t pend_nd = 0; uint32_t pend_beg = 0, pend_end = 0;
+	uint64_t *cq_gptr = NULL; uint32_t cq_gcap = 0; bool cq_groups = false; std::vector<uint32_t> cq_ng;
 	uint32_t idx_beg = 0, idx_end = 0; bool idx_len_sorted = false;      /* read range of the k-mer index; lengths non-increasing inside it (true unless -b clipped reads after the sort) */
 	/* z index */
 	uint64_t *zoff; uint64_t n_z; wtz_zindex_t Z; bool have_z;
@@ -472,6 +479,7 @@ extern "C" int wtz_ctx_create(int device, const wtz_params_c *params, uint64_t p
 	return WTZ_OK;
 }
 
+static void free_pending_index(wtz_ctx *c);
 static void free_kindex(wtz_ctx *c){ if(!c->shares_indexes){ dev_free_persist(c->ktab); dev_free_persist(c->kseeds); } c->ktab = NULL; c->kseeds = NULL; c->kmask = 0; }
 /* z-index allocation with recycling: a parked buffer of (nearly) the wanted size is taken instead of a fresh hipMalloc */
 static int zalloc(wtz_ctx *c, void **p, size_t n){
@@ -517,7 +525,8 @@ extern "C" void wtz_ctx_destroy(wtz_ctx_t *c){
 	if(!c) return;
 	{ CTX_ENTER(c); (void)dev_sync(); }
 	free_batch_storage(c); free_kindex(c); free_zindex(c);
-	dev_free_persist(c->cq_q); dev_free_persist(c->cq_nc); dev_free_persist(c->cq_cand); dev_free_persist(c->cq_bytes); dev_free_persist(c->cq_thr);
+	dev_free_persist(c->cq_q); dev_free_persist(c->cq_nc); dev_free_persist(c->cq_cand); dev_free_persist(c->cq_bytes); dev_free_persist(c->cq_thr); dev_free_persist(c->cq_gptr);
+	free_pending_index(c);
 #ifndef WTZ_EMUL
 	if(c->arena.base) (void)hipFree(c->arena.base);
 #endif
@@ -605,13 +614,14 @@ extern "C" int wtz_index_build(wtz_ctx_t *c, uint32_t id_beg, uint32_t id_end, u
 	CHK(dev_sort_pairs_u64_u32(d_keys, d_vals, tot, 2 * ksize));
 	lapix(5);
 	unsigned long long *d_stat = NULL; CHK(dev_alloc((void**)&d_stat, 4 * 8)); CHK(dev_set(d_stat, 0, 4 * 8));
-	CHK(wtz_launch<K_kstats>(0, tot, [=] WTZ_LAMBDA (uint64_t i){ wtz_task_kstats(i, d_keys, tot, d_stat + 0, d_stat + 1); }));
+	const uint64_t n_str = tot < (1ull << 18) ? (tot ? tot : 1) : (1ull << 18);      /* strided counting passes: one atomic per wavefront at the end */
+	CHK(wtz_launch<K_kstats>(0, n_str, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_kstats_stride(t, n_str, d_keys, tot, d_stat + 0, d_stat + 1); }));
 	unsigned long long h_stat[4]; CHK(dev_d2h(h_stat, d_stat, 4 * 8));
 	const uint64_t ktot = tot - h_stat[0], ktyp = h_stat[1];     /* d_stat[0] accumulates the saturation excess */
 	uint32_t K = *max_kmer_freq;
 	if(K < 2){ uint32_t kavg = (uint32_t)(ktot / (ktyp + 1)); if(kavg < 20) kavg = 20; K = kavg * 5; }       /* wtzmo.c:380-393 */
 	*max_kmer_freq = K;
-	CHK(wtz_launch<K_kinsert>(0, tot, [=] WTZ_LAMBDA (uint64_t i){ wtz_task_kinsert(i, d_keys, tot, K, (wtz_kslot_t*)NULL, 0, d_stat + 2); }));
+	CHK(wtz_launch<K_kinsert>(0, n_str, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_kkept_stride(t, n_str, d_keys, tot, K, d_stat + 2); }));
 	CHK(dev_d2h(h_stat, d_stat, 4 * 8));
 	const uint64_t n_kept = h_stat[2];
 	uint64_t cap = 1024; while(cap < n_kept * 2 + 2) cap <<= 1;
@@ -634,6 +644,89 @@ extern "C" int wtz_index_build(wtz_ctx_t *c, uint32_t id_beg, uint32_t id_end, u
 	}
 	return WTZ_OK;
 }
+
+
+/* ------------------------------------------------------------------------------------------------ */
+/* A2 sharded by read-id range (see include/wtzmo_hip.h)                                             */
+/* ------------------------------------------------------------------------------------------------ */
+static void free_pending_index(wtz_ctx *c){
+	dev_free_persist(c->pend_keys); dev_free_persist(c->pend_vals); dev_free_persist(c->pend_dk); dev_free_persist(c->pend_dc); dev_free_persist(c->pend_dstart);
+	c->pend_keys = NULL; c->pend_vals = NULL; c->pend_dk = NULL; c->pend_dc = NULL; c->pend_dstart = NULL; c->pend_tot = 0; c->pend_nd = 0;
+}
+extern "C" int wtz_index_count(wtz_ctx_t *c, uint32_t id_beg, uint32_t id_end, uint64_t *n_distinct, uint64_t *n_occ){
+	if(!c || !c->bits || !n_distinct) return wtz_fail(WTZ_E_ARG, "reads not uploaded / null argument");
+	if(id_end > c->n_reads) id_end = c->n_reads;
+	if(id_beg > id_end) id_beg = id_end;
+	CTX_ENTER(c);
+	if(c->shares_indexes) return wtz_fail(WTZ_E_STATE, "wtz_index_count on a cloned context");
+	free_kindex(c); free_pending_index(c);
+	wtz_timer tm; tm.start();
+	const wtz_reads_t R = ctx_reads(c); const uint32_t ksize = c->P.ksize, hk = c->P.hk, ksave = c->P.ksave;
+	std::vector<uint32_t> p_rid, p_jb;
+	for(uint32_t r = id_beg; r < id_end; r++) for(uint32_t jb = 0; jb == 0 || jb < c->h_rdlen[r]; jb += WTZ_WALK_CHUNK){ p_rid.push_back(r); p_jb.push_back(jb); }
+	const size_t np = p_rid.size();
+	uint32_t *d_prid = NULL, *d_pjb = NULL; uint64_t *d_cnt = NULL;
+	CHK(dev_alloc((void**)&d_prid, (np + 1) * 4)); CHK(dev_alloc((void**)&d_pjb, (np + 1) * 4)); CHK(dev_alloc((void**)&d_cnt, (np + 1) * 8));
+	CHK(dev_h2d(d_prid, p_rid.data(), np * 4)); CHK(dev_h2d(d_pjb, p_jb.data(), np * 4));
+	CHK(wtz_launch<K_kcount>(0, np, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_kcount((uint32_t)t, R, d_prid, d_pjb, ksize, hk, ksave, d_cnt); }));
+	std::vector<uint64_t> h_cnt(np + 1);
+	CHK(dev_d2h(h_cnt.data(), d_cnt, np * 8));
+	uint64_t tot = 0; for(size_t i = 0; i < np; i++){ uint64_t v = h_cnt[i]; h_cnt[i] = tot; tot += v; } h_cnt[np] = tot;
+	CHK(dev_h2d(d_cnt, h_cnt.data(), (np + 1) * 8));
+	if(tot >= 0xFFFFFFFFull) return wtz_fail(WTZ_E_ARG, "wtz_index_count: more than 2^32 k-mer occurrences in one shard; use more shards");
+	CHK(dev_alloc_persist((void**)&c->pend_keys, (tot + 1) * 8)); CHK(dev_alloc_persist((void**)&c->pend_vals, (tot + 1) * 4));
+	uint64_t *d_keys = c->pend_keys; uint32_t *d_vals = c->pend_vals;
+	CHK(wtz_launch<K_kfill>(0, np, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_kfill((uint32_t)t, R, d_prid, d_pjb, ksize, hk, ksave, d_cnt, d_keys, d_vals); }));
+	CHK(dev_sync());
+	CHK(dev_sort_pairs_u64_u32(d_keys, d_vals, tot, 2 * ksize));
+	uint32_t *d_flag = NULL, *d_dpos = NULL;
+	CHK(dev_alloc((void**)&d_flag, (tot + 2) * 4)); CHK(dev_alloc((void**)&d_dpos, (tot + 2) * 4)); CHK(dev_set(d_flag, 0, (tot + 2) * 4));
+	CHK(wtz_launch<K_khead>(0, tot, [=] WTZ_LAMBDA (uint64_t i){ wtz_task_khead(i, d_keys, d_flag); }));
+	CHK(dev_exclusive_scan_u32(d_flag, d_dpos, tot + 1));
+	uint32_t nd = 0; CHK(dev_d2h(&nd, d_dpos + tot, 4));
+	CHK(dev_alloc_persist((void**)&c->pend_dk, ((size_t)nd + 1) * 8)); CHK(dev_alloc_persist((void**)&c->pend_dc, ((size_t)nd + 1) * 4)); CHK(dev_alloc_persist((void**)&c->pend_dstart, ((size_t)nd + 1) * 8));
+	uint64_t *dk = c->pend_dk, *dst = c->pend_dstart; uint32_t *dc = c->pend_dc;
+	CHK(wtz_launch<K_kdistinct>(0, tot, [=] WTZ_LAMBDA (uint64_t i){ wtz_task_kdistinct(i, d_keys, tot, d_flag, d_dpos, dk, dc, dst); }));
+	CHK(dev_sync());
+	c->pend_tot = tot; c->pend_nd = nd; c->pend_beg = id_beg; c->pend_end = id_end;
+	c->cnt.ms_index += tm.stop();
+	*n_distinct = nd; if(n_occ) *n_occ = tot;
+	return WTZ_OK;
+}
+extern "C" int wtz_index_counts_fetch(wtz_ctx_t *c, uint64_t *kmers, uint32_t *cnts){
+	if(!c || !kmers || !cnts) return wtz_fail(WTZ_E_ARG, "null argument");
+	if(!c->pend_keys) return wtz_fail(WTZ_E_STATE, "wtz_index_counts_fetch before wtz_index_count");
+	CTX_ENTER(c);
+	CHK(dev_d2h(kmers, c->pend_dk, (size_t)c->pend_nd * 8)); CHK(dev_d2h(cnts, c->pend_dc, (size_t)c->pend_nd * 4));
+	return WTZ_OK;
+}
+extern "C" int wtz_index_finish(wtz_ctx_t *c, const uint32_t *total_cnt, uint32_t K, uint64_t *n_kept_out){
+	if(!c || (!total_cnt && c && c->pend_nd)) return wtz_fail(WTZ_E_ARG, "null argument");
+	if(!c->pend_keys) return wtz_fail(WTZ_E_STATE, "wtz_index_finish before wtz_index_count");
+	CTX_ENTER(c);
+	wtz_timer tm; tm.start();
+	const uint64_t nd = c->pend_nd;
+	uint32_t *d_tc = NULL; unsigned long long *d_stat = NULL;
+	CHK(dev_alloc((void**)&d_tc, (nd + 1) * 4)); CHK(dev_h2d(d_tc, total_cnt, nd * 4));
+	CHK(dev_alloc((void**)&d_stat, 8)); CHK(dev_set(d_stat, 0, 8));
+	const uint64_t *dk = c->pend_dk, *dst = c->pend_dstart; const uint32_t *dc = c->pend_dc;
+	CHK(wtz_launch<K_kinsert_total>(0, nd, [=] WTZ_LAMBDA (uint64_t d){ wtz_task_kinsert_total(d, dk, dc, dst, d_tc, K, (wtz_kslot_t*)NULL, 0, d_stat); }));
+	unsigned long long n_kept = 0; CHK(dev_d2h(&n_kept, d_stat, 8));
+	uint64_t cap = 1024; while(cap < n_kept * 2 + 2) cap <<= 1;
+	CHK(dev_alloc_persist((void**)&c->ktab, cap * sizeof(wtz_kslot_t))); CHK(dev_set(c->ktab, 0xFF, cap * sizeof(wtz_kslot_t)));
+	c->kmask = cap - 1;
+	wtz_kslot_t *tab = c->ktab; const uint64_t kmask = c->kmask;
+	CHK(wtz_launch<K_kinsert_total>(0, nd, [=] WTZ_LAMBDA (uint64_t d){ wtz_task_kinsert_total(d, dk, dc, dst, d_tc, K, tab, kmask, d_stat); }));
+	CHK(dev_sync());
+	c->kseeds = c->pend_vals; c->pend_vals = NULL; c->n_kocc = c->pend_tot;
+	c->idx_beg = c->pend_beg; c->idx_end = c->pend_end; c->idx_len_sorted = true;
+	for(uint32_t r = c->idx_beg; r + 1 < c->idx_end; r++) if(c->h_rdlen[r] < c->h_rdlen[r + 1]){ c->idx_len_sorted = false; break; }
+	free_pending_index(c);
+	c->cnt.ms_index += tm.stop();
+	if(n_kept_out) *n_kept_out = n_kept;
+	return WTZ_OK;
+}
+extern "C" void wtz_cand_tail_host(const uint64_t *groups, uint32_t ng, uint32_t kovl, uint32_t ncand, uint64_t *heap, uint32_t *hn){ wtz_cand_tail(groups, ng, kovl, ncand, heap, hn); }
 
 /* ------------------------------------------------------------------------------------------------ */
 /* A5: z-mer index of every read                                                                     */
@@ -697,7 +790,7 @@ extern "C" int wtz_zindex_build(wtz_ctx_t *c){
 extern "C" int wtz_candidates_begin(wtz_ctx_t *c, const uint32_t *qids, uint32_t nq, const uint64_t *cand, const uint32_t *ncand_in){
 	if(!c || !c->ktab || !qids || !cand || !ncand_in) return wtz_fail(WTZ_E_ARG, "index not built / null argument");
 	if(c->cq_pending) return wtz_fail(WTZ_E_STATE, "wtz_candidates_begin: a request is already in flight");
-	c->cq_n = nq;
+	c->cq_n = nq; c->cq_groups = false;
 	if(nq == 0){ c->cq_pending = true; return WTZ_OK; }
 	CTX_ENTER(c);
 	for(uint32_t i = 0; i < nq; i++) if(qids[i] >= c->n_reads) return wtz_fail(WTZ_E_ARG, "query id %u out of range", qids[i]);
@@ -771,6 +864,91 @@ extern "C" int wtz_candidates_end(wtz_ctx_t *c, uint64_t *cand, uint32_t *ncand_
 	{ unsigned long long hb = 0; CHK(dev_d2h(&hb, c->cq_bytes, 8)); c->cnt.bytes_seed_algo += hb; }
 	CHK(dev_d2h(cand, c->cq_cand, (size_t)nq * stride * 8)); CHK(dev_d2h(ncand_out, c->cq_nc, (size_t)nq * 4));
 	CHK(pool_check(c, "wtz_candidates"));
+	return WTZ_OK;
+}
+
+/* A3 against a SHARD of the index: the (read, strand) groups with ol >= -d of every query, for the caller to join over the shards */
+extern "C" int wtz_candidate_groups_begin(wtz_ctx_t *c, const uint32_t *qids, uint32_t nq){
+	if(!c || !c->ktab || (nq && !qids)) return wtz_fail(WTZ_E_ARG, "index not built / null argument");
+	if(c->cq_pending) return wtz_fail(WTZ_E_STATE, "wtz_candidate_groups_begin: a request is already in flight");
+	c->cq_n = nq; c->cq_groups = true;
+	if(nq == 0){ c->cq_pending = true; return WTZ_OK; }
+	CTX_ENTER(c);
+	for(uint32_t i = 0; i < nq; i++) if(qids[i] >= c->n_reads) return wtz_fail(WTZ_E_ARG, "query id %u out of range", qids[i]);
+	CHK(pool_reset(c));
+	const uint32_t stride = c->P.ncand + 1;
+	if(nq > c->cq_cap){
+		(void)dev_sync();
+		dev_free_persist(c->cq_q); dev_free_persist(c->cq_nc); dev_free_persist(c->cq_cand); dev_free_persist(c->cq_bytes); dev_free_persist(c->cq_thr);
+		uint32_t cap = c->cq_cap ? c->cq_cap : 1024; while(cap < nq) cap *= 2;
+		CHK(dev_alloc_persist((void**)&c->cq_q, (size_t)cap * 4)); CHK(dev_alloc_persist((void**)&c->cq_nc, (size_t)cap * 4)); CHK(dev_alloc_persist((void**)&c->cq_thr, (size_t)cap * 4));
+		CHK(dev_alloc_persist((void**)&c->cq_cand, (size_t)cap * stride * 8)); CHK(dev_alloc_persist((void**)&c->cq_bytes, 8));
+		c->cq_cap = cap;
+	}
+	if(nq > c->cq_gcap){ (void)dev_sync(); dev_free_persist(c->cq_gptr); c->cq_gptr = NULL; uint32_t cap = c->cq_gcap ? c->cq_gcap : 1024; while(cap < nq) cap *= 2; CHK(dev_alloc_persist((void**)&c->cq_gptr, (size_t)cap * 8)); c->cq_gcap = cap; }
+	uint32_t *d_q = c->cq_q, *d_n = c->cq_nc; uint64_t *d_cand = c->cq_cand, *d_gptr = c->cq_gptr; unsigned long long *d_bytes = c->cq_bytes;
+	CHK(dev_h2d(d_q, qids, (size_t)nq * 4)); CHK(dev_set(d_n, 0, (size_t)nq * 4)); CHK(dev_set(d_gptr, 0, (size_t)nq * 8)); CHK(dev_set(d_bytes, 0, 8));
+	const uint32_t *d_thr = NULL;
+	if(c->idx_len_sorted && c->idx_end > c->idx_beg){
+		std::vector<uint32_t> thr(nq);
+		for(uint32_t i = 0; i < nq; i++){
+			const uint32_t up = (uint32_t)(c->h_rdlen[qids[i]] * 1.2);              /* double multiply, wtzmo.c:445 */
+			uint32_t lo = c->idx_beg, hi = c->idx_end;
+			while(lo < hi){ const uint32_t mid = lo + (hi - lo) / 2; if(c->h_rdlen[mid] > up) lo = mid + 1; else hi = mid; }
+			thr[i] = lo;
+		}
+		CHK(dev_h2d(c->cq_thr, thr.data(), (size_t)nq * 4)); d_thr = c->cq_thr;
+	}
+	const wtz_reads_t R = ctx_reads(c); const wtz_params_t *dP = c->dP; const wtz_kslot_t *tab = c->ktab; const uint64_t kmask = c->kmask;
+	const uint32_t *seeds = c->kseeds; wtz_pool_t *pool = c->dpool; const uint32_t key_hi = c->idx_end << 1;
+	STAGE(c, "K_candidates (groups)");
+	c->cq_tm.start();
+#ifdef WTZ_EMUL
+	static thread_local uint32_t emul_cwg_lds[WTZ_CWG_LDS_BYTES / 4 + 16];
+	uint32_t *lds_emul = emul_cwg_lds;
+	CHK(wtz_launch_wg<K_candidates_wg>(nq, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_candidates_wg((uint32_t)t, R, d_q, dP, tab, kmask, seeds, pool, d_cand, d_n, stride, d_bytes, lds_emul, d_thr, key_hi, d_gptr); }, 1u, 0u));
+#else
+	CHK(wtz_launch_wg<K_candidates_wg>(nq, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_candidates_wg((uint32_t)t, R, d_q, dP, tab, kmask, seeds, pool, d_cand, d_n, stride, d_bytes, (uint32_t*)wtz_wave_scratch(), d_thr, key_hi, d_gptr); }, WTZ_CWG_THREADS, WTZ_CWG_LDS_BYTES));
+#endif
+	c->cq_tm.lap();
+	c->cq_pending = true;
+	return WTZ_OK;
+}
+extern "C" int wtz_candidate_groups_end(wtz_ctx_t *c, uint32_t *ngroups){
+	if(!c || !c->cq_pending || !c->cq_groups) return wtz_fail(WTZ_E_STATE, "wtz_candidate_groups_end without wtz_candidate_groups_begin");
+	c->cq_pending = false;
+	const uint32_t nq = c->cq_n;
+	c->cq_ng.assign(nq, 0);
+	if(nq == 0) return WTZ_OK;
+	if(!ngroups) return wtz_fail(WTZ_E_ARG, "null argument");
+	CTX_ENTER(c);
+	CHK(dev_sync());
+	c->cnt.ms_candidates += c->cq_tm.read(); c->cnt.n_candidates_q += nq;
+	{ unsigned long long hb = 0; CHK(dev_d2h(&hb, c->cq_bytes, 8)); c->cnt.bytes_seed_algo += hb; }
+	CHK(dev_d2h(c->cq_ng.data(), c->cq_nc, (size_t)nq * 4));
+	CHK(pool_check(c, "wtz_candidate_groups"));
+	for(uint32_t i = 0; i < nq; i++){ if(c->cq_ng[i] == 0xFFFFFFFFu) return wtz_fail(WTZ_E_POOL, "wtz_candidate_groups: query %u ran out of scratch", i); ngroups[i] = c->cq_ng[i]; }
+	return WTZ_OK;
+}
+extern "C" int wtz_candidate_groups_fetch(wtz_ctx_t *c, uint64_t *groups, uint64_t total){
+	if(!c || !c->cq_groups) return wtz_fail(WTZ_E_STATE, "wtz_candidate_groups_fetch before wtz_candidate_groups_end");
+	c->cq_groups = false;
+	const uint32_t nq = c->cq_n;
+	uint64_t tot = 0; for(uint32_t i = 0; i < nq; i++) tot += c->cq_ng[i];
+	if(tot != total) return wtz_fail(WTZ_E_ARG, "wtz_candidate_groups_fetch: expected room for %llu groups, got %llu", (unsigned long long)tot, (unsigned long long)total);
+	if(tot == 0) return WTZ_OK;
+	if(!groups) return wtz_fail(WTZ_E_ARG, "null output");
+	CTX_ENTER(c);
+	std::vector<uint64_t> off((size_t)nq + 1);
+	uint64_t o = 0; for(uint32_t i = 0; i < nq; i++){ off[i] = o; o += c->cq_ng[i]; } off[nq] = o;
+	uint64_t *d_off = NULL, *d_g = NULL;
+	CHK(dev_alloc((void**)&d_off, off.size() * 8)); CHK(dev_h2d(d_off, off.data(), off.size() * 8));
+	CHK(dev_alloc((void**)&d_g, (size_t)tot * 8));
+	const uint64_t *gp = c->cq_gptr;
+	CHK(wtz_launch<K_pack_groups>(0, nq, [=] WTZ_LAMBDA (uint64_t t){ const uint64_t *src = (const uint64_t*)(uintptr_t)gp[t]; const uint64_t n = d_off[t + 1] - d_off[t]; for(uint64_t k = 0; k < n; k++) d_g[d_off[t] + k] = src[k]; }));
+	CHK(dev_sync());
+	CHK(dev_d2h(groups, d_g, (size_t)tot * 8));
+	dev_free(d_off); dev_free(d_g);
 	return WTZ_OK;
 }
 extern "C" int wtz_candidates(wtz_ctx_t *c, const uint32_t *qids, uint32_t nq, uint64_t *cand, uint32_t *ncand_io){

@@ -121,6 +121,71 @@ WTZ_HD void wtz_task_kstats(uint64_t i, const uint64_t *keys, uint64_t n, unsign
 #endif
 }
 
+/* sharded index: the distinct k-mers of the sorted occurrences with their run lengths, compacted through the scan of the head flags */
+WTZ_HD void wtz_task_khead(uint64_t i, const uint64_t *keys, uint32_t *flag){ flag[i] = !(i && keys[i - 1] == keys[i]) ? 1u : 0u; }
+WTZ_HD void wtz_task_kdistinct(uint64_t i, const uint64_t *keys, uint64_t n, const uint32_t *flag, const uint32_t *dpos, uint64_t *dk, uint32_t *dc, uint64_t *dstart){
+	if(!flag[i]) return;
+	const uint64_t c = wtz_run_end(keys, n, i) - i;
+	dk[dpos[i]] = keys[i]; dc[dpos[i]] = c > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)c; dstart[dpos[i]] = i;
+}
+/* sharded index: distinct k-mer d with total count tc over all shards: kept iff 2 <= min(tc, 0xFFFF) <= K (wtzmo.c:276, 401-405) */
+WTZ_HD void wtz_task_kinsert_total(uint64_t d, const uint64_t *dk, const uint32_t *dc, const uint64_t *dstart, const uint32_t *tc, uint32_t K, wtz_kslot_t *tab, uint64_t cap_mask, unsigned long long *n_kept){
+	uint32_t c = tc[d]; if(c > 0xFFFFu) c = 0xFFFFu;
+	const bool kept = !(c > K || c <= 1);
+	if(tab == NULL){
+#if defined(__HIP_DEVICE_COMPILE__)
+		const unsigned long long m = __ballot(kept);
+		if(m && (threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(m)) atomicAdd(n_kept, (unsigned long long)__popcll(m));
+#else
+		if(kept) *n_kept += 1;
+#endif
+		return;
+	}
+	if(!kept) return;
+	uint64_t h = wtz_mix64(dk[d]) & cap_mask;
+	for(;;){
+#if defined(__HIP_DEVICE_COMPILE__)
+		unsigned long long old = atomicCAS((unsigned long long*)&tab[h].key, (unsigned long long)WTZ_KEMPTY, (unsigned long long)dk[d]);
+#else
+		uint64_t old = tab[h].key; if(old == WTZ_KEMPTY) tab[h].key = dk[d];
+#endif
+		if(old == WTZ_KEMPTY){ tab[h].val = (dstart[d] << 16) | (uint64_t)(dc[d] > 0xFFFFu ? 0xFFFFu : dc[d]); return; }
+		h = (h + 1) & cap_mask;
+	}
+}
+
+/* strided forms of the two counting passes: a thread takes every nt-th occurrence and adds its sums once per WAVEFRONT at the end (3.5 M
+ * same-address atomics - one per wavefront of the per-occurrence form - serialised in L2: 42 ms each at configs[2] for 2 ms of reading) */
+WTZ_HD void wtz_task_kstats_stride(uint64_t t, uint64_t nt, const uint64_t *keys, uint64_t n, unsigned long long *excess, unsigned long long *ktyp){
+	unsigned long long heads = 0, exc = 0;
+	for(uint64_t i = t; i < n; i += nt){
+		if(i && keys[i - 1] == keys[i]) continue;
+		heads++;
+		const uint64_t c = wtz_run_end(keys, n, i) - i;
+		if(c > 0xFFFFu) exc += c - 0xFFFFu;
+	}
+#if defined(__HIP_DEVICE_COMPILE__)
+	for(int d = 32; d > 0; d >>= 1){ heads += __shfl_xor(heads, d, 64); exc += __shfl_xor(exc, d, 64); }
+	if((threadIdx.x & 63u) == 0){ if(heads) atomicAdd(ktyp, heads); if(exc) atomicAdd(excess, exc); }
+#else
+	*ktyp += heads; *excess += exc;
+#endif
+}
+WTZ_HD void wtz_task_kkept_stride(uint64_t t, uint64_t nt, const uint64_t *keys, uint64_t n, uint32_t K, unsigned long long *n_kept){
+	unsigned long long kept = 0;
+	for(uint64_t i = t; i < n; i += nt){
+		if(i && keys[i - 1] == keys[i]) continue;
+		uint64_t c = wtz_run_end(keys, n, i) - i; if(c > 0xFFFFu) c = 0xFFFFu;
+		if(!(c > K || c <= 1)) kept++;
+	}
+#if defined(__HIP_DEVICE_COMPILE__)
+	for(int d = 32; d > 0; d >>= 1) kept += __shfl_xor(kept, d, 64);
+	if((threadIdx.x & 63u) == 0 && kept) atomicAdd(n_kept, kept);
+#else
+	*n_kept += kept;
+#endif
+}
+
 /* task: run heads with 2 <= cnt <= K are counted (tab == NULL) or inserted into the hash (wtzmo.c:396-411) */
 WTZ_HD void wtz_task_kinsert(uint64_t i, const uint64_t *keys, uint64_t n, uint32_t K, wtz_kslot_t *tab, uint64_t cap_mask, unsigned long long *n_kept){
 	const bool head = !(i && keys[i - 1] == keys[i]);
@@ -676,7 +741,7 @@ struct wtz_kq2_f { uint64_t *mer; wtz_kq_t *kq; uint32_t n;
 
 WTZ_HD void wtz_task_candidates_wg(uint32_t t, wtz_reads_t R, const uint32_t *qids, const wtz_params_t *P,
 		const wtz_kslot_t *tab, uint64_t tmask, const uint32_t *seeds, wtz_pool_t *pool, uint64_t *cand_out, uint32_t *ncand_out, uint32_t stride,
-		unsigned long long *algo_bytes, uint32_t *lds, const uint32_t *id_thr, uint32_t key_hi){
+		unsigned long long *algo_bytes, uint32_t *lds, const uint32_t *id_thr, uint32_t key_hi, uint64_t *gptr = NULL){
 	const uint32_t tid = WTZ_WG_TID, nt = WTZ_WG_N;
 	const uint32_t pbid = qids[t], L = R.rdlen[pbid];
 	const uint32_t pblen_up = (uint32_t)(L * 1.2);                       /* double multiply, wtzmo.c:445 */
@@ -843,9 +908,12 @@ WTZ_HD void wtz_task_candidates_wg(uint32_t t, wtz_reads_t R, const uint32_t *qi
 	WTZ_WG_SYNC();
 	/* ---- F ---- */
 	if(tid == 0){
-		uint32_t hn = ncand_out[t];                 /* heap carried across index parts (-G), 0 otherwise */
-		wtz_cand_tail(grp, ng, kovl, P->ncand, cand_out + (size_t)t * stride, &hn);
-		ncand_out[t] = hn;
+		if(gptr){ gptr[t] = (uint64_t)(uintptr_t)grp; ncand_out[t] = ng; }      /* sharded index: the groups go to the caller, who joins the shards (wtz_cand_tail_host) */
+		else {
+			uint32_t hn = ncand_out[t];                 /* heap carried across index parts (-G), 0 otherwise */
+			wtz_cand_tail(grp, ng, kovl, P->ncand, cand_out + (size_t)t * stride, &hn);
+			ncand_out[t] = hn;
+		}
 	}
 }
 

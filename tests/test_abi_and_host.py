@@ -94,6 +94,17 @@ def test_multi_device_central_commit(name, devs, emul_exe, tmp_path):
     assert md5 == case["md5_full"] and cont == case["md5_contained"]
 
 
+@pytest.mark.parametrize("name,devs", [("zmo", "0,0"), ("dmo", "0,0"), ("zmo", "0,0,0"), ("dmo", "0,0,0"), ("zmo_S1", "0,0"), ("zmo_I", "0,0")])
+def test_index_sharded_by_read_id_equals_unsharded(name, devs, emul_exe, tmp_path):
+    """--shard-index (BASELINE configs[4]): every device indexes one contiguous read-id range; the frequency filter and the
+    automatic cutoff use the k-mer counts of ALL shards (one exchange), every shard answers every query with its (read, strand) groups
+    and the heap replay runs over the shards' lists in shard order.  The output must be the UNSHARDED golden (`zmo`, not `zmo_G2`:
+    the reference's own -G filters each part by its own counts and gives different records)."""
+    case = manifest()["cases"][name]
+    md5, cont, _ = run_wtzmo_like(emul_exe, case, tmp_path, extra=["--gpu-list", devs, "--shard-index", "--batch", "16"])
+    assert md5 == case["md5_full"] and cont == case["md5_contained"]
+
+
 def test_word_level_base_packing(tmp_path):
     """wtz_pack32 (two 64-bit loads + funnel shift per 32 bases, both strands, complement) == 32 single-base extractions."""
     exe = os.path.join(str(tmp_path), "check_pack32")

@@ -47,6 +47,15 @@ def test_two_worker_contexts_same_output(name, gpu_exe, tmp_path):
     assert md5 == case["md5_full"] and cont == case["md5_contained"]
 
 
+@pytest.mark.parametrize("name,devs", [("zmo", "0,0"), ("dmo", "0,0,0"), ("zmo_S1", "0,0,0")])
+def test_index_sharded_by_read_id_equals_unsharded(name, devs, gpu_exe, tmp_path):
+    """--shard-index: contexts on this box's one GPU stand in for the devices; each indexes one read-id range, the k-mer filter uses the
+    counts of all shards, every query is answered by every shard: the UNSHARDED reference records must come out (SURVEY 8e, configs[4])."""
+    case = manifest()["cases"][name]
+    md5, cont, _ = run_wtzmo_like(gpu_exe, case, tmp_path, extra=["--gpu-list", devs, "--shard-index", "--batch", "16"])
+    assert md5 == case["md5_full"] and cont == case["md5_contained"]
+
+
 @pytest.mark.parametrize("name,devs", [("zmo", "0,0"), ("dmo", "0,0"), ("zmo_n", "0,0,0")])
 def test_multi_device_central_commit(name, devs, gpu_exe, tmp_path):
     """--gpu-list 0,0: two (three) contexts on this box's one GPU stand in for --gpus N: pairs dealt round-robin to the contexts, both

@@ -33,8 +33,10 @@ dist.destroy_process_group()
 '''
 
 
-@pytest.mark.parametrize("name,world", [("zmo", 2), ("dmo", 2), ("zmo", 3), ("zmo_n", 2)])
-def test_ranks_central_commit(name, world, tmp_path):
+@pytest.mark.parametrize("name,world,extra", [("zmo", 2, []), ("dmo", 2, []), ("zmo", 3, []), ("zmo_n", 2, []), ("zmo", 2, ["--shard-index"]), ("dmo", 3, ["--shard-index"])])
+def test_ranks_central_commit(name, world, extra, tmp_path):
+    """extra = --shard-index: the k-mer index is sharded by read-id range over the RANKS (one (k-mer, count) exchange at build time, the
+    groups of every query gathered from all ranks): rank 0's file must still be the unsharded `wtzmo -t 1` golden."""
     subprocess.run([os.path.join(ROOT, "tests", "emul", "build_emul.sh")], check=True)
     lib = os.path.join(ROOT, "tests", "emul", "libwtzmo_host_emul.so")
     case = manifest()["cases"][name]
@@ -47,7 +49,7 @@ def test_ranks_central_commit(name, world, tmp_path):
     procs = []
     for r in range(world):
         e = dict(env, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r))
-        procs.append(subprocess.Popen([sys.executable, w, ROOT, lib, os.path.join(GOLD, case["input"]), str(tmp_path)] + case_argv(case), env=e))
+        procs.append(subprocess.Popen([sys.executable, w, ROOT, lib, os.path.join(GOLD, case["input"]), str(tmp_path)] + case_argv(case) + extra, env=e))
     for p in procs:
         assert p.wait(timeout=900) == 0
     got = hashlib.md5(open(os.path.join(str(tmp_path), "r0.ovl"), "rb").read()).hexdigest()
