@@ -131,6 +131,9 @@ void wtz_cand_tail_host(const uint64_t *groups, uint32_t ng, uint32_t kovl, uint
 
 /* A5 for every read + the candidate-side occurrence caps of A6. Call once after wtz_upload_reads. */
 int  wtz_zindex_build(wtz_ctx_t *ctx);
+/* The same index for the listed reads only (ascending ids); every other read gets an empty slice.  For read sets whose whole z-index
+ * (16 B per base) does not fit beside the scratch pool: the caller rebuilds it per batch of queries from the batch's queries + candidates. */
+int  wtz_zindex_build_subset(wtz_ctx_t *ctx, const uint32_t *ids, uint32_t n);
 
 /* A3. cand: nq rows of (ncand+1) u64 `id<<32|ol`; ncand_io[i]: in = entries already in row i
  * (candidate heaps carried across -G index parts, else 0), out = entries after this index part.

@@ -72,6 +72,8 @@ typedef struct eng_s {
 	uint32_t *rdlen; uint32_t avg_rdlen;
 	uint64_t *closed_order; size_t n_order, cap_order; int keep_order;      /* -9: the pairs in the order they entered closed_alns (the file is a replay of it) */
 	wtz_ctx_t *ctx; FILE *out;
+	int zbatch;                 /* --zindex-batch (automatic above ~2.4 Gbp of reads): the z-mer index is rebuilt per batch of queries for the batch's queries + candidates instead
+	                             * of once for all reads (16 B per base: 160 GB at BASELINE configs[3]) */
 	int shard;                  /* --shard-index: the k-mer index is sharded by read-id range over the devices (reads and z-index stay replicated); output == unsharded */
 	uint32_t ndev; int devs[8]; wtz_ctx_t *ctxs[8];      /* --gpus N / --gpu-list: one context per device, reads + both indexes replicated; ctx == ctxs[0] */
 	uint64_t pair_bp, n_pairs, nrec;
@@ -1026,10 +1028,10 @@ static void process_batch(eng_t *E, batch_t *b){
 }
 
 /* both index builds of one more device (replicated indexes, --gpus) */
-typedef struct { wtz_ctx_t *ctx; uint32_t n_rd, K; int rc; char err[256]; int zonly; } ixjob_t;
+typedef struct { wtz_ctx_t *ctx; uint32_t n_rd, K; int rc; char err[256]; int zonly, nozidx; } ixjob_t;
 static void *ixjob_main(void *arg){
 	ixjob_t *j = (ixjob_t*)arg; wtz_index_stats_t ist;
-	j->rc = wtz_zindex_build(j->ctx);
+	j->rc = j->nozidx ? WTZ_OK : wtz_zindex_build(j->ctx);
 	if(j->rc == WTZ_OK && !j->zonly) j->rc = wtz_index_build(j->ctx, 0, j->n_rd, &j->K, &ist);
 	if(j->rc != WTZ_OK){ strncpy(j->err, wtz_last_error(), sizeof j->err - 1); j->err[sizeof j->err - 1] = 0; }
 	return NULL;
@@ -1114,6 +1116,21 @@ static void *worker_main(void *arg){
 			free(rows); free(nr);
 			pthread_mutex_lock(&E->mu); E->t_gpu += tg1 - tg0; E->t_call[0] += tg1 - tg0; pthread_mutex_unlock(&E->mu);
 		}
+		if(b->nbq && E->zbatch > 0){
+			/* per-batch z-index: the batch's queries and every read in their candidate rows (a superset of what the pair stages will look up) */
+			const uint32_t n_all = (uint32_t)(E->st.n_rd + E->st.n_qr);
+			uint8_t *mark = (uint8_t*)calloc((size_t)n_all + 1, 1); uint32_t *list = (uint32_t*)hx_realloc(NULL, 4 * ((size_t)n_all + 1)), nl = 0;
+			for(uint32_t s = 0; s < b->nbq; s++){
+				if(!b->want[s]) continue;
+				mark[b->bq[s]] = 1;
+				for(uint32_t k = 0; k < b->nrow[s]; k++){ const uint32_t id2 = (uint32_t)(b->rows[(size_t)s * E->stride + k] >> 32); if(id2 < n_all) mark[id2] = 1; }
+			}
+			for(uint32_t r = 0; r < n_all; r++) if(mark[r]) list[nl++] = r;
+			const double tz0 = now_s();
+			for(uint32_t d = 0; d < E->ndev; d++){ int rc = wtz_zindex_build_subset(E->ctxs[d], list, nl); DIE_WTZ(rc, "wtz_zindex_build_subset"); }
+			pthread_mutex_lock(&E->mu); E->t_gpu += now_s() - tz0; pthread_mutex_unlock(&E->mu);
+			free(mark); free(list);
+		}
 		if(b->nbq) process_batch(E, b);
 		/* ---- hand the turn to the next batch ---- */
 		pthread_mutex_lock(&E->mu);
@@ -1156,7 +1173,7 @@ int main(int argc, char **argv){
 	E->do_align = 1; E->n_idx = 1; E->n_job = 1; E->i_job = 0; E->max_batch = 2048; E->first_batch = 256; E->n_workers = 1;
 	pthread_mutex_init(&E->mu, NULL); pthread_cond_init(&E->cv, NULL);
 	static struct option lopts[] = { {"stats", required_argument, 0, 1000}, {"gpu", required_argument, 0, 1001}, {"pool-gb", required_argument, 0, 1002},
-		{"batch", required_argument, 0, 1003}, {"lib-check", no_argument, 0, 1004}, {"repeat", required_argument, 0, 1005}, {"first-batch", required_argument, 0, 1006}, {"workers", required_argument, 0, 1007}, {"pool-mb", required_argument, 0, 1008}, {"gpus", required_argument, 0, 1010}, {"gpu-list", required_argument, 0, 1011}, {"shard-index", no_argument, 0, 1012}, {0, 0, 0, 0} };
+		{"batch", required_argument, 0, 1003}, {"lib-check", no_argument, 0, 1004}, {"repeat", required_argument, 0, 1005}, {"first-batch", required_argument, 0, 1006}, {"workers", required_argument, 0, 1007}, {"pool-mb", required_argument, 0, 1008}, {"gpus", required_argument, 0, 1010}, {"gpu-list", required_argument, 0, 1011}, {"shard-index", no_argument, 0, 1012}, {"zindex-batch", required_argument, 0, 1013}, {0, 0, 0, 0} };
 	while((c = getopt_long(argc, argv, "ht:P:p:Ni:b:J:I:o:9:S:fCH:k:G:z:Z:U:y:d:r:q:l:K:A:B:r:R:L:F:W:w:e:M:X:O:E:T:s:m:nv", lopts, NULL)) != -1){
 		switch(c){
 			case 1000: statsf = optarg; break;
@@ -1167,6 +1184,7 @@ int main(int argc, char **argv){
 			case 1005: repeat = atoi(optarg); if(repeat < 1) repeat = 1; break;
 			case 1006: E->first_batch = (uint32_t)atoi(optarg); if(E->first_batch < 1) E->first_batch = 1; E->first_batch_set = 1; break;
 			case 1010: n_gpus = atoi(optarg); if(n_gpus < 1) n_gpus = 1; if(n_gpus > 8) n_gpus = 8; break;
+			case 1013: E->zbatch = atoi(optarg) ? 1 : -1; break;      /* 1 = per-batch z-index, 0 = never (default: by the size of the read set) */
 			case 1012: E->shard = 1; break;           /* k-mer index sharded over the devices of --gpus / --gpu-list (or over the ranks) */
 			case 1011: gpu_list = optarg; break;      /* explicit device ids, e.g. 0,1,2,3 (an id may repeat: two contexts on one GPU, used by the tests) */
 			case 1008: pool_mb = (uint64_t)atoll(optarg); break;      /* test hook: a pool small enough to force the batch-splitting path */
@@ -1321,6 +1339,9 @@ int main(int argc, char **argv){
 		if(g_dist.world > WTZ_DIST_MAX || !g_dist.bcast || !g_dist.send || !g_dist.recv){ fprintf(stderr, " -- wtzmo_set_dist: bad rank setup --\n"); exit(1); }
 		if(E->n_idx > 1 || E->n_workers > 1 || E->ndev > 1 || E->n_job > 1){ fprintf(stderr, " -- ranks (one process per GPU) exclude -G, -P, --workers and --gpus --\n"); exit(1); }
 	}
+	if(E->zbatch == 0 && E->st.nbase > 2400000000ull && g_dist.world == 1 && E->n_workers == 1){ E->zbatch = 1; fprintf(stderr, "[wtzmo-mi355x] %llu read bases: the z-mer index is built per batch of queries (--zindex-batch 0 to force the all-reads index)\n", (unsigned long long)E->st.nbase); }
+	if(E->zbatch > 0 && (g_dist.world > 1 || E->n_workers > 1)){ fprintf(stderr, " -- --zindex-batch excludes ranks and --workers --\n"); exit(1); }
+	if(E->zbatch > 0 && E->max_batch > 512) E->max_batch = 512;
 	if(E->shard && (E->n_idx > 1 || E->n_workers > 1)){ fprintf(stderr, " -- --shard-index excludes -G and --workers --\n"); exit(1); }
 	if(E->ndev > 1 && (E->n_idx > 1 || E->n_workers > 1)){
 		fprintf(stderr, "[wtzmo-mi355x] -G / --workers run on one device: --gpus ignored\n"); E->ndev = 1;
@@ -1383,8 +1404,8 @@ int main(int argc, char **argv){
 		if(g_hook) g_hook(rep, 0);
 		const double t0 = now_s();
 		pthread_t ixth[8]; ixjob_t ixj[8];
-		for(uint32_t d = 1; d < E->ndev; d++){ ixj[d].ctx = E->ctxs[d]; ixj[d].n_rd = n_rd; ixj[d].K = P->max_kmer_freq; ixj[d].zonly = E->shard; if(pthread_create(&ixth[d], NULL, ixjob_main, &ixj[d]) != 0) DIE_NOW(); }
-		rc = wtz_zindex_build(E->ctx); DIE_WTZ(rc, "wtz_zindex_build");
+		for(uint32_t d = 1; d < E->ndev; d++){ ixj[d].ctx = E->ctxs[d]; ixj[d].n_rd = n_rd; ixj[d].K = P->max_kmer_freq; ixj[d].zonly = E->shard; ixj[d].nozidx = E->zbatch > 0; if(pthread_create(&ixth[d], NULL, ixjob_main, &ixj[d]) != 0) DIE_NOW(); }
+		if(E->zbatch <= 0){ rc = wtz_zindex_build(E->ctx); DIE_WTZ(rc, "wtz_zindex_build"); }
 		/* ---- index parts (-G, wtzmo.c:1276-1303) ---- */
 		uint32_t pbbeg = 0, pbend = 0, K = P->max_kmer_freq;
 		wtz_index_stats_t ist;

@@ -330,7 +330,7 @@ struct wtz_ctx {
 	uint64_t *cq_gptr = NULL; uint32_t cq_gcap = 0; bool cq_groups = false; std::vector<uint32_t> cq_ng;
 	uint32_t idx_beg = 0, idx_end = 0; bool idx_len_sorted = false;      /* read range of the k-mer index; lengths non-increasing inside it (true unless -b clipped reads after the sort) */
 	/* z index */
-	uint64_t *zoff; uint64_t n_z; wtz_zindex_t Z; bool have_z;
+	uint64_t *zoff; uint64_t n_z; wtz_zindex_t Z; bool have_z; bool zsub = false; uint64_t zsub_cap = 0;      /* zsub: the z-index holds a subset of the reads (rebuilt per batch) */
 	/* pool */
 	/* scratch: ONE allocation of pool_bytes, cut in two bump pools: dpool[0] = results and scratch that live for the batch (match lists,
 	 * windows, anchors, CIGARs), dpool[1] = the transient pool of the K-sw3 trace matrices, reset after every launch group of extension
@@ -731,17 +731,30 @@ extern "C" void wtz_cand_tail_host(const uint64_t *groups, uint32_t ng, uint32_t
 /* ------------------------------------------------------------------------------------------------ */
 /* A5: z-mer index of every read                                                                     */
 /* ------------------------------------------------------------------------------------------------ */
-extern "C" int wtz_zindex_build(wtz_ctx_t *c){
+/* members == NULL: the z-index of every read.  Else (ascending read ids): of those reads only - every other read gets an empty slice, so the
+ * kernels address the index exactly as before.  The subset form is rebuilt per batch of queries (their candidate sets bound what a batch
+ * can look up), which is what lets a 10 Gbp read set (160 GB of z-index at 16 B per base) run in 288 GB: its arrays are allocated once
+ * with head-room and reused. */
+static int zindex_build_impl(wtz_ctx_t *c, const uint32_t *members, uint32_t nm){
 	if(!c || !c->bits) return wtz_fail(WTZ_E_ARG, "reads not uploaded");
 	CTX_ENTER(c);
 	if(c->shares_indexes) return wtz_fail(WTZ_E_STATE, "wtz_zindex_build on a cloned context");
-	zpark_all(c); c->zoff = NULL; memset(&c->Z, 0, sizeof c->Z); c->have_z = false;      /* the old arrays are recycled below */
+	const bool subset = members != NULL;
+	if(!subset || !c->zsub){ zpark_all(c); if(subset) zflush_parked(c); c->zoff = NULL; memset(&c->Z, 0, sizeof c->Z); c->zsub_cap = 0; }      /* the old arrays are recycled below */
+	c->have_z = false;
 	wtz_timer tm; tm.start();
 	const wtz_reads_t R = ctx_reads(c); const uint32_t nr = c->n_reads, zsize = c->P.zsize, hz = c->P.hz, zcut = c->P.max_zmer_freq;
-	CHK(zalloc(c, (void**)&c->zoff, ((size_t)nr + 1) * 8));
+	if(c->zoff == NULL) CHK(zalloc(c, (void**)&c->zoff, ((size_t)nr + 1) * 8));
 	uint64_t *d_off = c->zoff;
 	std::vector<uint32_t> p_rid, p_jb; std::vector<size_t> first_piece((size_t)nr + 1);
-	for(uint32_t r = 0; r < nr; r++){ first_piece[r] = p_rid.size(); for(uint32_t jb = 0; jb == 0 || jb < c->h_rdlen[r]; jb += WTZ_WALK_CHUNK){ p_rid.push_back(r); p_jb.push_back(jb); } }
+	{ uint32_t mi = 0;
+	  for(uint32_t r = 0; r < nr; r++){
+		first_piece[r] = p_rid.size();
+		if(subset){ if(mi < nm && members[mi] == r) mi++; else continue; }
+		for(uint32_t jb = 0; jb == 0 || jb < c->h_rdlen[r]; jb += WTZ_WALK_CHUNK){ p_rid.push_back(r); p_jb.push_back(jb); }
+	  }
+	  if(subset && mi != nm) return wtz_fail(WTZ_E_ARG, "wtz_zindex_build_subset: the read ids must be ascending, unique and in range");
+	}
 	const size_t np = p_rid.size(); first_piece[nr] = np;
 	uint32_t *d_prid = NULL, *d_pjb = NULL; uint64_t *d_poff = NULL;
 	CHK(dev_alloc((void**)&d_prid, (np + 1) * 4)); CHK(dev_alloc((void**)&d_pjb, (np + 1) * 4)); CHK(dev_alloc((void**)&d_poff, (np + 1) * 8));
@@ -755,11 +768,18 @@ extern "C" int wtz_zindex_build(wtz_ctx_t *c){
 	CHK(dev_h2d(d_off, h.data(), ((size_t)nr + 1) * 8));
 	c->n_z = tot;
 	wtz_zindex_t Z; memset(&Z, 0, sizeof Z); Z.zoff = c->zoff;
-	CHK(zalloc(c, (void**)&Z.mer, (tot + 1) * 4)); CHK(zalloc(c, (void**)&Z.pos, (tot + 1) * 4)); CHK(zalloc(c, (void**)&Z.len, (tot + 1) * 2));
-	CHK(zalloc(c, (void**)&Z.ok, tot + 1)); CHK(zalloc(c, (void**)&Z.sidx, (tot + 1) * 4));
-	CHK(zalloc(c, (void**)&Z.dmer, (tot + 1) * 4)); CHK(zalloc(c, (void**)&Z.dfirst, (tot + 1) * 4)); CHK(zalloc(c, (void**)&Z.dcnt, (tot + 1) * 2));
-	CHK(zalloc(c, (void**)&Z.dn, ((size_t)nr + 1) * 4));
-	zflush_parked(c);                     /* whatever did not fit a request goes back to the driver */
+	if(subset && c->zsub && tot + 1 <= c->zsub_cap) Z = c->Z;      /* the arrays of the previous subset are large enough */
+	else {
+		if(subset && c->zsub){ (void)dev_sync(); zpark_all(c); zflush_parked(c); CHK(zalloc(c, (void**)&c->zoff, ((size_t)nr + 1) * 8)); d_off = c->zoff; CHK(dev_h2d(d_off, h.data(), ((size_t)nr + 1) * 8)); Z.zoff = c->zoff; }
+		const uint64_t cap = subset ? tot + tot / 4 + 1024 : tot + 1;      /* subsets: head-room, so that most batches reuse the allocation */
+		CHK(zalloc(c, (void**)&Z.mer, cap * 4)); CHK(zalloc(c, (void**)&Z.pos, cap * 4)); CHK(zalloc(c, (void**)&Z.len, cap * 2));
+		CHK(zalloc(c, (void**)&Z.ok, cap)); CHK(zalloc(c, (void**)&Z.sidx, cap * 4));
+		CHK(zalloc(c, (void**)&Z.dmer, cap * 4)); CHK(zalloc(c, (void**)&Z.dfirst, cap * 4)); CHK(zalloc(c, (void**)&Z.dcnt, cap * 2));
+		CHK(zalloc(c, (void**)&Z.dn, ((size_t)nr + 1) * 4));
+		zflush_parked(c);                     /* whatever did not fit a request goes back to the driver */
+		c->zsub_cap = subset ? cap : 0;
+	}
+	c->zsub = subset;
 	c->Z = Z;
 	{
 		uint64_t *d_key = NULL; uint32_t *d_flag = NULL, *d_cnt = NULL, *d_dpos = NULL; uint32_t *d_val = Z.sidx;
@@ -780,6 +800,12 @@ extern "C" int wtz_zindex_build(wtz_ctx_t *c){
 	c->have_z = true;
 	c->cnt.ms_zindex += tm.stop();
 	return WTZ_OK;
+}
+extern "C" int wtz_zindex_build(wtz_ctx_t *c){ return zindex_build_impl(c, NULL, 0); }
+extern "C" int wtz_zindex_build_subset(wtz_ctx_t *c, const uint32_t *ids, uint32_t n){
+	if(!ids && n) return wtz_fail(WTZ_E_ARG, "null argument");
+	static const uint32_t none = 0;
+	return zindex_build_impl(c, ids ? ids : &none, n);
 }
 
 /* ------------------------------------------------------------------------------------------------ */

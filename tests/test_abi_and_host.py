@@ -105,6 +105,14 @@ def test_index_sharded_by_read_id_equals_unsharded(name, devs, emul_exe, tmp_pat
     assert md5 == case["md5_full"] and cont == case["md5_contained"]
 
 
+@pytest.mark.parametrize("name", ["zmo", "dmo", "zmo_I", "zmo_G2"])
+def test_per_batch_zindex_equals_all_reads_index(name, emul_exe, tmp_path):
+    """--zindex-batch 1 (wtz_zindex_build_subset per batch: the batch's queries + every read in their candidate rows)"""
+    case = manifest()["cases"][name]
+    md5, cont, _ = run_wtzmo_like(emul_exe, case, tmp_path, extra=["--zindex-batch", "1", "--batch", "7"])
+    assert md5 == case["md5_full"] and cont == case["md5_contained"]
+
+
 def test_word_level_base_packing(tmp_path):
     """wtz_pack32 (two 64-bit loads + funnel shift per 32 bases, both strands, complement) == 32 single-base extractions."""
     exe = os.path.join(str(tmp_path), "check_pack32")

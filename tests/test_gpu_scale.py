@@ -51,6 +51,9 @@ def reads_of(name):
 @pytest.mark.parametrize("name", CASES)
 def test_gpu_equals_reference_at_scale(name, gpu_exe):
     case = MAN["cases"][name]
+    if case["set"].startswith("fly") and not os.environ.get("WTZ_TEST_FLY"):
+        pytest.skip("BASELINE configs[3] shape (10 Gbp of reads: ~10 minutes to generate, 10 GB of FASTA): run with WTZ_TEST_FLY=1 "
+                    "(tools/gpu_r03_fly.sh; its log is kept under profiles/)")
     fa = reads_of(case["set"])
     out = os.path.join(TMP, "scale_%s.ovl" % name)
     stats = out + ".stats"
@@ -67,8 +70,22 @@ def test_gpu_equals_reference_at_scale(name, gpu_exe):
     assert (int(row[0]), int(row[1])) == (case["pairs"], case["pair_bp"]), "pairs entering pair alignment (the bench numerator) differ from the reference's -9 set"
     # planned, not exception-driven: the ranges of a batch are cut to the scratch pool BEFORE the device stages run (the halving after a
     # WTZ_E_POOL stays as the safety net for inputs whose pairs differ wildly in size: the repeat-rich set may use it)
-    if case["set"] != "repeat":
+    if case["set"] != "repeat" and not case["set"].startswith("fly"):
         assert b"splitting the batch" not in r.stderr, "a planned range overflowed the scratch pool"
+    os.remove(out)
+
+
+@pytest.mark.parametrize("name", ["ecoli_zmo", "ecoli_dmo"])
+def test_per_batch_zindex_at_scale(name, gpu_exe):
+    """--zindex-batch 1: the z-mer index rebuilt per batch of queries for the batch's queries + candidates (what a 10 Gbp read set needs to
+    fit 288 GB, BASELINE configs[3]) must give the reference's records like the all-reads index does."""
+    case = MAN["cases"][name]
+    fa = reads_of(case["set"])
+    out = os.path.join(TMP, "zbatch_%s.ovl" % name)
+    r = subprocess.run([gpu_exe, "-i", fa, "-fo", out, "--zindex-batch", "1"] + case["argv"], capture_output=True)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    md5, nrec = file_md5(out)
+    assert (nrec, md5) == (case["records"], case["md5_full"])
     os.remove(out)
 
 
