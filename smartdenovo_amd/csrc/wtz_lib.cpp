@@ -314,6 +314,7 @@ struct wtz_ctx {
 #ifndef WTZ_EMUL
 	hipStream_t stream;
 	hipStream_t stream_mw = 0; hipEvent_t ev_mw_fork = 0, ev_mw_join = 0;      /* side stream of the multi-wave K-sw3 launch */
+	hipStream_t stream_cls[8] = {0, 0, 0, 0, 0, 0, 0, 0}; hipEvent_t ev_cls[8] = {0, 0, 0, 0, 0, 0, 0, 0};   /* K-sw3 band classes, one launch each (created on first use) */
 	hipStream_t stream_gap = 0; hipEvent_t ev_gap_fork = 0, ev_gap_join = 0;   /* side stream of K_gap (runs beside the left extensions) */
 #endif
 	bool shares_indexes;      /* clone: reads / k-mer table / z-index belong to the parent context */
@@ -345,6 +346,8 @@ struct wtz_ctx {
 	uint32_t *cq_q = NULL, *cq_nc = NULL; uint64_t *cq_cand = NULL; unsigned long long *cq_bytes = NULL; uint32_t cq_cap = 0, cq_n = 0; bool cq_pending = false; wtz_timer cq_tm;
 	wtz_counters_t cnt;
 	uint64_t tpool_peak_call = 0, main_used_call = 0;      /* transient-pool high-water mark / main-pool bytes of the API call in progress */
+	int env_ext_mw_cw = 32;      /* WTZ_EXT_MW_CW: K-sw3 jobs with more band columns per lane than this run on four waves whatever their length */
+	int env_ext_split = 0;       /* WTZ_EXT_SPLIT=1: K-sw3 one-wave jobs in two launches by band class (experiment) */
 	int env_cand_wg = 1;         /* WTZ_CAND_WG=0: the one-wavefront-per-query sorting form of the seed lookup (the form before round 3) */
 	int env_cand_stream = 0;     /* WTZ_CAND_STREAM=1: sort-free candidate accumulation (LDS sketch + survivor table, wtz_seed.h); bit-exact, pays at 25x coverage only: see DESIGN.md */
 	int env_gap_lane = 1;        /* WTZ_GAP_LANE=0: every gap on a wavefront (the form before round 3) */
@@ -464,6 +467,8 @@ extern "C" int wtz_ctx_create(int device, const wtz_params_c *params, uint64_t p
 	c->env_trace = getenv("WTZ_STAGE_TRACE") != NULL;
 	c->env_cand_stream = (getenv("WTZ_CAND_STREAM") && atoi(getenv("WTZ_CAND_STREAM")) != 0);
 	if(getenv("WTZ_CAND_WG")) c->env_cand_wg = atoi(getenv("WTZ_CAND_WG"));
+	if(getenv("WTZ_EXT_SPLIT")) c->env_ext_split = atoi(getenv("WTZ_EXT_SPLIT"));
+	if(getenv("WTZ_EXT_MW_CW")) c->env_ext_mw_cw = atoi(getenv("WTZ_EXT_MW_CW"));
 	c->env_grp4 = (getenv("WTZ_WINALIGN4") && atoi(getenv("WTZ_WINALIGN4")) != 0);
 	if(getenv("WTZ_WINALIGN_LANE")) c->env_lane = atoi(getenv("WTZ_WINALIGN_LANE"));
 	if(getenv("WTZ_GAP_LANE")) c->env_gap_lane = atoi(getenv("WTZ_GAP_LANE"));
@@ -535,6 +540,7 @@ extern "C" void wtz_ctx_destroy(wtz_ctx_t *c){
 #ifndef WTZ_EMUL
 	if(c->stream_mw) (void)hipStreamDestroy(c->stream_mw);
 	if(c->stream_gap) (void)hipStreamDestroy(c->stream_gap);
+	for(int k = 0; k < 8; k++){ if(c->stream_cls[k]) (void)hipStreamDestroy(c->stream_cls[k]); if(c->ev_cls[k]) (void)hipEventDestroy(c->ev_cls[k]); }
 	{ hipEvent_t evs[4] = { c->ev_mw_fork, c->ev_mw_join, c->ev_gap_fork, c->ev_gap_join }; for(int k = 0; k < 4; k++) if(evs[k]) (void)hipEventDestroy(evs[k]); }
 	if(c->stream) (void)hipStreamDestroy(c->stream);
 #endif
@@ -1143,7 +1149,7 @@ static int run_extjobs(wtz_ctx *c, const wtz_env_t &V, wtz_extjob_t *d_jobs, uin
 	 * start the long ones first (key = query-side length, the row count upper bound) */
 	uint32_t *d_order = NULL; unsigned long long ext_sum = 0; int32_t ext_max = 0; uint32_t n_mw = 0;
 	const int mw_min = c->env_mw_min;
-	std::vector<uint32_t> ord(m); std::vector<uint64_t> need(m);
+	std::vector<uint32_t> ord(m); std::vector<uint64_t> need(m); std::vector<uint8_t> cw(m, 0);
 	unsigned long long geo_n[9] = {0}, geo_rows[9] = {0}, geo_cells[9] = {0};
 	{
 		/* (qlen, tlen, init_score, W) of every job: the order key, and the job's geometry = an upper bound of its trace bytes */
@@ -1163,6 +1169,7 @@ static int run_extjobs(wtz_ctx *c, const wtz_env_t &V, wtz_extjob_t *d_jobs, uin
 			if(qlen <= 0 || tlen <= 0) continue;
 			int32_t init = key4[(size_t)i * 4 + 2] < 0 ? 0 : key4[(size_t)i * 4 + 2], W = key4[(size_t)i * 4 + 3], ql, tl, n_col;
 			wtz_ext_geometry(qlen, tlen, init, W, c->P.M, c->P.O, c->P.O, c->P.E, c->P.T, ql, tl, n_col);
+			cw[i] = (uint8_t)((n_col + 63) / 64 > 255 ? 255 : (n_col + 63) / 64);
 			/* rows come 64 at a time; a row of the trace is the widest of the three wave forms: one-wave register kernel (4-column steps),
 			 * four-wave kernel (256 lanes), LDS-ring kernel (odd columns per lane) */
 			const uint64_t c_reg = ((uint64_t)(n_col + 63) / 64 + 3) / 4, c_mw = ((uint64_t)(n_col + 255) / 256 + 3) / 4 * 4, c_gen = ((((uint64_t)(n_col + 63) / 64) | 1) + 3) / 4;
@@ -1197,18 +1204,50 @@ static int run_extjobs(wtz_ctx *c, const wtz_env_t &V, wtz_extjob_t *d_jobs, uin
 			const uint32_t mw0 = g0 < n_mw ? g0 : n_mw, mw1 = g1 < n_mw ? g1 : n_mw;       /* four-wave jobs of the group: order[mw0, mw1) */
 			const uint32_t r0 = g0 > n_mw ? g0 : n_mw, r1 = g1 > n_mw ? g1 : n_mw;         /* one-wave jobs: order[r0, r1) */
 			if(use_reg){
-				if(mw1 > mw0){
+				bool split = false;
+				if(c->env_ext_split && g0 == 0 && g1 == m){
+					/* band classes in separate launches, each from a kernel with the register budget of its own row body (93 ... 319 VGPRs: five
+					 * resident waves per SIMD for the narrowest bands, one for the widest); WTZ_EXT_MW_CW: bands wider than that many columns
+					 * per lane go to the four-wave kernel whatever their length */
+					std::vector<uint32_t> lst[9];
+					for(uint32_t k = 0; k < m; k++){
+						const uint32_t j = ord[k]; const int w = cw[j];
+						if(w == 0 || w > 32) continue;
+						if(k < n_mw || w > c->env_ext_mw_cw) lst[0].push_back(j); else lst[c->env_ext_split >= 2 ? (w + 3) / 4 : (w <= 16 ? 4 : 8)].push_back(j);
+					}
+					uint32_t *d_cls = NULL; CHK(dev_alloc((void**)&d_cls, (size_t)m * 4 + 64));
+					uint32_t off[10]; off[0] = 0; for(int k = 0; k < 9; k++){ off[k + 1] = off[k] + (uint32_t)lst[k].size(); if(!lst[k].empty()) CHK(dev_h2d(d_cls + off[k], lst[k].data(), lst[k].size() * 4)); }
+					for(int k = 0; k < 8; k++) if(!c->stream_cls[k]){ if(hipStreamCreateWithFlags(&c->stream_cls[k], hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->ev_cls[k], hipEventDisableTiming) != hipSuccess) return wtz_fail(WTZ_E_HIP, "hipStreamCreate failed"); }
+					HIPCHK(hipEventRecord(c->ev_mw_fork, g_stream));
+					if(!lst[0].empty()){
+						HIPCHK(hipStreamWaitEvent(c->stream_mw, c->ev_mw_fork, 0));
+						hipLaunchKernelGGL((wtz_kernel_extjobs_mw<1032>), dim3((uint32_t)lst[0].size()), dim3(256), 0, c->stream_mw, d_jobs, (const uint32_t*)d_cls, (uint32_t)lst[0].size(), V.P, V.pool, V.pool + 1);
+						HIPCHK(hipGetLastError());
+						HIPCHK(hipEventRecord(c->ev_mw_join, c->stream_mw));
+					}
+#define WTZ_CLS_LAUNCH(K, LO, HI) if(!lst[K].empty()){ HIPCHK(hipStreamWaitEvent(c->stream_cls[K - 1], c->ev_mw_fork, 0)); \
+						hipLaunchKernelGGL((wtz_kernel_extjobs_reg<1032, LO, HI>), dim3((uint32_t)lst[K].size()), dim3(64), 0, c->stream_cls[K - 1], d_jobs, (const uint32_t*)d_cls + off[K], (uint32_t)lst[K].size(), V.P, V.pool, V.pool + 1); \
+						HIPCHK(hipGetLastError()); HIPCHK(hipEventRecord(c->ev_cls[K - 1], c->stream_cls[K - 1])); HIPCHK(hipStreamWaitEvent(g_stream, c->ev_cls[K - 1], 0)); }
+					if(c->env_ext_split >= 2){
+						WTZ_CLS_LAUNCH(8, 28, 32) WTZ_CLS_LAUNCH(7, 24, 28) WTZ_CLS_LAUNCH(6, 20, 24) WTZ_CLS_LAUNCH(5, 16, 20)
+						WTZ_CLS_LAUNCH(4, 12, 16) WTZ_CLS_LAUNCH(3, 8, 12) WTZ_CLS_LAUNCH(2, 4, 8) WTZ_CLS_LAUNCH(1, 0, 4)
+					} else { WTZ_CLS_LAUNCH(8, 16, 32) WTZ_CLS_LAUNCH(4, 0, 16) }
+#undef WTZ_CLS_LAUNCH
+					if(!lst[0].empty()) HIPCHK(hipStreamWaitEvent(g_stream, c->ev_mw_join, 0));
+					split = true;      /* d_cls is arena memory: released with the call's scope */
+				}
+				if(!split && mw1 > mw0){
 					/* long jobs on a side stream, concurrently with the one-wave kernel over the rest */
 					HIPCHK(hipEventRecord(c->ev_mw_fork, g_stream)); HIPCHK(hipStreamWaitEvent(c->stream_mw, c->ev_mw_fork, 0));
 					hipLaunchKernelGGL((wtz_kernel_extjobs_mw<1032>), dim3(mw1 - mw0), dim3(256), 0, c->stream_mw, d_jobs, (const uint32_t*)d_order + mw0, mw1 - mw0, V.P, V.pool, V.pool + 1);
 					HIPCHK(hipGetLastError());
 					HIPCHK(hipEventRecord(c->ev_mw_join, c->stream_mw));
 				}
-				if(r1 > r0){
+				if(r1 > r0 && !split){
 					hipLaunchKernelGGL((wtz_kernel_extjobs_reg<1032>), dim3(r1 - r0), dim3(64), 0, g_stream, d_jobs, (const uint32_t*)d_order + r0, r1 - r0, V.P, V.pool, V.pool + 1);
 					HIPCHK(hipGetLastError());
 				}
-				if(mw1 > mw0) HIPCHK(hipStreamWaitEvent(g_stream, c->ev_mw_join, 0));
+				if(!split && mw1 > mw0) HIPCHK(hipStreamWaitEvent(g_stream, c->ev_mw_join, 0));
 			}
 			hipLaunchKernelGGL((wtz_kernel_extjobs<2048, 1032>), dim3(g1 - g0), dim3(64), 0, g_stream, d_jobs, (const uint32_t*)d_order + g0, g1 - g0, V.P, V.pool, V.pool + 1);     /* whatever the register DP left */
 			HIPCHK(hipGetLastError());

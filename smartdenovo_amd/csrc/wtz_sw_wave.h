@@ -518,6 +518,9 @@ WTZ_D void wtz_shift_traceback(wtz_aln_t &x, uint8_t **zchunk, const int32_t *zb
 	static_assert(NDW <= 64 && ROWB <= 128, "window geometry");
 	uint32_t *S32 = (uint32_t*)tb; uint8_t *S8 = (uint8_t*)tb; uint8_t *Sd = S8 + 8192;
 	int32_t i_ = x.qe, j_ = x.te; uint32_t d_ = 0;
+#ifdef WTZ_EXP_NOTB
+	i_ = -1; j_ = -1;      /* diagnostic build: no traceback (results are wrong) */
+#endif
 	uint32_t run_op = 0xFFu, run_len = 0;
 	wtz_cigw_t Wr; Wr.v = &cigars; Wr.tail = 0;
 	int32_t cc = 0;
@@ -815,8 +818,15 @@ WTZ_D wtz_aln_t wtz_extend_shift_reg(int32_t qlen, const wtz_seq_packed &query, 
 		}
 		{
 			WTZ_GLOBAL_AS uint32_t *zr = wtz_as_global((uint32_t*)(z + (size_t)(i & 63) * zrow) + lane);
+#ifndef WTZ_EXP_NOTRACE
+			/* only the lanes that own band cells store: the bytes right of the band end are never read by the walk (E and H are -10000 there,
+			 * no path enters them), and in the first rows of an extension half of the lane blocks lie beyond it - the trace stores were a
+			 * quarter of this kernel's time (diagnostic builds without them: K-sw3 stage 927 -> 702 ms at configs[2]) */
 			#pragma unroll
-			for(int q4 = 0; q4 < C4; q4++) zr[(size_t)q4 * 64] = zw[q4];
+			for(int q4 = 0; q4 < C4; q4++) if(q4 * 4 < nv) zr[(size_t)q4 * 64] = zw[q4];
+#else
+			if(zw[0] == 0xFFFFFFFFu && zw[C4 - 1] == 0xFFFFFFFEu) zr[0] = 1;     /* diagnostic build: never true, keeps the trace computation alive */
+#endif
 		}
 		if(stop) break;
 	}
@@ -870,8 +880,10 @@ __global__ void __launch_bounds__(64) wtz_kernel_extjobs(wtz_extjob_t *jobs, con
 
 /* K-sw3 jobs through the register DP: LDS carries only the 2-bit target.  Jobs outside its envelope (band wider than
  * 64*32 columns, target longer than the LDS words, scores beyond the packed-key range) are left for wtz_kernel_extjobs. */
-template<int TW>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WTZ_OCC_EXTREG, 8))) wtz_kernel_extjobs_reg(wtz_extjob_t *jobs, const uint32_t *order, uint32_t n, const wtz_params_t *Pm, wtz_pool_t *pool, wtz_pool_t *tpool){
+/* CLO < columns per lane <= CHI: the whole envelope is <TW, 0, 32>; the launch may be split by band class (run_extjobs) so that the narrow
+ * bands run from a kernel with a smaller register budget and a smaller instruction footprint */
+template<int TW, int CLO = 0, int CHI = 32>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CHI <= 16 ? 2 : WTZ_OCC_EXTREG, 8))) wtz_kernel_extjobs_reg(wtz_extjob_t *jobs, const uint32_t *order, uint32_t n, const wtz_params_t *Pm, wtz_pool_t *pool, wtz_pool_t *tpool){
 	__shared__ uint64_t stb[TW];
 	const uint32_t b = blockIdx.x;
 	if(b >= n) return;
@@ -886,6 +898,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WTZ_OCC
 	const int32_t Cw = (n_col + 63) / 64;
 	if(Cw > 32 || (tl + 63) / 32 + 1 > TW || (ql + 63) / 64 > WTZ_TRACE_MAXCHUNK) return;
 	if((long long)init_score + (long long)Pm->M * (ql < tl ? ql : tl) >= (1 << 20)) return;
+	if(Cw <= CLO || (CHI < 32 && Cw > CHI)) return;        /* another launch's band class */
 	WTZ_PROF_BEGIN();
 	wtz_trace_t tr; tr.chunk = NULL; tr.zb = NULL; tr.n_chunk = 0; tr.zrow = 0; tr.cap_rows = 0;
 	wtz_cigar_t cg; cg.a = NULL; cg.n = cg.cap = 0; cg.pool = pool; cg.bad = 0;
@@ -893,14 +906,14 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WTZ_OCC
 	unsigned long long cells = 0; bool ok = true;
 	wtz_aln_t x;
 #define WTZ_EXTREG_CASE(CM) x = wtz_extend_shift_reg<CM>(job->qlen, job->q, job->tlen, job->t, job->init_score, ql, tl, W, Pm->M, Pm->X, Pm->O, Pm->O, Pm->E, Pm->T, stb, tr, tpool, cg, &cells, &ok)
-	if(Cw <= 4) WTZ_EXTREG_CASE(4);
-	else if(Cw <= 8) WTZ_EXTREG_CASE(8);
-	else if(Cw <= 12) WTZ_EXTREG_CASE(12);
-	else if(Cw <= 16) WTZ_EXTREG_CASE(16);
-	else if(Cw <= 20) WTZ_EXTREG_CASE(20);
-	else if(Cw <= 24) WTZ_EXTREG_CASE(24);
-	else if(Cw <= 28) WTZ_EXTREG_CASE(28);
-	else WTZ_EXTREG_CASE(32);
+	if(Cw <= 4){ if(CLO < 4 && CHI >= 4) WTZ_EXTREG_CASE(4); }
+	else if(Cw <= 8){ if(CLO < 8 && CHI >= 8) WTZ_EXTREG_CASE(8); }
+	else if(Cw <= 12){ if(CLO < 12 && CHI >= 12) WTZ_EXTREG_CASE(12); }
+	else if(Cw <= 16){ if(CLO < 16 && CHI >= 16) WTZ_EXTREG_CASE(16); }
+	else if(Cw <= 20){ if(CLO < 20 && CHI >= 20) WTZ_EXTREG_CASE(20); }
+	else if(Cw <= 24){ if(CLO < 24 && CHI >= 24) WTZ_EXTREG_CASE(24); }
+	else if(Cw <= 28){ if(CLO < 28 && CHI >= 28) WTZ_EXTREG_CASE(28); }
+	else { if(CHI >= 32) WTZ_EXTREG_CASE(32); }
 #undef WTZ_EXTREG_CASE
 	if(lane == 0){ job->x = x; job->cigar = cg.a; job->cigar_len = cg.n; job->bad = (!ok || cg.bad); job->cells = cells; job->done = 1; }
 	WTZ_PROF_ADD(8, pt_job); WTZ_PROF_MAX(15, pt_job); WTZ_PROF_CNT(10, 1);
@@ -1121,8 +1134,12 @@ WTZ_D wtz_aln_t wtz_extend_shift_mw(int32_t qlen, const wtz_seq_packed &query, i
 		if(tid == 0) wtz_as_global(zb)[i] = jb;
 		{
 			WTZ_GLOBAL_AS uint32_t *zr = wtz_as_global((uint32_t*)(z + (size_t)(i & 63) * zrow) + tid);
+#ifndef WTZ_EXP_NOTRACE
 			#pragma unroll
-			for(int q4 = 0; q4 < C4; q4++) zr[(size_t)q4 * NL] = zw[q4];
+			for(int q4 = 0; q4 < C4; q4++) if(q4 * 4 < nv) zr[(size_t)q4 * NL] = zw[q4];      /* see wtz_extend_shift_reg */
+#else
+			if(zw[0] == 0xFFFFFFFFu && zw[C4 - 1] == 0xFFFFFFFEu) zr[0] = 1;
+#endif
 		}
 		wtz_mw_barrier();                                                       /* ---- barrier 2 ---- */
 		const wtz_i4 wkk = sh->wkey;
