@@ -221,7 +221,10 @@ static const uint64_t hx_ref_sizes[] = {      /* hashset.h:30-44 (sys_prime_list
 	0x7ULL, 0xfULL, 0x1fULL, 0x43ULL, 0x89ULL, 0x115ULL, 0x22dULL, 0x45dULL, 0x8bdULL, 0x1181ULL, 0x2303ULL, 0x4609ULL, 0x8c17ULL, 0x1183dULL, 0x2307bULL,
 	0x460fdULL, 0x8c201ULL, 0x118411ULL, 0x230833ULL, 0x461069ULL, 0x8c20e1ULL, 0x11841cbULL, 0x2308397ULL, 0x461075bULL, 0x8c20ecbULL, 0x11841da5ULL,
 	0x23083b61ULL, 0x461076c7ULL, 0x8c20ed91ULL, 0x11841db31ULL, 0x23083b673ULL, 0x461076d1bULL, 0x8c20eda41ULL, 0x11841db48dULL, 0x23083b6937ULL,
-	0x461076d27fULL, 0x8c20eda50dULL, 0x11841db4a59ULL, 0x23083b694ebULL, 0x461076d29f1ULL, 0x8c20eda5441ULL };
+	0x461076d27fULL, 0x8c20eda50dULL, 0x11841db4a59ULL, 0x23083b694ebULL, 0x461076d29f1ULL, 0x8c20eda5441ULL, 0x11841db4a887ULL, 0x23083b69511fULL,
+	0x461076d2a2c1ULL, 0x8c20eda54591ULL, 0x11841db4a8b55ULL, 0x23083b69516c1ULL, 0x461076d2a2da5ULL, 0x8c20eda545b55ULL, 0x11841db4a8b6b5ULL,
+	0x23083b69516d91ULL, 0x461076d2a2db3bULL, 0x8c20eda545b69dULL, 0x11841db4a8b6d5dULL, 0x23083b69516daf5ULL, 0x461076d2a2db5edULL,
+	0x8c20eda545b6c5fULL, 0x11841db4a8b6d8ebULL, 0x23083b69516db1ffULL, 0x461076d2a2db643fULL, 0x8c20eda545b6c8f3ULL };
 static uint64_t hx_ref_size_for(uint64_t n){
 	const size_t last = sizeof hx_ref_sizes / sizeof hx_ref_sizes[0] - 1; size_t i = 0;
 	while(i < last && n > hx_ref_sizes[i]) i++;
@@ -257,7 +260,10 @@ static void hx_refslots_grow(hx_refslots_t *t){
 	free(waiting);
 	t->full = full; t->size = n; t->limit = (uint64_t)((float)n * 0.67f);
 }
-static void hx_refslots_put(hx_refslots_t *t, uint64_t key){      /* the caller inserts every key once (new keys only) */
+/* a put of a key that is already there: the reference's put_u64hash runs its capacity check BEFORE looking the key up (hashset.h:224-226, 351),
+ * so a duplicate arriving at a full table grows it one step earlier than the next new key would */
+static void hx_refslots_touch(hx_refslots_t *t){ if(t->count + 1 > t->limit) hx_refslots_grow(t); }
+static void hx_refslots_put(hx_refslots_t *t, uint64_t key){      /* new keys only; duplicates go through hx_refslots_touch */
 	if(t->count + 1 > t->limit) hx_refslots_grow(t);
 	uint64_t h = hx_ref_hash(key) % t->size;
 	while(t->full[h]) h = h + 1 == t->size ? 0 : h + 1;

@@ -1319,6 +1319,7 @@ int main(int argc, char **argv){
 			uint32_t a = hx_names_get(&nm, cols[0]), b = hx_names_get(&nm, cols[1]);
 			if(a == 0xFFFFFFFFu || b == 0xFFFFFFFFu) continue;
 			if(hx_set_put(&E->closed, hx_pair_key(a, b))) order_push(E, hx_pair_key(a, b));
+			else order_push(E, hx_pair_key(a, b) | 1u);        /* a repeated -L line is still a put_u64hash of the reference (wtzmo.c:1769): bit 0 marks it for the -9 replay */
 		}
 		hx_reader_close(fr);
 	}
@@ -1545,7 +1546,7 @@ int main(int argc, char **argv){
 		/* the reference lists the pairs in the iteration order of its hash set: replay the insertions (wtz_host.h, hx_refslots) */
 		FILE *pf = fopen(pairoutf, "w");
 		hx_refslots_t T; hx_refslots_init(&T, 1023);                 /* init_u64hash(1023), wtzmo.c:138 */
-		for(size_t i = 0; i < E->n_order; i++) hx_refslots_put(&T, E->closed_order[i]);
+		for(size_t i = 0; i < E->n_order; i++){ if(E->closed_order[i] & 1u) hx_refslots_touch(&T); else hx_refslots_put(&T, E->closed_order[i]); }
 		for(uint64_t k = 0; k < T.size; k++) if(T.full[k]) fprintf(pf, "%s\t%s\n", E->st.reads[(uint32_t)(T.slot[k] >> 33)].name, E->st.reads[(uint32_t)((T.slot[k] & 0xFFFFFFFFu) >> 1)].name);
 		fclose(pf); free(T.slot); free(T.full);
 	}

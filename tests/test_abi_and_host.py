@@ -120,3 +120,43 @@ def test_word_level_base_packing(tmp_path):
                     "-o", exe, os.path.join(ROOT, "tests", "emul", "check_pack32.cpp")], check=True)
     r = subprocess.run([exe], capture_output=True, text=True)
     assert r.returncode == 0 and " 0 bad" in r.stdout, r.stdout + r.stderr
+
+
+REF_EXE = os.path.join(ROOT, "oracle", "_ref", "wtzmo_ref")
+
+
+@pytest.mark.skipif(not os.path.exists(REF_EXE), reason="reference binary not built (needs /root/reference once)")
+@pytest.mark.parametrize("ndistinct,unrelated", [(748, True), (749, True), (748, False), (300, False)])
+def test_pair_file_replay_with_repeated_preload_lines(ndistinct, unrelated, emul_exe, tmp_path):
+    """-9 lists the tested pairs in the iteration order of the reference's hash set, and a REPEATED -L line is still a put_u64hash there: its
+    capacity check runs before the lookup (hashset.h:224-226, 351), so a duplicate arriving when the table is exactly full (748 keys in the
+    initial 1117 slots) grows it although no key is added.  `unrelated`: 40 random reads that share nothing, so the run itself tests no new pair and
+    the table the file is written from is the one the preload left (the case that tells the two behaviours apart); otherwise the tiny read
+    set, where new pairs follow the preload.  Live comparison with the compiled reference."""
+    import gzip
+    import random
+    if unrelated:
+        rng = random.Random(7)
+        fa = os.path.join(str(tmp_path), "unrelated.fa")
+        names = ["u%02d" % i for i in range(40)]
+        with open(fa, "w") as fh:
+            for n in names:
+                fh.write(">%s\n%s\n" % (n, "".join(rng.choice("ACGT") for _ in range(3000 + rng.randrange(500)))))
+    else:
+        fa = os.path.join(ROOT, "tests", "golden", "tiny.fa.gz")
+        names = [ln[1:].split()[0] for ln in gzip.open(fa, "rt") if ln.startswith(">")]
+    pairs = [(names[i], names[j]) for i in range(len(names)) for j in range(i + 1, len(names))][:ndistinct]
+    assert len(pairs) == ndistinct
+    lst = os.path.join(str(tmp_path), "tested.txt")
+    with open(lst, "w") as fh:
+        for a, b in pairs + pairs[:5]:
+            fh.write("%s\t%s\n" % (a, b))
+    argv = ["-i", fa, "-k", "16", "-s", "200", "-m", "0.6", "-L", lst]
+    outs = []
+    for tag, exe, extra in (("ref", REF_EXE, ["-t", "1"]), ("emul", emul_exe, ["--batch", "16"])):
+        o, p9 = os.path.join(str(tmp_path), tag + ".ovl"), os.path.join(str(tmp_path), tag + ".pairs")
+        subprocess.run([exe] + extra + argv + ["-fo", o, "-9", p9], check=True, capture_output=True)
+        outs.append((open(o, "rb").read(), open(p9, "rb").read()))
+    assert outs[0][0] == outs[1][0], ".ovl differs from the reference with -L"
+    assert outs[0][1] == outs[1][1], "-9 pair file is not in the reference's hash-set order"
+    assert outs[0][1].count(b"\n") >= ndistinct
