@@ -1170,7 +1170,7 @@ int main(int argc, char **argv){
 	P->kwin = 800; P->kovl = 300; P->ksave = 4; P->win_rep_norm = 20; P->win_rep_cutoff = 100; P->ncand = 500; P->nbest = 100;
 	P->ztot = 300; P->zovl = 200; P->max_kmer_freq = 0; P->max_zmer_freq = 64; P->max_kmer_var = 2;
 	P->xvar = 128; P->yvar = 64; P->min_block_len = 160; P->deviation_penalty = 1.0f; P->gap_penalty = 0.05f;
-	E->do_align = 1; E->n_idx = 1; E->n_job = 1; E->i_job = 0; E->max_batch = 2048; E->first_batch = 256; E->n_workers = 1;
+	E->do_align = 1; E->n_idx = 1; E->n_job = 1; E->i_job = 0; E->max_batch = 4096; E->first_batch = 256; E->n_workers = 1;
 	pthread_mutex_init(&E->mu, NULL); pthread_cond_init(&E->cv, NULL);
 	static struct option lopts[] = { {"stats", required_argument, 0, 1000}, {"gpu", required_argument, 0, 1001}, {"pool-gb", required_argument, 0, 1002},
 		{"batch", required_argument, 0, 1003}, {"lib-check", no_argument, 0, 1004}, {"repeat", required_argument, 0, 1005}, {"first-batch", required_argument, 0, 1006}, {"workers", required_argument, 0, 1007}, {"pool-mb", required_argument, 0, 1008}, {"gpus", required_argument, 0, 1010}, {"gpu-list", required_argument, 0, 1011}, {"shard-index", no_argument, 0, 1012}, {"zindex-batch", required_argument, 0, 1013}, {0, 0, 0, 0} };

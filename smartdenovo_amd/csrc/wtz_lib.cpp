@@ -346,6 +346,7 @@ struct wtz_ctx {
 	uint32_t *cq_q = NULL, *cq_nc = NULL; uint64_t *cq_cand = NULL; unsigned long long *cq_bytes = NULL; uint32_t cq_cap = 0, cq_n = 0; bool cq_pending = false; wtz_timer cq_tm;
 	wtz_counters_t cnt;
 	uint64_t tpool_peak_call = 0, main_used_call = 0;      /* transient-pool high-water mark / main-pool bytes of the API call in progress */
+	uint32_t env_xcd_group = 256;   /* WTZ_XCD_GROUP: consecutive pairs per XCD run in K_pair (0 = identity block -> pair mapping) */
 	int env_ext_mw_cw = 32;      /* WTZ_EXT_MW_CW: K-sw3 jobs with more band columns per lane than this run on four waves whatever their length */
 	int env_ext_split = 0;       /* WTZ_EXT_SPLIT=1: K-sw3 one-wave jobs in two launches by band class (experiment) */
 	int env_cand_wg = 1;         /* WTZ_CAND_WG=0: the one-wavefront-per-query sorting form of the seed lookup (the form before round 3) */
@@ -469,6 +470,7 @@ extern "C" int wtz_ctx_create(int device, const wtz_params_c *params, uint64_t p
 	if(getenv("WTZ_CAND_WG")) c->env_cand_wg = atoi(getenv("WTZ_CAND_WG"));
 	if(getenv("WTZ_EXT_SPLIT")) c->env_ext_split = atoi(getenv("WTZ_EXT_SPLIT"));
 	if(getenv("WTZ_EXT_MW_CW")) c->env_ext_mw_cw = atoi(getenv("WTZ_EXT_MW_CW"));
+	if(getenv("WTZ_XCD_GROUP")) c->env_xcd_group = (uint32_t)atoi(getenv("WTZ_XCD_GROUP"));
 	c->env_grp4 = (getenv("WTZ_WINALIGN4") && atoi(getenv("WTZ_WINALIGN4")) != 0);
 	if(getenv("WTZ_WINALIGN_LANE")) c->env_lane = atoi(getenv("WTZ_WINALIGN_LANE"));
 	if(getenv("WTZ_GAP_LANE")) c->env_gap_lane = atoi(getenv("WTZ_GAP_LANE"));
@@ -1039,7 +1041,15 @@ extern "C" int wtz_pairs_seed(wtz_ctx_t *c, const uint32_t *qid, const uint32_t 
 		signal(SIGABRT, wtz_crumbs_dump); signal(SIGPIPE, wtz_crumbs_dump); signal(SIGSEGV, wtz_crumbs_dump); signal(SIGBUS, wtz_crumbs_dump); signal(SIGTERM, wtz_crumbs_dump);
 	}
 #endif
-	CHK(wtz_launch_coop<K_pair>(0, n, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_pair((uint32_t)t, V, dq, dc, dr); }, c->P.dot_matrix ? WTZ_PAIR_DM_LDS_BYTES : WTZ_PAIR_LDS_BYTES));
+	/* XCD-aware task order: workgroups are dealt round-robin over the 8 XCDs, each with its own L2, and the pairs of a range are listed query by
+	 * query (about 30 candidates each), all of them searching the same query-side z-mer tables.  With the identity mapping an XCD's ~640 resident
+	 * waves hold every 8th pair of a 5 000-pair stretch, i.e. the tables of ~170 queries (20 MB against 4 MB of L2); giving every XCD runs of
+	 * `xg` CONSECUTIVE pairs makes that ~25 queries.  (WTZ_XCD_GROUP=0: identity.) */
+	const uint32_t xg = c->env_xcd_group; const uint64_t n64 = n;
+	CHK(wtz_launch_coop<K_pair>(0, n, [=] WTZ_LAMBDA (uint64_t b){
+		uint64_t t = b;
+		if(xg){ const uint64_t per = 8ull * xg, full = n64 / per * per; if(b < full){ const uint64_t r = b % per; t = b - r + (r & 7u) * xg + (r >> 3); } }
+		wtz_task_pair((uint32_t)t, V, dq, dc, dr); }, c->P.dot_matrix ? WTZ_PAIR_DM_LDS_BYTES : WTZ_PAIR_LDS_BYTES));
 #if defined(WTZ_DEBUG_CRUMBS) && !defined(WTZ_EMUL)
 	if(h_crumbs){
 		const double t0 = wtz_wall(); const double limit = atof(getenv("WTZ_DEBUG_CRUMBS")) > 1 ? atof(getenv("WTZ_DEBUG_CRUMBS")) : 20.0;

@@ -153,3 +153,45 @@ def test_gpu_equals_oracle_on_repeat_rich_input(engine, gpu_exe, oracle_exe, tmp
     subprocess.run([oracle_exe, "-i", fa, "-fo", b] + argv, check=True, capture_output=True)
     assert open(a, "rb").read() == open(b, "rb").read()
     assert open(a + ".contained", "rb").read() == open(b + ".contained", "rb").read()
+
+
+FORMS = [
+    {"WTZ_WINALIGN_LANE": "0"},                       # K-sw1: every window on the chained wave kernel (round-2 form)
+    {"WTZ_WINALIGN_LANE": "2"},                       # both K-sw1 paths, every window compared on the device (fails loudly on a difference)
+    {"WTZ_GAP_LANE": "0"},                            # K-sw2: every gap on a wavefront
+    {"WTZ_CAND_WG": "0"},                             # seed lookup: wave per query, whole-query sort
+    {"WTZ_CAND_STREAM": "1", "WTZ_CAND_WG": "0"},     # seed lookup: sort-free accumulation
+    {"WTZ_RANGE_OVERLAP": "0"},                       # host: strict plan -> compute -> commit order
+    {"WTZ_EXT_SPLIT": "2"},                           # K-sw3: one launch per band class
+    {"WTZ_EXT_SPLIT": "2", "WTZ_EXT_MW_CW": "8"},     # ... and every band wider than 8 columns per lane on four waves
+    {"WTZ_XCD_GROUP": "0"},                           # K_pair: identity block -> pair mapping
+    {"WTZ_GAP_SIDESTREAM": "1"},                      # gaps on a side stream beside the left extensions
+    {"WTZ_WINALIGN4": "1"},                           # four windows per wavefront
+    {"WTZ_SW_CHECK": "1"},                            # scalar body beside every wave DP
+]
+
+
+@pytest.fixture(scope="module")
+def forms_input(oracle_exe, tmp_path_factory):
+    d = str(tmp_path_factory.mktemp("forms"))
+    names, seqs = synth.synth_reads(200000, 12, seed=314, mean_len=9000.0, min_len=1000)
+    fa = os.path.join(d, "r.fa")
+    synth.write_fasta(fa, names, seqs)
+    b = os.path.join(d, "ora.ovl")
+    subprocess.run([oracle_exe, "-i", fa, "-fo", b] + FRESH["zmo"], check=True, capture_output=True)
+    return fa, open(b, "rb").read(), open(b + ".contained", "rb").read()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("env", FORMS, ids=["_".join("%s%s" % (k[4:], v) for k, v in sorted(e.items())) for e in FORMS])
+def test_every_switchable_form_writes_the_same_records(env, gpu_exe, forms_input, tmp_path):
+    """The library ships alternative forms of several stages behind environment switches (the previous round's kernels, experiments that did
+    not pay, cross-checks).  None may change the output: each runs a fresh seeded read set with enough reads for every stage to have work
+    and must write the oracle's (= the reference's) bytes."""
+    fa, want, want_contained = forms_input
+    a = os.path.join(str(tmp_path), "gpu.ovl")
+    r = subprocess.run([gpu_exe, "-i", fa, "-fo", a, "--batch", "64"] + FRESH["zmo"], capture_output=True, env=dict(os.environ, **env))
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    assert len(want) > 10000
+    assert open(a, "rb").read() == want, "%r changed the records" % (env,)
+    assert open(a + ".contained", "rb").read() == want_contained

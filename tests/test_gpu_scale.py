@@ -16,7 +16,8 @@ from conftest import GOLD, ROOT
 pytestmark = pytest.mark.gpu
 MAN = json.load(open(os.path.join(GOLD, "big_manifest.json")))
 TMP = os.environ.get("WTZ_BENCH_TMP", "/tmp/wtz_bench")
-CASES = sorted(MAN["cases"])
+CASES = sorted(c for c in MAN["cases"] if not MAN["cases"][c]["set"].startswith("fly"))
+FLY_CASES = sorted(c for c in MAN["cases"] if MAN["cases"][c]["set"].startswith("fly"))
 
 
 def file_md5(path):
@@ -48,12 +49,8 @@ def reads_of(name):
     return fa
 
 
-@pytest.mark.parametrize("name", CASES)
-def test_gpu_equals_reference_at_scale(name, gpu_exe):
+def check_case_at_scale(name, gpu_exe):
     case = MAN["cases"][name]
-    if case["set"].startswith("fly") and not os.environ.get("WTZ_TEST_FLY"):
-        pytest.skip("BASELINE configs[3] shape (10 Gbp of reads: ~10 minutes to generate, 10 GB of FASTA): run with WTZ_TEST_FLY=1 "
-                    "(tools/gpu_r03_fly.sh; its log is kept under profiles/)")
     fa = reads_of(case["set"])
     out = os.path.join(TMP, "scale_%s.ovl" % name)
     stats = out + ".stats"
@@ -61,6 +58,9 @@ def test_gpu_equals_reference_at_scale(name, gpu_exe):
         if os.path.exists(f):
             os.remove(f)
     r = subprocess.run([gpu_exe, "-i", fa, "-fo", out, "--stats", stats] + case["argv"], capture_output=True)
+    if os.environ.get("WTZ_TEST_KEEP_STDERR"):      # the drop-in's own log of the run (index sizes, per-batch z-index, timings): kept under profiles/ for the fly shape
+        os.makedirs(os.environ["WTZ_TEST_KEEP_STDERR"], exist_ok=True)
+        open(os.path.join(os.environ["WTZ_TEST_KEEP_STDERR"], "scale_%s.stderr.txt" % name), "wb").write(r.stderr)
     assert r.returncode == 0, r.stderr.decode()[-3000:]
     md5, nrec = file_md5(out)
     assert nrec == case["records"], "%d records, the reference wrote %d" % (nrec, case["records"])
@@ -73,6 +73,11 @@ def test_gpu_equals_reference_at_scale(name, gpu_exe):
     if case["set"] != "repeat" and not case["set"].startswith("fly"):
         assert b"splitting the batch" not in r.stderr, "a planned range overflowed the scratch pool"
     os.remove(out)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_gpu_equals_reference_at_scale(name, gpu_exe):
+    check_case_at_scale(name, gpu_exe)
 
 
 @pytest.mark.parametrize("name", ["ecoli_zmo", "ecoli_dmo"])
@@ -108,3 +113,29 @@ def test_dmo_heavy_pair_paths(env, gpu_exe):
     if "WTZ_DM_TIER4_KB" not in env:
         assert b"dmo tier 4" in r.stderr, "no pair reached the fourth launch: the test no longer covers it"
     os.remove(out)
+
+
+@pytest.mark.parametrize("name", FLY_CASES)
+def test_fly_shape_stripe_equals_reference(name, gpu_exe):
+    """BASELINE configs[3] shape on ONE device (last in the file: the input is 951 827 reads / 9.8 Gbp, 10 GB of FASTA regenerated here in about two
+    minutes): the query stripe `-P 128 -p 0` against the FULL k-mer index with the z-mer index rebuilt per batch of queries (automatic above
+    2.4 Gbp of reads) must give the md5 of the reference's `wtzmo -t 1 -P 128 -p 0` (43 minutes in the build container, tests/golden/make_fly_stripe.py).
+    WTZ_TEST_NO_FLY=1 skips it; so does a box without the disk / memory for the input."""
+    import shutil
+    if os.environ.get("WTZ_TEST_NO_FLY"):
+        pytest.skip("WTZ_TEST_NO_FLY set")
+    os.makedirs(TMP, exist_ok=True)
+    if shutil.disk_usage(TMP).free < 25 << 30:
+        pytest.skip("less than 25 GB free under %s for the 10 GB input" % TMP)
+    try:
+        avail = [int(l.split()[1]) for l in open("/proc/meminfo") if l.startswith("MemAvailable")][0] << 10
+    except Exception:
+        avail = 1 << 40
+    if avail < 48 << 30:
+        pytest.skip("less than 48 GB of host memory available for generating / loading the 10 Gbp read set")
+    check_case_at_scale(name, gpu_exe)
+    if os.environ.get("WTZ_TEST_KEEP_FLY"):
+        return
+    for f in os.listdir(TMP):          # 10 GB: not left behind for the bench
+        if f.startswith("reads_G%d_" % MAN["sets"][MAN["cases"][name]["set"]]["genome"]):
+            os.remove(os.path.join(TMP, f))

@@ -1,17 +1,25 @@
 #!/bin/bash
-# Round-3 measurement on the GPU box: GPU test-suite, the driver's exact bench command, dmo / E. coli lines, rocprofv3 kernel stats, PMC passes.
+# Round-3 measurement on the GPU box: GPU test-suite (incl. the configs[3]-shape stripe), the whole configs[3]-shape job, the driver's exact bench command,
+# dmo / E. coli lines, rocprofv3 kernel stats, PMC passes.
 # usage: tools/gpu_r03_measure.sh <tag>     (outputs under gpurun_out/<tag>/; summaries are copied to profiles/ by hand)
 TAG=${1:-r03m}
 R=$GRAFT_REPO_ROOT; [ -z "$R" ] && R=$(pwd)
 O=$R/gpurun_out/$TAG; mkdir -p $O
 export TMPDIR=/tmp
 cd $R
-timeout 1500 python -m pytest tests -x -q -m gpu > $O/pytest_gpu.log 2>&1; tail -2 $O/pytest_gpu.log
+( time WTZ_TEST_KEEP_FLY=1 WTZ_TEST_KEEP_STDERR=$O timeout 2400 python -m pytest tests -x -q -m gpu ) > $O/pytest_gpu.log 2>&1; tail -2 $O/pytest_gpu.log | head -1; grep real $O/pytest_gpu.log
+FLY=$(ls /tmp/wtz_bench/reads_G140000000_c70_s53.fa 2>/dev/null)
+if [ -n "$FLY" ]; then
+  # the WHOLE configs[3]-shape job on one device (no reference to compare with: `wtzmo -t 1` would take days; the stripe above pins parity): 80 GB of records go to /dev/null
+  ( time timeout 1500 bin/wtzmo -i $FLY -fo /dev/null -C -k 16 -s 200 -m 0.6 --stats $O/fly_full.stats ) > $O/fly_full.log 2>&1
+  grep -E "records|host seconds|batches in|kernel ms|real" $O/fly_full.log | cut -c1-260
+  rm -f /tmp/wtz_bench/reads_G140000000_c70_s53.fa*
+fi
 ( time python3 bench.py --gpus 1 --steps 20 --warmup 5 ) > $O/bench_zmo.json 2> $O/bench_zmo.err
 tail -1 $O/bench_zmo.json | cut -c1-400; grep real $O/bench_zmo.err
 python bench.py --engine dmo --steps 3 --warmup 2 > $O/bench_dmo.json 2> $O/bench_dmo.err; tail -1 $O/bench_dmo.json | cut -c1-300
-python bench.py --workload ecoli --no-cpu-baseline --steps 5 --warmup 2 > $O/bench_ecoli_zmo.json 2> $O/bench_ecoli_zmo.err; tail -1 $O/bench_ecoli_zmo.json | cut -c1-300
-python bench.py --workload ecoli --engine dmo --no-cpu-baseline --steps 5 --warmup 2 > $O/bench_ecoli_dmo.json 2> $O/bench_ecoli_dmo.err; tail -1 $O/bench_ecoli_dmo.json | cut -c1-300
+python bench.py --workload ecoli --steps 5 --warmup 2 > $O/bench_ecoli_zmo.json 2> $O/bench_ecoli_zmo.err; tail -1 $O/bench_ecoli_zmo.json | cut -c1-300
+python bench.py --workload ecoli --engine dmo --steps 5 --warmup 2 > $O/bench_ecoli_dmo.json 2> $O/bench_ecoli_dmo.err; tail -1 $O/bench_ecoli_dmo.json | cut -c1-300
 cd /tmp
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_zmo -o zmo -- python $R/bench.py --steps 2 --warmup 2 --no-cpu-baseline > $O/trace_zmo.log 2>&1
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_dmo -o dmo -- python $R/bench.py --engine dmo --steps 2 --warmup 2 --no-cpu-baseline > $O/trace_dmo.log 2>&1
