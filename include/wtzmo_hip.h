@@ -49,6 +49,9 @@ typedef struct {
 	int32_t  dot_matrix, xvar, yvar, min_block_len, max_overhang;
 	float    deviation_penalty, gap_penalty;
 	int32_t  refine;         /* -n: kswx_refine_alignment after stitching (wtzmo.c:1031-1034) */
+	int32_t  aux_strand;     /* 1 = the pair stages in align_hzmaux's form (hzm_aln.h:1693-1699, wtgbo's caller): only same-strand z-mer matches are kept
+	                          * (filter_by_region_hzmps with dir 0, hzm_aln.h:1188-1197, before the window merge), there is no n_hits gate, and the chain
+	                          * of strand 0 is kept when its weight is >= ztot (the caller passes -R there: hzm_aln.h:1699 compares with zovl) */
 } wtz_params_c;
 
 typedef struct wtz_ctx wtz_ctx_t;

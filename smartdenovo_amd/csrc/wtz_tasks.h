@@ -63,13 +63,14 @@ WTZ_HD void wtz_task_pair(uint32_t t, const wtz_env_t &V, const uint32_t *qid, c
 #endif
 	const uint64_t tk0 = WTZ_TICK();
 	WTZ_CRUMB(t, 1);
-	const bool ok = wtz_zmatch_coop(V.Z, q, c, V.R.rdlen[c], P->max_kmer_var, V.pool, &hits, &n);
+	const bool aux = P->aux_strand != 0;                     /* align_hzmaux's form of the pair stages (wtgbo): strand 0 only, no n_hits gate */
+	const bool ok = wtz_zmatch_coop(V.Z, q, c, V.R.rdlen[c], P->max_kmer_var, V.pool, &hits, &n, aux);
 	const uint64_t tk1 = WTZ_TICK();
 	WTZ_CRUMB(t, 2 | (n << 8));
 	wtz_zhit_t *sorted = NULL;
 #if defined(__HIP_DEVICE_COMPILE__)
 	__threadfence_block();
-	if(ok && n * P->zsize >= P->ztot){      /* uniform: the first ordering of either engine, wave-parallel when tie-free */
+	if(ok && (aux ? n > 0 : n * P->zsize >= P->ztot)){      /* uniform: the first ordering of either engine, wave-parallel when tie-free */
 		int pbad = 0;
 		if(P->dot_matrix) sorted = wtz_sort_hits_wave<1>(hits, n, V.pool, (uint64_t*)wtz_wave_scratch(), WTZ_PAIR_DM_LDS_BYTES / 8, &pbad);
 		else              sorted = wtz_sort_hits_wave<0>(hits, n, V.pool, (uint64_t*)wtz_wave_scratch(), WTZ_PAIR_LDS_BYTES / 8, &pbad);
@@ -80,7 +81,7 @@ WTZ_HD void wtz_task_pair(uint32_t t, const wtz_env_t &V, const uint32_t *qid, c
 	WTZ_CRUMB(t, 3 | (n << 8));
 	if(!ok || r.bad){ r.bad = 1; if(lane == 0) res[t] = r; WTZ_CRUMB(t, 0xFF); return; }
 	r.n_hits = n;
-	if(n * P->zsize < P->ztot){ r.gate = 0; if(lane == 0) res[t] = r; WTZ_CRUMB(t, 0xFF); return; }
+	if(aux ? n == 0 : n * P->zsize < P->ztot){ r.gate = 0; if(lane == 0) res[t] = r; WTZ_CRUMB(t, 0xFF); return; }
 	r.gate = 1;
 	if(P->dot_matrix){
 		wtz_vec<wtz_zhit_t> cache; cache.a = sorted ? sorted : hits; cache.n = n; cache.cap = n + 2; cache.pool = V.pool; cache.bad = 0;

@@ -20,7 +20,7 @@
 #define WTZ_KWIN_MAX_OFFSET_DEV 50
 
 /* ---- A6: walk the candidate's position-ordered z-mers, look each up in the query's table ---- */
-WTZ_HD bool wtz_zmatch(const wtz_zindex_t &Z, uint32_t q, uint32_t c, uint32_t clen, uint32_t max_var, wtz_vec<wtz_zhit_t> &out){
+WTZ_HD bool wtz_zmatch(const wtz_zindex_t &Z, uint32_t q, uint32_t c, uint32_t clen, uint32_t max_var, wtz_vec<wtz_zhit_t> &out, bool same_strand = false){
 	const uint64_t qo = Z.zoff[q], co = Z.zoff[c];
 	const uint32_t cn = (uint32_t)(Z.zoff[c + 1] - co), qd = Z.dn[q];
 	const uint32_t *dmer = Z.dmer + qo;
@@ -38,6 +38,7 @@ WTZ_HD bool wtz_zmatch(const wtz_zindex_t &Z, uint32_t q, uint32_t c, uint32_t c
 			uint32_t dv = qlen > clen2 ? qlen - clen2 : clen2 - qlen;
 			if(dv > max_var) continue;
 			uint32_t d1 = qpos & 1u, d2 = cpos & 1u;
+			if(same_strand && (d1 ^ d2)) continue;           /* align_hzmaux: filter_by_region_hzmps(dir 0), hzm_aln.h:1193 */
 			uint32_t off2 = (d1 ^ d2) ? clen - ((cpos >> 1) + clen2) : (cpos >> 1);
 			wtz_zhit_t h; h.o1 = (d1 << 31) | (qpos >> 1); h.o2 = (d2 << 31) | off2; h.ll = (clen2 << 16) | qlen; h.gid = 0;
 			if(!out.push(h)) return false;
@@ -50,7 +51,7 @@ WTZ_HD bool wtz_zmatch(const wtz_zindex_t &Z, uint32_t q, uint32_t c, uint32_t c
  * candidate-position order through an exclusive scan of the per-lane match counts (emission order is part of the
  * contract: hzm_aln.h:212-221).  Two passes: count (the dense index of each z-mer is cached), allocate exactly, fill.
  * Returns the match list through *out / *n_out on every lane; false when the pool is exhausted. */
-WTZ_HD bool wtz_zmatch_coop(const wtz_zindex_t &Z, uint32_t q, uint32_t c, uint32_t clen, uint32_t max_var, wtz_pool_t *pool, wtz_zhit_t **out, uint32_t *n_out){
+WTZ_HD bool wtz_zmatch_coop(const wtz_zindex_t &Z, uint32_t q, uint32_t c, uint32_t clen, uint32_t max_var, wtz_pool_t *pool, wtz_zhit_t **out, uint32_t *n_out, bool same_strand = false){
 	const uint64_t qo = Z.zoff[q], co = Z.zoff[c];
 	const uint32_t cn = (uint32_t)(Z.zoff[c + 1] - co), qd = Z.dn[q];
 	const uint32_t *dmer = Z.dmer + qo;
@@ -89,9 +90,12 @@ WTZ_HD bool wtz_zmatch_coop(const wtz_zindex_t &Z, uint32_t q, uint32_t c, uint3
 			if(act[u] && lo[u] < qd && dmer[lo[u]] == m[u]){
 				idx = lo[u];
 				const uint32_t clen2 = Z.len[co + k], first = Z.dfirst[qo + idx], n = Z.dcnt[qo + idx];
+				const uint32_t cdir = Z.pos[co + k] & 1u;
 				for(uint32_t e = 0; e < n; e++){
-					const uint32_t qlen = Z.len[qo + Z.sidx[qo + first + e]];
+					const uint32_t qi = Z.sidx[qo + first + e];
+					const uint32_t qlen = Z.len[qo + qi];
 					const uint32_t dvv = qlen > clen2 ? qlen - clen2 : clen2 - qlen;
+					if(same_strand && ((Z.pos[qo + qi] ^ cdir) & 1u)) continue;       /* align_hzmaux keeps strand 0 only (hzm_aln.h:1193) */
 					if(dvv <= max_var) cnt++;
 				}
 			}
@@ -120,6 +124,7 @@ WTZ_HD bool wtz_zmatch_coop(const wtz_zindex_t &Z, uint32_t q, uint32_t c, uint3
 				const uint32_t dv = qlen > clen2 ? qlen - clen2 : clen2 - qlen;
 				if(dv > max_var) continue;
 				const uint32_t d1 = qpos & 1u, d2 = cpos & 1u;
+				if(same_strand && (d1 ^ d2)) continue;
 				const uint32_t off2 = (d1 ^ d2) ? clen - ((cpos >> 1) + clen2) : (cpos >> 1);
 				wtz_zhit_t h; h.o1 = (d1 << 31) | (qpos >> 1); h.o2 = (d2 << 31) | off2; h.ll = (clen2 << 16) | qlen; h.gid = 0;
 				hits[o++] = h;

@@ -28,7 +28,7 @@ class Params(C.Structure):
                [("win_rep_norm", C.c_float), ("win_rep_cutoff", C.c_float)] + \
                [(n, C.c_int32) for n in ("w", "ew", "W", "M", "X", "O", "E", "T", "min_score")] + [("min_id", C.c_float)] + \
                [(n, C.c_int32) for n in ("dot_matrix", "xvar", "yvar", "min_block_len", "max_overhang")] + \
-               [("deviation_penalty", C.c_float), ("gap_penalty", C.c_float), ("refine", C.c_int32)]
+               [("deviation_penalty", C.c_float), ("gap_penalty", C.c_float), ("refine", C.c_int32), ("aux_strand", C.c_int32)]
 
     @classmethod
     def defaults(cls, **kw):
@@ -36,7 +36,7 @@ class Params(C.Structure):
         p = cls(ksize=16, zsize=10, hk=1, hz=1, ksave=4, kovl=300, ncand=500, nbest=100, kwin=800, kstep=400, ztot=300,
                 zovl=200, max_kmer_freq=0, max_zmer_freq=64, max_kmer_var=2, win_rep_norm=20.0, win_rep_cutoff=100.0,
                 w=50, ew=800, W=3200, M=2, X=-5, O=-3, E=-1, T=-50, min_score=200, min_id=0.5, dot_matrix=0, xvar=128,
-                yvar=64, min_block_len=160, max_overhang=256, deviation_penalty=1.0, gap_penalty=0.05, refine=0)
+                yvar=64, min_block_len=160, max_overhang=256, deviation_penalty=1.0, gap_penalty=0.05, refine=0, aux_strand=0)
         for k, v in kw.items():
             setattr(p, k, v)
         p.kstep = p.kwin // 2

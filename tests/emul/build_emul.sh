@@ -10,3 +10,6 @@ gcc -std=gnu11 -O2 -g -ffp-contract=off -Wall -Wextra -Wno-unused-parameter -Wno
 # the same host driver as a shared object (wtzmo_main + wtzmo_set_dist + step hook) on the emulated device layer: rank tests load it with ctypes
 gcc -std=gnu11 -O2 -g -ffp-contract=off -Wall -Wextra -Wno-unused-parameter -Wno-sign-compare -DWTZ_AS_LIB -shared -fPIC -I"$ROOT/include" \
     -o "$HERE/libwtzmo_host_emul.so" "$ROOT/smartdenovo_amd/csrc/host/wtzmo_main.c" -L"$HERE" -lwtz_emul -Wl,-rpath,'$ORIGIN' -lstdc++ -lm -lpthread
+# the drop-in wtgbo on the emulated device layer
+gcc -std=gnu11 -O2 -g -ffp-contract=off -Wall -Wextra -Wno-unused-parameter -Wno-sign-compare -I"$ROOT/include" \
+    -o "$HERE/wtgbo_emul" "$ROOT/smartdenovo_amd/csrc/host/wtgbo_main.c" -L"$HERE" -lwtz_emul -Wl,-rpath,'$ORIGIN' -lstdc++ -lm -lpthread

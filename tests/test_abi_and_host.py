@@ -28,8 +28,8 @@ def test_library_exports_all_symbols():
 
 def test_params_struct_layout():
     from smartdenovo_amd import hipabi
-    # 15 u32 + 2 f32 + 9 i32 + f32 + 5 i32 + 2 f32 + refine = 35 words
-    assert ctypes.sizeof(hipabi.Params) == 35 * 4
+    # 15 u32 + 2 f32 + 9 i32 + f32 + 5 i32 + 2 f32 + refine + aux_strand = 36 words
+    assert ctypes.sizeof(hipabi.Params) == 36 * 4
     assert hipabi.PAIR_SUMMARY.itemsize == 48 and hipabi.WINBOX.itemsize == 16 and hipabi.ALN_RESULT.itemsize == 72
 
 
