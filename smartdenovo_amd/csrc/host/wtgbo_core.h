@@ -257,8 +257,9 @@ static void gbo_job_push(gbo_t *G, uint32_t obj, uint32_t qry, uint32_t dir){
 
 /* the gates of align_hzmaux behind the stitched alignment (hzm_aln.h:1715-1718): the hit must cover min_sm of the overlap its
  * ends imply.  tlen = length of obj, qlen = length of qry */
-static int gbo_hit_passes(const gbo_res_t *r, int tlen, int qlen, float min_sm){
+static int gbo_hit_passes(const gbo_res_t *r, int tlen, int qlen, float min_sm, int refined){
 	if(!r->ok) return 0;
+	if(refined) return 1;       /* -n: the gates apply to the alignment BEFORE kswx_refine_alignment (hzm_aln.h:1718 vs 1721-1729) and ran on the device */
 	int beg = r->qb - r->tb; if(beg < 0) beg = 0;
 	int end = r->qe + tlen - r->te; if(end > qlen) end = qlen;
 	const int ovl = end - beg;
@@ -330,7 +331,7 @@ static uint64_t gbo_run_jobs(gbo_t *G, int graph_pass){
 		/* the worker runs job i (wtgbo.c:37-56) */
 		const gbo_res_t *r = &G->res[i];
 		w_job = i;
-		w_ret = gbo_hit_passes(r, (int)G->rdlen[j->obj], (int)G->rdlen[j->qry], o->min_id);
+		w_ret = gbo_hit_passes(r, (int)G->rdlen[j->obj], (int)G->rdlen[j->qry], o->min_id, o->refine);
 		w_contained = (w_ret && r->tb == 0 && r->te == (int)G->rdlen[j->qry]);
 		i++;
 	}

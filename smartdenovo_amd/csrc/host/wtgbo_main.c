@@ -95,7 +95,6 @@ int main(int argc, char **argv){
 	if(gbo_parse_args(&G->O, argc, argv)) return gbo_usage();
 	gbo_opt_t *o = &G->O;
 	if(o->zsize < 5 || o->zsize > 16){ fprintf(stderr, " -- -z must be within 5..16 --\n"); return gbo_usage(); }
-	if(o->refine){ fprintf(stderr, " -- wtgbo -n: the refined form of align_hzmaux (hzm_aln.h:1721-1729 gates on the unrefined alignment) is not built yet --\n"); return 1; }
 	if(wtz_device_count() <= 0){ fprintf(stderr, " -- no HIP device visible: wtgbo (MI355X build) has no CPU path for the alignment: %s --\n", wtz_last_error()); return 1; }
 	gbo_load_inputs(G);
 	/* ---- device: every read and its reverse complement ---- */
@@ -117,7 +116,7 @@ int main(int argc, char **argv){
 	P.w = o->w; P.ew = o->ew; P.W = o->W; P.M = o->M; P.X = o->X; P.O = o->O; P.E = o->E; P.T = o->T;
 	P.min_score = o->min_score; P.min_id = o->min_id;
 	P.dot_matrix = 0; P.xvar = 128; P.yvar = 64; P.min_block_len = 160; P.max_overhang = 256; P.deviation_penalty = 1.0f; P.gap_penalty = 0.05f;
-	P.refine = 0; P.aux_strand = 1;
+	P.refine = o->refine; P.aux_strand = 1;      /* -n: the device applies the gates of hzm_aln.h:1715-1718 before it refines (wtz_task_refine) */
 	gbo_dev_t D; memset(&D, 0, sizeof D);
 	D.n_rd = n;
 	int rc = wtz_ctx_create(o->gpu, &P, o->pool_gb << 30, &D.ctx); DIE_WTZ(rc, "wtz_ctx_create");

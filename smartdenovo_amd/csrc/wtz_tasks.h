@@ -1081,6 +1081,18 @@ WTZ_HD void wtz_task_refine(uint32_t t, const wtz_env_t &V, const wtz_alnitem_t 
 	wtz_alnres_dev_t r = res[t];
 	if(r.n_regs == 0 || r.bad) return;
 	const wtz_alnitem_t &it = items[t];
+	if(P->aux_strand){
+		/* align_hzmaux gates the STITCHED alignment before it refines it (hzm_aln.h:1715-1718; the refined one is returned unchecked, 1721-1729):
+		 * an item that fails leaves as "no regions" (n_regs 0), the caller's sign for "no hit" */
+		const int32_t tl = (int32_t)V.R.rdlen[it.q], ql = (int32_t)V.R.rdlen[it.c];
+		int32_t beg = r.x.qb - r.x.tb; if(beg < 0) beg = 0;
+		int32_t end = r.x.qe + tl - r.x.te; if(end > ql) end = ql;
+		const int32_t ovl = end - beg;
+		if(r.x.score < 0 || (float)r.x.mat < (float)r.x.aln * P->min_id || (float)r.x.mat < (float)ovl * P->min_id){
+			if(WTZ_LANE == 0){ r.n_regs = 0; res[t] = r; }
+			return;
+		}
+	}
 	const wtz_readview pb1 = wtz_view(V.R, it.q, 0), pb2 = wtz_view(V.R, it.c, it.dir);
 	wtz_cigar_t out; out.a = NULL; out.n = out.cap = 0; out.pool = V.pool; out.bad = 0;
 	if(WTZ_LANE == 0) out.init(V.pool, r.cigar_len + 64);
