@@ -33,3 +33,18 @@ void ora_sort_u64_lo32_desc(uint64_t *v, size_t n){ ora_sort_cand_desc(v, n, NUL
 ORA_DEFINE_SORT(ora_sort_u32_asc_impl, uint32_t, ORA_U32_GT)
 void ora_sort_u32_asc(uint32_t *v, size_t n){ ora_sort_u32_asc_impl(v, n, NULL); }
 int ora_median_c(int32_t *v, int32_t n){ return ora_median(v, n); }
+
+/* ---- f1: align_hzmaux (hzm_aln.h:1684-1775), whole-read form as wtgbo calls it ---- */
+#include "ora_hzmaux.h"
+int ora_align_hzmaux_c(const uint8_t *tseq, int tlen, const uint8_t *rdseq, int rdlen, const int32_t *prm, float min_sm, int refine, shim_aln_t *out, uint32_t *cigar_out, int cigar_cap){
+	static ora_hzmaux_t A;     /* scratch kept across calls */
+	ora_auxparams_t P;
+	P.zsize = (uint32_t)prm[0]; P.hz = (uint32_t)prm[1]; P.zwin = (uint32_t)prm[2]; P.zstep = (uint32_t)prm[3]; P.zovl = (uint32_t)prm[4]; P.zmax = (uint32_t)prm[5]; P.zvar = (uint32_t)prm[6];
+	P.w = prm[7]; P.W = prm[8]; P.ew = prm[9]; P.rw = prm[10]; P.M = prm[11]; P.X = prm[12]; P.I = prm[13]; P.D = prm[14]; P.E = prm[15]; P.T = prm[16];
+	ora_hzmaux_index(&A, &P, tseq, (uint32_t)tlen);
+	if(!ora_align_hzmaux(&A, &P, rdseq, rdlen, refine, min_sm)) return -1;
+	*out = A.hit;
+	if((int)A.cigars.n > cigar_cap) return -2;
+	memcpy(cigar_out, A.cigars.a, 4 * A.cigars.n);
+	return (int)A.cigars.n;
+}

@@ -44,3 +44,22 @@ int ref_global(int qlen, uint8_t *q, int tlen, uint8_t *t, int M, int X, int o_d
 void ref_sort_u64_lo32_desc(uint64_t *v, size_t n){ sort_array(v, n, uint64_t, (b & 0xFFFFFFFFU) > (a & 0xFFFFFFFFU)); }
 void ref_sort_u32_asc(uint32_t *v, size_t n){ sort_array(v, n, uint32_t, a > b); }
 int ref_median(int32_t *v, int32_t n){ return calculate_median_value(v, n); }
+
+/* ---- f1: the reference's own align_hzmaux (hzm_aln.h:1684-1775) on one (target, read) pair, whole-read form as wtgbo calls it (wtgbo.c:37-56).
+ * prm = zsize hz zwin zstep zovl zmax zvar w W ew rw M X I D E T.  Returns the number of CIGAR words, -1 = no hit. */
+int ref_align_hzmaux(const uint8_t *tseq, int tlen, uint8_t *rdseq, int rdlen, const int32_t *prm, float min_sm, int refine, shim_aln_t *out, uint32_t *cigar_out, int cigar_cap){
+	static HZMAux *aux = NULL;
+	int i;
+	if(aux == NULL) aux = init_hzmaux();
+	aux->zsize = prm[0]; aux->hz = prm[1]; aux->zwin = prm[2]; aux->zstep = prm[3]; aux->zovl = prm[4]; aux->zmax = prm[5]; aux->zvar = prm[6];
+	aux->w = prm[7]; aux->W = prm[8]; aux->ew = prm[9]; aux->rw = prm[10]; aux->M = prm[11]; aux->X = prm[12]; aux->I = prm[13]; aux->D = prm[14]; aux->E = prm[15]; aux->T = prm[16];
+	aux->has_alignment = 0;
+	reset_hzmaux(aux);
+	for(i = 0; i < tlen; i++) add_tseq_hzmaux(aux, tseq[i]);
+	ready_hzmaux(aux);
+	if(!align_hzmaux(aux, 0, rdseq, NULL, rdlen, 0, 0, refine, min_sm)) return -1;
+	*out = to_shim(aux->hit);
+	if((int)aux->cigars->size > cigar_cap) return -2;
+	memcpy(cigar_out, aux->cigars->buffer, sizeof(uint32_t) * aux->cigars->size);
+	return (int)aux->cigars->size;
+}

@@ -309,7 +309,7 @@ static uint64_t gbo_run_jobs(gbo_t *G, int graph_pass){
 			if(i > done) done = i;       /* jobs dropped behind a containing hit are not aligned at all when they fall into a later batch */
 			size_t n = G->njob - done; if(n > o->batch) n = o->batch;
 			G->ncig = 0;         /* the CIGARs of committed batches are no longer needed (the pending hit is re-pointed below) */
-			gbo_res_t keep; uint32_t *keepc = NULL;
+			gbo_res_t keep; uint32_t *keepc = NULL; memset(&keep, 0, sizeof keep);
 			if(w_ret){ keep = G->res[w_job]; keepc = (uint32_t*)hx_realloc(NULL, 4 * ((size_t)keep.cig_len + 1)); memcpy(keepc, G->cigar_pool + keep.cig_off, 4 * (size_t)keep.cig_len); }
 			gbo_align_jobs(G, G->jobs + done, n, G->res + done);
 			if(w_ret){ uint32_t *p = gbo_cigar_space(G, keep.cig_len); memcpy(p, keepc, 4 * (size_t)keep.cig_len); G->res[w_job].cig_off = (uint64_t)(p - G->cigar_pool); free(keepc); }

@@ -59,6 +59,18 @@ def emul_gbo():
     return os.path.join(ROOT, "tests", "emul", "wtgbo_emul")
 
 
+@pytest.fixture(scope="module")
+def oracle_gbo():
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "wtgbo_oracle"], check=True)
+    return os.path.join(ROOT, "oracle", "wtgbo_oracle")
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_wtgbo_oracle_equals_reference_golden(name, oracle_gbo, tmp_path):
+    """pins oracle/ora_hzmaux.h (align_hzmaux on the CPU) at program level"""
+    check_case(oracle_gbo, name, tmp_path)
+
+
 @pytest.mark.parametrize("name", CASES)
 def test_wtgbo_host_logic_on_emulated_device(name, emul_gbo, tmp_path):
     check_case(emul_gbo, name, tmp_path)
