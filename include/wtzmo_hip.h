@@ -17,6 +17,10 @@
  *                           kswx_extend_align_shift_core, ksw_global2) hzm_aln.h:1247-1486, kswx.h:101-335, ksw.c:503-586;
  *                           with params.refine also kswx_refine_alignment kswx.h:483-659
  *
+ *   wtz_pairs_seed + wtz_pairs_align with params.aux_strand = 1
+ *                        <- align_hzmaux, the pair routine of wtgbo   hzm_aln.h:1684-1775 (its caller wtgbo.c:37-56 orients the read first:
+ *                           the host uploads every read and its reverse complement, smartdenovo_amd/csrc/host/wtgbo_main.c)
+ *
  * Everything returned is integer and bit-exact against `wtzmo -t 1`.  The order-dependent state of
  * the reference (closed pairs, contained-read masking, per-read coverage: wtzmo.c:806-822, 1065-1100,
  * 1309-1334) stays with the caller: these functions are pure in (reads, parameters, arguments).
