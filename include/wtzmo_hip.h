@@ -99,6 +99,8 @@ typedef struct {
 	uint64_t n_extjobs;
 	double   ms_gap;                                                                  /* K-sw2 gap kernels alone (inside ms_stitch) */
 	uint64_t bytes_zmer_algo;                                                         /* algorithmic bytes of z-mer matching: candidate L/4 + 16 B per emitted match (hzm_aln.h:173-224) */
+	double   ms_ingest;                                                               /* K_pack_ascii + K_pack_fix of wtz_upload_reads_ascii (kernel time, copies excluded) */
+	uint64_t bytes_ingest_algo;                                                       /* 1 byte read + 2 bits written per base */
 } wtz_counters_t;
 
 const char *wtz_last_error(void);
@@ -113,6 +115,15 @@ int  wtz_ctx_clone(wtz_ctx_t *parent, uint64_t pool_bytes, wtz_ctx_t **out);
 /* bits: 2-bit packed bases, 32 per word, base i at bits ((~i)&31)*2 of word i>>5 (dna.h:78);
  * rdoff/rdlen per read in READ-ID order (id = rank by length DESC under the reference's sort, wtzmo.c:1708). */
 int  wtz_upload_reads(wtz_ctx_t *ctx, const uint64_t *bits, uint64_t n_words, const uint64_t *rdoff, const uint32_t *rdlen, uint32_t n_reads);
+
+/* f4: the same upload from the bases as TEXT - seq2basebank (dna.h:397-410) on the device.  seq = the sequences of all reads of the
+ * input concatenated in FILE order (n_bases bytes; upper or lower case; rdoff / rdlen index into it exactly as they would into the packed bank).
+ * Every byte that is not one of ACGTacgt becomes `lrand48() & 3`, drawn in file order like the reference's loader does (dna.h:405) with the state of a
+ * glibc process that never called srand48 (X0 = 0); rand_calls_before = lrand48 calls the emulated process made before this input (0 for wtzmo / wtgbo), *n_random (may be NULL) = such
+ * bytes found.  The resulting device bank is bit-identical to wtz_upload_reads of the host-packed bank. */
+int  wtz_upload_reads_ascii(wtz_ctx_t *ctx, const char *seq, uint64_t n_bases, const uint64_t *rdoff, const uint32_t *rdlen, uint32_t n_reads, uint64_t rand_calls_before, uint64_t *n_random);
+/* the packed bank back from the device (n_words = (n_bases + 31) / 32): what a host-side consumer of the 2-bit reads (wtgbo's reverse-complement views, tests) reads */
+int  wtz_fetch_read_bits(wtz_ctx_t *ctx, uint64_t *bits, uint64_t n_words);
 
 /* A2 over read ids [id_beg, id_end). *max_kmer_freq: in = -K (0/1 = auto), out = resolved cutoff. */
 int  wtz_index_build(wtz_ctx_t *ctx, uint32_t id_beg, uint32_t id_end, uint32_t *max_kmer_freq, wtz_index_stats_t *stats);

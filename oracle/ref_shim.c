@@ -63,3 +63,16 @@ int ref_align_hzmaux(const uint8_t *tseq, int tlen, uint8_t *rdseq, int rdlen, c
 	memcpy(cigar_out, aux->cigars->buffer, sizeof(uint32_t) * aux->cigars->size);
 	return (int)aux->cigars->size;
 }
+
+/* ---- f4: the reference's own loader of one sequence into a BaseBank (seq2basebank, dna.h:397-410) from the lrand48 state of a fresh glibc process (all
+ * zero: seed48 of three zeros restores exactly that, the multiplier and the addend being reset to their defaults), after `skip` earlier lrand48 calls.  bits_out must hold (len + 31) / 32 + 1 words. */
+void ref_seq2basebank(char *seq, uint64_t len, uint64_t skip, uint64_t *bits_out){
+	unsigned short s0[3] = {0, 0, 0};
+	uint64_t i;
+	BaseBank *bnk = init_basebank();
+	seed48(s0);
+	for(i = 0; i < skip; i++) (void)lrand48();
+	seq2basebank(bnk, seq, len);
+	memcpy(bits_out, bnk->bits, ((len + 31) / 32) * 8);
+	free_basebank(bnk);
+}

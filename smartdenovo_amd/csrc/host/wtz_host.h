@@ -78,6 +78,7 @@ typedef struct {
 	uint64_t *bits; uint64_t nbase, capw;      /* BaseBank layout, dna.h:318-322 */
 	hx_read_t *reads; uint32_t n_all, cap_reads;
 	uint32_t n_rd, n_qr;                        /* indexed reads / -I query-only reads */
+	int keep_text; char *text; uint64_t captext; /* f4: keep the bases as TEXT (file order) for wtz_upload_reads_ascii instead of packing them here */
 } hx_store_t;
 
 static inline void hx_store_put(hx_store_t *st, unsigned b){
@@ -99,6 +100,11 @@ static void hx_store_add(hx_store_t *st, const char *name, size_t nlen, const ch
 	hx_read_t *r = &st->reads[st->n_all++];
 	r->off = st->nbase; r->len = (uint32_t)slen;
 	r->name = (char*)hx_realloc(NULL, nlen + 1); memcpy(r->name, name, nlen); r->name[nlen] = 0;
+	if(st->keep_text){       /* packed (and its non-ACGT bytes drawn) on the device */
+		if(st->nbase + slen + 1 > st->captext){ uint64_t c = st->captext ? st->captext : ((uint64_t)1 << 20); while(c < st->nbase + slen + 1) c += c / 2; st->text = (char*)hx_realloc(st->text, c); st->captext = c; }
+		memcpy(st->text + st->nbase, seq, slen); st->nbase += slen;
+		return;
+	}
 	for(size_t i = 0; i < slen; i++){
 		int c = code[(unsigned char)seq[i]];
 		unsigned b = c ? (unsigned)(c - 1) : (unsigned)(lrand48() & 3);      /* non-ACGT: dna.h:405, file order, default seed */
@@ -153,8 +159,9 @@ static long hx_reader_line(hx_reader_t *r){
 	r->line[n] = 0; r->n = (long)n;
 	return r->n;
 }
-/* returns 1 and fills name/seq for the next record, 0 at end */
-static int hx_reader_seq(hx_reader_t *r, hx_str_t *name, hx_str_t *seq){
+/* returns 1 and fills name/seq for the next record, 0 at end; desc (may be NULL) = the rest of the header line behind the name
+ * (Sequence.header + tag.size, file_reader.c:327-328, 371-372) */
+static int hx_reader_seq_desc(hx_reader_t *r, hx_str_t *name, hx_str_t *desc, hx_str_t *seq){
 	long n;
 	if(r->kind == 0){
 		r->kind = 3;
@@ -164,7 +171,7 @@ static int hx_reader_seq(hx_reader_t *r, hx_str_t *name, hx_str_t *seq){
 			r->pushed = 1; break;
 		}
 	}
-	name->n = 0; seq->n = 0;
+	name->n = 0; seq->n = 0; if(desc) desc->n = 0;
 	if(r->kind == 1){
 		int state = 0;
 		while((n = hx_reader_line(r)) != -1){
@@ -173,6 +180,7 @@ static int hx_reader_seq(hx_reader_t *r, hx_str_t *name, hx_str_t *seq){
 				state = 1;
 				long i = 1; while(i < n && r->line[i] != ' ' && r->line[i] != '\t' && r->line[i] != '\r' && r->line[i] != '\n') i++;
 				hx_str_add(name, r->line + 1, (size_t)(i - 1));
+				if(desc) hx_str_add(desc, r->line + i, (size_t)(n - i));
 			} else if(state){ hx_str_add(seq, r->line, (size_t)n); state = 2; }
 		}
 		return state != 0;
@@ -182,7 +190,7 @@ static int hx_reader_seq(hx_reader_t *r, hx_str_t *name, hx_str_t *seq){
 		while(state != 4 && (n = hx_reader_line(r)) >= 0){
 			if(state == 0){ if(r->line[0] != '@') continue; state = 1;
 				long i = 1; while(i < n && r->line[i] != ' ' && r->line[i] != '\t' && r->line[i] != '\n') i++;
-				hx_str_add(name, r->line + 1, (size_t)(i - 1)); }
+				hx_str_add(name, r->line + 1, (size_t)(i - 1)); if(desc) hx_str_add(desc, r->line + i, (size_t)(n - i)); }
 			else if(state == 1){ state = 2; hx_str_add(seq, r->line, (size_t)n); }
 			else if(state == 2){ if(r->line[0] == '+') state = 3; }
 			else state = 4;
@@ -191,6 +199,8 @@ static int hx_reader_seq(hx_reader_t *r, hx_str_t *name, hx_str_t *seq){
 	}
 	return 0;
 }
+
+static int hx_reader_seq(hx_reader_t *r, hx_str_t *name, hx_str_t *seq){ return hx_reader_seq_desc(r, name, NULL, seq); }
 
 /* ---------------- open-addressing u64 set / name map ---------------- */
 typedef struct { uint64_t *tab; size_t cap, n; } hx_set_t;

@@ -1158,6 +1158,7 @@ int wtzmo_main(int argc, char **argv){
 int main(int argc, char **argv){
 #endif
 	eng_t *E = (eng_t*)calloc(1, sizeof(eng_t));
+	E->st.keep_text = 1;        /* --ingest device */
 	wtz_params_c *P = &E->P;
 	strlist_t pbs = {0}, flts = {0}, ovls = {0}, obts = {0}, tbas = {0};
 	char *output = NULL, *pairoutf = NULL, *statsf = NULL;
@@ -1173,7 +1174,7 @@ int main(int argc, char **argv){
 	E->do_align = 1; E->n_idx = 1; E->n_job = 1; E->i_job = 0; E->max_batch = 4096; E->first_batch = 256; E->n_workers = 1;
 	pthread_mutex_init(&E->mu, NULL); pthread_cond_init(&E->cv, NULL);
 	static struct option lopts[] = { {"stats", required_argument, 0, 1000}, {"gpu", required_argument, 0, 1001}, {"pool-gb", required_argument, 0, 1002},
-		{"batch", required_argument, 0, 1003}, {"lib-check", no_argument, 0, 1004}, {"repeat", required_argument, 0, 1005}, {"first-batch", required_argument, 0, 1006}, {"workers", required_argument, 0, 1007}, {"pool-mb", required_argument, 0, 1008}, {"gpus", required_argument, 0, 1010}, {"gpu-list", required_argument, 0, 1011}, {"shard-index", no_argument, 0, 1012}, {"zindex-batch", required_argument, 0, 1013}, {0, 0, 0, 0} };
+		{"batch", required_argument, 0, 1003}, {"lib-check", no_argument, 0, 1004}, {"repeat", required_argument, 0, 1005}, {"first-batch", required_argument, 0, 1006}, {"workers", required_argument, 0, 1007}, {"pool-mb", required_argument, 0, 1008}, {"gpus", required_argument, 0, 1010}, {"gpu-list", required_argument, 0, 1011}, {"shard-index", no_argument, 0, 1012}, {"zindex-batch", required_argument, 0, 1013}, {"ingest", required_argument, 0, 1014}, {0, 0, 0, 0} };
 	while((c = getopt_long(argc, argv, "ht:P:p:Ni:b:J:I:o:9:S:fCH:k:G:z:Z:U:y:d:r:q:l:K:A:B:r:R:L:F:W:w:e:M:X:O:E:T:s:m:nv", lopts, NULL)) != -1){
 		switch(c){
 			case 1000: statsf = optarg; break;
@@ -1184,6 +1185,7 @@ int main(int argc, char **argv){
 			case 1005: repeat = atoi(optarg); if(repeat < 1) repeat = 1; break;
 			case 1006: E->first_batch = (uint32_t)atoi(optarg); if(E->first_batch < 1) E->first_batch = 1; E->first_batch_set = 1; break;
 			case 1010: n_gpus = atoi(optarg); if(n_gpus < 1) n_gpus = 1; if(n_gpus > 8) n_gpus = 8; break;
+			case 1014: E->st.keep_text = (strcmp(optarg, "host") != 0); break;      /* f4: `device` (default) = the bases travel as text and are packed to 2 bits on the GPU (wtz_upload_reads_ascii), `host` = packed while reading */
 			case 1013: E->zbatch = atoi(optarg) ? 1 : -1; break;      /* 1 = per-batch z-index, 0 = never (default: by the size of the read set) */
 			case 1012: E->shard = 1; break;           /* k-mer index sharded over the devices of --gpus / --gpu-list (or over the ranks) */
 			case 1011: gpu_list = optarg; break;      /* explicit device ids, e.g. 0,1,2,3 (an id may repeat: two contexts on one GPU, used by the tests) */
@@ -1350,6 +1352,18 @@ int main(int argc, char **argv){
 	int rc;
 	for(uint32_t d = 0; d < E->ndev; d++){
 		rc = wtz_ctx_create(E->devs[d], P, pool_bytes, &E->ctxs[d]); DIE_WTZ(rc, "wtz_ctx_create");
+		if(E->st.keep_text && E->st.bits == NULL){
+			/* f4: seq2basebank on the device (dna.h:397-410); the packed bank comes back once for the other contexts of this process */
+			const double ti0 = now_s(); uint64_t n_other = 0;
+			rc = wtz_upload_reads_ascii(E->ctxs[d], E->st.text, E->st.nbase, rdoff, E->rdlen, n_all, 0, &n_other); DIE_WTZ(rc, "wtz_upload_reads_ascii");
+			const uint64_t nw = (E->st.nbase + 31) / 32;
+			E->st.bits = (uint64_t*)hx_realloc(NULL, 8 * (nw + 2)); E->st.capw = nw + 2; E->st.bits[nw] = E->st.bits[nw + 1] = 0;
+			rc = wtz_fetch_read_bits(E->ctxs[d], E->st.bits, nw); DIE_WTZ(rc, "wtz_fetch_read_bits");
+			free(E->st.text); E->st.text = NULL; E->st.captext = 0;
+			{ wtz_counters_t ic; if(wtz_get_counters(E->ctxs[d], &ic) == WTZ_OK) fprintf(stderr, "[wtzmo-mi355x] %llu bases packed on the device (%llu not ACGT): kernels %.2f ms = %.0f GB/s, with the copies %.0f ms\n",
+				(unsigned long long)E->st.nbase, (unsigned long long)n_other, ic.ms_ingest, ic.ms_ingest > 0 ? (double)ic.bytes_ingest_algo / ic.ms_ingest / 1e6 : 0.0, 1e3 * (now_s() - ti0)); }
+			continue;
+		}
 		rc = wtz_upload_reads(E->ctxs[d], E->st.bits, (E->st.nbase + 31) / 32, rdoff, E->rdlen, n_all); DIE_WTZ(rc, "wtz_upload_reads");
 	}
 	E->ctx = E->ctxs[0];

@@ -1,0 +1,85 @@
+/*
+ * wtz_ingest.h — f4: FASTA / FASTQ bases -> the reference's 2-bit BaseBank ON THE DEVICE.
+ *
+ *   wtz_pack_word      seq2basebank, dna.h:397-410 + base_bit_table dna.h:29-49 + bit2bits dna.h:78: 32 ASCII bases -> one word,
+ *                      base i at bits ((~i)&31)*2 of word i>>5; A/a 0, C/c 1, G/g 2, T/t 3
+ *   wtz_lrand48_state  every other byte becomes `lrand48() & 3` in FILE order (dna.h:405).  glibc's lrand48 is the 48-bit LCG
+ *                      X(k+1) = 0x5DEECE66D * X(k) + 0xB; a process that never called srand48 starts from X(0) = 0 (glibc's state is
+ *                      zero-initialised static data - NOT the 0x1234ABCD330E of the SVID text: its first four draws are 0, 2116118, 89401895,
+ *                      379337186), and the k-th call returns X(k) >> 17.  The k-th non-ACGT base of the input therefore gets bits 17-18 of X(k): the pack kernel
+ *                      only lists the positions of such bases, the host orders the (few) positions, and the fix-up kernel jumps the
+ *                      LCG to each rank in O(log k) by squaring the affine map.
+ *
+ * HBM-bound by construction: 1 byte read + 2 bits written per base, no re-reads.
+ */
+#ifndef WTZ_INGEST_H
+#define WTZ_INGEST_H
+
+#include "wtz_common.h"
+
+#if defined(__HIP_DEVICE_COMPILE__)
+#define WTZ_ING_NEXT(p) atomicAdd((p), 1ull)
+#define WTZ_ING_OR(p, v) atomicOr((p), (v))
+#else
+#define WTZ_ING_NEXT(p) ((*(p))++)
+#define WTZ_ING_OR(p, v) (*(p) |= (v))
+#endif
+
+/* X(k) of glibc's never-seeded drand48 family: the affine map x -> a*x + c (mod 2^48) applied k times to X(0) = 0 */
+WTZ_HD uint64_t wtz_lrand48_state(uint64_t k){
+	const uint64_t MASK = (1ull << 48) - 1;
+	uint64_t A = 1, C = 0;                      /* accumulated map: identity */
+	uint64_t a = 0x5DEECE66Dull, c = 0xBull;    /* current power of the step */
+	while(k){
+		if(k & 1){ C = (a * C + c) & MASK; A = (a * A) & MASK; }
+		c = (a * c + c) & MASK; a = (a * a) & MASK;
+		k >>= 1;
+	}
+	(void)A;                                    /* A * X(0) with X(0) = 0 */
+	return C & MASK;
+}
+
+/* 2-bit code of one byte, 4 = not a base (dna.h:29-49: exactly A a C c G g T t are bases) */
+WTZ_HD uint32_t wtz_base_code(uint32_t ch){
+	const uint32_t lo = ch | 0x20u;
+	const uint32_t t = (lo >> 1) & 3u;          /* a 0, c 1, g 3, t 2 */
+	const bool ok = (lo == 0x61u) || (lo == 0x63u) || (lo == 0x67u) || (lo == 0x74u);
+	return ok ? (t ^ (t >> 1)) : 4u;
+}
+
+/* word `w` of the bank from ascii[w*32 .. w*32+32) (clipped at n); positions of non-bases are appended to pos[] (any order) */
+WTZ_HD uint64_t wtz_pack_word(const uint8_t *ascii, uint64_t n, uint64_t w, unsigned long long *n_pos, uint64_t *pos, uint64_t pos_cap, uint64_t pos_base){
+	const uint64_t b0 = w * 32;
+	uint64_t word = 0;
+	if(b0 + 32 <= n){
+		/* 32 bytes as four 8-byte loads: the slice of a device chunk starts 32-byte aligned */
+		const uint64_t *p8 = (const uint64_t*)(const void*)(ascii + b0);
+		#pragma unroll
+		for(int q = 0; q < 4; q++){
+			const uint64_t v = p8[q];
+			#pragma unroll
+			for(int k = 0; k < 8; k++){
+				const uint32_t code = wtz_base_code((uint32_t)(v >> (8 * k)) & 0xFFu);
+				const int i = q * 8 + k;
+				if(code < 4u) word |= (uint64_t)code << ((31 - i) * 2);
+				else { const unsigned long long at = WTZ_ING_NEXT(n_pos); if(at < pos_cap) pos[at] = pos_base + b0 + (uint64_t)i; }
+			}
+		}
+	} else {
+		for(uint64_t i = b0; i < n; i++){
+			const uint32_t code = wtz_base_code(ascii[i]);
+			if(code < 4u) word |= (uint64_t)code << ((31 - (int)(i - b0)) * 2);
+			else { const unsigned long long at = WTZ_ING_NEXT(n_pos); if(at < pos_cap) pos[at] = pos_base + i; }
+		}
+	}
+	return word;
+}
+
+/* the r-th listed position (ascending) is non-base number rank0 + r + 1 of the input: its two bits come from X(rank0 + r + 1) */
+WTZ_HD void wtz_fix_random_base(uint64_t r, const uint64_t *pos_sorted, uint64_t rank0, uint64_t *bits){
+	const uint64_t i = pos_sorted[r];
+	const uint64_t v = (wtz_lrand48_state(rank0 + r + 1) >> 17) & 3ull;
+	if(v) WTZ_ING_OR((unsigned long long*)&bits[i >> 5], (unsigned long long)(v << (((~i) & 31u) << 1)));
+}
+
+#endif

@@ -80,6 +80,8 @@ struct K_pack_windows;
 struct K_pair;
 struct K_pair_big;
 struct K_refine;
+struct K_pack_ascii;
+struct K_pack_fix;
 struct K_stitch_fin;
 struct K_stitch_left;
 struct K_stitch_mid;
@@ -576,6 +578,84 @@ extern "C" int wtz_upload_reads(wtz_ctx_t *c, const uint64_t *bits, uint64_t n_w
 	CHK(dev_alloc_persist((void**)&c->rdoff, (size_t)n_reads * 8)); CHK(dev_h2d(c->rdoff, rdoff, (size_t)n_reads * 8));
 	CHK(dev_alloc_persist((void**)&c->rdlen, (size_t)n_reads * 4)); CHK(dev_h2d(c->rdlen, rdlen, (size_t)n_reads * 4));
 	c->n_words = n_words; c->n_reads = n_reads; c->h_rdlen.assign(rdlen, rdlen + n_reads);
+	return WTZ_OK;
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* f4: FASTA -> 2-bit on the device (seq2basebank, dna.h:397-410)                                    */
+/* ------------------------------------------------------------------------------------------------ */
+#include "wtz_ingest.h"
+#ifndef WTZ_EMUL
+/* dedicated streaming kernel: 256 threads, grid-stride over the words of the chunk, 32 bytes in / 8 bytes out per thread and step */
+__global__ void __launch_bounds__(256) wtz_kernel_pack_ascii(const uint8_t *ascii, uint64_t n, uint64_t n_words, uint64_t *bits, unsigned long long *n_pos, uint64_t *pos, uint64_t pos_cap, uint64_t pos_base){
+	const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+	for(uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; w < n_words; w += stride) bits[w] = wtz_pack_word(ascii, n, w, n_pos, pos, pos_cap, pos_base);
+}
+#endif
+extern "C" int wtz_upload_reads_ascii(wtz_ctx_t *c, const char *seq, uint64_t n_bases, const uint64_t *rdoff, const uint32_t *rdlen, uint32_t n_reads, uint64_t rand_calls_before, uint64_t *n_random){
+	if(!c || (!seq && n_bases) || !rdoff || !rdlen) return wtz_fail(WTZ_E_ARG, "null argument");
+	CTX_ENTER(c);
+	if(c->shares_indexes) return wtz_fail(WTZ_E_STATE, "wtz_upload_reads_ascii on a cloned context");
+	dev_free_persist(c->bits); dev_free_persist(c->rdoff); dev_free_persist(c->rdlen); c->bits = NULL; c->rdoff = NULL; c->rdlen = NULL;
+	free_kindex(c); free_zindex(c); free_batch(c);
+	const uint64_t n_words = (n_bases + 31) / 32;
+	CHK(dev_alloc_persist((void**)&c->bits, (n_words + 2) * 8)); CHK(dev_set(c->bits, 0, (n_words + 2) * 8));
+	CHK(dev_alloc_persist((void**)&c->rdoff, (size_t)n_reads * 8)); CHK(dev_h2d(c->rdoff, rdoff, (size_t)n_reads * 8));
+	CHK(dev_alloc_persist((void**)&c->rdlen, (size_t)n_reads * 4)); CHK(dev_h2d(c->rdlen, rdlen, (size_t)n_reads * 4));
+	c->n_words = n_words; c->n_reads = n_reads; c->h_rdlen.assign(rdlen, rdlen + n_reads);
+	const uint64_t CH = (uint64_t)256 << 20;             /* bases per chunk (a multiple of 32): 256 MB of text on the device at a time */
+	uint8_t *d_txt = NULL; unsigned long long *d_np = NULL; uint64_t *d_pos = NULL; uint64_t pos_cap = (uint64_t)1 << 20;
+	CHK(dev_alloc_persist((void**)&d_txt, (size_t)WTZ_MIN(CH, n_bases) + 64)); CHK(dev_alloc_persist((void**)&d_np, 16)); CHK(dev_alloc_persist((void**)&d_pos, pos_cap * 8));
+	uint64_t rank = rand_calls_before;
+	int rc = WTZ_OK;
+	for(uint64_t b0 = 0; b0 < n_bases && rc == WTZ_OK; b0 += CH){
+		const uint64_t nb = WTZ_MIN(CH, n_bases - b0), nw = (nb + 31) / 32;
+		if((rc = dev_h2d(d_txt, seq + b0, (size_t)nb))) break;
+		for(;;){
+			if((rc = dev_set(d_np, 0, 16))) break;
+			uint64_t *bits = c->bits + b0 / 32; unsigned long long *np = d_np; uint64_t *pos = d_pos; const uint8_t *txt = d_txt; const uint64_t cap = pos_cap;
+			wtz_timer tm; tm.start();
+#ifndef WTZ_EMUL
+			{ uint64_t nblk = (nw + 255) / 256; if(nblk > 256 * 64) nblk = 256 * 64;       /* 64 workgroups per CU: 8 words per thread at 256 M bases */
+			  hipLaunchKernelGGL(wtz_kernel_pack_ascii, dim3((uint32_t)nblk), dim3(256), 0, g_stream, txt, nb, nw, bits, np, pos, cap, b0);
+			  if(hipGetLastError() != hipSuccess){ rc = wtz_fail(WTZ_E_HIP, "wtz_kernel_pack_ascii launch failed"); break; } }
+#else
+			for(uint64_t w = 0; w < nw; w++) bits[w] = wtz_pack_word(txt, nb, w, np, pos, cap, b0);
+#endif
+			unsigned long long cnt = 0;
+			if((rc = dev_d2h(&cnt, d_np, 8))) break;
+			c->cnt.ms_ingest += tm.stop();
+			if(cnt > pos_cap){       /* more non-bases than the list holds: grow it and pack the chunk again */
+				dev_free_persist(d_pos); d_pos = NULL; pos_cap = cnt + cnt / 4;
+				if((rc = dev_alloc_persist((void**)&d_pos, pos_cap * 8))) break;
+				continue;
+			}
+			if(cnt){
+				std::vector<uint64_t> hp((size_t)cnt);
+				if((rc = dev_d2h(hp.data(), d_pos, (size_t)cnt * 8))) break;
+				std::sort(hp.begin(), hp.end());                    /* file order = ascending position */
+				if((rc = dev_h2d(d_pos, hp.data(), (size_t)cnt * 8))) break;
+				uint64_t *allbits = c->bits; const uint64_t r0 = rank;
+				wtz_timer tf; tf.start();
+				if((rc = wtz_launch<K_pack_fix>(0, cnt, [=] WTZ_LAMBDA (uint64_t r){ wtz_fix_random_base(r, pos, r0, allbits); }))) break;
+				if((rc = dev_sync())) break;
+				c->cnt.ms_ingest += tf.stop();
+				rank += cnt;
+			}
+			break;
+		}
+	}
+	dev_free_persist(d_txt); dev_free_persist(d_np); dev_free_persist(d_pos);
+	if(rc != WTZ_OK) return rc;
+	c->cnt.bytes_ingest_algo += n_bases + n_words * 8;
+	if(n_random) *n_random = rank - rand_calls_before;
+	return WTZ_OK;
+}
+extern "C" int wtz_fetch_read_bits(wtz_ctx_t *c, uint64_t *bits, uint64_t n_words){
+	if(!c || !bits || !c->bits) return wtz_fail(WTZ_E_ARG, "reads not uploaded / null argument");
+	if(n_words > c->n_words) return wtz_fail(WTZ_E_ARG, "wtz_fetch_read_bits: %llu words asked, %llu uploaded", (unsigned long long)n_words, (unsigned long long)c->n_words);
+	CTX_ENTER(c);
+	CHK(dev_d2h(bits, c->bits, (size_t)n_words * 8));
 	return WTZ_OK;
 }
 

@@ -18,7 +18,7 @@ SYMBOLS = [
     "wtz_index_build", "wtz_zindex_build", "wtz_candidates", "wtz_candidates_begin", "wtz_candidates_end", "wtz_batch_begin", "wtz_pairs_seed",
     "wtz_pairs_windows", "wtz_pairs_align", "wtz_fetch_cigars", "wtz_fetch_cigar_text", "wtz_host_alloc", "wtz_host_free", "wtz_get_counters", "wtz_reset_counters",
     "wtz_test_dp", "wtz_pool_info",
-    "wtz_index_count", "wtz_index_counts_fetch", "wtz_index_finish", "wtz_candidate_groups_begin", "wtz_candidate_groups_end", "wtz_candidate_groups_fetch", "wtz_cand_tail_host", "wtz_zindex_build_subset",
+    "wtz_index_count", "wtz_index_counts_fetch", "wtz_index_finish", "wtz_candidate_groups_begin", "wtz_candidate_groups_end", "wtz_candidate_groups_fetch", "wtz_cand_tail_host", "wtz_zindex_build_subset", "wtz_upload_reads_ascii", "wtz_fetch_read_bits",
 ]
 
 
@@ -68,7 +68,8 @@ class Counters(C.Structure):
     _fields_ = [(n, C.c_double) for n in ("ms_index", "ms_zindex", "ms_candidates", "ms_pairs", "ms_winalign", "ms_stitch")] + \
                [(n, C.c_uint64) for n in ("n_candidates_q", "n_pairs", "n_winalign", "n_stitch", "cells_shift", "cells_fixed",
                                           "cells_global", "bytes_seed_algo", "pool_peak")] + \
-               [("ms_ext", C.c_double), ("n_extjobs", C.c_uint64), ("ms_gap", C.c_double), ("bytes_zmer_algo", C.c_uint64)]
+               [("ms_ext", C.c_double), ("n_extjobs", C.c_uint64), ("ms_gap", C.c_double), ("bytes_zmer_algo", C.c_uint64),
+                ("ms_ingest", C.c_double), ("bytes_ingest_algo", C.c_uint64)]
 
 
 def load(path: str | None = None) -> C.CDLL:
@@ -143,6 +144,22 @@ class Context:
         self.n_reads = int(lens.size)
         self._keep = (words, offs, lens)
         self._chk(self.lib.wtz_upload_reads(self.h, words.ctypes.data, words.size, offs.ctypes.data, lens.ctypes.data, lens.size))
+
+    def upload_ascii(self, text: bytes, offs, lens, rand_calls_before=0):
+        """f4: the bases as text, packed on the device (wtz_upload_reads_ascii); returns the number of non-ACGT bytes"""
+        self.n_reads = int(lens.size)
+        self._keep = (text, offs, lens)
+        nr = C.c_uint64(0)
+        self.lib.wtz_upload_reads_ascii.argtypes = [C.c_void_p, C.c_char_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.POINTER(C.c_uint64)]
+        self._chk(self.lib.wtz_upload_reads_ascii(self.h, text, len(text), offs.ctypes.data, lens.ctypes.data, lens.size, rand_calls_before, C.byref(nr)))
+        return int(nr.value)
+
+    def fetch_read_bits(self, n_bases):
+        nw = (n_bases + 31) // 32
+        out = np.zeros(nw, dtype=np.uint64)
+        self.lib.wtz_fetch_read_bits.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
+        self._chk(self.lib.wtz_fetch_read_bits(self.h, out.ctypes.data, nw))
+        return out
 
     def index_build(self, beg=0, end=None, K=0):
         k = C.c_uint32(K)

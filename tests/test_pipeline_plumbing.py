@@ -22,8 +22,14 @@ def test_generated_makefile_rule_runs_the_drop_in(engine, tmp_path):
     ref = os.path.join(ROOT, "oracle", "_ref")
     bindir = os.path.join(str(tmp_path), "bin")
     os.makedirs(bindir)
-    links = {"wtpre": os.path.join(ref, "wtpre_ref"), "wtzmo": os.path.join(ROOT, "tests", "emul", "wtzmo_emul"), "wtlay": os.path.join(ref, "wtlay_ref"),
-             "wtclp": "/bin/true", "wtobt": "/bin/true", "wtgbo": "/bin/true", "wtcns": "/bin/true"}
+    import __graft_entry__ as ge
+    if not os.path.exists(ge.EXE_PRE):
+        subprocess.run(["gcc", "-std=gnu11", "-O2", "-Wno-unused-function", "-I" + os.path.join(ROOT, "include"), "-o", os.path.join(str(tmp_path), "wtpre_built"),
+                        os.path.join(ROOT, "smartdenovo_amd", "csrc", "host", "wtpre_main.c")], check=True)
+    pre = ge.EXE_PRE if os.path.exists(ge.EXE_PRE) else os.path.join(str(tmp_path), "wtpre_built")
+    # round 3: the steps either side of wtzmo are drop-ins too - wtpre (f4) in front, wtgbo (f1, on the emulated device layer here) behind
+    links = {"wtpre": pre, "wtzmo": os.path.join(ROOT, "tests", "emul", "wtzmo_emul"), "wtlay": os.path.join(ref, "wtlay_ref"),
+             "wtclp": "/bin/true", "wtobt": "/bin/true", "wtgbo": os.path.join(ROOT, "tests", "emul", "wtgbo_emul"), "wtcns": "/bin/true"}
     for n, t in links.items():
         os.symlink(t, os.path.join(bindir, n))
     env = dict(os.environ, PATH=bindir + ":" + os.environ["PATH"])
@@ -39,6 +45,10 @@ def test_generated_makefile_rule_runs_the_drop_in(engine, tmp_path):
     assert r.returncode == 0, r.stderr.decode()[-2000:]
     got = open(os.path.join(str(tmp_path), target), "rb").read()
     assert got.count(b"\n") > 50
+    # the prepared reads are what the reference's own wtpre writes for the rule `wtpre -J 3000 reads | gzip -c -1` (smartdenovo.pl:43-44)
+    want_pre = subprocess.run([os.path.join(ref, "wtpre_ref"), "-J", "3000", reads], capture_output=True, check=True).stdout
+    got_pre = subprocess.run(["gzip", "-dc", os.path.join(str(tmp_path), "asm.fa.gz")], capture_output=True, check=True).stdout
+    assert got_pre == want_pre and got_pre.count(b">") > 100
     # what the reference's own wtzmo writes for the same prepared reads (same rule, -t 1)
     argv = ["-k", "16", "-z", "10", "-Z", "16", "-U", "-1", "-m", "0.1", "-A", "1000"] if engine == "dmo" else ["-k", "16", "-s", "200", "-m", "0.6"]
     want_f = os.path.join(str(tmp_path), "ref.ovl")
@@ -47,6 +57,15 @@ def test_generated_makefile_rule_runs_the_drop_in(engine, tmp_path):
     if engine == "zmo":
         want = b"".join(b"\t".join(ln.split(b"\t")[:16]) + b"\n" for ln in want.split(b"\n") if ln)      # the rule pipes through cut -f1-16
     assert hashlib.md5(got).hexdigest() == hashlib.md5(want).hexdigest(), "the Makefile rule with the drop-in does not write the reference's records"
+    if engine == "zmo":
+        # the next rule of the zmo pipeline (smartdenovo.pl:60-61): $(EXE_GBO) ... -j asm.zmo.ovl.short -fo - | cut -f1-16 > asm.zmo.gbo.short
+        r = subprocess.run(["make", "-f", mak, "asm.zmo.gbo.short"], cwd=str(tmp_path), env=env, capture_output=True)
+        assert r.returncode == 0, r.stderr.decode()[-2000:]
+        got_g = open(os.path.join(str(tmp_path), "asm.zmo.gbo.short"), "rb").read()
+        rg = subprocess.run([os.path.join(ref, "wtgbo_ref"), "-t", "1", "-i", os.path.join(str(tmp_path), "asm.fa.gz"), "-j", os.path.join(str(tmp_path), target), "-fo", "-"],
+                            capture_output=True, check=True, cwd=str(tmp_path)).stdout
+        want_g = b"".join(b"\t".join(ln.split(b"\t")[:16]) + b"\n" for ln in rg.split(b"\n") if ln)
+        assert got_g == want_g and got_g.count(b"\n") > 10, "the wtgbo rule with the drop-in does not write the reference's records"
     # the consumer: the reference's wtlay must load the overlaps and lay the reads out (wtlay.h:238-268 parses >= 16 columns)
     lay = os.path.join(str(tmp_path), "asm.lay")
     r = subprocess.run([os.path.join(bindir, "wtlay"), "-i", os.path.join(str(tmp_path), "asm.fa.gz"), "-j", os.path.join(str(tmp_path), target), "-fo", lay] +
