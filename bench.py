@@ -238,6 +238,7 @@ def main():
     ms_gap = float(last[19]) if len(last) > 19 else 0.0
     n_ranges, n_split = (int(last[20]), int(last[21])) if len(last) > 21 else (0, 0)
     zmer_bytes = int(last[22]) if len(last) > 22 else 0
+    ing_ms, ing_bytes = (float(last[23]), int(last[24])) if len(last) > 24 else (0.0, 0)
 
     def valu_roofline(kernel, cells, ms_k, extra=None):
         ach = cells * OPS_PER_CELL / (ms_k * 1e-3) / 1e12 if ms_k > 0 else None
@@ -275,6 +276,10 @@ def main():
                           "frac": (seed_bytes / (ms["candidates"] * 1e-3) / 1e9 / HBM_PEAK_GBS) if ms["candidates"] > 0 else None,
                           "algorithmic_bytes_per_step": seed_bytes, "kernel_ms_per_step": ms["candidates"], "traffic": None},
     }
+    if ing_ms > 0:      # f4: FASTA text -> 2-bit BaseBank on the device, ONCE at load time (outside the timed steps: the metric excludes the FASTA load)
+        res["roofline_ingest"] = {"kernel": "wtz_kernel_pack_ascii (+ K_pack_fix for non-ACGT bytes): seq2basebank dna.h:397-410 on the device, measured once at load time, not inside the timed steps",
+                                  "bound": "hbm", "achieved": ing_bytes / (ing_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ing_bytes / (ing_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                  "algorithmic_bytes": ing_bytes, "kernel_ms": ing_ms, "traffic": None}
     # the nominal peak above is SURVEY 8d's formula (CUs x lanes x clock); what gfx950 ISSUES was measured with tools/ubench/valu_int32.hip
     # (profiles/r03_valu_int32_ubench.txt): v_add / v_sub ~60 Tlane-op/s, v_max_i32 / v_alignbit / v_mad_i32_i24 / v_lshl_or ~36.6 (half rate)
     for key in ("roofline", "roofline_sw1", "roofline_sw2"):

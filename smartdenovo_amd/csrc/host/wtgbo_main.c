@@ -20,6 +20,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <unistd.h>
+#include <pthread.h>
 #include "wtgbo_core.h"
 
 #define DIE_WTZ(rc, what) do { if((rc) != WTZ_OK){ fprintf(stderr, " -- %s failed: %s --\n", what, wtz_last_error()); fflush(NULL); _exit(1); } } while(0)
@@ -30,6 +31,14 @@ typedef struct {
 	uint32_t *cig; uint64_t capcig;
 	uint8_t *mark;            /* per uploaded read: in the current z-index subset */
 } gbo_dev_t;
+
+typedef struct { const wtz_params_c *P; int device; uint64_t pool_bytes; wtz_ctx_t *ctx; int rc; char err[256]; pthread_t th; } gbo_ctxjob_t;
+static void *gbo_ctxjob_main(void *arg){
+	gbo_ctxjob_t *j = (gbo_ctxjob_t*)arg;
+	j->rc = wtz_ctx_create(j->device, j->P, j->pool_bytes, &j->ctx);
+	if(j->rc != WTZ_OK) snprintf(j->err, sizeof j->err, "%s", wtz_last_error());
+	return NULL;
+}
 
 /* 0 = done, 1 = the scratch pool was too small for this many pairs */
 static int gbo_align_range(gbo_t *G, gbo_dev_t *D, const gbo_job_t *jobs, uint32_t n, gbo_res_t *res){
@@ -96,7 +105,20 @@ int main(int argc, char **argv){
 	gbo_opt_t *o = &G->O;
 	if(o->zsize < 5 || o->zsize > 16){ fprintf(stderr, " -- -z must be within 5..16 --\n"); return gbo_usage(); }
 	if(wtz_device_count() <= 0){ fprintf(stderr, " -- no HIP device visible: wtgbo (MI355X build) has no CPU path for the alignment: %s --\n", wtz_last_error()); return 1; }
-	gbo_load_inputs(G);
+	/* the context - above all the hipMalloc of its scratch pool, ~35 ms per GB - is created on a helper thread while the reads are loaded.  Default pool 16 GB, not the
+	 * library's 45 % of the HBM: a pass aligns thousands of pairs, not hundreds of thousands (E. coli shape: 5.4 s wall with the 128 GB default, 1.0 s with 16 GB) */
+	wtz_params_c P; memset(&P, 0, sizeof P);
+	P.ksize = 16; P.zsize = (uint32_t)o->zsize; P.hk = 1; P.hz = (uint32_t)o->hz; P.ksave = 4; P.kovl = 300; P.ncand = 500; P.nbest = 100;
+	P.kwin = (uint32_t)o->kwin; P.kstep = (uint32_t)o->kstep; P.ztot = (uint32_t)o->zovl; P.zovl = (uint32_t)o->zovl;
+	P.max_kmer_freq = 0; P.max_zmer_freq = (uint32_t)o->zcut; P.max_kmer_var = (uint32_t)o->kvar;
+	P.win_rep_norm = 20; P.win_rep_cutoff = 100;
+	P.w = o->w; P.ew = o->ew; P.W = o->W; P.M = o->M; P.X = o->X; P.O = o->O; P.E = o->E; P.T = o->T;
+	P.min_score = o->min_score; P.min_id = o->min_id;
+	P.dot_matrix = 0; P.xvar = 128; P.yvar = 64; P.min_block_len = 160; P.max_overhang = 256; P.deviation_penalty = 1.0f; P.gap_penalty = 0.05f;
+	P.refine = o->refine; P.aux_strand = 1;      /* -n: the device applies the gates of hzm_aln.h:1715-1718 before it refines (wtz_task_refine) */
+	static gbo_ctxjob_t cj; cj.P = &P; cj.device = o->gpu; cj.pool_bytes = (o->pool_gb ? o->pool_gb : 16) << 30; cj.ctx = NULL; cj.rc = WTZ_OK;
+	const int cj_started = (pthread_create(&cj.th, NULL, gbo_ctxjob_main, &cj) == 0);
+	gbo_load_inputs(G);            /* its error paths leave through exit(): join first if that ever matters - they fire within milliseconds of the start */
 	/* ---- device: every read and its reverse complement ---- */
 	const uint32_t n = G->n_rd;
 	uint64_t *rdoff = (uint64_t*)hx_realloc(NULL, 8 * ((size_t)n * 2 + 1));
@@ -108,18 +130,12 @@ int main(int argc, char **argv){
 		rdoff[n + i] = G->st.nbase; rdlen2[n + i] = len; tot += len;
 		for(uint32_t p = len; p > 0; p--){ const uint64_t x = off + p - 1; const unsigned b = (unsigned)(G->st.bits[x >> 5] >> (((~x) & 31u) << 1)) & 3u; hx_store_put(&G->st, 3u - b); }   /* revbitseq_basebank, dna.h */
 	}
-	wtz_params_c P; memset(&P, 0, sizeof P);
-	P.ksize = 16; P.zsize = (uint32_t)o->zsize; P.hk = 1; P.hz = (uint32_t)o->hz; P.ksave = 4; P.kovl = 300; P.ncand = 500; P.nbest = 100;
-	P.kwin = (uint32_t)o->kwin; P.kstep = (uint32_t)o->kstep; P.ztot = (uint32_t)o->zovl; P.zovl = (uint32_t)o->zovl;
-	P.max_kmer_freq = 0; P.max_zmer_freq = (uint32_t)o->zcut; P.max_kmer_var = (uint32_t)o->kvar;
-	P.win_rep_norm = 20; P.win_rep_cutoff = 100;
-	P.w = o->w; P.ew = o->ew; P.W = o->W; P.M = o->M; P.X = o->X; P.O = o->O; P.E = o->E; P.T = o->T;
-	P.min_score = o->min_score; P.min_id = o->min_id;
-	P.dot_matrix = 0; P.xvar = 128; P.yvar = 64; P.min_block_len = 160; P.max_overhang = 256; P.deviation_penalty = 1.0f; P.gap_penalty = 0.05f;
-	P.refine = o->refine; P.aux_strand = 1;      /* -n: the device applies the gates of hzm_aln.h:1715-1718 before it refines (wtz_task_refine) */
 	gbo_dev_t D; memset(&D, 0, sizeof D);
 	D.n_rd = n;
-	int rc = wtz_ctx_create(o->gpu, &P, o->pool_gb << 30, &D.ctx); DIE_WTZ(rc, "wtz_ctx_create");
+	if(cj_started) pthread_join(cj.th, NULL); else gbo_ctxjob_main(&cj);
+	if(cj.rc != WTZ_OK){ fprintf(stderr, " -- wtz_ctx_create failed: %s --\n", cj.err); fflush(NULL); _exit(1); }
+	D.ctx = cj.ctx;
+	int rc;
 	rc = wtz_upload_reads(D.ctx, G->st.bits, (G->st.nbase + 31) >> 5, rdoff, rdlen2, n * 2); DIE_WTZ(rc, "wtz_upload_reads");
 	D.zindex_all = o->zindex_batch < 0 ? (2 * tot <= 2400000000ull) : !o->zindex_batch;      /* 16 B per indexed base: all reads while that stays under ~40 GB */
 	if(D.zindex_all){ rc = wtz_zindex_build(D.ctx); DIE_WTZ(rc, "wtz_zindex_build"); }

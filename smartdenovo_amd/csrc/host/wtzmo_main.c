@@ -72,6 +72,7 @@ typedef struct eng_s {
 	uint32_t *rdlen; uint32_t avg_rdlen;
 	uint64_t *closed_order; size_t n_order, cap_order; int keep_order;      /* -9: the pairs in the order they entered closed_alns (the file is a replay of it) */
 	wtz_ctx_t *ctx; FILE *out;
+	double ing_ms; uint64_t ing_bytes;      /* f4: kernel time / algorithmic bytes of the device ingest at load time (wtz_upload_reads_ascii) */
 	int zbatch;                 /* --zindex-batch (automatic above ~2.4 Gbp of reads): the z-mer index is rebuilt per batch of queries for the batch's queries + candidates instead
 	                             * of once for all reads (16 B per base: 160 GB at BASELINE configs[3]) */
 	int shard;                  /* --shard-index: the k-mer index is sharded by read-id range over the devices (reads and z-index stay replicated); output == unsharded */
@@ -1028,6 +1029,17 @@ static void process_batch(eng_t *E, batch_t *b){
 }
 
 /* both index builds of one more device (replicated indexes, --gpus) */
+/* the device contexts - above all the hipMalloc of their scratch pools: ~35 ms per GB, 4.4 s for the default 128 GB - are created on a helper
+ * thread while the main thread reads the FASTA (measured on wtgbo, E. coli shape: 5.4 s wall with the 128 GB pool created up front, 1.0 s with 16 GB) */
+typedef struct { const wtz_params_c *P; uint64_t pool_bytes; int devs[8]; uint32_t ndev; wtz_ctx_t *ctxs[8]; int rc; char err[256]; pthread_t th; int started; } ctxjob_t;
+static void *ctxjob_main(void *arg){
+	ctxjob_t *j = (ctxjob_t*)arg;
+	for(uint32_t d = 0; d < j->ndev; d++){
+		j->rc = wtz_ctx_create(j->devs[d], j->P, j->pool_bytes, &j->ctxs[d]);
+		if(j->rc != WTZ_OK){ snprintf(j->err, sizeof j->err, "%s", wtz_last_error()); break; }      /* wtz_last_error is thread-local: keep the text */
+	}
+	return NULL;
+}
 typedef struct { wtz_ctx_t *ctx; uint32_t n_rd, K; int rc; char err[256]; int zonly, nozidx; } ixjob_t;
 static void *ixjob_main(void *arg){
 	ixjob_t *j = (ixjob_t*)arg; wtz_index_stats_t ist;
@@ -1260,10 +1272,22 @@ int main(int argc, char **argv){
 	if(E->n_job < 1) E->n_job = 1;
 	P->max_overhang = 2 * P->xvar; P->kstep = P->kwin / 2; P->dot_matrix = dot_matrix;
 
+	/* devices: --gpu <id> (one), --gpus N (ids 0..N-1) or --gpu-list; every device gets the reads and builds both indexes (replicated) */
+	E->ndev = 0;
+	if(gpu_list){ const char *q = gpu_list; while(*q && E->ndev < 8){ E->devs[E->ndev++] = atoi(q); while(*q && *q != ',') q++; if(*q == ',') q++; } }
+	else if(n_gpus > 1){ for(int d = 0; d < n_gpus; d++) E->devs[E->ndev++] = d; }
+	if(E->ndev == 0){ E->devs[0] = gpu; E->ndev = 1; }
+	if(E->ndev > 1 && (E->n_idx > 1 || E->n_workers > 1)){
+		fprintf(stderr, "[wtzmo-mi355x] -G / --workers run on one device: --gpus ignored\n"); E->ndev = 1;
+	}
+	static ctxjob_t cj; memset(&cj, 0, sizeof cj);
+	cj.P = P; cj.pool_bytes = pool_mb ? pool_mb << 20 : pool_gb << 30; cj.ndev = E->ndev; for(uint32_t d = 0; d < E->ndev; d++) cj.devs[d] = E->devs[d];
+	cj.started = (pthread_create(&cj.th, NULL, ctxjob_main, &cj) == 0);      /* from here to the join every error path leaves through DIE_NOW (_exit): exit() would tear HIP down under that thread */
+
 	/* ---- load reads (wtzmo.c:1691-1729) ---- */
 	hx_str_t name = {0}, seq = {0};
 	hx_reader_t *fr = hx_reader_open(pbs.a, pbs.n);
-	if(fr == NULL){ fprintf(stderr, " -- Cannot open %s --\n", pbs.a[0]); exit(1); }
+	if(fr == NULL){ fprintf(stderr, " -- Cannot open %s --\n", pbs.a[0]); DIE_NOW(); }
 	fprintf(stderr, "[wtzmo-mi355x] loading long reads\n");
 	while(hx_reader_seq(fr, &name, &seq)){
 		if((int)seq.n < min_rdlen) continue;
@@ -1273,7 +1297,7 @@ int main(int argc, char **argv){
 	hx_reader_close(fr);
 	hx_sort_exact(E->st.reads, E->st.n_rd, sizeof(hx_read_t), gt_read, NULL);
 	if(tbas.n){
-		if((fr = hx_reader_open(tbas.a, tbas.n)) == NULL) exit(1);
+		if((fr = hx_reader_open(tbas.a, tbas.n)) == NULL) DIE_NOW();
 		while(hx_reader_seq(fr, &name, &seq)){
 			if((int)seq.n < min_rdlen) continue;
 			hx_store_add(&E->st, name.s ? name.s : "", name.n, seq.s ? seq.s : "", seq.n);
@@ -1288,7 +1312,7 @@ int main(int argc, char **argv){
 	hx_names_t nm; hx_names_build(&nm, E->st.reads, n_rd);
 	char *cols[4];
 	if(obts.n){
-		if((fr = hx_reader_open(obts.a, obts.n)) == NULL) exit(1);
+		if((fr = hx_reader_open(obts.a, obts.n)) == NULL) DIE_NOW();
 		while(hx_reader_line(fr) != -1){
 			if(fr->line[0] == '#') continue;
 			int nc = 0; char *p = fr->line;
@@ -1303,7 +1327,7 @@ int main(int argc, char **argv){
 		hx_reader_close(fr);
 	}
 	if(flts.n){
-		if((fr = hx_reader_open(flts.a, flts.n)) == NULL) exit(1);
+		if((fr = hx_reader_open(flts.a, flts.n)) == NULL) DIE_NOW();
 		while(hx_reader_line(fr) != -1){
 			if(fr->line[0] == '#') continue;
 			uint32_t id = hx_names_get(&nm, fr->line);
@@ -1312,7 +1336,7 @@ int main(int argc, char **argv){
 		hx_reader_close(fr);
 	}
 	if(ovls.n){
-		if((fr = hx_reader_open(ovls.a, ovls.n)) == NULL) exit(1);
+		if((fr = hx_reader_open(ovls.a, ovls.n)) == NULL) DIE_NOW();
 		while(hx_reader_line(fr) != -1){
 			if(fr->line[0] == '#') continue;
 			int nc = 0; char *p = fr->line;
@@ -1333,25 +1357,19 @@ int main(int argc, char **argv){
 	  for(uint32_t i = 0; i < n_all; i++){ E->rdlen[i] = E->st.reads[i].len; rdoff[i] = E->st.reads[i].off; }
 	  for(uint32_t i = 0; i < nq; i++) tot += E->rdlen[b0 + i];
 	  E->avg_rdlen = nq ? (uint32_t)(tot / nq) : 10000; if(E->avg_rdlen == 0) E->avg_rdlen = 1; }        /* wtzmo.c:361-368 */
-	/* devices: --gpu <id> (one), --gpus N (ids 0..N-1) or --gpu-list; every device gets the reads and builds both indexes (replicated) */
-	E->ndev = 0;
-	if(gpu_list){ const char *q = gpu_list; while(*q && E->ndev < 8){ E->devs[E->ndev++] = atoi(q); while(*q && *q != ',') q++; if(*q == ',') q++; } }
-	else if(n_gpus > 1){ for(int d = 0; d < n_gpus; d++) E->devs[E->ndev++] = d; }
-	if(E->ndev == 0){ E->devs[0] = gpu; E->ndev = 1; }
 	if(g_dist.world > 1){
-		if(g_dist.world > WTZ_DIST_MAX || !g_dist.bcast || !g_dist.send || !g_dist.recv){ fprintf(stderr, " -- wtzmo_set_dist: bad rank setup --\n"); exit(1); }
-		if(E->n_idx > 1 || E->n_workers > 1 || E->ndev > 1 || E->n_job > 1){ fprintf(stderr, " -- ranks (one process per GPU) exclude -G, -P, --workers and --gpus --\n"); exit(1); }
+		if(g_dist.world > WTZ_DIST_MAX || !g_dist.bcast || !g_dist.send || !g_dist.recv){ fprintf(stderr, " -- wtzmo_set_dist: bad rank setup --\n"); DIE_NOW(); }
+		if(E->n_idx > 1 || E->n_workers > 1 || E->ndev > 1 || E->n_job > 1){ fprintf(stderr, " -- ranks (one process per GPU) exclude -G, -P, --workers and --gpus --\n"); DIE_NOW(); }
 	}
 	if(E->zbatch == 0 && E->st.nbase > 2400000000ull && g_dist.world == 1 && E->n_workers == 1){ E->zbatch = 1; fprintf(stderr, "[wtzmo-mi355x] %llu read bases: the z-mer index is built per batch of queries (--zindex-batch 0 to force the all-reads index)\n", (unsigned long long)E->st.nbase); }
-	if(E->zbatch > 0 && (g_dist.world > 1 || E->n_workers > 1)){ fprintf(stderr, " -- --zindex-batch excludes ranks and --workers --\n"); exit(1); }
+	if(E->zbatch > 0 && (g_dist.world > 1 || E->n_workers > 1)){ fprintf(stderr, " -- --zindex-batch excludes ranks and --workers --\n"); DIE_NOW(); }
 	if(E->zbatch > 0 && E->max_batch > 512) E->max_batch = 512;
-	if(E->shard && (E->n_idx > 1 || E->n_workers > 1)){ fprintf(stderr, " -- --shard-index excludes -G and --workers --\n"); exit(1); }
-	if(E->ndev > 1 && (E->n_idx > 1 || E->n_workers > 1)){
-		fprintf(stderr, "[wtzmo-mi355x] -G / --workers run on one device: --gpus ignored\n"); E->ndev = 1;
-	}
+	if(E->shard && (E->n_idx > 1 || E->n_workers > 1)){ fprintf(stderr, " -- --shard-index excludes -G and --workers --\n"); DIE_NOW(); }
 	int rc;
+	if(cj.started) pthread_join(cj.th, NULL); else ctxjob_main(&cj);
+	if(cj.rc != WTZ_OK){ fprintf(stderr, " -- wtz_ctx_create failed: %s --\n", cj.err); DIE_NOW(); }
 	for(uint32_t d = 0; d < E->ndev; d++){
-		rc = wtz_ctx_create(E->devs[d], P, pool_bytes, &E->ctxs[d]); DIE_WTZ(rc, "wtz_ctx_create");
+		E->ctxs[d] = cj.ctxs[d];
 		if(E->st.keep_text && E->st.bits == NULL){
 			/* f4: seq2basebank on the device (dna.h:397-410); the packed bank comes back once for the other contexts of this process */
 			const double ti0 = now_s(); uint64_t n_other = 0;
@@ -1360,6 +1378,7 @@ int main(int argc, char **argv){
 			E->st.bits = (uint64_t*)hx_realloc(NULL, 8 * (nw + 2)); E->st.capw = nw + 2; E->st.bits[nw] = E->st.bits[nw + 1] = 0;
 			rc = wtz_fetch_read_bits(E->ctxs[d], E->st.bits, nw); DIE_WTZ(rc, "wtz_fetch_read_bits");
 			free(E->st.text); E->st.text = NULL; E->st.captext = 0;
+			{ wtz_counters_t ic; if(wtz_get_counters(E->ctxs[d], &ic) == WTZ_OK){ E->ing_ms = ic.ms_ingest; E->ing_bytes = ic.bytes_ingest_algo; } }
 			{ wtz_counters_t ic; if(wtz_get_counters(E->ctxs[d], &ic) == WTZ_OK) fprintf(stderr, "[wtzmo-mi355x] %llu bases packed on the device (%llu not ACGT): kernels %.2f ms = %.0f GB/s, with the copies %.0f ms\n",
 				(unsigned long long)E->st.nbase, (unsigned long long)n_other, ic.ms_ingest, ic.ms_ingest > 0 ? (double)ic.bytes_ingest_algo / ic.ms_ingest / 1e6 : 0.0, 1e3 * (now_s() - ti0)); }
 			continue;
@@ -1544,9 +1563,9 @@ int main(int argc, char **argv){
 			(unsigned long long)E->n_batches, (unsigned long long)E->n_ranges, E->rows_all ? 1u : E->n_workers, (unsigned long long)E->used_queries, (unsigned long long)E->spec_queries, (unsigned long long)E->used_pairs, (unsigned long long)E->spec_pairs, (unsigned long long)E->used_items, (unsigned long long)E->spec_items);
 		fprintf(stderr, "[wtzmo-mi355x] kernel ms: index %.1f zindex %.1f candidates %.1f pairs %.1f winalign %.1f stitch %.1f (K-sw3 wave %.1f, K-sw2 gaps %.1f); cells shift %llu fixed %llu global %llu; pool peak %.2f GB\n",
 			cn.ms_index, cn.ms_zindex, cn.ms_candidates, cn.ms_pairs, cn.ms_winalign, cn.ms_stitch, cn.ms_ext, cn.ms_gap, (unsigned long long)cn.cells_shift, (unsigned long long)cn.cells_fixed, (unsigned long long)cn.cells_global, cn.pool_peak / 1073741824.0);
-		if(statsf){ FILE *sf = fopen(statsf, "a"); if(sf){ fprintf(sf, "%llu\t%llu\t%.6f\t%.6f\t%.3f\t%.3f\t%.3f\t%.3f\t%.3f\t%.3f\t%llu\t%llu\t%llu\t%llu\t%llu\t%.3f\t%llu\t%llu\t%llu\t%.3f\t%llu\t%llu\t%llu\n", (unsigned long long)E->n_pairs, (unsigned long long)E->pair_bp, t1 - t0, t_index,
+		if(statsf){ FILE *sf = fopen(statsf, "a"); if(sf){ fprintf(sf, "%llu\t%llu\t%.6f\t%.6f\t%.3f\t%.3f\t%.3f\t%.3f\t%.3f\t%.3f\t%llu\t%llu\t%llu\t%llu\t%llu\t%.3f\t%llu\t%llu\t%llu\t%.3f\t%llu\t%llu\t%llu\t%.4f\t%llu\n", (unsigned long long)E->n_pairs, (unsigned long long)E->pair_bp, t1 - t0, t_index,
 				cn.ms_index, cn.ms_zindex, cn.ms_candidates, cn.ms_pairs, cn.ms_winalign, cn.ms_stitch, (unsigned long long)cn.cells_shift, (unsigned long long)cn.cells_fixed, (unsigned long long)cn.cells_global, (unsigned long long)cn.bytes_seed_algo, (unsigned long long)E->nrec,
-				cn.ms_ext, (unsigned long long)cn.n_extjobs, (unsigned long long)E->used_queries, (unsigned long long)cn.pool_peak, cn.ms_gap, (unsigned long long)E->n_ranges, (unsigned long long)E->n_split, (unsigned long long)cn.bytes_zmer_algo); fclose(sf); } }
+				cn.ms_ext, (unsigned long long)cn.n_extjobs, (unsigned long long)E->used_queries, (unsigned long long)cn.pool_peak, cn.ms_gap, (unsigned long long)E->n_ranges, (unsigned long long)E->n_split, (unsigned long long)cn.bytes_zmer_algo, E->ing_ms, (unsigned long long)E->ing_bytes); fclose(sf); } }
 	}
 	stale_join(&stale_job); if(stale_job.pending) unlink(stale_job.path);
 	free(stale_job.path);

@@ -47,32 +47,45 @@ WTZ_HD uint32_t wtz_base_code(uint32_t ch){
 	return ok ? (t ^ (t >> 1)) : 4u;
 }
 
-/* word `w` of the bank from ascii[w*32 .. w*32+32) (clipped at n); positions of non-bases are appended to pos[] (any order) */
-WTZ_HD uint64_t wtz_pack_word(const uint8_t *ascii, uint64_t n, uint64_t w, unsigned long long *n_pos, uint64_t *pos, uint64_t pos_cap, uint64_t pos_base){
-	const uint64_t b0 = w * 32;
-	uint64_t word = 0;
-	if(b0 + 32 <= n){
-		/* 32 bytes as four 8-byte loads: the slice of a device chunk starts 32-byte aligned */
-		const uint64_t *p8 = (const uint64_t*)(const void*)(ascii + b0);
-		#pragma unroll
-		for(int q = 0; q < 4; q++){
-			const uint64_t v = p8[q];
-			#pragma unroll
-			for(int k = 0; k < 8; k++){
-				const uint32_t code = wtz_base_code((uint32_t)(v >> (8 * k)) & 0xFFu);
-				const int i = q * 8 + k;
-				if(code < 4u) word |= (uint64_t)code << ((31 - i) * 2);
-				else { const unsigned long long at = WTZ_ING_NEXT(n_pos); if(at < pos_cap) pos[at] = pos_base + b0 + (uint64_t)i; }
-			}
-		}
-	} else {
-		for(uint64_t i = b0; i < n; i++){
-			const uint32_t code = wtz_base_code(ascii[i]);
-			if(code < 4u) word |= (uint64_t)code << ((31 - (int)(i - b0)) * 2);
-			else { const unsigned long long at = WTZ_ING_NEXT(n_pos); if(at < pos_cap) pos[at] = pos_base + i; }
-		}
+/* four bytes at once: 0x80 in every byte of `v` that is one of ACGTacgt (exact zero-byte test, no borrow between bytes) */
+WTZ_HD uint32_t wtz_base_mask4(uint32_t lo){
+#define WTZ_EQ4(c) ({ const uint32_t x_ = lo ^ ((c) * 0x01010101u); ~(((x_ & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x_ | 0x7F7F7F7Fu); })
+	return WTZ_EQ4(0x61u) | WTZ_EQ4(0x63u) | WTZ_EQ4(0x67u) | WTZ_EQ4(0x74u);
+#undef WTZ_EQ4
+}
+/* the four 2-bit codes of four base bytes as one byte, first base in the top bits */
+WTZ_HD uint32_t wtz_base_pack4(uint32_t lo){
+	const uint32_t t = (lo >> 1) & 0x03030303u;                 /* a 0, c 1, g 3, t 2 per byte */
+	const uint32_t code = t ^ ((t >> 1) & 0x01010101u);         /* a 0, c 1, g 2, t 3 */
+	return (code * 0x40100401u) >> 24;                          /* c0 << 6 | c1 << 4 | c2 << 2 | c3: the partial products do not overlap */
+}
+
+/* HALF word `h` of the bank (16 bases: ascii[h*16 .. h*16+16), clipped at n) as it sits in the 64-bit word h >> 1: the even half holds the
+ * word's first 16 bases = its UPPER 32 bits.  Positions of non-bases are appended to pos[] (any order; one reservation per call). */
+WTZ_HD uint32_t wtz_pack_half(const uint8_t *ascii, uint64_t n, uint64_t h, unsigned long long *n_pos, uint64_t *pos, uint64_t pos_cap, uint64_t pos_base){
+	const uint64_t b0 = h * 16;
+	if(b0 + 16 <= n){
+		const uint32_t *p4 = (const uint32_t*)(const void*)(ascii + b0);      /* device chunks start 16-byte aligned */
+		const uint32_t v0 = p4[0] | 0x20202020u, v1 = p4[1] | 0x20202020u, v2 = p4[2] | 0x20202020u, v3 = p4[3] | 0x20202020u;
+		if((wtz_base_mask4(v0) & wtz_base_mask4(v1) & wtz_base_mask4(v2) & wtz_base_mask4(v3)) == 0x80808080u)
+			return (wtz_base_pack4(v0) << 24) | (wtz_base_pack4(v1) << 16) | (wtz_base_pack4(v2) << 8) | wtz_base_pack4(v3);
 	}
-	return word;
+	/* a non-base byte or the tail of the input: byte by byte */
+	uint32_t half = 0, bad = 0;
+	const uint64_t e = b0 + 16 <= n ? b0 + 16 : n;
+	for(uint64_t i = b0; i < e; i++){
+		const uint32_t code = wtz_base_code(ascii[i]);
+		if(code < 4u) half |= code << ((15 - (int)(i - b0)) * 2); else bad++;
+	}
+	if(bad){
+#if defined(__HIP_DEVICE_COMPILE__)
+		unsigned long long at = atomicAdd(n_pos, (unsigned long long)bad);
+#else
+		unsigned long long at = *n_pos; *n_pos += bad;
+#endif
+		for(uint64_t i = b0; i < e; i++) if(wtz_base_code(ascii[i]) >= 4u){ if(at < pos_cap) pos[at] = pos_base + i; at++; }
+	}
+	return half;
 }
 
 /* the r-th listed position (ascending) is non-base number rank0 + r + 1 of the input: its two bits come from X(rank0 + r + 1) */

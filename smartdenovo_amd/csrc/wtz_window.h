@@ -435,6 +435,50 @@ WTZ_HD uint32_t wtz_scan_windows_coop(const wtz_zhit_t *rs, uint32_t dir, uint32
 		}
 		if(pass) break;
 		if(n * zsize < zovl) return 0;
+#ifndef WTZ_NO_SCAN_PRECHECK
+		/* ---- exact early exit (round 3): can the sweep of hzm_aln.h:451-483 reach `ol >= zovl` at all?  In off2 order the running overlap is
+		 * ol = sum of len2 over the in-window matches j..i minus the overlaps of neighbours (a match adds len2 minus its overlap with the one
+		 * before, an eviction takes len2 minus the overlap with the one behind; ends are monotone in off2 for the matches of one strand), so
+		 * ol <= sum of len2 over j..i, and the while loop keeps off2[i] - off2[j] < kwin: the in-window matches lie in nadj adjacent bins of
+		 * kwin / 8 columns (1.125 kwin in all).  If no such run of bins holds zovl bases of matches, no window can open, n2 stays 0 and the scan returns 0 - without
+		 * the off2 ordering, the gather and the lane-0 sweep.  Tie order cannot matter: the bound is over sets. ---- */
+		if(K != NULL){
+			uint32_t mn = 0xFFFFFFFFu, mx = 0;
+			for(uint32_t b0 = beg; b0 < end; b0 += WTZ_NLANES){
+				const uint32_t idx = b0 + lane;
+				if(idx < end){ const uint32_t o1 = rs[idx].o1, o2 = rs[idx].o2; if((((o1 ^ o2) >> 31) == dir) && ((int32_t)(o1 & 0x7FFFFFFFu) >= bound)){ const uint32_t f = o2 & 0x7FFFFFFFu; mn = f < mn ? f : mn; mx = f > mx ? f : mx; } }
+			}
+			mn = wtz_coop_min32(mn); mx = ~wtz_coop_min32(~mx);
+			const uint32_t bw = kwin >= 8 ? kwin / 8 : 1;          /* bins of an eighth of the window: the in-window matches span < kwin columns = at most nadj adjacent bins */
+			const uint32_t nadj = (kwin - 1) / bw + 1;
+			const uint32_t nb = (mx - mn) / bw + 1 + nadj;         /* nadj empty bins behind the last: every run of nadj bins starting at a used bin is inside the array */
+			if(nb <= sc.lds_u64 * 2){
+				uint32_t *B = (uint32_t*)K;
+				for(uint32_t b = lane; b < nb; b += WTZ_NLANES) B[b] = 0;
+				WTZ_WAVE_SYNC();
+				for(uint32_t b0 = beg; b0 < end; b0 += WTZ_NLANES){
+					const uint32_t idx = b0 + lane;
+					if(idx < end){
+						const uint32_t o1 = rs[idx].o1, o2 = rs[idx].o2;
+						if((((o1 ^ o2) >> 31) == dir) && ((int32_t)(o1 & 0x7FFFFFFFu) >= bound)){
+							const uint32_t bin = ((o2 & 0x7FFFFFFFu) - mn) / bw, l2 = rs[idx].ll >> 16;
+#if defined(__HIP_DEVICE_COMPILE__)
+							atomicAdd(&B[bin], l2);
+#else
+							B[bin] += l2;
+#endif
+						}
+					}
+				}
+				WTZ_WAVE_SYNC();
+				uint32_t best = 0;
+				for(uint32_t b = lane; b + nadj <= nb; b += WTZ_NLANES){ uint32_t v = 0; for(uint32_t t = 0; t < nadj; t++) v += B[b + t]; best = v > best ? v : best; }
+				best = ~wtz_coop_min32(~best);
+				WTZ_WAVE_SYNC();                                  /* K is written again by the second pass */
+				if(best < zovl){ WTZ_PROF_CNT(23, 0); return 0; }
+			}
+		}
+#endif
 		uint32_t np0 = 64; while(np0 < n) np0 <<= 1;
 		if(K == NULL || np0 + 2 * n + 2 > sc.lds_u64){       /* does not fit: scalar body on lane 0 */
 			uint32_t r = 0; int32_t e = -0x7FFFFFFF;
@@ -518,7 +562,11 @@ WTZ_HD uint32_t wtz_scan_windows_coop(const wtz_zhit_t *rs, uint32_t dir, uint32
 				} else { sc.wb[n2] = j; sc.we[n2] = i; lwo = ol; lwb_o2 = jo2; lwe_o2 = ZH_OFF2(p); n2++; }
 			}
 		}
+#ifdef WTZ_EXP_CNT_EMPTY
+		WTZ_PROF_ADD(19, pw3); pw4 = WTZ_PROF_T(); WTZ_PROF_CNT(23, n2 == 0 ? 1 : 0);      /* diagnostic build: scans whose sweep finds no window */
+#else
 		WTZ_PROF_ADD(19, pw3); pw4 = WTZ_PROF_T(); WTZ_PROF_CNT(23, n2);
+#endif
 		int32_t last_end1 = 0; uint32_t last_ovl = 0;
 		for(uint32_t wi = 0; wi < n2; wi++){
 			const uint32_t size = anchors.n, wb = sc.wb[wi], we = sc.we[wi];
