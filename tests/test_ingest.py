@@ -77,3 +77,23 @@ def test_first_draws_are_those_of_a_fresh_glibc_process(emul_lib):
     """0, 2116118, 89401895, 379337186: `lrand48() & 3` of a never-seeded process = 0, 2, 3, 2 - independent of the shim"""
     got, cnt, _ = device_bits(emul_lib, b"NNNNACGT")
     assert cnt == 4 and int(got[0]) >> 48 == int("00" "10" "11" "10" "00" "01" "10" "11", 2)
+
+
+# ---- the host driver: both ingest paths write the reference's file (edge.fq holds runs of N / n: the draws matter) ----
+@pytest.mark.parametrize("mode", ["device", "host"])
+def test_wtzmo_ingest_modes_on_emulated_device(mode, tmp_path):
+    from conftest import manifest, run_wtzmo_like
+    subprocess.run([os.path.join(ROOT, "tests", "emul", "build_emul.sh")], check=True)
+    case = manifest()["cases"]["zmo_edge_fq"]
+    md5, cont, _ = run_wtzmo_like(os.path.join(ROOT, "tests", "emul", "wtzmo_emul"), case, tmp_path, extra=["--ingest", mode, "--batch", "16"])
+    assert md5 == case["md5_full"] and cont == case["md5_contained"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["device", "host"])
+@pytest.mark.parametrize("name", ["zmo_edge_fq", "dmo_edge_fa"])
+def test_gpu_wtzmo_ingest_modes(mode, name, gpu_exe, tmp_path):
+    from conftest import manifest, run_wtzmo_like
+    case = manifest()["cases"][name]
+    md5, cont, _ = run_wtzmo_like(gpu_exe, case, tmp_path, extra=["--ingest", mode])
+    assert md5 == case["md5_full"] and cont == case["md5_contained"]
