@@ -65,8 +65,13 @@ WTZ_HD uint32_t wtz_base_pack4(uint32_t lo){
 WTZ_HD uint32_t wtz_pack_half(const uint8_t *ascii, uint64_t n, uint64_t h, unsigned long long *n_pos, uint64_t *pos, uint64_t pos_cap, uint64_t pos_base){
 	const uint64_t b0 = h * 16;
 	if(b0 + 16 <= n){
-		const uint32_t *p4 = (const uint32_t*)(const void*)(ascii + b0);      /* device chunks start 16-byte aligned */
+#if defined(__HIP_DEVICE_COMPILE__)
+		const uint4 q = *(const uint4*)(const void*)(ascii + b0);             /* one 16-byte load: device chunks start 256-byte aligned, b0 is a multiple of 16 */
+		const uint32_t v0 = q.x | 0x20202020u, v1 = q.y | 0x20202020u, v2 = q.z | 0x20202020u, v3 = q.w | 0x20202020u;
+#else
+		uint32_t p4[4]; memcpy(p4, ascii + b0, 16);
 		const uint32_t v0 = p4[0] | 0x20202020u, v1 = p4[1] | 0x20202020u, v2 = p4[2] | 0x20202020u, v3 = p4[3] | 0x20202020u;
+#endif
 		if((wtz_base_mask4(v0) & wtz_base_mask4(v1) & wtz_base_mask4(v2) & wtz_base_mask4(v3)) == 0x80808080u)
 			return (wtz_base_pack4(v0) << 24) | (wtz_base_pack4(v1) << 16) | (wtz_base_pack4(v2) << 8) | wtz_base_pack4(v3);
 	}
