@@ -122,6 +122,10 @@ int  wtz_upload_reads(wtz_ctx_t *ctx, const uint64_t *bits, uint64_t n_words, co
  * glibc process that never called srand48 (X0 = 0); rand_calls_before = lrand48 calls the emulated process made before this input (0 for wtzmo / wtgbo), *n_random (may be NULL) = such
  * bytes found.  The resulting device bank is bit-identical to wtz_upload_reads of the host-packed bank. */
 int  wtz_upload_reads_ascii(wtz_ctx_t *ctx, const char *seq, uint64_t n_bases, const uint64_t *rdoff, const uint32_t *rdlen, uint32_t n_reads, uint64_t rand_calls_before, uint64_t *n_random);
+/* wtgbo's view of the reads (wtgbo.c:48-49 reverse-complements a '-' candidate BEFORE its z-mers are taken; revbitseq_basebank, dna.h): appends to the n uploaded
+ * reads their reverse complements as reads n .. 2n-1 (read n + i = reverse complement of read i over its current [rdoff, rdoff + rdlen) range), packed on the device.
+ * Indexes built before the call are dropped. */
+int  wtz_append_revcomp_views(wtz_ctx_t *ctx);
 /* the packed bank back from the device (n_words = (n_bases + 31) / 32): what a host-side consumer of the 2-bit reads (wtgbo's reverse-complement views, tests) reads */
 int  wtz_fetch_read_bits(wtz_ctx_t *ctx, uint64_t *bits, uint64_t n_words);
 

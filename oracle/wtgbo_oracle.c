@@ -45,6 +45,7 @@ int main(int argc, char **argv){
 	gbo_t *G = (gbo_t*)calloc(1, sizeof(gbo_t));
 	if(gbo_parse_args(&G->O, argc, argv)) return gbo_usage();
 	gbo_opt_t *o = &G->O;
+	G->st.keep_text = 0;        /* the CPU checker packs while reading (its lrand48 draws are the C library's own) */
 	gbo_load_inputs(G);
 	static gbo_cpu_t D;
 	D.indexed = 0xFFFFFFFFu;

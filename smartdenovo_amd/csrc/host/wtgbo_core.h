@@ -41,7 +41,7 @@ typedef struct {
 	strlist_t pbs, ovls, obss, obts;
 	char *output, *pairoutf;
 	/* ours */
-	int gpu; uint64_t pool_gb; uint32_t batch; int zindex_batch;
+	int gpu; uint64_t pool_gb; uint32_t batch; int zindex_batch; int ingest_host;
 } gbo_opt_t;
 
 typedef struct {
@@ -106,7 +106,7 @@ static int gbo_usage(void){      /* wtgbo.c:267-309: to stdout, return 1 */
 	" -W <int>    Maximum bandwidth, [3200]\n"
 	" -n          Refine the alignment\n"
 	" -N <int>    Max turns of iteration, [5]\n"
-	" --gpu <int> --pool-gb <int> --batch <int> --zindex-batch <0|1>   device selection / scratch pool / pairs per device batch / z-mer index per batch\n"
+	" --gpu <int> --pool-gb <int> --batch <int> --zindex-batch <0|1> --ingest <device|host>   device selection / scratch pool / pairs per device batch / z-mer index per batch / where the reads are packed\n"
 	"\n");
 	return 1;
 }
@@ -117,7 +117,7 @@ static int gbo_parse_args(gbo_opt_t *o, int argc, char **argv){
 	o->max_ext = 0; o->max_iter = 5; o->ncpu = 1; o->w = 50; o->ew = 800; o->W = 3200; o->M = 2; o->X = -5; o->O = -3; o->E = -1; o->T = -50;
 	o->hz = 1; o->zsize = 10; o->kwin = 800; o->kstep = 0; o->zovl = 200; o->zcut = 100; o->kvar = 2; o->refine = 0;      /* wtgbo.c:385-411 */
 	o->gpu = 0; o->pool_gb = 0; o->batch = 16384; o->zindex_batch = -1;
-	static const struct option lopts[] = { {"gpu", 1, 0, 1001}, {"pool-gb", 1, 0, 1002}, {"batch", 1, 0, 1003}, {"zindex-batch", 1, 0, 1004}, {0, 0, 0, 0} };
+	static const struct option lopts[] = { {"gpu", 1, 0, 1001}, {"pool-gb", 1, 0, 1002}, {"batch", 1, 0, 1003}, {"zindex-batch", 1, 0, 1004}, {"ingest", 1, 0, 1005}, {0, 0, 0, 0} };
 	int c; optind = 1;
 	while((c = getopt_long(argc, argv, "hi:b:j:L:s:m:u:o:9:fQq:c:t:Hz:Z:y:l:r:R:w:e:W:M:X:O:E:T:nN:", lopts, NULL)) != -1){
 		switch(c){
@@ -157,6 +157,7 @@ static int gbo_parse_args(gbo_opt_t *o, int argc, char **argv){
 			case 1002: o->pool_gb = (uint64_t)atoll(optarg); break;
 			case 1003: o->batch = (uint32_t)atoi(optarg); if(o->batch < 1) o->batch = 1; break;
 			case 1004: o->zindex_batch = atoi(optarg); break;
+			case 1005: o->ingest_host = (strcmp(optarg, "host") == 0); break;      /* `device` (default): bases packed to 2 bits on the GPU; `host`: while reading */
 			default: return 1;
 		}
 	}

@@ -118,25 +118,24 @@ int main(int argc, char **argv){
 	P.refine = o->refine; P.aux_strand = 1;      /* -n: the device applies the gates of hzm_aln.h:1715-1718 before it refines (wtz_task_refine) */
 	static gbo_ctxjob_t cj; cj.P = &P; cj.device = o->gpu; cj.pool_bytes = (o->pool_gb ? o->pool_gb : 16) << 30; cj.ctx = NULL; cj.rc = WTZ_OK;
 	const int cj_started = (pthread_create(&cj.th, NULL, gbo_ctxjob_main, &cj) == 0);
+	G->st.keep_text = (o->ingest_host == 0);
 	gbo_load_inputs(G);            /* its error paths leave through exit(): join first if that ever matters - they fire within milliseconds of the start */
-	/* ---- device: every read and its reverse complement ---- */
+	/* ---- device: every read and its reverse complement.  The bases travel as text and are packed on the device (wtz_upload_reads_ascii),
+	 * the reverse-complement views are made there too (wtz_append_revcomp_views): the host never touches a base ---- */
 	const uint32_t n = G->n_rd;
-	uint64_t *rdoff = (uint64_t*)hx_realloc(NULL, 8 * ((size_t)n * 2 + 1));
-	uint32_t *rdlen2 = (uint32_t*)hx_realloc(NULL, 4 * ((size_t)n * 2 + 1));
-	for(uint32_t i = 0; i < n; i++){ rdoff[i] = G->st.reads[i].off; rdlen2[i] = G->st.reads[i].len; }
+	uint64_t *rdoff = (uint64_t*)hx_realloc(NULL, 8 * ((size_t)n + 1));
 	uint64_t tot = 0;
-	for(uint32_t i = 0; i < n; i++){
-		const uint64_t off = G->st.reads[i].off; const uint32_t len = G->st.reads[i].len;
-		rdoff[n + i] = G->st.nbase; rdlen2[n + i] = len; tot += len;
-		for(uint32_t p = len; p > 0; p--){ const uint64_t x = off + p - 1; const unsigned b = (unsigned)(G->st.bits[x >> 5] >> (((~x) & 31u) << 1)) & 3u; hx_store_put(&G->st, 3u - b); }   /* revbitseq_basebank, dna.h */
-	}
+	for(uint32_t i = 0; i < n; i++){ rdoff[i] = G->st.reads[i].off; tot += G->st.reads[i].len; }
 	gbo_dev_t D; memset(&D, 0, sizeof D);
 	D.n_rd = n;
 	if(cj_started) pthread_join(cj.th, NULL); else gbo_ctxjob_main(&cj);
 	if(cj.rc != WTZ_OK){ fprintf(stderr, " -- wtz_ctx_create failed: %s --\n", cj.err); fflush(NULL); _exit(1); }
 	D.ctx = cj.ctx;
 	int rc;
-	rc = wtz_upload_reads(D.ctx, G->st.bits, (G->st.nbase + 31) >> 5, rdoff, rdlen2, n * 2); DIE_WTZ(rc, "wtz_upload_reads");
+	if(G->st.keep_text){ rc = wtz_upload_reads_ascii(D.ctx, G->st.text, G->st.nbase, rdoff, G->rdlen, n, 0, NULL); DIE_WTZ(rc, "wtz_upload_reads_ascii"); free(G->st.text); G->st.text = NULL; }
+	else { rc = wtz_upload_reads(D.ctx, G->st.bits, (G->st.nbase + 31) >> 5, rdoff, G->rdlen, n); DIE_WTZ(rc, "wtz_upload_reads"); }
+	rc = wtz_append_revcomp_views(D.ctx); DIE_WTZ(rc, "wtz_append_revcomp_views");
+	free(rdoff);
 	D.zindex_all = o->zindex_batch < 0 ? (2 * tot <= 2400000000ull) : !o->zindex_batch;      /* 16 B per indexed base: all reads while that stays under ~40 GB */
 	if(D.zindex_all){ rc = wtz_zindex_build(D.ctx); DIE_WTZ(rc, "wtz_zindex_build"); }
 	else D.mark = (uint8_t*)calloc((size_t)n * 2 + 1, 1);

@@ -100,4 +100,15 @@ WTZ_HD void wtz_fix_random_base(uint64_t r, const uint64_t *pos_sorted, uint64_t
 	if(v) WTZ_ING_OR((unsigned long long*)&bits[i >> 5], (unsigned long long)(v << (((~i) & 31u) << 1)));
 }
 
+/* word `k` of the reverse-complement view of a read: view base j = 3 - read base (len - 1 - j)  (revbitseq_basebank, dna.h) */
+WTZ_HD uint64_t wtz_revcomp_word(const uint64_t *bits, uint64_t off, uint32_t len, uint32_t k){
+	uint64_t w = 0;
+	const uint32_t j0 = k * 32u;
+	for(uint32_t t = 0; t < 32u && j0 + t < len; t++){
+		const uint32_t b = 3u - wtz_base_at(bits, off + (uint64_t)(len - 1u - (j0 + t)));
+		w |= (uint64_t)b << ((31u - t) * 2u);
+	}
+	return w;
+}
+
 #endif

@@ -82,6 +82,7 @@ struct K_pair_big;
 struct K_refine;
 struct K_pack_ascii;
 struct K_pack_fix;
+struct K_revcomp_views;
 struct K_stitch_fin;
 struct K_stitch_left;
 struct K_stitch_mid;
@@ -662,6 +663,37 @@ extern "C" int wtz_upload_reads_ascii(wtz_ctx_t *c, const char *seq, uint64_t n_
 	if(rc != WTZ_OK) return rc;
 	c->cnt.bytes_ingest_algo += n_bases + n_words * 8;
 	if(n_random) *n_random = rank - rand_calls_before;
+	return WTZ_OK;
+}
+extern "C" int wtz_append_revcomp_views(wtz_ctx_t *c){
+	if(!c || !c->bits) return wtz_fail(WTZ_E_ARG, "reads not uploaded");
+	CTX_ENTER(c);
+	if(c->shares_indexes) return wtz_fail(WTZ_E_STATE, "wtz_append_revcomp_views on a cloned context");
+	free_kindex(c); free_zindex(c); free_batch(c);
+	const uint32_t n = c->n_reads;
+	if((uint64_t)n * 2 > 0xFFFFFFFFull) return wtz_fail(WTZ_E_ARG, "too many reads for their reverse-complement views");
+	std::vector<uint64_t> h_off((size_t)n * 2), vw((size_t)n + 1);      /* vw[i] = first word of view i behind the old bank */
+	CHK(dev_d2h(h_off.data(), c->rdoff, (size_t)n * 8));
+	uint64_t words = 0;
+	for(uint32_t i = 0; i < n; i++){ vw[i] = words; words += ((uint64_t)c->h_rdlen[i] + 31) / 32; }
+	vw[n] = words;
+	const uint64_t old_w = c->n_words, new_w = old_w + words;
+	uint64_t *nb = NULL; uint64_t *nro = NULL; uint32_t *nrl = NULL;
+	CHK(dev_alloc_persist((void**)&nb, (new_w + 2) * 8)); CHK(dev_set(nb + old_w, 0, (words + 2) * 8)); CHK(dev_d2d(nb, c->bits, old_w * 8));
+	std::vector<uint32_t> h_len((size_t)n * 2);
+	for(uint32_t i = 0; i < n; i++){ h_len[i] = c->h_rdlen[i]; h_len[n + i] = c->h_rdlen[i]; h_off[n + i] = (old_w + vw[i]) * 32; }
+	CHK(dev_alloc_persist((void**)&nro, (size_t)n * 2 * 8)); CHK(dev_h2d(nro, h_off.data(), (size_t)n * 2 * 8));
+	CHK(dev_alloc_persist((void**)&nrl, (size_t)n * 2 * 4)); CHK(dev_h2d(nrl, h_len.data(), (size_t)n * 2 * 4));
+	uint64_t *d_vw = NULL; CHK(dev_alloc((void**)&d_vw, ((size_t)n + 1) * 8)); CHK(dev_h2d(d_vw, vw.data(), ((size_t)n + 1) * 8));
+	const uint64_t *src = c->bits; const uint64_t *ro = nro; const uint32_t *rl = nrl; uint64_t *dst = nb + old_w;
+	CHK(wtz_launch<K_revcomp_views>(0, words, [=] WTZ_LAMBDA (uint64_t w){
+		uint32_t lo = 0, hi = n;                         /* the view that holds word w: last i with vw[i] <= w */
+		while(hi - lo > 1){ const uint32_t mid = (lo + hi) >> 1; if(d_vw[mid] <= w) lo = mid; else hi = mid; }
+		dst[w] = wtz_revcomp_word(src, ro[lo], rl[lo], (uint32_t)(w - d_vw[lo]));
+	}));
+	CHK(dev_sync());
+	dev_free_persist(c->bits); dev_free_persist(c->rdoff); dev_free_persist(c->rdlen);
+	c->bits = nb; c->rdoff = nro; c->rdlen = nrl; c->n_words = new_w; c->n_reads = n * 2; c->h_rdlen = h_len;
 	return WTZ_OK;
 }
 extern "C" int wtz_fetch_read_bits(wtz_ctx_t *c, uint64_t *bits, uint64_t n_words){

@@ -18,7 +18,7 @@ SYMBOLS = [
     "wtz_index_build", "wtz_zindex_build", "wtz_candidates", "wtz_candidates_begin", "wtz_candidates_end", "wtz_batch_begin", "wtz_pairs_seed",
     "wtz_pairs_windows", "wtz_pairs_align", "wtz_fetch_cigars", "wtz_fetch_cigar_text", "wtz_host_alloc", "wtz_host_free", "wtz_get_counters", "wtz_reset_counters",
     "wtz_test_dp", "wtz_pool_info",
-    "wtz_index_count", "wtz_index_counts_fetch", "wtz_index_finish", "wtz_candidate_groups_begin", "wtz_candidate_groups_end", "wtz_candidate_groups_fetch", "wtz_cand_tail_host", "wtz_zindex_build_subset", "wtz_upload_reads_ascii", "wtz_fetch_read_bits",
+    "wtz_index_count", "wtz_index_counts_fetch", "wtz_index_finish", "wtz_candidate_groups_begin", "wtz_candidate_groups_end", "wtz_candidate_groups_fetch", "wtz_cand_tail_host", "wtz_zindex_build_subset", "wtz_upload_reads_ascii", "wtz_fetch_read_bits", "wtz_append_revcomp_views",
 ]
 
 
@@ -153,6 +153,12 @@ class Context:
         self.lib.wtz_upload_reads_ascii.argtypes = [C.c_void_p, C.c_char_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.POINTER(C.c_uint64)]
         self._chk(self.lib.wtz_upload_reads_ascii(self.h, text, len(text), offs.ctypes.data, lens.ctypes.data, lens.size, rand_calls_before, C.byref(nr)))
         return int(nr.value)
+
+    def append_revcomp_views(self):
+        """reads n .. 2n-1 := reverse complements of reads 0 .. n-1 (wtz_append_revcomp_views)"""
+        self.lib.wtz_append_revcomp_views.argtypes = [C.c_void_p]
+        self._chk(self.lib.wtz_append_revcomp_views(self.h))
+        self.n_reads *= 2
 
     def fetch_read_bits(self, n_bases):
         nw = (n_bases + 31) // 32

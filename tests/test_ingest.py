@@ -97,3 +97,36 @@ def test_gpu_wtzmo_ingest_modes(mode, name, gpu_exe, tmp_path):
     case = manifest()["cases"][name]
     md5, cont, _ = run_wtzmo_like(gpu_exe, case, tmp_path, extra=["--ingest", mode])
     assert md5 == case["md5_full"] and cont == case["md5_contained"]
+
+
+def test_revcomp_views_on_emulated_device(emul_lib):
+    """wtz_append_revcomp_views: read n + i = reverse complement of read i (revbitseq_basebank), packed on the device; ragged lengths, one empty read"""
+    from smartdenovo_amd import hipabi
+    rng = np.random.default_rng(9)
+    seqs = [rng.integers(0, 4, size=int(L), dtype=np.uint8) for L in (1, 31, 32, 33, 64, 1000, 4097, 0, 77)]
+    ctx = hipabi.Context(hipabi.Params.defaults(), pool_bytes=1 << 28, lib_path=emul_lib)
+    try:
+        words, offs, lens = hipabi.pack_reads(seqs)
+        ctx.upload(words, offs, lens)
+        ctx.append_revcomp_views()
+        nold = int(words.size)
+        tot_new = sum((s.size + 31) // 32 for s in seqs)
+        bits = ctx.fetch_read_bits((nold + tot_new) * 32)
+        at = nold
+        for s in seqs:
+            nw = (s.size + 31) // 32
+            want, _, _ = hipabi.pack_reads([(3 - s)[::-1].copy()]) if s.size else (np.zeros(0, dtype=np.uint64), None, None)
+            assert np.array_equal(bits[at:at + nw], want[:nw])
+            at += nw
+    finally:
+        ctx.close()
+
+
+@pytest.mark.gpu
+def test_gpu_wtgbo_ingest_modes(tmp_path):
+    """bin/wtgbo packs the reads and makes their reverse-complement views on the device by default; --ingest host packs while reading: same bytes (tiny_b_L has clipped reads)"""
+    import test_wtgbo as G
+    import __graft_entry__ as ge
+    for name in ("tiny_b_L", "grid4"):
+        for mode in ("device", "host"):
+            G.check_case(ge.EXE_GBO, name, tmp_path, ["--ingest", mode])
