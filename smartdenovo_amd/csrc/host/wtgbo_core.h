@@ -66,48 +66,19 @@ static uint32_t *gbo_cigar_space(gbo_t *G, uint64_t n){
 
 static const char *gbo_date(void){ static char buf[64]; time_t t = time(NULL); struct tm tmv; localtime_r(&t, &tmv); strftime(buf, sizeof buf, "%a %b %e %H:%M:%S %Y", &tmv); return buf; }
 
-static int gbo_usage(void){      /* wtgbo.c:267-309: to stdout, return 1 */
-	printf(
-	"WTGBO: Overlapper based on overlap graph\n"
-	"SMARTdenovo: Ultra-fast de novo assembler for high noisy long reads\n"
-	"MI355X build of the pair alignment (align_hzmaux on gfx950); options as wtgbo 1.0\n"
-	"Usage: wtgbo [options]\n"
-	"Options:\n"
-	" -t <int>    Number of threads (accepted; the output is that of -t 1), [1]\n"
-	" -i <string> Long reads sequences file(s), + *\n"
-	" -b <string> Long reads retained region, often from wtobt, +\n"
-	"             Format: read_name\\toffset\\tlength\\toriginal_len\n"
-	" -j <string> Overlap file(s), + *\n"
-	"             Format: reads1\\t+/-\\tlen1\\tbeg1\\tend1\\treads2\\t+/-\\tlen2\\tbeg2\\tend2\\tscore\n"
-	" -L <string> Load pairs of read name from file, will avoid to calculate overlap them again, + [NULL]\n"
-	" -s <int>    Minimum alignment score, [200]\n"
-	" -m <float>  Minimum alignment identity, [0.6]\n"
-	" -u <int>    Maximum margin of alignment, [100]\n"
-	" -o <string> Output file of new overlaps, *\n"
-	" -9 <string> Record pairs of sequences have beed aligned regardless of successful, including pairs from '-L'\n"
-	"             Format: read1\\tread2\n"
-	" -f          Force overwrite output file\n"
-	" -c <int>    Minimum estimated coverage of edge to be trusted, [1]\n"
-	" -Q          Use number of matches as alignment score\n"
-	" -q <float>  Best score cutoff, [0.95]\n"
-	" -H          Turn off homopolymer compression\n"
-	" -z <int>    Smaller kmer size (z-mer), 5 <= <-z> <= 16, [10]\n"
-	" -Z <int>    Filter high frequency z-mers, maybe repetitive, [100]\n"
-	" -y <int>    Zmer window, [800]\n"
-	" -R <int>    Minimum size of seeding region within zmer window, [200]\n"
-	" -r <int>    Minimum size of total seeding region for zmer windows, [300]\n"
-	" -l <int>    Maximum variant of uncompressed sizes between two matched hz-kmer, [2]\n"
-	" -M <int>    Alignment penalty: match, [2]\n"
-	" -X <int>    Alignment penalty: mismatch, [-5]\n"
-	" -O <int>    Alignment penalty: insertion or deletion, [-3]\n"
-	" -E <int>    Alignment penalty: gap extension, [-1]\n"
-	" -T <int>    Alignment penalty: read end clipping, [-50]\n"
-	" -w <int>    Minimum bandwidth, iteratively doubled to maximum [50]\n"
-	" -W <int>    Maximum bandwidth, [3200]\n"
-	" -n          Refine the alignment\n"
-	" -N <int>    Max turns of iteration, [5]\n"
-	" --gpu <int> --pool-gb <int> --batch <int> --zindex-batch <0|1> --ingest <device|host>   device selection / scratch pool / pairs per device batch / z-mer index per batch / where the reads are packed\n"
-	"\n");
+static int gbo_usage(void){      /* wtgbo.c:267-309 prints its usage to stdout and returns 1; the option LETTERS and defaults are the contract, the wording is ours */
+	fputs(
+	"WTGBO (MI355X tool set): overlapper on the overlap graph - aligns read pairs the graph proposes (align_hzmaux on gfx950)\n"
+	"Usage: wtgbo [options]      (* = required, + = may be given several times)\n"
+	" inputs    -i <reads fa/fq[.gz]> *+   -j <overlap file, >= 16 columns> *+   -b <name offset length: retained region> +   -L <name name: pairs already tested> +\n"
+	" outputs   -o <new overlaps, - = stdout> *   -f overwrite   -9 <pairs tested, incl. those of -L>\n"
+	" graph     -s <int> min score [200]   -m <float> min identity [0.6]   -u <int> max unaligned margin [100]   -c <int> min edge coverage [1]\n"
+	"           -Q score = matches   -q <float> best-score cutoff [0.95]   -N <int> max iterations [5]\n"
+	" seeding   -H no homopolymer compression   -z <int> z-mer size 5..16 [10]   -Z <int> max z-mer frequency [100]   -y <int> window [800]\n"
+	"           -R <int> min seeded bases per window [200]   -r <int> (accepted, unused) [300]   -l <int> max z-mer length difference [2]\n"
+	" alignment -M 2 -X -5 -O -3 -E -1 -T -50 scores   -w <int> band [50]   -e <int> extension band [800]   -W <int> max band [3200]   -n refine\n"
+	" this build -t <int> accepted (the output is that of -t 1)   --gpu <id>   --pool-gb <n> [16]   --batch <pairs> [16384]   --zindex-batch <0|1>   --ingest <device|host>\n",
+	stdout);
 	return 1;
 }
 

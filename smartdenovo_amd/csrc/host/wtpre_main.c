@@ -16,81 +16,86 @@
 #include <unistd.h>
 #include "wtz_host.h"
 
-static int usage(void){
-	printf(
-	"WTPRE: Prepare raw reads for assembly\n"
-	"SMARTdenovo: Ultra-fast de novo assembler for high noisy long reads\n"
-	"Usage: wtpre [options] <raw_reads_file:fq/fa>\n"
-	"Options:\n"
-	" -o <string> Output of processed reads, [-]\n"
-	" -f          Force overwrite output file\n"
-	" -L          Keep all subreads in a well, default: the longest one\n"
-	" -J <int>    Jack knife of read length, [0]\n"
-	" -c <int>    Clip <-c> bases at both ends, [0]\n"
-	" -p <string> Change the read name into {\"%%s%%012d\", <-p>}, [pb]\n"
-	"\n"
-	"Example: \n"
-	"$> wtpre -J 5000 -p pb my_raw_reads_1.fq my_raw_reads_2.fq >wt.fa\n"
-	"\n");
+static int usage(void){      /* to stdout, return 1, like wtpre.c:22-42 */
+	fputs(
+	"WTPRE (MI355X tool set): prepare raw reads for assembly - rename, longest subread per well, length filter, clipping\n"
+	"Usage: wtpre [options] <raw_reads_file:fq/fa> [more files]\n"
+	" -o <file>   output [-]            -f  overwrite an existing output\n"
+	" -L          keep every subread of a well (default: the longest one)\n"
+	" -J <int>    drop reads shorter than this after clipping [0]\n"
+	" -c <int>    clip this many bases at both ends [0]\n"
+	" -p <string> reads are renamed <-p><12-digit serial> [pb]\n"
+	"e.g.  wtpre -J 5000 -p pb raw_1.fq raw_2.fq > wt.fa\n", stdout);
 	return 1;
 }
 
-static void set_str(hx_str_t *d, const char *p, size_t n){ d->n = 0; hx_str_add(d, p, n); }
+/* length of the WELL part of a subread name `<well>/<digits>_<digits>` (either digit string may be empty); the whole name when it does not end
+ * like that or nothing would be left in front (wtpre.c:89-108) */
+static size_t well_name_len(const char *tag, size_t n){
+	size_t k = n;
+	while(k && tag[k - 1] >= '0' && tag[k - 1] <= '9') k--;
+	if(k == 0 || tag[k - 1] != '_') return n;
+	k--;
+	while(k && tag[k - 1] >= '0' && tag[k - 1] <= '9') k--;
+	if(k == 0 || tag[k - 1] != '/') return n;
+	k--;
+	return k ? k : n;
+}
+
+typedef struct { hx_str_t well, desc, seq; int raw_len; } kept_t;       /* the subread kept for the current well */
+static void keep(kept_t *b, const char *tag, size_t wn, const hx_str_t *desc, const char *seq, int seqlen, int raw_len){
+	b->well.n = 0; hx_str_add(&b->well, tag, wn);
+	b->desc.n = 0; hx_str_add(&b->desc, desc->s ? desc->s : "", desc->n);
+	b->seq.n = 0; hx_str_add(&b->seq, seq, (size_t)seqlen);
+	b->raw_len = raw_len;
+}
+static void emit(FILE *out, const char *prefix, unsigned long long *serial, const char *desc, const char *seq){
+	fprintf(out, ">%s%012llu%s\n%s\n", prefix, (*serial)++, desc, seq);
+}
 
 int main(int argc, char **argv){
-	int longest = 1, min_len = 0, clp_len = 0, overwrite = 0, c;
+	int per_well = 1, min_len = 0, clip = 0, overwrite = 0, c;
 	const char *prefix = "pb", *outf = NULL;
 	while((c = getopt(argc, argv, "ho:fLJ:c:p:")) >= 0){
-		switch(c){
-			case 'h': return usage();
-			case 'o': outf = optarg; break;
-			case 'f': overwrite = 1; break;
-			case 'L': longest = 0; break;
-			case 'J': min_len = atoi(optarg); break;
-			case 'c': clp_len = atoi(optarg); break;
-			case 'p': prefix = optarg; break;
-			default: return usage();
-		}
+		if(c == 'o') outf = optarg;
+		else if(c == 'f') overwrite = 1;
+		else if(c == 'L') per_well = 0;
+		else if(c == 'J') min_len = atoi(optarg);
+		else if(c == 'c') clip = atoi(optarg);
+		else if(c == 'p') prefix = optarg;
+		else return usage();                     /* -h and anything unknown */
 	}
 	if(optind == argc) return usage();
-	if(!overwrite && outf && strcmp(outf, "-")){ FILE *t = fopen(outf, "r"); if(t){ fclose(t); fprintf(stderr, "File exists! '%s'\n\n", outf); return usage(); } }
+	const int to_stdout = (outf == NULL || strcmp(outf, "-") == 0);
+	if(!to_stdout && !overwrite && access(outf, F_OK) == 0){ fprintf(stderr, "File exists! '%s'\n\n", outf); return usage(); }
 	hx_reader_t *fr = hx_reader_open(argv + optind, argc - optind);
 	if(!fr){ fprintf(stderr, " -- Cannot open %s --\n", argv[optind]); return 1; }
-	FILE *out = outf ? (strcmp(outf, "-") == 0 ? stdout : fopen(outf, "w")) : stdout;
+	FILE *out = to_stdout ? stdout : fopen(outf, "w");
 	if(!out){ fprintf(stderr, " -- Cannot open %s for write --\n", outf); return 1; }
 	hx_str_t tag = {0, 0, 0}, dsc = {0, 0, 0}, seq = {0, 0, 0};
-	hx_str_t w_tag = {0, 0, 0}, w_dsc = {0, 0, 0}, w_seq = {0, 0, 0};       /* the well's best subread so far */
-	hx_str_add(&w_tag, "", 0); hx_str_add(&w_dsc, "", 0); hx_str_add(&w_seq, "", 0);
-	unsigned long long idx = 0; int max = 0;
+	kept_t best; memset(&best, 0, sizeof best);
+	hx_str_add(&best.well, "", 0); hx_str_add(&best.desc, "", 0); hx_str_add(&best.seq, "", 0);
+	unsigned long long serial = 0;
 	while(hx_reader_seq_desc(fr, &tag, &dsc, &seq)){
 		if(!tag.s) hx_str_add(&tag, "", 0);
 		if(!dsc.s) hx_str_add(&dsc, "", 0);
 		if(!seq.s) hx_str_add(&seq, "", 0);
-		const int seqlen = (int)seq.n - 2 * clp_len;
+		const int seqlen = (int)seq.n - 2 * clip;      /* -J applies to the clipped length (wtpre.c:84-85) */
 		if(seqlen < min_len) continue;
-		char *seqstr = seq.s + clp_len;
-		seqstr[seqlen] = 0;
-		if(longest){
-			int size = (int)tag.n, f = 0;
-			while(size){
-				const char ch = tag.s[size - 1];
-				if(ch <= '9' && ch >= '0') size--;
-				else if(ch == '_'){ if(f) break; size--; f = 1; }
-				else if(ch == '/'){ if(f == 1){ size--; f = 2; } break; }
-				else break;
-			}
-			if(size <= 0 || f < 2) size = (int)tag.n;
-			if((int)w_tag.n == size && strncmp(w_tag.s, tag.s, (size_t)size) == 0){
-				if(seqlen > max){ set_str(&w_tag, tag.s, (size_t)size); set_str(&w_dsc, dsc.s, dsc.n); set_str(&w_seq, seqstr, (size_t)seqlen); max = (int)seq.n; }
-			} else {
-				if(w_tag.n) fprintf(out, ">%s%012llu%s\n%s\n", prefix, idx++, w_dsc.s, w_seq.s);
-				set_str(&w_tag, tag.s, (size_t)size); set_str(&w_dsc, dsc.s, dsc.n); set_str(&w_seq, seqstr, (size_t)seqlen); max = (int)seq.n;
-			}
-		} else if(seqlen >= min_len){
-			fprintf(out, ">%s%012llu%s\n%s\n", prefix, idx++, dsc.s, seqstr);
+		char *body = seq.s + clip;
+		body[seqlen] = 0;
+		if(!per_well){ emit(out, prefix, &serial, dsc.s, body); continue; }
+		const size_t wn = well_name_len(tag.s, tag.n);
+		const int same_well = (best.well.n == wn && strncmp(best.well.s, tag.s, wn) == 0);
+		if(same_well){
+			/* the reference compares the newcomer's CLIPPED length with the kept read's UNCLIPPED one (wtpre.c:110,114) */
+			if(seqlen > best.raw_len) keep(&best, tag.s, wn, &dsc, body, seqlen, (int)seq.n);
+		} else {
+			if(best.well.n) emit(out, prefix, &serial, best.desc.s, best.seq.s);
+			keep(&best, tag.s, wn, &dsc, body, seqlen, (int)seq.n);
 		}
 	}
-	if(w_tag.n) fprintf(out, ">%s%012llu%s\n%s\n", prefix, idx++, w_dsc.s, w_seq.s);
+	if(best.well.n) emit(out, prefix, &serial, best.desc.s, best.seq.s);
 	hx_reader_close(fr);
 	if(out != stdout) fclose(out);
 	return 0;
