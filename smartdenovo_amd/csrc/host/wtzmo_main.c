@@ -87,7 +87,7 @@ typedef struct eng_s {
 	uint32_t cursor, qend, B; uint64_t next_seq, commit_seq;
 	/* planned batch sizing: main-pool bytes a pair has needed so far (largest seen, reads are processed longest first), so that the pairs of
 	 * a range are cut to fit the pool BEFORE the device stages run; WTZ_E_POOL and the halving below it remain as the safety net */
-	double bytes_per_pair; uint64_t main_cap; uint64_t n_split, n_ranges;
+	double bytes_per_pair, bpp_decay; uint64_t main_cap; uint64_t n_split, n_ranges;
 	pending_t pend;
 	/* stats */
 	char *cig_keep[16]; uint64_t cig_keep_cap[16];      /* page-locked CIGAR text buffer of worker w, kept across steps (pinning is the expensive part) */
@@ -882,6 +882,8 @@ static void process_range(eng_t *E, batch_t *b, uint32_t s0, uint32_t s1){
 			E->main_cap = pi.main_cap * b->nparts;                  /* the range is dealt over nparts pools */
 			const double bpp = (double)pi.main_used / (double)pt->npair;
 			if(pt->npair >= 8 && bpp > E->bytes_per_pair) E->bytes_per_pair = bpp;
+			else if(pt->npair >= 256 && E->bpp_decay > 0 && bpp < E->bytes_per_pair){      /* the longest reads come first: let the estimate follow the measurements down, 15 % per range at most */
+				const double floor_ = E->bytes_per_pair * E->bpp_decay; E->bytes_per_pair = bpp > floor_ ? bpp : floor_; }
 			pthread_mutex_unlock(&E->mu);
 		}
 	}
@@ -983,6 +985,7 @@ static void process_batch(eng_t *E, batch_t *b){
 				E->main_cap = pi.main_cap * b->nparts;
 				const double bpp = (double)pi.main_used / (double)pt->npair;
 				if(pt->npair >= 8 && bpp > E->bytes_per_pair) E->bytes_per_pair = bpp;
+				else if(pt->npair >= 256 && E->bpp_decay > 0 && bpp < E->bytes_per_pair){ const double floor_ = E->bytes_per_pair * E->bpp_decay; E->bytes_per_pair = bpp > floor_ ? bpp : floor_; }
 				pthread_mutex_unlock(&E->mu);
 			}
 		}
@@ -1171,6 +1174,7 @@ int main(int argc, char **argv){
 #endif
 	eng_t *E = (eng_t*)calloc(1, sizeof(eng_t));
 	E->st.keep_text = 1;        /* --ingest device */
+	E->bpp_decay = getenv("WTZ_BPP_DECAY") ? atof(getenv("WTZ_BPP_DECAY")) : 0.0;      /* experiment: 0 = the estimate only grows (default), e.g. 0.85 = it may fall by 15 % per range */
 	wtz_params_c *P = &E->P;
 	strlist_t pbs = {0}, flts = {0}, ovls = {0}, obts = {0}, tbas = {0};
 	char *output = NULL, *pairoutf = NULL, *statsf = NULL;
