@@ -284,8 +284,6 @@ def main():
     # (profiles/r03_valu_int32_ubench.txt): v_add / v_sub ~60 Tlane-op/s, v_max_i32 / v_alignbit / v_mad_i32_i24 / v_lshl_or ~36.6 (half rate)
     for key in ("roofline", "roofline_sw1", "roofline_sw2"):
         res[key]["peak_measured_Tops"] = {"v_add_u32": 63.5, "v_max_i32": 36.6}
-    if a.engine == "dmo":       # no banded SW in the dot-matrix engine (SURVEY finding 2): its dominant kernel is K_pair, priced against HBM
-        res["roofline"] = dict(res["roofline_zmer"])
     # HBM traffic: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command with --steps 1 --warmup 0 (so totals are per step),
     # condensed by tools/summarize_profiles.py into profiles/ (FETCH_SIZE doubled as the gfx950 guide says).  `traffic` is per LAUNCH like
     # `achieved` (total / dispatches), `traffic_per_step` the total next to the per-step algorithmic bytes.
@@ -319,6 +317,8 @@ def main():
             res["cpu_baseline"] = cpu_baseline(eng, a.cpu_genome, a.coverage, a.seed if a.cpu_genome == a.genome else a.seed + 1000, tmp, same_input=(a.cpu_genome == a.genome))
         except Exception as e:      # the baseline is reported, never required
             res["cpu_baseline"] = {"value": None, "error": str(e)}
+    if a.engine == "dmo":       # no banded SW in the dot-matrix engine (SURVEY finding 2): its dominant kernel is K_pair, priced against HBM (after the PMC traffic was attached above)
+        res["roofline"] = dict(res["roofline_zmer"])
     print(json.dumps(res))
     for leftover in (out, out + ".prev", out + ".contained"):
         if os.path.exists(leftover):
