@@ -541,6 +541,7 @@ WTZ_HD uint32_t wtz_scan_windows_coop(const wtz_zhit_t *rs, uint32_t dir, uint32
 	WTZ_PROF_ADD(18, pw2);
 	const unsigned long long pw3 = WTZ_PROF_T(); (void)pw3;
 	unsigned long long pw4 = 0; (void)pw4;
+	uint32_t n2_all = 0;
 	if(lane == 0){
 		uint32_t i, j, n2 = 0, ol = 0, ol2, lst = 0, s, t;
 		uint32_t lwo = 0, lwb_o2 = 0, lwe_o2 = 0;        /* the open window: overlap and off2 of its two ends */
@@ -567,23 +568,50 @@ WTZ_HD uint32_t wtz_scan_windows_coop(const wtz_zhit_t *rs, uint32_t dir, uint32
 #else
 		WTZ_PROF_ADD(19, pw3); pw4 = WTZ_PROF_T(); WTZ_PROF_CNT(23, n2);
 #endif
-		int32_t last_end1 = 0; uint32_t last_ovl = 0;
-		for(uint32_t wi = 0; wi < n2; wi++){
-			const uint32_t size = anchors.n, wb = sc.wb[wi], we = sc.we[wi];
-			int32_t offset, off; uint32_t offn = 0, cnt = 0;
+		n2_all = n2;
+	}
+	/* ---- the windows (hzm_aln.h:484-575).  Lane 0 walks them; the one step the whole wave takes is the ordering of a window's members by off1
+	 * (hzm_aln.h:519): distinct keys have ONE ascending order, so the wave-wide bitonic network gives it; equal off1 (one query z-mer matched at two
+	 * candidate positions) makes the reference's swap sequence observable and lane 0 redoes it from the original order.  (Round 3: the swap-exact sort
+	 * of every window on lane 0 was the largest part of the window build.) ---- */
+	n2_all = wtz_coop_bcast32(n2_all);
+	int32_t last_end1 = 0; uint32_t last_ovl = 0;
+	for(uint32_t wi = 0; wi < n2_all; wi++){
+		uint32_t size = 0, cnt = 0;
+		uint64_t *ak = K;                         /* (off1<<32 | position in S) of the members */
+		if(lane == 0){
+			const uint32_t wb = sc.wb[wi], we = sc.we[wi];
+			int32_t offset, off; uint32_t offn = 0, j;
+			size = anchors.n;
 			int32_t *as = (int32_t*)K;
 			for(j = wb; j <= we; j++){ const wtz_zhit_t p = S[j]; as[offn++] = (int32_t)ZH_OFF1(p) - (int32_t)ZH_OFF2(p); }
 			offset = wtz_median(as, (int32_t)offn);
-			uint64_t *ak = K;                     /* `as` is dead: (off1<<32 | position in S) of the members, hzm_aln.h:519 */
-			for(j = wb; j <= we; j++){
+			for(j = wb; j <= we; j++){            /* `as` is dead */
 				const wtz_zhit_t p = S[j];
 				off = (int32_t)ZH_OFF1(p) - (int32_t)ZH_OFF2(p);
 				if(off < offset - WTZ_KWIN_MAX_OFFSET_DEV || off > offset + WTZ_KWIN_MAX_OFFSET_DEV) continue;
 				ak[cnt++] = ((uint64_t)ZH_OFF1(p) << 32) | j;
 			}
-			if(cnt == 0) continue;
-			wtz_sort_exact(ak, (size_t)cnt, wtz_gt_hi32());
-			if(!anchors.reserve(size + cnt)) break;
+		}
+		cnt = wtz_coop_bcast32(cnt);
+		if(cnt == 0) continue;
+#if defined(__HIP_DEVICE_COMPILE__)
+		if(cnt <= 64u){
+			WTZ_WAVE_SYNC();
+			const uint64_t v = wtz_wave_sort64(lane < cnt ? ak[lane] : ~0ull);
+			const uint32_t nhi = (uint32_t)__shfl_down((int)(uint32_t)(v >> 32), 1, 64);
+			const bool tie = lane + 1 < cnt && (uint32_t)(v >> 32) == nhi;
+			uint32_t any; (void)wtz_coop_rank(tie, &any);
+			if(any){ if(lane == 0) wtz_sort_exact(ak, (size_t)cnt, wtz_gt_hi32()); }
+			else if(lane < cnt) ak[lane] = v;
+			WTZ_WAVE_SYNC();
+		} else
+#endif
+		{ if(lane == 0) wtz_sort_exact(ak, (size_t)cnt, wtz_gt_hi32()); WTZ_WAVE_SYNC(); }
+		uint32_t stop = 0;
+		if(lane == 0){ do {
+			uint32_t ol, lst;
+			if(!anchors.reserve(size + cnt)){ stop = 1; break; }
 			wtz_win_t w;
 			w.pb2 = 0; w.closed = 0; w.dir = (uint8_t)dir; w.pad = 0;
 			w.anchors[0] = size; w.anchors[1] = 0;
@@ -599,16 +627,18 @@ WTZ_HD uint32_t wtz_scan_windows_coop(const wtz_zhit_t *rs, uint32_t dir, uint32
 				if((int32_t)ZH_OFF2(p) < w.beg[1]) w.beg[1] = (int32_t)ZH_OFF2(p);
 				if((int32_t)(ZH_OFF2(p) + ZH_LEN2(p)) > w.end[1]) w.end[1] = (int32_t)(ZH_OFF2(p) + ZH_LEN2(p));
 			}
-			if(ol * 2 < zovl) continue;
-			if(ret && (w.end[1] <= (int32_t)((uint32_t)last_end1 + kwin / 3) && ol <= last_ovl)) continue;
+			if(ol * 2 < zovl) break;
+			if(ret && (w.end[1] <= (int32_t)((uint32_t)last_end1 + kwin / 3) && ol <= last_ovl)) break;
 			anchors.n = size + cnt;
 			w.ovl = WTZ_OVL29(ol);
 			w.anchors[1] = anchors.n;
-			if(!wins.push(w)) break;             /* pool exhausted: count only what is in the vector */
+			if(!wins.push(w)){ stop = 1; break; }      /* pool exhausted: count only what is in the vector */
 			ret++;
 			last_end1 = w.end[1]; last_ovl = w.ovl;
 			if(me0 < w.end[0]) me0 = w.end[0];
-		}
+		} while(0); }
+		if(wtz_coop_bcast32(stop)) break;
+		WTZ_WAVE_SYNC();
 	}
 	WTZ_PROF_ADD(20, pw4);
 	WTZ_WAVE_SYNC();
