@@ -94,6 +94,24 @@ def test_per_batch_zindex_at_scale(name, gpu_exe):
     os.remove(out)
 
 
+@pytest.mark.parametrize("name,extra", [("yeast100_zmo", ["--gpu-list", "0,0", "--shard-index"]), ("ecoli_dmo", ["--gpu-list", "0,0,0", "--shard-index"]),
+                                        ("yeast100_zmo", ["--gpu-list", "0,0"])],
+                         ids=["configs2_zmo_2_index_shards", "configs1_dmo_3_index_shards", "configs2_zmo_2_parts_central_commit"])
+def test_multi_context_modes_at_scale(name, extra, gpu_exe):
+    """The two multi-GPU forms at BASELINE scale, with contexts on this box's one device standing in for the devices (configs[3] / [4] shapes of work):
+    `--shard-index` = the k-mer index cut into read-id ranges with the counts of all shards in the filter, every query answered by every shard; plain `--gpu-list` =
+    index replicated, pairs dealt over the parts, one in-order commit.  Either must write the md5 of the reference's single `wtzmo -t 1` run."""
+    case = MAN["cases"][name]
+    fa = reads_of(case["set"])
+    out = os.path.join(TMP, "multi_%s_%d.ovl" % (name, len(extra)))
+    # 48 GB of scratch per context: the contexts share ONE device here, and each also holds the reads, its indexes and their build temporaries
+    r = subprocess.run([gpu_exe, "-i", fa, "-fo", out, "--pool-gb", "48"] + extra + case["argv"], capture_output=True)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    md5, nrec = file_md5(out)
+    assert (nrec, md5) == (case["records"], case["md5_full"])
+    os.remove(out)
+
+
 @pytest.mark.parametrize("env", [{"WTZ_DM_FIRST_BIG": "0", "WTZ_DM_TIER3_KB": "18"}, {"WTZ_DM_FIRST_BIG": "0", "WTZ_DM_TIER3_KB": "17", "WTZ_DM_TIER4_KB": "18"},
                                  {"WTZ_DM_FIRST_BIG": "0", "WTZ_DM_TIER3_KB": "159", "WTZ_DM_TIER4_KB": "159"}],
                          ids=["tier4_used", "scalar_fallback_used", "image_in_lds"])
