@@ -291,7 +291,7 @@ def main():
         import csv
         src = os.path.join(ROOT, "profiles", "r03_%s_%s_pmc_per_kernel.csv" % (a.workload, a.engine))
         kmap = {"wtz_kernel_extjobs_reg": "roofline", "wtz_kernel_extjobs_mw": "roofline", "K_winalign": "roofline_sw1", "K_ldp": "roofline_sw1", "K_ltb": "roofline_sw1", "K_lfold": "roofline_sw1", "K_lplan": "roofline_sw1",
-                "K_gap": "roofline_sw2", "K_gdp": "roofline_sw2", "K_gtb": "roofline_sw2", "K_candidates_wg": "roofline_seed", "K_candidates": "roofline_seed", "K_pair": "roofline_zmer", "K_pair_big": "roofline_zmer"}
+                "K_gap": "roofline_sw2", "K_gdp": "roofline_sw2", "K_gtb": "roofline_sw2", "K_candidates_wg": "roofline_seed", "K_candidates": "roofline_seed", "K_pair": "roofline_zmer", "K_pair_dm": "roofline_zmer", "K_pair_big": "roofline_zmer"}
         for row in csv.DictReader(open(src)):
             key = kmap.get(row["kernel"])
             if key is None:

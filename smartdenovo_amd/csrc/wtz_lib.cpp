@@ -78,6 +78,7 @@ struct K_kstats;
 struct K_pack_cigars;
 struct K_pack_windows;
 struct K_pair;
+struct K_pair_dm;
 struct K_pair_big;
 struct K_refine;
 struct K_pack_ascii;
@@ -151,6 +152,7 @@ template<typename TAG, typename F> __global__ void __launch_bounds__(64) wtz_ker
 template<typename TAG> struct wtz_occ { static constexpr int waves = 1; };
 template<> struct wtz_occ<K_winalign> { static constexpr int waves = WTZ_OCC_WINALIGN; };
 template<> struct wtz_occ<K_pair> { static constexpr int waves = WTZ_OCC_PAIR; };
+template<> struct wtz_occ<K_pair_dm> { static constexpr int waves = WTZ_OCC_PAIR; };
 template<> struct wtz_occ<K_gap> { static constexpr int waves = WTZ_OCC_GAP; };
 /* lane-per-problem K-sw1 (wtz_sw_lane.h): the band lives in 2 x (NC + 1) VGPRs */
 template<> struct wtz_occ<K_ldp> { static constexpr int waves = 2; };
@@ -1171,10 +1173,21 @@ extern "C" int wtz_pairs_seed(wtz_ctx_t *c, const uint32_t *qid, const uint32_t 
 	 * waves hold every 8th pair of a 5 000-pair stretch, i.e. the tables of ~170 queries (20 MB against 4 MB of L2); giving every XCD runs of
 	 * `xg` CONSECUTIVE pairs makes that ~25 queries.  (WTZ_XCD_GROUP=0: identity.) */
 	const uint32_t xg = c->env_xcd_group; const uint64_t n64 = n;
-	CHK(wtz_launch_coop<K_pair>(0, n, [=] WTZ_LAMBDA (uint64_t b){
-		uint64_t t = b;
-		if(xg){ const uint64_t per = 8ull * xg, full = n64 / per * per; if(b < full){ const uint64_t r = b % per; t = b - r + (r & 7u) * xg + (r >> 3); } }
-		wtz_task_pair((uint32_t)t, V, dq, dc, dr); }, c->P.dot_matrix ? WTZ_PAIR_DM_LDS_BYTES : WTZ_PAIR_LDS_BYTES));
+#ifdef WTZ_EMUL
+	CHK(wtz_launch_coop<K_pair>(0, n, [=] WTZ_LAMBDA (uint64_t b){ (void)xg; (void)n64; wtz_task_pair<-1>((uint32_t)b, V, dq, dc, dr); }, c->P.dot_matrix ? WTZ_PAIR_DM_LDS_BYTES : WTZ_PAIR_LDS_BYTES));
+#else
+	if(c->P.dot_matrix){
+		CHK(wtz_launch_coop<K_pair_dm>(0, n, [=] WTZ_LAMBDA (uint64_t b){
+			uint64_t t = b;
+			if(xg){ const uint64_t per = 8ull * xg, full = n64 / per * per; if(b < full){ const uint64_t r = b % per; t = b - r + (r & 7u) * xg + (r >> 3); } }
+			wtz_task_pair<1>((uint32_t)t, V, dq, dc, dr); }, WTZ_PAIR_DM_LDS_BYTES));
+	} else {
+		CHK(wtz_launch_coop<K_pair>(0, n, [=] WTZ_LAMBDA (uint64_t b){
+			uint64_t t = b;
+			if(xg){ const uint64_t per = 8ull * xg, full = n64 / per * per; if(b < full){ const uint64_t r = b % per; t = b - r + (r & 7u) * xg + (r >> 3); } }
+			wtz_task_pair<0>((uint32_t)t, V, dq, dc, dr); }, WTZ_PAIR_LDS_BYTES));
+	}
+#endif
 #if defined(WTZ_DEBUG_CRUMBS) && !defined(WTZ_EMUL)
 	if(h_crumbs){
 		const double t0 = wtz_wall(); const double limit = atof(getenv("WTZ_DEBUG_CRUMBS")) > 1 ? atof(getenv("WTZ_DEBUG_CRUMBS")) : 20.0;

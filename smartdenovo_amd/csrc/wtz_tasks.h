@@ -51,8 +51,12 @@ __device__ unsigned int *wtz_crumbs = NULL;
 #define WTZ_CRUMB(t, code) do { } while(0)
 #endif
 /* all lanes of the wavefront enter; the z-mer matching is cooperative, the order-sensitive remainder runs on lane 0 */
+/* ENGINE: 0 = windows + chain (zmo), 1 = dot matrix (dmo), -1 = decided at run time (host emulation).  One kernel per engine (round 3): a zmo launch does not
+ * carry the registers and code of the dot-matrix path and vice versa. */
+template<int ENGINE = -1>
 WTZ_HD void wtz_task_pair(uint32_t t, const wtz_env_t &V, const uint32_t *qid, const uint32_t *cid, wtz_pairres_t *res){
 	const wtz_params_t *P = V.P;
+	const bool dm = ENGINE < 0 ? (P->dot_matrix != 0) : (ENGINE == 1);
 	const uint32_t q = qid[t], c = cid[t];
 	wtz_pairres_t r; memset(&r, 0, sizeof r);
 	wtz_zhit_t *hits = NULL; uint32_t n = 0;
@@ -72,7 +76,7 @@ WTZ_HD void wtz_task_pair(uint32_t t, const wtz_env_t &V, const uint32_t *qid, c
 	__threadfence_block();
 	if(ok && (aux ? n > 0 : n * P->zsize >= P->ztot)){      /* uniform: the first ordering of either engine, wave-parallel when tie-free */
 		int pbad = 0;
-		if(P->dot_matrix) sorted = wtz_sort_hits_wave<1>(hits, n, V.pool, (uint64_t*)wtz_wave_scratch(), WTZ_PAIR_DM_LDS_BYTES / 8, &pbad);
+		if(dm) sorted = wtz_sort_hits_wave<1>(hits, n, V.pool, (uint64_t*)wtz_wave_scratch(), WTZ_PAIR_DM_LDS_BYTES / 8, &pbad);
 		else              sorted = wtz_sort_hits_wave<0>(hits, n, V.pool, (uint64_t*)wtz_wave_scratch(), WTZ_PAIR_LDS_BYTES / 8, &pbad);
 		if(pbad) r.bad = 1;
 	}
@@ -83,7 +87,7 @@ WTZ_HD void wtz_task_pair(uint32_t t, const wtz_env_t &V, const uint32_t *qid, c
 	r.n_hits = n;
 	if(aux ? n == 0 : n * P->zsize < P->ztot){ r.gate = 0; if(lane == 0) res[t] = r; WTZ_CRUMB(t, 0xFF); return; }
 	r.gate = 1;
-	if(P->dot_matrix){
+	if(dm){
 		wtz_vec<wtz_zhit_t> cache; cache.a = sorted ? sorted : hits; cache.n = n; cache.cap = n + 2; cache.pool = V.pool; cache.bad = 0;
 		const uint64_t tk2 = WTZ_TICK();
 		uint64_t tkd = 0;
