@@ -1367,7 +1367,8 @@ int main(int argc, char **argv){
 	}
 	if(E->zbatch == 0 && E->st.nbase > 2400000000ull && g_dist.world == 1 && E->n_workers == 1){ E->zbatch = 1; fprintf(stderr, "[wtzmo-mi355x] %llu read bases: the z-mer index is built per batch of queries (--zindex-batch 0 to force the all-reads index)\n", (unsigned long long)E->st.nbase); }
 	if(E->zbatch > 0 && (g_dist.world > 1 || E->n_workers > 1)){ fprintf(stderr, " -- --zindex-batch excludes ranks and --workers --\n"); DIE_NOW(); }
-	if(E->zbatch > 0 && E->max_batch > 512) E->max_batch = 512;
+	{ const uint32_t zb_max = getenv("WTZ_ZBATCH_MAX") ? (uint32_t)atoi(getenv("WTZ_ZBATCH_MAX")) : 1024u;      /* queries per batch when the z-mer index is rebuilt per batch: bounds its size (queries + <= -A candidates each); configs[3]-shape whole job: 36.0 s with 512, 33.3 s with 1 024, 33.1 s with 2 048 */
+	  if(E->zbatch > 0 && E->max_batch > zb_max) E->max_batch = zb_max; }
 	if(E->shard && (E->n_idx > 1 || E->n_workers > 1)){ fprintf(stderr, " -- --shard-index excludes -G and --workers --\n"); DIE_NOW(); }
 	int rc;
 	if(cj.started) pthread_join(cj.th, NULL); else ctxjob_main(&cj);
