@@ -156,6 +156,12 @@ int  wtz_zindex_build(wtz_ctx_t *ctx);
 /* The same index for the listed reads only (ascending ids); every other read gets an empty slice.  For read sets whose whole z-index
  * (16 B per base) does not fit beside the scratch pool: the caller rebuilds it per batch of queries from the batch's queries + candidates. */
 int  wtz_zindex_build_subset(wtz_ctx_t *ctx, const uint32_t *ids, uint32_t n);
+/* Several GPUs: the pairs of a batch are dealt by CANDIDATE id, so a device only ever walks the z-mers of its own share of the
+ * reads as candidates - the index above then holds that share only (wtz_zindex_build_subset once) - but it needs the table of every QUERY of
+ * the batch (hzm_aln.h:70-115 builds exactly that table per query, wtzmo.c:842-845).  This call builds a second, small index of the listed
+ * reads (ascending ids) that the pair stages read the query side from; it is rebuilt per batch and dropped by any rebuild of the index above
+ * or by ids == NULL, n == 0.  Results are identical to one index holding all reads. */
+int  wtz_zindex_build_queries(wtz_ctx_t *ctx, const uint32_t *ids, uint32_t n);
 
 /* A3. cand: nq rows of (ncand+1) u64 `id<<32|ol`; ncand_io[i]: in = entries already in row i
  * (candidate heaps carried across -G index parts, else 0), out = entries after this index part.

@@ -27,6 +27,7 @@
 #include <errno.h>
 #include <sys/stat.h>
 #include "wtz_host.h"
+#include "wtz_ovlb.h"
 
 static int usage(void){
 	printf(
@@ -42,7 +43,8 @@ static int usage(void){
 	" -z <int> -Z <int> -l <int> -y <int> -R <int> -r <int> -q <int>  z-mer windows [10,64,2,800,200,300,100]\n"
 	" -U <float>x5 | -U -1   dot-matrix engine    -A <int> -B <int> candidates / best [500,100]\n"
 	" -w -e -W -M -X -O -E -T  alignment [50,800,3200,2,-5,-3,-1,-50]   -s <int> -m <float> [200,0.5]\n"
-	" --gpu <int> | --gpus <int> (one process, N GPUs, ONE .ovl identical to -t 1)  --pool-gb <int> --batch <int> --stats <file>\n");
+	" --gpu <int> | --gpus <int> (one process, N GPUs, ONE .ovl identical to -t 1)  --pool-gb <int> --batch <int> --stats <file>\n"
+	" --shard-index  --zindex-batch <0|1>  --binary-out (64-byte records, include/wtz_ovlb.h; read by wtgbo --binary-in / wtovl)\n");
 	return 1;
 }
 
@@ -75,6 +77,9 @@ typedef struct eng_s {
 	double ing_ms; uint64_t ing_bytes;      /* f4: kernel time / algorithmic bytes of the device ingest at load time (wtz_upload_reads_ascii) */
 	int zbatch;                 /* --zindex-batch (automatic above ~2.4 Gbp of reads): the z-mer index is rebuilt per batch of queries for the batch's queries + candidates instead
 	                             * of once for all reads (16 B per base: 160 GB at BASELINE configs[3]) */
+	int binary_out;             /* --binary-out: 64-byte binary records behind a name table (include/wtz_ovlb.h) instead of the 17 text columns; the CIGAR text is not fetched */
+	int zsplit;                 /* several parts (devices or ranks): part d's z-mer index holds the candidate side of the reads = d (mod nparts) only, the queries of a batch get their own small
+	                             * index per batch (wtz_zindex_build_queries) - the replicated all-reads build (0.135 s of a 3.2 s configs[2] step, not divided by N) becomes 1 / N of it */
 	int shard;                  /* --shard-index: the k-mer index is sharded by read-id range over the devices (reads and z-index stay replicated); output == unsharded */
 	uint32_t ndev; int devs[8]; wtz_ctx_t *ctxs[8];      /* --gpus N / --gpu-list: one context per device, reads + both indexes replicated; ctx == ctxs[0] */
 	uint64_t pair_bp, n_pairs, nrec;
@@ -91,7 +96,7 @@ typedef struct eng_s {
 	pending_t pend;
 	/* stats */
 	char *cig_keep[16]; uint64_t cig_keep_cap[16];      /* page-locked CIGAR text buffer of worker w, kept across steps (pinning is the expensive part) */
-	double t_gpu, t_commit, t_call[6], t_io[2];      /* t_io: waiting for the writer thread before a text buffer is reused / at the end of the run */      /* t_call: wall seconds inside wtz_candidates / pairs_seed / pairs_windows / pairs_align / fetch_cigar_text / planning */
+	double t_gpu, t_commit, t_zbatch, t_call[6], t_io[2];      /* t_io: waiting for the writer thread before a text buffer is reused / at the end of the run */      /* t_call: wall seconds inside wtz_candidates / pairs_seed / pairs_windows / pairs_align / fetch_cigar_text / planning */
 	uint64_t spec_pairs, used_pairs, spec_items, used_items, spec_queries, used_queries, n_batches;
 	double extra_ms[6]; uint64_t extra_u64[7];      /* counters of the cloned contexts */
 } eng_t;
@@ -109,13 +114,22 @@ void wtzmo_set_dist(int rank, int world, wtz_dist_bcast_fn b, wtz_dist_send_fn s
 	g_dist.rank = rank; g_dist.world = world < 1 ? 1 : world; g_dist.bcast = b; g_dist.send = sd; g_dist.recv = rv;
 }
 #define WTZ_DIST_MAX 16
-enum { WTZ_CMD_DONE = 1, WTZ_CMD_PAIRS = 2, WTZ_CMD_CAND_BEGIN = 3, WTZ_CMD_CAND_END = 4, WTZ_CMD_GRP_BEGIN = 5, WTZ_CMD_GRP_END = 6 };
-typedef struct { uint64_t cmd, count[WTZ_DIST_MAX]; } wtz_dist_hdr_t;
+enum { WTZ_CMD_DONE = 1, WTZ_CMD_PAIRS = 2, WTZ_CMD_CAND_BEGIN = 3, WTZ_CMD_CAND_END = 4, WTZ_CMD_GRP_BEGIN = 5, WTZ_CMD_GRP_END = 6,
+       WTZ_CMD_ZIDX = 7,       /* the z-mer index of the batch: arg[0] queries (their ids follow as a broadcast) for the query-side index of every rank; arg[1] != 0: count[r] candidate
+                                * reads (ids sent to rank r) for rank r's per-batch candidate-side index (--zindex-batch) */
+       WTZ_CMD_ABORT = 8 };    /* rank 0 -> all: some rank failed; every rank leaves with exit code 1 (the reference's convention for every error: list.h:64-67) */
+typedef struct { uint64_t cmd, arg[2], count[WTZ_DIST_MAX]; } wtz_dist_hdr_t;
+/* Every reply of a rank > 0 starts with a status word: 0 = fine, 1 = scratch pool too small (the range is halved and redone), 2 = this rank failed (its own
+ * stderr says why).  On 2, rank 0 finishes the round of the exchange it is in (the other ranks' replies are already on their way), broadcasts WTZ_CMD_ABORT
+ * and every process exits 1 - nobody is left blocked in a receive. */
+enum { WTZ_ST_OK = 0, WTZ_ST_AGAIN = 1, WTZ_ST_FAILED = 2 };
 
-/* The pairs of a range are dealt round-robin to the PARTS of a batch, one part per GPU (--gpus N; one part otherwise): pair g of the
- * plan is local pair g / nparts of part g % nparts.  Every device stage is pure in its pairs, so a part runs pair seeding, windows,
- * alignment and CIGAR rendering of its share on its own context, all parts side by side on their own host threads; the commit reads
- * the results through PART_OF / LOCAL_OF in the plan's order, i.e. the output does not depend on the number of parts. */
+/* The pairs of a range are dealt to the PARTS of a batch, one part per GPU (--gpus N, or one rank per GPU; one part otherwise): pair
+ * (q, c) belongs to part c % nparts.  Every device stage is pure in its pairs, so a part runs pair seeding, windows, alignment and
+ * CIGAR rendering of its share on its own context, all parts side by side; the commit reads the results through PART_OF / LOCAL_OF
+ * in the plan's order, i.e. the output does not depend on the number of parts.  Dealing by candidate (round 4; it was round-robin)
+ * is what lets the z-mer index be split: part d walks only reads = d (mod nparts) as candidates, so its index holds the candidate side
+ * of that residue class only (1 / nparts of the build) plus a small query-side index of the batch's queries (wtz_zindex_build_queries). */
 typedef struct {
 	wtz_ctx_t *ctx; int remote;                 /* remote > 0: the part is computed by that rank (ctx == NULL here) */
 	uint32_t *pq, *pc; uint32_t npair, cappair;
@@ -126,9 +140,11 @@ typedef struct {
 	struct eng_s *E; int again;                /* result of the last part_stages run (1 = scratch pool too small) */
 	uint32_t *cq_ids, *cq_nr; uint64_t *cq_rows; uint32_t cq_n, cq_cap;      /* this device's share (every nparts-th query) of the candidate request in flight */
 } part_t;
-#define PART_OF(b, g) (&(b)->parts[(g) % (b)->nparts])
-#define CPART_OF(b, g) (&(b)->cparts[(g) % (b)->nparts])      /* commit side */
-#define LOCAL_OF(b, g) ((g) / (b)->nparts)
+#define PIDX(part, local) (((uint32_t)(local) << 4) | (uint32_t)(part))      /* a pair of the plan: part (device / rank) in the low 4 bits, its index inside the part above */
+#define PART_OF(b, g) (&(b)->parts[(g) & 15u])
+#define CPART_OF(b, g) (&(b)->cparts[(g) & 15u])      /* commit side */
+#define LOCAL_OF(b, g) ((g) >> 4)
+#define DEAL_PART(np, q, c) ((c) % (np))               /* the part a pair is dealt to: by CANDIDATE id, so that a device only needs the candidate-side z-mers of its own residue class of reads */
 
 typedef struct {       /* one batch in flight */
 	eng_t *E; wtz_ctx_t *ctx; uint64_t seq;    /* ctx: the context of the candidate requests (= parts[0].ctx) */
@@ -168,22 +184,65 @@ static uint32_t nbest_of(const eng_t *E, uint32_t id){
 	return nb < E->P.nbest ? E->P.nbest : nb;
 }
 
-/* ---------------- output: the commit formats the 16 numeric columns of a record into large chunks; the ~6 KB CIGAR text of a
- * record is NOT copied: the chunk carries an iovec that points into the page-locked buffer wtz_fetch_cigar_text filled, and a
- * writer thread hands the whole list to writev().  A worker owns two such buffers and alternates between them per batch; before a
- * buffer is filled again it waits until every chunk that points into it has been written (ext_busy). ---- */
+/* ---------------- output.  The commit only QUEUES a record (its integers + a pointer to the CIGAR text in the page-locked buffer that
+ * wtz_fetch_cigar_text filled); a writer thread turns queued records into bytes - the 16 numeric columns as text (print_hits_wtzmo,
+ * wtzmo.c:1235-1244) with the ~6 KB CIGAR text by reference in one writev(), or 64-byte binary records (--binary-out, include/wtz_ovlb.h) -
+ * so that formatting (0.15-0.18 s of a 0.45 s commit at configs[2] when the commit thread did it) is off the one sequential stream of the run.
+ * A part owns two text buffers and alternates between them per range; before a buffer is filled again it waits until every chunk that
+ * points into it has been written (ext_busy). ---- */
 #define OW_MAX_EXT 16
-typedef struct ochunk { char *buf; size_t n, cap, bytes; struct iovec *iov; int niov, capiov; unsigned ext_mask; struct ochunk *next; } ochunk_t;
+typedef struct {
+	uint32_t pb1, pb2; int32_t tb, te, qb, qe, score, mat, mis, ins, del, aln;
+	const char *cigar; uint32_t cigar_len; uint8_t dir2, kind; int8_t ext;      /* kind 0: an overlap record; 1: `cigar` is a heap string written verbatim (the "# ..." lines of -N) and freed; 2: a record whose CIGAR text is a heap copy, freed */
+} orec_t;
+typedef struct ochunk { orec_t *rec; int n, cap; size_t payload; unsigned ext_mask; struct ochunk *next; } ochunk_t;
 typedef struct {
 	FILE *fp; int fd; pthread_t th; pthread_mutex_t mu; pthread_cond_t cv, cv_ext;
 	ochunk_t *head, *tail, *freelist, *cur; int done, started;
 	int ext_busy[OW_MAX_EXT];
+	const hx_read_t *reads; int binary;
+	char *fmt; size_t capfmt; struct iovec *iov; size_t capiov;      /* the writer thread's formatting buffer and vector */
+	double t_format, t_write;                                        /* writer-thread seconds (reported, not on the commit's clock) */
 } owriter_t;
 static owriter_t g_ow;
-#define OCHUNK_BYTES ((size_t)4 << 20)
-#define OCHUNK_IOV 16384
+#define OCHUNK_RECS 8192
 #define OCHUNK_PAYLOAD ((size_t)32 << 20)
 
+static inline size_t put_str(char *o, const char *s){ size_t n = strlen(s); memcpy(o, s, n); return n; }
+static inline size_t put_int(char *o, long long v){          /* as printf("%d") */
+	char t[24]; int n = 0; size_t k = 0;
+	unsigned long long u = v < 0 ? 0ULL - (unsigned long long)v : (unsigned long long)v;
+	do { t[n++] = (char)('0' + u % 10); u /= 10; } while(u);
+	if(v < 0) o[k++] = '-';
+	while(n) o[k++] = t[--n];
+	return k;
+}
+/* columns 1-16 + the tab in front of the CIGAR column (print_hits_wtzmo, wtzmo.c:1235-1244): the integer columns by hand (a 16-field sprintf per
+ * record was half of the formatting time); the identity column stays with printf - its rounding of the binary quotient is part of the output */
+static size_t format_record(const hx_read_t *reads, const orec_t *h, char *o){
+	const int aln = h->aln == 0 ? 1 : h->aln;
+	size_t k = 0;
+	k += put_str(o + k, reads[h->pb1].name); o[k++] = '\t'; o[k++] = '+'; o[k++] = '\t';
+	k += put_int(o + k, (long long)reads[h->pb1].len); o[k++] = '\t'; k += put_int(o + k, h->tb); o[k++] = '\t'; k += put_int(o + k, h->te); o[k++] = '\t';
+	k += put_str(o + k, reads[h->pb2].name); o[k++] = '\t'; o[k++] = "+-"[h->dir2]; o[k++] = '\t';
+	k += put_int(o + k, (long long)reads[h->pb2].len); o[k++] = '\t'; k += put_int(o + k, h->qb); o[k++] = '\t'; k += put_int(o + k, h->qe); o[k++] = '\t';
+	k += put_int(o + k, h->score); o[k++] = '\t';
+	k += (size_t)sprintf(o + k, "%0.3f", 1.0 * h->mat / aln); o[k++] = '\t';
+	k += put_int(o + k, h->mat); o[k++] = '\t'; k += put_int(o + k, h->mis); o[k++] = '\t'; k += put_int(o + k, h->ins); o[k++] = '\t'; k += put_int(o + k, h->del); o[k++] = '\t';
+	return k;
+}
+static void ow_write_all(owriter_t *w, struct iovec *iov, size_t niov){
+	for(size_t i = 0; i < niov;){
+		size_t n = niov - i; if(n > 1024) n = 1024;
+		ssize_t r = writev(w->fd, iov + i, (int)n);
+		if(r < 0){ if(errno == EINTR) continue; fprintf(stderr, " -- write error on the output file: %s --\n", strerror(errno)); DIE_NOW(); }
+		while(r > 0 && i < niov){        /* consume what was written; a partially written entry is advanced in place */
+			if((size_t)r >= iov[i].iov_len){ r -= (ssize_t)iov[i].iov_len; i++; }
+			else { iov[i].iov_base = (char*)iov[i].iov_base + r; iov[i].iov_len -= (size_t)r; r = 0; }
+		}
+		while(i < niov && iov[i].iov_len == 0) i++;
+	}
+}
 static void *owriter_main(void *arg){
 	owriter_t *w = (owriter_t*)arg;
 	for(;;){
@@ -193,28 +252,48 @@ static void *owriter_main(void *arg){
 		if(c == NULL){ pthread_mutex_unlock(&w->mu); break; }
 		w->head = c->next; if(w->head == NULL) w->tail = NULL;
 		pthread_mutex_unlock(&w->mu);
-		for(int i = 0; i < c->niov;){
-			int n = c->niov - i; if(n > 1024) n = 1024;
-			ssize_t r = writev(w->fd, c->iov + i, n);
-			if(r < 0){ if(errno == EINTR) continue; fprintf(stderr, " -- write error on the output file: %s --\n", strerror(errno)); DIE_NOW(); }
-			while(r > 0 && i < c->niov){        /* consume what was written; a partially written entry is advanced in place */
-				if((size_t)r >= c->iov[i].iov_len){ r -= (ssize_t)c->iov[i].iov_len; i++; }
-				else { c->iov[i].iov_base = (char*)c->iov[i].iov_base + r; c->iov[i].iov_len -= (size_t)r; r = 0; }
+		const double tf0 = now_s();
+		/* upper bound of the formatted bytes of the chunk (CIGAR text by reference does not count) */
+		size_t need = 0;
+		for(int i = 0; i < c->n; i++){ const orec_t *h = &c->rec[i]; need += w->binary ? sizeof(wtz_ovlb_rec_t) : (h->kind == 1 ? 0 : strlen(w->reads[h->pb1].name) + strlen(w->reads[h->pb2].name) + 256 + (h->cigar && h->cigar_len < 256 ? h->cigar_len : 0)); }
+		if(need > w->capfmt){ w->capfmt = need + need / 2 + 4096; free(w->fmt); w->fmt = (char*)hx_realloc(NULL, w->capfmt); }
+		if((size_t)c->n * 3 + 4 > w->capiov){ w->capiov = (size_t)c->n * 3 + 4; w->iov = (struct iovec*)hx_realloc(w->iov, sizeof(struct iovec) * w->capiov); }
+		size_t k = 0, niov = 0, run0 = 0;        /* [run0, k): formatted bytes not yet covered by a vector entry */
+#define OW_FLUSH_RUN() do { if(k > run0){ w->iov[niov].iov_base = w->fmt + run0; w->iov[niov].iov_len = k - run0; niov++; run0 = k; } } while(0)
+		for(int i = 0; i < c->n; i++){
+			const orec_t *h = &c->rec[i];
+			if(h->kind == 1){ OW_FLUSH_RUN(); if(!w->binary){ w->iov[niov].iov_base = (void*)h->cigar; w->iov[niov].iov_len = h->cigar_len; niov++; } continue; }
+			if(w->binary){
+				wtz_ovlb_rec_t r; memset(&r, 0, sizeof r);
+				r.id1 = h->pb1; r.id2 = h->pb2; r.aln = (uint32_t)(h->aln == 0 ? 1 : h->aln); r.tb = h->tb; r.te = h->te; r.qb = h->qb; r.qe = h->qe; r.score = h->score;
+				r.mat = h->mat; r.mis = h->mis; r.ins = h->ins; r.del = h->del; r.dir2 = h->dir2;
+				memcpy(w->fmt + k, &r, sizeof r); k += sizeof r; continue;
 			}
+			k += format_record(w->reads, h, w->fmt + k);
+			if(h->cigar == NULL){ w->fmt[k++] = '0'; w->fmt[k++] = 'M'; }
+			else if(h->cigar_len < 256 && h->kind == 0){ memcpy(w->fmt + k, h->cigar, h->cigar_len); k += h->cigar_len; }
+			else { OW_FLUSH_RUN(); w->iov[niov].iov_base = (void*)h->cigar; w->iov[niov].iov_len = h->cigar_len; niov++; }
+			w->fmt[k++] = '\n';
 		}
+		OW_FLUSH_RUN();
+#undef OW_FLUSH_RUN
+		const double tf1 = now_s();
+		ow_write_all(w, w->iov, niov);
+		for(int i = 0; i < c->n; i++) if(c->rec[i].kind) free((void*)c->rec[i].cigar);
 		pthread_mutex_lock(&w->mu);
+		w->t_format += tf1 - tf0; w->t_write += now_s() - tf1;
 		for(int e = 0; e < OW_MAX_EXT; e++) if(c->ext_mask & (1u << e)) w->ext_busy[e]--;
 		if(c->ext_mask) pthread_cond_broadcast(&w->cv_ext);
-		c->n = 0; c->niov = 0; c->bytes = 0; c->ext_mask = 0; c->next = w->freelist; w->freelist = c;
+		c->n = 0; c->payload = 0; c->ext_mask = 0; c->next = w->freelist; w->freelist = c;
 		pthread_mutex_unlock(&w->mu);
 	}
 	return NULL;
 }
-static void out_start(FILE *fp){
+static void out_start(FILE *fp, const hx_read_t *reads, int binary){
 	owriter_t *w = &g_ow;
 	if(!w->started){ pthread_mutex_init(&w->mu, NULL); pthread_cond_init(&w->cv, NULL); pthread_cond_init(&w->cv_ext, NULL); }
 	fflush(fp);
-	w->fp = fp; w->fd = fileno(fp); w->head = w->tail = NULL; w->cur = NULL; w->done = 0; w->started = 1;
+	w->fp = fp; w->fd = fileno(fp); w->head = w->tail = NULL; w->cur = NULL; w->done = 0; w->started = 1; w->reads = reads; w->binary = binary; w->t_format = w->t_write = 0;
 	memset(w->ext_busy, 0, sizeof w->ext_busy);
 	pthread_create(&w->th, NULL, owriter_main, w);
 }
@@ -227,36 +306,23 @@ static void out_submit(owriter_t *w){
 	pthread_cond_signal(&w->cv);
 	pthread_mutex_unlock(&w->mu);
 }
-/* room for `need` more formatted bytes (and a few iovec entries) in the current chunk */
-static char *out_space(size_t need){
+/* the slot of the next queued record in the chunk under construction */
+static orec_t *out_slot(size_t payload){
 	owriter_t *w = &g_ow;
-	if(w->cur && (w->cur->n + need > w->cur->cap || w->cur->niov + 4 > w->cur->capiov || w->cur->bytes > OCHUNK_PAYLOAD)) out_submit(w);
+	if(w->cur && (w->cur->n == w->cur->cap || w->cur->payload > OCHUNK_PAYLOAD)) out_submit(w);
 	if(w->cur == NULL){
 		pthread_mutex_lock(&w->mu);
-		ochunk_t **pp = &w->freelist, *c = NULL;
-		for(; *pp; pp = &(*pp)->next) if((*pp)->cap >= need){ c = *pp; *pp = c->next; break; }
+		ochunk_t *c = w->freelist; if(c) w->freelist = c->next;
 		pthread_mutex_unlock(&w->mu);
-		if(c == NULL){
-			c = (ochunk_t*)hx_realloc(NULL, sizeof(ochunk_t)); c->cap = need > OCHUNK_BYTES ? need : OCHUNK_BYTES; c->buf = (char*)hx_realloc(NULL, c->cap);
-			c->capiov = OCHUNK_IOV; c->iov = (struct iovec*)hx_realloc(NULL, sizeof(struct iovec) * (size_t)c->capiov);
-		}
-		c->n = 0; c->niov = 0; c->bytes = 0; c->ext_mask = 0; c->next = NULL; w->cur = c;
+		if(c == NULL){ c = (ochunk_t*)hx_realloc(NULL, sizeof(ochunk_t)); c->cap = OCHUNK_RECS; c->rec = (orec_t*)hx_realloc(NULL, sizeof(orec_t) * (size_t)c->cap); }
+		c->n = 0; c->payload = 0; c->ext_mask = 0; c->next = NULL; w->cur = c;
 	}
-	return w->cur->buf + w->cur->n;
+	w->cur->payload += payload;
+	return &w->cur->rec[w->cur->n++];
 }
-/* n bytes were formatted at the pointer out_space returned */
-static void out_advance(size_t n){
-	ochunk_t *c = g_ow.cur;
-	char *p = c->buf + c->n;
-	if(c->niov && (char*)c->iov[c->niov - 1].iov_base + c->iov[c->niov - 1].iov_len == p) c->iov[c->niov - 1].iov_len += n;
-	else { c->iov[c->niov].iov_base = p; c->iov[c->niov].iov_len = n; c->niov++; }
-	c->n += n; c->bytes += n;
-}
-/* bytes that live in the external buffer `ext` (page-locked CIGAR text) follow: by reference */
-static void out_ext(const char *p, size_t n, int ext){
-	owriter_t *w = &g_ow; ochunk_t *c = w->cur;
-	c->iov[c->niov].iov_base = (void*)p; c->iov[c->niov].iov_len = n; c->niov++; c->bytes += n;
-	if(!(c->ext_mask & (1u << ext))){ c->ext_mask |= 1u << ext; pthread_mutex_lock(&w->mu); w->ext_busy[ext]++; pthread_mutex_unlock(&w->mu); }
+/* a line written verbatim (takes ownership of the heap string) */
+static void out_raw(char *text, size_t n){
+	orec_t *r = out_slot(n); memset(r, 0, sizeof *r); r->kind = 1; r->cigar = text; r->cigar_len = (uint32_t)n; r->ext = -1;
 }
 /* the external buffer `ext` is about to be overwritten: everything that points into it must be on the stream.  The chunk under
  * construction (g_ow.cur) belongs to whoever holds E->mu (the committing worker) and is never looked at here: every commit hands
@@ -269,7 +335,7 @@ static void out_wait_ext(int ext){
 	while(w->ext_busy[ext] > 0) pthread_cond_wait(&w->cv_ext, &w->mu);
 	pthread_mutex_unlock(&w->mu);
 }
-/* everything formatted so far is on the stream when this returns */
+/* everything queued so far is on the stream when this returns */
 static void out_finish(void){
 	owriter_t *w = &g_ow;
 	out_submit(w);
@@ -291,8 +357,8 @@ static void flush_pending(eng_t *E){
 			for(size_t i = 0; i < p->nseed; i++){
 				const seed_t *s = &p->seeds[i];
 				if(s->closed) continue;
-				char *o = out_space(strlen(reads[p->rd_id].name) + strlen(reads[s->pb2].name) + 96);
-				out_advance((size_t)sprintf(o, "# %s\t%c\t%d\t%s\t%c\t%d\t%d\n", reads[p->rd_id].name, '+', reads[p->rd_id].len,
+				char *o = (char*)hx_realloc(NULL, strlen(reads[p->rd_id].name) + strlen(reads[s->pb2].name) + 96);
+				out_raw(o, (size_t)sprintf(o, "# %s\t%c\t%d\t%s\t%c\t%d\t%d\n", reads[p->rd_id].name, '+', reads[p->rd_id].len,
 					reads[s->pb2].name, "+-"[s->dir], reads[s->pb2].len, s->ovl));
 			}
 		} else {
@@ -304,7 +370,7 @@ static void flush_pending(eng_t *E){
 				int r1 = (int)reads[h->pb1].len - h->te, r2 = (int)reads[h->pb2].len - h->qe;
 				uint32_t x2 = (uint32_t)(r1 < r2 ? r1 : r2);
 				if(x1 + x2 <= 200u){ E->rdcovs[h->pb1]++; E->rdcovs[h->pb2]++; }          /* max_unalign_in_dovetail, wtzmo.c:175 */
-				/* the record text itself was formatted when the hit was committed (emit_record): same order, same bytes */
+				/* the record itself was queued for the writer thread when the hit was committed (emit_record): same order, same bytes */
 			}
 		}
 	}
@@ -335,42 +401,19 @@ static void pend_hit(pending_t *p, const hit_t *h){
 	p->hits[p->nhit++] = *h;
 }
 
-/* one .ovl line (print_hits_wtzmo, wtzmo.c:1170-1249) into the output stream; cigar == NULL prints "0M" */
-static inline size_t put_str(char *o, const char *s){ size_t n = strlen(s); memcpy(o, s, n); return n; }
-static inline size_t put_int(char *o, long long v){          /* as printf("%d") */
-	char t[24]; int n = 0; size_t k = 0;
-	unsigned long long u = v < 0 ? 0ULL - (unsigned long long)v : (unsigned long long)v;
-	do { t[n++] = (char)('0' + u % 10); u /= 10; } while(u);
-	if(v < 0) o[k++] = '-';
-	while(n) o[k++] = t[--n];
-	return k;
-}
+/* one .ovl line (print_hits_wtzmo, wtzmo.c:1170-1249) queued for the writer thread; cigar == NULL prints "0M" */
 static void emit_record(eng_t *E, const hit_t *h, const char *cigar, size_t cigar_len, int ext){
-	const double te0 = now_s();
-	const hx_read_t *reads = E->st.reads;
-	const int aln = h->aln == 0 ? 1 : h->aln;
-	const int by_ref = (cigar && ext >= 0 && ext < OW_MAX_EXT && cigar_len >= 256);
-	char *o = out_space(strlen(reads[h->pb1].name) + strlen(reads[h->pb2].name) + 256 + (by_ref ? 0 : cigar_len));
-	/* the integer columns by hand (a 16-field sprintf per record was half of the commit's formatting time); the identity column stays with
-	 * printf: its rounding of the binary quotient is part of the output */
-	size_t k = 0;
-	k += put_str(o + k, reads[h->pb1].name); o[k++] = '\t'; o[k++] = '+'; o[k++] = '\t';
-	k += put_int(o + k, (long long)reads[h->pb1].len); o[k++] = '\t'; k += put_int(o + k, h->tb); o[k++] = '\t'; k += put_int(o + k, h->te); o[k++] = '\t';
-	k += put_str(o + k, reads[h->pb2].name); o[k++] = '\t'; o[k++] = "+-"[h->dir2]; o[k++] = '\t';
-	k += put_int(o + k, (long long)reads[h->pb2].len); o[k++] = '\t'; k += put_int(o + k, h->qb); o[k++] = '\t'; k += put_int(o + k, h->qe); o[k++] = '\t';
-	k += put_int(o + k, h->score); o[k++] = '\t';
-	k += (size_t)sprintf(o + k, "%0.3f", 1.0 * h->mat / aln); o[k++] = '\t';
-	k += put_int(o + k, h->mat); o[k++] = '\t'; k += put_int(o + k, h->mis); o[k++] = '\t'; k += put_int(o + k, h->ins); o[k++] = '\t'; k += put_int(o + k, h->del); o[k++] = '\t';
-	if(by_ref){
-		out_advance(k);
-		out_ext(cigar, cigar_len, ext);
-		o = g_ow.cur->buf + g_ow.cur->n; o[0] = '\n'; out_advance(1);       /* out_space reserved 256 spare bytes */
-		E->t_call[5] += now_s() - te0;
-		return;
+	(void)E;
+	orec_t *r = out_slot(cigar_len + 128);
+	r->pb1 = h->pb1; r->pb2 = h->pb2; r->tb = h->tb; r->te = h->te; r->qb = h->qb; r->qe = h->qe; r->score = h->score;
+	r->mat = h->mat; r->mis = h->mis; r->ins = h->ins; r->del = h->del; r->aln = h->aln; r->dir2 = (uint8_t)h->dir2; r->kind = 0;
+	r->cigar = cigar; r->cigar_len = (uint32_t)cigar_len; r->ext = (int8_t)ext;
+	if(cigar && cigar_len >= 256 && !(ext >= 0 && ext < OW_MAX_EXT)){      /* a text buffer the writer does not track (parts beyond OW_MAX_EXT / 2): the record takes a copy */
+		char *cp = (char*)hx_realloc(NULL, cigar_len); memcpy(cp, cigar, cigar_len); r->cigar = cp; r->kind = 2;
+	} else if(cigar && cigar_len >= 256){
+		owriter_t *w = &g_ow; ochunk_t *c = w->cur;
+		if(!(c->ext_mask & (1u << ext))){ c->ext_mask |= 1u << ext; pthread_mutex_lock(&w->mu); w->ext_busy[ext]++; pthread_mutex_unlock(&w->mu); }
 	}
-	if(cigar){ memcpy(o + k, cigar, cigar_len); k += cigar_len; } else { o[k++] = '0'; o[k++] = 'M'; }
-	o[k++] = '\n';
-	out_advance(k);
 }
 
 __attribute__((unused)) static char *cigar_text(const uint32_t *c, uint32_t n){        /* kswx.h:1093-1120 */
@@ -502,7 +545,7 @@ static void commit_query(eng_t *E, batch_t *b, uint32_t slot){
 			H.pb1 = pbid; H.pb2 = s->pb2; H.dir2 = s->dir; H.score = x->score;
 			H.tb = x->tb; H.te = x->te; H.qb = x->qb; H.qe = x->qe; H.mat = x->mat; H.mis = x->mis; H.ins = x->ins; H.del = x->del; H.aln = x->aln;
 			pend_hit(pd, &H);
-			emit_record(E, &H, pt->cig + x->text_off, x->text_len, pt->cig_ext);
+			if(E->binary_out) emit_record(E, &H, NULL, 0, -1); else emit_record(E, &H, pt->cig + x->text_off, x->text_len, pt->cig_ext);
 			{   /* dovetail / containment bookkeeping (wtzmo.c:1065-1100) */
 				const uint32_t len1 = E->rdlen[H.pb1], len2 = E->rdlen[H.pb2];
 				uint32_t x1 = (uint32_t)(H.tb < H.qb ? H.tb : H.qb);
@@ -532,7 +575,10 @@ static void commit_query(eng_t *E, batch_t *b, uint32_t slot){
 }
 
 /* ---------------- one batch: plan -> GPU -> commit ---------------- */
-#define TRY_WTZ(rc, what) do { if((rc) == WTZ_E_POOL) return 1; DIE_WTZ(rc, what); } while(0)
+/* a device stage of a part failed: 1 = scratch pool too small (nothing changed, the range is halved), otherwise fatal - at once in a one-process run; between
+ * ranks the part reports WTZ_ST_FAILED so that the exchange in flight is finished and rank 0 can end every rank in-band (ranks_abort) */
+#define TRY_WTZ(rc, what) do { if((rc) == WTZ_E_POOL) return WTZ_ST_AGAIN; \
+	if((rc) != WTZ_OK && g_dist.world > 1){ fprintf(stderr, " -- rank %d: %s failed: %s --\n", g_dist.rank, what, wtz_last_error()); return WTZ_ST_FAILED; } DIE_WTZ(rc, what); } while(0)
 
 /* under E->mu: pairs of slots [s0,s1) whose candidate pair is not closed right now */
 static void plan_pairs(eng_t *E, batch_t *b, uint32_t s0, uint32_t s1){
@@ -548,10 +594,12 @@ static void plan_pairs(eng_t *E, batch_t *b, uint32_t s0, uint32_t s1){
 			b->rowpair[(size_t)s * E->stride + k] = 0xFFFFFFFFu;
 			if((uint32_t)e == 0 || id2 == 0xFFFFFFFFu) continue;
 			if(hx_set_has(&E->closed, hx_pair_key(q, id2))) continue;
-			part_t *pt = PART_OF(b, b->npair);              /* round-robin: pair g is local pair g / nparts of part g % nparts */
+			const uint32_t dpart = DEAL_PART(b->nparts, q, id2);
+			part_t *pt = &b->parts[dpart];
 			if(pt->npair == pt->cappair){ pt->cappair = pt->cappair ? pt->cappair * 2 : 4096; pt->pq = (uint32_t*)hx_realloc(pt->pq, pt->cappair * 4); pt->pc = (uint32_t*)hx_realloc(pt->pc, pt->cappair * 4); }
+			if(pt->npair >= (1u << 28)){ fprintf(stderr, " -- more than 2^28 pairs of one range on one device --\n"); DIE_NOW(); }
 			pt->pq[pt->npair] = q; pt->pc[pt->npair] = id2; pt->npair++;
-			b->rowpair[(size_t)s * E->stride + k] = b->npair; b->npair++;
+			b->rowpair[(size_t)s * E->stride + k] = PIDX(dpart, pt->npair - 1); b->npair++;
 		}
 	}
 }
@@ -605,8 +653,11 @@ static int part_stages(eng_t *E, part_t *b){
 			b->aln = (wtz_aln_result_t*)hx_realloc(b->aln, sizeof(wtz_aln_result_t) * b->nitem);
 			{ const double tc0 = now_s(); rc = wtz_pairs_align(b->ctx, b->it_pair, b->it_dir, b->nitem, b->aln); b->t_call[3] += now_s() - tc0; } TRY_WTZ(rc, "wtz_pairs_align");
 			uint64_t tot = 0; for(uint32_t i = 0; i < b->nitem; i++) tot += b->aln[i].text_len;
-			if(!part_text_buffer(b, tot)) return 1;
-			{ const double tc0 = now_s(); rc = wtz_fetch_cigar_text(b->ctx, b->cig, tot); b->t_call[4] += now_s() - tc0; } TRY_WTZ(rc, "wtz_fetch_cigar_text");     /* rendered on the device */
+			if(E->binary_out) tot = 0;              /* binary records carry no CIGAR column (what `cut -f1-16` drops in the zmo pipeline): 3 GB per configs[2] step stay on the device */
+			else {
+				if(!part_text_buffer(b, tot)) return WTZ_ST_AGAIN;
+				{ const double tc0 = now_s(); rc = wtz_fetch_cigar_text(b->ctx, b->cig, tot); b->t_call[4] += now_s() - tc0; } TRY_WTZ(rc, "wtz_fetch_cigar_text");     /* rendered on the device */
+			}
 			b->ncig = tot;
 		}
 	}
@@ -627,6 +678,23 @@ static int gpu_stages(eng_t *E, batch_t *b){
 	return again;
 }
 
+/* rank 0, at a boundary of the protocol (every other rank is waiting for the next request): end all ranks */
+static void ranks_abort(const char *why){
+	fprintf(stderr, " -- %s: ending all %d ranks --\n", why, g_dist.world);
+	wtz_dist_hdr_t h; memset(&h, 0, sizeof h); h.cmd = WTZ_CMD_ABORT;
+	g_dist.bcast(&h, sizeof h);
+	DIE_NOW();
+}
+/* test hook: WTZ_RANK_FAIL_AT="<rank>:<n>" makes that rank's n-th device-stage request fail (the in-band abort path must end every rank with exit code 1) */
+static int rank_fail_injected(void){
+	static int rank = -2, at = 0, seen = 0;
+	if(rank == -2){ const char *e = getenv("WTZ_RANK_FAIL_AT"); rank = -1; if(e && sscanf(e, "%d:%d", &rank, &at) != 2) rank = -1; }
+	if(rank != g_dist.rank) return 0;
+	if(++seen != at) return 0;
+	fprintf(stderr, " -- rank %d: injected failure of request %d (WTZ_RANK_FAIL_AT) --\n", g_dist.rank, at);
+	return 1;
+}
+
 /* rank 0: part r of the range is computed by rank r (part 0 here, meanwhile) */
 static int gpu_stages_ranks(eng_t *E, batch_t *b){
 	const int dm = E->P.dot_matrix;
@@ -635,12 +703,14 @@ static int gpu_stages_ranks(eng_t *E, batch_t *b){
 	g_dist.bcast(&h, sizeof h);
 	for(uint32_t r = 1; r < b->nparts; r++){ part_t *pt = &b->parts[r]; if(pt->npair){ g_dist.send(pt->pq, 4 * (uint64_t)pt->npair, (int)r); g_dist.send(pt->pc, 4 * (uint64_t)pt->npair, (int)r); } }
 	b->parts[0].E = E;
-	int again = b->parts[0].again = part_stages(E, &b->parts[0]);
+	int st = b->parts[0].again = rank_fail_injected() ? WTZ_ST_FAILED : part_stages(E, &b->parts[0]);
+	int failed = st == WTZ_ST_FAILED ? 0 : -1;      /* the rank that failed (its replies still complete the round) */
 	for(uint32_t r = 1; r < b->nparts; r++){
 		part_t *pt = &b->parts[r];
 		uint64_t rh[4]; g_dist.recv(rh, sizeof rh, (int)r);
 		pt->nitem = 0; pt->ncig = 0; pt->again = (int)rh[0];
-		if(rh[0]){ again = 1; continue; }
+		if(rh[0] == WTZ_ST_FAILED){ if(failed < 0) failed = (int)r; continue; }
+		if(rh[0]){ if(st == WTZ_ST_OK) st = WTZ_ST_AGAIN; continue; }
 		if(pt->npair == 0) continue;
 		pt->sum = (wtz_pair_summary_t*)hx_realloc(pt->sum, sizeof(wtz_pair_summary_t) * (pt->npair + 1));
 		g_dist.recv(pt->sum, sizeof(wtz_pair_summary_t) * (uint64_t)pt->npair, (int)r);
@@ -662,56 +732,86 @@ static int gpu_stages_ranks(eng_t *E, batch_t *b){
 			pt->ncig = rh[3];
 		}
 	}
+	if(failed >= 0){ char why[64]; snprintf(why, sizeof why, "rank %d failed in the device stages of a range", failed); ranks_abort(why); }
 	b->nitem = 0; for(uint32_t d = 0; d < b->nparts; d++) b->nitem += b->parts[d].nitem;
-	return again;
+	return st;
 }
 
-/* ranks > 0: serve rank 0's requests with this GPU until the overlap phase is over */
+/* the z-mer index of a batch on one context: `cl` (zbatch) = the candidate-side reads of this device for the batch, `ql` (several parts) = the batch's queries */
+static int zbuild_part(wtz_ctx_t *ctx, int have_c, const uint32_t *cl, uint32_t ncl, int have_q, const uint32_t *ql, uint32_t nql){
+	int rc = WTZ_OK;
+	if(have_c) rc = wtz_zindex_build_subset(ctx, cl, ncl);
+	if(rc == WTZ_OK && have_q) rc = wtz_zindex_build_queries(ctx, ql, nql);
+	return rc;
+}
+
+/* ranks > 0: serve rank 0's requests with this GPU until the overlap phase is over.  A failure here never ends the process on the spot: it is reported in the
+ * status word of the next reply (the requests in between are answered with empty payloads), and rank 0 ends all ranks with WTZ_CMD_ABORT. */
 static void remote_loop(eng_t *E, part_t *pt){
 	const int dm = E->P.dot_matrix; const int me = g_dist.rank;
+	int failed = 0;
+#define REMOTE_TRY(rc, what) do { if((rc) != WTZ_OK && !failed){ failed = 1; fprintf(stderr, " -- rank %d: %s failed: %s --\n", me, what, wtz_last_error()); } } while(0)
 	pt->E = E;
 	for(;;){
 		wtz_dist_hdr_t h; g_dist.bcast(&h, sizeof h);
 		if(h.cmd == WTZ_CMD_DONE) break;
+		if(h.cmd == WTZ_CMD_ABORT){ fprintf(stderr, " -- rank %d: abort requested by rank 0 --\n", me); DIE_NOW(); }
 		const uint32_t n = (uint32_t)h.count[me];
 		if(h.cmd == WTZ_CMD_PAIRS){
 			if(n > pt->cappair){ pt->cappair = n; pt->pq = (uint32_t*)hx_realloc(pt->pq, 4 * (size_t)n); pt->pc = (uint32_t*)hx_realloc(pt->pc, 4 * (size_t)n); }
 			if(n){ g_dist.recv(pt->pq, 4 * (uint64_t)n, 0); g_dist.recv(pt->pc, 4 * (uint64_t)n, 0); }
 			pt->npair = n;
-			const int again = part_stages(E, pt);
+			if(rank_fail_injected()) failed = 1;
+			const int again = failed ? WTZ_ST_FAILED : part_stages(E, pt);
+			if(again == WTZ_ST_FAILED) failed = 1;
 			uint64_t rh[4] = { (uint64_t)again, pt->nbox, pt->nitem, pt->ncig };
-			if(n == 0 || dm){ rh[1] = 0; rh[2] = 0; rh[3] = 0; }
+			if(n == 0 || dm || again){ rh[1] = 0; rh[2] = 0; rh[3] = 0; }
 			g_dist.send(rh, sizeof rh, 0);
 			if(again || n == 0) continue;
 			g_dist.send(pt->sum, sizeof(wtz_pair_summary_t) * (uint64_t)n, 0);
 			if(dm) continue;
 			if(pt->nbox) g_dist.send(pt->boxes, sizeof(wtz_winbox_t) * pt->nbox, 0);
 			if(pt->nitem){ g_dist.send(pt->aln, sizeof(wtz_aln_result_t) * (uint64_t)pt->nitem, 0); if(pt->ncig) g_dist.send(pt->cig, pt->ncig, 0); }
+		} else if(h.cmd == WTZ_CMD_ZIDX){
+			const uint32_t nql = (uint32_t)h.arg[0]; const int have_c = h.arg[1] != 0;
+			uint32_t *ql = (uint32_t*)hx_realloc(NULL, 4 * ((size_t)nql + 1)), *cl = (uint32_t*)hx_realloc(NULL, 4 * ((size_t)n + 1));
+			if(nql) g_dist.bcast(ql, 4 * (uint64_t)nql);
+			if(have_c && n) g_dist.recv(cl, 4 * (uint64_t)n, 0);
+			if(!failed){ int rc = zbuild_part(pt->ctx, have_c, cl, n, 1, ql, nql); REMOTE_TRY(rc, "the z-mer index of the batch"); }
+			free(ql); free(cl);
 		} else if(h.cmd == WTZ_CMD_CAND_BEGIN){
 			if(n > pt->cq_cap){ pt->cq_cap = n; pt->cq_ids = (uint32_t*)hx_realloc(pt->cq_ids, 4 * (size_t)n); pt->cq_nr = (uint32_t*)hx_realloc(pt->cq_nr, 4 * (size_t)n); pt->cq_rows = (uint64_t*)hx_realloc(pt->cq_rows, (size_t)n * E->stride * 8); }
 			pt->cq_n = n;
 			if(n){ g_dist.recv(pt->cq_ids, 4 * (uint64_t)n, 0); memset(pt->cq_rows, 0, (size_t)n * E->stride * 8); memset(pt->cq_nr, 0, 4 * (size_t)n); }
-			int rc = wtz_candidates_begin(pt->ctx, pt->cq_ids, n, pt->cq_rows, pt->cq_nr); DIE_WTZ(rc, "wtz_candidates_begin");
+			if(!failed){ int rc = wtz_candidates_begin(pt->ctx, pt->cq_ids, n, pt->cq_rows, pt->cq_nr); REMOTE_TRY(rc, "wtz_candidates_begin"); }
 		} else if(h.cmd == WTZ_CMD_CAND_END){
-			int rc = wtz_candidates_end(pt->ctx, pt->cq_rows, pt->cq_nr); DIE_WTZ(rc, "wtz_candidates_end");
-			if(pt->cq_n){ g_dist.send(pt->cq_rows, (uint64_t)pt->cq_n * E->stride * 8, 0); g_dist.send(pt->cq_nr, 4 * (uint64_t)pt->cq_n, 0); }
+			if(!failed){ int rc = wtz_candidates_end(pt->ctx, pt->cq_rows, pt->cq_nr); REMOTE_TRY(rc, "wtz_candidates_end"); }
+			uint64_t st = failed ? WTZ_ST_FAILED : WTZ_ST_OK; g_dist.send(&st, 8, 0);
+			if(!failed && pt->cq_n){ g_dist.send(pt->cq_rows, (uint64_t)pt->cq_n * E->stride * 8, 0); g_dist.send(pt->cq_nr, 4 * (uint64_t)pt->cq_n, 0); }
 		} else if(h.cmd == WTZ_CMD_GRP_BEGIN){
 			/* sharded index: every rank answers every query of the request with the groups of its shard */
 			const uint32_t nq = (uint32_t)h.count[0];
 			if(nq > pt->cq_cap){ pt->cq_cap = nq; pt->cq_ids = (uint32_t*)hx_realloc(pt->cq_ids, 4 * (size_t)nq); pt->cq_nr = (uint32_t*)hx_realloc(pt->cq_nr, 4 * (size_t)nq); pt->cq_rows = (uint64_t*)hx_realloc(pt->cq_rows, (size_t)nq * E->stride * 8); }
 			pt->cq_n = nq;
 			if(nq) g_dist.bcast(pt->cq_ids, 4 * (uint64_t)nq);
-			int rc = wtz_candidate_groups_begin(pt->ctx, pt->cq_ids, nq); DIE_WTZ(rc, "wtz_candidate_groups_begin");
+			if(!failed){ int rc = wtz_candidate_groups_begin(pt->ctx, pt->cq_ids, nq); REMOTE_TRY(rc, "wtz_candidate_groups_begin"); }
 		} else if(h.cmd == WTZ_CMD_GRP_END){
-			int rc = wtz_candidate_groups_end(pt->ctx, pt->cq_nr); DIE_WTZ(rc, "wtz_candidate_groups_end");
-			uint64_t tot = 0; for(uint32_t k = 0; k < pt->cq_n; k++) tot += pt->cq_nr[k];
-			uint64_t *gr = (uint64_t*)hx_realloc(NULL, 8 * (tot + 1));
-			rc = wtz_candidate_groups_fetch(pt->ctx, gr, tot); DIE_WTZ(rc, "wtz_candidate_groups_fetch");
-			if(pt->cq_n) g_dist.send(pt->cq_nr, 4 * (uint64_t)pt->cq_n, 0);
-			if(tot) g_dist.send(gr, 8 * tot, 0);
+			uint64_t tot = 0; uint64_t *gr = NULL;
+			if(!failed){ int rc = wtz_candidate_groups_end(pt->ctx, pt->cq_nr); REMOTE_TRY(rc, "wtz_candidate_groups_end"); }
+			if(!failed){
+				for(uint32_t k = 0; k < pt->cq_n; k++) tot += pt->cq_nr[k];
+				gr = (uint64_t*)hx_realloc(NULL, 8 * (tot + 1));
+				int rc = wtz_candidate_groups_fetch(pt->ctx, gr, tot); REMOTE_TRY(rc, "wtz_candidate_groups_fetch");
+			}
+			uint64_t st = failed ? WTZ_ST_FAILED : WTZ_ST_OK; g_dist.send(&st, 8, 0);
+			if(!failed){
+				if(pt->cq_n) g_dist.send(pt->cq_nr, 4 * (uint64_t)pt->cq_n, 0);
+				if(tot) g_dist.send(gr, 8 * tot, 0);
+			}
 			free(gr);
 		} else { fprintf(stderr, " -- rank %d: unknown request %llu --\n", me, (unsigned long long)h.cmd); DIE_NOW(); }
 	}
+#undef REMOTE_TRY
 }
 
 /* Candidate search (A3) depends on the read and the index only, so the next batch's request can be in flight while this
@@ -719,6 +819,7 @@ static void remote_loop(eng_t *E, part_t *pt){
  * saturates meanwhile is dropped / demoted when the batch is formed - the batch composition is free (any batch size gives
  * the same output), only the query ORDER and the one-query masking lag are part of the contract. */
 static void shard_candidates_begin(eng_t *E, const uint32_t *ids, uint32_t n);
+static void ranks_abort(const char *why);
 static void prefetch_begin(eng_t *E, batch_t *b){
 	if(E->n_workers != 1 || E->rows_all || E->cursor >= E->qend) return;
 	const uint32_t B = E->B;
@@ -738,6 +839,7 @@ static void prefetch_begin(eng_t *E, batch_t *b){
 		int rc = wtz_candidates_begin(b->ctx, b->pf_ids, n, b->pf_rows, b->pf_nr); DIE_WTZ(rc, "wtz_candidates_begin");
 	} else {
 		/* the seed lookup is pure per query: query k of the request goes to device / rank k % nparts (the launches return at once) */
+		int local_failed = 0;
 		if(g_dist.world > 1){
 			wtz_dist_hdr_t h; memset(&h, 0, sizeof h); h.cmd = WTZ_CMD_CAND_BEGIN;
 			for(uint32_t d = 0; d < b->nparts; d++) h.count[d] = (n + b->nparts - 1 - d) / b->nparts;
@@ -751,8 +853,11 @@ static void prefetch_begin(eng_t *E, batch_t *b){
 			for(uint32_t k = 0; k < m; k++){ pt->cq_ids[k] = b->pf_ids[(size_t)k * b->nparts + d]; pt->cq_nr[k] = 0; }
 			if(m) memset(pt->cq_rows, 0, (size_t)m * E->stride * 8);
 			if(pt->remote){ if(m) g_dist.send(pt->cq_ids, 4 * (uint64_t)m, pt->remote); continue; }
-			int rc = wtz_candidates_begin(pt->ctx, pt->cq_ids, m, pt->cq_rows, pt->cq_nr); DIE_WTZ(rc, "wtz_candidates_begin");
+			int rc = wtz_candidates_begin(pt->ctx, pt->cq_ids, m, pt->cq_rows, pt->cq_nr);
+			if(rc != WTZ_OK && g_dist.world > 1){ fprintf(stderr, " -- rank 0: wtz_candidates_begin failed: %s --\n", wtz_last_error()); local_failed = 1; continue; }
+			DIE_WTZ(rc, "wtz_candidates_begin");
 		}
+		if(local_failed) ranks_abort("rank 0 failed in the seed lookup");      /* every rank has its ids: the request is complete, the next thing they read is a header */
 	}
 	b->pf_inflight = 1;
 }
@@ -835,23 +940,32 @@ static void shard_candidates_begin(eng_t *E, const uint32_t *ids, uint32_t n){
 }
 static void shard_candidates_end(eng_t *E, uint32_t n, uint64_t *rows, uint32_t *nr){
 	const uint32_t N = SHARD_N(E); const int ranks = g_dist.world > 1;
-	uint32_t *ng[WTZ_DIST_MAX]; uint64_t *gr[WTZ_DIST_MAX], tot[WTZ_DIST_MAX];
+	uint32_t *ng[WTZ_DIST_MAX]; uint64_t *gr[WTZ_DIST_MAX], tot[WTZ_DIST_MAX]; int failed = -1;
 	if(ranks){ wtz_dist_hdr_t h; memset(&h, 0, sizeof h); h.cmd = WTZ_CMD_GRP_END; g_dist.bcast(&h, sizeof h); }
 	for(uint32_t d = 0; d < N; d++){
 		ng[d] = (uint32_t*)hx_realloc(NULL, 4 * ((size_t)n + 1));
 		if(ranks && d){
+			uint64_t st = 0; g_dist.recv(&st, 8, (int)d);
+			tot[d] = 0; gr[d] = NULL;
+			if(st != WTZ_ST_OK){ if(failed < 0) failed = (int)d; memset(ng[d], 0, 4 * ((size_t)n + 1)); continue; }
 			if(n) g_dist.recv(ng[d], 4 * (uint64_t)n, (int)d);
-			tot[d] = 0; for(uint32_t k = 0; k < n; k++) tot[d] += ng[d][k];
+			for(uint32_t k = 0; k < n; k++) tot[d] += ng[d][k];
 			gr[d] = (uint64_t*)hx_realloc(NULL, 8 * (tot[d] + 1));
 			if(tot[d]) g_dist.recv(gr[d], 8 * tot[d], (int)d);
 			continue;
 		}
 		wtz_ctx_t *cx = ranks ? E->ctx : E->ctxs[d];
-		int rc = wtz_candidate_groups_end(cx, ng[d]); DIE_WTZ(rc, "wtz_candidate_groups_end");
-		tot[d] = 0; for(uint32_t k = 0; k < n; k++) tot[d] += ng[d][k];
-		gr[d] = (uint64_t*)hx_realloc(NULL, 8 * (tot[d] + 1));
-		rc = wtz_candidate_groups_fetch(cx, gr[d], tot[d]); DIE_WTZ(rc, "wtz_candidate_groups_fetch");
+		int rc = wtz_candidate_groups_end(cx, ng[d]);
+		tot[d] = 0; gr[d] = NULL;
+		if(rc == WTZ_OK){
+			for(uint32_t k = 0; k < n; k++) tot[d] += ng[d][k];
+			gr[d] = (uint64_t*)hx_realloc(NULL, 8 * (tot[d] + 1));
+			rc = wtz_candidate_groups_fetch(cx, gr[d], tot[d]);
+		}
+		if(rc != WTZ_OK && ranks){ fprintf(stderr, " -- rank 0: the candidate groups of its shard failed: %s --\n", wtz_last_error()); if(failed < 0) failed = 0; memset(ng[d], 0, 4 * ((size_t)n + 1)); tot[d] = 0; continue; }
+		DIE_WTZ(rc, "wtz_candidate_groups_end / _fetch");
 	}
+	if(failed >= 0){ char why[64]; snprintf(why, sizeof why, "rank %d failed in the sharded seed lookup", failed); ranks_abort(why); }
 	uint64_t off[WTZ_DIST_MAX], *join = NULL; size_t capj = 0; memset(off, 0, sizeof off);
 	for(uint32_t k = 0; k < n; k++){
 		size_t m = 0; for(uint32_t d = 0; d < N; d++) m += ng[d][k];
@@ -1043,10 +1157,18 @@ static void *ctxjob_main(void *arg){
 	}
 	return NULL;
 }
-typedef struct { wtz_ctx_t *ctx; uint32_t n_rd, K; int rc; char err[256]; int zonly, nozidx; } ixjob_t;
+typedef struct { wtz_ctx_t *ctx; uint32_t n_rd, K; int rc; char err[256]; int zonly, nozidx; uint32_t zmod, zres; } ixjob_t;
+/* the z-mer index of one device for the whole run: every read, or - several parts - the candidate side of its residue class of the indexed reads */
+static int zindex_for_part(wtz_ctx_t *ctx, uint32_t n_rd, uint32_t zmod, uint32_t zres){
+	if(zmod <= 1) return wtz_zindex_build(ctx);
+	uint32_t *m = (uint32_t*)hx_realloc(NULL, 4 * ((size_t)n_rd / zmod + 2)), n = 0;
+	for(uint32_t r = zres; r < n_rd; r += zmod) m[n++] = r;
+	const int rc = wtz_zindex_build_subset(ctx, m, n);
+	free(m); return rc;
+}
 static void *ixjob_main(void *arg){
 	ixjob_t *j = (ixjob_t*)arg; wtz_index_stats_t ist;
-	j->rc = j->nozidx ? WTZ_OK : wtz_zindex_build(j->ctx);
+	j->rc = j->nozidx ? WTZ_OK : zindex_for_part(j->ctx, j->n_rd, j->zmod, j->zres);
 	if(j->rc == WTZ_OK && !j->zonly) j->rc = wtz_index_build(j->ctx, 0, j->n_rd, &j->K, &ist);
 	if(j->rc != WTZ_OK){ strncpy(j->err, wtz_last_error(), sizeof j->err - 1); j->err[sizeof j->err - 1] = 0; }
 	return NULL;
@@ -1059,6 +1181,58 @@ static void *pin_main(void *arg){
 		if(!E->cig_keep[k]) E->cig_keep_cap[k] = 0;
 	}
 	return NULL;
+}
+
+/* The z-mer index of a batch (after its candidate rows are known, before its first range).
+ *   --zindex-batch (read sets whose all-reads index does not fit: 16 B per base): part d's index is rebuilt from the batch's candidate reads
+ *     = d (mod nparts) - with one part: from the batch's queries + all their candidates, one index;
+ *   several parts: the batch's queries go into the second, query-side index of EVERY part (wtz_zindex_build_queries).
+ * Parts of this process build side by side on their own threads; between ranks the lists travel with WTZ_CMD_ZIDX and every rank builds its own
+ * (no reply: a failure shows in the status word of the rank's next reply). */
+typedef struct { wtz_ctx_t *ctx; int have_c, have_q; const uint32_t *cl, *ql; uint32_t ncl, nql; int rc; char err[256]; } zjob_t;
+static void *zjob_main(void *arg){
+	zjob_t *j = (zjob_t*)arg;
+	j->rc = zbuild_part(j->ctx, j->have_c, j->cl, j->ncl, j->have_q, j->ql, j->nql);
+	if(j->rc != WTZ_OK) snprintf(j->err, sizeof j->err, "%s", wtz_last_error());
+	return NULL;
+}
+static void batch_zindex(eng_t *E, batch_t *b){
+	const uint32_t n_all = (uint32_t)(E->st.n_rd + E->st.n_qr), np = b->nparts; const int ranks = g_dist.world > 1;
+	const int have_c = E->zbatch > 0, have_q = E->zsplit;
+	uint32_t *ql = (uint32_t*)hx_realloc(NULL, 4 * ((size_t)b->nbq + 1)), nql = 0;
+	uint32_t *cl[WTZ_DIST_MAX], ncl[WTZ_DIST_MAX]; memset(cl, 0, sizeof cl); memset(ncl, 0, sizeof ncl);
+	for(uint32_t s = 0; s < b->nbq; s++) if(b->want[s]) ql[nql++] = b->bq[s];       /* ascending: a batch takes its queries in id order */
+	if(have_c){
+		uint8_t *mark = (uint8_t*)calloc((size_t)n_all + 1, 1);
+		for(uint32_t s = 0; s < b->nbq; s++){
+			if(!b->want[s]) continue;
+			if(!have_q) mark[b->bq[s]] = 1;          /* one part: queries and candidates share the one index */
+			for(uint32_t k = 0; k < b->nrow[s]; k++){ const uint32_t id2 = (uint32_t)(b->rows[(size_t)s * E->stride + k] >> 32); if(id2 < n_all) mark[id2] = 1; }
+		}
+		for(uint32_t d = 0; d < np; d++) cl[d] = (uint32_t*)hx_realloc(NULL, 4 * ((size_t)n_all / np + 2));
+		for(uint32_t r = 0; r < n_all; r++) if(mark[r]){ const uint32_t d = have_q ? DEAL_PART(np, 0, r) : 0; cl[d][ncl[d]++] = r; }
+		free(mark);
+	}
+	const double tz0 = now_s();
+	if(ranks){
+		wtz_dist_hdr_t h; memset(&h, 0, sizeof h); h.cmd = WTZ_CMD_ZIDX; h.arg[0] = nql; h.arg[1] = (uint64_t)have_c;
+		for(uint32_t d = 0; d < np; d++) h.count[d] = ncl[d];
+		g_dist.bcast(&h, sizeof h);
+		if(nql) g_dist.bcast(ql, 4 * (uint64_t)nql);
+		if(have_c) for(uint32_t d = 1; d < np; d++) if(ncl[d]) g_dist.send(cl[d], 4 * (uint64_t)ncl[d], (int)d);
+		const int rc = zbuild_part(E->ctx, have_c, cl[0], ncl[0], have_q, ql, nql);
+		if(rc != WTZ_OK){ fprintf(stderr, " -- rank 0: the z-mer index of the batch failed: %s --\n", wtz_last_error()); ranks_abort("rank 0 failed"); }
+	} else {
+		zjob_t zj[8]; pthread_t th[8];
+		for(uint32_t d = 0; d < np && d < 8; d++){ zj[d].ctx = b->parts[d].ctx; zj[d].have_c = have_c; zj[d].have_q = have_q; zj[d].cl = cl[d]; zj[d].ncl = ncl[d]; zj[d].ql = ql; zj[d].nql = nql; zj[d].rc = WTZ_OK; }
+		for(uint32_t d = 1; d < np; d++) if(pthread_create(&th[d], NULL, zjob_main, &zj[d]) != 0){ fprintf(stderr, " -- cannot start a device thread --\n"); DIE_NOW(); }
+		zjob_main(&zj[0]);
+		for(uint32_t d = 1; d < np; d++) pthread_join(th[d], NULL);
+		for(uint32_t d = 0; d < np; d++) if(zj[d].rc != WTZ_OK){ fprintf(stderr, " -- the z-mer index of the batch failed on device %d: %s --\n", E->devs[d], zj[d].err); DIE_NOW(); }
+	}
+	pthread_mutex_lock(&E->mu); E->t_gpu += now_s() - tz0; E->t_zbatch += now_s() - tz0; pthread_mutex_unlock(&E->mu);
+	for(uint32_t d = 0; d < np; d++) free(cl[d]);
+	free(ql);
 }
 
 static void *worker_main(void *arg){
@@ -1096,16 +1270,24 @@ static void *worker_main(void *arg){
 		/* ---- candidate heaps of the batch's queries (A3) ---- */
 		if(use_pf){
 			const double tg0 = now_s();
-			int rc = WTZ_OK;
+			int rc = WTZ_OK, cand_failed = -1;
 			if(E->shard) shard_candidates_end(E, b->pf_n, b->pf_rows, b->pf_nr);
 			else if(b->nparts == 1){ rc = wtz_candidates_end(b->ctx, b->pf_rows, b->pf_nr); DIE_WTZ(rc, "wtz_candidates_end"); }
 			else for(uint32_t d = 0; d < b->nparts; d++){
 				part_t *pt = &b->parts[d];
 				if(d == 0 && g_dist.world > 1){ wtz_dist_hdr_t h; memset(&h, 0, sizeof h); h.cmd = WTZ_CMD_CAND_END; g_dist.bcast(&h, sizeof h); }
-				if(pt->remote){ if(pt->cq_n){ g_dist.recv(pt->cq_rows, (uint64_t)pt->cq_n * E->stride * 8, pt->remote); g_dist.recv(pt->cq_nr, 4 * (uint64_t)pt->cq_n, pt->remote); } }
-				else { rc = wtz_candidates_end(pt->ctx, pt->cq_rows, pt->cq_nr); DIE_WTZ(rc, "wtz_candidates_end"); }
+				if(pt->remote){
+					uint64_t st = 0; g_dist.recv(&st, 8, pt->remote);
+					if(st != WTZ_ST_OK){ if(cand_failed < 0) cand_failed = pt->remote; continue; }
+					if(pt->cq_n){ g_dist.recv(pt->cq_rows, (uint64_t)pt->cq_n * E->stride * 8, pt->remote); g_dist.recv(pt->cq_nr, 4 * (uint64_t)pt->cq_n, pt->remote); }
+				} else {
+					rc = wtz_candidates_end(pt->ctx, pt->cq_rows, pt->cq_nr);
+					if(rc != WTZ_OK && g_dist.world > 1){ fprintf(stderr, " -- rank 0: wtz_candidates_end failed: %s --\n", wtz_last_error()); if(cand_failed < 0) cand_failed = 0; continue; }
+					DIE_WTZ(rc, "wtz_candidates_end");
+				}
 				for(uint32_t k = 0; k < pt->cq_n; k++){ const size_t g = (size_t)k * b->nparts + d; memcpy(b->pf_rows + g * E->stride, pt->cq_rows + (size_t)k * E->stride, (size_t)E->stride * 8); b->pf_nr[g] = pt->cq_nr[k]; }
 			}
+			if(cand_failed >= 0){ char why[64]; snprintf(why, sizeof why, "rank %d failed in the seed lookup", cand_failed); ranks_abort(why); }
 			const double tg1 = now_s();
 			b->pf_inflight = 0;
 			uint32_t k = 0;
@@ -1131,21 +1313,7 @@ static void *worker_main(void *arg){
 			free(rows); free(nr);
 			pthread_mutex_lock(&E->mu); E->t_gpu += tg1 - tg0; E->t_call[0] += tg1 - tg0; pthread_mutex_unlock(&E->mu);
 		}
-		if(b->nbq && E->zbatch > 0){
-			/* per-batch z-index: the batch's queries and every read in their candidate rows (a superset of what the pair stages will look up) */
-			const uint32_t n_all = (uint32_t)(E->st.n_rd + E->st.n_qr);
-			uint8_t *mark = (uint8_t*)calloc((size_t)n_all + 1, 1); uint32_t *list = (uint32_t*)hx_realloc(NULL, 4 * ((size_t)n_all + 1)), nl = 0;
-			for(uint32_t s = 0; s < b->nbq; s++){
-				if(!b->want[s]) continue;
-				mark[b->bq[s]] = 1;
-				for(uint32_t k = 0; k < b->nrow[s]; k++){ const uint32_t id2 = (uint32_t)(b->rows[(size_t)s * E->stride + k] >> 32); if(id2 < n_all) mark[id2] = 1; }
-			}
-			for(uint32_t r = 0; r < n_all; r++) if(mark[r]) list[nl++] = r;
-			const double tz0 = now_s();
-			for(uint32_t d = 0; d < E->ndev; d++){ int rc = wtz_zindex_build_subset(E->ctxs[d], list, nl); DIE_WTZ(rc, "wtz_zindex_build_subset"); }
-			pthread_mutex_lock(&E->mu); E->t_gpu += now_s() - tz0; pthread_mutex_unlock(&E->mu);
-			free(mark); free(list);
-		}
+		if(b->nbq && (E->zbatch > 0 || E->zsplit)) batch_zindex(E, b);
 		if(b->nbq) process_batch(E, b);
 		/* ---- hand the turn to the next batch ---- */
 		pthread_mutex_lock(&E->mu);
@@ -1190,7 +1358,7 @@ int main(int argc, char **argv){
 	E->do_align = 1; E->n_idx = 1; E->n_job = 1; E->i_job = 0; E->max_batch = 4096; E->first_batch = 256; E->n_workers = 1;
 	pthread_mutex_init(&E->mu, NULL); pthread_cond_init(&E->cv, NULL);
 	static struct option lopts[] = { {"stats", required_argument, 0, 1000}, {"gpu", required_argument, 0, 1001}, {"pool-gb", required_argument, 0, 1002},
-		{"batch", required_argument, 0, 1003}, {"lib-check", no_argument, 0, 1004}, {"repeat", required_argument, 0, 1005}, {"first-batch", required_argument, 0, 1006}, {"workers", required_argument, 0, 1007}, {"pool-mb", required_argument, 0, 1008}, {"gpus", required_argument, 0, 1010}, {"gpu-list", required_argument, 0, 1011}, {"shard-index", no_argument, 0, 1012}, {"zindex-batch", required_argument, 0, 1013}, {"ingest", required_argument, 0, 1014}, {0, 0, 0, 0} };
+		{"batch", required_argument, 0, 1003}, {"lib-check", no_argument, 0, 1004}, {"repeat", required_argument, 0, 1005}, {"first-batch", required_argument, 0, 1006}, {"workers", required_argument, 0, 1007}, {"pool-mb", required_argument, 0, 1008}, {"gpus", required_argument, 0, 1010}, {"gpu-list", required_argument, 0, 1011}, {"shard-index", no_argument, 0, 1012}, {"zindex-batch", required_argument, 0, 1013}, {"ingest", required_argument, 0, 1014}, {"binary-out", no_argument, 0, 1015}, {0, 0, 0, 0} };
 	while((c = getopt_long(argc, argv, "ht:P:p:Ni:b:J:I:o:9:S:fCH:k:G:z:Z:U:y:d:r:q:l:K:A:B:r:R:L:F:W:w:e:M:X:O:E:T:s:m:nv", lopts, NULL)) != -1){
 		switch(c){
 			case 1000: statsf = optarg; break;
@@ -1201,6 +1369,7 @@ int main(int argc, char **argv){
 			case 1005: repeat = atoi(optarg); if(repeat < 1) repeat = 1; break;
 			case 1006: E->first_batch = (uint32_t)atoi(optarg); if(E->first_batch < 1) E->first_batch = 1; E->first_batch_set = 1; break;
 			case 1010: n_gpus = atoi(optarg); if(n_gpus < 1) n_gpus = 1; if(n_gpus > 8) n_gpus = 8; break;
+			case 1015: E->binary_out = 1; break;      /* f3: binary record hand-off (include/wtz_ovlb.h) to a consumer that reads it (bin/wtgbo --binary-in, bin/wtovl) */
 			case 1014: E->st.keep_text = (strcmp(optarg, "host") != 0); break;      /* f4: `device` (default) = the bases travel as text and are packed to 2 bits on the GPU (wtz_upload_reads_ascii), `host` = packed while reading */
 			case 1013: E->zbatch = atoi(optarg) ? 1 : -1; break;      /* 1 = per-batch z-index, 0 = never (default: by the size of the read set) */
 			case 1012: E->shard = 1; break;           /* k-mer index sharded over the devices of --gpus / --gpu-list (or over the ranks) */
@@ -1365,8 +1534,11 @@ int main(int argc, char **argv){
 		if(g_dist.world > WTZ_DIST_MAX || !g_dist.bcast || !g_dist.send || !g_dist.recv){ fprintf(stderr, " -- wtzmo_set_dist: bad rank setup --\n"); DIE_NOW(); }
 		if(E->n_idx > 1 || E->n_workers > 1 || E->ndev > 1 || E->n_job > 1){ fprintf(stderr, " -- ranks (one process per GPU) exclude -G, -P, --workers and --gpus --\n"); DIE_NOW(); }
 	}
-	if(E->zbatch == 0 && E->st.nbase > 2400000000ull && g_dist.world == 1 && E->n_workers == 1){ E->zbatch = 1; fprintf(stderr, "[wtzmo-mi355x] %llu read bases: the z-mer index is built per batch of queries (--zindex-batch 0 to force the all-reads index)\n", (unsigned long long)E->st.nbase); }
-	if(E->zbatch > 0 && (g_dist.world > 1 || E->n_workers > 1)){ fprintf(stderr, " -- --zindex-batch excludes ranks and --workers --\n"); DIE_NOW(); }
+	E->zsplit = (g_dist.world > 1 || E->ndev > 1) && !getenv("WTZ_NO_ZSPLIT");
+	{ /* all-reads z-index: 16 B per base - with several parts only 1 / nparts of it per device, so the per-batch form starts nparts times later */
+	  const uint64_t zparts = E->zsplit ? (g_dist.world > 1 ? (uint64_t)g_dist.world : E->ndev) : 1;
+	  if(E->zbatch == 0 && E->st.nbase > 2400000000ull * zparts && E->n_workers == 1){ E->zbatch = 1; fprintf(stderr, "[wtzmo-mi355x] %llu read bases: the z-mer index is built per batch of queries (--zindex-batch 0 to force the all-reads index)\n", (unsigned long long)E->st.nbase); } }
+	if(E->zbatch > 0 && E->n_workers > 1){ fprintf(stderr, " -- --zindex-batch excludes --workers --\n"); DIE_NOW(); }
 	{ const uint32_t zb_max = getenv("WTZ_ZBATCH_MAX") ? (uint32_t)atoi(getenv("WTZ_ZBATCH_MAX")) : 1024u;      /* queries per batch when the z-mer index is rebuilt per batch: bounds its size (queries + <= -A candidates each); configs[3]-shape whole job: 36.0 s with 512, 33.3 s with 1 024, 33.1 s with 2 048 */
 	  if(E->zbatch > 0 && E->max_batch > zb_max) E->max_batch = zb_max; }
 	if(E->shard && (E->n_idx > 1 || E->n_workers > 1)){ fprintf(stderr, " -- --shard-index excludes -G and --workers --\n"); DIE_NOW(); }
@@ -1420,7 +1592,7 @@ int main(int argc, char **argv){
 			for(size_t i = 0; i < nclosed0; i++) hx_set_put(&E->closed, closed0[i]);
 			E->n_order = n_order0;
 			E->pair_bp = E->n_pairs = E->nrec = 0;
-			E->t_gpu = E->t_commit = 0; memset(E->t_call, 0, sizeof E->t_call); E->t_io[0] = E->t_io[1] = 0; E->spec_pairs = E->used_pairs = E->spec_items = E->used_items = E->spec_queries = E->used_queries = 0;
+			E->t_gpu = E->t_commit = E->t_zbatch = 0; memset(E->t_call, 0, sizeof E->t_call); E->t_io[0] = E->t_io[1] = 0; E->spec_pairs = E->used_pairs = E->spec_items = E->used_items = E->spec_queries = E->used_queries = 0;
 			E->rows_all = 0; E->n_batches = 0; E->n_split = 0; E->n_ranges = 0; E->bytes_per_pair = 0;      /* every repeat plans like a cold run: probe range first */
 			E->pend.rd_id = 0xFFFFFFFFu; E->pend.nhit = E->pend.nmask = E->pend.nclosed = E->pend.nseed = 0;
 			if(strcmp(output, "-")){
@@ -1439,12 +1611,19 @@ int main(int argc, char **argv){
 			}
 			wtz_reset_counters(E->ctx);
 		}
-		out_start(E->out);
+		if(E->binary_out && g_dist.rank == 0){      /* the name table: ids in the records are this run's read ids */
+			const char **nmv = (const char**)hx_realloc(NULL, sizeof(char*) * ((size_t)n_all + 1));
+			for(uint32_t i = 0; i < n_all; i++) nmv[i] = E->st.reads[i].name;
+			if(wtz_ovlb_write_header(E->out, n_all, nmv, E->rdlen) != 0){ fprintf(stderr, " -- cannot write the binary overlap header --\n"); DIE_NOW(); }
+			free(nmv);
+		}
+		out_start(E->out, E->st.reads, E->binary_out);
 		if(g_hook) g_hook(rep, 0);
 		const double t0 = now_s();
 		pthread_t ixth[8]; ixjob_t ixj[8];
-		for(uint32_t d = 1; d < E->ndev; d++){ ixj[d].ctx = E->ctxs[d]; ixj[d].n_rd = n_rd; ixj[d].K = P->max_kmer_freq; ixj[d].zonly = E->shard; ixj[d].nozidx = E->zbatch > 0; if(pthread_create(&ixth[d], NULL, ixjob_main, &ixj[d]) != 0) DIE_NOW(); }
-		if(E->zbatch <= 0){ rc = wtz_zindex_build(E->ctx); DIE_WTZ(rc, "wtz_zindex_build"); }
+		const uint32_t zmod = E->zsplit ? (g_dist.world > 1 ? (uint32_t)g_dist.world : E->ndev) : 1u;
+		for(uint32_t d = 1; d < E->ndev; d++){ ixj[d].ctx = E->ctxs[d]; ixj[d].n_rd = n_rd; ixj[d].K = P->max_kmer_freq; ixj[d].zonly = E->shard; ixj[d].nozidx = E->zbatch > 0; ixj[d].zmod = zmod; ixj[d].zres = d; if(pthread_create(&ixth[d], NULL, ixjob_main, &ixj[d]) != 0) DIE_NOW(); }
+		if(E->zbatch <= 0){ rc = zindex_for_part(E->ctx, n_rd, zmod, g_dist.world > 1 ? (uint32_t)g_dist.rank : 0u); DIE_WTZ(rc, "wtz_zindex_build"); }
 		/* ---- index parts (-G, wtzmo.c:1276-1303) ---- */
 		uint32_t pbbeg = 0, pbend = 0, K = P->max_kmer_freq;
 		wtz_index_stats_t ist;
@@ -1561,7 +1740,7 @@ int main(int argc, char **argv){
 		if(E->extra_u64[5] > cn.pool_peak) cn.pool_peak = E->extra_u64[5];
 		memset(E->extra_ms, 0, sizeof E->extra_ms); memset(E->extra_u64, 0, sizeof E->extra_u64);
 		fprintf(stderr, "[wtzmo-mi355x] %llu records, %llu pairs aligned, %llu pair-bp, %.3f s (index %.3f s)\n", (unsigned long long)E->nrec, (unsigned long long)E->n_pairs, (unsigned long long)E->pair_bp, t1 - t0, t_index);
-		fprintf(stderr, "[wtzmo-mi355x] host seconds: in GPU-stage calls %.3f, commit %.3f (record formatting %.3f); waiting for the output writer: %.3f before buffer reuse, %.3f at the end\n", E->t_gpu, E->t_commit, E->t_call[5], E->t_io[0], E->t_io[1]);
+		fprintf(stderr, "[wtzmo-mi355x] host seconds: in GPU-stage calls %.3f, commit %.3f, per-batch z-index %.3f; writer thread: formatting %.3f, write %.3f; waiting for it: %.3f before buffer reuse, %.3f at the end\n", E->t_gpu, E->t_commit, E->t_zbatch, g_ow.t_format, g_ow.t_write, E->t_io[0], E->t_io[1]);
 		fprintf(stderr, "[wtzmo-mi355x] wall seconds per call: candidates %.3f pairs_seed %.3f pairs_windows %.3f pairs_align %.3f cigar_text %.3f\n", E->t_call[0], E->t_call[1], E->t_call[2], E->t_call[3], E->t_call[4]);
 	if(E->n_split) fprintf(stderr, "[wtzmo-mi355x] %llu range(s) had to be split after a scratch-pool overflow (planned at %.0f KB per pair)\n", (unsigned long long)E->n_split, E->bytes_per_pair / 1024.0);
 	fprintf(stderr, "[wtzmo-mi355x] %llu batches in %llu ranges on %u worker context(s); speculation: queries %llu/%llu pairs %llu/%llu alignments %llu/%llu (used/planned)\n",

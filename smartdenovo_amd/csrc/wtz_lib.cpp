@@ -314,8 +314,14 @@ struct wtz_ctx {
 	int device;
 	/* z-index arrays of the previous build, kept for the rebuild (same read set -> same sizes): freeing and re-allocating 19 GB per
 	 * build cost 0.1 - 0.8 s of hipFree / hipMalloc at configs[2], depending on what else the host's memory manager was doing */
-	std::vector<std::pair<void*, size_t> > zparked;
-	std::vector<std::pair<void*, size_t> > zlive;
+	/* two z-index slots: [0] = the index proper (all reads, or the subset of the batch in flight), [1] = optional second index holding only the
+	 * QUERIES of the batch in flight (wtz_zindex_build_queries): with several GPUs every device keeps slot 0 for its own share of the candidate
+	 * reads and rebuilds the small slot 1 per batch, instead of all devices building the z-index of all reads */
+	struct zslot_t {
+		std::vector<std::pair<void*, size_t> > parked, live;
+		uint64_t *zoff = NULL; uint64_t n_z = 0; wtz_zindex_t Z; bool have = false; bool sub = false; uint64_t sub_cap = 0;      /* sub: the slot holds a subset of the reads (rebuilt per batch) */
+		zslot_t(){ memset(&Z, 0, sizeof Z); }
+	} zs[2];
 #ifndef WTZ_EMUL
 	hipStream_t stream;
 	hipStream_t stream_mw = 0; hipEvent_t ev_mw_fork = 0, ev_mw_join = 0;      /* side stream of the multi-wave K-sw3 launch */
@@ -336,7 +342,6 @@ struct wtz_ctx {
 	uint64_t *cq_gptr = NULL; uint32_t cq_gcap = 0; bool cq_groups = false; std::vector<uint32_t> cq_ng;
 	uint32_t idx_beg = 0, idx_end = 0; bool idx_len_sorted = false;      /* read range of the k-mer index; lengths non-increasing inside it (true unless -b clipped reads after the sort) */
 	/* z index */
-	uint64_t *zoff; uint64_t n_z; wtz_zindex_t Z; bool have_z; bool zsub = false; uint64_t zsub_cap = 0;      /* zsub: the z-index holds a subset of the reads (rebuilt per batch) */
 	/* pool */
 	/* scratch: ONE allocation of pool_bytes, cut in two bump pools: dpool[0] = results and scratch that live for the batch (match lists,
 	 * windows, anchors, CIGARs), dpool[1] = the transient pool of the K-sw3 trace matrices, reset after every launch group of extension
@@ -372,7 +377,7 @@ struct wtz_ctx {
 #endif
 
 static wtz_reads_t ctx_reads(const wtz_ctx *c){ wtz_reads_t R; R.bits = c->bits; R.rdoff = c->rdoff; R.rdlen = c->rdlen; R.n_reads = c->n_reads; return R; }
-static wtz_env_t ctx_env(const wtz_ctx *c){ wtz_env_t V; V.R = ctx_reads(c); V.Z = c->Z; V.P = c->dP; V.pool = c->dpool; V.dm_first_big = (uint32_t)c->env_dm_first_big; return V; }
+static wtz_env_t ctx_env(const wtz_ctx *c){ wtz_env_t V; V.R = ctx_reads(c); V.Z = c->zs[0].Z; V.ZQ = c->zs[1].have ? c->zs[1].Z : c->zs[0].Z; V.P = c->dP; V.pool = c->dpool; V.dm_first_big = (uint32_t)c->env_dm_first_big; return V; }
 
 static int tpool_reset(wtz_ctx *c){
 	wtz_pool_t p; p.base = c->pool_base + c->main_bytes; p.cap = c->pool_bytes - c->main_bytes; p.used = 0; p.overflow = 0; p.fail_at = c->env_tfail_at; p.nalloc = 0;
@@ -431,7 +436,6 @@ extern "C" int wtz_ctx_create(int device, const wtz_params_c *params, uint64_t p
 #endif
 	c->bits = NULL; c->rdoff = NULL; c->rdlen = NULL; c->n_reads = 0; c->n_words = 0;
 	c->ktab = NULL; c->kseeds = NULL; c->kmask = 0; c->n_kocc = 0;
-	c->zoff = NULL; c->n_z = 0; memset(&c->Z, 0, sizeof c->Z); c->have_z = false;
 	c->dpool = NULL; c->pool_base = NULL; c->pool_bytes = pool_bytes ? pool_bytes : (4ull << 30);
 #ifndef WTZ_EMUL
 	if(!pool_bytes){
@@ -494,21 +498,24 @@ extern "C" int wtz_ctx_create(int device, const wtz_params_c *params, uint64_t p
 static void free_pending_index(wtz_ctx *c);
 static void free_kindex(wtz_ctx *c){ if(!c->shares_indexes){ dev_free_persist(c->ktab); dev_free_persist(c->kseeds); } c->ktab = NULL; c->kseeds = NULL; c->kmask = 0; }
 /* z-index allocation with recycling: a parked buffer of (nearly) the wanted size is taken instead of a fresh hipMalloc */
-static int zalloc(wtz_ctx *c, void **p, size_t n){
+static int zalloc(wtz_ctx::zslot_t *z, void **p, size_t n){
 	if(n == 0) n = 16;
-	for(size_t i = 0; i < c->zparked.size(); i++){
-		if(c->zparked[i].second >= n && c->zparked[i].second <= n + n / 8 + 4096){
-			*p = c->zparked[i].first; c->zlive.push_back(c->zparked[i]); c->zparked.erase(c->zparked.begin() + (long)i); return WTZ_OK;
+	for(size_t i = 0; i < z->parked.size(); i++){
+		if(z->parked[i].second >= n && z->parked[i].second <= n + n / 8 + 4096){
+			*p = z->parked[i].first; z->live.push_back(z->parked[i]); z->parked.erase(z->parked.begin() + (long)i); return WTZ_OK;
 		}
 	}
 	int rc = dev_alloc_persist(p, n); if(rc) return rc;
-	c->zlive.push_back(std::make_pair(*p, n)); return WTZ_OK;
+	z->live.push_back(std::make_pair(*p, n)); return WTZ_OK;
 }
-static void zpark_all(wtz_ctx *c){ for(size_t i = 0; i < c->zlive.size(); i++) c->zparked.push_back(c->zlive[i]); c->zlive.clear(); }
-static void zflush_parked(wtz_ctx *c){ for(size_t i = 0; i < c->zparked.size(); i++) dev_free_persist(c->zparked[i].first); c->zparked.clear(); }
+static void zpark_all(wtz_ctx::zslot_t *z){ for(size_t i = 0; i < z->live.size(); i++) z->parked.push_back(z->live[i]); z->live.clear(); }
+static void zflush_parked(wtz_ctx::zslot_t *z){ for(size_t i = 0; i < z->parked.size(); i++) dev_free_persist(z->parked[i].first); z->parked.clear(); }
 static void free_zindex(wtz_ctx *c){
-	if(!c->shares_indexes){ zpark_all(c); zflush_parked(c); }      /* every z-index array comes from zalloc */
-	c->zoff = NULL; memset(&c->Z, 0, sizeof c->Z); c->have_z = false;
+	for(int k = 0; k < 2; k++){
+		wtz_ctx::zslot_t *z = &c->zs[k];
+		if(!c->shares_indexes){ zpark_all(z); zflush_parked(z); }      /* every z-index array comes from zalloc */
+		z->zoff = NULL; memset(&z->Z, 0, sizeof z->Z); z->have = false; z->sub = false; z->sub_cap = 0; z->n_z = 0;
+	}
 }
 static void free_batch(wtz_ctx *c){ c->n_pairs = 0; c->n_items = 0; c->have_pairs = false; c->have_items = false; }
 static void free_batch_storage(wtz_ctx *c){
@@ -566,7 +573,7 @@ extern "C" int wtz_ctx_clone(wtz_ctx_t *p, uint64_t pool_bytes, wtz_ctx_t **out)
 	c->bits = p->bits; c->n_words = p->n_words; c->rdoff = p->rdoff; c->rdlen = p->rdlen; c->n_reads = p->n_reads; c->h_rdlen = p->h_rdlen;
 	c->ktab = p->ktab; c->kmask = p->kmask; c->kseeds = p->kseeds; c->n_kocc = p->n_kocc;
 	c->idx_beg = p->idx_beg; c->idx_end = p->idx_end; c->idx_len_sorted = p->idx_len_sorted;
-	c->zoff = p->zoff; c->n_z = p->n_z; c->Z = p->Z; c->have_z = p->have_z;
+	for(int k = 0; k < 2; k++){ c->zs[k].zoff = p->zs[k].zoff; c->zs[k].n_z = p->zs[k].n_z; c->zs[k].Z = p->zs[k].Z; c->zs[k].have = p->zs[k].have; }
 	*out = c;
 	return WTZ_OK;
 }
@@ -870,17 +877,19 @@ extern "C" void wtz_cand_tail_host(const uint64_t *groups, uint32_t ng, uint32_t
  * kernels address the index exactly as before.  The subset form is rebuilt per batch of queries (their candidate sets bound what a batch
  * can look up), which is what lets a 10 Gbp read set (160 GB of z-index at 16 B per base) run in 288 GB: its arrays are allocated once
  * with head-room and reused. */
-static int zindex_build_impl(wtz_ctx_t *c, const uint32_t *members, uint32_t nm){
+static int zindex_build_impl(wtz_ctx_t *c, const uint32_t *members, uint32_t nm, int slot = 0){
 	if(!c || !c->bits) return wtz_fail(WTZ_E_ARG, "reads not uploaded");
 	CTX_ENTER(c);
 	if(c->shares_indexes) return wtz_fail(WTZ_E_STATE, "wtz_zindex_build on a cloned context");
 	const bool subset = members != NULL;
-	if(!subset || !c->zsub){ zpark_all(c); if(subset) zflush_parked(c); c->zoff = NULL; memset(&c->Z, 0, sizeof c->Z); c->zsub_cap = 0; }      /* the old arrays are recycled below */
-	c->have_z = false;
+	wtz_ctx::zslot_t *z = &c->zs[slot];
+	if(!subset || !z->sub){ zpark_all(z); if(subset) zflush_parked(z); z->zoff = NULL; memset(&z->Z, 0, sizeof z->Z); z->sub_cap = 0; }      /* the old arrays are recycled below */
+	z->have = false;
+	if(slot == 0) c->zs[1].have = false;       /* a query-side index belongs to the batch it was built for */
 	wtz_timer tm; tm.start();
 	const wtz_reads_t R = ctx_reads(c); const uint32_t nr = c->n_reads, zsize = c->P.zsize, hz = c->P.hz, zcut = c->P.max_zmer_freq;
-	if(c->zoff == NULL) CHK(zalloc(c, (void**)&c->zoff, ((size_t)nr + 1) * 8));
-	uint64_t *d_off = c->zoff;
+	if(z->zoff == NULL) CHK(zalloc(z, (void**)&z->zoff, ((size_t)nr + 1) * 8));
+	uint64_t *d_off = z->zoff;
 	std::vector<uint32_t> p_rid, p_jb; std::vector<size_t> first_piece((size_t)nr + 1);
 	{ uint32_t mi = 0;
 	  for(uint32_t r = 0; r < nr; r++){
@@ -901,21 +910,21 @@ static int zindex_build_impl(wtz_ctx_t *c, const uint32_t *members, uint32_t nm)
 	for(uint32_t r = 0; r <= nr; r++) h[r] = hp[first_piece[r]];
 	CHK(dev_h2d(d_poff, hp.data(), (np + 1) * 8));
 	CHK(dev_h2d(d_off, h.data(), ((size_t)nr + 1) * 8));
-	c->n_z = tot;
-	wtz_zindex_t Z; memset(&Z, 0, sizeof Z); Z.zoff = c->zoff;
-	if(subset && c->zsub && tot + 1 <= c->zsub_cap) Z = c->Z;      /* the arrays of the previous subset are large enough */
+	z->n_z = tot;
+	wtz_zindex_t Z; memset(&Z, 0, sizeof Z); Z.zoff = z->zoff;
+	if(subset && z->sub && tot + 1 <= z->sub_cap) Z = z->Z;      /* the arrays of the previous subset are large enough */
 	else {
-		if(subset && c->zsub){ (void)dev_sync(); zpark_all(c); zflush_parked(c); CHK(zalloc(c, (void**)&c->zoff, ((size_t)nr + 1) * 8)); d_off = c->zoff; CHK(dev_h2d(d_off, h.data(), ((size_t)nr + 1) * 8)); Z.zoff = c->zoff; }
+		if(subset && z->sub){ (void)dev_sync(); zpark_all(z); zflush_parked(z); CHK(zalloc(z, (void**)&z->zoff, ((size_t)nr + 1) * 8)); d_off = z->zoff; CHK(dev_h2d(d_off, h.data(), ((size_t)nr + 1) * 8)); Z.zoff = z->zoff; }
 		const uint64_t cap = subset ? tot + tot / 4 + 1024 : tot + 1;      /* subsets: head-room, so that most batches reuse the allocation */
-		CHK(zalloc(c, (void**)&Z.mer, cap * 4)); CHK(zalloc(c, (void**)&Z.pos, cap * 4)); CHK(zalloc(c, (void**)&Z.len, cap * 2));
-		CHK(zalloc(c, (void**)&Z.ok, cap)); CHK(zalloc(c, (void**)&Z.sidx, cap * 4));
-		CHK(zalloc(c, (void**)&Z.dmer, cap * 4)); CHK(zalloc(c, (void**)&Z.dfirst, cap * 4)); CHK(zalloc(c, (void**)&Z.dcnt, cap * 2));
-		CHK(zalloc(c, (void**)&Z.dn, ((size_t)nr + 1) * 4));
-		zflush_parked(c);                     /* whatever did not fit a request goes back to the driver */
-		c->zsub_cap = subset ? cap : 0;
+		CHK(zalloc(z, (void**)&Z.mer, cap * 4)); CHK(zalloc(z, (void**)&Z.pos, cap * 4)); CHK(zalloc(z, (void**)&Z.len, cap * 2));
+		CHK(zalloc(z, (void**)&Z.ok, cap)); CHK(zalloc(z, (void**)&Z.sidx, cap * 4));
+		CHK(zalloc(z, (void**)&Z.dmer, cap * 4)); CHK(zalloc(z, (void**)&Z.dfirst, cap * 4)); CHK(zalloc(z, (void**)&Z.dcnt, cap * 2));
+		CHK(zalloc(z, (void**)&Z.dn, ((size_t)nr + 1) * 4));
+		zflush_parked(z);                     /* whatever did not fit a request goes back to the driver */
+		z->sub_cap = subset ? cap : 0;
 	}
-	c->zsub = subset;
-	c->Z = Z;
+	z->sub = subset;
+	z->Z = Z;
 	{
 		uint64_t *d_key = NULL; uint32_t *d_flag = NULL, *d_cnt = NULL, *d_dpos = NULL; uint32_t *d_val = Z.sidx;
 		CHK(dev_alloc((void**)&d_key, (tot + 1) * 8));
@@ -932,7 +941,7 @@ static int zindex_build_impl(wtz_ctx_t *c, const uint32_t *members, uint32_t nm)
 		dev_free(d_key); dev_free(d_flag); dev_free(d_cnt); dev_free(d_dpos);
 	}
 	dev_free(d_prid); dev_free(d_pjb); dev_free(d_poff);
-	c->have_z = true;
+	z->have = true;
 	c->cnt.ms_zindex += tm.stop();
 	return WTZ_OK;
 }
@@ -941,6 +950,15 @@ extern "C" int wtz_zindex_build_subset(wtz_ctx_t *c, const uint32_t *ids, uint32
 	if(!ids && n) return wtz_fail(WTZ_E_ARG, "null argument");
 	static const uint32_t none = 0;
 	return zindex_build_impl(c, ids ? ids : &none, n);
+}
+/* second index for the QUERY side of the pair stages: the listed reads' tables are read from it, the candidates' z-mers from the index of
+ * wtz_zindex_build / _subset (which then only has to hold the reads this device sees as candidates).  ids == NULL && n == 0 drops it. */
+extern "C" int wtz_zindex_build_queries(wtz_ctx_t *c, const uint32_t *ids, uint32_t n){
+	if(!c) return wtz_fail(WTZ_E_ARG, "null argument");
+	if(!ids && n) return wtz_fail(WTZ_E_ARG, "null argument");
+	if(!ids){ c->zs[1].have = false; return WTZ_OK; }
+	if(!c->zs[0].have) return wtz_fail(WTZ_E_STATE, "wtz_zindex_build_queries before wtz_zindex_build / wtz_zindex_build_subset");
+	return zindex_build_impl(c, ids, n, 1);
 }
 
 /* ------------------------------------------------------------------------------------------------ */
@@ -1146,7 +1164,7 @@ static void wtz_crumbs_dump(int sig){
 #endif
 
 extern "C" int wtz_pairs_seed(wtz_ctx_t *c, const uint32_t *qid, const uint32_t *cid, uint32_t n, wtz_pair_summary_t *out){
-	if(!c || !c->have_z || (n && (!qid || !cid || !out))) return wtz_fail(WTZ_E_ARG, "z-index not built / null argument");
+	if(!c || !c->zs[0].have || (n && (!qid || !cid || !out))) return wtz_fail(WTZ_E_ARG, "z-index not built / null argument");
 	CTX_ENTER(c);
 	free_batch(c);
 	CHK(pool_reset(c));

@@ -18,6 +18,8 @@
 
 typedef struct {
 	wtz_reads_t R; wtz_zindex_t Z; const wtz_params_t *P; wtz_pool_t *pool;
+	wtz_zindex_t ZQ;             /* the index the QUERY's z-mer table is read from: == Z unless the caller keeps the queries of the batch in a second index
+	                              * (wtz_zindex_build_queries: several GPUs, each holding the candidate side of its own share of the reads only) */
 	uint32_t dm_first_big;       /* dmo: a strand whose image does not fit the slice of the first K_pair launch keeps it in the pool instead of leaving the pair to a later launch */
 } wtz_env_t;
 
@@ -68,7 +70,7 @@ WTZ_HD void wtz_task_pair(uint32_t t, const wtz_env_t &V, const uint32_t *qid, c
 	const uint64_t tk0 = WTZ_TICK();
 	WTZ_CRUMB(t, 1);
 	const bool aux = P->aux_strand != 0;                     /* align_hzmaux's form of the pair stages (wtgbo): strand 0 only, no n_hits gate */
-	const bool ok = wtz_zmatch_coop(V.Z, q, c, V.R.rdlen[c], P->max_kmer_var, V.pool, &hits, &n, aux);
+	const bool ok = wtz_zmatch_coop(V.ZQ, V.Z, q, c, V.R.rdlen[c], P->max_kmer_var, V.pool, &hits, &n, aux);
 	const uint64_t tk1 = WTZ_TICK();
 	WTZ_CRUMB(t, 2 | (n << 8));
 	wtz_zhit_t *sorted = NULL;

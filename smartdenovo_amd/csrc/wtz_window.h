@@ -20,21 +20,21 @@
 #define WTZ_KWIN_MAX_OFFSET_DEV 50
 
 /* ---- A6: walk the candidate's position-ordered z-mers, look each up in the query's table ---- */
-WTZ_HD bool wtz_zmatch(const wtz_zindex_t &Z, uint32_t q, uint32_t c, uint32_t clen, uint32_t max_var, wtz_vec<wtz_zhit_t> &out, bool same_strand = false){
-	const uint64_t qo = Z.zoff[q], co = Z.zoff[c];
-	const uint32_t cn = (uint32_t)(Z.zoff[c + 1] - co), qd = Z.dn[q];
-	const uint32_t *dmer = Z.dmer + qo;
+WTZ_HD bool wtz_zmatch(const wtz_zindex_t &ZQ, const wtz_zindex_t &ZC, uint32_t q, uint32_t c, uint32_t clen, uint32_t max_var, wtz_vec<wtz_zhit_t> &out, bool same_strand = false){
+	const uint64_t qo = ZQ.zoff[q], co = ZC.zoff[c];      /* ZQ: the index holding the query's table (A5), ZC: the one holding the candidate's position-ordered z-mers (the same index unless the caller split them) */
+	const uint32_t cn = (uint32_t)(ZC.zoff[c + 1] - co), qd = ZQ.dn[q];
+	const uint32_t *dmer = ZQ.dmer + qo;
 	for(uint32_t k = 0; k < cn; k++){
-		if(!Z.ok[co + k]) continue;                       /* per-table-entry hit cap (hzm_aln.h:208-211) */
-		uint32_t m = Z.mer[co + k];
+		if(!ZC.ok[co + k]) continue;                       /* per-table-entry hit cap (hzm_aln.h:208-211) */
+		uint32_t m = ZC.mer[co + k];
 		uint32_t lo = 0, hi = qd;
 		while(lo < hi){ uint32_t mid = (lo + hi) >> 1; if(dmer[mid] < m) lo = mid + 1; else hi = mid; }
 		if(lo >= qd || dmer[lo] != m) continue;
-		uint32_t cpos = Z.pos[co + k], clen2 = Z.len[co + k];
-		uint32_t first = Z.dfirst[qo + lo], cnt = Z.dcnt[qo + lo];
+		uint32_t cpos = ZC.pos[co + k], clen2 = ZC.len[co + k];
+		uint32_t first = ZQ.dfirst[qo + lo], cnt = ZQ.dcnt[qo + lo];
 		for(uint32_t e = 0; e < cnt; e++){
-			uint32_t qi = Z.sidx[qo + first + e];
-			uint32_t qpos = Z.pos[qo + qi], qlen = Z.len[qo + qi];
+			uint32_t qi = ZQ.sidx[qo + first + e];
+			uint32_t qpos = ZQ.pos[qo + qi], qlen = ZQ.len[qo + qi];
 			uint32_t dv = qlen > clen2 ? qlen - clen2 : clen2 - qlen;
 			if(dv > max_var) continue;
 			uint32_t d1 = qpos & 1u, d2 = cpos & 1u;
@@ -51,10 +51,10 @@ WTZ_HD bool wtz_zmatch(const wtz_zindex_t &Z, uint32_t q, uint32_t c, uint32_t c
  * candidate-position order through an exclusive scan of the per-lane match counts (emission order is part of the
  * contract: hzm_aln.h:212-221).  Two passes: count (the dense index of each z-mer is cached), allocate exactly, fill.
  * Returns the match list through *out / *n_out on every lane; false when the pool is exhausted. */
-WTZ_HD bool wtz_zmatch_coop(const wtz_zindex_t &Z, uint32_t q, uint32_t c, uint32_t clen, uint32_t max_var, wtz_pool_t *pool, wtz_zhit_t **out, uint32_t *n_out, bool same_strand = false){
-	const uint64_t qo = Z.zoff[q], co = Z.zoff[c];
-	const uint32_t cn = (uint32_t)(Z.zoff[c + 1] - co), qd = Z.dn[q];
-	const uint32_t *dmer = Z.dmer + qo;
+WTZ_HD bool wtz_zmatch_coop(const wtz_zindex_t &ZQ, const wtz_zindex_t &ZC, uint32_t q, uint32_t c, uint32_t clen, uint32_t max_var, wtz_pool_t *pool, wtz_zhit_t **out, uint32_t *n_out, bool same_strand = false){
+	const uint64_t qo = ZQ.zoff[q], co = ZC.zoff[c];      /* ZQ: the index holding the query's table (A5), ZC: the one holding the candidate's position-ordered z-mers (the same index unless the caller split them) */
+	const uint32_t cn = (uint32_t)(ZC.zoff[c + 1] - co), qd = ZQ.dn[q];
+	const uint32_t *dmer = ZQ.dmer + qo;
 	const uint32_t lane = WTZ_LANE;
 	uint64_t pa = 0;
 	if(lane == 0) pa = (uint64_t)(uintptr_t)wtz_pool_alloc(pool, (size_t)(cn + 1) * 8);
@@ -70,8 +70,8 @@ WTZ_HD bool wtz_zmatch_coop(const wtz_zindex_t &Z, uint32_t q, uint32_t c, uint3
 		#pragma unroll
 		for(int u = 0; u < 4; u++){
 			const uint32_t k = k0 + u * WTZ_NLANES + lane;
-			act[u] = k < cn && Z.ok[co + k];
-			m[u] = act[u] ? Z.mer[co + k] : 0u;
+			act[u] = k < cn && ZC.ok[co + k];
+			m[u] = act[u] ? ZC.mer[co + k] : 0u;
 			lo[u] = 0; hi[u] = act[u] ? qd : 0u;
 		}
 		for(;;){
@@ -89,13 +89,13 @@ WTZ_HD bool wtz_zmatch_coop(const wtz_zindex_t &Z, uint32_t q, uint32_t c, uint3
 			uint32_t cnt = 0, idx = 0xFFFFFFFFu;
 			if(act[u] && lo[u] < qd && dmer[lo[u]] == m[u]){
 				idx = lo[u];
-				const uint32_t clen2 = Z.len[co + k], first = Z.dfirst[qo + idx], n = Z.dcnt[qo + idx];
-				const uint32_t cdir = Z.pos[co + k] & 1u;
+				const uint32_t clen2 = ZC.len[co + k], first = ZQ.dfirst[qo + idx], n = ZQ.dcnt[qo + idx];
+				const uint32_t cdir = ZC.pos[co + k] & 1u;
 				for(uint32_t e = 0; e < n; e++){
-					const uint32_t qi = Z.sidx[qo + first + e];
-					const uint32_t qlen = Z.len[qo + qi];
+					const uint32_t qi = ZQ.sidx[qo + first + e];
+					const uint32_t qlen = ZQ.len[qo + qi];
 					const uint32_t dvv = qlen > clen2 ? qlen - clen2 : clen2 - qlen;
-					if(same_strand && ((Z.pos[qo + qi] ^ cdir) & 1u)) continue;       /* align_hzmaux keeps strand 0 only (hzm_aln.h:1193) */
+					if(same_strand && ((ZQ.pos[qo + qi] ^ cdir) & 1u)) continue;       /* align_hzmaux keeps strand 0 only (hzm_aln.h:1193) */
 					if(dvv <= max_var) cnt++;
 				}
 			}
@@ -116,11 +116,11 @@ WTZ_HD bool wtz_zmatch_coop(const wtz_zindex_t &Z, uint32_t q, uint32_t c, uint3
 		uint32_t chunk; uint32_t o = base + wtz_coop_excl_scan(cnt, &chunk);
 		if(cnt){
 			const uint32_t lo = found[k];
-			const uint32_t cpos = Z.pos[co + k], clen2 = Z.len[co + k];
-			const uint32_t first = Z.dfirst[qo + lo], n = Z.dcnt[qo + lo];
+			const uint32_t cpos = ZC.pos[co + k], clen2 = ZC.len[co + k];
+			const uint32_t first = ZQ.dfirst[qo + lo], n = ZQ.dcnt[qo + lo];
 			for(uint32_t e = 0; e < n; e++){
-				const uint32_t qi = Z.sidx[qo + first + e];
-				const uint32_t qpos = Z.pos[qo + qi], qlen = Z.len[qo + qi];
+				const uint32_t qi = ZQ.sidx[qo + first + e];
+				const uint32_t qpos = ZQ.pos[qo + qi], qlen = ZQ.len[qo + qi];
 				const uint32_t dv = qlen > clen2 ? qlen - clen2 : clen2 - qlen;
 				if(dv > max_var) continue;
 				const uint32_t d1 = qpos & 1u, d2 = cpos & 1u;

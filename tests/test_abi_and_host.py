@@ -113,6 +113,27 @@ def test_per_batch_zindex_equals_all_reads_index(name, emul_exe, tmp_path):
     assert md5 == case["md5_full"] and cont == case["md5_contained"]
 
 
+@pytest.mark.parametrize("name,devs,extra", [("zmo", "0,0", []), ("dmo", "0,0,0", []), ("zmo_I", "0,0", []), ("zmo", "0,0,0", ["--shard-index"]), ("dmo", "0,0", ["--shard-index"]), ("zmo_n", "0,0", [])])
+def test_per_batch_zindex_with_several_devices(name, devs, extra, emul_exe, tmp_path):
+    """--zindex-batch 1 with --gpu-list (round 4: the two used to exclude each other): pairs are dealt by candidate id, so device d rebuilds, per
+    batch, the candidate side of the batch's candidate reads = d (mod N) only, plus the query-side index of the batch's queries
+    (wtz_zindex_build_queries); also with the k-mer index sharded (the BASELINE configs[4] combination)."""
+    case = manifest()["cases"][name]
+    md5, cont, _ = run_wtzmo_like(emul_exe, case, tmp_path, extra=["--gpu-list", devs, "--zindex-batch", "1", "--batch", "7"] + extra)
+    assert md5 == case["md5_full"] and cont == case["md5_contained"]
+
+
+def test_split_zindex_can_be_switched_off(emul_exe, tmp_path):
+    """WTZ_NO_ZSPLIT=1: every device builds the z-mer index of all reads (the form before round 4); same records"""
+    case = manifest()["cases"]["zmo"]
+    env = dict(os.environ, WTZ_NO_ZSPLIT="1")
+    out = os.path.join(str(tmp_path), "o.ovl")
+    r = subprocess.run([emul_exe, "-i", os.path.join(ROOT, "tests", "golden", case["input"]), "-fo", out, "--gpu-list", "0,0", "--batch", "16"] + case["argv"], capture_output=True, env=env)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    import hashlib
+    assert hashlib.md5(open(out, "rb").read()).hexdigest() == case["md5_full"]
+
+
 def test_word_level_base_packing(tmp_path):
     """wtz_pack32 (two 64-bit loads + funnel shift per 32 bases, both strands, complement) == 32 single-base extractions."""
     exe = os.path.join(str(tmp_path), "check_pack32")

@@ -33,10 +33,13 @@ dist.destroy_process_group()
 '''
 
 
-@pytest.mark.parametrize("name,world,extra", [("zmo", 2, []), ("dmo", 2, []), ("zmo", 3, []), ("zmo_n", 2, []), ("zmo", 2, ["--shard-index"]), ("dmo", 3, ["--shard-index"])])
+@pytest.mark.parametrize("name,world,extra", [("zmo", 2, []), ("dmo", 2, []), ("zmo", 3, []), ("zmo_n", 2, []), ("zmo", 2, ["--shard-index"]), ("dmo", 3, ["--shard-index"]),
+                                              ("zmo", 2, ["--zindex-batch", "1"]), ("dmo", 3, ["--zindex-batch", "1"]), ("zmo", 2, ["--zindex-batch", "1", "--shard-index"]), ("zmo", 3, ["--zindex-batch", "1", "--shard-index"])])
 def test_ranks_central_commit(name, world, extra, tmp_path):
     """extra = --shard-index: the k-mer index is sharded by read-id range over the RANKS (one (k-mer, count) exchange at build time, the
-    groups of every query gathered from all ranks): rank 0's file must still be the unsharded `wtzmo -t 1` golden."""
+    groups of every query gathered from all ranks): rank 0's file must still be the unsharded `wtzmo -t 1` golden.
+    --zindex-batch 1 (round 4: it used to exclude ranks): rank r rebuilds, per batch, the z-mer index of the batch's candidate reads = r (mod N) and of
+    the batch's queries (WTZ_CMD_ZIDX) - with --shard-index on top this is the BASELINE configs[4] combination."""
     subprocess.run([os.path.join(ROOT, "tests", "emul", "build_emul.sh")], check=True)
     lib = os.path.join(ROOT, "tests", "emul", "libwtzmo_host_emul.so")
     case = manifest()["cases"][name]
@@ -61,3 +64,30 @@ def test_ranks_central_commit(name, world, extra, tmp_path):
         assert os.path.getsize(os.path.join(str(tmp_path), "r%d.ovl" % r)) == 0, "only rank 0 writes records"
         assert stats[r][1] > 1000, "rank %d computed nothing" % r       # bytes it sent back to rank 0
     assert stats[0][2] == sum(s[1] for s in stats[1:]) and stats[0][2] > 0
+
+
+def test_failed_rank_ends_all_ranks_in_band(tmp_path):
+    """A rank that fails reports it in the status word of its next reply; rank 0 finishes the round of the exchange, broadcasts WTZ_CMD_ABORT and every
+    process exits 1 (the reference's convention: every error is exit(1), list.h:64-67) - nobody stays blocked in a receive until a launcher kills it."""
+    subprocess.run([os.path.join(ROOT, "tests", "emul", "build_emul.sh")], check=True)
+    lib = os.path.join(ROOT, "tests", "emul", "libwtzmo_host_emul.so")
+    case = manifest()["cases"]["zmo"]
+    w = os.path.join(str(tmp_path), "worker.py")
+    open(w, "w").write(WORKER)
+    for failing in (1, 0):
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WTZ_RANK_FAIL_AT="%d:2" % failing)
+        procs = []
+        for r in range(3):
+            e = dict(env, RANK=str(r), WORLD_SIZE="3", LOCAL_RANK=str(r))
+            procs.append(subprocess.Popen([sys.executable, w, ROOT, lib, os.path.join(GOLD, case["input"]), str(tmp_path)] + case_argv(case), env=e, stderr=subprocess.PIPE))
+        errs = []
+        for p in procs:
+            _, err = p.communicate(timeout=300)          # a hang here is the failure this test exists for
+            errs.append(err.decode(errors="replace"))
+        assert [p.returncode for p in procs] == [1, 1, 1], [p.returncode for p in procs]
+        assert "ending all 3 ranks" in errs[0] and ("rank %d failed" % failing) in errs[0]
+        for r in (1, 2):
+            assert "abort requested by rank 0" in errs[r]
