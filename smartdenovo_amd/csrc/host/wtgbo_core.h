@@ -23,6 +23,11 @@
 #include <getopt.h>
 #include <time.h>
 #include "wtgbo_graph.h"
+#include "wtz_ovlb.h"
+
+/* every fatal input error leaves through _exit: the device context is being created on a helper thread meanwhile (wtgbo_main.c), and exit() would run the HIP
+ * runtime's teardown under it (the same rule as DIE_NOW in wtzmo_main.c) */
+#define GBO_DIE() do { fflush(NULL); _exit(1); } while(0)
 
 typedef struct { char **a; int n, cap; } strlist_t;
 static void sl_push(strlist_t *l, char *s){ if(l->n == l->cap){ l->cap = l->cap ? l->cap * 2 : 4; l->a = (char**)hx_realloc(l->a, sizeof(char*) * (size_t)l->cap); } l->a[l->n++] = s; }
@@ -41,7 +46,7 @@ typedef struct {
 	strlist_t pbs, ovls, obss, obts;
 	char *output, *pairoutf;
 	/* ours */
-	int gpu; uint64_t pool_gb; uint32_t batch; int zindex_batch; int ingest_host;
+	int gpu; uint64_t pool_gb; uint32_t batch; int zindex_batch; int ingest_host; int binary_in;
 } gbo_opt_t;
 
 typedef struct {
@@ -77,7 +82,7 @@ static int gbo_usage(void){      /* wtgbo.c:267-309 prints its usage to stdout a
 	" seeding   -H no homopolymer compression   -z <int> z-mer size 5..16 [10]   -Z <int> max z-mer frequency [100]   -y <int> window [800]\n"
 	"           -R <int> min seeded bases per window [200]   -r <int> (accepted, unused) [300]   -l <int> max z-mer length difference [2]\n"
 	" alignment -M 2 -X -5 -O -3 -E -1 -T -50 scores   -w <int> band [50]   -e <int> extension band [800]   -W <int> max band [3200]   -n refine\n"
-	" this build -t <int> accepted (the output is that of -t 1)   --gpu <id>   --pool-gb <n> [16]   --batch <pairs> [16384]   --zindex-batch <0|1>   --ingest <device|host>\n",
+	" this build -t <int> accepted (the output is that of -t 1)   --gpu <id>   --pool-gb <n> [16]   --batch <pairs> [16384]   --zindex-batch <0|1>   --ingest <device|host>   --binary-in (-j: binary records of wtzmo --binary-out)\n",
 	stdout);
 	return 1;
 }
@@ -88,7 +93,7 @@ static int gbo_parse_args(gbo_opt_t *o, int argc, char **argv){
 	o->max_ext = 0; o->max_iter = 5; o->ncpu = 1; o->w = 50; o->ew = 800; o->W = 3200; o->M = 2; o->X = -5; o->O = -3; o->E = -1; o->T = -50;
 	o->hz = 1; o->zsize = 10; o->kwin = 800; o->kstep = 0; o->zovl = 200; o->zcut = 100; o->kvar = 2; o->refine = 0;      /* wtgbo.c:385-411 */
 	o->gpu = 0; o->pool_gb = 0; o->batch = 16384; o->zindex_batch = -1;
-	static const struct option lopts[] = { {"gpu", 1, 0, 1001}, {"pool-gb", 1, 0, 1002}, {"batch", 1, 0, 1003}, {"zindex-batch", 1, 0, 1004}, {"ingest", 1, 0, 1005}, {0, 0, 0, 0} };
+	static const struct option lopts[] = { {"gpu", 1, 0, 1001}, {"pool-gb", 1, 0, 1002}, {"batch", 1, 0, 1003}, {"zindex-batch", 1, 0, 1004}, {"ingest", 1, 0, 1005}, {"binary-in", 0, 0, 1006}, {0, 0, 0, 0} };
 	int c; optind = 1;
 	while((c = getopt_long(argc, argv, "hi:b:j:L:s:m:u:o:9:fQq:c:t:Hz:Z:y:l:r:R:w:e:W:M:X:O:E:T:nN:", lopts, NULL)) != -1){
 		switch(c){
@@ -129,6 +134,7 @@ static int gbo_parse_args(gbo_opt_t *o, int argc, char **argv){
 			case 1003: o->batch = (uint32_t)atoi(optarg); if(o->batch < 1) o->batch = 1; break;
 			case 1004: o->zindex_batch = atoi(optarg); break;
 			case 1005: o->ingest_host = (strcmp(optarg, "host") == 0); break;      /* `device` (default): bases packed to 2 bits on the GPU; `host`: while reading */
+			case 1006: o->binary_in = 1; break;                   /* the -j files are binary overlap streams (include/wtz_ovlb.h); regular files are recognised by their magic without it */
 			default: return 1;
 		}
 	}
@@ -154,7 +160,7 @@ static int gbo_split_tabs(char *line, char **col, int maxcol){
 static void gbo_load_inputs(gbo_t *G){
 	gbo_opt_t *o = &G->O;
 	hx_reader_t *fr = hx_reader_open(o->pbs.a, o->pbs.n);
-	if(!fr) exit(1);
+	if(!fr) GBO_DIE();
 	fprintf(stderr, "[%s] loading reads\n", gbo_date());
 	hx_str_t name = {0, 0, 0}, seq = {0, 0, 0};
 	while(hx_reader_seq(fr, &name, &seq)) hx_store_add(&G->st, name.s ? name.s : "", name.n, seq.s ? seq.s : "", seq.n);      /* file order = node id (wtgbo.c:459-467) */
@@ -164,8 +170,8 @@ static void gbo_load_inputs(gbo_t *G){
 	hx_names_build(&G->names, G->st.reads, G->n_rd);
 	char *col[20];
 	if(o->obts.n){             /* wtgbo.c:468-479, set_read_clip_strgraph wtlay.h:181-191 */
-		fprintf(stderr, "[%s] loading reads obt information\n", gbo_date());
-		if((fr = hx_reader_open(o->obts.a, o->obts.n)) == NULL) exit(1);
+		fprintf(stderr, "[%s] loading the retained regions of the reads (-b)\n", gbo_date());
+		if((fr = hx_reader_open(o->obts.a, o->obts.n)) == NULL) GBO_DIE();
 		while(hx_reader_line(fr) != -1){
 			const int nc = gbo_split_tabs(fr->line, col, 20);
 			if(fr->line[0] == '#') continue;
@@ -179,15 +185,15 @@ static void gbo_load_inputs(gbo_t *G){
 		}
 		hx_reader_close(fr);
 		fprintf(stderr, "[%s] Done\n", gbo_date());
-	} else fprintf(stderr, "[%s] No obt information\n", gbo_date());
+	} else fprintf(stderr, "[%s] no retained regions given\n", gbo_date());
 	G->rdlen = (uint32_t*)hx_realloc(NULL, 4 * ((size_t)G->n_rd + 1));
 	for(uint32_t i = 0; i < G->n_rd; i++) G->rdlen[i] = G->st.reads[i].len;
 	gb_graph_init(&G->g, G->n_rd, G->rdlen);
 	G->g.min_score = o->min_score; G->g.min_id = o->min_id; G->g.max_margin = o->margin; G->g.mat_score = o->mat_score;
 	gb_closed_init(&G->closed);
 	if(o->obss.n){             /* wtgbo.c:488-506 */
-		if((fr = hx_reader_open(o->obss.a, o->obss.n)) == NULL) exit(1);
-		fprintf(stderr, "[%s] loading pairs of read name that alreadly tested\n", gbo_date());
+		if((fr = hx_reader_open(o->obss.a, o->obss.n)) == NULL) GBO_DIE();
+		fprintf(stderr, "[%s] loading the list of read pairs tested before (-L)\n", gbo_date());
 		while(hx_reader_line(fr) != -1){
 			const int nc = gbo_split_tabs(fr->line, col, 20);
 			if(fr->line[0] == '#') continue;
@@ -197,27 +203,71 @@ static void gbo_load_inputs(gbo_t *G){
 			gb_closed_put(&G->closed, gb_pair_id(a, b, 0));
 		}
 		hx_reader_close(fr);
-		fprintf(stderr, "[%s] there were %llu existing tested pairs\n", gbo_date(), (unsigned long long)G->closed.slots.count);
+		fprintf(stderr, "[%s] %llu pairs were tested before\n", gbo_date(), (unsigned long long)G->closed.slots.count);
 	}
 }
 
-/* load_overlaps_strgraph, wtlay.h:443-468 */
-static void gbo_load_overlaps(gbo_t *G){
-	hx_reader_t *fr = hx_reader_open(G->O.ovls.a, G->O.ovls.n);
-	if(!fr) exit(1);
-	char *col[20]; gb_ovl_t d; gb_biedge_t b; uint64_t n = 0;
-	while(hx_reader_line(fr) != -1){
-		if(fr->line[0] == '#') continue;
-		const int nc = gbo_split_tabs(fr->line, col, 20);
-		if(!gb_parse_overlap(&G->g, &G->names, col, nc, &d)) continue;
-		n++;
-		gb_closed_put(&G->closed, gb_pair_id(d.node[0], d.node[1], 0));
-		gb_closed_put(&G->closed, gb_pair_id(d.node[0], d.node[1], 1));
-		if(!gb_biedge_of(&G->g, &d, &b, 1)) continue;
-		if(!gb_count_biedge(&G->g, &b)) continue;
-		gb_biedges_push(&G->biedges, &b);
+/* an accepted overlap enters the closed-pair set and, when it is a proper dovetail / containment, the edge list (wtlay.h:452-466) */
+static void gbo_take_overlap(gbo_t *G, const gb_ovl_t *d, uint64_t *n){
+	gb_biedge_t b;
+	(*n)++;
+	gb_closed_put(&G->closed, gb_pair_id(d->node[0], d->node[1], 0));
+	gb_closed_put(&G->closed, gb_pair_id(d->node[0], d->node[1], 1));
+	if(!gb_biedge_of(&G->g, d, &b, 1)) return;
+	if(!gb_count_biedge(&G->g, &b)) return;
+	gb_biedges_push(&G->biedges, &b);
+}
+/* f3: the same loader fed by binary records (include/wtz_ovlb.h; `bin/wtzmo --binary-out`) instead of text lines.  The ids of a record index the
+ * WRITER's name table, so every name is looked up once per read, not twice per record; the identity the filter sees is the PRINTED one, i.e. the three
+ * decimals `%0.3f` leaves of mat / aln, parsed back exactly like the text loader parses column 12.  Returns records read, -1 = not a binary stream. */
+static long long gbo_load_overlaps_binary(gbo_t *G, FILE *fp, const char *first8, uint64_t *n){
+	wtz_ovlb_reader_t rd;
+	if(wtz_ovlb_open(&rd, fp, first8) != 0) return -1;
+	uint32_t *map = (uint32_t*)hx_realloc(NULL, 4 * ((size_t)rd.n_reads + 1));
+	for(uint64_t i = 0; i < rd.n_reads; i++) map[i] = hx_names_get(&G->names, rd.names[i]);
+	wtz_ovlb_rec_t r; gb_ovl_fields_t f; gb_ovl_t d; long long nrec = 0; int st; char idt[32];
+	while((st = wtz_ovlb_next(&rd, &r)) == 1){
+		nrec++;
+		f.node[0] = map[r.id1]; f.node[1] = map[r.id2]; f.name[0] = rd.names[r.id1]; f.name[1] = rd.names[r.id2];
+		f.dir[0] = 0; f.dir[1] = r.dir2 & 1; f.len[0] = (int)rd.rdlen[r.id1]; f.len[1] = (int)rd.rdlen[r.id2];
+		f.beg[0] = r.tb; f.end[0] = r.te; f.beg[1] = r.qb; f.end[1] = r.qe; f.score = r.score; f.mat = r.mat;
+		wtz_ovlb_identity_text(&r, idt); f.identity = (int)(atof(idt) * 1000);
+		if(gb_accept_overlap(&G->g, &f, &d)) gbo_take_overlap(G, &d, n);
 	}
-	hx_reader_close(fr);
+	if(st < 0){ fprintf(stderr, " -- truncated or corrupt binary overlap stream after %lld records --\n", nrec); GBO_DIE(); }
+	free(map); wtz_ovlb_close(&rd);
+	return nrec;
+}
+/* the loader of the graph's overlaps (load_overlaps_strgraph, wtlay.h:443-468); every -j file may be text (>= 16 columns) or binary (sniffed by its magic) */
+static void gbo_load_overlaps(gbo_t *G){
+	char *col[20]; gb_ovl_fields_t f; gb_ovl_t d; uint64_t n = 0;
+	for(int k = 0; k < G->O.ovls.n; k++){
+		char *path = G->O.ovls.a[k];
+		const size_t pl = strlen(path);
+		const int is_stdin = (strcmp(path, "-") == 0), is_gz = (pl > 3 && strcmp(path + pl - 3, ".gz") == 0);
+		if(G->O.binary_in || (!is_stdin && !is_gz)){
+			FILE *fp = is_stdin ? stdin : fopen(path, "rb");
+			if(!fp){ fprintf(stderr, " -- Cannot open %s --\n", path); GBO_DIE(); }
+			char m8[8]; const size_t got = fread(m8, 1, 8, fp);
+			if(got == 8 && memcmp(m8, WTZ_OVLB_MAGIC, 8) == 0){
+				const long long nrec = gbo_load_overlaps_binary(G, fp, m8, &n);
+				if(nrec < 0){ fprintf(stderr, " -- %s: unreadable binary overlap header --\n", path); GBO_DIE(); }
+				if(!is_stdin) fclose(fp);
+				continue;
+			}
+			if(G->O.binary_in){ fprintf(stderr, " -- %s is not a binary overlap stream (--binary-in) --\n", path); GBO_DIE(); }
+			fclose(fp);       /* text: read it again through the line reader */
+		}
+		hx_reader_t *fr = hx_reader_open(&path, 1);
+		if(!fr) GBO_DIE();
+		while(hx_reader_line(fr) != -1){
+			if(fr->line[0] == '#') continue;
+			const int nc = gbo_split_tabs(fr->line, col, 20);
+			if(!gb_fields_from_text(&G->names, col, nc, &f)) continue;
+			if(gb_accept_overlap(&G->g, &f, &d)) gbo_take_overlap(G, &d, &n);
+		}
+		hx_reader_close(fr);
+	}
 	fprintf(stderr, "loaded %llu overlaps\n", (unsigned long long)n);
 	gb_build_edges(&G->g, &G->biedges);
 }
@@ -328,10 +378,10 @@ static int gbo_run(gbo_t *G){
 		fprintf(stderr, "---------------------------\n[%s] iteration %d\n", gbo_date(), iter);
 		memset(g->dead, 0, (size_t)g->n_rd + 1);
 		if(iter == 1){
-			fprintf(stderr, "[%s] loading alignments\n", gbo_date());
+			fprintf(stderr, "[%s] loading the overlaps (-j)\n", gbo_date());
 			gbo_load_overlaps(G);
 		} else {              /* wtgbo.c:540-553 */
-			fprintf(stderr, "[%s] bulding edges\n", gbo_date());
+			fprintf(stderr, "[%s] rebuilding the edge lists with the new overlaps\n", gbo_date());
 			for(uint32_t i = 0; i < g->n_rd; i++){ g->nodes[i].ecnt[0] = g->nodes[i].ecnt[1] = 0; }
 			gb_biedges_t kept; memset(&kept, 0, sizeof kept);
 			for(size_t i = 0; i < G->biedges.n; i++) if(gb_count_biedge(g, &G->biedges.a[i])) gb_biedges_push(&kept, &G->biedges.a[i]);
@@ -339,18 +389,18 @@ static int gbo_run(gbo_t *G){
 			gb_build_edges(g, &kept);
 			free(kept.a);
 		}
-		fprintf(stderr, "[%s] calculating edge coverage ...\n", gbo_date());
+		fprintf(stderr, "[%s] edge coverage\n", gbo_date());
 		gb_edge_coverage(g);
 		unsigned long long n = gb_drop_duplicate_edges(g);
-		fprintf(stderr, "[%s] removed %llu duplicate edges\n", gbo_date(), n);
+		fprintf(stderr, "[%s] %llu duplicate edges dropped\n", gbo_date(), n);
 		n = gb_mask_contained(g);
-		fprintf(stderr, "[%s] masked %llu contained reads\n", gbo_date(), n);
+		fprintf(stderr, "[%s] %llu contained reads masked\n", gbo_date(), n);
 		n = gb_mask_low_cov(g, (uint32_t)o->edgecov_cutoff);
-		fprintf(stderr, "[%s] masked %llu low coverage (<%u) edges\n", gbo_date(), n, (unsigned)o->edgecov_cutoff);
+		fprintf(stderr, "[%s] %llu edges below coverage %u masked\n", gbo_date(), n, (unsigned)o->edgecov_cutoff);
 		n = gb_best_overlap(g, o->best_score_cutoff);
-		fprintf(stderr, "[%s] 'best_overlap' cut %llu non-best edges\n", gbo_date(), n);
+		fprintf(stderr, "[%s] best-overlap rule: %llu other edges cut\n", gbo_date(), n);
 		/* ---- graph based overlapping (gbo_core_wtgbo, wtgbo.c:143-208) ---- */
-		fprintf(stderr, "[%s] graph based overlapping\n", gbo_date());
+		fprintf(stderr, "[%s] pass 1: pairs two steps apart in the graph\n", gbo_date());
 		G->njob = 0;
 		for(uint32_t node = 0; node < g->n_rd; node++){
 			if(g->dead[node]) continue;
@@ -363,9 +413,9 @@ static int gbo_run(gbo_t *G){
 		}
 		fprintf(stderr, "[%s] %llu candidates\n", gbo_date(), (unsigned long long)G->njob);
 		unsigned long long nn = gbo_run_jobs(G, 1);
-		fprintf(stderr, "[%s] Done, %llu new overlaps\n", gbo_date(), nn);
+		fprintf(stderr, "[%s] %llu new overlaps\n", gbo_date(), nn);
 		/* ---- anchoring based overlapping (abo_core_wtgbo, wtgbo.c:267-330) ---- */
-		fprintf(stderr, "[%s] anchoring based overlapping\n", gbo_date());
+		fprintf(stderr, "[%s] pass 2: pairs anchored on the same stretch of a read\n", gbo_date());
 		G->njob = 0;
 		for(uint32_t node = 0; node < g->n_rd; node++){
 			c64.n = 0;
@@ -374,7 +424,7 @@ static int gbo_run(gbo_t *G){
 		}
 		fprintf(stderr, "[%s] %llu candidates\n", gbo_date(), (unsigned long long)G->njob);
 		n = gbo_run_jobs(G, 0);
-		fprintf(stderr, "[%s] Done, %llu new overlaps\n", gbo_date(), n);
+		fprintf(stderr, "[%s] %llu new overlaps\n", gbo_date(), n);
 		nn += n;
 		fflush(G->out);
 		if(nn == 0) break;

@@ -3,7 +3,7 @@
  * wtlay.h as far as wtgbo.c uses it, and the two candidate walks of wtgbo.c.  Everything here is sequential bookkeeping over
  * integers; the pair work the candidates feed (align_hzmaux, hzm_aln.h:1684-1775) runs on the device through include/wtzmo_hip.h.
  *
- *   gb_parse_overlap        <- parse_overlap_item_strgraph            wtlay.h:238-274
+ *   gb_fields_from_text / gb_fields_from_record (wtgbo_core.h) + gb_accept_overlap  <- parse_overlap_item_strgraph  wtlay.h:238-274
  *   gb_biedge_of            <- overlap_item2biedge(_v2)_strgraph      wtlay.h:276-344
  *   gb_load_overlaps        <- load_overlaps_strgraph                 wtlay.h:443-468
  *   gb_build_edges          <- load_overlaps_core_strgraph            wtlay.h:349-441
@@ -73,29 +73,46 @@ static void gb_graph_init(gb_graph_t *g, uint32_t n_rd, const uint32_t *rdlen){
 static inline uint32_t gb_next_a(gb_graph_t *g){ if(++g->cur_a == 0){ memset(g->stamp_a, 0, ((size_t)g->n_rd + 1) * 4); g->cur_a = 1; } return g->cur_a; }
 static inline uint32_t gb_next_b(gb_graph_t *g){ if(++g->cur_b == 0){ memset(g->stamp_b, 0, ((size_t)g->n_rd + 1) * 8); g->cur_b = 1; } return g->cur_b; }
 
-/* one line of an overlap file already cut into its tab-separated, non-empty columns (split_string, string.h:251-274).
- * 1 = usable, 0 = skip the line.  An inconsistent read length ends the program like the reference (wtlay.h:249-252). */
-static int gb_parse_overlap(const gb_graph_t *g, const hx_names_t *names, char **col, int ncol, gb_ovl_t *d){
-	if(ncol < 16) return 0;
-	d->node[0] = hx_names_get(names, col[0]);
-	if(d->node[0] == 0xFFFFFFFFu) return 0;
-	if(g->rdlen[d->node[0]] == 0) return 0;
-	d->dir[0] = (col[1][0] == '-');
-	int pb = atoi(col[2]);
-	if(pb != (int)g->rdlen[d->node[0]]){ fprintf(stderr, " -- Inconsistent read (%s) length %d != %d --\n", col[0], (int)g->rdlen[d->node[0]], pb); exit(1); }
-	d->beg[0] = atoi(col[3]); d->end[0] = atoi(col[4]);
-	d->node[1] = hx_names_get(names, col[5]);
-	if(d->node[1] == 0xFFFFFFFFu) return 0;
-	if(d->node[0] == d->node[1]) return 0;
-	if(g->rdlen[d->node[1]] == 0) return 0;
-	d->dir[1] = (col[6][0] == '-');
-	pb = atoi(col[7]);
-	if(pb != (int)g->rdlen[d->node[1]]){ fprintf(stderr, " -- Inconsistent read (%s) length %d != %d --\n", col[5], (int)g->rdlen[d->node[1]], pb); exit(1); }
-	d->beg[1] = atoi(col[8]); d->end[1] = atoi(col[9]);
-	d->score = g->mat_score ? atoi(col[12]) : atoi(col[10]);
-	d->identity = (int)(atof(col[11]) * 1000);
+/* One overlap as its consumer sees it, whatever carried it here: a text line already cut into its tab-separated, non-empty columns
+ * (split_string, string.h:251-274) or a binary record (include/wtz_ovlb.h).  Both loaders fill this and gb_accept_overlap decides. */
+typedef struct {
+	uint32_t node[2];            /* read ids in THIS program's numbering, 0xFFFFFFFF = name unknown here */
+	const char *name[2];         /* for the message only */
+	int dir[2], len[2], beg[2], end[2];
+	int score, mat;              /* columns 11 and 13 */
+	int identity;                /* (int)(atof(column 12) * 1000): the PRINTED three decimals, not mat / aln */
+} gb_ovl_fields_t;
+
+/* The filter in front of the graph (what parse_overlap_item_strgraph, wtlay.h:238-274, lets through).  1 = usable, 0 = skip.
+ * The ORDER of the tests is observable - a read-length mismatch ends the program, everything else skips the overlap - so side 0 is
+ * judged completely before side 1 is looked at, and the score / identity thresholds come last. */
+static int gb_accept_overlap(const gb_graph_t *g, const gb_ovl_fields_t *f, gb_ovl_t *d){
+	for(int s = 0; s < 2; s++){
+		const uint32_t id = f->node[s];
+		if(id == 0xFFFFFFFFu) return 0;
+		if(s == 1 && id == f->node[0]) return 0;               /* a read against itself */
+		if(g->rdlen[id] == 0) return 0;
+		if(f->len[s] != (int)g->rdlen[id]){
+			fprintf(stderr, " -- overlap file and read file disagree: read %s is %d bp long here, the overlap says %d --\n", f->name[s], (int)g->rdlen[id], f->len[s]);
+			fflush(NULL); _exit(1);
+		}
+		d->node[s] = id; d->dir[s] = f->dir[s]; d->beg[s] = f->beg[s]; d->end[s] = f->end[s];
+	}
+	d->score = g->mat_score ? f->mat : f->score;
+	d->identity = f->identity;
 	if(d->score < g->min_score) return 0;
 	if((float)d->identity < 1000 * g->min_id) return 0;
+	return 1;
+}
+/* a text line: needs its first 16 columns (wtlay.h:239-241) */
+static int gb_fields_from_text(const hx_names_t *names, char **col, int ncol, gb_ovl_fields_t *f){
+	if(ncol < 16) return 0;
+	for(int s = 0; s < 2; s++){
+		char **c = col + 5 * s;       /* name, strand, length, begin, end */
+		f->name[s] = c[0]; f->node[s] = hx_names_get(names, c[0]);
+		f->dir[s] = (c[1][0] == '-'); f->len[s] = atoi(c[2]); f->beg[s] = atoi(c[3]); f->end[s] = atoi(c[4]);
+	}
+	f->score = atoi(col[10]); f->identity = (int)(atof(col[11]) * 1000); f->mat = atoi(col[12]);
 	return 1;
 }
 
