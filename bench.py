@@ -9,9 +9,12 @@ exactly this input is pinned to the reference: tests/test_gpu_scale.py compares 
 The host driver runs in-process (libwtzmo_host.so = the C `wtzmo` main built as a shared object) so that exactly K steps are
 bracketed by barrier + torch.cuda.synchronize() on both sides.
 
-N > 1: one process per GPU (torchrun).  The order-dependent part of `wtzmo -t 1` is one sequential stream by definition, so rank 0 plans
-and commits; the pure device stages (seed lookup per query; pair seeding, windows, banded SW and CIGAR rendering per pair) are dealt
-round-robin over the ranks, each with the reads and both indexes replicated in its own HBM; requests go out from rank 0 and results
+N > 1: one process per GPU - launched by the driver under torch.distributed.run, or by `python bench.py --gpus N` itself when no launcher set
+WORLD_SIZE (it re-executes itself under torch.distributed.run; --gpus must equal the number of ranks).  The order-dependent part of `wtzmo -t 1`
+is one sequential stream by definition, so rank 0 plans and commits; the pure device stages (seed lookup per query; pair seeding, windows,
+banded SW and CIGAR rendering per pair) are dealt over the ranks - pairs by candidate id, so that a rank's z-mer index holds the candidate side
+of its own residue class of the reads plus the queries of the batch in flight; reads and k-mer index replicated in every HBM (or the k-mer
+index sharded by read id: --workload human30); requests go out from rank 0 and results
 (pair summaries, window boxes, alignment results, CIGAR text) come back with RCCL send / recv over xGMI inside the timed region
 (smartdenovo_amd/multigpu.py).  Rank 0 writes ONE .ovl, identical to `wtzmo -t 1` for any N; total work is fixed -> "strong" scaling.
 
@@ -21,8 +24,10 @@ roofline      = K-sw3 (shifting-band extension, the dominant DP stage; two concu
                 execute them x 12 int32 ops per cell / HIP-event time of the stage launches, against the int32 VALU peak
 roofline_sw1  = K-sw1 (fixed-band extension between anchors, K_winalign), roofline_sw2 = K-sw2 (global banded, K_gap): same pricing
 roofline_seed = seed lookup (K_candidates): algorithmic bytes (L/4 + 16 B per probe + 4 B per seed entry) / kernel time vs 8 TB/s
-cpu_baseline  = the REAL reference `wtzmo -t <cores>` (oracle/_ref, prebuilt) on a bounded sample of the same workload shape (same
-                coverage, smaller genome), its overlap phase timed like the GPU's (from "calculating overlaps" to exit; FASTA load excluded)
+cpu_baseline  = the REAL reference `wtzmo -t 32` (oracle/_ref, prebuilt) on THE BENCH INPUT ITSELF for configs[1] / configs[2] (a same-shape sample for the larger
+                shapes), its overlap phase timed like the GPU's (from "calculating overlaps" to exit; FASTA load excluded); cpu_baseline_all_cores = the same
+                binary with -t <all hardware threads> on a bounded sample (north_star's figure: slower than -t 32, the reference's index build is O(threads x bases))
+parity        = md5 of the last step's .ovl against reference `wtzmo -t 1` on the same input (tests/golden/big_manifest.json); a mismatch voids the run (exit 1)
 """
 from __future__ import annotations
 
@@ -46,11 +51,46 @@ HBM_PEAK_GBS = 8000.0
 OPS_PER_CELL = 12                                        # SURVEY 8d nominal op count of one DP cell update
 # seeds / sizes are those of tests/golden/big_manifest.json, so the md5 parity of exactly these inputs is a driver-run test
 WORKLOADS = {
-    "yeast100": dict(genome=12000000, coverage=100.0, seed=29, cpu_genome=600000,
+    "yeast100": dict(genome=12000000, coverage=100.0, seed=29, cpu_genome=12000000, golden="yeast100",      # the CPU baseline runs on the bench input itself (~200 s at -t 32)
                      name="BASELINE configs[2]: 1.2 Gbp of synthetic PacBio-shape reads (12 Mbp iid genome x100)"),
-    "ecoli": dict(genome=4600000, coverage=25.0, seed=11, cpu_genome=4600000,      # the CPU baseline runs on the bench input itself (about 14 s at -t 32)
+    "ecoli": dict(genome=4600000, coverage=25.0, seed=11, cpu_genome=4600000, golden="ecoli",      # the CPU baseline runs on the bench input itself (about 14 s at -t 32)
                   name="BASELINE configs[1]: E. coli-shape synthetic PacBio reads (4.6 Mbp iid genome x25)"),
+    # configs[3] shape: 951 827 reads / 9.8 Gbp (generating the 10 GB FASTA takes ~10 minutes of numpy before the first step; the z-mer index is rebuilt per batch of
+    # queries above 2.4 Gbp per device).  No whole-job reference exists (`wtzmo -t 1` would run for days): parity at this shape is pinned on the reference's
+    # -P 128 -p 0 stripe (tests/test_gpu_scale.py[fly70_zmo_P128p0]); the CPU baseline is a same-shape sample.
+    "fly70": dict(genome=140000000, coverage=70.0, seed=53, cpu_genome=1400000, golden=None, extra=[],
+                  name="BASELINE configs[3]: D. melanogaster-shape synthetic reads (140 Mbp iid genome x70 = 9.8 Gbp), query-sharded"),
+    # configs[4] shape, scaled to what one box can generate in minutes: 30x of an iid genome with the human pipeline's -k 17 (smartdenovo.pl:16), the k-mer index
+    # sharded by read-id range over the ranks (--shard-index) and the z-mer index per batch; --genome 3000000000 is the full configs[4] (90 Gbp: needs 8 GPUs)
+    "human30": dict(genome=100000000, coverage=30.0, seed=59, cpu_genome=2000000, golden=None, extra=["--shard-index", "--zindex-batch", "1"], k17=True,
+                    name="BASELINE configs[4] shape, scaled: 30x of a 100 Mbp iid genome (3 Gbp of reads), -k 17, per-GPU index shard"),
 }
+
+
+def file_md5(path):
+    import hashlib
+    h = hashlib.md5()
+    with open(path, "rb") as fh:
+        for blk in iter(lambda: fh.read(1 << 24), b""):
+            h.update(blk)
+    return h.hexdigest()
+
+
+def kernel_source_id():
+    """sha1 over the device sources (smartdenovo_amd/csrc/*.h, *.cpp): what a PMC summary under profiles/ was measured on, and what this run was built from"""
+    import hashlib
+    h = hashlib.sha1()
+    d = os.path.join(ROOT, "smartdenovo_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".h", ".cpp")):
+            h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def git_blob_id(path):
+    import hashlib
+    b = open(path, "rb").read()
+    return hashlib.sha1(b"blob %d\0" % len(b) + b).hexdigest()
 
 
 def gen_reads(path, genome, coverage, seed):
@@ -65,11 +105,11 @@ def gen_reads(path, genome, coverage, seed):
     return meta
 
 
-def cpu_baseline(engine_argv, genome, coverage, seed, tmp, same_input=False):
+def cpu_baseline(engine_argv, genome, coverage, seed, tmp, same_input=False, threads=0, fa=None):
     """Reference (or oracle port) timed on this host's cores on a bounded sample of the same workload shape."""
     ref = os.path.join(ROOT, "oracle", "_ref", "wtzmo_ref")
     ora = os.path.join(ROOT, "oracle", "wtzmo_oracle")
-    fa = os.path.join(tmp, "cpu_sample_G%d_c%g_s%d.fa" % (genome, coverage, seed))
+    fa = fa or os.path.join(tmp, "cpu_sample_G%d_c%g_s%d.fa" % (genome, coverage, seed))
     meta = gen_reads(fa, genome, coverage, seed)
     lens = {}
     name = None
@@ -80,7 +120,7 @@ def cpu_baseline(engine_argv, genome, coverage, seed, tmp, same_input=False):
             lens[name] = len(line.strip())
     # the reference's index build is O(threads x bases) (every thread scans every read, wtzmo.c:272): on the 256-thread GPU host
     # -t 256 is 4x SLOWER than -t 32 (56 s vs 13.8 s on the full E. coli-shape set), so the baseline uses min(32, cores)
-    ncpu = min(32, os.cpu_count() or 1)
+    ncpu = threads or min(32, os.cpu_count() or 1)
     out = os.path.join(tmp, "cpu.ovl")
     if os.path.exists(ref):
         pairs = os.path.join(tmp, "cpu.pairs")
@@ -125,12 +165,30 @@ def main():
     ap.add_argument("--pool-gb", type=int, default=0, help="device scratch (0 = the library's default: 45 % of the free HBM, at most 128 GB)")
     ap.add_argument("--cpu-genome", type=int, default=0, help="genome length of the bounded CPU-baseline sample (same coverage)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline", choices=["input", "sample"], default=None, help="reference wtzmo on the bench input itself (default where the workload has a golden) or on a bounded same-shape sample")
+    ap.add_argument("--no-verify", action="store_true", help="skip the md5 comparison of the last step's .ovl with the reference golden (tests/golden/big_manifest.json)")
     a = ap.parse_args()
     wl = WORKLOADS[a.workload]
-    a.genome = a.genome or wl["genome"]; a.coverage = a.coverage or wl["coverage"]; a.seed = a.seed or wl["seed"]; a.cpu_genome = a.cpu_genome or wl["cpu_genome"]
+    a.genome = a.genome or wl["genome"]; a.coverage = a.coverage or wl["coverage"]; a.seed = a.seed or wl["seed"]
+    same_as_golden = (a.genome == wl["genome"] and a.coverage == wl["coverage"] and a.seed == wl["seed"])
+    if a.cpu_baseline is None:
+        a.cpu_baseline = "input" if (wl.get("golden") and same_as_golden) else "sample"
+    a.cpu_genome = a.cpu_genome or (a.genome if a.cpu_baseline == "input" else min(wl["cpu_genome"], a.genome) if wl["cpu_genome"] != wl["genome"] else max(200000, a.genome // 20))
 
-    rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: become the launcher - one rank per GPU under torch.distributed.run (the driver's own
+        # multi-GPU command form), rank 0 prints the one JSON line
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus), "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        print("[bench] --gpus %d without WORLD_SIZE: launching %s" % (a.gpus, " ".join(cmd)), file=sys.stderr)
+        sys.exit(subprocess.run(cmd).returncode)
+    if a.gpus != world:
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d: the two must agree (the JSON line reports n_gpus = the number of ranks that ran)" % (a.gpus, world))
+    rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     import torch
     if not torch.cuda.is_available():
@@ -138,17 +196,21 @@ def main():
     # WTZ_BENCH_BACKEND=gloo: a test aid for boxes with fewer GPUs than ranks (RCCL refuses two ranks on one device): ranks share
     # the GPUs round-robin and exchange through gloo / host tensors; everything else is the measured path
     backend = os.environ.get("WTZ_BENCH_BACKEND", "nccl")
+    if backend == "nccl" and world > torch.cuda.device_count():
+        sys.exit("bench.py: %d ranks on %d visible GPU(s): RCCL needs one device per rank (WTZ_BENCH_BACKEND=gloo lets ranks share a device - a test aid, not a measurement)" % (world, torch.cuda.device_count()))
     local = local % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
     dist = None
     if world > 1:
+        import datetime
         import torch.distributed as dist_
         dist = dist_
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        long = datetime.timedelta(hours=3)      # rank 0 may generate a multi-GB synthetic read set before the first barrier
         if backend == "nccl":
-            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local), timeout=long)
         else:
-            dist.init_process_group(backend=backend, rank=rank, world_size=world)
+            dist.init_process_group(backend=backend, rank=rank, world_size=world, timeout=long)
 
     import __graft_entry__ as ge
     from smartdenovo_amd import multigpu
@@ -165,7 +227,10 @@ def main():
     if meta is None:
         meta = json.load(open(fa + ".meta"))
 
-    eng = ZMO if a.engine == "zmo" else DMO
+    eng = list(ZMO if a.engine == "zmo" else DMO)
+    if wl.get("k17"):
+        eng[eng.index("-k") + 1] = "17"
+    drv_extra = [x for x in wl.get("extra", []) if not (x == "--shard-index" and world == 1)]      # a sharded index needs more than one rank
     if rank == 0:
         # --repeat keeps at most ONE stale output next to the file being written (wtzmo_main.c: stale_job), whatever W + K is; an .ovl with
         # CIGARs is ~3 bytes per read base (3.4 GB at configs[2]).  r02's driver run died of ENOSPC after 20 kept files: check, and say so.
@@ -181,7 +246,7 @@ def main():
             os.remove(stale)
     stats = os.path.join(tmp, "bench_r%d.stats" % rank)
     W, K = a.warmup, a.steps
-    argv = ["wtzmo", "--gpu", str(local), "-i", fa, "-fo", out, "--repeat", str(W + K), "--stats", stats] + (["--pool-gb", str(a.pool_gb)] if a.pool_gb else []) + eng
+    argv = ["wtzmo", "--gpu", str(local), "-i", fa, "-fo", out, "--repeat", str(W + K), "--stats", stats] + (["--pool-gb", str(a.pool_gb)] if a.pool_gb else []) + drv_extra + eng
     if a.max_batch:
         argv += ["--batch", str(a.max_batch)]
     host = C.CDLL(ge.HOSTLIB)
@@ -254,8 +319,8 @@ def main():
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
         "config": {"workload": "%s: %d bp iid genome x%g, seed %d, lognormal mean 10 kb, 15%% error (ins:del:sub 50:30:20)" % (WORKLOADS[a.workload]["name"], a.genome, a.coverage, a.seed),
                    "reads": meta["reads"], "read_bases": meta["bases"], "engine": a.engine, "argv": " ".join(eng),
-                   "parallelism": "1 GPU" if world == 1 else "%d ranks: pairs and candidate requests dealt round-robin over the ranks (reads + both indexes replicated per GPU), "
-                                                              "central in-order commit on rank 0, results gathered with RCCL send/recv" % world,
+                   "parallelism": "1 GPU" if world == 1 else "%d ranks (%s): pairs dealt by candidate id, seed-lookup requests round-robin (reads + k-mer index replicated%s; z-mer index: candidate side of the rank's "
+                                                              "residue class + the batch's queries), central in-order commit on rank 0, results gathered with send/recv" % (world, "RCCL" if backend == "nccl" else backend + " - a test aid", ", k-mer index sharded by read id" if "--shard-index" in drv_extra else ""),
                    "parity": "this input's .ovl md5 == reference `wtzmo -t 1` (tests/test_gpu_scale.py, tests/golden/big_manifest.json)%s" % ("" if world == 1 else "; any N writes the same file (tests/test_multi_rank_gloo.py)"),
                    "scratch": "%d batch ranges planned to the pool, %d split after a pool overflow" % (n_ranges, n_split)},
         "pairs_per_step": n_pairs // K, "pair_bp_per_step": pair_bp // K, "records_last_step": int(last[14]),
@@ -286,10 +351,23 @@ def main():
         res[key]["peak_measured_Tops"] = {"v_add_u32": 63.5, "v_max_i32": 36.6}
     # HBM traffic: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command with --steps 1 --warmup 0 (so totals are per step),
     # condensed by tools/summarize_profiles.py into profiles/ (FETCH_SIZE doubled as the gfx950 guide says).  `traffic` is per LAUNCH like
-    # `achieved` (total / dispatches), `traffic_per_step` the total next to the per-step algorithmic bytes.
-    try:
-        import csv
-        src = os.path.join(ROOT, "profiles", "r03_%s_%s_pmc_per_kernel.csv" % (a.workload, a.engine))
+    # `achieved` (total / dispatches), `traffic_per_step` the total next to the per-step algorithmic bytes.  A PMC pass cannot run inside a timed
+    # bench run, so the numbers come from the newest committed summary of this workload / engine; its sidecar (<csv>.meta.json, written by
+    # tools/gpu_round_measure.sh) names the kernel sources it was measured on, and the line says whether they are the sources of THIS build.
+    import csv
+    import glob
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_%s_%s_pmc_per_kernel.csv" % (a.workload, a.engine))))
+    src = cands[-1] if cands else None
+    ksrc_now = kernel_source_id()
+    res["build"] = {"kernel_source_id": ksrc_now, "lib_md5": file_md5(ge.LIB)}
+    if src is None:
+        res["traffic_source"] = None
+    else:
+        prov = {"file": os.path.relpath(src, ROOT), "git_blob": git_blob_id(src), "measured_on_kernel_source_id": None, "same_kernel_sources_as_this_build": None}
+        if os.path.exists(src + ".meta.json"):
+            prov["measured_on_kernel_source_id"] = json.load(open(src + ".meta.json")).get("kernel_source_id")
+            prov["same_kernel_sources_as_this_build"] = (prov["measured_on_kernel_source_id"] == ksrc_now)
+        res["traffic_source"] = prov
         kmap = {"wtz_kernel_extjobs_reg": "roofline", "wtz_kernel_extjobs_mw": "roofline", "K_winalign": "roofline_sw1", "K_ldp": "roofline_sw1", "K_ltb": "roofline_sw1", "K_lfold": "roofline_sw1", "K_lplan": "roofline_sw1",
                 "K_gap": "roofline_sw2", "K_gdp": "roofline_sw2", "K_gtb": "roofline_sw2", "K_candidates_wg": "roofline_seed", "K_candidates": "roofline_seed", "K_pair": "roofline_zmer", "K_pair_dm": "roofline_zmer", "K_pair_big": "roofline_zmer"}
         for row in csv.DictReader(open(src)):
@@ -300,21 +378,40 @@ def main():
             R = res[key]
             R["traffic_per_step"] = (R.get("traffic_per_step") or 0.0) + tot
             R["traffic"] = (R["traffic"] or 0.0) + tot / max(1, int(row["dispatches"]))
-            R["traffic_note"] = "PMC (2 x FETCH_SIZE + WRITE_SIZE) of a --steps 1 run of this command, read from %s (not measured in this run)" % os.path.relpath(src, ROOT)
+            R["traffic_note"] = ("PMC (2 x FETCH_SIZE + WRITE_SIZE) of a --steps 1 run of this command, read from %s (git blob %s; not measured in this run; measured on %s kernel sources)"
+                                 % (prov["file"], prov["git_blob"][:12], "THIS build's" if prov["same_kernel_sources_as_this_build"] else ("OTHER (stale)" if prov["same_kernel_sources_as_this_build"] is False else "unrecorded")))
             if key not in ("roofline_seed", "roofline_zmer") and row.get("SQ_INSTS_VALU") and R["kernel_ms_per_step"] > 0:
                 # wave-level VALU instructions of one step x 2 issue cycles on a SIMD-32 / SIMD-cycles of the live kernel time
                 R["valu_issue_frac_pmc"] = (R.get("valu_issue_frac_pmc") or 0.0) + float(row["SQ_INSTS_VALU"]) * 2.0 / (R["kernel_ms_per_step"] * 1e-3 * 2.4e9 * 256 * 4)
         for key in ("roofline", "roofline_sw1", "roofline_sw2"):
             if res[key].get("traffic_per_step"):
                 res[key]["algorithmic_trace_bytes_per_step"] = res[key]["cells_per_step"]       # the reference's layout: 1 trace byte per cell
-    except Exception:
-        pass
     if world > 1:
         res["gathered_result_bytes_per_step"] = xchg.bytes_received // (W + K)
         res["exchange_messages_per_step"] = xchg.messages // (W + K)
+    # parity of THIS run: the last step's file against the md5 of reference `wtzmo -t 1` on the same input (generated once, committed)
+    gold = None
+    if wl.get("golden") and same_as_golden and not a.no_verify:
+        gold = json.load(open(os.path.join(ROOT, "tests", "golden", "big_manifest.json")))["cases"].get("%s_%s" % (wl["golden"], a.engine))
+    if gold is not None:
+        got = file_md5(out)
+        res["parity"] = {"md5": got, "reference_md5": gold["md5_full"], "match": got == gold["md5_full"], "records": int(last[14]), "reference_records": gold["records"]}
+        if not res["parity"]["match"]:
+            print(json.dumps(res))
+            sys.exit("bench.py: the .ovl of the last step differs from the reference golden (%s vs %s): the number above is void" % (got, gold["md5_full"]))
+    else:
+        res["parity"] = {"match": None, "note": "no whole-job reference output exists for this input (parity at this shape: tests/test_gpu_scale.py)"}
     if world == 1 and not a.no_cpu_baseline:
         try:
-            res["cpu_baseline"] = cpu_baseline(eng, a.cpu_genome, a.coverage, a.seed if a.cpu_genome == a.genome else a.seed + 1000, tmp, same_input=(a.cpu_genome == a.genome))
+            same = (a.cpu_genome == a.genome)
+            res["cpu_baseline"] = cpu_baseline(eng, a.cpu_genome, a.coverage, a.seed if same else a.seed + 1000, tmp, same_input=same, fa=fa if same else None)
+            res["cpu_baseline"]["threads_note"] = ("-t %d, not all %d hardware threads: the reference's index build is O(threads x bases) (every thread scans every read, wtzmo.c:272) - "
+                                                   "measured on this host, E. coli shape: -t 256 is 4x slower than -t 32" % (res["cpu_baseline"]["cores"], os.cpu_count() or 1))
+            if (os.cpu_count() or 1) > res["cpu_baseline"]["cores"]:
+                # north_star's "-t <all host cores>", stated too: on a bounded sample of the same shape (the full input at -t 256 runs for a quarter of an hour)
+                sg = a.cpu_genome if a.cpu_genome <= 1000000 else max(200000, a.genome // 20)
+                allc = cpu_baseline(eng, sg, a.coverage, a.seed + 1000, tmp, same_input=False, threads=os.cpu_count())
+                res["cpu_baseline_all_cores"] = allc
         except Exception as e:      # the baseline is reported, never required
             res["cpu_baseline"] = {"value": None, "error": str(e)}
     if a.engine == "dmo":       # no banded SW in the dot-matrix engine (SURVEY finding 2): its dominant kernel is K_pair, priced against HBM (after the PMC traffic was attached above)

@@ -187,6 +187,10 @@ int  wtz_pairs_align(wtz_ctx_t *ctx, const uint32_t *pair_idx, const uint8_t *di
 int  wtz_fetch_cigars(wtz_ctx_t *ctx, uint32_t *dst, uint64_t n_ops);
 /* the same CIGARs already rendered as text on the device (what the .ovl column 17 holds): sum of text_len bytes */
 int  wtz_fetch_cigar_text(wtz_ctx_t *ctx, char *dst, uint64_t n_bytes);
+/* the same text left ON THE DEVICE: *dev_ptr = device address of the n_bytes (valid until the next call on this context).  For a rank that does not write
+ * records itself (one process per GPU): the ~6 KB of CIGAR text per record go from this buffer to the committing rank's GPU over xGMI
+ * (RCCL send of a tensor that aliases it) without passing through this rank's host memory. */
+int  wtz_cigar_text_device(wtz_ctx_t *ctx, uint64_t n_bytes, void **dev_ptr);
 /* Page-locked host memory for the buffers the library copies results into (the CIGAR text is ~6 KB per record: a pageable
  * destination halves the copy rate).  Plain malloc semantics otherwise; NULL on failure.  No reference counterpart: the
  * reference formats its records in the worker's own heap (wtzmo.c:1064-1095). */

@@ -96,6 +96,7 @@ typedef struct eng_s {
 	pending_t pend;
 	/* stats */
 	char *cig_keep[16]; uint64_t cig_keep_cap[16];      /* page-locked CIGAR text buffer of worker w, kept across steps (pinning is the expensive part) */
+	double t_cq[4];             /* commit_query sections: candidate rows + closed filter + sort | window depth + seed weights + sort | hits (gates, queueing, masking) | plan_pairs */
 	double t_gpu, t_commit, t_zbatch, t_call[6], t_io[2];      /* t_io: waiting for the writer thread before a text buffer is reused / at the end of the run */      /* t_call: wall seconds inside wtz_candidates / pairs_seed / pairs_windows / pairs_align / fetch_cigar_text / planning */
 	uint64_t spec_pairs, used_pairs, spec_items, used_items, spec_queries, used_queries, n_batches;
 	double extra_ms[6]; uint64_t extra_u64[7];      /* counters of the cloned contexts */
@@ -109,10 +110,14 @@ typedef struct eng_s {
 typedef void (*wtz_dist_bcast_fn)(void *buf, uint64_t nbytes);                   /* from rank 0, same nbytes on every rank */
 typedef void (*wtz_dist_send_fn)(const void *buf, uint64_t nbytes, int dst);
 typedef void (*wtz_dist_recv_fn)(void *buf, uint64_t nbytes, int src);
-static struct { int rank, world; wtz_dist_bcast_fn bcast; wtz_dist_send_fn send; wtz_dist_recv_fn recv; } g_dist = { 0, 1, NULL, NULL, NULL };
+typedef void (*wtz_dist_send_dev_fn)(const void *dev_buf, uint64_t nbytes, int dst);      /* like send, but the bytes live in DEVICE memory of this rank's GPU */
+static struct { int rank, world; wtz_dist_bcast_fn bcast; wtz_dist_send_fn send; wtz_dist_recv_fn recv; wtz_dist_send_dev_fn send_dev; } g_dist = { 0, 1, NULL, NULL, NULL, NULL };
 void wtzmo_set_dist(int rank, int world, wtz_dist_bcast_fn b, wtz_dist_send_fn sd, wtz_dist_recv_fn rv){
-	g_dist.rank = rank; g_dist.world = world < 1 ? 1 : world; g_dist.bcast = b; g_dist.send = sd; g_dist.recv = rv;
+	g_dist.rank = rank; g_dist.world = world < 1 ? 1 : world; g_dist.bcast = b; g_dist.send = sd; g_dist.recv = rv; g_dist.send_dev = NULL;
 }
+/* optional: with this hook a rank > 0 hands its CIGAR text (the bulk of what travels: ~6.4 KB per record, 3.1 GB per configs[2] step) to the exchange straight
+ * from the device buffer the library rendered it into (wtz_cigar_text_device) - device to device over xGMI on the nccl backend, no copy through this rank's host */
+void wtzmo_set_dist_dev(wtz_dist_send_dev_fn f){ g_dist.send_dev = f; }
 #define WTZ_DIST_MAX 16
 enum { WTZ_CMD_DONE = 1, WTZ_CMD_PAIRS = 2, WTZ_CMD_CAND_BEGIN = 3, WTZ_CMD_CAND_END = 4, WTZ_CMD_GRP_BEGIN = 5, WTZ_CMD_GRP_END = 6,
        WTZ_CMD_ZIDX = 7,       /* the z-mer index of the batch: arg[0] queries (their ids follow as a broadcast) for the query-side index of every rank; arg[1] != 0: count[r] candidate
@@ -135,6 +140,7 @@ typedef struct {
 	uint32_t *pq, *pc; uint32_t npair, cappair;
 	wtz_pair_summary_t *sum; uint64_t *box_off; wtz_winbox_t *boxes; uint64_t nbox, capbox;
 	uint32_t *item_of; uint32_t *it_pair; uint8_t *it_dir; uint32_t nitem; wtz_aln_result_t *aln; char *cig; uint64_t ncig;
+	void *cig_dev;               /* rank > 0 with a device-send hook: the text stays on the device (wtz_cigar_text_device) */
 	char *cigs[2]; uint64_t capcigs[2]; int cig_sel, cig_ext, ext_base;      /* two page-locked CIGAR text buffers, alternating per range; ext ids of the output writer */
 	double t_call[6], t_io0;                   /* wall seconds of this part's device calls since the last fold into E (under E->mu) */
 	struct eng_s *E; int again;                /* result of the last part_stages run (1 = scratch pool too small) */
@@ -449,6 +455,7 @@ static void commit_query(eng_t *E, batch_t *b, uint32_t slot){
 	uint32_t bcov = E->rdcovs[pbid];
 	if(bcov >= nbest) return;
 	E->used_queries++; b->used_queries++;
+	const double tq0 = now_s();
 	/* candidates: closed filter, exact order, trim (wtzmo.c:813-822) */
 	if(!b->want[slot]){ fprintf(stderr, " -- internal error: no candidate row for read %u --\n", pbid); DIE_NOW(); }
 	uint32_t nc = b->nrow[slot];
@@ -459,6 +466,7 @@ static void commit_query(eng_t *E, batch_t *b, uint32_t slot){
 	}
 	hx_sort_exact(cand, nc, sizeof(cand_t), gt_cand, NULL);
 	while(nc && (uint32_t)cand[nc - 1].e == 0) nc--;
+	const double tq1 = now_s(); E->t_cq[0] += tq1 - tq0;
 	if(E->rows_all){       /* -G: the trimmed, sorted list persists as the reference's rdhits entry */
 		for(uint32_t i = 0; i < nc; i++) E->rows[(size_t)pbid * E->stride + i] = cand[i].e;
 		E->nrow[pbid] = nc;
@@ -525,6 +533,7 @@ static void commit_query(eng_t *E, batch_t *b, uint32_t slot){
 		if(ol * P->win_rep_cutoff < P->ztot * P->win_rep_norm) s->closed = 1;                 /* wtzmo.c:964 */
 	}
 	hx_sort_exact(seeds, nseed, sizeof(seed_t), gt_seed, NULL);
+	const double tq2 = now_s(); E->t_cq[1] += tq2 - tq1;
 	if(!E->do_align){
 		if(pd->capseed < nseed){ pd->capseed = nseed; pd->seeds = (seed_t*)hx_realloc(pd->seeds, sizeof(seed_t) * nseed); }
 		memcpy(pd->seeds, seeds, sizeof(seed_t) * nseed); pd->nseed = nseed;
@@ -572,6 +581,7 @@ static void commit_query(eng_t *E, batch_t *b, uint32_t slot){
 		}
 	}
 	free(cand); free(windeps); free(wdiff); free(seeds);
+	E->t_cq[2] += now_s() - tq2;
 }
 
 /* ---------------- one batch: plan -> GPU -> commit ---------------- */
@@ -582,6 +592,7 @@ static void commit_query(eng_t *E, batch_t *b, uint32_t slot){
 
 /* under E->mu: pairs of slots [s0,s1) whose candidate pair is not closed right now */
 static void plan_pairs(eng_t *E, batch_t *b, uint32_t s0, uint32_t s1){
+	const double tp0 = now_s();
 	b->npair = 0;
 	for(uint32_t d = 0; d < b->nparts; d++) b->parts[d].npair = 0;
 	if((size_t)b->nbq * E->stride > b->caprowpair){ b->caprowpair = (size_t)b->nbq * E->stride; b->rowpair = (uint32_t*)hx_realloc(b->rowpair, b->caprowpair * 4); }
@@ -602,6 +613,7 @@ static void plan_pairs(eng_t *E, batch_t *b, uint32_t s0, uint32_t s1){
 			b->rowpair[(size_t)s * E->stride + k] = PIDX(dpart, pt->npair - 1); b->npair++;
 		}
 	}
+	E->t_cq[3] += now_s() - tp0;
 }
 
 /* the alignment items of a part: the best strand of every pair whose chain passes -r (wtzmo.c:913-914); a pure function of the summaries */
@@ -654,7 +666,9 @@ static int part_stages(eng_t *E, part_t *b){
 			{ const double tc0 = now_s(); rc = wtz_pairs_align(b->ctx, b->it_pair, b->it_dir, b->nitem, b->aln); b->t_call[3] += now_s() - tc0; } TRY_WTZ(rc, "wtz_pairs_align");
 			uint64_t tot = 0; for(uint32_t i = 0; i < b->nitem; i++) tot += b->aln[i].text_len;
 			if(E->binary_out) tot = 0;              /* binary records carry no CIGAR column (what `cut -f1-16` drops in the zmo pipeline): 3 GB per configs[2] step stay on the device */
-			else {
+			else if(g_dist.rank > 0 && g_dist.send_dev){      /* this rank only forwards the text: it never leaves the device on this side */
+				const double tc0 = now_s(); b->cig_dev = NULL; rc = wtz_cigar_text_device(b->ctx, tot, &b->cig_dev); b->t_call[4] += now_s() - tc0; TRY_WTZ(rc, "wtz_cigar_text_device");
+			} else {
 				if(!part_text_buffer(b, tot)) return WTZ_ST_AGAIN;
 				{ const double tc0 = now_s(); rc = wtz_fetch_cigar_text(b->ctx, b->cig, tot); b->t_call[4] += now_s() - tc0; } TRY_WTZ(rc, "wtz_fetch_cigar_text");     /* rendered on the device */
 			}
@@ -771,7 +785,10 @@ static void remote_loop(eng_t *E, part_t *pt){
 			g_dist.send(pt->sum, sizeof(wtz_pair_summary_t) * (uint64_t)n, 0);
 			if(dm) continue;
 			if(pt->nbox) g_dist.send(pt->boxes, sizeof(wtz_winbox_t) * pt->nbox, 0);
-			if(pt->nitem){ g_dist.send(pt->aln, sizeof(wtz_aln_result_t) * (uint64_t)pt->nitem, 0); if(pt->ncig) g_dist.send(pt->cig, pt->ncig, 0); }
+			if(pt->nitem){
+				g_dist.send(pt->aln, sizeof(wtz_aln_result_t) * (uint64_t)pt->nitem, 0);
+				if(pt->ncig){ if(g_dist.send_dev) g_dist.send_dev(pt->cig_dev, pt->ncig, 0); else g_dist.send(pt->cig, pt->ncig, 0); }
+			}
 		} else if(h.cmd == WTZ_CMD_ZIDX){
 			const uint32_t nql = (uint32_t)h.arg[0]; const int have_c = h.arg[1] != 0;
 			uint32_t *ql = (uint32_t*)hx_realloc(NULL, 4 * ((size_t)nql + 1)), *cl = (uint32_t*)hx_realloc(NULL, 4 * ((size_t)n + 1));
@@ -1592,7 +1609,7 @@ int main(int argc, char **argv){
 			for(size_t i = 0; i < nclosed0; i++) hx_set_put(&E->closed, closed0[i]);
 			E->n_order = n_order0;
 			E->pair_bp = E->n_pairs = E->nrec = 0;
-			E->t_gpu = E->t_commit = E->t_zbatch = 0; memset(E->t_call, 0, sizeof E->t_call); E->t_io[0] = E->t_io[1] = 0; E->spec_pairs = E->used_pairs = E->spec_items = E->used_items = E->spec_queries = E->used_queries = 0;
+			memset(E->t_cq, 0, sizeof E->t_cq); E->t_gpu = E->t_commit = E->t_zbatch = 0; memset(E->t_call, 0, sizeof E->t_call); E->t_io[0] = E->t_io[1] = 0; E->spec_pairs = E->used_pairs = E->spec_items = E->used_items = E->spec_queries = E->used_queries = 0;
 			E->rows_all = 0; E->n_batches = 0; E->n_split = 0; E->n_ranges = 0; E->bytes_per_pair = 0;      /* every repeat plans like a cold run: probe range first */
 			E->pend.rd_id = 0xFFFFFFFFu; E->pend.nhit = E->pend.nmask = E->pend.nclosed = E->pend.nseed = 0;
 			if(strcmp(output, "-")){
@@ -1741,6 +1758,7 @@ int main(int argc, char **argv){
 		memset(E->extra_ms, 0, sizeof E->extra_ms); memset(E->extra_u64, 0, sizeof E->extra_u64);
 		fprintf(stderr, "[wtzmo-mi355x] %llu records, %llu pairs aligned, %llu pair-bp, %.3f s (index %.3f s)\n", (unsigned long long)E->nrec, (unsigned long long)E->n_pairs, (unsigned long long)E->pair_bp, t1 - t0, t_index);
 		fprintf(stderr, "[wtzmo-mi355x] host seconds: in GPU-stage calls %.3f, commit %.3f, per-batch z-index %.3f; writer thread: formatting %.3f, write %.3f; waiting for it: %.3f before buffer reuse, %.3f at the end\n", E->t_gpu, E->t_commit, E->t_zbatch, g_ow.t_format, g_ow.t_write, E->t_io[0], E->t_io[1]);
+		fprintf(stderr, "[wtzmo-mi355x] commit sections: candidate rows + closed filter + order %.3f, window depth + seed weights %.3f, hits %.3f; planning the pairs of the ranges %.3f\n", E->t_cq[0], E->t_cq[1], E->t_cq[2], E->t_cq[3]);
 		fprintf(stderr, "[wtzmo-mi355x] wall seconds per call: candidates %.3f pairs_seed %.3f pairs_windows %.3f pairs_align %.3f cigar_text %.3f\n", E->t_call[0], E->t_call[1], E->t_call[2], E->t_call[3], E->t_call[4]);
 	if(E->n_split) fprintf(stderr, "[wtzmo-mi355x] %llu range(s) had to be split after a scratch-pool overflow (planned at %.0f KB per pair)\n", (unsigned long long)E->n_split, E->bytes_per_pair / 1024.0);
 	fprintf(stderr, "[wtzmo-mi355x] %llu batches in %llu ranges on %u worker context(s); speculation: queries %llu/%llu pairs %llu/%llu alignments %llu/%llu (used/planned)\n",

@@ -350,6 +350,7 @@ struct wtz_ctx {
 	/* per-batch results */
 	uint32_t *d_qid, *d_cid; wtz_pairres_t *d_pairres; uint32_t n_pairs; std::vector<wtz_pairres_t> h_pairres;
 	wtz_alnres_dev_t *d_alnres; uint32_t n_items; std::vector<wtz_alnres_dev_t> h_alnres;
+	char *d_text = NULL; size_t cap_text = 0;      /* rendered CIGAR text of the last alignment call (wtz_fetch_cigar_text / wtz_cigar_text_device) */
 	bool have_pairs, have_items;
 	/* candidate request in flight (wtz_candidates_begin / _end) */
 	uint32_t *cq_thr = NULL;
@@ -544,6 +545,7 @@ extern "C" void wtz_ctx_destroy(wtz_ctx_t *c){
 	if(!c) return;
 	{ CTX_ENTER(c); (void)dev_sync(); }
 	free_batch_storage(c); free_kindex(c); free_zindex(c);
+	dev_free_persist(c->d_text);
 	dev_free_persist(c->cq_q); dev_free_persist(c->cq_nc); dev_free_persist(c->cq_cand); dev_free_persist(c->cq_bytes); dev_free_persist(c->cq_thr); dev_free_persist(c->cq_gptr);
 	free_pending_index(c);
 #ifndef WTZ_EMUL
@@ -1766,24 +1768,45 @@ extern "C" int wtz_fetch_cigars(wtz_ctx_t *c, uint32_t *dst, uint64_t n_ops){
 	return WTZ_OK;
 }
 
-extern "C" int wtz_fetch_cigar_text(wtz_ctx_t *c, char *dst, uint64_t n_bytes){
-	if(!c || !c->have_items) return wtz_fail(WTZ_E_STATE, "wtz_fetch_cigar_text before wtz_pairs_align");
-	CTX_ENTER(c);
+/* the CIGAR text of the last wtz_pairs_align rendered into a device buffer of the context (grow-only, valid until the next call on this context) */
+static int render_cigar_text(wtz_ctx_t *c, uint64_t n_bytes, char **d_text_out){
 	uint64_t tot = 0; for(uint32_t i = 0; i < c->n_items; i++) tot += c->h_alnres[i].text_len;
-	if(tot != n_bytes) return wtz_fail(WTZ_E_ARG, "wtz_fetch_cigar_text: expected room for %llu bytes, got %llu", (unsigned long long)tot, (unsigned long long)n_bytes);
+	if(tot != n_bytes) return wtz_fail(WTZ_E_ARG, "CIGAR text: expected room for %llu bytes, got %llu", (unsigned long long)tot, (unsigned long long)n_bytes);
+	*d_text_out = NULL;
 	if(tot == 0) return WTZ_OK;
-	if(!dst) return wtz_fail(WTZ_E_ARG, "null output");
+	if(tot + 16 > c->cap_text){
+		(void)dev_sync(); dev_free_persist(c->d_text); c->d_text = NULL; c->cap_text = 0;
+		const size_t cap = (size_t)(tot + tot / 4 + 4096);
+		CHK(dev_alloc_persist((void**)&c->d_text, cap)); c->cap_text = cap;
+	}
 	std::vector<uint64_t> off((size_t)c->n_items + 1);
 	uint64_t o = 0; for(uint32_t i = 0; i < c->n_items; i++){ off[i] = o; o += c->h_alnres[i].text_len; } off[c->n_items] = o;
-	uint64_t *d_off = NULL; char *d_t = NULL;
+	uint64_t *d_off = NULL; char *d_t = c->d_text;
 	CHK(dev_alloc((void**)&d_off, off.size() * 8)); CHK(dev_h2d(d_off, off.data(), off.size() * 8));
-	CHK(dev_alloc((void**)&d_t, (size_t)tot + 16));
 	const wtz_alnres_dev_t *dr = c->d_alnres;
 	STAGE(c, "K_cigar_text");
 	CHK(wtz_launch_coop<K_cigar_text>(0, c->n_items, [=] WTZ_LAMBDA (uint64_t t){ const wtz_alnres_dev_t &r = dr[t]; if(r.text_len) wtz_cigar_text_write_coop(r.cigar, r.cigar_len, d_t + d_off[t]); }));
 	CHK(dev_sync());
-	CHK(dev_d2h(dst, d_t, (size_t)tot));
-	dev_free(d_off); dev_free(d_t);
+	dev_free(d_off);
+	*d_text_out = d_t;
+	return WTZ_OK;
+}
+extern "C" int wtz_fetch_cigar_text(wtz_ctx_t *c, char *dst, uint64_t n_bytes){
+	if(!c || !c->have_items) return wtz_fail(WTZ_E_STATE, "wtz_fetch_cigar_text before wtz_pairs_align");
+	CTX_ENTER(c);
+	char *d_t = NULL;
+	CHK(render_cigar_text(c, n_bytes, &d_t));
+	if(n_bytes == 0) return WTZ_OK;
+	if(!dst) return wtz_fail(WTZ_E_ARG, "null output");
+	CHK(dev_d2h(dst, d_t, (size_t)n_bytes));
+	return WTZ_OK;
+}
+extern "C" int wtz_cigar_text_device(wtz_ctx_t *c, uint64_t n_bytes, void **dev_ptr){
+	if(!c || !c->have_items || !dev_ptr) return wtz_fail(WTZ_E_STATE, "wtz_cigar_text_device before wtz_pairs_align / null argument");
+	CTX_ENTER(c);
+	char *d_t = NULL;
+	CHK(render_cigar_text(c, n_bytes, &d_t));
+	*dev_ptr = d_t;
 	return WTZ_OK;
 }
 

@@ -49,7 +49,7 @@ def reads_of(name):
     return fa
 
 
-def check_case_at_scale(name, gpu_exe):
+def check_case_at_scale(name, gpu_exe, extra=()):
     case = MAN["cases"][name]
     fa = reads_of(case["set"])
     out = os.path.join(TMP, "scale_%s.ovl" % name)
@@ -57,10 +57,10 @@ def check_case_at_scale(name, gpu_exe):
     for f in (out, out + ".contained", stats):
         if os.path.exists(f):
             os.remove(f)
-    r = subprocess.run([gpu_exe, "-i", fa, "-fo", out, "--stats", stats] + case["argv"], capture_output=True)
+    r = subprocess.run([gpu_exe, "-i", fa, "-fo", out, "--stats", stats] + list(extra) + case["argv"], capture_output=True)
     if os.environ.get("WTZ_TEST_KEEP_STDERR"):      # the drop-in's own log of the run (index sizes, per-batch z-index, timings): kept under profiles/ for the fly shape
         os.makedirs(os.environ["WTZ_TEST_KEEP_STDERR"], exist_ok=True)
-        open(os.path.join(os.environ["WTZ_TEST_KEEP_STDERR"], "scale_%s.stderr.txt" % name), "wb").write(r.stderr)
+        open(os.path.join(os.environ["WTZ_TEST_KEEP_STDERR"], "scale_%s%s.stderr.txt" % (name, "_" + "_".join(x.strip("-").replace(",", "") for x in extra) if extra else "")), "wb").write(r.stderr)
     assert r.returncode == 0, r.stderr.decode()[-3000:]
     md5, nrec = file_md5(out)
     assert nrec == case["records"], "%d records, the reference wrote %d" % (nrec, case["records"])
@@ -95,12 +95,15 @@ def test_per_batch_zindex_at_scale(name, gpu_exe):
 
 
 @pytest.mark.parametrize("name,extra", [("yeast100_zmo", ["--gpu-list", "0,0", "--shard-index"]), ("ecoli_dmo", ["--gpu-list", "0,0,0", "--shard-index"]),
-                                        ("yeast100_zmo", ["--gpu-list", "0,0"])],
-                         ids=["configs2_zmo_2_index_shards", "configs1_dmo_3_index_shards", "configs2_zmo_2_parts_central_commit"])
+                                        ("yeast100_zmo", ["--gpu-list", "0,0"]), ("ecoli_zmo", ["--gpu-list", "0,0", "--zindex-batch", "1"]),
+                                        ("ecoli_dmo", ["--gpu-list", "0,0,0", "--zindex-batch", "1", "--shard-index"])],
+                         ids=["configs2_zmo_2_index_shards", "configs1_dmo_3_index_shards", "configs2_zmo_2_parts_central_commit", "configs1_zmo_2_parts_per_batch_zindex", "configs1_dmo_3_shards_per_batch_zindex"])
 def test_multi_context_modes_at_scale(name, extra, gpu_exe):
     """The two multi-GPU forms at BASELINE scale, with contexts on this box's one device standing in for the devices (configs[3] / [4] shapes of work):
     `--shard-index` = the k-mer index cut into read-id ranges with the counts of all shards in the filter, every query answered by every shard; plain `--gpu-list` =
-    index replicated, pairs dealt over the parts, one in-order commit.  Either must write the md5 of the reference's single `wtzmo -t 1` run."""
+    index replicated, pairs dealt over the parts (by candidate id: every context holds the candidate side of the z-mer index for its residue class of the reads and
+    a per-batch index of the queries), one in-order commit; `--zindex-batch 1` on top = the candidate side rebuilt per batch too (what configs[3] / [4] need - round 3
+    refused this combination).  Every form must write the md5 of the reference's single `wtzmo -t 1` run."""
     case = MAN["cases"][name]
     fa = reads_of(case["set"])
     out = os.path.join(TMP, "multi_%s_%d.ovl" % (name, len(extra)))
@@ -133,8 +136,9 @@ def test_dmo_heavy_pair_paths(env, gpu_exe):
     os.remove(out)
 
 
+@pytest.mark.parametrize("extra", [[], ["--gpu-list", "0,0", "--pool-gb", "48"]], ids=["one_context", "two_contexts"])
 @pytest.mark.parametrize("name", FLY_CASES)
-def test_fly_shape_stripe_equals_reference(name, gpu_exe):
+def test_fly_shape_stripe_equals_reference(name, extra, gpu_exe):
     """BASELINE configs[3] shape on ONE device (last in the file: the input is 951 827 reads / 9.8 Gbp, 10 GB of FASTA regenerated here in about two
     minutes): the query stripe `-P 128 -p 0` against the FULL k-mer index with the z-mer index rebuilt per batch of queries (automatic above
     2.4 Gbp of reads) must give the md5 of the reference's `wtzmo -t 1 -P 128 -p 0` (43 minutes in the build container, tests/golden/make_fly_stripe.py).
@@ -151,8 +155,8 @@ def test_fly_shape_stripe_equals_reference(name, gpu_exe):
         avail = 1 << 40
     if avail < 48 << 30:
         pytest.skip("less than 48 GB of host memory available for generating / loading the 10 Gbp read set")
-    check_case_at_scale(name, gpu_exe)
-    if os.environ.get("WTZ_TEST_KEEP_FLY"):
+    check_case_at_scale(name, gpu_exe, extra)       # two_contexts: the multi-GPU form of configs[3] - pairs dealt over two contexts, each rebuilding per batch the z-mer index of ITS candidates
+    if os.environ.get("WTZ_TEST_KEEP_FLY") or not extra:
         return
     for f in os.listdir(TMP):          # 10 GB: not left behind for the bench
         if f.startswith("reads_G%d_" % MAN["sets"][MAN["cases"][name]["set"]]["genome"]):
