@@ -26,6 +26,7 @@
 #include <sys/uio.h>
 #include <errno.h>
 #include <sys/stat.h>
+#include <fcntl.h>
 #include "wtz_host.h"
 #include "wtz_ovlb.h"
 
@@ -201,17 +202,25 @@ typedef struct {
 	uint32_t pb1, pb2; int32_t tb, te, qb, qe, score, mat, mis, ins, del, aln;
 	const char *cigar; uint32_t cigar_len; uint8_t dir2, kind; int8_t ext;      /* kind 0: an overlap record; 1: `cigar` is a heap string written verbatim (the "# ..." lines of -N) and freed; 2: a record whose CIGAR text is a heap copy, freed */
 } orec_t;
-typedef struct ochunk { orec_t *rec; int n, cap; size_t payload; unsigned ext_mask; struct ochunk *next; } ochunk_t;
+typedef struct ochunk { orec_t *rec; int n, cap; size_t payload; unsigned ext_mask; uint64_t seq; struct ochunk *next; } ochunk_t;
+#define OW_THREADS 3
+typedef struct { pthread_t th; char *fmt; size_t capfmt; struct iovec *iov; size_t capiov; } owthread_t;      /* a writer thread's formatting buffer and vector */
+/* OW_THREADS writer threads: each takes the next chunk, formats it (in parallel with the others), then waits for its TURN - the chunks' byte ranges follow
+ * the queue order - and learns its file offset.  A regular file is written with pwritev() at that offset AFTER the turn is passed on, so the page-cache
+ * copies of several chunks (3.4 GB per configs[2] step: 0.4 s on one thread, as long as a whole step would be on eight GPUs) run side by side; a pipe or a
+ * terminal is written inside the turn, i.e. strictly in order. */
 typedef struct {
-	FILE *fp; int fd; pthread_t th; pthread_mutex_t mu; pthread_cond_t cv, cv_ext;
+	FILE *fp; int fd; pthread_mutex_t mu; pthread_cond_t cv, cv_ext, cv_turn;
 	ochunk_t *head, *tail, *freelist, *cur; int done, started;
 	int ext_busy[OW_MAX_EXT];
 	const hx_read_t *reads; int binary;
-	char *fmt; size_t capfmt; struct iovec *iov; size_t capiov;      /* the writer thread's formatting buffer and vector */
-	double t_format, t_write;                                        /* writer-thread seconds (reported, not on the commit's clock) */
+	owthread_t T[OW_THREADS]; int nth;
+	int seekable; uint64_t submit_seq, turn_seq; off_t off;          /* off: where the chunk whose turn it is starts */
+	double t_format, t_write;                                        /* writer-thread seconds, summed over the threads (reported, not on the commit's clock) */
 } owriter_t;
 static owriter_t g_ow;
 #define OCHUNK_RECS 8192
+static int g_ochunk_recs = OCHUNK_RECS;      /* WTZ_OUT_CHUNK_RECS: test hook - tiny chunks put many of them in flight on the writer threads */
 #define OCHUNK_PAYLOAD ((size_t)32 << 20)
 
 static inline size_t put_str(char *o, const char *s){ size_t n = strlen(s); memcpy(o, s, n); return n; }
@@ -237,10 +246,11 @@ static size_t format_record(const hx_read_t *reads, const orec_t *h, char *o){
 	k += put_int(o + k, h->mat); o[k++] = '\t'; k += put_int(o + k, h->mis); o[k++] = '\t'; k += put_int(o + k, h->ins); o[k++] = '\t'; k += put_int(o + k, h->del); o[k++] = '\t';
 	return k;
 }
-static void ow_write_all(owriter_t *w, struct iovec *iov, size_t niov){
+static void ow_write_all(owriter_t *w, struct iovec *iov, size_t niov, off_t at){      /* at < 0: at the descriptor's own position */
 	for(size_t i = 0; i < niov;){
 		size_t n = niov - i; if(n > 1024) n = 1024;
-		ssize_t r = writev(w->fd, iov + i, (int)n);
+		ssize_t r = at < 0 ? writev(w->fd, iov + i, (int)n) : pwritev(w->fd, iov + i, (int)n, at);
+		if(r > 0 && at >= 0) at += r;
 		if(r < 0){ if(errno == EINTR) continue; fprintf(stderr, " -- write error on the output file: %s --\n", strerror(errno)); DIE_NOW(); }
 		while(r > 0 && i < niov){        /* consume what was written; a partially written entry is advanced in place */
 			if((size_t)r >= iov[i].iov_len){ r -= (ssize_t)iov[i].iov_len; i++; }
@@ -249,8 +259,9 @@ static void ow_write_all(owriter_t *w, struct iovec *iov, size_t niov){
 		while(i < niov && iov[i].iov_len == 0) i++;
 	}
 }
+typedef struct { owriter_t *w; int k; } owarg_t;
 static void *owriter_main(void *arg){
-	owriter_t *w = (owriter_t*)arg;
+	owriter_t *w = ((owarg_t*)arg)->w; owthread_t *me = &w->T[((owarg_t*)arg)->k];
 	for(;;){
 		pthread_mutex_lock(&w->mu);
 		while(w->head == NULL && !w->done) pthread_cond_wait(&w->cv, &w->mu);
@@ -262,32 +273,41 @@ static void *owriter_main(void *arg){
 		/* upper bound of the formatted bytes of the chunk (CIGAR text by reference does not count) */
 		size_t need = 0;
 		for(int i = 0; i < c->n; i++){ const orec_t *h = &c->rec[i]; need += w->binary ? sizeof(wtz_ovlb_rec_t) : (h->kind == 1 ? 0 : strlen(w->reads[h->pb1].name) + strlen(w->reads[h->pb2].name) + 256 + (h->cigar && h->cigar_len < 256 ? h->cigar_len : 0)); }
-		if(need > w->capfmt){ w->capfmt = need + need / 2 + 4096; free(w->fmt); w->fmt = (char*)hx_realloc(NULL, w->capfmt); }
-		if((size_t)c->n * 3 + 4 > w->capiov){ w->capiov = (size_t)c->n * 3 + 4; w->iov = (struct iovec*)hx_realloc(w->iov, sizeof(struct iovec) * w->capiov); }
-		size_t k = 0, niov = 0, run0 = 0;        /* [run0, k): formatted bytes not yet covered by a vector entry */
-#define OW_FLUSH_RUN() do { if(k > run0){ w->iov[niov].iov_base = w->fmt + run0; w->iov[niov].iov_len = k - run0; niov++; run0 = k; } } while(0)
+		if(need > me->capfmt){ me->capfmt = need + need / 2 + 4096; free(me->fmt); me->fmt = (char*)hx_realloc(NULL, me->capfmt); }
+		if((size_t)c->n * 3 + 4 > me->capiov){ me->capiov = (size_t)c->n * 3 + 4; me->iov = (struct iovec*)hx_realloc(me->iov, sizeof(struct iovec) * me->capiov); }
+		size_t k = 0, niov = 0, run0 = 0, total = 0;        /* [run0, k): formatted bytes not yet covered by a vector entry */
+#define OW_FLUSH_RUN() do { if(k > run0){ me->iov[niov].iov_base = me->fmt + run0; me->iov[niov].iov_len = k - run0; niov++; run0 = k; } } while(0)
 		for(int i = 0; i < c->n; i++){
 			const orec_t *h = &c->rec[i];
-			if(h->kind == 1){ OW_FLUSH_RUN(); if(!w->binary){ w->iov[niov].iov_base = (void*)h->cigar; w->iov[niov].iov_len = h->cigar_len; niov++; } continue; }
+			if(h->kind == 1){ OW_FLUSH_RUN(); if(!w->binary){ me->iov[niov].iov_base = (void*)h->cigar; me->iov[niov].iov_len = h->cigar_len; niov++; } continue; }
 			if(w->binary){
 				wtz_ovlb_rec_t r; memset(&r, 0, sizeof r);
 				r.id1 = h->pb1; r.id2 = h->pb2; r.aln = (uint32_t)(h->aln == 0 ? 1 : h->aln); r.tb = h->tb; r.te = h->te; r.qb = h->qb; r.qe = h->qe; r.score = h->score;
 				r.mat = h->mat; r.mis = h->mis; r.ins = h->ins; r.del = h->del; r.dir2 = h->dir2;
-				memcpy(w->fmt + k, &r, sizeof r); k += sizeof r; continue;
+				memcpy(me->fmt + k, &r, sizeof r); k += sizeof r; continue;
 			}
-			k += format_record(w->reads, h, w->fmt + k);
-			if(h->cigar == NULL){ w->fmt[k++] = '0'; w->fmt[k++] = 'M'; }
-			else if(h->cigar_len < 256 && h->kind == 0){ memcpy(w->fmt + k, h->cigar, h->cigar_len); k += h->cigar_len; }
-			else { OW_FLUSH_RUN(); w->iov[niov].iov_base = (void*)h->cigar; w->iov[niov].iov_len = h->cigar_len; niov++; }
-			w->fmt[k++] = '\n';
+			k += format_record(w->reads, h, me->fmt + k);
+			if(h->cigar == NULL){ me->fmt[k++] = '0'; me->fmt[k++] = 'M'; }
+			else if(h->cigar_len < 256 && h->kind == 0){ memcpy(me->fmt + k, h->cigar, h->cigar_len); k += h->cigar_len; }
+			else { OW_FLUSH_RUN(); me->iov[niov].iov_base = (void*)h->cigar; me->iov[niov].iov_len = h->cigar_len; niov++; }
+			me->fmt[k++] = '\n';
 		}
 		OW_FLUSH_RUN();
 #undef OW_FLUSH_RUN
+		for(size_t i = 0; i < niov; i++) total += me->iov[i].iov_len;
 		const double tf1 = now_s();
-		ow_write_all(w, w->iov, niov);
+		/* the turn: chunks reach the stream in the order they were queued */
+		pthread_mutex_lock(&w->mu);
+		while(w->turn_seq != c->seq) pthread_cond_wait(&w->cv_turn, &w->mu);
+		const off_t at = w->off;
+		if(w->seekable){ w->off += (off_t)total; w->turn_seq++; pthread_cond_broadcast(&w->cv_turn); }
+		pthread_mutex_unlock(&w->mu);
+		const double tf2 = now_s();
+		ow_write_all(w, me->iov, niov, w->seekable ? at : (off_t)-1);
 		for(int i = 0; i < c->n; i++) if(c->rec[i].kind) free((void*)c->rec[i].cigar);
 		pthread_mutex_lock(&w->mu);
-		w->t_format += tf1 - tf0; w->t_write += now_s() - tf1;
+		if(!w->seekable){ w->off += (off_t)total; w->turn_seq++; pthread_cond_broadcast(&w->cv_turn); }
+		w->t_format += tf1 - tf0; w->t_write += now_s() - tf2;
 		for(int e = 0; e < OW_MAX_EXT; e++) if(c->ext_mask & (1u << e)) w->ext_busy[e]--;
 		if(c->ext_mask) pthread_cond_broadcast(&w->cv_ext);
 		c->n = 0; c->payload = 0; c->ext_mask = 0; c->next = w->freelist; w->freelist = c;
@@ -297,16 +317,23 @@ static void *owriter_main(void *arg){
 }
 static void out_start(FILE *fp, const hx_read_t *reads, int binary){
 	owriter_t *w = &g_ow;
-	if(!w->started){ pthread_mutex_init(&w->mu, NULL); pthread_cond_init(&w->cv, NULL); pthread_cond_init(&w->cv_ext, NULL); }
+	static owarg_t args[OW_THREADS];
+	if(!w->started){ pthread_mutex_init(&w->mu, NULL); pthread_cond_init(&w->cv, NULL); pthread_cond_init(&w->cv_ext, NULL); pthread_cond_init(&w->cv_turn, NULL); }
 	fflush(fp);
 	w->fp = fp; w->fd = fileno(fp); w->head = w->tail = NULL; w->cur = NULL; w->done = 0; w->started = 1; w->reads = reads; w->binary = binary; w->t_format = w->t_write = 0;
 	memset(w->ext_busy, 0, sizeof w->ext_busy);
-	pthread_create(&w->th, NULL, owriter_main, w);
+	{ struct stat sb; const off_t pos = lseek(w->fd, 0, SEEK_CUR);       /* a regular file (not opened for appending) takes positioned writes */
+	  w->seekable = (pos >= 0 && fstat(w->fd, &sb) == 0 && S_ISREG(sb.st_mode) && !(fcntl(w->fd, F_GETFL) & O_APPEND) && !getenv("WTZ_OUT_SEQUENTIAL"));
+	  w->off = w->seekable ? pos : 0; }
+	w->submit_seq = w->turn_seq = 0;
+	{ const char *e = getenv("WTZ_OUT_CHUNK_RECS"); if(e && atoi(e) > 0 && atoi(e) < OCHUNK_RECS) g_ochunk_recs = atoi(e); }
+	w->nth = w->seekable ? OW_THREADS : 2;          /* a pipe still gets a second thread: formatting beside the write */
+	for(int k = 0; k < w->nth; k++){ args[k].w = w; args[k].k = k; if(pthread_create(&w->T[k].th, NULL, owriter_main, &args[k]) != 0){ fprintf(stderr, " -- cannot start an output thread --\n"); DIE_NOW(); } }
 }
 static void out_submit(owriter_t *w){
 	if(w->cur == NULL) return;
 	pthread_mutex_lock(&w->mu);
-	w->cur->next = NULL;
+	w->cur->next = NULL; w->cur->seq = w->submit_seq++;
 	if(w->tail) w->tail->next = w->cur; else w->head = w->cur;
 	w->tail = w->cur; w->cur = NULL;
 	pthread_cond_signal(&w->cv);
@@ -315,7 +342,7 @@ static void out_submit(owriter_t *w){
 /* the slot of the next queued record in the chunk under construction */
 static orec_t *out_slot(size_t payload){
 	owriter_t *w = &g_ow;
-	if(w->cur && (w->cur->n == w->cur->cap || w->cur->payload > OCHUNK_PAYLOAD)) out_submit(w);
+	if(w->cur && (w->cur->n >= g_ochunk_recs || w->cur->n == w->cur->cap || w->cur->payload > OCHUNK_PAYLOAD)) out_submit(w);
 	if(w->cur == NULL){
 		pthread_mutex_lock(&w->mu);
 		ochunk_t *c = w->freelist; if(c) w->freelist = c->next;
@@ -345,8 +372,9 @@ static void out_wait_ext(int ext){
 static void out_finish(void){
 	owriter_t *w = &g_ow;
 	out_submit(w);
-	pthread_mutex_lock(&w->mu); w->done = 1; pthread_cond_signal(&w->cv); pthread_mutex_unlock(&w->mu);
-	pthread_join(w->th, NULL);
+	pthread_mutex_lock(&w->mu); w->done = 1; pthread_cond_broadcast(&w->cv); pthread_mutex_unlock(&w->mu);
+	for(int k = 0; k < w->nth; k++) pthread_join(w->T[k].th, NULL);
+	if(w->seekable && lseek(w->fd, w->off, SEEK_SET) < 0){ fprintf(stderr, " -- cannot position the output file: %s --\n", strerror(errno)); DIE_NOW(); }      /* whatever follows through the FILE continues behind the records */
 }
 
 /* ---------------- record writer + state merge (wtzmo.c:1170-1249, 1319-1329) ---------------- */

@@ -28,8 +28,8 @@
  * indices are compile-time constants (the column loop is fully unrolled, NC = 16 / 32 / 64 / 104 columns per class), problems are sorted
  * by shape so that the lanes of a wavefront run the same trip counts, and blocks of 8 columns beyond the widest band of the wave are
  * skipped.  Trace: 4 bits per cell - the sign bits of the four differences the recurrence decides on (m - E, max(m, E) - F, open - extend for E and for F),
- * pushed with one v_alignbit_b32 each, no compare / select pair - rows contiguous PER LANE
- * in the transient pool — a row is one to four 16-byte stores per lane and the traceback of a lane walks its own cache lines.
+ * pushed with one v_alignbit_b32 each, no compare / select pair - in the transient pool, the rows of a wavefront's 64 lanes
+ * INTERLEAVED (wtz_ltr_at): a row is one to four 16-byte stores per lane, and a store instruction of the wave covers consecutive bytes.
  *
  * The same bodies compile for the host emulation (tests/emul: one lane per "wavefront"), so the planner / fold logic and the DP are
  * exercised by the CPU test-suite against the reference goldens.
@@ -83,6 +83,16 @@ template<int NC> struct wtz_lane_geo {
 };
 WTZ_HD uint32_t wtz_lane_rs(int32_t n_col){ return n_col <= 16 ? 2u : (n_col <= 32 ? 4u : (n_col <= 64 ? 8u : 16u)); }
 WTZ_HD uint32_t wtz_lane_class(int32_t n_col){ return n_col <= 16 ? 0u : (n_col <= 32 ? 1u : (n_col <= 64 ? 2u : 3u)); }
+/* Trace layout of a wavefront (round 4): LANE-INTERLEAVED.  A row of a lane is RS dwords, stored in units of U = min(RS, 4) dwords (one 8- or 16-byte store);
+ * unit q of row i of lane l sits at dword ((i * RS / U + q) * WTZ_NLANES + l) * U of the wave's block, i.e. the 64 lanes' units of one (row, q) are
+ * contiguous: a store instruction of the DP writes 512 / 1024 consecutive bytes instead of 64 scattered 8 / 16-byte pieces (K_ldp wrote 246 GB per
+ * configs[2] step for 84 GB of trace: partial lines), and the walkers of a wave - sorted by shape, so they move through their rows together - read
+ * neighbouring dwords of the same lines instead of one 64-byte line per lane and step (K_ltb fetched 448 GB per step).  With one lane per
+ * "wavefront" (host emulation) the formula is the old per-lane row-major layout. */
+WTZ_HD size_t wtz_ltr_at(uint32_t row, uint32_t RS, uint32_t d){
+	const uint32_t lu = RS >= 4u ? 2u : 1u;                    /* log2 U */
+	return (((((size_t)row * (RS >> lu)) + (d >> lu)) * WTZ_NLANES + WTZ_LANE) << lu) + (d & ((1u << lu) - 1u));
+}
 
 /* register-tail run writer of one lane: the open run stays in a register (kswx_push_cigar merges equal neighbours, kswx.h:39-44) */
 typedef struct { uint32_t *a; uint32_t n, tail; } wtz_lruns_t;
@@ -97,7 +107,7 @@ WTZ_HD void wtz_lruns_finish(wtz_lruns_t &w){ if(w.tail){ w.a[w.n++] = w.tail; w
  * K-sw1 of one lane.  `live` = this lane has a problem; every lane of the wavefront must call (uniform trip counts come from wave-wide
  * maxima).  ABS = true: the reference's function for a known init_score (function-level tests, and the form that could chain);
  * ABS = false: relative mode, see the header.  W / ql / tl: wtz_ext_geometry of the problem.  tr: this lane's trace rows (ql rows of
- * RS dwords), runs: room for ql + tl + 2 runs, written in TRACEBACK order (the reader reverses).
+ * RS dwords; the WAVE's block, lane-interleaved: wtz_ltr_at), runs: room for ql + tl + 2 runs, written in TRACEBACK order (the reader reverses).
  */
 template<int NC, bool ABS>
 WTZ_HD void wtz_lane_fixed(bool live, int32_t qlen, const wtz_seq_packed &q, int32_t tlen, const wtz_seq_packed &t, int32_t init_score,
@@ -143,7 +153,7 @@ WTZ_HD void wtz_lane_fixed(bool live, int32_t qlen, const wtz_seq_packed &q, int
 		int32_t key = ABS ? 0 : (int32_t)0x80000000;
 		const int32_t nmax = wtz_lane_wmax(n);
 		uint32_t acc[4] = {0u, 0u, 0u, 0u};
-		uint32_t *trow = tr + (size_t)i * RS;
+		uint32_t *trow = tr + wtz_ltr_at((uint32_t)i, (uint32_t)RS, 0u);      /* unit 0 of the row; unit q is q * 4 * WTZ_NLANES dwords further */
 		#pragma unroll
 		for(int c0 = 0; c0 < NC; c0 += 8){
 			if(c0 <= nmax){                                   /* uniform: some lane of the wave has a cell (or its closing slot) in this block of 8 columns */
@@ -175,7 +185,7 @@ WTZ_HD void wtz_lane_fixed(bool live, int32_t qlen, const wtz_seq_packed &q, int
 			if(((c0 + 8) & 31) == 0 || c0 + 8 >= NC){          /* a group of 32 columns is complete: one 16-byte store */
 				if(on && (c0 & ~31) < n){
 					if(RS == 2){ trow[0] = acc[0]; trow[1] = acc[1]; }
-					else { uint32_t *p = trow + (c0 >> 5) * 4; p[0] = acc[0]; p[1] = acc[1]; p[2] = acc[2]; p[3] = acc[3]; }
+					else { uint32_t *p = trow + (size_t)(c0 >> 5) * 4u * WTZ_NLANES; p[0] = acc[0]; p[1] = acc[1]; p[2] = acc[2]; p[3] = acc[3]; }
 				}
 				acc[0] = acc[1] = acc[2] = acc[3] = 0u;
 			}
@@ -212,7 +222,7 @@ WTZ_HD void wtz_lane_traceback(bool live, int32_t r, int32_t cc, int32_t W, uint
 	if(!live){ r = -1; cc = -1; }
 	while(r >= 0 && cc >= 0){
 		const int32_t jb = r > W ? r - W : 0, c = cc - jb;
-		const uint32_t nib = (tr[(size_t)r * RS + (uint32_t)(c >> 3)] >> (4 * (7 - (c & 7)))) & 15u;      /* cell 0 of a block sits in the top nibble; bits: 3 m < E, 2 max(m, E) < F, 1 E extended, 0 F extended */
+		const uint32_t nib = (tr[wtz_ltr_at((uint32_t)r, RS, (uint32_t)(c >> 3))] >> (4 * (7 - (c & 7)))) & 15u;      /* cell 0 of a block sits in the top nibble; bits: 3 m < E, 2 max(m, E) < F, 1 E extended, 0 F extended */
 		state = state == 0 ? ((nib & 4u) ? 2u : (nib >> 3)) : (state == 1 ? ((nib & 2u) ? 1u : 0u) : ((nib & 1u) ? 2u : 0u));
 		if((r >> 5) != rblk){ rblk = r >> 5; rw = wtz_pack32(rseq, rblk * 32, rlen); }
 		if((cc >> 5) != cblk){ cblk = cc >> 5; cw = wtz_pack32(cseq, cblk * 32, clen); }
@@ -274,7 +284,7 @@ WTZ_HD void wtz_lane_global(bool live, int32_t qlen, const wtz_seq_packed &q, in
 		int32_t left = jb == 0 ? -(o_del + e_del * (i + 1)) : MINF, g = MINF;
 		const int32_t nmax = wtz_lane_wmax(n);
 		uint32_t acc[4] = {0u, 0u, 0u, 0u};
-		uint32_t *trow = tr + (size_t)i * RS;
+		uint32_t *trow = tr + wtz_ltr_at((uint32_t)i, (uint32_t)RS, 0u);      /* unit 0 of the row; unit q is q * 4 * WTZ_NLANES dwords further */
 		#pragma unroll
 		for(int c0 = 0; c0 < NC; c0 += 8){
 			if(c0 <= nmax){
@@ -303,7 +313,7 @@ WTZ_HD void wtz_lane_global(bool live, int32_t qlen, const wtz_seq_packed &q, in
 			if(((c0 + 8) & 31) == 0 || c0 + 8 >= NC){
 				if(on && (c0 & ~31) < n){
 					if(RS == 2){ trow[0] = acc[0]; trow[1] = acc[1]; }
-					else { uint32_t *p = trow + (c0 >> 5) * 4; p[0] = acc[0]; p[1] = acc[1]; p[2] = acc[2]; p[3] = acc[3]; }
+					else { uint32_t *p = trow + (size_t)(c0 >> 5) * 4u * WTZ_NLANES; p[0] = acc[0]; p[1] = acc[1]; p[2] = acc[2]; p[3] = acc[3]; }
 				}
 				acc[0] = acc[1] = acc[2] = acc[3] = 0u;
 			}

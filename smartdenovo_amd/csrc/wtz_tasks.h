@@ -414,7 +414,7 @@ WTZ_HD void wtz_task_ldp(uint32_t gw, uint32_t wv, const wtz_env_t &V, const wtz
 	}
 	pa = wtz_coop_bcast64(pa);
 	if(pa == 0) return;                       /* the slots stay "not done": the fold reports the pool */
-	uint32_t *tr = (uint32_t*)(uintptr_t)pa + (size_t)WTZ_LANE * rows_max * RS;
+	uint32_t *tr = (uint32_t*)(uintptr_t)pa;      /* the wave's block; the lanes' rows are interleaved inside it (wtz_ltr_at) */
 	wtz_lres_t R; memset(&R, 0, sizeof R);
 	wtz_lane_fixed<NC, false>(live, pr.qlen, q, pr.tlen, tt, 0, W, ql, tl, M, X, I, D, E, T, tr, R);
 	if(live) res[slot] = R;
@@ -433,7 +433,7 @@ WTZ_HD void wtz_task_ltb(uint32_t gw, uint32_t wv, uint32_t RS, const wtz_env_t 
 	wtz_ext_geometry(pr.qlen, pr.tlen, 0, W, P->M, P->O, P->O, P->E, P->T, ql, tl, n_col);
 	const wtz_alnitem_t &it = items[tasks[pr.win].item];
 	const wtz_seq_packed q = wtz_view(V.R, it.c, it.dir).sub(pr.qoff, 1), tt = wtz_view(V.R, it.q, 0).sub(pr.toff, 1);
-	const uint32_t *tr = (const uint32_t*)(uintptr_t)pa + (size_t)WTZ_LANE * wrm[gw] * RS;
+	const uint32_t *tr = (const uint32_t*)(uintptr_t)pa;      /* lane-interleaved, as the DP kernel wrote it */
 	wtz_lane_traceback<false>(true, R.qe - 1, R.te - 1, W, RS, q, pr.qlen, tt, pr.tlen, tr, runs + runoff[slot], R);
 	res[slot] = R;
 }
@@ -861,7 +861,7 @@ WTZ_HD void wtz_task_gdp(uint32_t gw, uint32_t wv, const wtz_env_t &V, const wtz
 	}
 	pa = wtz_coop_bcast64(pa);
 	if(pa == 0) return;                      /* nothing published: the wave kernel takes these gaps (and reports the pool if it is really full) */
-	uint32_t *tr = (uint32_t*)(uintptr_t)pa + (size_t)WTZ_LANE * rows_max * RS;
+	uint32_t *tr = (uint32_t*)(uintptr_t)pa;      /* the wave's block; the lanes' rows are interleaved inside it (wtz_ltr_at) */
 	wtz_lres_t R; memset(&R, 0, sizeof R);
 	wtz_lane_global<NC>(live, G.dq, q, G.dt, tt, G.w, M, X, -I, -E, -D, -E, tr, R);
 	if(live) res[t] = R;
@@ -884,7 +884,7 @@ WTZ_HD void wtz_task_gtb(uint32_t gw, uint32_t wv, uint32_t RS, const wtz_env_t 
 	for(int32_t j = (int32_t)k - 1; j >= 0; j--) if(it.regs[j].pass == 1){ prev = j; break; }
 	const wtz_reg_t *reg1 = &it.regs[prev];
 	const wtz_seq_packed q = wtz_view(V.R, it.c, it.dir).sub(reg1->x.qe, 1), tt = wtz_view(V.R, it.q, 0).sub(reg1->x.te, 1);
-	const uint32_t *tr = (const uint32_t*)(uintptr_t)pa + (size_t)WTZ_LANE * wrm[gw] * RS;
+	const uint32_t *tr = (const uint32_t*)(uintptr_t)pa;      /* lane-interleaved, as the DP kernel wrote it */
 	uint32_t *rr = runs + runoff[t];
 	const int32_t r0 = G.dt - 1, c0 = (r0 + G.w + 1 < G.dq ? r0 + G.w + 1 : G.dq) - 1;
 	wtz_lane_traceback<true>(true, r0, c0, G.w, RS, tt, G.dt, q, G.dq, tr, rr, R);

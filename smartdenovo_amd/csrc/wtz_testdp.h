@@ -59,10 +59,10 @@ static __device__ void wtz_task_test_lane(uint32_t t, const wtz_dpprob_dev_t *pr
 	if(n_col > WTZ_LN_MAXCOLS || ql > WTZ_LN_MAXROWS || ql + tl > WTZ_LN_MAXSPAN || init > (1 << 20)){ if(WTZ_LANE == 0) res[t] = r; return; }      /* outside the envelope: declined */
 	const uint32_t RS = wtz_lane_rs(n_col);
 	unsigned long long pa = 0;
-	if(WTZ_LANE == 0) pa = (unsigned long long)(uintptr_t)wtz_pool_alloc(pool, (size_t)ql * RS * 4 + (size_t)(ql + tl + 4) * 4 + 32);
+	if(WTZ_LANE == 0) pa = (unsigned long long)(uintptr_t)wtz_pool_alloc(pool, (size_t)ql * RS * 4 * WTZ_NLANES + (size_t)(ql + tl + 4) * 4 + 32);      /* the wave's lane-interleaved trace block (wtz_ltr_at), although only lane 0 has a problem here */
 	pa = __shfl(pa, 0, 64);
 	if(pa == 0){ r.bad = 1; r.form = 64; if(WTZ_LANE == 0) res[t] = r; return; }
-	uint32_t *tr = (uint32_t*)(uintptr_t)pa, *runs = tr + (size_t)ql * RS + 4;
+	uint32_t *tr = (uint32_t*)(uintptr_t)pa, *runs = tr + (size_t)ql * RS * WTZ_NLANES + 4;
 	const bool live = WTZ_LANE == 0;
 	wtz_lres_t R; memset(&R, 0, sizeof R);
 	if(n_col <= 16)      wtz_lane_fixed<16, true>(live, p.qlen, p.q, p.tlen, p.t, init, W, ql, tl, M, X, I, D, E, T, tr, R);
@@ -86,10 +86,10 @@ static __device__ void wtz_task_test_lane_global(uint32_t t, const wtz_dpprob_de
 	if(p.qlen <= 0 || p.tlen <= 0 || WTZ_ABSDIFF(p.qlen, p.tlen) > w || n_col > WTZ_LN_MAXCOLS || p.tlen > WTZ_LG_MAXROWS){ if(WTZ_LANE == 0) res[t] = r; return; }     /* declined */
 	const uint32_t RS = wtz_lane_rs(n_col);
 	unsigned long long pa = 0;
-	if(WTZ_LANE == 0) pa = (unsigned long long)(uintptr_t)wtz_pool_alloc(pool, (size_t)p.tlen * RS * 4 + (size_t)(p.qlen + p.tlen + 4) * 4 + 32);
+	if(WTZ_LANE == 0) pa = (unsigned long long)(uintptr_t)wtz_pool_alloc(pool, (size_t)p.tlen * RS * 4 * WTZ_NLANES + (size_t)(p.qlen + p.tlen + 4) * 4 + 32);
 	pa = __shfl(pa, 0, 64);
 	if(pa == 0){ r.bad = 1; r.form = 64; if(WTZ_LANE == 0) res[t] = r; return; }
-	uint32_t *tr = (uint32_t*)(uintptr_t)pa, *runs = tr + (size_t)p.tlen * RS + 4;
+	uint32_t *tr = (uint32_t*)(uintptr_t)pa, *runs = tr + (size_t)p.tlen * RS * WTZ_NLANES + 4;
 	const bool live = WTZ_LANE == 0;
 	wtz_lres_t R; memset(&R, 0, sizeof R);
 	if(n_col <= 16)      wtz_lane_global<16>(live, p.qlen, p.q, p.tlen, p.t, w, M, X, -I, -E, -D, -E, tr, R);
