@@ -230,6 +230,8 @@ WTZ_HD int wtz_denoise_dir_coop(const wtz_zhit_t *rs, uint32_t n_rs, uint32_t di
 		uint8_t *lds, uint32_t lds_bytes, wtz_pool_t *pool, int32_t *bad, bool big = false){
 	const uint32_t lane = WTZ_LANE;
 	if(lds == NULL || n_rs > 65535u){ WTZ_PROF_CNT(60, 1000000); return 4; }
+	const unsigned long long pd0 = WTZ_PROF_T(); (void)pd0;      /* 10 / 59: wave time / calls of the strands whose image lives in the pool */
+	unsigned long long pdn = WTZ_PROF_T(); (void)pdn;      /* phase profiler: 24 image, 25 band list (lane 0), 26 productivity filter, 27 productive bands, 28 grouped order, 29 seeds (lane 0); 30 bands, 31 productive bands, 11 grouped matches */
 	/* image: per match 4 B (off1<<10 | len1) + 1 B (group id; 2 B when big); per distinct diagonal 4 B (offset) + 2 B (first match) +
 	 * 2 B (band members).  Work arrays: band keys / member lists and the group table.  The rs index of a match is only needed by the
 	 * parallel passes: it lives in the pool. */
@@ -319,6 +321,7 @@ WTZ_HD int wtz_denoise_dir_coop(const wtz_zhit_t *rs, uint32_t n_rs, uint32_t di
 		}
 	}
 	WTZ_WAVE_SYNC();
+	WTZ_PROF_ADD(24, pdn); pdn = WTZ_PROF_T();
 	/* ---- the bands.  Their sequence (hzm_aln.h:748-769, 832-834) depends on the diagonal offsets only, so lane 0 lists
 	 * them first; whether a band can change anything - it must contain a linear run of >= min_linear_len - is then decided
 	 * for all bands in parallel (small bands exactly, by replaying the sweep in registers; larger ones are simply kept), and
@@ -330,6 +333,64 @@ WTZ_HD int wtz_denoise_dir_coop(const wtz_zhit_t *rs, uint32_t n_rs, uint32_t di
 	if(bands == NULL){ *bad = 1; if(lane == 0) S.regs[dir].n = 0; return 0; }
 	uint32_t *prod = bands + (nd + 2u);
 	uint32_t nbands = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+	{
+		/* Round 4: the same band sequence walked by the WHOLE wave.  Lane 0 alone paid ~12 dependent LDS reads per band (2 800 cycles; 308 bands per strand at
+		 * configs[2]: a quarter of the denoise pass).  Here lane l holds Doff[doff + l]: the end of the band (first offset beyond lst + yvar, never the last
+		 * diagonal: hzm_aln.h:757-761) and the next start (first offset beyond lst + yvar / 2) are two ballots over that window; bands of more than 64 diagonals
+		 * take further windows.  Every quantity is wave-uniform; the quirks are those of wtz_band_next / wtz_band_advance. */
+		uint32_t doff = 0, wb = 0; int32_t end_offset = -0x7FFFFFFF;
+		int32_t w = lane < nd ? Doff[lane] : 0x7FFFFFFF;             /* register window: lane l holds Doff[wb + l]; a band start moves by a few diagonals, so one load serves ~10 bands
+		                                                              * (a strand whose image lives in the pool pays an L2 round trip per load) */
+		while(nd != 0 && doff < n_rs){                     /* hzm_aln.h:753 compares the diagonal index with rs->size */
+			uint32_t r = doff - wb;
+			if(r >= 32u){ wb = doff; r = 0; const uint32_t idx = wb + lane; w = idx < nd ? Doff[idx] : 0x7FFFFFFF; }
+			const uint32_t cap = nd - 1u - doff;                  /* dcnt stops before the last diagonal (doff <= nd - 1 always) */
+			const int32_t lst = __builtin_amdgcn_readlane(w, (int)__builtin_amdgcn_readfirstlane((int)r));
+			uint32_t dcnt;
+			{       /* the offsets ascend: lanes below r cannot exceed lst */
+				const unsigned long long m = __ballot(w > lst + yvar);
+				if(m){ dcnt = (uint32_t)__builtin_ctzll(m) - r; if(dcnt > cap) dcnt = cap; }
+				else if(64u - r > cap) dcnt = cap;
+				else {
+					uint32_t c = 64u - r;
+					for(;;){
+						const uint32_t idx = doff + c + lane;
+						const int32_t v = idx < nd ? Doff[idx] : 0x7FFFFFFF;
+						const unsigned long long m2 = __ballot(v > lst + yvar);
+						if(m2){ dcnt = c + (uint32_t)__builtin_ctzll(m2); if(dcnt > cap) dcnt = cap; break; }
+						if(c + 64u > cap){ dcnt = cap; break; }
+						c += 64u;
+					}
+				}
+			}
+			if(dcnt == 0) break;
+			int32_t voff = r + dcnt < 64u ? __builtin_amdgcn_readlane(w, (int)__builtin_amdgcn_readfirstlane((int)(r + dcnt))) : Doff[doff + dcnt];      /* Doff[doff + dcnt] */
+			voff = __builtin_amdgcn_readfirstlane(voff);
+			if(voff == end_offset){ doff += dcnt; continue; }
+			end_offset = voff;
+			if(lane == 0) bands[nbands] = (doff << 16) | dcnt;
+			nbands++;
+			uint32_t adv = dcnt;                                       /* wtz_band_advance: first diagonal of the band beyond lst + yvar / 2 */
+			{
+				const unsigned long long m = __ballot(w > lst + yvar / 2);
+				if(m){ const uint32_t f = (uint32_t)__builtin_ctzll(m) - r; if(f < dcnt) adv = f; }
+				else if(64u - r < dcnt){
+					uint32_t c = 64u - r;
+					for(;;){
+						const uint32_t idx = doff + c + lane;
+						const int32_t v = idx < nd ? Doff[idx] : 0x7FFFFFFF;
+						const unsigned long long m2 = __ballot(v > lst + yvar / 2);
+						if(m2){ const uint32_t f = c + (uint32_t)__builtin_ctzll(m2); if(f < dcnt) adv = f; break; }
+						c += 64u;
+						if(c >= dcnt) break;
+					}
+				}
+			}
+			doff += adv;
+		}
+	}
+#else
 	if(lane == 0){
 		uint32_t doff = 0, dcnt = 0; int32_t lst_offset = 0, end_offset = -0x7FFFFFFF;
 		for(;;){
@@ -350,8 +411,10 @@ WTZ_HD int wtz_denoise_dir_coop(const wtz_zhit_t *rs, uint32_t n_rs, uint32_t di
 			doff = a;
 		}
 	}
+#endif
 	nbands = wtz_coop_bcast32(nbands);
 	WTZ_WAVE_SYNC();
+	WTZ_PROF_ADD(25, pdn); pdn = WTZ_PROF_T(); WTZ_PROF_CNT(30, nbands);
 	uint32_t nprod = 0;
 	for(uint32_t b0 = 0; b0 < nbands; b0 += WTZ_NLANES){
 		const uint32_t b = b0 + lane;
@@ -389,11 +452,13 @@ WTZ_HD int wtz_denoise_dir_coop(const wtz_zhit_t *rs, uint32_t n_rs, uint32_t di
 	 *   run: hzm_aln.h:780-828 resets `len` to the PREVIOUS match's length) - so all runs of the band are measured at once;
 	 *   only the runs of >= min_linear_len matches' worth go through the sequential group merging, each as a wave-wide
 	 *   min-reduction + scatter. ---- */
+	WTZ_PROF_ADD(26, pdn); pdn = WTZ_PROF_T(); WTZ_PROF_CNT(31, nprod);
 	uint32_t fail = 0, ngrp = 1;
 	if(lane == 0) grp[0] = 0;
 	WTZ_WAVE_SYNC();
 	for(uint32_t pb = 0; pb < nprod && !fail; pb++){
 		const uint32_t doff = prod[pb] >> 16, dcnt = prod[pb] & 0xFFFFu;
+		unsigned long long pbn = WTZ_PROF_T(); (void)pbn;      /* profiler, inside a productive band: 46 members, 48 order by off1, 49 runs, 50 group merging; 54 members (count), 55 productive runs (count) */
 		/* members in diagonal order */
 		uint32_t nb = 0;
 		for(uint32_t d0 = 0; d0 < dcnt; d0 += WTZ_NLANES){
@@ -406,11 +471,31 @@ WTZ_HD int wtz_denoise_dir_coop(const wtz_zhit_t *rs, uint32_t n_rs, uint32_t di
 		}
 		if(nb > bcap){ fail = 2; WTZ_PROF_CNT(62, 1000000); break; }
 		WTZ_WAVE_SYNC();
-		uint32_t np2 = 64; while(np2 < nb) np2 <<= 1;
-		for(uint32_t i = lane; i < np2; i += WTZ_NLANES) bk[i] = i < nb ? (((T[blk[i]] >> 10) << 11) | i) : 0xFFFFFFFFu;
-		WTZ_WAVE_SYNC();
-		wtz_coop_sort_u32(bk, np2);
+		WTZ_PROF_ADD(46, pbn); pbn = WTZ_PROF_T(); WTZ_PROF_CNT(54, nb);
+		/* Members by off1 (hzm_aln.h:777-778).  The reference's sort is unstable, but members that tie on off1 are copies of ONE query z-mer (same off1 => same
+		 * strand-filtered query position => same len1: their T words are identical), a run never breaks between them (the second starts at or before the
+		 * first's end), and everything below reads T, or writes the SAME group id to every member of a run: no order among them can be observed.  So any
+		 * sorted order is the reference's (rounds 2-3 replayed the swap sequence on lane 0 for every band with such a tie: 60 k cycles per productive band,
+		 * a third of the whole denoise pass; -DWTZ_DM_EXACT_TIES keeps that form for cross-checking). */
+#if defined(__HIP_DEVICE_COMPILE__)
+		if(nb <= 64u){         /* the usual case (37 members on average at configs[2]): one key per lane, ordered in registers */
+			const uint64_t kv = lane < nb ? (uint64_t)(((T[blk[lane]] >> 10) << 11) | lane) : ~0ull;
+			const uint64_t sv = wtz_wave_sort64(kv);
+#ifdef WTZ_DM_EXACT_TIES
+			const uint32_t nx = (uint32_t)__shfl_down((int)(uint32_t)sv, 1, 64);
+			uint32_t any; (void)wtz_coop_rank(lane + 1 < nb && ((uint32_t)sv >> 11) == (nx >> 11), &any);
+			if(any){ if(lane == 0){ wtz_gt_blk_off1 g1; g1.T = T; wtz_sort_exact(blk, (size_t)nb, g1); } WTZ_WAVE_SYNC(); if(lane < nb) sblk[lane] = blk[lane]; }
+			else
+#endif
+			if(lane < nb) sblk[lane] = blk[(uint32_t)sv & 0x7FFu];
+		} else
+#endif
 		{
+			uint32_t np2 = 64; while(np2 < nb) np2 <<= 1;
+			for(uint32_t i = lane; i < np2; i += WTZ_NLANES) bk[i] = i < nb ? (((T[blk[i]] >> 10) << 11) | i) : 0xFFFFFFFFu;
+			WTZ_WAVE_SYNC();
+			wtz_coop_sort_u32(bk, np2);
+#ifdef WTZ_DM_EXACT_TIES
 			bool tie = false;
 			for(uint32_t i = lane; i + 1 < nb; i += WTZ_NLANES) if((bk[i] >> 11) == (bk[i + 1] >> 11)) tie = true;
 			uint32_t any; (void)wtz_coop_rank(tie, &any);
@@ -418,11 +503,12 @@ WTZ_HD int wtz_denoise_dir_coop(const wtz_zhit_t *rs, uint32_t n_rs, uint32_t di
 				if(lane == 0){ wtz_gt_blk_off1 g1; g1.T = T; wtz_sort_exact(blk, (size_t)nb, g1); }
 				WTZ_WAVE_SYNC();
 				for(uint32_t i = lane; i < nb; i += WTZ_NLANES) sblk[i] = blk[i];
-			} else {
-				for(uint32_t i = lane; i < nb; i += WTZ_NLANES) sblk[i] = blk[bk[i] & 0x7FFu];
-			}
+			} else
+#endif
+			for(uint32_t i = lane; i < nb; i += WTZ_NLANES) sblk[i] = blk[bk[i] & 0x7FFu];
 		}
 		WTZ_WAVE_SYNC();
+		WTZ_PROF_ADD(48, pbn); pbn = WTZ_PROF_T();
 		/* run heads: position 0 and every break; heads[] reuses the key words */
 		uint16_t *heads = (uint16_t*)bk;
 		uint32_t nrun = 0;
@@ -463,6 +549,7 @@ WTZ_HD int wtz_denoise_dir_coop(const wtz_zhit_t *rs, uint32_t n_rs, uint32_t di
 			npr += tot;
 		}
 		WTZ_WAVE_SYNC();
+		WTZ_PROF_ADD(49, pbn); pbn = WTZ_PROF_T(); WTZ_PROF_CNT(55, npr);
 		for(uint32_t q = 0; q < npr && !fail; q++){
 			const uint32_t r = pruns[q], j = heads[r], i = heads[r + 1];
 			uint32_t gmin = 0xFFFFFFFFu;
@@ -481,7 +568,9 @@ WTZ_HD int wtz_denoise_dir_coop(const wtz_zhit_t *rs, uint32_t n_rs, uint32_t di
 			for(uint32_t k = j + lane; k < i; k += WTZ_NLANES) WTZ_GID_SET(sblk[k], g0);
 			WTZ_WAVE_SYNC();
 		}
+		WTZ_PROF_ADD(50, pbn);
 	}
+	WTZ_PROF_ADD(27, pdn); pdn = WTZ_PROF_T();
 	fail = wtz_coop_bcast32(fail);
 	if(lane == 0 && !fail){      /* wtz_tidy_groups */
 		for(uint32_t i = 1; i < ngrp; i++){
@@ -495,6 +584,8 @@ WTZ_HD int wtz_denoise_dir_coop(const wtz_zhit_t *rs, uint32_t n_rs, uint32_t di
 	fail = wtz_coop_bcast32(fail);
 	if(fail) return (int)fail;
 	WTZ_WAVE_SYNC();
+	WTZ_PROF_ADD(51, pdn); WTZ_PROF_CNT(58, ngrp);      /* 51: tidy groups (lane 0), 52: count + allocation, 53: keys + order; 58 groups (count) */
+	unsigned long long pgn = WTZ_PROF_T(); (void)pgn;
 	/* ---- grouped matches, ordered by (group, off1) (hzm_aln.h:848-857) ---- */
 	uint32_t n_dst = 0;
 	for(uint32_t x0 = 0; x0 < nf; x0 += WTZ_NLANES){
@@ -511,7 +602,12 @@ WTZ_HD int wtz_denoise_dir_coop(const wtz_zhit_t *rs, uint32_t n_rs, uint32_t di
 	uint64_t *K = (uint64_t*)(uintptr_t)ka;
 	if(K == NULL){ *bad = 1; return 0; }
 	wtz_zhit_t *dstv = (wtz_zhit_t*)(K + np);
-	for(int pass = 0; pass < 2; pass++){
+	WTZ_PROF_ADD(52, pgn); pgn = WTZ_PROF_T();
+	/* keys (group, off1, position), then the order of hzm_aln.h:848-857.  Ties on (group, off1) are copies of one query z-mer again: what follows reads
+	 * their off1 / len1 (equal) and takes minima / maxima over their candidate side, so their relative order is unobservable (see the band order above).
+	 * The key words live in the pool; they are ordered through an LDS window - the band work arrays are free now (grp[] behind them is still read) -
+	 * instead of 45 bitonic stages straight on HBM words (5.0 of the 22.8 Tcycles of the denoise pass at configs[2]). */
+	{
 		uint32_t n = 0;
 		for(uint32_t x0 = 0; x0 < nf; x0 += WTZ_NLANES){
 			const uint32_t x = x0 + lane;
@@ -520,20 +616,33 @@ WTZ_HD int wtz_denoise_dir_coop(const wtz_zhit_t *rs, uint32_t n_rs, uint32_t di
 			if(keep) K[n + pos] = ((uint64_t)grp[WTZ_GID(x)] << 37) | ((uint64_t)(T[x] >> 10) << 16) | x;
 			n += tot;
 		}
+		for(uint32_t i = n_dst + lane; i < np; i += WTZ_NLANES) K[i] = ~0ull;
 		WTZ_WAVE_SYNC();
-		if(pass == 0){
-			for(uint32_t i = n_dst + lane; i < np; i += WTZ_NLANES) K[i] = ~0ull;
+		uint64_t *win = (uint64_t*)(((uintptr_t)bk + 7u) & ~(uintptr_t)7u);
+		const uint32_t avail = (8u * bcap - (uint32_t)((uintptr_t)win - (uintptr_t)bk)) / 8u;      /* bk + blk + sblk = 8 * bcap bytes */
+		uint32_t ln = 128u; while(ln * 2u <= avail) ln <<= 1;
+		wtz_coop_sort_u64_windowed(K, np, avail >= 128u ? win : NULL, ln);
+#ifdef WTZ_DM_EXACT_TIES
+		bool tie = false;
+		for(uint32_t i = lane; i + 1 < n_dst; i += WTZ_NLANES) if((K[i] >> 16) == (K[i + 1] >> 16)) tie = true;
+		uint32_t any; (void)wtz_coop_rank(tie, &any);
+		if(any){
+			n = 0;
+			for(uint32_t x0 = 0; x0 < nf; x0 += WTZ_NLANES){
+				const uint32_t x = x0 + lane;
+				const bool keep = x < nf && WTZ_GID(x) != 0;
+				uint32_t tot; const uint32_t pos = wtz_coop_rank(keep, &tot);
+				if(keep) K[n + pos] = ((uint64_t)grp[WTZ_GID(x)] << 37) | ((uint64_t)(T[x] >> 10) << 16) | x;
+				n += tot;
+			}
 			WTZ_WAVE_SYNC();
-			wtz_coop_sort_u64(K, np);
-			bool tie = false;
-			for(uint32_t i = lane; i + 1 < n_dst; i += WTZ_NLANES) if((K[i] >> 16) == (K[i + 1] >> 16)) tie = true;
-			uint32_t any; (void)wtz_coop_rank(tie, &any);
-			if(!any) break;
-		} else {
-			if(lane == 0) wtz_sort_exact(K, (size_t)n_dst, wtz_gt_hi48());       /* equal (group, off1): the reference's swap sequence decides */
+			if(lane == 0) wtz_sort_exact(K, (size_t)n_dst, wtz_gt_hi48());
 			WTZ_WAVE_SYNC();
 		}
+#endif
 	}
+	WTZ_PROF_ADD(53, pgn);
+	WTZ_PROF_ADD(28, pdn); pdn = WTZ_PROF_T(); WTZ_PROF_CNT(11, n_dst);
 	/* the strand image is dead: gather the ordered matches (with their final group id) */
 	for(uint32_t y = lane; y < n_dst; y += WTZ_NLANES){
 		wtz_zhit_t h = rs[ridx[(uint32_t)(K[y] & 0xFFFFu)]];
@@ -549,6 +658,47 @@ WTZ_HD int wtz_denoise_dir_coop(const wtz_zhit_t *rs, uint32_t n_rs, uint32_t di
 		WTZ_WAVE_SYNC();
 		dv = L;
 	}
+#if defined(__HIP_DEVICE_COMPILE__)
+	{
+		/* one seed per group (hzm_aln.h:858-889), the whole wave per group: bounds are minima / maxima over the members; the covered length adds, per member,
+		 * len1 or what it reaches beyond the member before it (the first member counts in full) - a function of the member and its predecessor, so it
+		 * sums in any order (modulo 2^29 like the reference's bit field).  Lane 0 alone walked the members with ~4 dependent reads each. */
+		uint32_t j = 0;
+		while(j < n_dst){
+			const uint32_t gj = dv[j].gid;
+			uint32_t i = j + 1;                                     /* end of the group: first member with another id */
+			for(;;){
+				const uint32_t y = i + lane;
+				const unsigned long long m = __ballot(y >= n_dst || dv[y].gid != gj);
+				if(m){ i += (uint32_t)__builtin_ctzll(m); break; }
+				i += 64u;
+			}
+			int32_t b0 = 0x7FFFFFFF, b1 = 0x7FFFFFFF, e0 = 0, e1 = 0; uint32_t ov = 0;
+			for(uint32_t k = j + lane; k < i; k += WTZ_NLANES){
+				const wtz_zhit_t p = dv[k];
+				const int32_t o1 = (int32_t)ZH_OFF1(p), l1 = (int32_t)ZH_LEN1(p), o2 = (int32_t)ZH_OFF2(p), l2 = (int32_t)ZH_LEN2(p);
+				int32_t lst = 0;
+				if(k > j){ const wtz_zhit_t pp = dv[k - 1]; lst = (int32_t)ZH_OFF1(pp) + (int32_t)ZH_LEN1(pp); }
+				b0 = o1 < b0 ? o1 : b0; e0 = o1 + l1 > e0 ? o1 + l1 : e0;
+				b1 = o2 < b1 ? o2 : b1; e1 = o2 + l2 > e1 ? o2 + l2 : e1;
+				ov += (uint32_t)((o1 > lst) ? l1 : o1 + l1 - lst);
+			}
+			for(int d = 32; d > 0; d >>= 1){
+				const int32_t xb0 = __shfl_xor(b0, d, 64), xb1 = __shfl_xor(b1, d, 64), xe0 = __shfl_xor(e0, d, 64), xe1 = __shfl_xor(e1, d, 64);
+				ov += (uint32_t)__shfl_xor((int)ov, d, 64);
+				b0 = xb0 < b0 ? xb0 : b0; b1 = xb1 < b1 ? xb1 : b1; e0 = xe0 > e0 ? xe0 : e0; e1 = xe1 > e1 ? xe1 : e1;
+			}
+			if(lane == 0){
+				wtz_win_t seed;
+				seed.pb2 = 0; seed.closed = 0; seed.dir = (uint8_t)dir; seed.pad = 0;
+				seed.anchors[0] = j; seed.anchors[1] = i;
+				seed.beg[0] = b0; seed.beg[1] = b1; seed.end[0] = e0; seed.end[1] = e1; seed.ovl = WTZ_OVL29(ov);
+				if(!(seed.end[0] - seed.beg[0] < min_linear_len)) (void)S.regs[dir].push(seed);      /* a failed push sets the vector's `bad` flag (the caller reports the pool) */
+			}
+			j = i;
+		}
+	}
+#else
 	if(lane == 0){
 		uint32_t j = 0;
 		for(uint32_t i = 1; i <= n_dst; i++){
@@ -572,7 +722,10 @@ WTZ_HD int wtz_denoise_dir_coop(const wtz_zhit_t *rs, uint32_t n_rs, uint32_t di
 			j = i;
 		}
 	}
+#endif
 	WTZ_WAVE_SYNC();
+	WTZ_PROF_ADD(29, pdn);
+	if(img != lds){ WTZ_PROF_ADD(10, pd0); WTZ_PROF_CNT(59, 1); }
 	return 0;
 #undef WTZ_GID
 #undef WTZ_GID_SET

@@ -70,7 +70,11 @@ WTZ_HD void wtz_task_pair(uint32_t t, const wtz_env_t &V, const uint32_t *qid, c
 	const uint64_t tk0 = WTZ_TICK();
 	WTZ_CRUMB(t, 1);
 	const bool aux = P->aux_strand != 0;                     /* align_hzmaux's form of the pair stages (wtgbo): strand 0 only, no n_hits gate */
+#if defined(__HIP_DEVICE_COMPILE__)
+	const bool ok = wtz_zmatch_coop(V.ZQ, V.Z, q, c, V.R.rdlen[c], P->max_kmer_var, V.pool, &hits, &n, aux, (uint32_t*)wtz_wave_scratch(), dm ? (uint32_t)WTZ_PAIR_DM_LDS_BYTES : (uint32_t)WTZ_PAIR_LDS_BYTES);      /* the LDS slice is free until the first ordering */
+#else
 	const bool ok = wtz_zmatch_coop(V.ZQ, V.Z, q, c, V.R.rdlen[c], P->max_kmer_var, V.pool, &hits, &n, aux);
+#endif
 	const uint64_t tk1 = WTZ_TICK();
 	WTZ_CRUMB(t, 2 | (n << 8));
 	wtz_zhit_t *sorted = NULL;

@@ -49,29 +49,78 @@ WTZ_HD bool wtz_zmatch(const wtz_zindex_t &ZQ, const wtz_zindex_t &ZC, uint32_t 
 
 /* A6, wave-cooperative: lanes take consecutive candidate z-mers, the matches of a 64-z-mer chunk are written in
  * candidate-position order through an exclusive scan of the per-lane match counts (emission order is part of the
- * contract: hzm_aln.h:212-221).  Two passes: count (the dense index of each z-mer is cached), allocate exactly, fill.
+ * contract: hzm_aln.h:212-221).  Passes: (round 4) prefilter + ordered compaction, count (the dense index of each surviving z-mer is
+ * cached), allocate exactly, fill.
+ * The prefilter: of a candidate's ~7 500 homopolymer-compressed 10-mers only ~10 % occur in the query at all (4 * 3^9 = 78 732 such z-mers,
+ * ~7 500 distinct in a 10 kb read), yet every one of them paid a 13-step binary search of dependent L2 loads in the query's table - with
+ * 64 lanes in lockstep a chunk costs the full chain whenever ANY lane has work, so skipping per lane buys nothing.  Instead the wave first
+ * sets one bit per distinct query z-mer in a bitmap in its LDS slice (multiplicative hash), streams the candidate's z-mers past it and
+ * COMPACTS the ones whose bit is set (ballot ranks: order kept); only those - a fifth - are searched.  A false positive is searched and
+ * found absent like before; the emitted matches and their order are unchanged.  `lds` == NULL (host emulation) or a query too long for
+ * the bitmap: every candidate z-mer is a survivor.
  * Returns the match list through *out / *n_out on every lane; false when the pool is exhausted. */
-WTZ_HD bool wtz_zmatch_coop(const wtz_zindex_t &ZQ, const wtz_zindex_t &ZC, uint32_t q, uint32_t c, uint32_t clen, uint32_t max_var, wtz_pool_t *pool, wtz_zhit_t **out, uint32_t *n_out, bool same_strand = false){
+WTZ_HD bool wtz_zmatch_coop(const wtz_zindex_t &ZQ, const wtz_zindex_t &ZC, uint32_t q, uint32_t c, uint32_t clen, uint32_t max_var, wtz_pool_t *pool, wtz_zhit_t **out, uint32_t *n_out, bool same_strand = false,
+		uint32_t *lds = NULL, uint32_t lds_bytes = 0){
 	const uint64_t qo = ZQ.zoff[q], co = ZC.zoff[c];      /* ZQ: the index holding the query's table (A5), ZC: the one holding the candidate's position-ordered z-mers (the same index unless the caller split them) */
 	const uint32_t cn = (uint32_t)(ZC.zoff[c + 1] - co), qd = ZQ.dn[q];
 	const uint32_t *dmer = ZQ.dmer + qo;
 	const uint32_t lane = WTZ_LANE;
 	uint64_t pa = 0;
-	if(lane == 0) pa = (uint64_t)(uintptr_t)wtz_pool_alloc(pool, (size_t)(cn + 1) * 8);
+	if(lane == 0) pa = (uint64_t)(uintptr_t)wtz_pool_alloc(pool, (size_t)(cn + 1) * 12);
 	pa = wtz_coop_bcast64(pa);
 	uint32_t *found = (uint32_t*)(uintptr_t)pa;
 	if(found == NULL) return false;
-	uint32_t *kcnt = found + (cn + 1);
-	uint32_t total = 0;
-	/* four candidate z-mers per lane and iteration: the binary searches are chains of dependent loads, so four independent
-	 * chains in flight per lane (stepped in lockstep) hide most of their latency */
+	uint32_t *kcnt = found + (cn + 1), *surv = kcnt + (cn + 1);
+	/* ---- prefilter ---- */
+	uint32_t lb = 0;                                          /* log2 of the bitmap's bits; 0 = no filter */
+	if(lds != NULL && lds_bytes >= 2048u && cn >= 256u){
+		lb = 14; while(lb < 20u && ((2u << lb) >> 3) <= lds_bytes) lb++;
+		if((uint64_t)qd * 3u > (1ull << lb)) lb = 0;            /* more than a third of the bits would be set: not worth a pass */
+	}
+	if(lb){
+		const uint32_t nw = (1u << lb) >> 5;
+		for(uint32_t w = lane; w < nw; w += WTZ_NLANES) lds[w] = 0u;
+		WTZ_WAVE_SYNC();
+		for(uint32_t i = lane; i < qd; i += WTZ_NLANES){
+			const uint32_t h = (dmer[i] * 0x9E3779B1u) >> (32u - lb);
+#if defined(__HIP_DEVICE_COMPILE__)
+			atomicOr(&lds[h >> 5], 1u << (h & 31u));
+#else
+			lds[h >> 5] |= 1u << (h & 31u);
+#endif
+		}
+		WTZ_WAVE_SYNC();
+	}
+	uint32_t ns = 0;
 	for(uint32_t k0 = 0; k0 < cn; k0 += 4 * WTZ_NLANES){
-		uint32_t m[4], lo[4], hi[4]; bool act[4];
+		uint32_t mm[4]; bool act[4];
 		#pragma unroll
 		for(int u = 0; u < 4; u++){
 			const uint32_t k = k0 + u * WTZ_NLANES + lane;
-			act[u] = k < cn && ZC.ok[co + k];
-			m[u] = act[u] ? ZC.mer[co + k] : 0u;
+			act[u] = k < cn && ZC.ok[co + k];              /* per-table-entry hit cap (hzm_aln.h:208-211) */
+			mm[u] = act[u] ? ZC.mer[co + k] : 0u;
+		}
+		#pragma unroll
+		for(int u = 0; u < 4; u++){
+			const uint32_t k = k0 + u * WTZ_NLANES + lane;
+			bool keep = act[u];
+			if(lb && keep){ const uint32_t h = (mm[u] * 0x9E3779B1u) >> (32u - lb); keep = ((lds[h >> 5] >> (h & 31u)) & 1u) != 0u; }
+			uint32_t tot; const uint32_t pos = wtz_coop_rank(keep, &tot);
+			if(keep) surv[ns + pos] = k;
+			ns += tot;
+		}
+	}
+	WTZ_WAVE_SYNC();
+	/* ---- the surviving z-mers in the query's table: dense index + number of query occurrences.  Four survivors per lane and iteration: the binary
+	 * searches are chains of dependent loads, so four independent chains in flight per lane (stepped in lockstep) hide most of their latency ---- */
+	uint32_t nflat = 0;                                       /* (candidate z-mer, query occurrence) combinations, before the length / strand tests */
+	for(uint32_t s0 = 0; s0 < ns; s0 += 4 * WTZ_NLANES){
+		uint32_t m[4], lo[4], hi[4]; bool act[4];
+		#pragma unroll
+		for(int u = 0; u < 4; u++){
+			const uint32_t si = s0 + u * WTZ_NLANES + lane;
+			act[u] = si < ns;
+			m[u] = act[u] ? ZC.mer[co + surv[si]] : 0u;
 			lo[u] = 0; hi[u] = act[u] ? qd : 0u;
 		}
 		for(;;){
@@ -85,52 +134,56 @@ WTZ_HD bool wtz_zmatch_coop(const wtz_zindex_t &ZQ, const wtz_zindex_t &ZC, uint
 		}
 		#pragma unroll
 		for(int u = 0; u < 4; u++){
-			const uint32_t k = k0 + u * WTZ_NLANES + lane;
-			uint32_t cnt = 0, idx = 0xFFFFFFFFu;
-			if(act[u] && lo[u] < qd && dmer[lo[u]] == m[u]){
-				idx = lo[u];
-				const uint32_t clen2 = ZC.len[co + k], first = ZQ.dfirst[qo + idx], n = ZQ.dcnt[qo + idx];
-				const uint32_t cdir = ZC.pos[co + k] & 1u;
-				for(uint32_t e = 0; e < n; e++){
-					const uint32_t qi = ZQ.sidx[qo + first + e];
-					const uint32_t qlen = ZQ.len[qo + qi];
-					const uint32_t dvv = qlen > clen2 ? qlen - clen2 : clen2 - qlen;
-					if(same_strand && ((ZQ.pos[qo + qi] ^ cdir) & 1u)) continue;       /* align_hzmaux keeps strand 0 only (hzm_aln.h:1193) */
-					if(dvv <= max_var) cnt++;
-				}
-			}
-			if(k < cn){ found[k] = idx; kcnt[k] = cnt; }
-			uint32_t chunk; (void)wtz_coop_excl_scan(cnt, &chunk);
-			total += chunk;
+			const uint32_t si = s0 + u * WTZ_NLANES + lane;
+			uint32_t cnt = 0, first = 0;
+			if(act[u] && lo[u] < qd && dmer[lo[u]] == m[u]){ first = ZQ.dfirst[qo + lo[u]]; cnt = ZQ.dcnt[qo + lo[u]]; }
+			uint32_t chunk; const uint32_t o = nflat + wtz_coop_excl_scan(cnt, &chunk);
+			if(si < ns){ found[si] = first; kcnt[si] = o; }          /* found: first entry of the z-mer's occurrence list; kcnt: where its combinations start in the flat order */
+			nflat += chunk;
 		}
 	}
+	/* ---- Round 4: the combinations FLAT, one per lane.  A lane used to walk its z-mer's occurrence list by itself (up to -Z of them, three dependent loads
+	 * each, twice: count, then fill) while the other lanes of the chunk waited for the longest list; the flat order (candidate position, then occurrence:
+	 * hzm_aln.h:212-221) is the emission order, so one pass with an ordered compaction of the combinations that pass the length / strand tests writes the
+	 * matches directly.  The list of (survivor, occurrence) is materialised first: a store per combination, no loads. ---- */
 	pa = 0;
-	if(lane == 0) pa = (uint64_t)(uintptr_t)wtz_pool_alloc(pool, (size_t)(total + 2) * sizeof(wtz_zhit_t));
+	if(lane == 0) pa = (uint64_t)(uintptr_t)wtz_pool_alloc(pool, (size_t)(nflat + 1) * 8 + (size_t)(nflat + 2) * sizeof(wtz_zhit_t));
 	pa = wtz_coop_bcast64(pa);
-	wtz_zhit_t *hits = (wtz_zhit_t*)(uintptr_t)pa;
-	if(hits == NULL) return false;
-	uint32_t base = 0;
-	for(uint32_t k0 = 0; k0 < cn; k0 += WTZ_NLANES){
-		const uint32_t k = k0 + lane;
-		const uint32_t cnt = k < cn ? kcnt[k] : 0;
-		uint32_t chunk; uint32_t o = base + wtz_coop_excl_scan(cnt, &chunk);
-		if(cnt){
-			const uint32_t lo = found[k];
-			const uint32_t cpos = ZC.pos[co + k], clen2 = ZC.len[co + k];
-			const uint32_t first = ZQ.dfirst[qo + lo], n = ZQ.dcnt[qo + lo];
-			for(uint32_t e = 0; e < n; e++){
-				const uint32_t qi = ZQ.sidx[qo + first + e];
-				const uint32_t qpos = ZQ.pos[qo + qi], qlen = ZQ.len[qo + qi];
-				const uint32_t dv = qlen > clen2 ? qlen - clen2 : clen2 - qlen;
-				if(dv > max_var) continue;
-				const uint32_t d1 = qpos & 1u, d2 = cpos & 1u;
-				if(same_strand && (d1 ^ d2)) continue;
-				const uint32_t off2 = (d1 ^ d2) ? clen - ((cpos >> 1) + clen2) : (cpos >> 1);
-				wtz_zhit_t h; h.o1 = (d1 << 31) | (qpos >> 1); h.o2 = (d2 << 31) | off2; h.ll = (clen2 << 16) | qlen; h.gid = 0;
-				hits[o++] = h;
-			}
+	if(pa == 0) return false;
+	wtz_zhit_t *hits = (wtz_zhit_t*)(uintptr_t)pa;                     /* room for every combination; `total` of them are used */
+	uint32_t *fs = (uint32_t*)(hits + (nflat + 2)), *fq = fs + (nflat + 1);
+	WTZ_WAVE_SYNC();                                                  /* kcnt[] / found[] of the neighbouring lanes */
+	for(uint32_t s0 = 0; s0 < ns; s0 += WTZ_NLANES){
+		const uint32_t si = s0 + lane;
+		if(si < ns){
+			const uint32_t o = kcnt[si], e1 = (si + 1 < ns) ? kcnt[si + 1] : nflat, first = found[si];
+			for(uint32_t e = o; e < e1; e++){ fs[e] = si; fq[e] = first + (e - o); }
 		}
-		base += chunk;
+	}
+	WTZ_WAVE_SYNC();
+	uint32_t total = 0;
+	for(uint32_t t0 = 0; t0 < nflat; t0 += 4 * WTZ_NLANES){
+		uint32_t kq[4], qi[4], qpos[4], qlen[4], cpos[4], clen2[4]; bool in[4];
+		#pragma unroll
+		for(int u = 0; u < 4; u++){ const uint32_t t = t0 + u * WTZ_NLANES + lane; in[u] = t < nflat; kq[u] = in[u] ? surv[fs[t]] : 0u; qi[u] = in[u] ? ZQ.sidx[qo + fq[t]] : 0u; }
+		#pragma unroll
+		for(int u = 0; u < 4; u++){
+			qpos[u] = in[u] ? ZQ.pos[qo + qi[u]] : 0u; qlen[u] = in[u] ? ZQ.len[qo + qi[u]] : 0u;
+			cpos[u] = in[u] ? ZC.pos[co + kq[u]] : 0u; clen2[u] = in[u] ? ZC.len[co + kq[u]] : 0u;
+		}
+		#pragma unroll
+		for(int u = 0; u < 4; u++){
+			const uint32_t dv = qlen[u] > clen2[u] ? qlen[u] - clen2[u] : clen2[u] - qlen[u];
+			const uint32_t d1 = qpos[u] & 1u, d2 = cpos[u] & 1u;
+			const bool keep = in[u] && dv <= max_var && !(same_strand && (d1 ^ d2));      /* |len1 - len2| <= -l (hzm_aln.h:214); align_hzmaux keeps strand 0 only (hzm_aln.h:1193) */
+			uint32_t tot; const uint32_t pos = wtz_coop_rank(keep, &tot);
+			if(keep){
+				const uint32_t off2 = (d1 ^ d2) ? clen - ((cpos[u] >> 1) + clen2[u]) : (cpos[u] >> 1);
+				wtz_zhit_t h; h.o1 = (d1 << 31) | (qpos[u] >> 1); h.o2 = (d2 << 31) | off2; h.ll = (clen2[u] << 16) | qlen[u]; h.gid = 0;
+				hits[total + pos] = h;
+			}
+			total += tot;
+		}
 	}
 	if(lane == 0){ wtz_zhit_t z0; z0.o1 = z0.o2 = z0.ll = z0.gid = 0; hits[total] = z0; hits[total + 1] = z0; }   /* the element the reference reads past the end */
 	*out = hits; *n_out = total;
@@ -434,7 +487,7 @@ WTZ_HD uint32_t wtz_scan_windows_coop(const wtz_zhit_t *rs, uint32_t dir, uint32
 			n += tot;
 		}
 		if(pass) break;
-		if(n * zsize < zovl) return 0;
+		if(n * zsize < zovl){ WTZ_PROF_ADD(12, pw0); WTZ_PROF_CNT(7, 1); return 0; }      /* profiler: 12 = time in scans that end before the ordering, 7 = how many */
 #ifndef WTZ_NO_SCAN_PRECHECK
 		/* ---- exact early exit (round 3): can the sweep of hzm_aln.h:451-483 reach `ol >= zovl` at all?  In off2 order the running overlap is
 		 * ol = sum of len2 over the in-window matches j..i minus the overlaps of neighbours (a match adds len2 minus its overlap with the one
@@ -475,7 +528,7 @@ WTZ_HD uint32_t wtz_scan_windows_coop(const wtz_zhit_t *rs, uint32_t dir, uint32
 				for(uint32_t b = lane; b + nadj <= nb; b += WTZ_NLANES){ uint32_t v = 0; for(uint32_t t = 0; t < nadj; t++) v += B[b + t]; best = v > best ? v : best; }
 				best = ~wtz_coop_min32(~best);
 				WTZ_WAVE_SYNC();                                  /* K is written again by the second pass */
-				if(best < zovl){ WTZ_PROF_CNT(23, 0); return 0; }
+				if(best < zovl){ WTZ_PROF_CNT(23, 0); WTZ_PROF_ADD(12, pw0); WTZ_PROF_CNT(7, 1); return 0; }
 			}
 		}
 #endif
