@@ -170,6 +170,21 @@ WTZ_D uint64_t wtz_wave_sort64(uint64_t v){
 	}
 	return v;
 }
+/* the same network over one u32 key per lane (half the cross-lane traffic of the 64-bit form) */
+WTZ_D uint32_t wtz_wave_sort32(uint32_t v){
+	const uint32_t lane = WTZ_LANE;
+	#pragma unroll
+	for(uint32_t k = 2; k <= 64; k <<= 1){
+		#pragma unroll
+		for(uint32_t j = k >> 1; j > 0; j >>= 1){
+			const uint32_t o = (uint32_t)__shfl_xor((int)v, (int)j, 64);
+			const bool take_min = (((lane & k) == 0) == ((lane & j) == 0));
+			const uint32_t mn = v < o ? v : o, mx = v < o ? o : v;
+			v = take_min ? mn : mx;
+		}
+	}
+	return v;
+}
 /* minimum over all lanes, uniform */
 WTZ_D uint32_t wtz_coop_min32(uint32_t v){
 	for(int d = 32; d > 0; d >>= 1){ const uint32_t y = (uint32_t)__shfl_xor((int)v, d, 64); v = y < v ? y : v; }

@@ -172,6 +172,7 @@ WTZ_HD void wtz_denoise_dir(wtz_zhit_t *rs, uint32_t n_rs, uint32_t dir, wtz_dms
 #define WTZ_DM_BCAP_BIG_AT 49152u
 #endif
 #define WTZ_DM_BCAP(lds_bytes) ((lds_bytes) >= WTZ_DM_BCAP_BIG_AT ? 2048u : ((lds_bytes) >= 24576u ? 1024u : 512u))      /* members of one diagonal band the LDS list holds */
+#define WTZ_DM_BCAP_MIN 512u
 #define WTZ_DM_GCAP 255u      /* linear groups of one strand (one byte per match) */
 struct wtz_gt_blk_off1 { const uint32_t *T; WTZ_HDM bool operator()(uint16_t a, uint16_t b) const { return (T[a] >> 10) > (T[b] >> 10); } };
 struct wtz_gt_hi48 { WTZ_HDM bool operator()(uint64_t a, uint64_t b) const { return (a >> 16) > (b >> 16); } };
@@ -214,58 +215,51 @@ WTZ_HD wtz_dm_counts_t wtz_dm_counts(const wtz_zhit_t *rs, uint32_t n_rs){
 	}
 	return c;
 }
-/* LDS bytes of the strand image of wtz_denoise_dir_coop */
+/* Strand image of wtz_denoise_dir_coop (round-4 layout).  Per match 4 B (off1 << 10 | len1) + the group id (1 B; 2 B in the `big` form); per distinct
+ * diagonal 2 B (first match) + 2 B (matches the band loop takes) + 4 B (offset).  The OFFSETS are only read while the band list is made, the group ids and
+ * the band work arrays only afterwards - so the offsets overlay those two (ids are zeroed once the list stands): 8 B per match + 4 B per diagonal instead of
+ * 5 + 8, i.e. at nd ~ nf a 24 KB slice holds strands of ~2 000 matches instead of ~1 500.  gw = bytes of a group id. */
+typedef struct { uint32_t off_fo, off_mc, off_g, off_w, total; } wtz_dm_layout_t;
+WTZ_HD wtz_dm_layout_t wtz_dm_layout(uint32_t nf, uint32_t nd, uint32_t gw, uint32_t wrk_bytes){
+	wtz_dm_layout_t L;
+	L.off_fo = 4u * (nf + 2u);
+	L.off_mc = L.off_fo + 2u * (nd + 2u);
+	L.off_g = (L.off_mc + 2u * (nd + 2u) + 3u) & ~3u;
+	L.off_w = (L.off_g + gw * (nf + 4u) + 7u) & ~7u;
+	const uint32_t dend = L.off_g + 4u * (nd + 2u);              /* end of the offsets, which start where the group ids start */
+	L.total = L.off_w + wrk_bytes > dend ? L.off_w + wrk_bytes : dend;
+	return L;
+}
+/* LDS bytes of the strand image + work arrays in the ordinary form (one-byte group ids) */
 WTZ_HD uint32_t wtz_denoise_lds_need(uint32_t nf, uint32_t nd, uint32_t lds_bytes){
-	const uint32_t fixed = 8u * WTZ_DM_BCAP(lds_bytes) + 2u * WTZ_DM_GCAP + 40u;
-	return ((5u * (nf + 4u) + 7u) & ~7u) + 8u * (nd + 2u) + fixed;
+	(void)lds_bytes;
+	return wtz_dm_layout(nf, nd, 1u, 8u * WTZ_DM_BCAP_MIN + 2u * WTZ_DM_GCAP + 40u).total;      /* with the smallest band list; a strand takes the largest that fits */
 }
 
-/* `big` (the last launch only): group ids of two bytes (up to WTZ_DM_GCAP_BIG linear groups instead of 255) and, when the per-match /
- * per-diagonal image still does not fit the slice next to the band work arrays, the image in the pool (the lane-0 loops then run
- * against L2 instead of LDS - several times slower than the LDS form, tens of times faster than the scalar body, which pays ~10
- * dependent HBM loads per match).  Returns 0 when done, else why not: 1 image too large, 2 band list overflow, 3 group table
- * overflow, 4 not applicable; nothing the caller sees has changed then. */
 #define WTZ_DM_GCAP_BIG 8191u
-WTZ_HD int wtz_denoise_dir_coop(const wtz_zhit_t *rs, uint32_t n_rs, uint32_t dir, uint32_t nf, uint32_t nd, wtz_dmscratch_t &S, int32_t xvar, int32_t yvar, int32_t min_linear_len,
-		uint8_t *lds, uint32_t lds_bytes, wtz_pool_t *pool, int32_t *bad, bool big = false){
+/* Everything of wtz_denoise_dir_coop behind the layout decision, compiled twice: IMG_LDS = the strand image is in the wave's LDS slice (the usual case),
+ * else in the pool.  One body with `img = fits ? lds : pool` left every access to the image a FLAT instruction - the address space of a selected pointer is
+ * unknown - i.e. 39 G flat loads / stores per configs[2] dmo step, each through the texture-address path although nine strands in ten hit LDS (round-4 PMC
+ * pass: 76 % of K_pair_dm's wave cycles waiting, the same 5.2 s with six or eight waves per CU).  With the pointer's origin a compile-time fact the LDS
+ * form uses ds_read / ds_write. */
+template<bool IMG_LDS>
+WTZ_HD int wtz_denoise_dir_body(const wtz_zhit_t *rs, uint32_t n_rs, uint32_t dir, uint32_t nf, uint32_t nd, wtz_dmscratch_t &S, int32_t xvar, int32_t yvar, int32_t min_linear_len,
+		uint8_t *lds, uint32_t lds_bytes, wtz_pool_t *pool, int32_t *bad, bool big, uint32_t bcap, uint32_t gcap, const wtz_dm_layout_t LY, uint8_t *img_pool, unsigned long long pd0, unsigned long long pdn){
 	const uint32_t lane = WTZ_LANE;
-	if(lds == NULL || n_rs > 65535u){ WTZ_PROF_CNT(60, 1000000); return 4; }
-	const unsigned long long pd0 = WTZ_PROF_T(); (void)pd0;      /* 10 / 59: wave time / calls of the strands whose image lives in the pool */
-	unsigned long long pdn = WTZ_PROF_T(); (void)pdn;      /* phase profiler: 24 image, 25 band list (lane 0), 26 productivity filter, 27 productive bands, 28 grouped order, 29 seeds (lane 0); 30 bands, 31 productive bands, 11 grouped matches */
-	/* image: per match 4 B (off1<<10 | len1) + 1 B (group id; 2 B when big); per distinct diagonal 4 B (offset) + 2 B (first match) +
-	 * 2 B (band members).  Work arrays: band keys / member lists and the group table.  The rs index of a match is only needed by the
-	 * parallel passes: it lives in the pool. */
-	const uint32_t bcap = big ? 2048u : WTZ_DM_BCAP(lds_bytes);
-	uint32_t gcap = WTZ_DM_GCAP;
-	if(big){      /* the group table takes what the slice leaves beside the band arrays */
-		if(lds_bytes < 8u * bcap + 40u + 2u * 512u) return 1;
-		gcap = (lds_bytes - 8u * bcap - 40u) / 2u;
-		if(gcap > WTZ_DM_GCAP_BIG) gcap = WTZ_DM_GCAP_BIG;
-	}
-	const uint32_t off_d = ((big ? 6u : 5u) * (nf + 4u) + 7u) & ~7u;
-	const uint32_t img_bytes = off_d + 8u * (nd + 2u), wrk_bytes = 8u * bcap + 2u * gcap + 40u;
-	uint8_t *img = lds, *wrk = lds + img_bytes;
-	if(!big){ if(wtz_denoise_lds_need(nf, nd, lds_bytes) > lds_bytes){ WTZ_PROF_CNT(61, 1000000); return 1; } }
-	else if(wrk_bytes > lds_bytes) return 1;
-	else if(img_bytes + wrk_bytes > lds_bytes){
-		uint64_t ia = 0;
-		if(lane == 0) ia = (uint64_t)(uintptr_t)wtz_pool_alloc(pool, (size_t)img_bytes + 16u);
-		ia = wtz_coop_bcast64(ia);
-		if(ia == 0){ *bad = 1; if(lane == 0) S.regs[dir].n = 0; return 0; }
-		img = (uint8_t*)(uintptr_t)ia; wrk = lds;
-	}
+	uint8_t *img = IMG_LDS ? lds : img_pool, *wrk = IMG_LDS ? lds + LY.off_w : lds;
+	(void)lds_bytes; (void)pd0;
 	uint64_t ra = 0;
 	if(lane == 0) ra = (uint64_t)(uintptr_t)wtz_pool_alloc(pool, (size_t)(nf + 2u) * 2u);
 	ra = wtz_coop_bcast64(ra);
 	uint16_t *ridx = (uint16_t*)(uintptr_t)ra;            /* index in rs (pool) */
 	if(ridx == NULL){ *bad = 1; if(lane == 0) S.regs[dir].n = 0; return 0; }
 	uint32_t *T = (uint32_t*)img;
-	uint8_t *gid8 = (uint8_t*)(T + (nf + 2u)); uint16_t *gid16 = (uint16_t*)(T + (nf + 2u));      /* group id of the match */
+	uint8_t *gid8 = img + LY.off_g; uint16_t *gid16 = (uint16_t*)(img + LY.off_g);      /* group id of the match (valid once the band list is made: the offsets lie here until then) */
 #define WTZ_GID(i) (big ? (uint32_t)gid16[i] : (uint32_t)gid8[i])
 #define WTZ_GID_SET(i, v) do { if(big) gid16[i] = (uint16_t)(v); else gid8[i] = (uint8_t)(v); } while(0)
-	int32_t *Doff = (int32_t*)(img + off_d);              /* diagonal offset */
-	uint16_t *Dfo = (uint16_t*)(Doff + (nd + 2u));        /* first match (strand-compacted position) */
-	uint16_t *Dmc = Dfo + (nd + 2u);                      /* matches the band loop takes from it */
+	int32_t *Doff = (int32_t*)(img + LY.off_g);           /* diagonal offset: over the group ids and (LDS image) the band work arrays, dead before either is first written */
+	uint16_t *Dfo = (uint16_t*)(img + LY.off_fo);         /* first match (strand-compacted position) */
+	uint16_t *Dmc = (uint16_t*)(img + LY.off_mc);         /* matches the band loop takes from it */
 	uint32_t *bk = (uint32_t*)(((uintptr_t)wrk + 3u) & ~(uintptr_t)3u);      /* band keys; later run heads */
 	uint16_t *blk = (uint16_t*)(bk + bcap);               /* band members, diagonal order */
 	uint16_t *sblk = blk + bcap;                           /* band members, off1 order */
@@ -298,7 +292,7 @@ WTZ_HD int wtz_denoise_dir_coop(const wtz_zhit_t *rs, uint32_t n_rs, uint32_t di
 				if(keep){ last_dg = dg; have = 1; }
 #endif
 				uint32_t htot; const uint32_t hpos = wtz_coop_rank(head, &htot);
-				if(keep){ T[n + pos] = (ZH_OFF1(hh[u]) << 10) | (ZH_LEN1(hh[u]) & 0x3FFu); WTZ_GID_SET(n + pos, 0); ridx[n + pos] = (uint16_t)idx; }
+				if(keep){ T[n + pos] = (ZH_OFF1(hh[u]) << 10) | (ZH_LEN1(hh[u]) & 0x3FFu); ridx[n + pos] = (uint16_t)idx; }
 				if(head){ Doff[h + hpos] = dg; Dfo[h + hpos] = (uint16_t)(n + pos); }
 				n += tot; h += htot;
 			}
@@ -414,6 +408,8 @@ WTZ_HD int wtz_denoise_dir_coop(const wtz_zhit_t *rs, uint32_t n_rs, uint32_t di
 #endif
 	nbands = wtz_coop_bcast32(nbands);
 	WTZ_WAVE_SYNC();
+	for(uint32_t x = lane; x < nf + 2u; x += WTZ_NLANES) WTZ_GID_SET(x, 0);      /* the offsets are dead: their bytes become the group ids (and the band work arrays) */
+	WTZ_WAVE_SYNC();
 	WTZ_PROF_ADD(25, pdn); pdn = WTZ_PROF_T(); WTZ_PROF_CNT(30, nbands);
 	uint32_t nprod = 0;
 	for(uint32_t b0 = 0; b0 < nbands; b0 += WTZ_NLANES){
@@ -425,16 +421,35 @@ WTZ_HD int wtz_denoise_dir_coop(const wtz_zhit_t *rs, uint32_t n_rs, uint32_t di
 			for(uint32_t i = 0; i < dcnt && nb <= 8u; i++) nb += Dmc[doff + i];
 			if(nb > 8u) keep = true;
 			else if(nb){
-				uint32_t v[8]; uint32_t m = 0;
-				for(uint32_t i = 0; i < dcnt; i++){ const uint32_t fo = Dfo[doff + i], mc = Dmc[doff + i]; for(uint32_t j = 0; j < mc; j++){ const uint32_t t = T[fo + j]; uint32_t q = m++; while(q && (v[q - 1] >> 10) > (t >> 10)){ v[q] = v[q - 1]; q--; } v[q] = t; } }
-				for(uint32_t i = 0; i + 1 < m; i++) if((v[i] >> 10) == (v[i + 1] >> 10)) keep = true;      /* equal off1: order-sensitive, leave it to the exact path */
+				/* the <= 8 members into eight NAMED registers (every index below is a compile-time constant after unrolling: an insertion sort into v[q]
+				 * with a run-time q put the array in scratch memory - this loop was 1.4 of the 10 Tcycles of the pass), ordered by a 19-exchange network;
+				 * members that tie on off1 carry identical words, so comparing whole words orders by off1 */
+				uint32_t v[8]; const uint32_t m = nb;
+				{
+					uint32_t ci = 0, cj = 0;
+					#pragma unroll
+					for(int s2 = 0; s2 < 8; s2++){
+						v[s2] = 0xFFFFFFFFu;
+						if((uint32_t)s2 < nb){ while(cj >= (uint32_t)Dmc[doff + ci]){ ci++; cj = 0; } v[s2] = T[(uint32_t)Dfo[doff + ci] + cj]; cj++; }
+					}
+				}
+#define WTZ_CE(A, B) do { const uint32_t lo_ = v[A] < v[B] ? v[A] : v[B], hi_ = v[A] < v[B] ? v[B] : v[A]; v[A] = lo_; v[B] = hi_; } while(0)
+				WTZ_CE(0, 1); WTZ_CE(2, 3); WTZ_CE(4, 5); WTZ_CE(6, 7); WTZ_CE(0, 2); WTZ_CE(1, 3); WTZ_CE(4, 6); WTZ_CE(5, 7); WTZ_CE(1, 2); WTZ_CE(5, 6);
+				WTZ_CE(0, 4); WTZ_CE(1, 5); WTZ_CE(2, 6); WTZ_CE(3, 7); WTZ_CE(2, 4); WTZ_CE(3, 5); WTZ_CE(1, 2); WTZ_CE(3, 4); WTZ_CE(5, 6);
+#undef WTZ_CE
+				#pragma unroll
+				for(int i = 0; i + 1 < 8; i++) if((uint32_t)(i + 1) < m && (v[i] >> 10) == (v[i + 1] >> 10)) keep = true;      /* equal off1: left to the wave path (conservative: it would be harmless here too) */
 				if(!keep){
 					int32_t p0o = (int32_t)(v[0] >> 10), p0l = (int32_t)(v[0] & 0x3FFu), len = p0l;
-					for(uint32_t i = 1; i <= m; i++){
-						const int32_t po = (i == m) ? WTZ_SEED_OFF_MAX : (int32_t)(v[i] >> 10), pl = (i == m) ? 0 : (int32_t)(v[i] & 0x3FFu);
-						if(po <= p0o + p0l || po <= p0o + p0l + xvar) len += (po + pl) - (p0o + p0l);
-						else { if(len >= min_linear_len) keep = true; len = p0l; }
-						p0o = po; p0l = pl;
+					#pragma unroll
+					for(int i = 1; i <= 8; i++){
+						if((uint32_t)i <= m){
+							const bool end = (uint32_t)i == m;
+							const int32_t po = end ? WTZ_SEED_OFF_MAX : (int32_t)(v[i < 8 ? i : 7] >> 10), pl = end ? 0 : (int32_t)(v[i < 8 ? i : 7] & 0x3FFu);
+							if(po <= p0o + p0l || po <= p0o + p0l + xvar) len += (po + pl) - (p0o + p0l);
+							else { if(len >= min_linear_len) keep = true; len = p0l; }
+							p0o = po; p0l = pl;
+						}
 					}
 				}
 			}
@@ -479,15 +494,15 @@ WTZ_HD int wtz_denoise_dir_coop(const wtz_zhit_t *rs, uint32_t n_rs, uint32_t di
 		 * a third of the whole denoise pass; -DWTZ_DM_EXACT_TIES keeps that form for cross-checking). */
 #if defined(__HIP_DEVICE_COMPILE__)
 		if(nb <= 64u){         /* the usual case (37 members on average at configs[2]): one key per lane, ordered in registers */
-			const uint64_t kv = lane < nb ? (uint64_t)(((T[blk[lane]] >> 10) << 11) | lane) : ~0ull;
-			const uint64_t sv = wtz_wave_sort64(kv);
+			const uint32_t kv = lane < nb ? (((T[blk[lane]] >> 10) << 11) | lane) : 0xFFFFFFFFu;
+			const uint32_t sv = wtz_wave_sort32(kv);
 #ifdef WTZ_DM_EXACT_TIES
-			const uint32_t nx = (uint32_t)__shfl_down((int)(uint32_t)sv, 1, 64);
-			uint32_t any; (void)wtz_coop_rank(lane + 1 < nb && ((uint32_t)sv >> 11) == (nx >> 11), &any);
+			const uint32_t nx = (uint32_t)__shfl_down((int)sv, 1, 64);
+			uint32_t any; (void)wtz_coop_rank(lane + 1 < nb && (sv >> 11) == (nx >> 11), &any);
 			if(any){ if(lane == 0){ wtz_gt_blk_off1 g1; g1.T = T; wtz_sort_exact(blk, (size_t)nb, g1); } WTZ_WAVE_SYNC(); if(lane < nb) sblk[lane] = blk[lane]; }
 			else
 #endif
-			if(lane < nb) sblk[lane] = blk[(uint32_t)sv & 0x7FFu];
+			if(lane < nb) sblk[lane] = blk[sv & 0x7FFu];
 		} else
 #endif
 		{
@@ -725,10 +740,52 @@ WTZ_HD int wtz_denoise_dir_coop(const wtz_zhit_t *rs, uint32_t n_rs, uint32_t di
 #endif
 	WTZ_WAVE_SYNC();
 	WTZ_PROF_ADD(29, pdn);
-	if(img != lds){ WTZ_PROF_ADD(10, pd0); WTZ_PROF_CNT(59, 1); }
+	if(!IMG_LDS){ WTZ_PROF_ADD(10, pd0); WTZ_PROF_CNT(59, 1); }
 	return 0;
 #undef WTZ_GID
 #undef WTZ_GID_SET
+}
+
+/* `big` (the last launch only): group ids of two bytes (up to WTZ_DM_GCAP_BIG linear groups instead of 255) and, when the per-match /
+ * per-diagonal image still does not fit the slice next to the band work arrays, the image in the pool (the lane-0 loops then run
+ * against L2 instead of LDS - several times slower than the LDS form, tens of times faster than the scalar body, which pays ~10
+ * dependent HBM loads per match).  Returns 0 when done, else why not: 1 image too large, 2 band list overflow, 3 group table
+ * overflow, 4 not applicable; nothing the caller sees has changed then. */
+WTZ_HD int wtz_denoise_dir_coop(const wtz_zhit_t *rs, uint32_t n_rs, uint32_t dir, uint32_t nf, uint32_t nd, wtz_dmscratch_t &S, int32_t xvar, int32_t yvar, int32_t min_linear_len,
+		uint8_t *lds, uint32_t lds_bytes, wtz_pool_t *pool, int32_t *bad, bool big = false){
+	const uint32_t lane = WTZ_LANE;
+	if(lds == NULL || n_rs > 65535u){ WTZ_PROF_CNT(60, 1000000); return 4; }
+	const unsigned long long pd0 = WTZ_PROF_T(); (void)pd0;      /* 10 / 59: wave time / calls of the strands whose image lives in the pool */
+	unsigned long long pdn = WTZ_PROF_T(); (void)pdn;      /* phase profiler: 24 image, 25 band list (lane 0), 26 productivity filter, 27 productive bands, 28 grouped order, 29 seeds (lane 0); 30 bands, 31 productive bands, 11 grouped matches */
+	/* image: per match 4 B (off1<<10 | len1) + 1 B (group id; 2 B when big); per distinct diagonal 4 B (offset) + 2 B (first match) +
+	 * 2 B (band members).  Work arrays: band keys / member lists and the group table.  The rs index of a match is only needed by the
+	 * parallel passes: it lives in the pool. */
+	/* members of one diagonal band the work arrays hold: the largest power of two (<= 2048) that fits beside this strand's image.  With a fixed 512 a
+	 * quarter of the strands of configs[2] (1.8 M of 6.5 M calls: a true overlap puts hundreds of matches into one 64-diagonal band) overflowed it and were
+	 * done again in the `big` form with their image in the pool. */
+	uint32_t bcap = 2048u;
+	if(!big) while(bcap > WTZ_DM_BCAP_MIN && wtz_dm_layout(nf, nd, 1u, 8u * bcap + 2u * WTZ_DM_GCAP + 40u).total > lds_bytes) bcap >>= 1;
+	uint32_t gcap = WTZ_DM_GCAP;
+	if(big){      /* the group table takes what the slice leaves beside the band arrays */
+		if(lds_bytes < 8u * bcap + 40u + 2u * 512u) return 1;
+		gcap = (lds_bytes - 8u * bcap - 40u) / 2u;
+		if(gcap > WTZ_DM_GCAP_BIG) gcap = WTZ_DM_GCAP_BIG;
+	}
+	const uint32_t wrk_bytes = 8u * bcap + 2u * gcap + 40u;
+	const wtz_dm_layout_t LY = wtz_dm_layout(nf, nd, big ? 2u : 1u, wrk_bytes);
+	uint8_t *img = lds;
+	if(!big){ if(LY.total > lds_bytes){ WTZ_PROF_CNT(61, 1000000); return 1; } }
+	else if(wrk_bytes > lds_bytes) return 1;
+	else if(LY.total > lds_bytes){
+		const uint32_t dend = LY.off_g + 4u * (nd + 2u), img_bytes = LY.off_w > dend ? LY.off_w : dend;      /* in the pool the offsets overlay the group ids only */
+		uint64_t ia = 0;
+		if(lane == 0) ia = (uint64_t)(uintptr_t)wtz_pool_alloc(pool, (size_t)img_bytes + 16u);
+		ia = wtz_coop_bcast64(ia);
+		if(ia == 0){ *bad = 1; if(lane == 0) S.regs[dir].n = 0; return 0; }
+		img = (uint8_t*)(uintptr_t)ia;
+	}
+	return (img == lds) ? wtz_denoise_dir_body<true>(rs, n_rs, dir, nf, nd, S, xvar, yvar, min_linear_len, lds, lds_bytes, pool, bad, big, bcap, gcap, LY, img, pd0, pdn)
+	                    : wtz_denoise_dir_body<false>(rs, n_rs, dir, nf, nd, S, xvar, yvar, min_linear_len, lds, lds_bytes, pool, bad, big, bcap, gcap, LY, img, pd0, pdn);
 }
 
 WTZ_HD void wtz_denoise(wtz_zhit_t *rs, uint32_t n_rs, wtz_dmscratch_t &S, int32_t xvar, int32_t yvar, int32_t min_linear_len, bool presorted){

@@ -360,6 +360,7 @@ struct wtz_ctx {
 	uint32_t env_xcd_group = 256;   /* WTZ_XCD_GROUP: consecutive pairs per XCD run in K_pair (0 = identity block -> pair mapping) */
 	int env_ext_mw_cw = 32;      /* WTZ_EXT_MW_CW: K-sw3 jobs with more band columns per lane than this run on four waves whatever their length */
 	int env_ext_split = 0;       /* WTZ_EXT_SPLIT=1: K-sw3 one-wave jobs in two launches by band class (experiment) */
+	int env_heavy_first = -1;    /* WTZ_PAIR_HEAVY_FIRST: the heaviest pairs of a K_pair launch first (-1 = engine default: dmo on, zmo off) */
 	int env_cand_wg = 1;         /* WTZ_CAND_WG=0: the one-wavefront-per-query sorting form of the seed lookup (the form before round 3) */
 	int env_cand_stream = 0;     /* WTZ_CAND_STREAM=1: sort-free candidate accumulation (LDS sketch + survivor table, wtz_seed.h); bit-exact, pays at 25x coverage only: see DESIGN.md */
 	int env_gap_lane = 1;        /* WTZ_GAP_LANE=0: every gap on a wavefront (the form before round 3) */
@@ -478,6 +479,7 @@ extern "C" int wtz_ctx_create(int device, const wtz_params_c *params, uint64_t p
 	c->env_trace = getenv("WTZ_STAGE_TRACE") != NULL;
 	c->env_cand_stream = (getenv("WTZ_CAND_STREAM") && atoi(getenv("WTZ_CAND_STREAM")) != 0);
 	if(getenv("WTZ_CAND_WG")) c->env_cand_wg = atoi(getenv("WTZ_CAND_WG"));
+	if(getenv("WTZ_PAIR_HEAVY_FIRST")) c->env_heavy_first = atoi(getenv("WTZ_PAIR_HEAVY_FIRST"));
 	if(getenv("WTZ_EXT_SPLIT")) c->env_ext_split = atoi(getenv("WTZ_EXT_SPLIT"));
 	if(getenv("WTZ_EXT_MW_CW")) c->env_ext_mw_cw = atoi(getenv("WTZ_EXT_MW_CW"));
 	if(getenv("WTZ_XCD_GROUP")) c->env_xcd_group = (uint32_t)atoi(getenv("WTZ_XCD_GROUP"));
@@ -1192,19 +1194,43 @@ extern "C" int wtz_pairs_seed(wtz_ctx_t *c, const uint32_t *qid, const uint32_t 
 	 * query (about 30 candidates each), all of them searching the same query-side z-mer tables.  With the identity mapping an XCD's ~640 resident
 	 * waves hold every 8th pair of a 5 000-pair stretch, i.e. the tables of ~170 queries (20 MB against 4 MB of L2); giving every XCD runs of
 	 * `xg` CONSECUTIVE pairs makes that ~25 queries.  (WTZ_XCD_GROUP=0: identity.) */
-	const uint32_t xg = c->env_xcd_group; const uint64_t n64 = n;
+	const uint32_t xg = c->env_xcd_group;
+	/* Heavy pairs first (round 4).  A pair's work grows faster than linearly with its matches (~ len(q) * len(c) / 78 732 chance matches of 10-mers alone), and
+	 * once the average dmo pair took a few ms the launch of a range ended with ONE wave still on a pair of 6 000 - 24 000 matches (100 - 230 M cycles of a
+	 * 120 - 170 ms launch: phase profile).  The n / 32 pairs with the largest len(q) * len(c) therefore head the task order (largest first); the others keep
+	 * the plan order - consecutive pairs share their query's tables - under the XCD mapping below.  WTZ_PAIR_HEAVY_FIRST=0 / 1 overrides the engine default
+	 * (dmo on; zmo off: its launches were measured full to the end). */
+	uint32_t nh = 0; const uint32_t *d_ord = NULL;
+#ifndef WTZ_EMUL
+	if(c->env_heavy_first >= 0 ? c->env_heavy_first != 0 : c->P.dot_matrix != 0){
+		nh = n / 32u;
+		if(nh >= 8u){
+			std::vector<uint64_t> key(n); std::vector<uint32_t> ord(n), hv(n);
+			for(uint32_t i = 0; i < n; i++){ key[i] = (uint64_t)c->h_rdlen[qid[i]] * c->h_rdlen[cid[i]]; hv[i] = i; }
+			std::nth_element(hv.begin(), hv.begin() + nh, hv.end(), [&](uint32_t a, uint32_t b){ return key[a] != key[b] ? key[a] > key[b] : a < b; });
+			std::sort(hv.begin(), hv.begin() + nh, [&](uint32_t a, uint32_t b){ return key[a] != key[b] ? key[a] > key[b] : a < b; });
+			std::vector<uint8_t> heavy(n, 0);
+			for(uint32_t k = 0; k < nh; k++){ ord[k] = hv[k]; heavy[hv[k]] = 1; }
+			uint32_t w = nh; for(uint32_t i = 0; i < n; i++) if(!heavy[i]) ord[w++] = i;
+			uint32_t *dd = NULL; CHK(dev_alloc((void**)&dd, (size_t)n * 4)); CHK(dev_h2d(dd, ord.data(), (size_t)n * 4)); d_ord = dd;
+		} else nh = 0;
+	}
+#endif
+	const uint64_t n64 = n - nh; const uint64_t nh64 = nh;
 #ifdef WTZ_EMUL
-	CHK(wtz_launch_coop<K_pair>(0, n, [=] WTZ_LAMBDA (uint64_t b){ (void)xg; (void)n64; wtz_task_pair<-1>((uint32_t)b, V, dq, dc, dr); }, c->P.dot_matrix ? WTZ_PAIR_DM_LDS_BYTES : WTZ_PAIR_LDS_BYTES));
+	CHK(wtz_launch_coop<K_pair>(0, n, [=] WTZ_LAMBDA (uint64_t b){ (void)xg; (void)n64; (void)nh64; (void)d_ord; wtz_task_pair<-1>((uint32_t)b, V, dq, dc, dr); }, c->P.dot_matrix ? WTZ_PAIR_DM_LDS_BYTES : WTZ_PAIR_LDS_BYTES));
 #else
 	if(c->P.dot_matrix){
 		CHK(wtz_launch_coop<K_pair_dm>(0, n, [=] WTZ_LAMBDA (uint64_t b){
 			uint64_t t = b;
-			if(xg){ const uint64_t per = 8ull * xg, full = n64 / per * per; if(b < full){ const uint64_t r = b % per; t = b - r + (r & 7u) * xg + (r >> 3); } }
+			if(b >= nh64){ const uint64_t b2 = b - nh64; t = b2; if(xg){ const uint64_t per = 8ull * xg, full = n64 / per * per; if(b2 < full){ const uint64_t r = b2 % per; t = b2 - r + (r & 7u) * xg + (r >> 3); } } t += nh64; }
+			if(d_ord) t = d_ord[t];
 			wtz_task_pair<1>((uint32_t)t, V, dq, dc, dr); }, WTZ_PAIR_DM_LDS_BYTES));
 	} else {
 		CHK(wtz_launch_coop<K_pair>(0, n, [=] WTZ_LAMBDA (uint64_t b){
 			uint64_t t = b;
-			if(xg){ const uint64_t per = 8ull * xg, full = n64 / per * per; if(b < full){ const uint64_t r = b % per; t = b - r + (r & 7u) * xg + (r >> 3); } }
+			if(b >= nh64){ const uint64_t b2 = b - nh64; t = b2; if(xg){ const uint64_t per = 8ull * xg, full = n64 / per * per; if(b2 < full){ const uint64_t r = b2 % per; t = b2 - r + (r & 7u) * xg + (r >> 3); } } t += nh64; }
+			if(d_ord) t = d_ord[t];
 			wtz_task_pair<0>((uint32_t)t, V, dq, dc, dr); }, WTZ_PAIR_LDS_BYTES));
 	}
 #endif

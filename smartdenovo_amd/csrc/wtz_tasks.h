@@ -31,9 +31,11 @@ typedef struct {
 #define WTZ_PAIR_LDS_BYTES 8192      /* K_pair, zmo: LDS slice of the window scans (measured with WTZ_OCC_PAIR: 16 KB / 1 -> 117 ms, 8 KB / 3 -> 99, 8 KB / 5 -> 90) */
 #endif
 #ifndef WTZ_PAIR_DM_LDS_BYTES
-#define WTZ_PAIR_DM_LDS_BYTES 20480  /* K_pair, dmo: LDS slice of the strand images.  A strand that does not fit keeps its image in the pool (dm_first_big), so the
-                                      * slice only has to hold the band work arrays of that form (17.4 KB); configs[2] step with 18 / 20 / 22 / 24 / 32 KB:
-                                      * 12.19 / 12.17 / 12.82 / 12.69 / 15.32 s (13.9 s when such pairs were left to later launches with 24 KB) */
+#define WTZ_PAIR_DM_LDS_BYTES 24576  /* K_pair, dmo: LDS slice of the strand images (six waves per CU).  A strand that does not fit keeps its image in the pool
+                                      * (dm_first_big) and pays an L2 round trip for everything the LDS form reads from the slice: at 20 KB that was 42 % of the
+                                      * strands of configs[2] and 60 % of the denoise wave time (round-4 phase profile).  Round-4 sweep of the configs[2] dmo step,
+                                      * 20 / 24 / 28 / 32 KB: K_pair_dm 5 735 / 5 220 / 5 423 / 5 462 ms.  (Round 3, when the per-band work dominated both forms alike,
+                                      * measured 18 / 20 / 22 / 24 / 32 KB = 12.19 / 12.17 / 12.82 / 12.69 / 15.32 s and kept 20 KB.) */
 #endif
 /* the LDS slice of the wave running the current task (wave-task kernels carry WTZ_WAVE_LDS_BYTES of dynamic LDS) */
 #if defined(__HIP_DEVICE_COMPILE__)

@@ -8,7 +8,7 @@ cd $R
 python bench.py --no-cpu-baseline --steps 2 --warmup 1 --engine dmo > $O/bench_dmo.json 2> $O/bench_dmo.err; python3 -c "
 import json;d=json.loads(open('$O/bench_dmo.json').read().strip().split('\n')[-1]);print('dmo %.3f s/step %.2f Gbp/s parity %s pairs-kernel %.0f ms'%(d['ms_per_step']/1e3,d['value'],d['parity'],d['kernel_ms_last_step']['pairs']))"
 WTZ_PROFILE_PAIR=1 tools/with_variant.sh prof python bench.py --no-cpu-baseline --steps 1 --warmup 0 --no-verify --engine dmo > $O/slots_dmo.json 2> $O/slots_dmo.err
-grep "phase-profile" $O/slots_dmo.err | grep -v " 2:0.0" | tr ' ' '\n' | grep -E "^(2[4-9]|3[01]|4[6-9]|5[0-8]|11|2|6|62):" | tr '\n' ' '; echo
+grep "phase-profile" $O/slots_dmo.err | grep -v " 2:0.0" | tr ' ' '\n' | grep -E "^(2[4-9]|3[01]|4[6-9]|5[0-9]|10|11|2|6|62):" | tr '\n' ' '; echo
 grep "pair-profile\] n=" $O/slots_dmo.err | python3 -c "
 import sys,re
 S=[0]*4;n=0
