@@ -363,8 +363,9 @@ struct wtz_candcmp_f { WTZ_HDM int operator()(uint64_t a, uint64_t b) const { ui
 
 /* The order-sensitive tail of A3 (wtzmo.c:516-571): strand merge x1/x2 + top-ncand min-heap with its two quirks.
  * groups: (key<<32 | ol) ascending by key. heap: in/out array with room for ncand+1 entries. */
-WTZ_HD void wtz_cand_tail(const uint64_t *groups, uint32_t ng, uint32_t kovl, uint32_t ncand, uint64_t *heap, uint32_t *hn){
-	uint64_t x1 = WTZ_CAND_NONE, x2; uint32_t n = *hn; wtz_candcmp_f cmp;
+/* the same in two pieces, so that a caller can feed the groups in portions (staged through LDS): `n` entries in the heap, `x1` the candidate not yet pushed */
+WTZ_HD void wtz_cand_tail_step(const uint64_t *groups, uint32_t ng, uint32_t kovl, uint32_t ncand, uint64_t *heap, uint32_t &n, uint64_t &x1){
+	uint64_t x2; wtz_candcmp_f cmp;
 	for(uint32_t i = 0; i < ng; i++){
 		uint32_t ol = (uint32_t)groups[i], key = (uint32_t)(groups[i] >> 32);
 		if(ol < kovl) continue;
@@ -377,8 +378,16 @@ WTZ_HD void wtz_cand_tail(const uint64_t *groups, uint32_t ng, uint32_t kovl, ui
 			x1 = x2;
 		}
 	}
+}
+WTZ_HD void wtz_cand_tail_finish(uint32_t ncand, uint64_t *heap, uint32_t &n, uint64_t x1){
+	wtz_candcmp_f cmp;
 	if(n >= ncand){ /* compared against ol == 0: never replaces (wtzmo.c:563-567) */ }
 	else wtz_heap_push(heap, n, x1, cmp);
+}
+WTZ_HD void wtz_cand_tail(const uint64_t *groups, uint32_t ng, uint32_t kovl, uint32_t ncand, uint64_t *heap, uint32_t *hn){
+	uint64_t x1 = WTZ_CAND_NONE; uint32_t n = *hn;
+	wtz_cand_tail_step(groups, ng, kovl, ncand, heap, n, x1);
+	wtz_cand_tail_finish(ncand, heap, n, x1);
 	*hn = n;
 }
 
@@ -906,14 +915,33 @@ WTZ_HD void wtz_task_candidates_wg(uint32_t t, wtz_reads_t R, const uint32_t *qi
 	__threadfence_block();
 #endif
 	WTZ_WG_SYNC();
-	/* ---- F ---- */
-	if(tid == 0){
-		if(gptr){ gptr[t] = (uint64_t)(uintptr_t)grp; ncand_out[t] = ng; }      /* sharded index: the groups go to the caller, who joins the shards (wtz_cand_tail_host) */
-		else {
-			uint32_t hn = ncand_out[t];                 /* heap carried across index parts (-G), 0 otherwise */
-			wtz_cand_tail(grp, ng, kovl, P->ncand, cand_out + (size_t)t * stride, &hn);
-			ncand_out[t] = hn;
+	/* ---- F: strand merge + candidate heap (wtzmo.c:516-571), one thread by definition.  Round 4: the heap (<= -A + 1 entries) and the groups it consumes
+	 * sit in LDS - every sift level on a heap in the pool was a dependent L2 round trip, and with -A 1000 (the dmo pipeline) most groups are pushed: the seed
+	 * lookup of a configs[2] dmo step took 460 ms against 87 ms with -A 500.  The sort / partition arrays are dead here. ---- */
+	if(gptr){ if(tid == 0){ gptr[t] = (uint64_t)(uintptr_t)grp; ncand_out[t] = ng; } }      /* sharded index: the groups go to the caller, who joins the shards (wtz_cand_tail_host) */
+	else if(P->ncand + 1u <= WTZ_CWG_CAP){
+		uint64_t *hp = sbuf, *gb = (uint64_t*)ends;             /* WTZ_CWG_CAP words each */
+		uint64_t *row = cand_out + (size_t)t * stride;
+		const uint32_t hn0 = ncand_out[t];                      /* heap carried across index parts (-G), 0 otherwise */
+		for(uint32_t i = tid; i < hn0; i += nt) hp[i] = row[i];
+		uint64_t x1 = WTZ_CAND_NONE; uint32_t n = hn0;          /* live on thread 0 */
+		for(uint32_t c0 = 0; c0 < ng; c0 += WTZ_CWG_CAP){
+			const uint32_t m = ng - c0 < WTZ_CWG_CAP ? ng - c0 : WTZ_CWG_CAP;
+			WTZ_WG_SYNC();
+			for(uint32_t i = tid; i < m; i += nt) gb[i] = grp[c0 + i];
+			WTZ_WG_SYNC();
+			if(tid == 0) wtz_cand_tail_step(gb, m, kovl, P->ncand, hp, n, x1);
 		}
+		WTZ_WG_SYNC();
+		if(tid == 0){ wtz_cand_tail_finish(P->ncand, hp, n, x1); tmp[0] = n; }
+		WTZ_WG_SYNC();
+		n = tmp[0];
+		for(uint32_t i = tid; i < n; i += nt) row[i] = hp[i];
+		if(tid == 0) ncand_out[t] = n;
+	} else if(tid == 0){
+		uint32_t hn = ncand_out[t];
+		wtz_cand_tail(grp, ng, kovl, P->ncand, cand_out + (size_t)t * stride, &hn);
+		ncand_out[t] = hn;
 	}
 }
 

@@ -204,22 +204,13 @@ struct wtz_gt_idx_off2 { const wtz_zhit_t *rs; WTZ_HDM bool operator()(uint32_t 
  * sequential sort instead.  Returns the sorted copy (with the two zeroed sentinels) or NULL (tie / too large / pool).
  */
 template<int SH> struct wtz_gt_keybits { WTZ_HDM bool operator()(uint64_t a, uint64_t b) const { return (a >> SH) > (b >> SH); } };
-template<int BYDIAG>
-WTZ_D wtz_zhit_t *wtz_sort_hits_wave(const wtz_zhit_t *hits, uint32_t n, wtz_pool_t *pool, uint64_t *lds, uint32_t lds_u64, int *pool_bad){
+/* the part of wtz_sort_hits_wave behind the choice of where the key words live, compiled for either answer: with `w = fits ? lds : pool` in one body every
+ * access to the keys was a FLAT instruction (see wtz_denoise_dir_body) */
+template<int BYDIAG, bool W_LDS>
+WTZ_D wtz_zhit_t *wtz_sort_hits_body(const wtz_zhit_t *hits, uint32_t n, wtz_pool_t *pool, uint64_t *lds, uint32_t lds_u64, uint64_t *w_pool, uint32_t np, int *pool_bad){
 	const uint32_t lane = WTZ_LANE;
-	*pool_bad = 0;
-	if(n < 2 || n > (BYDIAG ? 32767u : 65535u)) return NULL;
 	const int SH = BYDIAG ? 15 : 16;             /* index bits below the key */
-	uint32_t np = 64; while(np < n) np <<= 1;
-	uint64_t *w;
-	if(lds && np <= lds_u64) w = lds;
-	else {
-		uint64_t a = 0;
-		if(lane == 0) a = (uint64_t)(uintptr_t)wtz_pool_alloc(pool, (size_t)np * 8);
-		a = wtz_coop_bcast64(a);
-		w = (uint64_t*)(uintptr_t)a;
-		if(w == NULL){ *pool_bad = 1; return NULL; }
-	}
+	uint64_t *w = W_LDS ? lds : w_pool;
 	for(uint32_t i = lane; i < np; i += 64){
 		uint64_t v = ~0ull;
 		if(i < n){
@@ -229,7 +220,7 @@ WTZ_D wtz_zhit_t *wtz_sort_hits_wave(const wtz_zhit_t *hits, uint32_t n, wtz_poo
 		w[i] = v;
 	}
 	__threadfence_block();
-	if(w == lds) wtz_coop_sort_u64(w, np);
+	if(W_LDS) wtz_coop_sort_u64(w, np);
 	else {       /* key words in HBM: sort through the LDS window (largest power of two that fits) */
 		uint32_t ln = 128; while(lds && ln * 2 <= lds_u64) ln <<= 1;
 		wtz_coop_sort_u64_windowed(w, np, lds, lds ? ln : 0);
@@ -248,7 +239,7 @@ WTZ_D wtz_zhit_t *wtz_sort_hits_wave(const wtz_zhit_t *hits, uint32_t n, wtz_poo
 		/* an observable tie: the reference's swap sequence decides.  When the key words sit in LDS, lane 0 replays it there
 		 * on (key | index) words from the ORIGINAL order - the comparator looks at the key bits only, so the swaps are those of
 		 * sorting the matches themselves - instead of chasing 16-byte records through HBM */
-		if(w != lds) return NULL;
+		if(!W_LDS) return NULL;
 		for(uint32_t i = lane; i < n; i += 64){
 			uint64_t v;
 			if(BYDIAG) v = ((uint64_t)((int64_t)ZH_OFF1(hits[i]) - (int64_t)ZH_OFF2(hits[i]) + (1 << 24)) << 39) | ((uint64_t)ZH_OFF1(hits[i]) << 15) | i;
@@ -268,6 +259,24 @@ WTZ_D wtz_zhit_t *wtz_sort_hits_wave(const wtz_zhit_t *hits, uint32_t n, wtz_poo
 	if(lane == 0){ wtz_zhit_t z0; z0.o1 = z0.o2 = z0.ll = z0.gid = 0; out[n] = z0; out[n + 1] = z0; }
 	__threadfence_block();
 	return out;
+}
+template<int BYDIAG>
+WTZ_D wtz_zhit_t *wtz_sort_hits_wave(const wtz_zhit_t *hits, uint32_t n, wtz_pool_t *pool, uint64_t *lds, uint32_t lds_u64, int *pool_bad){
+	const uint32_t lane = WTZ_LANE;
+	*pool_bad = 0;
+	if(n < 2 || n > (BYDIAG ? 32767u : 65535u)) return NULL;
+	const int SH = BYDIAG ? 15 : 16;             /* index bits below the key */
+	uint32_t np = 64; while(np < n) np <<= 1;
+	uint64_t *w;
+	if(lds && np <= lds_u64) w = lds;
+	else {
+		uint64_t a = 0;
+		if(lane == 0) a = (uint64_t)(uintptr_t)wtz_pool_alloc(pool, (size_t)np * 8);
+		a = wtz_coop_bcast64(a);
+		w = (uint64_t*)(uintptr_t)a;
+		if(w == NULL){ *pool_bad = 1; return NULL; }
+	}
+	return (w == lds) ? wtz_sort_hits_body<BYDIAG, true>(hits, n, pool, lds, lds_u64, w, np, pool_bad) : wtz_sort_hits_body<BYDIAG, false>(hits, n, pool, lds, lds_u64, w, np, pool_bad);
 }
 #endif
 
