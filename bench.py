@@ -353,7 +353,7 @@ def main():
     # condensed by tools/summarize_profiles.py into profiles/ (FETCH_SIZE doubled as the gfx950 guide says).  `traffic` is per LAUNCH like
     # `achieved` (total / dispatches), `traffic_per_step` the total next to the per-step algorithmic bytes.  A PMC pass cannot run inside a timed
     # bench run, so the numbers come from the newest committed summary of this workload / engine; its sidecar (<csv>.meta.json, written by
-    # tools/gpu_round_measure.sh) names the kernel sources it was measured on, and the line says whether they are the sources of THIS build.
+    # tools/gpu_r04_final.sh) names the kernel sources it was measured on, and the line says whether they are the sources of THIS build.
     import csv
     import glob
     cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_%s_%s_pmc_per_kernel.csv" % (a.workload, a.engine))))
