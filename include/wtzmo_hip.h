@@ -226,6 +226,12 @@ typedef struct {
 } wtz_dp_result_t;
 int  wtz_test_dp(wtz_ctx_t *ctx, int32_t kind, int32_t form, const wtz_dp_problem_t *problems, uint32_t n, wtz_dp_result_t *out, uint32_t *cigar, uint64_t cigar_cap);
 
+/* f2: kswx_extend_align (kswx.h:469-481 = kswx_extend_align_shift_core kswx.h:101-232, W as the caller passes it) for n independent problems on
+ * views of the uploaded reads - what wtext's worker calls twice per overlap (wtext.c:250, 268) after it clipped the overlap's CIGAR to the retained regions.
+ * The jobs go through the same dispatch as the end extensions of wtzmo's stitched alignments.  out[i] = the kswx_t of the call (score, qe, te, aln, mat, mis, ins, del;
+ * an empty side returns the start score clamped at 0, like kswx.h:113-118) and cigar_off / cigar_len of its operations (len << 4 | op, first operation first) in `cigar`. */
+int  wtz_extend_batch(wtz_ctx_t *ctx, const wtz_dp_problem_t *problems, uint32_t n, wtz_dp_result_t *out, uint32_t *cigar, uint64_t cigar_cap);
+
 /* Scratch accounting, so that the caller can size its batches to the pool instead of discovering the limit by WTZ_E_POOL:
  * the context's scratch is cut into a main pool (everything that lives for the batch: match lists, windows, CIGARs) and a transient
  * pool (K-sw3 trace matrices; the library sizes its own launch groups to it).  main_used = bytes of the main pool in use after the

@@ -1103,8 +1103,10 @@ static void process_batch_serial(eng_t *E, batch_t *b, uint32_t s0){
  * ask for and the output cannot change - a few more speculative pairs are computed.  The finished range's result arrays are swapped into
  * the batch's spare set (cparts) so that the next range can fill `parts`.  A range that overflows the scratch pool is redone by the serial
  * path (halving), then the pipeline starts again behind it. */
-typedef struct { eng_t *E; batch_t *b; int again; double t0, t1; pthread_t th; int running; } gpujob_t;
-static void *gpujob_main(void *arg){ gpujob_t *j = (gpujob_t*)arg; j->t0 = now_s(); j->again = gpu_stages(j->E, j->b); j->t1 = now_s(); return NULL; }
+typedef struct { eng_t *E; batch_t *b; int again; double t0, t1; pthread_t th; int running; char err[256]; } gpujob_t;
+static void *gpujob_main(void *arg){ gpujob_t *j = (gpujob_t*)arg; j->t0 = now_s(); j->again = gpu_stages(j->E, j->b); j->t1 = now_s();
+	if(j->again) snprintf(j->err, sizeof j->err, "%s", wtz_last_error());      /* wtz_last_error is thread-local: the text is this helper thread's */
+	return NULL; }
 static void gpujob_start(gpujob_t *j, eng_t *E, batch_t *b){ j->E = E; j->b = b; j->again = 0; if(pthread_create(&j->th, NULL, gpujob_main, j) != 0){ fprintf(stderr, " -- cannot start the device-stage thread --\n"); DIE_NOW(); } j->running = 1; }
 static int gpujob_wait(gpujob_t *j){ if(j->running){ pthread_join(j->th, NULL); j->running = 0; } return j->again; }
 #define SWAP_FIELD(T, a, b) do { T t_ = (a); (a) = (b); (b) = t_; } while(0)
@@ -1122,7 +1124,7 @@ static void process_batch(eng_t *E, batch_t *b){
 			/* scratch pool exhausted: nothing of [s0, s1) is committed and nothing else is in flight: the serial path splits it */
 			b->cparts = b->parts;
 			pthread_mutex_lock(&E->mu); E->n_split++; E->bytes_per_pair = (E->bytes_per_pair > 0 ? E->bytes_per_pair : 1048576.0) * 2.0; pthread_mutex_unlock(&E->mu);
-			if(s1 - s0 <= 1){ fprintf(stderr, " -- device scratch pool too small even for one query: %s (use --pool-gb) --\n", wtz_last_error()); DIE_NOW(); }
+			if(s1 - s0 <= 1){ fprintf(stderr, " -- device scratch pool too small even for one query: %s (use --pool-gb) --\n", job.err); DIE_NOW(); }
 			fprintf(stderr, "[wtzmo-mi355x] scratch pool exhausted with %u queries in flight; splitting the batch\n", s1 - s0);
 			const uint32_t mid = s0 + (s1 - s0) / 2;
 			process_range(E, b, s0, mid); process_range(E, b, mid, s1);

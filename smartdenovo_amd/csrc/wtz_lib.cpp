@@ -621,15 +621,19 @@ extern "C" int wtz_upload_reads_ascii(wtz_ctx_t *c, const char *seq, uint64_t n_
 	dev_free_persist(c->bits); dev_free_persist(c->rdoff); dev_free_persist(c->rdlen); c->bits = NULL; c->rdoff = NULL; c->rdlen = NULL;
 	free_kindex(c); free_zindex(c); free_batch(c);
 	const uint64_t n_words = (n_bases + 31) / 32;
-	CHK(dev_alloc_persist((void**)&c->bits, (n_words + 2) * 8)); CHK(dev_set(c->bits, 0, (n_words + 2) * 8));
-	CHK(dev_alloc_persist((void**)&c->rdoff, (size_t)n_reads * 8)); CHK(dev_h2d(c->rdoff, rdoff, (size_t)n_reads * 8));
-	CHK(dev_alloc_persist((void**)&c->rdlen, (size_t)n_reads * 4)); CHK(dev_h2d(c->rdlen, rdlen, (size_t)n_reads * 4));
-	c->n_words = n_words; c->n_reads = n_reads; c->h_rdlen.assign(rdlen, rdlen + n_reads);
+	c->n_words = 0; c->n_reads = 0; c->h_rdlen.clear();        /* "no reads uploaded" until the last chunk is packed: a failure below leaves the context in that state, not over a half-packed bank */
 	const uint64_t CH = (uint64_t)256 << 20;             /* bases per chunk (a multiple of 32): 256 MB of text on the device at a time */
 	uint8_t *d_txt = NULL; unsigned long long *d_np = NULL; uint64_t *d_pos = NULL; uint64_t pos_cap = (uint64_t)1 << 20;
-	CHK(dev_alloc_persist((void**)&d_txt, (size_t)WTZ_MIN(CH, n_bases) + 64)); CHK(dev_alloc_persist((void**)&d_np, 16)); CHK(dev_alloc_persist((void**)&d_pos, pos_cap * 8));
-	uint64_t rank = rand_calls_before;
 	int rc = WTZ_OK;
+	if((rc = dev_alloc_persist((void**)&c->bits, (n_words + 2) * 8)) || (rc = dev_set(c->bits, 0, (n_words + 2) * 8)) ||
+	   (rc = dev_alloc_persist((void**)&c->rdoff, (size_t)n_reads * 8)) || (rc = dev_h2d(c->rdoff, rdoff, (size_t)n_reads * 8)) ||
+	   (rc = dev_alloc_persist((void**)&c->rdlen, (size_t)n_reads * 4)) || (rc = dev_h2d(c->rdlen, rdlen, (size_t)n_reads * 4)) ||
+	   (rc = dev_alloc_persist((void**)&d_txt, (size_t)WTZ_MIN(CH, n_bases) + 64)) || (rc = dev_alloc_persist((void**)&d_np, 16)) || (rc = dev_alloc_persist((void**)&d_pos, pos_cap * 8))){
+		dev_free_persist(d_txt); dev_free_persist(d_np); dev_free_persist(d_pos);
+		dev_free_persist(c->bits); dev_free_persist(c->rdoff); dev_free_persist(c->rdlen); c->bits = NULL; c->rdoff = NULL; c->rdlen = NULL;
+		return rc;
+	}
+	uint64_t rank = rand_calls_before;
 #ifndef WTZ_EMUL
 	/* an empty launch first: the first kernel launch of a process loads the library's code object (several ms), which is not this kernel's time */
 	hipLaunchKernelGGL(wtz_kernel_pack_ascii, dim3(1), dim3(256), 0, g_stream, (const uint8_t*)d_txt, (uint64_t)0, (uint64_t)0, (uint32_t*)c->bits, d_np, d_pos, pos_cap, (uint64_t)0);
@@ -673,7 +677,8 @@ extern "C" int wtz_upload_reads_ascii(wtz_ctx_t *c, const char *seq, uint64_t n_
 		}
 	}
 	dev_free_persist(d_txt); dev_free_persist(d_np); dev_free_persist(d_pos);
-	if(rc != WTZ_OK) return rc;
+	if(rc != WTZ_OK){ dev_free_persist(c->bits); dev_free_persist(c->rdoff); dev_free_persist(c->rdlen); c->bits = NULL; c->rdoff = NULL; c->rdlen = NULL; return rc; }
+	c->n_words = n_words; c->n_reads = n_reads; c->h_rdlen.assign(rdlen, rdlen + n_reads);
 	c->cnt.bytes_ingest_algo += n_bases + n_words * 8;
 	if(n_random) *n_random = rank - rand_calls_before;
 	return WTZ_OK;
@@ -1833,6 +1838,75 @@ extern "C" int wtz_cigar_text_device(wtz_ctx_t *c, uint64_t n_bytes, void **dev_
 	char *d_t = NULL;
 	CHK(render_cigar_text(c, n_bytes, &d_t));
 	*dev_ptr = d_t;
+	return WTZ_OK;
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* f2: end extensions for a caller that holds its own overlaps (wtext)                                */
+/* ------------------------------------------------------------------------------------------------ */
+/* kswx_extend_align (kswx.h:469-481) = kswx_extend_align_shift_core (kswx.h:101-232) for n independent problems on views of the uploaded reads: the SAME job
+ * dispatch as the ends of wtzmo's stitched alignments (run_extjobs: register DP on one or four wavefronts per job, LDS-ring and scalar forms for what is
+ * outside their envelope).  out[i]: the kswx_t of the call + where its CIGAR words (traceback order reversed: first operation first) start in `cigar`. */
+struct K_extcopy;
+extern "C" int wtz_extend_batch(wtz_ctx_t *c, const wtz_dp_problem_t *pr, uint32_t n, wtz_dp_result_t *out, uint32_t *cigar, uint64_t cigar_cap){
+	if(!c || !c->bits) return wtz_fail(WTZ_E_ARG, "reads not uploaded");
+	if(n == 0) return WTZ_OK;
+	if(!pr || !out || (!cigar && cigar_cap)) return wtz_fail(WTZ_E_ARG, "null argument");
+	CTX_ENTER(c);
+	CHK(pool_reset(c));
+	std::vector<uint64_t> h_off(c->n_reads);
+	CHK(dev_d2h(h_off.data(), c->rdoff, (size_t)c->n_reads * 8));
+	std::vector<wtz_extjob_t> jobs(n);
+	for(uint32_t i = 0; i < n; i++){
+		const wtz_dp_problem_t &p = pr[i];
+		if(p.q_read >= c->n_reads || p.t_read >= c->n_reads) return wtz_fail(WTZ_E_ARG, "problem %u: read id out of range", i);
+		if((p.q_strand != 1 && p.q_strand != -1) || (p.t_strand != 1 && p.t_strand != -1)) return wtz_fail(WTZ_E_ARG, "problem %u: strand must be +1 or -1", i);
+		wtz_readview vq, vt;
+		vq.bits = c->bits; vq.off = h_off[p.q_read]; vq.len = c->h_rdlen[p.q_read]; vq.rev = p.q_rev ? 1u : 0u;
+		vt.bits = c->bits; vt.off = h_off[p.t_read]; vt.len = c->h_rdlen[p.t_read]; vt.rev = p.t_rev ? 1u : 0u;
+		const int64_t qlast = (int64_t)p.q_from + (int64_t)p.q_strand * (p.q_len > 0 ? p.q_len - 1 : 0), tlast = (int64_t)p.t_from + (int64_t)p.t_strand * (p.t_len > 0 ? p.t_len - 1 : 0);
+		if(p.q_len < 0 || p.t_len < 0 || (p.q_len > 0 && (p.q_from < 0 || p.q_from >= (int64_t)vq.len || qlast < 0 || qlast >= (int64_t)vq.len))
+				|| (p.t_len > 0 && (p.t_from < 0 || p.t_from >= (int64_t)vt.len || tlast < 0 || tlast >= (int64_t)vt.len)))
+			return wtz_fail(WTZ_E_ARG, "problem %u: region outside its read", i);
+		wtz_extjob_t j; memset(&j, 0, sizeof j);
+		j.q = vq.sub(p.q_from, p.q_strand); j.t = vt.sub(p.t_from, p.t_strand); j.qlen = p.q_len; j.tlen = p.t_len; j.init_score = p.init_score; j.W = p.W; j.item = i; j.valid = 1;
+		jobs[i] = j;
+	}
+	const wtz_env_t V = ctx_env(c);
+	wtz_extjob_t *d_jobs = NULL; CHK(dev_alloc((void**)&d_jobs, (size_t)n * sizeof(wtz_extjob_t))); CHK(dev_h2d(d_jobs, jobs.data(), (size_t)n * sizeof(wtz_extjob_t)));
+	wtz_timer tm; tm.start();
+	CHK(run_extjobs(c, V, d_jobs, n));
+	CHK(dev_sync());
+	c->cnt.ms_stitch += tm.stop();
+	CHK(tpool_check(c, "wtz_extend_batch"));
+	CHK(dev_d2h(jobs.data(), d_jobs, (size_t)n * sizeof(wtz_extjob_t)));
+	std::vector<uint64_t> off((size_t)n + 1); uint64_t tot = 0;
+	for(uint32_t i = 0; i < n; i++){
+		if(jobs[i].bad) return wtz_fail(WTZ_E_POOL, "wtz_extend_batch: problem %u ran out of scratch", i);
+		const bool empty = jobs[i].qlen <= 0 || jobs[i].tlen <= 0;
+		off[i] = tot; tot += empty ? 0 : jobs[i].cigar_len;
+		c->cnt.cells_shift += jobs[i].cells;
+	}
+	off[n] = tot;
+	if(tot > cigar_cap) return wtz_fail(WTZ_E_ARG, "wtz_extend_batch: CIGAR buffer too small (%llu words needed)", (unsigned long long)tot);
+	if(tot){
+		uint64_t *d_off = NULL; uint32_t *d_flat = NULL;
+		CHK(dev_alloc((void**)&d_off, ((size_t)n + 1) * 8)); CHK(dev_h2d(d_off, off.data(), ((size_t)n + 1) * 8));
+		CHK(dev_alloc((void**)&d_flat, (size_t)tot * 4));
+		CHK(wtz_launch<K_extcopy>(0, n, [=] WTZ_LAMBDA (uint64_t t){ const uint64_t o = d_off[t], e = d_off[t + 1]; const uint32_t *src = d_jobs[t].cigar; for(uint64_t k = o; k < e; k++) d_flat[k] = src[k - o]; }));
+		CHK(dev_sync());
+		CHK(dev_d2h(cigar, d_flat, (size_t)tot * 4));
+	}
+	for(uint32_t i = 0; i < n; i++){
+		wtz_dp_result_t o; memset(&o, 0, sizeof o);
+		const wtz_extjob_t &j = jobs[i];
+		const bool empty = j.qlen <= 0 || j.tlen <= 0;
+		if(empty){ o.score = j.init_score < 0 ? 0 : j.init_score; }      /* kswx.h:113-118: an empty side returns the (clamped) start score and no operations */
+		else { o.score = j.x.score; o.tb = j.x.tb; o.te = j.x.te; o.qb = j.x.qb; o.qe = j.x.qe; o.aln = j.x.aln; o.mat = j.x.mat; o.mis = j.x.mis; o.ins = j.x.ins; o.del = j.x.del; o.cigar_len = j.cigar_len; }
+		o.cigar_off = off[i]; o.cells = j.cells; o.form_used = j.done ? j.done : 3;
+		out[i] = o;
+	}
+	CHK(pool_check(c, "wtz_extend_batch"));
 	return WTZ_OK;
 }
 
