@@ -20,6 +20,7 @@
 #define WTEXT_CORE_H
 
 #include <getopt.h>
+#include <pthread.h>
 #include <time.h>
 #include <unistd.h>
 #include "wtz_host.h"
@@ -59,6 +60,7 @@ typedef struct {
 	wx_job_t *jobs; wx_jobres_t *res; size_t njob, capjob;
 	uint32_t *cigar_pool; uint64_t ncig, capcig;
 	FILE *out; unsigned long long n_in, n_out, n_ext;
+	double t_read, t_clip, t_ext, t_write;      /* host seconds: reading + splitting the lines, clip + re-score, the two extension sweeps, record assembly */
 	void *backend;
 } wx_t;
 
@@ -264,12 +266,35 @@ static size_t wx_cigar_text(char *o, const uint32_t *cg, uint32_t n, int reverse
 	return k;
 }
 
+static double wx_now(void){ struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
+/* the clipping of a hit reads the shared read set and writes its own hit: `-t` threads take contiguous slices (nothing observable depends on it) */
+typedef struct { wx_t *W; size_t lo, hi; pthread_t th; int started; } wx_clipjob_t;
+static void *wx_clip_main(void *arg){
+	wx_clipjob_t *j = (wx_clipjob_t*)arg;
+	uint32_t *tmp = NULL, captmp = 0;
+	for(size_t i = j->lo; i < j->hi; i++) wx_clip_hit(j->W, &j->W->hits[i], &tmp, &captmp);
+	free(tmp);
+	return NULL;
+}
+static void wx_clip_all(wx_t *W){
+	int nt = W->O.ncpu; if(nt > 64) nt = 64;
+	if(nt < 2 || W->nhit < 256){ wx_clipjob_t j; memset(&j, 0, sizeof j); j.W = W; j.hi = W->nhit; wx_clip_main(&j); return; }
+	wx_clipjob_t *js = (wx_clipjob_t*)hx_realloc(NULL, sizeof(wx_clipjob_t) * (size_t)nt);
+	for(int t = 0; t < nt; t++){
+		js[t].W = W; js[t].lo = W->nhit * (size_t)t / (size_t)nt; js[t].hi = W->nhit * (size_t)(t + 1) / (size_t)nt;
+		js[t].started = (pthread_create(&js[t].th, NULL, wx_clip_main, &js[t]) == 0);
+		if(!js[t].started) wx_clip_main(&js[t]);
+	}
+	for(int t = 0; t < nt; t++) if(js[t].started) pthread_join(js[t].th, NULL);
+	free(js);
+}
+
 /* the hits of the block: clip, left extensions, right extensions, records in input order */
 static void wx_process_block(wx_t *W){
 	const wx_opt_t *o = &W->O;
-	uint32_t *tmp = NULL, captmp = 0;
-	for(size_t i = 0; i < W->nhit; i++) wx_clip_hit(W, &W->hits[i], &tmp, &captmp);
-	free(tmp);
+	double t0 = wx_now();
+	wx_clip_all(W);
+	W->t_clip += wx_now() - t0; t0 = wx_now();
 	for(int side = 0; side < 2; side++){
 		W->njob = 0; W->ncig = 0;
 		for(size_t i = 0; i < W->nhit; i++){
@@ -296,6 +321,7 @@ static void wx_process_block(wx_t *W){
 			else { h->jr = r->cig_len; h->core = (uint32_t*)hx_realloc(h->core, 4 * ((size_t)h->ncore + r->cig_len + 1)); memcpy(h->core + h->ncore, W->cigar_pool + r->cig_off, 4 * (size_t)r->cig_len); }
 		}
 	}
+	W->t_ext += wx_now() - t0; t0 = wx_now();
 	/* output_alignments_wtext, wtext.c:323-340 */
 	size_t capbuf = 1 << 16; char *buf = (char*)hx_realloc(NULL, capbuf);
 	const hx_read_t *R = W->st.reads;
@@ -320,6 +346,7 @@ static void wx_process_block(wx_t *W){
 	}
 	free(buf);
 	W->nhit = 0;
+	W->t_write += wx_now() - t0;
 }
 
 static int wx_run(wx_t *W){
@@ -332,6 +359,7 @@ static int wx_run(wx_t *W){
 	fprintf(stderr, "[%s] extending the overlaps\n", wx_date());
 	char **col = (char**)hx_realloc(NULL, sizeof(char*) * 24);
 	unsigned long long nb = 0; int eof = 0;
+	double t_rd = wx_now();
 	while(!eof){
 		const int mine = ((int)(nb++ % (unsigned long long)(o->n_job > 0 ? o->n_job : 1)) == o->i_job);       /* wtext.c:489: decided per batch of 100 LINES */
 		for(int i = 0; i < 100; i++){
@@ -354,10 +382,12 @@ static int wx_run(wx_t *W){
 			if(W->nhit == W->caphit){ W->caphit = W->caphit ? W->caphit * 2 : 4096; W->hits = (wx_hit_t*)hx_realloc(W->hits, sizeof(wx_hit_t) * W->caphit); }
 			W->hits[W->nhit++] = h; W->n_in++;
 		}
-		if(W->nhit >= o->block || (eof && W->nhit)) wx_process_block(W);
+		if(W->nhit >= o->block || (eof && W->nhit)){ W->t_read += wx_now() - t_rd; wx_process_block(W); t_rd = wx_now(); }
 	}
+	W->t_read += wx_now() - t_rd;
 	hx_reader_close(fr);
 	fprintf(stderr, "[%s] %llu overlaps read, %llu end extensions, %llu records written\n", wx_date(), W->n_in, W->n_ext, W->n_out);
+	fprintf(stderr, "[wtext] host seconds: lines %.2f, clip + re-score %.2f (%d thread%s), extension sweeps %.2f, records %.2f\n", W->t_read, W->t_clip, o->ncpu > 1 ? (o->ncpu > 64 ? 64 : o->ncpu) : 1, o->ncpu > 1 ? "s" : "", W->t_ext, W->t_write);
 	if(W->out != stdout) fclose(W->out); else fflush(stdout);
 	free(col);
 	return 0;
