@@ -555,6 +555,7 @@ WTZ_HD uint32_t wtz_scan_windows_coop(const wtz_zhit_t *rs, uint32_t dir, uint32
 	WTZ_PROF_ADD(16, pw0); WTZ_PROF_CNT(21, 1); WTZ_PROF_CNT(22, n);
 	const unsigned long long pw1 = WTZ_PROF_T(); (void)pw1;
 	uint32_t np = 64; while(np < n) np <<= 1;
+	bool had_tie = false; (void)had_tie;
 #if defined(__HIP_DEVICE_COMPILE__)
 	bool in_regs = false;
 	if(n <= 64u){
@@ -564,7 +565,7 @@ WTZ_HD uint32_t wtz_scan_windows_coop(const wtz_zhit_t *rs, uint32_t dir, uint32
 		const uint32_t nhi = (uint32_t)__shfl_down((int)(uint32_t)(v >> 32), 1, 64);
 		const bool tie = lane + 1 < n && (uint32_t)(v >> 32) == nhi;
 		uint32_t any; (void)wtz_coop_rank(tie, &any);
-		if(any){ if(lane == 0) wtz_sort_exact(K, (size_t)n, wtz_gt_hi32()); }      /* off2 ties: the reference's swap sequence decides (hzm_aln.h:449) */
+		if(any){ const unsigned long long px = WTZ_PROF_T(); (void)px; if(lane == 0) wtz_sort_exact(K, (size_t)n, wtz_gt_hi32()); WTZ_PROF_ADD(25, px); WTZ_PROF_CNT(24, 1); had_tie = true; }      /* off2 ties: the reference's swap sequence decides (hzm_aln.h:449) */
 		else if(lane < n) K[lane] = v;
 		WTZ_WAVE_SYNC();
 		in_regs = true;
@@ -590,7 +591,7 @@ WTZ_HD uint32_t wtz_scan_windows_coop(const wtz_zhit_t *rs, uint32_t dir, uint32
 				m += tot;
 			}
 			WTZ_WAVE_SYNC();
-			if(lane == 0) wtz_sort_exact(K, (size_t)n, wtz_gt_hi32());
+			{ const unsigned long long px = WTZ_PROF_T(); (void)px; if(lane == 0) wtz_sort_exact(K, (size_t)n, wtz_gt_hi32()); WTZ_PROF_ADD(25, px); WTZ_PROF_CNT(24, 1); had_tie = true; }
 			WTZ_WAVE_SYNC();
 		}
 	}
@@ -631,6 +632,9 @@ WTZ_HD uint32_t wtz_scan_windows_coop(const wtz_zhit_t *rs, uint32_t dir, uint32
 		WTZ_PROF_ADD(19, pw3); pw4 = WTZ_PROF_T(); WTZ_PROF_CNT(23, n2);
 #endif
 		n2_all = n2;
+#ifdef WTZ_PROFILE
+		if(had_tie){ uint32_t cut = 0; for(uint32_t wq = 0; wq < n2; wq++){ const uint32_t we = sc.we[wq]; if(we + 1 < n && ZH_OFF2(S[we + 1]) == ZH_OFF2(S[we])) cut = 1; } WTZ_PROF_CNT(28, cut); }
+#endif
 	}
 	/* ---- the windows (hzm_aln.h:484-575).  Lane 0 walks them; the one step the whole wave takes is the ordering of a window's members by off1
 	 * (hzm_aln.h:519): distinct keys have ONE ascending order, so the wave-wide bitonic network gives it; equal off1 (one query z-mer matched at two
@@ -664,12 +668,12 @@ WTZ_HD uint32_t wtz_scan_windows_coop(const wtz_zhit_t *rs, uint32_t dir, uint32
 			const uint32_t nhi = (uint32_t)__shfl_down((int)(uint32_t)(v >> 32), 1, 64);
 			const bool tie = lane + 1 < cnt && (uint32_t)(v >> 32) == nhi;
 			uint32_t any; (void)wtz_coop_rank(tie, &any);
-			if(any){ if(lane == 0) wtz_sort_exact(ak, (size_t)cnt, wtz_gt_hi32()); }
+			if(any){ const unsigned long long px = WTZ_PROF_T(); (void)px; if(lane == 0) wtz_sort_exact(ak, (size_t)cnt, wtz_gt_hi32()); WTZ_PROF_ADD(27, px); WTZ_PROF_CNT(26, 1); if(had_tie) WTZ_PROF_CNT(30, 1); }
 			else if(lane < cnt) ak[lane] = v;
 			WTZ_WAVE_SYNC();
 		} else
 #endif
-		{ if(lane == 0) wtz_sort_exact(ak, (size_t)cnt, wtz_gt_hi32()); WTZ_WAVE_SYNC(); }
+		{ const unsigned long long px = WTZ_PROF_T(); (void)px; if(lane == 0) wtz_sort_exact(ak, (size_t)cnt, wtz_gt_hi32()); WTZ_PROF_ADD(31, px); WTZ_PROF_CNT(29, 1); WTZ_WAVE_SYNC(); }
 		uint32_t stop = 0;
 		if(lane == 0){ do {
 			uint32_t ol, lst;
