@@ -289,6 +289,50 @@ static void wx_clip_all(wx_t *W){
 	free(js);
 }
 
+/* output_alignments_wtext, wtext.c:323-340: the records of a slice of hits as text; `-t` threads each take a contiguous slice, the slices are written in order */
+typedef struct { wx_t *W; size_t lo, hi; char *buf; size_t n, cap; unsigned long long n_out; pthread_t th; int started; } wx_fmtjob_t;
+static void *wx_fmt_main(void *arg){
+	wx_fmtjob_t *f = (wx_fmtjob_t*)arg; wx_t *W = f->W;
+	const hx_read_t *R = W->st.reads;
+	for(size_t i = f->lo; i < f->hi; i++){
+		wx_hit_t *h = &W->hits[i];
+		if(h->alive && h->x0.aln > 0){
+			const uint32_t nl = h->need_l ? h->jl : 0, nr = h->need_r ? h->jr : 0;
+			const size_t need = strlen(R[h->pb1].name) + strlen(R[h->pb2].name) + 256 + 12 * ((size_t)nl + h->ncore + nr);
+			if(f->n + need > f->cap){ f->cap = (f->n + need) * 2; f->buf = (char*)hx_realloc(f->buf, f->cap); }
+			char *buf = f->buf + f->n; size_t k = 0;
+			k += (size_t)sprintf(buf + k, "%s\t%c\t%d\t%d\t%d", R[h->pb1].name, "+-"[h->dir1], (int)W->clp_len[h->pb1], h->x0.tb, h->x0.te);
+			k += (size_t)sprintf(buf + k, "\t%s\t%c\t%d\t%d\t%d", R[h->pb2].name, "+-"[h->dir2], (int)W->clp_len[h->pb2], h->x0.qb, h->x0.qe);
+			k += (size_t)sprintf(buf + k, "\t%d\t%0.3f\t%d\t%d\t%d\t%d\t", h->x0.score, 1.0 * h->x0.mat / h->x0.aln, h->x0.mat, h->x0.mis, h->x0.ins, h->x0.del);
+			if(nl) k += wx_cigar_text(buf + k, (const uint32_t*)h->cigar_in, nl, 1);
+			k += wx_cigar_text(buf + k, h->core, h->ncore, 0);
+			if(nr) k += wx_cigar_text(buf + k, h->core + h->ncore, nr, 0);
+			buf[k++] = '\n';
+			f->n += k; f->n_out++;
+		}
+		free(h->cigar_in); free(h->core); h->cigar_in = NULL; h->core = NULL;
+	}
+	return NULL;
+}
+static void wx_write_records(wx_t *W){
+	const double t0 = wx_now();
+	int nt = W->O.ncpu; if(nt > 64) nt = 64; if(nt < 1 || W->nhit < 256) nt = 1;
+	wx_fmtjob_t *fs = (wx_fmtjob_t*)calloc((size_t)nt, sizeof(wx_fmtjob_t));
+	for(int t = 0; t < nt; t++){
+		fs[t].W = W; fs[t].lo = W->nhit * (size_t)t / (size_t)nt; fs[t].hi = W->nhit * (size_t)(t + 1) / (size_t)nt;
+		if(nt > 1) fs[t].started = (pthread_create(&fs[t].th, NULL, wx_fmt_main, &fs[t]) == 0);
+		if(!fs[t].started) wx_fmt_main(&fs[t]);
+	}
+	for(int t = 0; t < nt; t++){
+		if(fs[t].started) pthread_join(fs[t].th, NULL);
+		if(fs[t].n) fwrite(fs[t].buf, 1, fs[t].n, W->out);
+		W->n_out += fs[t].n_out; free(fs[t].buf);
+	}
+	free(fs);
+	W->nhit = 0;
+	W->t_write += wx_now() - t0;
+}
+
 /* the hits of the block: clip, left extensions, right extensions, records in input order */
 static void wx_process_block(wx_t *W){
 	const wx_opt_t *o = &W->O;
@@ -322,32 +366,9 @@ static void wx_process_block(wx_t *W){
 		}
 	}
 	W->t_ext += wx_now() - t0; t0 = wx_now();
-	/* output_alignments_wtext, wtext.c:323-340 */
-	size_t capbuf = 1 << 16; char *buf = (char*)hx_realloc(NULL, capbuf);
-	const hx_read_t *R = W->st.reads;
-	for(size_t i = 0; i < W->nhit; i++){
-		wx_hit_t *h = &W->hits[i];
-		if(h->alive && h->x0.aln > 0){
-			const uint32_t nl = h->need_l ? h->jl : 0, nr = h->need_r ? h->jr : 0;
-			const size_t need = strlen(R[h->pb1].name) + strlen(R[h->pb2].name) + 256 + 12 * ((size_t)nl + h->ncore + nr);
-			if(need > capbuf){ capbuf = need * 2; buf = (char*)hx_realloc(buf, capbuf); }
-			size_t k = 0;
-			k += (size_t)sprintf(buf + k, "%s\t%c\t%d\t%d\t%d", R[h->pb1].name, "+-"[h->dir1], (int)W->clp_len[h->pb1], h->x0.tb, h->x0.te);
-			k += (size_t)sprintf(buf + k, "\t%s\t%c\t%d\t%d\t%d", R[h->pb2].name, "+-"[h->dir2], (int)W->clp_len[h->pb2], h->x0.qb, h->x0.qe);
-			k += (size_t)sprintf(buf + k, "\t%d\t%0.3f\t%d\t%d\t%d\t%d\t", h->x0.score, 1.0 * h->x0.mat / h->x0.aln, h->x0.mat, h->x0.mis, h->x0.ins, h->x0.del);
-			if(nl) k += wx_cigar_text(buf + k, (const uint32_t*)h->cigar_in, nl, 1);
-			k += wx_cigar_text(buf + k, h->core, h->ncore, 0);
-			if(nr) k += wx_cigar_text(buf + k, h->core + h->ncore, nr, 0);
-			buf[k++] = '\n';
-			fwrite(buf, 1, k, W->out);
-			W->n_out++;
-		}
-		free(h->cigar_in); free(h->core); h->cigar_in = NULL; h->core = NULL;
-	}
-	free(buf);
-	W->nhit = 0;
-	W->t_write += wx_now() - t0;
+	wx_write_records(W);
 }
+static void *wx_block_main(void *arg){ wx_process_block((wx_t*)arg); return NULL; }
 
 static int wx_run(wx_t *W){
 	wx_opt_t *o = &W->O;
@@ -360,6 +381,9 @@ static int wx_run(wx_t *W){
 	char **col = (char**)hx_realloc(NULL, sizeof(char*) * 24);
 	unsigned long long nb = 0; int eof = 0;
 	double t_rd = wx_now();
+	/* the lines of the next block are read and split while the previous block is clipped, extended and written (a worker thread; `-t 1` keeps one thread) */
+	wx_hit_t *rh = NULL; size_t rn = 0, rcap = 0;
+	pthread_t worker; int worker_on = 0;
 	while(!eof){
 		const int mine = ((int)(nb++ % (unsigned long long)(o->n_job > 0 ? o->n_job : 1)) == o->i_job);       /* wtext.c:489: decided per batch of 100 LINES */
 		for(int i = 0; i < 100; i++){
@@ -379,15 +403,24 @@ static int wx_run(wx_t *W){
 			const int unprev2 = h.dir2 ? (int)W->pblen[id] - (int)(W->prev_off[id] + W->prev_len[id]) : (int)W->prev_off[id];
 			h.qb = atoi(col[8]) + unprev2; h.qe = atoi(col[9]) + unprev2;
 			h.cigar_in = strdup(col[16]);
-			if(W->nhit == W->caphit){ W->caphit = W->caphit ? W->caphit * 2 : 4096; W->hits = (wx_hit_t*)hx_realloc(W->hits, sizeof(wx_hit_t) * W->caphit); }
-			W->hits[W->nhit++] = h; W->n_in++;
+			if(rn == rcap){ rcap = rcap ? rcap * 2 : 4096; rh = (wx_hit_t*)hx_realloc(rh, sizeof(wx_hit_t) * rcap); }
+			rh[rn++] = h; W->n_in++;
 		}
-		if(W->nhit >= o->block || (eof && W->nhit)){ W->t_read += wx_now() - t_rd; wx_process_block(W); t_rd = wx_now(); }
+		if(rn >= o->block || (eof && rn)){
+			W->t_read += wx_now() - t_rd;
+			if(worker_on){ pthread_join(worker, NULL); worker_on = 0; }
+			{ wx_hit_t *th = W->hits; const size_t tc = W->caphit; W->hits = rh; W->nhit = rn; W->caphit = rcap; rh = th; rcap = tc; rn = 0; }
+			if(o->ncpu > 1 && !eof) worker_on = (pthread_create(&worker, NULL, wx_block_main, W) == 0);
+			if(!worker_on) wx_process_block(W);
+			t_rd = wx_now();
+		}
 	}
+	if(worker_on) pthread_join(worker, NULL);
+	free(rh);
 	W->t_read += wx_now() - t_rd;
 	hx_reader_close(fr);
 	fprintf(stderr, "[%s] %llu overlaps read, %llu end extensions, %llu records written\n", wx_date(), W->n_in, W->n_ext, W->n_out);
-	fprintf(stderr, "[wtext] host seconds: lines %.2f, clip + re-score %.2f (%d thread%s), extension sweeps %.2f, records %.2f\n", W->t_read, W->t_clip, o->ncpu > 1 ? (o->ncpu > 64 ? 64 : o->ncpu) : 1, o->ncpu > 1 ? "s" : "", W->t_ext, W->t_write);
+	fprintf(stderr, "[wtext] host seconds (with -t > 1 the lines of a block are read beside the work on the block before): lines %.2f, clip + re-score %.2f (%d thread%s), extension sweeps %.2f, records %.2f\n", W->t_read, W->t_clip, o->ncpu > 1 ? (o->ncpu > 64 ? 64 : o->ncpu) : 1, o->ncpu > 1 ? "s" : "", W->t_ext, W->t_write);
 	if(W->out != stdout) fclose(W->out); else fflush(stdout);
 	free(col);
 	return 0;

@@ -190,6 +190,16 @@ WTZ_D uint32_t wtz_coop_min32(uint32_t v){
 	for(int d = 32; d > 0; d >>= 1){ const uint32_t y = (uint32_t)__shfl_xor((int)v, d, 64); v = y < v ? y : v; }
 	return v;
 }
+/* inclusive running maximum over the lanes */
+WTZ_D uint32_t wtz_coop_incl_max32(uint32_t v){
+	const uint32_t lane = WTZ_LANE;
+	#pragma unroll
+	for(int d = 1; d < 64; d <<= 1){ const uint32_t y = (uint32_t)__shfl_up((int)v, d, 64); if(lane >= (uint32_t)d) v = y > v ? y : v; }
+	return v;
+}
+WTZ_D unsigned long long wtz_coop_ballot(bool p){ return __ballot(p); }
+/* value of lane `src` (any lane per lane) */
+WTZ_D uint32_t wtz_coop_shfl32(uint32_t v, uint32_t src){ return (uint32_t)__shfl((int)v, (int)src, 64); }
 /* value of lane `l` (l uniform) */
 WTZ_D uint32_t wtz_coop_lane32(uint32_t v, uint32_t l){ return (uint32_t)__builtin_amdgcn_readlane((int)v, __builtin_amdgcn_readfirstlane((int)l)); }
 #define WTZ_WAVE_SYNC() __threadfence_block()
@@ -209,6 +219,9 @@ WTZ_COOP_HOST uint32_t wtz_coop_bcast32(uint32_t v){ return v; }
 WTZ_COOP_HOST uint32_t wtz_coop_rank(bool keep, uint32_t *total){ *total = keep ? 1u : 0u; return 0; }
 WTZ_COOP_HOST uint32_t wtz_coop_lane32(uint32_t v, uint32_t){ return v; }
 WTZ_COOP_HOST uint32_t wtz_coop_min32(uint32_t v){ return v; }
+WTZ_COOP_HOST uint32_t wtz_coop_incl_max32(uint32_t v){ return v; }
+WTZ_COOP_HOST unsigned long long wtz_coop_ballot(bool p){ return p ? 1ull : 0ull; }
+WTZ_COOP_HOST uint32_t wtz_coop_shfl32(uint32_t v, uint32_t){ return v; }
 #define WTZ_WAVE_SYNC() do {} while(0)
 #endif
 

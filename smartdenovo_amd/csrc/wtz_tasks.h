@@ -246,6 +246,56 @@ WTZ_HD void wtz_cigar_reverse_coop(uint32_t *a, uint32_t n){
 	for(uint32_t i = WTZ_LANE; i < n / 2; i += WTZ_NLANES){ const uint32_t t = a[i]; a[i] = a[n - 1 - i]; a[n - 1 - i] = t; }
 	WTZ_WAVE_SYNC();
 }
+/* Several operation lists appended to `c` at once (what a sequence of wtz_cigar_concat_coop calls gives, kswx.h:46-52): a list whose first operation equals the last
+ * operation before it loses that element to its predecessor, every other element is copied.  One pass over the descriptors (where each list goes, whether it merges)
+ * instead of a dependent load + reserve + copy + fence per list: a stitched overlap is 2 x windows lists of a few dozen operations each.
+ * piece(p, &src, &n, &rev) describes list p of np (src may be read back to front: the left extension's list).  `lds` holds 6 words per list. */
+template<typename PF>
+WTZ_HD bool wtz_cigar_join_coop(wtz_cigar_t &c, uint32_t np, PF piece, uint32_t *lds, uint32_t lds_words){
+	if((uint64_t)np * 6u > lds_words) return false;
+	const uint32_t lane = WTZ_LANE;
+	uint32_t *LB = lds, *LN = lds + np, *LF = lds + 2 * np, *LW = lds + 3 * np; uint64_t *LS = (uint64_t*)(lds + 4 * np);      /* 4 np is even: 8-byte aligned */
+	uint32_t carry_valid = c.n ? 1u : 0u, carry_last = c.n ? c.a[c.n - 1] : 0u, total = 0;
+	for(uint32_t p0 = 0; p0 < np; p0 += WTZ_NLANES){
+		const uint32_t p = p0 + lane;
+		const uint32_t *src = NULL; uint32_t n = 0, rev = 0, fw = 0, lw = 0;
+		if(p < np){ piece(p, &src, &n, &rev); if(n){ fw = rev ? src[n - 1] : src[0]; lw = rev ? src[0] : src[n - 1]; } }
+		const unsigned long long mask = wtz_coop_ballot(n != 0);
+		const unsigned long long below = mask & ((1ull << lane) - 1ull);
+		const uint32_t from = below ? 63u - (uint32_t)__builtin_clzll(below) : 0u;
+		const uint32_t plw = wtz_coop_shfl32(lw, from);
+		const uint32_t prev = below ? plw : carry_last; const bool prev_ok = below ? true : (carry_valid != 0);
+		const uint32_t merged = (n && prev_ok && (fw & 0xFu) == (prev & 0xFu)) ? 1u : 0u;
+		uint32_t tot; const uint32_t ex = wtz_coop_excl_scan(n - merged, &tot);
+		if(p < np){ LB[p] = total + ex; LN[p] = n; LF[p] = merged | (rev << 1); LW[p] = fw; LS[p] = (uint64_t)(uintptr_t)src; }
+		if(mask){ const uint32_t top = 63u - (uint32_t)__builtin_clzll(mask); carry_last = wtz_coop_lane32(lw, top); carry_valid = 1; }
+		total += tot;
+	}
+	WTZ_WAVE_SYNC();
+	const uint32_t n0 = c.n;
+	if(!wtz_cigar_reserve_coop(c, n0 + total)) return true;          /* c.bad is set */
+	uint32_t *dst = c.a + n0;
+	for(uint32_t e = lane; e < total; e += WTZ_NLANES){
+		uint32_t lo = 0, hi = np - 1;                                     /* the last list whose first output position is <= e */
+		while(lo < hi){ const uint32_t mid = (lo + hi + 1) >> 1; if(LB[mid] <= e) lo = mid; else hi = mid - 1; }
+		const uint32_t fl = LF[lo], n = LN[lo], k = e - LB[lo] + (fl & 1u);
+		const uint32_t *src = (const uint32_t*)(uintptr_t)LS[lo];
+		dst[e] = (fl & 2u) ? src[n - 1 - k] : src[k];
+	}
+	WTZ_WAVE_SYNC();
+	for(uint32_t p = lane; p < np; p += WTZ_NLANES) if(LF[p] & 1u){
+		const uint32_t add = LW[p] & 0xFFFFFFF0u;                         /* lists of one element can pile up on the same predecessor */
+		uint32_t *w = dst + LB[p]; w--;                                   /* the element in front of the list's first output position (c's old last element for position 0) */
+#if defined(__HIP_DEVICE_COMPILE__)
+		atomicAdd(w, add);
+#else
+		*w += add;
+#endif
+	}
+	c.n = n0 + total;
+	WTZ_WAVE_SYNC();
+	return true;
+}
 WTZ_HD uint32_t wtz_cigar_text_len_coop(const uint32_t *c, uint32_t n){
 	uint32_t tot = 0;
 	for(uint32_t i0 = 0; i0 < n; i0 += WTZ_NLANES){
@@ -955,22 +1005,45 @@ WTZ_HD void wtz_task_stitch_mid(uint32_t t, const wtz_env_t &V, const wtz_alnite
 		x.score = y.score - 100 * M;
 		x.aln += y.aln; x.mat += y.mat; x.mis += y.mis; x.ins += y.ins; x.del += y.del;
 		x.qb -= y.qe; x.tb -= y.te;
-		if(jl.cigar_len){ wtz_cigar_reverse_coop(jl.cigar, jl.cigar_len); wtz_cigar_concat_coop(st.cigar, jl.cigar, jl.cigar_len); }
 	}
-	wtz_cigar_concat_coop(st.cigar, it.regs[st.first].cigar, it.regs[st.first].cigar_len);
-	for(uint32_t k = st.first + 1; k < it.nwin; k++){
-		if(it.regs[k].pass != 1) continue;
-		const wtz_reg_t *reg2 = &it.regs[k];
+	/* the operation lists in order: left extension (back to front), first window, then gap + window for every later window that passed */
+	const uint32_t first = st.first, nwr = it.nwin - first - 1;
+	const wtz_reg_t *regs = it.regs;
+	const uint32_t *lc = jobsL[t].valid ? jobsL[t].cigar : NULL; const uint32_t ln = jobsL[t].valid ? jobsL[t].cigar_len : 0u;
+#if defined(__HIP_DEVICE_COMPILE__)
+	uint32_t *jlds = (uint32_t*)wtz_wave_scratch(); const uint32_t jwords = WTZ_WAVE_LDS_BYTES / 4;
+#else
+	std::vector<uint64_t> jbuf(3 * (size_t)(2u + 2u * nwr) + 1); uint32_t *jlds = (uint32_t*)jbuf.data(); const uint32_t jwords = (uint32_t)(jbuf.size() * 2);
+#endif
+#ifdef WTZ_NO_CIGAR_JOIN
+	const bool joined = false; (void)jlds; (void)jwords; (void)lc;
+#else
+	const bool joined = wtz_cigar_join_coop(st.cigar, 2u + 2u * nwr, [=](uint32_t p, const uint32_t **src, uint32_t *n, uint32_t *rev){
+		*rev = 0;
+		if(p == 0){ *src = lc; *n = ln; *rev = 1; return; }
+		if(p == 1){ *src = regs[first].cigar; *n = regs[first].cigar_len; return; }
+		const uint32_t k = first + 1 + ((p - 2) >> 1);
+		if(regs[k].pass != 1){ *src = NULL; *n = 0; return; }
+		if(p & 1u){ *src = regs[k].cigar; *n = regs[k].cigar_len; } else { *src = gp[k].cigar; *n = gp[k].cigar_len; }
+	}, jlds, jwords);
+#endif
+	if(!joined){
+		if(ln){ wtz_cigar_reverse_coop(jobsL[t].cigar, ln); wtz_cigar_concat_coop(st.cigar, jobsL[t].cigar, ln); }
+		wtz_cigar_concat_coop(st.cigar, regs[first].cigar, regs[first].cigar_len);
+	}
+	for(uint32_t k = first + 1; k < it.nwin; k++){
+		if(regs[k].pass != 1) continue;
+		const wtz_reg_t *reg2 = &regs[k];
 		const wtz_gapres_t &g = gp[k];
 		if(!g.valid || g.bad) st.bad = 1;
 		st.cells_global += g.cells;
 		x.score += g.score;
 		x.aln += g.aln; x.mat += g.mat; x.mis += g.mis; x.ins += g.ins; x.del += g.del;
-		wtz_cigar_concat_coop(st.cigar, g.cigar, g.cigar_len);
+		if(!joined) wtz_cigar_concat_coop(st.cigar, g.cigar, g.cigar_len);
 		x.score += reg2->x.score;
 		x.aln += reg2->x.aln; x.mat += reg2->x.mat; x.mis += reg2->x.mis; x.ins += reg2->x.ins; x.del += reg2->x.del;
 		x.qe = reg2->x.qe; x.te = reg2->x.te;
-		wtz_cigar_concat_coop(st.cigar, reg2->cigar, reg2->cigar_len);
+		if(!joined) wtz_cigar_concat_coop(st.cigar, reg2->cigar, reg2->cigar_len);
 	}
 	if(st.cigar.bad) st.bad = 1;
 	if(x.te < len1 && x.qe < len2){

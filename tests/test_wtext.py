@@ -168,12 +168,18 @@ def test_gpu_wtext_blocks_never_change_the_output(extra, gpu_ext, gpu_exe, tmp_p
 
 
 @pytest.mark.gpu
-@pytest.mark.skipif(not all(os.path.exists(p) for p in (REF_EXT, REF_ZMO, REF_OBT)), reason="reference binaries not built (make -C oracle ref)")
-def test_gpu_wtext_after_gpu_wtzmo_equals_reference_chain(gpu_ext, gpu_exe, tmp_path):
-    """~2 800 reads: gpu wtzmo -> (reference wtobt) -> gpu wtext against reference wtzmo -> wtobt -> wtext, byte for byte."""
-    fa = os.path.join(str(tmp_path), "grid21.fa")
+@pytest.mark.skipif(not all(os.path.exists(p) for p in (REF_EXT, REF_OBT)), reason="reference binaries not built (make -C oracle ref)")
+def test_gpu_wtext_after_gpu_wtzmo_equals_reference_wtext(gpu_ext, gpu_exe, tmp_path):
+    """~2 800 reads: gpu wtzmo -> reference wtobt -> gpu wtext against reference `wtext -t 1` on the same two files, byte for byte
+    (bin/wtzmo's own parity with `wtzmo -t 1` is tests/test_gpu_parity.py's and test_gpu_scale.py's subject)."""
+    d = str(tmp_path)
+    fa = os.path.join(d, "grid21.fa")
     open(fa, "wb").write(gbo_inputs.grid_fasta(21, G=1200000))
-    zr, xr = _fresh_chain(REF_ZMO, REF_OBT, REF_EXT, fa, str(tmp_path), "ref", ["-t", "32"])
-    zg, xg = _fresh_chain(gpu_exe, REF_OBT, gpu_ext, fa, str(tmp_path), "gpu")
-    assert zr.count(b"\n") > 5000 and zg == zr
-    assert xr.count(b"\n") > 5000 and xg == xr
+    zo = os.path.join(d, "z.ovl"); ob = os.path.join(d, "z.obt"); xr = os.path.join(d, "ref.ext"); xg = os.path.join(d, "gpu.ext")
+    subprocess.run([gpu_exe, "-i", fa, "-fo", zo, "-k", "16", "-s", "200", "-m", "0.6"], check=True, stderr=subprocess.DEVNULL)
+    subprocess.run([REF_OBT, "-i", fa, "-j", zo, "-fo", ob, "-m", "0.6", "-c", "2"], check=True, stderr=subprocess.DEVNULL)
+    subprocess.run([REF_EXT, "-t", "1", "-i", fa, "-j", zo, "-b", ob, "-fo", xr], check=True, stderr=subprocess.DEVNULL)
+    subprocess.run([gpu_ext, "-t", "8", "--block", "4096", "-i", fa, "-j", zo, "-b", ob, "-fo", xg], check=True, stderr=subprocess.DEVNULL)
+    ref = open(xr, "rb").read()
+    assert ref.count(b"\n") > 5000
+    assert open(xg, "rb").read() == ref
