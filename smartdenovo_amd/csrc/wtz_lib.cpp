@@ -106,8 +106,14 @@ static double wtz_wall(){ return std::chrono::duration<double>(std::chrono::stea
 #ifndef WTZ_OCC_WINALIGN
 #define WTZ_OCC_WINALIGN 3
 #endif
+/* The pair kernels are latency-bound, so waves per SIMD pay - until the register budget of the occupancy target forces spills into the loops: with the window scan of
+ * round 4 (K_pair needs 135 VGPRs, K_pair_dm 149) five waves = 96 VGPRs and 76 / 42 spilled registers cost more than the fifth wave brings.  configs[2], ms per step:
+ * K_pair 1 731 (5 waves) / 773 (4) / 916 (3); K_pair_dm 5 384 / 5 149 / 5 282. */
+#ifndef WTZ_OCC_PAIR_DM
+#define WTZ_OCC_PAIR_DM 4
+#endif
 #ifndef WTZ_OCC_PAIR
-#define WTZ_OCC_PAIR 5      /* K_pair is latency-bound (14 % VALU issue): five waves per SIMD (102 VGPRs, a few spills) beat three without */
+#define WTZ_OCC_PAIR 4
 #endif
 #ifndef WTZ_OCC_GAP
 #define WTZ_OCC_GAP 1
@@ -152,11 +158,14 @@ template<typename TAG, typename F> __global__ void __launch_bounds__(64) wtz_ker
 template<typename TAG> struct wtz_occ { static constexpr int waves = 1; };
 template<> struct wtz_occ<K_winalign> { static constexpr int waves = WTZ_OCC_WINALIGN; };
 template<> struct wtz_occ<K_pair> { static constexpr int waves = WTZ_OCC_PAIR; };
-template<> struct wtz_occ<K_pair_dm> { static constexpr int waves = WTZ_OCC_PAIR; };
+template<> struct wtz_occ<K_pair_dm> { static constexpr int waves = WTZ_OCC_PAIR_DM; };
 template<> struct wtz_occ<K_gap> { static constexpr int waves = WTZ_OCC_GAP; };
 /* lane-per-problem K-sw1 (wtz_sw_lane.h): the band lives in 2 x (NC + 1) VGPRs */
-template<> struct wtz_occ<K_ldp> { static constexpr int waves = 2; };
-template<> struct wtz_occ<K_gdp> { static constexpr int waves = 2; };
+#ifndef WTZ_OCC_LDP
+#define WTZ_OCC_LDP 2
+#endif
+template<> struct wtz_occ<K_ldp> { static constexpr int waves = WTZ_OCC_LDP; };
+template<> struct wtz_occ<K_gdp> { static constexpr int waves = WTZ_OCC_LDP; };
 /* their tracebacks: chains of dependent loads, nothing to keep in registers */
 template<> struct wtz_occ<K_ltb> { static constexpr int waves = 8; };
 template<> struct wtz_occ<K_gtb> { static constexpr int waves = 8; };

@@ -134,6 +134,7 @@ WTZ_HD void wtz_task_pair(uint32_t t, const wtz_env_t &V, const uint32_t *qid, c
 	sc.lds = emul_lds;
 #endif
 	sc.lds_u64 = WTZ_PAIR_LDS_BYTES / 8;
+	sc.big = NULL; sc.big_u64 = 0;
 	for(uint32_t dir = 0; dir < 2; dir++){
 		wtz_vec<wtz_win_t> wins; wtz_vec<wtz_zhit_t> anchors;
 		wins.a = NULL; wins.n = wins.cap = 0; wins.pool = V.pool; wins.bad = 0;

@@ -308,7 +308,8 @@ WTZ_HD int32_t wtz_median(int32_t *rs, int32_t size){
 /* scratch of one (pair,strand) window scan: all sized by the number of matches of the pair.  `lds` (may be NULL) is the
  * wave's LDS slice: the small order-sensitive sorts / the quick-select run there when they fit - they are chains of
  * dependent loads on a single lane, so it is the access latency (LDS ~64 clk vs L2 ~500 clk) that matters */
-typedef struct { uint32_t *ts; int32_t *as; uint32_t *wb, *we, *wo; uint64_t *tk; wtz_zhit_t *ztmp; uint64_t *lds; uint32_t lds_u64; } wtz_winscratch_t;
+/* `big`: workspace in the pool for the scans whose matches do not fit the LDS slice (allocated by the first such scan of the pair, grown on demand) */
+typedef struct { uint32_t *ts; int32_t *as; uint32_t *wb, *we, *wo; uint64_t *tk; wtz_zhit_t *ztmp; uint64_t *lds; uint32_t lds_u64; mutable uint64_t *big; mutable uint32_t big_u64; } wtz_winscratch_t;
 struct wtz_gt_hi32 { WTZ_HDM bool operator()(uint64_t a, uint64_t b) const { return (uint32_t)(a >> 32) > (uint32_t)(b >> 32); } };
 
 WTZ_HD uint32_t wtz_scan_windows(const wtz_zhit_t *rs, uint32_t dir, uint32_t beg, uint32_t end, int32_t bound,
@@ -478,11 +479,274 @@ WTZ_HD void wtz_hitcur_get(wtz_hitcur_t &c, const wtz_zhit_t *rs, uint32_t lim, 
 	o1 = wtz_coop_lane32(c.o1, l); o2 = wtz_coop_lane32(c.o2, l); ll = wtz_coop_lane32(c.ll, l);
 }
 
-WTZ_HD uint32_t wtz_scan_windows_coop(const wtz_zhit_t *rs, uint32_t dir, uint32_t beg, uint32_t end, int32_t bound,
+/* the part of a scan that only the scans past the early exits reach (one in seven at configs[2]): ordering, sweep, windows.  WTZ_SCAN_REST_FN / WTZ_SCAN_FN choose
+ * whether it / the whole scan is inlined into the merge loop (WTZ_HD) or a function of its own (WTZ_HDN: the merge loop's cursors do not share the register file with this body) */
+#ifndef WTZ_SCAN_REST_FN
+#define WTZ_SCAN_REST_FN WTZ_HD
+#endif
+#ifndef WTZ_SCAN_FN
+#define WTZ_SCAN_FN WTZ_HD
+#endif
+WTZ_SCAN_REST_FN uint32_t wtz_scan_windows_rest(const wtz_zhit_t *rs, uint32_t dir, uint32_t beg, uint32_t end, int32_t bound,
+		wtz_vec<wtz_win_t> &wins, wtz_vec<wtz_zhit_t> &anchors, const wtz_winscratch_t &sc, uint32_t zsize, uint32_t kwin, uint32_t zovl, int32_t *max_e0, uint32_t n, unsigned long long pw0, uint64_t *K){
+	const uint32_t lane = WTZ_LANE;
+	/* K = the LDS slice, or the pool workspace of a scan that does not fit it: the same code, the orderings then go through the LDS slice as a window */
+	auto sort_keys = [&](uint64_t *w, uint32_t npw){
+		if(w == sc.lds || sc.lds == NULL){ wtz_coop_sort_u64(w, npw); return; }
+		uint32_t ln = 128; while(ln * 2 <= sc.lds_u64) ln <<= 1;
+		wtz_coop_sort_u64_windowed(w, npw, sc.lds_u64 >= 128u ? sc.lds : NULL, ln);
+	};
+	uint32_t ret = 0; int32_t me0 = -0x7FFFFFFF;
+	(void)pw0; (void)zsize;
+	WTZ_PROF_ADD(16, pw0); WTZ_PROF_CNT(21, 1); WTZ_PROF_CNT(22, n);
+	const unsigned long long pw1 = WTZ_PROF_T(); (void)pw1;
+	uint32_t np = 64; while(np < n) np <<= 1;
+	/* ---- order by off2 (hzm_aln.h:449).  Equal off2 = ONE candidate z-mer matched at several query positions (a start position holds one z-mer, and on the
+	 * reverse strand distinct starts have distinct ends), so tied matches agree in (off2, len2) and the sweep below - which reads nothing else - computes the same
+	 * overlaps, evicts a tie group as a whole and opens its windows at a group's first member whatever the order inside the group.  The order is observable in
+	 * exactly two places: (a) a window whose last member is a non-last member of a tie group (the rest of the group stays outside), (b) the swap-exact ordering
+	 * of a window's members by off1 when THAT has ties too (its input permutation changes).  So the first attempt takes the wave's order (ties by position in the
+	 * match list), watches for (a) and (b), and only then the scan is redone with the reference's swap sequence replayed on lane 0 - round 4's profile: 1.9 M of
+	 * 7.6 M scans had ties and their replays were two thirds of the ordering time. ---- */
+	bool had_tie = false, exact = false;
+	const uint32_t wins_n0 = wins.n, anchors_n0 = anchors.n;      /* lane 0's values are the ones used */
+retry_scan:
+	if(exact){
+		uint32_t m = 0;
+		for(uint32_t b0 = beg; b0 < end; b0 += WTZ_NLANES){      /* K in the ORIGINAL order again */
+			const uint32_t idx = b0 + lane;
+			bool keep = false; uint32_t o2 = 0;
+			if(idx < end){ const uint32_t o1 = rs[idx].o1; o2 = rs[idx].o2; keep = (((o1 ^ o2) >> 31) == dir) && ((int32_t)(o1 & 0x7FFFFFFFu) >= bound); }
+			uint32_t tot; const uint32_t pos = wtz_coop_rank(keep, &tot);
+			if(keep) K[m + pos] = ((uint64_t)(o2 & 0x7FFFFFFFu) << 32) | idx;
+			m += tot;
+		}
+		WTZ_WAVE_SYNC();
+		{ const unsigned long long px = WTZ_PROF_T(); (void)px; if(lane == 0) wtz_sort_exact(K, (size_t)n, wtz_gt_hi32()); WTZ_PROF_ADD(25, px); WTZ_PROF_CNT(24, 1000); }
+		WTZ_WAVE_SYNC();
+	} else {
+#if defined(__HIP_DEVICE_COMPILE__)
+	bool in_regs = false;
+	if(n <= 64u){
+		/* one key per lane: the order comes out of registers */
+		WTZ_WAVE_SYNC();
+		const uint64_t v = wtz_wave_sort64(lane < n ? K[lane] : ~0ull);
+		const uint32_t nhi = (uint32_t)__shfl_down((int)(uint32_t)(v >> 32), 1, 64);
+		const bool tie = lane + 1 < n && (uint32_t)(v >> 32) == nhi;
+		uint32_t any; (void)wtz_coop_rank(tie, &any);
+		had_tie = any != 0;
+		if(lane < n) K[lane] = v;
+		WTZ_WAVE_SYNC();
+		in_regs = true;
+	}
+	if(!in_regs)
+#endif
+	{
+	for(uint32_t i = n + lane; i < np; i += WTZ_NLANES) K[i] = ~0ull;
+	WTZ_WAVE_SYNC();
+	sort_keys(K, np);
+	bool tie = false;
+	for(uint32_t i = lane; i + 1 < n; i += WTZ_NLANES) if((K[i] >> 32) == (K[i + 1] >> 32)) tie = true;
+	uint32_t any; (void)wtz_coop_rank(tie, &any);
+	had_tie = any != 0;
+	}
+	if(had_tie) WTZ_PROF_CNT(26, 1000);
+	}
+	WTZ_PROF_ADD(17, pw1);
+	const unsigned long long pw2 = WTZ_PROF_T(); (void)pw2;
+	wtz_zhit_t *S = (wtz_zhit_t*)(K + np);
+	for(uint32_t x = lane; x < n; x += WTZ_NLANES) S[x] = rs[(uint32_t)K[x]];
+	WTZ_WAVE_SYNC();
+	WTZ_PROF_ADD(18, pw2);
+	const unsigned long long pw3 = WTZ_PROF_T(); (void)pw3;
+	unsigned long long pw4 = 0; (void)pw4;
+	uint32_t n2_all = 0;
+	{
+		/* ---- the sweep of hzm_aln.h:451-483, one match per lane.  The running overlap is a difference of two prefix sums (all of it modulo 2^32, like the loop):
+		 * entering match i adds add_i = len2_i, or end_i - end_(i-1) when it starts inside its predecessor; evicting match k takes evict_k = len2_k - (its overlap
+		 * with match k + 1); the eviction cursor after match i is the first j with end_i <= off2_j + kwin (off2 ascends: a binary search), never behind the cursor of
+		 * the match before (a running maximum).  So ol_i = A_i - E_j(i) for every i at once, and only the window bookkeeping - which merges an opening into the last
+		 * window or starts a new one depending on the last window's best member - walks the openings in order, on uniform values read from the lanes' registers. ---- */
+		uint32_t *EP = (uint32_t*)K;                    /* EP[j] = sum of evict_k over k < j; the off2 keys in K are dead after the gather */
+		uint32_t accA = 0, accE = 0, jrun = 0, n2 = 0;
+		uint32_t lwo = 0, lwb_o2 = 0, lwe_o2 = 0;      /* the open window: overlap and off2 of its two ends */
+		for(uint32_t c0 = 0; c0 < n; c0 += WTZ_NLANES){
+			const uint32_t i = c0 + lane; const bool in = i < n;
+			uint32_t o2 = 0, l2 = 0, e2 = 0, add = 0, ev = 0;
+			if(in){
+				const wtz_zhit_t p = S[i]; o2 = ZH_OFF2(p); l2 = ZH_LEN2(p); e2 = o2 + l2;
+				uint32_t lst = 0; if(i){ const wtz_zhit_t q = S[i - 1]; lst = ZH_OFF2(q) + ZH_LEN2(q); }
+				add = (o2 > lst) ? l2 : e2 - lst;
+				if(i + 1 < n){ const uint32_t s1 = ZH_OFF2(S[i + 1]); ev = l2 - (s1 < e2 ? e2 - s1 : 0u); }
+			}
+			uint32_t totA, totE;
+			const uint32_t exA = wtz_coop_excl_scan(add, &totA), exE = wtz_coop_excl_scan(ev, &totE);
+			if(in) EP[i] = accE + exE;
+			WTZ_WAVE_SYNC();
+			uint32_t jm = 0;
+			if(in){ uint32_t lo = 0, hi = i; while(lo < hi){ const uint32_t mid = (lo + hi) >> 1; if(e2 > ZH_OFF2(S[mid]) + kwin) lo = mid + 1; else hi = mid; } jm = lo; }
+			jm = wtz_coop_incl_max32(jm); jm = jm > jrun ? jm : jrun;
+			uint32_t ol = 0, jo2 = 0;
+			if(in){ ol = accA + exA + add - EP[jm]; jo2 = ZH_OFF2(S[jm]); }
+			const uint32_t lastl = (n - c0 < WTZ_NLANES ? n - c0 : WTZ_NLANES) - 1;
+			accA += totA; accE += totE; jrun = wtz_coop_lane32(jm, lastl);
+			unsigned long long fl = wtz_coop_ballot(in && ol >= zovl);
+			while(fl){
+				const uint32_t l = (uint32_t)__builtin_ctzll(fl); fl &= fl - 1;
+				const uint32_t ol_ = wtz_coop_lane32(ol, l), o2_ = wtz_coop_lane32(o2, l), jo2_ = wtz_coop_lane32(jo2, l), j_ = wtz_coop_lane32(jm, l);
+				if(n2 && (o2_ <= lwe_o2 + kwin / 3 || jo2_ <= lwb_o2 + kwin / 3)){
+					if(ol_ > lwo){ if(lane == 0){ sc.wb[n2-1] = j_; sc.we[n2-1] = c0 + l; } lwo = ol_; lwb_o2 = jo2_; lwe_o2 = o2_; }
+				} else { if(lane == 0){ sc.wb[n2] = j_; sc.we[n2] = c0 + l; } lwo = ol_; lwb_o2 = jo2_; lwe_o2 = o2_; n2++; }
+			}
+			WTZ_WAVE_SYNC();                                 /* EP of this chunk is read before the next chunk writes beside it */
+		}
+#ifdef WTZ_EXP_CNT_EMPTY
+		WTZ_PROF_ADD(19, pw3); pw4 = WTZ_PROF_T(); WTZ_PROF_CNT(23, n2 == 0 ? 1 : 0);      /* diagnostic build: scans whose sweep finds no window */
+#else
+		WTZ_PROF_ADD(19, pw3); pw4 = WTZ_PROF_T(); WTZ_PROF_CNT(23, n2);
+#endif
+		n2_all = n2;
+		if(had_tie && !exact){          /* (a): does a window end inside a tie group? */
+			uint32_t cut = 0;
+			if(lane == 0) for(uint32_t wq = 0; wq < n2; wq++){ const uint32_t we = sc.we[wq]; if(we + 1 < n && ZH_OFF2(S[we + 1]) == ZH_OFF2(S[we])) cut = 1; }
+			if(wtz_coop_bcast32(cut)) n2_all = 0xFFFFFFFFu;
+		}
+	}
+	/* ---- the windows (hzm_aln.h:484-575), every step on the whole wave (round 3 walked them on lane 0: chains of dependent LDS reads).
+	 *  - median diagonal (calculate_median_value returns the element of rank size / 2): the rank from the wave's sorting network (<= 64 members) or the LDS network;
+	 *  - members within KWIN_MAX_OFFSET_DEV of it, compacted in S order with ballot ranks;
+	 *  - their order by off1 (hzm_aln.h:519): distinct keys have ONE ascending order; equal off1 (one query z-mer matched at two candidate positions) makes the
+	 *    reference's swap sequence observable and lane 0 replays it from the S order;
+	 *  - anchors copied one per lane; the covered length is a sum of per-member terms that depend on the member before only (len1, or end - previous end), the box
+	 *    is four min / max reductions. ---- */
+	if(n2_all == 0xFFFFFFFFu){ WTZ_PROF_CNT(28, 1000); exact = true; goto retry_scan; }
+	int32_t last_end1 = 0; uint32_t last_ovl = 0;
+	for(uint32_t wi = 0; wi < n2_all; wi++){
+		uint32_t size = 0, cnt = 0, wb = 0, we = 0;
+		uint64_t *ak = K;                         /* (off1<<32 | position in S) of the members */
+		if(lane == 0){ size = anchors.n; wb = sc.wb[wi]; we = sc.we[wi]; }
+		size = wtz_coop_bcast32(size); wb = wtz_coop_bcast32(wb); we = wtz_coop_bcast32(we);
+		const uint32_t m = we - wb + 1;
+		int32_t offset;
+		WTZ_WAVE_SYNC();
+#if defined(__HIP_DEVICE_COMPILE__)
+		if(m <= 64u){
+			uint32_t key = 0xFFFFFFFFu;
+			if(lane < m){ const wtz_zhit_t p = S[wb + lane]; key = (uint32_t)((int32_t)ZH_OFF1(p) - (int32_t)ZH_OFF2(p)) ^ 0x80000000u; }
+			key = wtz_wave_sort32(key);
+			offset = (int32_t)(wtz_coop_lane32(key, m / 2) ^ 0x80000000u);
+		} else
+#endif
+		{
+			uint32_t mp = 64; while(mp < m) mp <<= 1;                /* m <= n <= np */
+			for(uint32_t x = lane; x < mp; x += WTZ_NLANES){
+				uint64_t v = ~0ull;
+				if(x < m){ const wtz_zhit_t p = S[wb + x]; v = (uint64_t)((uint32_t)((int32_t)ZH_OFF1(p) - (int32_t)ZH_OFF2(p)) ^ 0x80000000u); }
+				ak[x] = v;
+			}
+			WTZ_WAVE_SYNC();
+			sort_keys(ak, mp);
+			offset = (int32_t)((uint32_t)ak[m / 2] ^ 0x80000000u);
+			WTZ_WAVE_SYNC();
+		}
+		auto fill_members = [&]() -> uint32_t {   /* members within the deviation, in S order */
+			uint32_t c2 = 0;
+			for(uint32_t c0 = 0; c0 < m; c0 += WTZ_NLANES){
+				const uint32_t j = wb + c0 + lane;
+				bool keep = false; uint32_t o1 = 0;
+				if(c0 + lane < m){ const wtz_zhit_t p = S[j]; const int32_t off = (int32_t)ZH_OFF1(p) - (int32_t)ZH_OFF2(p); o1 = ZH_OFF1(p); keep = !(off < offset - WTZ_KWIN_MAX_OFFSET_DEV || off > offset + WTZ_KWIN_MAX_OFFSET_DEV); }
+				uint32_t tot; const uint32_t pos = wtz_coop_rank(keep, &tot);
+				if(keep) ak[c2 + pos] = ((uint64_t)o1 << 32) | j;
+				c2 += tot;
+			}
+			WTZ_WAVE_SYNC();
+			return c2;
+		};
+		cnt = fill_members();
+		if(cnt == 0) continue;
+		{
+			uint32_t any = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+			if(cnt <= 64u){
+				const uint64_t v = wtz_wave_sort64(lane < cnt ? ak[lane] : ~0ull);
+				const uint32_t nhi = (uint32_t)__shfl_down((int)(uint32_t)(v >> 32), 1, 64);
+				const bool tie = lane + 1 < cnt && (uint32_t)(v >> 32) == nhi;
+				(void)wtz_coop_rank(tie, &any);
+				if(!any && lane < cnt) ak[lane] = v;
+				WTZ_WAVE_SYNC();
+			} else
+#endif
+			{
+				uint32_t np2 = 64; while(np2 < cnt) np2 <<= 1;            /* cnt <= n <= np: the padding stays in front of S */
+				for(uint32_t i = cnt + lane; i < np2; i += WTZ_NLANES) ak[i] = ~0ull;
+				WTZ_WAVE_SYNC();
+				sort_keys(ak, np2);
+				bool tie = false;
+				for(uint32_t i = lane; i + 1 < cnt; i += WTZ_NLANES) if((ak[i] >> 32) == (ak[i + 1] >> 32)) tie = true;
+				(void)wtz_coop_rank(tie, &any);
+				WTZ_PROF_CNT(29, 1000);
+				if(any){ WTZ_WAVE_SYNC(); (void)fill_members(); }      /* back to the S order for the exact path */
+			}
+			if(any){
+				if(had_tie && !exact){         /* (b): both orders have ties - the scan again, with the reference's swap sequence for off2 */
+					if(lane == 0){ wins.n = wins_n0; anchors.n = anchors_n0; }
+					ret = 0; me0 = -0x7FFFFFFF; exact = true;
+					WTZ_PROF_CNT(30, 1000);
+					goto retry_scan;
+				}
+				const unsigned long long px = WTZ_PROF_T(); (void)px;
+				if(lane == 0) wtz_sort_exact(ak, (size_t)cnt, wtz_gt_hi32());
+				WTZ_PROF_ADD(27, px); WTZ_PROF_CNT(31, 1000);
+				WTZ_WAVE_SYNC();
+			}
+		}
+		uint32_t stop = 0; uint64_t abase = 0;
+		if(lane == 0){ if(!anchors.reserve(size + cnt)) stop = 1; else abase = (uint64_t)(uintptr_t)anchors.a; }
+		if(wtz_coop_bcast32(stop)) break;
+		abase = wtz_coop_bcast64(abase);
+		wtz_zhit_t *A = (wtz_zhit_t*)(uintptr_t)abase + size;
+		uint32_t ol = 0, b0 = 0x7FFFFFFFu, e0 = 0, b1 = 0x7FFFFFFFu, e1 = 0;
+		for(uint32_t c0 = 0; c0 < cnt; c0 += WTZ_NLANES){
+			const uint32_t k = c0 + lane; uint32_t add = 0;
+			if(k < cnt){
+				const wtz_zhit_t p = S[(uint32_t)ak[k]];
+				A[k] = p;
+				uint32_t lst = 0; if(k){ const wtz_zhit_t q = S[(uint32_t)ak[k - 1]]; lst = ZH_OFF1(q) + ZH_LEN1(q); }
+				const uint32_t o1 = ZH_OFF1(p), x1 = o1 + ZH_LEN1(p), o2 = ZH_OFF2(p), x2 = o2 + ZH_LEN2(p);
+				add = (o1 > lst) ? ZH_LEN1(p) : x1 - lst;
+				b0 = o1 < b0 ? o1 : b0; e0 = x1 > e0 ? x1 : e0; b1 = o2 < b1 ? o2 : b1; e1 = x2 > e1 ? x2 : e1;
+			}
+			uint32_t tot; (void)wtz_coop_excl_scan(add, &tot); ol += tot;
+		}
+		b0 = wtz_coop_min32(b0); b1 = wtz_coop_min32(b1); e0 = ~wtz_coop_min32(~e0); e1 = ~wtz_coop_min32(~e1);
+		if(ol * 2 < zovl) continue;
+		if(ret && ((int32_t)e1 <= (int32_t)((uint32_t)last_end1 + kwin / 3) && ol <= last_ovl)) continue;
+		if(lane == 0){
+			wtz_win_t w;
+			w.pb2 = 0; w.closed = 0; w.dir = (uint8_t)dir; w.pad = 0;
+			w.beg[0] = (int32_t)b0; w.beg[1] = (int32_t)b1; w.end[0] = (int32_t)e0; w.end[1] = (int32_t)e1;
+			anchors.n = size + cnt;
+			w.anchors[0] = size; w.anchors[1] = anchors.n;
+			w.ovl = WTZ_OVL29(ol);
+			if(!wins.push(w)) stop = 1;                /* pool exhausted: count only what is in the vector */
+		}
+		if(wtz_coop_bcast32(stop)) break;
+		ret++;
+		last_end1 = (int32_t)e1; last_ovl = WTZ_OVL29(ol);
+		if(me0 < (int32_t)e0) me0 = (int32_t)e0;
+		WTZ_WAVE_SYNC();
+	}
+	WTZ_PROF_ADD(20, pw4);
+	WTZ_WAVE_SYNC();
+	*max_e0 = (int32_t)wtz_coop_bcast32((uint32_t)me0);
+	return wtz_coop_bcast32(ret);
+}
+
+WTZ_SCAN_FN uint32_t wtz_scan_windows_coop(const wtz_zhit_t *rs, uint32_t dir, uint32_t beg, uint32_t end, int32_t bound,
 		wtz_vec<wtz_win_t> &wins, wtz_vec<wtz_zhit_t> &anchors, const wtz_winscratch_t &sc, uint32_t zsize, uint32_t kwin, uint32_t zovl, int32_t *max_e0){
 	const uint32_t lane = WTZ_LANE;
 	uint64_t *K = sc.lds;
-	uint32_t n = 0, ret = 0; int32_t me0 = -0x7FFFFFFF;
+	uint32_t n = 0;
 	const unsigned long long pw0 = WTZ_PROF_T(); (void)pw0;
 	/* ---- strand / bound filter (the prefix skip of hzm_aln.h:425-431 is the same predicate: off1 is non-decreasing) ---- */
 	constexpr uint32_t RC = 4;                         /* a range of up to RC matches per lane is read ONCE: count, early-exit bound and key fill run on the off2 values kept in registers */
@@ -610,258 +874,30 @@ WTZ_HD uint32_t wtz_scan_windows_coop(const wtz_zhit_t *rs, uint32_t dir, uint32
 		}
 #endif
 		uint32_t np0 = 64; while(np0 < n) np0 <<= 1;
-		if(K == NULL || np0 + 2 * n + 2 > sc.lds_u64){       /* does not fit: scalar body on lane 0 */
-			uint32_t r = 0; int32_t e = -0x7FFFFFFF;
-			if(lane == 0){
-				r = wtz_scan_windows(rs, dir, beg, end, bound, wins, anchors, sc, zsize, kwin, zovl);
-				for(uint32_t a = 0; a < r; a++){ const int32_t e0 = wins.a[wins.n + a - r].end[0]; if(e < e0) e = e0; }
+		if(K == NULL || np0 + 2 * n + 2 > sc.lds_u64){
+			/* does not fit the LDS slice (a few hundred matches of one strand inside one window: repeats): the same wave-parallel scan on a workspace in the pool.
+			 * (Round 3 ran these on lane 0 - a sort of thousands of matches by dependent memory accesses; the heaviest pair of a range took half of its launch.) */
+			const uint32_t need = np0 + 2 * n + 2;
+			if(sc.big_u64 < need){
+				const uint32_t cap = need > 2 * sc.big_u64 ? need : 2 * sc.big_u64;
+				uint64_t pa = 0;
+				if(lane == 0) pa = (uint64_t)(uintptr_t)wtz_pool_alloc(wins.pool, (size_t)cap * 8 + 16);
+				pa = wtz_coop_bcast64(pa);
+				if(pa){ sc.big = (uint64_t*)(uintptr_t)pa; sc.big_u64 = cap; }
 			}
-			*max_e0 = (int32_t)wtz_coop_bcast32((uint32_t)e);
-			return wtz_coop_bcast32(r);
-		}
-	}
-	WTZ_PROF_ADD(16, pw0); WTZ_PROF_CNT(21, 1); WTZ_PROF_CNT(22, n);
-	const unsigned long long pw1 = WTZ_PROF_T(); (void)pw1;
-	uint32_t np = 64; while(np < n) np <<= 1;
-	/* ---- order by off2 (hzm_aln.h:449).  Equal off2 = ONE candidate z-mer matched at several query positions (a start position holds one z-mer, and on the
-	 * reverse strand distinct starts have distinct ends), so tied matches agree in (off2, len2) and the sweep below - which reads nothing else - computes the same
-	 * overlaps, evicts a tie group as a whole and opens its windows at a group's first member whatever the order inside the group.  The order is observable in
-	 * exactly two places: (a) a window whose last member is a non-last member of a tie group (the rest of the group stays outside), (b) the swap-exact ordering
-	 * of a window's members by off1 when THAT has ties too (its input permutation changes).  So the first attempt takes the wave's order (ties by position in the
-	 * match list), watches for (a) and (b), and only then the scan is redone with the reference's swap sequence replayed on lane 0 - round 4's profile: 1.9 M of
-	 * 7.6 M scans had ties and their replays were two thirds of the ordering time. ---- */
-	bool had_tie = false, exact = false;
-	const uint32_t wins_n0 = wins.n, anchors_n0 = anchors.n;      /* lane 0's values are the ones used */
-retry_scan:
-	if(exact){
-		uint32_t m = 0;
-		for(uint32_t b0 = beg; b0 < end; b0 += WTZ_NLANES){      /* K in the ORIGINAL order again */
-			const uint32_t idx = b0 + lane;
-			bool keep = false; uint32_t o2 = 0;
-			if(idx < end){ const uint32_t o1 = rs[idx].o1; o2 = rs[idx].o2; keep = (((o1 ^ o2) >> 31) == dir) && ((int32_t)(o1 & 0x7FFFFFFFu) >= bound); }
-			uint32_t tot; const uint32_t pos = wtz_coop_rank(keep, &tot);
-			if(keep) K[m + pos] = ((uint64_t)(o2 & 0x7FFFFFFFu) << 32) | idx;
-			m += tot;
-		}
-		WTZ_WAVE_SYNC();
-		{ const unsigned long long px = WTZ_PROF_T(); (void)px; if(lane == 0) wtz_sort_exact(K, (size_t)n, wtz_gt_hi32()); WTZ_PROF_ADD(25, px); WTZ_PROF_CNT(24, 1000); }
-		WTZ_WAVE_SYNC();
-	} else {
-#if defined(__HIP_DEVICE_COMPILE__)
-	bool in_regs = false;
-	if(n <= 64u){
-		/* one key per lane: the order comes out of registers */
-		WTZ_WAVE_SYNC();
-		const uint64_t v = wtz_wave_sort64(lane < n ? K[lane] : ~0ull);
-		const uint32_t nhi = (uint32_t)__shfl_down((int)(uint32_t)(v >> 32), 1, 64);
-		const bool tie = lane + 1 < n && (uint32_t)(v >> 32) == nhi;
-		uint32_t any; (void)wtz_coop_rank(tie, &any);
-		had_tie = any != 0;
-		if(lane < n) K[lane] = v;
-		WTZ_WAVE_SYNC();
-		in_regs = true;
-	}
-	if(!in_regs)
-#endif
-	{
-	for(uint32_t i = n + lane; i < np; i += WTZ_NLANES) K[i] = ~0ull;
-	WTZ_WAVE_SYNC();
-	wtz_coop_sort_u64(K, np);
-	bool tie = false;
-	for(uint32_t i = lane; i + 1 < n; i += WTZ_NLANES) if((K[i] >> 32) == (K[i + 1] >> 32)) tie = true;
-	uint32_t any; (void)wtz_coop_rank(tie, &any);
-	had_tie = any != 0;
-	}
-	if(had_tie) WTZ_PROF_CNT(26, 1000);
-	}
-	WTZ_PROF_ADD(17, pw1);
-	const unsigned long long pw2 = WTZ_PROF_T(); (void)pw2;
-	wtz_zhit_t *S = (wtz_zhit_t*)(K + np);
-	for(uint32_t x = lane; x < n; x += WTZ_NLANES) S[x] = rs[(uint32_t)K[x]];
-	WTZ_WAVE_SYNC();
-	WTZ_PROF_ADD(18, pw2);
-	const unsigned long long pw3 = WTZ_PROF_T(); (void)pw3;
-	unsigned long long pw4 = 0; (void)pw4;
-	uint32_t n2_all = 0;
-	{
-		/* ---- the sweep of hzm_aln.h:451-483, one match per lane.  The running overlap is a difference of two prefix sums (all of it modulo 2^32, like the loop):
-		 * entering match i adds add_i = len2_i, or end_i - end_(i-1) when it starts inside its predecessor; evicting match k takes evict_k = len2_k - (its overlap
-		 * with match k + 1); the eviction cursor after match i is the first j with end_i <= off2_j + kwin (off2 ascends: a binary search), never behind the cursor of
-		 * the match before (a running maximum).  So ol_i = A_i - E_j(i) for every i at once, and only the window bookkeeping - which merges an opening into the last
-		 * window or starts a new one depending on the last window's best member - walks the openings in order, on uniform values read from the lanes' registers. ---- */
-		uint32_t *EP = (uint32_t*)K;                    /* EP[j] = sum of evict_k over k < j; the off2 keys in K are dead after the gather */
-		uint32_t accA = 0, accE = 0, jrun = 0, n2 = 0;
-		uint32_t lwo = 0, lwb_o2 = 0, lwe_o2 = 0;      /* the open window: overlap and off2 of its two ends */
-		for(uint32_t c0 = 0; c0 < n; c0 += WTZ_NLANES){
-			const uint32_t i = c0 + lane; const bool in = i < n;
-			uint32_t o2 = 0, l2 = 0, e2 = 0, add = 0, ev = 0;
-			if(in){
-				const wtz_zhit_t p = S[i]; o2 = ZH_OFF2(p); l2 = ZH_LEN2(p); e2 = o2 + l2;
-				uint32_t lst = 0; if(i){ const wtz_zhit_t q = S[i - 1]; lst = ZH_OFF2(q) + ZH_LEN2(q); }
-				add = (o2 > lst) ? l2 : e2 - lst;
-				if(i + 1 < n){ const uint32_t s1 = ZH_OFF2(S[i + 1]); ev = l2 - (s1 < e2 ? e2 - s1 : 0u); }
-			}
-			uint32_t totA, totE;
-			const uint32_t exA = wtz_coop_excl_scan(add, &totA), exE = wtz_coop_excl_scan(ev, &totE);
-			if(in) EP[i] = accE + exE;
-			WTZ_WAVE_SYNC();
-			uint32_t jm = 0;
-			if(in){ uint32_t lo = 0, hi = i; while(lo < hi){ const uint32_t mid = (lo + hi) >> 1; if(e2 > ZH_OFF2(S[mid]) + kwin) lo = mid + 1; else hi = mid; } jm = lo; }
-			jm = wtz_coop_incl_max32(jm); jm = jm > jrun ? jm : jrun;
-			uint32_t ol = 0, jo2 = 0;
-			if(in){ ol = accA + exA + add - EP[jm]; jo2 = ZH_OFF2(S[jm]); }
-			const uint32_t lastl = (n - c0 < WTZ_NLANES ? n - c0 : WTZ_NLANES) - 1;
-			accA += totA; accE += totE; jrun = wtz_coop_lane32(jm, lastl);
-			unsigned long long fl = wtz_coop_ballot(in && ol >= zovl);
-			while(fl){
-				const uint32_t l = (uint32_t)__builtin_ctzll(fl); fl &= fl - 1;
-				const uint32_t ol_ = wtz_coop_lane32(ol, l), o2_ = wtz_coop_lane32(o2, l), jo2_ = wtz_coop_lane32(jo2, l), j_ = wtz_coop_lane32(jm, l);
-				if(n2 && (o2_ <= lwe_o2 + kwin / 3 || jo2_ <= lwb_o2 + kwin / 3)){
-					if(ol_ > lwo){ if(lane == 0){ sc.wb[n2-1] = j_; sc.we[n2-1] = c0 + l; } lwo = ol_; lwb_o2 = jo2_; lwe_o2 = o2_; }
-				} else { if(lane == 0){ sc.wb[n2] = j_; sc.we[n2] = c0 + l; } lwo = ol_; lwb_o2 = jo2_; lwe_o2 = o2_; n2++; }
-			}
-			WTZ_WAVE_SYNC();                                 /* EP of this chunk is read before the next chunk writes beside it */
-		}
-#ifdef WTZ_EXP_CNT_EMPTY
-		WTZ_PROF_ADD(19, pw3); pw4 = WTZ_PROF_T(); WTZ_PROF_CNT(23, n2 == 0 ? 1 : 0);      /* diagnostic build: scans whose sweep finds no window */
-#else
-		WTZ_PROF_ADD(19, pw3); pw4 = WTZ_PROF_T(); WTZ_PROF_CNT(23, n2);
-#endif
-		n2_all = n2;
-		if(had_tie && !exact){          /* (a): does a window end inside a tie group? */
-			uint32_t cut = 0;
-			if(lane == 0) for(uint32_t wq = 0; wq < n2; wq++){ const uint32_t we = sc.we[wq]; if(we + 1 < n && ZH_OFF2(S[we + 1]) == ZH_OFF2(S[we])) cut = 1; }
-			if(wtz_coop_bcast32(cut)) n2_all = 0xFFFFFFFFu;
-		}
-	}
-	/* ---- the windows (hzm_aln.h:484-575), every step on the whole wave (round 3 walked them on lane 0: chains of dependent LDS reads).
-	 *  - median diagonal (calculate_median_value returns the element of rank size / 2): the rank from the wave's sorting network (<= 64 members) or the LDS network;
-	 *  - members within KWIN_MAX_OFFSET_DEV of it, compacted in S order with ballot ranks;
-	 *  - their order by off1 (hzm_aln.h:519): distinct keys have ONE ascending order; equal off1 (one query z-mer matched at two candidate positions) makes the
-	 *    reference's swap sequence observable and lane 0 replays it from the S order;
-	 *  - anchors copied one per lane; the covered length is a sum of per-member terms that depend on the member before only (len1, or end - previous end), the box
-	 *    is four min / max reductions. ---- */
-	if(n2_all == 0xFFFFFFFFu){ WTZ_PROF_CNT(28, 1000); exact = true; goto retry_scan; }
-	int32_t last_end1 = 0; uint32_t last_ovl = 0;
-	for(uint32_t wi = 0; wi < n2_all; wi++){
-		uint32_t size = 0, cnt = 0, wb = 0, we = 0;
-		uint64_t *ak = K;                         /* (off1<<32 | position in S) of the members */
-		if(lane == 0){ size = anchors.n; wb = sc.wb[wi]; we = sc.we[wi]; }
-		size = wtz_coop_bcast32(size); wb = wtz_coop_bcast32(wb); we = wtz_coop_bcast32(we);
-		const uint32_t m = we - wb + 1;
-		int32_t offset;
-		WTZ_WAVE_SYNC();
-#if defined(__HIP_DEVICE_COMPILE__)
-		if(m <= 64u){
-			uint32_t key = 0xFFFFFFFFu;
-			if(lane < m){ const wtz_zhit_t p = S[wb + lane]; key = (uint32_t)((int32_t)ZH_OFF1(p) - (int32_t)ZH_OFF2(p)) ^ 0x80000000u; }
-			key = wtz_wave_sort32(key);
-			offset = (int32_t)(wtz_coop_lane32(key, m / 2) ^ 0x80000000u);
-		} else
-#endif
-		{
-			uint32_t mp = 64; while(mp < m) mp <<= 1;                /* m <= n <= np */
-			for(uint32_t x = lane; x < mp; x += WTZ_NLANES){
-				uint64_t v = ~0ull;
-				if(x < m){ const wtz_zhit_t p = S[wb + x]; v = (uint64_t)((uint32_t)((int32_t)ZH_OFF1(p) - (int32_t)ZH_OFF2(p)) ^ 0x80000000u); }
-				ak[x] = v;
-			}
-			WTZ_WAVE_SYNC();
-			wtz_coop_sort_u64(ak, mp);
-			offset = (int32_t)((uint32_t)ak[m / 2] ^ 0x80000000u);
-			WTZ_WAVE_SYNC();
-		}
-		auto fill_members = [&]() -> uint32_t {   /* members within the deviation, in S order */
-			uint32_t c2 = 0;
-			for(uint32_t c0 = 0; c0 < m; c0 += WTZ_NLANES){
-				const uint32_t j = wb + c0 + lane;
-				bool keep = false; uint32_t o1 = 0;
-				if(c0 + lane < m){ const wtz_zhit_t p = S[j]; const int32_t off = (int32_t)ZH_OFF1(p) - (int32_t)ZH_OFF2(p); o1 = ZH_OFF1(p); keep = !(off < offset - WTZ_KWIN_MAX_OFFSET_DEV || off > offset + WTZ_KWIN_MAX_OFFSET_DEV); }
-				uint32_t tot; const uint32_t pos = wtz_coop_rank(keep, &tot);
-				if(keep) ak[c2 + pos] = ((uint64_t)o1 << 32) | j;
-				c2 += tot;
-			}
-			WTZ_WAVE_SYNC();
-			return c2;
-		};
-		cnt = fill_members();
-		if(cnt == 0) continue;
-		{
-			uint32_t any = 0;
-#if defined(__HIP_DEVICE_COMPILE__)
-			if(cnt <= 64u){
-				const uint64_t v = wtz_wave_sort64(lane < cnt ? ak[lane] : ~0ull);
-				const uint32_t nhi = (uint32_t)__shfl_down((int)(uint32_t)(v >> 32), 1, 64);
-				const bool tie = lane + 1 < cnt && (uint32_t)(v >> 32) == nhi;
-				(void)wtz_coop_rank(tie, &any);
-				if(!any && lane < cnt) ak[lane] = v;
-				WTZ_WAVE_SYNC();
-			} else
-#endif
-			{
-				uint32_t np2 = 64; while(np2 < cnt) np2 <<= 1;            /* cnt <= n <= np: the padding stays in front of S */
-				for(uint32_t i = cnt + lane; i < np2; i += WTZ_NLANES) ak[i] = ~0ull;
-				WTZ_WAVE_SYNC();
-				wtz_coop_sort_u64(ak, np2);
-				bool tie = false;
-				for(uint32_t i = lane; i + 1 < cnt; i += WTZ_NLANES) if((ak[i] >> 32) == (ak[i + 1] >> 32)) tie = true;
-				(void)wtz_coop_rank(tie, &any);
-				WTZ_PROF_CNT(29, 1000);
-				if(any){ WTZ_WAVE_SYNC(); (void)fill_members(); }      /* back to the S order for the exact path */
-			}
-			if(any){
-				if(had_tie && !exact){         /* (b): both orders have ties - the scan again, with the reference's swap sequence for off2 */
-					if(lane == 0){ wins.n = wins_n0; anchors.n = anchors_n0; }
-					ret = 0; me0 = -0x7FFFFFFF; exact = true;
-					WTZ_PROF_CNT(30, 1000);
-					goto retry_scan;
+			if(sc.big_u64 >= need) K = sc.big;
+			else {                                        /* no room in the pool either: scalar body on lane 0 */
+				uint32_t r = 0; int32_t e = -0x7FFFFFFF;
+				if(lane == 0){
+					r = wtz_scan_windows(rs, dir, beg, end, bound, wins, anchors, sc, zsize, kwin, zovl);
+					for(uint32_t a = 0; a < r; a++){ const int32_t e0 = wins.a[wins.n + a - r].end[0]; if(e < e0) e = e0; }
 				}
-				const unsigned long long px = WTZ_PROF_T(); (void)px;
-				if(lane == 0) wtz_sort_exact(ak, (size_t)cnt, wtz_gt_hi32());
-				WTZ_PROF_ADD(27, px); WTZ_PROF_CNT(31, 1000);
-				WTZ_WAVE_SYNC();
+				*max_e0 = (int32_t)wtz_coop_bcast32((uint32_t)e);
+				return wtz_coop_bcast32(r);
 			}
 		}
-		uint32_t stop = 0; uint64_t abase = 0;
-		if(lane == 0){ if(!anchors.reserve(size + cnt)) stop = 1; else abase = (uint64_t)(uintptr_t)anchors.a; }
-		if(wtz_coop_bcast32(stop)) break;
-		abase = wtz_coop_bcast64(abase);
-		wtz_zhit_t *A = (wtz_zhit_t*)(uintptr_t)abase + size;
-		uint32_t ol = 0, b0 = 0x7FFFFFFFu, e0 = 0, b1 = 0x7FFFFFFFu, e1 = 0;
-		for(uint32_t c0 = 0; c0 < cnt; c0 += WTZ_NLANES){
-			const uint32_t k = c0 + lane; uint32_t add = 0;
-			if(k < cnt){
-				const wtz_zhit_t p = S[(uint32_t)ak[k]];
-				A[k] = p;
-				uint32_t lst = 0; if(k){ const wtz_zhit_t q = S[(uint32_t)ak[k - 1]]; lst = ZH_OFF1(q) + ZH_LEN1(q); }
-				const uint32_t o1 = ZH_OFF1(p), x1 = o1 + ZH_LEN1(p), o2 = ZH_OFF2(p), x2 = o2 + ZH_LEN2(p);
-				add = (o1 > lst) ? ZH_LEN1(p) : x1 - lst;
-				b0 = o1 < b0 ? o1 : b0; e0 = x1 > e0 ? x1 : e0; b1 = o2 < b1 ? o2 : b1; e1 = x2 > e1 ? x2 : e1;
-			}
-			uint32_t tot; (void)wtz_coop_excl_scan(add, &tot); ol += tot;
-		}
-		b0 = wtz_coop_min32(b0); b1 = wtz_coop_min32(b1); e0 = ~wtz_coop_min32(~e0); e1 = ~wtz_coop_min32(~e1);
-		if(ol * 2 < zovl) continue;
-		if(ret && ((int32_t)e1 <= (int32_t)((uint32_t)last_end1 + kwin / 3) && ol <= last_ovl)) continue;
-		if(lane == 0){
-			wtz_win_t w;
-			w.pb2 = 0; w.closed = 0; w.dir = (uint8_t)dir; w.pad = 0;
-			w.beg[0] = (int32_t)b0; w.beg[1] = (int32_t)b1; w.end[0] = (int32_t)e0; w.end[1] = (int32_t)e1;
-			anchors.n = size + cnt;
-			w.anchors[0] = size; w.anchors[1] = anchors.n;
-			w.ovl = WTZ_OVL29(ol);
-			if(!wins.push(w)) stop = 1;                /* pool exhausted: count only what is in the vector */
-		}
-		if(wtz_coop_bcast32(stop)) break;
-		ret++;
-		last_end1 = (int32_t)e1; last_ovl = WTZ_OVL29(ol);
-		if(me0 < (int32_t)e0) me0 = (int32_t)e0;
-		WTZ_WAVE_SYNC();
 	}
-	WTZ_PROF_ADD(20, pw4);
-	WTZ_WAVE_SYNC();
-	*max_e0 = (int32_t)wtz_coop_bcast32((uint32_t)me0);
-	return wtz_coop_bcast32(ret);
+	return wtz_scan_windows_rest(rs, dir, beg, end, bound, wins, anchors, sc, zsize, kwin, zovl, max_e0, n, pw0, K);
 }
 
 WTZ_HD uint32_t wtz_merge_windows_coop(const wtz_zhit_t *rs, uint32_t n_rs, uint32_t dir, wtz_vec<wtz_win_t> &wins, wtz_vec<wtz_zhit_t> &anchors,

@@ -62,6 +62,23 @@ def test_host_logic_on_emulated_device(name, emul_exe, tmp_path):
     assert md5 == case["md5_full"] and cont == case["md5_contained"]
 
 
+def test_repeat_rich_window_scans_on_the_pool_workspace(emul_exe, oracle_exe, tmp_path):
+    """Tandem arrays + dispersed repeats: thousands of matches of one strand inside one 800-column window - scans that do not fit the wave's LDS slice and run the
+    wave-parallel body on a workspace in the pool (3 405 such scans on this input, up to 3 640 matches).  Output == the oracle's."""
+    import hashlib
+    from smartdenovo_amd import synth
+    names, seqs = synth.synth_reads(60000, 8, seed=123, mean_len=9000.0, min_len=1000, repeats=True)
+    fa = os.path.join(str(tmp_path), "rep.fa"); synth.write_fasta(fa, names, seqs)
+    md5 = {}
+    for tag, exe in (("emul", emul_exe), ("oracle", oracle_exe)):
+        out = os.path.join(str(tmp_path), tag + ".ovl")
+        r = subprocess.run([exe, "-i", fa, "-fo", out, "-k", "16", "-s", "200", "-m", "0.6"], capture_output=True)
+        assert r.returncode == 0, r.stderr.decode()[-2000:]
+        md5[tag] = hashlib.md5(open(out, "rb").read()).hexdigest()
+        assert open(out, "rb").read().count(b"\n") > 100
+    assert md5["emul"] == md5["oracle"]
+
+
 def test_scratch_pool_exhaustion_splits_the_batch(emul_exe, tmp_path):
     """WTZ_E_POOL path (wtzmo_main.c process_range): a pool too small for the whole batch halves it until it fits; the output
     is unchanged.  (A task that ran out of scratch once used to go on with a NULL row buffer: wtz_swmem_need is sticky now.)"""
