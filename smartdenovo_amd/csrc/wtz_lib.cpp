@@ -79,6 +79,7 @@ struct K_pack_cigars;
 struct K_pack_windows;
 struct K_pair;
 struct K_pair_dm;
+struct K_pair_zbig;
 struct K_pair_big;
 struct K_refine;
 struct K_pack_ascii;
@@ -159,6 +160,7 @@ template<typename TAG> struct wtz_occ { static constexpr int waves = 1; };
 template<> struct wtz_occ<K_winalign> { static constexpr int waves = WTZ_OCC_WINALIGN; };
 template<> struct wtz_occ<K_pair> { static constexpr int waves = WTZ_OCC_PAIR; };
 template<> struct wtz_occ<K_pair_dm> { static constexpr int waves = WTZ_OCC_PAIR_DM; };
+template<> struct wtz_occ<K_pair_zbig> { static constexpr int waves = 2; };      /* both scan bodies (168 VGPRs + spills at three waves); a handful of pairs per launch, each a long dependent chain */
 template<> struct wtz_occ<K_gap> { static constexpr int waves = WTZ_OCC_GAP; };
 /* lane-per-problem K-sw1 (wtz_sw_lane.h): the band lives in 2 x (NC + 1) VGPRs */
 #ifndef WTZ_OCC_LDP
@@ -1245,7 +1247,11 @@ extern "C" int wtz_pairs_seed(wtz_ctx_t *c, const uint32_t *qid, const uint32_t 
 			uint64_t t = b;
 			if(b >= nh64){ const uint64_t b2 = b - nh64; t = b2; if(xg){ const uint64_t per = 8ull * xg, full = n64 / per * per; if(b2 < full){ const uint64_t r = b2 % per; t = b2 - r + (r & 7u) * xg + (r >> 3); } } t += nh64; }
 			if(d_ord) t = d_ord[t];
-			wtz_task_pair<0>((uint32_t)t, V, dq, dc, dr); }, WTZ_PAIR_LDS_BYTES));
+#ifdef WTZ_PAIR_TWO_LAUNCH
+			wtz_task_pair<0, false>((uint32_t)t, V, dq, dc, dr); }, WTZ_PAIR_LDS_BYTES));       /* experiment: pairs with ranges beyond the LDS slice are marked and finished by K_pair_zbig */
+#else
+			wtz_task_pair<0, true>((uint32_t)t, V, dq, dc, dr); }, WTZ_PAIR_LDS_BYTES));
+#endif
 	}
 #endif
 #if defined(WTZ_DEBUG_CRUMBS) && !defined(WTZ_EMUL)
@@ -1267,6 +1273,25 @@ extern "C" int wtz_pairs_seed(wtz_ctx_t *c, const uint32_t *qid, const uint32_t 
 	{ const double ms1 = t1.stop(); if(c->env_profile) fprintf(stderr, "[pair-profile] K_pair first launch: %u pairs, %.1f ms\n", n, ms1); }
 	c->n_pairs = n; c->h_pairres.resize(n); c->have_pairs = true;
 	CHK(dev_d2h(c->h_pairres.data(), c->d_pairres, (size_t)n * sizeof(wtz_pairres_t)));
+#ifndef WTZ_EMUL
+	if(!c->P.dot_matrix){
+		/* zmo pairs with a window range that does not fit the LDS slice (hundreds of matches of one strand inside one window: repeats) were left by the first launch:
+		 * the launch that carries the pool-workspace body of the scan finishes them (round 3 ran those scans on lane 0 and the heaviest pair bounded its launch) */
+		std::vector<uint32_t> list;
+		for(uint32_t i = 0; i < n; i++) if(c->h_pairres[i].gate && c->h_pairres[i].dm_dir == WTZ_PAIR_NEEDS_ZBIG && !c->h_pairres[i].bad) list.push_back(i);
+		if(!list.empty()){
+			uint32_t *d_list = NULL; CHK(dev_alloc((void**)&d_list, list.size() * 4)); CHK(dev_h2d(d_list, list.data(), list.size() * 4));
+			wtz_timer tt; tt.start();
+			STAGE(c, "K_pair_zbig");
+			CHK(wtz_launch_coop<K_pair_zbig>(0, list.size(), [=] WTZ_LAMBDA (uint64_t t){ wtz_task_pair<0, true>(d_list[t], V, dq, dc, dr); }, WTZ_PAIR_LDS_BYTES));
+			CHK(dev_sync());
+			const double ms_t = tt.stop();
+			dev_free(d_list);
+			CHK(dev_d2h(c->h_pairres.data(), c->d_pairres, (size_t)n * sizeof(wtz_pairres_t)));
+			if(c->env_profile) fprintf(stderr, "[pair-profile] zmo pairs with ranges beyond the LDS slice: %zu of %u, %.1f ms\n", list.size(), n, ms_t);
+		}
+	}
+#endif
 	if(c->P.dot_matrix){
 		/* pairs whose strand images exceed the LDS slice of K_pair are finished by launches with larger slices: few pairs,
 		 * but they are the long ones that would otherwise bound the batch from a single lane */

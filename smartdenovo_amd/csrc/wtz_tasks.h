@@ -57,7 +57,10 @@ __device__ unsigned int *wtz_crumbs = NULL;
 /* all lanes of the wavefront enter; the z-mer matching is cooperative, the order-sensitive remainder runs on lane 0 */
 /* ENGINE: 0 = windows + chain (zmo), 1 = dot matrix (dmo), -1 = decided at run time (host emulation).  One kernel per engine (round 3): a zmo launch does not
  * carry the registers and code of the dot-matrix path and vice versa. */
-template<int ENGINE = -1>
+/* ZBIG (zmo): the window scans may use a workspace in the pool when a range does not fit the LDS slice.  The first launch runs without that body (its registers
+ * and code would be carried by every pair) and marks the few pairs that need it (dm_dir = WTZ_PAIR_NEEDS_ZBIG); a second launch finishes them. */
+#define WTZ_PAIR_NEEDS_ZBIG (-3)
+template<int ENGINE = -1, bool ZBIG = true>
 WTZ_HD void wtz_task_pair(uint32_t t, const wtz_env_t &V, const uint32_t *qid, const uint32_t *cid, wtz_pairres_t *res){
 	const wtz_params_t *P = V.P;
 	const bool dm = ENGINE < 0 ? (P->dot_matrix != 0) : (ENGINE == 1);
@@ -134,14 +137,19 @@ WTZ_HD void wtz_task_pair(uint32_t t, const wtz_env_t &V, const uint32_t *qid, c
 	sc.lds = emul_lds;
 #endif
 	sc.lds_u64 = WTZ_PAIR_LDS_BYTES / 8;
-	sc.big = NULL; sc.big_u64 = 0;
+	sc.big = NULL; sc.big_u64 = 0; sc.need_big = 0;
 	for(uint32_t dir = 0; dir < 2; dir++){
 		wtz_vec<wtz_win_t> wins; wtz_vec<wtz_zhit_t> anchors;
 		wins.a = NULL; wins.n = wins.cap = 0; wins.pool = V.pool; wins.bad = 0;
 		anchors.a = NULL; anchors.n = anchors.cap = 0; anchors.pool = V.pool; anchors.bad = 0;
 		if(lane == 0){ wins.init(V.pool, 16); anchors.init(V.pool, n + 16); }
 		WTZ_CRUMB(t, (6 + dir) | (n << 8));
-		const uint32_t nw = wtz_merge_windows_coop(hits, n, dir, wins, anchors, sc, P->zsize, P->kwin, P->kstep, P->zovl);
+		const uint32_t nw = wtz_merge_windows_coop<ZBIG>(hits, n, dir, wins, anchors, sc, P->zsize, P->kwin, P->kstep, P->zovl);
+		if(!ZBIG && sc.need_big){          /* a range that does not fit the LDS slice: the whole pair again in the launch with the pool-workspace body */
+			if(lane == 0){ wtz_pairres_t r2; memset(&r2, 0, sizeof r2); r2.n_hits = r.n_hits; r2.gate = 1; r2.dm_dir = WTZ_PAIR_NEEDS_ZBIG; res[t] = r2; }
+			WTZ_CRUMB(t, 0xFF);
+			return;
+		}
 		if(lane != 0) continue;
 		WTZ_CRUMB(t, (8 + dir) | (n << 8));
 		if(wins.bad || anchors.bad){ r.bad = 1; continue; }

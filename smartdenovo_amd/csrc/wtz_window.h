@@ -308,8 +308,9 @@ WTZ_HD int32_t wtz_median(int32_t *rs, int32_t size){
 /* scratch of one (pair,strand) window scan: all sized by the number of matches of the pair.  `lds` (may be NULL) is the
  * wave's LDS slice: the small order-sensitive sorts / the quick-select run there when they fit - they are chains of
  * dependent loads on a single lane, so it is the access latency (LDS ~64 clk vs L2 ~500 clk) that matters */
-/* `big`: workspace in the pool for the scans whose matches do not fit the LDS slice (allocated by the first such scan of the pair, grown on demand) */
-typedef struct { uint32_t *ts; int32_t *as; uint32_t *wb, *we, *wo; uint64_t *tk; wtz_zhit_t *ztmp; uint64_t *lds; uint32_t lds_u64; mutable uint64_t *big; mutable uint32_t big_u64; } wtz_winscratch_t;
+/* `big`: workspace in the pool for the scans whose matches do not fit the LDS slice (allocated by the first such scan of the pair, grown on demand);
+ * `need_big`: set by a scan of the LDS-only kernel that met such a range - the pair is finished by the launch that carries the pool-workspace body */
+typedef struct { uint32_t *ts; int32_t *as; uint32_t *wb, *we, *wo; uint64_t *tk; wtz_zhit_t *ztmp; uint64_t *lds; uint32_t lds_u64; mutable uint64_t *big; mutable uint32_t big_u64; mutable uint32_t need_big; } wtz_winscratch_t;
 struct wtz_gt_hi32 { WTZ_HDM bool operator()(uint64_t a, uint64_t b) const { return (uint32_t)(a >> 32) > (uint32_t)(b >> 32); } };
 
 WTZ_HD uint32_t wtz_scan_windows(const wtz_zhit_t *rs, uint32_t dir, uint32_t beg, uint32_t end, int32_t bound,
@@ -487,12 +488,15 @@ WTZ_HD void wtz_hitcur_get(wtz_hitcur_t &c, const wtz_zhit_t *rs, uint32_t lim, 
 #ifndef WTZ_SCAN_FN
 #define WTZ_SCAN_FN WTZ_HD
 #endif
+template<bool K_LDS>
 WTZ_SCAN_REST_FN uint32_t wtz_scan_windows_rest(const wtz_zhit_t *rs, uint32_t dir, uint32_t beg, uint32_t end, int32_t bound,
-		wtz_vec<wtz_win_t> &wins, wtz_vec<wtz_zhit_t> &anchors, const wtz_winscratch_t &sc, uint32_t zsize, uint32_t kwin, uint32_t zovl, int32_t *max_e0, uint32_t n, unsigned long long pw0, uint64_t *K){
+		wtz_vec<wtz_win_t> &wins, wtz_vec<wtz_zhit_t> &anchors, const wtz_winscratch_t &sc, uint32_t zsize, uint32_t kwin, uint32_t zovl, int32_t *max_e0, uint32_t n, unsigned long long pw0, uint64_t *KB){
 	const uint32_t lane = WTZ_LANE;
-	/* K = the LDS slice, or the pool workspace of a scan that does not fit it: the same code, the orderings then go through the LDS slice as a window */
+	/* K = the LDS slice (K_LDS: the address space stays static, DS instructions), or the pool workspace of a scan that does not fit it: the same code, the
+	 * orderings then go through the LDS slice as a window */
+	uint64_t *K = K_LDS ? sc.lds : KB;
 	auto sort_keys = [&](uint64_t *w, uint32_t npw){
-		if(w == sc.lds || sc.lds == NULL){ wtz_coop_sort_u64(w, npw); return; }
+		if(K_LDS || sc.lds == NULL){ wtz_coop_sort_u64(w, npw); return; }
 		uint32_t ln = 128; while(ln * 2 <= sc.lds_u64) ln <<= 1;
 		wtz_coop_sort_u64_windowed(w, npw, sc.lds_u64 >= 128u ? sc.lds : NULL, ln);
 	};
@@ -742,6 +746,14 @@ retry_scan:
 	return wtz_coop_bcast32(ret);
 }
 
+/* the pool-workspace instance as a function of its own: it is reached by a handful of pairs per launch, and inlined it doubled the scan's code inside the merge
+ * loop (218 spilled registers, K_pair 777 -> 1 428 ms) */
+WTZ_HDN uint32_t wtz_scan_windows_rest_pool(const wtz_zhit_t *rs, uint32_t dir, uint32_t beg, uint32_t end, int32_t bound,
+		wtz_vec<wtz_win_t> &wins, wtz_vec<wtz_zhit_t> &anchors, const wtz_winscratch_t &sc, uint32_t zsize, uint32_t kwin, uint32_t zovl, int32_t *max_e0, uint32_t n, unsigned long long pw0, uint64_t *KB){
+	return wtz_scan_windows_rest<false>(rs, dir, beg, end, bound, wins, anchors, sc, zsize, kwin, zovl, max_e0, n, pw0, KB);
+}
+
+template<bool ZBIG>
 WTZ_SCAN_FN uint32_t wtz_scan_windows_coop(const wtz_zhit_t *rs, uint32_t dir, uint32_t beg, uint32_t end, int32_t bound,
 		wtz_vec<wtz_win_t> &wins, wtz_vec<wtz_zhit_t> &anchors, const wtz_winscratch_t &sc, uint32_t zsize, uint32_t kwin, uint32_t zovl, int32_t *max_e0){
 	const uint32_t lane = WTZ_LANE;
@@ -877,7 +889,9 @@ WTZ_SCAN_FN uint32_t wtz_scan_windows_coop(const wtz_zhit_t *rs, uint32_t dir, u
 		if(K == NULL || np0 + 2 * n + 2 > sc.lds_u64){
 			/* does not fit the LDS slice (a few hundred matches of one strand inside one window: repeats): the same wave-parallel scan on a workspace in the pool.
 			 * (Round 3 ran these on lane 0 - a sort of thousands of matches by dependent memory accesses; the heaviest pair of a range took half of its launch.) */
+			if(!ZBIG){ sc.need_big = 1; *max_e0 = -0x7FFFFFFF; return 0; }
 			const uint32_t need = np0 + 2 * n + 2;
+#ifndef WTZ_PAIR_NO_POOL_SCAN
 			if(sc.big_u64 < need){
 				const uint32_t cap = need > 2 * sc.big_u64 ? need : 2 * sc.big_u64;
 				uint64_t pa = 0;
@@ -885,8 +899,23 @@ WTZ_SCAN_FN uint32_t wtz_scan_windows_coop(const wtz_zhit_t *rs, uint32_t dir, u
 				pa = wtz_coop_bcast64(pa);
 				if(pa){ sc.big = (uint64_t*)(uintptr_t)pa; sc.big_u64 = cap; }
 			}
-			if(sc.big_u64 >= need) K = sc.big;
-			else {                                        /* no room in the pool either: scalar body on lane 0 */
+#endif
+#ifdef WTZ_PAIR_NO_POOL_SCAN
+			if(false){
+#else
+			if(sc.big_u64 >= need){
+#endif
+				uint64_t *KB = sc.big; uint32_t m = 0;
+				for(uint32_t b0 = beg; b0 < end; b0 += WTZ_NLANES){
+					const uint32_t idx = b0 + lane;
+					bool keep = false; uint32_t o2 = 0;
+					if(idx < end){ const uint32_t o1 = rs[idx].o1; o2 = rs[idx].o2; keep = (((o1 ^ o2) >> 31) == dir) && ((int32_t)(o1 & 0x7FFFFFFFu) >= bound); }
+					uint32_t tot; const uint32_t pos = wtz_coop_rank(keep, &tot);
+					if(keep) KB[m + pos] = ((uint64_t)(o2 & 0x7FFFFFFFu) << 32) | idx;
+					m += tot;
+				}
+				if constexpr(ZBIG) return wtz_scan_windows_rest_pool(rs, dir, beg, end, bound, wins, anchors, sc, zsize, kwin, zovl, max_e0, n, pw0, KB);
+			} else {                                      /* no room in the pool either: scalar body on lane 0 */
 				uint32_t r = 0; int32_t e = -0x7FFFFFFF;
 				if(lane == 0){
 					r = wtz_scan_windows(rs, dir, beg, end, bound, wins, anchors, sc, zsize, kwin, zovl);
@@ -897,9 +926,10 @@ WTZ_SCAN_FN uint32_t wtz_scan_windows_coop(const wtz_zhit_t *rs, uint32_t dir, u
 			}
 		}
 	}
-	return wtz_scan_windows_rest(rs, dir, beg, end, bound, wins, anchors, sc, zsize, kwin, zovl, max_e0, n, pw0, K);
+	return wtz_scan_windows_rest<true>(rs, dir, beg, end, bound, wins, anchors, sc, zsize, kwin, zovl, max_e0, n, pw0, NULL);
 }
 
+template<bool ZBIG>
 WTZ_HD uint32_t wtz_merge_windows_coop(const wtz_zhit_t *rs, uint32_t n_rs, uint32_t dir, wtz_vec<wtz_win_t> &wins, wtz_vec<wtz_zhit_t> &anchors,
 		const wtz_winscratch_t &sc, uint32_t zsize, uint32_t kwin, uint32_t kstep, uint32_t zovl){
 	const uint32_t P_off1 = 0x1FFFFFu, P_len1 = 0x3FFu, lim = n_rs + 1;
@@ -922,7 +952,9 @@ WTZ_HD uint32_t wtz_merge_windows_coop(const wtz_zhit_t *rs, uint32_t n_rs, uint
 		if(p_off1 > p0_off1 + kwin){
 			if(ol >= zovl){
 				int32_t me0 = 0;
-				if((n = wtz_scan_windows_coop(rs, dir, j, i, (int32_t)wlst, wins, anchors, sc, zsize, kwin, zovl, &me0))){
+				n = wtz_scan_windows_coop<ZBIG>(rs, dir, j, i, (int32_t)wlst, wins, anchors, sc, zsize, kwin, zovl, &me0);
+				if(!ZBIG && sc.need_big) return 0;
+				if(n){
 					if((int32_t)wlst < me0 + 20) wlst = (uint32_t)(me0 + 20);
 					ret += n;
 					p0_off1 = p_off1; p0_len1 = p_len1; ol = p_len1; lst = p_off1 + p_len1; j = i;
