@@ -20,11 +20,13 @@
 #define WTZ_HD __host__ __device__ __forceinline__
 #define WTZ_HDM __host__ __device__ __forceinline__
 #define WTZ_HDN __host__ __device__ __noinline__
+#define WTZ_DN  __device__ __noinline__
 #define WTZ_D  __device__ __forceinline__
 #else
 #define WTZ_HD static inline
 #define WTZ_HDM inline
 #define WTZ_HDN static
+#define WTZ_DN  static
 #define WTZ_D  static inline
 #endif
 
@@ -143,10 +145,13 @@ WTZ_D uint32_t wtz_coop_excl_scan(uint32_t v, uint32_t *total){
 	uint32_t x = v; const uint32_t lane = WTZ_LANE;
 	#pragma unroll
 	for(int d = 1; d < 64; d <<= 1){ uint32_t y = __shfl_up(x, d, 64); if(lane >= (uint32_t)d) x += y; }
-	*total = __shfl(x, 63, 64);
+	*total = (uint32_t)__builtin_amdgcn_readlane((int)x, 63);      /* v_readlane: known uniform to the compiler (a shuffle's result is not, and branches on it become masked regions) */
 	return x - v;
 }
-WTZ_D uint64_t wtz_coop_bcast64(uint64_t v){ return (uint64_t)__shfl((unsigned long long)v, 0, 64); }
+WTZ_D uint64_t wtz_coop_bcast64(uint64_t v){      /* two v_readfirstlane (like wtz_coop_bcast32: every caller runs with all lanes active): the result is KNOWN uniform to the compiler, a shuffle's is not */
+	const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+	return ((uint64_t)hi << 32) | lo;
+}
 WTZ_D uint32_t wtz_coop_bcast32(uint32_t v){ return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 /* rank of this lane among the lanes whose predicate holds (ballot + mbcnt: no cross-lane data movement), and their number */
 WTZ_D uint32_t wtz_coop_rank(bool keep, uint32_t *total){
@@ -188,7 +193,7 @@ WTZ_D uint32_t wtz_wave_sort32(uint32_t v){
 /* minimum over all lanes, uniform */
 WTZ_D uint32_t wtz_coop_min32(uint32_t v){
 	for(int d = 32; d > 0; d >>= 1){ const uint32_t y = (uint32_t)__shfl_xor((int)v, d, 64); v = y < v ? y : v; }
-	return v;
+	return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);      /* every lane holds the minimum: tell the compiler it is uniform */
 }
 /* inclusive running maximum over the lanes */
 WTZ_D uint32_t wtz_coop_incl_max32(uint32_t v){

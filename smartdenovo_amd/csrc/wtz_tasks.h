@@ -76,10 +76,14 @@ WTZ_HD void wtz_task_pair(uint32_t t, const wtz_env_t &V, const uint32_t *qid, c
 	WTZ_CRUMB(t, 1);
 	const bool aux = P->aux_strand != 0;                     /* align_hzmaux's form of the pair stages (wtgbo): strand 0 only, no n_hits gate */
 #if defined(__HIP_DEVICE_COMPILE__)
-	const bool ok = wtz_zmatch_coop(V.ZQ, V.Z, q, c, V.R.rdlen[c], P->max_kmer_var, V.pool, &hits, &n, aux, (uint32_t*)wtz_wave_scratch(), dm ? (uint32_t)WTZ_PAIR_DM_LDS_BYTES : (uint32_t)WTZ_PAIR_LDS_BYTES);      /* the LDS slice is free until the first ordering */
+	const bool ok0 = wtz_zmatch_coop(V.ZQ, V.Z, q, c, V.R.rdlen[c], P->max_kmer_var, V.pool, &hits, &n, aux, (uint32_t*)wtz_wave_scratch(), dm ? (uint32_t)WTZ_PAIR_DM_LDS_BYTES : (uint32_t)WTZ_PAIR_LDS_BYTES);      /* the LDS slice is free until the first ordering */
 #else
-	const bool ok = wtz_zmatch_coop(V.ZQ, V.Z, q, c, V.R.rdlen[c], P->max_kmer_var, V.pool, &hits, &n, aux);
+	const bool ok0 = wtz_zmatch_coop(V.ZQ, V.Z, q, c, V.R.rdlen[c], P->max_kmer_var, V.pool, &hits, &n, aux);
 #endif
+	/* the same in every lane by construction; said explicitly, the early returns below are scalar branches and the window merge after them is not a masked region */
+	const bool ok = wtz_coop_bcast32(ok0 ? 1u : 0u) != 0;
+	n = wtz_coop_bcast32(n);
+	hits = (wtz_zhit_t*)(uintptr_t)wtz_coop_bcast64((uint64_t)(uintptr_t)hits);
 	const uint64_t tk1 = WTZ_TICK();
 	WTZ_CRUMB(t, 2 | (n << 8));
 	wtz_zhit_t *sorted = NULL;
@@ -89,7 +93,8 @@ WTZ_HD void wtz_task_pair(uint32_t t, const wtz_env_t &V, const uint32_t *qid, c
 		int pbad = 0;
 		if(dm) sorted = wtz_sort_hits_wave<1>(hits, n, V.pool, (uint64_t*)wtz_wave_scratch(), WTZ_PAIR_DM_LDS_BYTES / 8, &pbad);
 		else              sorted = wtz_sort_hits_wave<0>(hits, n, V.pool, (uint64_t*)wtz_wave_scratch(), WTZ_PAIR_LDS_BYTES / 8, &pbad);
-		if(pbad) r.bad = 1;
+		if(wtz_coop_bcast32((uint32_t)pbad)) r.bad = 1;
+		sorted = (wtz_zhit_t*)(uintptr_t)wtz_coop_bcast64((uint64_t)(uintptr_t)sorted);
 	}
 #endif
 	const uint32_t lane = WTZ_LANE;
@@ -144,7 +149,9 @@ WTZ_HD void wtz_task_pair(uint32_t t, const wtz_env_t &V, const uint32_t *qid, c
 		anchors.a = NULL; anchors.n = anchors.cap = 0; anchors.pool = V.pool; anchors.bad = 0;
 		if(lane == 0){ wins.init(V.pool, 16); anchors.init(V.pool, n + 16); }
 		WTZ_CRUMB(t, (6 + dir) | (n << 8));
+		const unsigned long long ptm = WTZ_PROF_T(); (void)ptm;
 		const uint32_t nw = wtz_merge_windows_coop<ZBIG>(hits, n, dir, wins, anchors, sc, P->zsize, P->kwin, P->kstep, P->zovl);
+		WTZ_PROF_ADD(63, ptm);      /* profiler: 63 = merge loop incl. its scans, 62 = chain + compaction */
 		if(!ZBIG && sc.need_big){          /* a range that does not fit the LDS slice: the whole pair again in the launch with the pool-workspace body */
 			if(lane == 0){ wtz_pairres_t r2; memset(&r2, 0, sizeof r2); r2.n_hits = r.n_hits; r2.gate = 1; r2.dm_dir = WTZ_PAIR_NEEDS_ZBIG; res[t] = r2; }
 			WTZ_CRUMB(t, 0xFF);
@@ -154,6 +161,7 @@ WTZ_HD void wtz_task_pair(uint32_t t, const wtz_env_t &V, const uint32_t *qid, c
 		WTZ_CRUMB(t, (8 + dir) | (n << 8));
 		if(wins.bad || anchors.bad){ r.bad = 1; continue; }
 		if(nw == 0) continue;
+		const unsigned long long ptc = WTZ_PROF_T(); (void)ptc;
 		int32_t *mem = (int32_t*)wtz_pool_alloc(V.pool, (size_t)wins.n * 8 + 8);
 		if(mem == NULL){ r.bad = 1; continue; }
 		r.ovl[dir] = WTZ_OVL29(wtz_chain_windows(wins.a, wins.n, P->W, mem));
@@ -162,6 +170,7 @@ WTZ_HD void wtz_task_pair(uint32_t t, const wtz_env_t &V, const uint32_t *qid, c
 		uint32_t k = 0;
 		for(uint32_t j = 0; j < wins.n; j++){ if(wins.a[j].closed) continue; wins.a[k++] = wins.a[j]; }
 		r.nwin[dir] = k; r.win[dir] = wins.a; r.anchors[dir] = anchors.a; r.nanchors[dir] = anchors.n;
+		WTZ_PROF_ADD(62, ptc);
 	}
 	if(lane != 0) return;
 	{ const uint64_t tk3 = WTZ_TICK(); r.tick[0] = (uint32_t)((tk1 - tk0) >> 10); r.tick[1] = (uint32_t)((tk2 - tk1) >> 10); r.tick[2] = (uint32_t)((tk3 - tk2) >> 10); r.tick[3] = (uint32_t)((tk3 - tk0) >> 10); }

@@ -748,7 +748,7 @@ retry_scan:
 
 /* the pool-workspace instance as a function of its own: it is reached by a handful of pairs per launch, and inlined it doubled the scan's code inside the merge
  * loop (218 spilled registers, K_pair 777 -> 1 428 ms) */
-WTZ_HDN uint32_t wtz_scan_windows_rest_pool(const wtz_zhit_t *rs, uint32_t dir, uint32_t beg, uint32_t end, int32_t bound,
+WTZ_DN uint32_t wtz_scan_windows_rest_pool(const wtz_zhit_t *rs, uint32_t dir, uint32_t beg, uint32_t end, int32_t bound,
 		wtz_vec<wtz_win_t> &wins, wtz_vec<wtz_zhit_t> &anchors, const wtz_winscratch_t &sc, uint32_t zsize, uint32_t kwin, uint32_t zovl, int32_t *max_e0, uint32_t n, unsigned long long pw0, uint64_t *KB){
 	return wtz_scan_windows_rest<false>(rs, dir, beg, end, bound, wins, anchors, sc, zsize, kwin, zovl, max_e0, n, pw0, KB);
 }
@@ -759,6 +759,8 @@ WTZ_SCAN_FN uint32_t wtz_scan_windows_coop(const wtz_zhit_t *rs, uint32_t dir, u
 	const uint32_t lane = WTZ_LANE;
 	uint64_t *K = sc.lds;
 	uint32_t n = 0;
+	beg = wtz_coop_bcast32(beg); end = wtz_coop_bcast32(end); bound = (int32_t)wtz_coop_bcast32((uint32_t)bound); dir = wtz_coop_bcast32(dir);      /* uniform by construction: scalar loop bounds */
+	zsize = wtz_coop_bcast32(zsize); kwin = wtz_coop_bcast32(kwin); zovl = wtz_coop_bcast32(zovl);
 	const unsigned long long pw0 = WTZ_PROF_T(); (void)pw0;
 	/* ---- strand / bound filter (the prefix skip of hzm_aln.h:425-431 is the same predicate: off1 is non-decreasing) ---- */
 	constexpr uint32_t RC = 4;                         /* a range of up to RC matches per lane is read ONCE: count, early-exit bound and key fill run on the off2 values kept in registers */
@@ -914,7 +916,11 @@ WTZ_SCAN_FN uint32_t wtz_scan_windows_coop(const wtz_zhit_t *rs, uint32_t dir, u
 					if(keep) KB[m + pos] = ((uint64_t)(o2 & 0x7FFFFFFFu) << 32) | idx;
 					m += tot;
 				}
-				if constexpr(ZBIG) return wtz_scan_windows_rest_pool(rs, dir, beg, end, bound, wins, anchors, sc, zsize, kwin, zovl, max_e0, n, pw0, KB);
+				if constexpr(ZBIG){       /* a real call: its results come back in vector registers - say again that they are uniform */
+					const uint32_t r = wtz_scan_windows_rest_pool(rs, dir, beg, end, bound, wins, anchors, sc, zsize, kwin, zovl, max_e0, n, pw0, KB);
+					*max_e0 = (int32_t)wtz_coop_bcast32((uint32_t)*max_e0);
+					return wtz_coop_bcast32(r);
+				}
 			} else {                                      /* no room in the pool either: scalar body on lane 0 */
 				uint32_t r = 0; int32_t e = -0x7FFFFFFF;
 				if(lane == 0){
@@ -932,6 +938,9 @@ WTZ_SCAN_FN uint32_t wtz_scan_windows_coop(const wtz_zhit_t *rs, uint32_t dir, u
 template<bool ZBIG>
 WTZ_HD uint32_t wtz_merge_windows_coop(const wtz_zhit_t *rs, uint32_t n_rs, uint32_t dir, wtz_vec<wtz_win_t> &wins, wtz_vec<wtz_zhit_t> &anchors,
 		const wtz_winscratch_t &sc, uint32_t zsize, uint32_t kwin, uint32_t kstep, uint32_t zovl){
+	/* every value this loop branches on is the same in all lanes - say so (v_readfirstlane): without it the compiler keeps the cursors in vector registers and
+	 * runs each of the ~4 000 iterations per pair through exec-mask save / restore sequences (round 4's profile: this loop, not the scans, was 55 % of K_pair) */
+	n_rs = wtz_coop_bcast32(n_rs); dir = wtz_coop_bcast32(dir); zsize = wtz_coop_bcast32(zsize); kwin = wtz_coop_bcast32(kwin); kstep = wtz_coop_bcast32(kstep); zovl = wtz_coop_bcast32(zovl);
 	const uint32_t P_off1 = 0x1FFFFFu, P_len1 = 0x3FFu, lim = n_rs + 1;
 	uint32_t i, j, n, ol, ol2, lst, wlst, s, t, ret, o1, o2, ll;
 	uint32_t p_off1, p_len1, p0_off1, p0_len1, p1_off1, p1_len1;
