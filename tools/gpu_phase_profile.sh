@@ -2,7 +2,7 @@
 # Where the pair kernels spend their wave time: the phase-profiler build (-DWTZ_PROFILE: clock ticks per slot, accumulated in LDS by lane 0 of every task) run for one
 # step of each engine.  Build the variant first (no GPU needed):  tools/build_variant.sh prof -DWTZ_PROFILE
 # usage (GPU box): tools/gpu_phase_profile.sh <tag>    -> gpurun_out/<tag>/slots_{dmo,zmo}.err; slot numbers are named where WTZ_PROF_ADD / WTZ_PROF_CNT use them
-# (dmo denoise: wtz_dotmatrix.h; zmo window scans: wtz_window.h; K-sw3 jobs: wtz_sw_wave.h)
+# (dmo denoise: wtz_dotmatrix.h; zmo window scans: wtz_window.h 12, 16-31; merge loop incl. scans 63 and chain 62: wtz_tasks.h; K-sw3 jobs: wtz_sw_wave.h)
 R=$GRAFT_REPO_ROOT; [ -z "$R" ] && R=$(pwd)
 O=$R/gpurun_out/${1:-phase}; mkdir -p $O
 export TMPDIR=/tmp
