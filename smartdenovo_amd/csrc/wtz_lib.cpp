@@ -225,20 +225,55 @@ template<typename TAG, typename F> static int wtz_launch_wave(hipStream_t st, ui
 /* transient device buffers come from a per-context arena (host-side bump pointer over one persistent allocation, released
  * stack-wise when the API call returns): no hipMalloc/hipFree - and therefore no device-wide synchronisation - on the batch
  * path, which is what lets two contexts overlap.  Requests that do not fit fall back to hipMalloc and are freed at release. */
-struct wtz_arena { uint8_t *base; size_t cap, top; std::vector<void*> overflow; };
+/* Overflow buffers are not given back to the driver when the call returns: they are kept (up to WTZ_ARENA_CACHE_BYTES) for the next request of about that size.  The
+ * index builds of a 1.2 Gbp read set take 2.4 + 2.4 + 1.2 GB of sort buffers beyond the arena; hipFree + hipMalloc of those cost 30 ms on one box and 850 ms on
+ * another (every repeat of the step), and each hipFree is a device-wide synchronisation. */
+#define WTZ_ARENA_CACHE_BYTES ((size_t)16 << 30)
+struct wtz_arena { uint8_t *base; size_t cap, top; std::vector<void*> overflow; std::vector<size_t> overflow_bytes; std::vector<std::pair<void*, size_t> > cache; size_t cache_bytes; };
 static thread_local wtz_arena *g_arena = NULL;
+static void arena_cache_flush(wtz_arena *a);
 static int dev_alloc(void **p, size_t n){
 	n = (n + 255) & ~(size_t)255; if(n == 0) n = 256;
 	if(g_arena && g_arena->top + n <= g_arena->cap){ *p = g_arena->base + g_arena->top; g_arena->top += n; return WTZ_OK; }
-	HIPCHK(hipMalloc(p, n));
-	if(g_arena) g_arena->overflow.push_back(*p);
+	if(g_arena){
+		for(size_t i = 0; i < g_arena->cache.size(); i++){
+			const size_t cb = g_arena->cache[i].second;
+			if(cb >= n && cb <= n + n / 8 + ((size_t)1 << 20)){
+				*p = g_arena->cache[i].first; g_arena->cache_bytes -= cb; g_arena->cache.erase(g_arena->cache.begin() + (long)i);
+				g_arena->overflow.push_back(*p); g_arena->overflow_bytes.push_back(cb); return WTZ_OK;
+			}
+		}
+	}
+	if(hipMalloc(p, n) != hipSuccess){
+		(void)hipGetLastError();
+		if(g_arena && !g_arena->cache.empty()){ (void)hipDeviceSynchronize(); arena_cache_flush(g_arena); }
+		HIPCHK(hipMalloc(p, n));
+	}
+	if(g_arena){ g_arena->overflow.push_back(*p); g_arena->overflow_bytes.push_back(n); }
 	return WTZ_OK;
 }
+static void arena_cache_flush(wtz_arena *a){ for(size_t i = 0; i < a->cache.size(); i++) (void)hipFree(a->cache[i].first); a->cache.clear(); a->cache_bytes = 0; }
 static void dev_free(void *){ /* released by the arena scope of the API call */ }
 struct wtz_arena_scope { wtz_arena *a; size_t mark; size_t nover;
 	wtz_arena_scope(wtz_arena *ar) : a(ar), mark(ar ? ar->top : 0), nover(ar ? ar->overflow.size() : 0) { g_arena = ar; }
-	~wtz_arena_scope(){ if(!a) return; if(a->overflow.size() > nover){ (void)hipStreamSynchronize(g_stream); while(a->overflow.size() > nover){ (void)hipFree(a->overflow.back()); a->overflow.pop_back(); } } a->top = mark; } };
-static int dev_alloc_persist(void **p, size_t n){ HIPCHK(hipMalloc(p, n ? n : 16)); return WTZ_OK; }
+	~wtz_arena_scope(){
+		if(!a) return;
+		if(a->overflow.size() > nover){
+			(void)hipStreamSynchronize(g_stream);
+			while(a->overflow.size() > nover){
+				void *q = a->overflow.back(); const size_t qb = a->overflow_bytes.back(); a->overflow.pop_back(); a->overflow_bytes.pop_back();
+				if(a->cache_bytes + qb <= WTZ_ARENA_CACHE_BYTES && a->cache.size() < 16){ a->cache.push_back(std::make_pair(q, qb)); a->cache_bytes += qb; }
+				else (void)hipFree(q);
+			}
+		}
+		a->top = mark;
+	} };
+static int dev_alloc_persist(void **p, size_t n){
+	if(hipMalloc(p, n ? n : 16) == hipSuccess) return WTZ_OK;
+	(void)hipGetLastError();
+	if(g_arena && !g_arena->cache.empty()){ (void)hipDeviceSynchronize(); arena_cache_flush(g_arena); }      /* the kept overflow buffers go first */
+	HIPCHK(hipMalloc(p, n ? n : 16)); return WTZ_OK;
+}
 static void dev_free_persist(void *p){ if(p) (void)hipFree(p); }
 static int dev_h2d(void *d, const void *h, size_t n){ if(n){ HIPCHK(hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, g_stream)); HIPCHK(hipStreamSynchronize(g_stream)); } return WTZ_OK; }
 static int dev_d2h(void *h, const void *d, size_t n){ if(n){ HIPCHK(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, g_stream)); HIPCHK(hipStreamSynchronize(g_stream)); } return WTZ_OK; }
@@ -340,6 +375,7 @@ struct wtz_ctx {
 	hipStream_t stream_gap = 0; hipEvent_t ev_gap_fork = 0, ev_gap_join = 0;   /* side stream of K_gap (runs beside the left extensions) */
 #endif
 	bool shares_indexes;      /* clone: reads / k-mer table / z-index belong to the parent context */
+	void *kpark_p[2]; size_t kpark_b[2], klive_b[2];      /* k-mer table [0] / seed list [1]: buffer parked for the next build, size of the live one (0: not from kalloc) */
 	wtz_arena arena;          /* transient device buffers of the API call in progress */
 	uint32_t cap_pairs, cap_items;     /* grow-only capacity of the per-batch result arrays */
 	wtz_params_t P; wtz_params_t *dP;
@@ -444,6 +480,7 @@ extern "C" int wtz_ctx_create(int device, const wtz_params_c *params, uint64_t p
 #endif
 	wtz_ctx *c = new wtz_ctx();
 	c->device = device; c->P = *params; c->dP = NULL; c->shares_indexes = false;
+	c->kpark_p[0] = c->kpark_p[1] = NULL; c->kpark_b[0] = c->kpark_b[1] = 0; c->klive_b[0] = c->klive_b[1] = 0;
 #ifndef WTZ_EMUL
 	c->stream = 0;
 #endif
@@ -466,7 +503,7 @@ extern "C" int wtz_ctx_create(int device, const wtz_params_c *params, uint64_t p
 	memset(&c->cnt, 0, sizeof c->cnt);
 	c->cap_pairs = c->cap_items = 0;
 #ifndef WTZ_EMUL
-	c->arena.base = NULL; c->arena.cap = 0; c->arena.top = 0;
+	c->arena.base = NULL; c->arena.cap = 0; c->arena.top = 0; c->arena.cache_bytes = 0;
 	{ void *ab = NULL; const size_t acap = (size_t)3 << 29;      /* 1.5 GB */
 	  if(hipMalloc(&ab, acap) == hipSuccess){ c->arena.base = (uint8_t*)ab; c->arena.cap = acap; } }
 #endif
@@ -510,7 +547,22 @@ extern "C" int wtz_ctx_create(int device, const wtz_params_c *params, uint64_t p
 }
 
 static void free_pending_index(wtz_ctx *c);
-static void free_kindex(wtz_ctx *c){ if(!c->shares_indexes){ dev_free_persist(c->ktab); dev_free_persist(c->kseeds); } c->ktab = NULL; c->kseeds = NULL; c->kmask = 0; }
+/* the table and the seed list of the previous build are kept for the next one of about the same size (a repeat of the step, the next shard of the same job) */
+static void kpark(wtz_ctx *c, int w, void *p, size_t bytes){ if(!p) return; if(c->kpark_p[w]) dev_free_persist(c->kpark_p[w]); c->kpark_p[w] = p; c->kpark_b[w] = bytes; }
+static void kflush(wtz_ctx *c){ for(int w = 0; w < 2; w++){ if(c->kpark_p[w]) dev_free_persist(c->kpark_p[w]); c->kpark_p[w] = NULL; c->kpark_b[w] = 0; } }
+static int kalloc(wtz_ctx *c, int w, void **p, size_t n){
+	if(c->kpark_p[w] && c->kpark_b[w] >= n && c->kpark_b[w] <= n + n / 8 + ((size_t)1 << 20)){ *p = c->kpark_p[w]; c->klive_b[w] = c->kpark_b[w]; c->kpark_p[w] = NULL; c->kpark_b[w] = 0; return WTZ_OK; }
+	if(c->kpark_p[w]){ dev_free_persist(c->kpark_p[w]); c->kpark_p[w] = NULL; c->kpark_b[w] = 0; }
+	int rc = dev_alloc_persist(p, n); if(rc == WTZ_OK) c->klive_b[w] = n; return rc;
+}
+static void free_kindex(wtz_ctx *c){
+	if(!c->shares_indexes){
+		if(c->klive_b[0]) kpark(c, 0, c->ktab, c->klive_b[0]); else dev_free_persist(c->ktab);
+		if(c->klive_b[1]) kpark(c, 1, c->kseeds, c->klive_b[1]); else dev_free_persist(c->kseeds);
+		c->klive_b[0] = c->klive_b[1] = 0;
+	}
+	c->ktab = NULL; c->kseeds = NULL; c->kmask = 0;
+}
 /* z-index allocation with recycling: a parked buffer of (nearly) the wanted size is taken instead of a fresh hipMalloc */
 static int zalloc(wtz_ctx::zslot_t *z, void **p, size_t n){
 	if(n == 0) n = 16;
@@ -557,11 +609,12 @@ static int reserve_items(wtz_ctx *c, uint32_t m){
 extern "C" void wtz_ctx_destroy(wtz_ctx_t *c){
 	if(!c) return;
 	{ CTX_ENTER(c); (void)dev_sync(); }
-	free_batch_storage(c); free_kindex(c); free_zindex(c);
+	free_batch_storage(c); free_kindex(c); if(!c->shares_indexes) kflush(c); free_zindex(c);
 	dev_free_persist(c->d_text);
 	dev_free_persist(c->cq_q); dev_free_persist(c->cq_nc); dev_free_persist(c->cq_cand); dev_free_persist(c->cq_bytes); dev_free_persist(c->cq_thr); dev_free_persist(c->cq_gptr);
 	free_pending_index(c);
 #ifndef WTZ_EMUL
+	arena_cache_flush(&c->arena);
 	if(c->arena.base) (void)hipFree(c->arena.base);
 #endif
 	if(!c->shares_indexes){ dev_free_persist(c->bits); dev_free_persist(c->rdoff); dev_free_persist(c->rdlen); }
@@ -766,7 +819,7 @@ extern "C" int wtz_index_build(wtz_ctx_t *c, uint32_t id_beg, uint32_t id_end, u
 	CHK(dev_h2d(d_cnt, h_cnt.data(), (np + 1) * 8));
 	lapix(2);
 	uint64_t *d_keys = NULL; uint32_t *d_vals = NULL;
-	CHK(dev_alloc((void**)&d_keys, (tot + 1) * 8)); CHK(dev_alloc_persist((void**)&d_vals, (tot + 1) * 4));
+	CHK(dev_alloc((void**)&d_keys, (tot + 1) * 8)); CHK(kalloc(c, 1, (void**)&d_vals, (tot + 1) * 4));
 	lapix(3);
 	CHK(wtz_launch<K_kfill>(0, np, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_kfill((uint32_t)t, R, d_prid, d_pjb, ksize, hk, ksave, d_cnt, d_keys, d_vals); }));
 	CHK(dev_sync());
@@ -787,7 +840,7 @@ extern "C" int wtz_index_build(wtz_ctx_t *c, uint32_t id_beg, uint32_t id_end, u
 	CHK(dev_d2h(h_stat, d_stat, 4 * 8));
 	const uint64_t n_kept = h_stat[2];
 	uint64_t cap = 1024; while(cap < n_kept * 2 + 2) cap <<= 1;
-	CHK(dev_alloc_persist((void**)&c->ktab, cap * sizeof(wtz_kslot_t))); CHK(dev_set(c->ktab, 0xFF, cap * sizeof(wtz_kslot_t)));
+	CHK(kalloc(c, 0, (void**)&c->ktab, cap * sizeof(wtz_kslot_t))); CHK(dev_set(c->ktab, 0xFF, cap * sizeof(wtz_kslot_t)));
 	c->kmask = cap - 1;
 	wtz_kslot_t *tab = c->ktab; const uint64_t kmask = c->kmask;
 	CHK(wtz_launch<K_kinsert>(0, tot, [=] WTZ_LAMBDA (uint64_t i){ wtz_task_kinsert(i, d_keys, tot, K, tab, kmask, d_stat + 2); }));
