@@ -17,8 +17,12 @@ def pmc(path):
         r[row["kernel"]] = r.get(row["kernel"], 0) + float(row["hbm_bytes_est"])
     return r
 def stats(path, steps):
+    rows = list(csv.DictReader(open(os.path.join(P, path))))
+    # the number of steps the trace covers comes from the file itself where it can: the z-mer index is built once per step (K_zrun: one launch per build at configs[2])
+    for row in rows:
+        if row["kernel"] == "K_zrun": steps = int(row["calls"])
     r = {}
-    for row in csv.DictReader(open(os.path.join(P, path))):
+    for row in rows:
         r[row["kernel"]] = r.get(row["kernel"], 0) + float(row["total_ms"]) / steps
     return r
 pz, pd = pmc("r04_yeast100_zmo_pmc_per_kernel.csv"), pmc("r04_yeast100_dmo_pmc_per_kernel.csv")
