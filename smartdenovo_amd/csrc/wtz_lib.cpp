@@ -539,7 +539,21 @@ extern "C" int wtz_ctx_create(int device, const wtz_params_c *params, uint64_t p
 	c->env_tfail_at = getenv("WTZ_TPOOL_FAIL_AT") ? (unsigned)atoi(getenv("WTZ_TPOOL_FAIL_AT")) : 0u;
 	int rc;
 	if((rc = dev_alloc_persist((void**)&c->dP, sizeof(wtz_params_t))) || (rc = dev_h2d(c->dP, &c->P, sizeof(wtz_params_t))) ||
-	   (rc = dev_alloc_persist((void**)&c->dpool, 2 * sizeof(wtz_pool_t))) || (rc = dev_alloc_persist((void**)&c->pool_base, c->pool_bytes)) || (rc = pool_reset(c))){
+	   (rc = dev_alloc_persist((void**)&c->dpool, 2 * sizeof(wtz_pool_t)))){
+		wtz_ctx_destroy(c); return rc;
+	}
+	/* a pool of the DEFAULT size is a share of what hipMemGetInfo reported a moment ago: another process on the device (parallel test workers, a second
+	 * rank) may have taken it since.  Halve and try again down to 4 GB - the pool size never changes a result (pool exhaustion splits the batch) -;
+	 * a size the caller asked for (--pool-gb) fails as it is. */
+	for(;;){
+		rc = dev_alloc_persist((void**)&c->pool_base, c->pool_bytes);
+		if(rc == WTZ_OK || pool_bytes || c->pool_bytes <= (4ull << 30)) break;
+#ifndef WTZ_EMUL
+		(void)hipGetLastError();              /* the refused allocation must not be what a later launch check reads */
+#endif
+		c->pool_bytes = (c->pool_bytes / 2) & ~(uint64_t)4095; c->main_bytes = (c->pool_bytes / 2) & ~(uint64_t)4095;
+	}
+	if(rc || (rc = pool_reset(c))){
 		wtz_ctx_destroy(c); return rc;
 	}
 	*out = c;
