@@ -58,11 +58,11 @@ WORKLOADS = {
     # configs[3] shape: 951 827 reads / 9.8 Gbp (generating the 10 GB FASTA takes ~10 minutes of numpy before the first step; the z-mer index is rebuilt per batch of
     # queries above 2.4 Gbp per device).  No whole-job reference exists (`wtzmo -t 1` would run for days): parity at this shape is pinned on the reference's
     # -P 128 -p 0 stripe (tests/test_gpu_scale.py[fly70_zmo_P128p0]); the CPU baseline is a same-shape sample.
-    "fly70": dict(genome=140000000, coverage=70.0, seed=53, cpu_genome=1400000, golden=None, extra=[],
+    "fly70": dict(genome=140000000, coverage=70.0, seed=53, cpu_genome=1400000, golden=None, extra=[], stripe="fly70_zmo_P128p0",
                   name="BASELINE configs[3]: D. melanogaster-shape synthetic reads (140 Mbp iid genome x70 = 9.8 Gbp), query-sharded"),
     # configs[4] shape, scaled to what one box can generate in minutes: 30x of an iid genome with the human pipeline's -k 17 (smartdenovo.pl:16), the k-mer index
     # sharded by read-id range over the ranks (--shard-index) and the z-mer index per batch; --genome 3000000000 is the full configs[4] (90 Gbp: needs 8 GPUs)
-    "human30": dict(genome=100000000, coverage=30.0, seed=59, cpu_genome=2000000, golden=None, extra=["--shard-index", "--zindex-batch", "1"], k17=True,
+    "human30": dict(genome=100000000, coverage=30.0, seed=59, cpu_genome=2000000, golden=None, extra=["--shard-index", "--zindex-batch", "1"], k17=True, stripe="human30_zmo_P64p0",
                     name="BASELINE configs[4] shape, scaled: 30x of a 100 Mbp iid genome (3 Gbp of reads), -k 17, per-GPU index shard"),
 }
 
@@ -77,14 +77,24 @@ def file_md5(path):
 
 
 def kernel_source_id():
-    """sha1 over the device sources (smartdenovo_amd/csrc/*.h, *.cpp): what a PMC summary under profiles/ was measured on, and what this run was built from"""
+    """sha1 of the gfx950 code objects the library was built with (the .hip_fatbin section of smartdenovo_amd/libwtzmo_hip.so): what a PMC summary under
+    profiles/ was measured on, and what this run executes.  Round 4 hashed the source files whole, so a host-only edit of wtz_lib.cpp (the pool retry)
+    made the driver's line call its traffic evidence stale although not one kernel had changed; the code objects only change when device code does."""
     import hashlib
-    h = hashlib.sha1()
-    d = os.path.join(ROOT, "smartdenovo_amd", "csrc")
-    for f in sorted(os.listdir(d)):
-        if f.endswith((".h", ".cpp")):
-            h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
-    return h.hexdigest()[:16]
+    import struct
+    lib = os.path.join(ROOT, "smartdenovo_amd", "libwtzmo_hip.so")
+    try:
+        b = open(lib, "rb").read()
+        shoff, = struct.unpack_from("<Q", b, 0x28); shentsize, shnum, shstrndx = struct.unpack_from("<HHH", b, 0x3A)
+        sec = [struct.unpack_from("<IIQQQQIIQQ", b, shoff + i * shentsize) for i in range(shnum)]
+        stro = sec[shstrndx][4]
+        for name, _t, _f, _a, off, size, *_ in sec:
+            nm = b[stro + name:b.index(b"\0", stro + name)]
+            if nm == b".hip_fatbin":
+                return hashlib.sha1(b[off:off + size]).hexdigest()[:16]
+    except (OSError, struct.error, ValueError):
+        pass
+    return "unbuilt"
 
 
 def git_blob_id(path):
@@ -399,6 +409,27 @@ def main():
         if not res["parity"]["match"]:
             print(json.dumps(res))
             sys.exit("bench.py: the .ovl of the last step differs from the reference golden (%s vs %s): the number above is void" % (got, gold["md5_full"]))
+    elif wl.get("stripe") and same_as_golden and not a.no_verify and a.engine == "zmo":
+        # no whole-job reference exists at this size (`wtzmo -t 1` would run for days): the reference's own query stripe (-P n -p 0: every n-th query against the
+        # FULL index, wtzmo.c:1291,1314) is pinned in big_manifest.json; a second, short pass of the drop-in over the same resident input - same index form as the
+        # timed steps (sharded over two contexts of this rank's device where the workload shards it) - must write its bytes.  Outside the timed region.
+        sc = json.load(open(os.path.join(ROOT, "tests", "golden", "big_manifest.json")))["cases"][wl["stripe"]]
+        out2 = os.path.join(tmp, "bench_stripe_r%d.ovl" % rank)
+        wx = list(wl.get("extra", []))
+        form = (["--gpu-list", "%d,%d" % (local, local), "--pool-gb", "48"] if "--shard-index" in wx else ["--gpu", str(local)])
+        t0s = time.perf_counter()
+        r = subprocess.run([ge.EXE] + form + ["-i", fa, "-fo", out2] + wx + sc["argv"], capture_output=True)
+        dts = time.perf_counter() - t0s
+        got = file_md5(out2) if r.returncode == 0 and os.path.exists(out2) else None
+        res["parity"] = {"kind": "reference stripe %s" % " ".join(sc["argv"][-4:]), "md5": got, "reference_md5": sc["md5_full"], "match": got == sc["md5_full"],
+                         "reference_records": sc["records"], "stripe_wall_s": round(dts, 1), "reference_seconds_t1": sc.get("reference_seconds"),
+                         "note": "no whole-job reference output exists at this size; the stripe is the reference's own -P/-p job striping against the full index"}
+        for f in (out2, out2 + ".contained"):
+            if os.path.exists(f):
+                os.remove(f)
+        if not res["parity"]["match"]:
+            print(json.dumps(res))
+            sys.exit("bench.py: the reference stripe differs (%s vs %s; rc %d): %s" % (got, sc["md5_full"], r.returncode, r.stderr.decode()[-500:]))
     else:
         res["parity"] = {"match": None, "note": "no whole-job reference output exists for this input (parity at this shape: tests/test_gpu_scale.py)"}
     if world == 1 and not a.no_cpu_baseline:

@@ -221,6 +221,7 @@ typedef struct {
 static owriter_t g_ow;
 #define OCHUNK_RECS 8192
 static int g_ochunk_recs = OCHUNK_RECS;      /* WTZ_OUT_CHUNK_RECS: test hook - tiny chunks put many of them in flight on the writer threads */
+static int g_out_lag_ms = 0;                 /* WTZ_OUT_LAG_MS: test hook - a writer that lags behind the commit (a slow consumer), so that text buffers are refilled while records still point into them */
 #define OCHUNK_PAYLOAD ((size_t)32 << 20)
 
 static inline size_t put_str(char *o, const char *s){ size_t n = strlen(s); memcpy(o, s, n); return n; }
@@ -269,6 +270,7 @@ static void *owriter_main(void *arg){
 		if(c == NULL){ pthread_mutex_unlock(&w->mu); break; }
 		w->head = c->next; if(w->head == NULL) w->tail = NULL;
 		pthread_mutex_unlock(&w->mu);
+		if(g_out_lag_ms > 0){ struct timespec ts = { g_out_lag_ms / 1000, (long)(g_out_lag_ms % 1000) * 1000000L }; nanosleep(&ts, NULL); }
 		const double tf0 = now_s();
 		/* upper bound of the formatted bytes of the chunk (CIGAR text by reference does not count) */
 		size_t need = 0;
@@ -327,6 +329,7 @@ static void out_start(FILE *fp, const hx_read_t *reads, int binary){
 	  w->off = w->seekable ? pos : 0; }
 	w->submit_seq = w->turn_seq = 0;
 	{ const char *e = getenv("WTZ_OUT_CHUNK_RECS"); if(e && atoi(e) > 0 && atoi(e) < OCHUNK_RECS) g_ochunk_recs = atoi(e); }
+	{ const char *e = getenv("WTZ_OUT_LAG_MS"); g_out_lag_ms = (e && atoi(e) > 0) ? atoi(e) : 0; }
 	w->nth = w->seekable ? OW_THREADS : 2;          /* a pipe still gets a second thread: formatting beside the write */
 	for(int k = 0; k < w->nth; k++){ args[k].w = w; args[k].k = k; if(pthread_create(&w->T[k].th, NULL, owriter_main, &args[k]) != 0){ fprintf(stderr, " -- cannot start an output thread --\n"); DIE_NOW(); } }
 }
@@ -442,9 +445,12 @@ static void emit_record(eng_t *E, const hit_t *h, const char *cigar, size_t ciga
 	r->pb1 = h->pb1; r->pb2 = h->pb2; r->tb = h->tb; r->te = h->te; r->qb = h->qb; r->qe = h->qe; r->score = h->score;
 	r->mat = h->mat; r->mis = h->mis; r->ins = h->ins; r->del = h->del; r->aln = h->aln; r->dir2 = (uint8_t)h->dir2; r->kind = 0;
 	r->cigar = cigar; r->cigar_len = (uint32_t)cigar_len; r->ext = (int8_t)ext;
-	if(cigar && cigar_len >= 256 && !(ext >= 0 && ext < OW_MAX_EXT)){      /* a text buffer the writer does not track (parts beyond OW_MAX_EXT / 2): the record takes a copy */
+	/* The text is read LATER, on a writer thread - the short ones too (they are copied into the formatted run there) - so every record that points into a
+	 * text buffer holds that buffer (ext_busy) until its chunk is on the stream, whatever its length: a chunk of short records only used to leave the
+	 * buffer unprotected, and the part refilled (or freed) it two ranges later under a writer that lagged behind a slow consumer. */
+	if(cigar && cigar_len > 0 && !(ext >= 0 && ext < OW_MAX_EXT)){      /* a text buffer the writer does not track (parts beyond OW_MAX_EXT / 2): the record takes a copy */
 		char *cp = (char*)hx_realloc(NULL, cigar_len); memcpy(cp, cigar, cigar_len); r->cigar = cp; r->kind = 2;
-	} else if(cigar && cigar_len >= 256){
+	} else if(cigar && cigar_len > 0){
 		owriter_t *w = &g_ow; ochunk_t *c = w->cur;
 		if(!(c->ext_mask & (1u << ext))){ c->ext_mask |= 1u << ext; pthread_mutex_lock(&w->mu); w->ext_busy[ext]++; pthread_mutex_unlock(&w->mu); }
 	}

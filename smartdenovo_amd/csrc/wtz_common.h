@@ -89,9 +89,20 @@ WTZ_HD uint32_t wtz_jenkins32(uint32_t key){      /* hashset.h:452-462, k-mer su
 WTZ_HD uint64_t wtz_mix64(uint64_t x){ x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33; return x; }
 
 /* ---------------- device bump pool ----------------
- * One large HBM arena per context; tasks carve scratch and result arrays out of it with a
- * single atomic add.  Nothing is freed inside a stage; the host resets `used` between
- * stages.  Exhaustion sets `overflow` (the stage then reports WTZ_E_POOL, loudly). */
+ * One large HBM arena per context; tasks carve scratch and result arrays out of it.  Nothing is freed inside a stage; the host resets
+ * the pool between stages.  Exhaustion sets `overflow` (the stage then reports WTZ_E_POOL, loudly).
+ *
+ * Round 5: the counter is no longer ONE word.  Through round 4 every allocation was a device-scope atomic add on `used`; a configs[2] step
+ * makes ~10^7 of them from ~2 000 resident waves, and same-address atomics serialise at a few tens of nanoseconds each: a K-sw3 job that
+ * executes ONE row took as long as 100 rows (measured: 40 000 one-row jobs 8.5 ms with the single counter, 0.16 ms without), the dmo pair
+ * kernel lost a fifth of its time there.  Now the global cursor `used` hands out SLABS (64 KB ... 2 MB by pool size) to WTZ_POOL_NSHARD
+ * shard cursors, each in its own 128-byte line and picked by the workgroup index; an allocation is one atomic add on its shard:
+ *   state = slab tag (slab offset / 256 + 1, 0 = none) << 32 | bytes taken of the slab.
+ * The add that CROSSES the slab's end (taken <= slab < taken + n: exactly one request per slab) fetches the next slab from the global
+ * cursor, serves itself from its start and publishes it with an exchange; requests that arrive on an exhausted slab before that are served
+ * from the global cursor directly, as are requests larger than a quarter slab.  No locks, no spinning (lanes of one wave allocate side by side).
+ * `used` = bytes handed out including slabs in progress: an upper bound of what is in use, at most NSHARD slabs above it. */
+#define WTZ_POOL_NSHARD 64
 typedef struct {
 	uint8_t *base;
 	unsigned long long cap;
@@ -99,7 +110,30 @@ typedef struct {
 	int overflow;
 	/* fault injection (WTZ_POOL_FAIL_AT=<n>, tests only): the n-th and every later request of a stage fails as if the pool were full */
 	unsigned int fail_at, nalloc;
+	unsigned long long slab;                                   /* bytes per slab (a multiple of 256); 0 = every request goes to the global cursor */
+	unsigned long long shard[WTZ_POOL_NSHARD * 16];             /* one cursor per 128-byte line */
 } wtz_pool_t;
+
+/* host side: a pool over [base, base + cap) with nothing handed out */
+static inline void wtz_pool_init(wtz_pool_t *p, uint8_t *base, unsigned long long cap, unsigned int fail_at){
+	memset(p, 0, sizeof *p);
+	p->base = base; p->cap = cap; p->fail_at = fail_at;
+	unsigned long long s = (unsigned long long)64 << 10;
+	while(s < ((unsigned long long)2 << 20) && s * 2048 <= cap) s <<= 1;
+	p->slab = cap >= ((unsigned long long)16 << 20) ? s : 0;
+	for(int k = 0; k < WTZ_POOL_NSHARD; k++) p->shard[k * 16] = p->slab;      /* tag 0, slab "taken" to its end: the first request crosses */
+}
+
+WTZ_HD void *wtz_pool_alloc_global(wtz_pool_t *p, unsigned long long n){
+	n = (n + 255ull) & ~255ull;          /* the global cursor moves in 256-byte steps: slab offsets fit the tag */
+#if defined(__HIP_DEVICE_COMPILE__)
+	const unsigned long long o = atomicAdd(&p->used, n);
+#else
+	const unsigned long long o = p->used; p->used += n;
+#endif
+	if(o + n > p->cap){ p->overflow = 1; return NULL; }
+	return p->base + o;
+}
 
 WTZ_HD void *wtz_pool_alloc(wtz_pool_t *p, size_t bytes){
 	unsigned long long n = ((unsigned long long)bytes + 15ull) & ~15ull;
@@ -112,12 +146,26 @@ WTZ_HD void *wtz_pool_alloc(wtz_pool_t *p, size_t bytes){
 		if(k + 1u >= p->fail_at){ p->overflow = 1; return NULL; }
 	}
 #if defined(__HIP_DEVICE_COMPILE__)
-	unsigned long long o = atomicAdd(&p->used, n);
+	const unsigned long long slab = p->slab;
+	if(slab == 0 || n > slab / 4) return wtz_pool_alloc_global(p, n);
+	unsigned long long *cur = &p->shard[(blockIdx.x & (unsigned)(WTZ_POOL_NSHARD - 1)) * 16u];
+	const unsigned long long st = atomicAdd(cur, n);
+	const unsigned long long tag = st >> 32, off = st & 0xFFFFFFFFull;
+	if(off + n <= slab) return p->base + ((tag - 1ull) << 8) + off;            /* inside the shard's slab (a shard without a slab reads as taken to the end) */
+	if(off <= slab){
+		/* this request crossed the end of the slab: it is the one that fetches the next */
+		const unsigned long long o = atomicAdd(&p->used, slab);
+		if(o + slab > p->cap){
+			if(o + n <= p->cap) return p->base + o;                                /* the tail of the pool still holds this request */
+			p->overflow = 1; return NULL;
+		}
+		atomicExch(cur, (((o >> 8) + 1ull) << 32) | n);
+		return p->base + o;
+	}
+	return wtz_pool_alloc_global(p, n);                                         /* between the crossing and the publication of the next slab */
 #else
-	unsigned long long o = p->used; p->used += n;
+	return wtz_pool_alloc_global(p, n);
 #endif
-	if(o + n > p->cap){ p->overflow = 1; return NULL; }
-	return p->base + o;
 }
 
 /* Pointers into the pool are generic (flat) by type.  A flat store inside a loop that also reads LDS forces the compiler to

@@ -18,6 +18,7 @@
 #include <algorithm>
 
 #include "wtz_tasks.h"
+#include "wtz_sw_frame.h"
 
 /* ------------------------------------------------------------------------------------------------ */
 /* device abstraction                                                                               */
@@ -228,7 +229,7 @@ template<typename TAG, typename F> static int wtz_launch_wave(hipStream_t st, ui
 /* Overflow buffers are not given back to the driver when the call returns: they are kept (up to WTZ_ARENA_CACHE_BYTES) for the next request of about that size.  The
  * index builds of a 1.2 Gbp read set take 2.4 + 2.4 + 1.2 GB of sort buffers beyond the arena; hipFree + hipMalloc of those cost 30 ms on one box and 850 ms on
  * another (every repeat of the step), and each hipFree is a device-wide synchronisation. */
-#define WTZ_ARENA_CACHE_BYTES ((size_t)16 << 30)
+#define WTZ_ARENA_CACHE_BYTES ((size_t)8 << 30)      /* the three sort buffers of a configs[2] index build are 6 GB; what does not fit is given back at once */
 struct wtz_arena { uint8_t *base; size_t cap, top; std::vector<void*> overflow; std::vector<size_t> overflow_bytes; std::vector<std::pair<void*, size_t> > cache; size_t cache_bytes; };
 static thread_local wtz_arena *g_arena = NULL;
 static void arena_cache_flush(wtz_arena *a);
@@ -254,9 +255,10 @@ static int dev_alloc(void **p, size_t n){
 }
 static void arena_cache_flush(wtz_arena *a){ for(size_t i = 0; i < a->cache.size(); i++) (void)hipFree(a->cache[i].first); a->cache.clear(); a->cache_bytes = 0; }
 static void dev_free(void *){ /* released by the arena scope of the API call */ }
-struct wtz_arena_scope { wtz_arena *a; size_t mark; size_t nover;
-	wtz_arena_scope(wtz_arena *ar) : a(ar), mark(ar ? ar->top : 0), nover(ar ? ar->overflow.size() : 0) { g_arena = ar; }
+struct wtz_arena_scope { wtz_arena *a, *prev; size_t mark; size_t nover;
+	wtz_arena_scope(wtz_arena *ar) : a(ar), prev(g_arena), mark(ar ? ar->top : 0), nover(ar ? ar->overflow.size() : 0) { g_arena = ar; }
 	~wtz_arena_scope(){
+		g_arena = prev;      /* never left pointing at an arena whose call has returned (its context may be destroyed next; wtz_ctx_destroy itself runs inside a scope) */
 		if(!a) return;
 		if(a->overflow.size() > nover){
 			(void)hipStreamSynchronize(g_stream);
@@ -406,6 +408,7 @@ struct wtz_ctx {
 	uint64_t tpool_peak_call = 0, main_used_call = 0;      /* transient-pool high-water mark / main-pool bytes of the API call in progress */
 	uint32_t env_xcd_group = 256;   /* WTZ_XCD_GROUP: consecutive pairs per XCD run in K_pair (0 = identity block -> pair mapping) */
 	int env_ext_mw_cw = 32;      /* WTZ_EXT_MW_CW: K-sw3 jobs with more band columns per lane than this run on four waves whatever their length */
+	int env_ext_fr = 1;          /* WTZ_EXT_FR=0: K-sw3 one-wave jobs on the round-4 register kernel (wtz_extend_shift_reg) instead of the frame form (wtz_sw_frame.h) */
 	int env_ext_split = 0;       /* WTZ_EXT_SPLIT=1: K-sw3 one-wave jobs in two launches by band class (experiment) */
 	int env_heavy_first = -1;    /* WTZ_PAIR_HEAVY_FIRST: the heaviest pairs of a K_pair launch first (-1 = engine default: dmo on, zmo off) */
 	int env_cand_wg = 1;         /* WTZ_CAND_WG=0: the one-wavefront-per-query sorting form of the seed lookup (the form before round 3) */
@@ -429,11 +432,11 @@ static wtz_reads_t ctx_reads(const wtz_ctx *c){ wtz_reads_t R; R.bits = c->bits;
 static wtz_env_t ctx_env(const wtz_ctx *c){ wtz_env_t V; V.R = ctx_reads(c); V.Z = c->zs[0].Z; V.ZQ = c->zs[1].have ? c->zs[1].Z : c->zs[0].Z; V.P = c->dP; V.pool = c->dpool; V.dm_first_big = (uint32_t)c->env_dm_first_big; return V; }
 
 static int tpool_reset(wtz_ctx *c){
-	wtz_pool_t p; p.base = c->pool_base + c->main_bytes; p.cap = c->pool_bytes - c->main_bytes; p.used = 0; p.overflow = 0; p.fail_at = c->env_tfail_at; p.nalloc = 0;
+	wtz_pool_t p; wtz_pool_init(&p, c->pool_base + c->main_bytes, c->pool_bytes - c->main_bytes, c->env_tfail_at);
 	return dev_h2d(c->dpool + 1, &p, sizeof p);
 }
 static int pool_reset(wtz_ctx *c){
-	wtz_pool_t p; p.base = c->pool_base; p.cap = c->main_bytes; p.used = 0; p.overflow = 0; p.fail_at = c->env_fail_at; p.nalloc = 0;
+	wtz_pool_t p; wtz_pool_init(&p, c->pool_base, c->main_bytes, c->env_fail_at);
 	CHK(dev_h2d(c->dpool, &p, sizeof p));
 	c->tpool_peak_call = 0;
 	return tpool_reset(c);
@@ -529,6 +532,7 @@ extern "C" int wtz_ctx_create(int device, const wtz_params_c *params, uint64_t p
 	if(getenv("WTZ_CAND_WG")) c->env_cand_wg = atoi(getenv("WTZ_CAND_WG"));
 	if(getenv("WTZ_PAIR_HEAVY_FIRST")) c->env_heavy_first = atoi(getenv("WTZ_PAIR_HEAVY_FIRST"));
 	if(getenv("WTZ_EXT_SPLIT")) c->env_ext_split = atoi(getenv("WTZ_EXT_SPLIT"));
+	if(getenv("WTZ_EXT_FR")) c->env_ext_fr = atoi(getenv("WTZ_EXT_FR"));
 	if(getenv("WTZ_EXT_MW_CW")) c->env_ext_mw_cw = atoi(getenv("WTZ_EXT_MW_CW"));
 	if(getenv("WTZ_XCD_GROUP")) c->env_xcd_group = (uint32_t)atoi(getenv("WTZ_XCD_GROUP"));
 	c->env_grp4 = (getenv("WTZ_WINALIGN4") && atoi(getenv("WTZ_WINALIGN4")) != 0);
@@ -546,12 +550,19 @@ extern "C" int wtz_ctx_create(int device, const wtz_params_c *params, uint64_t p
 	 * rank) may have taken it since.  Halve and try again down to 4 GB - the pool size never changes a result (pool exhaustion splits the batch) -;
 	 * a size the caller asked for (--pool-gb) fails as it is. */
 	for(;;){
-		rc = dev_alloc_persist((void**)&c->pool_base, c->pool_bytes);
-		if(rc == WTZ_OK || pool_bytes || c->pool_bytes <= (4ull << 30)) break;
 #ifndef WTZ_EMUL
-		(void)hipGetLastError();              /* the refused allocation must not be what a later launch check reads */
+		/* a refused attempt that will be retried goes through the raw call: wtz_last_error must not keep the message of a failure that was recovered from */
+		if(!pool_bytes && c->pool_bytes > (4ull << 30)){
+			if(hipMalloc((void**)&c->pool_base, c->pool_bytes) == hipSuccess){ rc = WTZ_OK; break; }
+			(void)hipGetLastError();              /* the refused allocation must not be what a later launch check reads */
+			c->pool_base = NULL;
+			uint64_t nb = c->pool_bytes / 2; if(nb < (4ull << 30)) nb = 4ull << 30;      /* never below the documented floor */
+			c->pool_bytes = nb & ~(uint64_t)4095; c->main_bytes = (c->pool_bytes / 2) & ~(uint64_t)4095;
+			continue;
+		}
 #endif
-		c->pool_bytes = (c->pool_bytes / 2) & ~(uint64_t)4095; c->main_bytes = (c->pool_bytes / 2) & ~(uint64_t)4095;
+		rc = dev_alloc_persist((void**)&c->pool_base, c->pool_bytes);      /* the last attempt (or the caller's own size) fails loudly */
+		break;
 	}
 	if(rc || (rc = pool_reset(c))){
 		wtz_ctx_destroy(c); return rc;
@@ -1544,7 +1555,8 @@ static int run_extjobs(wtz_ctx *c, const wtz_env_t &V, wtz_extjob_t *d_jobs, uin
 					HIPCHK(hipEventRecord(c->ev_mw_join, c->stream_mw));
 				}
 				if(r1 > r0 && !split){
-					hipLaunchKernelGGL((wtz_kernel_extjobs_reg<1032>), dim3(r1 - r0), dim3(64), 0, g_stream, d_jobs, (const uint32_t*)d_order + r0, r1 - r0, V.P, V.pool, V.pool + 1);
+					if(c->env_ext_fr) hipLaunchKernelGGL((wtz_kernel_extjobs_fr<1032>), dim3(r1 - r0), dim3(64), 0, g_stream, d_jobs, (const uint32_t*)d_order + r0, r1 - r0, V.P, V.pool, V.pool + 1);
+					else hipLaunchKernelGGL((wtz_kernel_extjobs_reg<1032>), dim3(r1 - r0), dim3(64), 0, g_stream, d_jobs, (const uint32_t*)d_order + r0, r1 - r0, V.P, V.pool, V.pool + 1);
 					HIPCHK(hipGetLastError());
 				}
 				if(!split && mw1 > mw0) HIPCHK(hipStreamWaitEvent(g_stream, c->ev_mw_join, 0));
@@ -1561,6 +1573,8 @@ static int run_extjobs(wtz_ctx *c, const wtz_env_t &V, wtz_extjob_t *d_jobs, uin
 			std::vector<int32_t> key(m); uint32_t nv = 0, n256 = 0, n512 = 0, n1k = 0, n2k = 0, n4k = 0; unsigned long long s512 = 0;
 			CHK(dev_sync());
 			{ std::vector<wtz_extjob_t> jj(m); CHK(dev_d2h(jj.data(), d_jobs, (size_t)m * sizeof(wtz_extjob_t))); uint32_t nd[4] = {0, 0, 0, 0}; for(uint32_t i = 0; i < m; i++){ key[i] = jj[i].valid ? jj[i].x.qe : -1; if(jj[i].valid) nd[jj[i].done & 3]++; }
+			  if(const char *dp = getenv("WTZ_EXT_DUMP")){      /* job geometry of this call, 8 int32 per valid job: the input of tools/ubench/ksw3_bench.py */
+				if(FILE *df = fopen(dp, "ab")){ for(uint32_t i = 0; i < m; i++) if(jj[i].valid){ const int32_t r[8] = {jj[i].qlen, jj[i].tlen, jj[i].init_score, jj[i].W, jj[i].x.qe, jj[i].x.te, (int32_t)(jj[i].cells > 0x7FFFFFFFull ? 0x7FFFFFFF : jj[i].cells), (int32_t)jj[i].done}; fwrite(r, 4, 8, df); } fclose(df); } }
 			  fprintf(stderr, "[ext-profile] n_mw %u; %u launch group(s); valid jobs finished by: nobody %u, one-wave %u, four-wave %u, general %u\n", n_mw, n_groups, nd[0], nd[1], nd[2], nd[3]); }
 			for(uint32_t i = 0; i < m; i++){ if(key[i] < 0) continue; nv++; if(key[i] >= 256) n256++; if(key[i] >= 512){ n512++; s512 += key[i]; } if(key[i] >= 1024) n1k++; if(key[i] >= 2048) n2k++; if(key[i] >= 4096) n4k++; }
 			fprintf(stderr, "[ext-profile] %u jobs (%u valid), rows (upper bound) sum %llu max %d, %.2f ms; qe>=256 %u >=512 %u (sum %llu) >=1k %u >=2k %u >=4k %u; transient pool peak %.2f GB\n", m, nv, ext_sum, ext_max, ms_l, n256, n512, s512, n1k, n2k, n4k, c->tpool_peak_call / 1073741824.0);

@@ -167,13 +167,16 @@ extern "C" int wtz_test_dp(wtz_ctx_t *c, int32_t kind, int32_t form, const wtz_d
 		std::vector<wtz_extjob_t> jobs(n);
 		for(uint32_t i = 0; i < n; i++){ wtz_extjob_t j; memset(&j, 0, sizeof j); j.q = hp[i].q; j.t = hp[i].t; j.qlen = hp[i].qlen; j.tlen = hp[i].tlen; j.init_score = hp[i].init_score; j.W = hp[i].W; j.item = i; j.valid = 1; jobs[i] = j; }
 		wtz_extjob_t *d_jobs = NULL; CHK(dev_alloc((void**)&d_jobs, (size_t)n * sizeof(wtz_extjob_t))); CHK(dev_h2d(d_jobs, jobs.data(), (size_t)n * sizeof(wtz_extjob_t)));
+		wtz_timer tform; tform.start();      /* the forced forms report their launch time through counters.ms_ext too (tools/ubench/ksw3_bench.py) */
 		if(form == 0){ CHK(run_extjobs(c, V, d_jobs, n)); }
 		else if(form == 1){ hipLaunchKernelGGL((wtz_kernel_extjobs_reg<1032>), dim3(n), dim3(64), 0, g_stream, d_jobs, (const uint32_t*)NULL, n, V.P, V.pool, V.pool + 1); HIPCHK(hipGetLastError()); }
 		else if(form == 2){ hipLaunchKernelGGL((wtz_kernel_extjobs_mw<1032>), dim3(n), dim3(256), 0, g_stream, d_jobs, (const uint32_t*)NULL, n, V.P, V.pool, V.pool + 1); HIPCHK(hipGetLastError()); }
 		else if(form == 3){ hipLaunchKernelGGL((wtz_kernel_extjobs<2048, 1032>), dim3(n), dim3(64), 0, g_stream, d_jobs, (const uint32_t*)NULL, n, V.P, V.pool, V.pool + 1); HIPCHK(hipGetLastError()); }
 		else if(form == 4){ CHK(wtz_launch_wave<K_extjob_scalar>(0, n, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_extjob_scalar((uint32_t)t, V, d_jobs); })); }
+		else if(form == 5){ hipLaunchKernelGGL((wtz_kernel_extjobs_fr<1032>), dim3(n), dim3(64), 0, g_stream, d_jobs, (const uint32_t*)NULL, n, V.P, V.pool, V.pool + 1); HIPCHK(hipGetLastError()); }
 		else return wtz_fail(WTZ_E_ARG, "WTZ_DP_SHIFT: unknown form %d", form);
 		CHK(dev_sync());
+		if(form != 0){ c->cnt.ms_ext += tform.stop(); c->cnt.n_extjobs += n; }
 		CHK(tpool_check(c, "wtz_test_dp"));
 		CHK(dev_d2h(jobs.data(), d_jobs, (size_t)n * sizeof(wtz_extjob_t)));
 		for(uint32_t i = 0; i < n; i++){

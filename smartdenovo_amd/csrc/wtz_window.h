@@ -788,7 +788,7 @@ WTZ_SCAN_FN uint32_t wtz_scan_windows_coop(const wtz_zhit_t *rs, uint32_t dir, u
 			for(uint32_t c = 0; c < RC; c++) if((kpm >> c) & 1u){ mn = q2[c] < mn ? q2[c] : mn; mx = q2[c] > mx ? q2[c] : mx; }
 			mn = wtz_coop_min32(mn); mx = ~wtz_coop_min32(~mx);
 			const uint32_t bw = kwin >= 8 ? kwin / 8 : 1;
-			const uint32_t nadj = (kwin - 1) / bw + 1;
+			const uint32_t nadj = (kwin - 1) / bw + 2;      /* the bins are aligned to mn, not to the window: kwin - 1 columns starting anywhere inside a bin reach into one more */
 			const uint32_t nb = (mx - mn) / bw + 1 + nadj;
 			if(nb <= sc.lds_u64 * 2){
 				uint32_t *B = (uint32_t*)K;
@@ -848,7 +848,7 @@ WTZ_SCAN_FN uint32_t wtz_scan_windows_coop(const wtz_zhit_t *rs, uint32_t dir, u
 		 * ol = sum of len2 over the in-window matches j..i minus the overlaps of neighbours (a match adds len2 minus its overlap with the one
 		 * before, an eviction takes len2 minus the overlap with the one behind; ends are monotone in off2 for the matches of one strand), so
 		 * ol <= sum of len2 over j..i, and the while loop keeps off2[i] - off2[j] < kwin: the in-window matches lie in nadj adjacent bins of
-		 * kwin / 8 columns (1.125 kwin in all).  If no such run of bins holds zovl bases of matches, no window can open, n2 stays 0 and the scan returns 0 - without
+		 * kwin / 8 columns (nine bins = 1.125 kwin: eight would miss a window that starts late in its first bin).  If no such run of bins holds zovl bases of matches, no window can open, n2 stays 0 and the scan returns 0 - without
 		 * the off2 ordering, the gather and the lane-0 sweep.  Tie order cannot matter: the bound is over sets. ---- */
 		if(K != NULL){
 			uint32_t mn = 0xFFFFFFFFu, mx = 0;
@@ -858,7 +858,7 @@ WTZ_SCAN_FN uint32_t wtz_scan_windows_coop(const wtz_zhit_t *rs, uint32_t dir, u
 			}
 			mn = wtz_coop_min32(mn); mx = ~wtz_coop_min32(~mx);
 			const uint32_t bw = kwin >= 8 ? kwin / 8 : 1;          /* bins of an eighth of the window: the in-window matches span < kwin columns = at most nadj adjacent bins */
-			const uint32_t nadj = (kwin - 1) / bw + 1;
+			const uint32_t nadj = (kwin - 1) / bw + 2;      /* the bins are aligned to mn, not to the window: kwin - 1 columns starting anywhere inside a bin reach into one more */
 			const uint32_t nb = (mx - mn) / bw + 1 + nadj;         /* nadj empty bins behind the last: every run of nadj bins starting at a used bin is inside the array */
 			if(nb <= sc.lds_u64 * 2){
 				uint32_t *B = (uint32_t*)K;

@@ -24,13 +24,13 @@ def file_md5(path):
     return h.hexdigest(), n
 
 
-def main():
+def main(shape="fly", genome=140000000, coverage=70.0, seed=53, jobs_total=128, zmo=ZMO, tmp="/tmp/wtz_fly"):
     ap = argparse.ArgumentParser()
-    ap.add_argument("--genome", type=int, default=140000000); ap.add_argument("--coverage", type=float, default=70.0); ap.add_argument("--seed", type=int, default=53)
-    ap.add_argument("--jobs-total", type=int, default=128); ap.add_argument("--tmp", default="/tmp/wtz_fly")
+    ap.add_argument("--genome", type=int, default=genome); ap.add_argument("--coverage", type=float, default=coverage); ap.add_argument("--seed", type=int, default=seed)
+    ap.add_argument("--jobs-total", type=int, default=jobs_total); ap.add_argument("--tmp", default=tmp)
     a = ap.parse_args()
     os.makedirs(a.tmp, exist_ok=True)
-    fa = os.path.join(a.tmp, "fly_G%d_c%g_s%d.fa" % (a.genome, a.coverage, a.seed))
+    fa = os.path.join(a.tmp, "%s_G%d_c%g_s%d.fa" % (shape, a.genome, a.coverage, a.seed))
     t0 = time.time()
     if not os.path.exists(fa + ".meta"):
         names, seqs = synth.synth_reads(a.genome, a.coverage, seed=a.seed)
@@ -39,10 +39,10 @@ def main():
         del names, seqs
     meta = json.load(open(fa + ".meta"))
     print("reads:", meta, "%.0f s" % (time.time() - t0), flush=True)
-    name = "fly%g_zmo_P%dp0" % (a.coverage, a.jobs_total)
+    name = "%s%g_zmo_P%dp0" % (shape, a.coverage, a.jobs_total)
     out = os.path.join(a.tmp, name + ".ovl"); pairs = os.path.join(a.tmp, name + ".pairs")
     t1 = time.time()
-    subprocess.run([REF, "-t", "1", "-P", str(a.jobs_total), "-p", "0", "-i", fa, "-fo", out, "-9", pairs] + ZMO, check=True, stdout=subprocess.DEVNULL)
+    subprocess.run([REF, "-t", "1", "-P", str(a.jobs_total), "-p", "0", "-i", fa, "-fo", out, "-9", pairs] + zmo, check=True, stdout=subprocess.DEVNULL)
     dt = time.time() - t1
     md5, nrec = file_md5(out)
     cont, ncont = file_md5(out + ".contained")
@@ -57,9 +57,9 @@ def main():
     for line in open(pairs):
         x, y = line.split(); npair += 1; bp += lens[x] + lens[y]
     man = json.load(open(MAN))
-    sname = "fly%g" % a.coverage
+    sname = "%s%g" % (shape, a.coverage)
     man["sets"][sname] = dict(genome=a.genome, coverage=a.coverage, seed=a.seed, repeats=False, reads=meta["reads"], bases=meta["bases"], md5_fasta=meta["md5"])
-    man["cases"][name] = dict(set=sname, engine="zmo", argv=ZMO + ["-P", str(a.jobs_total), "-p", "0"], md5_full=md5, records=nrec, md5_contained=cont, contained=ncont,
+    man["cases"][name] = dict(set=sname, engine="zmo", argv=list(zmo) + ["-P", str(a.jobs_total), "-p", "0"], md5_full=md5, records=nrec, md5_contained=cont, contained=ncont,
                               pairs=npair, pair_bp=bp, reference_seconds=round(dt, 1))
     json.dump(man, open(MAN, "w"), indent=1, sort_keys=True)
     print(name, man["cases"][name], flush=True)

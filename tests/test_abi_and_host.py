@@ -172,6 +172,30 @@ def test_writer_threads_keep_the_record_order(name, emul_exe, tmp_path):
     assert hashlib.md5(open(out, "rb").read()).hexdigest() == case["md5_full"]
 
 
+def test_short_cigar_records_survive_a_lagging_writer(emul_exe, oracle_exe, tmp_path):
+    """Accurate reads: most CIGAR texts are shorter than 256 bytes, the size below which the writer thread copies the text into its formatted run instead of
+    pointing at it.  The copy happens on the writer thread, LATER than the commit - so a chunk of short records must hold the part's text buffer like a chunk of
+    long ones does (round-4 regression: it did not, and a writer that lagged behind a slow consumer formatted text that the part had already refilled).
+    WTZ_OUT_LAG_MS delays every chunk on the writer threads; two records per chunk and batches of four queries put the refills in front of the writer."""
+    import hashlib
+    from smartdenovo_amd import synth
+    names, seqs = synth.synth_reads(40000, 18.0, seed=77, mean_len=2500.0, sigma=0.3, min_len=1200, err=0.002)
+    fa = os.path.join(str(tmp_path), "hifi.fa"); synth.write_fasta(fa, names, seqs)
+    argv = ["-i", fa, "-k", "16", "-s", "200", "-m", "0.6"]
+    ref = os.path.join(str(tmp_path), "ora.ovl")
+    subprocess.run([oracle_exe] + argv + ["-fo", ref], check=True, capture_output=True)
+    want = open(ref, "rb").read()
+    short = sum(1 for l in want.splitlines() if len(l.split(b"\t")[16]) < 256)
+    assert want.count(b"\n") > 200 and short > 0.5 * want.count(b"\n")
+    env = dict(os.environ, WTZ_OUT_CHUNK_RECS="2", WTZ_OUT_LAG_MS="15")
+    for extra in ([], ["--gpus", "3"]):
+        out = os.path.join(str(tmp_path), "lag.ovl")
+        subprocess.run([emul_exe] + argv + ["--batch", "4", "-fo", out] + extra, check=True, capture_output=True, env=env)
+        assert hashlib.md5(open(out, "rb").read()).hexdigest() == hashlib.md5(want).hexdigest(), "records differ under a lagging writer (%s)" % " ".join(extra)
+    r = subprocess.run([emul_exe] + argv + ["--batch", "4", "-fo", "-"], check=True, capture_output=True, env=env)      # a pipe: written strictly in turn
+    assert r.stdout == want
+
+
 def test_word_level_base_packing(tmp_path):
     """wtz_pack32 (two 64-bit loads + funnel shift per 32 bases, both strands, complement) == 32 single-base extractions."""
     exe = os.path.join(str(tmp_path), "check_pack32")

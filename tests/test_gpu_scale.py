@@ -16,8 +16,9 @@ from conftest import GOLD, ROOT
 pytestmark = pytest.mark.gpu
 MAN = json.load(open(os.path.join(GOLD, "big_manifest.json")))
 TMP = os.environ.get("WTZ_BENCH_TMP", "/tmp/wtz_bench")
-CASES = sorted(c for c in MAN["cases"] if not MAN["cases"][c]["set"].startswith("fly"))
+CASES = sorted(c for c in MAN["cases"] if not MAN["cases"][c]["set"].startswith(("fly", "human")))
 FLY_CASES = sorted(c for c in MAN["cases"] if MAN["cases"][c]["set"].startswith("fly"))
+HUMAN_CASES = sorted(c for c in MAN["cases"] if MAN["cases"][c]["set"].startswith("human"))
 
 
 def file_md5(path):
@@ -70,7 +71,7 @@ def check_case_at_scale(name, gpu_exe, extra=()):
     assert (int(row[0]), int(row[1])) == (case["pairs"], case["pair_bp"]), "pairs entering pair alignment (the bench numerator) differ from the reference's -9 set"
     # planned, not exception-driven: the ranges of a batch are cut to the scratch pool BEFORE the device stages run (the halving after a
     # WTZ_E_POOL stays as the safety net for inputs whose pairs differ wildly in size: the repeat-rich set may use it)
-    if case["set"] != "repeat" and not case["set"].startswith("fly"):
+    if case["set"] != "repeat" and not case["set"].startswith(("fly", "human")):
         assert b"splitting the batch" not in r.stderr, "a planned range overflowed the scratch pool"
     os.remove(out)
 
@@ -134,6 +135,28 @@ def test_dmo_heavy_pair_paths(env, gpu_exe):
     if "WTZ_DM_TIER4_KB" not in env:
         assert b"dmo tier 4" in r.stderr, "no pair reached the fourth launch: the test no longer covers it"
     os.remove(out)
+
+
+@pytest.mark.parametrize("extra", [["--gpu-list", "0,0", "--shard-index", "--zindex-batch", "1", "--pool-gb", "48"], []], ids=["configs4_form_2_index_shards_per_batch_zindex", "one_context"])
+@pytest.mark.parametrize("name", HUMAN_CASES)
+def test_human_shape_stripe_equals_reference(name, extra, gpu_exe):
+    """BASELINE configs[4]'s workload shape (synthetic 10 kb reads, 15 % error, 30x of a large genome, the human pipeline's `-k 17`: smartdenovo.pl:16) at the size
+    one box can generate and the build container could run the reference on: 291 161 reads / 3.0 Gbp (30x of a 100 Mbp genome, bench.py --workload human30).
+    The query stripe `-P 64 -p 0` against the FULL index must give the md5 of the reference's `wtzmo -t 1 -k 17 -P 64 -p 0` (11 minutes in the build
+    container, tests/golden/make_human_stripe.py) - through configs[4]'s own combination (the k-mer index cut into read-id ranges over two contexts like `-G`,
+    wtzmo.c:1281-1303, global counts in the filter, the z-mer index rebuilt per batch of queries) and through one context.  WTZ_TEST_NO_HUMAN=1 skips it."""
+    import shutil
+    if os.environ.get("WTZ_TEST_NO_HUMAN"):
+        pytest.skip("WTZ_TEST_NO_HUMAN set")
+    os.makedirs(TMP, exist_ok=True)
+    if shutil.disk_usage(TMP).free < 10 << 30:
+        pytest.skip("less than 10 GB free under %s for the 3 GB input" % TMP)
+    check_case_at_scale(name, gpu_exe, extra)
+    if os.environ.get("WTZ_TEST_KEEP_HUMAN") or extra:
+        return
+    for f in os.listdir(TMP):          # 3 GB: not left behind
+        if f.startswith("reads_G%d_" % MAN["sets"][MAN["cases"][name]["set"]]["genome"]):
+            os.remove(os.path.join(TMP, f))
 
 
 @pytest.mark.parametrize("extra", [[], ["--gpu-list", "0,0", "--pool-gb", "48"]], ids=["one_context", "two_contexts"])
