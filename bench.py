@@ -301,6 +301,11 @@ def main():
         d = torch.tensor([dt], dtype=torch.float64, device=xdev)
         dist.all_reduce(d, op=dist.ReduceOp.MAX)
         dt = float(d.item())
+    sent_dev = 0
+    if dist:      # what the peers sent straight from device memory (the CIGAR text: multigpu.py::_send_dev), summed over the ranks: rank 0 only receives
+        sd = torch.tensor([float(xchg.bytes_sent_from_device)], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        dist.all_reduce(sd)
+        sent_dev = int(sd.item())
     if rank != 0:
         if dist:
             dist.destroy_process_group()
@@ -399,6 +404,8 @@ def main():
     if world > 1:
         res["gathered_result_bytes_per_step"] = xchg.bytes_received // (W + K)
         res["exchange_messages_per_step"] = xchg.messages // (W + K)
+        res["bytes_sent_from_device"] = sent_dev      # all ranks, all steps: > 0 iff the device-resident send path carried the text
+        res["backend"] = backend
     # parity of THIS run: the last step's file against the md5 of reference `wtzmo -t 1` on the same input (generated once, committed)
     gold = None
     if wl.get("golden") and same_as_golden and not a.no_verify:

@@ -192,61 +192,80 @@ static uint32_t wx_parse_cigar(const char *s, uint32_t **out, uint32_t *cap){
 	return n;
 }
 
-/* wtext.c:129-244: the overlap's CIGAR clipped to the retained regions, the rest re-scored.  alive = 0: nothing of it is left (the record is dropped) */
-static void wx_clip_hit(wx_t *W, wx_hit_t *h, uint32_t **tmp, uint32_t *captmp){
+/* ---- an overlap against the retained regions of its two reads (what wtext.c:129-244 computes), in three steps of its own:
+ *   1. how many bases of each read the alignment must give up at its front and at its back (it may poke out of a region at either end),
+ *   2. wx_trim_end eats operations from that end until both reads have given up enough (a partly eaten match run is shortened in place),
+ *   3. wx_rescore walks what is left once, base by base, for the record's counts and score.
+ * Kept because the output shows it: gap operations at an end are eaten before the first match run is even looked at, whether or not anything had to be given up
+ * there; a match run gives up max(lack of read 1, lack of read 2) bases of BOTH reads; an end that runs out of operations, or two ends that meet, drop the record. ---- */
+typedef struct { int t, q; } wx_both_t;       /* one number per read: t = read 1 (the overlap's target columns), q = read 2 */
+
+/* returns the operations used up entirely (>= 0), *gave = the bases each read gave up; -1 when the list ends before both reads gave up `owe` */
+static int wx_trim_end(uint32_t *cg, uint32_t nc, int from_back, wx_both_t owe, wx_both_t *gave){
+	wx_both_t got = {0, 0}; uint32_t used = 0;
+	for(; used < nc; used++){
+		uint32_t *w = &cg[from_back ? nc - 1 - used : used];
+		const uint32_t op = *w & 0xFu; const int run = (int)(*w >> 4);
+		if(op == 1){ got.q += run; continue; }                    /* an insertion: bases of read 2 only */
+		if(op == 2){ got.t += run; continue; }                    /* a deletion: bases of read 1 only */
+		if(got.t >= owe.t && got.q >= owe.q) break;               /* a match run, and nothing is owed any more: the kept part starts here */
+		const int lack_t = owe.t - got.t, lack_q = owe.q - got.q;
+		int take = lack_t > lack_q ? lack_t : lack_q; if(take > run) take = run;
+		got.t += take; got.q += take;
+		if(take < run){ *w = ((uint32_t)(run - take) << 4) | op; break; }
+	}
+	*gave = got;
+	return (got.t < owe.t || got.q < owe.q) ? -1 : (int)used;
+}
+
+/* counts and score of the kept operations cg[0, n), read 1 from base at1, read 2 from base at2 (positions on the strands the overlap was reported on) */
+static void wx_rescore(const wx_t *W, const wx_hit_t *h, const uint32_t *cg, uint32_t n, int64_t at1, int64_t at2, wx_aln_t *x){
 	const wx_opt_t *o = &W->O;
-	int seqlens[2], clpoffs[2], clp[2], x[2], y[2], dy[2], cx[2], cy[2], nx[2], ny[2];
-	seqlens[0] = (int)W->pblen[h->pb1]; clpoffs[0] = (int)W->clp_off[h->pb1]; h->clplen[0] = (int)W->clp_len[h->pb1];
-	seqlens[1] = (int)W->pblen[h->pb2]; clpoffs[1] = (int)W->clp_off[h->pb2]; h->clplen[1] = (int)W->clp_len[h->pb2];
-	uint32_t nc = wx_parse_cigar(h->cigar_in, tmp, captmp);
+	for(uint32_t i = 0; i < n; i++){
+		const int op = (int)(cg[i] & 0xFu), run = (int)(cg[i] >> 4);
+		x->aln += run;
+		if(op == 1){ x->ins += run; at2 += run; x->score += o->O + o->E * run; }
+		else if(op == 2){ x->del += run; at1 += run; x->score += o->O + o->E * run; }
+		else {
+			for(int j = 0; j < run; j++){ if(wx_base(W, h->pb1, h->dir1, at1 + j) == wx_base(W, h->pb2, h->dir2, at2 + j)) x->mat++; else x->mis++; }
+			at1 += run; at2 += run;
+		}
+	}
+	x->score += x->mat * o->M; x->score += x->mis * o->X;
+}
+
+/* alive = 0 afterwards: nothing of the overlap is left inside the regions (the record is dropped, wtext.c:329) */
+static void wx_clip_hit(wx_t *W, wx_hit_t *h, uint32_t **tmp, uint32_t *captmp){
+	const uint32_t nc = wx_parse_cigar(h->cigar_in, tmp, captmp);
 	uint32_t *cg = *tmp;
 	free(h->cigar_in); h->cigar_in = NULL;
 	memset(&h->x0, 0, sizeof h->x0); h->alive = 0; h->need_l = h->need_r = 0; h->core = NULL; h->ncore = 0;
-	clp[0] = clp[1] = 0;
-	x[0] = h->tb; x[1] = h->qb; y[0] = seqlens[0] - h->te; y[1] = seqlens[1] - h->qe;
-	h->dx[0] = h->dir1 ? seqlens[0] - clpoffs[0] - h->clplen[0] : clpoffs[0];
-	h->dx[1] = h->dir2 ? seqlens[1] - clpoffs[1] - h->clplen[1] : clpoffs[1];
-	dy[0] = h->dir1 ? clpoffs[0] : seqlens[0] - clpoffs[0] - h->clplen[0];
-	dy[1] = h->dir2 ? clpoffs[1] : seqlens[1] - clpoffs[1] - h->clplen[1];
-	for(int k = 0; k < 2; k++){ cx[k] = h->dx[k] > x[k] ? h->dx[k] - x[k] : 0; cy[k] = dy[k] > y[k] ? dy[k] - y[k] : 0; nx[k] = ny[k] = 0; }
-	for(int side = 0; side < 2; side++){          /* side 0: from the front (wtext.c:168-191), side 1: from the back (193-216) */
-		int *cc = side ? cy : cx, *nn = side ? ny : nx;
-		while(clp[side] < (int)nc){
-			uint32_t *w = &cg[side ? nc - 1 - (uint32_t)clp[side] : (uint32_t)clp[side]];
-			const int op = (int)(*w & 0xFu); int len = (int)(*w >> 4);
-			if(op == 1) nn[1] += len;
-			else if(op == 2) nn[0] += len;
-			else {
-				if(nn[0] >= cc[0] && nn[1] >= cc[1]) break;
-				int d = cc[0] - nn[0] > cc[1] - nn[1] ? cc[0] - nn[0] : cc[1] - nn[1];
-				d = d > len ? len : d;
-				nn[0] += d; nn[1] += d;
-				if(d < len){ len -= d; *w = ((uint32_t)len << 4) | (uint32_t)op; break; }
-			}
-			clp[side]++;
-		}
-		if(nn[0] < cc[0] || nn[1] < cc[1]) return;
+	const uint32_t rd[2] = { h->pb1, h->pb2 }; const int rev[2] = { h->dir1, h->dir2 };
+	const int from[2] = { h->tb, h->qb }, upto[2] = { h->te, h->qe };
+	int before[2], after[2];              /* bases of the read outside its region, in front of / behind it on the overlap's strand */
+	for(int k = 0; k < 2; k++){
+		const int L = (int)W->pblen[rd[k]], off = (int)W->clp_off[rd[k]], keep = (int)W->clp_len[rd[k]];
+		h->clplen[k] = keep;
+		before[k] = rev[k] ? L - off - keep : off;
+		after[k] = rev[k] ? off : L - off - keep;
+		h->dx[k] = before[k];
 	}
-	if(clp[0] + clp[1] >= (int)nc) return;
+	const wx_both_t owe_front = { before[0] > from[0] ? before[0] - from[0] : 0, before[1] > from[1] ? before[1] - from[1] : 0 };
+	const int tail1 = (int)W->pblen[rd[0]] - upto[0], tail2 = (int)W->pblen[rd[1]] - upto[1];
+	const wx_both_t owe_back = { after[0] > tail1 ? after[0] - tail1 : 0, after[1] > tail2 ? after[1] - tail2 : 0 };
+	wx_both_t cut_front, cut_back;
+	const int nf = wx_trim_end(cg, nc, 0, owe_front, &cut_front);
+	if(nf < 0) return;
+	const int nb = wx_trim_end(cg, nc, 1, owe_back, &cut_back);
+	if(nb < 0 || nf + nb >= (int)nc) return;
 	wx_aln_t x0; memset(&x0, 0, sizeof x0);
-	x0.tb = h->tb + nx[0] - h->dx[0]; x0.qb = h->qb + nx[1] - h->dx[1];
-	x0.te = h->te - ny[0] - h->dx[0]; x0.qe = h->qe - ny[1] - h->dx[1];
-	cx[0] = x0.tb; cx[1] = x0.qb;
-	for(int i = clp[0]; i + clp[1] < (int)nc; i++){          /* wtext.c:225-244 */
-		const int op = (int)(cg[i] & 0xFu), len = (int)(cg[i] >> 4);
-		x0.aln += len;
-		if(op == 1){ x0.ins += len; cx[1] += len; x0.score += o->O + o->E * len; }
-		else if(op == 2){ x0.del += len; cx[0] += len; x0.score += o->O + o->E * len; }
-		else {
-			for(int j = 0; j < len; j++){ if(wx_base(W, h->pb1, h->dir1, (int64_t)h->dx[0] + cx[0] + j) == wx_base(W, h->pb2, h->dir2, (int64_t)h->dx[1] + cx[1] + j)) x0.mat++; else x0.mis++; }
-			cx[0] += len; cx[1] += len;
-		}
-	}
-	x0.score += x0.mat * o->M; x0.score += x0.mis * o->X;
-	h->ncore = nc - (uint32_t)clp[0] - (uint32_t)clp[1];
-	h->core = (uint32_t*)hx_realloc(NULL, 4 * ((size_t)h->ncore + 1)); memcpy(h->core, cg + clp[0], 4 * (size_t)h->ncore);
+	x0.tb = from[0] + cut_front.t - before[0]; x0.qb = from[1] + cut_front.q - before[1];      /* region coordinates */
+	x0.te = upto[0] - cut_back.t - before[0];  x0.qe = upto[1] - cut_back.q - before[1];
+	h->ncore = nc - (uint32_t)nf - (uint32_t)nb;
+	wx_rescore(W, h, cg + nf, h->ncore, (int64_t)before[0] + x0.tb, (int64_t)before[1] + x0.qb, &x0);
+	h->core = (uint32_t*)hx_realloc(NULL, 4 * ((size_t)h->ncore + 1)); memcpy(h->core, cg + nf, 4 * (size_t)h->ncore);
 	h->x0 = x0; h->alive = 1;
-	h->need_l = (x0.qb <= o->max_ext || x0.tb <= o->max_ext);                                   /* wtext.c:247 */
+	h->need_l = (x0.qb <= W->O.max_ext || x0.tb <= W->O.max_ext);                               /* wtext.c:247 */
 }
 
 static void wx_job_push(wx_t *W, const wx_job_t *j){

@@ -520,7 +520,9 @@ extern "C" int wtz_ctx_create(int device, const wtz_params_c *params, uint64_t p
 	g_stream = c->stream;
 	/* debugging switches are read once per context, not lazily from worker threads */
 	c->env_sw_mode = 0; if(getenv("WTZ_SW_SCALAR") && atoi(getenv("WTZ_SW_SCALAR"))) c->env_sw_mode = 1; if(getenv("WTZ_SW_CHECK") && atoi(getenv("WTZ_SW_CHECK"))) c->env_sw_mode = 2;
-	c->env_mw_min = getenv("WTZ_SW_MW_MIN") ? atoi(getenv("WTZ_SW_MW_MIN")) : 512;        /* measured flat between 128 and 1024 (tools/gpu_mw_sweep.sh); 0 = one wave per job always */
+	/* round 5: 0 = one wave per job always.  With the frame form at two waves per SIMD and the pool's counter sharded, the four-wave kernel (2.7x the SIMD time per row
+	 * for 1.5x the speed of one job) only costs throughput: K-sw3 stage at configs[2] 729 ms with the long jobs (>= 512 rows) on four waves, 692 with >= 2048, 612 with none */
+	c->env_mw_min = getenv("WTZ_SW_MW_MIN") ? atoi(getenv("WTZ_SW_MW_MIN")) : 0;
 	c->env_mw_top = getenv("WTZ_SW_MW_TOP") ? atoi(getenv("WTZ_SW_MW_TOP")) : 1 << 30;
 	c->env_use_reg = !(getenv("WTZ_SW_NOREG") && atoi(getenv("WTZ_SW_NOREG")));
 	c->env_gap_side = (getenv("WTZ_GAP_SIDESTREAM") && atoi(getenv("WTZ_GAP_SIDESTREAM"))) ? 1 : 0;

@@ -19,7 +19,8 @@
  *   - the row maximum: lanes entirely beyond the band end are masked after their local reduction; the one lane the band end cuts
  *     through checks whether its local arg-max fell on a cell beyond it and only then (rare: that cell is W columns off the running
  *     maximum) the wave repeats the reduction with per-cell masks.
- * The trace byte and its layout are those of wtz_extend_shift_reg, so wtz_shift_traceback is shared.
+ * The trace layout is that of wtz_extend_shift_reg and wtz_shift_traceback is shared; the byte holds the four decisions only - the "bases equal" bit (two ops per
+ * cell to insert) is gone: the walk counts diagonal steps and gap runs, and matches / mismatches follow from the score (see wtz_shift_traceback<C, NL, false>).
  * Values are kept < 2^20 in magnitude (caller's envelope, which now includes (ql+tl)*|E| for the frame term) so that the packed
  * arg-max key  H*2048 + (2047 - band column)  fits 32 bits in every intermediate form.
  */
@@ -109,12 +110,15 @@ WTZ_D void wtz_fr_row(int32_t (&hv)[C], int32_t (&ev)[C], uint32_t (&zw)[(C + 3)
 		const int32_t en = e > t ? e : t;
 		d = __builtin_amdgcn_alignbit(d, (uint32_t)(t - f), 31);                /* F extended */
 		f = f > t ? f : t;
-		d = (d << 1) | (((k < 16 ? eq_lo : eq_hi) >> (2 * (k & 15))) & 1u);
-		hv[k] = h; ev[k] = en;
+		hv[k] = h; ev[k] = en;                                                   /* no "bases equal" bit in this form's trace byte: mat / mis follow from the score (wtz_shift_traceback<.., false>) */
 		const int32_t kk = (int32_t)(((uint32_t)h << 11) + (uint32_t)ck[k]);
 		key = kk > key ? kk : key;
 		zw[k >> 2] |= d << (8 * (k & 3));
-		if constexpr((k & 3) == 3 || k == C - 1) WTZ_PIN(zw[k >> 2]);
+		if constexpr((k & 3) == 3 || k == C - 1){ WTZ_PIN(zw[k >> 2]);
+#ifdef WTZ_FR_SCHED_BARRIER
+			__builtin_amdgcn_sched_barrier(0);
+#endif
+		}
 	});
 	lkey = key;
 }
@@ -122,10 +126,10 @@ WTZ_D void wtz_fr_row(int32_t (&hv)[C], int32_t (&ev)[C], uint32_t (&zw)[(C + 3)
 template<int C>
 WTZ_D wtz_aln_t wtz_extend_shift_fr(int32_t qlen, const wtz_seq_packed &query, int32_t tlen, const wtz_seq_packed &target, int32_t init_score,
 		int32_t ql, int32_t tl, int32_t W, int32_t M, int32_t X, int32_t O, int32_t E, int32_t T,
-		uint64_t *tb, wtz_trace_t &tr, wtz_pool_t *pool, wtz_cigar_t &cigars, unsigned long long *cells, bool *ok){
+		uint64_t *tb, wtz_trace_t &tr, wtz_pool_t *pool, wtz_cigar_t &cigars, unsigned long long *cells, bool *ok, bool *consistent){
 	const int lane = (int)(threadIdx.x & 63);
 	wtz_aln_t x; memset(&x, 0, sizeof x);
-	*ok = true;
+	*ok = true; *consistent = true;
 	if(lane == 0) cigars.n = 0;
 	if(init_score < 0) init_score = 0;
 	constexpr int C4 = (C + 3) / 4;
@@ -293,7 +297,8 @@ WTZ_D wtz_aln_t wtz_extend_shift_fr(int32_t qlen, const wtz_seq_packed &query, i
 	if(gmax > 0 && gmax >= mx + T){ x.score = gmax; x.qe = gi; x.te = gj; }
 	else { x.score = mx; x.qe = mi; x.te = mj; }
 	__threadfence_block();
-	wtz_shift_traceback<C, 64>(x, zchunk, zb, zrow, tb, cigars);
+	const wtz_tb_score sc = { M, X, O, E, init_score };
+	if(!wtz_shift_traceback<C, 64, false>(x, zchunk, zb, zrow, tb, cigars, &sc)) *ok = false, *consistent = false;
 	return wtz_bcast_aln(x);
 }
 
@@ -317,15 +322,15 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WTZ_OCC
 		const long long aE = Pm->E < 0 ? -(long long)Pm->E : (long long)Pm->E, aX = Pm->X < 0 ? -(long long)Pm->X : (long long)Pm->X, aO = Pm->O < 0 ? -(long long)Pm->O : (long long)Pm->O;
 		const long long span = (long long)ql + tl + 4;
 		if((long long)init_score + (long long)(Pm->M > 0 ? Pm->M : -Pm->M) * (ql < tl ? ql : tl) + span * aE + 10000 + aX + aO + 16 >= (1 << 20)) return;
-		if(aE > 255) return;
+		if(aE > 255 || Pm->M == Pm->X) return;
 	}
 	if(Cw <= CLO || (CHI < 32 && Cw > CHI)) return;
 	wtz_trace_t tr; tr.chunk = NULL; tr.zb = NULL; tr.n_chunk = 0; tr.zrow = 0; tr.cap_rows = 0;
 	wtz_cigar_t cg; cg.a = NULL; cg.n = cg.cap = 0; cg.pool = pool; cg.bad = 0;
 	if(lane == 0) cg.init(pool, (uint32_t)ql / 2u + 16u);
-	unsigned long long cells = 0; bool ok = true;
+	unsigned long long cells = 0; bool ok = true, consistent = true;
 	wtz_aln_t x;
-#define WTZ_EXTFR_CASE(CM) x = wtz_extend_shift_fr<CM>(job->qlen, job->q, job->tlen, job->t, job->init_score, ql, tl, W, Pm->M, Pm->X, Pm->O, Pm->E, Pm->T, stb, tr, tpool, cg, &cells, &ok)
+#define WTZ_EXTFR_CASE(CM) x = wtz_extend_shift_fr<CM>(job->qlen, job->q, job->tlen, job->t, job->init_score, ql, tl, W, Pm->M, Pm->X, Pm->O, Pm->E, Pm->T, stb, tr, tpool, cg, &cells, &ok, &consistent)
 	if(Cw <= 4){ if(CLO < 4 && CHI >= 4) WTZ_EXTFR_CASE(4); }
 	else if(Cw <= 8){ if(CLO < 8 && CHI >= 8) WTZ_EXTFR_CASE(8); }
 	else if(Cw <= 12){ if(CLO < 12 && CHI >= 12) WTZ_EXTFR_CASE(12); }
@@ -335,6 +340,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WTZ_OCC
 	else if(Cw <= 28){ if(CLO < 28 && CHI >= 28) WTZ_EXTFR_CASE(28); }
 	else { if(CHI >= 32) WTZ_EXTFR_CASE(32); }
 #undef WTZ_EXTFR_CASE
+	if(!consistent) return;          /* mat / mis did not follow from the score: the job stays open for the general kernel (wtz_kernel_extjobs) */
 	if(lane == 0){ job->x = x; job->cigar = cg.a; job->cigar_len = cg.n; job->bad = (!ok || cg.bad); job->cells = cells; job->done = 5; }
 }
 

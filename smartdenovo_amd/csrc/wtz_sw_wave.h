@@ -509,8 +509,14 @@ WTZ_D void wtz_cigw_finish(wtz_cigw_t &w){ if(w.tail){ w.v->push(w.tail); w.tail
  * row above: 64 deltas in LDS), leaves the block after 64 rows or through either edge of the window, and the next block is
  * staged around the cell it stands on.  Runs go through the register-tail writer and are reversed once at the end.
  * LDS: 8192 + 64 bytes at `tb` (the target words are dead by now). ---- */
-template<int C, int NL>
-WTZ_D void wtz_shift_traceback(wtz_aln_t &x, uint8_t **zchunk, const int32_t *zb, uint32_t zrow, uint64_t *tb, wtz_cigar_t &cigars){
+/* EQ = false (the frame form, wtz_sw_frame.h): the trace byte holds the four decisions only (bit 3 m<e, bit 2 max(m,e)<f, bit 1 E extended, bit 0 F extended); the walk
+ * counts diagonal steps and gap runs, and matches / mismatches follow from the score: every gap run of the path was opened once (a run ends in the diagonal step
+ * of the cell it was opened from - kswx.h:175-183 opens from m, not from H - so two runs never touch), hence
+ *     score - init = M*mat + X*mis + runs*O + E*(ins + del),   mat + mis = diagonal steps.
+ * `sc` = {M, X, O, E, init_score (clamped)}; returns false when the identity does not come out in integers (never observed; the caller then leaves the job to the general kernel). */
+struct wtz_tb_score { int32_t M, X, O, E, init; };
+template<int C, int NL, bool EQ = true>
+WTZ_D bool wtz_shift_traceback(wtz_aln_t &x, uint8_t **zchunk, const int32_t *zb, uint32_t zrow, uint64_t *tb, wtz_cigar_t &cigars, const wtz_tb_score *sc = NULL){
 	const int lane = (int)(threadIdx.x & 63);
 	constexpr int C4 = (C + 3) / 4;
 	constexpr int NLW = (128 / C) < NL ? (128 / C) : NL;     /* lanes of a row inside the window */
@@ -522,6 +528,7 @@ WTZ_D void wtz_shift_traceback(wtz_aln_t &x, uint8_t **zchunk, const int32_t *zb
 	i_ = -1; j_ = -1;      /* diagnostic build: no traceback (results are wrong) */
 #endif
 	uint32_t run_op = 0xFFu, run_len = 0;
+	int32_t n_gap_runs = 0; bool consistent = true;
 	wtz_cigw_t Wr; Wr.v = &cigars; Wr.tail = 0;
 	int32_t cc = 0;
 	if(i_ >= 0) cc = j_ - wtz_as_global(zb)[i_];
@@ -556,8 +563,14 @@ WTZ_D void wtz_shift_traceback(wtz_aln_t &x, uint8_t **zchunk, const int32_t *zb
 				for(int u = 0; u < 8; u++){
 					/* the kernel's 5 decision bits -> the walker's byte: bits 1:0 move from H, bits 3:2 from E, bits 5:4 from F, bit 7 bases equal */
 					const uint32_t w = w8[u];
-					const uint32_t a = (w >> 3) & 0x01010101u, b = (w >> 4) & 0x01010101u;
-					const uint32_t v = (a << 1) | (b & (a ^ 0x01010101u)) | (w & 0x04040404u) | ((w & 0x02020202u) << 4) | ((w & 0x01010101u) << 7);
+					uint32_t v;
+					if constexpr(EQ){
+						const uint32_t a = (w >> 3) & 0x01010101u, b = (w >> 4) & 0x01010101u;
+						v = (a << 1) | (b & (a ^ 0x01010101u)) | (w & 0x04040404u) | ((w & 0x02020202u) << 4) | ((w & 0x01010101u) << 7);
+					} else {
+						const uint32_t a = (w >> 2) & 0x01010101u, b = (w >> 3) & 0x01010101u;
+						v = (a << 1) | (b & (a ^ 0x01010101u)) | ((w & 0x02020202u) << 1) | ((w & 0x01010101u) << 5);
+					}
 					const uint32_t pos = (uint32_t)(r8 + u) * 128u + pos0;
 					if constexpr((C & 3) == 0) S32[pos >> 2] = v;
 					else {
@@ -580,11 +593,11 @@ WTZ_D void wtz_shift_traceback(wtz_aln_t &x, uint8_t **zchunk, const int32_t *zb
 				}
 				const int32_t sft = (int32_t)Sd[rr];
 				d_ = (zv >> (d_ << 1)) & 0x03;
-				if(d_ == 0){ if(zv & 0x80u) x.mat++; else x.mis++; i_--; j_--; cc += sft - 1; }
+				if(d_ == 0){ if(!EQ || (zv & 0x80u)) x.mat++; else x.mis++; i_--; j_--; cc += sft - 1; }      /* !EQ: x.mat counts the diagonal steps until the end */
 				else if(d_ == 1){ i_--; x.ins++; cc += sft; }
 				else { j_--; x.del++; cc--; }
 				if(d_ == run_op) run_len++;
-				else { if(run_len) wtz_cigw_push(Wr, run_op, run_len); run_op = d_; run_len = 1; }
+				else { if(run_len) wtz_cigw_push(Wr, run_op, run_len); run_op = d_; run_len = 1; if(d_) n_gap_runs++; }
 			}
 		}
 		i_ = __builtin_amdgcn_readfirstlane(i_); j_ = __builtin_amdgcn_readfirstlane(j_); cc = __builtin_amdgcn_readfirstlane(cc);
@@ -592,12 +605,19 @@ WTZ_D void wtz_shift_traceback(wtz_aln_t &x, uint8_t **zchunk, const int32_t *zb
 	}
 	if(lane == 0){
 		if(run_len) wtz_cigw_push(Wr, run_op, run_len);
-		if(i_ >= 0){ x.ins += i_ + 1; wtz_cigw_push(Wr, 1, (uint32_t)(i_ + 1)); }
-		if(j_ >= 0){ x.del += j_ + 1; wtz_cigw_push(Wr, 2, (uint32_t)(j_ + 1)); }
+		if(i_ >= 0){ x.ins += i_ + 1; wtz_cigw_push(Wr, 1, (uint32_t)(i_ + 1)); n_gap_runs++; }
+		if(j_ >= 0){ x.del += j_ + 1; wtz_cigw_push(Wr, 2, (uint32_t)(j_ + 1)); n_gap_runs++; }
 		wtz_cigw_finish(Wr);
 		wtz_cigar_reverse(cigars.a, cigars.n);
+		if constexpr(!EQ){
+			const int32_t nd = x.mat, MXd = sc->M - sc->X;
+			const long long S = (long long)x.score - sc->init - (long long)n_gap_runs * sc->O - (long long)sc->E * (x.ins + x.del) - (long long)sc->X * nd;
+			if(MXd == 0 || S % MXd != 0 || S / MXd < 0 || S / MXd > nd) consistent = false;
+			else { x.mat = (int32_t)(S / MXd); x.mis = nd - x.mat; }
+		}
 		x.aln = x.mat + x.mis + x.ins + x.del; x.qe++; x.te++;
 	}
+	return __builtin_amdgcn_readfirstlane((int)consistent) != 0;
 }
 
 /*
