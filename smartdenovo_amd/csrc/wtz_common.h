@@ -305,6 +305,19 @@ static __host__ __device__ inline unsigned long long *wtz_prof_lds(){ return NUL
 #define WTZ_PROF_MAX(slot, t0) do { (void)(t0); } while(0)
 #endif
 
+/* phase clock of the seed-lookup workgroups, compiled in only with -DWTZ_PROFILE_CAND: ticks per phase, added to global slots by thread 0 of the workgroup
+ * (one atomic per phase per query); printed with the counters when WTZ_PROFILE_PAIR=1 */
+#if defined(__HIPCC__) && defined(WTZ_PROFILE_CAND)
+__device__ unsigned long long wtz_prof_cand[16];
+#define WTZ_CPROF_T() ((unsigned long long)clock64())
+#define WTZ_CPROF_ADD(slot, t0) do { if(threadIdx.x == 0){ const unsigned long long n_ = (unsigned long long)clock64(); atomicAdd(&wtz_prof_cand[slot], n_ - (t0)); (t0) = n_; } } while(0)
+#define WTZ_CPROF_CNT(slot, v) do { if(threadIdx.x == 0) atomicAdd(&wtz_prof_cand[slot], (unsigned long long)(v)); } while(0)
+#else
+#define WTZ_CPROF_T() 0ull
+#define WTZ_CPROF_ADD(slot, t0) do { (void)(t0); } while(0)
+#define WTZ_CPROF_CNT(slot, v) do { } while(0)
+#endif
+
 /* growable vector living in the pool (old storage is simply abandoned on growth) */
 template<typename T> struct wtz_vec {
 	T *a; uint32_t n, cap; wtz_pool_t *pool; int bad;

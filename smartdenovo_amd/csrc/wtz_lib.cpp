@@ -2067,6 +2067,17 @@ extern "C" int wtz_get_counters(wtz_ctx_t *c, wtz_counters_t *out){
 		}
 	}
 #endif
+#if !defined(WTZ_EMUL) && defined(WTZ_PROFILE_CAND)
+	if(c->env_profile){
+		unsigned long long h[16], z[16]; memset(z, 0, sizeof z);
+		if(hipMemcpyFromSymbol(h, HIP_SYMBOL(wtz_prof_cand), sizeof h) == hipSuccess){
+			fprintf(stderr, "[cand-profile] Mticks / counts:");
+			for(int k = 0; k < 16; k++) fprintf(stderr, " %d:%.1f", k, (double)h[k] / 1e6);
+			fprintf(stderr, "\n");
+			(void)hipMemcpyToSymbol(HIP_SYMBOL(wtz_prof_cand), z, sizeof z);
+		}
+	}
+#endif
 	return WTZ_OK;
 }
 extern "C" int wtz_reset_counters(wtz_ctx_t *c){ if(!c) return wtz_fail(WTZ_E_ARG, "null context"); memset(&c->cnt, 0, sizeof c->cnt); return WTZ_OK; }

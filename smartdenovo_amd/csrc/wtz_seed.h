@@ -760,6 +760,7 @@ WTZ_HD void wtz_task_candidates_wg(uint32_t t, wtz_reads_t R, const uint32_t *qi
 	uint32_t *ends = lds + WTZ_CWG_BINS + 2u * WTZ_CWG_CAP;              /* end / start of the tuple at each sorted position: 2 x CAP words */
 	uint32_t *tmp = ends + 2u * WTZ_CWG_CAP;                             /* 64 words of scan / broadcast scratch */
 	/* ---- A: the read's sampled k-mers ---- */
+	unsigned long long pc = WTZ_CPROF_T(); (void)pc;
 	if(tid == 0){
 		const uint64_t pa = (uint64_t)(uintptr_t)wtz_pool_alloc(pool, (size_t)(L + 2) * 24);
 		tmp[60] = (uint32_t)pa; tmp[61] = (uint32_t)(pa >> 32);
@@ -778,6 +779,7 @@ WTZ_HD void wtz_task_candidates_wg(uint32_t t, wtz_reads_t R, const uint32_t *qi
 		if(cnt){ wtz_kq2_f f; f.mer = kmer; f.kq = kq; f.n = ex; wtz_kmer_walk(R, pbid, P->ksize, P->hk, P->ksave, f, jb, je); }
 	}
 	WTZ_WG_SYNC();
+	WTZ_CPROF_ADD(0, pc); WTZ_CPROF_CNT(8, 1); WTZ_CPROF_CNT(9, nk);
 	/* ---- B + H: probe, histogram of the kept tuples over the key bins ---- */
 	const uint32_t key_lo = thr != 0xFFFFFFFFu ? thr << 1 : 0u;
 	uint32_t shift = 0; while(((key_hi > key_lo ? key_hi - key_lo : 1u) >> shift) > WTZ_CWG_BINS - 1u) shift++;
@@ -807,6 +809,7 @@ WTZ_HD void wtz_task_candidates_wg(uint32_t t, wtz_reads_t R, const uint32_t *qi
 		}
 	}
 	WTZ_WG_SYNC();
+	WTZ_CPROF_ADD(1, pc);
 	/* ---- S: bin offsets, buckets, scatter ---- */
 	uint32_t Tk = 0;
 	{
@@ -825,6 +828,7 @@ WTZ_HD void wtz_task_candidates_wg(uint32_t t, wtz_reads_t R, const uint32_t *qi
 	WTZ_WG_SYNC();
 	uint64_t *tup = (uint64_t*)(uintptr_t)(((uint64_t)tmp[61] << 32) | tmp[60]);
 	if(tup == NULL){ if(tid == 0) ncand_out[t] = 0xFFFFFFFFu; return; }
+	WTZ_CPROF_ADD(2, pc); WTZ_CPROF_CNT(10, Tk);
 	uint64_t *grp = tup + ((size_t)Tk + 2);                                          /* groups that reach -d, in key order (at most one per tuple) */
 	const uint32_t grp_cap = Tk + 2;
 	for(uint32_t e = tid; e < nk; e += nt){
@@ -839,6 +843,7 @@ WTZ_HD void wtz_task_candidates_wg(uint32_t t, wtz_reads_t R, const uint32_t *qi
 	__threadfence_block();
 #endif
 	WTZ_WG_SYNC();
+	WTZ_CPROF_ADD(3, pc);
 	/* ---- P: per bucket: sort, then the union length of every group ---- */
 	uint32_t ng = 0; int over = 0;
 	const uint32_t kovl = P->kovl;
@@ -857,7 +862,9 @@ WTZ_HD void wtz_task_candidates_wg(uint32_t t, wtz_reads_t R, const uint32_t *qi
 		WTZ_WG_SYNC();
 		bin0 = bin1;
 		const uint32_t n = t1 - t0;
+		WTZ_CPROF_ADD(4, pc);
 		if(n == 0) continue;
+		WTZ_CPROF_CNT(11, 1);
 		uint64_t *srt = sbuf; uint32_t *en = ends, *qo = ends + WTZ_CWG_CAP;
 		uint32_t np = 64; while(np < n) np <<= 1;
 		if(n > WTZ_CWG_CAP){
@@ -878,6 +885,7 @@ WTZ_HD void wtz_task_candidates_wg(uint32_t t, wtz_reads_t R, const uint32_t *qi
 #endif
 		WTZ_WG_SYNC();
 		wtz_wg_sort_u64(srt, np);
+		WTZ_CPROF_ADD(5, pc);
 		/* query interval of every tuple in sorted order: the walk below then touches LDS only */
 		for(uint32_t i = tid; i < n; i += nt){ const wtz_kq_t q = kq[(uint32_t)srt[i]]; qo[i] = q.qoff; en[i] = q.qoff + q.qlen; }
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -906,6 +914,7 @@ WTZ_HD void wtz_task_candidates_wg(uint32_t t, wtz_reads_t R, const uint32_t *qi
 			ng += chunk;
 		}
 		WTZ_WG_SYNC();
+		WTZ_CPROF_ADD(6, pc);
 	}
 #if defined(__HIP_DEVICE_COMPILE__)
 	over = __syncthreads_or(over);
@@ -938,6 +947,7 @@ WTZ_HD void wtz_task_candidates_wg(uint32_t t, wtz_reads_t R, const uint32_t *qi
 		n = tmp[0];
 		for(uint32_t i = tid; i < n; i += nt) row[i] = hp[i];
 		if(tid == 0) ncand_out[t] = n;
+		WTZ_CPROF_ADD(7, pc); WTZ_CPROF_CNT(12, ng); WTZ_CPROF_CNT(13, n);
 	} else if(tid == 0){
 		uint32_t hn = ncand_out[t];
 		wtz_cand_tail(grp, ng, kovl, P->ncand, cand_out + (size_t)t * stride, &hn);
