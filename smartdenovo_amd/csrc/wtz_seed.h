@@ -745,6 +745,52 @@ WTZ_HD void wtz_wg_sort_u64(uint64_t *a, uint32_t np){
 }
 
 typedef struct { uint32_t qoff, qlen; } wtz_kq_t;
+#define WTZ_CWG_SKETCH 16384u         /* 16-bit counters of the group sketch (32 KB: the sort slots + interval arrays, idle while the tuples are listed) */
+WTZ_HD uint32_t wtz_cwg_sk_hash(uint32_t sd){ return (sd * 0x9E3779B1u) >> 18; }      /* 14 bits */
+/* inclusive running maximum of one value per thread over the workgroup (tmp: 64 LDS words), *total = the maximum */
+WTZ_HD uint32_t wtz_wg_incl_max(uint32_t v, uint32_t *tmp, uint32_t *total){
+#if defined(__HIP_DEVICE_COMPILE__)
+	const uint32_t in = wtz_coop_incl_max32(v);
+	const uint32_t wv = threadIdx.x >> 6, nw = (blockDim.x + 63u) >> 6;
+	__syncthreads();
+	if((threadIdx.x & 63u) == 63u) tmp[wv] = in;
+	__syncthreads();
+	uint32_t base = 0, tot = 0;
+	for(uint32_t k = 0; k < nw; k++){ const uint32_t x = tmp[k]; if(k < wv && x > base) base = x; if(x > tot) tot = x; }
+	*total = tot;
+	return in > base ? in : base;
+#else
+	(void)tmp; *total = v; return v;
+#endif
+}
+/* the seed runs of a query's sampled k-mers, one WAVEFRONT per k-mer: koff[e] = run start << 16 | run length (wtz_kprobe), lanes take the run's entries side by
+ * side (one coalesced read; four k-mers' first reads are issued together).  f(seed, k-mer index, k-mer length) is called for every entry that is neither the
+ * query itself nor a read longer than 1.2 x the query (wtzmo.c:488-489).  Host emulation: one "lane". */
+typedef struct { uint32_t nk; const uint64_t *koff; const wtz_kq_t *kq; const uint32_t *seeds; const uint32_t *rdlen; uint32_t pbid, thr, pblen_up; } wtz_cwg_walk_t;
+template<typename F>
+WTZ_HD void wtz_cwg_for_seeds(const wtz_cwg_walk_t &W, F &&f){
+#if defined(__HIP_DEVICE_COMPILE__)
+	const uint32_t WV = 64u, lane = threadIdx.x & 63u, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+#else
+	const uint32_t WV = 1u, lane = 0u, wv = 0u, nw = 1u;
+#endif
+	for(uint32_t e0 = wv * 4u; e0 < W.nk; e0 += nw * 4u){
+		uint64_t ko[4]; uint32_t ql[4], s0[4];
+		#pragma unroll
+		for(uint32_t u = 0; u < 4u; u++){ const bool in = e0 + u < W.nk; ko[u] = in ? W.koff[e0 + u] : 0ull; ql[u] = in ? W.kq[e0 + u].qlen : 0u; }
+		#pragma unroll
+		for(uint32_t u = 0; u < 4u; u++) s0[u] = lane < (uint32_t)(ko[u] & 0xFFFFu) ? W.seeds[(ko[u] >> 16) + lane] : 0u;
+		#pragma unroll
+		for(uint32_t u = 0; u < 4u; u++){
+			const uint32_t c = (uint32_t)(ko[u] & 0xFFFFu); const uint64_t o = ko[u] >> 16;
+			for(uint32_t k = lane; k < c; k += WV){
+				const uint32_t sd = k == lane ? s0[u] : W.seeds[o + k];
+				const bool drop = ((sd >> 1) == W.pbid) || (W.thr != 0xFFFFFFFFu ? (sd >> 1) < W.thr : W.rdlen[sd >> 1] > W.pblen_up);      /* wtzmo.c:488-489 */
+				if(!drop) f(sd, e0 + u, ql[u]);
+			}
+		}
+	}
+}
 struct wtz_kq2_f { uint64_t *mer; wtz_kq_t *kq; uint32_t n;
 	WTZ_HDM void operator()(uint64_t m, uint32_t, uint32_t qo, uint32_t qe){ uint32_t l = qe - qo; if(l > 0xFFFFu) l = 0xFFFFu; mer[n] = m; kq[n].qoff = qo; kq[n].qlen = l; n++; } };
 
@@ -780,27 +826,23 @@ WTZ_HD void wtz_task_candidates_wg(uint32_t t, wtz_reads_t R, const uint32_t *qi
 	}
 	WTZ_WG_SYNC();
 	WTZ_CPROF_ADD(0, pc); WTZ_CPROF_CNT(8, 1); WTZ_CPROF_CNT(9, nk);
-	/* ---- B + H: probe, histogram of the kept tuples over the key bins ---- */
+	/* ---- B: one hash probe per sampled k-mer (thread per k-mer: independent random reads); the seed runs themselves are then walked by a WAVEFRONT per
+	 * k-mer (wtz_cwg_for_seeds): one coalesced read of the run instead of 64 lanes each stepping through a run of its own ---- */
 	const uint32_t key_lo = thr != 0xFFFFFFFFu ? thr << 1 : 0u;
 	uint32_t shift = 0; while(((key_hi > key_lo ? key_hi - key_lo : 1u) >> shift) > WTZ_CWG_BINS - 1u) shift++;
-	for(uint32_t i = tid; i < WTZ_CWG_BINS; i += nt) hist[i] = 0;
-	WTZ_WG_SYNC();
+	const uint32_t kovl = P->kovl;
 	unsigned long long my_T = 0;
 	for(uint32_t e = tid; e < nk; e += nt){
 		uint64_t o = 0; uint32_t c = 0;
 		if(!wtz_kprobe(tab, tmask, kmer[e], &o, &c)){ o = 0; c = 0; }
 		koff[e] = (o << 16) | c;
 		my_T += c;
-		for(uint32_t k = 0; k < c; k++){
-			const uint32_t sd = seeds[o + k];
-			const bool drop = ((sd >> 1) == pbid) || (thr != 0xFFFFFFFFu ? (sd >> 1) < thr : R.rdlen[sd >> 1] > pblen_up);      /* wtzmo.c:488-489 */
-			if(!drop) WTZ_LDS_ADD32(&hist[(sd - key_lo) >> shift], 1u);
-		}
 	}
 	{   /* algorithmic bytes of this query */
 		uint32_t tot_lo; const uint32_t dummy = wtz_wg_excl_scan((uint32_t)my_T, tmp, &tot_lo); (void)dummy;
 		if(tid == 0){
 			const unsigned long long bytes = (unsigned long long)L / 4 + 16ull * nk + 4ull * tot_lo;
+			WTZ_CPROF_CNT(14, tot_lo);
 #if defined(__HIP_DEVICE_COMPILE__)
 			atomicAdd(algo_bytes, bytes);
 #else
@@ -808,8 +850,30 @@ WTZ_HD void wtz_task_candidates_wg(uint32_t t, wtz_reads_t R, const uint32_t *qi
 #endif
 		}
 	}
+	/* ---- K: sketch.  Nearly every (read, strand) group is a chance hit of one or two k-mers and cannot reach -d; ol <= sum of the group's lengths, so a
+	 * hashed table of that sum (16-bit counters in units of `sk_unit` bases, rounded up; a counter stops counting at the threshold) tells which tuples can
+	 * belong to a group that does.  Collisions only add: no group that reaches -d is lost, and the groups that get through are folded exactly below. ---- */
+	uint32_t *sk = (uint32_t*)sbuf;                                    /* WTZ_CWG_SKETCH half-word counters over the sort slots + interval arrays (idle until stage P) */
+	const uint32_t sk_unit = kovl > 200u ? (kovl + 199u) / 200u : 1u, sk_thr = (kovl + sk_unit - 1u) / sk_unit;      /* <= 200 units per tuple: 256 racing adds stay below 2^16 */
+	for(uint32_t i = tid; i < WTZ_CWG_SKETCH / 2u; i += nt) sk[i] = 0;
+	for(uint32_t i = tid; i < WTZ_CWG_BINS; i += nt) hist[i] = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+	__threadfence_block();
+#endif
+	WTZ_WG_SYNC();
+	const wtz_cwg_walk_t SW = { nk, koff, kq, seeds, R.rdlen, pbid, thr, pblen_up };
+	wtz_cwg_for_seeds(SW, [&](uint32_t sd, uint32_t, uint32_t qlen){
+		const uint32_t h = wtz_cwg_sk_hash(sd), sh = (h & 1u) << 4;
+		if(((sk[h >> 1] >> sh) & 0xFFFFu) < sk_thr){ const uint32_t l = qlen < kovl ? qlen : kovl; WTZ_LDS_ADD32(&sk[h >> 1], ((l + sk_unit - 1u) / sk_unit) << sh); }
+	});
 	WTZ_WG_SYNC();
 	WTZ_CPROF_ADD(1, pc);
+	/* ---- H: histogram of the tuples the sketch lets through over the key bins ---- */
+	wtz_cwg_for_seeds(SW, [&](uint32_t sd, uint32_t, uint32_t){
+		const uint32_t h = wtz_cwg_sk_hash(sd);
+		if(((sk[h >> 1] >> ((h & 1u) << 4)) & 0xFFFFu) >= sk_thr) WTZ_LDS_ADD32(&hist[(sd - key_lo) >> shift], 1u);
+	});
+	WTZ_WG_SYNC();
 	/* ---- S: bin offsets, buckets, scatter ---- */
 	uint32_t Tk = 0;
 	{
@@ -831,14 +895,10 @@ WTZ_HD void wtz_task_candidates_wg(uint32_t t, wtz_reads_t R, const uint32_t *qi
 	WTZ_CPROF_ADD(2, pc); WTZ_CPROF_CNT(10, Tk);
 	uint64_t *grp = tup + ((size_t)Tk + 2);                                          /* groups that reach -d, in key order (at most one per tuple) */
 	const uint32_t grp_cap = Tk + 2;
-	for(uint32_t e = tid; e < nk; e += nt){
-		const uint32_t c = (uint32_t)(koff[e] & 0xFFFFu); const uint64_t o = koff[e] >> 16;
-		for(uint32_t k = 0; k < c; k++){
-			const uint32_t sd = seeds[o + k];
-			const bool drop = ((sd >> 1) == pbid) || (thr != 0xFFFFFFFFu ? (sd >> 1) < thr : R.rdlen[sd >> 1] > pblen_up);
-			if(!drop){ const uint32_t pos = WTZ_LDS_ADD32(&hist[(sd - key_lo) >> shift], 1u); tup[pos] = ((uint64_t)sd << 32) | e; }
-		}
-	}
+	wtz_cwg_for_seeds(SW, [&](uint32_t sd, uint32_t e, uint32_t){
+		const uint32_t h = wtz_cwg_sk_hash(sd);
+		if(((sk[h >> 1] >> ((h & 1u) << 4)) & 0xFFFFu) >= sk_thr){ const uint32_t pos = WTZ_LDS_ADD32(&hist[(sd - key_lo) >> shift], 1u); tup[pos] = ((uint64_t)sd << 32) | e; }
+	});
 #if defined(__HIP_DEVICE_COMPILE__)
 	__threadfence_block();
 #endif
@@ -846,20 +906,18 @@ WTZ_HD void wtz_task_candidates_wg(uint32_t t, wtz_reads_t R, const uint32_t *qi
 	WTZ_CPROF_ADD(3, pc);
 	/* ---- P: per bucket: sort, then the union length of every group ---- */
 	uint32_t ng = 0; int over = 0;
-	const uint32_t kovl = P->kovl;
 	/* buckets = consecutive bins while their tuples fit the sort slots (a bin above CAP is a bucket of its own); after the scatter a bin's cursor
-	 * stands at the start of the next bin, so bin b covers [hist[b - 1], hist[b]) */
+	 * stands at the start of the next bin, so bin b covers [hist[b - 1], hist[b]) and hist[] is non-decreasing: the end of a bucket is a binary search
+	 * that every thread does for itself (LDS broadcasts; thread 0 stepping through the bins was a twelfth of the kernel) */
 	for(uint32_t bin0 = 0; bin0 < WTZ_CWG_BINS; ){
-		if(tid == 0){
-			const uint32_t s0 = bin0 ? hist[bin0 - 1] : 0u;
-			uint32_t b1 = bin0 + 1;
-			while(b1 < WTZ_CWG_BINS && hist[b1] - s0 <= WTZ_CWG_CAP) b1++;
-			tmp[62] = b1;
+		const uint32_t t0 = bin0 ? hist[bin0 - 1] : 0u;
+		uint32_t bin1;
+		{
+			uint32_t lo = bin0 + 1, hi = WTZ_CWG_BINS;      /* the first b in (bin0, BINS) with hist[b] - t0 > CAP, or BINS */
+			while(lo < hi){ const uint32_t mid = lo + (hi - lo) / 2u; if(hist[mid] - t0 > WTZ_CWG_CAP) hi = mid; else lo = mid + 1; }
+			bin1 = lo;
 		}
-		WTZ_WG_SYNC();
-		const uint32_t bin1 = tmp[62];
-		const uint32_t t0 = bin0 ? hist[bin0 - 1] : 0u, t1 = hist[bin1 - 1];
-		WTZ_WG_SYNC();
+		const uint32_t t1 = hist[bin1 - 1];
 		bin0 = bin1;
 		const uint32_t n = t1 - t0;
 		WTZ_CPROF_ADD(4, pc);
@@ -867,7 +925,9 @@ WTZ_HD void wtz_task_candidates_wg(uint32_t t, wtz_reads_t R, const uint32_t *qi
 		WTZ_CPROF_CNT(11, 1);
 		uint64_t *srt = sbuf; uint32_t *en = ends, *qo = ends + WTZ_CWG_CAP;
 		uint32_t np = 64; while(np < n) np <<= 1;
-		if(n > WTZ_CWG_CAP){
+		const bool in_lds = n <= WTZ_CWG_CAP;
+		WTZ_WG_SYNC();                                      /* the previous bucket's readers are done with the sort slots */
+		if(!in_lds){
 			/* one bin alone holds more than CAP tuples (a read that shares thousands of k-mers with the query: duplicates, repeats): same steps on
 			 * arrays in the pool */
 			if(tid == 0){
@@ -886,34 +946,77 @@ WTZ_HD void wtz_task_candidates_wg(uint32_t t, wtz_reads_t R, const uint32_t *qi
 		WTZ_WG_SYNC();
 		wtz_wg_sort_u64(srt, np);
 		WTZ_CPROF_ADD(5, pc);
-		/* query interval of every tuple in sorted order: the walk below then touches LDS only */
+		/* query interval of every tuple in sorted order: the fold below then touches LDS only */
 		for(uint32_t i = tid; i < n; i += nt){ const wtz_kq_t q = kq[(uint32_t)srt[i]]; qo[i] = q.qoff; en[i] = q.qoff + q.qlen; }
 #if defined(__HIP_DEVICE_COMPILE__)
 		__threadfence_block();
 #endif
 		WTZ_WG_SYNC();
-		/* the thread at a group's first tuple folds the group (wtzmo.c:558-560); nearly all groups have one or two tuples, the real overlaps a few
-		 * hundred; groups with ol >= -d are appended in key order */
-		for(uint32_t i0 = 0; i0 < n; i0 += nt){
-			const uint32_t i = i0 + tid;
-			uint32_t keep = 0; uint64_t g = 0;
-			if(i < n){
-				const uint32_t key = (uint32_t)(srt[i] >> 32);
-				if(i == 0 || (uint32_t)(srt[i - 1] >> 32) != key){
-					uint32_t ol = 0, lst = 0;
-					for(uint32_t r = i; r < n && (uint32_t)(srt[r] >> 32) == key; r++){
-						const uint32_t q0 = qo[r], e1 = en[r];
-						if(q0 >= lst) ol += e1 - q0; else ol += e1 - lst;       /* wtzmo.c:558-559: len, or off + len - lst (u32 arithmetic) */
-						lst = e1;
-					}
-					if(ol >= kovl){ keep = 1; g = ((uint64_t)key << 32) | ol; }
+		if(in_lds){
+			/* the union-length recurrence of wtzmo.c:558-560 without a walk: after a group's first tuple `lst` is the end of the tuple before, so the addend of
+			 * tuple i is  en[i] - (qo[i] >= en[i-1] ? qo[i] : en[i-1])  (first tuple: en - qo; u32 arithmetic as the reference's) and ol is a segmented sum.  Two
+			 * workgroup scans over the sorted bucket: S = running sum of the addends (kept where qo was), H = position + 1 of the latest group start (kept in the
+			 * low word of the sort slot: the k-mer index there is dead); the last tuple of a group then has ol = S[i] - S[H[i] - 2]. */
+			uint32_t carry_s = 0, carry_h = 0;
+			for(uint32_t i0 = 0; i0 < n; i0 += nt){
+				const uint32_t i = i0 + tid;
+				uint32_t add = 0, hd = 0;
+				if(i < n){
+					const uint32_t key = (uint32_t)(srt[i] >> 32), q0 = qo[i], e1 = en[i];
+					if(i == 0 || (uint32_t)(srt[i - 1] >> 32) != key){ add = e1 - q0; hd = i + 1; }
+					else { const uint32_t lst = en[i - 1]; add = q0 >= lst ? e1 - q0 : e1 - lst; }
 				}
+				uint32_t tot_s, tot_h;
+				const uint32_t ex = wtz_wg_excl_scan(add, tmp, &tot_s);
+				const uint32_t hm = wtz_wg_incl_max(hd, tmp, &tot_h);
+				if(i < n){
+					qo[i] = carry_s + ex + add;
+					const uint32_t hh = hm > carry_h ? hm : carry_h;
+					srt[i] = (srt[i] & 0xFFFFFFFF00000000ull) | hh;
+				}
+				carry_s += tot_s; if(tot_h > carry_h) carry_h = tot_h;
 			}
-			uint32_t chunk; const uint32_t ex = wtz_wg_excl_scan(keep, tmp, &chunk);
-			if(keep){ if(ng + ex < grp_cap) grp[ng + ex] = g; else over = 1; }
-			ng += chunk;
+#if defined(__HIP_DEVICE_COMPILE__)
+			__threadfence_block();
+#endif
+			WTZ_WG_SYNC();
+			for(uint32_t i0 = 0; i0 < n; i0 += nt){
+				const uint32_t i = i0 + tid;
+				uint32_t keep = 0; uint64_t g = 0;
+				if(i < n){
+					const uint32_t key = (uint32_t)(srt[i] >> 32);
+					if(i + 1 == n || (uint32_t)(srt[i + 1] >> 32) != key){
+						const uint32_t hh = (uint32_t)srt[i];                 /* >= 1: tuple 0 starts a group */
+						const uint32_t ol = qo[i] - (hh >= 2u ? qo[hh - 2u] : 0u);
+						if(ol >= kovl){ keep = 1; g = ((uint64_t)key << 32) | ol; }
+					}
+				}
+				uint32_t chunk; const uint32_t ex = wtz_wg_excl_scan(keep, tmp, &chunk);
+				if(keep){ if(ng + ex < grp_cap) grp[ng + ex] = g; else over = 1; }
+				ng += chunk;
+			}
+		} else {
+			/* the thread at a group's first tuple folds the group (wtzmo.c:558-560) */
+			for(uint32_t i0 = 0; i0 < n; i0 += nt){
+				const uint32_t i = i0 + tid;
+				uint32_t keep = 0; uint64_t g = 0;
+				if(i < n){
+					const uint32_t key = (uint32_t)(srt[i] >> 32);
+					if(i == 0 || (uint32_t)(srt[i - 1] >> 32) != key){
+						uint32_t ol = 0, lst = 0;
+						for(uint32_t r = i; r < n && (uint32_t)(srt[r] >> 32) == key; r++){
+							const uint32_t q0 = qo[r], e1 = en[r];
+							if(q0 >= lst) ol += e1 - q0; else ol += e1 - lst;       /* wtzmo.c:558-559: len, or off + len - lst (u32 arithmetic) */
+							lst = e1;
+						}
+						if(ol >= kovl){ keep = 1; g = ((uint64_t)key << 32) | ol; }
+					}
+				}
+				uint32_t chunk; const uint32_t ex = wtz_wg_excl_scan(keep, tmp, &chunk);
+				if(keep){ if(ng + ex < grp_cap) grp[ng + ex] = g; else over = 1; }
+				ng += chunk;
+			}
 		}
-		WTZ_WG_SYNC();
 		WTZ_CPROF_ADD(6, pc);
 	}
 #if defined(__HIP_DEVICE_COMPILE__)
