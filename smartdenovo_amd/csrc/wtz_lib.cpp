@@ -187,7 +187,7 @@ template<typename TAG, typename F> static int wtz_launch_coop(hipStream_t st, ui
 	return WTZ_OK;
 }
 /* one task per WORKGROUP of NT threads (wave-size multiples): every thread enters the task body (WTZ_WG_TID / WTZ_WG_SYNC inside) */
-template<typename TAG, typename F> __global__ void __launch_bounds__(256) wtz_kernel_wg_tasks(uint64_t n, F f){
+template<typename TAG, typename F> __global__ void __launch_bounds__(WTZ_CWG_THREADS) wtz_kernel_wg_tasks(uint64_t n, F f){
 	const uint64_t i = blockIdx.x;
 	if(i < n) f(i);
 }

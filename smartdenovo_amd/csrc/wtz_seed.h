@@ -691,7 +691,9 @@ WTZ_D bool wtz_cand_stream(uint32_t t, const wtz_reads_t &R, uint32_t pbid, uint
  *   F  thread 0 replays strand merge + candidate heap with its quirks over the groups that reach -d (wtz_cand_tail), unchanged.
  * HBM traffic per tuple: 4 B seed entry read twice, 8 B written and read once: ~24 B instead of ~700.
  */
-#define WTZ_CWG_THREADS 256u
+#ifndef WTZ_CWG_THREADS
+#define WTZ_CWG_THREADS 512u
+#endif
 #define WTZ_CWG_BINS 4096u
 #define WTZ_CWG_CAP 2048u
 #define WTZ_CWG_LDS_BYTES (WTZ_CWG_BINS * 4u + WTZ_CWG_CAP * 8u + 2u * WTZ_CWG_CAP * 4u + 64u * 4u)
@@ -770,27 +772,49 @@ typedef struct { uint32_t nk; const uint64_t *koff; const wtz_kq_t *kq; const ui
 template<typename F>
 WTZ_HD void wtz_cwg_for_seeds(const wtz_cwg_walk_t &W, F &&f){
 #if defined(__HIP_DEVICE_COMPILE__)
-	const uint32_t WV = 64u, lane = threadIdx.x & 63u, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
-#else
-	const uint32_t WV = 1u, lane = 0u, wv = 0u, nw = 1u;
-#endif
-	for(uint32_t e0 = wv * 4u; e0 < W.nk; e0 += nw * 4u){
-		uint64_t ko[4]; uint32_t ql[4], s0[4];
-		#pragma unroll
-		for(uint32_t u = 0; u < 4u; u++){ const bool in = e0 + u < W.nk; ko[u] = in ? W.koff[e0 + u] : 0ull; ql[u] = in ? W.kq[e0 + u].qlen : 0u; }
-		#pragma unroll
-		for(uint32_t u = 0; u < 4u; u++) s0[u] = lane < (uint32_t)(ko[u] & 0xFFFFu) ? W.seeds[(ko[u] >> 16) + lane] : 0u;
-		#pragma unroll
-		for(uint32_t u = 0; u < 4u; u++){
-			const uint32_t c = (uint32_t)(ko[u] & 0xFFFFu); const uint64_t o = ko[u] >> 16;
-			for(uint32_t k = lane; k < c; k += WV){
-				const uint32_t sd = k == lane ? s0[u] : W.seeds[o + k];
-				const bool drop = ((sd >> 1) == W.pbid) || (W.thr != 0xFFFFFFFFu ? (sd >> 1) < W.thr : W.rdlen[sd >> 1] > W.pblen_up);      /* wtzmo.c:488-489 */
-				if(!drop) f(sd, e0 + u, ql[u]);
+	/* 64 k-mers per step: every lane fetches one run descriptor, then the wave takes the runs four at a time with the descriptors read from the lanes'
+	 * registers (v_readlane: no dependent load in front of the seed reads) */
+	const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+	for(uint32_t base = wv * 64u; base < W.nk; base += nw * 64u){
+		const uint32_t cnt = W.nk - base < 64u ? W.nk - base : 64u;
+		const bool in = lane < cnt;
+		const uint64_t myko = in ? W.koff[base + lane] : 0ull;
+		const uint32_t myql = in ? W.kq[base + lane].qlen : 0u;
+		const uint32_t my_lo = (uint32_t)myko, my_hi = (uint32_t)(myko >> 32);
+		for(uint32_t u0 = 0; u0 < cnt; u0 += 4u){
+			uint64_t ko[4]; uint32_t ql[4], s0[4];
+			#pragma unroll
+			for(uint32_t u = 0; u < 4u; u++){
+				const uint32_t src = u0 + u < 64u ? u0 + u : 63u;       /* lanes >= cnt hold empty runs */
+				ko[u] = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)my_hi, (int)src) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)my_lo, (int)src);
+				ql[u] = (uint32_t)__builtin_amdgcn_readlane((int)myql, (int)src);
+				if(u0 + u >= cnt) ko[u] = 0ull;
+			}
+			#pragma unroll
+			for(uint32_t u = 0; u < 4u; u++) s0[u] = lane < (uint32_t)(ko[u] & 0xFFFFu) ? W.seeds[(ko[u] >> 16) + lane] : 0u;
+			#pragma unroll
+			for(uint32_t u = 0; u < 4u; u++){
+				const uint32_t c = (uint32_t)(ko[u] & 0xFFFFu); const uint64_t o = ko[u] >> 16;
+				for(uint32_t k = lane; k < c; k += 64u){
+					const uint32_t sd = k == lane ? s0[u] : W.seeds[o + k];
+					const bool drop = ((sd >> 1) == W.pbid) || (W.thr != 0xFFFFFFFFu ? (sd >> 1) < W.thr : W.rdlen[sd >> 1] > W.pblen_up);      /* wtzmo.c:488-489 */
+					if(!drop) f(sd, base + u0 + u, ql[u]);
+				}
 			}
 		}
 	}
+#else
+	for(uint32_t e = 0; e < W.nk; e++){
+		const uint32_t c = (uint32_t)(W.koff[e] & 0xFFFFu); const uint64_t o = W.koff[e] >> 16; const uint32_t ql = W.kq[e].qlen;
+		for(uint32_t k = 0; k < c; k++){
+			const uint32_t sd = W.seeds[o + k];
+			const bool drop = ((sd >> 1) == W.pbid) || (W.thr != 0xFFFFFFFFu ? (sd >> 1) < W.thr : W.rdlen[sd >> 1] > W.pblen_up);      /* wtzmo.c:488-489 */
+			if(!drop) f(sd, e, ql);
+		}
+	}
+#endif
 }
+
 struct wtz_kq2_f { uint64_t *mer; wtz_kq_t *kq; uint32_t n;
 	WTZ_HDM void operator()(uint64_t m, uint32_t, uint32_t qo, uint32_t qe){ uint32_t l = qe - qo; if(l > 0xFFFFu) l = 0xFFFFu; mer[n] = m; kq[n].qoff = qo; kq[n].qlen = l; n++; } };
 
@@ -831,7 +855,7 @@ WTZ_HD void wtz_task_candidates_wg(uint32_t t, wtz_reads_t R, const uint32_t *qi
 	const uint32_t key_lo = thr != 0xFFFFFFFFu ? thr << 1 : 0u;
 	uint32_t shift = 0; while(((key_hi > key_lo ? key_hi - key_lo : 1u) >> shift) > WTZ_CWG_BINS - 1u) shift++;
 	const uint32_t kovl = P->kovl;
-	unsigned long long my_T = 0;
+	unsigned long long my_T = 0; uint32_t T_all = 0;
 	for(uint32_t e = tid; e < nk; e += nt){
 		uint64_t o = 0; uint32_t c = 0;
 		if(!wtz_kprobe(tab, tmask, kmer[e], &o, &c)){ o = 0; c = 0; }
@@ -840,6 +864,7 @@ WTZ_HD void wtz_task_candidates_wg(uint32_t t, wtz_reads_t R, const uint32_t *qi
 	}
 	{   /* algorithmic bytes of this query */
 		uint32_t tot_lo; const uint32_t dummy = wtz_wg_excl_scan((uint32_t)my_T, tmp, &tot_lo); (void)dummy;
+		T_all = tot_lo;
 		if(tid == 0){
 			const unsigned long long bytes = (unsigned long long)L / 4 + 16ull * nk + 4ull * tot_lo;
 			WTZ_CPROF_CNT(14, tot_lo);
@@ -868,11 +893,25 @@ WTZ_HD void wtz_task_candidates_wg(uint32_t t, wtz_reads_t R, const uint32_t *qi
 	});
 	WTZ_WG_SYNC();
 	WTZ_CPROF_ADD(1, pc);
-	/* ---- H: histogram of the tuples the sketch lets through over the key bins ---- */
-	wtz_cwg_for_seeds(SW, [&](uint32_t sd, uint32_t, uint32_t){
+	/* ---- H: the tuples the sketch lets through: histogram over the key bins, and the tuples themselves listed once (in any order) so that the scatter below
+	 * reads a sixth of the seed entries back instead of walking all the runs a third time ---- */
+	if(tid == 0){
+		const uint64_t pa = (uint64_t)(uintptr_t)wtz_pool_alloc(pool, ((size_t)T_all + 2) * 8);
+		tmp[60] = (uint32_t)pa; tmp[61] = (uint32_t)(pa >> 32); tmp[59] = 0;
+	}
+	WTZ_WG_SYNC();
+	uint64_t *lst_t = (uint64_t*)(uintptr_t)(((uint64_t)tmp[61] << 32) | tmp[60]);
+	if(lst_t == NULL){ if(tid == 0) ncand_out[t] = 0xFFFFFFFFu; return; }
+	wtz_cwg_for_seeds(SW, [&](uint32_t sd, uint32_t e, uint32_t){
 		const uint32_t h = wtz_cwg_sk_hash(sd);
-		if(((sk[h >> 1] >> ((h & 1u) << 4)) & 0xFFFFu) >= sk_thr) WTZ_LDS_ADD32(&hist[(sd - key_lo) >> shift], 1u);
+		if(((sk[h >> 1] >> ((h & 1u) << 4)) & 0xFFFFu) >= sk_thr){
+			WTZ_LDS_ADD32(&hist[(sd - key_lo) >> shift], 1u);
+			lst_t[WTZ_LDS_ADD32(&tmp[59], 1u)] = ((uint64_t)sd << 32) | e;
+		}
 	});
+#if defined(__HIP_DEVICE_COMPILE__)
+	__threadfence_block();
+#endif
 	WTZ_WG_SYNC();
 	/* ---- S: bin offsets, buckets, scatter ---- */
 	uint32_t Tk = 0;
@@ -895,10 +934,7 @@ WTZ_HD void wtz_task_candidates_wg(uint32_t t, wtz_reads_t R, const uint32_t *qi
 	WTZ_CPROF_ADD(2, pc); WTZ_CPROF_CNT(10, Tk);
 	uint64_t *grp = tup + ((size_t)Tk + 2);                                          /* groups that reach -d, in key order (at most one per tuple) */
 	const uint32_t grp_cap = Tk + 2;
-	wtz_cwg_for_seeds(SW, [&](uint32_t sd, uint32_t e, uint32_t){
-		const uint32_t h = wtz_cwg_sk_hash(sd);
-		if(((sk[h >> 1] >> ((h & 1u) << 4)) & 0xFFFFu) >= sk_thr){ const uint32_t pos = WTZ_LDS_ADD32(&hist[(sd - key_lo) >> shift], 1u); tup[pos] = ((uint64_t)sd << 32) | e; }
-	});
+	for(uint32_t i = tid; i < Tk; i += nt){ const uint64_t w = lst_t[i]; tup[WTZ_LDS_ADD32(&hist[((uint32_t)(w >> 32) - key_lo) >> shift], 1u)] = w; }
 #if defined(__HIP_DEVICE_COMPILE__)
 	__threadfence_block();
 #endif
