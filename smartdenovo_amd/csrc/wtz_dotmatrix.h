@@ -2,8 +2,8 @@
  * wtz_dotmatrix.h — per-pair task body of the SW-free "dmo" engine (A7d).
  *
  *   wtz_denoise        hzm_aln.h:721-889    denoising_hzmps
- *   wtz_merge_blocks   hzm_aln.h:933-1054   fast_merge_wtseedv
- *   wtz_chain_blocks   hzm_aln.h:1056-1132  chaining_overhang_wtseedv
+ *   wtz_merge_blocks   hzm_aln.h:933-1054   fast_merge_wtseedv (wtz_blockband + wtz_blocklabels, one lane)
+ *   wtz_chain_blocks_coop hzm_aln.h:1056-1132  chaining_overhang_wtseedv (the whole wavefront: one step per block)
  *   wtz_dot_matrix_align hzm_aln.h:1134-1181
  *
  * The load-bearing quirks of the reference are kept (SURVEY §8a trap 3): the band loop compares a
@@ -793,107 +793,168 @@ WTZ_HD void wtz_denoise(wtz_zhit_t *rs, uint32_t n_rs, wtz_dmscratch_t &S, int32
 	for(uint32_t dir = 0; dir < 2; dir++) wtz_denoise_dir(rs, n_rs, dir, S, xvar, yvar, min_linear_len);
 }
 
+/* ---------------------------------------------------------------------------------------------------------------------------------------------------
+ * Block merging (fast_merge_wtseedv, hzm_aln.h:933-1054) as three steps over small arrays; executed by ONE lane (a strand has a handful of blocks - the
+ * wave's share of this stage is the chain below).  What has to come out as the reference's does, and why it is written the way it is:
+ *   - the blocks are first put in (diagonal, beg0) order and every block is a "diagonal" of its own (hzm_aln.h:942-955: `d` is reset per block), so a band
+ *     is an index interval [lo, hi) of that order: hi stops at the first diagonal beyond D[lo] + span and never reaches the last block (957-962); a band
+ *     whose closing diagonal equals that of the band emitted before is skipped whole (964-967); the next band starts at the first diagonal beyond
+ *     D[lo] + span / 2 (1005-1008).  wtz_blockband walks that sequence over a plain array of diagonals.
+ *   - inside a band the members are taken in beg0 order (the reference's own unstable sort: ties are observable) and cut into runs: a run is led by its
+ *     first member and takes every following member that begins no later than the LEADER's end + xvar (982, 998: s0 only moves at a cut).
+ *   - a run adopts the label of its first labelled member - through the forwarding table - and forwards the labels of its other labelled members to it
+ *     (986-992); the table is then flattened by the reference's own three-level pass (1010-1019, not a full closure: kept as is), blocks are relabelled,
+ *     put in (label, beg0) order, every label's blocks folded into the first one (bounding box, ovl summed in 29 bits) and the folded ones dropped.
+ * --------------------------------------------------------------------------------------------------------------------------------------------------- */
+struct wtz_blockband {
+	const int32_t *D; uint32_t n; int32_t span;
+	uint32_t at; int32_t closing; bool have_closing;
+	WTZ_HDM void start(const int32_t *diag, uint32_t count, int32_t sp){ D = diag; n = count; span = sp; at = 0; closing = 0; have_closing = false; }
+	/* the next band to process as [lo, hi); false when the sweep is over */
+	WTZ_HDM bool next(uint32_t &lo, uint32_t &hi){
+		while(at < n){
+			const int32_t first = D[at];
+			uint32_t len = 0;
+			while(D[at + len] <= first + span && at + len + 1 < n) len++;
+			if(len == 0) return false;
+			const int32_t cl = D[at + len];
+			if(have_closing && cl == closing){ at += len; continue; }
+			closing = cl; have_closing = true;
+			lo = at; hi = at + len;
+			uint32_t nx = lo;
+			while(nx < hi && D[nx] <= first + span / 2) nx++;
+			at = nx;
+			return true;
+		}
+		return false;
+	}
+};
+/* label forwarding table of the merge: entry 0 = "no label" */
+struct wtz_blocklabels {
+	wtz_vec<uint32_t> *fw;
+	WTZ_HDM bool reset(){ fw->n = 0; return fw->push(0u); }
+	WTZ_HDM uint32_t fresh(){ const uint32_t g = fw->n; return fw->push(g) ? g : 0u; }
+	/* one run of band members ord[a..b): all end up with the label the run adopts */
+	WTZ_HDM bool adopt(wtz_win_t *blk, const uint32_t *ord, uint32_t a, uint32_t b){
+		uint32_t lab = 0;
+		for(uint32_t k = a; k < b; k++){
+			const uint32_t old = blk[ord[k]].pb2;
+			if(old == 0) continue;
+			if(lab == 0) lab = fw->a[old]; else fw->a[old] = lab;
+		}
+		if(lab == 0){ lab = fresh(); if(lab == 0) return false; }
+		for(uint32_t k = a; k < b; k++) blk[ord[k]].pb2 = lab;
+		return true;
+	}
+};
+
 WTZ_HD void wtz_merge_blocks(wtz_vec<wtz_win_t> &rv, wtz_dmscratch_t &S, int32_t xvar, int32_t yvar){
-	wtz_win_t *regs = rv.a; const uint32_t n = rv.n;
-	uint32_t i, j, k, doff, dcnt = 0, gid;
-	int32_t lst_offset = 0, end_offset;
-	wtz_sort_exact(regs, (size_t)n, wtz_gt_wdiag());
+	wtz_win_t *blk = rv.a; const uint32_t n = rv.n;
+	wtz_sort_exact(blk, (size_t)n, wtz_gt_wdiag());
+	/* the diagonals as a plain array (in the `offset` fields of the diagonal scratch: its other fields are not needed - every block is its own diagonal) */
 	S.diags.n = 0;
 	if(!S.diags.reserve(n + 2)) return;
-	for(i = 0; i < n; i++){ wtz_diag_t d; d.offset = regs[i].beg[0] - regs[i].beg[1]; d.off = i; d.cnt = 1; S.diags.a[S.diags.n++] = d; }
-	doff = 0; end_offset = -0x7FFFFFFF;
-	S.grps.n = 0; S.grps.push(0);
-	for(;;){
-		int st = wtz_band_next(S.diags.a, S.diags.n, n, doff, dcnt, lst_offset, end_offset, yvar);
-		if(st == 0) break;
-		if(st == 1) continue;
+	int32_t *D = (int32_t*)S.diags.a;
+	for(uint32_t i = 0; i < n; i++) D[i] = blk[i].beg[0] - blk[i].beg[1];
+	wtz_blocklabels labels; labels.fw = &S.grps;
+	if(!labels.reset()) return;
+	wtz_blockband sweep; sweep.start(D, n, yvar);
+	uint32_t lo, hi;
+	while(sweep.next(lo, hi)){
 		S.block.n = 0;
-		for(i = 0; i < dcnt; i++){ const wtz_diag_t dg = S.diags.a[i + doff]; for(j = 0; j < dg.cnt; j++) if(!S.block.push(dg.off + j)) return; }
-		wtz_gt_widx_beg0 gb; gb.rs = regs;
-		wtz_sort_exact(S.block.a, (size_t)S.block.n, gb);
-		int32_t s0_end0 = S.block.n ? regs[S.block.a[0]].end[0] : 0;
-		j = 0;
-		for(i = 1; i <= S.block.n; i++){
-			const int32_t s_beg0 = (i == S.block.n) ? WTZ_SEED_OFF_MAX : regs[S.block.a[i]].beg[0];
-			const int32_t s_end0 = (i == S.block.n) ? 0 : regs[S.block.a[i]].end[0];
-			if(s_beg0 <= s0_end0 + xvar){
-			} else {
-				gid = 0;
-				for(k = j; k < i; k++){
-					uint32_t g = regs[S.block.a[k]].pb2;
-					if(g){ if(gid == 0) gid = S.grps.a[g]; else S.grps.a[g] = gid; }
-				}
-				if(gid == 0){ gid = S.grps.n; if(!S.grps.push(gid)) return; }
-				for(; j < i; j++) regs[S.block.a[j]].pb2 = gid;
-				j = i;
-				s0_end0 = s_end0;
-			}
+		if(!S.block.reserve(hi - lo)) return;
+		uint32_t *ord = S.block.a; const uint32_t m = hi - lo;
+		for(uint32_t k = 0; k < m; k++) ord[k] = lo + k;
+		S.block.n = m;
+		wtz_gt_widx_beg0 by_beg; by_beg.rs = blk;
+		wtz_sort_exact(ord, (size_t)m, by_beg);
+		uint32_t lead = 0;
+		for(uint32_t k = 1; k <= m; k++){
+			if(k < m && blk[ord[k]].beg[0] <= blk[ord[lead]].end[0] + xvar) continue;      /* still inside the leader's reach (k == m: the sentinel of hzm_aln.h:940 starts beyond everything) */
+			if(!labels.adopt(blk, ord, lead, k)) return;
+			lead = k;
 		}
-		wtz_band_advance(S.diags.a, doff, dcnt, lst_offset, yvar);
 	}
 	wtz_tidy_groups(S.grps.a, S.grps.n);
-	for(i = 0; i < n; i++){ if(regs[i].pb2 == 0) continue; regs[i].pb2 = S.grps.a[regs[i].pb2]; }
-	wtz_sort_exact(regs, (size_t)n, wtz_gt_wgrp());
-	for(j = 0; j < n; j++) if(regs[j].pb2) break;
-	for(i = j + 1; i <= n; i++){
-		if(i < n && regs[i].pb2 == regs[j].pb2) continue;
-		wtz_win_t *s0 = &regs[j];
-		for(k = j + 1; k < i; k++){
-			wtz_win_t *s = &regs[k];
-			s->closed = 1;
-			if(s->beg[0] < s0->beg[0]) s0->beg[0] = s->beg[0];
-			if(s->end[0] > s0->end[0]) s0->end[0] = s->end[0];
-			if(s->beg[1] < s0->beg[1]) s0->beg[1] = s->beg[1];
-			if(s->end[1] > s0->end[1]) s0->end[1] = s->end[1];
-			s0->ovl = WTZ_OVL29(s0->ovl + s->ovl);
+	for(uint32_t i = 0; i < n; i++) if(blk[i].pb2) blk[i].pb2 = S.grps.a[blk[i].pb2];
+	wtz_sort_exact(blk, (size_t)n, wtz_gt_wgrp());
+	uint32_t head = 0;
+	while(head < n && blk[head].pb2 == 0) head++;                   /* unlabelled blocks stay as they are (they sort first) */
+	while(head < n){
+		uint32_t tail = head + 1;
+		wtz_win_t acc = blk[head];
+		for(; tail < n && blk[tail].pb2 == acc.pb2; tail++){
+			const wtz_win_t &o = blk[tail];
+			acc.beg[0] = o.beg[0] < acc.beg[0] ? o.beg[0] : acc.beg[0]; acc.end[0] = o.end[0] > acc.end[0] ? o.end[0] : acc.end[0];
+			acc.beg[1] = o.beg[1] < acc.beg[1] ? o.beg[1] : acc.beg[1]; acc.end[1] = o.end[1] > acc.end[1] ? o.end[1] : acc.end[1];
+			acc.ovl = WTZ_OVL29(acc.ovl + o.ovl);
+			blk[tail].closed = 1;
 		}
-		j = i;
+		blk[head] = acc;
+		head = tail;
 	}
-	wtz_sort_exact(regs, (size_t)n, wtz_gt_wclosed());
-	for(i = 0; i < n; i++) if(regs[i].closed) break;
-	rv.n = i;
+	wtz_sort_exact(blk, (size_t)n, wtz_gt_wclosed());
+	uint32_t kept = 0;
+	while(kept < n && !blk[kept].closed) kept++;
+	rv.n = kept;
 }
 
 WTZ_HD int32_t wtz_w30(int32_t v){ return (int32_t)((uint32_t)v << 2) >> 2; }     /* node_t.weight:30, hzm_aln.h:1057 */
 
-WTZ_HD int32_t wtz_chain_blocks(int32_t pblen1, int32_t pblen2, wtz_vec<wtz_win_t> &rv, wtz_pool_t *pool, int32_t tail_margin, int32_t max_overhang, float band_penalty, float gap_penalty, int32_t *bad,
-		int32_t *fast_mem = NULL, uint32_t fast_ints = 0){
-	wtz_win_t *regs = rv.a; const uint32_t n = rv.n; uint32_t i, j;
-	int32_t mw, bt, band, gap, weight, W, score;
-	wtz_sort_exact(regs, (size_t)n, wtz_gt_wbeg0());
-	int32_t *mem = (fast_mem && 4 * n + 4 <= fast_ints) ? fast_mem : (int32_t*)wtz_pool_alloc(pool, (size_t)(4 * n + 4) * 4);
-	if(mem == NULL){ *bad = 1; return 0; }
-	int32_t *nw = mem, *nbt = mem + n, *nhead = mem + 2 * n, *ntail = mem + 3 * n;
-	for(i = 0; i < n; i++){
-		nbt[i] = -1; nw[i] = 0; nhead[i] = 0; ntail[i] = 0;
-		if(regs[i].beg[0] <= tail_margin || regs[i].beg[1] <= tail_margin) nhead[i] = 1;
-		if(regs[i].end[0] + tail_margin > pblen1 || regs[i].end[1] + tail_margin > pblen2) ntail[i] = 1;
+/* ---------------------------------------------------------------------------------------------------------------------------------------------------
+ * Chain of blocks (chaining_overhang_wtseedv, hzm_aln.h:1056-1132) on the whole wavefront.  The reference runs  for i: for j > i  with a `continue` for
+ * blocks that start too far before i's end and a `break` at the first block (not skipped) that starts more than W = weight(i) / gap_penalty beyond it.
+ * The blocks are in beg0 order, so "beyond W" is monotone in j: once a block is, every later one is too - and a later block that the `continue`s would have
+ * skipped changes nothing either way.  The update of j from i is therefore a LOCAL decision (not skipped, within W), independent of the other j: the inner
+ * loop is one step of 64 lanes (more blocks: further steps, ended by the same monotone test), and only the outer loop is sequential - n steps instead of
+ * n^2 / 2.  State per block in `st` (3 n words: weight, predecessor, head flag).  Entered by every lane with uniform arguments; blk / st may be LDS or pool.
+ * Host emulation: one lane.
+ * --------------------------------------------------------------------------------------------------------------------------------------------------- */
+WTZ_HD int32_t wtz_chain_blocks_coop(int32_t len0, int32_t len1, wtz_win_t *blk, uint32_t n, int32_t *st, int32_t margin, int32_t overhang, float dev_penalty, float gap_penalty){
+	const uint32_t lane = WTZ_LANE;
+	int32_t *wt = st, *from = st + n, *hd = st + 2 * n;
+	for(uint32_t j = lane; j < n; j += WTZ_NLANES){
+		wt[j] = 0; from[j] = -1;
+		hd[j] = (blk[j].beg[0] <= margin || blk[j].beg[1] <= margin) ? 1 : 0;
+		blk[j].closed = 1;
 	}
-	mw = -1000000; bt = -1;
-	for(i = 0; i < n; i++){
-		wtz_win_t *r1 = &regs[i];
-		r1->closed = 1;
-		nw[i] = wtz_w30(nw[i] + (int32_t)r1->ovl);
-		weight = nw[i] * ((nhead[i] + 3) * (ntail[i] + 3)) / 16;
-		if(weight > mw){ mw = weight; bt = (int32_t)i; }
-		W = (int32_t)((float)nw[i] / gap_penalty);
-		for(j = i + 1; j < n; j++){
-			const wtz_win_t *r2 = &regs[j];
-			if(r2->beg[0] + max_overhang < r1->end[0]) continue;
-			if(r2->beg[1] + max_overhang < r1->end[1]) continue;
-			if(r2->beg[0] - r1->end[0] > W) break;
-			band = WTZ_ABSDIFF(r2->beg[0] - r1->end[0], r2->beg[1] - r1->end[1]);
-			gap  = WTZ_MAX(r2->beg[0] - r1->end[0], r2->beg[1] - r1->end[1]);
-			if(gap < 0) gap = -gap;
-			float fa = (float)band * band_penalty, fb = (float)gap * gap_penalty;
-			score = (int32_t)(fa + fb);
-			score = nw[i] - score;
-			if(nw[j] <= score){ nw[j] = wtz_w30(score); nbt[j] = (int32_t)i; nhead[j] = nhead[i]; }
+	WTZ_WAVE_SYNC();
+	int32_t best = -1000000, best_at = -1;
+	for(uint32_t i = 0; i < n; i++){
+		const int32_t e0 = blk[i].end[0], e1 = blk[i].end[1];
+		const int32_t wi = wtz_w30(wt[i] + (int32_t)blk[i].ovl), hi = hd[i];
+		const int32_t ti = (e0 + margin > len0 || e1 + margin > len1) ? 1 : 0;
+		const int32_t rank = wi * ((hi + 3) * (ti + 3)) / 16;
+		if(rank > best){ best = rank; best_at = (int32_t)i; }
+		const int32_t reach = (int32_t)((float)wi / gap_penalty);
+		WTZ_WAVE_SYNC();                                              /* every lane has read wt[i] before lane 0 rewrites it */
+		if(lane == 0) wt[i] = wi;
+		for(uint32_t j0 = i + 1; j0 < n; j0 += WTZ_NLANES){
+			const uint32_t j = j0 + lane;
+			bool past = false;
+			if(j < n){
+				const int32_t b0 = blk[j].beg[0], b1 = blk[j].beg[1];
+				const bool skipped = (b0 + overhang < e0) || (b1 + overhang < e1);
+				const int32_t d0 = b0 - e0, d1 = b1 - e1;
+				if(!skipped){
+					if(d0 > reach) past = true;
+					else {
+						const int32_t band = WTZ_ABSDIFF(d0, d1);
+						int32_t gap = WTZ_MAX(d0, d1); if(gap < 0) gap = -gap;
+						const float fa = (float)band * dev_penalty, fb = (float)gap * gap_penalty;
+						const int32_t sc = wi - (int32_t)(fa + fb);
+						if(wt[j] <= sc){ wt[j] = wtz_w30(sc); from[j] = (int32_t)i; hd[j] = hi; }
+					}
+				}
+			}
+			if(wtz_coop_ballot(past) != 0ull) break;
 		}
+		WTZ_WAVE_SYNC();
 	}
-	mw = 0;
-	while(bt >= 0){ regs[bt].closed = 0; mw += (int32_t)regs[bt].ovl; bt = nbt[bt]; }
-	return mw;
+	int32_t total = 0;
+	for(int32_t k = best_at; k >= 0; k = from[k]){ if(lane == 0) blk[k].closed = 0; total += (int32_t)blk[k].ovl; }
+	WTZ_WAVE_SYNC();
+	return total;
 }
 
 /* Entered by every lane of the wavefront (lane 0 alone in the host emulation); the result is valid on lane 0.
@@ -949,26 +1010,38 @@ WTZ_HD wtz_dm_result_t wtz_dot_matrix_align(wtz_vec<wtz_zhit_t> &cache, wtz_pool
 #else
 	*tick_denoise = 0;
 #endif
-	if(lane != 0) return ret;
-	/* blocks + scratch of the merge / chain passes into LDS when they are few (the usual case) */
-	int32_t *chain_mem = NULL; uint32_t chain_ints = 0;
-	if(lds && lds_bytes >= 12288u && S.regs[0].n <= 64u && S.regs[1].n <= 64u){
-		wtz_win_t *r0 = (wtz_win_t*)lds, *r1 = r0 + 64;
-		for(uint32_t i = 0; i < S.regs[0].n; i++) r0[i] = S.regs[0].a[i];
-		for(uint32_t i = 0; i < S.regs[1].n; i++) r1[i] = S.regs[1].a[i];
-		S.regs[0].a = r0; S.regs[0].cap = 64; S.regs[1].a = r1; S.regs[1].cap = 64;
-		uint8_t *q = (uint8_t*)(r1 + 64);
-		S.diags.a = (wtz_diag_t*)q; S.diags.n = 0; S.diags.cap = 72; q += 72 * sizeof(wtz_diag_t);
-		S.block.a = (uint32_t*)q; S.block.n = 0; S.block.cap = 128; q += 128 * 4;
-		S.grps.a = (uint32_t*)q; S.grps.n = 0; S.grps.cap = 128; q += 128 * 4;
-		chain_mem = (int32_t*)q; chain_ints = 4 * 64 + 4;
-	}
+	/* blocks + scratch of the merge pass into LDS when they are few (the usual case); lane 0 merges, the wave chains */
 	const unsigned long long ptm = WTZ_PROF_T();
-	wtz_merge_blocks(S.regs[0], S, P->xvar, 2 * P->yvar);
-	wtz_merge_blocks(S.regs[1], S, P->xvar, 2 * P->yvar);
-	weight[0] = wtz_chain_blocks(pblen1, pblen2, S.regs[0], pool, P->xvar, P->max_overhang, P->deviation_penalty, P->gap_penalty, bad, chain_mem, chain_ints);
-	weight[1] = wtz_chain_blocks(pblen1, pblen2, S.regs[1], pool, P->xvar, P->max_overhang, P->deviation_penalty, P->gap_penalty, bad, chain_mem, chain_ints);
+	int32_t *chain_mem = NULL;
+	if(lane == 0){
+		if(lds && lds_bytes >= 12288u && S.regs[0].n <= 64u && S.regs[1].n <= 64u){
+			wtz_win_t *r0 = (wtz_win_t*)lds, *r1 = r0 + 64;
+			for(uint32_t i = 0; i < S.regs[0].n; i++) r0[i] = S.regs[0].a[i];
+			for(uint32_t i = 0; i < S.regs[1].n; i++) r1[i] = S.regs[1].a[i];
+			S.regs[0].a = r0; S.regs[0].cap = 64; S.regs[1].a = r1; S.regs[1].cap = 64;
+			uint8_t *q = (uint8_t*)(r1 + 64);
+			S.diags.a = (wtz_diag_t*)q; S.diags.n = 0; S.diags.cap = 72; q += 72 * sizeof(wtz_diag_t);
+			S.block.a = (uint32_t*)q; S.block.n = 0; S.block.cap = 128; q += 128 * 4;
+			S.grps.a = (uint32_t*)q; S.grps.n = 0; S.grps.cap = 128; q += 128 * 4;
+			chain_mem = (int32_t*)q;                                   /* 3 x 64 words */
+		}
+		wtz_merge_blocks(S.regs[0], S, P->xvar, 2 * P->yvar);
+		wtz_merge_blocks(S.regs[1], S, P->xvar, 2 * P->yvar);
+		for(int k = 0; k < 2; k++) wtz_sort_exact(S.regs[k].a, (size_t)S.regs[k].n, wtz_gt_wbeg0());      /* hzm_aln.h:1065 */
+		if(chain_mem == NULL || S.regs[0].n > 64u || S.regs[1].n > 64u){
+			const uint32_t m = S.regs[0].n > S.regs[1].n ? S.regs[0].n : S.regs[1].n;
+			chain_mem = (int32_t*)wtz_pool_alloc(pool, (size_t)(3u * m + 4u) * 4u);
+			if(chain_mem == NULL) *bad = 1;
+		}
+	}
+	WTZ_WAVE_SYNC();
+	wtz_win_t *cb[2]; uint32_t cn[2];
+	for(int k = 0; k < 2; k++){ cb[k] = (wtz_win_t*)(uintptr_t)wtz_coop_bcast64((uint64_t)(uintptr_t)S.regs[k].a); cn[k] = wtz_coop_bcast32(S.regs[k].n); }
+	chain_mem = (int32_t*)(uintptr_t)wtz_coop_bcast64((uint64_t)(uintptr_t)chain_mem);
+	if(chain_mem == NULL){ weight[0] = weight[1] = 0; cn[0] = cn[1] = 0; }
+	else for(int k = 0; k < 2; k++) weight[k] = wtz_chain_blocks_coop(pblen1, pblen2, cb[k], cn[k], chain_mem, P->xvar, P->max_overhang, P->deviation_penalty, P->gap_penalty);
 	WTZ_PROF_ADD(6, ptm);
+	if(lane != 0) return ret;
 	if(S.dst.bad || S.regs[0].bad || S.regs[1].bad || S.diags.bad || S.block.bad || S.grps.bad) *bad = 1;
 	d = (weight[0] < weight[1]);
 	ret.score = weight[d];

@@ -408,6 +408,7 @@ struct wtz_ctx {
 	uint64_t tpool_peak_call = 0, main_used_call = 0;      /* transient-pool high-water mark / main-pool bytes of the API call in progress */
 	uint32_t env_xcd_group = 256;   /* WTZ_XCD_GROUP: consecutive pairs per XCD run in K_pair (0 = identity block -> pair mapping) */
 	int env_ext_mw_cw = 32;      /* WTZ_EXT_MW_CW: K-sw3 jobs with more band columns per lane than this run on four waves whatever their length */
+	int env_ext_fr_split = 0;    /* WTZ_EXT_FR_SPLIT=1: the frame kernel per band class (<= 16 / <= 28 / <= 32 columns per lane), three concurrent launches at 4 / 3 / 2 waves per SIMD */
 	int env_ext_fr = 1;          /* WTZ_EXT_FR=0: K-sw3 one-wave jobs on the round-4 register kernel (wtz_extend_shift_reg) instead of the frame form (wtz_sw_frame.h) */
 	int env_ext_split = 0;       /* WTZ_EXT_SPLIT=1: K-sw3 one-wave jobs in two launches by band class (experiment) */
 	int env_heavy_first = -1;    /* WTZ_PAIR_HEAVY_FIRST: the heaviest pairs of a K_pair launch first (-1 = engine default: dmo on, zmo off) */
@@ -535,6 +536,7 @@ extern "C" int wtz_ctx_create(int device, const wtz_params_c *params, uint64_t p
 	if(getenv("WTZ_PAIR_HEAVY_FIRST")) c->env_heavy_first = atoi(getenv("WTZ_PAIR_HEAVY_FIRST"));
 	if(getenv("WTZ_EXT_SPLIT")) c->env_ext_split = atoi(getenv("WTZ_EXT_SPLIT"));
 	if(getenv("WTZ_EXT_FR")) c->env_ext_fr = atoi(getenv("WTZ_EXT_FR"));
+	if(getenv("WTZ_EXT_FR_SPLIT")) c->env_ext_fr_split = atoi(getenv("WTZ_EXT_FR_SPLIT"));
 	if(getenv("WTZ_EXT_MW_CW")) c->env_ext_mw_cw = atoi(getenv("WTZ_EXT_MW_CW"));
 	if(getenv("WTZ_XCD_GROUP")) c->env_xcd_group = (uint32_t)atoi(getenv("WTZ_XCD_GROUP"));
 	c->env_grp4 = (getenv("WTZ_WINALIGN4") && atoi(getenv("WTZ_WINALIGN4")) != 0);
@@ -1555,6 +1557,23 @@ static int run_extjobs(wtz_ctx *c, const wtz_env_t &V, wtz_extjob_t *d_jobs, uin
 					hipLaunchKernelGGL((wtz_kernel_extjobs_mw<1032>), dim3(mw1 - mw0), dim3(256), 0, c->stream_mw, d_jobs, (const uint32_t*)d_order + mw0, mw1 - mw0, V.P, V.pool, V.pool + 1);
 					HIPCHK(hipGetLastError());
 					HIPCHK(hipEventRecord(c->ev_mw_join, c->stream_mw));
+				}
+				if(r1 > r0 && !split && mw1 == mw0 && c->env_ext_fr && c->env_ext_fr_split && g0 == 0 && g1 == m){
+					/* the frame kernel per band class: three concurrent launches, each compiled for the occupancy its widest row body allows */
+					std::vector<uint32_t> lst[3];
+					for(uint32_t k = r0; k < r1; k++){ const uint32_t j = ord[k]; const int w = cw[j]; if(w == 0 || w > 32) continue; lst[w <= 16 ? 0 : (w <= 28 ? 1 : 2)].push_back(j); }
+					uint32_t *d_cls = NULL; CHK(dev_alloc((void**)&d_cls, (size_t)m * 4 + 64));
+					uint32_t off[4]; off[0] = 0; for(int k = 0; k < 3; k++){ off[k + 1] = off[k] + (uint32_t)lst[k].size(); if(!lst[k].empty()) CHK(dev_h2d(d_cls + off[k], lst[k].data(), lst[k].size() * 4)); }
+					for(int k = 0; k < 3; k++) if(!c->stream_cls[k]){ if(hipStreamCreateWithFlags(&c->stream_cls[k], hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->ev_cls[k], hipEventDisableTiming) != hipSuccess) return wtz_fail(WTZ_E_HIP, "hipStreamCreate failed"); }
+					HIPCHK(hipEventRecord(c->ev_mw_fork, g_stream));
+#define WTZ_FRCLS_LAUNCH(K, LO, HI) if(!lst[K].empty()){ \
+						if(c->env_ext_fr_split == 2){ hipLaunchKernelGGL((wtz_kernel_extjobs_fr<1032, LO, HI>), dim3((uint32_t)lst[K].size()), dim3(64), 0, g_stream, d_jobs, (const uint32_t*)d_cls + off[K], (uint32_t)lst[K].size(), V.P, V.pool, V.pool + 1); HIPCHK(hipGetLastError()); } \
+						else { HIPCHK(hipStreamWaitEvent(c->stream_cls[K], c->ev_mw_fork, 0)); \
+						hipLaunchKernelGGL((wtz_kernel_extjobs_fr<1032, LO, HI>), dim3((uint32_t)lst[K].size()), dim3(64), 0, c->stream_cls[K], d_jobs, (const uint32_t*)d_cls + off[K], (uint32_t)lst[K].size(), V.P, V.pool, V.pool + 1); \
+						HIPCHK(hipGetLastError()); HIPCHK(hipEventRecord(c->ev_cls[K], c->stream_cls[K])); HIPCHK(hipStreamWaitEvent(g_stream, c->ev_cls[K], 0)); } }
+					WTZ_FRCLS_LAUNCH(2, 28, 32) WTZ_FRCLS_LAUNCH(1, 16, 28) WTZ_FRCLS_LAUNCH(0, 0, 16)
+#undef WTZ_FRCLS_LAUNCH
+					split = true;
 				}
 				if(r1 > r0 && !split){
 					if(c->env_ext_fr) hipLaunchKernelGGL((wtz_kernel_extjobs_fr<1032>), dim3(r1 - r0), dim3(64), 0, g_stream, d_jobs, (const uint32_t*)d_order + r0, r1 - r0, V.P, V.pool, V.pool + 1);

@@ -34,6 +34,15 @@
 #ifndef WTZ_OCC_EXTFR
 #define WTZ_OCC_EXTFR 2
 #endif
+/* resident waves per SIMD the band classes of the split launch are compiled for (WTZ_EXT_FR_SPLIT=1: bands of <= 16 / <= 28 / <= 32 columns per lane in three
+ * concurrent launches, each kernel with the register budget of its widest row body) */
+#ifndef WTZ_OCC_EXTFR_LO
+#define WTZ_OCC_EXTFR_LO 4
+#endif
+#ifndef WTZ_OCC_EXTFR_MID
+#define WTZ_OCC_EXTFR_MID 2
+#endif
+#define WTZ_FR_OCC(CHI) ((CHI) <= 16 ? WTZ_OCC_EXTFR_LO : ((CHI) <= 28 ? WTZ_OCC_EXTFR_MID : WTZ_OCC_EXTFR))
 
 /* pins a value in program order: the trace bytes must be computed where the cell is, not sunk into the conditional store block */
 #define WTZ_PIN(v) asm volatile("" : "+v"(v))
@@ -304,7 +313,7 @@ WTZ_D wtz_aln_t wtz_extend_shift_fr(int32_t qlen, const wtz_seq_packed &query, i
 
 /* one wavefront per job; jobs outside the envelope are left for the older forms (wtz_kernel_extjobs_reg / wtz_kernel_extjobs) */
 template<int TW, int CLO = 0, int CHI = 32>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WTZ_OCC_EXTFR, 8))) wtz_kernel_extjobs_fr(wtz_extjob_t *jobs, const uint32_t *order, uint32_t n, const wtz_params_t *Pm, wtz_pool_t *pool, wtz_pool_t *tpool){
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WTZ_FR_OCC(CHI), 8))) wtz_kernel_extjobs_fr(wtz_extjob_t *jobs, const uint32_t *order, uint32_t n, const wtz_params_t *Pm, wtz_pool_t *pool, wtz_pool_t *tpool){
 	__shared__ uint64_t stb[TW];
 	const uint32_t b = blockIdx.x;
 	if(b >= n) return;
