@@ -128,13 +128,13 @@ WTZ_HD void wtz_task_pair(uint32_t t, const wtz_env_t &V, const uint32_t *qid, c
 	wtz_winscratch_t sc;
 	{
 		uint64_t pa = 0;
-		if(lane == 0) pa = (uint64_t)(uintptr_t)wtz_pool_alloc(V.pool, (size_t)(n + 2) * (4 * 5 + 8 + sizeof(wtz_zhit_t)) + 16);
+		if(lane == 0) pa = (uint64_t)(uintptr_t)wtz_pool_alloc(V.pool, (size_t)(n + 2) * (4 * 7 + 8 + sizeof(wtz_zhit_t)) + 16);
 		pa = wtz_coop_bcast64(pa);
 		sc.ts = (uint32_t*)(uintptr_t)pa;
 	}
 	if(sc.ts == NULL){ r.bad = 1; if(lane == 0) res[t] = r; WTZ_CRUMB(t, 0xFF); return; }
-	sc.as = (int32_t*)(sc.ts + (n + 2)); sc.wb = sc.ts + 2 * (n + 2); sc.we = sc.ts + 3 * (n + 2); sc.wo = sc.ts + 4 * (n + 2);
-	sc.tk = (uint64_t*)(sc.ts + 5 * (n + 2) + ((5 * (n + 2)) & 1)); sc.ztmp = (wtz_zhit_t*)(sc.tk + (n + 2));
+	sc.as = (int32_t*)(sc.ts + (n + 2)); sc.wb = sc.ts + 2 * (n + 2); sc.we = sc.ts + 3 * (n + 2); sc.wo = sc.ts + 4 * (n + 2); sc.wf = sc.ts + 5 * (n + 2); sc.wd = sc.ts + 6 * (n + 2);
+	sc.tk = (uint64_t*)(sc.ts + 7 * (n + 2) + ((7 * (n + 2)) & 1)); sc.ztmp = (wtz_zhit_t*)(sc.tk + (n + 2));
 #if defined(__HIP_DEVICE_COMPILE__)
 	sc.lds = (uint64_t*)wtz_wave_scratch();
 #else
@@ -143,6 +143,9 @@ WTZ_HD void wtz_task_pair(uint32_t t, const wtz_env_t &V, const uint32_t *qid, c
 #endif
 	sc.lds_u64 = WTZ_PAIR_LDS_BYTES / 8;
 	sc.big = NULL; sc.big_u64 = 0; sc.need_big = 0;
+#ifndef WTZ_MERGE_SCALAR
+	wtz_merge_prepare(hits, n, sc, P->kwin);
+#endif
 	for(uint32_t dir = 0; dir < 2; dir++){
 		wtz_vec<wtz_win_t> wins; wtz_vec<wtz_zhit_t> anchors;
 		wins.a = NULL; wins.n = wins.cap = 0; wins.pool = V.pool; wins.bad = 0;
@@ -150,7 +153,11 @@ WTZ_HD void wtz_task_pair(uint32_t t, const wtz_env_t &V, const uint32_t *qid, c
 		if(lane == 0){ wins.init(V.pool, 16); anchors.init(V.pool, n + 16); }
 		WTZ_CRUMB(t, (6 + dir) | (n << 8));
 		const unsigned long long ptm = WTZ_PROF_T(); (void)ptm;
+#ifdef WTZ_MERGE_SCALAR
 		const uint32_t nw = wtz_merge_windows_coop<ZBIG>(hits, n, dir, wins, anchors, sc, P->zsize, P->kwin, P->kstep, P->zovl);
+#else
+		const uint32_t nw = wtz_merge_windows_wave<ZBIG>(hits, n, dir, wins, anchors, sc, P->zsize, P->kwin, P->kstep, P->zovl);
+#endif
 		WTZ_PROF_ADD(63, ptm);      /* profiler: 63 = merge loop incl. its scans, 62 = chain + compaction */
 		if(!ZBIG && sc.need_big){          /* a range that does not fit the LDS slice: the whole pair again in the launch with the pool-workspace body */
 			if(lane == 0){ wtz_pairres_t r2; memset(&r2, 0, sizeof r2); r2.n_hits = r.n_hits; r2.gate = 1; r2.dm_dir = WTZ_PAIR_NEEDS_ZBIG; res[t] = r2; }

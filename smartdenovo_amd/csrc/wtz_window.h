@@ -310,7 +310,8 @@ WTZ_HD int32_t wtz_median(int32_t *rs, int32_t size){
  * dependent loads on a single lane, so it is the access latency (LDS ~64 clk vs L2 ~500 clk) that matters */
 /* `big`: workspace in the pool for the scans whose matches do not fit the LDS slice (allocated by the first such scan of the pair, grown on demand);
  * `need_big`: set by a scan of the LDS-only kernel that met such a range - the pair is finished by the launch that carries the pool-workspace body */
-typedef struct { uint32_t *ts; int32_t *as; uint32_t *wb, *we, *wo; uint64_t *tk; wtz_zhit_t *ztmp; uint64_t *lds; uint32_t lds_u64; mutable uint64_t *big; mutable uint32_t big_u64; mutable uint32_t need_big; } wtz_winscratch_t;
+/* `wf`, `wd` (n + 2 words each): the two per-match tables of the wave-parallel window merge (wtz_merge_prepare) */
+typedef struct { uint32_t *ts; int32_t *as; uint32_t *wb, *we, *wo; uint64_t *tk; wtz_zhit_t *ztmp; uint64_t *lds; uint32_t lds_u64; mutable uint64_t *big; mutable uint32_t big_u64; mutable uint32_t need_big; uint32_t *wf, *wd; } wtz_winscratch_t;
 struct wtz_gt_hi32 { WTZ_HDM bool operator()(uint64_t a, uint64_t b) const { return (uint32_t)(a >> 32) > (uint32_t)(b >> 32); } };
 
 WTZ_HD uint32_t wtz_scan_windows(const wtz_zhit_t *rs, uint32_t dir, uint32_t beg, uint32_t end, int32_t bound,
@@ -994,6 +995,140 @@ WTZ_HD uint32_t wtz_merge_windows_coop(const wtz_zhit_t *rs, uint32_t n_rs, uint
 			else continue;
 			lst = p_off1 + p_len1;
 		}
+	}
+	return ret;
+}
+
+/* ---------------------------------------------------------------------------------------------------------------------------------------------------
+ * The window merge on the whole wavefront (round 5).  wtz_merge_windows_coop above is the reference's loop (hzm_aln.h:580-656) with every lane doing the same
+ * scalar work: ~8 000 dependent steps per pair, ~40 scalar instructions each, through the ONE scalar unit the 16 waves of a CU share - three quarters of K_pair.
+ * Between two window scans the loop is a function of tables that do not depend on its state:
+ *   - the matches are in off1 order (both strands), so "match i lies beyond off1[j] + kwin" is  j < F[i]  with  F[i] = the first index whose off1 + kwin reaches
+ *     off1[i]  (non-decreasing in i), and the `while` that moves the window start there is  j <- max(j, F[i]);  the start before step i is therefore the running
+ *     maximum of F over the matches of the strand taken so far;
+ *   - moving the start from x to y changes ol by  D[x] + ... + D[y-1],  D[k] = overlap(k, k+1) - len1[k]  (u32 arithmetic as the reference's, over ALL
+ *     matches: the reference's cursor does not look at the strand, hzm_aln.h:626,640) = PD[y] - PD[x] with PD the running sum of D;
+ *   - a match inside the window adds  end - max(off1, lst)  when that is positive, and lst is the running maximum of the ends of the matches that were inside
+ *     the window when they came by (a match that finds the window too short is never added: hzm_aln.h:606-647).
+ * So 64 consecutive matches are taken at once: running maxima and one running sum give every lane the state the loop would have in front of ITS match; the
+ * first lane whose match finds the window too short with ol >= zovl (a scan is due) - or that carries the sentinel offset the reference breaks on - is handled
+ * exactly like the loop does, with the state of that lane, and the sweep goes on behind it.  Scans and everything they decide are untouched.
+ * F and PD are made once per pair (wtz_merge_prepare) and serve both strands.  Host emulation: the same code with one lane.
+ * --------------------------------------------------------------------------------------------------------------------------------------------------- */
+#if defined(__HIP_DEVICE_COMPILE__)
+WTZ_D uint32_t wtz_coop_excl_max32(uint32_t v){ const uint32_t in = wtz_coop_incl_max32(v); const uint32_t up = (uint32_t)__shfl_up((int)in, 1, 64); return WTZ_LANE ? up : 0u; }
+WTZ_D uint32_t wtz_coop_all_max32(uint32_t v){ return (uint32_t)__builtin_amdgcn_readlane((int)wtz_coop_incl_max32(v), 63); }
+WTZ_D uint32_t wtz_coop_first_lane(unsigned long long m){ return (uint32_t)__builtin_amdgcn_readfirstlane((int)__builtin_ctzll(m)); }
+#else
+WTZ_COOP_HOST uint32_t wtz_coop_excl_max32(uint32_t){ return 0u; }
+WTZ_COOP_HOST uint32_t wtz_coop_all_max32(uint32_t v){ return v; }
+WTZ_COOP_HOST uint32_t wtz_coop_first_lane(unsigned long long){ return 0u; }
+#endif
+
+/* F (sc.wf) and PD (sc.wd) of a pair's ordered matches; rs[n_rs] is the readable zero element behind them */
+WTZ_HD void wtz_merge_prepare(const wtz_zhit_t *rs, uint32_t n_rs, const wtz_winscratch_t &sc, uint32_t kwin){
+	const uint32_t lane = WTZ_LANE;
+	n_rs = wtz_coop_bcast32(n_rs); kwin = wtz_coop_bcast32(kwin);
+	uint32_t f_carry = 0, d_carry = 0;
+	for(uint32_t b0 = 0; b0 < n_rs; b0 += WTZ_NLANES){
+		const uint32_t i = b0 + lane; const bool in = i < n_rs;
+		uint32_t a = 0, l = 0, a1 = 0, l1 = 0;
+		if(in){ a = ZH_OFF1(rs[i]); l = ZH_LEN1(rs[i]); a1 = ZH_OFF1(rs[i + 1]); l1 = ZH_LEN1(rs[i + 1]); }
+		/* F: the answer lies in [F of the block before, i] */
+		uint32_t lo = f_carry, hi = in ? i : f_carry;
+		while(wtz_coop_ballot(lo < hi) != 0ull){
+			if(lo < hi){ const uint32_t mid = lo + (hi - lo) / 2u; if(ZH_OFF1(rs[mid]) + kwin >= a) hi = mid; else lo = mid + 1u; }
+		}
+		if(in) sc.wf[i] = lo;
+		f_carry = wtz_coop_all_max32(in ? lo : 0u);
+		/* PD: running sum of D in front of i */
+		const uint32_t s = WTZ_MAX(a, a1), t = WTZ_MIN(a + l, a1 + l1);
+		const uint32_t d = in ? ((s < t ? t - s : 0u) - l) : 0u;
+		uint32_t tot; const uint32_t ex = wtz_coop_excl_scan(d, &tot);
+		if(in) sc.wd[i] = d_carry + ex;
+		d_carry += tot;
+	}
+	if(lane == 0) sc.wd[n_rs] = d_carry;
+	WTZ_WAVE_SYNC();
+}
+
+template<bool ZBIG>
+WTZ_HD uint32_t wtz_merge_windows_wave(const wtz_zhit_t *rs, uint32_t n_rs, uint32_t dir, wtz_vec<wtz_win_t> &wins, wtz_vec<wtz_zhit_t> &anchors,
+		const wtz_winscratch_t &sc, uint32_t zsize, uint32_t kwin, uint32_t kstep, uint32_t zovl){
+	n_rs = wtz_coop_bcast32(n_rs); dir = wtz_coop_bcast32(dir); zsize = wtz_coop_bcast32(zsize); kwin = wtz_coop_bcast32(kwin); kstep = wtz_coop_bcast32(kstep); zovl = wtz_coop_bcast32(zovl);
+	const uint32_t SENT_OFF = 0x1FFFFFu, lane = WTZ_LANE;
+	const uint32_t *F = sc.wf, *PD = sc.wd;
+	uint32_t j = n_rs;                                   /* the first match of the strand */
+	for(uint32_t b0 = 0; b0 < n_rs; b0 += WTZ_NLANES){
+		const uint32_t i = b0 + lane;
+		const unsigned long long m = wtz_coop_ballot(i < n_rs && ZH_STRAND(rs[i]) == dir);
+		if(m){ j = b0 + wtz_coop_first_lane(m); break; }
+	}
+	if(j >= n_rs) return 0;
+	uint32_t ol = 0, lst = 0, wlst = 0, ret = 0, i0 = j;
+	while(i0 < n_rs){
+		const uint32_t i = i0 + lane; const bool in = i < n_rs;
+		uint32_t o1 = 0, o2 = 0, ll = 0, fv = 0;
+		if(in){ const wtz_zhit_t h = rs[i]; o1 = h.o1; o2 = h.o2; ll = h.ll; fv = F[i]; }
+		const bool act = in && (((o1 ^ o2) >> 31) == dir);
+		const uint32_t a = o1 & 0x7FFFFFFFu, l = ll & 0xFFFFu, e = a + l;
+		const uint32_t fc = act ? (fv > j ? fv : j) : 0u;
+		const uint32_t jx = wtz_coop_excl_max32(fc), jcur = jx > j ? jx : j;               /* window start in front of this lane's step */
+		const bool ov = act && fc > jcur;                                                    /* the window is too short for this match */
+		const uint32_t ein = (act && !ov) ? e : 0u;
+		const uint32_t lx = wtz_coop_excl_max32(ein), lstb = lx > lst ? lx : lst;            /* lst in front of this lane's step */
+		uint32_t delta = 0;
+		if(ov) delta = PD[fc] - PD[jcur];
+		else if(act){ if(a >= lstb) delta = l; else if((int32_t)e > (int32_t)lstb) delta = e - lstb; }
+		uint32_t tot; const uint32_t olb = ol + wtz_coop_excl_scan(delta, &tot);            /* ol in front of this lane's step */
+		const unsigned long long stop = wtz_coop_ballot(ov && (olb >= zovl || a == SENT_OFF));
+		if(stop == 0ull){
+			ol += tot;
+			const uint32_t lm = wtz_coop_all_max32(ein), jm = wtz_coop_all_max32(fc);
+			if(lm > lst) lst = lm;
+			if(jm > j) j = jm;
+			i0 += WTZ_NLANES;
+			continue;
+		}
+		/* the step of the first such lane, as the loop takes it (hzm_aln.h:606-645) */
+		const uint32_t tl = wtz_coop_first_lane(stop), it = i0 + tl;
+		ol = wtz_coop_lane32(olb, tl); lst = wtz_coop_lane32(lstb, tl); j = wtz_coop_lane32(jcur, tl);
+		const uint32_t pa = wtz_coop_lane32(a, tl), pl = wtz_coop_lane32(l, tl);
+		bool taken = false;
+		if(ol >= zovl){
+			int32_t me0 = 0;
+			const uint32_t n = wtz_scan_windows_coop<ZBIG>(rs, dir, j, it, (int32_t)wlst, wins, anchors, sc, zsize, kwin, zovl, &me0);
+			if(!ZBIG && sc.need_big) return 0;
+			if(n){
+				if((int32_t)wlst < me0 + 20) wlst = (uint32_t)(me0 + 20);
+				ret += n;
+				ol = pl; lst = pa + pl; j = it; taken = true;
+			} else if(kstep){
+				/* the window start moves on by kstep bases (never beyond this match): the first index from j whose off1 reaches off1[j] + kstep */
+				const uint32_t nxt = (uint32_t)wtz_coop_bcast32(ZH_OFF1(rs[j])) + kstep;
+				uint32_t jn = it;
+				for(uint32_t b0 = j; b0 < it; b0 += WTZ_NLANES){
+					const uint32_t k = b0 + lane;
+					const unsigned long long m = wtz_coop_ballot(k < it && (int32_t)ZH_OFF1(rs[k]) >= (int32_t)nxt);
+					if(m){ jn = b0 + wtz_coop_first_lane(m); break; }
+				}
+				ol += wtz_coop_bcast32(PD[jn]) - wtz_coop_bcast32(PD[j]);
+				j = jn;
+			}
+		}
+		if(pa == SENT_OFF) return ret;                                   /* hzm_aln.h:633: the sentinel value ends the loop, also on a real match */
+		if(!taken){
+			const uint32_t fi = wtz_coop_bcast32(F[it]);
+			if(fi > j){ ol += wtz_coop_bcast32(PD[fi]) - wtz_coop_bcast32(PD[j]); j = fi; }
+		}
+		i0 = it + 1u;
+	}
+	/* the sentinel behind the last match (hzm_aln.h:589): one more scan when the window has enough in it; nothing after it is observable */
+	if(SENT_OFF > wtz_coop_bcast32(ZH_OFF1(rs[j])) + kwin && ol >= zovl){
+		int32_t me0 = 0;
+		const uint32_t n = wtz_scan_windows_coop<ZBIG>(rs, dir, j, n_rs, (int32_t)wlst, wins, anchors, sc, zsize, kwin, zovl, &me0);
+		if(!ZBIG && sc.need_big) return 0;
+		ret += n;
 	}
 	return ret;
 }
