@@ -328,6 +328,41 @@ WTZ_HD int wtz_denoise_dir_body(const wtz_zhit_t *rs, uint32_t n_rs, uint32_t di
 	uint32_t *prod = bands + (nd + 2u);
 	uint32_t nbands = 0;
 #if defined(__HIP_DEVICE_COMPILE__)
+	if constexpr(IMG_LDS){
+		/* Round 5: the band sequence is a chain  start -> start + advance(start)  whose links depend on the diagonal offsets only: the length of the band that
+		 * starts at diagonal d (first offset beyond Doff[d] + yvar, never the last diagonal: hzm_aln.h:757-761), its closing offset and the step to the next
+		 * start (first offset beyond Doff[d] + yvar / 2) are computed for 64 starts at once - lane l searches for d = wb + l in the LDS image - and the chain
+		 * is then followed through those registers: three v_readlane per band.  The round-4 form below paid two ballots, their scalar bit scans and a dozen
+		 * dependent scalar instructions per band on the one scalar unit the waves of a CU share (800 cycles per band, 260 bands per strand: 30 % of the pass). */
+		uint32_t doff = 0, wb = 0x80000000u; int32_t end_offset = -0x7FFFFFFF;
+		uint32_t vd = 0, va = 0; int32_t vv = 0;
+		while(nd != 0 && doff < n_rs){
+			if(doff - wb >= 64u){
+				wb = doff;
+				const uint32_t d = wb + lane;
+				vd = 0; va = 0; vv = 0;
+				if(d < nd && yvar >= 0){
+					const int32_t first = Doff[d];
+					const uint32_t cap = nd - 1u - d;
+					uint32_t lo = d + 1u, hi = nd;
+					while(lo < hi){ const uint32_t mid = lo + (hi - lo) / 2u; if(Doff[mid] > first + yvar) hi = mid; else lo = mid + 1u; }
+					const uint32_t dc = lo - d < cap ? lo - d : cap;
+					lo = d; hi = d + dc;
+					while(lo < hi){ const uint32_t mid = lo + (hi - lo) / 2u; if(Doff[mid] > first + yvar / 2) hi = mid; else lo = mid + 1u; }
+					vd = dc; va = lo - d; vv = Doff[d + dc];
+				}
+			}
+			const int r = (int)__builtin_amdgcn_readfirstlane((int)(doff - wb));
+			const uint32_t dcnt = (uint32_t)__builtin_amdgcn_readlane((int)vd, r);
+			if(dcnt == 0) break;
+			const int32_t voff = __builtin_amdgcn_readlane(vv, r);
+			if(voff == end_offset){ doff += dcnt; continue; }
+			end_offset = voff;
+			if(lane == 0) bands[nbands] = (doff << 16) | dcnt;
+			nbands++;
+			doff += (uint32_t)__builtin_amdgcn_readlane((int)va, r);
+		}
+	} else
 	{
 		/* Round 4: the same band sequence walked by the WHOLE wave.  Lane 0 alone paid ~12 dependent LDS reads per band (2 800 cycles; 308 bands per strand at
 		 * configs[2]: a quarter of the denoise pass).  Here lane l holds Doff[doff + l]: the end of the band (first offset beyond lst + yvar, never the last

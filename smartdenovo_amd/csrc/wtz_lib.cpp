@@ -115,7 +115,7 @@ static double wtz_wall(){ return std::chrono::duration<double>(std::chrono::stea
 #define WTZ_OCC_PAIR_DM 4
 #endif
 #ifndef WTZ_OCC_PAIR
-#define WTZ_OCC_PAIR 4
+#define WTZ_OCC_PAIR 5
 #endif
 #ifndef WTZ_OCC_GAP
 #define WTZ_OCC_GAP 1
