@@ -256,7 +256,10 @@ def main():
             os.remove(stale)
     stats = os.path.join(tmp, "bench_r%d.stats" % rank)
     W, K = a.warmup, a.steps
-    argv = ["wtzmo", "--gpu", str(local), "-i", fa, "-fo", out, "--repeat", str(W + K), "--stats", stats] + (["--pool-gb", str(a.pool_gb)] if a.pool_gb else []) + drv_extra + eng
+    dev_args = ["--gpu", str(local)]
+    if os.environ.get("WTZ_BENCH_CONTEXTS"):      # experiment: several contexts on this rank's device (--gpu-list d,d: every range dealt over them, their launches side by side)
+        dev_args = ["--gpu-list", ",".join([str(local)] * int(os.environ["WTZ_BENCH_CONTEXTS"]))]
+    argv = ["wtzmo"] + dev_args + ["-i", fa, "-fo", out, "--repeat", str(W + K), "--stats", stats] + (["--pool-gb", str(a.pool_gb)] if a.pool_gb else []) + drv_extra + eng
     if a.max_batch:
         argv += ["--batch", str(a.max_batch)]
     host = C.CDLL(ge.HOSTLIB)

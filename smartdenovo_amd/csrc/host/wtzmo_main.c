@@ -1088,7 +1088,9 @@ static uint32_t range_end(eng_t *E, batch_t *b, uint32_t s0){
 	const double prior = cap / 2048.0 > 1048576.0 ? cap / 2048.0 : 1048576.0;
 	const double bpp = E->bytes_per_pair > 0 ? E->bytes_per_pair : prior;
 	pthread_mutex_unlock(&E->mu);
-	uint64_t budget = cap > 0 ? (uint64_t)(0.7 * cap / bpp) : ~0ull;
+	static double fill = -1.0;      /* WTZ_RANGE_FILL: the share of the main pool a range is planned to (candidate rows are an upper bound of its pairs) */
+	if(fill < 0){ const char *e = getenv("WTZ_RANGE_FILL"); fill = e ? atof(e) : 0.7; if(fill <= 0) fill = 0.7; }
+	uint64_t budget = cap > 0 ? (uint64_t)(fill * cap / bpp) : ~0ull;
 	if(budget < 16) budget = 16;
 	uint32_t s1 = s0; uint64_t acc = 0;
 	while(s1 < b->nbq && (s1 == s0 || acc + (b->want[s1] ? b->nrow[s1] : 0) <= budget)){ acc += b->want[s1] ? b->nrow[s1] : 0; s1++; }

@@ -19,6 +19,7 @@
 
 #include "wtz_tasks.h"
 #include "wtz_sw_frame.h"
+#include "wtz_stitch_fused.h"
 
 /* ------------------------------------------------------------------------------------------------ */
 /* device abstraction                                                                               */
@@ -409,6 +410,8 @@ struct wtz_ctx {
 	uint32_t env_xcd_group = 256;   /* WTZ_XCD_GROUP: consecutive pairs per XCD run in K_pair (0 = identity block -> pair mapping) */
 	int env_ext_mw_cw = 32;      /* WTZ_EXT_MW_CW: K-sw3 jobs with more band columns per lane than this run on four waves whatever their length */
 	int env_ext_fr_split = 0;    /* WTZ_EXT_FR_SPLIT=1: the frame kernel per band class (<= 16 / <= 28 / <= 32 columns per lane), three concurrent launches at 4 / 3 / 2 waves per SIMD */
+	int env_ext_fused = 1;       /* WTZ_EXT_FUSED=0: the two end extensions of a stitched overlap in two launches with K_stitch_mid between them instead of on one wavefront (wtz_stitch_fused.h) */
+	bool fused_ran = false;      /* this stitch stage's fused launch has run: the extension launches behind it only sweep up what it left open */
 	int env_ext_fr = 1;          /* WTZ_EXT_FR=0: K-sw3 one-wave jobs on the round-4 register kernel (wtz_extend_shift_reg) instead of the frame form (wtz_sw_frame.h) */
 	int env_ext_split = 0;       /* WTZ_EXT_SPLIT=1: K-sw3 one-wave jobs in two launches by band class (experiment) */
 	int env_heavy_first = -1;    /* WTZ_PAIR_HEAVY_FIRST: the heaviest pairs of a K_pair launch first (-1 = engine default: dmo on, zmo off) */
@@ -536,6 +539,7 @@ extern "C" int wtz_ctx_create(int device, const wtz_params_c *params, uint64_t p
 	if(getenv("WTZ_PAIR_HEAVY_FIRST")) c->env_heavy_first = atoi(getenv("WTZ_PAIR_HEAVY_FIRST"));
 	if(getenv("WTZ_EXT_SPLIT")) c->env_ext_split = atoi(getenv("WTZ_EXT_SPLIT"));
 	if(getenv("WTZ_EXT_FR")) c->env_ext_fr = atoi(getenv("WTZ_EXT_FR"));
+	if(getenv("WTZ_EXT_FUSED")) c->env_ext_fused = atoi(getenv("WTZ_EXT_FUSED"));
 	if(getenv("WTZ_EXT_FR_SPLIT")) c->env_ext_fr_split = atoi(getenv("WTZ_EXT_FR_SPLIT"));
 	if(getenv("WTZ_EXT_MW_CW")) c->env_ext_mw_cw = atoi(getenv("WTZ_EXT_MW_CW"));
 	if(getenv("WTZ_XCD_GROUP")) c->env_xcd_group = (uint32_t)atoi(getenv("WTZ_XCD_GROUP"));
@@ -1442,10 +1446,81 @@ extern "C" int wtz_pairs_windows(wtz_ctx_t *c, wtz_winbox_t *wins, uint64_t n_wi
 	return WTZ_OK;
 }
 
+#ifndef WTZ_EMUL
+/* upper bound of the transient-pool bytes one K-sw3 job takes (trace rows come 64 at a time; a row is the widest of the wave forms), its row bound and its band class */
+static uint64_t ext_trace_need(const wtz_ctx *c, int32_t qlen, int32_t tlen, int32_t init, int32_t W, int32_t *ql_out, int32_t *ncol_out){
+	if(ql_out) *ql_out = 0;
+	if(ncol_out) *ncol_out = 0;
+	if(qlen <= 0 || tlen <= 0) return 0;
+	if(init < 0) init = 0;
+	int32_t ql, tl, n_col;
+	wtz_ext_geometry(qlen, tlen, init, W, c->P.M, c->P.O, c->P.O, c->P.E, c->P.T, ql, tl, n_col);
+	if(ql_out) *ql_out = ql;
+	if(ncol_out) *ncol_out = n_col;
+	/* one-wave register kernel (4-column steps), four-wave kernel (256 lanes), LDS-ring kernel (odd columns per lane) */
+	const uint64_t c_reg = ((uint64_t)(n_col + 63) / 64 + 3) / 4, c_mw = ((uint64_t)(n_col + 255) / 256 + 3) / 4 * 4, c_gen = ((((uint64_t)(n_col + 63) / 64) | 1) + 3) / 4;
+	uint64_t zrow = (c_reg > c_gen ? c_reg : c_gen) * 256; if(c_mw * 256 > zrow) zrow = c_mw * 256;
+	uint64_t nb = ((uint64_t)(ql + 63) / 64) * 64 * zrow + (uint64_t)WTZ_TRACE_MAXCHUNK * 8 + (uint64_t)(ql + 2) * 4 + 256;
+	if((n_col + 63) / 64 > 32 || (tl + 63) / 32 + 1 > 1032){      /* outside the wave forms: the scalar body's row arrays and byte matrix, grown in powers of two */
+		uint64_t z = 1024; while(z < (uint64_t)ql * (uint64_t)n_col) z <<= 1;
+		uint64_t r = 64; while(r < (uint64_t)tl + 3) r <<= 1;
+		uint64_t zb = 64; while(zb < (uint64_t)ql + 2) zb <<= 1;
+		nb = z + 8 * r + 4 * zb + 256;
+	}
+	return nb;
+}
+
+/* Both end extensions of every item of the stage on one wavefront per item (wtz_stitch_fused.h).  The items are ordered by the rows their two extensions can
+ * run at most (longest first) and the launch is made only if the traces of ALL jobs fit the transient pool together (their geometry is known before any
+ * extension has run: wtz_task_stitch_left's rgeo); otherwise c->fused_ran stays false and the stage runs its launches one after the other as before. */
+static int run_stitch_fused(wtz_ctx *c, const wtz_env_t &V, const wtz_alnitem_t *d_items, wtz_stitch_state_t *d_st, wtz_extjob_t *d_jl, wtz_extjob_t *d_jr, const wtz_gapres_t *d_gaps, const int32_t *d_rgeo, uint32_t m){
+	c->fused_ran = false;
+	if(m == 0) return WTZ_OK;
+	int32_t *d_key = NULL; CHK(dev_alloc((void**)&d_key, (size_t)m * 16));
+	CHK(wtz_launch<K_misc>(0, m, [=] WTZ_LAMBDA (uint64_t t){ const wtz_extjob_t &j = d_jl[t]; d_key[4 * t] = j.valid ? j.qlen : -1; d_key[4 * t + 1] = j.tlen; d_key[4 * t + 2] = d_rgeo[2 * t]; d_key[4 * t + 3] = d_rgeo[2 * t + 1]; }));
+	std::vector<int32_t> key4((size_t)m * 4); CHK(dev_d2h(key4.data(), d_key, (size_t)m * 16)); dev_free(d_key);
+	std::vector<int64_t> rows(m); std::vector<uint32_t> ord(m);
+	const uint64_t budget = (c->pool_bytes - c->main_bytes) / 16 * 15;
+	uint64_t acc = 0; unsigned long long ext_sum = 0;
+	for(uint32_t i = 0; i < m; i++){
+		int32_t qa = 0, qb = 0;
+		acc += ext_trace_need(c, key4[(size_t)i * 4], key4[(size_t)i * 4 + 1], 0, -c->P.ew, &qa, NULL);
+		acc += ext_trace_need(c, key4[(size_t)i * 4 + 2], key4[(size_t)i * 4 + 3], 0, -c->P.ew, &qb, NULL);
+		rows[i] = (int64_t)qa + qb; ext_sum += (unsigned long long)rows[i]; ord[i] = i;
+	}
+	if(acc > budget) return WTZ_OK;          /* the two launches cut their jobs into groups that fit */
+	std::stable_sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t b){ return rows[a] > rows[b]; });
+	uint32_t *d_order = NULL; CHK(dev_alloc((void**)&d_order, (size_t)m * 4)); CHK(dev_h2d(d_order, ord.data(), (size_t)m * 4));
+	CHK(tpool_reset(c));
+	wtz_timer te; te.start();
+	hipLaunchKernelGGL((wtz_kernel_stitch_ext_fr<1032>), dim3(m), dim3(64), WTZ_WAVE_LDS_BYTES, g_stream, V, d_items, d_st, d_jl, d_jr, d_gaps, (const uint32_t*)d_order, m);
+	HIPCHK(hipGetLastError());
+	const double ms_l = te.stop();
+	c->cnt.ms_ext += ms_l; c->cnt.n_extjobs += 2ull * m;
+	c->fused_ran = true;
+	if(c->env_profile) fprintf(stderr, "[ext-profile] fused launch: %u items, rows (upper bound) sum %llu, %.2f ms\n", m, ext_sum, ms_l);
+	dev_free(d_order);
+	return tpool_check(c, "K-sw3 extension jobs (both ends on one wavefront)");
+}
+#endif
+
 /* K-sw3 jobs of a batch: one wavefront per job (wtz_sw_wave.h).  WTZ_SW_SCALAR=1 forces the scalar body,
  * WTZ_SW_CHECK=1 runs both and fails loudly on any difference (on-device cross-check). */
-static int run_extjobs(wtz_ctx *c, const wtz_env_t &V, wtz_extjob_t *d_jobs, uint32_t m){
+static int run_extjobs(wtz_ctx *c, const wtz_env_t &V, wtz_extjob_t *d_jobs, uint32_t m, bool leftover = false){
 	if(m == 0) return WTZ_OK;
+#ifndef WTZ_EMUL
+	if(leftover){
+		/* behind the fused launch (run_stitch_fused): what is still open is outside the frame kernel's envelope - the general kernel takes it; every other wavefront leaves at once */
+		if(!c->fused_ran) leftover = false;
+		else {
+			wtz_timer te; te.start();
+			hipLaunchKernelGGL((wtz_kernel_extjobs<2048, 1032>), dim3(m), dim3(64), 0, g_stream, d_jobs, (const uint32_t*)NULL, m, V.P, V.pool, V.pool + 1);
+			HIPCHK(hipGetLastError());
+			c->cnt.ms_ext += te.stop();
+			return tpool_check(c, "K-sw3 extension jobs");
+		}
+	}
+#endif
 #ifdef WTZ_EMUL
 	return wtz_launch_wave<K_extjob_scalar>(0, m, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_extjob_scalar((uint32_t)t, V, d_jobs); });
 #else
@@ -1473,32 +1548,23 @@ static int run_extjobs(wtz_ctx *c, const wtz_env_t &V, wtz_extjob_t *d_jobs, uin
 		std::vector<int32_t> key4((size_t)m * 4); CHK(dev_d2h(key4.data(), d_key, (size_t)m * 16)); dev_free(d_key);
 		std::vector<int32_t> key(m);
 		for(uint32_t i = 0; i < m; i++){ key[i] = key4[(size_t)i * 4]; if(key[i] > 0){ ext_sum += (unsigned long long)key[i]; if(key[i] > ext_max) ext_max = key[i]; } }
-		for(uint32_t i = 0; i < m; i++) ord[i] = i;
-		std::stable_sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t b){ return key[a] > key[b]; });
-		CHK(dev_alloc((void**)&d_order, (size_t)m * 4)); CHK(dev_h2d(d_order, ord.data(), (size_t)m * 4));
-		const int mw_top = c->env_mw_top;
-		if(mw_min > 0) while(n_mw < m && n_mw < (uint32_t)mw_top && key[ord[n_mw]] >= mw_min) n_mw++;          /* the long jobs head the order: four waves each */
+		std::vector<int32_t> rows(m, -1);       /* the order key: the rows the job can run at most (the shorter side + W, not the query side alone: most long overhangs face a short one) */
 		for(uint32_t i = 0; i < m; i++){
 			const int32_t qlen = key4[(size_t)i * 4], tlen = key4[(size_t)i * 4 + 1];
 			need[i] = 0;
 			if(qlen <= 0 || tlen <= 0) continue;
-			int32_t init = key4[(size_t)i * 4 + 2] < 0 ? 0 : key4[(size_t)i * 4 + 2], W = key4[(size_t)i * 4 + 3], ql, tl, n_col;
-			wtz_ext_geometry(qlen, tlen, init, W, c->P.M, c->P.O, c->P.O, c->P.E, c->P.T, ql, tl, n_col);
+			int32_t ql = 0, n_col = 0;
+			need[i] = ext_trace_need(c, qlen, tlen, key4[(size_t)i * 4 + 2], key4[(size_t)i * 4 + 3], &ql, &n_col);
 			cw[i] = (uint8_t)((n_col + 63) / 64 > 255 ? 255 : (n_col + 63) / 64);
-			/* rows come 64 at a time; a row of the trace is the widest of the three wave forms: one-wave register kernel (4-column steps),
-			 * four-wave kernel (256 lanes), LDS-ring kernel (odd columns per lane) */
-			const uint64_t c_reg = ((uint64_t)(n_col + 63) / 64 + 3) / 4, c_mw = ((uint64_t)(n_col + 255) / 256 + 3) / 4 * 4, c_gen = ((((uint64_t)(n_col + 63) / 64) | 1) + 3) / 4;
-			uint64_t zrow = (c_reg > c_gen ? c_reg : c_gen) * 256; if(c_mw * 256 > zrow) zrow = c_mw * 256;
-			uint64_t nb = ((uint64_t)(ql + 63) / 64) * 64 * zrow + (uint64_t)WTZ_TRACE_MAXCHUNK * 8 + (uint64_t)(ql + 2) * 4 + 256;
-			if((n_col + 63) / 64 > 32 || (tl + 63) / 32 + 1 > 1032){      /* outside the wave forms: the scalar body's row arrays and byte matrix, grown in powers of two */
-				uint64_t z = 1024; while(z < (uint64_t)ql * (uint64_t)n_col) z <<= 1;
-				uint64_t r = 64; while(r < (uint64_t)tl + 3) r <<= 1;
-				uint64_t zb = 64; while(zb < (uint64_t)ql + 2) zb <<= 1;
-				nb = z + 8 * r + 4 * zb + 256;
-			}
-			need[i] = nb;
+			rows[i] = ql;
 			if(c->env_profile){ const int b = (n_col + 63) / 64 > 32 ? 8 : ((n_col + 63) / 64 - 1) / 4; geo_n[b]++; geo_rows[b] += (unsigned long long)ql; geo_cells[b] += (unsigned long long)ql * (unsigned long long)n_col; }
 		}
+		for(uint32_t i = 0; i < m; i++) ord[i] = i;
+		if(mw_min > 0) std::stable_sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t b){ return key[a] > key[b]; });      /* the four-wave share is cut by the query side */
+		else std::stable_sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t b){ return rows[a] > rows[b]; });
+		CHK(dev_alloc((void**)&d_order, (size_t)m * 4)); CHK(dev_h2d(d_order, ord.data(), (size_t)m * 4));
+		const int mw_top = c->env_mw_top;
+		if(mw_min > 0) while(n_mw < m && n_mw < (uint32_t)mw_top && key[ord[n_mw]] >= mw_min) n_mw++;          /* the long jobs head the order: four waves each */
 		if(c->env_profile){
 			fprintf(stderr, "[ext-profile] geometry by columns per lane (upper bounds):");
 			for(int b = 0; b < 9; b++) if(geo_n[b]) fprintf(stderr, " C<=%d: %llu jobs %.1f Mrows %.1f Gcells;", b < 8 ? 4 * b + 4 : 999, geo_n[b], (double)geo_rows[b] / 1e6, (double)geo_cells[b] / 1e9);
@@ -1842,7 +1908,14 @@ extern "C" int wtz_pairs_align(wtz_ctx_t *c, const uint32_t *pair_idx, const uin
 		wtz_gapres_t *d_gaps = NULL; CHK(dev_alloc((void**)&d_gaps, (size_t)(nreg + 1) * sizeof(wtz_gapres_t)));
 		const uint64_t nwt = wt.size();
 		STAGE(c, "K_stitch_left");
-		CHK(wtz_launch_wave<K_stitch_left>(0, m, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_stitch_left((uint32_t)t, V, d_items, d_st, d_jl); }));
+		int32_t *d_rgeo = NULL;
+#ifndef WTZ_EMUL
+		const bool fused = c->env_ext_fused && c->env_ext_fr && c->env_sw_mode == 0 && c->env_use_reg && c->env_mw_min <= 0 && !c->env_ext_split && !c->env_ext_fr_split;
+		if(fused) CHK(dev_alloc((void**)&d_rgeo, (size_t)m * 8));
+#else
+		CHK(dev_alloc((void**)&d_rgeo, (size_t)m * 8));      /* host emulation: the prediction of the right extension's geometry is compared with what K_stitch_mid asks for */
+#endif
+		CHK(wtz_launch_wave<K_stitch_left>(0, m, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_stitch_left((uint32_t)t, V, d_items, d_st, d_jl, d_rgeo); }));
 		uint32_t *d_glist = NULL, n_glist = (uint32_t)nwt; const bool gap_lane = c->env_gap_lane != 0;
 #ifndef WTZ_EMUL
 		wtz_timer tgap; tgap.start();          /* K-sw2: lane pipeline + wavefront kernel */
@@ -1877,8 +1950,9 @@ extern "C" int wtz_pairs_align(wtz_ctx_t *c, const uint32_t *pair_idx, const uin
 			g_stream = main_stream;
 			CHK(rc_gap);
 			if(gap_side) HIPCHK(hipEventRecord(c->ev_gap_join, c->stream_gap));
+			if(fused){ STAGE(c, "extjobs left + join + right on one wavefront"); CHK(run_stitch_fused(c, V, d_items, d_st, d_jl, d_jr, d_gaps, d_rgeo, m)); }
 			STAGE(c, "extjobs left");
-			CHK(run_extjobs(c, V, d_jl, m));
+			CHK(run_extjobs(c, V, d_jl, m, fused));
 			if(gap_side) HIPCHK(hipStreamWaitEvent(main_stream, c->ev_gap_join, 0));
 			else c->cnt.ms_gap += tgap.read();      /* after the extension jobs: no extra synchronisation for the lap */
 		}
@@ -1886,7 +1960,17 @@ extern "C" int wtz_pairs_align(wtz_ctx_t *c, const uint32_t *pair_idx, const uin
 		STAGE(c, "K_stitch_mid");
 		CHK(wtz_launch_coop<K_stitch_mid>(0, m, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_stitch_mid((uint32_t)t, V, d_items, d_st, d_jl, d_jr, d_gaps); }));
 		STAGE(c, "extjobs right");
+#ifdef WTZ_EMUL
+		for(uint32_t t = 0; t < m; t++){
+			const wtz_extjob_t &jr = d_jr[t];
+			const int32_t pq = d_rgeo[2 * (size_t)t], pt = d_rgeo[2 * (size_t)t + 1];
+			if(jr.valid ? (pq != jr.qlen || pt != jr.tlen) : (pq >= 0 && !d_st[t].bad))
+				return wtz_fail(WTZ_E_STATE, "stitch: predicted right extension of item %u (%d x %d) differs from the one K_stitch_mid asks for (valid %u: %d x %d)", t, pq, pt, jr.valid, jr.qlen, jr.tlen);
+		}
 		CHK(run_extjobs(c, V, d_jr, m));
+#else
+		CHK(run_extjobs(c, V, d_jr, m, fused));
+#endif
 		STAGE(c, "K_stitch_fin");
 		CHK(wtz_launch_coop<K_stitch_fin>(0, m, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_stitch_fin((uint32_t)t, V, d_items, d_st, d_jl, d_jr, d_res); }));
 		if(c->P.refine) STAGE(c, "K_refine");

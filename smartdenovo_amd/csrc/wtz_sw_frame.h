@@ -311,29 +311,26 @@ WTZ_D wtz_aln_t wtz_extend_shift_fr(int32_t qlen, const wtz_seq_packed &query, i
 	return wtz_bcast_aln(x);
 }
 
-/* one wavefront per job; jobs outside the envelope are left for the older forms (wtz_kernel_extjobs_reg / wtz_kernel_extjobs) */
-template<int TW, int CLO = 0, int CHI = 32>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WTZ_FR_OCC(CHI), 8))) wtz_kernel_extjobs_fr(wtz_extjob_t *jobs, const uint32_t *order, uint32_t n, const wtz_params_t *Pm, wtz_pool_t *pool, wtz_pool_t *tpool){
-	__shared__ uint64_t stb[TW];
-	const uint32_t b = blockIdx.x;
-	if(b >= n) return;
-	wtz_extjob_t *job = &jobs[order ? order[b] : b];
-	if(!job->valid || job->done) return;
+/* one K-sw3 job on the calling wavefront in the frame form; false = the job is outside the envelope (or its counts did not follow from the score) and stays
+ * open for the older forms (wtz_kernel_extjobs_reg / wtz_kernel_extjobs).  stb: TW 64-bit words of LDS of this wave. */
+template<int TW, int CLO, int CHI>
+WTZ_D bool wtz_extjob_run_fr(wtz_extjob_t *job, const wtz_params_t *Pm, wtz_pool_t *pool, wtz_pool_t *tpool, uint64_t *stb){
+	if(!job->valid || job->done) return true;
 	const int lane = (int)(threadIdx.x & 63);
-	if(job->qlen <= 0 || job->tlen <= 0) return;
+	if(job->qlen <= 0 || job->tlen <= 0) return false;
 	const int32_t init_score = job->init_score < 0 ? 0 : job->init_score;
 	int32_t W = job->W, ql, tl, n_col;
 	wtz_ext_geometry(job->qlen, job->tlen, init_score, W, Pm->M, Pm->O, Pm->O, Pm->E, Pm->T, ql, tl, n_col);
 	const int32_t Cw = (n_col + 63) / 64;
-	if(Cw > 32 || (tl + 63) / 32 + 1 > TW || (ql + 63) / 64 > WTZ_TRACE_MAXCHUNK) return;
+	if(Cw > 32 || (tl + 63) / 32 + 1 > TW || (ql + 63) / 64 > WTZ_TRACE_MAXCHUNK) return false;
 	{
 		/* every value of the DP, its frame image and the -10000 family stay below 2^20 in magnitude */
 		const long long aE = Pm->E < 0 ? -(long long)Pm->E : (long long)Pm->E, aX = Pm->X < 0 ? -(long long)Pm->X : (long long)Pm->X, aO = Pm->O < 0 ? -(long long)Pm->O : (long long)Pm->O;
 		const long long span = (long long)ql + tl + 4;
-		if((long long)init_score + (long long)(Pm->M > 0 ? Pm->M : -Pm->M) * (ql < tl ? ql : tl) + span * aE + 10000 + aX + aO + 16 >= (1 << 20)) return;
-		if(aE > 255 || Pm->M == Pm->X) return;
+		if((long long)init_score + (long long)(Pm->M > 0 ? Pm->M : -Pm->M) * (ql < tl ? ql : tl) + span * aE + 10000 + aX + aO + 16 >= (1 << 20)) return false;
+		if(aE > 255 || Pm->M == Pm->X) return false;
 	}
-	if(Cw <= CLO || (CHI < 32 && Cw > CHI)) return;
+	if(Cw <= CLO || (CHI < 32 && Cw > CHI)) return false;
 	wtz_trace_t tr; tr.chunk = NULL; tr.zb = NULL; tr.n_chunk = 0; tr.zrow = 0; tr.cap_rows = 0;
 	wtz_cigar_t cg; cg.a = NULL; cg.n = cg.cap = 0; cg.pool = pool; cg.bad = 0;
 	if(lane == 0) cg.init(pool, (uint32_t)ql / 2u + 16u);
@@ -349,8 +346,18 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WTZ_FR_
 	else if(Cw <= 28){ if(CLO < 28 && CHI >= 28) WTZ_EXTFR_CASE(28); }
 	else { if(CHI >= 32) WTZ_EXTFR_CASE(32); }
 #undef WTZ_EXTFR_CASE
-	if(!consistent) return;          /* mat / mis did not follow from the score: the job stays open for the general kernel (wtz_kernel_extjobs) */
+	if(!consistent) return false;          /* mat / mis did not follow from the score: the job stays open for the general kernel (wtz_kernel_extjobs) */
 	if(lane == 0){ job->x = x; job->cigar = cg.a; job->cigar_len = cg.n; job->bad = (!ok || cg.bad); job->cells = cells; job->done = 5; }
+	return true;
+}
+
+/* one wavefront per job */
+template<int TW, int CLO = 0, int CHI = 32>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WTZ_FR_OCC(CHI), 8))) wtz_kernel_extjobs_fr(wtz_extjob_t *jobs, const uint32_t *order, uint32_t n, const wtz_params_t *Pm, wtz_pool_t *pool, wtz_pool_t *tpool){
+	__shared__ uint64_t stb[TW];
+	const uint32_t b = blockIdx.x;
+	if(b >= n) return;
+	(void)wtz_extjob_run_fr<TW, CLO, CHI>(&jobs[order ? order[b] : b], Pm, pool, tpool, stb);
 }
 
 #endif /* __HIPCC__ */

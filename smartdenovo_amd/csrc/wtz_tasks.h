@@ -686,7 +686,9 @@ WTZ_D void wtz_task_winalign4(uint32_t t_base, uint32_t n, const wtz_env_t &V, c
  * The band-doubling loops around both extensions start at w = ew and stop at "w >= ew" (hzm_aln.h:1361-1374,
  * 1456-1468): exactly one call each.
  */
-typedef struct { wtz_aln_t x; wtz_cigar_t cigar; uint32_t first, nreg; int32_t bad; unsigned long long cells_global; } wtz_stitch_state_t;
+typedef struct { wtz_aln_t x; wtz_cigar_t cigar; uint32_t first, nreg; int32_t bad; unsigned long long cells_global;
+	uint32_t mid;          /* 1: wtz_task_stitch_mid has run for this item (by the fused launch, wtz_kernel_stitch_ext_fr): K_stitch_mid skips it */
+} wtz_stitch_state_t;
 
 /* K-sw2 between two consecutive passing windows (hzm_aln.h:1386-1447), one task per window slot so that all gaps of a
  * batch run side by side; stored at the slot of the RIGHT window of the gap */
@@ -992,7 +994,9 @@ WTZ_HD void wtz_task_gtb_all(uint32_t wv, const wtz_lclass_t &L, const wtz_env_t
 }
 WTZ_HD void wtz_task_glist(uint32_t t, const uint8_t *done, uint32_t *list){ if(!done[t]){ const uint32_t k = WTZ_ATOMIC_INC32(&list[0]); list[1 + k] = t; } }
 
-WTZ_HD void wtz_task_stitch_left(uint32_t t, const wtz_env_t &V, const wtz_alnitem_t *items, wtz_stitch_state_t *sts, wtz_extjob_t *jobs){
+/* rgeo (optional): qlen / tlen of the RIGHT extension wtz_task_stitch_mid will ask for (-1: none) - they follow from the last window that passed alone, so the
+ * launch that runs both extensions of an item on one wavefront can order its items and plan its trace memory before any extension has run */
+WTZ_HD void wtz_task_stitch_left(uint32_t t, const wtz_env_t &V, const wtz_alnitem_t *items, wtz_stitch_state_t *sts, wtz_extjob_t *jobs, int32_t *rgeo = NULL){
 	const wtz_params_t *P = V.P;
 	const wtz_alnitem_t &it = items[t];
 	wtz_stitch_state_t st; memset(&st, 0, sizeof st);
@@ -1008,17 +1012,28 @@ WTZ_HD void wtz_task_stitch_left(uint32_t t, const wtz_env_t &V, const wtz_alnit
 			jb.init_score = st.x.score + 100 * P->M; jb.W = -P->ew;
 		}
 	}
+	if(rgeo){
+		int32_t rq = -1, rt = -1;
+		if(st.nreg && !st.bad){
+			int32_t qe = st.x.qe, te = st.x.te;
+			for(uint32_t k = st.first + 1; k < it.nwin; k++) if(it.regs[k].pass == 1){ qe = it.regs[k].x.qe; te = it.regs[k].x.te; }
+			const int32_t len1 = (int32_t)V.R.rdlen[it.q], len2 = (int32_t)V.R.rdlen[it.c];
+			if(te < len1 && qe < len2){ rq = len2 - qe; rt = len1 - te; }
+		}
+		rgeo[2 * (size_t)t] = rq; rgeo[2 * (size_t)t + 1] = rt;
+	}
 	sts[t] = st; jobs[t] = jb;
 }
 
-WTZ_HD void wtz_task_stitch_mid(uint32_t t, const wtz_env_t &V, const wtz_alnitem_t *items, wtz_stitch_state_t *sts, const wtz_extjob_t *jobsL, wtz_extjob_t *jobsR, const wtz_gapres_t *gaps){
+WTZ_HD void wtz_task_stitch_mid(uint32_t t, const wtz_env_t &V, const wtz_alnitem_t *items, wtz_stitch_state_t *sts, const wtz_extjob_t *jobsL, wtz_extjob_t *jobsR, const wtz_gapres_t *gaps, bool fused = false){
 	const wtz_params_t *P = V.P;
 	const wtz_alnitem_t &it = items[t];
 	const int32_t M = P->M;
 	const bool l0 = (WTZ_LANE == 0);
 	wtz_stitch_state_t st = sts[t];
+	if(st.mid) return;          /* done by the fused launch */
 	wtz_extjob_t jr; memset(&jr, 0, sizeof jr); jr.item = t;
-	if(st.nreg == 0 || st.bad){ if(l0) jobsR[t] = jr; return; }
+	if(st.nreg == 0 || st.bad){ if(l0){ jobsR[t] = jr; if(fused) sts[t].mid = 1; } return; }
 	const wtz_readview pb1 = wtz_view(V.R, it.q, 0), pb2 = wtz_view(V.R, it.c, it.dir);
 	const int32_t len1 = (int32_t)pb1.len, len2 = (int32_t)pb2.len;
 	const wtz_gapres_t *gp = gaps + (it.regs - items[0].regs);
@@ -1075,7 +1090,7 @@ WTZ_HD void wtz_task_stitch_mid(uint32_t t, const wtz_env_t &V, const wtz_alnite
 		jr.valid = 1; jr.qlen = len2 - x.qe; jr.tlen = len1 - x.te; jr.q = pb2.sub(x.qe, 1); jr.t = pb1.sub(x.te, 1);
 		jr.init_score = x.score; jr.W = -P->ew;
 	}
-	if(l0){ st.x = x; sts[t] = st; jobsR[t] = jr; }
+	if(l0){ st.x = x; st.mid = fused ? 1u : 0u; sts[t] = st; jobsR[t] = jr; }
 }
 
 WTZ_HD void wtz_task_stitch_fin(uint32_t t, const wtz_env_t &V, const wtz_alnitem_t *items, wtz_stitch_state_t *sts, const wtz_extjob_t *jobsL, const wtz_extjob_t *jobsR, wtz_alnres_dev_t *out){
