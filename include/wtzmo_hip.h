@@ -105,6 +105,9 @@ typedef struct {
 
 const char *wtz_last_error(void);
 int  wtz_device_count(void);
+/* free / total bytes of the device's HBM right now.  No reference counterpart: the reference sizes nothing (its indexes live in host RAM, wtzmo.c:249-430,
+ * hzm_aln.h:70-115); the host driver sizes the scratch pool and chooses between the all-reads z-mer index and the per-batch one from it. */
+int  wtz_device_memory(int device, uint64_t *free_bytes, uint64_t *total_bytes);
 
 int  wtz_ctx_create(int device, const wtz_params_c *params, uint64_t pool_bytes, wtz_ctx_t **out);
 void wtz_ctx_destroy(wtz_ctx_t *ctx);

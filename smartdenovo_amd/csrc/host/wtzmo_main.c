@@ -1089,7 +1089,10 @@ static uint32_t range_end(eng_t *E, batch_t *b, uint32_t s0){
 	const double bpp = E->bytes_per_pair > 0 ? E->bytes_per_pair : prior;
 	pthread_mutex_unlock(&E->mu);
 	static double fill = -1.0;      /* WTZ_RANGE_FILL: the share of the main pool a range is planned to (candidate rows are an upper bound of its pairs) */
-	if(fill < 0){ const char *e = getenv("WTZ_RANGE_FILL"); fill = e ? atof(e) : 0.7; if(fill <= 0) fill = 0.7; }
+	/* measured at configs[2] (round 5, gpurun_out/r05r, r05s; every stage of a range ends in the tail of its slowest tasks, so fewer and larger ranges win until the
+	 * pool overflows and a range is redone in halves): 0.7 -> 28 ranges 2.10 s, 1.0 -> 21 ranges 1.98 s, 1.4 -> 16 ranges 1.97 s (pool peak 96 of 128 GB),
+	 * 1.8 -> one overflow, 2.11 s; with batches of 8 192 queries 1.4 -> 14 ranges 1.94 s */
+	if(fill < 0){ const char *e = getenv("WTZ_RANGE_FILL"); fill = e ? atof(e) : 1.3; if(fill <= 0) fill = 1.3; }
 	uint64_t budget = cap > 0 ? (uint64_t)(fill * cap / bpp) : ~0ull;
 	if(budget < 16) budget = 16;
 	uint32_t s1 = s0; uint64_t acc = 0;
@@ -1203,7 +1206,12 @@ static void process_batch(eng_t *E, batch_t *b){
 /* both index builds of one more device (replicated indexes, --gpus) */
 /* the device contexts - above all the hipMalloc of their scratch pools: ~35 ms per GB, 4.4 s for the default 128 GB - are created on a helper
  * thread while the main thread reads the FASTA (measured on wtgbo, E. coli shape: 5.4 s wall with the 128 GB pool created up front, 1.0 s with 16 GB) */
-typedef struct { const wtz_params_c *P; uint64_t pool_bytes; int devs[8]; uint32_t ndev; wtz_ctx_t *ctxs[8]; int rc; char err[256]; pthread_t th; int started; } ctxjob_t;
+typedef struct { const wtz_params_c *P; uint64_t pool_bytes; int devs[8]; uint32_t ndev; wtz_ctx_t *ctxs[8]; int rc; char err[256]; pthread_t th; int started, joined; } ctxjob_t;
+/* device bytes a read set of `bases` bases needs beside the scratch pool when the z-mer index holds every read: the index itself (25 B per z-mer, measured
+ * 15.8 B per base), reads (2 bits per base), k-mer seeds + table (< 1.5 B per base), and - transient - the largest of the build temporaries (k-mer index: sort
+ * keys + values of 0.19 occurrences per base, double-buffered = 4.6 B per base, gone before the z-mer index is allocated; z-mer chunks: 8 GB), the arena */
+#define WTZ_ZALL_MIN_BASES 2400000000ull
+static uint64_t zall_bytes(uint64_t bases){ return (uint64_t)((double)bases * 18.0) + (14ull << 30); }
 static void *ctxjob_main(void *arg){
 	ctxjob_t *j = (ctxjob_t*)arg;
 	for(uint32_t d = 0; d < j->ndev; d++){
@@ -1410,7 +1418,7 @@ int main(int argc, char **argv){
 	P->kwin = 800; P->kovl = 300; P->ksave = 4; P->win_rep_norm = 20; P->win_rep_cutoff = 100; P->ncand = 500; P->nbest = 100;
 	P->ztot = 300; P->zovl = 200; P->max_kmer_freq = 0; P->max_zmer_freq = 64; P->max_kmer_var = 2;
 	P->xvar = 128; P->yvar = 64; P->min_block_len = 160; P->deviation_penalty = 1.0f; P->gap_penalty = 0.05f;
-	E->do_align = 1; E->n_idx = 1; E->n_job = 1; E->i_job = 0; E->max_batch = 4096; E->first_batch = 256; E->n_workers = 1;
+	E->do_align = 1; E->n_idx = 1; E->n_job = 1; E->i_job = 0; E->max_batch = 8192; E->first_batch = 256; E->n_workers = 1;
 	pthread_mutex_init(&E->mu, NULL); pthread_cond_init(&E->cv, NULL);
 	static struct option lopts[] = { {"stats", required_argument, 0, 1000}, {"gpu", required_argument, 0, 1001}, {"pool-gb", required_argument, 0, 1002},
 		{"batch", required_argument, 0, 1003}, {"lib-check", no_argument, 0, 1004}, {"repeat", required_argument, 0, 1005}, {"first-batch", required_argument, 0, 1006}, {"workers", required_argument, 0, 1007}, {"pool-mb", required_argument, 0, 1008}, {"gpus", required_argument, 0, 1010}, {"gpu-list", required_argument, 0, 1011}, {"shard-index", no_argument, 0, 1012}, {"zindex-batch", required_argument, 0, 1013}, {"ingest", required_argument, 0, 1014}, {"binary-out", no_argument, 0, 1015}, {0, 0, 0, 0} };
@@ -1509,7 +1517,26 @@ int main(int argc, char **argv){
 		fprintf(stderr, "[wtzmo-mi355x] -G / --workers run on one device: --gpus ignored\n"); E->ndev = 1;
 	}
 	static ctxjob_t cj; memset(&cj, 0, sizeof cj);
-	cj.P = P; cj.pool_bytes = pool_mb ? pool_mb << 20 : pool_gb << 30; cj.ndev = E->ndev; for(uint32_t d = 0; d < E->ndev; d++) cj.devs[d] = E->devs[d];
+	/* Large inputs on ONE device (configs[3]: 10 Gbp): the all-reads z-mer index (16 B per base, built once, in chunks) beats the per-batch one (rebuilt for every
+	 * batch's queries + candidates: 8.1 of 28.8 s per configs[3]-shape step) whenever it fits BESIDE the scratch pool - so the pool, which is allocated now, on a
+	 * helper thread, while the reads are still being parsed, is sized from the input files' sizes (a byte of FASTA is at most a base; gz: x4): what the indexes
+	 * will need stays free.  The exact test follows once the reads are counted (below); a pipe or an underestimate just means the per-batch form as before. */
+	uint64_t pool_auto = 0;
+	if(!pool_gb && !pool_mb && E->ndev == 1 && g_dist.world == 1 && E->n_workers == 1 && E->zbatch <= 0 && !getenv("WTZ_NO_ZALL")){
+		uint64_t est = 0; int known = 1;
+		for(int k = 0; k < pbs.n + tbas.n; k++){
+			const char *fn = k < pbs.n ? pbs.a[k] : tbas.a[k - pbs.n]; struct stat sb;
+			if(stat(fn, &sb) != 0 || !S_ISREG(sb.st_mode)){ known = 0; break; }
+			const size_t ln = strlen(fn);
+			est += (ln > 3 && !strcmp(fn + ln - 3, ".gz")) ? (uint64_t)sb.st_size * 4 : (uint64_t)sb.st_size;
+		}
+		uint64_t fr_b = 0, tot_b = 0;
+		if(known && est > WTZ_ZALL_MIN_BASES && wtz_device_memory(E->devs[0], &fr_b, &tot_b) == WTZ_OK){
+			const uint64_t need = zall_bytes(est);
+			if(fr_b > need + (48ull << 30)){ pool_auto = fr_b - need; if(pool_auto > (128ull << 30)) pool_auto = 128ull << 30; }
+		}
+	}
+	cj.P = P; cj.pool_bytes = pool_mb ? pool_mb << 20 : (pool_gb ? pool_gb << 30 : pool_auto); cj.ndev = E->ndev; for(uint32_t d = 0; d < E->ndev; d++) cj.devs[d] = E->devs[d];
 	cj.started = (pthread_create(&cj.th, NULL, ctxjob_main, &cj) == 0);      /* from here to the join every error path leaves through DIE_NOW (_exit): exit() would tear HIP down under that thread */
 
 	/* ---- load reads (wtzmo.c:1691-1729) ---- */
@@ -1592,13 +1619,22 @@ int main(int argc, char **argv){
 	E->zsplit = (g_dist.world > 1 || E->ndev > 1) && !getenv("WTZ_NO_ZSPLIT");
 	{ /* all-reads z-index: 16 B per base - with several parts only 1 / nparts of it per device, so the per-batch form starts nparts times later */
 	  const uint64_t zparts = E->zsplit ? (g_dist.world > 1 ? (uint64_t)g_dist.world : E->ndev) : 1;
-	  if(E->zbatch == 0 && E->st.nbase > 2400000000ull * zparts && E->n_workers == 1){ E->zbatch = 1; fprintf(stderr, "[wtzmo-mi355x] %llu read bases: the z-mer index is built per batch of queries (--zindex-batch 0 to force the all-reads index)\n", (unsigned long long)E->st.nbase); } }
+	  int zall = 0;
+	  if(E->zbatch == 0 && E->st.nbase > WTZ_ZALL_MIN_BASES * zparts && E->n_workers == 1 && zparts == 1 && !getenv("WTZ_NO_ZALL")){
+		/* the contexts (scratch pools) exist by now: does the all-reads index fit into what they left? */
+		if(cj.started){ pthread_join(cj.th, NULL); cj.started = 0; cj.joined = 1; }
+		uint64_t fr_b = 0, tot_b = 0;
+		if(cj.joined && cj.rc == WTZ_OK && wtz_device_memory(E->devs[0], &fr_b, &tot_b) == WTZ_OK && fr_b > zall_bytes(E->st.nbase)){
+			zall = 1; fprintf(stderr, "[wtzmo-mi355x] %llu read bases: all-reads z-mer index (%.0f GB of %.0f GB free beside the scratch pool)\n", (unsigned long long)E->st.nbase, zall_bytes(E->st.nbase) / 1e9, fr_b / 1e9);
+		}
+	  }
+	  if(!zall && E->zbatch == 0 && E->st.nbase > WTZ_ZALL_MIN_BASES * zparts && E->n_workers == 1){ E->zbatch = 1; fprintf(stderr, "[wtzmo-mi355x] %llu read bases: the z-mer index is built per batch of queries (--zindex-batch 0 to force the all-reads index)\n", (unsigned long long)E->st.nbase); } }
 	if(E->zbatch > 0 && E->n_workers > 1){ fprintf(stderr, " -- --zindex-batch excludes --workers --\n"); DIE_NOW(); }
 	{ const uint32_t zb_max = getenv("WTZ_ZBATCH_MAX") ? (uint32_t)atoi(getenv("WTZ_ZBATCH_MAX")) : 1024u;      /* queries per batch when the z-mer index is rebuilt per batch: bounds its size (queries + <= -A candidates each); configs[3]-shape whole job: 36.0 s with 512, 33.3 s with 1 024, 33.1 s with 2 048 */
 	  if(E->zbatch > 0 && E->max_batch > zb_max) E->max_batch = zb_max; }
 	if(E->shard && (E->n_idx > 1 || E->n_workers > 1)){ fprintf(stderr, " -- --shard-index excludes -G and --workers --\n"); DIE_NOW(); }
 	int rc;
-	if(cj.started) pthread_join(cj.th, NULL); else ctxjob_main(&cj);
+	if(cj.started) pthread_join(cj.th, NULL); else if(!cj.joined) ctxjob_main(&cj);
 	if(cj.rc != WTZ_OK){ fprintf(stderr, " -- wtz_ctx_create failed: %s --\n", cj.err); DIE_NOW(); }
 	for(uint32_t d = 0; d < E->ndev; d++){
 		E->ctxs[d] = cj.ctxs[d];

@@ -476,6 +476,19 @@ extern "C" int wtz_device_count(void){
 #endif
 }
 
+extern "C" int wtz_device_memory(int device, uint64_t *free_bytes, uint64_t *total_bytes){
+	if(!free_bytes || !total_bytes) return wtz_fail(WTZ_E_ARG, "null argument");
+#ifndef WTZ_EMUL
+	int prev = 0; HIPCHK(hipGetDevice(&prev)); HIPCHK(hipSetDevice(device));
+	size_t fr = 0, tot = 0; const hipError_t e = hipMemGetInfo(&fr, &tot); (void)hipSetDevice(prev);
+	if(e != hipSuccess) return wtz_fail(WTZ_E_HIP, "hipMemGetInfo: %s", hipGetErrorString(e));
+	*free_bytes = fr; *total_bytes = tot;
+#else
+	(void)device; *free_bytes = *total_bytes = 16ull << 30;
+#endif
+	return WTZ_OK;
+}
+
 extern "C" int wtz_ctx_create(int device, const wtz_params_c *params, uint64_t pool_bytes, wtz_ctx_t **out){
 	if(!params || !out) return wtz_fail(WTZ_E_ARG, "null argument");
 	if(params->ksize < 5 || params->ksize > 32 || params->zsize < 5 || params->zsize > 16 || params->ksave < 1) return wtz_fail(WTZ_E_ARG, "k/z/S out of range (wtzmo.c:1658-1660)");
@@ -1032,19 +1045,39 @@ static int zindex_build_impl(wtz_ctx_t *c, const uint32_t *members, uint32_t nm,
 	z->sub = subset;
 	z->Z = Z;
 	{
-		uint64_t *d_key = NULL; uint32_t *d_flag = NULL, *d_cnt = NULL, *d_dpos = NULL; uint32_t *d_val = Z.sidx;
-		CHK(dev_alloc((void**)&d_key, (tot + 1) * 8));
-		CHK(wtz_launch<K_zfill>(0, np, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_zfill((uint32_t)t, R, d_prid, d_pjb, d_poff, zsize, hz, Z, d_key, d_val); }));
+		/* chunks of consecutive reads, so that the temporaries (sort keys and their double buffer, run flags / lengths / ranks: 32 B per z-mer beside the 25 B the
+		 * index keeps) are bounded by the chunk and not by the read set: every step below is per read.  WTZ_ZCHUNK_M: z-mers per chunk in millions */
+		static uint64_t chunk_z = 0;
+		if(!chunk_z){ const char *e = getenv("WTZ_ZCHUNK_M"); chunk_z = (uint64_t)((e && atof(e) > 0 ? atof(e) : 256.0) * 1e6); if(chunk_z < 1) chunk_z = 1; }
 		unsigned rbits = 1; while((1ull << rbits) < (uint64_t)nr + 1) rbits++;
-		CHK(dev_sort_pairs_u64_u32(d_key, d_val, tot, 32 + rbits));          /* stable: positions ascend inside a (read, mer) run */
-		CHK(dev_alloc((void**)&d_flag, (tot + 2) * 4)); CHK(dev_alloc((void**)&d_cnt, (tot + 2) * 4)); CHK(dev_alloc((void**)&d_dpos, (tot + 2) * 4));
-		CHK(dev_set(d_flag, 0, (tot + 2) * 4));
-		CHK(wtz_launch<K_zrun>(0, tot, [=] WTZ_LAMBDA (uint64_t i){ wtz_task_zrun(i, d_key, d_val, tot, zcut, Z, d_flag, d_cnt); }));
-		CHK(dev_exclusive_scan_u32(d_flag, d_dpos, tot + 1));
-		CHK(wtz_launch<K_zdistinct>(0, tot, [=] WTZ_LAMBDA (uint64_t i){ wtz_task_zdistinct(i, d_key, d_flag, d_cnt, d_dpos, Z); }));
-		CHK(wtz_launch<K_zdn>(0, nr, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_zdn((uint32_t)t, d_dpos, Z); }));
-		CHK(dev_sync());
-		dev_free(d_key); dev_free(d_flag); dev_free(d_cnt); dev_free(d_dpos);
+		uint32_t r0 = 0;
+		while(r0 < nr){
+			uint32_t r1 = r0 + 1;
+			while(r1 < nr && h[r1 + 1] - h[r0] <= chunk_z) r1++;
+			const uint64_t base = h[r0], n = h[r1] - h[r0];
+			const size_t p0 = first_piece[r0], p1 = first_piece[r1];
+			if(n){
+#ifndef WTZ_EMUL
+				wtz_arena_scope chunk_scope(g_arena);      /* dev_free is a no-op inside an API call: the chunk's temporaries go back (to the arena / its cache) when this scope ends */
+#endif
+				uint64_t *d_key = NULL; uint32_t *d_flag = NULL, *d_cnt = NULL, *d_dpos = NULL; uint32_t *d_val = Z.sidx;
+				CHK(dev_alloc((void**)&d_key, (n + 1) * 8));
+				CHK(wtz_launch<K_zfill>(0, p1 - p0, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_zfill((uint32_t)(p0 + t), R, d_prid, d_pjb, d_poff, zsize, hz, Z, d_key, d_val, base); }));
+				CHK(dev_sort_pairs_u64_u32(d_key, d_val + base, n, 32 + rbits));          /* stable: positions ascend inside a (read, mer) run */
+				CHK(dev_alloc((void**)&d_flag, (n + 2) * 4)); CHK(dev_alloc((void**)&d_cnt, (n + 2) * 4)); CHK(dev_alloc((void**)&d_dpos, (n + 2) * 4));
+				CHK(dev_set(d_flag, 0, (n + 2) * 4));
+				const uint32_t *d_valb = d_val + base;
+				CHK(wtz_launch<K_zrun>(0, n, [=] WTZ_LAMBDA (uint64_t i){ wtz_task_zrun(i, d_key, d_valb, n, zcut, Z, d_flag, d_cnt); }));
+				CHK(dev_exclusive_scan_u32(d_flag, d_dpos, n + 1));
+				CHK(wtz_launch<K_zdistinct>(0, n, [=] WTZ_LAMBDA (uint64_t i){ wtz_task_zdistinct(i, d_key, d_flag, d_cnt, d_dpos, Z, base); }));
+				CHK(wtz_launch<K_zdn>(0, r1 - r0, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_zdn(r0 + (uint32_t)t, d_dpos, Z, base); }));
+				CHK(dev_sync());
+				dev_free(d_key); dev_free(d_flag); dev_free(d_cnt); dev_free(d_dpos);
+			} else {
+				uint32_t *dn = Z.dn + r0; CHK(dev_set(dn, 0, (size_t)(r1 - r0) * 4));
+			}
+			r0 = r1;
+		}
 	}
 	dev_free(d_prid); dev_free(d_pjb); dev_free(d_poff);
 	z->have = true;

@@ -299,10 +299,11 @@ struct wtz_zfill2_f { uint32_t *mer, *pos; uint16_t *len; uint64_t *key; uint32_
 	WTZ_HDM void operator()(uint32_t m, uint32_t d, uint32_t o, uint32_t l){ mer[k] = m; pos[k] = (o << 1) | d; len[k] = (uint16_t)l; key[k] = (rid << 32) | m; val[k] = k; k++; } };
 
 /* piece t writes at poff[t] (absolute); `val` = position of the z-mer inside its read's list */
-WTZ_HD void wtz_task_zfill(uint32_t t, wtz_reads_t R, const uint32_t *piece_rid, const uint32_t *piece_jb, const uint64_t *poff, uint32_t zsize, uint32_t hz, wtz_zindex_t Z, uint64_t *key, uint32_t *val){
+/* `base`: the build runs over chunks of consecutive reads (bounded temporaries); key / flag / cnt / dpos are the chunk's arrays and start at element `base` of the index, val (= Z.sidx) and the index arrays are whole */
+WTZ_HD void wtz_task_zfill(uint32_t t, wtz_reads_t R, const uint32_t *piece_rid, const uint32_t *piece_jb, const uint64_t *poff, uint32_t zsize, uint32_t hz, wtz_zindex_t Z, uint64_t *key, uint32_t *val, uint64_t base = 0){
 	const uint32_t r = piece_rid[t];
 	const uint64_t o = Z.zoff[r];
-	wtz_zfill2_f f; f.mer = Z.mer + o; f.pos = Z.pos + o; f.len = Z.len + o; f.key = key + o; f.val = val + o; f.k = (uint32_t)(poff[t] - o); f.rid = r;
+	wtz_zfill2_f f; f.mer = Z.mer + o; f.pos = Z.pos + o; f.len = Z.len + o; f.key = key + (o - base); f.val = val + o; f.k = (uint32_t)(poff[t] - o); f.rid = r;
 	wtz_zmer_walk(R, r, zsize, hz, f, piece_jb[t], piece_jb[t] + WTZ_WALK_CHUNK);
 }
 
@@ -321,15 +322,15 @@ WTZ_HD void wtz_task_zrun(uint64_t i, const uint64_t *key, const uint32_t *val, 
 	flag[i] = (c && c < max_kcnt) ? 1u : 0u;                 /* kept iff 0 < count < max_kcnt (hzm_aln.h:107) */
 }
 
-WTZ_HD void wtz_task_zdistinct(uint64_t i, const uint64_t *key, const uint32_t *flag, const uint32_t *cnt, const uint32_t *dpos, wtz_zindex_t Z){
+WTZ_HD void wtz_task_zdistinct(uint64_t i, const uint64_t *key, const uint32_t *flag, const uint32_t *cnt, const uint32_t *dpos, wtz_zindex_t Z, uint64_t base = 0){      /* i: element of the chunk */
 	if(!flag[i]) return;
 	const uint32_t r = (uint32_t)(key[i] >> 32);
 	const uint64_t o = Z.zoff[r];
-	const uint32_t d = dpos[i] - dpos[o];
-	Z.dmer[o + d] = (uint32_t)key[i]; Z.dfirst[o + d] = (uint32_t)(i - o); Z.dcnt[o + d] = (uint16_t)cnt[i];
+	const uint32_t d = dpos[i] - dpos[o - base];
+	Z.dmer[o + d] = (uint32_t)key[i]; Z.dfirst[o + d] = (uint32_t)(i + base - o); Z.dcnt[o + d] = (uint16_t)cnt[i];
 }
 
-WTZ_HD void wtz_task_zdn(uint32_t r, const uint32_t *dpos, wtz_zindex_t Z){ Z.dn[r] = dpos[Z.zoff[r + 1]] - dpos[Z.zoff[r]]; }
+WTZ_HD void wtz_task_zdn(uint32_t r, const uint32_t *dpos, wtz_zindex_t Z, uint64_t base = 0){ Z.dn[r] = dpos[Z.zoff[r + 1] - base] - dpos[Z.zoff[r] - base]; }
 
 /* ================= K-seed ================= */
 typedef struct { uint32_t key, ol, lst; } wtz_gacc_t;        /* per (rd<<1|dir): running union length */

@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libwtzmo_hip.so")
 
 SYMBOLS = [
-    "wtz_last_error", "wtz_device_count", "wtz_ctx_create", "wtz_ctx_destroy", "wtz_ctx_clone", "wtz_upload_reads",
+    "wtz_last_error", "wtz_device_count", "wtz_device_memory", "wtz_ctx_create", "wtz_ctx_destroy", "wtz_ctx_clone", "wtz_upload_reads",
     "wtz_index_build", "wtz_zindex_build", "wtz_candidates", "wtz_candidates_begin", "wtz_candidates_end", "wtz_batch_begin", "wtz_pairs_seed",
     "wtz_pairs_windows", "wtz_pairs_align", "wtz_fetch_cigars", "wtz_fetch_cigar_text", "wtz_cigar_text_device", "wtz_host_alloc", "wtz_host_free", "wtz_get_counters", "wtz_reset_counters",
     "wtz_test_dp", "wtz_extend_batch", "wtz_pool_info",
