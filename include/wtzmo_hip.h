@@ -190,6 +190,12 @@ int  wtz_pairs_align(wtz_ctx_t *ctx, const uint32_t *pair_idx, const uint8_t *di
 int  wtz_fetch_cigars(wtz_ctx_t *ctx, uint32_t *dst, uint64_t n_ops);
 /* the same CIGARs already rendered as text on the device (what the .ovl column 17 holds): sum of text_len bytes */
 int  wtz_fetch_cigar_text(wtz_ctx_t *ctx, char *dst, uint64_t n_bytes);
+/* wtz_fetch_cigar_text in two halves (kswx_cigar2string kswx.h:1093-1120, as above): _begin renders the text and starts its copy to dst on a stream of its own and
+ * returns, _end waits for that copy.  In between the context takes the next range's calls (wtz_batch_begin ... wtz_pairs_align): the copy - 3.4 GB per configs[2]
+ * step, 72 ms at the rate of the link - runs beside their kernels.  dst (page-locked: wtz_host_alloc) must not be read before _end returns.  _end may be called
+ * from another thread than the one that drives the context. */
+int  wtz_fetch_cigar_text_begin(wtz_ctx_t *ctx, char *dst, uint64_t n_bytes);
+int  wtz_fetch_cigar_text_end(wtz_ctx_t *ctx);
 /* the same text left ON THE DEVICE: *dev_ptr = device address of the n_bytes (valid until the next call on this context).  For a rank that does not write
  * records itself (one process per GPU): the ~6 KB of CIGAR text per record go from this buffer to the committing rank's GPU over xGMI
  * (RCCL send of a tensor that aliases it) without passing through this rank's host memory. */

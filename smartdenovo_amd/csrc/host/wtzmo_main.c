@@ -142,6 +142,7 @@ typedef struct {
 	wtz_pair_summary_t *sum; uint64_t *box_off; wtz_winbox_t *boxes; uint64_t nbox, capbox;
 	uint32_t *item_of; uint32_t *it_pair; uint8_t *it_dir; uint32_t nitem; wtz_aln_result_t *aln; char *cig; uint64_t ncig;
 	void *cig_dev;               /* rank > 0 with a device-send hook: the text stays on the device (wtz_cigar_text_device) */
+	int text_pending;           /* wtz_fetch_cigar_text_begin has been called for this range: part_text_wait() before the text is read */
 	char *cigs[2]; uint64_t capcigs[2]; int cig_sel, cig_ext, ext_base;      /* two page-locked CIGAR text buffers, alternating per range; ext ids of the output writer */
 	double t_call[6], t_io0;                   /* wall seconds of this part's device calls since the last fold into E (under E->mu) */
 	struct eng_s *E; int again;                /* result of the last part_stages run (1 = scratch pool too small) */
@@ -679,6 +680,15 @@ static int part_text_buffer(part_t *b, uint64_t tot){
 	b->cig = b->cigs[sel];
 	return 1;
 }
+/* the CIGAR text of the part's last range is on its way to the host (wtz_fetch_cigar_text_begin): wait for it */
+static void part_text_wait(part_t *pt, double *t_acc){
+	if(!pt->text_pending || pt->ctx == NULL) return;
+	const double t0 = now_s();
+	const int rc = wtz_fetch_cigar_text_end(pt->ctx);
+	if(t_acc) *t_acc += now_s() - t0;
+	pt->text_pending = 0;
+	if(rc != WTZ_OK){ fprintf(stderr, " -- wtz_fetch_cigar_text_end failed: %s --\n", wtz_last_error()); DIE_NOW(); }
+}
 /* no lock held: the speculative device stages of ONE part's pairs on its context. 1 = scratch pool too small, nothing changed */
 static int part_stages(eng_t *E, part_t *b){
 	const wtz_params_c *P = &E->P;
@@ -704,6 +714,9 @@ static int part_stages(eng_t *E, part_t *b){
 				const double tc0 = now_s(); b->cig_dev = NULL; rc = wtz_cigar_text_device(b->ctx, tot, &b->cig_dev); b->t_call[4] += now_s() - tc0; TRY_WTZ(rc, "wtz_cigar_text_device");
 			} else {
 				if(!part_text_buffer(b, tot)) return WTZ_ST_AGAIN;
+				if(g_dist.world == 1){      /* the copy runs beside what the context does next: part_text_wait() before anybody reads the text */
+					const double tc0 = now_s(); rc = wtz_fetch_cigar_text_begin(b->ctx, b->cig, tot); b->t_call[4] += now_s() - tc0; TRY_WTZ(rc, "wtz_fetch_cigar_text_begin"); b->text_pending = 1;
+				} else
 				{ const double tc0 = now_s(); rc = wtz_fetch_cigar_text(b->ctx, b->cig, tot); b->t_call[4] += now_s() - tc0; } TRY_WTZ(rc, "wtz_fetch_cigar_text");     /* rendered on the device */
 			}
 			b->ncig = tot;
@@ -1038,6 +1051,7 @@ static void process_range(eng_t *E, batch_t *b, uint32_t s0, uint32_t s1){
 	pthread_mutex_unlock(&E->mu);
 	const double tg0 = now_s();
 	const int again = gpu_stages(E, b);
+	for(uint32_t d = 0; d < b->nparts; d++) part_text_wait(&b->parts[d], &b->parts[d].t_call[4]);      /* this path commits at once */
 	const double tg1 = now_s();
 	if(!again && b->npair){
 		for(uint32_t d = 0; d < b->nparts; d++){
@@ -1133,6 +1147,7 @@ static void process_batch(eng_t *E, batch_t *b){
 		const int again = gpujob_wait(&job);
 		if(again){
 			/* scratch pool exhausted: nothing of [s0, s1) is committed and nothing else is in flight: the serial path splits it */
+			for(uint32_t d = 0; d < b->nparts; d++) part_text_wait(&b->parts[d], NULL);
 			b->cparts = b->parts;
 			pthread_mutex_lock(&E->mu); E->n_split++; E->bytes_per_pair = (E->bytes_per_pair > 0 ? E->bytes_per_pair : 1048576.0) * 2.0; pthread_mutex_unlock(&E->mu);
 			if(s1 - s0 <= 1){ fprintf(stderr, " -- device scratch pool too small even for one query: %s (use --pool-gb) --\n", job.err); DIE_NOW(); }
@@ -1168,6 +1183,7 @@ static void process_batch(eng_t *E, batch_t *b){
 			SWAP_FIELD(uint64_t, p->capbox, c->capbox); SWAP_FIELD(uint64_t, p->nbox, c->nbox);
 			SWAP_FIELD(uint32_t*, p->item_of, c->item_of); SWAP_FIELD(uint32_t*, p->it_pair, c->it_pair); SWAP_FIELD(uint8_t*, p->it_dir, c->it_dir); SWAP_FIELD(wtz_aln_result_t*, p->aln, c->aln);
 			c->cig = p->cig; c->cig_ext = p->cig_ext; c->ncig = p->ncig; c->nitem = p->nitem; c->npair = p->npair;
+			c->ctx = p->ctx; c->text_pending = p->text_pending; p->text_pending = 0;
 		}
 		b->cparts = b->spare;
 		double t_gpu_call[5] = {0, 0, 0, 0, 0}, t_io0 = 0;
@@ -1180,6 +1196,7 @@ static void process_batch(eng_t *E, batch_t *b){
 			pthread_mutex_lock(&E->mu); plan_pairs(E, b, n0, n1); pthread_mutex_unlock(&E->mu);
 			gpujob_start(&job, E, b);
 		} else if(!b->pf_inflight){ pthread_mutex_lock(&E->mu); prefetch_begin(E, b); pthread_mutex_unlock(&E->mu); }
+		for(uint32_t d = 0; d < b->nparts; d++) part_text_wait(&b->spare[d], &t_gpu_call[4]);      /* the finished range's text: its copy ran beside the planning above and the first kernels of the next range */
 		const double tc0 = now_s();
 		pthread_mutex_lock(&E->mu);
 		E->t_gpu += tg1 - tg0;
@@ -1208,10 +1225,10 @@ static void process_batch(eng_t *E, batch_t *b){
  * thread while the main thread reads the FASTA (measured on wtgbo, E. coli shape: 5.4 s wall with the 128 GB pool created up front, 1.0 s with 16 GB) */
 typedef struct { const wtz_params_c *P; uint64_t pool_bytes; int devs[8]; uint32_t ndev; wtz_ctx_t *ctxs[8]; int rc; char err[256]; pthread_t th; int started, joined; } ctxjob_t;
 /* device bytes a read set of `bases` bases needs beside the scratch pool when the z-mer index holds every read: the index itself (25 B per z-mer, measured
- * 15.8 B per base), reads (2 bits per base), k-mer seeds + table (< 1.5 B per base), and - transient - the largest of the build temporaries (k-mer index: sort
- * keys + values of 0.19 occurrences per base, double-buffered = 4.6 B per base, gone before the z-mer index is allocated; z-mer chunks: 8 GB), the arena */
+ * 15.8 B per base), reads (2 bits per base), k-mer seeds + table (< 2.5 B per base), and - transient - the largest of the build temporaries (k-mer index: sort
+ * keys + values of 0.19 occurrences per base, double-buffered = 6 B per base, gone before the z-mer index is allocated: BUILD_ZINDEX; z-mer chunks: 8 GB), the arena */
 #define WTZ_ZALL_MIN_BASES 2400000000ull
-static uint64_t zall_bytes(uint64_t bases){ return (uint64_t)((double)bases * 18.0) + (14ull << 30); }
+static uint64_t zall_bytes(uint64_t bases){ return (uint64_t)((double)bases * 19.0) + (14ull << 30); }
 static void *ctxjob_main(void *arg){
 	ctxjob_t *j = (ctxjob_t*)arg;
 	for(uint32_t d = 0; d < j->ndev; d++){
@@ -1410,7 +1427,7 @@ int main(int argc, char **argv){
 	strlist_t pbs = {0}, flts = {0}, ovls = {0}, obts = {0}, tbas = {0};
 	char *output = NULL, *pairoutf = NULL, *statsf = NULL;
 	int c, min_rdlen = 0, overwrite = 0, dot_matrix = 0, write_contained = 1, refine = 0, gpu = 0, lib_check = 0, repeat = 1;
-	uint64_t pool_gb = 0, pool_mb = 0; float optval;
+	uint64_t pool_gb = 0, pool_mb = 0; float optval; int max_batch_set = 0;
 	int n_gpus = 1; const char *gpu_list = NULL;
 	/* defaults: wtzmo.c:1543-1588 */
 	P->w = 50; P->ew = 800; P->W = 3200; P->M = 2; P->X = -5; P->O = -3; P->E = -1; P->T = -50;
@@ -1427,7 +1444,7 @@ int main(int argc, char **argv){
 			case 1000: statsf = optarg; break;
 			case 1001: gpu = atoi(optarg); break;
 			case 1002: pool_gb = (uint64_t)atoll(optarg); break;
-			case 1003: E->max_batch = (uint32_t)atoi(optarg); if(E->max_batch < 1) E->max_batch = 1; break;
+			case 1003: E->max_batch = (uint32_t)atoi(optarg); if(E->max_batch < 1) E->max_batch = 1; max_batch_set = 1; break;
 			case 1004: lib_check = 1; break;
 			case 1005: repeat = atoi(optarg); if(repeat < 1) repeat = 1; break;
 			case 1006: E->first_batch = (uint32_t)atoi(optarg); if(E->first_batch < 1) E->first_batch = 1; E->first_batch_set = 1; break;
@@ -1533,7 +1550,7 @@ int main(int argc, char **argv){
 		uint64_t fr_b = 0, tot_b = 0;
 		if(known && est > WTZ_ZALL_MIN_BASES && wtz_device_memory(E->devs[0], &fr_b, &tot_b) == WTZ_OK){
 			const uint64_t need = zall_bytes(est);
-			if(fr_b > need + (48ull << 30)){ pool_auto = fr_b - need; if(pool_auto > (128ull << 30)) pool_auto = 128ull << 30; }
+			if(fr_b > need + (56ull << 30)){ pool_auto = fr_b - need - (8ull << 30); if(pool_auto > (128ull << 30)) pool_auto = 128ull << 30; }      /* 8 GB: the arena, and the estimate against the exact count */
 		}
 	}
 	cj.P = P; cj.pool_bytes = pool_mb ? pool_mb << 20 : (pool_gb ? pool_gb << 30 : pool_auto); cj.ndev = E->ndev; for(uint32_t d = 0; d < E->ndev; d++) cj.devs[d] = E->devs[d];
@@ -1625,7 +1642,11 @@ int main(int argc, char **argv){
 		if(cj.started){ pthread_join(cj.th, NULL); cj.started = 0; cj.joined = 1; }
 		uint64_t fr_b = 0, tot_b = 0;
 		if(cj.joined && cj.rc == WTZ_OK && wtz_device_memory(E->devs[0], &fr_b, &tot_b) == WTZ_OK && fr_b > zall_bytes(E->st.nbase)){
-			zall = 1; fprintf(stderr, "[wtzmo-mi355x] %llu read bases: all-reads z-mer index (%.0f GB of %.0f GB free beside the scratch pool)\n", (unsigned long long)E->st.nbase, zall_bytes(E->st.nbase) / 1e9, fr_b / 1e9);
+			zall = 1;
+			/* the seed lookup's scratch grows with the tuples of a query (coverage x length: ~450 k at the configs[3] shape = 6.8 MB per query) and the pool is the smaller one
+			 * chosen above: batches of 2 048 queries at most (8 192 asked for 55.7 GB of a 49 GB main pool) */
+			if(!max_batch_set && E->max_batch > 2048) E->max_batch = 2048;
+			fprintf(stderr, "[wtzmo-mi355x] %llu read bases: all-reads z-mer index (%.0f GB of %.0f GB free beside the scratch pool)\n", (unsigned long long)E->st.nbase, zall_bytes(E->st.nbase) / 1e9, fr_b / 1e9);
 		}
 	  }
 	  if(!zall && E->zbatch == 0 && E->st.nbase > WTZ_ZALL_MIN_BASES * zparts && E->n_workers == 1){ E->zbatch = 1; fprintf(stderr, "[wtzmo-mi355x] %llu read bases: the z-mer index is built per batch of queries (--zindex-batch 0 to force the all-reads index)\n", (unsigned long long)E->st.nbase); } }
@@ -1714,7 +1735,9 @@ int main(int argc, char **argv){
 		pthread_t ixth[8]; ixjob_t ixj[8];
 		const uint32_t zmod = E->zsplit ? (g_dist.world > 1 ? (uint32_t)g_dist.world : E->ndev) : 1u;
 		for(uint32_t d = 1; d < E->ndev; d++){ ixj[d].ctx = E->ctxs[d]; ixj[d].n_rd = n_rd; ixj[d].K = P->max_kmer_freq; ixj[d].zonly = E->shard; ixj[d].nozidx = E->zbatch > 0; ixj[d].zmod = zmod; ixj[d].zres = d; if(pthread_create(&ixth[d], NULL, ixjob_main, &ixj[d]) != 0) DIE_NOW(); }
-		if(E->zbatch <= 0){ rc = zindex_for_part(E->ctx, n_rd, zmod, g_dist.world > 1 ? (uint32_t)g_dist.rank : 0u); DIE_WTZ(rc, "wtz_zindex_build"); }
+		/* the z-mer index of this context is built AFTER its (last) k-mer index: only the pair stages read it, and the k-mer build's sort buffers (6 B per base) are
+		 * gone by then - on a 10 Gbp read set the two do not fit side by side next to the scratch pool */
+#define BUILD_ZINDEX() do { if(E->zbatch <= 0){ rc = zindex_for_part(E->ctx, n_rd, zmod, g_dist.world > 1 ? (uint32_t)g_dist.rank : 0u); DIE_WTZ(rc, "wtz_zindex_build"); } } while(0)
 		/* ---- index parts (-G, wtzmo.c:1276-1303) ---- */
 		uint32_t pbbeg = 0, pbend = 0, K = P->max_kmer_freq;
 		wtz_index_stats_t ist;
@@ -1727,6 +1750,7 @@ int main(int argc, char **argv){
 			const double ti = now_s();
 			shard_index_build(E, n_rd, &K);
 			t_index += now_s() - ti;
+			BUILD_ZINDEX();
 		}
 		for(uint32_t i_idx = 0; i_idx < E->n_idx && !E->shard; i_idx++){
 			pbbeg = pbend; pbend = pbbeg + (n_rd + E->n_idx - 1) / E->n_idx;
@@ -1735,7 +1759,7 @@ int main(int argc, char **argv){
 			t_index += now_s() - ti;
 			fprintf(stderr, "[wtzmo-mi355x] index %u/%u: %llu k-mer occurrences, %llu distinct, %llu kept, cutoff %u\n", i_idx + 1, E->n_idx,
 				(unsigned long long)ist.n_occ, (unsigned long long)ist.n_distinct, (unsigned long long)ist.n_kept, K);
-			if(i_idx + 1 >= E->n_idx) break;
+			if(i_idx + 1 >= E->n_idx){ BUILD_ZINDEX(); break; }
 			/* just_query pass: accumulate candidate heaps of every unmasked read of this job */
 			uint32_t n = 0;
 			for(uint32_t j = 0; j < n_rd; j++){ if((j % E->n_job) != E->i_job) continue; if(E->masked[j]) continue; ids[n++] = j; }

@@ -93,7 +93,7 @@ struct K_stitch_mid;
 struct K_winalign;
 struct K_winalign4;
 struct K_winalign_big;
-struct K_zfill;
+struct K_zfill; struct K_zread;
 struct K_zrun;
 struct K_zdistinct;
 struct K_zdn;
@@ -401,6 +401,9 @@ struct wtz_ctx {
 	uint32_t *d_qid, *d_cid; wtz_pairres_t *d_pairres; uint32_t n_pairs; std::vector<wtz_pairres_t> h_pairres;
 	wtz_alnres_dev_t *d_alnres; uint32_t n_items; std::vector<wtz_alnres_dev_t> h_alnres;
 	char *d_text = NULL; size_t cap_text = 0;      /* rendered CIGAR text of the last alignment call (wtz_fetch_cigar_text / wtz_cigar_text_device) */
+#ifndef WTZ_EMUL
+	hipStream_t stream_copy = 0; hipEvent_t ev_text_ready = 0, ev_text_done = 0; bool text_inflight = false;      /* wtz_fetch_cigar_text_begin / _end: the text's way to the host beside the next range's kernels */
+#endif
 	bool have_pairs, have_items;
 	/* candidate request in flight (wtz_candidates_begin / _end) */
 	uint32_t *cq_thr = NULL;
@@ -410,6 +413,7 @@ struct wtz_ctx {
 	uint32_t env_xcd_group = 256;   /* WTZ_XCD_GROUP: consecutive pairs per XCD run in K_pair (0 = identity block -> pair mapping) */
 	int env_ext_mw_cw = 32;      /* WTZ_EXT_MW_CW: K-sw3 jobs with more band columns per lane than this run on four waves whatever their length */
 	int env_ext_fr_split = 0;    /* WTZ_EXT_FR_SPLIT=1: the frame kernel per band class (<= 16 / <= 28 / <= 32 columns per lane), three concurrent launches at 4 / 3 / 2 waves per SIMD */
+	int env_zread = 1;           /* WTZ_ZREAD=0: every read's z-mer index by the device-wide form (strided fill + radix sort) instead of one workgroup per read (wtz_task_zread) */
 	int env_ext_fused = 1;       /* WTZ_EXT_FUSED=0: the two end extensions of a stitched overlap in two launches with K_stitch_mid between them instead of on one wavefront (wtz_stitch_fused.h) */
 	bool fused_ran = false;      /* this stitch stage's fused launch has run: the extension launches behind it only sweep up what it left open */
 	int env_ext_fr = 1;          /* WTZ_EXT_FR=0: K-sw3 one-wave jobs on the round-4 register kernel (wtz_extend_shift_reg) instead of the frame form (wtz_sw_frame.h) */
@@ -553,6 +557,7 @@ extern "C" int wtz_ctx_create(int device, const wtz_params_c *params, uint64_t p
 	if(getenv("WTZ_EXT_SPLIT")) c->env_ext_split = atoi(getenv("WTZ_EXT_SPLIT"));
 	if(getenv("WTZ_EXT_FR")) c->env_ext_fr = atoi(getenv("WTZ_EXT_FR"));
 	if(getenv("WTZ_EXT_FUSED")) c->env_ext_fused = atoi(getenv("WTZ_EXT_FUSED"));
+	if(getenv("WTZ_ZREAD")) c->env_zread = atoi(getenv("WTZ_ZREAD"));
 	if(getenv("WTZ_EXT_FR_SPLIT")) c->env_ext_fr_split = atoi(getenv("WTZ_EXT_FR_SPLIT"));
 	if(getenv("WTZ_EXT_MW_CW")) c->env_ext_mw_cw = atoi(getenv("WTZ_EXT_MW_CW"));
 	if(getenv("WTZ_XCD_GROUP")) c->env_xcd_group = (uint32_t)atoi(getenv("WTZ_XCD_GROUP"));
@@ -668,6 +673,7 @@ extern "C" void wtz_ctx_destroy(wtz_ctx_t *c){
 #ifndef WTZ_EMUL
 	if(c->stream_mw) (void)hipStreamDestroy(c->stream_mw);
 	if(c->stream_gap) (void)hipStreamDestroy(c->stream_gap);
+	if(c->stream_copy){ (void)hipStreamSynchronize(c->stream_copy); (void)hipStreamDestroy(c->stream_copy); if(c->ev_text_ready) (void)hipEventDestroy(c->ev_text_ready); if(c->ev_text_done) (void)hipEventDestroy(c->ev_text_done); }
 	for(int k = 0; k < 8; k++){ if(c->stream_cls[k]) (void)hipStreamDestroy(c->stream_cls[k]); if(c->ev_cls[k]) (void)hipEventDestroy(c->ev_cls[k]); }
 	{ hipEvent_t evs[4] = { c->ev_mw_fork, c->ev_mw_join, c->ev_gap_fork, c->ev_gap_join }; for(int k = 0; k < 4; k++) if(evs[k]) (void)hipEventDestroy(evs[k]); }
 	if(c->stream) (void)hipStreamDestroy(c->stream);
@@ -1050,10 +1056,32 @@ static int zindex_build_impl(wtz_ctx_t *c, const uint32_t *members, uint32_t nm,
 		static uint64_t chunk_z = 0;
 		if(!chunk_z){ const char *e = getenv("WTZ_ZCHUNK_M"); chunk_z = (uint64_t)((e && atof(e) > 0 ? atof(e) : 256.0) * 1e6); if(chunk_z < 1) chunk_z = 1; }
 		unsigned rbits = 1; while((1ull << rbits) < (uint64_t)nr + 1) rbits++;
+		/* reads whose z-mers fit the LDS of a CU are indexed by one workgroup each (wtz_task_zread); the ids are in length order, so what does not fit is a
+		 * prefix [0, rL) of the ids (plus whatever short read sits among them): that prefix goes through the device-wide form in chunks */
+		uint32_t rL = nr;
+		if(c->env_zread){
+			rL = 0;
+			for(uint32_t r = 0; r < nr; r++) if(h[r + 1] - h[r] > WTZ_ZR_MAXN || c->h_rdlen[r] > WTZ_ZR_SUB * WTZ_ZR_MAXPC) rL = r + 1;
+			std::vector<uint32_t> lst[4];
+			for(uint32_t r = rL; r < nr; r++){ const uint64_t nz = h[r + 1] - h[r]; if(nz) lst[nz <= 2048 ? 0 : (nz <= 4096 ? 1 : (nz <= 8192 ? 2 : 3))].push_back(r); }
+			if(nr > rL){ uint32_t *dn = Z.dn + rL; CHK(dev_set(dn, 0, (size_t)(nr - rL) * 4)); }
+			for(int k = 0; k < 4; k++){
+				if(lst[k].empty()) continue;
+				const uint32_t np = 2048u << k, nth = k >= 2 ? 512u : 256u, ldsb = WTZ_ZR_LDS_BYTES(np);
+				uint32_t *d_lst = NULL; CHK(dev_alloc((void**)&d_lst, lst[k].size() * 4)); CHK(dev_h2d(d_lst, lst[k].data(), lst[k].size() * 4));
+#ifdef WTZ_EMUL
+				std::vector<uint32_t> emul_lds(ldsb / 4 + 16); uint32_t *lds_emul = emul_lds.data();
+				CHK(wtz_launch_wg<K_zread>(lst[k].size(), [=] WTZ_LAMBDA (uint64_t t){ wtz_task_zread(d_lst[t], R, zsize, hz, zcut, Z, lds_emul, np); }, 1u, 0u));
+#else
+				CHK(wtz_launch_wg<K_zread>(lst[k].size(), [=] WTZ_LAMBDA (uint64_t t){ wtz_task_zread(d_lst[t], R, zsize, hz, zcut, Z, (uint32_t*)wtz_wave_scratch(), np); }, nth, ldsb));
+#endif
+			}
+			CHK(dev_sync());
+		}
 		uint32_t r0 = 0;
-		while(r0 < nr){
+		while(r0 < rL){
 			uint32_t r1 = r0 + 1;
-			while(r1 < nr && h[r1 + 1] - h[r0] <= chunk_z) r1++;
+			while(r1 < rL && h[r1 + 1] - h[r0] <= chunk_z) r1++;
 			const uint64_t base = h[r0], n = h[r1] - h[r0];
 			const size_t p0 = first_piece[r0], p1 = first_piece[r1];
 			if(n){
@@ -1983,7 +2011,10 @@ extern "C" int wtz_pairs_align(wtz_ctx_t *c, const uint32_t *pair_idx, const uin
 			g_stream = main_stream;
 			CHK(rc_gap);
 			if(gap_side) HIPCHK(hipEventRecord(c->ev_gap_join, c->stream_gap));
-			if(fused){ STAGE(c, "extjobs left + join + right on one wavefront"); CHK(run_stitch_fused(c, V, d_items, d_st, d_jl, d_jr, d_gaps, d_rgeo, m)); }
+			if(fused){
+				if(gap_side) HIPCHK(hipStreamWaitEvent(main_stream, c->ev_gap_join, 0));      /* the join inside the fused launch reads the gaps */
+				STAGE(c, "extjobs left + join + right on one wavefront"); CHK(run_stitch_fused(c, V, d_items, d_st, d_jl, d_jr, d_gaps, d_rgeo, m));
+			}
 			STAGE(c, "extjobs left");
 			CHK(run_extjobs(c, V, d_jl, m, fused));
 			if(gap_side) HIPCHK(hipStreamWaitEvent(main_stream, c->ev_gap_join, 0));
@@ -2053,11 +2084,14 @@ extern "C" int wtz_fetch_cigars(wtz_ctx_t *c, uint32_t *dst, uint64_t n_ops){
 }
 
 /* the CIGAR text of the last wtz_pairs_align rendered into a device buffer of the context (grow-only, valid until the next call on this context) */
-static int render_cigar_text(wtz_ctx_t *c, uint64_t n_bytes, char **d_text_out){
+static int render_cigar_text(wtz_ctx_t *c, uint64_t n_bytes, char **d_text_out, bool wait = true){
 	uint64_t tot = 0; for(uint32_t i = 0; i < c->n_items; i++) tot += c->h_alnres[i].text_len;
 	if(tot != n_bytes) return wtz_fail(WTZ_E_ARG, "CIGAR text: expected room for %llu bytes, got %llu", (unsigned long long)tot, (unsigned long long)n_bytes);
 	*d_text_out = NULL;
 	if(tot == 0) return WTZ_OK;
+#ifndef WTZ_EMUL
+	if(c->text_inflight){ HIPCHK(hipEventSynchronize(c->ev_text_done)); c->text_inflight = false; }      /* the buffer is still being copied out (a caller that never asked for the end of it) */
+#endif
 	if(tot + 16 > c->cap_text){
 		(void)dev_sync(); dev_free_persist(c->d_text); c->d_text = NULL; c->cap_text = 0;
 		const size_t cap = (size_t)(tot + tot / 4 + 4096);
@@ -2070,7 +2104,7 @@ static int render_cigar_text(wtz_ctx_t *c, uint64_t n_bytes, char **d_text_out){
 	const wtz_alnres_dev_t *dr = c->d_alnres;
 	STAGE(c, "K_cigar_text");
 	CHK(wtz_launch_coop<K_cigar_text>(0, c->n_items, [=] WTZ_LAMBDA (uint64_t t){ const wtz_alnres_dev_t &r = dr[t]; if(r.text_len) wtz_cigar_text_write_coop(r.cigar, r.cigar_len, d_t + d_off[t]); }));
-	CHK(dev_sync());
+	if(wait) CHK(dev_sync());
 	dev_free(d_off);
 	*d_text_out = d_t;
 	return WTZ_OK;
@@ -2083,6 +2117,42 @@ extern "C" int wtz_fetch_cigar_text(wtz_ctx_t *c, char *dst, uint64_t n_bytes){
 	if(n_bytes == 0) return WTZ_OK;
 	if(!dst) return wtz_fail(WTZ_E_ARG, "null output");
 	CHK(dev_d2h(dst, d_t, (size_t)n_bytes));
+	return WTZ_OK;
+}
+/* the same in two halves: _begin renders the text and starts its copy on a stream of its own, _end waits for the copy.  Between the two the context is free for
+ * the next calls (wtz_batch_begin ... wtz_pairs_align of the next range): at configs[2] the text is 3.4 GB per step = 72 ms at the rate of the link, and the
+ * scratch pool is not involved - the text is rendered into a buffer of its own.  dst must stay valid (and untouched) until _end returns. */
+extern "C" int wtz_fetch_cigar_text_begin(wtz_ctx_t *c, char *dst, uint64_t n_bytes){
+	if(!c || !c->have_items) return wtz_fail(WTZ_E_STATE, "wtz_fetch_cigar_text_begin before wtz_pairs_align");
+	CTX_ENTER(c);
+#ifdef WTZ_EMUL
+	char *d_t = NULL; CHK(render_cigar_text(c, n_bytes, &d_t));
+	if(n_bytes && !dst) return wtz_fail(WTZ_E_ARG, "null output");
+	if(n_bytes) memcpy(dst, d_t, (size_t)n_bytes);
+	return WTZ_OK;
+#else
+	if(!c->stream_copy){
+		if(hipStreamCreateWithFlags(&c->stream_copy, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->ev_text_ready, hipEventDisableTiming) != hipSuccess
+			|| hipEventCreateWithFlags(&c->ev_text_done, hipEventDisableTiming) != hipSuccess) return wtz_fail(WTZ_E_HIP, "hipStreamCreate / hipEventCreate failed");
+	}
+	char *d_t = NULL;
+	CHK(render_cigar_text(c, n_bytes, &d_t, false));
+	if(n_bytes == 0) return WTZ_OK;
+	if(!dst) return wtz_fail(WTZ_E_ARG, "null output");
+	HIPCHK(hipEventRecord(c->ev_text_ready, g_stream));
+	HIPCHK(hipStreamWaitEvent(c->stream_copy, c->ev_text_ready, 0));
+	HIPCHK(hipMemcpyAsync(dst, d_t, (size_t)n_bytes, hipMemcpyDeviceToHost, c->stream_copy));
+	HIPCHK(hipEventRecord(c->ev_text_done, c->stream_copy));
+	c->text_inflight = true;
+	return WTZ_OK;
+#endif
+}
+extern "C" int wtz_fetch_cigar_text_end(wtz_ctx_t *c){
+	if(!c) return wtz_fail(WTZ_E_ARG, "null argument");
+#ifndef WTZ_EMUL
+	/* no CTX_ENTER: this may be called while another thread runs the next range's calls on the context; it touches the event only */
+	if(c->text_inflight && c->ev_text_done){ HIPCHK(hipEventSynchronize(c->ev_text_done)); }
+#endif
 	return WTZ_OK;
 }
 extern "C" int wtz_cigar_text_device(wtz_ctx_t *c, uint64_t n_bytes, void **dev_ptr){

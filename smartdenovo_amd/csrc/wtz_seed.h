@@ -730,13 +730,14 @@ WTZ_HD uint32_t wtz_wg_excl_scan(uint32_t v, uint32_t *tmp, uint32_t *total){
 WTZ_HD void wtz_wg_sort_u64(uint64_t *a, uint32_t np){
 #if defined(__HIP_DEVICE_COMPILE__)
 	const uint32_t tid = threadIdx.x, nt = blockDim.x;
-	for(uint32_t k = 2; k <= np; k <<= 1){
-		for(uint32_t j = k >> 1; j > 0; j >>= 1){
+	for(uint32_t lk = 1; (1u << lk) <= np; lk++){
+		for(uint32_t lj = lk; lj-- > 0; ){
+			const uint32_t j = 1u << lj;
 			__syncthreads();
 			for(uint32_t t = tid; t < np / 2; t += nt){
-				const uint32_t i = ((t / j) * (j << 1)) + (t % j);
+				const uint32_t i = ((t >> lj) << (lj + 1)) | (t & (j - 1u));      /* shifts: j is a power of two, but only the loop knows */
 				const uint64_t x = a[i], y = a[i + j];
-				const bool asc = ((i & k) == 0);
+				const bool asc = ((i >> lk) & 1u) == 0;
 				if((x > y) == asc){ a[i] = y; a[i + j] = x; }
 			}
 		}
@@ -766,6 +767,74 @@ WTZ_HD uint32_t wtz_wg_incl_max(uint32_t v, uint32_t *tmp, uint32_t *total){
 	(void)tmp; *total = v; return v;
 #endif
 }
+/*
+ * The z-mer index of ONE read by one workgroup (round 5; hzm_aln.h:70-115 is per read too).  The device-wide form above moves every z-mer of the read set
+ * through HBM five times - K_zfill's strided stores (a lane per 1 024-base piece: 64 lanes x 5 arrays of open lines per wave, 480 GB/s), a 49-bit radix sort
+ * of (read, mer) keys (7 passes), K_zrun, a scan, K_zdistinct: 131 of the 137 ms the index of configs[2] takes.  A read has a few thousand z-mers: they fit
+ * the LDS of one CU.  Here the workgroup walks the read in pieces of 128 bases (two walks: count, then fill - the position-ordered arrays go out as the walk
+ * produces them), keeps (mer << 32 | position rank) in LDS, orders them with the workgroup's bitonic network (keys are unique, so the order is the stable
+ * (mer, position) order of the radix sort), and derives the sorted view, the candidate-side cap and the table of distinct retained z-mers from the
+ * ordered keys with two running scans: nothing is written that is not part of the index.  Reads with more z-mers than the LDS holds stay with the form above.
+ *   lds: np u64 keys | WTZ_ZR_MAXPC piece offsets | 64 words of scan scratch
+ */
+#define WTZ_ZR_SUB 128u
+#define WTZ_ZR_MAXPC 512u
+#define WTZ_ZR_MAXN 16384u
+#define WTZ_ZR_LDS_BYTES(np) ((np) * 8u + WTZ_ZR_MAXPC * 4u + 64u * 4u + 64u)
+struct wtz_zread_fill_f { uint32_t *mer, *pos; uint16_t *len; uint64_t *keys; uint32_t k;
+	WTZ_HDM void operator()(uint32_t m, uint32_t d, uint32_t o, uint32_t l){ mer[k] = m; pos[k] = (o << 1) | d; len[k] = (uint16_t)l; keys[k] = ((uint64_t)m << 32) | k; k++; } };
+WTZ_HD void wtz_task_zread(uint32_t r, const wtz_reads_t &R, uint32_t zsize, uint32_t hz, uint32_t zcut, wtz_zindex_t Z, uint32_t *lds, uint32_t np){
+	const uint32_t tid = WTZ_WG_TID, nt = WTZ_WG_N;
+	const uint64_t o = Z.zoff[r]; const uint32_t n = (uint32_t)(Z.zoff[r + 1] - o);
+	if(n == 0){ if(tid == 0) Z.dn[r] = 0; return; }
+	uint64_t *keys = (uint64_t*)lds; uint32_t *pc = lds + 2 * (size_t)np, *tmp = pc + WTZ_ZR_MAXPC;
+	const uint32_t len = R.rdlen[r], npc = (len + WTZ_ZR_SUB - 1) / WTZ_ZR_SUB;
+	for(uint32_t p = tid; p < npc; p += nt){ wtz_zcount_f f; f.n = 0; wtz_zmer_walk(R, r, zsize, hz, f, p * WTZ_ZR_SUB, p * WTZ_ZR_SUB + WTZ_ZR_SUB); pc[p] = f.n; }
+	WTZ_WG_SYNC();
+	{
+		uint32_t carry = 0;
+		for(uint32_t b = 0; b < npc; b += nt){
+			const uint32_t v = b + tid < npc ? pc[b + tid] : 0u;
+			uint32_t tot; const uint32_t ex = wtz_wg_excl_scan(v, tmp, &tot);
+			if(b + tid < npc) pc[b + tid] = carry + ex;
+			carry += tot;
+			WTZ_WG_SYNC();
+		}
+	}
+	for(uint32_t p = tid; p < npc; p += nt){
+		wtz_zread_fill_f f; f.mer = Z.mer + o; f.pos = Z.pos + o; f.len = Z.len + o; f.keys = keys; f.k = pc[p];
+		wtz_zmer_walk(R, r, zsize, hz, f, p * WTZ_ZR_SUB, p * WTZ_ZR_SUB + WTZ_ZR_SUB);
+	}
+	for(uint32_t i = n + tid; i < np; i += nt) keys[i] = ~0ull;
+	WTZ_WG_SYNC();
+	wtz_wg_sort_u64(keys, np);
+	/* ordered keys -> sorted view, cap flags, distinct table.  Element i: head = first of its run of equal z-mers, tail = last; the run's length is known at
+	 * its tail (i - head + 1), and numbering the retained runs by their tails gives the same dense index as numbering them by their heads */
+	uint32_t hcarry = 0, dcarry = 0;
+	for(uint32_t b = 0; b < n; b += nt){
+		const uint32_t i = b + tid; const bool in = i < n;
+		const uint64_t k = in ? keys[i] : 0ull;
+		const uint32_t m = (uint32_t)(k >> 32), idx = (uint32_t)k;
+		const bool head = in && (i == 0 || (uint32_t)(keys[i - 1] >> 32) != m);
+		const bool tail = in && (i + 1 == n || (uint32_t)(keys[i + 1] >> 32) != m);
+		uint32_t hmax; uint32_t hi = wtz_wg_incl_max(head ? i + 1 : 0u, tmp, &hmax);       /* position + 1 of the latest head at or before i */
+		if(hi < hcarry) hi = hcarry;
+		hcarry = hmax > hcarry ? hmax : hcarry;
+		const uint32_t h0 = hi - 1, rank = in ? i - h0 : 0u, c = rank + 1;
+		if(in){
+			Z.sidx[o + i] = idx;
+			Z.ok[o + idx] = (zcut > 255u) ? 1 : (rank < zcut ? 1 : 0);
+		}
+		const uint32_t fl = (tail && c < zcut) ? 1u : 0u;
+		WTZ_WG_SYNC();
+		uint32_t dtot; const uint32_t d = dcarry + wtz_wg_excl_scan(fl, tmp, &dtot);
+		if(fl){ Z.dmer[o + d] = m; Z.dfirst[o + d] = h0; Z.dcnt[o + d] = (uint16_t)(c < 0xFFFFu ? c : 0xFFFFu); }
+		dcarry += dtot;
+		WTZ_WG_SYNC();
+	}
+	if(tid == 0) Z.dn[r] = dcarry;
+}
+
 /* the seed runs of a query's sampled k-mers, one WAVEFRONT per k-mer: koff[e] = run start << 16 | run length (wtz_kprobe), lanes take the run's entries side by
  * side (one coalesced read; four k-mers' first reads are issued together).  f(seed, k-mer index, k-mer length) is called for every entry that is neither the
  * query itself nor a read longer than 1.2 x the query (wtzmo.c:488-489).  Host emulation: one "lane". */

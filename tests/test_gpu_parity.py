@@ -168,6 +168,10 @@ FORMS = [
     {"WTZ_GAP_SIDESTREAM": "1"},                      # gaps on a side stream beside the left extensions
     {"WTZ_WINALIGN4": "1"},                           # four windows per wavefront
     {"WTZ_SW_CHECK": "1"},                            # scalar body beside every wave DP
+    {"WTZ_EXT_FUSED": "0"},                           # K-sw3: the two end extensions in two launches with K_stitch_mid between them (rounds 1-4) instead of on one wavefront
+    {"WTZ_ZREAD": "0"},                               # z-mer index: device-wide fill + radix sort for every read instead of one workgroup per read
+    {"WTZ_ZREAD": "0", "WTZ_ZCHUNK_M": "0.02"},       # ... built in many small chunks of reads
+    {"WTZ_RANGE_FILL": "0.5", "WTZ_GAP_SIDESTREAM": "1"},   # smaller ranges; gaps on the side stream in front of the fused extension launch
 ]
 
 
