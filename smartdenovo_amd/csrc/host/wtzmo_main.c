@@ -1643,9 +1643,9 @@ int main(int argc, char **argv){
 		uint64_t fr_b = 0, tot_b = 0;
 		if(cj.joined && cj.rc == WTZ_OK && wtz_device_memory(E->devs[0], &fr_b, &tot_b) == WTZ_OK && fr_b > zall_bytes(E->st.nbase)){
 			zall = 1;
-			/* the seed lookup's scratch grows with the tuples of a query (coverage x length: ~450 k at the configs[3] shape = 6.8 MB per query) and the pool is the smaller one
-			 * chosen above: batches of 2 048 queries at most (8 192 asked for 55.7 GB of a 49 GB main pool) */
-			if(!max_batch_set && E->max_batch > 2048) E->max_batch = 2048;
+			/* the seed lookup's scratch grows with the tuples of a query (coverage x length: ~450 k at the configs[3] shape = 26 MB per query) and the pool is the smaller one
+			 * chosen above: batches of 1 024 queries at most, as with the per-batch index (2 048 asked for 54.4 GB of a 49 GB main pool) */
+			if(!max_batch_set && E->max_batch > 1024) E->max_batch = 1024;
 			fprintf(stderr, "[wtzmo-mi355x] %llu read bases: all-reads z-mer index (%.0f GB of %.0f GB free beside the scratch pool)\n", (unsigned long long)E->st.nbase, zall_bytes(E->st.nbase) / 1e9, fr_b / 1e9);
 		}
 	  }

@@ -415,6 +415,7 @@ struct wtz_ctx {
 	int env_ext_fr_split = 0;    /* WTZ_EXT_FR_SPLIT=1: the frame kernel per band class (<= 16 / <= 28 / <= 32 columns per lane), three concurrent launches at 4 / 3 / 2 waves per SIMD */
 	int env_zread = 1;           /* WTZ_ZREAD=0: every read's z-mer index by the device-wide form (strided fill + radix sort) instead of one workgroup per read (wtz_task_zread) */
 	int env_ext_fused = 1;       /* WTZ_EXT_FUSED=0: the two end extensions of a stitched overlap in two launches with K_stitch_mid between them instead of on one wavefront (wtz_stitch_fused.h) */
+	double ext_use_ratio = 0.4; uint64_t tpool_last_used = 0;      /* run_stitch_fused: share of the trace upper bounds the fused launches have really taken */
 	bool fused_ran = false;      /* this stitch stage's fused launch has run: the extension launches behind it only sweep up what it left open */
 	int env_ext_fr = 1;          /* WTZ_EXT_FR=0: K-sw3 one-wave jobs on the round-4 register kernel (wtz_extend_shift_reg) instead of the frame form (wtz_sw_frame.h) */
 	int env_ext_split = 0;       /* WTZ_EXT_SPLIT=1: K-sw3 one-wave jobs in two launches by band class (experiment) */
@@ -453,6 +454,7 @@ static int pool_reset(wtz_ctx *c){
 static int tpool_check(wtz_ctx *c, const char *stage){
 	wtz_pool_t p; CHK(dev_d2h(&p, c->dpool + 1, sizeof p));
 	const uint64_t u = p.used > p.cap ? p.cap : p.used;
+	c->tpool_last_used = u;
 	if(u > c->tpool_peak_call) c->tpool_peak_call = u;
 	if(p.overflow && c->env_fail_once) c->env_tfail_at = 0;
 	if(p.overflow) return wtz_fail(WTZ_E_POOL, "%s: transient trace pool exhausted (%llu of %llu bytes requested); use a larger pool",
@@ -1061,9 +1063,14 @@ static int zindex_build_impl(wtz_ctx_t *c, const uint32_t *members, uint32_t nm,
 		uint32_t rL = nr;
 		if(c->env_zread){
 			rL = 0;
-			for(uint32_t r = 0; r < nr; r++) if(h[r + 1] - h[r] > WTZ_ZR_MAXN || c->h_rdlen[r] > WTZ_ZR_SUB * WTZ_ZR_MAXPC) rL = r + 1;
+			for(uint32_t r = 0; r < nr; r++) if(h[r + 1] - h[r] > WTZ_ZR_MAXN || c->h_rdlen[r] > WTZ_ZR_SUB * WTZ_ZR_MAXPC || c->h_rdlen[r] > WTZ_ZR_MAXLEN(WTZ_ZR_MAXN)) rL = r + 1;
 			std::vector<uint32_t> lst[4];
-			for(uint32_t r = rL; r < nr; r++){ const uint64_t nz = h[r + 1] - h[r]; if(nz) lst[nz <= 2048 ? 0 : (nz <= 4096 ? 1 : (nz <= 8192 ? 2 : 3))].push_back(r); }
+			for(uint32_t r = rL; r < nr; r++){
+				const uint64_t nz = h[r + 1] - h[r]; if(!nz) continue;
+				int k = nz <= 2048 ? 0 : (nz <= 4096 ? 1 : (nz <= 8192 ? 2 : 3));
+				while(k < 3 && c->h_rdlen[r] > WTZ_ZR_MAXLEN(2048u << k)) k++;      /* the class must hold the read's bases as well */
+				lst[k].push_back(r);
+			}
 			if(nr > rL){ uint32_t *dn = Z.dn + rL; CHK(dev_set(dn, 0, (size_t)(nr - rL) * 4)); }
 			for(int k = 0; k < 4; k++){
 				if(lst[k].empty()) continue;
@@ -1509,13 +1516,13 @@ extern "C" int wtz_pairs_windows(wtz_ctx_t *c, wtz_winbox_t *wins, uint64_t n_wi
 
 #ifndef WTZ_EMUL
 /* upper bound of the transient-pool bytes one K-sw3 job takes (trace rows come 64 at a time; a row is the widest of the wave forms), its row bound and its band class */
-static uint64_t ext_trace_need(const wtz_ctx *c, int32_t qlen, int32_t tlen, int32_t init, int32_t W, int32_t *ql_out, int32_t *ncol_out){
+WTZ_HD uint64_t wtz_ext_trace_need(int32_t qlen, int32_t tlen, int32_t init, int32_t W, int32_t M, int32_t O, int32_t E, int32_t T, int32_t *ql_out, int32_t *ncol_out){
 	if(ql_out) *ql_out = 0;
 	if(ncol_out) *ncol_out = 0;
 	if(qlen <= 0 || tlen <= 0) return 0;
 	if(init < 0) init = 0;
 	int32_t ql, tl, n_col;
-	wtz_ext_geometry(qlen, tlen, init, W, c->P.M, c->P.O, c->P.O, c->P.E, c->P.T, ql, tl, n_col);
+	wtz_ext_geometry(qlen, tlen, init, W, M, O, O, E, T, ql, tl, n_col);
 	if(ql_out) *ql_out = ql;
 	if(ncol_out) *ncol_out = n_col;
 	/* one-wave register kernel (4-column steps), four-wave kernel (256 lanes), LDS-ring kernel (odd columns per lane) */
@@ -1530,6 +1537,9 @@ static uint64_t ext_trace_need(const wtz_ctx *c, int32_t qlen, int32_t tlen, int
 	}
 	return nb;
 }
+static uint64_t ext_trace_need(const wtz_ctx *c, int32_t qlen, int32_t tlen, int32_t init, int32_t W, int32_t *ql_out, int32_t *ncol_out){
+	return wtz_ext_trace_need(qlen, tlen, init, W, c->P.M, c->P.O, c->P.E, c->P.T, ql_out, ncol_out);
+}
 
 /* Both end extensions of every item of the stage on one wavefront per item (wtz_stitch_fused.h).  The items are ordered by the rows their two extensions can
  * run at most (longest first) and the launch is made only if the traces of ALL jobs fit the transient pool together (their geometry is known before any
@@ -1537,21 +1547,31 @@ static uint64_t ext_trace_need(const wtz_ctx *c, int32_t qlen, int32_t tlen, int
 static int run_stitch_fused(wtz_ctx *c, const wtz_env_t &V, const wtz_alnitem_t *d_items, wtz_stitch_state_t *d_st, wtz_extjob_t *d_jl, wtz_extjob_t *d_jr, const wtz_gapres_t *d_gaps, const int32_t *d_rgeo, uint32_t m){
 	c->fused_ran = false;
 	if(m == 0) return WTZ_OK;
-	int32_t *d_key = NULL; CHK(dev_alloc((void**)&d_key, (size_t)m * 16));
-	CHK(wtz_launch<K_misc>(0, m, [=] WTZ_LAMBDA (uint64_t t){ const wtz_extjob_t &j = d_jl[t]; d_key[4 * t] = j.valid ? j.qlen : -1; d_key[4 * t + 1] = j.tlen; d_key[4 * t + 2] = d_rgeo[2 * t]; d_key[4 * t + 3] = d_rgeo[2 * t + 1]; }));
-	std::vector<int32_t> key4((size_t)m * 4); CHK(dev_d2h(key4.data(), d_key, (size_t)m * 16)); dev_free(d_key);
-	std::vector<int64_t> rows(m); std::vector<uint32_t> ord(m);
-	const uint64_t budget = (c->pool_bytes - c->main_bytes) / 16 * 15;
-	uint64_t acc = 0; unsigned long long ext_sum = 0;
-	for(uint32_t i = 0; i < m; i++){
-		int32_t qa = 0, qb = 0;
-		acc += ext_trace_need(c, key4[(size_t)i * 4], key4[(size_t)i * 4 + 1], 0, -c->P.ew, &qa, NULL);
-		acc += ext_trace_need(c, key4[(size_t)i * 4 + 2], key4[(size_t)i * 4 + 3], 0, -c->P.ew, &qb, NULL);
-		rows[i] = (int64_t)qa + qb; ext_sum += (unsigned long long)rows[i]; ord[i] = i;
+	/* order and budget on the device (the host form - fetch the geometry, order 31 000 items, send the order back - was 2.7 ms of an idle device per range):
+	 * key = the rows both jobs can run at most, inverted (ascending stable radix sort = longest first, ties in item order); the trace bounds are summed with an atomic */
+	uint64_t *d_k = NULL; uint32_t *d_order = NULL; unsigned long long *d_acc = NULL;
+	CHK(dev_alloc((void**)&d_k, (size_t)m * 8)); CHK(dev_alloc((void**)&d_order, (size_t)m * 4)); CHK(dev_alloc((void**)&d_acc, 16)); CHK(dev_set(d_acc, 0, 16));
+	{
+		const int32_t pM = c->P.M, pO = c->P.O, pE = c->P.E, pT = c->P.T, pW = -c->P.ew;
+		CHK(wtz_launch<K_misc>(0, m, [=] WTZ_LAMBDA (uint64_t t){
+			const wtz_extjob_t &j = d_jl[t];
+			int32_t qa = 0, qb = 0;
+			unsigned long long nb = wtz_ext_trace_need(j.valid ? j.qlen : -1, j.tlen, 0, pW, pM, pO, pE, pT, &qa, (int32_t*)NULL);
+			nb += wtz_ext_trace_need(d_rgeo[2 * t], d_rgeo[2 * t + 1], 0, pW, pM, pO, pE, pT, &qb, (int32_t*)NULL);
+			const uint32_t rows = (uint32_t)qa + (uint32_t)qb;
+			d_k[t] = (uint64_t)(0xFFFFFFFFu - rows); d_order[t] = (uint32_t)t;
+			if(nb) WTZ_ATOMIC_ADD64(&d_acc[0], nb);
+			if(rows) WTZ_ATOMIC_ADD64(&d_acc[1], (unsigned long long)rows);
+		}));
 	}
-	if(acc > budget) return WTZ_OK;          /* the two launches cut their jobs into groups that fit */
-	std::stable_sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t b){ return rows[a] > rows[b]; });
-	uint32_t *d_order = NULL; CHK(dev_alloc((void**)&d_order, (size_t)m * 4)); CHK(dev_h2d(d_order, ord.data(), (size_t)m * 4));
+	CHK(dev_sort_pairs_u64_u32(d_k, d_order, m, 32));
+	unsigned long long h_acc[2] = {0, 0}; CHK(dev_d2h(h_acc, d_acc, 16));
+	const uint64_t acc = h_acc[0]; const unsigned long long ext_sum = h_acc[1];
+	const uint64_t budget = (c->pool_bytes - c->main_bytes) / 16 * 15;
+	/* acc sums UPPER bounds (every job run to its last row); the traces are allocated 64 rows at a time as a job runs, and most jobs end early: what the launches
+	 * before this one took of their bounds (x 1.3, never below a fifth) is what this one is expected to take.  An estimate that was too low ends in WTZ_E_POOL like
+	 * any other exhausted pool: the host redoes the range in halves. */
+	if((double)acc * c->ext_use_ratio > (double)budget){ if(c->env_profile) fprintf(stderr, "[ext-profile] fused launch declined: %u items, trace bounds %.1f GB x %.2f against %.1f GB\n", m, acc / 1e9, c->ext_use_ratio, budget / 1e9); return WTZ_OK; }          /* the two launches cut their jobs into groups that fit */
 	CHK(tpool_reset(c));
 	wtz_timer te; te.start();
 	hipLaunchKernelGGL((wtz_kernel_stitch_ext_fr<1032>), dim3(m), dim3(64), WTZ_WAVE_LDS_BYTES, g_stream, V, d_items, d_st, d_jl, d_jr, d_gaps, (const uint32_t*)d_order, m);
@@ -1561,7 +1581,9 @@ static int run_stitch_fused(wtz_ctx *c, const wtz_env_t &V, const wtz_alnitem_t 
 	c->fused_ran = true;
 	if(c->env_profile) fprintf(stderr, "[ext-profile] fused launch: %u items, rows (upper bound) sum %llu, %.2f ms\n", m, ext_sum, ms_l);
 	dev_free(d_order);
-	return tpool_check(c, "K-sw3 extension jobs (both ends on one wavefront)");
+	CHK(tpool_check(c, "K-sw3 extension jobs (both ends on one wavefront)"));
+	if(acc){ const double seen = 1.3 * (double)c->tpool_last_used / (double)acc, keep = c->ext_use_ratio * 0.9; c->ext_use_ratio = seen > keep ? seen : keep; if(c->ext_use_ratio < 0.2) c->ext_use_ratio = 0.2; if(c->ext_use_ratio > 1.0) c->ext_use_ratio = 1.0; }
+	return WTZ_OK;
 }
 #endif
 

@@ -780,16 +780,61 @@ WTZ_HD uint32_t wtz_wg_incl_max(uint32_t v, uint32_t *tmp, uint32_t *total){
 #define WTZ_ZR_SUB 128u
 #define WTZ_ZR_MAXPC 512u
 #define WTZ_ZR_MAXN 16384u
-#define WTZ_ZR_LDS_BYTES(np) ((np) * 8u + WTZ_ZR_MAXPC * 4u + 64u * 4u + 64u)
-struct wtz_zread_fill_f { uint32_t *mer, *pos; uint16_t *len; uint64_t *keys; uint32_t k;
-	WTZ_HDM void operator()(uint32_t m, uint32_t d, uint32_t o, uint32_t l){ mer[k] = m; pos[k] = (o << 1) | d; len[k] = (uint16_t)l; keys[k] = ((uint64_t)m << 32) | k; k++; } };
+#define WTZ_ZR_SMALL 24u              /* buckets up to this size are ordered by one lane (insertion) */
+#define WTZ_ZR_MAXLEN(np) ((np) * 5u / 2u)                 /* bases of a read of the class: its packed bases are staged in LDS (the walks' warm starts step BACKWARDS base by base: from HBM that was ~40 dependent loads per piece and 90 % of the kernel) */
+#define WTZ_ZR_LDS_BYTES(np) ((np) * 8u + ((np) / 4u + 1u) * 4u + WTZ_ZR_MAXPC * 4u + 64u * 4u + (WTZ_ZR_MAXLEN(np) / 32u + 4u) * 8u + 16u * 4u + 64u)
+struct wtz_zread_cnt_f { uint32_t n; uint32_t *hist; uint32_t bsh;
+	WTZ_HDM void operator()(uint32_t m, uint32_t, uint32_t, uint32_t){ n++; WTZ_LDS_ADD32(&hist[m >> bsh], 1u); } };
+struct wtz_zread_fill_f { uint32_t *mer, *pos; uint16_t *len; uint64_t *keys; uint32_t *cur; uint32_t bsh; uint32_t k;
+	WTZ_HDM void operator()(uint32_t m, uint32_t d, uint32_t o, uint32_t l){
+		mer[k] = m; pos[k] = (o << 1) | d; len[k] = (uint16_t)l;
+		const uint32_t slot = WTZ_LDS_ADD32(&cur[m >> bsh], 1u);           /* any order inside the bucket: the keys are unique, every correct order is THE order */
+		keys[slot] = ((uint64_t)m << 32) | k; k++;
+	} };
+/* n (any number of) u64 words in LDS ordered by the whole workgroup: the bitonic network with all comparators pointing up (first step of a merge against the
+ * mirror image), so that the missing elements behind n act as +infinity without being stored */
+WTZ_HD void wtz_wg_sort_u64_n(uint64_t *a, uint32_t n){
+#if defined(__HIP_DEVICE_COMPILE__)
+	const uint32_t tid = threadIdx.x, nt = blockDim.x;
+	uint32_t lp = 1; while((1u << lp) < n) lp++;
+	for(uint32_t lk = 1; lk <= lp; lk++){
+		for(uint32_t lj = lk; lj-- > 0; ){
+			const uint32_t j = 1u << lj;
+			__syncthreads();
+			for(uint32_t t = tid; t < (1u << lp) / 2; t += nt){
+				const uint32_t i = ((t >> lj) << (lj + 1)) | (t & (j - 1u));
+				const uint32_t q = (lj + 1 == lk) ? (i ^ ((2u << lj) - 1u)) : (i | j);      /* mirror inside the block of 2j for the first step of a merge, i + j after it */
+				if(q < n){ const uint64_t x = a[i], y = a[q]; if(x > y){ a[i] = y; a[q] = x; } }
+			}
+		}
+	}
+	__syncthreads();
+#else
+	wtz_heapsort_u64(a, n);
+#endif
+}
 WTZ_HD void wtz_task_zread(uint32_t r, const wtz_reads_t &R, uint32_t zsize, uint32_t hz, uint32_t zcut, wtz_zindex_t Z, uint32_t *lds, uint32_t np){
 	const uint32_t tid = WTZ_WG_TID, nt = WTZ_WG_N;
 	const uint64_t o = Z.zoff[r]; const uint32_t n = (uint32_t)(Z.zoff[r + 1] - o);
 	if(n == 0){ if(tid == 0) Z.dn[r] = 0; return; }
-	uint64_t *keys = (uint64_t*)lds; uint32_t *pc = lds + 2 * (size_t)np, *tmp = pc + WTZ_ZR_MAXPC;
+	const uint32_t nbk = np / 4u;                               /* buckets by the leading bits of the z-mer: ~4 z-mers each (canonical z-mers lean to the small values: up to ~8) */
+	uint32_t lb = 0; while((1u << lb) < nbk) lb++;
+	const uint32_t bsh = 32u - lb;
+	uint64_t *keys = (uint64_t*)lds; uint32_t *bk = lds + 2 * (size_t)np, *pc = bk + nbk + 1, *tmp = pc + WTZ_ZR_MAXPC;
 	const uint32_t len = R.rdlen[r], npc = (len + WTZ_ZR_SUB - 1) / WTZ_ZR_SUB;
-	for(uint32_t p = tid; p < npc; p += nt){ wtz_zcount_f f; f.n = 0; wtz_zmer_walk(R, r, zsize, hz, f, p * WTZ_ZR_SUB, p * WTZ_ZR_SUB + WTZ_ZR_SUB); pc[p] = f.n; }
+	/* the read's 2-bit words in LDS, addressed as a one-read bank: read 0 starts at the offset of the read inside its first word */
+	uint64_t *lbits = (uint64_t*)(((uintptr_t)(tmp + 64) + 7u) & ~(uintptr_t)7u);
+	const uint32_t nwl = WTZ_ZR_MAXLEN(np) / 32u + 4u;
+	uint64_t *loff = lbits + nwl; uint32_t *llen = (uint32_t*)(loff + 1);
+	{
+		const uint64_t off = R.rdoff[r], w0 = off >> 5, nw = ((off + len + 31u) >> 5) - w0;
+		for(uint32_t w = tid; w < (uint32_t)nw; w += nt) lbits[w] = R.bits[w0 + w];
+		if(tid == 0){ loff[0] = off & 31u; llen[0] = len; }
+	}
+	wtz_reads_t RL; RL.bits = lbits; RL.rdoff = loff; RL.rdlen = llen; RL.n_reads = 1;
+	for(uint32_t b = tid; b <= nbk; b += nt) bk[b] = 0;
+	WTZ_WG_SYNC();
+	for(uint32_t p = tid; p < npc; p += nt){ wtz_zread_cnt_f f; f.n = 0; f.hist = bk; f.bsh = bsh; wtz_zmer_walk(RL, 0u, zsize, hz, f, p * WTZ_ZR_SUB, p * WTZ_ZR_SUB + WTZ_ZR_SUB); pc[p] = f.n; }
 	WTZ_WG_SYNC();
 	{
 		uint32_t carry = 0;
@@ -800,14 +845,45 @@ WTZ_HD void wtz_task_zread(uint32_t r, const wtz_reads_t &R, uint32_t zsize, uin
 			carry += tot;
 			WTZ_WG_SYNC();
 		}
+		carry = 0;
+		for(uint32_t b = 0; b < nbk; b += nt){                      /* bucket counts -> bucket starts; the fill advances them to the bucket ends */
+			const uint32_t v = b + tid < nbk ? bk[b + tid] : 0u;
+			uint32_t tot; const uint32_t ex = wtz_wg_excl_scan(v, tmp, &tot);
+			if(b + tid < nbk) bk[b + tid] = carry + ex;
+			carry += tot;
+			WTZ_WG_SYNC();
+		}
 	}
 	for(uint32_t p = tid; p < npc; p += nt){
-		wtz_zread_fill_f f; f.mer = Z.mer + o; f.pos = Z.pos + o; f.len = Z.len + o; f.keys = keys; f.k = pc[p];
-		wtz_zmer_walk(R, r, zsize, hz, f, p * WTZ_ZR_SUB, p * WTZ_ZR_SUB + WTZ_ZR_SUB);
+		wtz_zread_fill_f f; f.mer = Z.mer + o; f.pos = Z.pos + o; f.len = Z.len + o; f.keys = keys; f.cur = bk; f.bsh = bsh; f.k = pc[p];
+		wtz_zmer_walk(RL, 0u, zsize, hz, f, p * WTZ_ZR_SUB, p * WTZ_ZR_SUB + WTZ_ZR_SUB);
 	}
-	for(uint32_t i = n + tid; i < np; i += nt) keys[i] = ~0ull;
 	WTZ_WG_SYNC();
-	wtz_wg_sort_u64(keys, np);
+	/* bucket b is keys[bk[b-1], bk[b]) now.  Small buckets: one lane each; the others (a z-mer repeated all over the read) are listed and ordered by the workgroup */
+	if(tid == 0) pc[0] = 0;
+	WTZ_WG_SYNC();
+	for(uint32_t b = tid; b < nbk; b += nt){
+		const uint32_t s0 = b ? bk[b - 1] : 0u, e0 = bk[b], cnt = e0 - s0;
+		if(cnt < 2) continue;
+		if(cnt > WTZ_ZR_SMALL){ const uint32_t q = WTZ_LDS_ADD32(&pc[0], 1u); if(q + 1 < WTZ_ZR_MAXPC) pc[1 + q] = b; continue; }
+		for(uint32_t i = s0 + 1; i < e0; i++){
+			const uint64_t v = keys[i]; uint32_t j = i;
+			while(j > s0 && keys[j - 1] > v){ keys[j] = keys[j - 1]; j--; }
+			keys[j] = v;
+		}
+	}
+	WTZ_WG_SYNC();
+	{
+		const uint32_t nbig = pc[0];
+		if(nbig + 1 >= WTZ_ZR_MAXPC){                               /* more large buckets than the list holds: the whole array at once */
+			WTZ_WG_SYNC();
+			wtz_wg_sort_u64_n(keys, n);
+		} else for(uint32_t q = 0; q < nbig; q++){
+			const uint32_t b = pc[1 + q], s0 = b ? bk[b - 1] : 0u;
+			wtz_wg_sort_u64_n(keys + s0, bk[b] - s0);
+		}
+	}
+	WTZ_WG_SYNC();
 	/* ordered keys -> sorted view, cap flags, distinct table.  Element i: head = first of its run of equal z-mers, tail = last; the run's length is known at
 	 * its tail (i - head + 1), and numbering the retained runs by their tails gives the same dense index as numbering them by their heads */
 	uint32_t hcarry = 0, dcarry = 0;

@@ -384,8 +384,10 @@ WTZ_HD void wtz_task_winalign(uint32_t t, const wtz_env_t &V, const wtz_wintask_
 /* ---------------- A9 with one lane per K-sw1 problem (wtz_sw_lane.h): planner, DP, fold ---------------- */
 #if defined(__HIP_DEVICE_COMPILE__)
 #define WTZ_ATOMIC_INC32(p) atomicAdd((p), 1u)
+#define WTZ_ATOMIC_ADD64(p, v) atomicAdd((p), (unsigned long long)(v))
 #else
 #define WTZ_ATOMIC_INC32(p) ((*(p))++)
+#define WTZ_ATOMIC_ADD64(p, v) (*(p) += (unsigned long long)(v))
 #endif
 /* window t: number of anchors = number of problem slots */
 WTZ_HD void wtz_task_lcount(uint32_t t, const wtz_wintask_t *tasks, const wtz_alnitem_t *items, uint32_t *na){

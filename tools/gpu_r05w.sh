@@ -5,7 +5,7 @@ T=${1:-r05w}
 O=$R/gpurun_out/$T; mkdir -p $O
 export TMPDIR=/tmp
 cd $R
-timeout 1200 python -m pytest tests/test_gpu_parity.py -x -q -k "switchable" > $O/pytest_forms.txt 2>&1; tail -2 $O/pytest_forms.txt
+timeout 1200 python -m pytest tests/test_gpu_parity.py -x -q -k "not switchable" > $O/pytest_forms.txt 2>&1; tail -2 $O/pytest_forms.txt
 run(){ tag=$1; shift; args=$1; shift
   env "$@" timeout 900 python bench.py --steps 3 --warmup 1 --no-cpu-baseline $args > $O/bench_$tag.json 2> $O/bench_$tag.err
   grep "kernel ms" $O/bench_$tag.err | tail -1
