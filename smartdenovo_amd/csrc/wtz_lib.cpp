@@ -1063,18 +1063,18 @@ static int zindex_build_impl(wtz_ctx_t *c, const uint32_t *members, uint32_t nm,
 		uint32_t rL = nr;
 		if(c->env_zread){
 			rL = 0;
-			for(uint32_t r = 0; r < nr; r++) if(h[r + 1] - h[r] > WTZ_ZR_MAXN || c->h_rdlen[r] > WTZ_ZR_SUB * WTZ_ZR_MAXPC || c->h_rdlen[r] > WTZ_ZR_MAXLEN(WTZ_ZR_MAXN)) rL = r + 1;
-			std::vector<uint32_t> lst[4];
+			static const uint32_t cls[7] = { 2048u, 3072u, 4096u, 6144u, 8192u, 12288u, 16384u };      /* LDS per workgroup follows the class: finer classes = more workgroups per CU */
+			for(uint32_t r = 0; r < nr; r++) if(h[r + 1] - h[r] > WTZ_ZR_MAXN || c->h_rdlen[r] > WTZ_ZR_MAXLEN(WTZ_ZR_MAXN)) rL = r + 1;
+			std::vector<uint32_t> lst[7];
 			for(uint32_t r = rL; r < nr; r++){
 				const uint64_t nz = h[r + 1] - h[r]; if(!nz) continue;
-				int k = nz <= 2048 ? 0 : (nz <= 4096 ? 1 : (nz <= 8192 ? 2 : 3));
-				while(k < 3 && c->h_rdlen[r] > WTZ_ZR_MAXLEN(2048u << k)) k++;      /* the class must hold the read's bases as well */
+				int k = 0; while(k < 6 && (nz > cls[k] || c->h_rdlen[r] > WTZ_ZR_MAXLEN(cls[k]))) k++;      /* the class holds the read's z-mers and its bases */
 				lst[k].push_back(r);
 			}
 			if(nr > rL){ uint32_t *dn = Z.dn + rL; CHK(dev_set(dn, 0, (size_t)(nr - rL) * 4)); }
-			for(int k = 0; k < 4; k++){
+			for(int k = 6; k >= 0; k--){
 				if(lst[k].empty()) continue;
-				const uint32_t np = 2048u << k, nth = k >= 2 ? 512u : 256u, ldsb = WTZ_ZR_LDS_BYTES(np);
+				const uint32_t np = cls[k], nth = 512u, ldsb = wtz_zr_lds_bytes(np);
 				uint32_t *d_lst = NULL; CHK(dev_alloc((void**)&d_lst, lst[k].size() * 4)); CHK(dev_h2d(d_lst, lst[k].data(), lst[k].size() * 4));
 #ifdef WTZ_EMUL
 				std::vector<uint32_t> emul_lds(ldsb / 4 + 16); uint32_t *lds_emul = emul_lds.data();

@@ -775,14 +775,15 @@ WTZ_HD uint32_t wtz_wg_incl_max(uint32_t v, uint32_t *tmp, uint32_t *total){
  * produces them), keeps (mer << 32 | position rank) in LDS, orders them with the workgroup's bitonic network (keys are unique, so the order is the stable
  * (mer, position) order of the radix sort), and derives the sorted view, the candidate-side cap and the table of distinct retained z-mers from the
  * ordered keys with two running scans: nothing is written that is not part of the index.  Reads with more z-mers than the LDS holds stay with the form above.
- *   lds: np u64 keys | WTZ_ZR_MAXPC piece offsets | 64 words of scan scratch
+ *   lds: np u64 keys | bucket cursors | piece offsets | 64 words of scan scratch | the read's 2-bit words (wtz_zr_lds_bytes)
  */
-#define WTZ_ZR_SUB 128u
-#define WTZ_ZR_MAXPC 512u
+#define WTZ_ZR_SUB 32u                 /* bases per walk piece: a 10 kb read keeps 320 of the workgroup's threads busy (128-base pieces: 80; the walks are what a read's time is made of) */
 #define WTZ_ZR_MAXN 16384u
 #define WTZ_ZR_SMALL 24u              /* buckets up to this size are ordered by one lane (insertion) */
-#define WTZ_ZR_MAXLEN(np) ((np) * 5u / 2u)                 /* bases of a read of the class: its packed bases are staged in LDS (the walks' warm starts step BACKWARDS base by base: from HBM that was ~40 dependent loads per piece and 90 % of the kernel) */
-#define WTZ_ZR_LDS_BYTES(np) ((np) * 8u + ((np) / 4u + 1u) * 4u + WTZ_ZR_MAXPC * 4u + 64u * 4u + (WTZ_ZR_MAXLEN(np) / 32u + 4u) * 8u + 16u * 4u + 64u)
+#define WTZ_ZR_MAXLEN(np) ((np) * 2u)                     /* bases of a read of the class: its packed bases are staged in LDS (the walks' warm starts step BACKWARDS base by base) */
+#define WTZ_ZR_MAXPC(np) (WTZ_ZR_MAXLEN(np) / WTZ_ZR_SUB)
+WTZ_HD uint32_t wtz_zr_nbk(uint32_t np){ uint32_t b = 64; while(b < np / 4u) b <<= 1; return b; }      /* buckets: a power of two, ~4 z-mers each */
+WTZ_HD uint32_t wtz_zr_lds_bytes(uint32_t np){ return np * 8u + (wtz_zr_nbk(np) + 1u) * 4u + WTZ_ZR_MAXPC(np) * 4u + 64u * 4u + (WTZ_ZR_MAXLEN(np) / 32u + 4u) * 8u + 16u * 4u + 64u; }
 struct wtz_zread_cnt_f { uint32_t n; uint32_t *hist; uint32_t bsh;
 	WTZ_HDM void operator()(uint32_t m, uint32_t, uint32_t, uint32_t){ n++; WTZ_LDS_ADD32(&hist[m >> bsh], 1u); } };
 struct wtz_zread_fill_f { uint32_t *mer, *pos; uint16_t *len; uint64_t *keys; uint32_t *cur; uint32_t bsh; uint32_t k;
@@ -817,10 +818,10 @@ WTZ_HD void wtz_task_zread(uint32_t r, const wtz_reads_t &R, uint32_t zsize, uin
 	const uint32_t tid = WTZ_WG_TID, nt = WTZ_WG_N;
 	const uint64_t o = Z.zoff[r]; const uint32_t n = (uint32_t)(Z.zoff[r + 1] - o);
 	if(n == 0){ if(tid == 0) Z.dn[r] = 0; return; }
-	const uint32_t nbk = np / 4u;                               /* buckets by the leading bits of the z-mer: ~4 z-mers each (canonical z-mers lean to the small values: up to ~8) */
+	const uint32_t nbk = wtz_zr_nbk(np);                        /* buckets by the leading bits of the z-mer: ~4 z-mers each (canonical z-mers lean to the small values: up to ~8) */
 	uint32_t lb = 0; while((1u << lb) < nbk) lb++;
-	const uint32_t bsh = 32u - lb;
-	uint64_t *keys = (uint64_t*)lds; uint32_t *bk = lds + 2 * (size_t)np, *pc = bk + nbk + 1, *tmp = pc + WTZ_ZR_MAXPC;
+	const uint32_t bsh = 32u - lb, maxpc = WTZ_ZR_MAXPC(np);
+	uint64_t *keys = (uint64_t*)lds; uint32_t *bk = lds + 2 * (size_t)np, *pc = bk + nbk + 1, *tmp = pc + maxpc;
 	const uint32_t len = R.rdlen[r], npc = (len + WTZ_ZR_SUB - 1) / WTZ_ZR_SUB;
 	/* the read's 2-bit words in LDS, addressed as a one-read bank: read 0 starts at the offset of the read inside its first word */
 	uint64_t *lbits = (uint64_t*)(((uintptr_t)(tmp + 64) + 7u) & ~(uintptr_t)7u);
@@ -865,7 +866,7 @@ WTZ_HD void wtz_task_zread(uint32_t r, const wtz_reads_t &R, uint32_t zsize, uin
 	for(uint32_t b = tid; b < nbk; b += nt){
 		const uint32_t s0 = b ? bk[b - 1] : 0u, e0 = bk[b], cnt = e0 - s0;
 		if(cnt < 2) continue;
-		if(cnt > WTZ_ZR_SMALL){ const uint32_t q = WTZ_LDS_ADD32(&pc[0], 1u); if(q + 1 < WTZ_ZR_MAXPC) pc[1 + q] = b; continue; }
+		if(cnt > WTZ_ZR_SMALL){ const uint32_t q = WTZ_LDS_ADD32(&pc[0], 1u); if(q + 1 < maxpc) pc[1 + q] = b; continue; }
 		for(uint32_t i = s0 + 1; i < e0; i++){
 			const uint64_t v = keys[i]; uint32_t j = i;
 			while(j > s0 && keys[j - 1] > v){ keys[j] = keys[j - 1]; j--; }
@@ -875,7 +876,7 @@ WTZ_HD void wtz_task_zread(uint32_t r, const wtz_reads_t &R, uint32_t zsize, uin
 	WTZ_WG_SYNC();
 	{
 		const uint32_t nbig = pc[0];
-		if(nbig + 1 >= WTZ_ZR_MAXPC){                               /* more large buckets than the list holds: the whole array at once */
+		if(nbig + 1 >= maxpc){                               /* more large buckets than the list holds: the whole array at once */
 			WTZ_WG_SYNC();
 			wtz_wg_sort_u64_n(keys, n);
 		} else for(uint32_t q = 0; q < nbig; q++){
