@@ -262,6 +262,8 @@ def main():
     argv = ["wtzmo"] + dev_args + ["-i", fa, "-fo", out, "--repeat", str(W + K), "--stats", stats] + (["--pool-gb", str(a.pool_gb)] if a.pool_gb else []) + drv_extra + eng
     if a.max_batch:
         argv += ["--batch", str(a.max_batch)]
+    if os.environ.get("WTZ_BENCH_FIRST_BATCH"):      # experiment: size of the first batch of the ramp (256 -> x4 -> ... -> --batch)
+        argv += ["--first-batch", os.environ["WTZ_BENCH_FIRST_BATCH"]]
     host = C.CDLL(ge.HOSTLIB)
     xchg = None
     if dist:

@@ -100,6 +100,7 @@ typedef struct eng_s {
 	double t_cq[4];             /* commit_query sections: candidate rows + closed filter + sort | window depth + seed weights + sort | hits (gates, queueing, masking) | plan_pairs */
 	double t_gpu, t_commit, t_zbatch, t_call[6], t_io[2];      /* t_io: waiting for the writer thread before a text buffer is reused / at the end of the run */      /* t_call: wall seconds inside wtz_candidates / pairs_seed / pairs_windows / pairs_align / fetch_cigar_text / planning */
 	uint64_t spec_pairs, used_pairs, spec_items, used_items, spec_queries, used_queries, n_batches;
+	double last_used_ratio;      /* queries used / planned of the batch that finished last (process_batch: may the next batch be formed in front of the last commit?) */
 	double extra_ms[6]; uint64_t extra_u64[7];      /* counters of the cloned contexts */
 } eng_t;
 
@@ -154,7 +155,7 @@ typedef struct {
 #define LOCAL_OF(b, g) ((g) >> 4)
 #define DEAL_PART(np, q, c) ((c) % (np))               /* the part a pair is dealt to: by CANDIDATE id, so that a device only needs the candidate-side z-mers of its own residue class of reads */
 
-typedef struct {       /* one batch in flight */
+typedef struct batch_s {       /* one batch in flight */
 	eng_t *E; wtz_ctx_t *ctx; uint64_t seq;    /* ctx: the context of the candidate requests (= parts[0].ctx) */
 	uint32_t *bq; uint32_t nbq, capbq;         /* queries in dispatch order */
 	uint8_t *want;                              /* slot needs GPU work (not saturated when planned) */
@@ -169,6 +170,10 @@ typedef struct {       /* one batch in flight */
 	int holds_turn;
 	/* candidates of the NEXT batch, requested before this batch is committed (single worker, no -G) */
 	int pf_inflight; uint32_t *pf_ids; uint32_t pf_n, pf_cap; uint64_t *pf_rows; uint32_t *pf_nr; uint32_t pf_cursor_end;
+	/* batches pipelined like ranges (single worker, one process): while the LAST range of this batch is committed, `alt` - a second batch on the same
+	 * context(s) - has been formed from the prefetched candidates and runs its first range.  formed: batch_form() has run; started: its first range [0, start_s1) is
+	 * already on the device (start_job) */
+	struct batch_s *alt; int shares_ctx, formed, started; uint32_t start_s1; void *start_job;
 } batch_t;
 
 /* a device-stage failure ends the process at once: other host threads (index builders, parts) may still be inside HIP calls, and running the
@@ -1135,14 +1140,21 @@ static void *gpujob_main(void *arg){ gpujob_t *j = (gpujob_t*)arg; j->t0 = now_s
 static void gpujob_start(gpujob_t *j, eng_t *E, batch_t *b){ j->E = E; j->b = b; j->again = 0; if(pthread_create(&j->th, NULL, gpujob_main, j) != 0){ fprintf(stderr, " -- cannot start the device-stage thread --\n"); DIE_NOW(); } j->running = 1; }
 static int gpujob_wait(gpujob_t *j){ if(j->running){ pthread_join(j->th, NULL); j->running = 0; } return j->again; }
 #define SWAP_FIELD(T, a, b) do { T t_ = (a); (a) = (b); (b) = t_; } while(0)
+static int batch_form(batch_t *b);
 static void process_batch(eng_t *E, batch_t *b){
 	static int overlap = -1;
 	if(overlap < 0){ const char *e = getenv("WTZ_RANGE_OVERLAP"); overlap = e ? atoi(e) : 1; }
 	if(!overlap || E->n_workers != 1 || b->nbq == 0){ b->cparts = b->parts; process_batch_serial(E, b, 0); return; }
-	gpujob_t job; memset(&job, 0, sizeof job);
-	uint32_t s0 = 0, s1 = range_end(E, b, s0);
-	pthread_mutex_lock(&E->mu); plan_pairs(E, b, s0, s1); pthread_mutex_unlock(&E->mu);
-	gpujob_start(&job, E, b);
+	if(b->start_job == NULL) b->start_job = calloc(1, sizeof(gpujob_t));
+	gpujob_t *jobp = (gpujob_t*)b->start_job;
+#define job (*jobp)
+	uint32_t s0 = 0, s1;
+	if(b->started){ s1 = b->start_s1; b->started = 0; }      /* the batch before this one started our first range in front of its last commit */
+	else {
+		s1 = range_end(E, b, s0);
+		pthread_mutex_lock(&E->mu); plan_pairs(E, b, s0, s1); pthread_mutex_unlock(&E->mu);
+		gpujob_start(&job, E, b);
+	}
 	for(;;){
 		const int again = gpujob_wait(&job);
 		if(again){
@@ -1195,7 +1207,39 @@ static void process_batch(eng_t *E, batch_t *b){
 			n1 = range_end(E, b, n0);
 			pthread_mutex_lock(&E->mu); plan_pairs(E, b, n0, n1); pthread_mutex_unlock(&E->mu);
 			gpujob_start(&job, E, b);
-		} else if(!b->pf_inflight){ pthread_mutex_lock(&E->mu); prefetch_begin(E, b); pthread_mutex_unlock(&E->mu); }
+		} else {
+			if(!b->pf_inflight){ pthread_mutex_lock(&E->mu); prefetch_begin(E, b); pthread_mutex_unlock(&E->mu); }
+			batch_t *nb = b->alt;
+			/* ... unless this batch is still discovering masks at a high rate (the longest reads come first and contain many of the reads behind them): a batch formed
+			 * one range early would then hold queries the last commit is about to mask (E. coli shape: 6 790 queries planned for 3 017 used, 0.274 s per step against
+			 * 0.242).  The measure is the batch's own record so far: queries used of the slots committed before its last range (the batch before, for a one-range batch) */
+			static double min_used = -1.0; if(min_used < 0){ const char *e = getenv("WTZ_BATCH_OVERLAP_MIN_USED"); min_used = e ? atof(e) : 0.85; }
+			const double used_ratio = s0 >= 64 ? (double)b->used_queries / (double)s0 : E->last_used_ratio;
+			if(nb && b->pf_inflight && !nb->formed && used_ratio >= min_used){
+				/* batches pipelined like ranges: the next batch is formed NOW, from the candidates just requested and the masks / coverage as they are (one range older
+				 * than a batch formed after the commit below: whoever that commit masks or saturates is computed for nothing and dropped when its turn comes - the
+				 * same superset argument as for ranges), and its first range runs on the device while this batch's last range is committed */
+#define SWAP_PF(T, f) do { T t_ = b->f; b->f = nb->f; nb->f = t_; } while(0)
+				SWAP_PF(int, pf_inflight); SWAP_PF(uint32_t*, pf_ids); SWAP_PF(uint32_t, pf_n); SWAP_PF(uint32_t, pf_cap); SWAP_PF(uint64_t*, pf_rows); SWAP_PF(uint32_t*, pf_nr); SWAP_PF(uint32_t, pf_cursor_end);
+				for(uint32_t d = 0; d < b->nparts; d++){      /* several parts: the request's per-part arrays travel with it */
+					part_t *pa = &b->parts[d], *pn = &nb->parts[d];
+#define SWAP_CQ(T, f) do { T t_ = pa->f; pa->f = pn->f; pn->f = t_; } while(0)
+					SWAP_CQ(uint32_t*, cq_ids); SWAP_CQ(uint32_t*, cq_nr); SWAP_CQ(uint64_t*, cq_rows); SWAP_CQ(uint32_t, cq_cap); SWAP_CQ(uint32_t, cq_n);
+#undef SWAP_CQ
+				}
+#undef SWAP_PF
+				if(batch_form(nb)){
+					nb->formed = 1;
+					if(nb->nbq){
+						if(nb->start_job == NULL) nb->start_job = calloc(1, sizeof(gpujob_t));
+						nb->start_s1 = range_end(E, nb, 0);
+						pthread_mutex_lock(&E->mu); plan_pairs(E, nb, 0, nb->start_s1); pthread_mutex_unlock(&E->mu);
+						gpujob_start((gpujob_t*)nb->start_job, E, nb);
+						nb->started = 1;
+					}
+				}
+			}
+		}
 		for(uint32_t d = 0; d < b->nparts; d++) part_text_wait(&b->spare[d], &t_gpu_call[4]);      /* the finished range's text: its copy ran beside the planning above and the first kernels of the next range */
 		const double tc0 = now_s();
 		pthread_mutex_lock(&E->mu);
@@ -1218,6 +1262,7 @@ static void process_batch(eng_t *E, batch_t *b){
 		s0 = n0; s1 = n1;
 	}
 	b->cparts = b->parts;
+#undef job
 }
 
 /* both index builds of one more device (replicated indexes, --gpus) */
@@ -1315,93 +1360,104 @@ static void batch_zindex(eng_t *E, batch_t *b){
 	free(ql);
 }
 
+/* the next batch of queries (id order) with their candidate heaps (A3) and - where the z-mer index is per batch - its index; 0: no queries left */
+static int batch_form(batch_t *b){
+	eng_t *E = b->E;
+	/* ---- take the next batch of queries (id order) ---- */
+	pthread_mutex_lock(&E->mu);
+	if(E->cursor >= E->qend){ pthread_mutex_unlock(&E->mu); return 0; }
+	const uint32_t B = E->B;
+	const int use_pf = b->pf_inflight;
+	const uint32_t jend = use_pf ? b->pf_cursor_end : E->qend;      /* a prefetched batch covers exactly the reads the prefetch looked at */
+	const uint32_t need = use_pf ? (jend - E->cursor) + 1 : B + 1;  /* saturated reads of the range ride along without candidates */
+	if(need > b->capbq){ b->capbq = need; b->bq = (uint32_t*)hx_realloc(b->bq, 4 * (size_t)b->capbq); b->want = (uint8_t*)hx_realloc(b->want, b->capbq); b->ids = (uint32_t*)hx_realloc(b->ids, 4 * (size_t)b->capbq);
+		b->rows = (uint64_t*)hx_realloc(b->rows, (size_t)b->capbq * E->stride * 8); b->nrow = (uint32_t*)hx_realloc(b->nrow, 4 * (size_t)b->capbq); }
+	b->nbq = 0;
+	uint32_t j = E->cursor, nwant = 0;
+	for(; j < jend && (use_pf || b->nbq < B); j++){
+		if((j % E->n_job) != E->i_job) continue;
+		if(E->masked[j]) continue;
+		/* reads whose coverage is already saturated (wtzmo.c:808) need no GPU work but stay in the dispatch sequence:
+		 * their dispatch is what merges the previous query's masks (one-query masking lag) */
+		const int sat = E->rdcovs[j] >= nbest_of(E, j);
+		b->want[b->nbq] = (uint8_t)!sat; b->nrow[b->nbq] = 0;
+		if(!sat){
+			if(E->rows_all){ memcpy(b->rows + (size_t)b->nbq * E->stride, E->rows + (size_t)j * E->stride, (size_t)E->stride * 8); b->nrow[b->nbq] = E->nrow[j]; }
+			nwant++;
+		}
+		b->bq[b->nbq++] = j;
+	}
+	E->cursor = j;
+	b->seq = E->next_seq++; b->holds_turn = 0; b->spec_queries = b->nbq; b->used_queries = 0;
+	E->spec_queries += b->nbq; E->n_batches++;
+	if(E->B < E->max_batch) E->B = E->B * 4 > E->max_batch ? E->max_batch : E->B * 4;      /* ramp-up; corrected at commit */
+	pthread_mutex_unlock(&E->mu);
+	/* ---- candidate heaps of the batch's queries (A3) ---- */
+	if(use_pf){
+		const double tg0 = now_s();
+		int rc = WTZ_OK, cand_failed = -1;
+		if(E->shard) shard_candidates_end(E, b->pf_n, b->pf_rows, b->pf_nr);
+		else if(b->nparts == 1){ rc = wtz_candidates_end(b->ctx, b->pf_rows, b->pf_nr); DIE_WTZ(rc, "wtz_candidates_end"); }
+		else for(uint32_t d = 0; d < b->nparts; d++){
+			part_t *pt = &b->parts[d];
+			if(d == 0 && g_dist.world > 1){ wtz_dist_hdr_t h; memset(&h, 0, sizeof h); h.cmd = WTZ_CMD_CAND_END; g_dist.bcast(&h, sizeof h); }
+			if(pt->remote){
+				uint64_t st = 0; g_dist.recv(&st, 8, pt->remote);
+				if(st != WTZ_ST_OK){ if(cand_failed < 0) cand_failed = pt->remote; continue; }
+				if(pt->cq_n){ g_dist.recv(pt->cq_rows, (uint64_t)pt->cq_n * E->stride * 8, pt->remote); g_dist.recv(pt->cq_nr, 4 * (uint64_t)pt->cq_n, pt->remote); }
+			} else {
+				rc = wtz_candidates_end(pt->ctx, pt->cq_rows, pt->cq_nr);
+				if(rc != WTZ_OK && g_dist.world > 1){ fprintf(stderr, " -- rank 0: wtz_candidates_end failed: %s --\n", wtz_last_error()); if(cand_failed < 0) cand_failed = 0; continue; }
+				DIE_WTZ(rc, "wtz_candidates_end");
+			}
+			for(uint32_t k = 0; k < pt->cq_n; k++){ const size_t g = (size_t)k * b->nparts + d; memcpy(b->pf_rows + g * E->stride, pt->cq_rows + (size_t)k * E->stride, (size_t)E->stride * 8); b->pf_nr[g] = pt->cq_nr[k]; }
+		}
+		if(cand_failed >= 0){ char why[64]; snprintf(why, sizeof why, "rank %d failed in the seed lookup", cand_failed); ranks_abort(why); }
+		const double tg1 = now_s();
+		b->pf_inflight = 0;
+		uint32_t k = 0;
+		for(uint32_t s = 0; s < b->nbq; s++){
+			if(!b->want[s]) continue;
+			while(k < b->pf_n && b->pf_ids[k] < b->bq[s]) k++;
+			if(k >= b->pf_n || b->pf_ids[k] != b->bq[s]){ fprintf(stderr, " -- internal error: read %u has no prefetched candidates --\n", b->bq[s]); DIE_NOW(); }
+			memcpy(b->rows + (size_t)s * E->stride, b->pf_rows + (size_t)k * E->stride, (size_t)E->stride * 8); b->nrow[s] = b->pf_nr[k];
+		}
+		pthread_mutex_lock(&E->mu); E->t_gpu += tg1 - tg0; E->t_call[0] += tg1 - tg0; pthread_mutex_unlock(&E->mu);
+	} else if(nwant){
+		uint32_t n = 0;
+		for(uint32_t s = 0; s < b->nbq; s++) if(b->want[s]) b->ids[n++] = b->bq[s];
+		uint64_t *rows = (uint64_t*)hx_realloc(NULL, (size_t)n * E->stride * 8); uint32_t *nr = (uint32_t*)hx_realloc(NULL, 4 * (size_t)n);
+		n = 0;
+		for(uint32_t s = 0; s < b->nbq; s++) if(b->want[s]){ memcpy(rows + (size_t)n * E->stride, b->rows + (size_t)s * E->stride, (size_t)b->nrow[s] * 8); nr[n] = b->nrow[s]; n++; }
+		const double tg0 = now_s();
+		if(E->shard){ shard_candidates_begin(E, b->ids, n); shard_candidates_end(E, n, rows, nr); }
+		else { int rc = wtz_candidates(b->ctx, b->ids, n, rows, nr); DIE_WTZ(rc, "wtz_candidates"); }
+		const double tg1 = now_s();
+		n = 0;
+		for(uint32_t s = 0; s < b->nbq; s++) if(b->want[s]){ memcpy(b->rows + (size_t)s * E->stride, rows + (size_t)n * E->stride, (size_t)E->stride * 8); b->nrow[s] = nr[n]; n++; }
+		free(rows); free(nr);
+		pthread_mutex_lock(&E->mu); E->t_gpu += tg1 - tg0; E->t_call[0] += tg1 - tg0; pthread_mutex_unlock(&E->mu);
+	}
+	if(b->nbq && (E->zbatch > 0 || E->zsplit)) batch_zindex(E, b);
+	return 1;
+}
+
+static void process_batch(eng_t *E, batch_t *b);
 static void *worker_main(void *arg){
 	batch_t *b = (batch_t*)arg; eng_t *E = b->E;
 	for(;;){
-		/* ---- take the next batch of queries (id order) ---- */
-		pthread_mutex_lock(&E->mu);
-		if(E->cursor >= E->qend){ pthread_mutex_unlock(&E->mu); break; }
-		const uint32_t B = E->B;
-		const int use_pf = b->pf_inflight;
-		const uint32_t jend = use_pf ? b->pf_cursor_end : E->qend;      /* a prefetched batch covers exactly the reads the prefetch looked at */
-		const uint32_t need = use_pf ? (jend - E->cursor) + 1 : B + 1;  /* saturated reads of the range ride along without candidates */
-		if(need > b->capbq){ b->capbq = need; b->bq = (uint32_t*)hx_realloc(b->bq, 4 * (size_t)b->capbq); b->want = (uint8_t*)hx_realloc(b->want, b->capbq); b->ids = (uint32_t*)hx_realloc(b->ids, 4 * (size_t)b->capbq);
-			b->rows = (uint64_t*)hx_realloc(b->rows, (size_t)b->capbq * E->stride * 8); b->nrow = (uint32_t*)hx_realloc(b->nrow, 4 * (size_t)b->capbq); }
-		b->nbq = 0;
-		uint32_t j = E->cursor, nwant = 0;
-		for(; j < jend && (use_pf || b->nbq < B); j++){
-			if((j % E->n_job) != E->i_job) continue;
-			if(E->masked[j]) continue;
-			/* reads whose coverage is already saturated (wtzmo.c:808) need no GPU work but stay in the dispatch sequence:
-			 * their dispatch is what merges the previous query's masks (one-query masking lag) */
-			const int sat = E->rdcovs[j] >= nbest_of(E, j);
-			b->want[b->nbq] = (uint8_t)!sat; b->nrow[b->nbq] = 0;
-			if(!sat){
-				if(E->rows_all){ memcpy(b->rows + (size_t)b->nbq * E->stride, E->rows + (size_t)j * E->stride, (size_t)E->stride * 8); b->nrow[b->nbq] = E->nrow[j]; }
-				nwant++;
-			}
-			b->bq[b->nbq++] = j;
-		}
-		E->cursor = j;
-		b->seq = E->next_seq++; b->holds_turn = 0; b->spec_queries = b->nbq; b->used_queries = 0;
-		E->spec_queries += b->nbq; E->n_batches++;
-		if(E->B < E->max_batch) E->B = E->B * 4 > E->max_batch ? E->max_batch : E->B * 4;      /* ramp-up; corrected at commit */
-		pthread_mutex_unlock(&E->mu);
-		/* ---- candidate heaps of the batch's queries (A3) ---- */
-		if(use_pf){
-			const double tg0 = now_s();
-			int rc = WTZ_OK, cand_failed = -1;
-			if(E->shard) shard_candidates_end(E, b->pf_n, b->pf_rows, b->pf_nr);
-			else if(b->nparts == 1){ rc = wtz_candidates_end(b->ctx, b->pf_rows, b->pf_nr); DIE_WTZ(rc, "wtz_candidates_end"); }
-			else for(uint32_t d = 0; d < b->nparts; d++){
-				part_t *pt = &b->parts[d];
-				if(d == 0 && g_dist.world > 1){ wtz_dist_hdr_t h; memset(&h, 0, sizeof h); h.cmd = WTZ_CMD_CAND_END; g_dist.bcast(&h, sizeof h); }
-				if(pt->remote){
-					uint64_t st = 0; g_dist.recv(&st, 8, pt->remote);
-					if(st != WTZ_ST_OK){ if(cand_failed < 0) cand_failed = pt->remote; continue; }
-					if(pt->cq_n){ g_dist.recv(pt->cq_rows, (uint64_t)pt->cq_n * E->stride * 8, pt->remote); g_dist.recv(pt->cq_nr, 4 * (uint64_t)pt->cq_n, pt->remote); }
-				} else {
-					rc = wtz_candidates_end(pt->ctx, pt->cq_rows, pt->cq_nr);
-					if(rc != WTZ_OK && g_dist.world > 1){ fprintf(stderr, " -- rank 0: wtz_candidates_end failed: %s --\n", wtz_last_error()); if(cand_failed < 0) cand_failed = 0; continue; }
-					DIE_WTZ(rc, "wtz_candidates_end");
-				}
-				for(uint32_t k = 0; k < pt->cq_n; k++){ const size_t g = (size_t)k * b->nparts + d; memcpy(b->pf_rows + g * E->stride, pt->cq_rows + (size_t)k * E->stride, (size_t)E->stride * 8); b->pf_nr[g] = pt->cq_nr[k]; }
-			}
-			if(cand_failed >= 0){ char why[64]; snprintf(why, sizeof why, "rank %d failed in the seed lookup", cand_failed); ranks_abort(why); }
-			const double tg1 = now_s();
-			b->pf_inflight = 0;
-			uint32_t k = 0;
-			for(uint32_t s = 0; s < b->nbq; s++){
-				if(!b->want[s]) continue;
-				while(k < b->pf_n && b->pf_ids[k] < b->bq[s]) k++;
-				if(k >= b->pf_n || b->pf_ids[k] != b->bq[s]){ fprintf(stderr, " -- internal error: read %u has no prefetched candidates --\n", b->bq[s]); DIE_NOW(); }
-				memcpy(b->rows + (size_t)s * E->stride, b->pf_rows + (size_t)k * E->stride, (size_t)E->stride * 8); b->nrow[s] = b->pf_nr[k];
-			}
-			pthread_mutex_lock(&E->mu); E->t_gpu += tg1 - tg0; E->t_call[0] += tg1 - tg0; pthread_mutex_unlock(&E->mu);
-		} else if(nwant){
-			uint32_t n = 0;
-			for(uint32_t s = 0; s < b->nbq; s++) if(b->want[s]) b->ids[n++] = b->bq[s];
-			uint64_t *rows = (uint64_t*)hx_realloc(NULL, (size_t)n * E->stride * 8); uint32_t *nr = (uint32_t*)hx_realloc(NULL, 4 * (size_t)n);
-			n = 0;
-			for(uint32_t s = 0; s < b->nbq; s++) if(b->want[s]){ memcpy(rows + (size_t)n * E->stride, b->rows + (size_t)s * E->stride, (size_t)b->nrow[s] * 8); nr[n] = b->nrow[s]; n++; }
-			const double tg0 = now_s();
-			if(E->shard){ shard_candidates_begin(E, b->ids, n); shard_candidates_end(E, n, rows, nr); }
-			else { int rc = wtz_candidates(b->ctx, b->ids, n, rows, nr); DIE_WTZ(rc, "wtz_candidates"); }
-			const double tg1 = now_s();
-			n = 0;
-			for(uint32_t s = 0; s < b->nbq; s++) if(b->want[s]){ memcpy(b->rows + (size_t)s * E->stride, rows + (size_t)n * E->stride, (size_t)E->stride * 8); b->nrow[s] = nr[n]; n++; }
-			free(rows); free(nr);
-			pthread_mutex_lock(&E->mu); E->t_gpu += tg1 - tg0; E->t_call[0] += tg1 - tg0; pthread_mutex_unlock(&E->mu);
-		}
-		if(b->nbq && (E->zbatch > 0 || E->zsplit)) batch_zindex(E, b);
+		if(!b->formed && !batch_form(b)) break;       /* formed already: by the batch before it, in front of its last commit */
+		b->formed = 0;
 		if(b->nbq) process_batch(E, b);
 		/* ---- hand the turn to the next batch ---- */
 		pthread_mutex_lock(&E->mu);
 		while(!b->holds_turn && E->commit_seq != b->seq) pthread_cond_wait(&E->cv, &E->mu);
 		E->commit_seq = b->seq + 1;
 		if(b->used_queries * 2 < b->spec_queries && E->B > E->first_batch){ E->B /= 2; if(E->B < 8) E->B = 8; }   /* too much discarded work */
+		E->last_used_ratio = b->spec_queries ? (double)b->used_queries / (double)b->spec_queries : 0.0;
 		pthread_cond_broadcast(&E->cv);
 		pthread_mutex_unlock(&E->mu);
+		if(b->alt && b->alt->formed) b = b->alt;      /* formed (and started) in front of this batch's last commit */
 	}
 	return NULL;
 }
@@ -1796,10 +1852,14 @@ int main(int argc, char **argv){
 				uint32_t nq = 0; for(uint32_t j = qbeg; j < E->qend; j++) if((j % E->n_job) == E->i_job) nq++;
 				if(nq <= E->max_batch) E->B = E->max_batch;
 			}
-			E->next_seq = 0; E->commit_seq = 0;
+			E->next_seq = 0; E->commit_seq = 0; E->last_used_ratio = 0.0;
 			uint32_t nw = E->rows_all ? 1 : E->n_workers;          /* -G keeps per-read heaps that the commit rewrites: one batch at a time */
+			/* one worker, one process: a SECOND batch on the same context(s), formed and started in front of the first one's last commit (process_batch);
+			 * WTZ_BATCH_OVERLAP=0 / WTZ_RANGE_OVERLAP=0 keep one batch at a time */
+			const int nalt = (nw == 1 && g_dist.world == 1 && !E->rows_all && !(getenv("WTZ_BATCH_OVERLAP") && !atoi(getenv("WTZ_BATCH_OVERLAP"))) && !(getenv("WTZ_RANGE_OVERLAP") && !atoi(getenv("WTZ_RANGE_OVERLAP")))) ? 1 : 0;
+			const uint32_t nw_run = nw; nw += (uint32_t)nalt;
 			batch_t *bs = (batch_t*)calloc(nw, sizeof(batch_t)); pthread_t *th = (pthread_t*)calloc(nw, sizeof(pthread_t));
-			const uint32_t nparts = g_dist.world > 1 ? (uint32_t)g_dist.world : (nw == 1 ? E->ndev : 1);
+			const uint32_t nparts = g_dist.world > 1 ? (uint32_t)g_dist.world : (nw_run == 1 ? E->ndev : 1);
 			for(uint32_t w = 0; w < nw; w++){
 				bs[w].E = E;
 				bs[w].nparts = nparts; bs[w].parts = (part_t*)calloc(nparts, sizeof(part_t)); bs[w].spare = (part_t*)calloc(nparts, sizeof(part_t)); bs[w].cparts = bs[w].parts;
@@ -1808,25 +1868,26 @@ int main(int argc, char **argv){
 					pt->ext_base = slot < 8 ? (int)slot * 2 : -1;
 					if(slot < 8) for(int k = 0; k < 2; k++){ pt->cigs[k] = E->cig_keep[slot * 2 + k]; pt->capcigs[k] = E->cig_keep_cap[slot * 2 + k]; E->cig_keep[slot * 2 + k] = NULL; E->cig_keep_cap[slot * 2 + k] = 0; }
 					if(g_dist.world > 1){ pt->remote = (int)d; pt->ctx = d == 0 ? E->ctx : NULL; }       /* part r belongs to rank r */
-					else if(w == 0) pt->ctx = E->ctxs[d];
+					else if(w == 0 || (nalt && w == 1)) pt->ctx = E->ctxs[d];       /* the alternate batch runs on the same contexts, never at the same time */
 					else { rc = wtz_ctx_clone(E->ctx, pool_bytes, &pt->ctx); DIE_WTZ(rc, "wtz_ctx_clone"); }
 				}
 				bs[w].ctx = bs[w].parts[0].ctx;
 			}
+			if(nalt){ bs[0].alt = &bs[1]; bs[1].alt = &bs[0]; bs[1].shares_ctx = 1; }
 			if(g_dist.rank > 0){
 				/* this rank serves rank 0's requests with its GPU; plan, commit and output are rank 0's */
 				part_t *me = &bs[0].parts[0]; me->ctx = E->ctx; me->remote = 0; me->ext_base = -1;
 				remote_loop(E, me);
 			} else {
-				for(uint32_t w = 1; w < nw; w++) pthread_create(&th[w], NULL, worker_main, &bs[w]);
+				for(uint32_t w = 1; w < nw_run; w++) pthread_create(&th[w], NULL, worker_main, &bs[w]);
 				worker_main(&bs[0]);
-				for(uint32_t w = 1; w < nw; w++) pthread_join(th[w], NULL);
+				for(uint32_t w = 1; w < nw_run; w++) pthread_join(th[w], NULL);
 				if(g_dist.world > 1){ wtz_dist_hdr_t h; memset(&h, 0, sizeof h); h.cmd = WTZ_CMD_DONE; g_dist.bcast(&h, sizeof h); }
 			}
 			for(uint32_t w = 0; w < nw; w++){
 				for(uint32_t d = 0; d < nparts; d++){
 					part_t *pt = &bs[w].parts[d]; const uint32_t slot = w * nparts + d;
-					if((w || d) && pt->ctx){      /* counters of the other contexts: work adds up, kernel times of parallel devices do not (the longest counts) */
+					if((w || d) && pt->ctx && !bs[w].shares_ctx){      /* counters of the other contexts: work adds up, kernel times of parallel devices do not (the longest counts) */
 						wtz_counters_t cw; wtz_get_counters(pt->ctx, &cw);
 						if(w){ E->extra_ms[0] += cw.ms_candidates; E->extra_ms[1] += cw.ms_pairs; E->extra_ms[2] += cw.ms_winalign; E->extra_ms[3] += cw.ms_stitch; E->extra_ms[4] += cw.ms_ext; E->extra_ms[5] += cw.ms_gap; }
 						E->extra_u64[0] += cw.cells_shift; E->extra_u64[1] += cw.cells_fixed; E->extra_u64[2] += cw.cells_global; E->extra_u64[3] += cw.bytes_seed_algo; E->extra_u64[4] += cw.n_extjobs; E->extra_u64[6] += cw.bytes_zmer_algo;
@@ -1839,7 +1900,7 @@ int main(int argc, char **argv){
 				}
 				for(uint32_t d = 0; d < nparts; d++){ part_t *sp = &bs[w].spare[d]; free(sp->sum); free(sp->box_off); free(sp->boxes); free(sp->item_of); free(sp->it_pair); free(sp->it_dir); free(sp->aln); }
 				free(bs[w].spare);
-				free(bs[w].parts);
+				free(bs[w].parts); free(bs[w].start_job);
 				free(bs[w].bq); free(bs[w].want); free(bs[w].ids); free(bs[w].rows); free(bs[w].nrow); free(bs[w].rowpair); free(bs[w].pf_ids); free(bs[w].pf_rows); free(bs[w].pf_nr);
 			}
 			free(bs); free(th);

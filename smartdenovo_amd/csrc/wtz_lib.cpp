@@ -1571,17 +1571,26 @@ static int run_stitch_fused(wtz_ctx *c, const wtz_env_t &V, const wtz_alnitem_t 
 	/* acc sums UPPER bounds (every job run to its last row); the traces are allocated 64 rows at a time as a job runs, and most jobs end early: what the launches
 	 * before this one took of their bounds (x 1.3, never below a fifth) is what this one is expected to take.  An estimate that was too low ends in WTZ_E_POOL like
 	 * any other exhausted pool: the host redoes the range in halves. */
-	if((double)acc * c->ext_use_ratio > (double)budget){ if(c->env_profile) fprintf(stderr, "[ext-profile] fused launch declined: %u items, trace bounds %.1f GB x %.2f against %.1f GB\n", m, acc / 1e9, c->ext_use_ratio, budget / 1e9); return WTZ_OK; }          /* the two launches cut their jobs into groups that fit */
-	CHK(tpool_reset(c));
-	wtz_timer te; te.start();
-	hipLaunchKernelGGL((wtz_kernel_stitch_ext_fr<1032>), dim3(m), dim3(64), WTZ_WAVE_LDS_BYTES, g_stream, V, d_items, d_st, d_jl, d_jr, d_gaps, (const uint32_t*)d_order, m);
-	HIPCHK(hipGetLastError());
-	const double ms_l = te.stop();
+	/* what does not fit at once runs in up to four groups (every ng-th item of the order each: all groups are ordered longest-first), the transient pool reset between them */
+	uint32_t ng = 1; while(ng < 4 && (double)acc * c->ext_use_ratio / ng > (double)budget) ng++;
+	if((double)acc * c->ext_use_ratio / ng > (double)budget){ if(c->env_profile) fprintf(stderr, "[ext-profile] fused launch declined: %u items, trace bounds %.1f GB x %.2f against %.1f GB\n", m, acc / 1e9, c->ext_use_ratio, budget / 1e9); return WTZ_OK; }          /* the two launches cut their jobs into groups that fit */
+	double ms_l = 0; uint64_t used_sum = 0;
+	for(uint32_t g = 0; g < ng; g++){
+		const uint32_t mg = (m - g + ng - 1) / ng;
+		if(mg == 0) continue;
+		CHK(tpool_reset(c));
+		wtz_timer te; te.start();
+		hipLaunchKernelGGL((wtz_kernel_stitch_ext_fr<1032>), dim3(mg), dim3(64), WTZ_WAVE_LDS_BYTES, g_stream, V, d_items, d_st, d_jl, d_jr, d_gaps, (const uint32_t*)d_order, mg, ng, g);
+		HIPCHK(hipGetLastError());
+		ms_l += te.stop();
+		CHK(tpool_check(c, "K-sw3 extension jobs (both ends on one wavefront)"));
+		used_sum += c->tpool_last_used;
+	}
 	c->cnt.ms_ext += ms_l; c->cnt.n_extjobs += 2ull * m;
 	c->fused_ran = true;
-	if(c->env_profile) fprintf(stderr, "[ext-profile] fused launch: %u items, rows (upper bound) sum %llu, %.2f ms\n", m, ext_sum, ms_l);
+	if(c->env_profile) fprintf(stderr, "[ext-profile] fused launch: %u items in %u group(s), rows (upper bound) sum %llu, %.2f ms\n", m, ng, ext_sum, ms_l);
+	c->tpool_last_used = used_sum;
 	dev_free(d_order);
-	CHK(tpool_check(c, "K-sw3 extension jobs (both ends on one wavefront)"));
 	if(acc){ const double seen = 1.3 * (double)c->tpool_last_used / (double)acc, keep = c->ext_use_ratio * 0.9; c->ext_use_ratio = seen > keep ? seen : keep; if(c->ext_use_ratio < 0.2) c->ext_use_ratio = 0.2; if(c->ext_use_ratio > 1.0) c->ext_use_ratio = 1.0; }
 	return WTZ_OK;
 }
@@ -1893,7 +1902,7 @@ extern "C" int wtz_pairs_align(wtz_ctx_t *c, const uint32_t *pair_idx, const uin
 	const bool prof_wall = c->env_profile; double tw[6] = {0, 0, 0, 0, 0, 0}; double tw0 = prof_wall ? wtz_wall() : 0;
 	auto lapw = [&](int k){ if(prof_wall){ const double t = wtz_wall(); tw[k] += t - tw0; tw0 = t; } };
 	CHK(reserve_items(c, m));
-	std::vector<wtz_alnitem_t> items(m); std::vector<wtz_wintask_t> wt; uint64_t nreg = 0;
+	std::vector<wtz_alnitem_t> items(m); uint64_t nreg = 0;      /* the window tasks (item, window) are listed on the device: one per region slot, in slot order */
 	std::vector<uint32_t> h_q(c->n_pairs), h_c(c->n_pairs);
 	CHK(dev_d2h(h_q.data(), c->d_qid, (size_t)c->n_pairs * 4)); CHK(dev_d2h(h_c.data(), c->d_cid, (size_t)c->n_pairs * 4));
 	for(uint32_t i = 0; i < m; i++){
@@ -1901,21 +1910,22 @@ extern "C" int wtz_pairs_align(wtz_ctx_t *c, const uint32_t *pair_idx, const uin
 		const wtz_pairres_t &r = c->h_pairres[pair_idx[i]];
 		wtz_alnitem_t it; it.q = h_q[pair_idx[i]]; it.c = h_c[pair_idx[i]]; it.dir = dir[i];
 		it.win = r.win[dir[i]]; it.anchors = r.anchors[dir[i]]; it.nwin = r.nwin[dir[i]]; it.regs = (wtz_reg_t*)(uintptr_t)nreg;
-		for(uint32_t k = 0; k < it.nwin; k++){ wtz_wintask_t w; w.item = i; w.widx = k; wt.push_back(w); }
 		nreg += it.nwin; items[i] = it;
 	}
 	wtz_reg_t *d_regs = NULL, *d_regs_chk = NULL; wtz_alnitem_t *d_items = NULL; wtz_wintask_t *d_wt = NULL;
 	CHK(dev_alloc((void**)&d_regs, (size_t)(nreg + 1) * sizeof(wtz_reg_t)));
 	for(uint32_t i = 0; i < m; i++) items[i].regs = d_regs + (uintptr_t)items[i].regs;
 	CHK(dev_alloc((void**)&d_items, (size_t)m * sizeof(wtz_alnitem_t))); CHK(dev_h2d(d_items, items.data(), (size_t)m * sizeof(wtz_alnitem_t)));
-	CHK(dev_alloc((void**)&d_wt, (wt.size() + 1) * sizeof(wtz_wintask_t))); CHK(dev_h2d(d_wt, wt.data(), wt.size() * sizeof(wtz_wintask_t)));
+	CHK(dev_alloc((void**)&d_wt, (size_t)(nreg + 1) * sizeof(wtz_wintask_t)));
+	{ const wtz_alnitem_t *di = d_items; wtz_wintask_t *dw = d_wt; const wtz_reg_t *r0 = d_regs;
+	  CHK(wtz_launch<K_misc>(0, m, [=] WTZ_LAMBDA (uint64_t i){ const wtz_alnitem_t &it = di[i]; wtz_wintask_t *w = dw + (it.regs - r0); for(uint32_t k = 0; k < it.nwin; k++){ w[k].item = (uint32_t)i; w[k].widx = k; } })); }
 	const wtz_env_t V = ctx_env(c); wtz_alnres_dev_t *d_res = c->d_alnres;
 	lapw(0);
 	wtz_timer tm; tm.start();
 	bool lane_done = false;
 	if(c->env_lane && !c->env_grp4){
 		/* one lane per K-sw1 problem (wtz_sw_lane.h); what it leaves (d_fb) goes through the chained kernel below */
-		const uint64_t nwt0 = wt.size();
+		const uint64_t nwt0 = (size_t)nreg;
 		uint32_t *d_fb = NULL, n_fb = 0;
 		CHK(dev_alloc((void**)&d_fb, (nwt0 + 1) * 4));
 		STAGE(c, "K-sw1 lane pipeline");
@@ -1936,13 +1946,13 @@ extern "C" int wtz_pairs_align(wtz_ctx_t *c, const uint32_t *pair_idx, const uin
 		if(c->env_lane == 2){ CHK(dev_sync()); CHK(dev_alloc((void**)&d_regs_chk, (size_t)(nreg + 1) * sizeof(wtz_reg_t))); CHK(dev_d2d(d_regs_chk, d_regs, (size_t)nreg * sizeof(wtz_reg_t))); }
 	}
 #ifdef WTZ_EMUL
-	if(!lane_done) CHK(wtz_launch_coop<K_winalign>(0, wt.size(), [=] WTZ_LAMBDA (uint64_t t){ wtz_task_winalign((uint32_t)t, V, d_wt, d_items); }, WTZ_WINALIGN_LDS_BYTES + WTZ_WINALIGN_QW_BYTES));
+	if(!lane_done) CHK(wtz_launch_coop<K_winalign>(0, (size_t)nreg, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_winalign((uint32_t)t, V, d_wt, d_items); }, WTZ_WINALIGN_LDS_BYTES + WTZ_WINALIGN_QW_BYTES));
 #else
 	if(!lane_done){
 		/* first launch: FOUR windows per wavefront (one per 16-lane group, wtz_sw_grp.h); a window with a problem outside the group form's
 		 * envelope queues itself for the one-window-per-wave kernel: its lean form first (register DP with one / two band columns per lane,
 		 * no scalar body: fewer VGPRs), then - for what that form defers in turn - the full task */
-		const uint64_t nwt0 = wt.size();
+		const uint64_t nwt0 = (size_t)nreg;
 		uint32_t *d_defer4 = NULL, *d_defer = NULL;
 		CHK(dev_alloc((void**)&d_defer4, (nwt0 + 1) * 4)); CHK(dev_set(d_defer4, 0, 4));
 		CHK(dev_alloc((void**)&d_defer, (nwt0 + 1) * 4)); CHK(dev_set(d_defer, 0, 4));
@@ -1957,7 +1967,7 @@ extern "C" int wtz_pairs_align(wtz_ctx_t *c, const uint32_t *pair_idx, const uin
 		}
 		CHK(dev_d2h(&n_def, d_defer, 4));
 		if(n_def) CHK(wtz_launch_coop<K_winalign_big>(0, n_def, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_winalign<true>((uint32_t)t, V, d_wt, d_items, NULL, d_defer); }, WTZ_WINALIGN_LDS_BYTES + WTZ_WINALIGN_QW_BYTES));
-		if(c->env_profile) fprintf(stderr, "[winalign-profile] %zu windows, %u left by the four-per-wave form, %u redone by the full task\n", wt.size(), n_def4, n_def);
+		if(c->env_profile) fprintf(stderr, "[winalign-profile] %zu windows, %u left by the four-per-wave form, %u redone by the full task\n", (size_t)nreg, n_def4, n_def);
 		dev_free(d_defer4);
 		dev_free(d_defer);
 	}
@@ -1981,7 +1991,7 @@ extern "C" int wtz_pairs_align(wtz_ctx_t *c, const uint32_t *pair_idx, const uin
 		}
 		dev_free(d_regs_chk);
 	}
-	c->cnt.ms_winalign += tm.stop(); c->cnt.n_winalign += wt.size();
+	c->cnt.ms_winalign += tm.stop(); c->cnt.n_winalign += (size_t)nreg;
 	lapw(1);
 	tm.start();
 	{
@@ -1989,7 +1999,7 @@ extern "C" int wtz_pairs_align(wtz_ctx_t *c, const uint32_t *pair_idx, const uin
 		CHK(dev_alloc((void**)&d_st, (size_t)m * sizeof(wtz_stitch_state_t)));
 		CHK(dev_alloc((void**)&d_jl, (size_t)m * sizeof(wtz_extjob_t))); CHK(dev_alloc((void**)&d_jr, (size_t)m * sizeof(wtz_extjob_t)));
 		wtz_gapres_t *d_gaps = NULL; CHK(dev_alloc((void**)&d_gaps, (size_t)(nreg + 1) * sizeof(wtz_gapres_t)));
-		const uint64_t nwt = wt.size();
+		const uint64_t nwt = (size_t)nreg;
 		STAGE(c, "K_stitch_left");
 		int32_t *d_rgeo = NULL;
 #ifndef WTZ_EMUL

@@ -31,10 +31,10 @@ __device__ __attribute__((noinline)) void wtz_stitch_mid_call(uint32_t t, const 
 }
 template<int TW>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WTZ_OCC_EXTFR, 8))) wtz_kernel_stitch_ext_fr(const wtz_env_t V, const wtz_alnitem_t *items, wtz_stitch_state_t *sts,
-		wtz_extjob_t *jobsL, wtz_extjob_t *jobsR, const wtz_gapres_t *gaps, const uint32_t *order, uint32_t n){
+		wtz_extjob_t *jobsL, wtz_extjob_t *jobsR, const wtz_gapres_t *gaps, const uint32_t *order, uint32_t n, uint32_t stride, uint32_t first){
 	const uint32_t b = blockIdx.x;
 	if(b >= n) return;
-	const uint32_t t = order[b];
+	const uint32_t t = order[(size_t)b * stride + first];      /* group `first` of `stride`: every stride-th item of the order, so that each group is ordered longest-first too */
 	#pragma nounroll
 	for(int side = 0; side < 2; side++){
 		if(side){
