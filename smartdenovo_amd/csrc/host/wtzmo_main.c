@@ -100,7 +100,8 @@ typedef struct eng_s {
 	double t_cq[4];             /* commit_query sections: candidate rows + closed filter + sort | window depth + seed weights + sort | hits (gates, queueing, masking) | plan_pairs */
 	double t_gpu, t_commit, t_zbatch, t_call[6], t_io[2];      /* t_io: waiting for the writer thread before a text buffer is reused / at the end of the run */      /* t_call: wall seconds inside wtz_candidates / pairs_seed / pairs_windows / pairs_align / fetch_cigar_text / planning */
 	uint64_t spec_pairs, used_pairs, spec_items, used_items, spec_queries, used_queries, n_batches;
-	double last_used_ratio;      /* queries used / planned of the batch that finished last (process_batch: may the next batch be formed in front of the last commit?) */
+	uint64_t n_masked;           /* reads masked by commits of this step (flush_pending) */
+	double last_mask_rate;       /* new masks per used query of the batch that finished last (process_batch: may the next batch be formed in front of the last commit?) */
 	double extra_ms[6]; uint64_t extra_u64[7];      /* counters of the cloned contexts */
 } eng_t;
 
@@ -173,7 +174,7 @@ typedef struct batch_s {       /* one batch in flight */
 	/* batches pipelined like ranges (single worker, one process): while the LAST range of this batch is committed, `alt` - a second batch on the same
 	 * context(s) - has been formed from the prefetched candidates and runs its first range.  formed: batch_form() has run; started: its first range [0, start_s1) is
 	 * already on the device (start_job) */
-	struct batch_s *alt; int shares_ctx, formed, started; uint32_t start_s1; void *start_job;
+	struct batch_s *alt; int shares_ctx, formed, started; uint32_t start_s1; void *start_job; uint64_t masked_at_form;
 } batch_t;
 
 /* a device-stage failure ends the process at once: other host threads (index builders, parts) may still be inside HIP calls, and running the
@@ -418,7 +419,7 @@ static void flush_pending(eng_t *E){
 		}
 	}
 	p->nhit = 0; p->nseed = 0;
-	for(size_t i = 0; i < p->nmask; i++) E->masked[p->masks[i]] = 1;
+	for(size_t i = 0; i < p->nmask; i++){ if(!E->masked[p->masks[i]]) E->n_masked++; E->masked[p->masks[i]] = 1; }
 	p->nmask = 0;
 	for(size_t i = 0; i < p->nclosed; i++){
 		if(hx_set_put(&E->closed, p->closed[i])){
@@ -1210,15 +1211,20 @@ static void process_batch(eng_t *E, batch_t *b){
 		} else {
 			if(!b->pf_inflight){ pthread_mutex_lock(&E->mu); prefetch_begin(E, b); pthread_mutex_unlock(&E->mu); }
 			batch_t *nb = b->alt;
-			/* ... unless this batch is still discovering masks at a high rate (the longest reads come first and contain many of the reads behind them): a batch formed
-			 * one range early would then hold queries the last commit is about to mask (E. coli shape: 6 790 queries planned for 3 017 used, 0.274 s per step against
-			 * 0.242).  The measure is the batch's own record so far: queries used of the slots committed before its last range (the batch before, for a one-range batch) */
-			static double min_used = -1.0; if(min_used < 0){ const char *e = getenv("WTZ_BATCH_OVERLAP_MIN_USED"); min_used = e ? atof(e) : 0.85; }
-			const double used_ratio = s0 >= 64 ? (double)b->used_queries / (double)s0 : E->last_used_ratio;
-			if(nb && b->pf_inflight && !nb->formed && used_ratio >= min_used){
-				/* batches pipelined like ranges: the next batch is formed NOW, from the candidates just requested and the masks / coverage as they are (one range older
-				 * than a batch formed after the commit below: whoever that commit masks or saturates is computed for nothing and dropped when its turn comes - the
-				 * same superset argument as for ranges), and its first range runs on the device while this batch's last range is committed */
+			/* ... where that pays.  The commit about to run masks reads (the longest reads come first and contain many of the reads behind them), and whatever it masks
+			 * inside the range started early was computed for nothing: E. coli shape with every boundary overlapped 6 790 queries planned for 3 017 used, 0.274 s per step
+			 * against 0.242; configs[2] 1.81 s against 1.85.  So the next batch is FORMED here (its candidates are known: that is what the estimate needs; a slot masked
+			 * later is skipped when its range is planned) and its first range is STARTED here only if
+			 *     expected waste = share of the reads to come that the commit will mask (new masks per used query of this batch so far x the queries of its last range /
+			 *                      the unmasked reads to come, at most 1) x the pairs of that first range x the step's device time per planned pair
+			 *  <= what is hidden  = the queries of the last range x the step's commit time per used query (+ 3 ms of forming and planning).
+			 * WTZ_BATCH_OVERLAP_GAIN scales the right side (default 1; 0 = never start early, 1e9 = always) */
+			static double gain = -1.0; if(gain < 0){ const char *e = getenv("WTZ_BATCH_OVERLAP_GAIN"); gain = e ? atof(e) : 1.0; }
+			if(nb && b->pf_inflight && !nb->formed && gain > 0){
+				const double rate = (s0 >= 64 && b->used_queries >= 32) ? (double)(E->n_masked - b->masked_at_form) / (double)b->used_queries : E->last_mask_rate;
+				uint64_t left = 0; for(uint32_t j = E->cursor; j < E->qend; j++) left += !E->masked[j];
+				uint32_t n_last = 0; for(uint32_t s = s0; s < s1; s++) n_last += (b->want[s] && !E->masked[b->bq[s]]);
+				double waste = rate < 0 ? 1.0 : rate * (double)n_last / (double)(left ? left : 1); if(waste > 1.0) waste = 1.0;
 #define SWAP_PF(T, f) do { T t_ = b->f; b->f = nb->f; nb->f = t_; } while(0)
 				SWAP_PF(int, pf_inflight); SWAP_PF(uint32_t*, pf_ids); SWAP_PF(uint32_t, pf_n); SWAP_PF(uint32_t, pf_cap); SWAP_PF(uint64_t*, pf_rows); SWAP_PF(uint32_t*, pf_nr); SWAP_PF(uint32_t, pf_cursor_end);
 				for(uint32_t d = 0; d < b->nparts; d++){      /* several parts: the request's per-part arrays travel with it */
@@ -1231,11 +1237,22 @@ static void process_batch(eng_t *E, batch_t *b){
 				if(batch_form(nb)){
 					nb->formed = 1;
 					if(nb->nbq){
-						if(nb->start_job == NULL) nb->start_job = calloc(1, sizeof(gpujob_t));
-						nb->start_s1 = range_end(E, nb, 0);
-						pthread_mutex_lock(&E->mu); plan_pairs(E, nb, 0, nb->start_s1); pthread_mutex_unlock(&E->mu);
-						gpujob_start((gpujob_t*)nb->start_job, E, nb);
-						nb->started = 1;
+						const uint32_t s1n = range_end(E, nb, 0);
+						uint64_t rows = 0; for(uint32_t s = 0; s < s1n; s++) rows += nb->want[s] ? nb->nrow[s] : 0;
+						pthread_mutex_lock(&E->mu);
+						const double per_pair = E->spec_pairs ? E->t_gpu / (double)E->spec_pairs : -1.0, per_commit = E->used_queries ? E->t_commit / (double)E->used_queries : 0.0;
+						pthread_mutex_unlock(&E->mu);
+						const double cost = per_pair < 0 ? 1e30 : waste * (double)rows * per_pair, hidden = (double)n_last * per_commit + 0.003;
+						const int early = gain >= 1e8 || cost <= gain * hidden;
+						if(getenv("WTZ_BATCH_OVERLAP_TRACE")) fprintf(stderr, "[batch-overlap] batch %llu: %.2f new masks per used query, last range %u queries, %llu unmasked reads to come: share masked %.3f; first range of the next batch %llu pairs: expected waste %.1f ms against %.1f ms hidden -> %s\n",
+							(unsigned long long)b->seq, rate, n_last, (unsigned long long)left, waste, (unsigned long long)rows, cost < 1e29 ? cost * 1e3 : -1.0, hidden * 1e3, early ? "started early" : "formed only");
+						if(early){
+							if(nb->start_job == NULL) nb->start_job = calloc(1, sizeof(gpujob_t));
+							nb->start_s1 = s1n;
+							pthread_mutex_lock(&E->mu); plan_pairs(E, nb, 0, nb->start_s1); pthread_mutex_unlock(&E->mu);
+							gpujob_start((gpujob_t*)nb->start_job, E, nb);
+							nb->started = 1;
+						}
 					}
 				}
 			}
@@ -1388,7 +1405,7 @@ static int batch_form(batch_t *b){
 		b->bq[b->nbq++] = j;
 	}
 	E->cursor = j;
-	b->seq = E->next_seq++; b->holds_turn = 0; b->spec_queries = b->nbq; b->used_queries = 0;
+	b->seq = E->next_seq++; b->holds_turn = 0; b->spec_queries = b->nbq; b->used_queries = 0; b->masked_at_form = E->n_masked;
 	E->spec_queries += b->nbq; E->n_batches++;
 	if(E->B < E->max_batch) E->B = E->B * 4 > E->max_batch ? E->max_batch : E->B * 4;      /* ramp-up; corrected at commit */
 	pthread_mutex_unlock(&E->mu);
@@ -1454,7 +1471,7 @@ static void *worker_main(void *arg){
 		while(!b->holds_turn && E->commit_seq != b->seq) pthread_cond_wait(&E->cv, &E->mu);
 		E->commit_seq = b->seq + 1;
 		if(b->used_queries * 2 < b->spec_queries && E->B > E->first_batch){ E->B /= 2; if(E->B < 8) E->B = 8; }   /* too much discarded work */
-		E->last_used_ratio = b->spec_queries ? (double)b->used_queries / (double)b->spec_queries : 0.0;
+		E->last_mask_rate = b->used_queries ? (double)(E->n_masked - b->masked_at_form) / (double)b->used_queries : -1.0;
 		pthread_cond_broadcast(&E->cv);
 		pthread_mutex_unlock(&E->mu);
 		if(b->alt && b->alt->formed) b = b->alt;      /* formed (and started) in front of this batch's last commit */
@@ -1852,7 +1869,7 @@ int main(int argc, char **argv){
 				uint32_t nq = 0; for(uint32_t j = qbeg; j < E->qend; j++) if((j % E->n_job) == E->i_job) nq++;
 				if(nq <= E->max_batch) E->B = E->max_batch;
 			}
-			E->next_seq = 0; E->commit_seq = 0; E->last_used_ratio = 0.0;
+			E->next_seq = 0; E->commit_seq = 0; E->last_mask_rate = -1.0; E->n_masked = 0;
 			uint32_t nw = E->rows_all ? 1 : E->n_workers;          /* -G keeps per-read heaps that the commit rewrites: one batch at a time */
 			/* one worker, one process: a SECOND batch on the same context(s), formed and started in front of the first one's last commit (process_batch);
 			 * WTZ_BATCH_OVERLAP=0 / WTZ_RANGE_OVERLAP=0 keep one batch at a time */

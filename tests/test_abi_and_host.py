@@ -62,6 +62,18 @@ def test_host_logic_on_emulated_device(name, emul_exe, tmp_path):
     assert md5 == case["md5_full"] and cont == case["md5_contained"]
 
 
+@pytest.mark.parametrize("name", ["zmo", "dmo", "zmo_B2", "zmo_L", "zmo_9", "zmo_n"])
+@pytest.mark.parametrize("gain", ["1e9", "0"])
+def test_batches_pipelined_or_one_at_a_time(name, gain, emul_exe, tmp_path, monkeypatch):
+    """Round 5: the next batch is formed (from the prefetched candidates and the masks as they are) in front of the last commit of the batch before it and its first range
+    runs meanwhile - where the work that commit is expected to mask costs less than the wait it hides.  Forced on at every boundary (WTZ_BATCH_OVERLAP_GAIN=1e9) and off everywhere (0) with
+    batches of 7 queries: the same bytes as the reference, incl. the order of the -9 pair file."""
+    monkeypatch.setenv("WTZ_BATCH_OVERLAP_GAIN", gain)
+    case = manifest()["cases"][name]
+    md5, cont, _ = run_wtzmo_like(emul_exe, case, tmp_path, extra=["--batch", "7"], exact_pairs=True)
+    assert md5 == case["md5_full"] and cont == case["md5_contained"]
+
+
 def test_repeat_rich_window_scans_on_the_pool_workspace(emul_exe, oracle_exe, tmp_path):
     """Tandem arrays + dispersed repeats: thousands of matches of one strand inside one 800-column window - scans that do not fit the wave's LDS slice and run the
     wave-parallel body on a workspace in the pool (3 405 such scans on this input, up to 3 640 matches).  Output == the oracle's."""

@@ -162,6 +162,8 @@ FORMS = [
     {"WTZ_CAND_WG": "0"},                             # seed lookup: wave per query, whole-query sort
     {"WTZ_CAND_STREAM": "1", "WTZ_CAND_WG": "0"},     # seed lookup: sort-free accumulation
     {"WTZ_RANGE_OVERLAP": "0"},                       # host: strict plan -> compute -> commit order
+    {"WTZ_BATCH_OVERLAP": "0"},                       # host: one batch at a time (ranges still pipelined)
+    {"WTZ_BATCH_OVERLAP_GAIN": "1e9"},              # host: every batch formed in front of the commit before it, whatever the mask rate
     {"WTZ_EXT_SPLIT": "2"},                           # K-sw3: one launch per band class
     {"WTZ_EXT_SPLIT": "2", "WTZ_EXT_MW_CW": "8"},     # ... and every band wider than 8 columns per lane on four waves
     {"WTZ_XCD_GROUP": "0"},                           # K_pair: identity block -> pair mapping
