@@ -345,8 +345,8 @@ def main():
                    "scratch": "%d batch ranges planned to the pool, %d split after a pool overflow" % (n_ranges, n_split)},
         "pairs_per_step": n_pairs // K, "pair_bp_per_step": pair_bp // K, "records_last_step": int(last[14]),
         "kernel_ms_last_step": dict(ms, ksw3_wave=ms_ext, ksw2_gap=ms_gap),
-        "roofline": valu_roofline("K-sw3 shifting-band extension (kswx_extend_align_shift_core), DP rows in registers in the anti-diagonal frame: wtz_kernel_extjobs_fr (one wavefront per "
-                                  "job, wtz_sw_frame.h; wtz_kernel_extjobs_reg / _mw / wtz_kernel_extjobs take what is outside its envelope); time = HIP events around the launches of the stage",
+        "roofline": valu_roofline("K-sw3 shifting-band extension (kswx_extend_align_shift_core), DP rows in registers in the anti-diagonal frame (wtz_sw_frame.h): wtz_kernel_stitch_ext_fr - both end "
+                                  "extensions of a stitched overlap and the join between them on one wavefront (wtz_stitch_fused.h) -, wtz_kernel_extjobs_fr where that launch declines, wtz_kernel_extjobs for what is outside the frame form's envelope; time = HIP events around the launches of the stage",
                                   cells_shift, ms_ext, {"backtrack_GBps": cells_shift / (ms_ext * 1e-3) / 1e9 if ms_ext > 0 else None}),
         "roofline_sw1": valu_roofline("K-sw1 fixed-band extension between anchors (kswx_extend_align_core), one LANE per problem: K_lplan -> K_ldp (register DP, relative mode) -> "
                                       "K_ltb (traceback) -> K_lfold (score chain, z-mer runs, CIGAR) + the chained wave kernel for the windows the fold leaves; the time is the whole stage's", cells_fixed, ms["winalign"]),
@@ -388,7 +388,7 @@ def main():
             prov["measured_on_kernel_source_id"] = json.load(open(src + ".meta.json")).get("kernel_source_id")
             prov["same_kernel_sources_as_this_build"] = (prov["measured_on_kernel_source_id"] == ksrc_now)
         res["traffic_source"] = prov
-        kmap = {"wtz_kernel_extjobs_fr": "roofline", "wtz_kernel_extjobs_reg": "roofline", "wtz_kernel_extjobs_mw": "roofline", "wtz_kernel_extjobs": "roofline", "K_winalign": "roofline_sw1", "K_ldp": "roofline_sw1", "K_ltb": "roofline_sw1", "K_lfold": "roofline_sw1", "K_lplan": "roofline_sw1",
+        kmap = {"wtz_kernel_stitch_ext_fr": "roofline", "wtz_kernel_extjobs_fr": "roofline", "wtz_kernel_extjobs_reg": "roofline", "wtz_kernel_extjobs_mw": "roofline", "wtz_kernel_extjobs": "roofline", "K_winalign": "roofline_sw1", "K_ldp": "roofline_sw1", "K_ltb": "roofline_sw1", "K_lfold": "roofline_sw1", "K_lplan": "roofline_sw1",
                 "K_gap": "roofline_sw2", "K_gdp": "roofline_sw2", "K_gtb": "roofline_sw2", "K_candidates_wg": "roofline_seed", "K_candidates": "roofline_seed", "K_pair": "roofline_zmer", "K_pair_dm": "roofline_zmer", "K_pair_big": "roofline_zmer"}
         for row in csv.DictReader(open(src)):
             key = kmap.get(row["kernel"])
