@@ -41,7 +41,7 @@ L.append("| configs[3] shape (9.8 Gbp of reads, all-reads z-index beside a pool 
 L.append("")
 L.append("| line | kernel(s) | cells (bytes) per step | kernel ms | frac | PMC traffic per step |")
 L.append("|---|---|---|---|---|---|")
-r = z["roofline"]; L.append("| `roofline` K-sw3 | `wtz_kernel_stitch_ext_fr` (+ `wtz_kernel_extjobs_fr` where the fused launch declines) | %.1f G cells (= trace bytes) | %.0f | **%.4f** of 78.6 Tint32op/s (%.0f G cells/s) | %s |" % (r["cells_per_step"] / 1e9, r["kernel_ms_per_step"], r["frac"], r["cell_updates_per_s"] / 1e9, gb(pz["wtz_kernel_extjobs_reg"] + pz["wtz_kernel_extjobs_mw"])))
+r = z["roofline"]; L.append("| `roofline` K-sw3 | `wtz_kernel_stitch_ext_fr` (+ `wtz_kernel_extjobs_fr` where the fused launch declines) | %.1f G cells (= trace bytes) | %.0f | **%.4f** of 78.6 Tint32op/s (%.0f G cells/s) | %s |" % (r["cells_per_step"] / 1e9, r["kernel_ms_per_step"], r["frac"], r["cell_updates_per_s"] / 1e9, gb(pz.get("wtz_kernel_stitch_ext_fr", 0) + pz.get("wtz_kernel_extjobs_fr", 0) + pz.get("wtz_kernel_extjobs", 0))))
 r = z["roofline_sw1"]; L.append("| `roofline_sw1` K-sw1 | `K_lplan` → `K_ldp` → `K_ltb` → `K_lfold` (+ `K_winalign`) | %.1f G cells | %.0f | **%.4f** (%.0f G cells/s) | %s |" % (r["cells_per_step"] / 1e9, r["kernel_ms_per_step"], r["frac"], r["cell_updates_per_s"] / 1e9, gb(sum(pz.get(k, 0) for k in ("K_lplan", "K_ldp", "K_ltb", "K_lfold", "K_winalign")))))
 r = z["roofline_sw2"]; L.append("| `roofline_sw2` K-sw2 | `K_gplan` → `K_gdp` → `K_gtb`, `K_gap` | %.1f G cells | %.0f | **%.4f** (%.0f G cells/s) | %s |" % (r["cells_per_step"] / 1e9, r["kernel_ms_per_step"], r["frac"], r["cell_updates_per_s"] / 1e9, gb(sum(pz.get(k, 0) for k in ("K_gplan", "K_gdp", "K_gtb", "K_gap")))))
 r = z["roofline_zmer"]; L.append("| `roofline_zmer` zmo | `K_pair` | %.1f GB | %.0f | %.4f of 8 TB/s | %s |" % (r["algorithmic_bytes_per_step"] / 1e9, r["kernel_ms_per_step"], r["frac"], gb(pz["K_pair"])))
