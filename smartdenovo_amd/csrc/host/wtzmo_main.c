@@ -101,6 +101,7 @@ typedef struct eng_s {
 	double t_gpu, t_commit, t_zbatch, t_call[6], t_io[2];      /* t_io: waiting for the writer thread before a text buffer is reused / at the end of the run */      /* t_call: wall seconds inside wtz_candidates / pairs_seed / pairs_windows / pairs_align / fetch_cigar_text / planning */
 	uint64_t spec_pairs, used_pairs, spec_items, used_items, spec_queries, used_queries, n_batches;
 	uint64_t n_masked;           /* reads masked by commits of this step (flush_pending) */
+	double cand_bpq; uint64_t cand_main_cap; uint32_t cand_cap0;      /* seed lookup: main-pool bytes per query of the requests so far (the largest), the pool they ran in; cand_cap0: batch cap until the first measurement (large inputs) */
 	double last_mask_rate;       /* new masks per used query of the batch that finished last (process_batch: may the next batch be formed in front of the last commit?) */
 	double extra_ms[6]; uint64_t extra_u64[7];      /* counters of the cloned contexts */
 } eng_t;
@@ -1377,6 +1378,8 @@ static void batch_zindex(eng_t *E, batch_t *b){
 	free(ql);
 }
 
+static void cand_scratch_seen(eng_t *E, batch_t *b, uint32_t n_lookup);
+static uint32_t cand_batch_cap(const eng_t *E);
 /* the next batch of queries (id order) with their candidate heaps (A3) and - where the z-mer index is per batch - its index; 0: no queries left */
 static int batch_form(batch_t *b){
 	eng_t *E = b->E;
@@ -1407,14 +1410,14 @@ static int batch_form(batch_t *b){
 	E->cursor = j;
 	b->seq = E->next_seq++; b->holds_turn = 0; b->spec_queries = b->nbq; b->used_queries = 0; b->masked_at_form = E->n_masked;
 	E->spec_queries += b->nbq; E->n_batches++;
-	if(E->B < E->max_batch) E->B = E->B * 4 > E->max_batch ? E->max_batch : E->B * 4;      /* ramp-up; corrected at commit */
+	{ const uint32_t mb = cand_batch_cap(E); if(E->B < mb) E->B = E->B * 4 > mb ? mb : E->B * 4; else if(E->B > mb) E->B = mb; }      /* ramp-up; corrected at commit */
 	pthread_mutex_unlock(&E->mu);
 	/* ---- candidate heaps of the batch's queries (A3) ---- */
 	if(use_pf){
 		const double tg0 = now_s();
 		int rc = WTZ_OK, cand_failed = -1;
 		if(E->shard) shard_candidates_end(E, b->pf_n, b->pf_rows, b->pf_nr);
-		else if(b->nparts == 1){ rc = wtz_candidates_end(b->ctx, b->pf_rows, b->pf_nr); DIE_WTZ(rc, "wtz_candidates_end"); }
+		else if(b->nparts == 1){ rc = wtz_candidates_end(b->ctx, b->pf_rows, b->pf_nr); DIE_WTZ(rc, "wtz_candidates_end"); cand_scratch_seen(E, b, b->pf_n); }
 		else for(uint32_t d = 0; d < b->nparts; d++){
 			part_t *pt = &b->parts[d];
 			if(d == 0 && g_dist.world > 1){ wtz_dist_hdr_t h; memset(&h, 0, sizeof h); h.cmd = WTZ_CMD_CAND_END; g_dist.bcast(&h, sizeof h); }
@@ -1448,7 +1451,7 @@ static int batch_form(batch_t *b){
 		for(uint32_t s = 0; s < b->nbq; s++) if(b->want[s]){ memcpy(rows + (size_t)n * E->stride, b->rows + (size_t)s * E->stride, (size_t)b->nrow[s] * 8); nr[n] = b->nrow[s]; n++; }
 		const double tg0 = now_s();
 		if(E->shard){ shard_candidates_begin(E, b->ids, n); shard_candidates_end(E, n, rows, nr); }
-		else { int rc = wtz_candidates(b->ctx, b->ids, n, rows, nr); DIE_WTZ(rc, "wtz_candidates"); }
+		else { int rc = wtz_candidates(b->ctx, b->ids, n, rows, nr); DIE_WTZ(rc, "wtz_candidates"); cand_scratch_seen(E, b, n); }
 		const double tg1 = now_s();
 		n = 0;
 		for(uint32_t s = 0; s < b->nbq; s++) if(b->want[s]){ memcpy(b->rows + (size_t)s * E->stride, rows + (size_t)n * E->stride, (size_t)E->stride * 8); b->nrow[s] = nr[n]; n++; }
@@ -1457,6 +1460,23 @@ static int batch_form(batch_t *b){
 	}
 	if(b->nbq && (E->zbatch > 0 || E->zsplit)) batch_zindex(E, b);
 	return 1;
+}
+/* the seed lookup allocates its scratch per query from the main pool as it goes (tuples of the query: coverage x length) and an exhausted pool ends the run: the
+ * batches are capped at what 0.6 of the pool holds at the bytes per query of the requests before (the longest reads come first, so the estimate errs on the safe side) */
+static void cand_scratch_seen(eng_t *E, batch_t *b, uint32_t n_lookup){
+	wtz_pool_info_t pi;
+	if(n_lookup < 32 || b->nparts != 1 || E->shard || b->ctx == NULL || wtz_pool_info(b->ctx, &pi) != WTZ_OK || pi.main_used == 0) return;
+	const double bpq = (double)pi.main_used / (double)n_lookup;
+	pthread_mutex_lock(&E->mu);
+	{ const double keep = E->cand_bpq * 0.7; E->cand_bpq = bpq > keep ? bpq : keep; }      /* follows the measurements down by at most 30 % per request (reads get shorter) */
+	E->cand_main_cap = pi.main_cap;
+	pthread_mutex_unlock(&E->mu);
+}
+static uint32_t cand_batch_cap(const eng_t *E){
+	uint32_t cap = E->max_batch;
+	if(E->cand_bpq > 0 && E->cand_main_cap){ const double c = 0.6 * (double)E->cand_main_cap / E->cand_bpq; if(c < (double)cap) cap = c < 256.0 ? 256u : (uint32_t)c; }
+	else if(E->cand_cap0 && cap > E->cand_cap0) cap = E->cand_cap0;
+	return cap;
 }
 
 static void process_batch(eng_t *E, batch_t *b);
@@ -1717,8 +1737,8 @@ int main(int argc, char **argv){
 		if(cj.joined && cj.rc == WTZ_OK && wtz_device_memory(E->devs[0], &fr_b, &tot_b) == WTZ_OK && fr_b > zall_bytes(E->st.nbase)){
 			zall = 1;
 			/* the seed lookup's scratch grows with the tuples of a query (coverage x length: ~450 k at the configs[3] shape = 26 MB per query) and the pool is the smaller one
-			 * chosen above: batches of 1 024 queries at most, as with the per-batch index (2 048 asked for 54.4 GB of a 49 GB main pool) */
-			if(!max_batch_set && E->max_batch > 1024) E->max_batch = 1024;
+			 * chosen above: batches of 1 024 queries until the first request has been measured, then what 0.6 of the pool holds (round 5: 2 048 queries had asked for 54.4 GB of a 49 GB main pool before the group list took the place of the dead tuple list) */
+			if(!max_batch_set) E->cand_cap0 = 1024;      /* until the first request has been measured (cand_batch_cap) */
 			fprintf(stderr, "[wtzmo-mi355x] %llu read bases: all-reads z-mer index (%.0f GB of %.0f GB free beside the scratch pool)\n", (unsigned long long)E->st.nbase, zall_bytes(E->st.nbase) / 1e9, fr_b / 1e9);
 		}
 	  }
@@ -1869,7 +1889,7 @@ int main(int argc, char **argv){
 				uint32_t nq = 0; for(uint32_t j = qbeg; j < E->qend; j++) if((j % E->n_job) == E->i_job) nq++;
 				if(nq <= E->max_batch) E->B = E->max_batch;
 			}
-			E->next_seq = 0; E->commit_seq = 0; E->last_mask_rate = -1.0; E->n_masked = 0;
+			E->next_seq = 0; E->commit_seq = 0; E->last_mask_rate = -1.0; E->n_masked = 0; E->cand_bpq = 0;
 			uint32_t nw = E->rows_all ? 1 : E->n_workers;          /* -G keeps per-read heaps that the commit rewrites: one batch at a time */
 			/* one worker, one process: a SECOND batch on the same context(s), formed and started in front of the first one's last commit (process_batch);
 			 * WTZ_BATCH_OVERLAP=0 / WTZ_RANGE_OVERLAP=0 keep one batch at a time */

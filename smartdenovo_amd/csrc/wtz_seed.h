@@ -1072,15 +1072,17 @@ WTZ_HD void wtz_task_candidates_wg(uint32_t t, wtz_reads_t R, const uint32_t *qi
 	}
 	WTZ_WG_SYNC();
 	if(tid == 0){
-		const uint64_t pa = Tk ? (uint64_t)(uintptr_t)wtz_pool_alloc(pool, ((size_t)Tk + 2) * 16) : 1ull;
+		const uint64_t pa = Tk ? (uint64_t)(uintptr_t)wtz_pool_alloc(pool, ((size_t)Tk + 2) * 8) : 1ull;
 		tmp[60] = (uint32_t)pa; tmp[61] = (uint32_t)(pa >> 32);
 	}
 	WTZ_WG_SYNC();
 	uint64_t *tup = (uint64_t*)(uintptr_t)(((uint64_t)tmp[61] << 32) | tmp[60]);
 	if(tup == NULL){ if(tid == 0) ncand_out[t] = 0xFFFFFFFFu; return; }
 	WTZ_CPROF_ADD(2, pc); WTZ_CPROF_CNT(10, Tk);
-	uint64_t *grp = tup + ((size_t)Tk + 2);                                          /* groups that reach -d, in key order (at most one per tuple) */
-	const uint32_t grp_cap = Tk + 2;
+	/* groups that reach -d, in key order (at most one per tuple): they take the place of the tuple LIST, which is dead once the scatter below has read it (round 5: a third
+	 * of the scratch of a query - 26 MB at the configs[3] shape, which is what caps the batch there) */
+	uint64_t *grp = lst_t;
+	const uint32_t grp_cap = T_all + 2;
 	for(uint32_t i = tid; i < Tk; i += nt){ const uint64_t w = lst_t[i]; tup[WTZ_LDS_ADD32(&hist[((uint32_t)(w >> 32) - key_lo) >> shift], 1u)] = w; }
 #if defined(__HIP_DEVICE_COMPILE__)
 	__threadfence_block();
