@@ -100,6 +100,7 @@ typedef struct eng_s {
 	double t_cq[4];             /* commit_query sections: candidate rows + closed filter + sort | window depth + seed weights + sort | hits (gates, queueing, masking) | plan_pairs */
 	double t_gpu, t_commit, t_zbatch, t_call[6], t_io[2];      /* t_io: waiting for the writer thread before a text buffer is reused / at the end of the run */      /* t_call: wall seconds inside wtz_candidates / pairs_seed / pairs_windows / pairs_align / fetch_cigar_text / planning */
 	uint64_t spec_pairs, used_pairs, spec_items, used_items, spec_queries, used_queries, n_batches;
+	double pair_row_ratio;       /* planned pairs per candidate row of the ranges before (plan_pairs): the rows bound a range, closed pairs and masked queries thin them out */
 	uint64_t n_masked;           /* reads masked by commits of this step (flush_pending) */
 	double cand_bpq; uint64_t cand_main_cap; uint32_t cand_cap0;      /* seed lookup: main-pool bytes per query of the requests so far (the largest), the pool they ran in; cand_cap0: batch cap until the first measurement (large inputs) */
 	double last_mask_rate;       /* new masks per used query of the batch that finished last (process_batch: may the next batch be formed in front of the last commit?) */
@@ -638,8 +639,10 @@ static void plan_pairs(eng_t *E, batch_t *b, uint32_t s0, uint32_t s1){
 	b->npair = 0;
 	for(uint32_t d = 0; d < b->nparts; d++) b->parts[d].npair = 0;
 	if((size_t)b->nbq * E->stride > b->caprowpair){ b->caprowpair = (size_t)b->nbq * E->stride; b->rowpair = (uint32_t*)hx_realloc(b->rowpair, b->caprowpair * 4); }
+	uint64_t rows_seen = 0;
 	for(uint32_t s = s0; s < s1; s++){
 		const uint32_t q = b->bq[s];
+		rows_seen += b->want[s] ? b->nrow[s] : 0;              /* what range_end counted */
 		if(!b->want[s] || E->masked[q] || E->rdcovs[q] >= nbest_of(E, q)) continue;
 		for(uint32_t k = 0; k < b->nrow[s]; k++){
 			const uint64_t e = b->rows[(size_t)s * E->stride + k];
@@ -654,6 +657,10 @@ static void plan_pairs(eng_t *E, batch_t *b, uint32_t s0, uint32_t s1){
 			pt->pq[pt->npair] = q; pt->pc[pt->npair] = id2; pt->npair++;
 			b->rowpair[(size_t)s * E->stride + k] = PIDX(dpart, pt->npair - 1); b->npair++;
 		}
+	}
+	if(rows_seen >= 256){      /* the share of the rows that became pairs: follows the ranges down by a tenth per range at most, up at once */
+		const double r = (double)b->npair / (double)rows_seen, keep = E->pair_row_ratio * 0.9;
+		E->pair_row_ratio = r > keep ? r : keep;
 	}
 	E->t_cq[3] += now_s() - tp0;
 }
@@ -1108,13 +1115,18 @@ static uint32_t range_end(eng_t *E, batch_t *b, uint32_t s0){
 	const double cap = E->main_cap ? (double)E->main_cap : 0.0;
 	const double prior = cap / 2048.0 > 1048576.0 ? cap / 2048.0 : 1048576.0;
 	const double bpp = E->bytes_per_pair > 0 ? E->bytes_per_pair : prior;
+	const double row_ratio = E->pair_row_ratio;
 	pthread_mutex_unlock(&E->mu);
 	static double fill = -1.0;      /* WTZ_RANGE_FILL: the share of the main pool a range is planned to (candidate rows are an upper bound of its pairs) */
 	/* measured at configs[2] (round 5, gpurun_out/r05r, r05s; every stage of a range ends in the tail of its slowest tasks, so fewer and larger ranges win until the
 	 * pool overflows and a range is redone in halves): 0.7 -> 28 ranges 2.10 s, 1.0 -> 21 ranges 1.98 s, 1.4 -> 16 ranges 1.97 s (pool peak 96 of 128 GB),
 	 * 1.8 -> one overflow, 2.11 s; with batches of 8 192 queries 1.4 -> 14 ranges 1.94 s */
-	if(fill < 0){ const char *e = getenv("WTZ_RANGE_FILL"); fill = e ? atof(e) : 1.3; if(fill <= 0) fill = 1.3; }
-	uint64_t budget = cap > 0 ? (uint64_t)(fill * cap / bpp) : ~0ull;
+	if(fill < 0){ const char *e = getenv("WTZ_RANGE_FILL"); fill = e ? atof(e) : 1.2; if(fill <= 0) fill = 1.2; }
+	/* the budget is in PAIRS, the slots are cut by candidate ROWS: closed pairs (the other read of the pair came first), masked and saturated queries thin the rows out -
+	 * to 0.9 at configs[2], to less than a tenth at the configs[3] shape (70x: every pair is found from both sides), where ranges held 17 000 pairs for a pool that holds
+	 * 40 000.  The share measured on the ranges before (+ 25 %) scales the budget; an estimate that was too low ends in the split of the range like any other */
+	double ratio = row_ratio * 1.25; if(ratio > 1.0 || ratio <= 0) ratio = 1.0;
+	uint64_t budget = cap > 0 ? (uint64_t)(fill * cap / bpp / ratio) : ~0ull;
 	if(budget < 16) budget = 16;
 	uint32_t s1 = s0; uint64_t acc = 0;
 	while(s1 < b->nbq && (s1 == s0 || acc + (b->want[s1] ? b->nrow[s1] : 0) <= budget)){ acc += b->want[s1] ? b->nrow[s1] : 0; s1++; }
@@ -1889,7 +1901,7 @@ int main(int argc, char **argv){
 				uint32_t nq = 0; for(uint32_t j = qbeg; j < E->qend; j++) if((j % E->n_job) == E->i_job) nq++;
 				if(nq <= E->max_batch) E->B = E->max_batch;
 			}
-			E->next_seq = 0; E->commit_seq = 0; E->last_mask_rate = -1.0; E->n_masked = 0; E->cand_bpq = 0;
+			E->next_seq = 0; E->commit_seq = 0; E->last_mask_rate = -1.0; E->n_masked = 0; E->cand_bpq = 0; E->pair_row_ratio = 1.0;
 			uint32_t nw = E->rows_all ? 1 : E->n_workers;          /* -G keeps per-read heaps that the commit rewrites: one batch at a time */
 			/* one worker, one process: a SECOND batch on the same context(s), formed and started in front of the first one's last commit (process_batch);
 			 * WTZ_BATCH_OVERLAP=0 / WTZ_RANGE_OVERLAP=0 keep one batch at a time */
