@@ -1160,23 +1160,22 @@ static void process_batch(eng_t *E, batch_t *b){
 	if(overlap < 0){ const char *e = getenv("WTZ_RANGE_OVERLAP"); overlap = e ? atoi(e) : 1; }
 	if(!overlap || E->n_workers != 1 || b->nbq == 0){ b->cparts = b->parts; process_batch_serial(E, b, 0); return; }
 	if(b->start_job == NULL) b->start_job = calloc(1, sizeof(gpujob_t));
-	gpujob_t *jobp = (gpujob_t*)b->start_job;
-#define job (*jobp)
+	gpujob_t *job = (gpujob_t*)b->start_job;      /* lives in the batch: the batch before may have started our first range already */
 	uint32_t s0 = 0, s1;
 	if(b->started){ s1 = b->start_s1; b->started = 0; }      /* the batch before this one started our first range in front of its last commit */
 	else {
 		s1 = range_end(E, b, s0);
 		pthread_mutex_lock(&E->mu); plan_pairs(E, b, s0, s1); pthread_mutex_unlock(&E->mu);
-		gpujob_start(&job, E, b);
+		gpujob_start(job, E, b);
 	}
 	for(;;){
-		const int again = gpujob_wait(&job);
+		const int again = gpujob_wait(job);
 		if(again){
 			/* scratch pool exhausted: nothing of [s0, s1) is committed and nothing else is in flight: the serial path splits it */
 			for(uint32_t d = 0; d < b->nparts; d++) part_text_wait(&b->parts[d], NULL);
 			b->cparts = b->parts;
 			pthread_mutex_lock(&E->mu); E->n_split++; E->bytes_per_pair = (E->bytes_per_pair > 0 ? E->bytes_per_pair : 1048576.0) * 2.0; pthread_mutex_unlock(&E->mu);
-			if(s1 - s0 <= 1){ fprintf(stderr, " -- device scratch pool too small even for one query: %s (use --pool-gb) --\n", job.err); DIE_NOW(); }
+			if(s1 - s0 <= 1){ fprintf(stderr, " -- device scratch pool too small even for one query: %s (use --pool-gb) --\n", job->err); DIE_NOW(); }
 			fprintf(stderr, "[wtzmo-mi355x] scratch pool exhausted with %u queries in flight; splitting the batch\n", s1 - s0);
 			const uint32_t mid = s0 + (s1 - s0) / 2;
 			process_range(E, b, s0, mid); process_range(E, b, mid, s1);
@@ -1185,10 +1184,10 @@ static void process_batch(eng_t *E, batch_t *b){
 			if(s0 >= b->nbq) break;
 			s1 = range_end(E, b, s0);
 			pthread_mutex_lock(&E->mu); plan_pairs(E, b, s0, s1); pthread_mutex_unlock(&E->mu);
-			gpujob_start(&job, E, b);
+			gpujob_start(job, E, b);
 			continue;
 		}
-		const double tg0 = job.t0, tg1 = job.t1;
+		const double tg0 = job->t0, tg1 = job->t1;
 		const uint32_t r_npair = b->npair, r_nitem = b->nitem;
 		if(b->npair){
 			for(uint32_t d = 0; d < b->nparts; d++){
@@ -1220,7 +1219,7 @@ static void process_batch(eng_t *E, batch_t *b){
 		if(n0 < b->nbq){
 			n1 = range_end(E, b, n0);
 			pthread_mutex_lock(&E->mu); plan_pairs(E, b, n0, n1); pthread_mutex_unlock(&E->mu);
-			gpujob_start(&job, E, b);
+			gpujob_start(job, E, b);
 		} else {
 			if(!b->pf_inflight){ pthread_mutex_lock(&E->mu); prefetch_begin(E, b); pthread_mutex_unlock(&E->mu); }
 			batch_t *nb = b->alt;
@@ -1292,7 +1291,6 @@ static void process_batch(eng_t *E, batch_t *b){
 		s0 = n0; s1 = n1;
 	}
 	b->cparts = b->parts;
-#undef job
 }
 
 /* both index builds of one more device (replicated indexes, --gpus) */
