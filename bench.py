@@ -77,22 +77,38 @@ def file_md5(path):
 
 
 def kernel_source_id():
-    """sha1 of the gfx950 code objects the library was built with (the .hip_fatbin section of smartdenovo_amd/libwtzmo_hip.so): what a PMC summary under
-    profiles/ was measured on, and what this run executes.  Round 4 hashed the source files whole, so a host-only edit of wtz_lib.cpp (the pool retry)
-    made the driver's line call its traffic evidence stale although not one kernel had changed; the code objects only change when device code does."""
+    """sha1 over the CODE of the gfx950 code objects the library was built with: the .text (ISA), .rodata (kernel descriptors) and .note (kernel metadata: registers,
+    LDS, scratch) sections of every amdgcn entry of the clang offload bundle in the .hip_fatbin section of smartdenovo_amd/libwtzmo_hip.so.  That is what a PMC summary
+    under profiles/ was measured on and what this run executes.  Round 4 hashed the source files whole (a host-only edit of wtz_lib.cpp made the driver's line call
+    its evidence stale although no kernel had changed); the first round-5 form hashed the whole .hip_fatbin - and two builds of the SAME sources differ there: the
+    order of the code object's dynamic symbol table is not deterministic (.dynsym / .dynstr / .strtab differ, .text / .rodata / .note do not: checked on four builds,
+    one of them in another directory).  A rebuild of unchanged sources - the driver's at round end - now gives the same id."""
     import hashlib
     import struct
+
+    def sections(elf):
+        shoff, = struct.unpack_from("<Q", elf, 0x28); shentsize, shnum, shstrndx = struct.unpack_from("<HHH", elf, 0x3A)
+        sec = [struct.unpack_from("<IIQQQQIIQQ", elf, shoff + i * shentsize) for i in range(shnum)]
+        stro = sec[shstrndx][4]
+        return {elf[stro + name:elf.index(b"\0", stro + name)]: (off, size, typ) for name, typ, _f, _a, off, size, *_ in sec}
+
     lib = os.path.join(ROOT, "smartdenovo_amd", "libwtzmo_hip.so")
     try:
         b = open(lib, "rb").read()
-        shoff, = struct.unpack_from("<Q", b, 0x28); shentsize, shnum, shstrndx = struct.unpack_from("<HHH", b, 0x3A)
-        sec = [struct.unpack_from("<IIQQQQIIQQ", b, shoff + i * shentsize) for i in range(shnum)]
-        stro = sec[shstrndx][4]
-        for name, _t, _f, _a, off, size, *_ in sec:
-            nm = b[stro + name:b.index(b"\0", stro + name)]
-            if nm == b".hip_fatbin":
-                return hashlib.sha1(b[off:off + size]).hexdigest()[:16]
-    except (OSError, struct.error, ValueError):
+        off, size, _t = sections(b)[b".hip_fatbin"]
+        fb = b[off:off + size]
+        if fb[:24] != b"__CLANG_OFFLOAD_BUNDLE__":
+            return "unbuilt"
+        n, = struct.unpack_from("<Q", fb, 24); p = 32; h = hashlib.sha1(); found = False
+        for _ in range(n):
+            eoff, esize, tl = struct.unpack_from("<QQQ", fb, p); p += 24; triple = fb[p:p + tl]; p += tl
+            if esize and b"amdgcn" in triple:
+                elf = fb[eoff:eoff + esize]; sc = sections(elf)
+                for nm in (b".text", b".rodata", b".note"):
+                    if nm in sc and sc[nm][2] != 8:
+                        o, z, _ = sc[nm]; h.update(nm); h.update(elf[o:o + z]); found = True
+        return h.hexdigest()[:16] if found else "unbuilt"
+    except (OSError, struct.error, ValueError, KeyError):
         pass
     return "unbuilt"
 
