@@ -188,7 +188,7 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--engine", choices=["zmo", "dmo"], default="zmo")
     ap.add_argument("--max-batch", type=int, default=0)
-    ap.add_argument("--pool-gb", type=int, default=0, help="device scratch (0 = the library's default: 45 % of the free HBM, at most 128 GB)")
+    ap.add_argument("--pool-gb", type=int, default=0, help="device scratch (0 = the library's default: 45 %% of the free HBM, at most 128 GB)")
     ap.add_argument("--cpu-genome", type=int, default=0, help="genome length of the bounded CPU-baseline sample (same coverage)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline", choices=["input", "sample"], default=None, help="reference wtzmo on the bench input itself (default where the workload has a golden) or on a bounded same-shape sample")
