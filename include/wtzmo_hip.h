@@ -247,6 +247,9 @@ int  wtz_extend_batch(wtz_ctx_t *ctx, const wtz_dp_problem_t *problems, uint32_t
  * last stage call (wtz_pairs_seed / wtz_pairs_align), transient_peak = high-water mark of the transient pool during it. */
 typedef struct { uint64_t main_cap, main_used, transient_cap, transient_peak; } wtz_pool_info_t;
 int  wtz_pool_info(wtz_ctx_t *ctx, wtz_pool_info_t *out);
+/* which pool the context's last WTZ_E_POOL came from: 0 = none yet, 1 = the main pool (the caller's bytes-per-pair estimate was too low: plan smaller ranges from
+ * now on), 2 = the transient trace pool of the K-sw3 launches (the library's own trace budget was too low and has been raised: redo the range, keep the estimate) */
+int  wtz_pool_failure_kind(wtz_ctx_t *ctx);
 
 int  wtz_get_counters(wtz_ctx_t *ctx, wtz_counters_t *out);
 int  wtz_reset_counters(wtz_ctx_t *ctx);

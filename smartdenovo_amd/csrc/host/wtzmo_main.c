@@ -95,6 +95,10 @@ typedef struct eng_s {
 	 * a range are cut to fit the pool BEFORE the device stages run; WTZ_E_POOL and the halving below it remain as the safety net */
 	double bytes_per_pair, bpp_decay; uint64_t main_cap; uint64_t n_split, n_ranges;
 	pending_t pend;
+	/* commit_query scratch kept across queries (round 6: the two calloc'ed depth arrays of a query were 60 KB of zeroing + a 10 000-step scalar prefix each -
+	 * more than half of the sequential commit): cq_dep = +1 / -1 marks, then the running depth, as 16-bit words (the reference's counters are u2i and wrap the
+	 * same way); only the span the query's windows touch is summed, and it is zeroed again behind the query */
+	void *cq_cand; size_t cq_capcand; void *cq_seeds; size_t cq_capseeds; uint16_t *cq_dep; size_t cq_capdep;
 	/* stats */
 	char *cig_keep[16]; uint64_t cig_keep_cap[16];      /* page-locked CIGAR text buffer of worker w, kept across steps (pinning is the expensive part) */
 	double t_cq[4];             /* commit_query sections: candidate rows + closed filter + sort | window depth + seed weights + sort | hits (gates, queueing, masking) | plan_pairs */
@@ -479,6 +483,26 @@ __attribute__((unused)) static char *cigar_text(const uint32_t *c, uint32_t n){ 
 	s[k] = 0; return s;
 }
 
+/* a[i] <- a[lo] + ... + a[i] for i in [lo, hi), 16-bit wrap-around; lo is a multiple of 8 */
+#ifdef __SSE2__
+#include <emmintrin.h>
+#endif
+static void depth_prefix_u16(uint16_t *a, size_t lo, size_t hi){
+	size_t i = lo; uint16_t run = 0;
+#ifdef __SSE2__
+	__m128i carry = _mm_setzero_si128();
+	for(; i + 8 <= hi; i += 8){
+		__m128i x = _mm_loadu_si128((const __m128i*)(a + i));
+		x = _mm_add_epi16(x, _mm_slli_si128(x, 2)); x = _mm_add_epi16(x, _mm_slli_si128(x, 4)); x = _mm_add_epi16(x, _mm_slli_si128(x, 8));
+		x = _mm_add_epi16(x, carry);
+		_mm_storeu_si128((__m128i*)(a + i), x);
+		carry = _mm_shuffle_epi32(_mm_shufflehi_epi16(x, 0xFF), 0xFF);      /* the last sum in every word */
+	}
+	if(i > lo) run = a[i - 1];
+#endif
+	for(; i < hi; i++){ run = (uint16_t)(run + a[i]); a[i] = run; }
+}
+
 /* weights[i] of wtzmo.c:933-936: float = (depth rule); then float = float * (double positional factor) */
 static inline float rep_weight(const uint16_t *windeps, const wtz_params_c *P, int alen, int i){
 	float w = (windeps[i] <= P->win_rep_norm) ? 1.0 : ((windeps[i] >= P->win_rep_cutoff) ? 0.0 : P->win_rep_norm / (float)windeps[i]);
@@ -502,7 +526,8 @@ static void commit_query(eng_t *E, batch_t *b, uint32_t slot){
 	/* candidates: closed filter, exact order, trim (wtzmo.c:813-822) */
 	if(!b->want[slot]){ fprintf(stderr, " -- internal error: no candidate row for read %u --\n", pbid); DIE_NOW(); }
 	uint32_t nc = b->nrow[slot];
-	cand_t *cand = (cand_t*)hx_realloc(NULL, sizeof(cand_t) * (nc + 1));
+	if(E->cq_capcand < (size_t)nc + 1){ E->cq_capcand = ((size_t)nc + 1) * 2; E->cq_cand = hx_realloc(E->cq_cand, sizeof(cand_t) * E->cq_capcand); }
+	cand_t *cand = (cand_t*)E->cq_cand;
 	for(uint32_t i = 0; i < nc; i++){
 		cand[i].e = b->rows[(size_t)slot * E->stride + i]; cand[i].pidx = b->rowpair[(size_t)slot * E->stride + i]; cand[i].pad = 0;
 		if(hx_set_has(&E->closed, hx_pair_key(pbid, cand[i].e >> 32))) cand[i].e &= 0xFFFFFFFF00000000ULL;
@@ -533,12 +558,16 @@ static void commit_query(eng_t *E, batch_t *b, uint32_t slot){
 				emit_record(E, &H, NULL, 0, -1);
 			}
 		}
-		free(cand);
 		return;
 	}
-	uint16_t *windeps = (uint16_t*)calloc((size_t)alen + 1, 2);
-	int32_t *wdiff = (int32_t*)calloc((size_t)alen + 2, 4);
-	seed_t *seeds = (seed_t*)hx_realloc(NULL, sizeof(seed_t) * (nc + 1)); uint32_t nseed = 0;
+	if(E->cq_capdep < (size_t)alen + 24){      /* zero from the start and after every query */
+		E->cq_capdep = ((size_t)alen + 24) * 2; free(E->cq_dep);
+		E->cq_dep = (uint16_t*)calloc(E->cq_capdep, 2); if(!E->cq_dep){ fprintf(stderr, " -- Out of memory --\n"); DIE_NOW(); }
+	}
+	uint16_t *windeps = E->cq_dep;
+	int dep_lo = alen, dep_hi = 0;             /* span of the marks */
+	if(E->cq_capseeds < (size_t)nc + 1){ E->cq_capseeds = ((size_t)nc + 1) * 2; E->cq_seeds = hx_realloc(E->cq_seeds, sizeof(seed_t) * E->cq_capseeds); }
+	seed_t *seeds = (seed_t*)E->cq_seeds; uint32_t nseed = 0;
 	for(uint32_t i = 0; i < nc; i++){
 		const uint32_t id2 = (uint32_t)(cand[i].e >> 32);
 		if(cand[i].pidx == 0xFFFFFFFFu){ fprintf(stderr, " -- internal error: pair (%u,%u) missing from the batch plan --\n", pbid, id2); DIE_NOW(); }
@@ -549,13 +578,15 @@ static void commit_query(eng_t *E, batch_t *b, uint32_t slot){
 		for(uint32_t dir = 0; dir < 2; dir++){
 			const wtz_winbox_t *bx = pt->boxes + pt->box_off[(size_t)li * 2 + dir];
 			for(uint32_t k = 0; k < S->nwin[dir]; k++){       /* wtzmo.c:908 increments windeps over [beg,end): kept as +1/-1 marks, summed below */
-				if(bx[k].beg[0] < bx[k].end[0]){ wdiff[bx[k].beg[0]]++; wdiff[bx[k].end[0]]--; }
+				const int wb = bx[k].beg[0], we = bx[k].end[0];
+				if(wb < we){ windeps[wb]++; windeps[we]--; if(wb < dep_lo) dep_lo = wb; if(we > dep_hi) dep_hi = we; }
 			}
 		}
 		const uint32_t dir = (S->ovl[0] < S->ovl[1]);
 		if(S->ovl[dir] >= P->ztot){ seed_t s; s.pb2 = id2; s.dir = dir; s.ovl = S->ovl[dir]; s.closed = 0; s.pidx = cand[i].pidx; seeds[nseed++] = s; }
 	}
-	{ int32_t run = 0; for(int i = 0; i < alen; i++){ run += wdiff[i]; windeps[i] = (uint16_t)run; } }       /* uint16 wrap-around as in the reference's u2i counters */
+	/* running depth over the span of the marks (it is zero outside: every interval is closed); arithmetic modulo 2^16 like the reference's u2i counters */
+	if(dep_lo < dep_hi) depth_prefix_u16(windeps, (size_t)(dep_lo & ~7), (size_t)dep_hi + 1);
 	/* repeat weighting: the reference fills weights[0..alen) (wtzmo.c:933-936) but only reads the entry at the middle of each
 	 * window (954): evaluated on demand by rep_weight() with the same float/double mix */
 	for(uint32_t i = 0; i < nseed; i++){
@@ -623,7 +654,7 @@ static void commit_query(eng_t *E, batch_t *b, uint32_t slot){
 			}
 		}
 	}
-	free(cand); free(windeps); free(wdiff); free(seeds);
+	if(dep_lo < dep_hi) memset(windeps + (dep_lo & ~7), 0, 2 * (size_t)(dep_hi + 1 - (dep_lo & ~7)));
 	E->t_cq[2] += now_s() - tq2;
 }
 
@@ -1059,6 +1090,21 @@ static void shard_candidates_end(eng_t *E, uint32_t n, uint64_t *rows, uint32_t 
 
 /* slots [s0,s1): plan pairs, run the device stages, commit in query order when it is this batch's turn. A range whose
  * scratch demand exceeds the pool is split in two (the second half is planned after the first half is committed). */
+/* a range came back with "scratch pool too small": was it the library's transient trace pool alone (its own budget, raised by now) on every local part that failed?
+ * Then the bytes-per-pair estimate of the MAIN pool is not what was wrong and stays as it is (one under-estimated trace budget used to halve every later
+ * range).  Parts on other ranks cannot be asked: they count as a main-pool failure. */
+static int range_failed_on_traces_only(const batch_t *b){
+	if(g_dist.world > 1) return 0;
+	int seen = 0;
+	for(uint32_t d = 0; d < b->nparts; d++){
+		const part_t *pt = &b->parts[d];
+		if(!pt->ctx || pt->npair == 0) continue;
+		const int k = wtz_pool_failure_kind(pt->ctx);
+		if(k == 1) return 0;
+		if(k == 2) seen = 1;
+	}
+	return seen;
+}
 static void process_range(eng_t *E, batch_t *b, uint32_t s0, uint32_t s1){
 	pthread_mutex_lock(&E->mu);
 	plan_pairs(E, b, s0, s1);
@@ -1081,7 +1127,7 @@ static void process_range(eng_t *E, batch_t *b, uint32_t s0, uint32_t s1){
 		}
 	}
 	if(again){
-		pthread_mutex_lock(&E->mu); E->n_split++; E->bytes_per_pair = (E->bytes_per_pair > 0 ? E->bytes_per_pair : 1048576.0) * 2.0; pthread_mutex_unlock(&E->mu);
+		pthread_mutex_lock(&E->mu); E->n_split++; if(!range_failed_on_traces_only(b)) E->bytes_per_pair = (E->bytes_per_pair > 0 ? E->bytes_per_pair : 1048576.0) * 2.0; pthread_mutex_unlock(&E->mu);
 		if(s1 - s0 <= 1){ fprintf(stderr, " -- device scratch pool too small even for one query: %s (use --pool-gb) --\n", wtz_last_error()); DIE_NOW(); }
 		fprintf(stderr, "[wtzmo-mi355x] scratch pool exhausted with %u queries in flight; splitting the batch\n", s1 - s0);
 		const uint32_t mid = s0 + (s1 - s0) / 2;
@@ -1174,7 +1220,7 @@ static void process_batch(eng_t *E, batch_t *b){
 			/* scratch pool exhausted: nothing of [s0, s1) is committed and nothing else is in flight: the serial path splits it */
 			for(uint32_t d = 0; d < b->nparts; d++) part_text_wait(&b->parts[d], NULL);
 			b->cparts = b->parts;
-			pthread_mutex_lock(&E->mu); E->n_split++; E->bytes_per_pair = (E->bytes_per_pair > 0 ? E->bytes_per_pair : 1048576.0) * 2.0; pthread_mutex_unlock(&E->mu);
+			pthread_mutex_lock(&E->mu); E->n_split++; if(!range_failed_on_traces_only(b)) E->bytes_per_pair = (E->bytes_per_pair > 0 ? E->bytes_per_pair : 1048576.0) * 2.0; pthread_mutex_unlock(&E->mu);
 			if(s1 - s0 <= 1){ fprintf(stderr, " -- device scratch pool too small even for one query: %s (use --pool-gb) --\n", job->err); DIE_NOW(); }
 			fprintf(stderr, "[wtzmo-mi355x] scratch pool exhausted with %u queries in flight; splitting the batch\n", s1 - s0);
 			const uint32_t mid = s0 + (s1 - s0) / 2;
@@ -1993,5 +2039,6 @@ int main(int argc, char **argv){
 	}
 	for(int w = 0; w < 16; w++) wtz_host_free(E->cig_keep[w]);
 	for(uint32_t d = 0; d < E->ndev; d++) wtz_ctx_destroy(E->ctxs[d]);
+	free(E->cq_cand); free(E->cq_seeds); free(E->cq_dep);
 	return 0;
 }

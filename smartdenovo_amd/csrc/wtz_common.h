@@ -120,7 +120,7 @@ static inline void wtz_pool_init(wtz_pool_t *p, uint8_t *base, unsigned long lon
 	p->base = base; p->cap = cap; p->fail_at = fail_at;
 	unsigned long long s = (unsigned long long)64 << 10;
 	while(s < ((unsigned long long)2 << 20) && s * 2048 <= cap) s <<= 1;
-	p->slab = cap >= ((unsigned long long)16 << 20) ? s : 0;
+	p->slab = cap >= ((unsigned long long)128 << 20) ? s : 0;      /* 64 shards of >= 64 KB each are up to 4 MB of slack on top of a planned budget: small pools keep the single cursor */
 	for(int k = 0; k < WTZ_POOL_NSHARD; k++) p->shard[k * 16] = p->slab;      /* tag 0, slab "taken" to its end: the first request crosses */
 }
 
@@ -137,6 +137,9 @@ WTZ_HD void *wtz_pool_alloc_global(wtz_pool_t *p, unsigned long long n){
 
 WTZ_HD void *wtz_pool_alloc(wtz_pool_t *p, size_t bytes){
 	unsigned long long n = ((unsigned long long)bytes + 15ull) & ~15ull;
+	/* a pool that has refused a request stays refusing until its reset (the stage ends in WTZ_E_POOL whatever else it computes): no later request moves a shard
+	 * cursor, so the 32-bit offset of a shard that lost its slab cannot be driven round into the tag by the requests of a failing stage */
+	if(p->overflow) return NULL;
 	if(p->fail_at){
 #if defined(__HIP_DEVICE_COMPILE__)
 		const unsigned int k = atomicAdd(&p->nalloc, 1u);
@@ -156,7 +159,10 @@ WTZ_HD void *wtz_pool_alloc(wtz_pool_t *p, size_t bytes){
 		/* this request crossed the end of the slab: it is the one that fetches the next */
 		const unsigned long long o = atomicAdd(&p->used, slab);
 		if(o + slab > p->cap){
-			if(o + n <= p->cap) return p->base + o;                                /* the tail of the pool still holds this request */
+			/* the tail of the pool: no further slab.  The shard is parked (tag 0, offset just beyond a slab: every later request of the shard goes to the global
+			 * cursor, which is beyond the pool's end by now and refuses - see the test at the top) */
+			atomicExch(cur, slab + 1ull);
+			if(o + n <= p->cap) return p->base + o;                                /* the tail still holds this request */
 			p->overflow = 1; return NULL;
 		}
 		atomicExch(cur, (((o >> 8) + 1ull) << 32) | n);

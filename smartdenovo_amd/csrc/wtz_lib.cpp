@@ -15,6 +15,7 @@
 #include <stdlib.h>
 #include <stdarg.h>
 #include <vector>
+#include <atomic>
 #include <algorithm>
 
 #include "wtz_tasks.h"
@@ -402,7 +403,10 @@ struct wtz_ctx {
 	wtz_alnres_dev_t *d_alnres; uint32_t n_items; std::vector<wtz_alnres_dev_t> h_alnres;
 	char *d_text = NULL; size_t cap_text = 0;      /* rendered CIGAR text of the last alignment call (wtz_fetch_cigar_text / wtz_cigar_text_device) */
 #ifndef WTZ_EMUL
-	hipStream_t stream_copy = 0; hipEvent_t ev_text_ready = 0, ev_text_done = 0; bool text_inflight = false;      /* wtz_fetch_cigar_text_begin / _end: the text's way to the host beside the next range's kernels */
+	/* copies are numbered: copy k signals ev_text_done[k & 1].  text_begun = copies started (device-stage thread), text_known_done = copies known to have finished
+	 * (a render waits for the latest one before it refills d_text), text_ended = copies whose end has been asked for (the caller's commit thread, in the same order).
+	 * Round 5 had ONE event and a plain bool shared by the two threads: _end could wait on the event after _begin had re-recorded it for the next range. */
+	hipStream_t stream_copy = 0; hipEvent_t ev_text_ready = 0, ev_text_done[2] = {0, 0}; std::atomic<uint64_t> text_begun{0}, text_known_done{0}, text_ended{0};      /* wtz_fetch_cigar_text_begin / _end: the text's way to the host beside the next range's kernels */
 #endif
 	bool have_pairs, have_items;
 	/* candidate request in flight (wtz_candidates_begin / _end) */
@@ -415,6 +419,7 @@ struct wtz_ctx {
 	int env_ext_fr_split = 0;    /* WTZ_EXT_FR_SPLIT=1: the frame kernel per band class (<= 16 / <= 28 / <= 32 columns per lane), three concurrent launches at 4 / 3 / 2 waves per SIMD */
 	int env_zread = 1;           /* WTZ_ZREAD=0: every read's z-mer index by the device-wide form (strided fill + radix sort) instead of one workgroup per read (wtz_task_zread) */
 	int env_ext_fused = 1;       /* WTZ_EXT_FUSED=0: the two end extensions of a stitched overlap in two launches with K_stitch_mid between them instead of on one wavefront (wtz_stitch_fused.h) */
+	int last_pool_fail = 0;      /* which pool the last WTZ_E_POOL came from: 1 = main, 2 = transient (wtz_pool_failure_kind) */
 	double ext_use_ratio = 0.4; uint64_t tpool_last_used = 0;      /* run_stitch_fused: share of the trace upper bounds the fused launches have really taken */
 	bool fused_ran = false;      /* this stitch stage's fused launch has run: the extension launches behind it only sweep up what it left open */
 	int env_ext_fr = 1;          /* WTZ_EXT_FR=0: K-sw3 one-wave jobs on the round-4 register kernel (wtz_extend_shift_reg) instead of the frame form (wtz_sw_frame.h) */
@@ -457,6 +462,7 @@ static int tpool_check(wtz_ctx *c, const char *stage){
 	c->tpool_last_used = u;
 	if(u > c->tpool_peak_call) c->tpool_peak_call = u;
 	if(p.overflow && c->env_fail_once) c->env_tfail_at = 0;
+	if(p.overflow) c->last_pool_fail = 2;
 	if(p.overflow) return wtz_fail(WTZ_E_POOL, "%s: transient trace pool exhausted (%llu of %llu bytes requested); use a larger pool",
 		stage, (unsigned long long)p.used, (unsigned long long)p.cap);
 	return WTZ_OK;
@@ -467,6 +473,7 @@ static int pool_check(wtz_ctx *c, const char *stage){
 	c->main_used_call = u;
 	if(u + c->tpool_peak_call > c->cnt.pool_peak) c->cnt.pool_peak = u + c->tpool_peak_call;
 	if(p.overflow && c->env_fail_once) c->env_fail_at = 0;       /* injected failure: only the first stage call that gets that far */
+	if(p.overflow) c->last_pool_fail = 1;
 	if(p.overflow) return wtz_fail(WTZ_E_POOL, "%s: device scratch pool exhausted (%llu of %llu bytes requested); use fewer items per call or a larger pool",
 		stage, (unsigned long long)p.used, (unsigned long long)p.cap);
 	return WTZ_OK;
@@ -675,7 +682,7 @@ extern "C" void wtz_ctx_destroy(wtz_ctx_t *c){
 #ifndef WTZ_EMUL
 	if(c->stream_mw) (void)hipStreamDestroy(c->stream_mw);
 	if(c->stream_gap) (void)hipStreamDestroy(c->stream_gap);
-	if(c->stream_copy){ (void)hipStreamSynchronize(c->stream_copy); (void)hipStreamDestroy(c->stream_copy); if(c->ev_text_ready) (void)hipEventDestroy(c->ev_text_ready); if(c->ev_text_done) (void)hipEventDestroy(c->ev_text_done); }
+	if(c->stream_copy){ (void)hipStreamSynchronize(c->stream_copy); (void)hipStreamDestroy(c->stream_copy); if(c->ev_text_ready) (void)hipEventDestroy(c->ev_text_ready); for(int k = 0; k < 2; k++) if(c->ev_text_done[k]) (void)hipEventDestroy(c->ev_text_done[k]); }
 	for(int k = 0; k < 8; k++){ if(c->stream_cls[k]) (void)hipStreamDestroy(c->stream_cls[k]); if(c->ev_cls[k]) (void)hipEventDestroy(c->ev_cls[k]); }
 	{ hipEvent_t evs[4] = { c->ev_mw_fork, c->ev_mw_join, c->ev_gap_fork, c->ev_gap_join }; for(int k = 0; k < 4; k++) if(evs[k]) (void)hipEventDestroy(evs[k]); }
 	if(c->stream) (void)hipStreamDestroy(c->stream);
@@ -1573,7 +1580,7 @@ static int run_stitch_fused(wtz_ctx *c, const wtz_env_t &V, const wtz_alnitem_t 
 	 * any other exhausted pool: the host redoes the range in halves. */
 	/* what does not fit at once runs in up to four groups (every ng-th item of the order each: all groups are ordered longest-first), the transient pool reset between them */
 	uint32_t ng = 1; while(ng < 4 && (double)acc * c->ext_use_ratio / ng > (double)budget) ng++;
-	if((double)acc * c->ext_use_ratio / ng > (double)budget){ if(c->env_profile) fprintf(stderr, "[ext-profile] fused launch declined: %u items, trace bounds %.1f GB x %.2f against %.1f GB\n", m, acc / 1e9, c->ext_use_ratio, budget / 1e9); return WTZ_OK; }          /* the two launches cut their jobs into groups that fit */
+	if((double)acc * c->ext_use_ratio / ng > (double)budget){ if(c->env_profile) fprintf(stderr, "[ext-profile] fused launch declined: %u items, trace bounds %.1f GB x %.2f against %.1f GB\n", m, acc / 1e9, c->ext_use_ratio, budget / 1e9); dev_free(d_order); dev_free(d_k); dev_free(d_acc); return WTZ_OK; }          /* the two launches cut their jobs into groups that fit */
 	double ms_l = 0; uint64_t used_sum = 0;
 	for(uint32_t g = 0; g < ng; g++){
 		const uint32_t mg = (m - g + ng - 1) / ng;
@@ -1583,14 +1590,23 @@ static int run_stitch_fused(wtz_ctx *c, const wtz_env_t &V, const wtz_alnitem_t 
 		hipLaunchKernelGGL((wtz_kernel_stitch_ext_fr<1032>), dim3(mg), dim3(64), WTZ_WAVE_LDS_BYTES, g_stream, V, d_items, d_st, d_jl, d_jr, d_gaps, (const uint32_t*)d_order, mg, ng, g);
 		HIPCHK(hipGetLastError());
 		ms_l += te.stop();
-		CHK(tpool_check(c, "K-sw3 extension jobs (both ends on one wavefront)"));
+		{
+			const int rc_t = tpool_check(c, "K-sw3 extension jobs (both ends on one wavefront)");
+			if(rc_t != WTZ_OK){
+				/* the budget under-estimated what the traces take: the next launch is planned with twice the share (the host redoes this range in halves and is told
+				 * that it was the transient pool, so that its bytes-per-pair estimate of the MAIN pool is left alone: wtz_pool_failure_kind) */
+				c->ext_use_ratio = c->ext_use_ratio * 2.0 > 1.0 ? 1.0 : c->ext_use_ratio * 2.0;
+				dev_free(d_order); dev_free(d_k); dev_free(d_acc);
+				return rc_t;
+			}
+		}
 		used_sum += c->tpool_last_used;
 	}
 	c->cnt.ms_ext += ms_l; c->cnt.n_extjobs += 2ull * m;
 	c->fused_ran = true;
 	if(c->env_profile) fprintf(stderr, "[ext-profile] fused launch: %u items in %u group(s), rows (upper bound) sum %llu, %.2f ms\n", m, ng, ext_sum, ms_l);
 	c->tpool_last_used = used_sum;
-	dev_free(d_order);
+	dev_free(d_order); dev_free(d_k); dev_free(d_acc);
 	if(acc){ const double seen = 1.3 * (double)c->tpool_last_used / (double)acc, keep = c->ext_use_ratio * 0.9; c->ext_use_ratio = seen > keep ? seen : keep; if(c->ext_use_ratio < 0.2) c->ext_use_ratio = 0.2; if(c->ext_use_ratio > 1.0) c->ext_use_ratio = 1.0; }
 	return WTZ_OK;
 }
@@ -2122,7 +2138,10 @@ static int render_cigar_text(wtz_ctx_t *c, uint64_t n_bytes, char **d_text_out, 
 	*d_text_out = NULL;
 	if(tot == 0) return WTZ_OK;
 #ifndef WTZ_EMUL
-	if(c->text_inflight){ HIPCHK(hipEventSynchronize(c->ev_text_done)); c->text_inflight = false; }      /* the buffer is still being copied out (a caller that never asked for the end of it) */
+	{   /* the buffer may still be on its way out (the latest copy; the ones before it are in front of it on the same stream) */
+		const uint64_t b = c->text_begun.load();
+		if(b > c->text_known_done.load()){ HIPCHK(hipEventSynchronize(c->ev_text_done[(b - 1) & 1])); c->text_known_done.store(b); }
+	}
 #endif
 	if(tot + 16 > c->cap_text){
 		(void)dev_sync(); dev_free_persist(c->d_text); c->d_text = NULL; c->cap_text = 0;
@@ -2165,7 +2184,7 @@ extern "C" int wtz_fetch_cigar_text_begin(wtz_ctx_t *c, char *dst, uint64_t n_by
 #else
 	if(!c->stream_copy){
 		if(hipStreamCreateWithFlags(&c->stream_copy, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->ev_text_ready, hipEventDisableTiming) != hipSuccess
-			|| hipEventCreateWithFlags(&c->ev_text_done, hipEventDisableTiming) != hipSuccess) return wtz_fail(WTZ_E_HIP, "hipStreamCreate / hipEventCreate failed");
+			|| hipEventCreateWithFlags(&c->ev_text_done[0], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_text_done[1], hipEventDisableTiming) != hipSuccess) return wtz_fail(WTZ_E_HIP, "hipStreamCreate / hipEventCreate failed");
 	}
 	char *d_t = NULL;
 	CHK(render_cigar_text(c, n_bytes, &d_t, false));
@@ -2174,8 +2193,7 @@ extern "C" int wtz_fetch_cigar_text_begin(wtz_ctx_t *c, char *dst, uint64_t n_by
 	HIPCHK(hipEventRecord(c->ev_text_ready, g_stream));
 	HIPCHK(hipStreamWaitEvent(c->stream_copy, c->ev_text_ready, 0));
 	HIPCHK(hipMemcpyAsync(dst, d_t, (size_t)n_bytes, hipMemcpyDeviceToHost, c->stream_copy));
-	HIPCHK(hipEventRecord(c->ev_text_done, c->stream_copy));
-	c->text_inflight = true;
+	{ const uint64_t k = c->text_begun.load(); HIPCHK(hipEventRecord(c->ev_text_done[k & 1], c->stream_copy)); c->text_begun.store(k + 1); }
 	return WTZ_OK;
 #endif
 }
@@ -2183,7 +2201,10 @@ extern "C" int wtz_fetch_cigar_text_end(wtz_ctx_t *c){
 	if(!c) return wtz_fail(WTZ_E_ARG, "null argument");
 #ifndef WTZ_EMUL
 	/* no CTX_ENTER: this may be called while another thread runs the next range's calls on the context; it touches the event only */
-	if(c->text_inflight && c->ev_text_done){ HIPCHK(hipEventSynchronize(c->ev_text_done)); }
+	const uint64_t e = c->text_ended.load();
+	if(e >= c->text_begun.load()) return WTZ_OK;                /* nothing in flight that has not been ended */
+	if(e >= c->text_known_done.load()){ HIPCHK(hipEventSynchronize(c->ev_text_done[e & 1])); }      /* at worst the event has been re-recorded for copy e + 2 (whose render waited for copy e + 1): a longer wait, never a shorter one */
+	c->text_ended.store(e + 1);
 #endif
 	return WTZ_OK;
 }
@@ -2284,6 +2305,8 @@ extern "C" void wtz_host_free(void *p){
 	(void)hipHostFree(p);
 #endif
 }
+
+extern "C" int wtz_pool_failure_kind(wtz_ctx_t *c){ return c ? c->last_pool_fail : 0; }
 
 extern "C" int wtz_pool_info(wtz_ctx_t *c, wtz_pool_info_t *out){
 	if(!c || !out) return wtz_fail(WTZ_E_ARG, "null argument");

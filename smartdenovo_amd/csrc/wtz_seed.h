@@ -820,7 +820,11 @@ WTZ_HD void wtz_task_zread(uint32_t r, const wtz_reads_t &R, uint32_t zsize, uin
 	if(n == 0){ if(tid == 0) Z.dn[r] = 0; return; }
 	const uint32_t nbk = wtz_zr_nbk(np);                        /* buckets by the leading bits of the z-mer: ~4 z-mers each (canonical z-mers lean to the small values: up to ~8) */
 	uint32_t lb = 0; while((1u << lb) < nbk) lb++;
-	const uint32_t bsh = 32u - lb, maxpc = WTZ_ZR_MAXPC(np);
+	/* a z-mer has 2 * zsize bits (20 at the default -z 10): the bucket is its LEADING lb bits.  Round 5 shifted by 32 - lb, which sent every z-mer of a read below 2^(32 - lb)
+	 * - all of them at -z 10 - to bucket 0: the one-lane insertion path never ran, every LDS atomic of the two walks hit the same word, and the whole array
+	 * went through the workgroup's bitonic network */
+	const uint32_t kbits = 2u * zsize < 32u ? 2u * zsize : 32u;
+	const uint32_t bsh = kbits > lb ? kbits - lb : 0u, maxpc = WTZ_ZR_MAXPC(np);
 	uint64_t *keys = (uint64_t*)lds; uint32_t *bk = lds + 2 * (size_t)np, *pc = bk + nbk + 1, *tmp = pc + maxpc;
 	const uint32_t len = R.rdlen[r], npc = (len + WTZ_ZR_SUB - 1) / WTZ_ZR_SUB;
 	/* the read's 2-bit words in LDS, addressed as a one-read bank: read 0 starts at the offset of the read inside its first word */

@@ -164,19 +164,26 @@ WTZ_HD void wtz_task_pair(uint32_t t, const wtz_env_t &V, const uint32_t *qid, c
 			WTZ_CRUMB(t, 0xFF);
 			return;
 		}
-		if(lane != 0) continue;
 		WTZ_CRUMB(t, (8 + dir) | (n << 8));
-		if(wins.bad || anchors.bad){ r.bad = 1; continue; }
+		/* the vectors belong to lane 0: what the chain needs of them as uniform values */
+		if(wtz_coop_bcast32((uint32_t)(wins.bad | anchors.bad))){ r.bad = 1; continue; }
 		if(nw == 0) continue;
 		const unsigned long long ptc = WTZ_PROF_T(); (void)ptc;
-		int32_t *mem = (int32_t*)wtz_pool_alloc(V.pool, (size_t)wins.n * 8 + 8);
-		if(mem == NULL){ r.bad = 1; continue; }
-		r.ovl[dir] = WTZ_OVL29(wtz_chain_windows(wins.a, wins.n, P->W, mem));
+		WTZ_WAVE_SYNC();                                       /* lane 0 wrote the windows; every lane reads them */
+		const uint32_t wn = wtz_coop_bcast32(wins.n);
+		wtz_win_t *wa = (wtz_win_t*)(uintptr_t)wtz_coop_bcast64((uint64_t)(uintptr_t)wins.a);
+		int32_t *mem = NULL;
+		if(wn > 64u || WTZ_NLANES == 1u){
+			uint64_t pa = 0;
+			if(lane == 0) pa = (uint64_t)(uintptr_t)wtz_pool_alloc(V.pool, (size_t)wn * 8 + 8);
+			mem = (int32_t*)(uintptr_t)wtz_coop_bcast64(pa);
+			if(mem == NULL){ r.bad = 1; continue; }
+		}
+		r.ovl[dir] = WTZ_OVL29(wtz_chain_windows_wave(wa, wn, P->W, mem));
 		if(r.ovl[dir] < P->ztot) continue;
-		/* keep the chain members in place (compact to the front); their anchors[] keep indexing `anchors` */
-		uint32_t k = 0;
-		for(uint32_t j = 0; j < wins.n; j++){ if(wins.a[j].closed) continue; wins.a[k++] = wins.a[j]; }
-		r.nwin[dir] = k; r.win[dir] = wins.a; r.anchors[dir] = anchors.a; r.nanchors[dir] = anchors.n;
+		/* keep the chain members in place (compacted to the front); their anchors[] keep indexing `anchors` */
+		const uint32_t k = wtz_keep_chain_members(wa, wn);
+		r.nwin[dir] = k; r.win[dir] = wa; r.anchors[dir] = anchors.a; r.nanchors[dir] = anchors.n;
 		WTZ_PROF_ADD(62, ptc);
 	}
 	if(lane != 0) return;

@@ -3,10 +3,11 @@
  * detection and window chaining of the zmo engine (A7z).
  *
  *   wtz_zmatch            hzm_aln.h:173-224   query_single_read_seeds against the prebuilt tables
- *   wtz_median            hzm_aln.h:316-343   calculate_median_value
- *   wtz_scan_windows      hzm_aln.h:410-578   potential_paired_kmers_windows (fast chaining branch)
- *   wtz_merge_windows     hzm_aln.h:580-656   merge_paired_kmers_window
- *   wtz_chain_windows     hzm_aln.h:658-713   chaining_wtseedv
+ *   wtz_scan_windows_coop hzm_aln.h:410-578   potential_paired_kmers_windows (fast chaining branch; its median, hzm_aln.h:316-343, is a rank selection on the sorting network)
+ *   wtz_merge_windows_wave hzm_aln.h:580-656  merge_paired_kmers_window
+ *   wtz_chain_windows_wave hzm_aln.h:658-713  chaining_wtseedv
+ * Every body is wave-cooperative (one lane in the host emulation); round 6 removed the scalar restatements that used to sit behind "does not fit" branches
+ * (a range that fits neither the LDS slice nor a pool workspace means the pool is exhausted: the stage ends in WTZ_E_POOL and the host redoes the range).
  *
  * All ordering-sensitive steps use wtz_sort_exact (the reference's unstable sort) because
  * tie order leaks into the output (SURVEY §8a trap 1).  Integer promotions follow the
@@ -280,31 +281,6 @@ WTZ_D wtz_zhit_t *wtz_sort_hits_wave(const wtz_zhit_t *hits, uint32_t n, wtz_poo
 }
 #endif
 
-WTZ_HD int32_t wtz_median(int32_t *rs, int32_t size){
-	int32_t i, j, key, mid, beg, end, tmp;
-	if(size == 0) return 0;
-	beg = 0; end = size - 1;
-	while(beg < end){
-		mid = beg + (end - beg) / 2;
-		if(rs[beg] > rs[mid]){ tmp = rs[beg]; rs[beg] = rs[mid]; rs[mid] = tmp; }
-		if(rs[mid] > rs[end]){
-			tmp = rs[end]; rs[end] = rs[mid]; rs[mid] = tmp;
-			if(rs[beg] > rs[mid]){ tmp = rs[beg]; rs[beg] = rs[mid]; rs[mid] = tmp; }
-		}
-		key = rs[mid];
-		i = beg + 1; j = end - 1;
-		for(;;){
-			while(key > rs[i]) i++;
-			while(rs[j] > key) j--;
-			if(i < j){ tmp = rs[i]; rs[i] = rs[j]; rs[j] = tmp; i++; j--; }
-			else break;
-		}
-		if(i == j){ i++; j--; }
-		if(i <= size / 2) beg = i; else end = j;
-	}
-	return rs[size / 2];
-}
-
 /* scratch of one (pair,strand) window scan: all sized by the number of matches of the pair.  `lds` (may be NULL) is the
  * wave's LDS slice: the small order-sensitive sorts / the quick-select run there when they fit - they are chains of
  * dependent loads on a single lane, so it is the access latency (LDS ~64 clk vs L2 ~500 clk) that matters */
@@ -313,150 +289,6 @@ WTZ_HD int32_t wtz_median(int32_t *rs, int32_t size){
 /* `wf`, `wd` (n + 2 words each): the two per-match tables of the wave-parallel window merge (wtz_merge_prepare) */
 typedef struct { uint32_t *ts; int32_t *as; uint32_t *wb, *we, *wo; uint64_t *tk; wtz_zhit_t *ztmp; uint64_t *lds; uint32_t lds_u64; mutable uint64_t *big; mutable uint32_t big_u64; mutable uint32_t need_big; uint32_t *wf, *wd; } wtz_winscratch_t;
 struct wtz_gt_hi32 { WTZ_HDM bool operator()(uint64_t a, uint64_t b) const { return (uint32_t)(a >> 32) > (uint32_t)(b >> 32); } };
-
-WTZ_HD uint32_t wtz_scan_windows(const wtz_zhit_t *rs, uint32_t dir, uint32_t beg, uint32_t end, int32_t bound,
-		wtz_vec<wtz_win_t> &wins, wtz_vec<wtz_zhit_t> &anchors, const wtz_winscratch_t &sc, uint32_t zsize, uint32_t kwin, uint32_t zovl){
-	uint32_t i, j, n = 0, n2, ol, ol2, s, t, lst, ret;
-	while(beg < end){
-		if((ZH_STRAND(rs[beg]) ^ dir) || (int32_t)ZH_OFF1(rs[beg]) < bound) beg++;
-		else break;
-	}
-	for(i = beg; i < end; i++){ if(ZH_STRAND(rs[i]) ^ dir) continue; n++; }
-	if(n * zsize < zovl) return 0;
-	uint32_t *ts = sc.ts;
-	{   /* hzm_aln.h:449: indices ordered by off2 under the unstable sort.  Sorting (off2<<32 | index) words with a comparator
-	     * that looks at off2 only performs the same swaps as sorting the indices through the indirection */
-		uint64_t *tk = (sc.lds && n <= sc.lds_u64) ? sc.lds : sc.tk;
-		n = 0;
-		for(i = beg; i < end; i++){ if(ZH_STRAND(rs[i]) ^ dir) continue; tk[n++] = ((uint64_t)ZH_OFF2(rs[i]) << 32) | i; }
-		wtz_sort_exact(tk, (size_t)n, wtz_gt_hi32());
-		for(i = 0; i < n; i++) ts[i] = (uint32_t)tk[i];
-	}
-	ol = 0; lst = 0; n2 = 0;
-	for(i = j = 0; i < n; i++){
-		const wtz_zhit_t p = rs[ts[i]];
-		while(ZH_OFF2(p) + ZH_LEN2(p) > ZH_OFF2(rs[ts[j]]) + kwin){
-			const wtz_zhit_t p0 = rs[ts[j++]];
-			const wtz_zhit_t p1 = rs[ts[j]];
-			s = ZH_OFF2(p1); t = ZH_OFF2(p0) + ZH_LEN2(p0);
-			ol2 = s < t ? t - s : 0;
-			ol = ol + ol2 - ZH_LEN2(p0);
-		}
-		ol += (ZH_OFF2(p) > lst) ? ZH_LEN2(p) : ZH_OFF2(p) + ZH_LEN2(p) - lst;
-		lst = ZH_OFF2(p) + ZH_LEN2(p);
-		if(ol >= zovl){
-			if(n2 && ( ZH_OFF2(rs[ts[i]]) <= ZH_OFF2(rs[ts[sc.we[n2-1]]]) + kwin / 3 ||
-			           ZH_OFF2(rs[ts[j]]) <= ZH_OFF2(rs[ts[sc.wb[n2-1]]]) + kwin / 3 )){
-				if(ol > sc.wo[n2-1]){ sc.wb[n2-1] = j; sc.we[n2-1] = i; sc.wo[n2-1] = ol; }
-			} else { sc.wb[n2] = j; sc.we[n2] = i; sc.wo[n2] = ol; n2++; }
-		}
-	}
-	ret = 0;
-	for(i = 0; i < n2; i++){
-		const uint32_t size = anchors.n;
-		int32_t offset, off; uint32_t offn = 0;
-		int32_t *as = (sc.lds && (sc.we[i] - sc.wb[i] + 1) <= sc.lds_u64 * 2) ? (int32_t*)sc.lds : sc.as;
-		for(j = sc.wb[i]; j <= sc.we[i]; j++){ const wtz_zhit_t p = rs[ts[j]]; as[offn++] = (int32_t)ZH_OFF1(p) - (int32_t)ZH_OFF2(p); }
-		offset = wtz_median(as, (int32_t)offn);
-		ol = lst = 0;
-		for(j = sc.wb[i]; j <= sc.we[i]; j++){
-			const wtz_zhit_t p = rs[ts[j]];
-			off = (int32_t)ZH_OFF1(p) - (int32_t)ZH_OFF2(p);
-			if(off < offset - WTZ_KWIN_MAX_OFFSET_DEV || off > offset + WTZ_KWIN_MAX_OFFSET_DEV) continue;
-			if(!anchors.push(p)) return ret;
-			ol += (ZH_OFF2(p) > lst) ? ZH_LEN2(p) : ZH_OFF2(p) + ZH_LEN2(p) - lst;
-			lst = ZH_OFF2(p) + ZH_LEN2(p);
-		}
-		if(anchors.n == size) continue;
-		{   /* hzm_aln.h:519: anchors ordered by off1 under the unstable sort, done on (off1<<32 | position) words, then permuted */
-			const uint32_t cnt = anchors.n - size;
-			uint64_t *ak = (sc.lds && cnt <= sc.lds_u64) ? sc.lds : sc.tk;
-			for(uint32_t k = 0; k < cnt; k++){ ak[k] = ((uint64_t)ZH_OFF1(anchors.a[size + k]) << 32) | k; sc.ztmp[k] = anchors.a[size + k]; }
-			wtz_sort_exact(ak, (size_t)cnt, wtz_gt_hi32());
-			for(uint32_t k = 0; k < cnt; k++) anchors.a[size + k] = sc.ztmp[(uint32_t)ak[k]];
-		}
-		wtz_win_t w;
-		w.pb2 = 0; w.closed = 0; w.dir = (uint8_t)dir; w.pad = 0;
-		w.anchors[0] = size; w.anchors[1] = 0;
-		w.beg[0] = w.beg[1] = 0x7FFFFFFF; w.end[0] = w.end[1] = 0;
-		w.ovl = WTZ_OVL29(ol);
-		ol = lst = 0;
-		for(uint32_t k = size; k < anchors.n; k++){
-			const wtz_zhit_t p = anchors.a[k];
-			ol += (ZH_OFF1(p) > lst) ? ZH_LEN1(p) : ZH_OFF1(p) + ZH_LEN1(p) - lst;
-			lst = ZH_OFF1(p) + ZH_LEN1(p);
-			if((int32_t)ZH_OFF1(p) < w.beg[0]) w.beg[0] = (int32_t)ZH_OFF1(p);
-			if((int32_t)(ZH_OFF1(p) + ZH_LEN1(p)) > w.end[0]) w.end[0] = (int32_t)(ZH_OFF1(p) + ZH_LEN1(p));
-			if((int32_t)ZH_OFF2(p) < w.beg[1]) w.beg[1] = (int32_t)ZH_OFF2(p);
-			if((int32_t)(ZH_OFF2(p) + ZH_LEN2(p)) > w.end[1]) w.end[1] = (int32_t)(ZH_OFF2(p) + ZH_LEN2(p));
-		}
-		if(ol * 2 < zovl){
-			anchors.n = size;
-		} else if(ret && (w.end[1] <= (int32_t)((uint32_t)wins.a[wins.n - 1].end[1] + kwin / 3) && ol <= wins.a[wins.n - 1].ovl)){
-			anchors.n = size;
-		} else {
-			w.ovl = WTZ_OVL29(ol);
-			w.anchors[1] = anchors.n;
-			if(!wins.push(w)) return ret;        /* pool exhausted: only windows that ARE in the vector are counted (callers index wins.a[wins.n - ret ...]) */
-			ret++;
-		}
-	}
-	return ret;
-}
-
-/* rs must have one readable (zeroed) element past n_rs: the reference reads it too (hzm_aln.h:626) */
-WTZ_HD uint32_t wtz_merge_windows(const wtz_zhit_t *rs, uint32_t n_rs, uint32_t dir, wtz_vec<wtz_win_t> &wins, wtz_vec<wtz_zhit_t> &anchors,
-		const wtz_winscratch_t &sc, uint32_t zsize, uint32_t kwin, uint32_t kstep, uint32_t zovl){
-	const uint32_t P_off1 = 0x1FFFFFu, P_len1 = 0x3FFu;
-	uint32_t i, j, n, a, ol, ol2, lst, wlst, s, t, ret;
-	uint32_t p_off1, p_len1, p0_off1, p0_len1, p1_off1, p1_len1;
-	int32_t nxt;
-	ol = 0; lst = 0; wlst = 0; ret = 0;
-	for(j = 0; j < n_rs; j++){ if(ZH_STRAND(rs[j]) ^ dir) continue; break; }
-	if(j == n_rs) return 0;
-	p0_off1 = ZH_OFF1(rs[j]); p0_len1 = ZH_LEN1(rs[j]);
-	for(i = j; i <= n_rs; i++){
-		if(i < n_rs){ if(ZH_STRAND(rs[i]) ^ dir) continue; p_off1 = ZH_OFF1(rs[i]); p_len1 = ZH_LEN1(rs[i]); }
-		else { p_off1 = P_off1; p_len1 = P_len1; }
-		if(p_off1 > p0_off1 + kwin){
-			if(ol >= zovl){
-				if((n = wtz_scan_windows(rs, dir, j, i, (int32_t)wlst, wins, anchors, sc, zsize, kwin, zovl))){
-					for(a = 0; a < n; a++){
-						int32_t e0 = wins.a[wins.n + a - n].end[0] + 20;
-						if((int32_t)wlst < e0) wlst = (uint32_t)e0;
-					}
-					ret += n;
-					p0_off1 = p_off1; p0_len1 = p_len1; ol = p_len1; lst = p_off1 + p_len1; j = i;
-				} else {
-					nxt = (int32_t)(p0_off1 + kstep);
-					while((int32_t)p0_off1 < nxt && j < i){
-						++j; p1_off1 = ZH_OFF1(rs[j]); p1_len1 = ZH_LEN1(rs[j]);
-						s = WTZ_MAX(p0_off1, p1_off1);
-						t = WTZ_MIN(p0_off1 + p0_len1, p1_off1 + p1_len1);
-						ol2 = s < t ? t - s : 0;
-						ol = ol + ol2 - p0_len1;
-						p0_off1 = p1_off1; p0_len1 = p1_len1;
-					}
-				}
-			}
-			if(p_off1 == P_off1) break;          /* the sentinel, or a real match at 0x1FFFFF (hzm_aln.h:589,633) */
-			while(p_off1 > p0_off1 + kwin){
-				++j; p1_off1 = ZH_OFF1(rs[j]); p1_len1 = ZH_LEN1(rs[j]);
-				s = WTZ_MAX(p0_off1, p1_off1);
-				t = WTZ_MIN(p0_off1 + p0_len1, p1_off1 + p1_len1);
-				ol2 = s < t ? t - s : 0;
-				ol = ol + ol2 - p0_len1;
-				p0_off1 = p1_off1; p0_len1 = p1_len1;
-			}
-		} else {
-			if(p_off1 >= lst) ol += p_len1;
-			else if((int32_t)(p_off1 + p_len1) > (int32_t)lst) ol += p_off1 + p_len1 - lst;
-			else continue;
-			lst = p_off1 + p_len1;
-		}
-	}
-	return ret;
-}
 
 /*
  * Wave-cooperative form of the two functions above (same results).  What bounds a pair here is not arithmetic but the
@@ -766,7 +598,8 @@ WTZ_SCAN_FN uint32_t wtz_scan_windows_coop(const wtz_zhit_t *rs, uint32_t dir, u
 	/* ---- strand / bound filter (the prefix skip of hzm_aln.h:425-431 is the same predicate: off1 is non-decreasing) ---- */
 	constexpr uint32_t RC = 4;                         /* a range of up to RC matches per lane is read ONCE: count, early-exit bound and key fill run on the off2 values kept in registers */
 #ifndef WTZ_NO_SCAN_CACHE
-	const bool cached = (K != NULL) && (end - beg <= WTZ_NLANES * RC) && (sc.lds_u64 >= 64u);
+	/* ... and its ordering workspace (power of two >= 64 keys + two words per match + 2) fits the slice whatever the count turns out to be */
+	const bool cached = (K != NULL) && (end - beg <= WTZ_NLANES * RC) && (sc.lds_u64 >= (WTZ_NLANES * RC > 64u ? WTZ_NLANES * RC : 64u) + 2u * WTZ_NLANES * RC + 2u);
 #else
 	const bool cached = false;
 #endif
@@ -813,16 +646,6 @@ WTZ_SCAN_FN uint32_t wtz_scan_windows_coop(const wtz_zhit_t *rs, uint32_t dir, u
 			}
 		}
 #endif
-		uint32_t np0 = 64; while(np0 < n) np0 <<= 1;
-		if(np0 + 2 * n + 2 > sc.lds_u64){       /* does not fit: scalar body on lane 0 */
-			uint32_t r = 0; int32_t e = -0x7FFFFFFF;
-			if(lane == 0){
-				r = wtz_scan_windows(rs, dir, beg, end, bound, wins, anchors, sc, zsize, kwin, zovl);
-				for(uint32_t a = 0; a < r; a++){ const int32_t e0 = wins.a[wins.n + a - r].end[0]; if(e < e0) e = e0; }
-			}
-			*max_e0 = (int32_t)wtz_coop_bcast32((uint32_t)e);
-			return wtz_coop_bcast32(r);
-		}
 		uint32_t m = 0;
 		#pragma unroll
 		for(uint32_t c = 0; c < RC; c++){
@@ -922,14 +745,10 @@ WTZ_SCAN_FN uint32_t wtz_scan_windows_coop(const wtz_zhit_t *rs, uint32_t dir, u
 					*max_e0 = (int32_t)wtz_coop_bcast32((uint32_t)*max_e0);
 					return wtz_coop_bcast32(r);
 				}
-			} else {                                      /* no room in the pool either: scalar body on lane 0 */
-				uint32_t r = 0; int32_t e = -0x7FFFFFFF;
-				if(lane == 0){
-					r = wtz_scan_windows(rs, dir, beg, end, bound, wins, anchors, sc, zsize, kwin, zovl);
-					for(uint32_t a = 0; a < r; a++){ const int32_t e0 = wins.a[wins.n + a - r].end[0]; if(e < e0) e = e0; }
-				}
-				*max_e0 = (int32_t)wtz_coop_bcast32((uint32_t)e);
-				return wtz_coop_bcast32(r);
+			} else {                                      /* no room in the pool either: wtz_pool_alloc has flagged the pool, the stage ends in WTZ_E_POOL and the range is redone in halves */
+				if(lane == 0) wins.bad = 1;
+				*max_e0 = -0x7FFFFFFF;
+				return 0;
 			}
 		}
 	}
@@ -1133,31 +952,103 @@ WTZ_HD uint32_t wtz_merge_windows_wave(const wtz_zhit_t *rs, uint32_t n_rs, uint
 	return ret;
 }
 
-/* returns the chain weight; members get closed=0, the rest closed=1. mem: 2*n ints */
-WTZ_HD int32_t wtz_chain_windows(wtz_win_t *regs, uint32_t n, int32_t W, int32_t *mem){
-	const int32_t max_overhang = 0; const float band_penalty = 0.05f;
-	int32_t *weight = mem, *back = mem + n;
-	int32_t mw = -1000000, bt = -1, band;
-	for(uint32_t i = 0; i < n; i++){ weight[i] = 0; back[i] = -1; }
-	for(uint32_t i = 0; i < n; i++){
-		wtz_win_t *r1 = &regs[i];
-		r1->closed = 1;
-		weight[i] += (int32_t)r1->ovl;
-		if(weight[i] > mw){ mw = weight[i]; bt = (int32_t)i; }
-		for(uint32_t j = i + 1; j < n; j++){
-			const wtz_win_t *r2 = &regs[j];
-			if(r2->beg[1] + max_overhang < r1->end[1]) continue;
-			if(r2->beg[0] + max_overhang < r1->end[0]) continue;
-			if(r2->beg[0] - r1->end[0] > W && r2->beg[1] - r1->end[1] > W) break;
-			band = WTZ_ABSDIFF(r2->beg[0] - r1->end[0], r2->beg[1] - r1->end[1]);
-			if(band > W) continue;
-			band = (int32_t)((float)band * band_penalty);
-			if(weight[j] < weight[i] - band){ weight[j] = weight[i] - band; back[j] = (int32_t)i; }
+/* ---------------------------------------------------------------------------------------------------------------------------------------------------
+ * The window chain of a strand on the whole wavefront (round 6; chaining_wtseedv, hzm_aln.h:658-713).
+ * Window i - once its own weight is final - hands  weight_i - 0.05 * |gap0 - gap1|  on to every LATER window j that starts behind its end on both axes with a
+ * diagonal shift of at most W, and the reference's loop over j STOPS at the first j that lies more than W behind i on BOTH axes (hzm_aln.h:687; windows in front
+ * of that j that lie beyond W on one axis only are skipped by the band test, not by the stop).  Nothing about that needs the loop: with one window per lane the
+ * stop is the first set bit of a ballot, the lanes in front of it update their own weight / predecessor, and window i's end and weight are read from its lane
+ * (v_readlane: i is the scalar loop counter).  The sequential remainder is the reference's own dependence - n steps over i, a window's weight must be final
+ * before it is handed on - instead of n^2 / 2 dependent loads on lane 0 (round 5: `if(lane != 0) continue; wtz_chain_windows(...)`).
+ * Entered by every lane with uniform arguments.  Returns the chain's length on the query axis (uniform); chain members get closed = 0, all others 1.
+ * More than 64 windows of one strand (a read covered for > 50 kb): the same steps with the per-window state in `st` (2 n words) and the windows read from the
+ * pool 64 at a time; the host emulation (one lane) always takes this form.
+ * --------------------------------------------------------------------------------------------------------------------------------------------------- */
+WTZ_HD int32_t wtz_chain_windows_wave(wtz_win_t *wins, uint32_t n, int32_t W, int32_t *st){
+	const uint32_t lane = WTZ_LANE;
+	const float shift_cost = 0.05f;                            /* band_penalty, hzm_aln.h:665; the product is truncated to int (hzm_aln.h:690) */
+#if defined(__HIP_DEVICE_COMPILE__)
+	if(n <= 64u){
+		const bool mine = lane < n;
+		int32_t qb = 0, qe = 0, tb = 0, te = 0, own = 0;
+		if(mine){ qb = wins[lane].beg[0]; qe = wins[lane].end[0]; tb = wins[lane].beg[1]; te = wins[lane].end[1]; own = (int32_t)wins[lane].ovl; }
+		int32_t acc = 0, pred = -1;                             /* weight handed to this lane's window so far, and by whom */
+		int32_t top = -1000000, top_at = -1;
+		for(uint32_t i = 0; i < n; i++){
+			const int32_t wi = __builtin_amdgcn_readlane(acc, (int)i) + __builtin_amdgcn_readlane(own, (int)i);
+			if(wi > top){ top = wi; top_at = (int32_t)i; }
+			const int32_t g0 = qb - __builtin_amdgcn_readlane(qe, (int)i), g1 = tb - __builtin_amdgcn_readlane(te, (int)i);
+			const bool later = mine && lane > i;
+			const unsigned long long far = __ballot(later && g0 > W && g1 > W);
+			const uint32_t stop_at = far ? (uint32_t)__builtin_ctzll(far) : 64u;
+			if(later && lane < stop_at && g0 >= 0 && g1 >= 0){
+				const int32_t shift = g0 > g1 ? g0 - g1 : g1 - g0;
+				if(shift <= W){
+					const int32_t offer = wi - (int32_t)((float)shift * shift_cost);
+					if(acc < offer){ acc = offer; pred = (int32_t)i; }
+				}
+			}
 		}
+		unsigned long long chain = 0ull; int32_t span = 0;
+		for(int32_t k = top_at; k >= 0; k = __builtin_amdgcn_readlane(pred, k)){
+			chain |= 1ull << k;
+			span += __builtin_amdgcn_readlane(qe, k) - __builtin_amdgcn_readlane(qb, k);
+		}
+		if(mine) wins[lane].closed = ((chain >> lane) & 1ull) ? 0 : 1;
+		WTZ_WAVE_SYNC();
+		return span;
 	}
-	mw = 0;
-	while(bt >= 0){ wtz_win_t *r1 = &regs[bt]; r1->closed = 0; mw += r1->end[0] - r1->beg[0]; bt = back[bt]; }
-	return mw;
+#endif
+	int32_t *acc = st, *pred = st + n;
+	for(uint32_t j = lane; j < n; j += WTZ_NLANES){ acc[j] = 0; pred[j] = -1; wins[j].closed = 1; }
+	WTZ_WAVE_SYNC();
+	int32_t top = -1000000, top_at = -1;
+	for(uint32_t i = 0; i < n; i++){
+		const int32_t wi = (int32_t)wtz_coop_bcast32((uint32_t)(acc[i] + (int32_t)wins[i].ovl));
+		const int32_t qe = (int32_t)wtz_coop_bcast32((uint32_t)wins[i].end[0]), te = (int32_t)wtz_coop_bcast32((uint32_t)wins[i].end[1]);
+		if(wi > top){ top = wi; top_at = (int32_t)i; }
+		for(uint32_t j0 = i + 1; j0 < n; j0 += WTZ_NLANES){
+			const uint32_t j = j0 + lane; const bool mine = j < n;
+			int32_t g0 = 0, g1 = 0;
+			if(mine){ g0 = wins[j].beg[0] - qe; g1 = wins[j].beg[1] - te; }
+			const unsigned long long far = wtz_coop_ballot(mine && g0 > W && g1 > W);
+			const uint32_t stop_at = far ? wtz_coop_first_lane(far) : WTZ_NLANES;
+			if(mine && lane < stop_at && g0 >= 0 && g1 >= 0){
+				const int32_t shift = g0 > g1 ? g0 - g1 : g1 - g0;
+				if(shift <= W){
+					const int32_t offer = wi - (int32_t)((float)shift * shift_cost);
+					if(acc[j] < offer){ acc[j] = offer; pred[j] = (int32_t)i; }
+				}
+			}
+			if(far) break;
+		}
+		WTZ_WAVE_SYNC();                                         /* the updates of this step are visible to the uniform reads of the next */
+	}
+	int32_t span = 0;
+	for(int32_t k = top_at; k >= 0; k = (int32_t)wtz_coop_bcast32((uint32_t)pred[k])){
+		if(lane == 0) wins[k].closed = 0;
+		span += (int32_t)wtz_coop_bcast32((uint32_t)(wins[k].end[0] - wins[k].beg[0]));
+	}
+	WTZ_WAVE_SYNC();
+	return span;
+}
+
+/* the chain members moved to the front of the array in their order (64 at a time: every lane reads its window before any lane writes; a group writes at or in
+ * front of its own first slot, never into a group that has not been read); returns their number (uniform) */
+WTZ_HD uint32_t wtz_keep_chain_members(wtz_win_t *wins, uint32_t n){
+	const uint32_t lane = WTZ_LANE;
+	uint32_t k = 0;
+	for(uint32_t j0 = 0; j0 < n; j0 += WTZ_NLANES){
+		const uint32_t j = j0 + lane;
+		wtz_win_t w; bool keep = false;
+		if(j < n){ w = wins[j]; keep = !w.closed; }
+		uint32_t tot; const uint32_t at = wtz_coop_rank(keep, &tot);
+		WTZ_WAVE_SYNC();
+		if(keep) wins[k + at] = w;
+		k += tot;
+		WTZ_WAVE_SYNC();
+	}
+	return k;
 }
 
 /* result of one (query, candidate) pair; the window/anchor arrays live in the pool until the next stage reset */

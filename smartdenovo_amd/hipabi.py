@@ -17,7 +17,7 @@ SYMBOLS = [
     "wtz_last_error", "wtz_device_count", "wtz_device_memory", "wtz_ctx_create", "wtz_ctx_destroy", "wtz_ctx_clone", "wtz_upload_reads",
     "wtz_index_build", "wtz_zindex_build", "wtz_candidates", "wtz_candidates_begin", "wtz_candidates_end", "wtz_batch_begin", "wtz_pairs_seed",
     "wtz_pairs_windows", "wtz_pairs_align", "wtz_fetch_cigars", "wtz_fetch_cigar_text", "wtz_fetch_cigar_text_begin", "wtz_fetch_cigar_text_end", "wtz_cigar_text_device", "wtz_host_alloc", "wtz_host_free", "wtz_get_counters", "wtz_reset_counters",
-    "wtz_test_dp", "wtz_extend_batch", "wtz_pool_info",
+    "wtz_test_dp", "wtz_extend_batch", "wtz_pool_info", "wtz_pool_failure_kind",
     "wtz_index_count", "wtz_index_counts_fetch", "wtz_index_finish", "wtz_candidate_groups_begin", "wtz_candidate_groups_end", "wtz_candidate_groups_fetch", "wtz_cand_tail_host", "wtz_zindex_build_subset", "wtz_zindex_build_queries", "wtz_upload_reads_ascii", "wtz_fetch_read_bits", "wtz_append_revcomp_views",
 ]
 
