@@ -340,6 +340,11 @@ def main():
     n_ranges, n_split = (int(last[20]), int(last[21])) if len(last) > 21 else (0, 0)
     zmer_bytes = int(last[22]) if len(last) > 22 else 0
     ing_ms, ing_bytes = (float(last[23]), int(last[24])) if len(last) > 24 else (0.0, 0)
+    host_s = None
+    if len(last) > 32:      # host seconds of the last step: what tools/design_numbers.py builds the N = 8 budget of DESIGN section 7 from
+        host_s = {"wall": float(last[2]), "index_builds": float(last[3]), "device_stage_calls": float(last[25]), "commit": float(last[26]),
+                  "commit_sections": {"rows_closed_filter_order": float(last[27]), "window_depth_seed_weights": float(last[28]), "hits": float(last[29]), "plan_pairs": float(last[30])},
+                  "batches": int(last[31]), "ranges": n_ranges, "queries_planned": int(last[32]), "queries_used": int(last[17])}
 
     def valu_roofline(kernel, cells, ms_k, extra=None):
         ach = cells * OPS_PER_CELL / (ms_k * 1e-3) / 1e12 if ms_k > 0 else None
@@ -361,6 +366,7 @@ def main():
                    "scratch": "%d batch ranges planned to the pool, %d split after a pool overflow" % (n_ranges, n_split)},
         "pairs_per_step": n_pairs // K, "pair_bp_per_step": pair_bp // K, "records_last_step": int(last[14]),
         "kernel_ms_last_step": dict(ms, ksw3_wave=ms_ext, ksw2_gap=ms_gap),
+        "host_seconds_last_step": host_s,
         "roofline": valu_roofline("K-sw3 shifting-band extension (kswx_extend_align_shift_core), DP rows in registers in the anti-diagonal frame (wtz_sw_frame.h): wtz_kernel_stitch_ext_fr - both end "
                                   "extensions of a stitched overlap and the join between them on one wavefront (wtz_stitch_fused.h) -, wtz_kernel_extjobs_fr where that launch declines, wtz_kernel_extjobs for what is outside the frame form's envelope; time = HIP events around the launches of the stage",
                                   cells_shift, ms_ext, {"backtrack_GBps": cells_shift / (ms_ext * 1e-3) / 1e9 if ms_ext > 0 else None}),

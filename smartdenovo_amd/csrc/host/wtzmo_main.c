@@ -101,6 +101,7 @@ typedef struct eng_s {
 	void *cq_cand; size_t cq_capcand; void *cq_seeds; size_t cq_capseeds; uint16_t *cq_dep; size_t cq_capdep;
 	/* stats */
 	char *cig_keep[16]; uint64_t cig_keep_cap[16];      /* page-locked CIGAR text buffer of worker w, kept across steps (pinning is the expensive part) */
+	double t_cq1[4];            /* section 1 of commit_query in its parts: window marks | running depth | seed weights | seed order */
 	double t_cq[4];             /* commit_query sections: candidate rows + closed filter + sort | window depth + seed weights + sort | hits (gates, queueing, masking) | plan_pairs */
 	double t_gpu, t_commit, t_zbatch, t_call[6], t_io[2];      /* t_io: waiting for the writer thread before a text buffer is reused / at the end of the run */      /* t_call: wall seconds inside wtz_candidates / pairs_seed / pairs_windows / pairs_align / fetch_cigar_text / planning */
 	uint64_t spec_pairs, used_pairs, spec_items, used_items, spec_queries, used_queries, n_batches;
@@ -146,6 +147,7 @@ enum { WTZ_ST_OK = 0, WTZ_ST_AGAIN = 1, WTZ_ST_FAILED = 2 };
  * of that residue class only (1 / nparts of the build) plus a small query-side index of the batch's queries (wtz_zindex_build_queries). */
 typedef struct {
 	wtz_ctx_t *ctx; int remote;                 /* remote > 0: the part is computed by that rank (ctx == NULL here) */
+	uint8_t *xbuf; uint64_t xcap;              /* ranks: staging of one packed message (round 6: a request is ONE message, a reply a status word + ONE message + the CIGAR text) */
 	uint32_t *pq, *pc; uint32_t npair, cappair;
 	wtz_pair_summary_t *sum; uint64_t *box_off; wtz_winbox_t *boxes; uint64_t nbox, capbox;
 	uint32_t *item_of; uint32_t *it_pair; uint8_t *it_dir; uint32_t nitem; wtz_aln_result_t *aln; char *cig; uint64_t ncig;
@@ -585,8 +587,10 @@ static void commit_query(eng_t *E, batch_t *b, uint32_t slot){
 		const uint32_t dir = (S->ovl[0] < S->ovl[1]);
 		if(S->ovl[dir] >= P->ztot){ seed_t s; s.pb2 = id2; s.dir = dir; s.ovl = S->ovl[dir]; s.closed = 0; s.pidx = cand[i].pidx; seeds[nseed++] = s; }
 	}
+	const double tqa = now_s(); E->t_cq1[0] += tqa - tq1;
 	/* running depth over the span of the marks (it is zero outside: every interval is closed); arithmetic modulo 2^16 like the reference's u2i counters */
 	if(dep_lo < dep_hi) depth_prefix_u16(windeps, (size_t)(dep_lo & ~7), (size_t)dep_hi + 1);
+	const double tqb = now_s(); E->t_cq1[1] += tqb - tqa;
 	/* repeat weighting: the reference fills weights[0..alen) (wtzmo.c:933-936) but only reads the entry at the middle of each
 	 * window (954): evaluated on demand by rep_weight() with the same float/double mix */
 	for(uint32_t i = 0; i < nseed; i++){
@@ -606,8 +610,9 @@ static void commit_query(eng_t *E, batch_t *b, uint32_t slot){
 		s->ovl = ol & 0x1FFFFFFFu;
 		if(ol * P->win_rep_cutoff < P->ztot * P->win_rep_norm) s->closed = 1;                 /* wtzmo.c:964 */
 	}
+	const double tqc = now_s(); E->t_cq1[2] += tqc - tqb;
 	hx_sort_exact(seeds, nseed, sizeof(seed_t), gt_seed, NULL);
-	const double tq2 = now_s(); E->t_cq[1] += tq2 - tq1;
+	const double tq2 = now_s(); E->t_cq[1] += tq2 - tq1; E->t_cq1[3] += tq2 - tqc;
 	if(!E->do_align){
 		if(pd->capseed < nseed){ pd->capseed = nseed; pd->seeds = (seed_t*)hx_realloc(pd->seeds, sizeof(seed_t) * nseed); }
 		memcpy(pd->seeds, seeds, sizeof(seed_t) * nseed); pd->nseed = nseed;
@@ -801,13 +806,24 @@ static int rank_fail_injected(void){
 	return 1;
 }
 
+static uint8_t *part_xbuf(part_t *pt, uint64_t n){
+	if(n > pt->xcap){ pt->xcap = n + n / 4 + 4096; pt->xbuf = (uint8_t*)hx_realloc(pt->xbuf, pt->xcap); }
+	return pt->xbuf;
+}
 /* rank 0: part r of the range is computed by rank r (part 0 here, meanwhile) */
 static int gpu_stages_ranks(eng_t *E, batch_t *b){
 	const int dm = E->P.dot_matrix;
 	wtz_dist_hdr_t h; memset(&h, 0, sizeof h); h.cmd = WTZ_CMD_PAIRS;
 	for(uint32_t r = 0; r < b->nparts; r++) h.count[r] = b->parts[r].npair;
 	g_dist.bcast(&h, sizeof h);
-	for(uint32_t r = 1; r < b->nparts; r++){ part_t *pt = &b->parts[r]; if(pt->npair){ g_dist.send(pt->pq, 4 * (uint64_t)pt->npair, (int)r); g_dist.send(pt->pc, 4 * (uint64_t)pt->npair, (int)r); } }
+	for(uint32_t r = 1; r < b->nparts; r++){
+		part_t *pt = &b->parts[r];
+		if(pt->npair){      /* queries | candidates in one message */
+			uint8_t *x = part_xbuf(pt, 8 * (uint64_t)pt->npair);
+			memcpy(x, pt->pq, 4 * (size_t)pt->npair); memcpy(x + 4 * (size_t)pt->npair, pt->pc, 4 * (size_t)pt->npair);
+			g_dist.send(x, 8 * (uint64_t)pt->npair, (int)r);
+		}
+	}
 	b->parts[0].E = E;
 	int st = b->parts[0].again = rank_fail_injected() ? WTZ_ST_FAILED : part_stages(E, &b->parts[0]);
 	int failed = st == WTZ_ST_FAILED ? 0 : -1;      /* the rank that failed (its replies still complete the round) */
@@ -818,8 +834,14 @@ static int gpu_stages_ranks(eng_t *E, batch_t *b){
 		if(rh[0] == WTZ_ST_FAILED){ if(failed < 0) failed = (int)r; continue; }
 		if(rh[0]){ if(st == WTZ_ST_OK) st = WTZ_ST_AGAIN; continue; }
 		if(pt->npair == 0) continue;
+		/* the reply proper: summaries | window boxes | alignment results in ONE message whose size the status word's counts give (round 5: three messages);
+		 * the CIGAR text follows as a message of its own - it comes straight out of the peer's device memory */
+		const uint64_t nb_r = dm ? 0 : rh[1], ni_r = dm ? 0 : rh[2];
+		const uint64_t sz_sum = sizeof(wtz_pair_summary_t) * (uint64_t)pt->npair, sz_box = sizeof(wtz_winbox_t) * nb_r, sz_aln = sizeof(wtz_aln_result_t) * ni_r;
+		uint8_t *x = part_xbuf(pt, sz_sum + sz_box + sz_aln);
+		g_dist.recv(x, sz_sum + sz_box + sz_aln, (int)r);
 		pt->sum = (wtz_pair_summary_t*)hx_realloc(pt->sum, sizeof(wtz_pair_summary_t) * (pt->npair + 1));
-		g_dist.recv(pt->sum, sizeof(wtz_pair_summary_t) * (uint64_t)pt->npair, (int)r);
+		memcpy(pt->sum, x, sz_sum);
 		if(dm) continue;
 		pt->box_off = (uint64_t*)hx_realloc(pt->box_off, 8 * ((size_t)pt->npair * 2 + 1));
 		uint64_t nb = 0;
@@ -827,12 +849,12 @@ static int gpu_stages_ranks(eng_t *E, batch_t *b){
 		pt->box_off[(size_t)pt->npair * 2] = nb; pt->nbox = nb;
 		if(nb != rh[1]){ fprintf(stderr, " -- rank %u reports %llu windows, its summaries say %llu --\n", r, (unsigned long long)rh[1], (unsigned long long)nb); DIE_NOW(); }
 		if(nb > pt->capbox){ pt->capbox = nb; pt->boxes = (wtz_winbox_t*)hx_realloc(pt->boxes, sizeof(wtz_winbox_t) * nb); }
-		if(nb) g_dist.recv(pt->boxes, sizeof(wtz_winbox_t) * nb, (int)r);
+		if(nb) memcpy(pt->boxes, x + sz_sum, sz_box);
 		part_plan_items(E, pt);
 		if(pt->nitem != rh[2]){ fprintf(stderr, " -- rank %u aligned %llu items, the plan has %u --\n", r, (unsigned long long)rh[2], pt->nitem); DIE_NOW(); }
 		if(pt->nitem){
 			pt->aln = (wtz_aln_result_t*)hx_realloc(pt->aln, sizeof(wtz_aln_result_t) * pt->nitem);
-			g_dist.recv(pt->aln, sizeof(wtz_aln_result_t) * (uint64_t)pt->nitem, (int)r);
+			memcpy(pt->aln, x + sz_sum + sz_box, sz_aln);
 			if(!part_text_buffer(pt, rh[3])) DIE_NOW();
 			if(rh[3]) g_dist.recv(pt->cig, rh[3], (int)r);
 			pt->ncig = rh[3];
@@ -865,7 +887,7 @@ static void remote_loop(eng_t *E, part_t *pt){
 		const uint32_t n = (uint32_t)h.count[me];
 		if(h.cmd == WTZ_CMD_PAIRS){
 			if(n > pt->cappair){ pt->cappair = n; pt->pq = (uint32_t*)hx_realloc(pt->pq, 4 * (size_t)n); pt->pc = (uint32_t*)hx_realloc(pt->pc, 4 * (size_t)n); }
-			if(n){ g_dist.recv(pt->pq, 4 * (uint64_t)n, 0); g_dist.recv(pt->pc, 4 * (uint64_t)n, 0); }
+			if(n){ uint8_t *x = part_xbuf(pt, 8 * (uint64_t)n); g_dist.recv(x, 8 * (uint64_t)n, 0); memcpy(pt->pq, x, 4 * (size_t)n); memcpy(pt->pc, x + 4 * (size_t)n, 4 * (size_t)n); }
 			pt->npair = n;
 			if(rank_fail_injected()) failed = 1;
 			const int again = failed ? WTZ_ST_FAILED : part_stages(E, pt);
@@ -874,13 +896,13 @@ static void remote_loop(eng_t *E, part_t *pt){
 			if(n == 0 || dm || again){ rh[1] = 0; rh[2] = 0; rh[3] = 0; }
 			g_dist.send(rh, sizeof rh, 0);
 			if(again || n == 0) continue;
-			g_dist.send(pt->sum, sizeof(wtz_pair_summary_t) * (uint64_t)n, 0);
-			if(dm) continue;
-			if(pt->nbox) g_dist.send(pt->boxes, sizeof(wtz_winbox_t) * pt->nbox, 0);
-			if(pt->nitem){
-				g_dist.send(pt->aln, sizeof(wtz_aln_result_t) * (uint64_t)pt->nitem, 0);
-				if(pt->ncig){ if(g_dist.send_dev) g_dist.send_dev(pt->cig_dev, pt->ncig, 0); else g_dist.send(pt->cig, pt->ncig, 0); }
+			{
+				const uint64_t sz_sum = sizeof(wtz_pair_summary_t) * (uint64_t)n, sz_box = dm ? 0 : sizeof(wtz_winbox_t) * pt->nbox, sz_aln = dm ? 0 : sizeof(wtz_aln_result_t) * (uint64_t)pt->nitem;
+				uint8_t *x = part_xbuf(pt, sz_sum + sz_box + sz_aln);
+				memcpy(x, pt->sum, sz_sum); if(sz_box) memcpy(x + sz_sum, pt->boxes, sz_box); if(sz_aln) memcpy(x + sz_sum + sz_box, pt->aln, sz_aln);
+				g_dist.send(x, sz_sum + sz_box + sz_aln, 0);
 			}
+			if(!dm && pt->nitem && pt->ncig){ if(g_dist.send_dev) g_dist.send_dev(pt->cig_dev, pt->ncig, 0); else g_dist.send(pt->cig, pt->ncig, 0); }
 		} else if(h.cmd == WTZ_CMD_ZIDX){
 			const uint32_t nql = (uint32_t)h.arg[0]; const int have_c = h.arg[1] != 0;
 			uint32_t *ql = (uint32_t*)hx_realloc(NULL, 4 * ((size_t)nql + 1)), *cl = (uint32_t*)hx_realloc(NULL, 4 * ((size_t)n + 1));
@@ -895,8 +917,13 @@ static void remote_loop(eng_t *E, part_t *pt){
 			if(!failed){ int rc = wtz_candidates_begin(pt->ctx, pt->cq_ids, n, pt->cq_rows, pt->cq_nr); REMOTE_TRY(rc, "wtz_candidates_begin"); }
 		} else if(h.cmd == WTZ_CMD_CAND_END){
 			if(!failed){ int rc = wtz_candidates_end(pt->ctx, pt->cq_rows, pt->cq_nr); REMOTE_TRY(rc, "wtz_candidates_end"); }
-			uint64_t st = failed ? WTZ_ST_FAILED : WTZ_ST_OK; g_dist.send(&st, 8, 0);
-			if(!failed && pt->cq_n){ g_dist.send(pt->cq_rows, (uint64_t)pt->cq_n * E->stride * 8, 0); g_dist.send(pt->cq_nr, 4 * (uint64_t)pt->cq_n, 0); }
+			{   /* status | rows | counts in one message of a size rank 0 knows (a failed rank sends the same size with the status set) */
+				const uint64_t sz_rows = (uint64_t)pt->cq_n * E->stride * 8, sz_nr = 4 * (uint64_t)pt->cq_n;
+				uint8_t *x = part_xbuf(pt, 8 + sz_rows + sz_nr);
+				const uint64_t st = failed ? WTZ_ST_FAILED : WTZ_ST_OK; memcpy(x, &st, 8);
+				if(pt->cq_n){ memcpy(x + 8, pt->cq_rows, sz_rows); memcpy(x + 8 + sz_rows, pt->cq_nr, sz_nr); }
+				g_dist.send(x, 8 + sz_rows + sz_nr, 0);
+			}
 		} else if(h.cmd == WTZ_CMD_GRP_BEGIN){
 			/* sharded index: every rank answers every query of the request with the groups of its shard */
 			const uint32_t nq = (uint32_t)h.count[0];
@@ -912,10 +939,12 @@ static void remote_loop(eng_t *E, part_t *pt){
 				gr = (uint64_t*)hx_realloc(NULL, 8 * (tot + 1));
 				int rc = wtz_candidate_groups_fetch(pt->ctx, gr, tot); REMOTE_TRY(rc, "wtz_candidate_groups_fetch");
 			}
-			uint64_t st = failed ? WTZ_ST_FAILED : WTZ_ST_OK; g_dist.send(&st, 8, 0);
-			if(!failed){
-				if(pt->cq_n) g_dist.send(pt->cq_nr, 4 * (uint64_t)pt->cq_n, 0);
-				if(tot) g_dist.send(gr, 8 * tot, 0);
+			{   /* status | group counts in one message of a known size, then the groups */
+				uint8_t *x = part_xbuf(pt, 8 + 4 * (uint64_t)pt->cq_n);
+				const uint64_t st = failed ? WTZ_ST_FAILED : WTZ_ST_OK; memcpy(x, &st, 8);
+				if(pt->cq_n){ if(failed) memset(x + 8, 0, 4 * (size_t)pt->cq_n); else memcpy(x + 8, pt->cq_nr, 4 * (size_t)pt->cq_n); }
+				g_dist.send(x, 8 + 4 * (uint64_t)pt->cq_n, 0);
+				if(!failed && tot) g_dist.send(gr, 8 * tot, 0);
 			}
 			free(gr);
 		} else { fprintf(stderr, " -- rank %d: unknown request %llu --\n", me, (unsigned long long)h.cmd); DIE_NOW(); }
@@ -1054,10 +1083,10 @@ static void shard_candidates_end(eng_t *E, uint32_t n, uint64_t *rows, uint32_t 
 	for(uint32_t d = 0; d < N; d++){
 		ng[d] = (uint32_t*)hx_realloc(NULL, 4 * ((size_t)n + 1));
 		if(ranks && d){
-			uint64_t st = 0; g_dist.recv(&st, 8, (int)d);
+			uint64_t st = 0;
+			{ uint8_t *x = (uint8_t*)hx_realloc(NULL, 8 + 4 * (size_t)n); g_dist.recv(x, 8 + 4 * (uint64_t)n, (int)d); memcpy(&st, x, 8); if(n) memcpy(ng[d], x + 8, 4 * (size_t)n); free(x); }
 			tot[d] = 0; gr[d] = NULL;
 			if(st != WTZ_ST_OK){ if(failed < 0) failed = (int)d; memset(ng[d], 0, 4 * ((size_t)n + 1)); continue; }
-			if(n) g_dist.recv(ng[d], 4 * (uint64_t)n, (int)d);
 			for(uint32_t k = 0; k < n; k++) tot[d] += ng[d][k];
 			gr[d] = (uint64_t*)hx_realloc(NULL, 8 * (tot[d] + 1));
 			if(tot[d]) g_dist.recv(gr[d], 8 * tot[d], (int)d);
@@ -1478,9 +1507,12 @@ static int batch_form(batch_t *b){
 			part_t *pt = &b->parts[d];
 			if(d == 0 && g_dist.world > 1){ wtz_dist_hdr_t h; memset(&h, 0, sizeof h); h.cmd = WTZ_CMD_CAND_END; g_dist.bcast(&h, sizeof h); }
 			if(pt->remote){
-				uint64_t st = 0; g_dist.recv(&st, 8, pt->remote);
+				const uint64_t sz_rows = (uint64_t)pt->cq_n * E->stride * 8, sz_nr = 4 * (uint64_t)pt->cq_n;
+				uint8_t *x = part_xbuf(pt, 8 + sz_rows + sz_nr);
+				g_dist.recv(x, 8 + sz_rows + sz_nr, pt->remote);
+				uint64_t st = 0; memcpy(&st, x, 8);
 				if(st != WTZ_ST_OK){ if(cand_failed < 0) cand_failed = pt->remote; continue; }
-				if(pt->cq_n){ g_dist.recv(pt->cq_rows, (uint64_t)pt->cq_n * E->stride * 8, pt->remote); g_dist.recv(pt->cq_nr, 4 * (uint64_t)pt->cq_n, pt->remote); }
+				if(pt->cq_n){ memcpy(pt->cq_rows, x + 8, sz_rows); memcpy(pt->cq_nr, x + 8 + sz_rows, sz_nr); }
 			} else {
 				rc = wtz_candidates_end(pt->ctx, pt->cq_rows, pt->cq_nr);
 				if(rc != WTZ_OK && g_dist.world > 1){ fprintf(stderr, " -- rank 0: wtz_candidates_end failed: %s --\n", wtz_last_error()); if(cand_failed < 0) cand_failed = 0; continue; }
@@ -1853,7 +1885,7 @@ int main(int argc, char **argv){
 			for(size_t i = 0; i < nclosed0; i++) hx_set_put(&E->closed, closed0[i]);
 			E->n_order = n_order0;
 			E->pair_bp = E->n_pairs = E->nrec = 0;
-			memset(E->t_cq, 0, sizeof E->t_cq); E->t_gpu = E->t_commit = E->t_zbatch = 0; memset(E->t_call, 0, sizeof E->t_call); E->t_io[0] = E->t_io[1] = 0; E->spec_pairs = E->used_pairs = E->spec_items = E->used_items = E->spec_queries = E->used_queries = 0;
+			memset(E->t_cq, 0, sizeof E->t_cq); memset(E->t_cq1, 0, sizeof E->t_cq1); E->t_gpu = E->t_commit = E->t_zbatch = 0; memset(E->t_call, 0, sizeof E->t_call); E->t_io[0] = E->t_io[1] = 0; E->spec_pairs = E->used_pairs = E->spec_items = E->used_items = E->spec_queries = E->used_queries = 0;
 			E->rows_all = 0; E->n_batches = 0; E->n_split = 0; E->n_ranges = 0; E->bytes_per_pair = 0;      /* every repeat plans like a cold run: probe range first */
 			E->pend.rd_id = 0xFFFFFFFFu; E->pend.nhit = E->pend.nmask = E->pend.nclosed = E->pend.nseed = 0;
 			if(strcmp(output, "-")){
@@ -2011,15 +2043,17 @@ int main(int argc, char **argv){
 		fprintf(stderr, "[wtzmo-mi355x] %llu records, %llu pairs aligned, %llu pair-bp, %.3f s (index %.3f s)\n", (unsigned long long)E->nrec, (unsigned long long)E->n_pairs, (unsigned long long)E->pair_bp, t1 - t0, t_index);
 		fprintf(stderr, "[wtzmo-mi355x] host seconds: in GPU-stage calls %.3f, commit %.3f, per-batch z-index %.3f; writer thread: formatting %.3f, write %.3f; waiting for it: %.3f before buffer reuse, %.3f at the end\n", E->t_gpu, E->t_commit, E->t_zbatch, g_ow.t_format, g_ow.t_write, E->t_io[0], E->t_io[1]);
 		fprintf(stderr, "[wtzmo-mi355x] commit sections: candidate rows + closed filter + order %.3f, window depth + seed weights %.3f, hits %.3f; planning the pairs of the ranges %.3f\n", E->t_cq[0], E->t_cq[1], E->t_cq[2], E->t_cq[3]);
+		fprintf(stderr, "[wtzmo-mi355x] window depth + seed weights in parts: window marks %.3f, running depth %.3f, seed weights %.3f, seed order %.3f\n", E->t_cq1[0], E->t_cq1[1], E->t_cq1[2], E->t_cq1[3]);
 		fprintf(stderr, "[wtzmo-mi355x] wall seconds per call: candidates %.3f pairs_seed %.3f pairs_windows %.3f pairs_align %.3f cigar_text %.3f\n", E->t_call[0], E->t_call[1], E->t_call[2], E->t_call[3], E->t_call[4]);
 	if(E->n_split) fprintf(stderr, "[wtzmo-mi355x] %llu range(s) had to be split after a scratch-pool overflow (planned at %.0f KB per pair)\n", (unsigned long long)E->n_split, E->bytes_per_pair / 1024.0);
 	fprintf(stderr, "[wtzmo-mi355x] %llu batches in %llu ranges on %u worker context(s); speculation: queries %llu/%llu pairs %llu/%llu alignments %llu/%llu (used/planned)\n",
 			(unsigned long long)E->n_batches, (unsigned long long)E->n_ranges, E->rows_all ? 1u : E->n_workers, (unsigned long long)E->used_queries, (unsigned long long)E->spec_queries, (unsigned long long)E->used_pairs, (unsigned long long)E->spec_pairs, (unsigned long long)E->used_items, (unsigned long long)E->spec_items);
 		fprintf(stderr, "[wtzmo-mi355x] kernel ms: index %.1f zindex %.1f candidates %.1f pairs %.1f winalign %.1f stitch %.1f (K-sw3 wave %.1f, K-sw2 gaps %.1f); cells shift %llu fixed %llu global %llu; pool peak %.2f GB\n",
 			cn.ms_index, cn.ms_zindex, cn.ms_candidates, cn.ms_pairs, cn.ms_winalign, cn.ms_stitch, cn.ms_ext, cn.ms_gap, (unsigned long long)cn.cells_shift, (unsigned long long)cn.cells_fixed, (unsigned long long)cn.cells_global, cn.pool_peak / 1073741824.0);
-		if(statsf){ FILE *sf = fopen(statsf, "a"); if(sf){ fprintf(sf, "%llu\t%llu\t%.6f\t%.6f\t%.3f\t%.3f\t%.3f\t%.3f\t%.3f\t%.3f\t%llu\t%llu\t%llu\t%llu\t%llu\t%.3f\t%llu\t%llu\t%llu\t%.3f\t%llu\t%llu\t%llu\t%.4f\t%llu\n", (unsigned long long)E->n_pairs, (unsigned long long)E->pair_bp, t1 - t0, t_index,
+		if(statsf){ FILE *sf = fopen(statsf, "a"); if(sf){ fprintf(sf, "%llu\t%llu\t%.6f\t%.6f\t%.3f\t%.3f\t%.3f\t%.3f\t%.3f\t%.3f\t%llu\t%llu\t%llu\t%llu\t%llu\t%.3f\t%llu\t%llu\t%llu\t%.3f\t%llu\t%llu\t%llu\t%.4f\t%llu\t%.4f\t%.4f\t%.4f\t%.4f\t%.4f\t%.4f\t%llu\t%llu\n", (unsigned long long)E->n_pairs, (unsigned long long)E->pair_bp, t1 - t0, t_index,
 				cn.ms_index, cn.ms_zindex, cn.ms_candidates, cn.ms_pairs, cn.ms_winalign, cn.ms_stitch, (unsigned long long)cn.cells_shift, (unsigned long long)cn.cells_fixed, (unsigned long long)cn.cells_global, (unsigned long long)cn.bytes_seed_algo, (unsigned long long)E->nrec,
-				cn.ms_ext, (unsigned long long)cn.n_extjobs, (unsigned long long)E->used_queries, (unsigned long long)cn.pool_peak, cn.ms_gap, (unsigned long long)E->n_ranges, (unsigned long long)E->n_split, (unsigned long long)cn.bytes_zmer_algo, E->ing_ms, (unsigned long long)E->ing_bytes); fclose(sf); } }
+				cn.ms_ext, (unsigned long long)cn.n_extjobs, (unsigned long long)E->used_queries, (unsigned long long)cn.pool_peak, cn.ms_gap, (unsigned long long)E->n_ranges, (unsigned long long)E->n_split, (unsigned long long)cn.bytes_zmer_algo, E->ing_ms, (unsigned long long)E->ing_bytes,
+				E->t_gpu, E->t_commit, E->t_cq[0], E->t_cq[1], E->t_cq[2], E->t_cq[3], (unsigned long long)E->n_batches, (unsigned long long)E->spec_queries); fclose(sf); } }      /* columns 25-32 (round 6): host seconds in the device-stage calls / in the commit / its four sections, batches, planned queries */
 	}
 	stale_join(&stale_job); if(stale_job.pending) unlink(stale_job.path);
 	free(stale_job.path);

@@ -422,6 +422,7 @@ struct wtz_ctx {
 	int last_pool_fail = 0;      /* which pool the last WTZ_E_POOL came from: 1 = main, 2 = transient (wtz_pool_failure_kind) */
 	double ext_use_ratio = 0.4; uint64_t tpool_last_used = 0;      /* run_stitch_fused: share of the trace upper bounds the fused launches have really taken */
 	bool fused_ran = false;      /* this stitch stage's fused launch has run: the extension launches behind it only sweep up what it left open */
+	int env_ext_mw_rows = 2048;  /* WTZ_EXT_MW_ROWS: items whose two extensions can run at least this many rows go to the four-wave frame kernel beside the fused launch (0 = never) */
 	int env_ext_fr = 1;          /* WTZ_EXT_FR=0: K-sw3 one-wave jobs on the round-4 register kernel (wtz_extend_shift_reg) instead of the frame form (wtz_sw_frame.h) */
 	int env_ext_split = 0;       /* WTZ_EXT_SPLIT=1: K-sw3 one-wave jobs in two launches by band class (experiment) */
 	int env_heavy_first = -1;    /* WTZ_PAIR_HEAVY_FIRST: the heaviest pairs of a K_pair launch first (-1 = engine default: dmo on, zmo off) */
@@ -529,6 +530,9 @@ extern "C" int wtz_ctx_create(int device, const wtz_params_c *params, uint64_t p
 		size_t fr = 0, tot = 0;
 		if(hipMemGetInfo(&fr, &tot) == hipSuccess && fr / 20 * 9 > c->pool_bytes) c->pool_bytes = (uint64_t)(fr / 20 * 9);
 		if(c->pool_bytes > (128ull << 30)) c->pool_bytes = 128ull << 30;
+		/* WTZ_DEFAULT_POOL_MB: the size a caller gets that did not ask for one (tests: the 128 GB default costs 4.4 s of hipMalloc per process - a hundred
+		 * small golden cases spent 400 s of the GPU suite allocating; the pool size never changes a result, only the number of ranges) */
+		if(const char *e = getenv("WTZ_DEFAULT_POOL_MB")){ const long long mb = atoll(e); if(mb >= 64 && ((uint64_t)mb << 20) < c->pool_bytes) c->pool_bytes = (uint64_t)mb << 20; }
 	}
 #endif
 	c->pool_bytes &= ~(uint64_t)4095; c->main_bytes = (c->pool_bytes / 2) & ~(uint64_t)4095;
@@ -565,6 +569,7 @@ extern "C" int wtz_ctx_create(int device, const wtz_params_c *params, uint64_t p
 	if(getenv("WTZ_PAIR_HEAVY_FIRST")) c->env_heavy_first = atoi(getenv("WTZ_PAIR_HEAVY_FIRST"));
 	if(getenv("WTZ_EXT_SPLIT")) c->env_ext_split = atoi(getenv("WTZ_EXT_SPLIT"));
 	if(getenv("WTZ_EXT_FR")) c->env_ext_fr = atoi(getenv("WTZ_EXT_FR"));
+	if(getenv("WTZ_EXT_MW_ROWS")) c->env_ext_mw_rows = atoi(getenv("WTZ_EXT_MW_ROWS"));
 	if(getenv("WTZ_EXT_FUSED")) c->env_ext_fused = atoi(getenv("WTZ_EXT_FUSED"));
 	if(getenv("WTZ_ZREAD")) c->env_zread = atoi(getenv("WTZ_ZREAD"));
 	if(getenv("WTZ_EXT_FR_SPLIT")) c->env_ext_fr_split = atoi(getenv("WTZ_EXT_FR_SPLIT"));
@@ -1557,9 +1562,10 @@ static int run_stitch_fused(wtz_ctx *c, const wtz_env_t &V, const wtz_alnitem_t 
 	/* order and budget on the device (the host form - fetch the geometry, order 31 000 items, send the order back - was 2.7 ms of an idle device per range):
 	 * key = the rows both jobs can run at most, inverted (ascending stable radix sort = longest first, ties in item order); the trace bounds are summed with an atomic */
 	uint64_t *d_k = NULL; uint32_t *d_order = NULL; unsigned long long *d_acc = NULL;
-	CHK(dev_alloc((void**)&d_k, (size_t)m * 8)); CHK(dev_alloc((void**)&d_order, (size_t)m * 4)); CHK(dev_alloc((void**)&d_acc, 16)); CHK(dev_set(d_acc, 0, 16));
+	CHK(dev_alloc((void**)&d_k, (size_t)m * 8)); CHK(dev_alloc((void**)&d_order, (size_t)m * 4)); CHK(dev_alloc((void**)&d_acc, 32)); CHK(dev_set(d_acc, 0, 32));
 	{
 		const int32_t pM = c->P.M, pO = c->P.O, pE = c->P.E, pT = c->P.T, pW = -c->P.ew;
+		const uint32_t mw_rows = c->env_ext_mw_rows > 0 ? (uint32_t)c->env_ext_mw_rows : 0xFFFFFFFFu;
 		CHK(wtz_launch<K_misc>(0, m, [=] WTZ_LAMBDA (uint64_t t){
 			const wtz_extjob_t &j = d_jl[t];
 			int32_t qa = 0, qb = 0;
@@ -1569,10 +1575,11 @@ static int run_stitch_fused(wtz_ctx *c, const wtz_env_t &V, const wtz_alnitem_t 
 			d_k[t] = (uint64_t)(0xFFFFFFFFu - rows); d_order[t] = (uint32_t)t;
 			if(nb) WTZ_ATOMIC_ADD64(&d_acc[0], nb);
 			if(rows) WTZ_ATOMIC_ADD64(&d_acc[1], (unsigned long long)rows);
+			if(rows >= mw_rows) WTZ_ATOMIC_ADD64(&d_acc[2], 1ull);
 		}));
 	}
 	CHK(dev_sort_pairs_u64_u32(d_k, d_order, m, 32));
-	unsigned long long h_acc[2] = {0, 0}; CHK(dev_d2h(h_acc, d_acc, 16));
+	unsigned long long h_acc[4] = {0, 0, 0, 0}; CHK(dev_d2h(h_acc, d_acc, 32));
 	const uint64_t acc = h_acc[0]; const unsigned long long ext_sum = h_acc[1];
 	const uint64_t budget = (c->pool_bytes - c->main_bytes) / 16 * 15;
 	/* acc sums UPPER bounds (every job run to its last row); the traces are allocated 64 rows at a time as a job runs, and most jobs end early: what the launches
@@ -1587,9 +1594,21 @@ static int run_stitch_fused(wtz_ctx *c, const wtz_env_t &V, const wtz_alnitem_t 
 		if(mg == 0) continue;
 		CHK(tpool_reset(c));
 		wtz_timer te; te.start();
-		hipLaunchKernelGGL((wtz_kernel_stitch_ext_fr<1032>), dim3(mg), dim3(64), WTZ_WAVE_LDS_BYTES, g_stream, V, d_items, d_st, d_jl, d_jr, d_gaps, (const uint32_t*)d_order, mg, ng, g);
+		/* the items at the head of the order (longest first) whose extensions can run >= WTZ_EXT_MW_ROWS rows: four wavefronts each on the side stream, beside the
+		 * one-wavefront launch over the rest - they are the launch's critical path (a row takes a wavefront ~2 us whatever else the device does) */
+		uint32_t n_long = 0;
+		if(ng == 1 && c->env_ext_mw_rows > 0){ n_long = (uint32_t)h_acc[2]; if(n_long > m / 8u) n_long = m / 8u; }
+		if(n_long){
+			HIPCHK(hipEventRecord(c->ev_mw_fork, g_stream)); HIPCHK(hipStreamWaitEvent(c->stream_mw, c->ev_mw_fork, 0));
+			hipLaunchKernelGGL((wtz_kernel_stitch_ext_frmw<1032>), dim3(n_long), dim3(256), WTZ_WAVE_LDS_BYTES, c->stream_mw, V, d_items, d_st, d_jl, d_jr, d_gaps, (const uint32_t*)d_order, n_long);
+			HIPCHK(hipGetLastError());
+			HIPCHK(hipEventRecord(c->ev_mw_join, c->stream_mw));
+		}
+		if(mg > n_long) hipLaunchKernelGGL((wtz_kernel_stitch_ext_fr<1032>), dim3(mg - n_long), dim3(64), WTZ_WAVE_LDS_BYTES, g_stream, V, d_items, d_st, d_jl, d_jr, d_gaps, (const uint32_t*)d_order + n_long, mg - n_long, ng, g);
 		HIPCHK(hipGetLastError());
+		if(n_long) HIPCHK(hipStreamWaitEvent(g_stream, c->ev_mw_join, 0));
 		ms_l += te.stop();
+		if(c->env_profile && n_long) fprintf(stderr, "[ext-profile] %u of %u items on four wavefronts each\n", n_long, m);
 		{
 			const int rc_t = tpool_check(c, "K-sw3 extension jobs (both ends on one wavefront)");
 			if(rc_t != WTZ_OK){

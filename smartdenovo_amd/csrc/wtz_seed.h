@@ -703,12 +703,15 @@ WTZ_D bool wtz_cand_stream(uint32_t t, const wtz_reads_t &R, uint32_t pbid, uint
 #define WTZ_WG_N ((uint32_t)blockDim.x)
 #define WTZ_WG_SYNC() __syncthreads()
 #define WTZ_LDS_ADD32(p, v) atomicAdd((p), (v))
+#define WTZ_LDS_CAS32(p, o, n) atomicCAS((p), (o), (n))
 #else
 #define WTZ_WG_TID 0u
 #define WTZ_WG_N 1u
 #define WTZ_WG_SYNC() do {} while(0)
 static inline uint32_t wtz_lds_add32_host(uint32_t *p, uint32_t v){ const uint32_t o = *p; *p += v; return o; }
 #define WTZ_LDS_ADD32(p, v) wtz_lds_add32_host((p), (v))
+static inline uint32_t wtz_lds_cas32_host(uint32_t *p, uint32_t o, uint32_t n){ const uint32_t c = *p; if(c == o) *p = n; return c; }
+#define WTZ_LDS_CAS32(p, o, n) wtz_lds_cas32_host((p), (o), (n))
 #endif
 /* exclusive prefix sum of one value per thread over the workgroup (tmp: 64 LDS words), *total = the sum */
 WTZ_HD uint32_t wtz_wg_excl_scan(uint32_t v, uint32_t *tmp, uint32_t *total){
@@ -749,8 +752,28 @@ WTZ_HD void wtz_wg_sort_u64(uint64_t *a, uint32_t np){
 }
 
 typedef struct { uint32_t qoff, qlen; } wtz_kq_t;
-#define WTZ_CWG_SKETCH 16384u         /* 16-bit counters of the group sketch (32 KB: the sort slots + interval arrays, idle while the tuples are listed) */
-WTZ_HD uint32_t wtz_cwg_sk_hash(uint32_t sd){ return (sd * 0x9E3779B1u) >> 18; }      /* 14 bits */
+/* Group sketch (round 6): 65 536 saturating 4-BIT counters in the 32 KB of the sort slots + interval arrays (idle while the tuples are listed).  Round 5 had 16 384 16-bit
+ * counters in the same bytes: at the configs[3] shape a long query has some hundred thousand tuples, ~30 per counter, every counter reached the threshold and the
+ * sketch let everything through (3.7 of 17.7 s).  What a counter has to tell is only "can the groups hashed here reach -d": 15 units of ceil(-d / 15)
+ * bases are enough for that, and four times the counters for the same LDS cut the load per counter to a quarter. */
+#define WTZ_CWG_SKETCH 65536u
+WTZ_HD uint32_t wtz_cwg_sk_hash(uint32_t sd){ return (sd * 0x9E3779B1u) >> 16; }      /* 16 bits */
+/* counter h of sk += v, saturating at 15; nothing is added once it holds `thr` (<= 15).  A compare-and-swap loop on the word: racing adds can neither carry into the
+ * neighbouring nibble nor wrap this one (a wrapped counter would drop a group that reaches -d: a wrong result, not a slow one) */
+WTZ_HD void wtz_cwg_sk_add(uint32_t *sk, uint32_t h, uint32_t v, uint32_t thr){
+	uint32_t *w = &sk[h >> 3]; const uint32_t sh = (h & 7u) << 2;
+	uint32_t cur = *w;
+	for(;;){
+		const uint32_t c = (cur >> sh) & 15u;
+		if(c >= thr) return;
+		uint32_t nc = c + v; if(nc > 15u) nc = 15u;
+		const uint32_t want = (cur & ~(15u << sh)) | (nc << sh);
+		const uint32_t got = WTZ_LDS_CAS32(w, cur, want);
+		if(got == cur) return;
+		cur = got;
+	}
+}
+WTZ_HD bool wtz_cwg_sk_pass(const uint32_t *sk, uint32_t h, uint32_t thr){ return ((sk[h >> 3] >> ((h & 7u) << 2)) & 15u) >= thr; }
 /* inclusive running maximum of one value per thread over the workgroup (tmp: 64 LDS words), *total = the maximum */
 WTZ_HD uint32_t wtz_wg_incl_max(uint32_t v, uint32_t *tmp, uint32_t *total){
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -784,14 +807,6 @@ WTZ_HD uint32_t wtz_wg_incl_max(uint32_t v, uint32_t *tmp, uint32_t *total){
 #define WTZ_ZR_MAXPC(np) (WTZ_ZR_MAXLEN(np) / WTZ_ZR_SUB)
 WTZ_HD uint32_t wtz_zr_nbk(uint32_t np){ uint32_t b = 64; while(b < np / 4u) b <<= 1; return b; }      /* buckets: a power of two, ~4 z-mers each */
 WTZ_HD uint32_t wtz_zr_lds_bytes(uint32_t np){ return np * 8u + (wtz_zr_nbk(np) + 1u) * 4u + WTZ_ZR_MAXPC(np) * 4u + 64u * 4u + (WTZ_ZR_MAXLEN(np) / 32u + 4u) * 8u + 16u * 4u + 64u; }
-struct wtz_zread_cnt_f { uint32_t n; uint32_t *hist; uint32_t bsh;
-	WTZ_HDM void operator()(uint32_t m, uint32_t, uint32_t, uint32_t){ n++; WTZ_LDS_ADD32(&hist[m >> bsh], 1u); } };
-struct wtz_zread_fill_f { uint32_t *mer, *pos; uint16_t *len; uint64_t *keys; uint32_t *cur; uint32_t bsh; uint32_t k;
-	WTZ_HDM void operator()(uint32_t m, uint32_t d, uint32_t o, uint32_t l){
-		mer[k] = m; pos[k] = (o << 1) | d; len[k] = (uint16_t)l;
-		const uint32_t slot = WTZ_LDS_ADD32(&cur[m >> bsh], 1u);           /* any order inside the bucket: the keys are unique, every correct order is THE order */
-		keys[slot] = ((uint64_t)m << 32) | k; k++;
-	} };
 /* n (any number of) u64 words in LDS ordered by the whole workgroup: the bitonic network with all comparators pointing up (first step of a merge against the
  * mirror image), so that the missing elements behind n act as +infinity without being stored */
 WTZ_HD void wtz_wg_sort_u64_n(uint64_t *a, uint32_t n){
@@ -818,13 +833,12 @@ WTZ_HD void wtz_task_zread(uint32_t r, const wtz_reads_t &R, uint32_t zsize, uin
 	const uint32_t tid = WTZ_WG_TID, nt = WTZ_WG_N;
 	const uint64_t o = Z.zoff[r]; const uint32_t n = (uint32_t)(Z.zoff[r + 1] - o);
 	if(n == 0){ if(tid == 0) Z.dn[r] = 0; return; }
-	const uint32_t nbk = wtz_zr_nbk(np);                        /* buckets by the leading bits of the z-mer: ~4 z-mers each (canonical z-mers lean to the small values: up to ~8) */
-	uint32_t lb = 0; while((1u << lb) < nbk) lb++;
-	/* a z-mer has 2 * zsize bits (20 at the default -z 10): the bucket is its LEADING lb bits.  Round 5 shifted by 32 - lb, which sent every z-mer of a read below 2^(32 - lb)
-	 * - all of them at -z 10 - to bucket 0: the one-lane insertion path never ran, every LDS atomic of the two walks hit the same word, and the whole array
-	 * went through the workgroup's bitonic network */
-	const uint32_t kbits = 2u * zsize < 32u ? 2u * zsize : 32u;
-	const uint32_t bsh = kbits > lb ? kbits - lb : 0u, maxpc = WTZ_ZR_MAXPC(np);
+	/* Round 6: no buckets.  Round 5 dropped the keys into LDS buckets by "the leading bits of the z-mer" - with a shift taken from a 32-bit key, so that every z-mer
+	 * of a read (2 * zsize = 20 bits at -z 10) went to bucket 0: 2 n same-address LDS atomics and the whole array through the workgroup's network.
+	 * With the buckets really populated (a 20-bit shift) the index of configs[2] took 93 ms instead of 83: hp-compressed canonical z-mers crowd a few leading-bit
+	 * prefixes, and every bucket beyond 24 keys is a workgroup sort of its own.  What was fast about the accident is kept and the atomics go: a key's slot is its
+	 * position rank, which the fill walk has anyway (no histogram, no cursors), and the whole array is ordered by the network. */
+	const uint32_t nbk = wtz_zr_nbk(np), maxpc = WTZ_ZR_MAXPC(np);      /* nbk: the (now unused) cursor words keep the LDS layout of wtz_zr_lds_bytes */
 	uint64_t *keys = (uint64_t*)lds; uint32_t *bk = lds + 2 * (size_t)np, *pc = bk + nbk + 1, *tmp = pc + maxpc;
 	const uint32_t len = R.rdlen[r], npc = (len + WTZ_ZR_SUB - 1) / WTZ_ZR_SUB;
 	/* the read's 2-bit words in LDS, addressed as a one-read bank: read 0 starts at the offset of the read inside its first word */
@@ -837,9 +851,8 @@ WTZ_HD void wtz_task_zread(uint32_t r, const wtz_reads_t &R, uint32_t zsize, uin
 		if(tid == 0){ loff[0] = off & 31u; llen[0] = len; }
 	}
 	wtz_reads_t RL; RL.bits = lbits; RL.rdoff = loff; RL.rdlen = llen; RL.n_reads = 1;
-	for(uint32_t b = tid; b <= nbk; b += nt) bk[b] = 0;
 	WTZ_WG_SYNC();
-	for(uint32_t p = tid; p < npc; p += nt){ wtz_zread_cnt_f f; f.n = 0; f.hist = bk; f.bsh = bsh; wtz_zmer_walk(RL, 0u, zsize, hz, f, p * WTZ_ZR_SUB, p * WTZ_ZR_SUB + WTZ_ZR_SUB); pc[p] = f.n; }
+	for(uint32_t p = tid; p < npc; p += nt){ wtz_zcount_f f; f.n = 0; wtz_zmer_walk(RL, 0u, zsize, hz, f, p * WTZ_ZR_SUB, p * WTZ_ZR_SUB + WTZ_ZR_SUB); pc[p] = f.n; }
 	WTZ_WG_SYNC();
 	{
 		uint32_t carry = 0;
@@ -850,44 +863,13 @@ WTZ_HD void wtz_task_zread(uint32_t r, const wtz_reads_t &R, uint32_t zsize, uin
 			carry += tot;
 			WTZ_WG_SYNC();
 		}
-		carry = 0;
-		for(uint32_t b = 0; b < nbk; b += nt){                      /* bucket counts -> bucket starts; the fill advances them to the bucket ends */
-			const uint32_t v = b + tid < nbk ? bk[b + tid] : 0u;
-			uint32_t tot; const uint32_t ex = wtz_wg_excl_scan(v, tmp, &tot);
-			if(b + tid < nbk) bk[b + tid] = carry + ex;
-			carry += tot;
-			WTZ_WG_SYNC();
-		}
 	}
 	for(uint32_t p = tid; p < npc; p += nt){
-		wtz_zread_fill_f f; f.mer = Z.mer + o; f.pos = Z.pos + o; f.len = Z.len + o; f.keys = keys; f.cur = bk; f.bsh = bsh; f.k = pc[p];
+		wtz_zfill_f f; f.mer = Z.mer + o; f.pos = Z.pos + o; f.len = Z.len + o; f.key = keys; f.k = pc[p];       /* key[k] = mer << 32 | k: unique, so every correct order IS the stable (mer, position) order */
 		wtz_zmer_walk(RL, 0u, zsize, hz, f, p * WTZ_ZR_SUB, p * WTZ_ZR_SUB + WTZ_ZR_SUB);
 	}
 	WTZ_WG_SYNC();
-	/* bucket b is keys[bk[b-1], bk[b]) now.  Small buckets: one lane each; the others (a z-mer repeated all over the read) are listed and ordered by the workgroup */
-	if(tid == 0) pc[0] = 0;
-	WTZ_WG_SYNC();
-	for(uint32_t b = tid; b < nbk; b += nt){
-		const uint32_t s0 = b ? bk[b - 1] : 0u, e0 = bk[b], cnt = e0 - s0;
-		if(cnt < 2) continue;
-		if(cnt > WTZ_ZR_SMALL){ const uint32_t q = WTZ_LDS_ADD32(&pc[0], 1u); if(q + 1 < maxpc) pc[1 + q] = b; continue; }
-		for(uint32_t i = s0 + 1; i < e0; i++){
-			const uint64_t v = keys[i]; uint32_t j = i;
-			while(j > s0 && keys[j - 1] > v){ keys[j] = keys[j - 1]; j--; }
-			keys[j] = v;
-		}
-	}
-	WTZ_WG_SYNC();
-	{
-		const uint32_t nbig = pc[0];
-		if(nbig + 1 >= maxpc){                               /* more large buckets than the list holds: the whole array at once */
-			WTZ_WG_SYNC();
-			wtz_wg_sort_u64_n(keys, n);
-		} else for(uint32_t q = 0; q < nbig; q++){
-			const uint32_t b = pc[1 + q], s0 = b ? bk[b - 1] : 0u;
-			wtz_wg_sort_u64_n(keys + s0, bk[b] - s0);
-		}
-	}
+	wtz_wg_sort_u64_n(keys, n);
 	WTZ_WG_SYNC();
 	/* ordered keys -> sorted view, cap flags, distinct table.  Element i: head = first of its run of equal z-mers, tail = last; the run's length is known at
 	 * its tail (i - head + 1), and numbering the retained runs by their tails gives the same dense index as numbering them by their heads */
@@ -1029,9 +1011,11 @@ WTZ_HD void wtz_task_candidates_wg(uint32_t t, wtz_reads_t R, const uint32_t *qi
 	/* ---- K: sketch.  Nearly every (read, strand) group is a chance hit of one or two k-mers and cannot reach -d; ol <= sum of the group's lengths, so a
 	 * hashed table of that sum (16-bit counters in units of `sk_unit` bases, rounded up; a counter stops counting at the threshold) tells which tuples can
 	 * belong to a group that does.  Collisions only add: no group that reaches -d is lost, and the groups that get through are folded exactly below. ---- */
-	uint32_t *sk = (uint32_t*)sbuf;                                    /* WTZ_CWG_SKETCH half-word counters over the sort slots + interval arrays (idle until stage P) */
-	const uint32_t sk_unit = kovl > 200u ? (kovl + 199u) / 200u : 1u, sk_thr = (kovl + sk_unit - 1u) / sk_unit;      /* <= 200 units per tuple: 256 racing adds stay below 2^16 */
-	for(uint32_t i = tid; i < WTZ_CWG_SKETCH / 2u; i += nt) sk[i] = 0;
+	uint32_t *sk = (uint32_t*)sbuf;                                    /* WTZ_CWG_SKETCH 4-bit counters over the sort slots + interval arrays (idle until stage P) */
+	/* units of sk_unit bases, every tuple rounded UP (the sum of the round-ups is at least the round-up of the sum): a group whose lengths add up to -d holds
+	 * at least sk_thr = ceil(-d / sk_unit) <= 15 units */
+	const uint32_t sk_unit = kovl > 15u ? (kovl + 14u) / 15u : 1u, sk_thr = (kovl + sk_unit - 1u) / sk_unit;
+	for(uint32_t i = tid; i < WTZ_CWG_SKETCH / 8u; i += nt) sk[i] = 0;
 	for(uint32_t i = tid; i < WTZ_CWG_BINS; i += nt) hist[i] = 0;
 #if defined(__HIP_DEVICE_COMPILE__)
 	__threadfence_block();
@@ -1039,8 +1023,8 @@ WTZ_HD void wtz_task_candidates_wg(uint32_t t, wtz_reads_t R, const uint32_t *qi
 	WTZ_WG_SYNC();
 	const wtz_cwg_walk_t SW = { nk, koff, kq, seeds, R.rdlen, pbid, thr, pblen_up };
 	wtz_cwg_for_seeds(SW, [&](uint32_t sd, uint32_t, uint32_t qlen){
-		const uint32_t h = wtz_cwg_sk_hash(sd), sh = (h & 1u) << 4;
-		if(((sk[h >> 1] >> sh) & 0xFFFFu) < sk_thr){ const uint32_t l = qlen < kovl ? qlen : kovl; WTZ_LDS_ADD32(&sk[h >> 1], ((l + sk_unit - 1u) / sk_unit) << sh); }
+		const uint32_t l = qlen < kovl ? qlen : kovl;
+		wtz_cwg_sk_add(sk, wtz_cwg_sk_hash(sd), (l + sk_unit - 1u) / sk_unit, sk_thr);
 	});
 	WTZ_WG_SYNC();
 	WTZ_CPROF_ADD(1, pc);
@@ -1054,8 +1038,7 @@ WTZ_HD void wtz_task_candidates_wg(uint32_t t, wtz_reads_t R, const uint32_t *qi
 	uint64_t *lst_t = (uint64_t*)(uintptr_t)(((uint64_t)tmp[61] << 32) | tmp[60]);
 	if(lst_t == NULL){ if(tid == 0) ncand_out[t] = 0xFFFFFFFFu; return; }
 	wtz_cwg_for_seeds(SW, [&](uint32_t sd, uint32_t e, uint32_t){
-		const uint32_t h = wtz_cwg_sk_hash(sd);
-		if(((sk[h >> 1] >> ((h & 1u) << 4)) & 0xFFFFu) >= sk_thr){
+		if(wtz_cwg_sk_pass(sk, wtz_cwg_sk_hash(sd), sk_thr)){
 			WTZ_LDS_ADD32(&hist[(sd - key_lo) >> shift], 1u);
 			lst_t[WTZ_LDS_ADD32(&tmp[59], 1u)] = ((uint64_t)sd << 32) | e;
 		}

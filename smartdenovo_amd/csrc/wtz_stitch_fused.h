@@ -16,6 +16,7 @@
 
 #include "wtz_tasks.h"
 #include "wtz_sw_frame.h"
+#include "wtz_sw_frame_mw.h"
 
 #ifdef __HIPCC__
 /* the extension as a function of its own: its 250 registers are allocated for it alone, and what the kernel keeps across the call (the item, the side) is saved
@@ -43,6 +44,25 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WTZ_OCC
 		}
 		if(!wtz_extjob_run_fr_call<TW>(side ? &jobsR[t] : &jobsL[t], V.P, V.pool, V.pool + 1)) return;
 		__threadfence_block();          /* lane 0 wrote the result and the operation list the join reads */
+	}
+}
+/* the same for the items with the longest extensions, on FOUR wavefronts per item (wtz_sw_frame_mw.h): these few items are the critical path of the whole launch.
+ * Wave 0 runs the join between the two extensions; the other waves wait at the barrier. */
+template<int TW>
+__global__ void __launch_bounds__(256) wtz_kernel_stitch_ext_frmw(const wtz_env_t V, const wtz_alnitem_t *items, wtz_stitch_state_t *sts,
+		wtz_extjob_t *jobsL, wtz_extjob_t *jobsR, const wtz_gapres_t *gaps, const uint32_t *order, uint32_t n){
+	__shared__ uint64_t stb[TW]; __shared__ wtz_frmw_shared_t shm;
+	const uint32_t b = blockIdx.x;
+	if(b >= n) return;
+	const uint32_t t = order[b];
+	#pragma nounroll
+	for(int side = 0; side < 2; side++){
+		if(side){
+			if(threadIdx.x < 64u) wtz_stitch_mid_call<TW>(t, &V, items, sts, jobsL, jobsR, gaps);
+			__threadfence_block(); __syncthreads();      /* lane 0 wrote the right job; the whole workgroup reads it */
+		}
+		if(!wtz_extjob_run_frmw<TW>(side ? &jobsR[t] : &jobsL[t], V.P, V.pool, V.pool + 1, stb, &shm)) return;      /* the same answer in every thread */
+		__threadfence_block(); __syncthreads();
 	}
 }
 #endif

@@ -141,6 +141,11 @@ WTZ_D wtz_aln_t wtz_extend_shift_fr(int32_t qlen, const wtz_seq_packed &query, i
 	*ok = true; *consistent = true;
 	if(lane == 0) cigars.n = 0;
 	if(init_score < 0) init_score = 0;
+	/* the job's numbers arrive through vector loads: say that they are the same in all lanes (round 6: the row loop ran on a VECTOR compare of i against ql - an
+	 * exec-masked loop with a dozen mask instructions per row - and kept the band bounds in vector registers) */
+	qlen = __builtin_amdgcn_readfirstlane(qlen); tlen = __builtin_amdgcn_readfirstlane(tlen); init_score = __builtin_amdgcn_readfirstlane(init_score);
+	ql = __builtin_amdgcn_readfirstlane(ql); tl = __builtin_amdgcn_readfirstlane(tl); W = __builtin_amdgcn_readfirstlane(W);
+	M = __builtin_amdgcn_readfirstlane(M); X = __builtin_amdgcn_readfirstlane(X); O = __builtin_amdgcn_readfirstlane(O); E = __builtin_amdgcn_readfirstlane(E); T = __builtin_amdgcn_readfirstlane(T);
 	constexpr int C4 = (C + 3) / 4;
 	const uint32_t zrow = (uint32_t)C4 * 256u;
 	if(!wtz_trace_prepare(tr, pool, zrow, ql, true)){ *ok = false; return x; }
@@ -172,6 +177,11 @@ WTZ_D wtz_aln_t wtz_extend_shift_fr(int32_t qlen, const wtz_seq_packed &query, i
 	unsigned long long ncell = 0;
 	uint32_t qw_lo = 0, qw_hi = 0, qcur = 0;
 	int32_t jb_n = 0, je_n = tl; uint64_t tbits_n;
+	/* arg-max key offset of the lane: ((i + jb + l*C) * E) * 2048 + 2047 - l*C; it moves by (1 + band shift) * E * 2048 per row (round 6: was a multiply per row) */
+	int32_t koff = (colrel0 * E) * 2048 + 2047 - colrel0;
+	const int32_t E2048 = E * 2048;
+	/* band start of row r in lane r & 63 (v_writelane), written out once per 64 rows (round 6: lane 0 stored one word per row behind an exec-mask switch) */
+	int32_t zbv = 0;
 	{
 		if(je_n > W + 1) je_n = W + 1;              /* row 0: c = 0 */
 		if(je_n > tl) je_n = tl;
@@ -223,7 +233,6 @@ WTZ_D wtz_aln_t wtz_extend_shift_fr(int32_t qlen, const wtz_seq_packed &query, i
 		else if(s == 0) wtz_fr_row<C, 0>(hv, ev, zw, eq_lo, eq_hi, lane, bnd, SF, MX, Xp, O, ck, key);
 		else            wtz_fr_row<C, 2>(hv, ev, zw, eq_lo, eq_hi, lane, bnd, SF, MX, Xp, O, ck, key);
 		const int32_t nvt = je - jb;                       /* band-relative column of the first cell beyond the band end */
-		const int32_t koff = ((i + jb + colrel0) * E) * 2048 + 2047 - colrel0;
 		/* ---- row maximum and its FIRST arg-max (kswx.h:172) ---- */
 		{
 			const bool part = colrel0 < nvt && colrel0 + C > nvt;
@@ -245,32 +254,16 @@ WTZ_D wtz_aln_t wtz_extend_shift_fr(int32_t qlen, const wtz_seq_packed &query, i
 		key = wtz_wave_max_i32(key);
 		int32_t imax = 0, mj2 = -1;
 		if((key >> 11) > 0){ imax = key >> 11; mj2 = jb + (2047 - (key & 2047)); }
-		if(lane == 0) wtz_as_global(zb)[i] = jb;
-		/* ---- H(i, je-1) for the target-end rule; the three slots a later row may read beyond this row's band end ---- */
-		{
+		zbv = (lane == (i & 63)) ? jb : zbv;      /* (v_writelane would take two scalar operands: one more than a VALU instruction of this ISA may read) */
+		if((i & 63) == 63) wtz_as_global(zb)[(i & ~63) + lane] = zbv;
+		/* ---- H(i, je-1) for the target-end rule ---- */
+		if(je == tlen){
 			const int32_t idx = nvt - 1;
-			const int32_t Lb = __builtin_amdgcn_readfirstlane(nvt / C), kb = __builtin_amdgcn_readfirstlane(nvt % C);
 			const int32_t Ll = __builtin_amdgcn_readfirstlane(idx / C), kl = __builtin_amdgcn_readfirstlane(idx % C);
-			const int32_t SG = -10000 - (i + je) * E;               /* rh[je+1] = -10000 (kswx.h:191): H(i, je) */
-			const int32_t SE1 = -10000 - (i + 1 + je) * E;          /* re[je] = -10000 (kswx.h:179): E(i+1, je) */
-			const int32_t SE2 = -10000 - (i + 2 + je) * E;          /* re[je+1] = -10000 (kswx.h:192): E(i+1, je+1) */
 			int32_t hsel = 0;
-			const bool touch = (je == tlen);
-			if(touch){
-				wtz_uniform_switch<0, C>(kl, [&](auto kc){ constexpr int k = decltype(kc)::value; hsel = hv[k]; WTZ_PIN_TAG(hsel, k); });
-				const int32_t h1 = __builtin_amdgcn_readlane(hsel, Ll) + (i + je - 1) * E;      /* H(i, je-1) */
-				if(gmax < h1){ gmax = h1; gi = i; gj = je - 1; }
-			}
-			if(Lb < 64){
-				wtz_uniform_switch<0, C>(kb, [&](auto kc){
-					constexpr int k = decltype(kc)::value;
-					hv[k] = (lane == Lb) ? SG : hv[k];
-					ev[k] = (lane == Lb) ? SE1 : ev[k];
-					if constexpr(k + 1 < C) ev[k + 1] = (lane == Lb) ? SE2 : ev[k + 1];
-					else ev[0] = (lane == Lb + 1) ? SE2 : ev[0];
-					WTZ_PIN_TAG(hv[k], k);
-				});
-			}
+			wtz_uniform_switch<0, C>(kl, [&](auto kc){ constexpr int k = decltype(kc)::value; hsel = hv[k]; WTZ_PIN_TAG(hsel, k); });
+			const int32_t h1 = __builtin_amdgcn_readlane(hsel, Ll) + (i + je - 1) * E;      /* H(i, je-1) */
+			if(gmax < h1){ gmax = h1; gi = i; gj = je - 1; }
 		}
 		if(i + 1 == qlen && gmax < imax){ gmax = imax; gi = i; gj = mj2; }
 		jbp = jb;
@@ -283,11 +276,34 @@ WTZ_D wtz_aln_t wtz_extend_shift_fr(int32_t qlen, const wtz_seq_packed &query, i
 			if(jb_n < c - W) jb_n = c - W;
 			if(je_n > c + W + 1) je_n = c + W + 1;
 			if(je_n > tl) je_n = tl;
-			const int32_t j0n = jb_n + colrel0;
-			const int32_t jj = j0n < tl ? j0n : (tl > 0 ? tl - 1 : 0);
-			const int32_t w = jj >> 5, sh = (jj & 31) * 2;
-			const uint64_t w0 = tb[w], w1 = tb[w + 1];
-			tbits_n = sh ? ((w0 >> sh) | (w1 << (64 - sh))) : w0;
+			koff += (1 + jb_n - jb) * E2048;
+			if(jb_n != jb){       /* the band start moved: the lane's target bits move with it (round 6: while the band start stands - the first W rows of every job - they are kept) */
+				const int32_t j0n = jb_n + colrel0;
+				const int32_t jj = j0n < tl ? j0n : (tl > 0 ? tl - 1 : 0);
+				const int32_t w = jj >> 5, sh = (jj & 31) * 2;
+				const uint64_t w0 = tb[w], w1 = tb[w + 1];
+				tbits_n = sh ? ((w0 >> sh) | (w1 << (64 - sh))) : w0;
+			}
+			/* ---- the slots the NEXT row reads beyond this row's band end: H(i, je), E(i+1, je), E(i+1, je+1) are the reference's -10000 (kswx.h:179, 191-192).  They are
+			 * read only by a row whose band end lies further right (by one or two columns), so they are set only then (round 6: every row paid four scalar divisions,
+			 * a switch over the register index and four selects; a band that stands still - every row of a job whose target side is shorter than W, every row after
+			 * the band has reached the target's end - needs none of it: what lies beyond its end is never read by a cell inside it) ---- */
+			if(je_n > je){
+				const int32_t Lb = __builtin_amdgcn_readfirstlane(nvt / C), kb = __builtin_amdgcn_readfirstlane(nvt % C);
+				const int32_t SG = -10000 - (i + je) * E;               /* rh[je+1] = -10000 (kswx.h:191): H(i, je) */
+				const int32_t SE1 = -10000 - (i + 1 + je) * E;          /* re[je] = -10000 (kswx.h:179): E(i+1, je) */
+				const int32_t SE2 = -10000 - (i + 2 + je) * E;          /* re[je+1] = -10000 (kswx.h:192): E(i+1, je+1) */
+				if(Lb < 64){
+					wtz_uniform_switch<0, C>(kb, [&](auto kc){
+						constexpr int k = decltype(kc)::value;
+						hv[k] = (lane == Lb) ? SG : hv[k];
+						ev[k] = (lane == Lb) ? SE1 : ev[k];
+						if constexpr(k + 1 < C) ev[k + 1] = (lane == Lb) ? SE2 : ev[k + 1];
+						else ev[0] = (lane == Lb + 1) ? SE2 : ev[0];
+						WTZ_PIN_TAG(hv[k], k);
+					});
+				}
+			}
 		}
 #ifndef WTZ_EXP_NOTRACE
 		if(colrel0 < nvt){
@@ -303,6 +319,10 @@ WTZ_D wtz_aln_t wtz_extend_shift_fr(int32_t qlen, const wtz_seq_packed &query, i
 	}
 	if(cells && lane == 0) *cells += ncell;
 	if(!*ok) return x;
+	{   /* band starts of the rows of the last, incomplete block of 64 (i = rows run; a `break` leaves i at the last row run) */
+		const int32_t last = i < ql ? i : ql - 1;
+		if(last >= 0 && (last & 63) != 63 && lane <= (last & 63)) wtz_as_global(zb)[(last & ~63) + lane] = zbv;
+	}
 	if(gmax > 0 && gmax >= mx + T){ x.score = gmax; x.qe = gi; x.te = gj; }
 	else { x.score = mx; x.qe = mi; x.te = mj; }
 	__threadfence_block();
@@ -337,12 +357,19 @@ WTZ_D bool wtz_extjob_run_fr(wtz_extjob_t *job, const wtz_params_t *Pm, wtz_pool
 	unsigned long long cells = 0; bool ok = true, consistent = true;
 	wtz_aln_t x;
 #define WTZ_EXTFR_CASE(CM) x = wtz_extend_shift_fr<CM>(job->qlen, job->q, job->tlen, job->t, job->init_score, ql, tl, W, Pm->M, Pm->X, Pm->O, Pm->E, Pm->T, stb, tr, tpool, cg, &cells, &ok, &consistent)
+	/* one instantiation per two columns per lane from 4 on (round 6: steps of four left the mean job a sixth of its cells beyond its band's widest row) */
 	if(Cw <= 4){ if(CLO < 4 && CHI >= 4) WTZ_EXTFR_CASE(4); }
+	else if(Cw <= 6){ if(CLO < 6 && CHI >= 6) WTZ_EXTFR_CASE(6); }
 	else if(Cw <= 8){ if(CLO < 8 && CHI >= 8) WTZ_EXTFR_CASE(8); }
+	else if(Cw <= 10){ if(CLO < 10 && CHI >= 10) WTZ_EXTFR_CASE(10); }
 	else if(Cw <= 12){ if(CLO < 12 && CHI >= 12) WTZ_EXTFR_CASE(12); }
+	else if(Cw <= 14){ if(CLO < 14 && CHI >= 14) WTZ_EXTFR_CASE(14); }
 	else if(Cw <= 16){ if(CLO < 16 && CHI >= 16) WTZ_EXTFR_CASE(16); }
+	else if(Cw <= 18){ if(CLO < 18 && CHI >= 18) WTZ_EXTFR_CASE(18); }
 	else if(Cw <= 20){ if(CLO < 20 && CHI >= 20) WTZ_EXTFR_CASE(20); }
+	else if(Cw <= 22){ if(CLO < 22 && CHI >= 22) WTZ_EXTFR_CASE(22); }
 	else if(Cw <= 24){ if(CLO < 24 && CHI >= 24) WTZ_EXTFR_CASE(24); }
+	else if(Cw <= 26){ if(CLO < 26 && CHI >= 26) WTZ_EXTFR_CASE(26); }
 	else if(Cw <= 28){ if(CLO < 28 && CHI >= 28) WTZ_EXTFR_CASE(28); }
 	else { if(CHI >= 32) WTZ_EXTFR_CASE(32); }
 #undef WTZ_EXTFR_CASE

@@ -50,13 +50,26 @@ class RankExchange:
         self._cb = (BCAST(self._bcast), SEND(self._send), RECV(self._recv))      # keep the callbacks alive
         self._cb_dev = SEND_DEV(self._send_dev)
         self.bytes_sent_from_device = 0
+        self._stage = None
         self.dev_is_host = False        # the emulated device layer of the CPU tests: "device" pointers are host pointers
+
+    def _stage_buf(self, m):
+        """nccl moves device tensors only: ONE grow-only device staging buffer for the host-resident messages (round 5 allocated a tensor per message);
+        on gloo the host view itself is the message - no copy on either side"""
+        if self._stage is None or self._stage.numel() < m:
+            self._stage = torch.empty(max(m, 1 << 20), dtype=torch.uint8, device=self.device)
+        return self._stage[:m]
 
     def _bcast(self, ptr, n):
         for o in range(0, n, _CHUNK):
             m = min(_CHUNK, n - o)
             h = _host_view(ptr + o, m)
-            t = h.to(self.device) if self.rank == 0 else torch.empty(m, dtype=torch.uint8, device=self.device)
+            if self.device == "cpu":
+                self.dist.broadcast(h, 0)
+                continue
+            t = self._stage_buf(m)
+            if self.rank == 0:
+                t.copy_(h)
             self.dist.broadcast(t, 0)
             if self.rank != 0:
                 h.copy_(t)
@@ -65,7 +78,13 @@ class RankExchange:
     def _send(self, ptr, n, dst):
         for o in range(0, n, _CHUNK):
             m = min(_CHUNK, n - o)
-            self.dist.send(_host_view(ptr + o, m).to(self.device), dst)
+            h = _host_view(ptr + o, m)
+            if self.device == "cpu":
+                self.dist.send(h, dst)
+            else:
+                t = self._stage_buf(m)
+                t.copy_(h)
+                self.dist.send(t, dst)
         self.bytes_sent += n
         self.messages += 1
 
@@ -88,9 +107,13 @@ class RankExchange:
     def _recv(self, ptr, n, src):
         for o in range(0, n, _CHUNK):
             m = min(_CHUNK, n - o)
-            t = torch.empty(m, dtype=torch.uint8, device=self.device)
-            self.dist.recv(t, src)
-            _host_view(ptr + o, m).copy_(t)
+            h = _host_view(ptr + o, m)
+            if self.device == "cpu":
+                self.dist.recv(h, src)
+            else:
+                t = self._stage_buf(m)
+                self.dist.recv(t, src)
+                h.copy_(t)
         self.bytes_received += n
         self.messages += 1
 

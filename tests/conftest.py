@@ -9,6 +9,10 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLD = os.path.join(ROOT, "tests", "golden")
 sys.path.insert(0, ROOT)
+# A process that does not ask for a pool size gets the library's default: 45 % of the free HBM up to 128 GB = 4.4 s of hipMalloc.  The pool size never changes a
+# result (tests/test_gpu_parity.py::test_scratch_pool_exhaustion_is_survived_or_loud, the --pool-mb cases), and a hundred small golden cases spent 400 of the GPU
+# suite's 814 s allocating it (round 6, --durations).  The product's own default is still run by smoke(), bench.py and the scale tests' explicit sizes.
+os.environ.setdefault("WTZ_DEFAULT_POOL_MB", "8192")
 
 
 def pytest_configure(config):

@@ -58,7 +58,15 @@ def check_case_at_scale(name, gpu_exe, extra=()):
     for f in (out, out + ".contained", stats):
         if os.path.exists(f):
             os.remove(f)
-    r = subprocess.run([gpu_exe, "-i", fa, "-fo", out, "--stats", stats] + list(extra) + case["argv"], capture_output=True)
+    env = dict(os.environ)
+    if "--pool-gb" not in extra and "--pool-mb" not in extra:
+        # the suite's small default pool (conftest: WTZ_DEFAULT_POOL_MB) is for the golden cases; the planner is measured at the product's sizes.  The configs[3] / [4]
+        # shapes size their pool from the input files themselves (all-reads z-mer index beside it): they run exactly as a user would start them.
+        if case["set"].startswith(("fly", "human")):
+            env.pop("WTZ_DEFAULT_POOL_MB", None)
+        else:
+            extra = tuple(extra) + ("--pool-gb", "48")
+    r = subprocess.run([gpu_exe, "-i", fa, "-fo", out, "--stats", stats] + list(extra) + case["argv"], capture_output=True, env=env)
     if os.environ.get("WTZ_TEST_KEEP_STDERR"):      # the drop-in's own log of the run (index sizes, per-batch z-index, timings): kept under profiles/ for the fly shape
         os.makedirs(os.environ["WTZ_TEST_KEEP_STDERR"], exist_ok=True)
         open(os.path.join(os.environ["WTZ_TEST_KEEP_STDERR"], "scale_%s%s.stderr.txt" % (name, "_" + "_".join(x.strip("-").replace(",", "") for x in extra) if extra else "")), "wb").write(r.stderr)

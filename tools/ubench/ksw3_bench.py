@@ -2,7 +2,8 @@
 """K-sw3 in isolation: a seeded sample of the extension jobs of one configs[2] zmo step (geometry dumped by `WTZ_PROFILE_PAIR=1 WTZ_EXT_DUMP=... bench.py`,
 40 000 of 984 153 jobs: tools/ubench/ksw3_jobs_yeast100.npz) on synthetic homologous sequences (two 15 %-error copies of one random segment per job,
 aligned from their common start - what an end extension sees), run through the device forms of kswx_extend_align_shift_core via the test-only ABI entry
-wtz_test_dp:  1 = round-4 one-wave register kernel, 2 = four-wave kernel, 5 = one-wave kernel in the anti-diagonal frame (round 5), 0 = the product's dispatch.
+wtz_test_dp:  1 = round-4 one-wave register kernel, 2 = four-wave kernel, 5 = one-wave kernel in the anti-diagonal frame (round 5), 6 = the frame form on four
+wavefronts (round 6), 0 = the product's dispatch.
 Every form's results are compared with form 1's (itself pinned to the reference's vectors by tests/test_gpu_dp_forms.py) - all fields and every CIGAR word.
 
   python tools/ubench/ksw3_bench.py [--forms 1,5,0] [--jobs 40000] [--reps 3]
