@@ -53,11 +53,13 @@ typedef struct { char **a; int n, cap; } strlist_t;
 static void sl_push(strlist_t *l, char *s){ if(l->n == l->cap){ l->cap = l->cap ? l->cap * 2 : 4; l->a = (char**)hx_realloc(l->a, sizeof(char*) * (size_t)l->cap); } l->a[l->n++] = s; }
 
 typedef struct { uint64_t e; uint32_t pidx; uint32_t pad; } cand_t;
-static int gt_cand(const void *a, const void *b, void *ctx){ (void)ctx; return (uint32_t)((const cand_t*)b)->e > (uint32_t)((const cand_t*)a)->e; }   /* wtzmo.c:821 */
+#define GT_CAND(a, b) ((uint32_t)(b)->e > (uint32_t)(a)->e)                  /* wtzmo.c:821 */
+HX_DEFINE_SORT_EXACT(sort_cands_exact, cand_t, GT_CAND)
 static int gt_read(const void *a, const void *b, void *ctx){ (void)ctx; return ((const hx_read_t*)b)->len > ((const hx_read_t*)a)->len; }               /* wtzmo.c:1708 */
 
 typedef struct { uint32_t pb2, dir, ovl, closed, pidx; } seed_t;
-static int gt_seed(const void *a, const void *b, void *ctx){ (void)ctx; return ((const seed_t*)b)->ovl > ((const seed_t*)a)->ovl; }                    /* wtzmo.c:986 */
+#define GT_SEED(a, b) ((b)->ovl > (a)->ovl)                                 /* wtzmo.c:986 */
+HX_DEFINE_SORT_EXACT(sort_seeds_exact, seed_t, GT_SEED)
 
 typedef struct { uint32_t pb1, pb2, dir2; int qb, qe, tb, te, score, mat, mis, ins, del, aln; char *cigar; } hit_t;
 
@@ -513,6 +515,19 @@ static inline float rep_weight(const uint16_t *windeps, const wtz_params_c *P, i
 	return w;
 }
 
+/* The commit of a query walks its pairs' summaries and window boxes - results that arrived from the device a moment ago and are in no cache - in candidate order:
+ * 72 of the commit's 240 ms per configs[2] step were those misses (round 6, timers in parts).  The lines of the NEXT query's pairs are requested while this one is committed. */
+static void commit_prefetch(const eng_t *E, const batch_t *b, uint32_t slot){
+	if(!b->want[slot] || E->masked[b->bq[slot]]) return;
+	const uint32_t n = b->nrow[slot]; const int dm = E->P.dot_matrix;
+	for(uint32_t k = 0; k < n; k++){
+		const uint32_t g = b->rowpair[(size_t)slot * E->stride + k];
+		if(g == 0xFFFFFFFFu) continue;
+		const part_t *pt = CPART_OF(b, g); const uint32_t li = LOCAL_OF(b, g);
+		__builtin_prefetch(&pt->sum[li], 0, 1);
+		if(!dm){ __builtin_prefetch(&pt->box_off[(size_t)li * 2], 0, 1); if(pt->item_of) __builtin_prefetch(&pt->item_of[li], 0, 1); }
+	}
+}
 /* ---------------- commit of one query over the batch results (wtzmo.c:806-1130) ---------------- */
 static void commit_query(eng_t *E, batch_t *b, uint32_t slot){
 	const wtz_params_c *P = &E->P;
@@ -534,9 +549,20 @@ static void commit_query(eng_t *E, batch_t *b, uint32_t slot){
 		cand[i].e = b->rows[(size_t)slot * E->stride + i]; cand[i].pidx = b->rowpair[(size_t)slot * E->stride + i]; cand[i].pad = 0;
 		if(hx_set_has(&E->closed, hx_pair_key(pbid, cand[i].e >> 32))) cand[i].e &= 0xFFFFFFFF00000000ULL;
 	}
-	hx_sort_exact(cand, nc, sizeof(cand_t), gt_cand, NULL);
+	sort_cands_exact(cand, nc);
 	while(nc && (uint32_t)cand[nc - 1].e == 0) nc--;
 	const double tq1 = now_s(); E->t_cq[0] += tq1 - tq0;
+	if(!P->dot_matrix){     /* the window boxes of the pairs that will be walked below (their summaries were requested one query ago) */
+		for(uint32_t i = 0; i < nc; i++){
+			if(cand[i].pidx == 0xFFFFFFFFu) continue;
+			const part_t *pt = CPART_OF(b, cand[i].pidx); const uint32_t li = LOCAL_OF(b, cand[i].pidx);
+			const wtz_pair_summary_t *S = &pt->sum[li];
+			if(!S->gate) continue;
+			const wtz_winbox_t *bx = pt->boxes + pt->box_off[(size_t)li * 2];
+			const uint32_t nb = S->nwin[0] + S->nwin[1];
+			for(uint32_t k = 0; k < nb; k += 4) __builtin_prefetch(bx + k, 0, 1);      /* 16-byte boxes: four per line */
+		}
+	}
 	if(E->rows_all){       /* -G: the trimmed, sorted list persists as the reference's rdhits entry */
 		for(uint32_t i = 0; i < nc; i++) E->rows[(size_t)pbid * E->stride + i] = cand[i].e;
 		E->nrow[pbid] = nc;
@@ -611,13 +637,17 @@ static void commit_query(eng_t *E, batch_t *b, uint32_t slot){
 		if(ol * P->win_rep_cutoff < P->ztot * P->win_rep_norm) s->closed = 1;                 /* wtzmo.c:964 */
 	}
 	const double tqc = now_s(); E->t_cq1[2] += tqc - tqb;
-	hx_sort_exact(seeds, nseed, sizeof(seed_t), gt_seed, NULL);
+	sort_seeds_exact(seeds, nseed);
 	const double tq2 = now_s(); E->t_cq[1] += tq2 - tq1; E->t_cq1[3] += tq2 - tqc;
 	if(!E->do_align){
 		if(pd->capseed < nseed){ pd->capseed = nseed; pd->seeds = (seed_t*)hx_realloc(pd->seeds, sizeof(seed_t) * nseed); }
 		memcpy(pd->seeds, seeds, sizeof(seed_t) * nseed); pd->nseed = nseed;
 	} else {
 		uint32_t ncand = P->ncand;
+		for(uint32_t i = 0; i < nseed && i < ncand; i++){      /* the alignment results the loop below reads */
+			const part_t *pt = CPART_OF(b, seeds[i].pidx); const uint32_t item = pt->item_of[LOCAL_OF(b, seeds[i].pidx)];
+			if(item != 0xFFFFFFFFu) __builtin_prefetch(&pt->aln[item], 0, 1);
+		}
 		for(uint32_t i = 0; i < nseed && i < ncand; i++){
 			seed_t *s = &seeds[i];
 			if(s->closed){ ncand++; continue; }
@@ -1173,6 +1203,7 @@ static void process_range(eng_t *E, batch_t *b, uint32_t s0, uint32_t s1){
 	E->spec_pairs += b->npair; E->spec_items += b->nitem;
 	/* commit in query order with the reference's one-query masking lag (wtzmo.c:1315-1333) */
 	for(uint32_t s = s0; s < s1; s++){
+		if(s + 1 < s1) commit_prefetch(E, b, s + 1);
 		if(E->masked[b->bq[s]]) continue;
 		flush_pending(E);
 		commit_query(E, b, s);
@@ -1354,6 +1385,7 @@ static void process_batch(eng_t *E, batch_t *b){
 		b->holds_turn = 1;
 		E->spec_pairs += r_npair; E->spec_items += r_nitem;
 		for(uint32_t s = s0; s < s1; s++){
+			if(s + 1 < s1) commit_prefetch(E, b, s + 1);
 			if(E->masked[b->bq[s]]) continue;
 			flush_pending(E);
 			commit_query(E, b, s);
@@ -1954,7 +1986,7 @@ int main(int argc, char **argv){
 					uint32_t nc = tmp_n[k]; cand_t *cd = (cand_t*)hx_realloc(NULL, sizeof(cand_t) * (nc + 1));
 					for(uint32_t x = 0; x < nc; x++){ cd[x].e = tmp_rows[(size_t)k * E->stride + x]; cd[x].pidx = 0; cd[x].pad = 0;
 						if(hx_set_has(&E->closed, hx_pair_key(ids[a + k], cd[x].e >> 32))) cd[x].e &= 0xFFFFFFFF00000000ULL; }
-					hx_sort_exact(cd, nc, sizeof(cand_t), gt_cand, NULL);
+					sort_cands_exact(cd, nc);
 					while(nc && (uint32_t)cd[nc - 1].e == 0) nc--;
 					for(uint32_t x = 0; x < nc; x++) E->rows[(size_t)ids[a + k] * E->stride + x] = cd[x].e;
 					E->nrow[ids[a + k]] = nc; free(cd);

@@ -422,7 +422,10 @@ struct wtz_ctx {
 	int last_pool_fail = 0;      /* which pool the last WTZ_E_POOL came from: 1 = main, 2 = transient (wtz_pool_failure_kind) */
 	double ext_use_ratio = 0.4; uint64_t tpool_last_used = 0;      /* run_stitch_fused: share of the trace upper bounds the fused launches have really taken */
 	bool fused_ran = false;      /* this stitch stage's fused launch has run: the extension launches behind it only sweep up what it left open */
-	int env_ext_mw_rows = 2048;  /* WTZ_EXT_MW_ROWS: items whose two extensions can run at least this many rows go to the four-wave frame kernel beside the fused launch (0 = never) */
+	int env_ext_mw_rows = 0;     /* WTZ_EXT_MW_ROWS=<n>: items whose two extensions can run at least n rows go to the four-wave frame kernel (wtz_sw_frame_mw.h) beside the fused launch.
+	                              * Off by default: measured at configs[2] (gpurun_out/r06d) K-sw3 418 ms without it, 490 ms with n = 2048 (1 000 of 30 000 items per range), 654 ms with
+	                              * n = 1024, 418 ms with n = 4096 (5-8 items per range) - the launches are bound by the row RATE of the resident wavefronts (time = ~5 ms + 0.65 ms per
+	                              * million rows), not by their longest job, and four wavefronts spend 2.2 x the instructions of one on a row */
 	int env_ext_fr = 1;          /* WTZ_EXT_FR=0: K-sw3 one-wave jobs on the round-4 register kernel (wtz_extend_shift_reg) instead of the frame form (wtz_sw_frame.h) */
 	int env_ext_split = 0;       /* WTZ_EXT_SPLIT=1: K-sw3 one-wave jobs in two launches by band class (experiment) */
 	int env_heavy_first = -1;    /* WTZ_PAIR_HEAVY_FIRST: the heaviest pairs of a K_pair launch first (-1 = engine default: dmo on, zmo off) */
