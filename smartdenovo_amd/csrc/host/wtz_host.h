@@ -243,6 +243,25 @@ static int hx_set_has(const hx_set_t *s, uint64_t v){
 	while(s->tab[i] != ~0ULL){ if(s->tab[i] == v) return 1; i = (i + 1) & m; }
 	return 0;
 }
+/* the same probe for a thread that reads while the owner inserts (round 6: the commit's helper threads).  Safe as long as the table does not grow meanwhile
+ * (hx_set_reserve in front): a slot goes from empty to a key in one aligned 64-bit store, so a reader sees the key or not yet - callers detect "not yet" by
+ * other means (wtzmo_main.c: closed_touch) */
+static int hx_set_has_racy(const hx_set_t *s, uint64_t v){
+	if(!s->cap) return 0;
+	size_t m = s->cap - 1, i = hx_mix(v) & m;
+	for(;;){ const uint64_t x = __atomic_load_n(&s->tab[i], __ATOMIC_RELAXED); if(x == ~0ULL) return 0; if(x == v) return 1; i = (i + 1) & m; }
+}
+static int hx_set_put(hx_set_t *s, uint64_t v);
+/* room for `extra` more keys without a growth step */
+static void hx_set_reserve(hx_set_t *s, size_t extra){
+	while((s->n + extra + 1) * 2 > s->cap){
+		size_t oc = s->cap; uint64_t *ot = s->tab;
+		s->cap = oc ? oc * 2 : 4096; s->n = 0;
+		s->tab = (uint64_t*)hx_realloc(NULL, s->cap * 8); memset(s->tab, 0xFF, s->cap * 8);
+		for(size_t k = 0; k < oc; k++) if(ot[k] != ~0ULL) hx_set_put(s, ot[k]);
+		free(ot);
+	}
+}
 static int hx_set_put(hx_set_t *s, uint64_t v){       /* returns 1 if newly inserted */
 	if((s->n + 1) * 2 > s->cap){
 		size_t oc = s->cap; uint64_t *ot = s->tab;
@@ -253,7 +272,7 @@ static int hx_set_put(hx_set_t *s, uint64_t v){       /* returns 1 if newly inse
 	}
 	size_t m = s->cap - 1, i = hx_mix(v) & m;
 	while(s->tab[i] != ~0ULL){ if(s->tab[i] == v) return 0; i = (i + 1) & m; }
-	s->tab[i] = v; s->n++; return 1;
+	__atomic_store_n(&s->tab[i], v, __ATOMIC_RELAXED); s->n++; return 1;
 }
 /* ---- the ORDER of the -9 pair file.  The reference writes closed_alns in the iteration order of its own hash set (wtzmo.c:1797-1801):
  * slot order of an open-addressing table (hashset.h:64-432: linear probing, Jenkins 64-bit hash of the key modulo a size taken from a

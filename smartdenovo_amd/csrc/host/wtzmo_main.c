@@ -60,6 +60,12 @@ static int gt_read(const void *a, const void *b, void *ctx){ (void)ctx; return (
 typedef struct { uint32_t pb2, dir, ovl, closed, pidx; } seed_t;
 #define GT_SEED(a, b) ((b)->ovl > (a)->ovl)                                 /* wtzmo.c:986 */
 HX_DEFINE_SORT_EXACT(sort_seeds_exact, seed_t, GT_SEED)
+/* what the order-free part of a query's commit (closed filter, candidate order, window depth, seed weights, seed order) leaves for the sequential part;
+ * buffers grow and are kept.  dep: +1 / -1 marks, then the running depth, as 16-bit words (the reference's counters are u2i and wrap the same way): zero between queries */
+typedef struct {
+	cand_t *cand; size_t capcand; seed_t *seeds; size_t capseeds; uint16_t *dep; size_t capdep;
+	uint32_t nc, nseed, ngate; double t[5];      /* t: candidate rows + closed filter + order | window marks | running depth | seed weights | seed order */
+} cq_work_t;
 
 typedef struct { uint32_t pb1, pb2, dir2; int qb, qe, tb, te, score, mat, mis, ins, del, aln; char *cigar; } hit_t;
 
@@ -100,7 +106,10 @@ typedef struct eng_s {
 	/* commit_query scratch kept across queries (round 6: the two calloc'ed depth arrays of a query were 60 KB of zeroing + a 10 000-step scalar prefix each -
 	 * more than half of the sequential commit): cq_dep = +1 / -1 marks, then the running depth, as 16-bit words (the reference's counters are u2i and wrap the
 	 * same way); only the span the query's windows touch is summed, and it is zeroed again behind the query */
-	void *cq_cand; size_t cq_capcand; void *cq_seeds; size_t cq_capseeds; uint16_t *cq_dep; size_t cq_capdep;
+	cq_work_t cq;                      /* the commit thread's own */
+	struct cq_spec_s *spec;            /* helper threads that prepare the queries ahead of the commit (cq_spec_*) */
+	uint32_t *closed_touch;            /* per read: number of closed pairs with this read added so far; a prepared query is valid iff its read's count has not moved */
+	uint64_t n_spec_hit, n_spec_miss; double t_spec_wait, t_spec_ctl, t_flush;
 	/* stats */
 	char *cig_keep[16]; uint64_t cig_keep_cap[16];      /* page-locked CIGAR text buffer of worker w, kept across steps (pinning is the expensive part) */
 	double t_cq1[4];            /* section 1 of commit_query in its parts: window marks | running depth | seed weights | seed order */
@@ -436,6 +445,8 @@ static void flush_pending(eng_t *E){
 			order_push(E, p->closed[i]);
 			uint32_t a = (uint32_t)(p->closed[i] >> 33), b = (uint32_t)((p->closed[i] & 0xFFFFFFFFu) >> 1);
 			E->pair_bp += (uint64_t)E->rdlen[a] + E->rdlen[b]; E->n_pairs++;
+			/* behind the insertion: a helper that sees the new count sees the pair (cq_spec_*) */
+			__atomic_fetch_add(&E->closed_touch[a], 1u, __ATOMIC_RELEASE); __atomic_fetch_add(&E->closed_touch[b], 1u, __ATOMIC_RELEASE);
 		}
 	}
 	p->nclosed = 0;
@@ -529,40 +540,173 @@ static void commit_prefetch(const eng_t *E, const batch_t *b, uint32_t slot){
 	}
 }
 /* ---------------- commit of one query over the batch results (wtzmo.c:806-1130) ---------------- */
+/* The part that does not depend on the ORDER of the commits, only on the set of closed pairs: candidates filtered by that set, in the reference's order, trimmed
+ * (wtzmo.c:813-822); window depth, repeat-weighted seeds, seed order (wtzmo.c:905-986).  `racy`: called by a helper thread beside the committing thread (cq_spec_*). */
+static void cq_prepare(const eng_t *E, const batch_t *b, uint32_t slot, cq_work_t *w, int racy){
+	const wtz_params_c *P = &E->P;
+	const uint32_t pbid = b->bq[slot];
+	const int alen = (int)E->rdlen[pbid];
+	const double tq0 = now_s();
+	uint32_t nc = b->nrow[slot];
+	if(w->capcand < (size_t)nc + 1){ w->capcand = ((size_t)nc + 1) * 2; w->cand = (cand_t*)hx_realloc(w->cand, sizeof(cand_t) * w->capcand); }
+	cand_t *cand = w->cand;
+	for(uint32_t i = 0; i < nc; i++){
+		cand[i].e = b->rows[(size_t)slot * E->stride + i]; cand[i].pidx = b->rowpair[(size_t)slot * E->stride + i]; cand[i].pad = 0;
+		const uint64_t key = hx_pair_key(pbid, cand[i].e >> 32);
+		if(racy ? hx_set_has_racy(&E->closed, key) : hx_set_has(&E->closed, key)) cand[i].e &= 0xFFFFFFFF00000000ULL;
+	}
+	sort_cands_exact(cand, nc);
+	while(nc && (uint32_t)cand[nc - 1].e == 0) nc--;
+	w->nc = nc; w->nseed = 0; w->ngate = 0;
+	const double tq1 = now_s(); w->t[0] = tq1 - tq0; w->t[1] = w->t[2] = w->t[3] = w->t[4] = 0;
+	if(P->dot_matrix) return;
+	for(uint32_t i = 0; i < nc; i++){       /* the window boxes of the pairs that are walked below (their summaries were requested one query ago: commit_prefetch) */
+		if(cand[i].pidx == 0xFFFFFFFFu) continue;
+		const part_t *pt = CPART_OF(b, cand[i].pidx); const uint32_t li = LOCAL_OF(b, cand[i].pidx);
+		const wtz_pair_summary_t *S = &pt->sum[li];
+		if(!S->gate) continue;
+		const wtz_winbox_t *bx = pt->boxes + pt->box_off[(size_t)li * 2];
+		const uint32_t nb = S->nwin[0] + S->nwin[1];
+		for(uint32_t k = 0; k < nb; k += 4) __builtin_prefetch(bx + k, 0, 1);      /* 16-byte boxes: four per line */
+	}
+	if(w->capdep < (size_t)alen + 24){      /* zero from the start and after every query */
+		w->capdep = ((size_t)alen + 24) * 2; free(w->dep);
+		w->dep = (uint16_t*)calloc(w->capdep, 2); if(!w->dep){ fprintf(stderr, " -- Out of memory --\n"); DIE_NOW(); }
+	}
+	uint16_t *windeps = w->dep;
+	int dep_lo = alen, dep_hi = 0;             /* span of the marks */
+	if(w->capseeds < (size_t)nc + 1){ w->capseeds = ((size_t)nc + 1) * 2; w->seeds = (seed_t*)hx_realloc(w->seeds, sizeof(seed_t) * w->capseeds); }
+	seed_t *seeds = w->seeds; uint32_t nseed = 0, ngate = 0;
+	for(uint32_t i = 0; i < nc; i++){
+		const uint32_t id2 = (uint32_t)(cand[i].e >> 32);
+		if(cand[i].pidx == 0xFFFFFFFFu){ fprintf(stderr, " -- internal error: pair (%u,%u) missing from the batch plan --\n", pbid, id2); DIE_NOW(); }
+		const part_t *pt = CPART_OF(b, cand[i].pidx); const uint32_t li = LOCAL_OF(b, cand[i].pidx);
+		const wtz_pair_summary_t *S = &pt->sum[li];
+		if(!S->gate) continue;
+		ngate++;
+		for(uint32_t dir = 0; dir < 2; dir++){
+			const wtz_winbox_t *bx = pt->boxes + pt->box_off[(size_t)li * 2 + dir];
+			for(uint32_t k = 0; k < S->nwin[dir]; k++){       /* wtzmo.c:908 increments windeps over [beg,end): kept as +1/-1 marks, summed below */
+				const int wb = bx[k].beg[0], we = bx[k].end[0];
+				if(wb < we){ windeps[wb]++; windeps[we]--; if(wb < dep_lo) dep_lo = wb; if(we > dep_hi) dep_hi = we; }
+			}
+		}
+		const uint32_t dir = (S->ovl[0] < S->ovl[1]);
+		if(S->ovl[dir] >= P->ztot){ seed_t sd; sd.pb2 = id2; sd.dir = dir; sd.ovl = S->ovl[dir]; sd.closed = 0; sd.pidx = cand[i].pidx; seeds[nseed++] = sd; }
+	}
+	const double tqa = now_s(); w->t[1] = tqa - tq1;
+	/* running depth over the span of the marks (it is zero outside: every interval is closed); arithmetic modulo 2^16 like the reference's u2i counters */
+	if(dep_lo < dep_hi) depth_prefix_u16(windeps, (size_t)(dep_lo & ~7), (size_t)dep_hi + 1);
+	const double tqb = now_s(); w->t[2] = tqb - tqa;
+	/* repeat weighting: the reference fills weights[0..alen) (wtzmo.c:933-936) but only reads the entry at the middle of each
+	 * window (954): evaluated on demand by rep_weight() with the same float/double mix */
+	for(uint32_t i = 0; i < nseed; i++){
+		seed_t *sd = &seeds[i];
+		const int blen = (int)E->rdlen[sd->pb2];
+		const part_t *pt = CPART_OF(b, sd->pidx); const uint32_t li = LOCAL_OF(b, sd->pidx);
+		const wtz_pair_summary_t *S = &pt->sum[li];
+		const wtz_winbox_t *bx = pt->boxes + pt->box_off[(size_t)li * 2 + sd->dir];
+		uint32_t ol = 0; double avg;
+		for(uint32_t k = 0; k < S->nwin[sd->dir]; k++){
+			avg = (bx[k].end[0] - bx[k].beg[0]) * rep_weight(windeps, P, alen, (bx[k].beg[0] + bx[k].end[0]) / 2);
+			int mid = (int)((bx[k].beg[1] + bx[k].end[1]) / 2);
+			int df = mid < blen / 2 ? blen / 2 - mid : mid - blen / 2;
+			avg = avg * (0.3 + 0.7 * (df / (blen / 2.0)));
+			ol += avg;
+		}
+		sd->ovl = ol & 0x1FFFFFFFu;
+		if(ol * P->win_rep_cutoff < P->ztot * P->win_rep_norm) sd->closed = 1;                 /* wtzmo.c:964 */
+	}
+	const double tqc = now_s(); w->t[3] = tqc - tqb;
+	sort_seeds_exact(seeds, nseed);
+	if(dep_lo < dep_hi) memset(windeps + (dep_lo & ~7), 0, 2 * (size_t)(dep_hi + 1 - (dep_lo & ~7)));
+	w->nseed = nseed; w->ngate = ngate; w->t[4] = now_s() - tqc;
+}
+
+/* ---- queries prepared ahead of the commit by helper threads (round 6).  The prepared part of a query depends on the closed-pair set only through the pairs that
+ * hold the query's own read, so: every pair that enters the set bumps a counter of both its reads (flush_pending, AFTER the insertion); a helper notes the
+ * query's counter BEFORE it reads the set; the committing thread takes a prepared query iff the counter has not moved since - otherwise it prepares the query
+ * again itself, as before.  The set is read while the committing thread inserts into it: no growth happens meanwhile (hx_set_reserve in front of the range),
+ * and a slot goes from empty to a key in one aligned store.  WTZ_COMMIT_HELPERS=<n> (default 4, 0 = none). ---- */
+#define CQ_RING 64u
+typedef struct { cq_work_t w; uint32_t v0; int skipped; uint64_t ready_for; } cq_ent_t;      /* ready_for == slot + 1: filled for that slot */
+typedef struct cq_spec_s {
+	eng_t *E; const batch_t *b; uint32_t s0, s1;
+	uint64_t next, done; int stop, active, nth;        /* next: the slot a helper takes next; done: slots below it are consumed (a ring entry is free again) */
+	pthread_t th[16]; cq_ent_t ring[CQ_RING];
+} cq_spec_t;
+static void *cq_spec_main(void *arg){
+	cq_spec_t *sp = (cq_spec_t*)arg; eng_t *E = sp->E; const batch_t *b = sp->b;
+	for(;;){
+		uint64_t s = __atomic_load_n(&sp->next, __ATOMIC_RELAXED);
+		if(s >= sp->s1 || __atomic_load_n(&sp->stop, __ATOMIC_RELAXED)) break;
+		if(s >= __atomic_load_n(&sp->done, __ATOMIC_ACQUIRE) + CQ_RING){ __builtin_ia32_pause(); continue; }      /* the ring is full: the commit has to catch up */
+		if(!__atomic_compare_exchange_n(&sp->next, &s, s + 1, 0, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) continue;
+		cq_ent_t *en = &sp->ring[s % CQ_RING];
+		/* the entry's previous occupant (slot s - CQ_RING) may have been passed by the commit without being waited for (a masked or saturated query) while its helper is
+		 * still at work: it has been taken before this slot and will finish */
+		if(s >= (uint64_t)sp->s0 + CQ_RING) while(__atomic_load_n(&en->ready_for, __ATOMIC_ACQUIRE) != s - CQ_RING + 1) __builtin_ia32_pause();
+		const uint32_t pbid = b->bq[s];
+		en->skipped = (!b->want[s] || __atomic_load_n(&E->masked[pbid], __ATOMIC_RELAXED)) ? 1 : 0;
+		if(!en->skipped){
+			en->v0 = __atomic_load_n(&E->closed_touch[pbid], __ATOMIC_ACQUIRE);
+			cq_prepare(E, b, (uint32_t)s, &en->w, 1);
+		}
+		__atomic_store_n(&en->ready_for, s + 1, __ATOMIC_RELEASE);
+	}
+	return NULL;
+}
+static void cq_spec_start(eng_t *E, const batch_t *b, uint32_t s0, uint32_t s1, uint64_t npair){
+	static int nth = -1;
+	if(nth < 0){ const char *e = getenv("WTZ_COMMIT_HELPERS"); nth = e ? atoi(e) : 4; if(nth < 0) nth = 0; if(nth > 16) nth = 16; }
+	if(!E->spec){ E->spec = (cq_spec_t*)calloc(1, sizeof(cq_spec_t)); if(!E->spec) DIE_NOW(); }
+	cq_spec_t *sp = E->spec;
+	sp->active = 0;
+	if(nth == 0 || E->rows_all || s1 < s0 + 2) return;
+	hx_set_reserve(&E->closed, (size_t)npair * 2 + 4096);      /* every pair this commit can close, with room: the table must not grow under the helpers */
+	sp->E = E; sp->b = b; sp->s0 = s0; sp->s1 = s1; sp->next = s0; sp->done = s0; sp->stop = 0; sp->nth = 0;
+	for(uint32_t k = 0; k < CQ_RING; k++) sp->ring[k].ready_for = 0;
+	for(int k = 0; k < nth; k++){ if(pthread_create(&sp->th[sp->nth], NULL, cq_spec_main, sp) == 0) sp->nth++; }
+	sp->active = sp->nth > 0;
+}
+static inline void cq_spec_done(eng_t *E, uint32_t slot){ if(E->spec && E->spec->active) __atomic_store_n(&E->spec->done, (uint64_t)slot + 1, __ATOMIC_RELEASE); }
+static void cq_spec_stop(eng_t *E){
+	cq_spec_t *sp = E->spec;
+	if(!sp || !sp->active) return;
+	__atomic_store_n(&sp->stop, 1, __ATOMIC_RELAXED);
+	for(int k = 0; k < sp->nth; k++) pthread_join(sp->th[k], NULL);
+	sp->active = 0;
+}
+/* the prepared part of query `slot`: a helper's if it is still valid, else made here */
+static cq_work_t *cq_take(eng_t *E, batch_t *b, uint32_t slot){
+	cq_spec_t *sp = E->spec;
+	if(sp && sp->active){
+		cq_ent_t *en = &sp->ring[slot % CQ_RING];
+		const double t0 = now_s();
+		while(__atomic_load_n(&en->ready_for, __ATOMIC_ACQUIRE) != (uint64_t)slot + 1) __builtin_ia32_pause();      /* slots are taken in order: some helper has this one */
+		E->t_spec_wait += now_s() - t0;
+		if(!en->skipped && __atomic_load_n(&E->closed_touch[b->bq[slot]], __ATOMIC_ACQUIRE) == en->v0){ E->n_spec_hit++; return &en->w; }
+		E->n_spec_miss++;
+	}
+	cq_prepare(E, b, slot, &E->cq, 0);
+	E->t_cq[0] += E->cq.t[0]; E->t_cq[1] += E->cq.t[1] + E->cq.t[2] + E->cq.t[3] + E->cq.t[4];
+	for(int k = 0; k < 4; k++) E->t_cq1[k] += E->cq.t[k + 1];
+	return &E->cq;
+}
+
 static void commit_query(eng_t *E, batch_t *b, uint32_t slot){
 	const wtz_params_c *P = &E->P;
 	pending_t *pd = &E->pend;
 	const uint32_t pbid = b->bq[slot];
-	const int alen = (int)E->rdlen[pbid];
 	pd->rd_id = pbid;
 	const uint32_t nbest = nbest_of(E, pbid);
 	uint32_t bcov = E->rdcovs[pbid];
 	if(bcov >= nbest) return;
 	E->used_queries++; b->used_queries++;
-	const double tq0 = now_s();
-	/* candidates: closed filter, exact order, trim (wtzmo.c:813-822) */
 	if(!b->want[slot]){ fprintf(stderr, " -- internal error: no candidate row for read %u --\n", pbid); DIE_NOW(); }
-	uint32_t nc = b->nrow[slot];
-	if(E->cq_capcand < (size_t)nc + 1){ E->cq_capcand = ((size_t)nc + 1) * 2; E->cq_cand = hx_realloc(E->cq_cand, sizeof(cand_t) * E->cq_capcand); }
-	cand_t *cand = (cand_t*)E->cq_cand;
-	for(uint32_t i = 0; i < nc; i++){
-		cand[i].e = b->rows[(size_t)slot * E->stride + i]; cand[i].pidx = b->rowpair[(size_t)slot * E->stride + i]; cand[i].pad = 0;
-		if(hx_set_has(&E->closed, hx_pair_key(pbid, cand[i].e >> 32))) cand[i].e &= 0xFFFFFFFF00000000ULL;
-	}
-	sort_cands_exact(cand, nc);
-	while(nc && (uint32_t)cand[nc - 1].e == 0) nc--;
-	const double tq1 = now_s(); E->t_cq[0] += tq1 - tq0;
-	if(!P->dot_matrix){     /* the window boxes of the pairs that will be walked below (their summaries were requested one query ago) */
-		for(uint32_t i = 0; i < nc; i++){
-			if(cand[i].pidx == 0xFFFFFFFFu) continue;
-			const part_t *pt = CPART_OF(b, cand[i].pidx); const uint32_t li = LOCAL_OF(b, cand[i].pidx);
-			const wtz_pair_summary_t *S = &pt->sum[li];
-			if(!S->gate) continue;
-			const wtz_winbox_t *bx = pt->boxes + pt->box_off[(size_t)li * 2];
-			const uint32_t nb = S->nwin[0] + S->nwin[1];
-			for(uint32_t k = 0; k < nb; k += 4) __builtin_prefetch(bx + k, 0, 1);      /* 16-byte boxes: four per line */
-		}
-	}
+	cq_work_t *w = cq_take(E, b, slot);
+	const double tq2 = now_s();
+	cand_t *cand = w->cand; const uint32_t nc = w->nc;
 	if(E->rows_all){       /* -G: the trimmed, sorted list persists as the reference's rdhits entry */
 		for(uint32_t i = 0; i < nc; i++) E->rows[(size_t)pbid * E->stride + i] = cand[i].e;
 		E->nrow[pbid] = nc;
@@ -586,59 +730,11 @@ static void commit_query(eng_t *E, batch_t *b, uint32_t slot){
 				emit_record(E, &H, NULL, 0, -1);
 			}
 		}
+		E->t_cq[2] += now_s() - tq2;
 		return;
 	}
-	if(E->cq_capdep < (size_t)alen + 24){      /* zero from the start and after every query */
-		E->cq_capdep = ((size_t)alen + 24) * 2; free(E->cq_dep);
-		E->cq_dep = (uint16_t*)calloc(E->cq_capdep, 2); if(!E->cq_dep){ fprintf(stderr, " -- Out of memory --\n"); DIE_NOW(); }
-	}
-	uint16_t *windeps = E->cq_dep;
-	int dep_lo = alen, dep_hi = 0;             /* span of the marks */
-	if(E->cq_capseeds < (size_t)nc + 1){ E->cq_capseeds = ((size_t)nc + 1) * 2; E->cq_seeds = hx_realloc(E->cq_seeds, sizeof(seed_t) * E->cq_capseeds); }
-	seed_t *seeds = (seed_t*)E->cq_seeds; uint32_t nseed = 0;
-	for(uint32_t i = 0; i < nc; i++){
-		const uint32_t id2 = (uint32_t)(cand[i].e >> 32);
-		if(cand[i].pidx == 0xFFFFFFFFu){ fprintf(stderr, " -- internal error: pair (%u,%u) missing from the batch plan --\n", pbid, id2); DIE_NOW(); }
-		const part_t *pt = CPART_OF(b, cand[i].pidx); const uint32_t li = LOCAL_OF(b, cand[i].pidx);
-		const wtz_pair_summary_t *S = &pt->sum[li];
-		if(!S->gate) continue;
-		E->used_pairs++;
-		for(uint32_t dir = 0; dir < 2; dir++){
-			const wtz_winbox_t *bx = pt->boxes + pt->box_off[(size_t)li * 2 + dir];
-			for(uint32_t k = 0; k < S->nwin[dir]; k++){       /* wtzmo.c:908 increments windeps over [beg,end): kept as +1/-1 marks, summed below */
-				const int wb = bx[k].beg[0], we = bx[k].end[0];
-				if(wb < we){ windeps[wb]++; windeps[we]--; if(wb < dep_lo) dep_lo = wb; if(we > dep_hi) dep_hi = we; }
-			}
-		}
-		const uint32_t dir = (S->ovl[0] < S->ovl[1]);
-		if(S->ovl[dir] >= P->ztot){ seed_t s; s.pb2 = id2; s.dir = dir; s.ovl = S->ovl[dir]; s.closed = 0; s.pidx = cand[i].pidx; seeds[nseed++] = s; }
-	}
-	const double tqa = now_s(); E->t_cq1[0] += tqa - tq1;
-	/* running depth over the span of the marks (it is zero outside: every interval is closed); arithmetic modulo 2^16 like the reference's u2i counters */
-	if(dep_lo < dep_hi) depth_prefix_u16(windeps, (size_t)(dep_lo & ~7), (size_t)dep_hi + 1);
-	const double tqb = now_s(); E->t_cq1[1] += tqb - tqa;
-	/* repeat weighting: the reference fills weights[0..alen) (wtzmo.c:933-936) but only reads the entry at the middle of each
-	 * window (954): evaluated on demand by rep_weight() with the same float/double mix */
-	for(uint32_t i = 0; i < nseed; i++){
-		seed_t *s = &seeds[i];
-		const int blen = (int)E->rdlen[s->pb2];
-		const part_t *pt = CPART_OF(b, s->pidx); const uint32_t li = LOCAL_OF(b, s->pidx);
-		const wtz_pair_summary_t *S = &pt->sum[li];
-		const wtz_winbox_t *bx = pt->boxes + pt->box_off[(size_t)li * 2 + s->dir];
-		uint32_t ol = 0; double avg;
-		for(uint32_t k = 0; k < S->nwin[s->dir]; k++){
-			avg = (bx[k].end[0] - bx[k].beg[0]) * rep_weight(windeps, P, alen, (bx[k].beg[0] + bx[k].end[0]) / 2);
-			int mid = (int)((bx[k].beg[1] + bx[k].end[1]) / 2);
-			int df = mid < blen / 2 ? blen / 2 - mid : mid - blen / 2;
-			avg = avg * (0.3 + 0.7 * (df / (blen / 2.0)));
-			ol += avg;
-		}
-		s->ovl = ol & 0x1FFFFFFFu;
-		if(ol * P->win_rep_cutoff < P->ztot * P->win_rep_norm) s->closed = 1;                 /* wtzmo.c:964 */
-	}
-	const double tqc = now_s(); E->t_cq1[2] += tqc - tqb;
-	sort_seeds_exact(seeds, nseed);
-	const double tq2 = now_s(); E->t_cq[1] += tq2 - tq1; E->t_cq1[3] += tq2 - tqc;
+	E->used_pairs += w->ngate;
+	seed_t *seeds = w->seeds; const uint32_t nseed = w->nseed;
 	if(!E->do_align){
 		if(pd->capseed < nseed){ pd->capseed = nseed; pd->seeds = (seed_t*)hx_realloc(pd->seeds, sizeof(seed_t) * nseed); }
 		memcpy(pd->seeds, seeds, sizeof(seed_t) * nseed); pd->nseed = nseed;
@@ -689,7 +785,6 @@ static void commit_query(eng_t *E, batch_t *b, uint32_t slot){
 			}
 		}
 	}
-	if(dep_lo < dep_hi) memset(windeps + (dep_lo & ~7), 0, 2 * (size_t)(dep_hi + 1 - (dep_lo & ~7)));
 	E->t_cq[2] += now_s() - tq2;
 }
 
@@ -1202,12 +1297,13 @@ static void process_range(eng_t *E, batch_t *b, uint32_t s0, uint32_t s1){
 	b->holds_turn = 1;
 	E->spec_pairs += b->npair; E->spec_items += b->nitem;
 	/* commit in query order with the reference's one-query masking lag (wtzmo.c:1315-1333) */
+	{ const double tc = now_s(); cq_spec_start(E, b, s0, s1, b->npair); E->t_spec_ctl += now_s() - tc; }
 	for(uint32_t s = s0; s < s1; s++){
 		if(s + 1 < s1) commit_prefetch(E, b, s + 1);
-		if(E->masked[b->bq[s]]) continue;
-		flush_pending(E);
-		commit_query(E, b, s);
+		if(!E->masked[b->bq[s]]){ const double tf = now_s(); flush_pending(E); E->t_flush += now_s() - tf; commit_query(E, b, s); }
+		cq_spec_done(E, s);
 	}
+	{ const double tc = now_s(); cq_spec_stop(E); E->t_spec_ctl += now_s() - tc; }
 	out_submit(&g_ow);      /* nothing of this batch stays in the chunk under construction (see out_wait_ext) */
 	E->t_commit += now_s() - tg1;
 	pthread_mutex_unlock(&E->mu);
@@ -1384,12 +1480,13 @@ static void process_batch(eng_t *E, batch_t *b){
 		while(!b->holds_turn && E->commit_seq != b->seq) pthread_cond_wait(&E->cv, &E->mu);
 		b->holds_turn = 1;
 		E->spec_pairs += r_npair; E->spec_items += r_nitem;
+		{ const double tc = now_s(); cq_spec_start(E, b, s0, s1, r_npair); E->t_spec_ctl += now_s() - tc; }
 		for(uint32_t s = s0; s < s1; s++){
 			if(s + 1 < s1) commit_prefetch(E, b, s + 1);
-			if(E->masked[b->bq[s]]) continue;
-			flush_pending(E);
-			commit_query(E, b, s);
+			if(!E->masked[b->bq[s]]){ const double tf = now_s(); flush_pending(E); E->t_flush += now_s() - tf; commit_query(E, b, s); }
+			cq_spec_done(E, s);
 		}
+		{ const double tc = now_s(); cq_spec_stop(E); E->t_spec_ctl += now_s() - tc; }
 		out_submit(&g_ow);
 		E->t_commit += now_s() - tc0;
 		E->n_ranges++;
@@ -1794,6 +1891,7 @@ int main(int argc, char **argv){
 	fprintf(stderr, "[wtzmo-mi355x] %u reads (+%u query-only), %llu bp\n", n_rd, E->st.n_qr, (unsigned long long)E->st.nbase);
 	E->masked = (uint8_t*)calloc((size_t)n_all + 1, 1);
 	E->rdcovs = (uint32_t*)calloc((size_t)n_all + 1, 4);
+	E->closed_touch = (uint32_t*)calloc((size_t)n_all + 1, 4);
 	hx_names_t nm; hx_names_build(&nm, E->st.reads, n_rd);
 	char *cols[4];
 	if(obts.n){
@@ -1917,7 +2015,7 @@ int main(int argc, char **argv){
 			for(size_t i = 0; i < nclosed0; i++) hx_set_put(&E->closed, closed0[i]);
 			E->n_order = n_order0;
 			E->pair_bp = E->n_pairs = E->nrec = 0;
-			memset(E->t_cq, 0, sizeof E->t_cq); memset(E->t_cq1, 0, sizeof E->t_cq1); E->t_gpu = E->t_commit = E->t_zbatch = 0; memset(E->t_call, 0, sizeof E->t_call); E->t_io[0] = E->t_io[1] = 0; E->spec_pairs = E->used_pairs = E->spec_items = E->used_items = E->spec_queries = E->used_queries = 0;
+			memset(E->t_cq, 0, sizeof E->t_cq); memset(E->t_cq1, 0, sizeof E->t_cq1); E->n_spec_hit = E->n_spec_miss = 0; E->t_spec_wait = E->t_spec_ctl = E->t_flush = 0; memset(E->closed_touch, 0, 4 * ((size_t)n_all + 1)); E->t_gpu = E->t_commit = E->t_zbatch = 0; memset(E->t_call, 0, sizeof E->t_call); E->t_io[0] = E->t_io[1] = 0; E->spec_pairs = E->used_pairs = E->spec_items = E->used_items = E->spec_queries = E->used_queries = 0;
 			E->rows_all = 0; E->n_batches = 0; E->n_split = 0; E->n_ranges = 0; E->bytes_per_pair = 0;      /* every repeat plans like a cold run: probe range first */
 			E->pend.rd_id = 0xFFFFFFFFu; E->pend.nhit = E->pend.nmask = E->pend.nclosed = E->pend.nseed = 0;
 			if(strcmp(output, "-")){
@@ -2075,6 +2173,7 @@ int main(int argc, char **argv){
 		fprintf(stderr, "[wtzmo-mi355x] %llu records, %llu pairs aligned, %llu pair-bp, %.3f s (index %.3f s)\n", (unsigned long long)E->nrec, (unsigned long long)E->n_pairs, (unsigned long long)E->pair_bp, t1 - t0, t_index);
 		fprintf(stderr, "[wtzmo-mi355x] host seconds: in GPU-stage calls %.3f, commit %.3f, per-batch z-index %.3f; writer thread: formatting %.3f, write %.3f; waiting for it: %.3f before buffer reuse, %.3f at the end\n", E->t_gpu, E->t_commit, E->t_zbatch, g_ow.t_format, g_ow.t_write, E->t_io[0], E->t_io[1]);
 		fprintf(stderr, "[wtzmo-mi355x] commit sections: candidate rows + closed filter + order %.3f, window depth + seed weights %.3f, hits %.3f; planning the pairs of the ranges %.3f\n", E->t_cq[0], E->t_cq[1], E->t_cq[2], E->t_cq[3]);
+		fprintf(stderr, "[wtzmo-mi355x] queries prepared ahead of the commit by helper threads: %llu taken, %llu prepared again (their read's closed pairs had moved), %.3f s waited for a helper, %.3f s starting / joining them; merging the queries' results into the global state (flush) %.3f s; the sections below count the committing thread only\n", (unsigned long long)E->n_spec_hit, (unsigned long long)E->n_spec_miss, E->t_spec_wait, E->t_spec_ctl, E->t_flush);
 		fprintf(stderr, "[wtzmo-mi355x] window depth + seed weights in parts: window marks %.3f, running depth %.3f, seed weights %.3f, seed order %.3f\n", E->t_cq1[0], E->t_cq1[1], E->t_cq1[2], E->t_cq1[3]);
 		fprintf(stderr, "[wtzmo-mi355x] wall seconds per call: candidates %.3f pairs_seed %.3f pairs_windows %.3f pairs_align %.3f cigar_text %.3f\n", E->t_call[0], E->t_call[1], E->t_call[2], E->t_call[3], E->t_call[4]);
 	if(E->n_split) fprintf(stderr, "[wtzmo-mi355x] %llu range(s) had to be split after a scratch-pool overflow (planned at %.0f KB per pair)\n", (unsigned long long)E->n_split, E->bytes_per_pair / 1024.0);
@@ -2105,6 +2204,8 @@ int main(int argc, char **argv){
 	}
 	for(int w = 0; w < 16; w++) wtz_host_free(E->cig_keep[w]);
 	for(uint32_t d = 0; d < E->ndev; d++) wtz_ctx_destroy(E->ctxs[d]);
-	free(E->cq_cand); free(E->cq_seeds); free(E->cq_dep);
+	free(E->cq.cand); free(E->cq.seeds); free(E->cq.dep);
+	if(E->spec){ for(uint32_t k = 0; k < CQ_RING; k++){ free(E->spec->ring[k].w.cand); free(E->spec->ring[k].w.seeds); free(E->spec->ring[k].w.dep); } free(E->spec); }
+	free(E->closed_touch);
 	return 0;
 }

@@ -823,11 +823,6 @@ WTZ_HD int wtz_denoise_dir_coop(const wtz_zhit_t *rs, uint32_t n_rs, uint32_t di
 	                    : wtz_denoise_dir_body<false>(rs, n_rs, dir, nf, nd, S, xvar, yvar, min_linear_len, lds, lds_bytes, pool, bad, big, bcap, gcap, LY, img, pd0, pdn);
 }
 
-WTZ_HD void wtz_denoise(wtz_zhit_t *rs, uint32_t n_rs, wtz_dmscratch_t &S, int32_t xvar, int32_t yvar, int32_t min_linear_len, bool presorted){
-	if(!presorted) wtz_sort_exact(rs, (size_t)n_rs, wtz_gt_zdiag());      /* hzm_aln.h:728; done by the wavefront when tie-free */
-	for(uint32_t dir = 0; dir < 2; dir++) wtz_denoise_dir(rs, n_rs, dir, S, xvar, yvar, min_linear_len);
-}
-
 /* ---------------------------------------------------------------------------------------------------------------------------------------------------
  * Block merging (fast_merge_wtseedv, hzm_aln.h:933-1054) as three steps over small arrays; executed by ONE lane (a strand has a handful of blocks - the
  * wave's share of this stage is the chain below).  What has to come out as the reference's does, and why it is written the way it is:

@@ -697,7 +697,7 @@ WTZ_D bool wtz_cand_stream(uint32_t t, const wtz_reads_t &R, uint32_t pbid, uint
 #endif
 #define WTZ_CWG_BINS 4096u
 #define WTZ_CWG_CAP 2048u
-#define WTZ_CWG_LDS_BYTES (WTZ_CWG_BINS * 4u + WTZ_CWG_CAP * 8u + 2u * WTZ_CWG_CAP * 4u + 64u * 4u)
+#define WTZ_CWG_LDS_BYTES (64u * 4u + 65536u)      /* scratch words + the larger of { bins + sort slots + interval arrays = 48 KB, the group sketch = 64 KB } */
 #if defined(__HIP_DEVICE_COMPILE__)
 #define WTZ_WG_TID ((uint32_t)threadIdx.x)
 #define WTZ_WG_N ((uint32_t)blockDim.x)
@@ -752,28 +752,31 @@ WTZ_HD void wtz_wg_sort_u64(uint64_t *a, uint32_t np){
 }
 
 typedef struct { uint32_t qoff, qlen; } wtz_kq_t;
-/* Group sketch (round 6): 65 536 saturating 4-BIT counters in the 32 KB of the sort slots + interval arrays (idle while the tuples are listed).  Round 5 had 16 384 16-bit
- * counters in the same bytes: at the configs[3] shape a long query has some hundred thousand tuples, ~30 per counter, every counter reached the threshold and the
- * sketch let everything through (3.7 of 17.7 s).  What a counter has to tell is only "can the groups hashed here reach -d": 15 units of ceil(-d / 15)
- * bases are enough for that, and four times the counters for the same LDS cut the load per counter to a quarter. */
+/* Group sketch (round 6): 65 536 saturating 8-BIT counters of the groups' length sums in units of 2 bases, 64 KB of LDS (everything behind the scratch words: bins, sort
+ * slots and interval arrays are idle while the tuples are walked; the bin histogram is made from the LISTED tuples afterwards).  History: round 5 had 16 384 16-bit
+ * counters over 32 KB - at the configs[3] shape (a query of 10 kb meets ~460 000 tuples there: hp-compressed 16-mers have only 4 * 3^15 values, 10 Gbp of reads put
+ * dozens of chance occurrences behind every one) every counter reached the threshold and everything passed; the first round-6 form (65 536 4-bit counters in units
+ * of 20 bases, 32 KB) still let 51 % through (phase clock at that shape, profiles/r06_seed_lookup_phase_clock_fly70.txt: the round-up of a 21-base tuple to two units
+ * put 12 units of a threshold of 15 on the average counter), and sort + fold of what passed were 82 % of the kernel.  Here the average counter holds 37 units of a
+ * threshold of 150. */
 #define WTZ_CWG_SKETCH 65536u
 WTZ_HD uint32_t wtz_cwg_sk_hash(uint32_t sd){ return (sd * 0x9E3779B1u) >> 16; }      /* 16 bits */
-/* counter h of sk += v, saturating at 15; nothing is added once it holds `thr` (<= 15).  A compare-and-swap loop on the word: racing adds can neither carry into the
- * neighbouring nibble nor wrap this one (a wrapped counter would drop a group that reaches -d: a wrong result, not a slow one) */
+/* counter h of sk += v, saturating at 255; nothing is added once it holds `thr` (<= 255).  A compare-and-swap loop on the word: racing adds can neither carry into the
+ * neighbouring byte nor wrap this one (a wrapped counter would drop a group that reaches -d: a wrong result, not a slow one) */
 WTZ_HD void wtz_cwg_sk_add(uint32_t *sk, uint32_t h, uint32_t v, uint32_t thr){
-	uint32_t *w = &sk[h >> 3]; const uint32_t sh = (h & 7u) << 2;
+	uint32_t *w = &sk[h >> 2]; const uint32_t sh = (h & 3u) << 3;
 	uint32_t cur = *w;
 	for(;;){
-		const uint32_t c = (cur >> sh) & 15u;
+		const uint32_t c = (cur >> sh) & 255u;
 		if(c >= thr) return;
-		uint32_t nc = c + v; if(nc > 15u) nc = 15u;
-		const uint32_t want = (cur & ~(15u << sh)) | (nc << sh);
+		uint32_t nc = c + v; if(nc > 255u) nc = 255u;
+		const uint32_t want = (cur & ~(255u << sh)) | (nc << sh);
 		const uint32_t got = WTZ_LDS_CAS32(w, cur, want);
 		if(got == cur) return;
 		cur = got;
 	}
 }
-WTZ_HD bool wtz_cwg_sk_pass(const uint32_t *sk, uint32_t h, uint32_t thr){ return ((sk[h >> 3] >> ((h & 7u) << 2)) & 15u) >= thr; }
+WTZ_HD bool wtz_cwg_sk_pass(const uint32_t *sk, uint32_t h, uint32_t thr){ return ((sk[h >> 2] >> ((h & 3u) << 3)) & 255u) >= thr; }
 /* inclusive running maximum of one value per thread over the workgroup (tmp: 64 LDS words), *total = the maximum */
 WTZ_HD uint32_t wtz_wg_incl_max(uint32_t v, uint32_t *tmp, uint32_t *total){
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -923,15 +926,31 @@ WTZ_HD void wtz_cwg_for_seeds(const wtz_cwg_walk_t &W, F &&f){
 				ql[u] = (uint32_t)__builtin_amdgcn_readlane((int)myql, (int)src);
 				if(u0 + u >= cnt) ko[u] = 0ull;
 			}
-			#pragma unroll
-			for(uint32_t u = 0; u < 4u; u++) s0[u] = lane < (uint32_t)(ko[u] & 0xFFFFu) ? W.seeds[(ko[u] >> 16) + lane] : 0u;
+			/* the first two chunks of 64 entries of all four runs are requested together; what a run has beyond them (hp-compressed 16-mers of a 10 Gbp read set: ~240 entries
+			 * per k-mer) comes four chunks at a time - every load of a round is on its way before the first is used (round 5 fetched the later chunks one by one, each
+			 * waiting out its own trip to HBM) */
+			uint32_t s1[4];
 			#pragma unroll
 			for(uint32_t u = 0; u < 4u; u++){
 				const uint32_t c = (uint32_t)(ko[u] & 0xFFFFu); const uint64_t o = ko[u] >> 16;
-				for(uint32_t k = lane; k < c; k += 64u){
-					const uint32_t sd = k == lane ? s0[u] : W.seeds[o + k];
+				s0[u] = lane < c ? W.seeds[o + lane] : 0u;
+				s1[u] = lane + 64u < c ? W.seeds[o + 64u + lane] : 0u;
+			}
+			#pragma unroll
+			for(uint32_t u = 0; u < 4u; u++){
+				const uint32_t c = (uint32_t)(ko[u] & 0xFFFFu); const uint64_t o = ko[u] >> 16;
+				auto take = [&](uint32_t sd){
 					const bool drop = ((sd >> 1) == W.pbid) || (W.thr != 0xFFFFFFFFu ? (sd >> 1) < W.thr : W.rdlen[sd >> 1] > W.pblen_up);      /* wtzmo.c:488-489 */
 					if(!drop) f(sd, base + u0 + u, ql[u]);
+				};
+				if(lane < c) take(s0[u]);
+				if(lane + 64u < c) take(s1[u]);
+				for(uint32_t k0 = 128u; k0 < c; k0 += 256u){
+					uint32_t v[4];
+					#pragma unroll
+					for(uint32_t j = 0; j < 4u; j++){ const uint32_t k = k0 + j * 64u + lane; v[j] = k < c ? W.seeds[o + k] : 0u; }
+					#pragma unroll
+					for(uint32_t j = 0; j < 4u; j++){ if(k0 + j * 64u + lane < c) take(v[j]); }
 				}
 			}
 		}
@@ -958,10 +977,10 @@ WTZ_HD void wtz_task_candidates_wg(uint32_t t, wtz_reads_t R, const uint32_t *qi
 	const uint32_t pbid = qids[t], L = R.rdlen[pbid];
 	const uint32_t pblen_up = (uint32_t)(L * 1.2);                       /* double multiply, wtzmo.c:445 */
 	const uint32_t thr = id_thr ? id_thr[t] : 0xFFFFFFFFu;              /* indexed reads in non-increasing length order: "longer than 1.2 x" is "id below thr" */
-	uint32_t *hist = lds;                                                /* WTZ_CWG_BINS counters / cursors, later the per-group sums */
-	uint64_t *sbuf = (uint64_t*)(lds + WTZ_CWG_BINS);                    /* WTZ_CWG_CAP sort slots */
-	uint32_t *ends = lds + WTZ_CWG_BINS + 2u * WTZ_CWG_CAP;              /* end / start of the tuple at each sorted position: 2 x CAP words */
-	uint32_t *tmp = ends + 2u * WTZ_CWG_CAP;                             /* 64 words of scan / broadcast scratch */
+	uint32_t *tmp = lds;                                                 /* 64 words of scan / broadcast scratch (first: the sketch below takes everything behind it) */
+	uint32_t *hist = lds + 64u;                                          /* WTZ_CWG_BINS counters / cursors, later the per-group sums */
+	uint64_t *sbuf = (uint64_t*)(hist + WTZ_CWG_BINS);                   /* WTZ_CWG_CAP sort slots */
+	uint32_t *ends = hist + WTZ_CWG_BINS + 2u * WTZ_CWG_CAP;             /* end / start of the tuple at each sorted position: 2 x CAP words */
 	/* ---- A: the read's sampled k-mers ---- */
 	unsigned long long pc = WTZ_CPROF_T(); (void)pc;
 	if(tid == 0){
@@ -1011,12 +1030,11 @@ WTZ_HD void wtz_task_candidates_wg(uint32_t t, wtz_reads_t R, const uint32_t *qi
 	/* ---- K: sketch.  Nearly every (read, strand) group is a chance hit of one or two k-mers and cannot reach -d; ol <= sum of the group's lengths, so a
 	 * hashed table of that sum (16-bit counters in units of `sk_unit` bases, rounded up; a counter stops counting at the threshold) tells which tuples can
 	 * belong to a group that does.  Collisions only add: no group that reaches -d is lost, and the groups that get through are folded exactly below. ---- */
-	uint32_t *sk = (uint32_t*)sbuf;                                    /* WTZ_CWG_SKETCH 4-bit counters over the sort slots + interval arrays (idle until stage P) */
+	uint32_t *sk = hist;                                               /* WTZ_CWG_SKETCH 8-bit counters over bins + sort slots + interval arrays + 16 KB behind them */
 	/* units of sk_unit bases, every tuple rounded UP (the sum of the round-ups is at least the round-up of the sum): a group whose lengths add up to -d holds
-	 * at least sk_thr = ceil(-d / sk_unit) <= 15 units */
-	const uint32_t sk_unit = kovl > 15u ? (kovl + 14u) / 15u : 1u, sk_thr = (kovl + sk_unit - 1u) / sk_unit;
-	for(uint32_t i = tid; i < WTZ_CWG_SKETCH / 8u; i += nt) sk[i] = 0;
-	for(uint32_t i = tid; i < WTZ_CWG_BINS; i += nt) hist[i] = 0;
+	 * at least sk_thr = ceil(-d / sk_unit) <= 255 units */
+	const uint32_t sk_unit = kovl > 255u ? (kovl + 254u) / 255u : 1u, sk_thr = (kovl + sk_unit - 1u) / sk_unit;
+	for(uint32_t i = tid; i < WTZ_CWG_SKETCH / 4u; i += nt) sk[i] = 0;
 #if defined(__HIP_DEVICE_COMPILE__)
 	__threadfence_block();
 #endif
@@ -1028,8 +1046,7 @@ WTZ_HD void wtz_task_candidates_wg(uint32_t t, wtz_reads_t R, const uint32_t *qi
 	});
 	WTZ_WG_SYNC();
 	WTZ_CPROF_ADD(1, pc);
-	/* ---- H: the tuples the sketch lets through: histogram over the key bins, and the tuples themselves listed once (in any order) so that the scatter below
-	 * reads a sixth of the seed entries back instead of walking all the runs a third time ---- */
+	/* ---- H: the tuples the sketch lets through, listed once (in any order): the scatter below reads them back instead of walking all the runs a third time ---- */
 	if(tid == 0){
 		const uint64_t pa = (uint64_t)(uintptr_t)wtz_pool_alloc(pool, ((size_t)T_all + 2) * 8);
 		tmp[60] = (uint32_t)pa; tmp[61] = (uint32_t)(pa >> 32); tmp[59] = 0;
@@ -1038,11 +1055,21 @@ WTZ_HD void wtz_task_candidates_wg(uint32_t t, wtz_reads_t R, const uint32_t *qi
 	uint64_t *lst_t = (uint64_t*)(uintptr_t)(((uint64_t)tmp[61] << 32) | tmp[60]);
 	if(lst_t == NULL){ if(tid == 0) ncand_out[t] = 0xFFFFFFFFu; return; }
 	wtz_cwg_for_seeds(SW, [&](uint32_t sd, uint32_t e, uint32_t){
-		if(wtz_cwg_sk_pass(sk, wtz_cwg_sk_hash(sd), sk_thr)){
-			WTZ_LDS_ADD32(&hist[(sd - key_lo) >> shift], 1u);
-			lst_t[WTZ_LDS_ADD32(&tmp[59], 1u)] = ((uint64_t)sd << 32) | e;
-		}
+		if(wtz_cwg_sk_pass(sk, wtz_cwg_sk_hash(sd), sk_thr)) lst_t[WTZ_LDS_ADD32(&tmp[59], 1u)] = ((uint64_t)sd << 32) | e;
 	});
+#if defined(__HIP_DEVICE_COMPILE__)
+	__threadfence_block();
+#endif
+	WTZ_WG_SYNC();
+	/* the sketch is dead: its first 16 KB become the histogram of the listed tuples over the key bins */
+	const uint32_t n_listed = tmp[59];
+	WTZ_WG_SYNC();
+	for(uint32_t i = tid; i < WTZ_CWG_BINS; i += nt) hist[i] = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+	__threadfence_block();
+#endif
+	WTZ_WG_SYNC();
+	for(uint32_t i = tid; i < n_listed; i += nt) WTZ_LDS_ADD32(&hist[((uint32_t)(lst_t[i] >> 32) - key_lo) >> shift], 1u);
 #if defined(__HIP_DEVICE_COMPILE__)
 	__threadfence_block();
 #endif

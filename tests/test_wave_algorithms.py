@@ -3,7 +3,7 @@ the wave-cooperative bodies with ONE lane, so the cross-lane logic of a rewrite 
 
 * the zmo window chain on a wavefront (smartdenovo_amd/csrc/wtz_window.h: wtz_chain_windows_wave): one window per lane, the reference's inner `break` as the first
   set bit of a ballot - against the double loop of chaining_wtseedv (/root/reference/hzm_aln.h:658-713) restated here in its plainest form;
-* the group sketch of the seed lookup (wtz_seed.h: wtz_cwg_sk_add / wtz_cwg_sk_pass): saturating 4-bit counters must never lose a group whose lengths reach -d,
+* the group sketch of the seed lookup (wtz_seed.h: wtz_cwg_sk_add / wtz_cwg_sk_pass): saturating 8-bit counters must never lose a group whose lengths reach -d,
   whatever collides with it and in whatever order the adds arrive."""
 import numpy as np
 import pytest
@@ -74,15 +74,15 @@ def test_window_chain_break_is_not_monotone_and_still_exact():
 
 def sketch_run(groups, kovl, order_seed, ncounters):
     """groups: list of (hash, [lengths]); returns the set of hashes whose counter reaches the threshold, adds applied in a shuffled order"""
-    unit = (kovl + 14) // 15 if kovl > 15 else 1
+    unit = (kovl + 254) // 255 if kovl > 255 else 1
     thr = (kovl + unit - 1) // unit
     cnt = np.zeros(ncounters, np.int64)
     adds = [(h % ncounters, min(l, kovl)) for h, ls in groups for l in ls]
     np.random.default_rng(order_seed).shuffle(adds)
     for h, l in adds:
         if cnt[h] >= thr: continue
-        cnt[h] = min(15, cnt[h] + (l + unit - 1) // unit)
-    assert thr <= 15
+        cnt[h] = min(255, cnt[h] + (l + unit - 1) // unit)
+    assert thr <= 255
     return {h % ncounters for h, _ in groups if cnt[h % ncounters] >= thr}, thr
 
 
