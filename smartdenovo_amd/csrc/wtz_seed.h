@@ -761,6 +761,7 @@ typedef struct { uint32_t qoff, qlen; } wtz_kq_t;
  * threshold of 150. */
 #define WTZ_CWG_SKETCH 65536u
 WTZ_HD uint32_t wtz_cwg_sk_hash(uint32_t sd){ return (sd * 0x9E3779B1u) >> 16; }      /* 16 bits */
+WTZ_HD uint32_t wtz_cwg_sk_hash2(uint32_t sd){ return ((sd ^ (sd >> 15)) * 0x85EBCA6Bu) >> 16; }      /* the second level's: independent of the first */
 /* counter h of sk += v, saturating at 255; nothing is added once it holds `thr` (<= 255).  A compare-and-swap loop on the word: racing adds can neither carry into the
  * neighbouring byte nor wrap this one (a wrapped counter would drop a group that reaches -d: a wrong result, not a slow one) */
 WTZ_HD void wtz_cwg_sk_add(uint32_t *sk, uint32_t h, uint32_t v, uint32_t thr){
@@ -1055,15 +1056,61 @@ WTZ_HD void wtz_task_candidates_wg(uint32_t t, wtz_reads_t R, const uint32_t *qi
 	uint64_t *lst_t = (uint64_t*)(uintptr_t)(((uint64_t)tmp[61] << 32) | tmp[60]);
 	if(lst_t == NULL){ if(tid == 0) ncand_out[t] = 0xFFFFFFFFu; return; }
 	wtz_cwg_for_seeds(SW, [&](uint32_t sd, uint32_t e, uint32_t){
-		if(wtz_cwg_sk_pass(sk, wtz_cwg_sk_hash(sd), sk_thr)) lst_t[WTZ_LDS_ADD32(&tmp[59], 1u)] = ((uint64_t)sd << 32) | e;
+		const bool ps = wtz_cwg_sk_pass(sk, wtz_cwg_sk_hash(sd), sk_thr);
+#if defined(__HIP_DEVICE_COMPILE__)
+		/* one LDS atomic per wavefront instruction, not per tuple (512 threads on one counter): the lanes that pass take consecutive slots behind the leader's */
+		const unsigned long long pm = __ballot(ps);
+		if(pm){
+			const uint32_t ldr = (uint32_t)__builtin_ctzll(pm);
+			uint32_t at = 0;
+			if((threadIdx.x & 63u) == ldr) at = atomicAdd(&tmp[59], (uint32_t)__popcll(pm));
+			at = (uint32_t)__shfl((int)at, (int)ldr, 64);
+			if(ps) lst_t[at + __builtin_amdgcn_mbcnt_hi((uint32_t)(pm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pm, 0u))] = ((uint64_t)sd << 32) | e;
+		}
+#else
+		if(ps) lst_t[WTZ_LDS_ADD32(&tmp[59], 1u)] = ((uint64_t)sd << 32) | e;
+#endif
 	});
 #if defined(__HIP_DEVICE_COMPILE__)
 	__threadfence_block();
 #endif
 	WTZ_WG_SYNC();
-	/* the sketch is dead: its first 16 KB become the histogram of the listed tuples over the key bins */
-	const uint32_t n_listed = tmp[59];
+	uint32_t n_listed = tmp[59];
 	WTZ_WG_SYNC();
+	/* ---- second level (round 6): where many counters reached the threshold only because ~30 groups share each (a long query at the configs[3] shape: 37 % of 460 000
+	 * tuples listed for 41 groups that reach -d), the LISTED tuples are counted again under another hash - a few per counter now - and the list is compacted to what
+	 * passes that too.  Exact: a group that reaches -d brought all its tuples through the first level (they share its counter), so its second counter holds its whole
+	 * sum as well. ---- */
+	if(n_listed > 2u * WTZ_CWG_CAP){
+		for(uint32_t i = tid; i < WTZ_CWG_SKETCH / 4u; i += nt) sk[i] = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+		__threadfence_block();
+#endif
+		WTZ_WG_SYNC();
+		for(uint32_t i = tid; i < n_listed; i += nt){
+			const uint64_t w = lst_t[i];
+			const uint32_t ql2 = kq[(uint32_t)w].qlen, l = ql2 < kovl ? ql2 : kovl;
+			wtz_cwg_sk_add(sk, wtz_cwg_sk_hash2((uint32_t)(w >> 32)), (l + sk_unit - 1u) / sk_unit, sk_thr);
+		}
+		WTZ_WG_SYNC();
+		/* in-place compaction, a round of nt tuples at a time: a round is read before anything of it is written, and it writes at or in front of its own first slot */
+		uint32_t kept = 0;
+		for(uint32_t i0 = 0; i0 < n_listed; i0 += nt){
+			const uint32_t i = i0 + tid;
+			uint64_t w = 0; uint32_t keep = 0;
+			if(i < n_listed){ w = lst_t[i]; keep = wtz_cwg_sk_pass(sk, wtz_cwg_sk_hash2((uint32_t)(w >> 32)), sk_thr) ? 1u : 0u; }
+			uint32_t tot; const uint32_t ex = wtz_wg_excl_scan(keep, tmp, &tot);      /* (its barriers also separate this round's reads from its writes) */
+			if(keep) lst_t[kept + ex] = w;
+			kept += tot;
+			WTZ_WG_SYNC();
+		}
+		n_listed = kept;
+#if defined(__HIP_DEVICE_COMPILE__)
+		__threadfence_block();
+#endif
+		WTZ_WG_SYNC();
+	}
+	/* the sketch is dead: its first 16 KB become the histogram of the listed tuples over the key bins */
 	for(uint32_t i = tid; i < WTZ_CWG_BINS; i += nt) hist[i] = 0;
 #if defined(__HIP_DEVICE_COMPILE__)
 	__threadfence_block();

@@ -10,7 +10,7 @@ def short(n):
     m = re.search(r"rocprim|hipcub", n)
     return "rocprim" if m else n[:40]
 def main():
-    d = sys.argv[1]; mingap = float(sys.argv[2]) * 1e3 if len(sys.argv) > 2 else 20e3
+    d = sys.argv[1]; mingap = float(sys.argv[2]) * 1e3 if len(sys.argv) > 2 and sys.argv[2][0] != "-" else 20e3
     ev = []
     for f in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
         for r in csv.DictReader(open(f)): ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short(r.get("Kernel_Name", ""))))
@@ -18,6 +18,11 @@ def main():
         for r in csv.DictReader(open(f)): ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), "copy"))
     if not ev: print("no trace under", d); return
     ev.sort()
+    # the LAST step only (the first holds one-time page-locked allocations, the process start the FASTA load): a step begins with the k-mer index build's first kernel
+    starts = [e[0] for e in ev if e[2] == "K_kcount"]
+    if starts and "--all" not in sys.argv:
+        cut = max(starts); ev = [e for e in ev if e[0] >= cut]
+        print("# last step only (from the last K_kcount on); --all for the whole trace")
     t0, t1 = ev[0][0], max(e[1] for e in ev)
     busy_end, last = ev[0][1], ev[0][2]; idle = 0; by = collections.Counter(); big = []
     for s, e, n in ev[1:]:
@@ -32,5 +37,5 @@ def main():
     print("idle ms by the kernel in front of the gap:", [(k, round(v / 1e6, 1)) for k, v in by.most_common(12)])
     print("kernel ms:", [(k, round(v / 1e6, 1)) for k, v in ksum.most_common(24)])
     print("gaps >= 1 ms (ms into the trace, gap ms, before, after):")
-    for b in big[:60]: print("  %.1f  %.2f  %s -> %s" % b)
+    for b in big[:80]: print("  %.1f  %.2f  %s -> %s" % b)
 if __name__ == "__main__": main()

@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
-"""Regenerates the "Round-5 numbers" block of DESIGN.md §6 from the committed measurement files under profiles/ (bench lines, rocprofv3 kernel statistics,
-PMC per kernel): python tools/design_numbers.py [--write].  Nothing in it is typed by hand."""
+"""Regenerates the "Round-6 numbers" block of DESIGN.md §6 AND the N = 8 budget table of §7 from the committed measurement files under profiles/ (bench lines with
+their host seconds, rocprofv3 kernel statistics, PMC per kernel): python tools/design_numbers.py [--write].  Nothing in it is typed by hand."""
 import csv, json, os, re, sys
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); P = os.path.join(R, "profiles")
 J = lambda n: json.loads(open(os.path.join(P, n)).read().strip().split("\n")[-1])
-z, d, e, ed, fly = J("r05_bench_driver_cmd.json"), J("r05_bench_dmo.json"), J("r05_bench_ecoli_zmo.json"), J("r05_bench_ecoli_dmo.json"), J("r05_bench_fly70.json")
+z, d, e, ed, fly = J("r06_bench_driver_cmd.json"), J("r06_bench_dmo.json"), J("r06_bench_ecoli_zmo.json"), J("r06_bench_ecoli_dmo.json"), J("r06_bench_fly70.json")
 def cpu(x):
     c = x.get("cpu_baseline")
     if not c: return "–"
@@ -25,19 +25,19 @@ def stats(path, steps):
     for row in rows:
         r[row["kernel"]] = r.get(row["kernel"], 0) + float(row["total_ms"]) / steps
     return r
-pz, pd = pmc("r05_yeast100_zmo_pmc_per_kernel.csv"), pmc("r05_yeast100_dmo_pmc_per_kernel.csv")
-sz, sd = stats("r05_yeast100_zmo_kernel_stats.csv", 4), stats("r05_yeast100_dmo_kernel_stats.csv", 2)
+pz, pd = pmc("r06_yeast100_zmo_pmc_per_kernel.csv"), pmc("r06_yeast100_dmo_pmc_per_kernel.csv")
+sz, sd = stats("r06_yeast100_zmo_kernel_stats.csv", 4), stats("r06_yeast100_dmo_kernel_stats.csv", 2)
 gb = lambda x: "%.0f GB" % (x / 1e9)
 L = []
-L.append("**Round-5 numbers** (MI355X; `profiles/r05_*`, made by `tools/gpu_r05_final.sh` on the last kernels of the round, this block by `tools/design_numbers.py`; every line's md5 == reference):")
+L.append("**Round-6 numbers** (MI355X; `profiles/r06_*`, made by `tools/gpu_r06_final.sh` on the last kernels of the round, this block by `tools/design_numbers.py`; every line's md5 == reference):")
 L.append("")
-L.append("| workload / engine | step | value | end of round 4 | reference on the same host (2×EPYC 9575F) |")
+L.append("| workload / engine | step | value | end of round 5 | reference on the same host (2×EPYC 9575F) |")
 L.append("|---|---|---|---|---|")
-L.append("| configs[2] zmo (`-k 16 -s 200 -m 0.6`), %s records, %.1f Gbp of pairs | **%.3f s** (%d steps) | **%.2f Gbp/s** | 2.895 s / 5.84 | %s |" % (format(z["records_last_step"], ",").replace(",", " "), z["pair_bp_per_step"] / 1e9, z["ms_per_step"] / 1e3, z["steps"], z["value"], cpu(z)))
-L.append("| configs[2] dmo (`-U -1 -m 0.1 -A 1000 -Z 16`), %s records, %.1f Gbp | **%.3f s** | **%.2f Gbp/s** | 6.156 s / 13.35 | %s |" % (format(d["records_last_step"], ",").replace(",", " "), d["pair_bp_per_step"] / 1e9, d["ms_per_step"] / 1e3, d["value"], cpu(d)))
-L.append("| configs[1] zmo, %s records | %.3f s | %.2f Gbp/s | 0.322 s / 2.99 | %s |" % (format(e["records_last_step"], ",").replace(",", " "), e["ms_per_step"] / 1e3, e["value"], cpu(e)))
-L.append("| configs[1] dmo, %s records | %.3f s | %.2f Gbp/s | 0.249 s / 7.84 | – |" % (format(ed["records_last_step"], ",").replace(",", " "), ed["ms_per_step"] / 1e3, ed["value"]))
-L.append("| configs[3] shape (9.8 Gbp of reads, all-reads z-index beside a pool sized from the input), %s records, %.0f Gbp | %.1f s | %.2f Gbp/s | 30.7 s / 4.01 | no whole-job reference (days); parity on the `-P 128` stripe |" % (format(fly["records_last_step"], ",").replace(",", " "), fly["pair_bp_per_step"] / 1e9, fly["ms_per_step"] / 1e3, fly["value"]))
+L.append("| configs[2] zmo (`-k 16 -s 200 -m 0.6`), %s records, %.1f Gbp of pairs | **%.3f s** (%d steps) | **%.2f Gbp/s** | 1.793 s / 9.43 | %s |" % (format(z["records_last_step"], ",").replace(",", " "), z["pair_bp_per_step"] / 1e9, z["ms_per_step"] / 1e3, z["steps"], z["value"], cpu(z)))
+L.append("| configs[2] dmo (`-U -1 -m 0.1 -A 1000 -Z 16`), %s records, %.1f Gbp | **%.3f s** | **%.2f Gbp/s** | 4.226 s / 19.45 | %s |" % (format(d["records_last_step"], ",").replace(",", " "), d["pair_bp_per_step"] / 1e9, d["ms_per_step"] / 1e3, d["value"], cpu(d)))
+L.append("| configs[1] zmo, %s records | %.3f s | %.2f Gbp/s | 0.255 s / 3.78 | %s |" % (format(e["records_last_step"], ",").replace(",", " "), e["ms_per_step"] / 1e3, e["value"], cpu(e)))
+L.append("| configs[1] dmo, %s records | %.3f s | %.2f Gbp/s | 0.230 s / 8.51 | – |" % (format(ed["records_last_step"], ",").replace(",", " "), ed["ms_per_step"] / 1e3, ed["value"]))
+L.append("| configs[3] shape (9.8 Gbp of reads, all-reads z-index beside a pool sized from the input), %s records, %.0f Gbp | %.1f s | %.2f Gbp/s | 17.7 s / 6.97 | no whole-job reference (days); parity on the `-P 128` stripe |" % (format(fly["records_last_step"], ",").replace(",", " "), fly["pair_bp_per_step"] / 1e9, fly["ms_per_step"] / 1e3, fly["value"]))
 L.append("")
 L.append("| line | kernel(s) | cells (bytes) per step | kernel ms | frac | PMC traffic per step |")
 L.append("|---|---|---|---|---|---|")
@@ -49,18 +49,46 @@ r = d["roofline_zmer"]; L.append("| `roofline_zmer` dmo | `K_pair_dm` (+ `K_pair
 r = z["roofline_seed"]; r2 = d["roofline_seed"]; L.append("| `roofline_seed` zmo / dmo | `K_candidates_wg` | %.1f GB / %.1f GB | %.0f / %.0f | %.4f / %.4f of 8 TB/s | %s / %s |" % (r["algorithmic_bytes_per_step"] / 1e9, r2["algorithmic_bytes_per_step"] / 1e9, r["kernel_ms_per_step"], r2["kernel_ms_per_step"], r["frac"], r2["frac"], gb(pz["K_candidates_wg"]), gb(pd["K_candidates_wg"])))
 r = z["roofline_ingest"]; L.append("| `roofline_ingest` | `wtz_kernel_pack_ascii` (load time, outside the steps) | %.2f GB | %.3f | **%.2f** of 8 TB/s | – |" % (r["algorithmic_bytes"] / 1e9, r["kernel_ms"], r["frac"]))
 L.append("")
-L.append("PMC traffic = 2 × FETCH_SIZE + WRITE_SIZE (the gfx950 units and corrections of the guide's rocprofv3 section), separate `--pmc` passes of a `--steps 1` run, `profiles/r05_yeast100_{zmo,dmo}_pmc_per_kernel.csv` (+ `.meta.json`: the kernel-source hash they were measured on).")
+L.append("PMC traffic = 2 × FETCH_SIZE + WRITE_SIZE (the gfx950 units and corrections of the guide's rocprofv3 section), separate `--pmc` passes of a `--steps 1` run, `profiles/r06_yeast100_{zmo,dmo}_pmc_per_kernel.csv` (+ `.meta.json`: the kernel-source hash they were measured on).")
 L.append("")
 k = z["kernel_ms_last_step"]; g = lambda n: sz.get(n, 0)
-L.append("Where a configs[2] zmo step goes (rocprofv3, `profiles/r05_yeast100_zmo_kernel_stats.csv`, per step): K-sw3 %.0f ms (`wtz_kernel_stitch_ext_fr` %.0f + `wtz_kernel_extjobs_fr` %.0f ms), `K_pair` %.0f, K-sw1 stage %.0f (`K_ldp` %.0f, `K_ltb` %.0f, `K_lplan` %.0f, `K_lfold` %.0f, `K_winalign` %.0f), K-sw2 %.0f (`K_gap` %.0f, `K_gdp` %.0f, `K_gplan` %.0f, `K_gtb` %.0f), stitch glue %.0f (`K_stitch_mid` %.0f, `K_stitch_left` %.0f), z-index %.0f, seed lookup %.0f, k-mer index %.0f; rank-0 commit and the writer threads run beside the device stages."
+L.append("Where a configs[2] zmo step goes (rocprofv3, `profiles/r06_yeast100_zmo_kernel_stats.csv`, per step): K-sw3 %.0f ms (`wtz_kernel_stitch_ext_fr` %.0f + `wtz_kernel_extjobs_fr` %.0f ms), `K_pair` %.0f, K-sw1 stage %.0f (`K_ldp` %.0f, `K_ltb` %.0f, `K_lplan` %.0f, `K_lfold` %.0f, `K_winalign` %.0f), K-sw2 %.0f (`K_gap` %.0f, `K_gdp` %.0f, `K_gplan` %.0f, `K_gtb` %.0f), stitch glue %.0f (`K_stitch_mid` %.0f, `K_stitch_left` %.0f), z-index %.0f, seed lookup %.0f, k-mer index %.0f; rank-0 commit and the writer threads run beside the device stages."
          % (k["ksw3_wave"], g("wtz_kernel_stitch_ext_fr"), g("wtz_kernel_extjobs_fr"), k["pairs"], k["winalign"], g("K_ldp"), g("K_ltb"), g("K_lplan"), g("K_lfold"), g("K_winalign"), k["ksw2_gap"], g("K_gap"), g("K_gdp"), g("K_gplan"), g("K_gtb"),
             g("K_stitch_mid") + g("K_stitch_left") + g("K_stitch_fin") + g("K_cigar_text"), g("K_stitch_mid"), g("K_stitch_left"), k["zindex"], k["candidates"], k["index"]))
 k = d["kernel_ms_last_step"]
 L.append("dmo: `K_pair_dm` %.0f ms of %.0f (tiers by LDS need + `K_pair_big` %.0f ms), seed lookup %.0f (all 116 541 reads are queried: no masking in this engine), z-index %.0f, k-mer index %.0f." % (k["pairs"], d["ms_per_step"], sd.get("K_pair_big", 0), k["candidates"], k["zindex"], k["index"]))
 block = "\n".join(L) + "\n"
+# ---- section 7: the N = 8 budget of a configs[2] zmo step, from the N = 1 line's own host seconds ----
+h = z.get("host_seconds_last_step") or {}
+B = []
+if h:
+    S = z["ms_per_step"] / 1e3; K = z["kernel_ms_last_step"]["index"] / 1e3; Z = z["kernel_ms_last_step"]["zindex"] / 1e3
+    G = h["device_stage_calls"]; M = h["commit"]; X = max(0.0, S - K - Z - G); nb = h.get("batches", 5)
+    Z8 = Z / 8 + 0.007 * nb          # candidate side of the reads = d (mod 8) + the query side per batch (measured at N = 8 contexts in round 4: 6.8 ms per batch of 4 096 queries)
+    core = max(G / 8, M)
+    S8 = K + Z8 + core + X; S8s = K / 8 + 0.005 + Z8 + core + X
+    try: x2 = J("r06_bench_yeast_2ranks_gloo.json")
+    except Exception: x2 = {}
+    B.append("`\"scaling\": \"strong\"`.  **Budget of a configs[2] zmo step at N = 8**, recomputed by `tools/design_numbers.py` from the host seconds of the N = 1 driver line (`profiles/r06_bench_driver_cmd.json`, `host_seconds_last_step`); RCCL has not carried N > 1 ranks - no multi-GPU box in the builder's reach - so this is arithmetic, not a measurement:")
+    B.append("")
+    B.append("| part of the step | N = 1 (measured) | divides by N? | at N = 8 |")
+    B.append("|---|---|---|---|")
+    B.append("| device-stage calls of the ranges (pair seeding, alignment, CIGAR text; kernels %.2f s + syncs / copies) | %.3f s | yes - pairs dealt by candidate id, no collective | %.3f s |" % (sum(z["kernel_ms_last_step"][k] for k in ("candidates", "pairs", "winalign", "stitch")) / 1e3, G, G / 8))
+    B.append("| rank 0: sequential commit (beside the device stages of the next range) | %.3f s (round 5: 0.256; sections of the committing thread: %s) | no | %.3f s - %s |" % (M, ", ".join("%s %.3f" % (k.replace("_", " "), v) for k, v in h["commit_sections"].items()), M, "hidden behind the device share" if M <= G / 8 else "LONGER than the device share: it bounds the step"))
+    B.append("| k-mer index build | %.3f s | replicated: no (`--shard-index`: yes, + one exchange of counts) | %.3f s (sharded: ~%.3f) |" % (K, K, K / 8 + 0.005))
+    B.append("| z-mer index | %.3f s | candidate side / N, query side per batch (%d batches) | %.3f s |" % (Z, nb, Z8))
+    B.append("| everything else inside the step (batch forming, planning, the first range and the last commit of a batch, joins) = step - the rows above | %.3f s | no | %.3f s |" % (X, X))
+    B.append("| results to rank 0 | - | 3.1 GB of CIGAR text per step from 7 peers over xGMI (>= 50 GB/s per link) + one D2H on rank 0; %s messages per step at N = 2 (round 5: 323) | ~0.06 s, beside rank 0's own share |" % (x2.get("exchange_messages_per_step", "?")))
+    B.append("")
+    B.append("=> %.3f + %.3f + max(%.3f, %.3f) + %.3f = **%.3f s per step against %.3f s: x%.1f at N = 8** with the replicated k-mer index, **x%.1f** with `--shard-index` (%.3f s); the device work alone would give x8.  What keeps it under x6: the %.3f s of the step that no rank but rank 0 can do (index builds that are not divided + the commit + the step's sequential remainder) - Amdahl: every millisecond taken out of the kernels moves this number DOWN." % (K, Z8, G / 8, M, X, S8, S, S / S8, S / S8s, S8s, K + Z8 + X))
+budget = "\n".join(B) + "\n"
 if "--write" in sys.argv:
     p = os.path.join(R, "DESIGN.md"); s = open(p).read()
-    i0 = s.index("**Round-5 numbers**"); i1 = s.index("What bounds them (details and the experiments")
-    open(p, "w").write(s[:i0] + block + "\n" + s[i1:])
+    i0 = s.index("**Round-6 numbers**") if "**Round-6 numbers**" in s else s.index("**Round-5 numbers**"); i1 = s.index("What bounds them (details and the experiments")
+    s = s[:i0] + block + "\n" + s[i1:]
+    if budget.strip():
+        j0 = s.index('`"scaling": "strong"`.'); j1 = s.index("## 8. Out of scope / next")
+        s = s[:j0] + budget + "\n" + s[j1:]
+    open(p, "w").write(s)
 else:
-    print(block)
+    print(block); print(budget)
