@@ -375,7 +375,6 @@ struct wtz_ctx {
 #ifndef WTZ_EMUL
 	hipStream_t stream;
 	hipStream_t stream_mw = 0; hipEvent_t ev_mw_fork = 0, ev_mw_join = 0;      /* side stream of the multi-wave K-sw3 launch */
-	hipStream_t stream_cls[8] = {0, 0, 0, 0, 0, 0, 0, 0}; hipEvent_t ev_cls[8] = {0, 0, 0, 0, 0, 0, 0, 0};   /* K-sw3 band classes, one launch each (created on first use) */
 	hipStream_t stream_gap = 0; hipEvent_t ev_gap_fork = 0, ev_gap_join = 0;   /* side stream of K_gap (runs beside the left extensions) */
 #endif
 	bool shares_indexes;      /* clone: reads / k-mer table / z-index belong to the parent context */
@@ -415,8 +414,6 @@ struct wtz_ctx {
 	wtz_counters_t cnt;
 	uint64_t tpool_peak_call = 0, main_used_call = 0;      /* transient-pool high-water mark / main-pool bytes of the API call in progress */
 	uint32_t env_xcd_group = 256;   /* WTZ_XCD_GROUP: consecutive pairs per XCD run in K_pair (0 = identity block -> pair mapping) */
-	int env_ext_mw_cw = 32;      /* WTZ_EXT_MW_CW: K-sw3 jobs with more band columns per lane than this run on four waves whatever their length */
-	int env_ext_fr_split = 0;    /* WTZ_EXT_FR_SPLIT=1: the frame kernel per band class (<= 16 / <= 28 / <= 32 columns per lane), three concurrent launches at 4 / 3 / 2 waves per SIMD */
 	int env_zread = 1;           /* WTZ_ZREAD=0: every read's z-mer index by the device-wide form (strided fill + radix sort) instead of one workgroup per read (wtz_task_zread) */
 	int env_ext_fused = 1;       /* WTZ_EXT_FUSED=0: the two end extensions of a stitched overlap in two launches with K_stitch_mid between them instead of on one wavefront (wtz_stitch_fused.h) */
 	int last_pool_fail = 0;      /* which pool the last WTZ_E_POOL came from: 1 = main, 2 = transient (wtz_pool_failure_kind) */
@@ -427,7 +424,6 @@ struct wtz_ctx {
 	                              * n = 1024, 418 ms with n = 4096 (5-8 items per range) - the launches are bound by the row RATE of the resident wavefronts (time = ~5 ms + 0.65 ms per
 	                              * million rows), not by their longest job, and four wavefronts spend 2.2 x the instructions of one on a row */
 	int env_ext_fr = 1;          /* WTZ_EXT_FR=0: K-sw3 one-wave jobs on the round-4 register kernel (wtz_extend_shift_reg) instead of the frame form (wtz_sw_frame.h) */
-	int env_ext_split = 0;       /* WTZ_EXT_SPLIT=1: K-sw3 one-wave jobs in two launches by band class (experiment) */
 	int env_heavy_first = -1;    /* WTZ_PAIR_HEAVY_FIRST: the heaviest pairs of a K_pair launch first (-1 = engine default: dmo on, zmo off) */
 	int env_cand_wg = 1;         /* WTZ_CAND_WG=0: the one-wavefront-per-query sorting form of the seed lookup (the form before round 3) */
 	int env_cand_stream = 0;     /* WTZ_CAND_STREAM=1: sort-free candidate accumulation (LDS sketch + survivor table, wtz_seed.h); bit-exact, pays at 25x coverage only: see DESIGN.md */
@@ -437,7 +433,7 @@ struct wtz_ctx {
 	bool env_trace = false;      /* WTZ_STAGE_TRACE: name every device stage on stderr before it is launched (locating a device fault) */
 	bool env_fail_once = false;      /* WTZ_POOL_FAIL_ONCE: the injected failure hits one stage call only (the retry must then succeed) */
 	unsigned env_fail_at = 0, env_tfail_at = 0;      /* WTZ_POOL_FAIL_AT / WTZ_TPOOL_FAIL_AT: fault injection into the main / transient pool */
-	int env_dm_first_big = 1; int env_sw_mode = 0, env_mw_min = 512, env_mw_top = 1 << 30, env_use_reg = 1, env_gap_side = 0; bool env_profile = false;     /* WTZ_* debugging switches, read in wtz_ctx_create */
+	int env_dm_first_big = 1; int env_sw_mode = 0, env_use_reg = 1, env_gap_side = 0; bool env_profile = false;     /* WTZ_* debugging switches, read in wtz_ctx_create */
 };
 
 #ifndef WTZ_EMUL
@@ -559,8 +555,6 @@ extern "C" int wtz_ctx_create(int device, const wtz_params_c *params, uint64_t p
 	c->env_sw_mode = 0; if(getenv("WTZ_SW_SCALAR") && atoi(getenv("WTZ_SW_SCALAR"))) c->env_sw_mode = 1; if(getenv("WTZ_SW_CHECK") && atoi(getenv("WTZ_SW_CHECK"))) c->env_sw_mode = 2;
 	/* round 5: 0 = one wave per job always.  With the frame form at two waves per SIMD and the pool's counter sharded, the four-wave kernel (2.7x the SIMD time per row
 	 * for 1.5x the speed of one job) only costs throughput: K-sw3 stage at configs[2] 729 ms with the long jobs (>= 512 rows) on four waves, 692 with >= 2048, 612 with none */
-	c->env_mw_min = getenv("WTZ_SW_MW_MIN") ? atoi(getenv("WTZ_SW_MW_MIN")) : 0;
-	c->env_mw_top = getenv("WTZ_SW_MW_TOP") ? atoi(getenv("WTZ_SW_MW_TOP")) : 1 << 30;
 	c->env_use_reg = !(getenv("WTZ_SW_NOREG") && atoi(getenv("WTZ_SW_NOREG")));
 	c->env_gap_side = (getenv("WTZ_GAP_SIDESTREAM") && atoi(getenv("WTZ_GAP_SIDESTREAM"))) ? 1 : 0;
 	c->env_profile = getenv("WTZ_PROFILE_PAIR") != NULL;
@@ -570,13 +564,10 @@ extern "C" int wtz_ctx_create(int device, const wtz_params_c *params, uint64_t p
 	c->env_cand_stream = (getenv("WTZ_CAND_STREAM") && atoi(getenv("WTZ_CAND_STREAM")) != 0);
 	if(getenv("WTZ_CAND_WG")) c->env_cand_wg = atoi(getenv("WTZ_CAND_WG"));
 	if(getenv("WTZ_PAIR_HEAVY_FIRST")) c->env_heavy_first = atoi(getenv("WTZ_PAIR_HEAVY_FIRST"));
-	if(getenv("WTZ_EXT_SPLIT")) c->env_ext_split = atoi(getenv("WTZ_EXT_SPLIT"));
 	if(getenv("WTZ_EXT_FR")) c->env_ext_fr = atoi(getenv("WTZ_EXT_FR"));
 	if(getenv("WTZ_EXT_MW_ROWS")) c->env_ext_mw_rows = atoi(getenv("WTZ_EXT_MW_ROWS"));
 	if(getenv("WTZ_EXT_FUSED")) c->env_ext_fused = atoi(getenv("WTZ_EXT_FUSED"));
 	if(getenv("WTZ_ZREAD")) c->env_zread = atoi(getenv("WTZ_ZREAD"));
-	if(getenv("WTZ_EXT_FR_SPLIT")) c->env_ext_fr_split = atoi(getenv("WTZ_EXT_FR_SPLIT"));
-	if(getenv("WTZ_EXT_MW_CW")) c->env_ext_mw_cw = atoi(getenv("WTZ_EXT_MW_CW"));
 	if(getenv("WTZ_XCD_GROUP")) c->env_xcd_group = (uint32_t)atoi(getenv("WTZ_XCD_GROUP"));
 	c->env_grp4 = (getenv("WTZ_WINALIGN4") && atoi(getenv("WTZ_WINALIGN4")) != 0);
 	if(getenv("WTZ_WINALIGN_LANE")) c->env_lane = atoi(getenv("WTZ_WINALIGN_LANE"));
@@ -691,7 +682,6 @@ extern "C" void wtz_ctx_destroy(wtz_ctx_t *c){
 	if(c->stream_mw) (void)hipStreamDestroy(c->stream_mw);
 	if(c->stream_gap) (void)hipStreamDestroy(c->stream_gap);
 	if(c->stream_copy){ (void)hipStreamSynchronize(c->stream_copy); (void)hipStreamDestroy(c->stream_copy); if(c->ev_text_ready) (void)hipEventDestroy(c->ev_text_ready); for(int k = 0; k < 2; k++) if(c->ev_text_done[k]) (void)hipEventDestroy(c->ev_text_done[k]); }
-	for(int k = 0; k < 8; k++){ if(c->stream_cls[k]) (void)hipStreamDestroy(c->stream_cls[k]); if(c->ev_cls[k]) (void)hipEventDestroy(c->ev_cls[k]); }
 	{ hipEvent_t evs[4] = { c->ev_mw_fork, c->ev_mw_join, c->ev_gap_fork, c->ev_gap_join }; for(int k = 0; k < 4; k++) if(evs[k]) (void)hipEventDestroy(evs[k]); }
 	if(c->stream) (void)hipStreamDestroy(c->stream);
 #endif
@@ -1667,8 +1657,7 @@ static int run_extjobs(wtz_ctx *c, const wtz_env_t &V, wtz_extjob_t *d_jobs, uin
 	}
 	/* longest-processing-time-first: the rows of an extension are sequential, so the longest job bounds the launch;
 	 * start the long ones first (key = query-side length, the row count upper bound) */
-	uint32_t *d_order = NULL; unsigned long long ext_sum = 0; int32_t ext_max = 0; uint32_t n_mw = 0;
-	const int mw_min = c->env_mw_min;
+	uint32_t *d_order = NULL; unsigned long long ext_sum = 0; int32_t ext_max = 0;
 	std::vector<uint32_t> ord(m); std::vector<uint64_t> need(m); std::vector<uint8_t> cw(m, 0);
 	unsigned long long geo_n[9] = {0}, geo_rows[9] = {0}, geo_cells[9] = {0};
 	{
@@ -1690,11 +1679,8 @@ static int run_extjobs(wtz_ctx *c, const wtz_env_t &V, wtz_extjob_t *d_jobs, uin
 			if(c->env_profile){ const int b = (n_col + 63) / 64 > 32 ? 8 : ((n_col + 63) / 64 - 1) / 4; geo_n[b]++; geo_rows[b] += (unsigned long long)ql; geo_cells[b] += (unsigned long long)ql * (unsigned long long)n_col; }
 		}
 		for(uint32_t i = 0; i < m; i++) ord[i] = i;
-		if(mw_min > 0) std::stable_sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t b){ return key[a] > key[b]; });      /* the four-wave share is cut by the query side */
-		else std::stable_sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t b){ return rows[a] > rows[b]; });
+		std::stable_sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t b){ return rows[a] > rows[b]; });
 		CHK(dev_alloc((void**)&d_order, (size_t)m * 4)); CHK(dev_h2d(d_order, ord.data(), (size_t)m * 4));
-		const int mw_top = c->env_mw_top;
-		if(mw_min > 0) while(n_mw < m && n_mw < (uint32_t)mw_top && key[ord[n_mw]] >= mw_min) n_mw++;          /* the long jobs head the order: four waves each */
 		if(c->env_profile){
 			fprintf(stderr, "[ext-profile] geometry by columns per lane (upper bounds):");
 			for(int b = 0; b < 9; b++) if(geo_n[b]) fprintf(stderr, " C<=%d: %llu jobs %.1f Mrows %.1f Gcells;", b < 8 ? 4 * b + 4 : 999, geo_n[b], (double)geo_rows[b] / 1e6, (double)geo_cells[b] / 1e9);
@@ -1712,71 +1698,13 @@ static int run_extjobs(wtz_ctx *c, const wtz_env_t &V, wtz_extjob_t *d_jobs, uin
 			uint32_t g1 = g0; uint64_t acc = 0;
 			while(g1 < m && (g1 == g0 || acc + need[ord[g1]] <= budget)){ acc += need[ord[g1]]; g1++; }
 			CHK(tpool_reset(c));      /* the traces of the previous group / the previous stage are dead: their CIGARs are in the main pool */
-			const uint32_t mw0 = g0 < n_mw ? g0 : n_mw, mw1 = g1 < n_mw ? g1 : n_mw;       /* four-wave jobs of the group: order[mw0, mw1) */
-			const uint32_t r0 = g0 > n_mw ? g0 : n_mw, r1 = g1 > n_mw ? g1 : n_mw;         /* one-wave jobs: order[r0, r1) */
 			if(use_reg){
-				bool split = false;
-				if(c->env_ext_split && g0 == 0 && g1 == m){
-					/* band classes in separate launches, each from a kernel with the register budget of its own row body (93 ... 319 VGPRs: five
-					 * resident waves per SIMD for the narrowest bands, one for the widest); WTZ_EXT_MW_CW: bands wider than that many columns
-					 * per lane go to the four-wave kernel whatever their length */
-					std::vector<uint32_t> lst[9];
-					for(uint32_t k = 0; k < m; k++){
-						const uint32_t j = ord[k]; const int w = cw[j];
-						if(w == 0 || w > 32) continue;
-						if(k < n_mw || w > c->env_ext_mw_cw) lst[0].push_back(j); else lst[c->env_ext_split >= 2 ? (w + 3) / 4 : (w <= 16 ? 4 : 8)].push_back(j);
-					}
-					uint32_t *d_cls = NULL; CHK(dev_alloc((void**)&d_cls, (size_t)m * 4 + 64));
-					uint32_t off[10]; off[0] = 0; for(int k = 0; k < 9; k++){ off[k + 1] = off[k] + (uint32_t)lst[k].size(); if(!lst[k].empty()) CHK(dev_h2d(d_cls + off[k], lst[k].data(), lst[k].size() * 4)); }
-					for(int k = 0; k < 8; k++) if(!c->stream_cls[k]){ if(hipStreamCreateWithFlags(&c->stream_cls[k], hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->ev_cls[k], hipEventDisableTiming) != hipSuccess) return wtz_fail(WTZ_E_HIP, "hipStreamCreate failed"); }
-					HIPCHK(hipEventRecord(c->ev_mw_fork, g_stream));
-					if(!lst[0].empty()){
-						HIPCHK(hipStreamWaitEvent(c->stream_mw, c->ev_mw_fork, 0));
-						hipLaunchKernelGGL((wtz_kernel_extjobs_mw<1032>), dim3((uint32_t)lst[0].size()), dim3(256), 0, c->stream_mw, d_jobs, (const uint32_t*)d_cls, (uint32_t)lst[0].size(), V.P, V.pool, V.pool + 1);
-						HIPCHK(hipGetLastError());
-						HIPCHK(hipEventRecord(c->ev_mw_join, c->stream_mw));
-					}
-#define WTZ_CLS_LAUNCH(K, LO, HI) if(!lst[K].empty()){ HIPCHK(hipStreamWaitEvent(c->stream_cls[K - 1], c->ev_mw_fork, 0)); \
-						hipLaunchKernelGGL((wtz_kernel_extjobs_reg<1032, LO, HI>), dim3((uint32_t)lst[K].size()), dim3(64), 0, c->stream_cls[K - 1], d_jobs, (const uint32_t*)d_cls + off[K], (uint32_t)lst[K].size(), V.P, V.pool, V.pool + 1); \
-						HIPCHK(hipGetLastError()); HIPCHK(hipEventRecord(c->ev_cls[K - 1], c->stream_cls[K - 1])); HIPCHK(hipStreamWaitEvent(g_stream, c->ev_cls[K - 1], 0)); }
-					if(c->env_ext_split >= 2){
-						WTZ_CLS_LAUNCH(8, 28, 32) WTZ_CLS_LAUNCH(7, 24, 28) WTZ_CLS_LAUNCH(6, 20, 24) WTZ_CLS_LAUNCH(5, 16, 20)
-						WTZ_CLS_LAUNCH(4, 12, 16) WTZ_CLS_LAUNCH(3, 8, 12) WTZ_CLS_LAUNCH(2, 4, 8) WTZ_CLS_LAUNCH(1, 0, 4)
-					} else { WTZ_CLS_LAUNCH(8, 16, 32) WTZ_CLS_LAUNCH(4, 0, 16) }
-#undef WTZ_CLS_LAUNCH
-					if(!lst[0].empty()) HIPCHK(hipStreamWaitEvent(g_stream, c->ev_mw_join, 0));
-					split = true;      /* d_cls is arena memory: released with the call's scope */
-				}
-				if(!split && mw1 > mw0){
-					/* long jobs on a side stream, concurrently with the one-wave kernel over the rest */
-					HIPCHK(hipEventRecord(c->ev_mw_fork, g_stream)); HIPCHK(hipStreamWaitEvent(c->stream_mw, c->ev_mw_fork, 0));
-					hipLaunchKernelGGL((wtz_kernel_extjobs_mw<1032>), dim3(mw1 - mw0), dim3(256), 0, c->stream_mw, d_jobs, (const uint32_t*)d_order + mw0, mw1 - mw0, V.P, V.pool, V.pool + 1);
-					HIPCHK(hipGetLastError());
-					HIPCHK(hipEventRecord(c->ev_mw_join, c->stream_mw));
-				}
-				if(r1 > r0 && !split && mw1 == mw0 && c->env_ext_fr && c->env_ext_fr_split && g0 == 0 && g1 == m){
-					/* the frame kernel per band class: three concurrent launches, each compiled for the occupancy its widest row body allows */
-					std::vector<uint32_t> lst[3];
-					for(uint32_t k = r0; k < r1; k++){ const uint32_t j = ord[k]; const int w = cw[j]; if(w == 0 || w > 32) continue; lst[w <= 16 ? 0 : (w <= 28 ? 1 : 2)].push_back(j); }
-					uint32_t *d_cls = NULL; CHK(dev_alloc((void**)&d_cls, (size_t)m * 4 + 64));
-					uint32_t off[4]; off[0] = 0; for(int k = 0; k < 3; k++){ off[k + 1] = off[k] + (uint32_t)lst[k].size(); if(!lst[k].empty()) CHK(dev_h2d(d_cls + off[k], lst[k].data(), lst[k].size() * 4)); }
-					for(int k = 0; k < 3; k++) if(!c->stream_cls[k]){ if(hipStreamCreateWithFlags(&c->stream_cls[k], hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->ev_cls[k], hipEventDisableTiming) != hipSuccess) return wtz_fail(WTZ_E_HIP, "hipStreamCreate failed"); }
-					HIPCHK(hipEventRecord(c->ev_mw_fork, g_stream));
-#define WTZ_FRCLS_LAUNCH(K, LO, HI) if(!lst[K].empty()){ \
-						if(c->env_ext_fr_split == 2){ hipLaunchKernelGGL((wtz_kernel_extjobs_fr<1032, LO, HI>), dim3((uint32_t)lst[K].size()), dim3(64), 0, g_stream, d_jobs, (const uint32_t*)d_cls + off[K], (uint32_t)lst[K].size(), V.P, V.pool, V.pool + 1); HIPCHK(hipGetLastError()); } \
-						else { HIPCHK(hipStreamWaitEvent(c->stream_cls[K], c->ev_mw_fork, 0)); \
-						hipLaunchKernelGGL((wtz_kernel_extjobs_fr<1032, LO, HI>), dim3((uint32_t)lst[K].size()), dim3(64), 0, c->stream_cls[K], d_jobs, (const uint32_t*)d_cls + off[K], (uint32_t)lst[K].size(), V.P, V.pool, V.pool + 1); \
-						HIPCHK(hipGetLastError()); HIPCHK(hipEventRecord(c->ev_cls[K], c->stream_cls[K])); HIPCHK(hipStreamWaitEvent(g_stream, c->ev_cls[K], 0)); } }
-					WTZ_FRCLS_LAUNCH(2, 28, 32) WTZ_FRCLS_LAUNCH(1, 16, 28) WTZ_FRCLS_LAUNCH(0, 0, 16)
-#undef WTZ_FRCLS_LAUNCH
-					split = true;
-				}
-				if(r1 > r0 && !split){
-					if(c->env_ext_fr) hipLaunchKernelGGL((wtz_kernel_extjobs_fr<1032>), dim3(r1 - r0), dim3(64), 0, g_stream, d_jobs, (const uint32_t*)d_order + r0, r1 - r0, V.P, V.pool, V.pool + 1);
-					else hipLaunchKernelGGL((wtz_kernel_extjobs_reg<1032>), dim3(r1 - r0), dim3(64), 0, g_stream, d_jobs, (const uint32_t*)d_order + r0, r1 - r0, V.P, V.pool, V.pool + 1);
-					HIPCHK(hipGetLastError());
-				}
-				if(!split && mw1 > mw0) HIPCHK(hipStreamWaitEvent(g_stream, c->ev_mw_join, 0));
+				/* one wavefront per job, longest first: the frame form (wtz_sw_frame.h), or the round-4 register form it replaced (WTZ_EXT_FR=0: kept as DP form 1, the
+				 * reference the isolated bench compares against).  Retired in round 6 (git history keeps them): the launches per band class (WTZ_EXT_SPLIT, WTZ_EXT_FR_SPLIT:
+				 * profiles/r06_ksw3_split_in_step_kernel_trace.txt) and the round-4 four-wave kernel with its WTZ_SW_MW_MIN / WTZ_EXT_MW_CW routing. */
+				if(c->env_ext_fr) hipLaunchKernelGGL((wtz_kernel_extjobs_fr<1032>), dim3(g1 - g0), dim3(64), 0, g_stream, d_jobs, (const uint32_t*)d_order + g0, g1 - g0, V.P, V.pool, V.pool + 1);
+				else hipLaunchKernelGGL((wtz_kernel_extjobs_reg<1032>), dim3(g1 - g0), dim3(64), 0, g_stream, d_jobs, (const uint32_t*)d_order + g0, g1 - g0, V.P, V.pool, V.pool + 1);
+				HIPCHK(hipGetLastError());
 			}
 			hipLaunchKernelGGL((wtz_kernel_extjobs<2048, 1032>), dim3(g1 - g0), dim3(64), 0, g_stream, d_jobs, (const uint32_t*)d_order + g0, g1 - g0, V.P, V.pool, V.pool + 1);     /* whatever the register DP left */
 			HIPCHK(hipGetLastError());
@@ -1792,7 +1720,7 @@ static int run_extjobs(wtz_ctx *c, const wtz_env_t &V, wtz_extjob_t *d_jobs, uin
 			{ std::vector<wtz_extjob_t> jj(m); CHK(dev_d2h(jj.data(), d_jobs, (size_t)m * sizeof(wtz_extjob_t))); uint32_t nd[4] = {0, 0, 0, 0}; for(uint32_t i = 0; i < m; i++){ key[i] = jj[i].valid ? jj[i].x.qe : -1; if(jj[i].valid) nd[jj[i].done & 3]++; }
 			  if(const char *dp = getenv("WTZ_EXT_DUMP")){      /* job geometry of this call, 8 int32 per valid job: the input of tools/ubench/ksw3_bench.py */
 				if(FILE *df = fopen(dp, "ab")){ for(uint32_t i = 0; i < m; i++) if(jj[i].valid){ const int32_t r[8] = {jj[i].qlen, jj[i].tlen, jj[i].init_score, jj[i].W, jj[i].x.qe, jj[i].x.te, (int32_t)(jj[i].cells > 0x7FFFFFFFull ? 0x7FFFFFFF : jj[i].cells), (int32_t)jj[i].done}; fwrite(r, 4, 8, df); } fclose(df); } }
-			  fprintf(stderr, "[ext-profile] n_mw %u; %u launch group(s); valid jobs finished by: nobody %u, one-wave %u, four-wave %u, general %u\n", n_mw, n_groups, nd[0], nd[1], nd[2], nd[3]); }
+			  fprintf(stderr, "[ext-profile] %u launch group(s); valid jobs finished by: nobody %u, one-wave %u, four-wave %u, general %u\n", n_groups, nd[0], nd[1], nd[2], nd[3]); }
 			for(uint32_t i = 0; i < m; i++){ if(key[i] < 0) continue; nv++; if(key[i] >= 256) n256++; if(key[i] >= 512){ n512++; s512 += key[i]; } if(key[i] >= 1024) n1k++; if(key[i] >= 2048) n2k++; if(key[i] >= 4096) n4k++; }
 			fprintf(stderr, "[ext-profile] %u jobs (%u valid), rows (upper bound) sum %llu max %d, %.2f ms; qe>=256 %u >=512 %u (sum %llu) >=1k %u >=2k %u >=4k %u; transient pool peak %.2f GB\n", m, nv, ext_sum, ext_max, ms_l, n256, n512, s512, n1k, n2k, n4k, c->tpool_peak_call / 1073741824.0);
 		}
@@ -2041,7 +1969,7 @@ extern "C" int wtz_pairs_align(wtz_ctx_t *c, const uint32_t *pair_idx, const uin
 		STAGE(c, "K_stitch_left");
 		int32_t *d_rgeo = NULL;
 #ifndef WTZ_EMUL
-		const bool fused = c->env_ext_fused && c->env_ext_fr && c->env_sw_mode == 0 && c->env_use_reg && c->env_mw_min <= 0 && !c->env_ext_split && !c->env_ext_fr_split;
+		const bool fused = c->env_ext_fused && c->env_ext_fr && c->env_sw_mode == 0 && c->env_use_reg;
 		if(fused) CHK(dev_alloc((void**)&d_rgeo, (size_t)m * 8));
 #else
 		CHK(dev_alloc((void**)&d_rgeo, (size_t)m * 8));      /* host emulation: the prediction of the right extension's geometry is compared with what K_stitch_mid asks for */

@@ -760,8 +760,18 @@ typedef struct { uint32_t qoff, qlen; } wtz_kq_t;
  * put 12 units of a threshold of 15 on the average counter), and sort + fold of what passed were 82 % of the kernel.  Here the average counter holds 37 units of a
  * threshold of 150. */
 #define WTZ_CWG_SKETCH 65536u
+/* second level: from how many listed tuples on, and how many units one part of it may hold (the host emulation sets both small so that the CPU suite's little inputs go
+ * through the second level and through several parts of it) */
+#ifdef WTZ_EMUL
+#define WTZ_CWG_L2_MIN 48u
+#define WTZ_CWG_L2_PART_UNITS 1024u
+#else
+#define WTZ_CWG_L2_MIN (2u * WTZ_CWG_CAP)
+#define WTZ_CWG_L2_PART_UNITS (65536u * 48u)
+#endif
 WTZ_HD uint32_t wtz_cwg_sk_hash(uint32_t sd){ return (sd * 0x9E3779B1u) >> 16; }      /* 16 bits */
 WTZ_HD uint32_t wtz_cwg_sk_hash2(uint32_t sd){ return ((sd ^ (sd >> 15)) * 0x85EBCA6Bu) >> 16; }      /* the second level's: independent of the first */
+WTZ_HD uint32_t wtz_cwg_sk_hash3(uint32_t sd){ return ((sd ^ (sd >> 13)) * 0x27D4EB2Fu) >> 16; }      /* which part of the second level a key belongs to */
 /* counter h of sk += v, saturating at 255; nothing is added once it holds `thr` (<= 255).  A compare-and-swap loop on the word: racing adds can neither carry into the
  * neighbouring byte nor wrap this one (a wrapped counter would drop a group that reaches -d: a wrong result, not a slow one) */
 WTZ_HD void wtz_cwg_sk_add(uint32_t *sk, uint32_t h, uint32_t v, uint32_t thr){
@@ -1055,7 +1065,11 @@ WTZ_HD void wtz_task_candidates_wg(uint32_t t, wtz_reads_t R, const uint32_t *qi
 	WTZ_WG_SYNC();
 	uint64_t *lst_t = (uint64_t*)(uintptr_t)(((uint64_t)tmp[61] << 32) | tmp[60]);
 	if(lst_t == NULL){ if(tid == 0) ncand_out[t] = 0xFFFFFFFFu; return; }
-	wtz_cwg_for_seeds(SW, [&](uint32_t sd, uint32_t e, uint32_t){
+	/* a listed tuple: key << 32 | k-mer index << 8 | sketch units (a read has fewer than 2^24 bases; the index stays above the units, so that the sort below still orders
+	 * a group's tuples by query offset; the units ride along so that the second level needs no gather through the k-mer table: a dependent load per tuple was most of its time) */
+	wtz_cwg_for_seeds(SW, [&](uint32_t sd, uint32_t e0, uint32_t qlen){
+		const uint32_t l0 = qlen < kovl ? qlen : kovl;
+		const uint32_t e = ((e0 & 0xFFFFFFu) << 8) | ((l0 + sk_unit - 1u) / sk_unit);
 		const bool ps = wtz_cwg_sk_pass(sk, wtz_cwg_sk_hash(sd), sk_thr);
 #if defined(__HIP_DEVICE_COMPILE__)
 		/* one LDS atomic per wavefront instruction, not per tuple (512 threads on one counter): the lanes that pass take consecutive slots behind the leader's */
@@ -1078,29 +1092,60 @@ WTZ_HD void wtz_task_candidates_wg(uint32_t t, wtz_reads_t R, const uint32_t *qi
 	uint32_t n_listed = tmp[59];
 	WTZ_WG_SYNC();
 	/* ---- second level (round 6): where many counters reached the threshold only because ~30 groups share each (a long query at the configs[3] shape: 37 % of 460 000
-	 * tuples listed for 41 groups that reach -d), the LISTED tuples are counted again under another hash - a few per counter now - and the list is compacted to what
-	 * passes that too.  Exact: a group that reaches -d brought all its tuples through the first level (they share its counter), so its second counter holds its whole
+	 * tuples listed for 41 groups that reach -d), the LISTED tuples are counted again under another hash, in as many parts of the key space as keep the counters sparse (the longest
+	 * queries list a million tuples), and the list is compacted to what passes that too.  Exact: a group that reaches -d brought all its tuples through the first level (they share its counter), so its second counter holds its whole
 	 * sum as well. ---- */
-	if(n_listed > 2u * WTZ_CWG_CAP){
-		for(uint32_t i = tid; i < WTZ_CWG_SKETCH / 4u; i += nt) sk[i] = 0;
+	if(n_listed > WTZ_CWG_L2_MIN){
+		/* as many parts as keep the average counter near a third of the threshold (a listed tuple is ~12 units); a group's tuples share its key, hence its part */
+		const uint32_t parts = (uint32_t)(((uint64_t)n_listed * 12u + WTZ_CWG_L2_PART_UNITS - 1u) / WTZ_CWG_L2_PART_UNITS);
+		const uint64_t DEAD = ~0ull;
+		for(uint32_t part = 0; part < parts; part++){
+			for(uint32_t i = tid; i < WTZ_CWG_SKETCH / 4u; i += nt) sk[i] = 0;
 #if defined(__HIP_DEVICE_COMPILE__)
-		__threadfence_block();
+			__threadfence_block();
 #endif
-		WTZ_WG_SYNC();
-		for(uint32_t i = tid; i < n_listed; i += nt){
-			const uint64_t w = lst_t[i];
-			const uint32_t ql2 = kq[(uint32_t)w].qlen, l = ql2 < kovl ? ql2 : kovl;
-			wtz_cwg_sk_add(sk, wtz_cwg_sk_hash2((uint32_t)(w >> 32)), (l + sk_unit - 1u) / sk_unit, sk_thr);
+			WTZ_WG_SYNC();
+			for(uint32_t i0 = 0; i0 < n_listed; i0 += 4u * nt){      /* four loads on their way per thread before the first is used */
+				uint64_t w4[4];
+				#pragma unroll
+				for(uint32_t j = 0; j < 4u; j++){ const uint32_t i = i0 + j * nt + tid; w4[j] = i < n_listed ? lst_t[i] : DEAD; }
+				#pragma unroll
+				for(uint32_t j = 0; j < 4u; j++){
+					if(w4[j] == DEAD) continue;
+					const uint32_t sd2 = (uint32_t)(w4[j] >> 32);
+					if(parts > 1u && ((wtz_cwg_sk_hash3(sd2) * parts) >> 16) != part) continue;
+					wtz_cwg_sk_add(sk, wtz_cwg_sk_hash2(sd2), ((uint32_t)w4[j]) & 255u, sk_thr);
+				}
+			}
+			WTZ_WG_SYNC();
+			for(uint32_t i0 = 0; i0 < n_listed; i0 += 4u * nt){      /* every thread marks the slots it read itself */
+				uint64_t w4[4];
+				#pragma unroll
+				for(uint32_t j = 0; j < 4u; j++){ const uint32_t i = i0 + j * nt + tid; w4[j] = i < n_listed ? lst_t[i] : DEAD; }
+				#pragma unroll
+				for(uint32_t j = 0; j < 4u; j++){
+					if(w4[j] == DEAD) continue;
+					const uint32_t sd2 = (uint32_t)(w4[j] >> 32);
+					if(parts > 1u && ((wtz_cwg_sk_hash3(sd2) * parts) >> 16) != part) continue;
+					if(!wtz_cwg_sk_pass(sk, wtz_cwg_sk_hash2(sd2), sk_thr)) lst_t[i0 + j * nt + tid] = DEAD;
+				}
+			}
+			WTZ_WG_SYNC();
 		}
-		WTZ_WG_SYNC();
-		/* in-place compaction, a round of nt tuples at a time: a round is read before anything of it is written, and it writes at or in front of its own first slot */
+		/* in-place compaction (any order), a round of 4 x nt tuples at a time: a round is read before anything of it is written, and it writes at or in front of its own first slot */
 		uint32_t kept = 0;
-		for(uint32_t i0 = 0; i0 < n_listed; i0 += nt){
-			const uint32_t i = i0 + tid;
-			uint64_t w = 0; uint32_t keep = 0;
-			if(i < n_listed){ w = lst_t[i]; keep = wtz_cwg_sk_pass(sk, wtz_cwg_sk_hash2((uint32_t)(w >> 32)), sk_thr) ? 1u : 0u; }
-			uint32_t tot; const uint32_t ex = wtz_wg_excl_scan(keep, tmp, &tot);      /* (its barriers also separate this round's reads from its writes) */
-			if(keep) lst_t[kept + ex] = w;
+		for(uint32_t i0 = 0; i0 < n_listed; i0 += 4u * nt){
+			uint64_t w[4]; uint32_t keep = 0;
+			#pragma unroll
+			for(uint32_t j = 0; j < 4u; j++){
+				const uint32_t i = i0 + j * nt + tid;
+				w[j] = DEAD;
+				if(i < n_listed) w[j] = lst_t[i];
+				if(w[j] != DEAD) keep |= 1u << j;
+			}
+			uint32_t tot; uint32_t at = kept + wtz_wg_excl_scan((uint32_t)__builtin_popcount(keep), tmp, &tot);      /* (its barriers also separate this round's reads from its writes) */
+			#pragma unroll
+			for(uint32_t j = 0; j < 4u; j++) if((keep >> j) & 1u) lst_t[at++] = w[j];
 			kept += tot;
 			WTZ_WG_SYNC();
 		}
@@ -1193,7 +1238,7 @@ WTZ_HD void wtz_task_candidates_wg(uint32_t t, wtz_reads_t R, const uint32_t *qi
 		wtz_wg_sort_u64(srt, np);
 		WTZ_CPROF_ADD(5, pc);
 		/* query interval of every tuple in sorted order: the fold below then touches LDS only */
-		for(uint32_t i = tid; i < n; i += nt){ const wtz_kq_t q = kq[(uint32_t)srt[i]]; qo[i] = q.qoff; en[i] = q.qoff + q.qlen; }
+		for(uint32_t i = tid; i < n; i += nt){ const wtz_kq_t q = kq[(uint32_t)srt[i] >> 8]; qo[i] = q.qoff; en[i] = q.qoff + q.qlen; }
 #if defined(__HIP_DEVICE_COMPILE__)
 		__threadfence_block();
 #endif

@@ -940,297 +940,12 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CHI <= 
 	WTZ_PROF_END();
 }
 
-/*
- * K-sw3 for LONG extensions on NW wavefronts of one workgroup.  The rows of an extension are sequential and a lone wave is
- * instruction-issue bound (about 40 VALU ops per cell, one op per 4 cycles), so a launch ends when its longest job does; here
- * the band is cut into NW*64 lane blocks of C columns (thread t owns band-relative columns t*C .. t*C+C-1), every wave issues a
- * quarter of the cells on its own SIMD and the row-to-row hand-over crosses waves through a few LDS words:
- *   - before barrier 1 each wave publishes the maximum of its lanes' F aggregates; after it a lane's F start is the maximum of
- *     its in-wave exclusive scan and the totals of the waves to its left;
- *   - before barrier 2 each wave publishes its row arg-max key, the H/E values its neighbours' edge lanes will shift in
- *     (hv[C-1] of lane 63; hv[0], ev[0], ev[1] of lane 0) and, on the rows that touch the target end, H(i, je-1);
- *     after it every thread derives the same row maximum, band centre and stop decision.
- * The barriers are s_waitcnt lgkmcnt(0) + s_barrier: the row's trace stores are NOT waited for.  Cells, trace byte and
- * traceback are those of wtz_extend_shift_reg (results identical to kswx_extend_align_shift_core).  Wave 0 walks the traceback.
- */
+/* four int32 as one 128-bit LDS access, and the workgroup barrier of the multi-wave K-sw3 form (wtz_sw_frame_mw.h): the row's trace stores are NOT waited for */
 struct alignas(16) wtz_i4 { int32_t v[4]; };
-typedef struct { wtz_i4 wagg, wkey, edge[4]; int32_t h1, pad; unsigned long long zbase, chunk_tab, zb_tab; } wtz_mw_shared_t;
 
 WTZ_D void wtz_mw_barrier(){ asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-template<int CMAX, int S>
-WTZ_D void wtz_shift_row_inputs_x(int32_t (&hv)[CMAX], int32_t (&ev)[CMAX], int32_t h_prev, int32_t h0_next, int32_t e0_next, int32_t e1_next){
-	/* as wtz_shift_row_inputs, with the values the edge lanes take from the neighbouring waves (or the band boundary) */
-	if(S == 0){
-		const int32_t prv = wtz_dpp_wave_shr1(h_prev, hv[CMAX - 1]);
-		#pragma unroll
-		for(int k = CMAX - 1; k > 0; k--) hv[k] = hv[k - 1];
-		hv[0] = prv;
-	} else if(S == 1){
-		const int32_t ne0 = wtz_dpp_wave_shl1(e0_next, ev[0]);
-		#pragma unroll
-		for(int k = 0; k + 1 < CMAX; k++) ev[k] = ev[k + 1];
-		ev[CMAX - 1] = ne0;
-	} else {
-		const int32_t nh0 = wtz_dpp_wave_shl1(h0_next, hv[0]);
-		const int32_t ne0 = wtz_dpp_wave_shl1(e0_next, ev[0]), ne1 = wtz_dpp_wave_shl1(e1_next, ev[1]);
-		#pragma unroll
-		for(int k = 0; k + 1 < CMAX; k++) hv[k] = hv[k + 1];
-		hv[CMAX - 1] = nh0;
-		#pragma unroll
-		for(int k = 0; k + 2 < CMAX; k++) ev[k] = ev[k + 2];
-		ev[CMAX - 2] = ne0; ev[CMAX - 1] = ne1;
-	}
-}
-
-template<int C, int NW>
-WTZ_D wtz_aln_t wtz_extend_shift_mw(int32_t qlen, const wtz_seq_packed &query, int32_t tlen, const wtz_seq_packed &target, int32_t init_score,
-		int32_t ql, int32_t tl, int32_t W, int32_t M, int32_t X, int32_t I, int32_t D, int32_t E, int32_t T,
-		uint64_t *tb, wtz_mw_shared_t *sh_generic, wtz_pool_t *pool, wtz_cigar_t &cigars, unsigned long long *cells, bool *ok){
-	static_assert(C >= 2 && NW >= 2 && NW <= 4, "lane block of at least two columns, at most four waves");
-	/* LDS-typed (a generic pointer would make these flat ops that wait for vmcnt(0)) and NOT volatile: the asm barriers clobber
-	 * memory, so every value is re-read after a barrier, but as one 128-bit read per group instead of one waited read per word */
-	WTZ_LDS_AS wtz_mw_shared_t *sh = wtz_as_lds(sh_generic);
-	const int tid = (int)threadIdx.x, lane = tid & 63, wid = tid >> 6;
-	constexpr int C4 = (C + 3) / 4, NL = 64 * NW;
-	wtz_aln_t x; memset(&x, 0, sizeof x);
-	*ok = true;
-	if(tid == 0) cigars.n = 0;
-	if(init_score < 0) init_score = 0;
-	const uint32_t zrow = (uint32_t)C4 * 4u * (uint32_t)NL;
-	if(tid == 0){
-		sh->chunk_tab = (unsigned long long)(uintptr_t)wtz_pool_alloc(pool, (size_t)WTZ_TRACE_MAXCHUNK * 8);
-		sh->zb_tab = (unsigned long long)(uintptr_t)wtz_pool_alloc(pool, (size_t)(ql + 2) * 4);
-	}
-	{
-		const int32_t nw = (tl + 31) / 32 + 1;
-		for(int32_t w = tid; w < nw; w += NL) tb[w] = wtz_pack32(target, w * 32, tl);
-	}
-	if(lane == 63) sh->edge[wid].v[0] = init_score + D + E * (tid * C + C);        /* H(-1, last column of the wave): row 0 shifts it into the next wave */
-	__syncthreads();
-	uint8_t **zchunk = (uint8_t**)(uintptr_t)sh->chunk_tab; int32_t *zb = (int32_t*)(uintptr_t)sh->zb_tab;
-	if(zchunk == NULL || zb == NULL){ *ok = false; return x; }
-	uint8_t *z = NULL;
-	int32_t hv[C], ev[C];
-	/* "row -1": H(-1, j) = init_score + D + E*(j+1) (rh[] of kswx.h:143-144 one column to the left), so that row 0 is an ordinary
-	 * row with a band shift of 0 and H(-1,-1) = init_score as its left boundary: no first-iteration special case in the loop */
-	#pragma unroll
-	for(int k = 0; k < C; k++){ hv[k] = init_score + D + E * (tid * C + k + 1); ev[k] = -10000; }
-	int32_t bnd_col = init_score;                 /* H(i-1, -1): init_score for row 0, init_score + I + E*i after */
-	int32_t mx = init_score, mi = -1, mj = -1, gmax = 0, gi = -1, gj = -1;
-	int32_t jbp = 0, c = 0, i;
-	unsigned long long ncell = 0;
-	const int32_t CE = C * E, IE = I + E, DE = D + E;
-	uint32_t qw_lo = 0, qw_hi = 0, qcur = 0;
-	const int32_t colrel0 = tid * C;
-	int32_t jb_n = 0, je_n = tl; uint64_t tbits_n;
-	{
-		if(je_n > W + 1) je_n = W + 1;
-		if(je_n > tl) je_n = tl;
-		const int32_t jj = colrel0 < tl ? colrel0 : (tl > 0 ? tl - 1 : 0);
-		const int32_t w = jj >> 5, shb = (jj & 31) * 2;
-		const uint64_t w0 = tb[w], w1 = tb[w + 1];
-		tbits_n = shb ? ((w0 >> shb) | (w1 << (64 - shb))) : w0;
-	}
-	__builtin_amdgcn_s_waitcnt(0x0F70);
-	const unsigned long long pt_mwrows = WTZ_PROF_T(); (void)pt_mwrows;
-	for(i = 0; i < ql; i++){
-		if((i & 63) == 0){
-			if(tid == 0){ uint8_t *p = (uint8_t*)wtz_pool_alloc(pool, (size_t)zrow * 64); wtz_as_global(zchunk)[(uint32_t)i >> 6] = p; sh->zbase = (unsigned long long)(uintptr_t)p; }
-			if((i & 2047) == 0){ const uint64_t qw = wtz_pack32(query, i + lane * 32, ql); qw_lo = (uint32_t)qw; qw_hi = (uint32_t)(qw >> 32); }
-			__builtin_amdgcn_s_waitcnt(0x0F70);          /* vmcnt(0), once per 64 rows (see wtz_extend_shift_reg) */
-		}
-		const int32_t jb = jb_n, je = je_n;
-		if((i & 15) == 0){
-			const int32_t qs = __builtin_amdgcn_readfirstlane((i & 2047) >> 5);
-			qcur = (i & 16) ? (uint32_t)__builtin_amdgcn_readlane((int)qw_hi, qs) : (uint32_t)__builtin_amdgcn_readlane((int)qw_lo, qs);
-		}
-		const uint32_t qbase = (qcur >> ((i & 15) * 2)) & 3u;
-		const int32_t j0 = jb + colrel0;
-		const uint64_t tbits = tbits_n;
-		{
-			const int32_t s = jb - jbp;
-			if(s == 0){
-				const int32_t bnd = (jb == 0) ? bnd_col : -10000;
-				const int32_t hp = (wid == 0) ? bnd : sh->edge[wid > 0 ? wid - 1 : 0].v[0];
-				wtz_shift_row_inputs_x<C, 0>(hv, ev, hp, 0, 0, 0);
-			} else {
-				const int wn = wid + 1 < NW ? wid + 1 : wid; const bool last = (wid + 1 == NW);
-				const wtz_i4 eg = sh->edge[wn];
-				if(s == 1){
-					const int32_t e0 = last ? -10000 : eg.v[2];
-					wtz_shift_row_inputs_x<C, 1>(hv, ev, 0, 0, e0, 0);
-				} else {
-					const int32_t h0 = last ? -10000 : eg.v[1], e0 = last ? -10000 : eg.v[2], e1 = last ? -10000 : eg.v[3];
-					wtz_shift_row_inputs_x<C, 2>(hv, ev, 0, h0, e0, e1);
-				}
-			}
-		}
-		const int32_t nv = je - j0;
-		uint32_t eq_lo, eq_hi;
-		{
-			const uint32_t qrep = 0x55555555u * qbase;
-			const uint32_t x_lo = (uint32_t)tbits ^ qrep, x_hi = (uint32_t)(tbits >> 32) ^ qrep;
-			eq_lo = ~(x_lo | (x_lo >> 1)) & 0x55555555u; eq_hi = ~(x_hi | (x_hi >> 1)) & 0x55555555u;
-		}
-		const int32_t MX = M - X, nE = -E;
-		int32_t agg = -0x3FFFFFFF;
-		wtz_static_for<0, C>([&](auto kc){
-			constexpr int k = decltype(kc)::value;
-			const int32_t b = (int32_t)(((k < 16 ? eq_lo : eq_hi) >> (2 * (k & 15))) & 1u);
-			const int32_t m = wtz_mad24(b, MX, hv[k]) + X;
-			hv[k] = m;
-			const int32_t cand = wtz_mad24_imm<k>(nE, m);
-			agg = cand > agg ? cand : agg;
-		});
-		agg += DE + (C - 1) * E;
-		int32_t f;
-		{
-			/* in-wave inclusive max scan of g; lane 63 holds the wave total */
-			const int32_t ident = -0x3FFFFFFF;
-			int32_t xs = agg - tid * CE, t;
-			t = wtz_dpp_mov<0x111, 0xF>(ident, xs); xs = xs > t ? xs : t;
-			t = wtz_dpp_mov<0x112, 0xF>(ident, xs); xs = xs > t ? xs : t;
-			t = wtz_dpp_mov<0x114, 0xF>(ident, xs); xs = xs > t ? xs : t;
-			t = wtz_dpp_mov<0x118, 0xF>(ident, xs); xs = xs > t ? xs : t;
-			t = wtz_dpp_mov<0x142, 0xA>(ident, xs); xs = xs > t ? xs : t;
-			t = wtz_dpp_mov<0x143, 0xC>(ident, xs); xs = xs > t ? xs : t;
-			if(lane == 63) sh->wagg.v[wid] = xs;
-			int32_t pm = wtz_dpp_mov<0x138, 0xF>(ident, xs);
-			wtz_mw_barrier();                                                   /* ---- barrier 1 ---- */
-			const wtz_i4 wa = sh->wagg;
-			#pragma unroll
-			for(int w2 = 0; w2 + 1 < NW; w2++){ const int32_t v = wa.v[w2]; pm = (w2 < wid && v > pm) ? v : pm; }
-			const int32_t from_prev = (tid == 0) ? -0x3FFFFFFF : pm + (tid - 1) * CE;
-			const int32_t from_init = -10000 + tid * CE;
-			f = from_prev > from_init ? from_prev : from_init;
-		}
-		if((i & 63) == 0){
-			const unsigned long long za = sh->zbase;
-			const uint32_t zlo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)za), zhi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(za >> 32));
-			z = (uint8_t*)(uintptr_t)(((unsigned long long)zhi << 32) | zlo);
-			if((zlo | zhi) == 0){ *ok = false; break; }
-		}
-		int32_t key = -0x40000000, kg = -0x40000000;
-		uint32_t zw[C4];
-		#pragma unroll
-		for(int q4 = 0; q4 < C4; q4++) zw[q4] = 0;
-		#pragma unroll
-		for(int k = 0; k < C; k++){
-			const bool valid = (k < nv);
-			const int32_t m = hv[k], e = ev[k];
-			const int32_t h0 = m > e ? m : e;
-			uint32_t d = (uint32_t)(m - e) >> 31;
-			d = __builtin_amdgcn_alignbit(d, (uint32_t)(h0 - f), 31);
-			const int32_t h = h0 > f ? h0 : f;
-			const int32_t te = m + IE, e2 = e + E;
-			d = __builtin_amdgcn_alignbit(d, (uint32_t)(te - e2), 31);
-			const int32_t en = e2 > te ? e2 : te;
-			const int32_t tf = m + DE, f2 = f + E;
-			d = __builtin_amdgcn_alignbit(d, (uint32_t)(tf - f2), 31);
-			f = f2 > tf ? f2 : tf;
-			d = (d << 1) | (((k < 16 ? eq_lo : eq_hi) >> (2 * (k & 15))) & 1u);
-			const int32_t hm = valid ? h : -10000;
-			hv[k] = hm; ev[k] = valid ? en : -10000;
-			const int32_t kk = (int32_t)(((uint32_t)hm << 11) + (uint32_t)(-(k & 15)));
-			kg = kk > kg ? kk : kg;
-			if((k & 15) == 15 || k == C - 1){ const int32_t t = kg - (k & ~15); key = t > key ? t : key; kg = -0x40000000; }
-			zw[k >> 2] |= (valid ? d : 0u) << (8 * (k & 3));
-		}
-		key += 2047 - colrel0;
-		ncell += (unsigned long long)(je - jb);
-		key = wtz_wave_max_i32(key);
-		if(lane == 0){ sh->wkey.v[wid] = key; sh->edge[wid].v[1] = hv[0]; sh->edge[wid].v[2] = ev[0]; sh->edge[wid].v[3] = ev[1]; }
-		if(lane == 63) sh->edge[wid].v[0] = hv[C - 1];
-		if(je == tlen){
-			const int32_t idx = je - 1 - jb, gl = idx / C, kl = idx - gl * C;
-			if(tid == gl){
-				int32_t hsel = hv[0];
-				#pragma unroll
-				for(int k = 1; k < C; k++) hsel = (kl == k) ? hv[k] : hsel;
-				sh->h1 = hsel;                                                   /* H(i, je-1) */
-			}
-		}
-		if(tid == 0) wtz_as_global(zb)[i] = jb;
-		{
-			WTZ_GLOBAL_AS uint32_t *zr = wtz_as_global((uint32_t*)(z + (size_t)(i & 63) * zrow) + tid);
-#ifndef WTZ_EXP_NOTRACE
-			#pragma unroll
-			for(int q4 = 0; q4 < C4; q4++) if(q4 * 4 < nv) zr[(size_t)q4 * NL] = zw[q4];      /* see wtz_extend_shift_reg */
-#else
-			if(zw[0] == 0xFFFFFFFFu && zw[C4 - 1] == 0xFFFFFFFEu) zr[0] = 1;
-#endif
-		}
-		wtz_mw_barrier();                                                       /* ---- barrier 2 ---- */
-		const wtz_i4 wkk = sh->wkey;
-		#pragma unroll
-		for(int w2 = 0; w2 < NW; w2++){ const int32_t v = wkk.v[w2]; key = v > key ? v : key; }
-		key = __builtin_amdgcn_readfirstlane(key);
-		int32_t imax = 0, mj2 = -1;
-		if((key >> 11) > 0){ imax = key >> 11; mj2 = jb + (2047 - (key & 2047)); }
-		if(je == tlen){
-			const int32_t h1 = __builtin_amdgcn_readfirstlane(sh->h1);
-			if(gmax < h1){ gmax = h1; gi = i; gj = je - 1; }
-		}
-		if(i + 1 == qlen && gmax < imax){ gmax = imax; gi = i; gj = mj2; }
-		jbp = jb; bnd_col = init_score + I + E * (i + 1);
-		if(imax > mx){ mx = imax; mi = i; mj = mj2; }
-		else if(imax <= 0) break;
-		c++; if(c < mj2) c++; else if(c > mj2) c--;
-		jb_n = 0; je_n = tl;
-		if(jb_n < c - W) jb_n = c - W;
-		if(je_n > c + W + 1) je_n = c + W + 1;
-		if(je_n > tl) je_n = tl;
-		{
-			const int32_t j0n = jb_n + colrel0;
-			const int32_t jj = j0n < tl ? j0n : (tl > 0 ? tl - 1 : 0);
-			const int32_t w = jj >> 5, shb = (jj & 31) * 2;
-			const uint64_t w0 = tb[w], w1 = tb[w + 1];
-			tbits_n = shb ? ((w0 >> shb) | (w1 << (64 - shb))) : w0;
-		}
-	}
-	if(cells && tid == 0) *cells += ncell;
-	__syncthreads();                /* every wave's trace is visible to wave 0; the target words in LDS are dead */
-	if(!*ok || wid != 0) return x;
-	WTZ_PROF_ADD(56, pt_mwrows); WTZ_PROF_CNT(58, i < ql ? i + 1 : ql); WTZ_PROF_CNT(59, 1);
-	if(gmax > 0 && gmax >= mx + T){ x.score = gmax; x.qe = gi; x.te = gj; }
-	else { x.score = mx; x.qe = mi; x.te = mj; }
-	const unsigned long long pt_mwtb = WTZ_PROF_T(); (void)pt_mwtb;
-	wtz_shift_traceback<C, NL>(x, zchunk, zb, zrow, tb, cigars);
-	WTZ_PROF_ADD(57, pt_mwtb);
-	return wtz_bcast_aln(x);
-}
-
-/* K-sw3 jobs on four waves each (the long ones: `order` lists them).  Jobs outside the envelope stay !done for wtz_kernel_extjobs. */
-template<int TW>
-__global__ void __launch_bounds__(256) wtz_kernel_extjobs_mw(wtz_extjob_t *jobs, const uint32_t *order, uint32_t n, const wtz_params_t *Pm, wtz_pool_t *pool, wtz_pool_t *tpool){
-	__shared__ uint64_t stb[TW]; __shared__ wtz_mw_shared_t shm;
-	const uint32_t b = blockIdx.x;
-	if(b >= n) return;
-	wtz_extjob_t *job = &jobs[order ? order[b] : b];
-	if(!job->valid || job->done) return;
-	const int tid = (int)threadIdx.x;
-	if(job->qlen <= 0 || job->tlen <= 0) return;
-	const int32_t init_score = job->init_score < 0 ? 0 : job->init_score;
-	int32_t W = job->W, ql, tl, n_col;
-	wtz_ext_geometry(job->qlen, job->tlen, init_score, W, Pm->M, Pm->O, Pm->O, Pm->E, Pm->T, ql, tl, n_col);
-	const int32_t Cw = (n_col + 255) / 256;
-	if(Cw > 8 || (tl + 63) / 32 + 1 > TW || (ql + 63) / 64 > WTZ_TRACE_MAXCHUNK) return;
-	if((long long)init_score + (long long)Pm->M * (ql < tl ? ql : tl) >= (1 << 20)) return;
-	WTZ_PROF_BEGIN();
-	wtz_cigar_t cg; cg.a = NULL; cg.n = cg.cap = 0; cg.pool = pool; cg.bad = 0;
-	if(tid == 0) cg.init(pool, (uint32_t)ql / 2u + 16u);
-	unsigned long long cells = 0; bool ok = true;
-	wtz_aln_t x;
-#define WTZ_EXTMW_CASE(CM) x = wtz_extend_shift_mw<CM, 4>(job->qlen, job->q, job->tlen, job->t, job->init_score, ql, tl, W, Pm->M, Pm->X, Pm->O, Pm->O, Pm->E, Pm->T, stb, &shm, tpool, cg, &cells, &ok)
-	if(Cw <= 2) WTZ_EXTMW_CASE(2);
-	else if(Cw <= 4) WTZ_EXTMW_CASE(4);
-	else if(Cw <= 7) WTZ_EXTMW_CASE(7);
-	else WTZ_EXTMW_CASE(8);
-#undef WTZ_EXTMW_CASE
-	if(tid == 0){ job->x = x; job->cigar = cg.a; job->cigar_len = cg.n; job->bad = (!ok || cg.bad); job->cells = cells; job->done = 2; }
-	WTZ_PROF_END();
-}
+/* (the round-4 four-wave kernel wtz_extend_shift_mw / wtz_kernel_extjobs_mw lived here: retired in round 6 - its frame-form successor is wtz_sw_frame_mw.h, DP form 6) */
 
 /*
  * K-sw1 for the small problems between two anchors of a window (80 % have a band of <= 64 columns, 96 % <= 128 rows):

@@ -905,7 +905,7 @@ WTZ_HD void wtz_task_gplan(uint32_t t, const wtz_env_t &V, const wtz_wintask_t *
 	const wtz_alnitem_t &it = items[tasks[t].item];
 	const uint32_t k = tasks[t].widx;
 	wtz_lgap_t G; G.slot = t; G.dq = G.dt = 0; G.w = 0;
-	uint32_t cap = 0; uint64_t ky = 0x3FFFFull; uint8_t dn = 0;
+	uint32_t cap = 0; uint64_t ky = 0x3FFFFull; uint8_t dn = 0; int32_t cls = -1;
 	wtz_gapres_t *slot = gaps + (it.regs - items[0].regs) + k;
 	int32_t prev = -1;
 	if(k && it.regs[k].pass == 1) for(int32_t j = (int32_t)k - 1; j >= 0; j--) if(it.regs[j].pass == 1){ prev = j; break; }
@@ -919,10 +919,21 @@ WTZ_HD void wtz_task_gplan(uint32_t t, const wtz_env_t &V, const wtz_wintask_t *
 			if(n_col <= WTZ_LN_MAXCOLS && dt <= WTZ_LG_MAXROWS){
 				G.dq = dq; G.dt = dt; G.w = w; cap = (uint32_t)(dq + dt + 2);
 				ky = 0x3FFFFull - (uint64_t)(((uint32_t)n_col << 11) | (uint32_t)dt);
-				WTZ_ATOMIC_INC32(&ccnt[wtz_lane_class(n_col)]);
+				cls = (int32_t)wtz_lane_class(n_col);
 			}
 		}
 	}
+	/* the four class counters: one atomic per class and wavefront (round 6: every lane bumped one of four addresses - ~10 M same-address atomics per configs[2] step in a
+	 * kernel that does nothing else but a few dependent loads) */
+#if defined(__HIP_DEVICE_COMPILE__)
+	#pragma unroll
+	for(int32_t c4 = 0; c4 < 4; c4++){
+		const unsigned long long m = __ballot(cls == c4);
+		if(m && (threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(m)) atomicAdd(&ccnt[c4], (uint32_t)__popcll(m));
+	}
+#else
+	if(cls >= 0) WTZ_ATOMIC_INC32(&ccnt[cls]);
+#endif
 	gp[t] = G; runcap[t] = cap; key[t] = ky; val[t] = t; done[t] = dn;
 }
 template<int NC>

@@ -170,7 +170,6 @@ extern "C" int wtz_test_dp(wtz_ctx_t *c, int32_t kind, int32_t form, const wtz_d
 		wtz_timer tform; tform.start();      /* the forced forms report their launch time through counters.ms_ext too (tools/ubench/ksw3_bench.py) */
 		if(form == 0){ CHK(run_extjobs(c, V, d_jobs, n)); }
 		else if(form == 1){ hipLaunchKernelGGL((wtz_kernel_extjobs_reg<1032>), dim3(n), dim3(64), 0, g_stream, d_jobs, (const uint32_t*)NULL, n, V.P, V.pool, V.pool + 1); HIPCHK(hipGetLastError()); }
-		else if(form == 2){ hipLaunchKernelGGL((wtz_kernel_extjobs_mw<1032>), dim3(n), dim3(256), 0, g_stream, d_jobs, (const uint32_t*)NULL, n, V.P, V.pool, V.pool + 1); HIPCHK(hipGetLastError()); }
 		else if(form == 3){ hipLaunchKernelGGL((wtz_kernel_extjobs<2048, 1032>), dim3(n), dim3(64), 0, g_stream, d_jobs, (const uint32_t*)NULL, n, V.P, V.pool, V.pool + 1); HIPCHK(hipGetLastError()); }
 		else if(form == 4){ CHK(wtz_launch_wave<K_extjob_scalar>(0, n, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_extjob_scalar((uint32_t)t, V, d_jobs); })); }
 		else if(form == 5){ hipLaunchKernelGGL((wtz_kernel_extjobs_fr<1032>), dim3(n), dim3(64), 0, g_stream, d_jobs, (const uint32_t*)NULL, n, V.P, V.pool, V.pool + 1); HIPCHK(hipGetLastError()); }

@@ -164,7 +164,6 @@ FORMS = [
     {"WTZ_RANGE_OVERLAP": "0"},                       # host: strict plan -> compute -> commit order
     {"WTZ_BATCH_OVERLAP": "0"},                       # host: one batch at a time (ranges still pipelined)
     {"WTZ_BATCH_OVERLAP_GAIN": "1e9"},              # host: every batch formed in front of the commit before it, whatever the mask rate
-    {"WTZ_EXT_SPLIT": "2"},                           # K-sw3: one launch per band class
     {"WTZ_EXT_MW_ROWS": "600"},                       # K-sw3: the items whose extensions can run >= 600 rows on FOUR wavefronts each (frame form, wtz_sw_frame_mw.h) beside the fused launch
     {"WTZ_XCD_GROUP": "0"},                           # K_pair: identity block -> pair mapping
     {"WTZ_GAP_SIDESTREAM": "1"},                      # gaps on a side stream beside the left extensions
