@@ -423,6 +423,9 @@ struct wtz_ctx {
 	                              * Off by default: measured at configs[2] (gpurun_out/r06d) K-sw3 418 ms without it, 490 ms with n = 2048 (1 000 of 30 000 items per range), 654 ms with
 	                              * n = 1024, 418 ms with n = 4096 (5-8 items per range) - the launches are bound by the row RATE of the resident wavefronts (time = ~5 ms + 0.65 ms per
 	                              * million rows), not by their longest job, and four wavefronts spend 2.2 x the instructions of one on a row */
+	int env_ext_pk = 1;          /* WTZ_EXT_PK=0: K-sw3 without the packed 16-bit form (wtz_sw_frame16.h) in front of the 32-bit frame form */
+	unsigned long long ext_fr_total = 0;        /* items dealt to the 32-bit form before the launch (geometry outside the 16-bit window) */
+	unsigned long long ext_open_total = 0;      /* items the packed form declined (outside its 16-bit window) and the 32-bit form finished */
 	int env_ext_fr = 1;          /* WTZ_EXT_FR=0: K-sw3 one-wave jobs on the round-4 register kernel (wtz_extend_shift_reg) instead of the frame form (wtz_sw_frame.h) */
 	int env_heavy_first = -1;    /* WTZ_PAIR_HEAVY_FIRST: the heaviest pairs of a K_pair launch first (-1 = engine default: dmo on, zmo off) */
 	int env_cand_wg = 1;         /* WTZ_CAND_WG=0: the one-wavefront-per-query sorting form of the seed lookup (the form before round 3) */
@@ -565,6 +568,7 @@ extern "C" int wtz_ctx_create(int device, const wtz_params_c *params, uint64_t p
 	if(getenv("WTZ_CAND_WG")) c->env_cand_wg = atoi(getenv("WTZ_CAND_WG"));
 	if(getenv("WTZ_PAIR_HEAVY_FIRST")) c->env_heavy_first = atoi(getenv("WTZ_PAIR_HEAVY_FIRST"));
 	if(getenv("WTZ_EXT_FR")) c->env_ext_fr = atoi(getenv("WTZ_EXT_FR"));
+	if(getenv("WTZ_EXT_PK")) c->env_ext_pk = atoi(getenv("WTZ_EXT_PK"));
 	if(getenv("WTZ_EXT_MW_ROWS")) c->env_ext_mw_rows = atoi(getenv("WTZ_EXT_MW_ROWS"));
 	if(getenv("WTZ_EXT_FUSED")) c->env_ext_fused = atoi(getenv("WTZ_EXT_FUSED"));
 	if(getenv("WTZ_ZREAD")) c->env_zread = atoi(getenv("WTZ_ZREAD"));
@@ -1555,23 +1559,42 @@ static int run_stitch_fused(wtz_ctx *c, const wtz_env_t &V, const wtz_alnitem_t 
 	/* order and budget on the device (the host form - fetch the geometry, order 31 000 items, send the order back - was 2.7 ms of an idle device per range):
 	 * key = the rows both jobs can run at most, inverted (ascending stable radix sort = longest first, ties in item order); the trace bounds are summed with an atomic */
 	uint64_t *d_k = NULL; uint32_t *d_order = NULL; unsigned long long *d_acc = NULL;
+	uint32_t *d_open = NULL;
 	CHK(dev_alloc((void**)&d_k, (size_t)m * 8)); CHK(dev_alloc((void**)&d_order, (size_t)m * 4)); CHK(dev_alloc((void**)&d_acc, 32)); CHK(dev_set(d_acc, 0, 32));
+	if(c->env_ext_pk) CHK(dev_alloc((void**)&d_open, ((size_t)m + 1) * 4));
 	{
 		const int32_t pM = c->P.M, pO = c->P.O, pE = c->P.E, pT = c->P.T, pW = -c->P.ew;
 		const uint32_t mw_rows = c->env_ext_mw_rows > 0 ? (uint32_t)c->env_ext_mw_rows : 0xFFFFFFFFu;
+		const bool use_pk = c->env_ext_pk != 0; const wtz_params_t *dP = V.P;
 		CHK(wtz_launch<K_misc>(0, m, [=] WTZ_LAMBDA (uint64_t t){
 			const wtz_extjob_t &j = d_jl[t];
 			int32_t qa = 0, qb = 0;
 			unsigned long long nb = wtz_ext_trace_need(j.valid ? j.qlen : -1, j.tlen, 0, pW, pM, pO, pE, pT, &qa, (int32_t*)NULL);
 			nb += wtz_ext_trace_need(d_rgeo[2 * t], d_rgeo[2 * t + 1], 0, pW, pM, pO, pE, pT, &qb, (int32_t*)NULL);
 			const uint32_t rows = (uint32_t)qa + (uint32_t)qb;
-			d_k[t] = (uint64_t)(0xFFFFFFFFu - rows); d_order[t] = (uint32_t)t;
+			/* which form takes the item (bit 32 of the key: the items of the 32-bit form end up behind those of the packed form, both longest-first): the packed
+			 * form needs both extensions inside its 16-bit window - the left one's init_score is known, the right one's is not (wtz_pk_window_any_init) */
+			uint32_t to_fr = 0;
+			if(use_pk){
+				if(j.valid && j.qlen > 0 && j.tlen > 0){
+					int32_t W = pW, ql = 0, tl = 0, nc = 0, bias, ng, sh; const int32_t in0 = j.init_score < 0 ? 0 : j.init_score;
+					wtz_ext_geometry(j.qlen, j.tlen, in0, W, pM, pO, pO, pE, pT, ql, tl, nc);
+					if(!wtz_pk_window(dP, in0, ql, tl, &bias, &ng, &sh)) to_fr = 1;
+				}
+				if(d_rgeo[2 * t] > 0 && d_rgeo[2 * t + 1] > 0){
+					int32_t W = pW, ql = 0, tl = 0, nc = 0;
+					wtz_ext_geometry(d_rgeo[2 * t], d_rgeo[2 * t + 1], 0, W, pM, pO, pO, pE, pT, ql, tl, nc);
+					if(!wtz_pk_window_any_init(dP, ql, tl)) to_fr = 1;
+				}
+			}
+			d_k[t] = ((uint64_t)to_fr << 32) | (uint64_t)(0xFFFFFFFFu - rows); d_order[t] = (uint32_t)t;
+			if(to_fr) WTZ_ATOMIC_ADD64(&d_acc[3], 1ull);
 			if(nb) WTZ_ATOMIC_ADD64(&d_acc[0], nb);
 			if(rows) WTZ_ATOMIC_ADD64(&d_acc[1], (unsigned long long)rows);
 			if(rows >= mw_rows) WTZ_ATOMIC_ADD64(&d_acc[2], 1ull);
 		}));
 	}
-	CHK(dev_sort_pairs_u64_u32(d_k, d_order, m, 32));
+	CHK(dev_sort_pairs_u64_u32(d_k, d_order, m, 33));
 	unsigned long long h_acc[4] = {0, 0, 0, 0}; CHK(dev_d2h(h_acc, d_acc, 32));
 	const uint64_t acc = h_acc[0]; const unsigned long long ext_sum = h_acc[1];
 	const uint64_t budget = (c->pool_bytes - c->main_bytes) / 16 * 15;
@@ -1580,7 +1603,7 @@ static int run_stitch_fused(wtz_ctx *c, const wtz_env_t &V, const wtz_alnitem_t 
 	 * any other exhausted pool: the host redoes the range in halves. */
 	/* what does not fit at once runs in up to four groups (every ng-th item of the order each: all groups are ordered longest-first), the transient pool reset between them */
 	uint32_t ng = 1; while(ng < 4 && (double)acc * c->ext_use_ratio / ng > (double)budget) ng++;
-	if((double)acc * c->ext_use_ratio / ng > (double)budget){ if(c->env_profile) fprintf(stderr, "[ext-profile] fused launch declined: %u items, trace bounds %.1f GB x %.2f against %.1f GB\n", m, acc / 1e9, c->ext_use_ratio, budget / 1e9); dev_free(d_order); dev_free(d_k); dev_free(d_acc); return WTZ_OK; }          /* the two launches cut their jobs into groups that fit */
+	if((double)acc * c->ext_use_ratio / ng > (double)budget){ if(c->env_profile) fprintf(stderr, "[ext-profile] fused launch declined: %u items, trace bounds %.1f GB x %.2f against %.1f GB\n", m, acc / 1e9, c->ext_use_ratio, budget / 1e9); dev_free(d_order); dev_free(d_k); dev_free(d_acc); if(d_open) dev_free(d_open); return WTZ_OK; }          /* the two launches cut their jobs into groups that fit */
 	double ms_l = 0; uint64_t used_sum = 0;
 	for(uint32_t g = 0; g < ng; g++){
 		const uint32_t mg = (m - g + ng - 1) / ng;
@@ -1597,7 +1620,28 @@ static int run_stitch_fused(wtz_ctx *c, const wtz_env_t &V, const wtz_alnitem_t 
 			HIPCHK(hipGetLastError());
 			HIPCHK(hipEventRecord(c->ev_mw_join, c->stream_mw));
 		}
-		if(mg > n_long) hipLaunchKernelGGL((wtz_kernel_stitch_ext_fr<1032>), dim3(mg - n_long), dim3(64), WTZ_WAVE_LDS_BYTES, g_stream, V, d_items, d_st, d_jl, d_jr, d_gaps, (const uint32_t*)d_order + n_long, mg - n_long, ng, g);
+		if(mg > n_long && c->env_ext_pk){
+			/* the packed 16-bit form; the items dealt to the 32-bit form beforehand (the tail of the order: a handful of the longest extensions per step) run beside
+			 * it on the side stream; what the packed form declines after all is listed and finished by the 32-bit form behind it */
+			uint32_t n_fr = (ng == 1 && !n_long) ? (uint32_t)h_acc[3] : 0u;
+			if(n_fr > mg - n_long) n_fr = mg - n_long;
+			CHK(dev_set(d_open, 0, 4));
+			if(n_fr){
+				HIPCHK(hipEventRecord(c->ev_mw_fork, g_stream)); HIPCHK(hipStreamWaitEvent(c->stream_mw, c->ev_mw_fork, 0));
+				hipLaunchKernelGGL((wtz_kernel_stitch_ext_fr<1032>), dim3(n_fr), dim3(64), WTZ_WAVE_LDS_BYTES, c->stream_mw, V, d_items, d_st, d_jl, d_jr, d_gaps, (const uint32_t*)d_order + (mg - n_fr), n_fr, 1u, 0u);
+				HIPCHK(hipGetLastError());
+				HIPCHK(hipEventRecord(c->ev_mw_join, c->stream_mw));
+			}
+			const uint32_t n_pk = mg - n_long - n_fr;
+			if(n_pk){
+				hipLaunchKernelGGL((wtz_kernel_stitch_ext_pk<1032>), dim3(n_pk), dim3(64), WTZ_PK_LDS_BYTES(1032), g_stream, V, d_items, d_st, d_jl, d_jr, d_gaps, (const uint32_t*)d_order + n_long, n_pk, ng, g, d_open);
+				HIPCHK(hipGetLastError());
+			}
+			if(n_fr) HIPCHK(hipStreamWaitEvent(g_stream, c->ev_mw_join, 0));
+			uint32_t n_open = 0; CHK(dev_d2h(&n_open, d_open, 4));
+			c->ext_open_total += n_open; c->ext_fr_total += n_fr;
+			if(n_open){ hipLaunchKernelGGL((wtz_kernel_stitch_ext_fr<1032>), dim3(n_open), dim3(64), WTZ_WAVE_LDS_BYTES, g_stream, V, d_items, d_st, d_jl, d_jr, d_gaps, (const uint32_t*)d_open + 1, n_open, 1u, 0u); HIPCHK(hipGetLastError()); }
+		} else if(mg > n_long) hipLaunchKernelGGL((wtz_kernel_stitch_ext_fr<1032>), dim3(mg - n_long), dim3(64), WTZ_WAVE_LDS_BYTES, g_stream, V, d_items, d_st, d_jl, d_jr, d_gaps, (const uint32_t*)d_order + n_long, mg - n_long, ng, g);
 		HIPCHK(hipGetLastError());
 		if(n_long) HIPCHK(hipStreamWaitEvent(g_stream, c->ev_mw_join, 0));
 		ms_l += te.stop();
@@ -1608,7 +1652,7 @@ static int run_stitch_fused(wtz_ctx *c, const wtz_env_t &V, const wtz_alnitem_t 
 				/* the budget under-estimated what the traces take: the next launch is planned with twice the share (the host redoes this range in halves and is told
 				 * that it was the transient pool, so that its bytes-per-pair estimate of the MAIN pool is left alone: wtz_pool_failure_kind) */
 				c->ext_use_ratio = c->ext_use_ratio * 2.0 > 1.0 ? 1.0 : c->ext_use_ratio * 2.0;
-				dev_free(d_order); dev_free(d_k); dev_free(d_acc);
+				dev_free(d_order); dev_free(d_k); dev_free(d_acc); if(d_open) dev_free(d_open);
 				return rc_t;
 			}
 		}
@@ -1616,9 +1660,9 @@ static int run_stitch_fused(wtz_ctx *c, const wtz_env_t &V, const wtz_alnitem_t 
 	}
 	c->cnt.ms_ext += ms_l; c->cnt.n_extjobs += 2ull * m;
 	c->fused_ran = true;
-	if(c->env_profile) fprintf(stderr, "[ext-profile] fused launch: %u items in %u group(s), rows (upper bound) sum %llu, %.2f ms\n", m, ng, ext_sum, ms_l);
+	if(c->env_profile) fprintf(stderr, "[ext-profile] fused launch: %u items in %u group(s), rows (upper bound) sum %llu, %.2f ms; items of the 32-bit form so far: dealt %llu, declined by the packed form %llu\n", m, ng, ext_sum, ms_l, c->ext_fr_total, c->ext_open_total);
 	c->tpool_last_used = used_sum;
-	dev_free(d_order); dev_free(d_k); dev_free(d_acc);
+	dev_free(d_order); dev_free(d_k); dev_free(d_acc); if(d_open) dev_free(d_open);
 	if(acc){ const double seen = 1.3 * (double)c->tpool_last_used / (double)acc, keep = c->ext_use_ratio * 0.9; c->ext_use_ratio = seen > keep ? seen : keep; if(c->ext_use_ratio < 0.2) c->ext_use_ratio = 0.2; if(c->ext_use_ratio > 1.0) c->ext_use_ratio = 1.0; }
 	return WTZ_OK;
 }
@@ -1702,6 +1746,10 @@ static int run_extjobs(wtz_ctx *c, const wtz_env_t &V, wtz_extjob_t *d_jobs, uin
 				/* one wavefront per job, longest first: the frame form (wtz_sw_frame.h), or the round-4 register form it replaced (WTZ_EXT_FR=0: kept as DP form 1, the
 				 * reference the isolated bench compares against).  Retired in round 6 (git history keeps them): the launches per band class (WTZ_EXT_SPLIT, WTZ_EXT_FR_SPLIT:
 				 * profiles/r06_ksw3_split_in_step_kernel_trace.txt) and the round-4 four-wave kernel with its WTZ_SW_MW_MIN / WTZ_EXT_MW_CW routing. */
+				if(c->env_ext_fr && c->env_ext_pk){      /* two 16-bit cells per register (wtz_sw_frame16.h); what is outside its window stays open for the 32-bit form */
+					hipLaunchKernelGGL((wtz_kernel_extjobs_pk<1032>), dim3(g1 - g0), dim3(64), 0, g_stream, d_jobs, (const uint32_t*)d_order + g0, g1 - g0, V.P, V.pool, V.pool + 1);
+					HIPCHK(hipGetLastError());
+				}
 				if(c->env_ext_fr) hipLaunchKernelGGL((wtz_kernel_extjobs_fr<1032>), dim3(g1 - g0), dim3(64), 0, g_stream, d_jobs, (const uint32_t*)d_order + g0, g1 - g0, V.P, V.pool, V.pool + 1);
 				else hipLaunchKernelGGL((wtz_kernel_extjobs_reg<1032>), dim3(g1 - g0), dim3(64), 0, g_stream, d_jobs, (const uint32_t*)d_order + g0, g1 - g0, V.P, V.pool, V.pool + 1);
 				HIPCHK(hipGetLastError());
@@ -1812,6 +1860,19 @@ static int run_winalign_lane(wtz_ctx *c, const wtz_env_t &V, const wtz_wintask_t
 		CHK(wtz_launch<K_lfold>(0, nwt, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_lfold((uint32_t)t, V, d_wt, d_items, d_woff, pp, ro, rn, rs, d_flag, d_fb, d_uidx, d_nu); }));
 	}
 	CHK(dev_d2h(n_fb, d_fb, 4));
+	if(*n_fb > 64){
+		/* the windows left to the chained wave kernel, the ones with the most anchors first (a window's chain of problems is sequential; K_lfold appends in the order its lanes
+		 * arrive: the same tail as the gap list's, run_gap_lane) */
+		const uint32_t nl = *n_fb; uint64_t *d_k2 = NULL; CHK(dev_alloc((void**)&d_k2, (size_t)nl * 8));
+		const uint32_t *lst = d_fb + 1;
+		CHK(wtz_launch<K_misc>(0, nl, [=] WTZ_LAMBDA (uint64_t i){
+			const wtz_wintask_t tk = d_wt[lst[i]];
+			const wtz_win_t &w = d_items[tk.item].win[tk.widx];
+			d_k2[i] = 0xFFFFFFFFull - (unsigned long long)(w.anchors[1] - w.anchors[0]);
+		}));
+		CHK(dev_sort_pairs_u64_u32(d_k2, d_fb + 1, nl, 32));
+		dev_free(d_k2);
+	}
 	lap(5);
 	if(c->env_profile) fprintf(stderr, "[lane-profile] %llu windows, %u anchor slots, K-sw1 problems by band class <=16 / <=32 / <=64 / <=104: %u / %u / %u / %u, %u run entries, %u windows left to the chained kernel; ms: count+scan %.2f plan %.2f scan+alloc %.2f sort %.2f dp %.2f traceback %.2f fold %.2f\n",
 		(unsigned long long)nwt, NS, ccnt[0], ccnt[1], ccnt[2], ccnt[3], NR, *n_fb, tp[0] * 1e3, tp[1] * 1e3, tp[2] * 1e3, tp[3] * 1e3, tp[4] * 1e3, tp[6] * 1e3, tp[5] * 1e3);
@@ -1853,6 +1914,21 @@ static int run_gap_lane(wtz_ctx *c, const wtz_env_t &V, const wtz_wintask_t *d_w
 		CHK(wtz_launch<K_glist>(0, nwt, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_glist((uint32_t)t, dn, d_list); }));
 	}
 	CHK(dev_d2h(n_list, d_list, 4));
+	if(*n_list > 64){
+		/* the gaps left to the wavefront kernel, heaviest first (rows x lane-columns of the first band): K_glist appends them in whatever order its lanes arrive, and a
+		 * launch of a few thousand wave-sized DPs of very different lengths ended in the tail of whichever long one started last (round 6) */
+		const uint32_t nl = *n_list; uint64_t *d_k2 = NULL; CHK(dev_alloc((void**)&d_k2, (size_t)nl * 8));
+		const wtz_lgap_t *gp = d_gp; const uint32_t *lst = d_list + 1;
+		CHK(wtz_launch<K_misc>(0, nl, [=] WTZ_LAMBDA (uint64_t i){
+			const wtz_lgap_t G = gp[lst[i]];
+			const int32_t nc = G.dq < 2 * G.w + 1 ? G.dq : 2 * G.w + 1;
+			unsigned long long wgt = (unsigned long long)(G.dt > 0 ? G.dt : 0) * (unsigned long long)((nc > 0 ? nc : 0) / 64 + 1);
+			if(wgt > 0xFFFFFFFEull) wgt = 0xFFFFFFFEull;
+			d_k2[i] = 0xFFFFFFFFull - wgt;
+		}));
+		CHK(dev_sort_pairs_u64_u32(d_k2, d_list + 1, nl, 32));
+		dev_free(d_k2);
+	}
 	if(c->env_profile) fprintf(stderr, "[lane-profile] %llu window slots, K-sw2 gaps by band class <=16 / <=32 / <=64 / <=104: %u / %u / %u / %u, %u left to the wavefront kernel\n",
 		(unsigned long long)nwt, ccnt[0], ccnt[1], ccnt[2], ccnt[3], *n_list);
 	dev_free(d_ccnt);

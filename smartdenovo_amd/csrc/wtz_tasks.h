@@ -464,16 +464,24 @@ WTZ_HD void wtz_task_lplan(uint32_t t, const wtz_env_t &V, const wtz_wintask_t *
 	nu[t] = n_used;
 	wflag[t] = fb ? 1 : 0;
 	if(fb){ for(uint32_t k = 0; k < na; k++){ key[base + k] = 0xFFFFull; runcap[base + k] = 0; } }
-	else {
-		#pragma unroll
-		for(int q4 = 0; q4 < 4; q4++) if(cc[q4]){
+	/* the four class counters: summed over the wavefront first (round 6: up to four same-address atomics per LANE - tens of millions per configs[2] step; K_gplan lost 35
+	 * of its 38 ms with the same change).  A wavefront that is not full (the last of the launch) keeps the per-lane form: a shuffle must not read a lane that is not there. */
 #if defined(__HIP_DEVICE_COMPILE__)
-			atomicAdd(&ccnt[q4], cc[q4]);
-#else
-			ccnt[q4] += cc[q4];
-#endif
+	{
+		const bool full = __ballot(1) == ~0ull;
+		#pragma unroll
+		for(int q4 = 0; q4 < 4; q4++){
+			uint32_t v = fb ? 0u : cc[q4];
+			if(full){
+				#pragma unroll
+				for(int o = 32; o > 0; o >>= 1) v += (uint32_t)__shfl_xor((int)v, o, 64);
+				if((threadIdx.x & 63u) == 0u && v) atomicAdd(&ccnt[q4], v);
+			} else if(v) atomicAdd(&ccnt[q4], v);
 		}
 	}
+#else
+	if(!fb) for(int q4 = 0; q4 < 4; q4++) ccnt[q4] += cc[q4];
+#endif
 }
 
 /* one wavefront = WTZ_NLANES problems of the shape-sorted order[lo, hi): relative-mode K-sw1, forward part; the wave's trace rows stay in the
@@ -916,8 +924,9 @@ WTZ_HD void wtz_task_gplan(uint32_t t, const wtz_env_t &V, const wtz_wintask_t *
 		if(dq > 0 && dt > 0){
 			int32_t w = P->w; while(w < WTZ_ABSDIFF(dq, dt)) w <<= 1;
 			const int32_t n_col = dq < 2 * w + 1 ? dq : 2 * w + 1;
+			G.dq = dq; G.dt = dt; G.w = w;      /* also for the gaps the lanes do not take: the wavefront kernel's launch is ordered by them (run_gap_lane) */
 			if(n_col <= WTZ_LN_MAXCOLS && dt <= WTZ_LG_MAXROWS){
-				G.dq = dq; G.dt = dt; G.w = w; cap = (uint32_t)(dq + dt + 2);
+				cap = (uint32_t)(dq + dt + 2);
 				ky = 0x3FFFFull - (uint64_t)(((uint32_t)n_col << 11) | (uint32_t)dt);
 				cls = (int32_t)wtz_lane_class(n_col);
 			}

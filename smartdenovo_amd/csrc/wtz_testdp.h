@@ -174,6 +174,7 @@ extern "C" int wtz_test_dp(wtz_ctx_t *c, int32_t kind, int32_t form, const wtz_d
 		else if(form == 4){ CHK(wtz_launch_wave<K_extjob_scalar>(0, n, [=] WTZ_LAMBDA (uint64_t t){ wtz_task_extjob_scalar((uint32_t)t, V, d_jobs); })); }
 		else if(form == 5){ hipLaunchKernelGGL((wtz_kernel_extjobs_fr<1032>), dim3(n), dim3(64), 0, g_stream, d_jobs, (const uint32_t*)NULL, n, V.P, V.pool, V.pool + 1); HIPCHK(hipGetLastError()); }
 		else if(form == 6){ hipLaunchKernelGGL((wtz_kernel_extjobs_frmw<1032>), dim3(n), dim3(256), 0, g_stream, d_jobs, (const uint32_t*)NULL, n, V.P, V.pool, V.pool + 1); HIPCHK(hipGetLastError()); }      /* frame form on four wavefronts (round 6) */
+		else if(form == 7){ hipLaunchKernelGGL((wtz_kernel_extjobs_pk<1032>), dim3(n), dim3(64), 0, g_stream, d_jobs, (const uint32_t*)NULL, n, V.P, V.pool, V.pool + 1); HIPCHK(hipGetLastError()); }      /* frame form, two 16-bit cells per register (round 6) */
 		else return wtz_fail(WTZ_E_ARG, "WTZ_DP_SHIFT: unknown form %d", form);
 		CHK(dev_sync());
 		if(form != 0){ c->cnt.ms_ext += tform.stop(); c->cnt.n_extjobs += n; }

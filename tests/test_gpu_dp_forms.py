@@ -60,15 +60,16 @@ def check(vec, idx, out, cigs, kind, form, must):
 # K-sw3: which forms must answer which class.  1 = one-wave register kernel (band <= 64 x 32 columns, target <= 1032 LDS words, key range),
 # (2 = the round-4 four-wave kernel: retired in round 6), 3 = LDS-ring kernel incl. its scalar fallback (everything), 4 = scalar body (everything),
 # 5 = one-wave kernel in the anti-diagonal frame (round 5, the product's one-wave form: same envelope as 1),
-# 6 = the frame form on four wavefronts (round 6: the product's form for the items with the longest extensions; band <= 256 x 8)
+# 6 = the frame form on four wavefronts (round 6; band <= 256 x 8), 7 = the frame form with two 16-bit cells per register (round 6: the product's first choice; same band envelope, values inside a 16-bit window)
 SHIFT_MUST = {
     1: {"s_c1", "s_c4", "s_c8", "s_c12", "s_c16", "s_c20", "s_c24", "s_c28", "s_c32", "s_short", "s_rows", "s_stop", "s_end", "s_homo", "s_neginit"},
     5: {"s_c1", "s_c4", "s_c8", "s_c12", "s_c16", "s_c20", "s_c24", "s_c28", "s_c32", "s_short", "s_rows", "s_stop", "s_end", "s_homo", "s_neginit"},
     6: {"s_c1", "s_c4", "s_c8", "s_c12", "s_c16", "s_c20", "s_c24", "s_c28", "s_c32", "s_short", "s_rows", "s_stop", "s_end", "s_homo", "s_neginit"},
+    7: {"s_c1", "s_c4", "s_c8", "s_c12", "s_c16", "s_c20", "s_c24", "s_c28", "s_c32", "s_short", "s_rows", "s_stop", "s_end", "s_homo", "s_neginit"},
 }
 
 
-@pytest.mark.parametrize("form", [0, 1, 3, 4, 5, 6])
+@pytest.mark.parametrize("form", [0, 1, 3, 4, 5, 6, 7])
 def test_shift_extension_forms(form, vec):
     idx = [int(i) for i in np.nonzero(vec.kind == 0)[0]]
     ctx = make_ctx(vec)
@@ -80,8 +81,8 @@ def test_shift_extension_forms(form, vec):
     ans = check(vec, idx, out, cigs, 0, form, must)
     if form == 0:       # the product's dispatch: the register kernels take what they can, the general kernel the rest
         used = {str(vec.cls[i]): int(out["form_used"][k]) for k, i in enumerate(idx)}
-        assert used["s_wide"] == 3 and used["s_keyovf"] == 3 and used["s_longt"] == 3 and used["s_c4"] in (1, 5, 6)
-    if form in (1, 5, 6):  # outside the register kernels' envelope
+        assert used["s_wide"] == 3 and used["s_keyovf"] == 3 and used["s_longt"] == 3 and used["s_c4"] in (1, 5, 6, 7)
+    if form in (1, 5, 6, 7):  # outside the register kernels' envelope
         for cls in ("s_wide", "s_keyovf", "s_longt", "s_empty"):
             assert ans[cls][0] == 0, "form %d should decline %s" % (form, cls)
 
