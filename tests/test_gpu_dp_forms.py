@@ -81,9 +81,10 @@ def test_shift_extension_forms(form, vec):
     ans = check(vec, idx, out, cigs, 0, form, must)
     if form == 0:       # the product's dispatch: the register kernels take what they can, the general kernel the rest
         used = {str(vec.cls[i]): int(out["form_used"][k]) for k, i in enumerate(idx)}
-        assert used["s_wide"] == 3 and used["s_keyovf"] == 3 and used["s_longt"] == 3 and used["s_c4"] in (1, 5, 6, 7)
+        assert used["s_wide"] == 3 and used["s_keyovf"] in (3, 7) and used["s_longt"] == 3 and used["s_c4"] in (1, 5, 6, 7)
     if form in (1, 5, 6, 7):  # outside the register kernels' envelope
-        for cls in ("s_wide", "s_keyovf", "s_longt", "s_empty"):
+        # (the packed form keeps values relative to a per-job bias: an init_score near 2^20 is inside its window, and its answer is checked like any other)
+        for cls in ("s_wide", "s_longt", "s_empty") + (() if form == 7 else ("s_keyovf",)):
             assert ans[cls][0] == 0, "form %d should decline %s" % (form, cls)
 
 
