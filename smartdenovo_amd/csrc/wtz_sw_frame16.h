@@ -54,6 +54,13 @@ WTZ_D int32_t wtz_pk_lo(uint32_t a){ return (int32_t)(int16_t)(a & 0xFFFFu); }
 WTZ_D int32_t wtz_pk_hi(uint32_t a){ return (int32_t)a >> 16; }
 /* (lo >> 16) | (hi << 16): the high half of `lo` under the low half of `hi` */
 WTZ_D uint32_t wtz_pk_join(uint32_t hi, uint32_t lo){ return __builtin_amdgcn_alignbit(hi, lo, 16); }
+/* acc*2 + (half H of v == low half of t): a compare on one half (SDWA) and an add with carry */
+template<int H>
+WTZ_D uint32_t wtz_pk_eqacc(uint32_t acc, uint32_t v, uint32_t t){
+	if constexpr(H) asm("v_cmp_eq_u16_sdwa vcc, %1, %2 src0_sel:WORD_1 src1_sel:WORD_0\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(acc) : "v"(v), "v"(t) : "vcc");
+	else asm("v_cmp_eq_u16_sdwa vcc, %1, %2 src0_sel:WORD_0 src1_sel:WORD_0\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(acc) : "v"(v), "v"(t) : "vcc");
+	return acc;
+}
 /* the even bits of a 64-bit word, packed */
 WTZ_D uint32_t wtz_even_bits(uint64_t x){
 	x &= 0x5555555555555555ULL;
@@ -378,24 +385,35 @@ WTZ_D wtz_aln_t wtz_extend_shift_pk(int32_t qlen, const wtz_seq_packed &query, i
 				const int32_t vidx = 127 - (K & 127), Ls = vidx >> 1, hs = vidx & 1;
 				const int32_t T16 = (K >> 7) - Ls * C * E;                 /* the winning run's value of h + column*E */
 				const int32_t klim = (vidx == vcut) ? kcut : C2;           /* its cells inside the band: k < klim */
-				int32_t gsel = -1;
-				#pragma unroll
-				for(int g = 0; g < CQ; g++){
-					const uint32_t sg = (uint32_t)__builtin_amdgcn_readlane((int32_t)gm[g], Ls);
-					const int32_t v = hs ? wtz_pk_hi(sg) : wtz_pk_lo(sg);
-					const bool full = 4 * g + 4 <= klim;
-					if(gsel < 0 && (!full || v == T16)) gsel = g;
-				}
+				/* the first register k < klim of lane Ls whose half hs holds T16.  In every lane at once (round 6: the first form read the group maxima and the four
+				 * candidates of a group into scalar registers and compared them there - a hundred scalar instructions per row, more than the row's own share of a
+				 * lone wavefront's time): a bit per group maximum that equals T16, the first such group among those entirely inside the band (else the group the
+				 * band end cuts), a bit per register of that group, and only the two masks of lane Ls go to the scalar unit */
+				const uint32_t Tv = (uint32_t)T16 & 0xFFFFu;
+				const int32_t nfull = klim >> 2;                           /* groups 0 .. nfull-1 lie entirely inside the band */
 				int32_t kf = -1;
-				wtz_uniform_switch<0, CQ>(gsel, [&](auto gc){
-					constexpr int g = decltype(gc)::value;
+				auto find = [&](auto hc){
+					constexpr int H = decltype(hc)::value;
+					uint32_t ag = 0;
 					#pragma unroll
-					for(int k = 4 * g; k < 4 * g + 4 && k < C2; k++){
-						const uint32_t sv = (uint32_t)__builtin_amdgcn_readlane((int32_t)wtz_pk_adds(hv[k], ckp[k]), Ls);
-						const int32_t v = hs ? wtz_pk_hi(sv) : wtz_pk_lo(sv);
-						if(kf < 0 && k < klim && v == T16) kf = k;
+					for(int g = CQ - 1; g >= 0; g--) ag = wtz_pk_eqacc<H>(ag, gm[g], Tv);            /* bit g: group g's maximum is T16 */
+					const uint32_t sg = (uint32_t)__builtin_amdgcn_readlane((int32_t)ag, Ls) & ((1u << nfull) - 1u);
+					const int32_t gsel = sg ? (int32_t)__builtin_ctz(sg) : nfull;
+					if(gsel < CQ){
+						uint32_t ae = 0;
+						wtz_uniform_switch<0, CQ>(gsel, [&](auto gc){
+							constexpr int g = decltype(gc)::value;
+							uint32_t a = 0;
+							#pragma unroll
+							for(int k = 4 * g + 3; k >= 4 * g; k--) a = (k < C2) ? wtz_pk_eqacc<H>(a, wtz_pk_adds(hv[k < C2 ? k : 0], ckp[k < C2 ? k : 0]), Tv) : a + a;      /* bit k - 4g */
+							ae = a; WTZ_PIN_TAG(ae, g);
+						});
+						const int32_t room = klim - 4 * gsel;                 /* registers of the group inside the band */
+						const uint32_t se = (uint32_t)__builtin_amdgcn_readlane((int32_t)ae, Ls) & (room >= 4 ? 0xFu : ((1u << (room > 0 ? room : 0)) - 1u));
+						if(se) kf = 4 * gsel + (int32_t)__builtin_ctz(se);
 					}
-				});
+				};
+				if(hs) find(wtz_ic<1>{}); else find(wtz_ic<0>{});
 				if(kf < 0){ lost = true; kf = 0; }
 				mj2 = jb + Ls * C + hs * C2 + kf;
 			}
@@ -552,13 +570,21 @@ WTZ_D bool wtz_extjob_run_pk(wtz_extjob_t *job, const wtz_params_t *Pm, wtz_pool
 	unsigned long long cells = 0; bool ok = true, consistent = true;
 	wtz_aln_t x;
 #define WTZ_EXTPK_CASE(CM) x = wtz_extend_shift_pk<CM, TW>(job->qlen, job->q, job->tlen, job->t, job->init_score, ql, tl, W, Pm->M, Pm->X, Pm->O, Pm->E, Pm->T, bias, ng, sh, (uint32_t*)stb, tr, tpool, cg, &cells, &ok, &consistent)
+	/* one instantiation per register of a lane (two columns): a job's band is at most two columns per lane narrower than its class */
 	if(Cw <= 4) WTZ_EXTPK_CASE(2);
+	else if(Cw <= 6) WTZ_EXTPK_CASE(3);
 	else if(Cw <= 8) WTZ_EXTPK_CASE(4);
+	else if(Cw <= 10) WTZ_EXTPK_CASE(5);
 	else if(Cw <= 12) WTZ_EXTPK_CASE(6);
+	else if(Cw <= 14) WTZ_EXTPK_CASE(7);
 	else if(Cw <= 16) WTZ_EXTPK_CASE(8);
+	else if(Cw <= 18) WTZ_EXTPK_CASE(9);
 	else if(Cw <= 20) WTZ_EXTPK_CASE(10);
+	else if(Cw <= 22) WTZ_EXTPK_CASE(11);
 	else if(Cw <= 24) WTZ_EXTPK_CASE(12);
+	else if(Cw <= 26) WTZ_EXTPK_CASE(13);
 	else if(Cw <= 28) WTZ_EXTPK_CASE(14);
+	else if(Cw <= 30) WTZ_EXTPK_CASE(15);
 	else WTZ_EXTPK_CASE(16);
 #undef WTZ_EXTPK_CASE
 	if(!consistent) return false;
