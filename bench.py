@@ -357,7 +357,7 @@ def main():
     res = {
         "metric": "Gbp of candidate pairs aligned/sec (wtzmo all-vs-all)",
         "value": value, "unit": "Gbp/s", "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3,
-        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "int32/int16", "data": "synthetic",
         "config": {"workload": "%s: %d bp iid genome x%g, seed %d, lognormal mean 10 kb, 15%% error (ins:del:sub 50:30:20)" % (WORKLOADS[a.workload]["name"], a.genome, a.coverage, a.seed),
                    "reads": meta["reads"], "read_bases": meta["bases"], "engine": a.engine, "argv": " ".join(eng),
                    "parallelism": "1 GPU" if world == 1 else "%d ranks (%s): pairs dealt by candidate id, seed-lookup requests round-robin (reads + k-mer index replicated%s; z-mer index: candidate side of the rank's "
@@ -367,9 +367,11 @@ def main():
         "pairs_per_step": n_pairs // K, "pair_bp_per_step": pair_bp // K, "records_last_step": int(last[14]),
         "kernel_ms_last_step": dict(ms, ksw3_wave=ms_ext, ksw2_gap=ms_gap),
         "host_seconds_last_step": host_s,
-        "roofline": valu_roofline("K-sw3 shifting-band extension (kswx_extend_align_shift_core), DP rows in registers in the anti-diagonal frame (wtz_sw_frame.h): wtz_kernel_stitch_ext_fr - both end "
-                                  "extensions of a stitched overlap and the join between them on one wavefront (wtz_stitch_fused.h) -, wtz_kernel_extjobs_fr where that launch declines, wtz_kernel_extjobs for what is outside the frame form's envelope; time = HIP events around the launches of the stage",
-                                  cells_shift, ms_ext, {"backtrack_GBps": cells_shift / (ms_ext * 1e-3) / 1e9 if ms_ext > 0 else None}),
+        "roofline": valu_roofline("K-sw3 shifting-band extension (kswx_extend_align_shift_core), DP rows in registers in the anti-diagonal frame: wtz_kernel_stitch_ext_pk - both end extensions of a stitched "
+                                  "overlap and the join between them on one wavefront (wtz_stitch_fused.h), TWO 16-bit cells per vector register (wtz_sw_frame16.h, round 6) -, beside it wtz_kernel_stitch_ext_fr (the 32-bit "
+                                  "frame form, wtz_sw_frame.h) for the items outside the 16-bit window, wtz_kernel_extjobs for what is outside every register form's envelope; time = HIP events around the launches of the stage; "
+                                  "the roof stays the int32 one the earlier rounds were priced against (12 ops per cell at 78.6 Tint32op/s) - against the packed-int16 rate of the VALU (twice that) the fraction is half",
+                                  cells_shift, ms_ext, {"backtrack_GBps": cells_shift / (ms_ext * 1e-3) / 1e9 if ms_ext > 0 else None, "arithmetic": "int16 pairs (v_pk_*), int32 where a job's values leave a 16-bit window"}),
         "roofline_sw1": valu_roofline("K-sw1 fixed-band extension between anchors (kswx_extend_align_core), one LANE per problem: K_lplan -> K_ldp (register DP, relative mode) -> "
                                       "K_ltb (traceback) -> K_lfold (score chain, z-mer runs, CIGAR) + the chained wave kernel for the windows the fold leaves; the time is the whole stage's", cells_fixed, ms["winalign"]),
         "roofline_sw2": valu_roofline("K-sw2 global banded alignment of the gaps between windows (ksw_global2 incl. every band-doubling call): one lane per gap (K_gplan / K_gdp / K_gtb), "
@@ -410,7 +412,7 @@ def main():
             prov["measured_on_kernel_source_id"] = json.load(open(src + ".meta.json")).get("kernel_source_id")
             prov["same_kernel_sources_as_this_build"] = (prov["measured_on_kernel_source_id"] == ksrc_now)
         res["traffic_source"] = prov
-        kmap = {"wtz_kernel_stitch_ext_fr": "roofline", "wtz_kernel_extjobs_fr": "roofline", "wtz_kernel_extjobs_reg": "roofline", "wtz_kernel_extjobs_mw": "roofline", "wtz_kernel_extjobs": "roofline", "K_winalign": "roofline_sw1", "K_ldp": "roofline_sw1", "K_ltb": "roofline_sw1", "K_lfold": "roofline_sw1", "K_lplan": "roofline_sw1",
+        kmap = {"wtz_kernel_stitch_ext_pk": "roofline", "wtz_kernel_extjobs_pk": "roofline", "wtz_kernel_stitch_ext_fr": "roofline", "wtz_kernel_extjobs_fr": "roofline", "wtz_kernel_extjobs_reg": "roofline", "wtz_kernel_extjobs_mw": "roofline", "wtz_kernel_extjobs": "roofline", "K_winalign": "roofline_sw1", "K_ldp": "roofline_sw1", "K_ltb": "roofline_sw1", "K_lfold": "roofline_sw1", "K_lplan": "roofline_sw1",
                 "K_gap": "roofline_sw2", "K_gdp": "roofline_sw2", "K_gtb": "roofline_sw2", "K_candidates_wg": "roofline_seed", "K_candidates": "roofline_seed", "K_pair": "roofline_zmer", "K_pair_dm": "roofline_zmer", "K_pair_big": "roofline_zmer"}
         for row in csv.DictReader(open(src)):
             key = kmap.get(row["kernel"])

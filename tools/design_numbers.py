@@ -41,7 +41,7 @@ L.append("| configs[3] shape (9.8 Gbp of reads, all-reads z-index beside a pool 
 L.append("")
 L.append("| line | kernel(s) | cells (bytes) per step | kernel ms | frac | PMC traffic per step |")
 L.append("|---|---|---|---|---|---|")
-r = z["roofline"]; L.append("| `roofline` K-sw3 | `wtz_kernel_stitch_ext_fr` (+ `wtz_kernel_extjobs_fr` where the fused launch declines) | %.1f G cells (= trace bytes) | %.0f | **%.4f** of 78.6 Tint32op/s (%.0f G cells/s) | %s |" % (r["cells_per_step"] / 1e9, r["kernel_ms_per_step"], r["frac"], r["cell_updates_per_s"] / 1e9, gb(pz.get("wtz_kernel_stitch_ext_fr", 0) + pz.get("wtz_kernel_extjobs_fr", 0) + pz.get("wtz_kernel_extjobs", 0))))
+r = z["roofline"]; L.append("| `roofline` K-sw3 | `wtz_kernel_stitch_ext_pk` (packed 16-bit; + `wtz_kernel_stitch_ext_fr` for the items outside its window) | %.1f G cells (trace: a nibble per cell) | %.0f | **%.4f** of 78.6 Tint32op/s (%.0f G cells/s) | %s |" % (r["cells_per_step"] / 1e9, r["kernel_ms_per_step"], r["frac"], r["cell_updates_per_s"] / 1e9, gb(pz.get("wtz_kernel_stitch_ext_pk", 0) + pz.get("wtz_kernel_stitch_ext_fr", 0) + pz.get("wtz_kernel_extjobs_pk", 0) + pz.get("wtz_kernel_extjobs_fr", 0) + pz.get("wtz_kernel_extjobs", 0))))
 r = z["roofline_sw1"]; L.append("| `roofline_sw1` K-sw1 | `K_lplan` → `K_ldp` → `K_ltb` → `K_lfold` (+ `K_winalign`) | %.1f G cells | %.0f | **%.4f** (%.0f G cells/s) | %s |" % (r["cells_per_step"] / 1e9, r["kernel_ms_per_step"], r["frac"], r["cell_updates_per_s"] / 1e9, gb(sum(pz.get(k, 0) for k in ("K_lplan", "K_ldp", "K_ltb", "K_lfold", "K_winalign")))))
 r = z["roofline_sw2"]; L.append("| `roofline_sw2` K-sw2 | `K_gplan` → `K_gdp` → `K_gtb`, `K_gap` | %.1f G cells | %.0f | **%.4f** (%.0f G cells/s) | %s |" % (r["cells_per_step"] / 1e9, r["kernel_ms_per_step"], r["frac"], r["cell_updates_per_s"] / 1e9, gb(sum(pz.get(k, 0) for k in ("K_gplan", "K_gdp", "K_gtb", "K_gap")))))
 r = z["roofline_zmer"]; L.append("| `roofline_zmer` zmo | `K_pair` | %.1f GB | %.0f | %.4f of 8 TB/s | %s |" % (r["algorithmic_bytes_per_step"] / 1e9, r["kernel_ms_per_step"], r["frac"], gb(pz["K_pair"])))
@@ -52,8 +52,8 @@ L.append("")
 L.append("PMC traffic = 2 × FETCH_SIZE + WRITE_SIZE (the gfx950 units and corrections of the guide's rocprofv3 section), separate `--pmc` passes of a `--steps 1` run, `profiles/r06_yeast100_{zmo,dmo}_pmc_per_kernel.csv` (+ `.meta.json`: the kernel-source hash they were measured on).")
 L.append("")
 k = z["kernel_ms_last_step"]; g = lambda n: sz.get(n, 0)
-L.append("Where a configs[2] zmo step goes (rocprofv3, `profiles/r06_yeast100_zmo_kernel_stats.csv`, per step): K-sw3 %.0f ms (`wtz_kernel_stitch_ext_fr` %.0f + `wtz_kernel_extjobs_fr` %.0f ms), `K_pair` %.0f, K-sw1 stage %.0f (`K_ldp` %.0f, `K_ltb` %.0f, `K_lplan` %.0f, `K_lfold` %.0f, `K_winalign` %.0f), K-sw2 %.0f (`K_gap` %.0f, `K_gdp` %.0f, `K_gplan` %.0f, `K_gtb` %.0f), stitch glue %.0f (`K_stitch_mid` %.0f, `K_stitch_left` %.0f), z-index %.0f, seed lookup %.0f, k-mer index %.0f; rank-0 commit and the writer threads run beside the device stages."
-         % (k["ksw3_wave"], g("wtz_kernel_stitch_ext_fr"), g("wtz_kernel_extjobs_fr"), k["pairs"], k["winalign"], g("K_ldp"), g("K_ltb"), g("K_lplan"), g("K_lfold"), g("K_winalign"), k["ksw2_gap"], g("K_gap"), g("K_gdp"), g("K_gplan"), g("K_gtb"),
+L.append("Where a configs[2] zmo step goes (rocprofv3, `profiles/r06_yeast100_zmo_kernel_stats.csv`, per step): K-sw3 %.0f ms (`wtz_kernel_stitch_ext_pk` %.0f ms, beside it `wtz_kernel_stitch_ext_fr` %.0f ms on the side stream), `K_pair` %.0f, K-sw1 stage %.0f (`K_ldp` %.0f, `K_ltb` %.0f, `K_lplan` %.0f, `K_lfold` %.0f, `K_winalign` %.0f), K-sw2 %.0f (`K_gap` %.0f, `K_gdp` %.0f, `K_gplan` %.0f, `K_gtb` %.0f), stitch glue %.0f (`K_stitch_mid` %.0f, `K_stitch_left` %.0f), z-index %.0f, seed lookup %.0f, k-mer index %.0f; rank-0 commit and the writer threads run beside the device stages."
+         % (k["ksw3_wave"], g("wtz_kernel_stitch_ext_pk"), g("wtz_kernel_stitch_ext_fr"), k["pairs"], k["winalign"], g("K_ldp"), g("K_ltb"), g("K_lplan"), g("K_lfold"), g("K_winalign"), k["ksw2_gap"], g("K_gap"), g("K_gdp"), g("K_gplan"), g("K_gtb"),
             g("K_stitch_mid") + g("K_stitch_left") + g("K_stitch_fin") + g("K_cigar_text"), g("K_stitch_mid"), g("K_stitch_left"), k["zindex"], k["candidates"], k["index"]))
 k = d["kernel_ms_last_step"]
 L.append("dmo: `K_pair_dm` %.0f ms of %.0f (tiers by LDS need + `K_pair_big` %.0f ms), seed lookup %.0f (all 116 541 reads are queried: no masking in this engine), z-index %.0f, k-mer index %.0f." % (k["pairs"], d["ms_per_step"], sd.get("K_pair_big", 0), k["candidates"], k["zindex"], k["index"]))
