@@ -11,7 +11,8 @@
  * |O| under an H).  A job whose window hi - lo fits 16 bits keeps  value - (hi + lo)/2  in signed halves: sums never wrap inside the band, comparisons are
  * signed 16-bit maxima, and the four decisions are the SIGNS of saturating differences (v_pk_sub_i16 clamp: the sign survives a difference beyond 15 bits).
  * Cells right of the band end may wrap - they feed only cells further right (wtz_sw_frame.h) and the row maximum excludes them EXACTLY here (below), not by
- * "a cell W columns off the maximum never wins".  A job outside the window is declined and stays open for wtz_extend_shift_fr.
+ * "a cell W columns off the maximum never wins".  Where the init score alone pushes the window beyond 16 bits the -10000 family is raised (wtz_pk_window,
+ * case (b): the argument is stated there).  A job outside both windows is declined and stays open for wtz_extend_shift_fr.
  *
  * Layout.  Lane l owns the C = 2*C2 band-relative columns l*C .. l*C + C - 1 as two runs: register k holds column l*C + k in its low half (run A) and column
  * l*C + C2 + k in its high half (run B).  Both runs move through the three row bodies (band shift S = 0, 1, 2) by register renaming exactly like the 32-bit
@@ -20,7 +21,8 @@
  * packed maximum), the lanes' carry-in is the prefix maximum over lane aggregates as before.
  * Row maximum: packed maxima of  h + column*E  over groups of four registers, the lane's two run maxima into one 32-bit key (value, 127 - run index), one wave
  * reduction; the run the band end cuts through contributes the maximum over its valid cells only (a wave-uniform switch over the cut position); the FIRST
- * arg-max column inside the winning run is found on the scalar unit from v_readlane'd group maxima and the four candidates of one group.
+ * arg-max column inside the winning run comes from per-lane match masks (a 16-bit compare on one half + an add with carry per register: first the group
+ * maxima, then the four registers of one group), of which only the winning lane's two words go to the scalar unit.
  * Target: two bit planes in LDS (low / high bit of the base, 32 columns per word), so that "bases equal" is one dense bit per column: (P_lo ^ ~q_lo) & (P_hi ^ ~q_hi).
  * Trace: a NIBBLE per cell (the four decisions), eight cells per dword: half the trace bytes of the 32-bit form; wtz_shift_traceback_pk stages it into the
  * walker's byte window of wtz_shift_traceback.
@@ -37,14 +39,11 @@
 #endif
 
 typedef short wtz_v2s __attribute__((ext_vector_type(2)));
-typedef unsigned short wtz_v2u __attribute__((ext_vector_type(2)));
-WTZ_D uint32_t wtz_pk_add(uint32_t a, uint32_t b){ return __builtin_bit_cast(uint32_t, (wtz_v2s)(__builtin_bit_cast(wtz_v2s, a) + __builtin_bit_cast(wtz_v2s, b))); }
 WTZ_D uint32_t wtz_pk_max(uint32_t a, uint32_t b){ return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(wtz_v2s, a), __builtin_bit_cast(wtz_v2s, b))); }
 /* a + b per half, saturating: inside a job's window it is the plain sum; the family that stands in for minus infinity stops at the bottom of the 16 bits instead of wrapping */
 WTZ_D uint32_t wtz_pk_adds(uint32_t a, uint32_t b){ return __builtin_bit_cast(uint32_t, __builtin_elementwise_add_sat(__builtin_bit_cast(wtz_v2s, a), __builtin_bit_cast(wtz_v2s, b))); }
 /* sign of a - b in each half, whatever the distance (saturating difference) */
 WTZ_D uint32_t wtz_pk_subs(uint32_t a, uint32_t b){ return __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(__builtin_bit_cast(wtz_v2s, a), __builtin_bit_cast(wtz_v2s, b))); }
-WTZ_D uint32_t wtz_pk_sign(uint32_t a){ return __builtin_bit_cast(uint32_t, (wtz_v2u)(__builtin_bit_cast(wtz_v2u, a) >> (wtz_v2u)15)); }
 /* a*b + c per half (mod 2^16) in one op */
 WTZ_D uint32_t wtz_pk_mad(uint32_t a, uint32_t b, uint32_t c){ uint32_t r; asm("v_pk_mad_u16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
 /* (a & mask) | (b & ~mask): v_bfi_b32 */

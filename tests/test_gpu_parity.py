@@ -169,6 +169,7 @@ FORMS = [
     {"WTZ_GAP_SIDESTREAM": "1"},                      # gaps on a side stream beside the left extensions
     {"WTZ_WINALIGN4": "1"},                           # four windows per wavefront
     {"WTZ_SW_CHECK": "1"},                            # scalar body beside every wave DP
+    {"WTZ_EXT_PK": "0"},                              # K-sw3: the 32-bit frame form alone (round 5-6), without the packed 16-bit form in front
     {"WTZ_EXT_FUSED": "0"},                           # K-sw3: the two end extensions in two launches with K_stitch_mid between them (rounds 1-4) instead of on one wavefront
     {"WTZ_ZREAD": "0"},                               # z-mer index: device-wide fill + radix sort for every read instead of one workgroup per read
     {"WTZ_ZREAD": "0", "WTZ_ZCHUNK_M": "0.02"},       # ... built in many small chunks of reads
