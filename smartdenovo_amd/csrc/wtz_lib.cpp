@@ -1582,9 +1582,16 @@ static int run_stitch_fused(wtz_ctx *c, const wtz_env_t &V, const wtz_alnitem_t 
 					if(!wtz_pk_window(dP, in0, ql, tl, &bias, &ng, &sh)) to_fr = 1;
 				}
 				if(d_rgeo[2 * t] > 0 && d_rgeo[2 * t + 1] > 0){
+					/* the right extension's init_score (wtz_task_stitch_mid) = the left extension's score - 100 M + the windows and gaps behind the first window: all of it
+					 * known here but the left extension's gain, which lies in [0, M * min(its two sides)] */
+					const wtz_stitch_state_t &st = d_st[t]; const wtz_alnitem_t &it = d_items[t];
+					long long i_lo = st.x.score, gain = 0;
+					if(j.valid && j.qlen > 0 && j.tlen > 0) gain = (long long)pM * (j.qlen < j.tlen ? j.qlen : j.tlen);
+					const wtz_gapres_t *gp = d_gaps + (it.regs - d_items[0].regs);
+					for(uint32_t k = st.first + 1; k < it.nwin; k++) if(it.regs[k].pass == 1) i_lo += (long long)gp[k].score + it.regs[k].x.score;
 					int32_t W = pW, ql = 0, tl = 0, nc = 0;
 					wtz_ext_geometry(d_rgeo[2 * t], d_rgeo[2 * t + 1], 0, W, pM, pO, pO, pE, pT, ql, tl, nc);
-					if(!wtz_pk_window_any_init(dP, ql, tl)) to_fr = 1;
+					if(!wtz_pk_window_range(dP, ql, tl, i_lo, i_lo + gain)) to_fr = 1;
 				}
 			}
 			d_k[t] = ((uint64_t)to_fr << 32) | (uint64_t)(0xFFFFFFFFu - rows); d_order[t] = (uint32_t)t;

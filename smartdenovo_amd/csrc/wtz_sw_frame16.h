@@ -530,23 +530,27 @@ WTZ_D bool wtz_pk_window(const wtz_params_t *Pm, int32_t init_score, int32_t ql,
 	return true;
 }
 
-/* Does a job of this geometry fit the packed form whatever its init_score turns out to be?  (The right extension's init_score is the score of everything before
- * it: unknown when a stage's items are dealt to the two forms.)  (a) holds up to an init_score Ia, (b) from Ib on: both cases together cover every init_score
- * when (b)'s window fits and Ib < Ia. */
-WTZ_D bool wtz_pk_window_any_init(const wtz_params_t *Pm, int32_t ql, int32_t tl){
+/* Does a job of this geometry fit the packed form for EVERY init_score in [i_lo, i_hi]?  (The right extension's init_score is the score of everything before it;
+ * when a stage's items are dealt to the two forms all of it is known but the left extension's own gain: a range.)  Window (a) holds up to an init_score Ia,
+ * window (b) from Ib on. */
+WTZ_D bool wtz_pk_window_range(const wtz_params_t *Pm, int32_t ql, int32_t tl, long long i_lo, long long i_hi){
 	const long long M = Pm->M, X = Pm->X, O = Pm->O, E = Pm->E;
 	if(E > 0 || E < -255 || X > 0 || M < 0 || O > 0 || M == X || M - X > 4096) return false;
+	if(i_lo < 0) i_lo = 0;
+	if(i_hi < 0) i_hi = 0;
 	const long long aE = -E, aO = -O, aX = -X, Xp = X - 2 * E, Xm = Xp < 0 ? Xp : 0;
 	const long long mn = ql < tl ? ql : tl;
-	if(M * mn >= 10000) return false;
 	const long long top = M * mn + ((long long)ql + tl + 4) * aE + (M - X) + 64;                       /* hi - init */
 	const long long lo_a = -10000 + ((long long)ql + 3) * Xm + O - 33 * aE - 64;
 	const long long Ia = 65000 + lo_a - top;                                                            /* (a) fits up to this init_score */
+	if(i_hi <= Ia) return true;
+	if(M * mn >= 10000) return false;
 	const long long step = aX > aO + aE ? aX : aO + aE;
 	const long long fall = aO + ((long long)tl + 1) * aE + ((long long)ql + 1) * step + ((long long)ql + 2) * aO;      /* init - Rlow */
 	const long long Ib = -10000 + 64 + M * mn + fall;                                                   /* (b)'s family stands above -10000 beyond this init_score */
 	const long long width_b = top + fall + M * mn + 64 + 33 * aE + 64;
-	return width_b <= 65000 && Ib < Ia;
+	if(width_b > 65000) return false;
+	return i_lo > Ib || Ib < Ia;          /* all of the range in (b), or the two windows overlap */
 }
 
 /* one K-sw3 job on the calling wavefront in the packed form; false = declined (outside the window or the envelope of wtz_extjob_run_fr: the job stays open).
