@@ -40,3 +40,32 @@ def write_grid(path: str, seed: int, expect_md5: str = None) -> str:
         assert m == expect_md5, "generator drift: grid(%d) md5 %s != %s" % (seed, m, expect_md5)
     open(path, "wb").write(b)
     return m
+
+
+def pile_inputs(seed: int = 1023, n: int = 1100, L: int = 400):
+    """A read side with MORE than SG_MAX_EDGE = 1 023 overlaps (wtlay.h:35): read r0000 and `n` error-free reads that all dovetail its 3' end, and a
+    hand-written overlap file (the 16 columns of a wtzmo record) that lists r0000 against each of them and nothing else - no overlapper run needed.
+    The reference's loader keeps the first 1 023 of them in file order (wtlay.h:459-463); with `-N 1` everything behind that is defined behaviour
+    (the surplus is only written past a slice from iteration 2 on: DESIGN section 9), and the anchoring pass then aligns every pair among the kept
+    1 023 neighbours - 522 753 pairs - so the output says exactly which edges survived the limit.  Returns (FASTA bytes, overlap-file bytes)."""
+    rng = np.random.default_rng(seed)
+    g = synth.random_genome(1000, rng)
+    names, seqs, lines = ["r0000"], [g[0:L].copy()], []
+    for k in range(1, n + 1):
+        s = 100 + (k * 7) % 100
+        names.append("r%04d" % k)
+        seqs.append(g[s:s + L].copy())
+        ol = L - s
+        lines.append("\t".join(map(str, ["r0000", "+", L, s, L, "r%04d" % k, "+", L, 0, ol, 2 * ol, "1.000", ol, 0, 0, 0])))
+    return synth.to_fasta_bytes(names, seqs), ("\n".join(lines) + "\n").encode()
+
+
+def write_pile(dirname: str, expect=None):
+    fa, ov = pile_inputs()
+    got = {"md5_reads": hashlib.md5(fa).hexdigest(), "md5_ovl": hashlib.md5(ov).hexdigest()}
+    if expect is not None:
+        assert got["md5_reads"] == expect["md5_reads"] and got["md5_ovl"] == expect["md5_ovl"], "generator drift: pile inputs %r != %r" % (got, expect)
+    pf, po = os.path.join(dirname, "pile.fa"), os.path.join(dirname, "pile.ovl16")
+    open(pf, "wb").write(fa)
+    open(po, "wb").write(ov)
+    return pf, po, got

@@ -69,6 +69,13 @@ def main():
             man["cases"][name] = {"reads": reads, "ovl": ovl, "argv": extra, "md5_full": md5(full), "md5_pairs": md5(open(pairs, "rb").read()),
                                   "records": len(lines), "repeated_lines": sum(1 for i in range(1, len(lines)) if lines[i] == lines[i - 1])}
             print(name, man["cases"][name]["records"], man["cases"][name]["repeated_lines"])
+        # a read side beyond SG_MAX_EDGE: generated reads + a hand-written overlap file, one iteration (4-5 minutes of the reference)
+        pf, po, ids = gbo_inputs.write_pile(td)
+        out = os.path.join(td, "pile.ovl"); pairs = os.path.join(td, "pile.pairs")
+        subprocess.run([GBO, "-t", "1", "-N", "1", "-i", pf, "-j", po, "-fo", out, "-9", pairs], check=True, stderr=subprocess.DEVNULL)
+        full = open(out, "rb").read()
+        man["edge_limit"] = dict(ids, argv=["-N", "1"], md5_full=md5(full), md5_pairs=md5(open(pairs, "rb").read()), records=full.count(b"\n"))
+        print("edge_limit", man["edge_limit"]["records"])
     json.dump(man, open(os.path.join(HERE, "gbo_manifest.json"), "w"), indent=1, sort_keys=True)
 
 

@@ -122,6 +122,23 @@ def test_wtgbo_equals_live_reference_on_fresh_input(emul_gbo, tmp_path):
     assert res["ref"][0] == res["emul"][0] and res["ref"][1] == res["emul"][1]
 
 
+
+def _run_edge_limit(exe, tmp):
+    """a read side with 1 100 overlaps: the loader's 1 023-edge limit (SG_MAX_EDGE, wtlay.h:35, 459-463) decides which 522 753 pairs the anchoring pass aligns"""
+    E = MAN["edge_limit"]
+    pf, po, _ = gbo_inputs.write_pile(str(tmp), E)
+    out = os.path.join(str(tmp), "p.ovl"); pairs = os.path.join(str(tmp), "p.pairs")
+    r = subprocess.run([exe, "-t", "1", "-i", pf, "-j", po, "-fo", out, "-9", pairs] + E["argv"], capture_output=True)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    full = open(out, "rb").read()
+    assert full.count(b"\n") == E["records"] == 1023 * 1022 // 2
+    assert md5_file(out) == E["md5_full"], "output differs from the reference's at the 1 023-edge limit"
+    assert md5_file(pairs) == E["md5_pairs"]
+
+
+def test_wtgbo_edge_limit_of_a_read_side_equals_reference(oracle_gbo, tmp_path):
+    _run_edge_limit(oracle_gbo, tmp_path)
+
 # ------------------------------------------------------------------ GPU
 @pytest.fixture(scope="module")
 def gpu_gbo():
@@ -167,3 +184,8 @@ def test_gpu_wtgbo_after_gpu_wtzmo_equals_reference_chain(gpu_gbo, gpu_exe, tmp_
         outs[tag] = (open(o, "rb").read(), open(p, "rb").read())
     assert outs["ref"][0].count(b"\n") > 500
     assert outs["gpu"][0] == outs["ref"][0] and outs["gpu"][1] == outs["ref"][1]
+
+
+@pytest.mark.gpu
+def test_gpu_wtgbo_edge_limit_of_a_read_side_equals_reference(gpu_gbo, tmp_path):
+    _run_edge_limit(gpu_gbo, tmp_path)
