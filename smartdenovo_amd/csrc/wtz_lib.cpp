@@ -119,9 +119,12 @@ static double wtz_wall(){ return std::chrono::duration<double>(std::chrono::stea
 #ifndef WTZ_OCC_PAIR
 #define WTZ_OCC_PAIR 5
 #endif
+/* K_gap (K-sw2 on a wavefront): 213 registers when left alone - two waves per SIMD, where its 12 KB LDS slice lets a CU hold thirteen.  At three (168 registers, 34 spilled
+ * values outside the row loop) the K-sw2 stage of a configs[2] step goes from 200 to 188 ms (round 6). */
 #ifndef WTZ_OCC_GAP
-#define WTZ_OCC_GAP 1
+#define WTZ_OCC_GAP 3
 #endif
+
 /* every context owns a non-blocking HIP stream; the API entry points make it current for the calling host thread, so that
  * two host threads can drive two contexts (two batches in flight) whose kernels and copies overlap on the device */
 static thread_local hipStream_t g_stream = 0;
